@@ -1,0 +1,117 @@
+"""ctypes binding of libbcp_hip.so (include/bcp_hip.h).
+
+The product path loads ONLY bcp_amd/csrc/libbcp_hip.so (built for gfx950 by
+__graft_entry__.build()).  If it is missing this module raises: there is no CPU fallback and
+the oracle is never imported from here.  `Binding` is parametrised by a CDLL handle only so that
+tests can drive the very same wrappers against the host kernel-logic simulator
+(tests/_emu/libbcp_emu.so, see tools/emu) with CPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
+
+P = C.c_void_p
+I = C.c_int
+L = C.c_longlong
+F = C.c_float
+U64 = C.c_ulonglong
+SZ = C.c_size_t
+
+# name -> (restype, argtypes)
+_SIGS = {
+    "bcp_version": (I, []),
+    "bcp_last_error": (C.c_char_p, []),
+    "bcp_device_arch": (I, [C.c_char_p, I]),
+    "bcp_event_create": (I, [C.POINTER(P)]),
+    "bcp_event_record": (I, [P, P]),
+    "bcp_event_elapsed_ms": (I, [P, P, C.POINTER(F)]),
+    "bcp_event_destroy": (I, [P]),
+    "bcp_mix_box": (I, [P, P, P, I, I, I, I, I, P, P]),
+    "bcp_plabel_bin": (I, [P, P, L, F, P]),
+    "bcp_plabel_argmax4": (I, [P, P, L, P]),
+    "bcp_cc_workspace_bytes": (SZ, [I, I, I, I, I]),
+    "bcp_cc_largest": (I, [P, P, P, I, I, I, I, I, I, P, P]),
+    "bcp_mixloss_workspace_bytes": (SZ, [I, I]),
+    "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P]),
+    "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, P]),
+    "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
+    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P]),
+    "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, P]),
+    "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
+    "bcp_conv3_pack_weight": (I, [P, P, P, I, I, I, P]),
+    "bcp_conv3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P]),
+    "bcp_conv3_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
+    "bcp_conv3_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "bcp_conv3_c1_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "bcp_conv3_c1_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, P]),
+    "bcp_k2_pack_weight": (I, [P, P, I, I, I, P]),
+    "bcp_down_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "bcp_down_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "bcp_up_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
+    "bcp_up_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "bcp_pw_fwd": (I, [P, P, P, P, L, I, I, P]),
+    "bcp_tn_workspace_bytes": (SZ, [L, I, I]),
+    "bcp_k2_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "bcp_pw16_fwd": (I, [P, P, P, P, L, I, P]),
+    "bcp_pw16_bwd": (I, [P, P, P, P, P, P, L, I, I, P, P]),
+    "bcp_colsum": (I, [P, L, I, P, I, P, P]),
+    "bcp_maxpool2d_fwd": (I, [P, P, I, I, I, I, P]),
+    "bcp_maxpool2d_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "bcp_bilinear2x_fwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "bcp_bilinear2x_bwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "bcp_copy_channels": (I, [P, P, L, I, I, I, I, I, I, P]),
+    "bcp_ema": (I, [P, P, L, C.c_double, P]),
+    "bcp_sgd": (I, [P, P, P, P, L, F, F, F, F, I, C.c_double, P]),
+    "bcp_adam": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "bcp_cast": (I, [P, P, L, I, P]),
+    "bcp_axpy": (I, [P, P, L, F, P]),
+    "bcp_bernoulli": (I, [P, L, F, F, I, U64, P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+
+class BcpError(RuntimeError):
+    pass
+
+
+class Binding:
+    """A loaded library with typed entry points; `call` raises BcpError on a non-zero status."""
+
+    def __init__(self, path: str):
+        if not os.path.exists(path):
+            raise BcpError(
+                f"{path} is missing: the HIP extension has not been built.  Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the product path.")
+        self.path = path
+        self.cdll = C.CDLL(path)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n != "bcp_version"}
+
+    def last_error(self) -> str:
+        return self.cdll.bcp_last_error().decode("utf-8", "replace")
+
+    def call(self, name: str, *args):
+        rc = getattr(self.cdll, name)(*args)
+        if name in self._status_fns and rc != 0:
+            raise BcpError(f"{name} failed ({rc}): {self.last_error()}")
+        return rc
+
+
+_product = None
+
+
+def product() -> Binding:
+    """The gfx950 library.  Loud failure when absent."""
+    global _product
+    if _product is None:
+        _product = Binding(LIB_PATH)
+    return _product

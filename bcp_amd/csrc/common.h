@@ -1,0 +1,85 @@
+// bcp_amd/csrc/common.h -- shared device/host helpers for libbcp_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#define BCP_OK 0
+#define BCP_EINVAL (-1)   // bad argument (shape / alignment / divisibility)
+#define BCP_ELAUNCH (-2)  // HIP reported a launch error
+#define BCP_EUNSUP (-3)   // configuration not supported by this build
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace bcp {
+
+void set_error(const char* fmt, ...);
+
+#define BCP_REQUIRE(cond, ...)          \
+  do {                                  \
+    if (!(cond)) {                      \
+      ::bcp::set_error(__VA_ARGS__);    \
+      return BCP_EINVAL;                \
+    }                                   \
+  } while (0)
+
+#define BCP_CHECK_LAUNCH(name)                                          \
+  do {                                                                  \
+    hipError_t e__ = hipGetLastError();                                 \
+    if (e__ != hipSuccess) {                                            \
+      ::bcp::set_error("%s: %s", name, hipGetErrorString(e__));         \
+      return BCP_ELAUNCH;                                               \
+    }                                                                   \
+  } while (0)
+
+static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- wavefront (64-lane) reductions; every lane of the wave must call.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum of NV doubles per thread (blockDim.x == 256, 4 waves); result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_sum_256(double (&v)[NV], double* lds /* [4*NV] */) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = wave_sum(v[i]);
+  __syncthreads();
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[wid * NV + i] = v[i];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = lds[i] + lds[NV + i] + lds[2 * NV + i] + lds[3 * NV + i];
+  }
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// activation codes shared with the host side
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2 };
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == ACT_RELU) return z > 0.f ? z : 0.f;
+  if (act == ACT_LRELU) return z > 0.f ? z : 0.01f * z;
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == ACT_LRELU) return z > 0.f ? 1.f : 0.01f;
+  return 1.f;
+}
+
+}  // namespace bcp

@@ -1,0 +1,655 @@
+// bcp_amd/csrc/conv3.hip -- 3x3x3 (V-Net) and 3x3 (U-Net) convolution, pad 1, stride 1, channels-last
+// fp32, as an implicit GEMM on the CDNA4 fp32 matrix cores (v_mfma_f32_16x16x4_f32, exact f32
+// fmaf-chain numerics, 157 TF/s peak) -- SURVEY.md A1.1 / A2.   fwd, dgrad (same kernel, flipped
+// + transposed weight pack) and wgrad.
+//
+// Reference ops: nn.Conv3d(k=3,pad=1) networks/VNet.py:17, nn.Conv2d(k=3,pad=1) networks/unet.py:19-25
+// and their autograd backward.
+//
+// Data layout: X [N][D][H][W][Cin], Y [N][D][H][W][Cout] (NDHWC; 2D = D 1, KD 1).
+// Packed weights Wp[tap][Cin16/4][Cout16][4] (cin%4 innermost) so that one ds_read_b128 feeds four
+// MFMA k-steps: lane l = (i = l&15, g = l>>4) holds A[vox i][cin 4g..4g+3] and B[cin 4g..4g+3][cout i];
+// k-step j uses element j of both, i.e. the k index of the instruction is the cin permutation
+// {4g+j} -- the same permutation on both operands, so the dot product is unchanged.
+//
+// Block = 256 threads = 4 waves, output tile TD x TH x TW voxels (M = 64*MT) x (16*NT) channels.
+// Per 16-channel cin chunk the (TD+2)(TH+2)(TW+2) input halo is staged ONCE in LDS ([vox][16+4 pad]),
+// and all 27 taps read it at shifted offsets (2.5x halo over-read from L2 instead of 27x);
+// weights stream through a double-buffered LDS stage of WT taps.  fp32 MFMA is slow enough
+// (32 cycles / instruction / SIMD) that LDS bandwidth is not the limiter; the structure is chosen
+// so every wave issues MT*NT*4 back-to-back MFMAs per tap per (MT+NT) ds_read_b128.
+#include "common.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+static constexpr int XS = 20;  // LDS floats per halo voxel: 16 channels + 4 pad (16-B aligned rows)
+
+template <int KD, int TD, int TH, int TW>
+struct Tile {
+  static constexpr int M = TD * TH * TW;
+  static constexpr int MT = M / 64;
+  static constexpr int PD = (KD == 3) ? 1 : 0;
+  static constexpr int HD = TD + 2 * PD, HH = TH + 2, HW = TW + 2;
+  static constexpr int HV = HD * HH * HW;
+  static constexpr int T = KD * 9;
+  static_assert(M % 64 == 0, "tile must hold a multiple of 64 voxels");
+  __device__ static __forceinline__ int voff(int m) {  // halo-local voxel index of tile voxel m at tap (0,0,0)
+    const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+    return (td * HH + th) * HW + tw;
+  }
+  __device__ static __forceinline__ int tapoff(int tap) {
+    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+    return (kd * HH + kh) * HW + kw;
+  }
+};
+
+struct ConvDims {
+  int N, D, H, W;
+  int Cin, Cout;        // real channel counts (row strides of X and Y)
+  int Cin16, Cout16;    // padded to multiples of 16 (packed-weight extents)
+  int tiles_d, tiles_h, tiles_w;
+};
+
+// stage one 16-channel chunk of the input halo of tile (n, d0, h0, w0) into LDS (zero outside the volume)
+template <class TL>
+__device__ __forceinline__ void load_halo(const float* __restrict__ X, float* __restrict__ Xs, const ConvDims& cd, int n,
+                                          int d0, int h0, int w0, int cc) {
+  for (int q = threadIdx.x; q < TL::HV * 4; q += 256) {
+    const int hv = q >> 2, part = q & 3;
+    const int hw = hv % TL::HW, hh = (hv / TL::HW) % TL::HH, hd = hv / (TL::HW * TL::HH);
+    const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+    const int c = cc * 16 + part * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)w < (unsigned)cd.W && c < cd.Cin)
+      v = ld4(X + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cin + c);
+    st4(Xs + hv * XS + part * 4, v);
+  }
+}
+
+__device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, int TH, int TW, int& n, int& d0, int& h0,
+                                            int& w0) {
+  const int tw = bx % cd.tiles_w;
+  const int th = (bx / cd.tiles_w) % cd.tiles_h;
+  const int td = (bx / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d;
+  n = bx / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
+  d0 = td * TD;
+  h0 = th * TH;
+  w0 = tw * TW;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad
+// ------------------------------------------------------------------------------------------------
+template <int KD, int TD, int TH, int TW, int NT, int WT>
+__global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                    const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd,
+                                                    int accumulate) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
+  constexpr int S = T / WT;                     // weight stages per cin chunk
+  static_assert(T % WT == 0, "WT must divide the tap count");
+  constexpr int NBUF = (S > 1) ? 2 : 1;
+  constexpr int WSTAGE4 = WT * 4 * CT;          // float4s per weight stage
+  constexpr int NW4 = (WSTAGE4 + 255) / 256;    // per-thread prefetch registers
+
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* Xs = smem;                             // [HV][XS]
+  float* Ws = smem + TL::HV * XS;               // [NBUF][WT][4][CT][4]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  int n, d0, h0, w0;
+  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
+  const int cout0 = blockIdx.y * CT;
+  const int cin4 = cd.Cin16 >> 2;
+
+  int voff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = cd.Cin16 >> 4;
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // everyone is done with the previous chunk's LDS contents
+    load_halo<TL>(X, Xs, cd, n, d0, h0, w0, cc);
+    // weight stage 0 of this chunk
+    for (int q = threadIdx.x; q < WSTAGE4; q += 256) {
+      const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
+      st4(Ws + q * 4, ld4(Wp + ((((long long)tl * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 0; st < S; ++st) {
+      float4 pre[NW4];
+      if (S > 1 && st + 1 < S) {
+#pragma unroll
+        for (int u = 0; u < NW4; ++u) {
+          const int q = threadIdx.x + u * 256;
+          if (q < WSTAGE4) {
+            const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
+            const int tap = (st + 1) * WT + tl;
+            pre[u] = ld4(Wp + ((((long long)tap * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
+          }
+        }
+      }
+      const float* Wb = Ws + (st & (NBUF - 1)) * WSTAGE4 * 4;
+#pragma unroll
+      for (int tl = 0; tl < WT; ++tl) {
+        const int toff = TL::tapoff(st * WT + tl) * XS;
+        float4 a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + toff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wb + ((tl * 4 + lg) * CT + nt * 16 + li) * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+          }
+      }
+      if (S > 1) {
+        if (st + 1 < S) {
+          float* Wn = Ws + ((st + 1) & 1) * WSTAGE4 * 4;
+#pragma unroll
+          for (int u = 0; u < NW4; ++u) {
+            const int q = threadIdx.x + u * 256;
+            if (q < WSTAGE4) st4(Wn + q * 4, pre[u]);
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
+
+  // epilogue: lane (li, lg) holds rows (voxels) lg*4+r, column (cout) li of each 16x16 tile
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = (wave * MT + mt) * 16 + lg * 4 + r;
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int d = d0 + td, h = h0 + th, w = w0 + tw;
+      if (d < cd.D && h < cd.H && w < cd.W) {
+        float* yrow = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int co = cout0 + nt * 16 + li;
+          if (co < cd.Cout) {
+            float v = acc[mt][nt][r];
+            if (bias) v += bias[co];
+            if (accumulate) v += yrow[co];
+            yrow[co] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dW[tap][ci][co] = sum_v X[v + off(tap)][ci] * dY[v][co]
+// GEMM per tap with M = 16 ci (one chunk), N = 16*NT co, K = voxels.  Lane (i, g) supplies
+// A[ci i][vox g] and B[vox g][co i] per k-step of 4 voxels -- plain ds_read_b32 from the
+// [vox][chan] tiles.  The 4 waves split the taps (wave w owns taps w, w+4, ...), every wave walks
+// all M voxels of the tile; a block loops over a group of spatial tiles and writes ONE partial
+// [T][16][CT] slab, which k_wgrad_reduce sums (deterministic, no atomics) straight into the torch
+// weight-gradient layout [Cout][Cin][T].
+// ------------------------------------------------------------------------------------------------
+template <int KD, int TD, int TH, int TW, int NT>
+__global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
+                                                     float* __restrict__ partial, ConvDims cd, int tiles_total,
+                                                     int tiles_per_group) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int T = TL::T, CT = NT * 16, M = TL::M;
+  constexpr int TPW = (T + 3) / 4;                      // taps per wave
+  constexpr int YS = (CT % 32 == 0) ? CT + 16 : CT;     // dY tile row stride (bank spread for the 4 k-groups)
+
+  HIP_DYNAMIC_SHARED(float, smem)
+  float* Xs = smem;                 // [HV][XS]
+  float* Ys = smem + TL::HV * XS;   // [M][YS]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int cc = blockIdx.y;                 // cin chunk
+  const int cout0 = blockIdx.z * CT;
+  const int grp = blockIdx.x;
+
+  f32x4 acc[TPW][NT];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int toff[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = wave + 4 * t;
+    toff[t] = (tap < T ? TL::tapoff(tap) : 0) * XS + li;
+  }
+
+  int t_end = (grp + 1) * tiles_per_group;
+  if (t_end > tiles_total) t_end = tiles_total;
+  for (int tile = grp * tiles_per_group; tile < t_end; ++tile) {
+    int n, d0, h0, w0;
+    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+    __syncthreads();
+    load_halo<TL>(X, Xs, cd, n, d0, h0, w0, cc);
+    for (int q = threadIdx.x; q < M * (CT / 4); q += 256) {
+      const int m = q / (CT / 4), c4 = q % (CT / 4);
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int d = d0 + td, h = h0 + th, w = w0 + tw;
+      const int co = cout0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d < cd.D && h < cd.H && w < cd.W && co < cd.Cout)
+        v = ld4(dY + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout + co);
+      st4(Ys + m * YS + c4 * 4, v);
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int k = 0; k < M / 4; ++k) {
+      const int m = k * 4 + lg;
+      const int vx = TL::voff(m) * XS;
+      float b[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[m * YS + nt * 16 + li];
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        if (wave + 4 * t < T) {  // wave-uniform
+          const float a = Xs[vx + toff[t]];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[t][nt], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial[grp][tap][ci][co]: lane (li, lg) holds ci = lg*4 + r (rows), co = li (cols)
+  float* P = partial + (long long)grp * T * cd.Cin16 * cd.Cout16;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap < T) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          P[((long long)tap * cd.Cin16 + cc * 16 + lg * 4 + r) * cd.Cout16 + cout0 + nt * 16 + li] = acc[t][nt][r];
+    }
+  }
+}
+
+// dW_torch[co][ci][tap] (+)= sum_g partial[g][tap][ci][co]
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dW, int G, int T,
+                                                      int Cin, int Cout, int Cin16, int Cout16, int accumulate) {
+  const long long total = (long long)T * Cin * Cout;
+  const long long slab = (long long)T * Cin16 * Cout16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const int ci = (int)((i / Cout) % Cin);
+    const int tap = (int)(i / ((long long)Cout * Cin));
+    const float* p = partial + ((long long)tap * Cin16 + ci) * Cout16 + co;
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += p[g * slab];
+    float* o = dW + ((long long)co * Cin + ci) * T + tap;
+    *o = accumulate ? (*o + s) : s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight packing (torch [Cout][Cin][T] -> Wp[tap][Cin16/4][Cout16][4]), forward and dgrad flavours
+// ------------------------------------------------------------------------------------------------
+// fwd:   Wp[t][ci/4][co][ci%4] = w[co][ci][t]                       (GEMM K = cin, N = cout)
+// dgrad: Wp[t][co/4][ci][co%4] = w[co][ci][T-1-t]                   (K = cout, N = cin; flipped taps)
+__global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                                    int T, int K16, int N16, int dgrad) {
+  const long long total = (long long)T * K16 * N16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k4 = (int)(i & 3);
+    const int nn = (int)((i >> 2) % N16);
+    const int kq = (int)((i / (4LL * N16)) % (K16 / 4));
+    const int t = (int)(i / ((long long)K16 * N16));
+    const int kk = kq * 4 + k4;
+    float v = 0.f;
+    if (!dgrad) {
+      if (kk < Cin && nn < Cout) v = w[((long long)nn * Cin + kk) * T + t];
+    } else {
+      if (kk < Cout && nn < Cin) v = w[((long long)kk * Cin + nn) * T + (T - 1 - t)];
+    }
+    wp[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// first layer: Cin = 1 -> Cout = 16 (HBM-bound: 4 B in, 64 B out per voxel).  Direct VALU kernel:
+// the single-channel halo sits in LDS, each thread owns one voxel and 16 accumulators.
+// ------------------------------------------------------------------------------------------------
+template <int KD, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, const float* __restrict__ w /*[16][1][T]*/,
+                                                  const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd) {
+  using TL = Tile<KD, TD, TH, TW>;
+  static_assert(TL::M == 256, "one voxel per thread");
+  constexpr int T = TL::T;
+  __shared__ float Xs[TL::HV];
+  __shared__ float Ws[T * 16];
+  int n, d0, h0, w0;
+  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
+  for (int q = threadIdx.x; q < TL::HV; q += 256) {
+    const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
+    const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
+    float v = 0.f;
+    if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
+      v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
+    Xs[q] = v;
+  }
+  for (int q = threadIdx.x; q < T * 16; q += 256) Ws[q] = w[(q & 15) * T + (q >> 4)];  // -> [tap][co]
+  __syncthreads();
+  const int m = threadIdx.x;
+  const int base = TL::voff(m);
+  float acc[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) acc[c] = bias ? bias[c] : 0.f;
+#pragma unroll
+  for (int tap = 0; tap < T; ++tap) {
+    const float x = Xs[base + TL::tapoff(tap)];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, Ws[tap * 16 + c], acc[c]);
+  }
+  const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+  const int d = d0 + td, h = h0 + th, wq = w0 + tw;
+  if (d < cd.D && h < cd.H && wq < cd.W) {
+    float* y = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16;
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) st4(y + c, make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]));
+  }
+}
+
+// wgrad of the Cin = 1 layer: dW[co][0][tap] = sum_v x[v+off] * dY[v][co].  Thread q < T*16 owns output
+// (tap, co) and walks the tile's voxels out of LDS; blocks loop over a tile group, partials reduced by
+// k_wgrad_reduce (Cin16 = 1 there).
+template <int KD, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void k_conv3_c1_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
+                                                        float* __restrict__ partial, ConvDims cd, int tiles_total,
+                                                        int tiles_per_group) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int T = TL::T, M = TL::M;
+  constexpr int NO = (T * 16 + 255) / 256;  // outputs per thread
+  __shared__ float Xs[TL::HV];
+  __shared__ float Ys[M * 16];
+  float acc[NO];
+  int otap[NO], oco[NO];
+#pragma unroll
+  for (int u = 0; u < NO; ++u) {
+    acc[u] = 0.f;
+    const int o = threadIdx.x + u * 256;
+    otap[u] = (o < T * 16) ? TL::tapoff(o >> 4) : 0;
+    oco[u] = o & 15;
+  }
+  const int grp = blockIdx.x;
+  int t_end = (grp + 1) * tiles_per_group;
+  if (t_end > tiles_total) t_end = tiles_total;
+  for (int tile = grp * tiles_per_group; tile < t_end; ++tile) {
+    int n, d0, h0, w0;
+    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+    __syncthreads();
+    for (int q = threadIdx.x; q < TL::HV; q += 256) {
+      const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
+      const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
+      float v = 0.f;
+      if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
+        v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
+      Xs[q] = v;
+    }
+    for (int q = threadIdx.x; q < M * 4; q += 256) {
+      const int m = q >> 2, c4 = q & 3;
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int d = d0 + td, h = h0 + th, wq = w0 + tw;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d < cd.D && h < cd.H && wq < cd.W) v = ld4(dY + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16 + c4 * 4);
+      st4(Ys + m * 16 + c4 * 4, v);
+    }
+    __syncthreads();
+    for (int m = 0; m < M; ++m) {
+      const int vx = TL::voff(m);
+#pragma unroll
+      for (int u = 0; u < NO; ++u) acc[u] = fmaf(Xs[vx + otap[u]], Ys[m * 16 + oco[u]], acc[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < NO; ++u) {
+    const int o = threadIdx.x + u * 256;
+    if (o < T * 16) partial[(long long)grp * T * 16 + o] = acc[u];  // [grp][tap][ci=0][co]
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side dispatch
+// ------------------------------------------------------------------------------------------------
+struct Cfg { int KD, TD, TH, TW, NT, WT; };
+
+template <int KD, int TD, int TH, int TW, int NT, int WT>
+static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, hipStream_t s) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int S = TL::T / WT, NBUF = S > 1 ? 2 : 1;
+  const size_t lds = (size_t)(TL::HV * XS + NBUF * WT * 4 * NT * 16 * 4) * sizeof(float);
+  cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
+  auto kfn = k_conv3_mfma<KD, TD, TH, TW, NT, WT>;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const dim3 grid(cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, cd.Cout16 / (NT * 16));
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate);
+  return 0;
+}
+
+template <int KD, int TD, int TH, int TW, int NT>
+static int launch_wgrad(const float* X, const float* dY, float* partial, ConvDims cd, int groups, hipStream_t s) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int CT = NT * 16, YS = (CT % 32 == 0) ? CT + 16 : CT;
+  const size_t lds = (size_t)(TL::HV * XS + TL::M * YS) * sizeof(float);
+  cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
+  const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+  const int tpg = cdiv(tiles, groups);
+  auto kfn = k_conv3_wgrad<KD, TD, TH, TW, NT>;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const dim3 grid(cdiv(tiles, tpg), cd.Cin16 / 16, cd.Cout16 / CT);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, dY, partial, cd, tiles, tpg);
+  return cdiv(tiles, tpg);
+}
+
+// tile / blocking choice: big tiles while the grid still fills 256 CUs, otherwise 64-voxel tiles
+// and narrower channel slabs (deep V-Net levels are tiny GEMMs).
+static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16) {
+  Cfg c;
+  c.KD = KD;
+  const long long vox = (long long)N * D * H * W;
+  if (KD == 3) {
+    if (vox >= 256LL * 1024) { c.TD = 4; c.TH = 4; c.TW = 16; }
+    else if (vox >= 64LL * 1024) { c.TD = 4; c.TH = 8; c.TW = 8; }
+    else { c.TD = 4; c.TH = 4; c.TW = 4; }
+  } else {
+    c.TD = 1;
+    if (vox >= 128LL * 1024) { c.TH = 16; c.TW = 16; } else { c.TH = 8; c.TW = 8; }
+  }
+  const int M = c.TD * c.TH * c.TW;
+  const long long tiles = (long long)N * cdiv(D, c.TD) * cdiv(H, c.TH) * cdiv(W, c.TW);
+  int nt = (M == 256) ? 4 : 4;
+  while (nt > 1 && (Cout16 % (nt * 16) != 0)) nt >>= 1;
+  while (nt > 1 && tiles * (Cout16 / (nt * 16)) < 256) nt >>= 1;  // more blocks for small problems
+  c.NT = nt;
+  c.WT = 0;
+  return c;
+}
+
+}  // namespace bcp
+
+using namespace bcp;
+
+static int fill_dims(ConvDims& cd, int N, int D, int H, int W, int Cin, int Cout) {
+  cd.N = N; cd.D = D; cd.H = H; cd.W = W; cd.Cin = Cin; cd.Cout = Cout;
+  cd.Cin16 = (Cin + 15) / 16 * 16;
+  cd.Cout16 = (Cout + 15) / 16 * 16;
+  cd.tiles_d = cd.tiles_h = cd.tiles_w = 0;
+  return 0;
+}
+
+extern "C" size_t bcp_conv3_packed_weight_floats(int Cin, int Cout, int KD) {
+  const int K16 = (Cin + 15) / 16 * 16, N16 = (Cout + 15) / 16 * 16;
+  return (size_t)KD * 9 * K16 * N16;
+}
+
+extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad, int Cin, int Cout, int KD, void* stream) {
+  BCP_REQUIRE(w && (wp_fwd || wp_dgrad), "bcp_conv3_pack_weight: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && Cin > 0 && Cout > 0, "bcp_conv3_pack_weight: bad arguments");
+  const int T = KD * 9, Ci16 = (Cin + 15) / 16 * 16, Co16 = (Cout + 15) / 16 * 16;
+  const long long total = (long long)T * Ci16 * Co16;
+  const int grid = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
+  if (wp_fwd) hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_fwd, Cout, Cin, T, Ci16, Co16, 0);
+  if (wp_dgrad) hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_dgrad, Cout, Cin, T, Co16, Ci16, 1);
+  BCP_CHECK_LAUNCH("bcp_conv3_pack_weight");
+  return BCP_OK;
+}
+
+#define BCP_FWD_CASE(KD_, TD_, TH_, TW_, NT_, WT_)                                                             \
+  if (c.KD == KD_ && c.TD == TD_ && c.TH == TH_ && c.TW == TW_ && c.NT == NT_) {                               \
+    launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (hipStream_t)stream);             \
+    done = true;                                                                                               \
+  }
+
+extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                             int Cout, int KD, int accumulate, void* stream) {
+  BCP_REQUIRE(x && wp && y, "bcp_conv3_fwd: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd: bad extents");
+  BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd: KD=1 needs D=1");
+  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd: Cin=%d must be a multiple of 4 (Cin=1 has its own entry point)", Cin);
+  BCP_REQUIRE(aligned16(x) && aligned16(wp), "bcp_conv3_fwd: x / wp must be 16-B aligned");
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  const Cfg c = choose_cfg(KD, N, D, H, W, cd.Cout16);
+  bool done = false;
+  BCP_FWD_CASE(3, 4, 4, 16, 1, 27) BCP_FWD_CASE(3, 4, 4, 16, 2, 9) BCP_FWD_CASE(3, 4, 4, 16, 4, 3)
+  BCP_FWD_CASE(3, 4, 8, 8, 1, 27) BCP_FWD_CASE(3, 4, 8, 8, 2, 9) BCP_FWD_CASE(3, 4, 8, 8, 4, 3)
+  BCP_FWD_CASE(3, 4, 4, 4, 1, 27) BCP_FWD_CASE(3, 4, 4, 4, 2, 9) BCP_FWD_CASE(3, 4, 4, 4, 4, 3)
+  BCP_FWD_CASE(1, 1, 16, 16, 1, 9) BCP_FWD_CASE(1, 1, 16, 16, 2, 9) BCP_FWD_CASE(1, 1, 16, 16, 4, 3)
+  BCP_FWD_CASE(1, 1, 8, 8, 1, 9) BCP_FWD_CASE(1, 1, 8, 8, 2, 9) BCP_FWD_CASE(1, 1, 8, 8, 4, 3)
+  BCP_REQUIRE(done, "bcp_conv3_fwd: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
+  BCP_CHECK_LAUNCH("bcp_conv3_fwd");
+  return BCP_OK;
+}
+
+// groups so that the wgrad grid has a few hundred blocks
+static int wgrad_groups(const Cfg& c, int N, int D, int H, int W, int Cin16, int Cout16) {
+  const int tiles = N * cdiv(D, c.TD) * cdiv(H, c.TH) * cdiv(W, c.TW);
+  const int chan_blocks = (Cin16 / 16) * (Cout16 / (c.NT * 16));
+  int g = cdiv(512, chan_blocks);
+  if (g > tiles) g = tiles;
+  if (g < 1) g = 1;
+  const int tpg = cdiv(tiles, g);
+  return cdiv(tiles, tpg);
+}
+
+static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
+  Cfg c = choose_cfg(KD, N, D, H, W, Cout16);
+  // accumulators: TPW * NT * 4 regs (TPW = 7 for 27 taps) -> cap NT at 4; small problems keep NT from choose_cfg
+  if (c.NT > 4) c.NT = 4;
+  return c;
+}
+
+extern "C" size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD) {
+  const int Ci16 = (Cin + 15) / 16 * 16, Co16 = (Cout + 15) / 16 * 16;
+  if (Cin == 1) {
+    const int tiles = N * cdiv(D, KD == 3 ? 4 : 1) * cdiv(H, KD == 3 ? 4 : 16) * cdiv(W, 16);
+    int g = tiles < 512 ? tiles : 512;
+    return (size_t)g * KD * 9 * 16 * sizeof(float);
+  }
+  const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, Co16);
+  const int g = wgrad_groups(c, N, D, H, W, Ci16, Co16);
+  return (size_t)g * KD * 9 * Ci16 * Co16 * sizeof(float);
+}
+
+#define BCP_WG_CASE(KD_, TD_, TH_, TW_, NT_)                                                     \
+  if (c.KD == KD_ && c.TD == TD_ && c.TH == TH_ && c.TW == TW_ && c.NT == NT_) {                 \
+    G = launch_wgrad<KD_, TD_, TH_, TW_, NT_>(x, dy, ws, cd, groups, (hipStream_t)stream);       \
+    done = true;                                                                                 \
+  }
+
+extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin, int Cout, int KD,
+                               int accumulate, void* workspace, void* stream) {
+  BCP_REQUIRE(x && dy && dw && workspace, "bcp_conv3_wgrad: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_wgrad: bad extents");
+  BCP_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "bcp_conv3_wgrad: Cin/Cout must be multiples of 4");
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, cd.Cout16);
+  const int groups = wgrad_groups(c, N, D, H, W, cd.Cin16, cd.Cout16);
+  float* ws = reinterpret_cast<float*>(workspace);
+  bool done = false;
+  int G = 0;
+  BCP_WG_CASE(3, 4, 4, 16, 1) BCP_WG_CASE(3, 4, 4, 16, 2) BCP_WG_CASE(3, 4, 4, 16, 4)
+  BCP_WG_CASE(3, 4, 8, 8, 1) BCP_WG_CASE(3, 4, 8, 8, 2) BCP_WG_CASE(3, 4, 8, 8, 4)
+  BCP_WG_CASE(3, 4, 4, 4, 1) BCP_WG_CASE(3, 4, 4, 4, 2) BCP_WG_CASE(3, 4, 4, 4, 4)
+  BCP_WG_CASE(1, 1, 16, 16, 1) BCP_WG_CASE(1, 1, 16, 16, 2) BCP_WG_CASE(1, 1, 16, 16, 4)
+  BCP_WG_CASE(1, 1, 8, 8, 1) BCP_WG_CASE(1, 1, 8, 8, 2) BCP_WG_CASE(1, 1, 8, 8, 4)
+  BCP_REQUIRE(done, "bcp_conv3_wgrad: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
+  const int T = KD * 9;
+  const long long total = (long long)T * Cin * Cout;
+  const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout, cd.Cin16, cd.Cout16,
+                     accumulate);
+  BCP_CHECK_LAUNCH("bcp_conv3_wgrad");
+  return BCP_OK;
+}
+
+// ---- Cin = 1 -> Cout = 16 first layer
+extern "C" int bcp_conv3_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int KD,
+                                void* stream) {
+  BCP_REQUIRE(x && w && y, "bcp_conv3_c1_fwd: null pointer");
+  BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_fwd: bad KD/D");
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, 1, 16);
+  if (KD == 3) {
+    cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 4); cd.tiles_w = cdiv(W, 16);
+    hipLaunchKernelGGL((k_conv3_c1<3, 4, 4, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0,
+                       (hipStream_t)stream, x, w, bias, y, cd);
+  } else {
+    cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16);
+    hipLaunchKernelGGL((k_conv3_c1<1, 1, 16, 16>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, (hipStream_t)stream, x, w,
+                       bias, y, cd);
+  }
+  BCP_CHECK_LAUNCH("bcp_conv3_c1_fwd");
+  return BCP_OK;
+}
+
+extern "C" int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int KD, int accumulate,
+                                  void* workspace, void* stream) {
+  BCP_REQUIRE(x && dy && dw && workspace, "bcp_conv3_c1_wgrad: null pointer");
+  BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_wgrad: bad KD/D");
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, 1, 16);
+  float* ws = reinterpret_cast<float*>(workspace);
+  int G;
+  if (KD == 3) {
+    cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 4); cd.tiles_w = cdiv(W, 16);
+    const int tiles = N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+    const int g0 = tiles < 512 ? tiles : 512, tpg = cdiv(tiles, g0);
+    G = cdiv(tiles, tpg);
+    hipLaunchKernelGGL((k_conv3_c1_wgrad<3, 4, 4, 16>), dim3(G), dim3(256), 0, (hipStream_t)stream, x, dy, ws, cd, tiles, tpg);
+  } else {
+    cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16);
+    const int tiles = N * cd.tiles_h * cd.tiles_w;
+    const int g0 = tiles < 512 ? tiles : 512, tpg = cdiv(tiles, g0);
+    G = cdiv(tiles, tpg);
+    hipLaunchKernelGGL((k_conv3_c1_wgrad<1, 1, 16, 16>), dim3(G), dim3(256), 0, (hipStream_t)stream, x, dy, ws, cd, tiles, tpg);
+  }
+  const int T = KD * 9;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(T * 16, 256)), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16,
+                     accumulate);
+  BCP_CHECK_LAUNCH("bcp_conv3_c1_wgrad");
+  return BCP_OK;
+}

@@ -1,0 +1,287 @@
+// bcp_amd/csrc/elementwise.hip -- HBM-bound BCP ops for gfx950: box copy-paste mix (A3+A4),
+// pseudo-label (A5), EMA (A10), SGD/Adam (A11), label casts, weight packing.
+// Every kernel is a 16-B-per-lane vectorised grid-stride stream (guide Appendix B "element-wise").
+#include "common.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+static inline int stream_grid(long long n_items, int block) {
+  long long g = (n_items + block - 1) / block;
+  if (g > 2048) g = 2048;  // 256 CUs x 8 blocks, grid-stride the rest (guide G11)
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---------------------------------------------------------------- mix (A3+A4)
+// out = a outside the box, b inside (reference: a*mask + b*(1-mask), mask = 1 outside the box;
+// LA_BCP_train.py:248-251, ACDC_BCP_train.py:372-373, utils/BCP_utils.py:18-28).
+// Layout [N][D][H][W][C] with C*W % 4 == 0; the box is in (d,h,w) voxel coordinates.
+__global__ __launch_bounds__(256) void k_mix_box(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, long long n_vec, int D, int H, int W, int C,
+                                                 int d0, int d1, int h0, int h1, int w0, int w1) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const int rowlen = W * C;  // floats per (n,d,h) row
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const long long e = i * 4;
+    const long long row = e / rowlen;
+    const int inrow = (int)(e - row * rowlen);
+    const int h = (int)(row % H);
+    const int d = (int)((row / H) % D);
+    const bool dh_in = (d >= d0) & (d < d1) & (h >= h0) & (h < h1);
+    float4 va = ld4(a + e), vb = ld4(b + e), vo;
+    float* po = &vo.x;
+    const float* pa = &va.x;
+    const float* pb = &vb.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int w = (inrow + k) / C;
+      const bool in = dh_in & (w >= w0) & (w < w1);
+      po[k] = in ? pb[k] : pa[k];
+    }
+    st4(out + e, vo);
+  }
+}
+
+// ---------------------------------------------------------------- pseudo-label (A5)
+// LA / pancreas: softmax over 2 channels, (p1 >= thres) -> uint8 (LA_BCP_train.py:57-60).
+__global__ __launch_bounds__(256) void k_plabel_bin(const float* __restrict__ logits, uint8_t* __restrict__ out,
+                                                    long long n_vec, float thres) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    const float4 l0 = ld4(logits + i * 8), l1 = ld4(logits + i * 8 + 4);
+    const float x[8] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+    uchar4 r;
+    unsigned char* pr = &r.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float m = fmaxf(x[2 * k], x[2 * k + 1]);
+      const float e0 = expf(x[2 * k] - m), e1 = expf(x[2 * k + 1] - m);
+      const float p1 = e1 / (e0 + e1);
+      pr[k] = (p1 >= thres) ? 1 : 0;
+    }
+    *reinterpret_cast<uchar4*>(out + i * 4) = r;
+  }
+}
+
+// ACDC: softmax over 4 channels then argmax, first maximum wins (ACDC_BCP_train.py:112-114).
+__global__ __launch_bounds__(256) void k_plabel_argmax4(const float* __restrict__ logits, uint8_t* __restrict__ out,
+                                                        long long n_pix) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
+    const float4 l = ld4(logits + i * 4);
+    const float m = fmaxf(fmaxf(l.x, l.y), fmaxf(l.z, l.w));
+    const float e0 = expf(l.x - m), e1 = expf(l.y - m), e2 = expf(l.z - m), e3 = expf(l.w - m);
+    const float s = e0 + e1 + e2 + e3;
+    const float p0 = e0 / s, p1 = e1 / s, p2 = e2 / s, p3 = e3 / s;
+    int best = 0;
+    float pb = p0;
+    if (p1 > pb) { pb = p1; best = 1; }
+    if (p2 > pb) { pb = p2; best = 2; }
+    if (p3 > pb) { pb = p3; best = 3; }
+    out[i] = (uint8_t)best;
+  }
+}
+
+// ---------------------------------------------------------------- EMA (A10)
+// dst = alpha*dst + (1-alpha)*src with the reference's two roundings per term
+// (ema.mul_(alpha).add_((1-alpha)*param), utils/BCP_utils.py:78-81); no FMA contraction.
+__global__ __launch_bounds__(256) void k_ema(float* __restrict__ dst, const float* __restrict__ src, long long n,
+                                             float alpha, float one_minus_alpha) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  const long long nv = n / 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+    float4 d = ld4(dst + i * 4);
+    const float4 s = ld4(src + i * 4);
+    d.x = __fadd_rn(__fmul_rn(d.x, alpha), __fmul_rn(one_minus_alpha, s.x));
+    d.y = __fadd_rn(__fmul_rn(d.y, alpha), __fmul_rn(one_minus_alpha, s.y));
+    d.z = __fadd_rn(__fmul_rn(d.z, alpha), __fmul_rn(one_minus_alpha, s.z));
+    d.w = __fadd_rn(__fmul_rn(d.w, alpha), __fmul_rn(one_minus_alpha, s.w));
+    st4(dst + i * 4, d);
+  }
+  for (long long i = nv * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    dst[i] = __fadd_rn(__fmul_rn(dst[i], alpha), __fmul_rn(one_minus_alpha, src[i]));
+}
+
+// ---------------------------------------------------------------- SGD / Adam (A11)
+// torch.optim.SGD (LA_BCP_train.py:218): g += wd*p; buf = m*buf + g (first step: buf = g); p -= lr*buf.
+// Optional fused EMA of a teacher copy (28 B/param instead of 20 + 12).
+__global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                             float* __restrict__ ema, long long n, float lr, float momentum, float wd,
+                                             float gscale, int first_step, float alpha, float one_minus_alpha) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float pv = p[i];
+    const float gv = __fadd_rn(g[i] * gscale, __fmul_rn(wd, pv));
+    const float bv = first_step ? gv : __fadd_rn(__fmul_rn(momentum, buf[i]), gv);
+    buf[i] = bv;
+    pv = __fadd_rn(pv, __fmul_rn(-lr, bv));
+    p[i] = pv;
+    if (ema) ema[i] = __fadd_rn(__fmul_rn(ema[i], alpha), __fmul_rn(one_minus_alpha, pv));
+  }
+}
+
+// torch.optim.Adam defaults (pancreas/dataloaders.py:182): bias-corrected, eps outside the sqrt.
+__global__ __launch_bounds__(256) void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                              float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                              float bc1, float bc2_sqrt, float gscale) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gv = g[i] * gscale;
+    const float mv = m[i] * b1 + (1.f - b1) * gv;
+    const float vv = v[i] * b2 + (1.f - b2) * gv * gv;
+    m[i] = mv;
+    v[i] = vv;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    p[i] = p[i] - (lr / bc1) * (mv / denom);
+  }
+}
+
+// ---------------------------------------------------------------- casts / fills
+__global__ __launch_bounds__(256) void k_i64_to_u8(const long long* __restrict__ in, uint8_t* __restrict__ out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint8_t)in[i];
+}
+__global__ __launch_bounds__(256) void k_f32_to_u8(const float* __restrict__ in, uint8_t* __restrict__ out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (uint8_t)in[i];
+}
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t* __restrict__ in, float* __restrict__ out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (float)in[i];
+}
+__global__ __launch_bounds__(256) void k_u8_to_i64(const uint8_t* __restrict__ in, long long* __restrict__ out, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = (long long)in[i];
+}
+__global__ __launch_bounds__(256) void k_axpy(float* __restrict__ y, const float* __restrict__ x, long long n, float a) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = y[i] + a * x[i];
+}
+
+// Counter-hash Bernoulli keep-masks for throughput runs (parity runs inject masks instead).
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(256) void k_bernoulli_f32(float* __restrict__ out, long long n, float p_keep, float keep_value,
+                                                       unsigned seed_lo, unsigned seed_hi) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const unsigned h = mix32((unsigned)i ^ mix32(seed_lo + 0x9e3779b9u * (unsigned)(i >> 32)) ^ seed_hi);
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    out[i] = (u < p_keep) ? keep_value : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void k_bernoulli_u8(uint8_t* __restrict__ out, long long n, float p_keep,
+                                                      unsigned seed_lo, unsigned seed_hi) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const unsigned h = mix32((unsigned)i ^ mix32(seed_lo + 0x9e3779b9u * (unsigned)(i >> 32)) ^ seed_hi);
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    out[i] = (u < p_keep) ? 1 : 0;
+  }
+}
+
+}  // namespace bcp
+
+using namespace bcp;
+
+extern "C" int bcp_mix_box(const float* a, const float* b, float* out, int N, int D, int H, int W, int C,
+                           const int* box6, void* stream) {
+  BCP_REQUIRE(a && b && out && box6, "bcp_mix_box: null pointer");
+  BCP_REQUIRE(aligned16(a) && aligned16(b) && aligned16(out), "bcp_mix_box: pointers must be 16-B aligned");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bcp_mix_box: bad extents");
+  BCP_REQUIRE((W * C) % 4 == 0, "bcp_mix_box: W*C must be a multiple of 4");
+  const long long n_vec = (long long)N * D * H * W * C / 4;
+  hipLaunchKernelGGL(k_mix_box, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_vec, D, H,
+                     W, C, box6[0], box6[0] + box6[3], box6[1], box6[1] + box6[4], box6[2], box6[2] + box6[5]);
+  BCP_CHECK_LAUNCH("bcp_mix_box");
+  return BCP_OK;
+}
+
+extern "C" int bcp_plabel_bin(const float* logits, uint8_t* out, long long n_vox, float thres, void* stream) {
+  BCP_REQUIRE(logits && out, "bcp_plabel_bin: null pointer");
+  BCP_REQUIRE(n_vox > 0 && n_vox % 4 == 0, "bcp_plabel_bin: n_vox must be a positive multiple of 4");
+  BCP_REQUIRE(aligned16(logits) && (reinterpret_cast<uintptr_t>(out) & 3u) == 0, "bcp_plabel_bin: alignment");
+  hipLaunchKernelGGL(k_plabel_bin, dim3(stream_grid(n_vox / 4, 256)), dim3(256), 0, (hipStream_t)stream, logits, out,
+                     n_vox / 4, thres);
+  BCP_CHECK_LAUNCH("bcp_plabel_bin");
+  return BCP_OK;
+}
+
+extern "C" int bcp_plabel_argmax4(const float* logits, uint8_t* out, long long n_pix, void* stream) {
+  BCP_REQUIRE(logits && out && n_pix > 0, "bcp_plabel_argmax4: bad argument");
+  BCP_REQUIRE(aligned16(logits), "bcp_plabel_argmax4: alignment");
+  hipLaunchKernelGGL(k_plabel_argmax4, dim3(stream_grid(n_pix, 256)), dim3(256), 0, (hipStream_t)stream, logits, out,
+                     n_pix);
+  BCP_CHECK_LAUNCH("bcp_plabel_argmax4");
+  return BCP_OK;
+}
+
+extern "C" int bcp_ema(float* dst, const float* src, long long n, double alpha, void* stream) {
+  BCP_REQUIRE(dst && src && n > 0, "bcp_ema: bad argument");
+  BCP_REQUIRE(aligned16(dst) && aligned16(src), "bcp_ema: alignment");
+  // (1 - alpha) is formed in double then rounded to f32, as python does for (1 - alpha) * tensor
+  const float oma = (float)(1.0 - alpha);
+  hipLaunchKernelGGL(k_ema, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, n, (float)alpha, oma);
+  BCP_CHECK_LAUNCH("bcp_ema");
+  return BCP_OK;
+}
+
+extern "C" int bcp_sgd(float* p, const float* g, float* buf, float* ema_or_null, long long n, float lr, float momentum,
+                       float weight_decay, float grad_scale, int first_step, double ema_alpha, void* stream) {
+  BCP_REQUIRE(p && g && buf && n > 0, "bcp_sgd: bad argument");
+  const float oma = (float)(1.0 - ema_alpha);
+  hipLaunchKernelGGL(k_sgd, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, buf, ema_or_null, n, lr,
+                     momentum, weight_decay, grad_scale, first_step, (float)ema_alpha, oma);
+  BCP_CHECK_LAUNCH("bcp_sgd");
+  return BCP_OK;
+}
+
+extern "C" int bcp_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                        float eps, int step, float grad_scale, void* stream) {
+  BCP_REQUIRE(p && g && m && v && n > 0 && step >= 1, "bcp_adam: bad argument");
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  hipLaunchKernelGGL(k_adam, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                     beta2, eps, (float)bc1, (float)sqrt(bc2), grad_scale);
+  BCP_CHECK_LAUNCH("bcp_adam");
+  return BCP_OK;
+}
+
+extern "C" int bcp_cast(const void* in, void* out, long long n, int kind, void* stream) {
+  BCP_REQUIRE(in && out && n > 0, "bcp_cast: bad argument");
+  const dim3 g(stream_grid(n, 256)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (kind) {
+    case BCP_CAST_I64_U8: hipLaunchKernelGGL(k_i64_to_u8, g, b, 0, s, (const long long*)in, (uint8_t*)out, n); break;
+    case BCP_CAST_F32_U8: hipLaunchKernelGGL(k_f32_to_u8, g, b, 0, s, (const float*)in, (uint8_t*)out, n); break;
+    case BCP_CAST_U8_F32: hipLaunchKernelGGL(k_u8_to_f32, g, b, 0, s, (const uint8_t*)in, (float*)out, n); break;
+    case BCP_CAST_U8_I64: hipLaunchKernelGGL(k_u8_to_i64, g, b, 0, s, (const uint8_t*)in, (long long*)out, n); break;
+    default: BCP_REQUIRE(false, "bcp_cast: unknown kind %d", kind);
+  }
+  BCP_CHECK_LAUNCH("bcp_cast");
+  return BCP_OK;
+}
+
+extern "C" int bcp_axpy(float* y, const float* x, long long n, float a, void* stream) {
+  BCP_REQUIRE(y && x && n > 0, "bcp_axpy: bad argument");
+  hipLaunchKernelGGL(k_axpy, dim3(stream_grid(n, 256)), dim3(256), 0, (hipStream_t)stream, y, x, n, a);
+  BCP_CHECK_LAUNCH("bcp_axpy");
+  return BCP_OK;
+}
+
+extern "C" int bcp_bernoulli(void* out, long long n, float p_keep, float keep_value, int as_u8, unsigned long long seed,
+                             void* stream) {
+  BCP_REQUIRE(out && n > 0, "bcp_bernoulli: bad argument");
+  const dim3 g(stream_grid(n, 256)), b(256);
+  if (as_u8)
+    hipLaunchKernelGGL(k_bernoulli_u8, g, b, 0, (hipStream_t)stream, (uint8_t*)out, n, p_keep, (unsigned)seed,
+                       (unsigned)(seed >> 32));
+  else
+    hipLaunchKernelGGL(k_bernoulli_f32, g, b, 0, (hipStream_t)stream, (float*)out, n, p_keep, keep_value, (unsigned)seed,
+                       (unsigned)(seed >> 32));
+  BCP_CHECK_LAUNCH("bcp_bernoulli");
+  return BCP_OK;
+}

@@ -1,0 +1,516 @@
+// bcp_amd/csrc/gemm.hip -- row-gather / row-scatter fp32 MFMA GEMMs for the non-overlapping convs:
+//   * k=2,s=2 down conv  (nn.Conv3d(k=2,stride=2),          networks/VNet.py:74)   fwd / dgrad / wgrad
+//   * k=2,s=2 up conv    (nn.ConvTranspose3d(k=2,stride=2), networks/VNet.py:101)  fwd / dgrad / wgrad
+//   * 1x1 conv           (nn.Conv2d(k=1), networks/unet.py:48)                     fwd / dgrad / wgrad
+//   * the 16 -> n_classes 1x1x1 output conv (networks/VNet.py:210), a tiny VALU stream.
+// A 2x2x2/stride-2 conv has no halo: it is a plain GEMM whose A rows are gathered from the 8 fine
+// voxels under a coarse voxel ("PATCH" row map), and the transposed conv is the same GEMM with the
+// C rows scattered to them.  These layers are HBM-bound at the top V-Net level (AI ~ 13 FLOP/B).
+//
+// NN kernel:  C(m, n) = sum_k A(m, k) * B[k][n] (+ bias)      B packed [K/4][N][4] (k%4 innermost)
+// TN kernel:  P[k][n] = sum_m A(m, k) * B(m, n)                (weight gradients; M = voxels)
+// Both use v_mfma_f32_16x16x4_f32; lane (i = l&15, g = l>>4).
+#include "common.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+enum { MAP_PLAIN = 0, MAP_PATCH = 1 };
+
+// Row map: logical matrix [M][L]; PLAIN: p + m*L + q.  PATCH: m indexes a coarse voxel of a fine
+// [N][D][H][W][Cs] tensor, q = s*Cs + c with s = (pd*2 + ph)*2 + pw.
+struct RowMap {
+  float* p;
+  int mode;
+  int L;            // logical row length
+  int Cs;           // channels of the fine tensor (PATCH)
+  int D, H, W;      // fine dims (PATCH)
+  __device__ __forceinline__ long long base(int m) const {  // offset of (m, s=0, c=0)
+    if (mode == MAP_PLAIN) return (long long)m * L;
+    const int Wc = W >> 1, Hc = H >> 1, Dc = D >> 1;
+    const int wc = m % Wc, hc = (m / Wc) % Hc, dc = (m / (Wc * Hc)) % Dc, n = m / (Wc * Hc * Dc);
+    return ((((long long)n * D + 2 * dc) * H + 2 * hc) * W + 2 * wc) * Cs;
+  }
+  __device__ __forceinline__ long long off(int q) const {   // add to base(m) for logical column q (PATCH: within one segment run)
+    if (mode == MAP_PLAIN) return q;
+    const int s = q / Cs, c = q - s * Cs;
+    const int pw = s & 1, ph = (s >> 1) & 1, pd = s >> 2;
+    return (((long long)pd * H + ph) * W + pw) * Cs + c;
+  }
+};
+
+static constexpr int AS = 20;  // LDS row stride of the A chunk (16 + 4 pad)
+
+// ------------------------------------------------------------------------------------------------
+// NN: block = 64 rows x (16*NT) cols, waves split the rows (one 16-row m-tile each).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restrict__ Bp, const float* __restrict__ bias,
+                                                 RowMap C, int M, int K, int N, int bias_mod, int accumulate) {
+  constexpr int CT = NT * 16;
+  __shared__ float As[64 * AS];
+  __shared__ float Bs[4 * CT * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * CT;
+
+  // staging role: thread -> (row, 16-B part)
+  const int srow = threadIdx.x >> 2, spart = threadIdx.x & 3;
+  const bool srow_ok = (m0 + srow) < M;
+  const long long sbase = srow_ok ? A.base(m0 + srow) : 0;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < K; kc += 16) {
+    __syncthreads();
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (srow_ok) v = ld4(A.p + sbase + A.off(kc + spart * 4));
+    st4(As + srow * AS + spart * 4, v);
+    for (int q = threadIdx.x; q < 4 * CT; q += 256) {
+      const int co = q % CT, kq = q / CT;
+      st4(Bs + q * 4, ld4(Bp + (((long long)(kc >> 2) + kq) * N + n0 + co) * 4));
+    }
+    __syncthreads();
+    const float4 a = ld4(As + (wave * 16 + li) * AS + lg * 4);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float4 b = ld4(Bs + ((lg * CT) + nt * 16 + li) * 4);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int m = m0 + wave * 16 + lg * 4 + r;
+    if (m < M) {
+      const long long cb = C.base(m);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int n = n0 + nt * 16 + li;
+        float* o = C.p + cb + C.off(n);
+        float v = acc[nt][r];
+        if (bias) v += bias[n % bias_mod];
+        if (accumulate) v += *o;
+        *o = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: P[grp][k][n] = sum over the group's rows of A(m,k) * B(m,n).  Block = (row group, 64 k, 16*NT n);
+// wave w owns k-subtile w.  Per k-step of 4 rows: lane (i, g) supplies A(row g, k i) and B(row g, n i).
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void k_gemm_tn(RowMap A, RowMap B, float* __restrict__ partial, int M, int K, int N,
+                                                 int rows_per_group) {
+  constexpr int CT = NT * 16;
+  constexpr int AS2 = 64 + 16;                          // [row][64 k] + bank spread
+  constexpr int BS2 = (CT % 32 == 0) ? CT + 16 : CT;    // [row][CT n]
+  __shared__ float As[64 * AS2];
+  __shared__ float Bs[64 * BS2];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int grp = blockIdx.x, k0 = blockIdx.y * 64, n0 = blockIdx.z * CT;
+  const int r_begin = grp * rows_per_group;
+  int r_end = r_begin + rows_per_group;
+  if (r_end > M) r_end = M;
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int rc = r_begin; rc < r_end; rc += 64) {
+    __syncthreads();
+    // A chunk: 64 rows x 64 k  = 1024 float4
+    for (int q = threadIdx.x; q < 64 * 16; q += 256) {
+      const int row = q >> 4, part = q & 15;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rc + row < r_end && k0 + part * 4 < K) v = ld4(A.p + A.base(rc + row) + A.off(k0 + part * 4));
+      st4(As + row * AS2 + part * 4, v);
+    }
+    for (int q = threadIdx.x; q < 64 * (CT / 4); q += 256) {
+      const int row = q / (CT / 4), part = q % (CT / 4);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rc + row < r_end) v = ld4(B.p + B.base(rc + row) + B.off(n0 + part * 4));
+      st4(Bs + row * BS2 + part * 4, v);
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kk = 0; kk < 16; ++kk) {
+      const int row = kk * 4 + lg;
+      const float a = As[row * AS2 + wave * 16 + li];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[row * BS2 + nt * 16 + li], acc[nt], 0, 0, 0);
+    }
+  }
+  float* P = partial + (long long)grp * K * N;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + wave * 16 + lg * 4 + r;
+      if (k < K) P[(long long)k * N + n0 + nt * 16 + li] = acc[nt][r];
+    }
+}
+
+// out[ (k1*ok1 + k2*ok2 + n1*on1 + n2*on2) ] (+)= sum_g partial[g][k][n],  k = k1*K2 + k2, n = n1*N2 + n2
+struct Idx4 { int K2, N2; long long sk1, sk2, sn1, sn2; };
+
+__global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ partial, float* __restrict__ out, int G, int K, int N,
+                                                   Idx4 ix, int accumulate) {
+  const long long total = (long long)K * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % N), k = (int)(i / N);
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += partial[(long long)g * total + i];
+    float* o = out + (k / ix.K2) * ix.sk1 + (k % ix.K2) * ix.sk2 + (n / ix.N2) * ix.sn1 + (n % ix.N2) * ix.sn2;
+    *o = accumulate ? (*o + s) : s;
+  }
+}
+
+// Bp[(k/4)][n][k%4] = w[(k/K2)*sk1 + (k%K2)*sk2 + (n/N2)*sn1 + (n%N2)*sn2]
+__global__ __launch_bounds__(256) void k_pack_gemm_b(const float* __restrict__ w, float* __restrict__ bp, int K, int N, Idx4 ix) {
+  const long long total = (long long)K * N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k4 = (int)(i & 3);
+    const int n = (int)((i >> 2) % N);
+    const int k = (int)(i / (4LL * N)) * 4 + k4;
+    bp[i] = w[(k / ix.K2) * ix.sk1 + (k % ix.K2) * ix.sk2 + (n / ix.N2) * ix.sn1 + (n % ix.N2) * ix.sn2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16 -> CO (<= 4) pointwise output conv: y[v][co] = b[co] + sum_ci x[v][ci] w[co][ci]
+// ------------------------------------------------------------------------------------------------
+template <int CO>
+__global__ __launch_bounds__(256) void k_pw16_fwd(const float* __restrict__ x, const float* __restrict__ w,
+                                                  const float* __restrict__ bias, float* __restrict__ y, long long nvox) {
+  __shared__ float Ws[CO * 16 + CO];
+  if ((int)threadIdx.x < CO * 16) Ws[threadIdx.x] = w[threadIdx.x];
+  if ((int)threadIdx.x < CO) Ws[CO * 16 + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  __syncthreads();
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+    float xv[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+      const float4 t = ld4(x + v * 16 + c);
+      xv[c] = t.x; xv[c + 1] = t.y; xv[c + 2] = t.z; xv[c + 3] = t.w;
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+      float s = Ws[CO * 16 + co];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) s = fmaf(xv[c], Ws[co * 16 + c], s);
+      y[v * CO + co] = s;
+    }
+  }
+}
+
+// backward: dx[v][ci] = sum_co dy[v][co] w[co][ci];  acc (fp64 atomics): dw[co][ci], db[co]
+template <int CO>
+__global__ __launch_bounds__(256) void k_pw16_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                  const float* __restrict__ w, float* __restrict__ dx,
+                                                  double* __restrict__ accum /* [CO*16 + CO] */, long long nvox) {
+  __shared__ float Ws[CO * 16];
+  __shared__ double red[4][CO * 16 + CO];
+  if ((int)threadIdx.x < CO * 16) Ws[threadIdx.x] = w[threadIdx.x];
+  __syncthreads();
+  float gw[CO][16], gb[CO];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+    gb[co] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) gw[co][c] = 0.f;
+  }
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
+    float xv[16], dv[CO], o[16];
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) {
+      const float4 t = ld4(x + v * 16 + c);
+      xv[c] = t.x; xv[c + 1] = t.y; xv[c + 2] = t.z; xv[c + 3] = t.w;
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) dv[co] = dy[v * CO + co];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float s = 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        s = fmaf(dv[co], Ws[co * 16 + c], s);
+        gw[co][c] = fmaf(dv[co], xv[c], gw[co][c]);
+      }
+      o[c] = s;
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) gb[co] += dv[co];
+#pragma unroll
+    for (int c = 0; c < 16; c += 4) st4(dx + v * 16 + c, make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]));
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const double r = wave_sum((double)gw[co][c]);
+      if (lane == 0) red[wid][co * 16 + c] = r;
+    }
+    const double rb = wave_sum((double)gb[co]);
+    if (lane == 0) red[wid][CO * 16 + co] = rb;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < CO * 16 + CO)
+    atomicAdd(&accum[threadIdx.x], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+__global__ void k_pw16_finalize(const double* __restrict__ accum, float* __restrict__ dw, float* __restrict__ db, int CO,
+                                int accumulate) {
+  const int i = threadIdx.x;
+  if (i < CO * 16) dw[i] = (accumulate ? dw[i] : 0.f) + (float)accum[i];
+  else if (i < CO * 16 + CO) db[i - CO * 16] = (accumulate ? db[i - CO * 16] : 0.f) + (float)accum[i];
+}
+
+// column sums of a [rows][C] matrix (bias gradients of convs that are NOT followed by a norm)
+__global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, long long rows, int C, double* __restrict__ accum) {
+  // thread t owns column t % C (C <= 256, 256 % C == 0)
+  const int col = threadIdx.x % C, slot = threadIdx.x / C, slots = 256 / C;
+  double s = 0.0;
+  for (long long r = (long long)blockIdx.x * slots + slot; r < rows; r += (long long)gridDim.x * slots) s += (double)x[r * C + col];
+  atomicAdd(&accum[col], s);
+}
+__global__ void k_colsum_finalize(const double* __restrict__ accum, float* __restrict__ out, int C, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C) out[i] = (accumulate ? out[i] : 0.f) + (float)accum[i];
+}
+
+static RowMap make_map(const float* p, int mode, int L, int Cs, int D, int H, int W) {
+  RowMap m;
+  m.p = const_cast<float*>(p);
+  m.mode = mode; m.L = L; m.Cs = Cs; m.D = D; m.H = H; m.W = W;
+  return m;
+}
+
+static int pick_nt(int N, long long row_blocks) {
+  int nt = 4;
+  while (nt > 1 && (N % (nt * 16) != 0)) nt >>= 1;
+  while (nt > 1 && row_blocks * (N / (nt * 16)) < 256) nt >>= 1;
+  return nt;
+}
+
+static int launch_nn(RowMap A, const float* Bp, const float* bias, RowMap C, int M, int K, int N, int bias_mod, int accumulate,
+                     hipStream_t s) {
+  const int rb = cdiv(M, 64);
+  const int nt = pick_nt(N, rb);
+  const dim3 grid(rb, N / (nt * 16));
+  if (nt == 4) hipLaunchKernelGGL((k_gemm_nn<4>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate);
+  else if (nt == 2) hipLaunchKernelGGL((k_gemm_nn<2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate);
+  else hipLaunchKernelGGL((k_gemm_nn<1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate);
+  return 0;
+}
+
+static int tn_groups(int M, int K, int N, int nt) {
+  const int chan_blocks = cdiv(K, 64) * (N / (nt * 16));
+  int g = cdiv(512, chan_blocks);
+  const int max_g = cdiv(M, 64);
+  if (g > max_g) g = max_g;
+  if (g < 1) g = 1;
+  return g;
+}
+static int tn_nt(int N) {
+  int nt = 4;
+  while (nt > 1 && (N % (nt * 16) != 0)) nt >>= 1;
+  return nt;
+}
+
+static int launch_tn(RowMap A, RowMap B, float* partial, float* out, int M, int K, int N, Idx4 ix, int accumulate, hipStream_t s) {
+  const int nt = tn_nt(N);
+  const int g0 = tn_groups(M, K, N, nt);
+  const int rpg = cdiv(cdiv(M, g0), 64) * 64;
+  const int G = cdiv(M, rpg);
+  const dim3 grid(G, cdiv(K, 64), N / (nt * 16));
+  if (nt == 4) hipLaunchKernelGGL((k_gemm_tn<4>), grid, dim3(256), 0, s, A, B, partial, M, K, N, rpg);
+  else if (nt == 2) hipLaunchKernelGGL((k_gemm_tn<2>), grid, dim3(256), 0, s, A, B, partial, M, K, N, rpg);
+  else hipLaunchKernelGGL((k_gemm_tn<1>), grid, dim3(256), 0, s, A, B, partial, M, K, N, rpg);
+  const long long total = (long long)K * N;
+  hipLaunchKernelGGL(k_tn_reduce, dim3((int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, s, partial,
+                     out, G, K, N, ix, accumulate);
+  return 0;
+}
+
+}  // namespace bcp
+
+using namespace bcp;
+
+// kind: which GEMM the packed matrix feeds (see include/bcp_hip.h)
+extern "C" int bcp_k2_pack_weight(const float* w, float* bp, int Cin, int Cout, int kind, void* stream) {
+  BCP_REQUIRE(w && bp && Cin > 0 && Cout > 0, "bcp_k2_pack_weight: bad argument");
+  BCP_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "bcp_k2_pack_weight: channels must be multiples of 16");
+  int K, N;
+  Idx4 ix;
+  switch (kind) {
+    case BCP_PACK_DOWN_FWD:    // w[co][ci][s]: B[k = s*Cin + ci][n = co]
+      K = 8 * Cin; N = Cout; ix = {Cin, Cout, 1, 8, 0, (long long)Cin * 8}; break;
+    case BCP_PACK_DOWN_DGRAD:  // B[k = co][n = s*Cin + ci] = w[co][ci][s]
+      K = Cout; N = 8 * Cin; ix = {Cout, Cin, 0, (long long)Cin * 8, 1, 8}; break;
+    case BCP_PACK_UP_FWD:      // w[ci][co][s]: B[k = ci][n = s*Cout + co]
+      K = Cin; N = 8 * Cout; ix = {Cin, Cout, 0, (long long)Cout * 8, 1, 8}; break;
+    case BCP_PACK_UP_DGRAD:    // B[k = s*Cout + co][n = ci] = w[ci][co][s]
+      K = 8 * Cout; N = Cin; ix = {Cout, Cin, 1, 8, 0, (long long)Cout * 8}; break;
+    case BCP_PACK_PW_FWD:      // w[co][ci]: B[k = ci][n = co]
+      K = Cin; N = Cout; ix = {Cin, Cout, 0, 1, 0, (long long)Cin}; break;
+    case BCP_PACK_PW_DGRAD:    // B[k = co][n = ci] = w[co][ci]
+      K = Cout; N = Cin; ix = {Cout, Cin, 0, (long long)Cin, 0, 1}; break;
+    default: BCP_REQUIRE(false, "bcp_k2_pack_weight: unknown kind %d", kind);
+  }
+  const long long total = (long long)K * N;
+  hipLaunchKernelGGL(k_pack_gemm_b, dim3((int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, w, bp, K, N, ix);
+  BCP_CHECK_LAUNCH("bcp_k2_pack_weight");
+  return BCP_OK;
+}
+
+// Down conv forward:  y[coarse][Cout] = gather(x fine [N][D][H][W][Cin]) * B + bias
+extern "C" int bcp_down_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                            int Cout, void* stream) {
+  BCP_REQUIRE(x && bp && y, "bcp_down_fwd: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_down_fwd: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  launch_nn(make_map(x, MAP_PATCH, 8 * Cin, Cin, D, H, W), bp, bias, make_map(y, MAP_PLAIN, Cout, 0, 0, 0, 0), M, 8 * Cin, Cout,
+            Cout, 0, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_down_fwd");
+  return BCP_OK;
+}
+
+// Down conv dgrad: dx fine (+)= scatter(dy[coarse][Cout] * B');  (D,H,W) are the FINE dims
+extern "C" int bcp_down_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout,
+                              int accumulate, void* stream) {
+  BCP_REQUIRE(dy && bp && dx, "bcp_down_dgrad: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_down_dgrad: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  launch_nn(make_map(dy, MAP_PLAIN, Cout, 0, 0, 0, 0), bp, nullptr, make_map(dx, MAP_PATCH, 8 * Cin, Cin, D, H, W), M, Cout,
+            8 * Cin, 1, accumulate, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_down_dgrad");
+  return BCP_OK;
+}
+
+// Up (transposed) conv forward: y fine [N][D][H][W][Cout] = scatter(x[coarse][Cin] * B) + bias; (D,H,W) FINE dims
+extern "C" int bcp_up_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                          int Cout, void* stream) {
+  BCP_REQUIRE(x && bp && y, "bcp_up_fwd: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_up_fwd: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  launch_nn(make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), bp, bias, make_map(y, MAP_PATCH, 8 * Cout, Cout, D, H, W), M, Cin, 8 * Cout,
+            Cout, 0, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_up_fwd");
+  return BCP_OK;
+}
+
+// Up conv dgrad: dx[coarse][Cin] = gather(dy fine) * B'
+extern "C" int bcp_up_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout,
+                            int accumulate, void* stream) {
+  BCP_REQUIRE(dy && bp && dx, "bcp_up_dgrad: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_up_dgrad: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  launch_nn(make_map(dy, MAP_PATCH, 8 * Cout, Cout, D, H, W), bp, nullptr, make_map(dx, MAP_PLAIN, Cin, 0, 0, 0, 0), M, 8 * Cout,
+            Cin, 1, accumulate, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_up_dgrad");
+  return BCP_OK;
+}
+
+extern "C" int bcp_pw_fwd(const float* x, const float* bp, const float* bias, float* y, long long rows, int Cin, int Cout,
+                          void* stream) {
+  BCP_REQUIRE(x && bp && y && rows > 0 && rows < (1LL << 31), "bcp_pw_fwd: bad argument");
+  BCP_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "bcp_pw_fwd: channels must be multiples of 16");
+  launch_nn(make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), bp, bias, make_map(y, MAP_PLAIN, Cout, 0, 0, 0, 0), (int)rows, Cin, Cout, Cout,
+            0, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_pw_fwd");
+  return BCP_OK;
+}
+
+extern "C" size_t bcp_tn_workspace_bytes(long long M, int K, int N) {
+  const int nt = tn_nt(N);
+  const int g0 = tn_groups((int)M, K, N, nt);
+  const int rpg = cdiv(cdiv(M, g0), 64) * 64;
+  return (size_t)cdiv(M, rpg) * K * N * sizeof(float);
+}
+
+// Weight gradients.  kind selects the layer type; (D,H,W) are the FINE dims for the k2 kinds.
+//   BCP_WG_DOWN: x fine [.,Cin], dy coarse [.,Cout] -> dw[Cout][Cin][8]
+//   BCP_WG_UP:   x coarse [.,Cin], dy fine [.,Cout] -> dw[Cin][Cout][8]
+//   BCP_WG_PW:   x [rows][Cin], dy [rows][Cout]      -> dw[Cout][Cin]      (rows = N*D*H*W)
+extern "C" int bcp_k2_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin, int Cout, int kind,
+                            int accumulate, void* workspace, void* stream) {
+  BCP_REQUIRE(x && dy && dw && workspace, "bcp_k2_wgrad: null pointer");
+  BCP_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "bcp_k2_wgrad: channels must be multiples of 16");
+  float* ws = reinterpret_cast<float*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  if (kind == BCP_WG_DOWN) {
+    const int M = N * (D / 2) * (H / 2) * (W / 2);
+    Idx4 ix = {Cin, Cout, 1, 8, 0, (long long)Cin * 8};  // k = s*Cin + ci, n = co -> dw[co][ci][s]
+    launch_tn(make_map(x, MAP_PATCH, 8 * Cin, Cin, D, H, W), make_map(dy, MAP_PLAIN, Cout, 0, 0, 0, 0), ws, dw, M, 8 * Cin, Cout, ix,
+              accumulate, s);
+  } else if (kind == BCP_WG_UP) {
+    const int M = N * (D / 2) * (H / 2) * (W / 2);
+    Idx4 ix = {Cin, Cout, 0, (long long)Cout * 8, 1, 8};  // k = ci, n = s*Cout + co -> dw[ci][co][s]
+    launch_tn(make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), make_map(dy, MAP_PATCH, 8 * Cout, Cout, D, H, W), ws, dw, M, Cin, 8 * Cout, ix,
+              accumulate, s);
+  } else if (kind == BCP_WG_PW) {
+    const long long M = (long long)N * D * H * W;
+    BCP_REQUIRE(M < (1LL << 31), "bcp_k2_wgrad: too many rows");
+    Idx4 ix = {Cin, Cout, 0, 1, 0, (long long)Cin};  // k = ci, n = co -> dw[co][ci]
+    launch_tn(make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), make_map(dy, MAP_PLAIN, Cout, 0, 0, 0, 0), ws, dw, (int)M, Cin, Cout, ix,
+              accumulate, s);
+  } else {
+    BCP_REQUIRE(false, "bcp_k2_wgrad: unknown kind %d", kind);
+  }
+  BCP_CHECK_LAUNCH("bcp_k2_wgrad");
+  return BCP_OK;
+}
+
+extern "C" int bcp_pw16_fwd(const float* x, const float* w, const float* bias, float* y, long long nvox, int Cout, void* stream) {
+  BCP_REQUIRE(x && w && y && nvox > 0, "bcp_pw16_fwd: bad argument");
+  const int grid = (int)((nvox + 255) / 256 > 2048 ? 2048 : (nvox + 255) / 256);
+  if (Cout == 2) hipLaunchKernelGGL((k_pw16_fwd<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, nvox);
+  else if (Cout == 4) hipLaunchKernelGGL((k_pw16_fwd<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, nvox);
+  else BCP_REQUIRE(false, "bcp_pw16_fwd: Cout=%d unsupported (2 or 4)", Cout);
+  BCP_CHECK_LAUNCH("bcp_pw16_fwd");
+  return BCP_OK;
+}
+
+// workspace: (Cout*16 + Cout) doubles
+extern "C" int bcp_pw16_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long nvox,
+                            int Cout, int accumulate, void* workspace, void* stream) {
+  BCP_REQUIRE(x && dy && w && dx && dw && db && workspace && nvox > 0, "bcp_pw16_bwd: bad argument");
+  double* acc = reinterpret_cast<double*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(acc, 0, (size_t)(Cout * 17) * sizeof(double), s);
+  const int grid = (int)((nvox + 255) / 256 > 1024 ? 1024 : (nvox + 255) / 256);
+  if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd<2>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox);
+  else if (Cout == 4) hipLaunchKernelGGL((k_pw16_bwd<4>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox);
+  else BCP_REQUIRE(false, "bcp_pw16_bwd: Cout=%d unsupported (2 or 4)", Cout);
+  hipLaunchKernelGGL(k_pw16_finalize, dim3(1), dim3(128), 0, s, acc, dw, db, Cout, accumulate);
+  BCP_CHECK_LAUNCH("bcp_pw16_bwd");
+  return BCP_OK;
+}
+
+// workspace: C doubles
+extern "C" int bcp_colsum(const float* x, long long rows, int C, float* out, int accumulate, void* workspace, void* stream) {
+  BCP_REQUIRE(x && out && workspace && rows > 0, "bcp_colsum: bad argument");
+  BCP_REQUIRE(C >= 1 && C <= 256 && 256 % C == 0, "bcp_colsum: C must divide 256");
+  double* acc = reinterpret_cast<double*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  hipMemsetAsync(acc, 0, (size_t)C * sizeof(double), s);
+  const int slots = 256 / C;
+  long long g = (rows + slots * 64 - 1) / (slots * 64);
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  hipLaunchKernelGGL(k_colsum, dim3((int)g), dim3(256), 0, s, x, rows, C, acc);
+  hipLaunchKernelGGL(k_colsum_finalize, dim3(cdiv(C, 256)), dim3(256), 0, s, acc, out, C, accumulate);
+  BCP_CHECK_LAUNCH("bcp_colsum");
+  return BCP_OK;
+}

@@ -1,0 +1,330 @@
+// bcp_amd/csrc/loss.hip -- fused masked Dice + CE ("mix_loss") forward / backward for gfx950.
+//
+// Reference semantics:
+//   LA / pancreas  utils/BCP_utils.py:58-69 + utils/losses.py:47-77  (per-(n,c) soft Dice, smooth 1e-5)
+//   ACDC           ACDC_BCP_train.py:167-179 + utils/losses.py:102-134 (per-class Dice over the batch,
+//                  squared denominators, smooth 1e-10; returns dice and ce separately)
+// Every voxel lies in exactly one of the two complementary masks (M = outside the box -> "image"
+// term, 1-M = inside -> "patch" term), so ONE pass over the logits accumulates both terms:
+// 8 B logits + 2 x 1 B labels per voxel (C=2).  Partial sums are fp64 (wavefront shuffles ->
+// LDS -> one fp64 atomic per block per quantity); a 1-block finalize kernel turns them into the
+// loss scalar(s) and the per-(n,term,class) coefficient table the backward pass needs, so the
+// backward is a second single pass (8 B logits re-read + 8 B dlogits written per voxel).
+#include "common.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+// accumulator layout (doubles):
+//   acc[((n*2 + t)*C + c)*3 + {0: inter, 1: union|z, 2: ysum}]   n < N
+//   tail: acc[N*2*C*3 + t*2 + {0: ce_sum, 1: count}]
+// coefficient layout (floats) written by the finalize kernel:
+//   coef[((n*2 + t)*C + c)*2 + {0: A, 1: B}],  tail coef[N*2*C*2 + t] = CE coefficient
+// LA flavour:  dL/dP_c = A*1[y==c] - B          (A,B already hold -1/2 * w_t/(N*C) and signs)
+// ACDC flavour: dL/dP_c = A*1[y==c] - B*P_c
+
+template <int C>
+struct Softmax {
+  float p[C];
+  __device__ __forceinline__ void compute(const float* x) {
+    float m = x[0];
+#pragma unroll
+    for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - m); s += p[c]; }
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int c = 0; c < C; ++c) p[c] *= inv;
+    lse = m + logf(s);
+  }
+  float lse;
+};
+
+__device__ __forceinline__ bool in_box(int d, int h, int w, const int* bx) {
+  return (d >= bx[0]) & (d < bx[1]) & (h >= bx[2]) & (h < bx[3]) & (w >= bx[4]) & (w < bx[5]);
+}
+
+struct BoxArg { int v[6]; };  // d0,d1,h0,h1,w0,w1 (half-open)
+
+// One block handles a contiguous range of voxels of ONE sample n = blockIdx.y.
+template <int C, bool ACDC>
+__global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ img_l,
+                                                     const uint8_t* __restrict__ patch_l,
+                                                     const uint8_t* __restrict__ mask /* nullable: 1 = image term */,
+                                                     BoxArg box, int D, int H, int W, double* __restrict__ acc, int N) {
+  const int n = blockIdx.y;
+  const long long V = (long long)D * H * W;
+  const float* lg = logits + (long long)n * V * C;
+  const uint8_t* la = img_l + (long long)n * V;
+  const uint8_t* lb = patch_l + (long long)n * V;
+  const uint8_t* mk = mask ? mask + (long long)n * V : nullptr;
+  double s[2][C][3];
+  double ce[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < C; ++c) s[t][c][0] = s[t][c][1] = s[t][c][2] = 0.0;
+
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+    float x[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) x[c] = lg[v * C + c];
+    int t;
+    if (mk) {
+      t = mk[v] ? 0 : 1;
+    } else {
+      const int w = (int)(v % W);
+      const int h = (int)((v / W) % H);
+      const int d = (int)(v / ((long long)W * H));
+      t = in_box(d, h, w, box.v) ? 1 : 0;
+    }
+    const int y = t ? lb[v] : la[v];
+    Softmax<C> sm;
+    sm.compute(x);
+    // branch-free accumulation into the term the voxel belongs to
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const float m = (tt == t) ? 1.f : 0.f;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float oh = (y == c) ? 1.f : 0.f;
+        s[tt][c][0] += (double)(sm.p[c] * oh * m);
+        if (ACDC) {
+          s[tt][c][1] += (double)(sm.p[c] * sm.p[c] * m);
+          s[tt][c][2] += (double)(oh * m);
+        } else {
+          s[tt][c][1] += (double)((sm.p[c] + oh) * m);
+        }
+      }
+      float xy = x[0];
+#pragma unroll
+      for (int c = 1; c < C; ++c) xy = (y == c) ? x[c] : xy;
+      ce[tt] += (double)((sm.lse - xy) * m);
+      cnt[tt] += (double)m;
+    }
+  }
+  // block reduction: wave shuffles then LDS, then one fp64 atomic per quantity
+  __shared__ double red[4][2 * C * 3 + 4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const double r = wave_sum(s[t][c][k]);
+        if (lane == 0) red[wid][(t * C + c) * 3 + k] = r;
+      }
+    const double r1 = wave_sum(ce[t]), r2 = wave_sum(cnt[t]);
+    if (lane == 0) { red[wid][2 * C * 3 + t * 2] = r1; red[wid][2 * C * 3 + t * 2 + 1] = r2; }
+  }
+  __syncthreads();
+  const int nq = 2 * C * 3 + 4;
+  if ((int)threadIdx.x < nq) {
+    const double r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if ((int)threadIdx.x < 2 * C * 3)
+      atomicAdd(&acc[(long long)n * 2 * C * 3 + threadIdx.x], r);
+    else
+      atomicAdd(&acc[(long long)N * 2 * C * 3 + (threadIdx.x - 2 * C * 3)], r);
+  }
+}
+
+// out[0] = LA: loss ; ACDC: dice.   out[1] = ACDC: ce (LA: ce part, informational). out[2] = LA dice part.
+template <int C, bool ACDC>
+__global__ void k_mixloss_finalize(const double* __restrict__ acc, float* __restrict__ coef, float* __restrict__ out, int N,
+                                   float w_img, float w_patch) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const double wt[2] = {(double)w_img, (double)w_patch};
+  const double* tail = acc + (long long)N * 2 * C * 3;
+  double dice_total = 0.0, ce_total = 0.0;
+  for (int t = 0; t < 2; ++t) {
+    const double cecoef = wt[t] / (tail[t * 2 + 1] + 1e-16);
+    ce_total += cecoef * tail[t * 2];
+    coef[(long long)N * 2 * C * 2 + t] = (float)cecoef;
+  }
+  if (!ACDC) {
+    const double smooth = 1e-5;
+    for (int t = 0; t < 2; ++t) {
+      double dsum = 0.0;
+      for (int n = 0; n < N; ++n)
+        for (int c = 0; c < C; ++c) {
+          const double* q = acc + (((long long)n * 2 + t) * C + c) * 3;
+          const double I = q[0], U = q[1];
+          dsum += (2.0 * I + smooth) / (U + smooth);
+          // d/dP_c of -(w/(N*C)) * (2I+s)/(U+s)  at a voxel with label y:
+          //   -(w/(N*C)) * [ 2*1[y==c]/(U+s) - (2I+s)/(U+s)^2 ]
+          const double k = -wt[t] / ((double)N * C);
+          float* cf = coef + (((long long)n * 2 + t) * C + c) * 2;
+          cf[0] = (float)(k * 2.0 / (U + smooth));
+          cf[1] = (float)(k * (2.0 * I + smooth) / ((U + smooth) * (U + smooth)));
+        }
+      dice_total += wt[t] * (1.0 - dsum / ((double)N * C));
+    }
+    out[0] = (float)((dice_total + ce_total) / 2.0);
+    out[1] = (float)ce_total;
+    out[2] = (float)dice_total;
+  } else {
+    const double smooth = 1e-10;
+    for (int t = 0; t < 2; ++t) {
+      double lsum = 0.0;
+      for (int c = 0; c < C; ++c) {
+        double I = 0.0, Z = 0.0, Y = 0.0;
+        for (int n = 0; n < N; ++n) {
+          const double* q = acc + (((long long)n * 2 + t) * C + c) * 3;
+          I += q[0]; Z += q[1]; Y += q[2];
+        }
+        const double den = Z + Y + smooth;
+        lsum += 1.0 - (2.0 * I + smooth) / den;
+        // d/dP_c of (w/C) * [1 - (2I+s)/den]:  -(w/C) * [ 2*1[y==c]/den - (2I+s)*2*P_c/den^2 ]
+        const double k = -wt[t] / (double)C;
+        for (int n = 0; n < N; ++n) {
+          float* cf = coef + (((long long)n * 2 + t) * C + c) * 2;
+          cf[0] = (float)(k * 2.0 / den);
+          cf[1] = (float)(k * (2.0 * I + smooth) * 2.0 / (den * den));
+        }
+      }
+      dice_total += wt[t] * lsum / (double)C;
+    }
+    out[0] = (float)dice_total;
+    out[1] = (float)ce_total;
+    out[2] = (float)((dice_total + ce_total) / 2.0);
+  }
+}
+
+template <int C, bool ACDC>
+__global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ logits, const uint8_t* __restrict__ img_l,
+                                                     const uint8_t* __restrict__ patch_l, const uint8_t* __restrict__ mask,
+                                                     BoxArg box, int D, int H, int W, const float* __restrict__ coef,
+                                                     float* __restrict__ dlogits, int N, float g_dice, float g_ce) {
+  const int n = blockIdx.y;
+  const long long V = (long long)D * H * W;
+  const float* lg = logits + (long long)n * V * C;
+  float* dl = dlogits + (long long)n * V * C;
+  const uint8_t* la = img_l + (long long)n * V;
+  const uint8_t* lb = patch_l + (long long)n * V;
+  const uint8_t* mk = mask ? mask + (long long)n * V : nullptr;
+  __shared__ float cf[2][C][2];
+  __shared__ float cce[2];
+  if ((int)threadIdx.x < 2 * C * 2) (&cf[0][0][0])[threadIdx.x] = coef[(long long)n * 2 * C * 2 + threadIdx.x];
+  if ((int)threadIdx.x < 2) cce[threadIdx.x] = coef[(long long)N * 2 * C * 2 + threadIdx.x];
+  __syncthreads();
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+    float x[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) x[c] = lg[v * C + c];
+    int t;
+    if (mk) {
+      t = mk[v] ? 0 : 1;
+    } else {
+      const int w = (int)(v % W);
+      const int h = (int)((v / W) % H);
+      const int d = (int)(v / ((long long)W * H));
+      t = in_box(d, h, w, box.v) ? 1 : 0;
+    }
+    const int y = t ? lb[v] : la[v];
+    Softmax<C> sm;
+    sm.compute(x);
+    float gp[C];
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float oh = (y == c) ? 1.f : 0.f;
+      gp[c] = ACDC ? (cf[t][c][0] * oh - cf[t][c][1] * sm.p[c]) : (cf[t][c][0] * oh - cf[t][c][1]);
+      dot += gp[c] * sm.p[c];
+    }
+    const float kce = g_ce * cce[t];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float oh = (y == c) ? 1.f : 0.f;
+      dl[v * C + c] = g_dice * (sm.p[c] * (gp[c] - dot)) + kce * (sm.p[c] - oh);
+    }
+  }
+}
+
+static inline int loss_grid(long long V) {
+  long long g = (V + 255) / 256;
+  if (g > 1024) g = 1024;
+  return (int)(g < 1 ? 1 : g);
+}
+
+template <int C, bool ACDC>
+static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
+                      int N, int D, int H, int W, float w_img, float w_patch, double* acc,
+                      float* coef, float* out, hipStream_t s) {
+  BoxArg bx;
+  bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
+  bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
+  bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
+  const size_t acc_bytes = ((size_t)N * 2 * C * 3 + 4) * sizeof(double);
+  hipMemsetAsync(acc, 0, acc_bytes, s);
+  const long long V = (long long)D * H * W;
+  hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(loss_grid(V), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
+                     W, acc, N);
+  hipLaunchKernelGGL((k_mixloss_finalize<C, ACDC>), dim3(1), dim3(64), 0, s, acc, coef, out, N, w_img, w_patch);
+  return 0;
+}
+
+template <int C, bool ACDC>
+static int launch_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
+                      int N, int D, int H, int W, const float* coef, float* dlogits, float g_dice, float g_ce, hipStream_t s) {
+  BoxArg bx;
+  bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
+  bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
+  bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
+  const long long V = (long long)D * H * W;
+  hipLaunchKernelGGL((k_mixloss_bwd<C, ACDC>), dim3(loss_grid(V), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
+                     W, coef, dlogits, N, g_dice, g_ce);
+  return 0;
+}
+
+}  // namespace bcp
+
+using namespace bcp;
+
+extern "C" size_t bcp_mixloss_workspace_bytes(int N, int C) {
+  // [acc doubles | coef floats], both 16-B aligned
+  const size_t acc = ((size_t)N * 2 * C * 3 + 4) * sizeof(double);
+  const size_t coef = ((size_t)N * 2 * C * 2 + 2) * sizeof(float);
+  return ((acc + 15) / 16) * 16 + ((coef + 15) / 16) * 16;
+}
+
+static inline float* coef_ptr(void* ws, int N, int C) {
+  const size_t acc = ((size_t)N * 2 * C * 3 + 4) * sizeof(double);
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((acc + 15) / 16) * 16);
+}
+
+extern "C" int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null,
+                               const int* box6, int N, int D, int H, int W, int C, int flavour, float w_img, float w_patch,
+                               void* workspace, float* out3, void* stream) {
+  BCP_REQUIRE(logits && img_l && patch_l && box6 && workspace && out3, "bcp_mixloss_fwd: null pointer");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "bcp_mixloss_fwd: bad extents");
+  BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4),
+              "bcp_mixloss_fwd: flavour/C combination unsupported (LA: C=2, ACDC: C=4), got flavour=%d C=%d", flavour, C);
+  double* acc = reinterpret_cast<double*>(workspace);
+  float* coef = coef_ptr(workspace, N, C);
+  if (flavour == BCP_LOSS_LA)
+    launch_fwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out3,
+                         (hipStream_t)stream);
+  else
+    launch_fwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out3,
+                        (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_mixloss_fwd");
+  return BCP_OK;
+}
+
+extern "C" int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null,
+                               const int* box6, int N, int D, int H, int W, int C, int flavour, const void* workspace,
+                               float g_dice, float g_ce, float* dlogits, void* stream) {
+  BCP_REQUIRE(logits && img_l && patch_l && box6 && workspace && dlogits, "bcp_mixloss_bwd: null pointer");
+  BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4), "bcp_mixloss_bwd: flavour/C");
+  const float* coef = coef_ptr(const_cast<void*>(workspace), N, C);
+  if (flavour == BCP_LOSS_LA)
+    launch_bwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, (hipStream_t)stream);
+  else
+    launch_bwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_mixloss_bwd");
+  return BCP_OK;
+}

@@ -1,0 +1,315 @@
+// bcp_amd/csrc/norm.hip -- BatchNorm (train) / InstanceNorm + activation (+dropout, +residual) forward
+// and backward for channels-last activations [rows][C] on gfx950.
+//
+// Reference: nn.BatchNorm3d/2d in train() mode (networks/VNet.py:18-26, networks/unet.py:21-28),
+// nn.InstanceNorm3d(affine=False) (pancreas/Vnet.py:93), nn.ReLU / nn.LeakyReLU(0.01),
+// nn.Dropout3d(p=0.5) (VNet.py:165,211) / nn.Dropout(p) (unet.py:23), skip add after the ReLU
+// (VNet.py:220-233).
+//
+// All four kernels are pure HBM streams over [rows][C] with C the fastest dim: a thread owns one
+// float4 channel group and walks rows, so a wave reads 1 KiB contiguous per instruction.
+// Statistics accumulate in fp64 per thread -> LDS -> per-block partials -> 1-block finalize (no
+// atomics, bitwise reproducible).
+//   groups G = 1            : BatchNorm over all rows (N*spatial)
+//   groups G = N            : InstanceNorm, rows_per_group = spatial
+#include "common.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+struct NormEpilogue {
+  const float* chan_scale;     // nullable [N][C]: Dropout3d keep*1/(1-p) per (sample, channel)
+  const uint8_t* elem_mask;    // nullable [rows][C]: elementwise Dropout keep mask
+  float elem_scale;            // 1/(1-p) for elem_mask
+  long long rows_per_sample;   // spatial size (rows per n) for chan_scale indexing
+  int act;
+};
+
+// ------------------------------------------------------------------ column reductions
+// MODE 0: (sum x, sum x^2) of y.   MODE 1: (sum dz, sum dz*xhat) for the backward pass.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y, const float* __restrict__ da,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     NormEpilogue ep, long long rows_per_group, int C,
+                                                     double* __restrict__ partial /* [G][nb][C][2] */) {
+  const int C4 = C >> 2;
+  const int col = threadIdx.x % C4;        // float4 column
+  const int slot = threadIdx.x / C4;       // row slot within a pass
+  const int slots = 256 / C4;
+  const int g = blockIdx.y, nb = gridDim.x;
+  const long long chunk = (rows_per_group + nb - 1) / nb;
+  const long long r0 = (long long)blockIdx.x * chunk;
+  long long r1 = r0 + chunk;
+  if (r1 > rows_per_group) r1 = rows_per_group;
+  const long long gbase = (long long)g * rows_per_group;
+
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0), mu = sh, rs = sc;
+  if (MODE == 1) {
+    sc = ld4(scale + (long long)g * C + col * 4);
+    sh = ld4(shift + (long long)g * C + col * 4);
+    mu = ld4(mean + (long long)g * C + col * 4);
+    rs = ld4(rstd + (long long)g * C + col * 4);
+  }
+  if (slot < slots) {
+    for (long long r = r0 + slot; r < r1; r += slots) {
+      const long long row = gbase + r;
+      const float4 v = ld4(y + row * C + col * 4);
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s1[k] += (double)vv[k]; s2[k] += (double)vv[k] * (double)vv[k]; }
+      } else {
+        const float4 d4 = ld4(da + row * C + col * 4);
+        float dz[4] = {d4.x, d4.y, d4.z, d4.w};
+        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+        float cs[4] = {1.f, 1.f, 1.f, 1.f};
+        if (ep.chan_scale) {
+          const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + col * 4);
+          cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+        }
+        if (ep.elem_mask) {
+          const uchar4 m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + row * C + col * 4);
+          cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
+          cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float z = vv[k] * scv[k] + shv[k];
+          const float g1 = dz[k] * cs[k] * act_grad(z, ep.act);
+          const float xh = (vv[k] - muv[k]) * rsv[k];
+          s1[k] += (double)g1;
+          s2[k] += (double)g1 * (double)xh;
+        }
+      }
+    }
+  }
+  __shared__ double red[256][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = s1[k]; red[threadIdx.x][4 + k] = s2[k]; }
+  __syncthreads();
+  if ((int)threadIdx.x < C4) {
+    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+    for (int s = 0; s < slots; ++s) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { a1[k] += red[s * C4 + col][k]; a2[k] += red[s * C4 + col][4 + k]; }
+    }
+    double* out = partial + (((long long)g * nb + blockIdx.x) * C + col * 4) * 2;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { out[k * 2] = a1[k]; out[k * 2 + 1] = a2[k]; }
+  }
+}
+
+// forward finalize: one thread per (g, c)
+__global__ void k_norm_finalize(const double* __restrict__ partial, int nb, int G, int C, long long rows_per_group,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
+                                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
+                                float* __restrict__ shift) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * C) return;
+  const int g = idx / C, c = idx % C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    const double* p = partial + (((long long)g * nb + b) * C + c) * 2;
+    s1 += p[0];
+    s2 += p[1];
+  }
+  const double n = (double)rows_per_group;
+  const double m = s1 / n;
+  double var = s2 / n - m * m;
+  if (var < 0.0) var = 0.0;
+  const double r = 1.0 / sqrt(var + (double)eps);
+  mean[idx] = (float)m;
+  rstd[idx] = (float)r;
+  const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
+  scale[idx] = (float)(ga * r);
+  shift[idx] = (float)(be - m * ga * r);
+  if (running_mean && g == 0) {
+    // torch: running = (1-momentum)*running + momentum*stat, with the UNBIASED variance
+    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
+    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+  }
+}
+
+// backward finalize: dgamma/dbeta (+= or =) and the two per-(g,c) means used by the apply pass
+__global__ void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, int G, int C, long long rows_per_group,
+                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                    float* __restrict__ c1, float* __restrict__ c2) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * C) return;
+  const int g = idx / C, c = idx % C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < nb; ++b) {
+    const double* p = partial + (((long long)g * nb + b) * C + c) * 2;
+    s1 += p[0];
+    s2 += p[1];
+  }
+  c1[idx] = (float)(s1 / (double)rows_per_group);
+  c2[idx] = (float)(s2 / (double)rows_per_group);
+  if (dgamma && g == 0) {
+    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
+    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
+  }
+}
+
+// ------------------------------------------------------------------ apply passes
+// a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]
+__global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y, const float* __restrict__ scale,
+                                                    const float* __restrict__ shift, const float* __restrict__ residual,
+                                                    NormEpilogue ep, long long rows, long long rows_per_group, int C,
+                                                    float* __restrict__ out) {
+  const int C4 = C >> 2;
+  const long long nvec = rows * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const long long row = i / C4;
+    const int col = (int)(i - row * C4);
+    const long long g = row / rows_per_group;
+    const float4 v = ld4(y + i * 4);
+    const float4 sc = ld4(scale + g * C + col * 4), sh = ld4(shift + g * C + col * 4);
+    float o[4] = {act_fwd(v.x * sc.x + sh.x, ep.act), act_fwd(v.y * sc.y + sh.y, ep.act),
+                  act_fwd(v.z * sc.z + sh.z, ep.act), act_fwd(v.w * sc.w + sh.w, ep.act)};
+    if (ep.chan_scale) {
+      const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + col * 4);
+      o[0] *= c4.x; o[1] *= c4.y; o[2] *= c4.z; o[3] *= c4.w;
+    }
+    if (ep.elem_mask) {
+      const uchar4 m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+      o[0] *= m4.x ? ep.elem_scale : 0.f; o[1] *= m4.y ? ep.elem_scale : 0.f;
+      o[2] *= m4.z ? ep.elem_scale : 0.f; o[3] *= m4.w ? ep.elem_scale : 0.f;
+    }
+    if (residual) {
+      const float4 r4 = ld4(residual + i * 4);
+      o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
+    }
+    st4(out + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+// dy = scale * (dz - c1 - xhat*c2),  dz = da * epilogue' * act'(z)
+__global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict__ y, const float* __restrict__ da,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                        const float* __restrict__ c1, const float* __restrict__ c2,
+                                                        NormEpilogue ep, long long rows, long long rows_per_group, int C,
+                                                        float* __restrict__ dy) {
+  const int C4 = C >> 2;
+  const long long nvec = rows * C4;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
+    const long long row = i / C4;
+    const int col = (int)(i - row * C4);
+    const long long g = row / rows_per_group;
+    const long long gc = g * C + col * 4;
+    const float4 v = ld4(y + i * 4), d4 = ld4(da + i * 4);
+    const float4 sc = ld4(scale + gc), sh = ld4(shift + gc), mu = ld4(mean + gc), rs = ld4(rstd + gc);
+    const float4 k1 = ld4(c1 + gc), k2 = ld4(c2 + gc);
+    float cs[4] = {1.f, 1.f, 1.f, 1.f};
+    if (ep.chan_scale) {
+      const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + col * 4);
+      cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+    }
+    if (ep.elem_mask) {
+      const uchar4 m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+      cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
+      cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
+    }
+    const float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+    const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z = vv[k] * scv[k] + shv[k];
+      const float dz = dd[k] * cs[k] * act_grad(z, ep.act);
+      const float xh = (vv[k] - muv[k]) * rsv[k];
+      o[k] = scv[k] * (dz - k1v[k] - xh * k2v[k]);
+    }
+    st4(dy + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+static inline int norm_blocks(long long rows_per_group, int C) {
+  // enough blocks to fill the chip, but at least ~64 rows per thread-slot to amortise the LDS reduce
+  const int slots = 256 / (C / 4);
+  long long nb = rows_per_group / ((long long)slots * 16);
+  if (nb > 1024) nb = 1024;
+  if (nb < 1) nb = 1;
+  return (int)nb;
+}
+
+static inline int apply_grid(long long nvec) {
+  long long g = (nvec + 255) / 256;
+  if (g > 2048) g = 2048;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace bcp
+
+using namespace bcp;
+
+extern "C" size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C) {
+  if (G < 1 || C < 16 || rows_per_group < 1) return 0;
+  // per-block fp64 partials, then the two per-(g,c) backward means (c1, c2)
+  return (size_t)G * norm_blocks(rows_per_group, C) * C * 2 * sizeof(double) + (size_t)2 * G * C * sizeof(float);
+}
+
+static int check_norm_args(const char* fn, int G, long long rows_per_group, int C) {
+  BCP_REQUIRE(G >= 1 && rows_per_group >= 1, "%s: bad extents", fn);
+  BCP_REQUIRE(C >= 16 && C <= 1024 && (C % 4) == 0 && 256 % (C / 4) == 0, "%s: C=%d unsupported (need C in {16,32,64,...,1024})", fn, C);
+  return BCP_OK;
+}
+
+extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, int act,
+                            const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale,
+                            const float* residual, float* stats /* [4][G][C]: mean, rstd, scale, shift */, void* workspace,
+                            float* out, void* stream) {
+  if (int rc = check_norm_args("bcp_norm_fwd", G, rows_per_group, C)) return rc;
+  BCP_REQUIRE(y && stats && workspace && out, "bcp_norm_fwd: null pointer");
+  BCP_REQUIRE(aligned16(y) && aligned16(out) && aligned16(stats), "bcp_norm_fwd: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = norm_blocks(rows_per_group, C);
+  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  double* partial = reinterpret_cast<double*>(workspace);
+  float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
+  hipLaunchKernelGGL((k_col_partial<0>), dim3(nb, G), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, rows_per_group, C, partial);
+  hipLaunchKernelGGL(k_norm_finalize, dim3(cdiv(G * C, 256)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+  const long long rows = (long long)G * rows_per_group;
+  hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, scale, shift, residual, ep, rows,
+                     rows_per_group, C, out);
+  BCP_CHECK_LAUNCH("bcp_norm_fwd");
+  return BCP_OK;
+}
+
+extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats,
+                            int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
+                            float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy,
+                            void* stream) {
+  if (int rc = check_norm_args("bcp_norm_bwd", G, rows_per_group, C)) return rc;
+  BCP_REQUIRE(y && da && stats && workspace && dy, "bcp_norm_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int nb = norm_blocks(rows_per_group, C);
+  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  double* partial = reinterpret_cast<double*>(workspace);
+  const float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
+  // c1/c2 live behind the partials in the workspace
+  float* c1 = reinterpret_cast<float*>(partial + (size_t)G * nb * C * 2);
+  float* c2 = c1 + (long long)G * C;
+  hipLaunchKernelGGL((k_col_partial<1>), dim3(nb, G), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, rows_per_group, C,
+                     partial);
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(cdiv(G * C, 256)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
+                     dbeta, accumulate, c1, c2);
+  const long long rows = (long long)G * rows_per_group;
+  hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, da, scale, shift, mean, rstd, c1,
+                     c2, ep, rows, rows_per_group, C, dy);
+  BCP_CHECK_LAUNCH("bcp_norm_bwd");
+  return BCP_OK;
+}

@@ -1,0 +1,180 @@
+// bcp_amd/csrc/pool2d.hip -- 2-D U-Net plumbing, channels-last [N][H][W][C] fp32:
+//   nn.MaxPool2d(2)                                             networks/unet.py:36
+//   nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True)   networks/unet.py:50
+//   torch.cat([skip, up], dim=1)                                networks/unet.py:56
+// The upsample writes straight into its half of the concat buffer (row stride ld, channel offset),
+// so the concat never costs an extra pass; its backward is a deterministic gather (no atomics).
+#include "common.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+__global__ __launch_bounds__(256) void k_maxpool2d_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W,
+                                                       int C) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int wo = (int)((i / C4) % Wo), ho = (int)((i / ((long long)C4 * Wo)) % Ho), n = (int)(i / ((long long)C4 * Wo * Ho));
+    const float* p = x + ((((long long)n * H + 2 * ho) * W + 2 * wo) * C) + c4 * 4;
+    const float4 a = ld4(p), b = ld4(p + C), c = ld4(p + (long long)W * C), d = ld4(p + (long long)W * C + C);
+    float4 o;
+    o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
+    o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
+    o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(c.z, d.z));
+    o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(c.w, d.w));
+    st4(y + i * 4, o);
+  }
+}
+
+// gradient goes to the FIRST maximal element of each 2x2 window (row-major), as torch's max_pool2d does
+__global__ __launch_bounds__(256) void k_maxpool2d_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, int N, int H, int W, int C, int accumulate) {
+  const int Ho = H >> 1, Wo = W >> 1;
+  const long long total = (long long)N * Ho * Wo * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int wo = (int)((i / C) % Wo), ho = (int)((i / ((long long)C * Wo)) % Ho), n = (int)(i / ((long long)C * Wo * Ho));
+    const long long base = (((long long)n * H + 2 * ho) * W + 2 * wo) * C + c;
+    const long long off[4] = {0, C, (long long)W * C, (long long)W * C + C};
+    int best = 0;
+    float bv = x[base];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) {
+      const float v = x[base + off[k]];
+      if (v > bv) { bv = v; best = k; }
+    }
+    const float g = dy[i];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float v = (k == best) ? g : 0.f;
+      dx[base + off[k]] = accumulate ? dx[base + off[k]] + v : v;
+    }
+  }
+}
+
+struct Lerp { int i0, i1; float l0, l1; };
+__device__ __forceinline__ Lerp lerp_ac(int o, int in, int out) {  // align_corners=True source coordinate (torch upsample math, fp32)
+  const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  const float src = scale * (float)o;
+  Lerp r;
+  r.i0 = (int)src;
+  r.i1 = r.i0 + ((r.i0 < in - 1) ? 1 : 0);
+  r.l1 = src - (float)r.i0;
+  r.l0 = 1.f - r.l1;
+  return r;
+}
+
+__global__ __launch_bounds__(256) void k_bilinear2x_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W,
+                                                        int C, int ldy, int y_off) {
+  const int Ho = 2 * H, Wo = 2 * W, C4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const int wo = (int)((i / C4) % Wo), ho = (int)((i / ((long long)C4 * Wo)) % Ho), n = (int)(i / ((long long)C4 * Wo * Ho));
+    const Lerp lh = lerp_ac(ho, H, Ho), lw = lerp_ac(wo, W, Wo);
+    const float* p = x + (long long)n * H * W * C + c4 * 4;
+    const float4 a = ld4(p + ((long long)lh.i0 * W + lw.i0) * C), b = ld4(p + ((long long)lh.i0 * W + lw.i1) * C);
+    const float4 c = ld4(p + ((long long)lh.i1 * W + lw.i0) * C), d = ld4(p + ((long long)lh.i1 * W + lw.i1) * C);
+    float4 o;
+    o.x = lh.l0 * (lw.l0 * a.x + lw.l1 * b.x) + lh.l1 * (lw.l0 * c.x + lw.l1 * d.x);
+    o.y = lh.l0 * (lw.l0 * a.y + lw.l1 * b.y) + lh.l1 * (lw.l0 * c.y + lw.l1 * d.y);
+    o.z = lh.l0 * (lw.l0 * a.z + lw.l1 * b.z) + lh.l1 * (lw.l0 * c.z + lw.l1 * d.z);
+    o.w = lh.l0 * (lw.l0 * a.w + lw.l1 * b.w) + lh.l1 * (lw.l0 * c.w + lw.l1 * d.w);
+    st4(y + (((long long)n * Ho + ho) * Wo + wo) * ldy + y_off + c4 * 4, o);
+  }
+}
+
+// dx[h][w] = sum over output pixels whose stencil touches (h, w) of weight * dy  (gather; deterministic)
+__global__ __launch_bounds__(256) void k_bilinear2x_bwd(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
+                                                        int C, int lddy, int dy_off) {
+  const int Ho = 2 * H, Wo = 2 * W;
+  const long long total = (long long)N * H * W * C;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const int w = (int)((i / C) % W), h = (int)((i / ((long long)C * W)) % H), n = (int)(i / ((long long)C * W * H));
+    // output rows whose source coordinate lies in (h-1, h+1): o in [2h-3, 2h+3] is a safe superset for scale (H-1)/(2H-1) in (0, 0.5]
+    float s = 0.f;
+    for (int ho = max(0, 2 * h - 3); ho <= min(Ho - 1, 2 * h + 4); ++ho) {
+      const Lerp lh = lerp_ac(ho, H, Ho);
+      float wh = 0.f;
+      if (lh.i0 == h) wh += lh.l0;
+      if (lh.i1 == h) wh += lh.l1;
+      if (wh == 0.f) continue;
+      for (int wo = max(0, 2 * w - 3); wo <= min(Wo - 1, 2 * w + 4); ++wo) {
+        const Lerp lw = lerp_ac(wo, W, Wo);
+        float ww = 0.f;
+        if (lw.i0 == w) ww += lw.l0;
+        if (lw.i1 == w) ww += lw.l1;
+        if (ww == 0.f) continue;
+        s += wh * ww * dy[(((long long)n * Ho + ho) * Wo + wo) * lddy + dy_off + c];
+      }
+    }
+    dx[i] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_copy_channels(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C,
+                                                       int ld_src, int src_off, int ld_dst, int dst_off, int accumulate) {
+  const int C4 = C >> 2;
+  const long long total = rows * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long r = i / C4;
+    const int c4 = (int)(i - r * C4);
+    float4 v = ld4(src + r * ld_src + src_off + c4 * 4);
+    float* d = dst + r * ld_dst + dst_off + c4 * 4;
+    if (accumulate) {
+      const float4 o = ld4(d);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    st4(d, v);
+  }
+}
+
+static inline int sgrid(long long n) {
+  long long g = (n + 255) / 256;
+  if (g > 2048) g = 2048;
+  return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace bcp
+
+using namespace bcp;
+
+extern "C" int bcp_maxpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
+  BCP_REQUIRE(x && y && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "bcp_maxpool2d_fwd: bad argument");
+  hipLaunchKernelGGL(k_maxpool2d_fwd, dim3(sgrid((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
+                     N, H, W, C);
+  BCP_CHECK_LAUNCH("bcp_maxpool2d_fwd");
+  return BCP_OK;
+}
+extern "C" int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate, void* stream) {
+  BCP_REQUIRE(x && dy && dx && N > 0 && H % 2 == 0 && W % 2 == 0, "bcp_maxpool2d_bwd: bad argument");
+  hipLaunchKernelGGL(k_maxpool2d_bwd, dim3(sgrid((long long)N * (H / 2) * (W / 2) * C)), dim3(256), 0, (hipStream_t)stream, x, dy, dx,
+                     N, H, W, C, accumulate);
+  BCP_CHECK_LAUNCH("bcp_maxpool2d_bwd");
+  return BCP_OK;
+}
+extern "C" int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int y_off, void* stream) {
+  BCP_REQUIRE(x && y && N > 0 && C % 4 == 0 && ldy % 4 == 0 && y_off % 4 == 0, "bcp_bilinear2x_fwd: bad argument");
+  hipLaunchKernelGGL(k_bilinear2x_fwd, dim3(sgrid((long long)N * 4 * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W,
+                     C, ldy, y_off);
+  BCP_CHECK_LAUNCH("bcp_bilinear2x_fwd");
+  return BCP_OK;
+}
+extern "C" int bcp_bilinear2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, int lddy, int dy_off, void* stream) {
+  BCP_REQUIRE(dy && dx && N > 0, "bcp_bilinear2x_bwd: bad argument");
+  hipLaunchKernelGGL(k_bilinear2x_bwd, dim3(sgrid((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C, lddy,
+                     dy_off);
+  BCP_CHECK_LAUNCH("bcp_bilinear2x_bwd");
+  return BCP_OK;
+}
+extern "C" int bcp_copy_channels(const float* src, float* dst, long long rows, int C, int ld_src, int src_off, int ld_dst, int dst_off,
+                                 int accumulate, void* stream) {
+  BCP_REQUIRE(src && dst && rows > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && src_off % 4 == 0 && dst_off % 4 == 0,
+              "bcp_copy_channels: bad argument");
+  hipLaunchKernelGGL(k_copy_channels, dim3(sgrid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, dst, rows, C, ld_src, src_off,
+                     ld_dst, dst_off, accumulate);
+  BCP_CHECK_LAUNCH("bcp_copy_channels");
+  return BCP_OK;
+}

@@ -1,0 +1,401 @@
+"""Tensor-level wrappers over the C ABI (include/bcp_hip.h).  PyTorch tensors are containers only:
+every op here is one call into libbcp_hip.so on the tensor's data_ptr() and the current stream.
+
+Physical layout convention ("cl" tensors): activations are contiguous [N, D, H, W, C] (2-D: D == 1),
+labels / masks contiguous uint8 [N, D, H, W].  The logical NCDHW view the reference's scripts see is
+`cl.permute(0, 4, 1, 2, 3)` (torch channels_last_3d strides) -- a view, never a copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+LOSS_LA, LOSS_ACDC = 0, 1
+PACK_DOWN_FWD, PACK_DOWN_DGRAD, PACK_UP_FWD, PACK_UP_DGRAD, PACK_PW_FWD, PACK_PW_DGRAD = range(6)
+WG_DOWN, WG_UP, WG_PW = range(3)
+CAST_I64_U8, CAST_F32_U8, CAST_U8_F32, CAST_U8_I64 = range(4)
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class Ops:
+    """All kernels, bound to one library handle.  `Ops.product()` is the only constructor product
+    code uses; tests build `Ops(Binding(emu_path), allow_cpu=True)` to run the same wrappers on the
+    host simulator."""
+
+    _product = None
+
+    def __init__(self, binding: _lib.Binding, allow_cpu: bool = False):
+        self.b = binding
+        self.allow_cpu = allow_cpu
+        self._ws = {}
+        self._box_cache = {}
+
+    @classmethod
+    def product(cls) -> "Ops":
+        if cls._product is None:
+            cls._product = cls(_lib.product(), allow_cpu=False)
+        return cls._product
+
+    # ------------------------------------------------------------------ helpers
+    def _chk(self, *ts):
+        for t in ts:
+            if t is None:
+                continue
+            if not self.allow_cpu and not t.is_cuda:
+                raise _lib.BcpError("HIP op called with a CPU tensor: the product path has no CPU fallback")
+            if not t.is_contiguous():
+                raise _lib.BcpError("HIP op needs contiguous tensors (physical NDHWC)")
+
+    def stream(self, t):
+        if t.is_cuda:
+            return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+        return None
+
+    def workspace(self, key, nbytes, like):
+        """grow-only scratch buffer per (key, device)"""
+        k = (key, like.device)
+        w = self._ws.get(k)
+        if w is None or w.numel() < nbytes:
+            w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
+            self._ws[k] = w
+        return w
+
+    def box_arg(self, box6):
+        key = tuple(int(v) for v in box6)
+        a = self._box_cache.get(key)
+        if a is None:
+            a = (C.c_int * 6)(*key)
+            if len(self._box_cache) > 4096:
+                self._box_cache.clear()
+            self._box_cache[key] = a
+        return a
+
+    # ------------------------------------------------------------------ BCP ops
+    def mix_box(self, a, b, box6, out=None):
+        """out = a outside the box, b inside.  a, b: [N,D,H,W,C] float32."""
+        self._chk(a, b)
+        N, D, H, W, Cc = a.shape
+        if out is None:
+            out = torch.empty_like(a)
+        self.b.call("bcp_mix_box", _p(a), _p(b), _p(out), N, D, H, W, Cc, self.box_arg(box6), self.stream(a))
+        return out
+
+    def plabel_bin(self, logits, thres=0.5):
+        self._chk(logits)
+        N, D, H, W, Cc = logits.shape
+        assert Cc == 2
+        out = torch.empty((N, D, H, W), dtype=torch.uint8, device=logits.device)
+        self.b.call("bcp_plabel_bin", _p(logits), _p(out), N * D * H * W, float(thres), self.stream(logits))
+        return out
+
+    def plabel_argmax4(self, logits):
+        self._chk(logits)
+        N, D, H, W, Cc = logits.shape
+        assert Cc == 4
+        out = torch.empty((N, D, H, W), dtype=torch.uint8, device=logits.device)
+        self.b.call("bcp_plabel_argmax4", _p(logits), _p(out), N * D * H * W, self.stream(logits))
+        return out
+
+    def cc_largest(self, seg, nclass=1, connectivity=3, want_f32=False):
+        """seg uint8 [N,D,H,W] -> (uint8 same shape, optional float32 copy)"""
+        self._chk(seg)
+        N, D, H, W = seg.shape
+        nbytes = self.b.call("bcp_cc_workspace_bytes", N, D, H, W, nclass)
+        ws = self.workspace("cc", nbytes, seg)
+        out = torch.empty_like(seg)
+        outf = torch.empty(seg.shape, dtype=torch.float32, device=seg.device) if want_f32 else None
+        self.b.call("bcp_cc_largest", _p(seg), _p(out), _p(outf), N, D, H, W, nclass, connectivity, _p(ws), self.stream(seg))
+        return (out, outf) if want_f32 else out
+
+    def mixloss_fwd(self, logits, img_l, patch_l, box6, flavour, w_img, w_patch, mask=None):
+        """-> (out3 float32[3] on device, workspace tensor to hand to mixloss_bwd)"""
+        self._chk(logits, img_l, patch_l, mask)
+        N, D, H, W, Cc = logits.shape
+        nbytes = self.b.call("bcp_mixloss_workspace_bytes", N, Cc)
+        ws = torch.empty(int(nbytes), dtype=torch.uint8, device=logits.device)  # kept alive for backward
+        out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
+        self.b.call("bcp_mixloss_fwd", _p(logits), _p(img_l), _p(patch_l), _p(mask), self.box_arg(box6), N, D, H, W, Cc, flavour,
+                    float(w_img), float(w_patch), _p(ws), _p(out3), self.stream(logits))
+        return out3, ws
+
+    def mixloss_bwd(self, logits, img_l, patch_l, box6, flavour, ws, g_dice, g_ce, mask=None):
+        self._chk(logits, img_l, patch_l, mask)
+        N, D, H, W, Cc = logits.shape
+        dlogits = torch.empty_like(logits)
+        self.b.call("bcp_mixloss_bwd", _p(logits), _p(img_l), _p(patch_l), _p(mask), self.box_arg(box6), N, D, H, W, Cc, flavour,
+                    _p(ws), float(g_dice), float(g_ce), _p(dlogits), self.stream(logits))
+        return dlogits
+
+    # ------------------------------------------------------------------ norm
+    def norm_fwd(self, y, G, gamma, beta, rmean, rvar, act, out=None, chan_scale=None, elem_mask=None, elem_scale=1.0,
+                 residual=None, momentum=0.1, eps=1e-5):
+        """y [N,D,H,W,C] -> (a, stats[4,G,C]).  G = 1: BatchNorm; G = N: InstanceNorm."""
+        self._chk(y, gamma, beta, rmean, rvar, chan_scale, elem_mask, residual)
+        N = y.shape[0]
+        Cc = y.shape[-1]
+        rows = y.numel() // Cc
+        rpg = rows // G
+        rps = rows // N
+        nbytes = self.b.call("bcp_norm_workspace_bytes", G, rpg, Cc)
+        ws = self.workspace("norm", nbytes, y)
+        stats = torch.empty((4, G, Cc), dtype=torch.float32, device=y.device)
+        if out is None:
+            out = torch.empty_like(y)
+        self.b.call("bcp_norm_fwd", _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps), act,
+                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws), _p(out), self.stream(y))
+        return out, stats
+
+    def norm_bwd(self, y, da, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
+                 elem_scale=1.0, out=None):
+        self._chk(y, da, stats, dgamma, dbeta, chan_scale, elem_mask)
+        N = y.shape[0]
+        Cc = y.shape[-1]
+        rows = y.numel() // Cc
+        rpg = rows // G
+        rps = rows // N
+        nbytes = self.b.call("bcp_norm_workspace_bytes", G, rpg, Cc)
+        ws = self.workspace("norm", nbytes, y)
+        if out is None:
+            out = torch.empty_like(y)
+        self.b.call("bcp_norm_bwd", _p(y), _p(da), G, rpg, Cc, _p(stats), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale),
+                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(out), self.stream(y))
+        return out
+
+    # ------------------------------------------------------------------ 3x3(x3) conv
+    def conv3_pack(self, w, KD):
+        """torch weight [Cout,Cin,(3,)3,3] -> (wp_fwd, wp_dgrad) packed for the MFMA kernels"""
+        self._chk(w)
+        Cout, Cin = w.shape[0], w.shape[1]
+        n = self.b.call("bcp_conv3_packed_weight_floats", Cin, Cout, KD)
+        wf = torch.empty(int(n), dtype=torch.float32, device=w.device)
+        wd = torch.empty(int(n), dtype=torch.float32, device=w.device)
+        self.b.call("bcp_conv3_pack_weight", _p(w), _p(wf), _p(wd), Cin, Cout, KD, self.stream(w))
+        return wf, wd
+
+    def conv3_fwd(self, x, wp, bias, Cout, KD, out=None, accumulate=False):
+        self._chk(x, wp, bias)
+        N, D, H, W, Cin = x.shape
+        if out is None:
+            out = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), self.stream(x))
+        return out
+
+    def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):
+        """dw: torch-layout gradient tensor [Cout,Cin,(3,)3,3], written (or += when accumulate)"""
+        self._chk(x, dy, dw)
+        N, D, H, W, Cin = x.shape
+        Cout = dy.shape[-1]
+        nbytes = self.b.call("bcp_conv3_wgrad_workspace_bytes", N, D, H, W, Cin, Cout, KD)
+        ws = self.workspace("wgrad", nbytes, x)
+        self.b.call("bcp_conv3_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), self.stream(x))
+        return dw
+
+    def conv3_c1_fwd(self, x, w, bias, KD, out=None):
+        self._chk(x, w, bias)
+        N, D, H, W, Cin = x.shape
+        assert Cin == 1 and w.shape[0] == 16
+        if out is None:
+            out = torch.empty((N, D, H, W, 16), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_conv3_c1_fwd", _p(x), _p(w), _p(bias), _p(out), N, D, H, W, KD, self.stream(x))
+        return out
+
+    def conv3_c1_wgrad(self, x, dy, dw, KD, accumulate=False):
+        self._chk(x, dy, dw)
+        N, D, H, W, _ = x.shape
+        nbytes = self.b.call("bcp_conv3_wgrad_workspace_bytes", N, D, H, W, 1, 16, KD)
+        ws = self.workspace("wgrad", nbytes, x)
+        self.b.call("bcp_conv3_c1_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, KD, int(bool(accumulate)), _p(ws), self.stream(x))
+        return dw
+
+    # ------------------------------------------------------------------ k2s2 / 1x1 GEMM convs
+    def k2_pack(self, w, Cin, Cout, kind):
+        self._chk(w)
+        bp = torch.empty(w.numel(), dtype=torch.float32, device=w.device)
+        self.b.call("bcp_k2_pack_weight", _p(w), _p(bp), Cin, Cout, kind, self.stream(w))
+        return bp
+
+    def down_fwd(self, x, bp, bias, Cout, out=None):
+        self._chk(x, bp, bias)
+        N, D, H, W, Cin = x.shape
+        if out is None:
+            out = torch.empty((N, D // 2, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_down_fwd", _p(x), _p(bp), _p(bias), _p(out), N, D, H, W, Cin, Cout, self.stream(x))
+        return out
+
+    def down_dgrad(self, dy, bp, Cin, out=None, accumulate=False):
+        self._chk(dy, bp, out)
+        N, Dc, Hc, Wc, Cout = dy.shape
+        if out is None:
+            assert not accumulate
+            out = torch.empty((N, 2 * Dc, 2 * Hc, 2 * Wc, Cin), dtype=torch.float32, device=dy.device)
+        self.b.call("bcp_down_dgrad", _p(dy), _p(bp), _p(out), N, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, int(bool(accumulate)), self.stream(dy))
+        return out
+
+    def up_fwd(self, x, bp, bias, Cout, out=None):
+        self._chk(x, bp, bias)
+        N, Dc, Hc, Wc, Cin = x.shape
+        if out is None:
+            out = torch.empty((N, 2 * Dc, 2 * Hc, 2 * Wc, Cout), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_up_fwd", _p(x), _p(bp), _p(bias), _p(out), N, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, self.stream(x))
+        return out
+
+    def up_dgrad(self, dy, bp, Cin, out=None, accumulate=False):
+        self._chk(dy, bp, out)
+        N, D, H, W, Cout = dy.shape
+        if out is None:
+            out = torch.empty((N, D // 2, H // 2, W // 2, Cin), dtype=torch.float32, device=dy.device)
+        self.b.call("bcp_up_dgrad", _p(dy), _p(bp), _p(out), N, D, H, W, Cin, Cout, int(bool(accumulate)), self.stream(dy))
+        return out
+
+    def pw_fwd(self, x, bp, bias, Cout, out=None):
+        self._chk(x, bp, bias)
+        Cin = x.shape[-1]
+        rows = x.numel() // Cin
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-1]) + (Cout,), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_pw_fwd", _p(x), _p(bp), _p(bias), _p(out), rows, Cin, Cout, self.stream(x))
+        return out
+
+    def k2_wgrad(self, x, dy, dw, kind, accumulate=False):
+        """kind WG_DOWN: x fine, dy coarse; WG_UP: x coarse, dy fine; WG_PW: same grid."""
+        self._chk(x, dy, dw)
+        Cin, Cout = x.shape[-1], dy.shape[-1]
+        fine = x if kind != WG_UP else dy
+        N, D, H, W = fine.shape[:4]
+        if kind == WG_DOWN:
+            M, K, Nn = N * (D // 2) * (H // 2) * (W // 2), 8 * Cin, Cout
+        elif kind == WG_UP:
+            M, K, Nn = N * (D // 2) * (H // 2) * (W // 2), Cin, 8 * Cout
+        else:
+            M, K, Nn = N * D * H * W, Cin, Cout
+        nbytes = self.b.call("bcp_tn_workspace_bytes", M, K, Nn)
+        ws = self.workspace("wgrad", nbytes, x)
+        self.b.call("bcp_k2_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, Cin, Cout, kind, int(bool(accumulate)), _p(ws), self.stream(x))
+        return dw
+
+    def pw16_fwd(self, x, w, bias, Cout, out=None):
+        self._chk(x, w, bias)
+        assert x.shape[-1] == 16
+        nvox = x.numel() // 16
+        if out is None:
+            out = torch.empty(tuple(x.shape[:-1]) + (Cout,), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_pw16_fwd", _p(x), _p(w), _p(bias), _p(out), nvox, Cout, self.stream(x))
+        return out
+
+    def pw16_bwd(self, x, dy, w, dw, db, accumulate=False, dx=None):
+        self._chk(x, dy, w, dw, db)
+        Cout = dy.shape[-1]
+        nvox = x.numel() // 16
+        if dx is None:
+            dx = torch.empty_like(x)
+        ws = self.workspace("pw16", Cout * 17 * 8, x)
+        self.b.call("bcp_pw16_bwd", _p(x), _p(dy), _p(w), _p(dx), _p(dw), _p(db), nvox, Cout, int(bool(accumulate)), _p(ws), self.stream(x))
+        return dx
+
+    def colsum(self, x, out, accumulate=False):
+        self._chk(x, out)
+        Cc = x.shape[-1]
+        ws = self.workspace("colsum", Cc * 8, x)
+        self.b.call("bcp_colsum", _p(x), x.numel() // Cc, Cc, _p(out), int(bool(accumulate)), _p(ws), self.stream(x))
+        return out
+
+    # ------------------------------------------------------------------ 2-D U-Net plumbing
+    def maxpool2d_fwd(self, x):
+        self._chk(x)
+        N, D, H, W, Cc = x.shape
+        assert D == 1
+        y = torch.empty((N, 1, H // 2, W // 2, Cc), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_maxpool2d_fwd", _p(x), _p(y), N, H, W, Cc, self.stream(x))
+        return y
+
+    def maxpool2d_bwd(self, x, dy, dx, accumulate=False):
+        self._chk(x, dy, dx)
+        N, D, H, W, Cc = x.shape
+        self.b.call("bcp_maxpool2d_bwd", _p(x), _p(dy), _p(dx), N, H, W, Cc, int(bool(accumulate)), self.stream(x))
+        return dx
+
+    def bilinear2x_fwd(self, x, y, y_off):
+        """writes the 2x upsample of x [N,1,H,W,C] into channels [y_off, y_off+C) of y [N,1,2H,2W,ld]"""
+        self._chk(x, y)
+        N, D, H, W, Cc = x.shape
+        self.b.call("bcp_bilinear2x_fwd", _p(x), _p(y), N, H, W, Cc, y.shape[-1], y_off, self.stream(x))
+        return y
+
+    def bilinear2x_bwd(self, dy, dy_off, Cc):
+        self._chk(dy)
+        N, D, Ho, Wo, ld = dy.shape
+        dx = torch.empty((N, 1, Ho // 2, Wo // 2, Cc), dtype=torch.float32, device=dy.device)
+        self.b.call("bcp_bilinear2x_bwd", _p(dy), _p(dx), N, Ho // 2, Wo // 2, Cc, ld, dy_off, self.stream(dy))
+        return dx
+
+    def copy_channels(self, src, dst, Cc, src_off=0, dst_off=0, accumulate=False):
+        self._chk(src, dst)
+        rows = src.numel() // src.shape[-1]
+        self.b.call("bcp_copy_channels", _p(src), _p(dst), rows, Cc, src.shape[-1], src_off, dst.shape[-1], dst_off,
+                    int(bool(accumulate)), self.stream(src))
+        return dst
+
+    # ------------------------------------------------------------------ optimiser / EMA / misc
+    def ema(self, dst, src, alpha):
+        self._chk(dst, src)
+        self.b.call("bcp_ema", _p(dst), _p(src), dst.numel(), float(alpha), self.stream(dst))
+
+    def sgd(self, p, g, buf, lr, momentum, wd, first_step, grad_scale=1.0, ema=None, ema_alpha=0.99):
+        self._chk(p, g, buf, ema)
+        self.b.call("bcp_sgd", _p(p), _p(g), _p(buf), _p(ema), p.numel(), float(lr), float(momentum), float(wd), float(grad_scale),
+                    int(bool(first_step)), float(ema_alpha), self.stream(p))
+
+    def adam(self, p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-8, grad_scale=1.0):
+        self._chk(p, g, m, v)
+        self.b.call("bcp_adam", _p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(b1), float(b2), float(eps), int(step),
+                    float(grad_scale), self.stream(p))
+
+    def cast(self, x, kind):
+        self._chk(x)
+        dt = {CAST_I64_U8: torch.uint8, CAST_F32_U8: torch.uint8, CAST_U8_F32: torch.float32, CAST_U8_I64: torch.int64}[kind]
+        out = torch.empty(x.shape, dtype=dt, device=x.device)
+        self.b.call("bcp_cast", _p(x), _p(out), x.numel(), kind, self.stream(x))
+        return out
+
+    def to_u8(self, x):
+        """labels of any reference dtype (int64 / float32 / uint8) -> uint8 on device"""
+        if x.dtype == torch.uint8:
+            return x if x.is_contiguous() else x.contiguous()
+        x = x if x.is_contiguous() else x.contiguous()
+        if x.dtype == torch.int64:
+            return self.cast(x, CAST_I64_U8)
+        if x.dtype == torch.float32:
+            return self.cast(x, CAST_F32_U8)
+        raise _lib.BcpError(f"unsupported label dtype {x.dtype}")
+
+    def axpy(self, y, x, a=1.0):
+        self._chk(y, x)
+        self.b.call("bcp_axpy", _p(y), _p(x), y.numel(), float(a), self.stream(y))
+        return y
+
+    def bernoulli(self, out, p_keep, keep_value, seed):
+        self._chk(out)
+        self.b.call("bcp_bernoulli", _p(out), out.numel(), float(p_keep), float(keep_value), int(out.dtype == torch.uint8), int(seed),
+                    self.stream(out))
+        return out
+
+    # ------------------------------------------------------------------ timing (bench)
+    def event(self):
+        e = C.c_void_p()
+        self.b.call("bcp_event_create", C.byref(e))
+        return e
+
+    def event_record(self, e, like):
+        self.b.call("bcp_event_record", e, self.stream(like))
+
+    def event_elapsed_ms(self, e0, e1):
+        ms = C.c_float()
+        self.b.call("bcp_event_elapsed_ms", e0, e1, C.byref(ms))
+        return ms.value

@@ -1,0 +1,150 @@
+/* include/bcp_hip.h -- C ABI of libbcp_hip.so: the MI355X (gfx950) kernels behind the BCP training hot path.
+ *
+ * The reference (DeepMed-Lab-ECNU/BCP) has NO plugin / FFI interface: its seam is a set of Python
+ * callables.  This header is the boundary a maintainer would bind instead; every
+ * entry point names the reference code it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - every function returns 0 (BCP_OK) or a negative BCP_E* code; bcp_last_error() (thread-local)
+ *     explains the last failure.  Nothing throws, nothing calls exit().
+ *   - all pointers are DEVICE pointers owned by the caller (outputs and workspaces included);
+ *     `*_workspace_bytes` tells how much scratch an op needs.  The library allocates nothing and
+ *     never synchronises: work is enqueued on `stream` (a hipStream_t passed as void*).
+ *   - activations are channels-last fp32: [N][D][H][W][C] (2-D: D = 1).  float* must be 16-B aligned.
+ *   - labels / masks are uint8.  A "box" is int[6] = {d0, h0, w0, size_d, size_h, size_w}: the
+ *     zero region of the reference's mask (mask = 1 outside the box).
+ *   - `accumulate` != 0 means "+=" into the output (gradient accumulation over the two student
+ *     forwards, skip-connection gradient joins).
+ */
+#ifndef BCP_HIP_H
+#define BCP_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BCP_OK 0
+#define BCP_EINVAL (-1)
+#define BCP_ELAUNCH (-2)
+#define BCP_EUNSUP (-3)
+
+enum { BCP_ACT_NONE = 0, BCP_ACT_RELU = 1, BCP_ACT_LRELU = 2 };
+enum { BCP_LOSS_LA = 0, BCP_LOSS_ACDC = 1 };
+enum { BCP_CAST_I64_U8 = 0, BCP_CAST_F32_U8 = 1, BCP_CAST_U8_F32 = 2, BCP_CAST_U8_I64 = 3 };
+enum { BCP_PACK_DOWN_FWD = 0, BCP_PACK_DOWN_DGRAD = 1, BCP_PACK_UP_FWD = 2, BCP_PACK_UP_DGRAD = 3, BCP_PACK_PW_FWD = 4, BCP_PACK_PW_DGRAD = 5 };
+enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
+
+/* ---- library ------------------------------------------------------------------------------- */
+int bcp_version(void);
+const char* bcp_last_error(void);
+/* writes the gcnArchName of the current device ("gfx950...") */
+int bcp_device_arch(char* buf, int n);
+/* hipEvent-based timing on an arbitrary stream (bench.py uses it for per-kernel roofline numbers) */
+int bcp_event_create(void** ev);
+int bcp_event_record(void* ev, void* stream);
+int bcp_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int bcp_event_destroy(void* ev);
+
+/* ---- bidirectional copy-paste mix: a*mask + b*(1-mask)  (LA_BCP_train.py:248-251, ACDC_BCP_train.py:372-373,
+ *      train_pancreas.py:155-156; mask from utils/BCP_utils.py:18-28 context_mask / ACDC generate_mask) ------- */
+int bcp_mix_box(const float* a, const float* b, float* out, int N, int D, int H, int W, int C, const int* box6, void* stream);
+
+/* ---- pseudo-labels (LA_BCP_train.py:57-60 get_cut_mask; ACDC_BCP_train.py:112-114 get_ACDC_masks) ---------- */
+int bcp_plabel_bin(const float* logits /*[n_vox][2]*/, uint8_t* out, long long n_vox, float thres, void* stream);
+int bcp_plabel_argmax4(const float* logits /*[n_pix][4]*/, uint8_t* out, long long n_pix, void* stream);
+
+/* ---- largest connected component (LA_BCP_train.py:65-77, pancreas_utils.py:284-296, ACDC_BCP_train.py:89-109)
+ *      connectivity = number of axes allowed to differ: 3-D 3 -> 26-conn, 2 -> 18, 1 -> 6; 2-D (D=1) 2 -> 8, 1 -> 4.
+ *      seg values 0..nclass; per sample and per class the largest component is kept (ties: first in raster order). */
+size_t bcp_cc_workspace_bytes(int N, int D, int H, int W, int nclass);
+int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8_or_null, float* out_f32_or_null, int N, int D, int H, int W, int nclass,
+                   int connectivity, void* workspace, void* stream);
+
+/* ---- masked Dice + CE "mix_loss" (utils/BCP_utils.py:58-69 + utils/losses.py:47-77 [flavour LA, C=2];
+ *      ACDC_BCP_train.py:167-179 + utils/losses.py:102-134 [flavour ACDC, C=4]).  mask_or_null: explicit uint8 mask
+ *      (1 = image term) or NULL to use the box.  out3: LA {loss, ce, dice}; ACDC {dice, ce, (dice+ce)/2}.
+ *      bwd writes d(g_dice*dice + g_ce*ce)/dlogits (LA: pass g_dice = g_ce = 0.5*upstream). */
+size_t bcp_mixloss_workspace_bytes(int N, int C);
+int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6,
+                    int N, int D, int H, int W, int C, int flavour, float w_img, float w_patch, void* workspace, float* out3,
+                    void* stream);
+int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6,
+                    int N, int D, int H, int W, int C, int flavour, const void* workspace, float g_dice, float g_ce, float* dlogits,
+                    void* stream);
+
+/* ---- norm + activation (+Dropout3d channel scale, +elementwise dropout mask, +residual)
+ *      (nn.BatchNorm3d/2d train mode networks/VNet.py:18-26, networks/unet.py:21-28; nn.InstanceNorm3d pancreas/Vnet.py:93;
+ *      ReLU / LeakyReLU(0.01); Dropout3d VNet.py:165,211; Dropout unet.py:23; skip add VNet.py:220-233).
+ *      G = 1: BatchNorm over all rows; G = N: InstanceNorm.  stats = float[4][G][C] {mean, rstd, scale, shift}. */
+size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C);
+int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
+                 float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
+                 const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace, float* out,
+                 void* stream);
+int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
+                 const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
+                 float* dbeta, int accumulate, void* workspace, float* dy, void* stream);
+
+/* ---- 3x3x3 / 3x3 convolution, pad 1 (nn.Conv3d networks/VNet.py:17, nn.Conv2d networks/unet.py:19-25) on fp32 MFMA.
+ *      KD = 3 (3-D) or 1 (2-D, D = 1).  Weights are packed once per optimizer step from the torch layout
+ *      [Cout][Cin][KD*9]: wp_fwd feeds bcp_conv3_fwd(x -> y); wp_dgrad feeds the SAME entry point as
+ *      bcp_conv3_fwd(dy -> dx, Cin/Cout swapped).  Channel counts must be multiples of 4 (padded to 16 inside). */
+size_t bcp_conv3_packed_weight_floats(int Cin, int Cout, int KD);
+int bcp_conv3_pack_weight(const float* w, float* wp_fwd_or_null, float* wp_dgrad_or_null, int Cin, int Cout, int KD, void* stream);
+int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin, int Cout,
+                  int KD, int accumulate, void* stream);
+size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD);
+int bcp_conv3_wgrad(const float* x, const float* dy, float* dw /*[Cout][Cin][KD*9]*/, int N, int D, int H, int W, int Cin, int Cout,
+                    int KD, int accumulate, void* workspace, void* stream);
+/* first layer, Cin = 1 -> Cout = 16 (torch weight layout used directly) */
+int bcp_conv3_c1_fwd(const float* x, const float* w, const float* bias_or_null, float* y, int N, int D, int H, int W, int KD, void* stream);
+int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int KD, int accumulate, void* workspace,
+                       void* stream);
+
+/* ---- k=2,s=2 conv (networks/VNet.py:74), k=2,s=2 transposed conv (networks/VNet.py:101), 1x1 conv (networks/unet.py:48).
+ *      (D,H,W) are always the FINE grid dims.  Packed B matrices via bcp_k2_pack_weight(kind). */
+int bcp_k2_pack_weight(const float* w, float* bp /*K*N floats*/, int Cin, int Cout, int kind, void* stream);
+int bcp_down_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+int bcp_down_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+int bcp_up_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+int bcp_up_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
+int bcp_pw_fwd(const float* x, const float* bp, const float* bias_or_null, float* y, long long rows, int Cin, int Cout, void* stream);
+size_t bcp_tn_workspace_bytes(long long M, int K, int N);
+int bcp_k2_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin, int Cout, int kind, int accumulate,
+                 void* workspace, void* stream);
+/* 16 -> {2,4} pointwise output conv (networks/VNet.py:210 out_conv) and its backward (dx, dw +=, db +=);
+ * bwd workspace = (Cout*17) doubles */
+int bcp_pw16_fwd(const float* x, const float* w, const float* bias_or_null, float* y, long long nvox, int Cout, void* stream);
+int bcp_pw16_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long nvox, int Cout,
+                 int accumulate, void* workspace, void* stream);
+/* column sums of [rows][C] (bias gradients of convs not followed by a norm); workspace = C doubles */
+int bcp_colsum(const float* x, long long rows, int C, float* out, int accumulate, void* workspace, void* stream);
+
+/* ---- 2-D U-Net plumbing (networks/unet.py:36-57): MaxPool2d(2), bilinear x2 align_corners=True, channel concat ---- */
+int bcp_maxpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate, void* stream);
+int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int y_off, void* stream);
+int bcp_bilinear2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, int lddy, int dy_off, void* stream);
+int bcp_copy_channels(const float* src, float* dst, long long rows, int C, int ld_src, int src_off, int ld_dst, int dst_off,
+                      int accumulate, void* stream);
+
+/* ---- optimiser / mean teacher (utils/BCP_utils.py:78-81 update_ema_variables, ACDC_BCP_train.py:123-129 update_model_ema,
+ *      torch.optim.SGD LA_BCP_train.py:218, torch.optim.Adam pancreas/dataloaders.py:182) over FLAT fp32 buffers ------- */
+/* alpha is a double so that (1 - alpha) is formed exactly as python forms it before the fp32 multiply */
+int bcp_ema(float* dst, const float* src, long long n, double alpha, void* stream);
+int bcp_sgd(float* p, const float* g, float* buf, float* ema_or_null, long long n, float lr, float momentum, float weight_decay,
+            float grad_scale, int first_step, double ema_alpha, void* stream);
+int bcp_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
+             float grad_scale, void* stream);
+
+/* ---- small utilities ---------------------------------------------------------------------------- */
+int bcp_cast(const void* in, void* out, long long n, int kind, void* stream);
+int bcp_axpy(float* y, const float* x, long long n, float a, void* stream);
+int bcp_bernoulli(void* out, long long n, float p_keep, float keep_value, int as_u8, unsigned long long seed, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BCP_HIP_H */

@@ -1,0 +1,390 @@
+"""Per-kernel parity checks: every C-ABI entry point against the oracle / plain torch fp32 on the same
+seeded inputs.  Shared by tests/test_emu_kernels.py (host simulator, CPU tensors; debugging aid for
+the kernel logic) and tests/test_gpu_kernels.py (-m gpu: the real libbcp_hip.so on an MI355X).
+
+Tolerances: integer / byte outputs bit-exact; fp32 outputs rtol 1e-4 (atol scaled to the tensor's
+magnitude) -- different but equally valid fp32 summation orders; loss scalars 1e-5 (north_star)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import bcp_oracle as O
+from bcp_amd import hip_ops as H
+
+
+def to_cl(x):
+    """NCDHW / NCHW -> physical [N,D,H,W,C]"""
+    if x.dim() == 4:
+        x = x.unsqueeze(2)
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def from_cl(x, two_d=False):
+    y = x.permute(0, 4, 1, 2, 3)
+    return y.squeeze(2) if two_d else y
+
+
+def close(a, b, rtol=1e-4, atol_scale=1e-5, msg=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    scale = max(float(b.abs().max()), 1e-30)
+    err = float((a - b).abs().max())
+    tol = atol_scale * scale + rtol * scale
+    assert a.shape == b.shape, f"{msg}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    assert err <= tol, f"{msg}: max|diff| {err:.3e} > {tol:.3e} (ref max {scale:.3e})"
+
+
+def rel_l2(a, b):
+    a = a.detach().cpu().double().reshape(-1)
+    b = b.detach().cpu().double().reshape(-1)
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+def R(rng, *shape):
+    return torch.from_numpy(rng.standard_normal(shape, dtype=np.float32))
+
+
+# ----------------------------------------------------------------------------------------------
+def check_mix_box(ops, dev):
+    rng = np.random.default_rng(0)
+    for shape, box in (((2, 6, 8, 12, 1), (1, 2, 3, 4, 5, 6)), ((1, 1, 16, 16, 1), (0, 3, 4, 1, 10, 9)), ((2, 4, 4, 8, 16), (0, 0, 0, 2, 2, 4))):
+        a, b = R(rng, *shape).to(dev), R(rng, *shape).to(dev)
+        out = ops.mix_box(a, b, box)
+        m = torch.ones(shape[1:4])
+        m[box[0]:box[0] + box[3], box[1]:box[1] + box[4], box[2]:box[2] + box[5]] = 0
+        m = m.view(1, *shape[1:4], 1)
+        ref = a.cpu() * m + b.cpu() * (1 - m)
+        assert torch.equal(out.cpu(), ref), "mix_box must be bit-exact"
+
+
+def check_plabel(ops, dev, golden_dir):
+    g = np.load(f"{golden_dir}/plabel_cc.npz")
+    lo = torch.from_numpy(g["logits3d"])
+    out = ops.plabel_bin(to_cl(lo).to(dev))
+    ref = O.get_cut_mask(lo)
+    diff = int((out.cpu().long() != ref).sum())
+    assert diff <= 2, f"plabel_bin differs from the oracle in {diff} voxels (expf ulp ties only)"
+    assert out[0, 0, 0, :4].tolist() == [1, 1, 1, 1], "exact tie p == 0.5 must give 1"
+    lo2 = torch.from_numpy(g["logits2d"])
+    out2 = ops.plabel_argmax4(to_cl(lo2).to(dev))
+    assert int((out2.cpu()[:, 0].long() != O.get_acdc_argmax(lo2)).sum()) <= 2
+    # first-max-wins on exact ties
+    t = torch.zeros(1, 1, 1, 4, 4)
+    t[0, 0, 0, 1] = torch.tensor([1., 1., 0., 0.])
+    t[0, 0, 0, 2] = torch.tensor([0., 2., 2., 2.])
+    assert ops.plabel_argmax4(t.to(dev)).cpu().view(-1).tolist() == [0, 0, 1, 0]
+
+
+def check_cc(ops, dev, golden_dir):
+    g = np.load(f"{golden_dir}/plabel_cc.npz")
+    cut = torch.from_numpy(g["cut"])
+    for conn, key in ((3, "cc26"), (2, "cc18"), (1, "cc6")):
+        out, outf = ops.cc_largest(cut.to(dev).contiguous(), 1, conn, want_f32=True)
+        assert np.array_equal(out.cpu().numpy(), g[key]), f"cc {key} must be bit-exact"
+        assert np.array_equal(outf.cpu().numpy().astype(np.uint8), g[key])
+    am = torch.from_numpy(g["argmax"]).unsqueeze(1).contiguous()  # [N,1,H,W]
+    out = ops.cc_largest(am.to(dev), 3, 2)
+    assert np.array_equal(out.cpu().numpy()[:, 0], g["argmax_cc"]), "ACDC per-class 8-conn CC must be bit-exact"
+    # empty input passes through; tie between equal-size components -> first in raster order
+    z = torch.zeros(1, 4, 4, 4, dtype=torch.uint8)
+    assert int(ops.cc_largest(z.to(dev), 1, 3).sum()) == 0
+    z[0, 0, 0, 0] = 1
+    z[0, 3, 3, 3] = 1
+    o = ops.cc_largest(z.to(dev), 1, 3).cpu()
+    assert int(o[0, 0, 0, 0]) == 1 and int(o[0, 3, 3, 3]) == 0
+    # random blobs vs the oracle
+    rng = np.random.default_rng(3)
+    seg = (F.avg_pool3d(R(rng, 2, 1, 20, 24, 28), 3, 1, 1)[:, 0] > 0.15).to(torch.uint8).contiguous()
+    for conn, oc in ((3, None), (2, 2), (1, 1)):
+        ref = O.largest_cc(seg.long(), oc)
+        assert torch.equal(ops.cc_largest(seg.to(dev), 1, conn).cpu().float(), ref)
+
+
+def check_mixloss(ops, dev, golden_dir):
+    g = np.load(f"{golden_dir}/mixloss_la.npz")
+    lo = torch.from_numpy(g["logits"])
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    box = (2, 3, 1, 10, 10, 5)
+    lcl = to_cl(lo).to(dev)
+    a8, b8 = a.to(torch.uint8).to(dev), b.to(torch.uint8).to(dev)
+    for key, (wi, wp) in (("1", (1.0, 0.5)), ("2", (0.5, 1.0))):
+        out3, ws = ops.mixloss_fwd(lcl, a8, b8, box, H.LOSS_LA, wi, wp)
+        assert abs(float(out3[0]) - float(g["l" + key])) < 1e-5, (float(out3[0]), float(g["l" + key]))
+        dl = ops.mixloss_bwd(lcl, a8, b8, box, H.LOSS_LA, ws, 0.5, 0.5)
+        close(from_cl(dl), torch.from_numpy(g["g" + key]), rtol=1e-4, msg="mixloss_la grad " + key)
+        # explicit-mask path must agree with the box path
+        m8 = torch.from_numpy(g["mask"]).to(torch.uint8).to(dev)
+        out3m, wsm = ops.mixloss_fwd(lcl, a8, b8, (0, 0, 0, 0, 0, 0), H.LOSS_LA, wi, wp, mask=m8)
+        assert abs(float(out3m[0]) - float(out3[0])) < 1e-7
+    # supervised loss = empty box, weight 1 (LA_BCP_train.py:159-161)
+    out3, ws = ops.mixloss_fwd(lcl, a8, a8, (0, 0, 0, 0, 0, 0), H.LOSS_LA, 1.0, 0.0)
+    assert abs(float(out3[0]) - float(g["l3"])) < 1e-5
+    dl = ops.mixloss_bwd(lcl, a8, a8, (0, 0, 0, 0, 0, 0), H.LOSS_LA, ws, 0.5, 0.5)
+    close(from_cl(dl), torch.from_numpy(g["g3"]), rtol=1e-4, msg="sup loss grad")
+
+    g = np.load(f"{golden_dir}/mixloss_acdc.npz")
+    lo = torch.from_numpy(g["logits"])
+    a8, b8 = torch.from_numpy(g["a"]).to(torch.uint8).unsqueeze(1).contiguous().to(dev), torch.from_numpy(g["b"]).to(torch.uint8).unsqueeze(1).contiguous().to(dev)
+    lcl = to_cl(lo).to(dev)
+    box = (0, 4, 6, 1, 21, 21)
+    for key, (wi, wp) in (("1", (0.5, 1.0)), ("2", (1.0, 0.5))):
+        out3, ws = ops.mixloss_fwd(lcl, a8, b8, box, H.LOSS_ACDC, wi, wp)
+        assert abs(float(out3[0]) - float(g["d" + key])) < 1e-5 and abs(float(out3[1]) - float(g["c" + key])) < 1e-5
+        dl = ops.mixloss_bwd(lcl, a8, b8, box, H.LOSS_ACDC, ws, 0.5, 0.5)
+        close(from_cl(dl, True), torch.from_numpy(g["g" + key]), rtol=1e-4, msg="mixloss_acdc grad " + key)
+
+
+def check_norm(ops, dev):
+    rng = np.random.default_rng(4)
+    for (N, Cc, sp, act, use_cs, use_res, G) in ((2, 16, (4, 6, 8), H.ACT_RELU, True, True, 1), (1, 64, (2, 4, 4), H.ACT_RELU, False, False, 1),
+                                                  (3, 32, (1, 8, 8), H.ACT_LRELU, False, False, 1), (2, 32, (4, 4, 4), H.ACT_RELU, False, False, 2),
+                                                  (1, 256, (2, 2, 2), H.ACT_RELU, True, False, 1)):
+        y = (R(rng, N, Cc, *sp) * 1.7 + 0.4).requires_grad_(True)
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cc).astype(np.float32)).requires_grad_(True)
+        beta = torch.from_numpy(rng.uniform(-0.3, 0.3, Cc).astype(np.float32)).requires_grad_(True)
+        rm, rv = torch.zeros(Cc), torch.ones(Cc)
+        cs = torch.from_numpy(((rng.random((N, Cc)) < 0.5) * 2.0).astype(np.float32)) if use_cs else None
+        res = R(rng, N, Cc, *sp) if use_res else None
+        em = torch.from_numpy((rng.random((N, Cc, *sp)) < 0.8).astype(np.uint8)) if act == H.ACT_LRELU else None
+        # reference
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        if G == 1:
+            z = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+        else:
+            z = F.instance_norm(y, eps=1e-5)
+        a_ref = F.relu(z) if act == H.ACT_RELU else F.leaky_relu(z, 0.01)
+        if cs is not None:
+            a_ref = a_ref * cs.view(N, Cc, 1, 1, 1)
+        if em is not None:
+            a_ref = a_ref * em.float() / 0.8
+        if res is not None:
+            a_ref = a_ref + res
+        da = R(rng, N, Cc, *sp)
+        a_ref.backward(da)
+        # HIP
+        ycl = to_cl(y.detach()).to(dev)
+        rmd, rvd = rm.clone().to(dev), rv.clone().to(dev)
+        a, stats = ops.norm_fwd(ycl, G, gamma.detach().to(dev) if G == 1 else None, beta.detach().to(dev) if G == 1 else None,
+                                rmd if G == 1 else None, rvd if G == 1 else None, act,
+                                chan_scale=None if cs is None else cs.to(dev), elem_mask=None if em is None else to_cl(em).to(dev),
+                                elem_scale=1 / 0.8, residual=None if res is None else to_cl(res).to(dev))
+        close(from_cl(a), a_ref, msg=f"norm fwd C={Cc} G={G}")
+        if G == 1:
+            close(rmd, rm_ref, msg="running_mean")
+            close(rvd, rv_ref, msg="running_var")
+        dg, db = torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)
+        dy = ops.norm_bwd(ycl, to_cl(da).to(dev), G, stats, act, dg if G == 1 else None, db if G == 1 else None, False,
+                          chan_scale=None if cs is None else cs.to(dev), elem_mask=None if em is None else to_cl(em).to(dev), elem_scale=1 / 0.8)
+        close(from_cl(dy), y.grad, rtol=2e-4, msg=f"norm bwd dy C={Cc} G={G}")
+        if G == 1:
+            close(dg, gamma.grad, rtol=2e-4, msg="dgamma")
+            close(db, beta.grad, rtol=2e-4, msg="dbeta")
+            # accumulate
+            ops.norm_bwd(ycl, to_cl(da).to(dev), G, stats, act, dg, db, True, chan_scale=None if cs is None else cs.to(dev),
+                         elem_mask=None if em is None else to_cl(em).to(dev), elem_scale=1 / 0.8)
+            close(dg, 2 * gamma.grad, rtol=2e-4, msg="dgamma accumulate")
+
+
+CONV3_CASES = (
+    # (N, Cin, Cout, spatial, KD)
+    (1, 16, 16, (4, 4, 16), 3),       # exactly one 4x4x16 tile
+    (1, 16, 16, (5, 6, 18), 3),       # partial tiles
+    (2, 32, 32, (4, 8, 8), 3),
+    (1, 64, 64, (4, 4, 4), 3),
+    (1, 32, 16, (6, 5, 7), 3),        # Cin != Cout, odd dims
+    (1, 128, 128, (3, 3, 2), 3),      # deep level, tiny spatial
+    (2, 16, 16, (1, 16, 16), 1),      # 2-D
+    (1, 32, 64, (1, 9, 11), 1),
+    (1, 16, 4, (1, 8, 8), 1),         # U-Net out_conv: Cout = 4 (padded to 16 inside)
+)
+
+
+def check_conv3(ops, dev, cases=CONV3_CASES):
+    rng = np.random.default_rng(5)
+    for (N, Cin, Cout, sp, KD) in cases:
+        two_d = KD == 1
+        ksz = (3, 3) if two_d else (3, 3, 3)
+        xs = sp[1:] if two_d else sp
+        x = R(rng, N, Cin, *xs).requires_grad_(True)
+        w = (R(rng, Cout, Cin, *ksz) * 0.1).requires_grad_(True)
+        b = R(rng, Cout) * 0.1
+        y_ref = (F.conv2d(x, w, b, padding=1) if two_d else F.conv3d(x, w, b, padding=1))
+        dy = R(rng, *y_ref.shape)
+        y_ref.backward(dy)
+        tag = f"conv3 N={N} {Cin}->{Cout} {sp} KD={KD}"
+        wf, wd = ops.conv3_pack(w.detach().to(dev).contiguous(), KD)
+        xcl = to_cl(x.detach()).to(dev)
+        y = ops.conv3_fwd(xcl, wf, b.to(dev), Cout, KD)
+        close(from_cl(y, two_d), y_ref, msg=tag + " fwd")
+        dycl = to_cl(dy).to(dev)
+        if Cout % 4 == 0 and Cout >= 4:
+            dx = ops.conv3_fwd(dycl, wd, None, Cin, KD)
+            close(from_cl(dx, two_d), x.grad, msg=tag + " dgrad")
+            # accumulate flag
+            dx2 = ops.conv3_fwd(dycl, wd, None, Cin, KD, out=dx.clone(), accumulate=True)
+            close(from_cl(dx2, two_d), 2 * x.grad, msg=tag + " dgrad accumulate")
+        dw = torch.full(w.shape, 3.0).to(dev)
+        ops.conv3_wgrad(xcl, dycl, dw, KD, accumulate=False)
+        close(dw, w.grad, rtol=2e-4, msg=tag + " wgrad")
+        ops.conv3_wgrad(xcl, dycl, dw, KD, accumulate=True)
+        close(dw, 2 * w.grad, rtol=2e-4, msg=tag + " wgrad accumulate")
+
+
+def check_conv3_c1(ops, dev):
+    rng = np.random.default_rng(6)
+    for (N, sp, KD) in ((1, (5, 6, 18), 3), (2, (4, 4, 16), 3), (2, (1, 17, 20), 1)):
+        two_d = KD == 1
+        ksz = (3, 3) if two_d else (3, 3, 3)
+        xs = sp[1:] if two_d else sp
+        x = R(rng, N, 1, *xs)
+        w = (R(rng, 16, 1, *ksz) * 0.2).requires_grad_(True)
+        b = R(rng, 16) * 0.1
+        y_ref = (F.conv2d(x, w, b, padding=1) if two_d else F.conv3d(x, w, b, padding=1))
+        dy = R(rng, *y_ref.shape)
+        y_ref.backward(dy)
+        xcl = to_cl(x).to(dev)
+        y = ops.conv3_c1_fwd(xcl, w.detach().to(dev).contiguous(), b.to(dev), KD)
+        close(from_cl(y, two_d), y_ref, msg=f"conv3_c1 fwd {sp}")
+        dw = torch.zeros(w.shape).to(dev)
+        ops.conv3_c1_wgrad(xcl, to_cl(dy).to(dev), dw, KD)
+        close(dw, w.grad, rtol=2e-4, msg=f"conv3_c1 wgrad {sp}")
+
+
+def check_k2(ops, dev):
+    rng = np.random.default_rng(7)
+    for (N, Cin, Cout, sp) in ((1, 16, 32, (4, 6, 8)), (2, 32, 64, (2, 4, 6)), (1, 128, 256, (2, 2, 2))):
+        # down conv
+        x = R(rng, N, Cin, *sp).requires_grad_(True)
+        w = (R(rng, Cout, Cin, 2, 2, 2) * 0.1).requires_grad_(True)
+        b = R(rng, Cout) * 0.1
+        y_ref = F.conv3d(x, w, b, stride=2)
+        dy = R(rng, *y_ref.shape)
+        y_ref.backward(dy)
+        wd = w.detach().to(dev).contiguous()
+        xcl, dycl = to_cl(x.detach()).to(dev), to_cl(dy).to(dev)
+        y = ops.down_fwd(xcl, ops.k2_pack(wd, Cin, Cout, H.PACK_DOWN_FWD), b.to(dev), Cout)
+        close(from_cl(y), y_ref, msg=f"down fwd {Cin}->{Cout}")
+        dx = ops.down_dgrad(dycl, ops.k2_pack(wd, Cin, Cout, H.PACK_DOWN_DGRAD), Cin)
+        close(from_cl(dx), x.grad, msg="down dgrad")
+        dx2 = ops.down_dgrad(dycl, ops.k2_pack(wd, Cin, Cout, H.PACK_DOWN_DGRAD), Cin, out=dx.clone(), accumulate=True)
+        close(from_cl(dx2), 2 * x.grad, msg="down dgrad accumulate")
+        dw = torch.zeros(w.shape).to(dev)
+        ops.k2_wgrad(xcl, dycl, dw, H.WG_DOWN)
+        close(dw, w.grad, rtol=2e-4, msg="down wgrad")
+        # up conv (Cout -> Cin so shapes chain): x2 coarse [N,Cout,sp/2] -> fine [N,Cin,sp]
+        x2 = R(rng, N, Cout, *[s // 2 for s in sp]).requires_grad_(True)
+        w2 = (R(rng, Cout, Cin, 2, 2, 2) * 0.1).requires_grad_(True)   # ConvTranspose3d weight [Cin_t, Cout_t, 2,2,2]
+        b2 = R(rng, Cin) * 0.1
+        y2_ref = F.conv_transpose3d(x2, w2, b2, stride=2)
+        dy2 = R(rng, *y2_ref.shape)
+        y2_ref.backward(dy2)
+        w2d = w2.detach().to(dev).contiguous()
+        x2cl, dy2cl = to_cl(x2.detach()).to(dev), to_cl(dy2).to(dev)
+        y2 = ops.up_fwd(x2cl, ops.k2_pack(w2d, Cout, Cin, H.PACK_UP_FWD), b2.to(dev), Cin)
+        close(from_cl(y2), y2_ref, msg=f"up fwd {Cout}->{Cin}")
+        dx2 = ops.up_dgrad(dy2cl, ops.k2_pack(w2d, Cout, Cin, H.PACK_UP_DGRAD), Cout)
+        close(from_cl(dx2), x2.grad, msg="up dgrad")
+        dw2 = torch.zeros(w2.shape).to(dev)
+        ops.k2_wgrad(x2cl, dy2cl, dw2, H.WG_UP)
+        close(dw2, w2.grad, rtol=2e-4, msg="up wgrad")
+    # 1x1 conv (U-Net decoder) fwd / dgrad / wgrad, bias grad via colsum
+    for (N, Cin, Cout, hw) in ((2, 64, 32, (8, 8)), (3, 256, 128, (4, 4))):
+        x = R(rng, N, Cin, *hw).requires_grad_(True)
+        w = (R(rng, Cout, Cin, 1, 1) * 0.1).requires_grad_(True)
+        b = (R(rng, Cout) * 0.1).requires_grad_(True)
+        y_ref = F.conv2d(x, w, b)
+        dy = R(rng, *y_ref.shape)
+        y_ref.backward(dy)
+        wd = w.detach().to(dev).contiguous()
+        xcl, dycl = to_cl(x.detach()).to(dev), to_cl(dy).to(dev)
+        y = ops.pw_fwd(xcl, ops.k2_pack(wd, Cin, Cout, H.PACK_PW_FWD), b.detach().to(dev), Cout)
+        close(from_cl(y, True), y_ref, msg="pw fwd")
+        dx = ops.pw_fwd(dycl, ops.k2_pack(wd, Cin, Cout, H.PACK_PW_DGRAD), None, Cin)
+        close(from_cl(dx, True), x.grad, msg="pw dgrad")
+        dw = torch.zeros(w.shape).to(dev)
+        ops.k2_wgrad(xcl, dycl, dw, H.WG_PW)
+        close(dw, w.grad, rtol=2e-4, msg="pw wgrad")
+        db = torch.zeros(Cout).to(dev)
+        ops.colsum(dycl, db)
+        close(db, b.grad, rtol=2e-4, msg="colsum")
+    # 16 -> 2 output conv
+    x = R(rng, 2, 16, 4, 6, 8).requires_grad_(True)
+    w = (R(rng, 2, 16, 1, 1, 1) * 0.3).requires_grad_(True)
+    b = (R(rng, 2) * 0.1).requires_grad_(True)
+    y_ref = F.conv3d(x, w, b)
+    dy = R(rng, *y_ref.shape)
+    y_ref.backward(dy)
+    xcl, dycl = to_cl(x.detach()).to(dev), to_cl(dy).to(dev)
+    wd = w.detach().to(dev).contiguous()
+    y = ops.pw16_fwd(xcl, wd, b.detach().to(dev), 2)
+    close(from_cl(y), y_ref, msg="pw16 fwd")
+    dw, db = torch.zeros(w.shape).to(dev), torch.zeros(2).to(dev)
+    dx = ops.pw16_bwd(xcl, dycl, wd, dw, db)
+    close(from_cl(dx), x.grad, msg="pw16 dx")
+    close(dw, w.grad, rtol=2e-4, msg="pw16 dw")
+    close(db, b.grad, rtol=2e-4, msg="pw16 db")
+
+
+def check_pool2d(ops, dev):
+    rng = np.random.default_rng(8)
+    x = R(rng, 2, 16, 8, 12).requires_grad_(True)
+    y_ref = F.max_pool2d(x, 2)
+    dy = R(rng, *y_ref.shape)
+    y_ref.backward(dy)
+    xcl = to_cl(x.detach()).to(dev)
+    y = ops.maxpool2d_fwd(xcl)
+    assert torch.equal(from_cl(y, True).cpu(), y_ref.detach())
+    dx = ops.maxpool2d_bwd(xcl, to_cl(dy).to(dev), torch.empty_like(xcl))
+    assert torch.equal(from_cl(dx, True).cpu(), x.grad)
+    # bilinear x2 align_corners=True into the second half of a concat buffer, and its backward
+    x = R(rng, 2, 16, 5, 7).requires_grad_(True)
+    skip = R(rng, 2, 16, 10, 14)
+    up = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    cat = torch.cat([skip, up], 1)
+    dcat = R(rng, *cat.shape)
+    cat.backward(dcat)
+    buf = torch.empty(2, 1, 10, 14, 32).to(dev)
+    ops.copy_channels(to_cl(skip).to(dev), buf, 16, 0, 0)
+    ops.bilinear2x_fwd(to_cl(x.detach()).to(dev), buf, 16)
+    close(from_cl(buf, True), cat, msg="bilinear+concat fwd")
+    dx = ops.bilinear2x_bwd(to_cl(dcat).to(dev), 16, 16)
+    close(from_cl(dx, True), x.grad, msg="bilinear bwd")
+
+
+def check_optim(ops, dev):
+    rng = np.random.default_rng(9)
+    n = 1000 + 3
+    p, g = R(rng, n), R(rng, n)
+    t = R(rng, n)
+    # EMA: bit-exact vs the reference expression
+    ref = t.clone()
+    ref.mul_(0.99).add_((1 - 0.99) * p)
+    td = t.clone().to(dev)
+    ops.ema(td, p.to(dev), 0.99)
+    assert torch.equal(td.cpu(), ref), "EMA must be bit-exact"
+    # SGD momentum, two steps, vs torch.optim.SGD
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, buf = p.clone().to(dev), torch.zeros(n).to(dev)
+    for step in range(2):
+        gg = g * (step + 1)
+        pr.grad = gg.clone()
+        opt.step()
+        ops.sgd(pd, gg.to(dev), buf, 0.01, 0.9, 1e-4, first_step=(step == 0))
+    close(pd, pr.detach(), rtol=1e-6, atol_scale=1e-7, msg="sgd")
+    # Adam
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pd, m, v = p.clone().to(dev), torch.zeros(n).to(dev), torch.zeros(n).to(dev)
+    for step in range(3):
+        pr.grad = g.clone()
+        opt.step()
+        ops.adam(pd, g.to(dev), m, v, 1e-3, step + 1)
+    close(pd, pr.detach(), rtol=1e-5, atol_scale=1e-6, msg="adam")
+    # casts
+    lab = torch.from_numpy(rng.integers(0, 4, (3, 5, 7)))
+    assert torch.equal(ops.to_u8(lab.to(dev)).cpu(), lab.to(torch.uint8))
+    assert torch.equal(ops.to_u8(lab.float().to(dev)).cpu(), lab.to(torch.uint8))
+
+
+ALL_CHECKS = ("mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")

@@ -275,3 +275,12 @@ inline void bcpemu_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStre
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   bcpemu_launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), (hipStream_t)(stream), ##__VA_ARGS__)
+
+// ---- added: rounding-mode intrinsics and 64-bit atomicMax used by the kernels
+inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
+inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }
+inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v) {
+  unsigned long long old = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) {}
+  return old;
+}
