@@ -37,7 +37,7 @@ _SIGS = {
     "bcp_cc_largest": (I, [P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_mixloss_workspace_bytes": (SZ, [I, I]),
     "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P]),
-    "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, P]),
+    "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, P, P]),
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
     "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P]),
     "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, P]),

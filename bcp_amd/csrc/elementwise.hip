@@ -4,6 +4,14 @@
 #include "common.h"
 #include "../../include/bcp_hip.h"
 
+// EMA / SGD must round every product and sum separately (bit-exact vs the reference's mul_/add_ chain):
+// hipcc defaults to -ffp-contract=fast, which would fuse __fmul_rn + __fadd_rn into v_fma_f32.
+#pragma clang fp contract(off)
+namespace bcp {
+__device__ __forceinline__ float rn_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float rn_add(float a, float b) { return a + b; }
+}  // namespace bcp
+
 namespace bcp {
 
 static inline int stream_grid(long long n_items, int block) {
@@ -93,14 +101,14 @@ __global__ __launch_bounds__(256) void k_ema(float* __restrict__ dst, const floa
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
     float4 d = ld4(dst + i * 4);
     const float4 s = ld4(src + i * 4);
-    d.x = __fadd_rn(__fmul_rn(d.x, alpha), __fmul_rn(one_minus_alpha, s.x));
-    d.y = __fadd_rn(__fmul_rn(d.y, alpha), __fmul_rn(one_minus_alpha, s.y));
-    d.z = __fadd_rn(__fmul_rn(d.z, alpha), __fmul_rn(one_minus_alpha, s.z));
-    d.w = __fadd_rn(__fmul_rn(d.w, alpha), __fmul_rn(one_minus_alpha, s.w));
+    d.x = rn_add(rn_mul(d.x, alpha), rn_mul(one_minus_alpha, s.x));
+    d.y = rn_add(rn_mul(d.y, alpha), rn_mul(one_minus_alpha, s.y));
+    d.z = rn_add(rn_mul(d.z, alpha), rn_mul(one_minus_alpha, s.z));
+    d.w = rn_add(rn_mul(d.w, alpha), rn_mul(one_minus_alpha, s.w));
     st4(dst + i * 4, d);
   }
   for (long long i = nv * 4 + (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    dst[i] = __fadd_rn(__fmul_rn(dst[i], alpha), __fmul_rn(one_minus_alpha, src[i]));
+    dst[i] = rn_add(rn_mul(dst[i], alpha), rn_mul(one_minus_alpha, src[i]));
 }
 
 // ---------------------------------------------------------------- SGD / Adam (A11)
@@ -112,12 +120,12 @@ __global__ __launch_bounds__(256) void k_sgd(float* __restrict__ p, const float*
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float pv = p[i];
-    const float gv = __fadd_rn(g[i] * gscale, __fmul_rn(wd, pv));
-    const float bv = first_step ? gv : __fadd_rn(__fmul_rn(momentum, buf[i]), gv);
+    const float gv = rn_add(g[i] * gscale, rn_mul(wd, pv));
+    const float bv = first_step ? gv : rn_add(rn_mul(momentum, buf[i]), gv);
     buf[i] = bv;
-    pv = __fadd_rn(pv, __fmul_rn(-lr, bv));
+    pv = rn_add(pv, rn_mul(-lr, bv));
     p[i] = pv;
-    if (ema) ema[i] = __fadd_rn(__fmul_rn(ema[i], alpha), __fmul_rn(one_minus_alpha, pv));
+    if (ema) ema[i] = rn_add(rn_mul(ema[i], alpha), rn_mul(one_minus_alpha, pv));
   }
 }
 

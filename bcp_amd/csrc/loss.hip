@@ -197,7 +197,8 @@ template <int C, bool ACDC>
 __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ logits, const uint8_t* __restrict__ img_l,
                                                      const uint8_t* __restrict__ patch_l, const uint8_t* __restrict__ mask,
                                                      BoxArg box, int D, int H, int W, const float* __restrict__ coef,
-                                                     float* __restrict__ dlogits, int N, float g_dice, float g_ce) {
+                                                     float* __restrict__ dlogits, int N, float g_dice, float g_ce,
+                                                     const float* __restrict__ g_dev /* nullable [2] */) {
   const int n = blockIdx.y;
   const long long V = (long long)D * H * W;
   const float* lg = logits + (long long)n * V * C;
@@ -210,6 +211,7 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
   if ((int)threadIdx.x < 2 * C * 2) (&cf[0][0][0])[threadIdx.x] = coef[(long long)n * 2 * C * 2 + threadIdx.x];
   if ((int)threadIdx.x < 2) cce[threadIdx.x] = coef[(long long)N * 2 * C * 2 + threadIdx.x];
   __syncthreads();
+  if (g_dev) { g_dice *= g_dev[0]; g_ce *= g_dev[1]; }  // upstream gradients stay on the device (no host sync)
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
     float x[C];
@@ -269,14 +271,14 @@ static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* 
 
 template <int C, bool ACDC>
 static int launch_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
-                      int N, int D, int H, int W, const float* coef, float* dlogits, float g_dice, float g_ce, hipStream_t s) {
+                      int N, int D, int H, int W, const float* coef, float* dlogits, float g_dice, float g_ce, const float* g_dev, hipStream_t s) {
   BoxArg bx;
   bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
   bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
   const long long V = (long long)D * H * W;
   hipLaunchKernelGGL((k_mixloss_bwd<C, ACDC>), dim3(loss_grid(V), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
-                     W, coef, dlogits, N, g_dice, g_ce);
+                     W, coef, dlogits, N, g_dice, g_ce, g_dev);
   return 0;
 }
 
@@ -317,14 +319,14 @@ extern "C" int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const 
 
 extern "C" int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null,
                                const int* box6, int N, int D, int H, int W, int C, int flavour, const void* workspace,
-                               float g_dice, float g_ce, float* dlogits, void* stream) {
+                               float g_dice, float g_ce, const float* g_dev_or_null, float* dlogits, void* stream) {
   BCP_REQUIRE(logits && img_l && patch_l && box6 && workspace && dlogits, "bcp_mixloss_bwd: null pointer");
   BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4), "bcp_mixloss_bwd: flavour/C");
   const float* coef = coef_ptr(const_cast<void*>(workspace), N, C);
   if (flavour == BCP_LOSS_LA)
-    launch_bwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, (hipStream_t)stream);
+    launch_bwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, (hipStream_t)stream);
   else
-    launch_bwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, (hipStream_t)stream);
+    launch_bwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_mixloss_bwd");
   return BCP_OK;
 }

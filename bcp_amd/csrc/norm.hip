@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const float z = vv[k] * scv[k] + shv[k];
+          const float z = (vv[k] - muv[k]) * scv[k] + shv[k];
           const float g1 = dz[k] * cs[k] * act_grad(z, ep.act);
           const float xh = (vv[k] - muv[k]) * rsv[k];
           s1[k] += (double)g1;
@@ -126,7 +126,7 @@ __global__ void k_norm_finalize(const double* __restrict__ partial, int nb, int 
   rstd[idx] = (float)r;
   const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
   scale[idx] = (float)(ga * r);
-  shift[idx] = (float)(be - m * ga * r);
+  shift[idx] = (float)be;   // z = (y - mean) * scale + beta: subtract the mean FIRST (no cancellation against mean*scale)
   if (running_mean && g == 0) {
     // torch: running = (1-momentum)*running + momentum*stat, with the UNBIASED variance
     const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
@@ -159,9 +159,9 @@ __global__ void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, 
 // ------------------------------------------------------------------ apply passes
 // a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]
 __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y, const float* __restrict__ scale,
-                                                    const float* __restrict__ shift, const float* __restrict__ residual,
-                                                    NormEpilogue ep, long long rows, long long rows_per_group, int C,
-                                                    float* __restrict__ out) {
+                                                    const float* __restrict__ shift, const float* __restrict__ mean,
+                                                    const float* __restrict__ residual, NormEpilogue ep, long long rows,
+                                                    long long rows_per_group, int C, float* __restrict__ out) {
   const int C4 = C >> 2;
   const long long nvec = rows * C4;
   const long long stride = (long long)gridDim.x * blockDim.x;
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
     const int col = (int)(i - row * C4);
     const long long g = row / rows_per_group;
     const float4 v = ld4(y + i * 4);
-    const float4 sc = ld4(scale + g * C + col * 4), sh = ld4(shift + g * C + col * 4);
-    float o[4] = {act_fwd(v.x * sc.x + sh.x, ep.act), act_fwd(v.y * sc.y + sh.y, ep.act),
-                  act_fwd(v.z * sc.z + sh.z, ep.act), act_fwd(v.w * sc.w + sh.w, ep.act)};
+    const float4 sc = ld4(scale + g * C + col * 4), sh = ld4(shift + g * C + col * 4), mu = ld4(mean + g * C + col * 4);
+    float o[4] = {act_fwd((v.x - mu.x) * sc.x + sh.x, ep.act), act_fwd((v.y - mu.y) * sc.y + sh.y, ep.act),
+                  act_fwd((v.z - mu.z) * sc.z + sh.z, ep.act), act_fwd((v.w - mu.w) * sc.w + sh.w, ep.act)};
     if (ep.chan_scale) {
       const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + col * 4);
       o[0] *= c4.x; o[1] *= c4.y; o[2] *= c4.z; o[3] *= c4.w;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float z = vv[k] * scv[k] + shv[k];
+      const float z = (vv[k] - muv[k]) * scv[k] + shv[k];
       const float dz = dd[k] * cs[k] * act_grad(z, ep.act);
       const float xh = (vv[k] - muv[k]) * rsv[k];
       o[k] = scv[k] * (dz - k1v[k] - xh * k2v[k]);
@@ -283,7 +283,7 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   hipLaunchKernelGGL(k_norm_finalize, dim3(cdiv(G * C, 256)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
   const long long rows = (long long)G * rows_per_group;
-  hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, scale, shift, residual, ep, rows,
+  hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, scale, shift, mean, residual, ep, rows,
                      rows_per_group, C, out);
   BCP_CHECK_LAUNCH("bcp_norm_fwd");
   return BCP_OK;

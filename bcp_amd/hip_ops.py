@@ -125,12 +125,12 @@ class Ops:
                     float(w_img), float(w_patch), _p(ws), _p(out3), self.stream(logits))
         return out3, ws
 
-    def mixloss_bwd(self, logits, img_l, patch_l, box6, flavour, ws, g_dice, g_ce, mask=None):
+    def mixloss_bwd(self, logits, img_l, patch_l, box6, flavour, ws, g_dice, g_ce, mask=None, g_dev=None):
         self._chk(logits, img_l, patch_l, mask)
         N, D, H, W, Cc = logits.shape
         dlogits = torch.empty_like(logits)
         self.b.call("bcp_mixloss_bwd", _p(logits), _p(img_l), _p(patch_l), _p(mask), self.box_arg(box6), N, D, H, W, Cc, flavour,
-                    _p(ws), float(g_dice), float(g_ce), _p(dlogits), self.stream(logits))
+                    _p(ws), float(g_dice), float(g_ce), _p(g_dev), _p(dlogits), self.stream(logits))
         return dlogits
 
     # ------------------------------------------------------------------ norm

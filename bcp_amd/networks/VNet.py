@@ -1,0 +1,234 @@
+"""3-D V-Net on the MI355X kernels -- drop-in for the reference's networks/VNet.py:VNet (LA, BatchNorm3d +
+Dropout3d) and pancreas/Vnet.py:VNet (InstanceNorm3d, `branchs` head).
+
+Same constructor arguments, same `state_dict()` keys / shapes (259 / 60), same `parameters()` order,
+same call result: `(out_seg, features)` for the LA net, `[out]` for the pancreas net.  What differs is
+what runs: every layer is a call into libbcp_hip.so (NDHWC fp32, MFMA implicit-GEMM convs, fused
+norm+act(+dropout,+skip) streams), scheduled by `_forward_impl` / `_backward_impl` below; autograd
+sees ONE node per call (networks/_hipnet.py:NetFn).
+
+Topology (networks/VNet.py:167-186, 213-239): block_one(1->16) dw block_two(2x32) dw block_three(3x64) dw
+block_four(3x128) dw block_five(3x256) [Dropout3d] up+x4 block_six(3x128) up+x3 block_seven(3x64) up+x2
+block_eight(2x32) up+x1 block_nine(16) [Dropout3d] out_conv(16->n_classes, 1x1x1).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops as H
+from ._hipnet import BNP, ConvP, HipNet, Holder, NetFn, Seq, contrastive_heads
+
+
+class _Layer:
+    __slots__ = ("kind", "conv", "bn", "cin", "cout", "name", "skip_push", "skip_pop", "drop")
+
+    def __init__(self, kind, conv, bn, cin, cout, name):
+        self.kind, self.conv, self.bn, self.cin, self.cout, self.name = kind, conv, bn, cin, cout, name
+        self.skip_push = False   # the INPUT of this (dw) layer is a skip source
+        self.skip_pop = False    # this (up) layer adds the matching skip after its ReLU
+        self.drop = None         # 'x5' / 'x9': Dropout3d on this layer's output
+
+
+class VNet(HipNet):
+    def __init__(self, n_channels=3, n_classes=2, n_filters=16, normalization="none", has_dropout=False, has_residual=False,
+                 variant="la"):
+        super().__init__()
+        assert n_filters == 16 and not has_residual, "only the configuration the BCP scripts use is implemented"
+        assert n_channels == 1, "the hot path is single-channel (LA / pancreas); see DESIGN.md"
+        la = variant == "la"
+        if la:
+            assert normalization == "batchnorm", "networks/net_factory.py builds the LA V-Net with batchnorm"
+        else:
+            assert normalization == "instancenorm"
+        self.variant = variant
+        self.norm = normalization
+        self.has_dropout = has_dropout
+        self.n_classes = n_classes
+        nf = n_filters
+        self._layers = []
+        bn = la
+
+        def block(owner, name, n, cin, cout, kind="c3"):
+            items = []
+            for i in range(n):
+                ci = cin if i == 0 else cout
+                if kind == "c3":
+                    w = (cout, ci, 3, 3, 3)
+                    fan = ci * 27
+                elif kind == "dw":
+                    w = (cout, ci, 2, 2, 2)
+                    fan = ci * 8
+                else:  # ConvTranspose3d weight [Cin, Cout, 2,2,2]; torch's fan_in uses dim 1
+                    w = (ci, cout, 2, 2, 2)
+                    fan = cout * 8
+                conv = ConvP(w, fan, cout)
+                items.append((3 * i, conv))
+                b = BNP(cout) if bn else None
+                if b is not None:
+                    b._live = True
+                    items.append((3 * i + 1, b))
+                k = "c1" if (kind == "c3" and ci == 1) else kind
+                self._layers.append(_Layer(k, conv, b, ci, cout, f"{name}.{3 * i}"))
+            h = Holder()
+            h.conv = Seq(items)
+            setattr(owner, name, h)
+
+        enc = Holder() if la else self
+        dec = Holder() if la else self
+        block(enc, "block_one", 1, n_channels, nf)
+        block(enc, "block_one_dw", 1, nf, 2 * nf, "dw")
+        block(enc, "block_two", 2, 2 * nf, 2 * nf)
+        block(enc, "block_two_dw", 1, 2 * nf, 4 * nf, "dw")
+        block(enc, "block_three", 3, 4 * nf, 4 * nf)
+        block(enc, "block_three_dw", 1, 4 * nf, 8 * nf, "dw")
+        block(enc, "block_four", 3, 8 * nf, 8 * nf)
+        block(enc, "block_four_dw", 1, 8 * nf, 16 * nf, "dw")
+        block(enc, "block_five", 3, 16 * nf, 16 * nf)
+        if la:
+            enc.dropout = nn.Dropout3d(p=0.5, inplace=False)  # parameter-free; kept for module-tree parity
+        block(dec, "block_five_up", 1, 16 * nf, 8 * nf, "up")
+        block(dec, "block_six", 3, 8 * nf, 8 * nf)
+        block(dec, "block_six_up", 1, 8 * nf, 4 * nf, "up")
+        block(dec, "block_seven", 3, 4 * nf, 4 * nf)
+        block(dec, "block_seven_up", 1, 4 * nf, 2 * nf, "up")
+        block(dec, "block_eight", 2, 2 * nf, 2 * nf)
+        block(dec, "block_eight_up", 1, 2 * nf, nf, "up")
+        if la:
+            block(dec, "block_nine", 1, nf, nf)
+            dec.out_conv = ConvP((n_classes, nf, 1, 1, 1), nf, n_classes)
+            dec.dropout = nn.Dropout3d(p=0.5, inplace=False)
+            self.encoder, self.decoder = enc, dec
+            self.pool = nn.MaxPool3d(3, stride=2)
+            contrastive_heads(self, 2)
+            object.__setattr__(self, "_out", dec.out_conv)   # alias without a second registration
+        else:
+            br = Holder()
+            block(br, "b0", 1, nf, nf)
+            head = ConvP((n_classes, nf, 1, 1, 1), nf, n_classes)
+            self.branchs = nn.ModuleList([Seq([(0, br.b0), (1, head)])])
+            object.__setattr__(self, "_out", head)
+        for L in self._layers:
+            if L.kind == "dw":
+                L.skip_push = True
+            if L.kind == "up":
+                L.skip_pop = True
+        if la:
+            # Dropout3d sites: after block_five's last conv (x5) and after block_nine (x9)
+            idx5 = max(i for i, L in enumerate(self._layers) if L.name.startswith("block_five."))
+            self._layers[idx5].drop = "x5"
+            self._layers[-1].drop = "x9"
+        # parameters that take part in the optimiser: everything the forward pass touches
+        ids = set()
+        for L in self._layers:
+            ids.add(id(L.conv.weight)); ids.add(id(L.conv.bias))
+            if L.bn is not None:
+                ids.add(id(L.bn.weight)); ids.add(id(L.bn.bias))
+        ids.add(id(self._out.weight)); ids.add(id(self._out.bias))
+        self._opt_param_ids = ids
+
+    # ------------------------------------------------------------------ public call
+    def forward(self, input, turnoff_drop=False):
+        x = input
+        N = x.shape[0]
+        assert x.dim() == 5 and x.shape[1] == 1, "expected [N,1,X,Y,Z]"
+        self._ensure_flat()
+        xcl = x.contiguous().view(N, x.shape[2], x.shape[3], x.shape[4], 1)
+        self._turnoff_drop = bool(turnoff_drop)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in (self._layers[0].conv.weight,)):
+            out = NetFn.apply(xcl, self._layers[0].conv.weight, self)
+        else:
+            out, _ = self._forward_impl(xcl, save=False)
+        logits = out.permute(0, 4, 1, 2, 3)  # logical [N,C,X,Y,Z], channels_last_3d strides
+        if self.variant == "la":
+            return logits, None   # second value (pooled x5) is dead in every train script (LA_BCP_train.py:158,252)
+        return [logits]
+
+    # ------------------------------------------------------------------ schedule
+    def _chan_scale(self, L, N, dev):
+        if L.drop is None or not self.has_dropout or not self.training or getattr(self, "_turnoff_drop", False):
+            return None
+        if self.drop_masks is not None:
+            m = self.drop_masks[L.drop]
+            return (m.to(device=dev, dtype=torch.float32) * 2.0).contiguous()
+        cs = torch.empty((N, L.cout), dtype=torch.float32, device=dev)
+        return self.ops.bernoulli(cs, 0.5, 2.0, self.next_seed())
+
+    def _forward_impl(self, xcl, save):
+        ops = self.ops
+        N = xcl.shape[0]
+        G = 1 if self.norm == "batchnorm" else N
+        h = xcl
+        skips = []
+        saved = []
+        for li, L in enumerate(self._layers):
+            w, b = L.conv.weight, L.conv.bias
+            if L.skip_push:
+                skips.append(h)
+            if L.kind == "c1":
+                y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
+            elif L.kind == "c3":
+                wf, _ = self._packed(("c3", li), w, lambda w=w: ops.conv3_pack(w.data, 3))
+                y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)
+            elif L.kind == "dw":
+                bp = self._packed(("dwf", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_DOWN_FWD))
+                y = ops.down_fwd(h, bp, b.data, L.cout)
+            else:
+                bp = self._packed(("upf", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_UP_FWD))
+                y = ops.up_fwd(h, bp, b.data, L.cout)
+            res = skips.pop() if L.skip_pop else None
+            cs = self._chan_scale(L, N, xcl.device)
+            if L.bn is not None:
+                a, stats = ops.norm_fwd(y, G, L.bn.weight.data, L.bn.bias.data, L.bn.running_mean, L.bn.running_var, H.ACT_RELU,
+                                        chan_scale=cs, residual=res)
+            else:
+                a, stats = ops.norm_fwd(y, G, None, None, None, None, H.ACT_RELU, chan_scale=cs, residual=res)
+            if save:
+                saved.append((h, y, stats, cs))
+            h = a
+        if self.norm == "batchnorm" and self.training:
+            self._nbt_tick()
+        logits = ops.pw16_fwd(h, self._out.weight.data, self._out.bias.data, self.n_classes)
+        if save:
+            saved.append((h,))
+        return logits, saved
+
+    def _backward_impl(self, saved, dout):
+        ops = self.ops
+        G = 1 if self.norm == "batchnorm" else saved[0][0].shape[0]
+        dlogits = dout if dout.is_contiguous() else dout.contiguous()
+        self.begin_backward()
+        (h_last,) = saved[-1]
+        dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
+        skip_grads = []
+        for li in range(len(self._layers) - 1, -1, -1):
+            L = self._layers[li]
+            x_in, y, stats, cs = saved[li]
+            w = L.conv.weight
+            da = dh
+            if L.skip_pop:
+                skip_grads.append(da)       # d(out)/d(skip) = identity: the skip source gets `da` itself
+            if L.bn is not None:
+                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, L.bn.weight.grad, L.bn.bias.grad, True, chan_scale=cs)
+            else:
+                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, None, None, False, chan_scale=cs)
+            gw, acc = w.grad, True
+            # conv biases feed a norm: their gradient is identically zero (DESIGN.md "bias gradients"); the flat
+            # gradient buffer was cleared by begin_backward(), nothing to add.
+            if L.kind == "c1":
+                ops.conv3_c1_wgrad(x_in, dy, gw, 3, accumulate=acc)
+                dh = None
+            elif L.kind == "c3":
+                ops.conv3_wgrad(x_in, dy, gw, 3, accumulate=acc)
+                _, wd = self._packed(("c3", li), w, lambda w=w: ops.conv3_pack(w.data, 3))
+                dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
+            elif L.kind == "dw":
+                ops.k2_wgrad(x_in, dy, gw, H.WG_DOWN, accumulate=acc)
+                bp = self._packed(("dwd", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_DOWN_DGRAD))
+                sg = skip_grads.pop()        # x_in is a skip source: join the decoder-side gradient in place
+                dh = ops.down_dgrad(dy, bp, L.cin, out=sg, accumulate=True)
+            else:
+                ops.k2_wgrad(x_in, dy, gw, H.WG_UP, accumulate=acc)
+                bp = self._packed(("upd", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_UP_DGRAD))
+                dh = ops.up_dgrad(dy, bp, L.cin)
+        return None

@@ -1,0 +1,211 @@
+"""Shared machinery of the HIP-backed networks: reference-exact parameter trees living in ONE flat fp32
+buffer (so EMA / SGD / the DP all-reduce are single launches), packed-weight caches, and the
+autograd bridge (one Function node per network call; the whole backward is scheduled by hand).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from ..hip_ops import Ops
+
+
+class ConvP(nn.Module):
+    """parameter holder with the reference's `weight` / `bias` names (torch default init bounds)"""
+
+    def __init__(self, wshape, fan_in, bias_n):
+        super().__init__()
+        import math
+        bound = 1.0 / math.sqrt(max(fan_in, 1))
+        self.weight = nn.Parameter(torch.empty(wshape).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(bias_n).uniform_(-bound, bound))
+
+
+class BNP(nn.Module):
+    """BatchNorm parameter / buffer holder (state_dict-compatible with nn.BatchNorm{2,3}d)"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+        self.register_buffer("running_mean", torch.zeros(c))
+        self.register_buffer("running_var", torch.ones(c))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+
+class Seq(nn.Module):
+    """numbered children, like nn.Sequential's naming (indices may have gaps for ReLU / Dropout slots)"""
+
+    def __init__(self, items):
+        super().__init__()
+        for idx, m in items:
+            self.add_module(str(idx), m)
+
+
+class Holder(nn.Module):
+    pass
+
+
+def contrastive_heads(owner: nn.Module, n_sel: int):
+    """the reference's never-called heads (networks/VNet.py:250-278, networks/unet.py:216-247): kept so
+    state_dict()/parameters() match key for key"""
+    owner.projection_head = nn.Sequential(nn.Linear(16, 32), nn.BatchNorm1d(32), nn.ReLU(inplace=True), nn.Linear(32, 32))
+    owner.prediction_head = nn.Sequential(nn.Linear(32, 32), nn.BatchNorm1d(32), nn.ReLU(inplace=True), nn.Linear(32, 32))
+    for fam in ("contrastive_class_selector_", "contrastive_class_selector_memory"):
+        for c in range(n_sel):
+            sel = nn.Sequential(nn.Linear(32, 32), nn.BatchNorm1d(32), nn.LeakyReLU(negative_slope=0.2, inplace=True), nn.Linear(32, 1))
+            owner.__setattr__(fam + str(c), sel)
+
+
+class HipNet(nn.Module):
+    """Base class: flat parameter / gradient storage + autograd bridge."""
+
+    def __init__(self):
+        super().__init__()
+        self._ops = None
+        self._flat = None
+        self._flat_grad = None
+        self._n_trainable_flat = 0   # prefix of the flat buffer that takes part in the optimiser (enc + dec)
+        self._pack_cache = {}
+        self._bump = 0               # incremented when the flat buffer is modified outside torch (fused SGD / EMA)
+        self.drop_masks = None       # injectable dropout keep-masks (parity runs)
+        self._drop_seed = 0x9E3779B97F4A7C15
+
+    # ------------------------------------------------------------------ ops / storage
+    @property
+    def ops(self) -> Ops:
+        if self._ops is None:
+            self._ops = Ops.product()
+        return self._ops
+
+    def set_ops(self, ops: Ops):
+        """tests only: run this network on another binding (the host simulator)"""
+        self._ops = ops
+        return self
+
+    def _ordered_params(self):
+        return list(self.parameters())
+
+    def flatten_(self):
+        """(re)locate every parameter inside one contiguous fp32 buffer, in registration order"""
+        ps = self._ordered_params()
+        dev = ps[0].device
+        total = sum(p.numel() for p in ps)
+        # 16-B alignment of every view: pad each tensor to a multiple of 4 floats
+        offs, off = [], 0
+        for p in ps:
+            offs.append(off)
+            off += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self._flat = flat
+        self._flat_grad = torch.zeros_like(flat)
+        self._offs = {id(p): o for p, o in zip(ps, offs)}
+        n_train = 0
+        for p, o in zip(ps, offs):
+            if id(p) in self._opt_param_ids:
+                n_train = o + (p.numel() + 3) // 4 * 4
+        self._n_trainable_flat = n_train
+        self._pack_cache.clear()
+        return self
+
+    def _ensure_flat(self):
+        ps = self._ordered_params()
+        if self._flat is None or self._flat.device != ps[0].device or ps[0].data_ptr() != self._flat.data_ptr() + 4 * self._offs.get(id(ps[0]), -1):
+            self.flatten_()
+        else:
+            last = ps[-1]
+            if last.data_ptr() != self._flat.data_ptr() + 4 * self._offs[id(last)]:
+                self.flatten_()
+
+    def flat_params(self):
+        self._ensure_flat()
+        return self._flat
+
+    def flat_grads(self):
+        self._ensure_flat()
+        return self._flat_grad
+
+    def flat_trainable(self):
+        """(params, grads) prefix views covering exactly the encoder+decoder parameters"""
+        self._ensure_flat()
+        n = self._n_trainable_flat
+        return self._flat[:n], self._flat_grad[:n]
+
+    def grad_view(self, p):
+        o = self._offs[id(p)]
+        return self._flat_grad[o:o + p.numel()].view(p.shape)
+
+    def attach_grad(self, p):
+        """-> (grad tensor, accumulate?)  first touch after zero_grad() re-attaches the flat view"""
+        if p.grad is None:
+            p.grad = self.grad_view(p)
+            return p.grad, False
+        return p.grad, True
+
+    def bump(self):
+        self._bump += 1
+
+    def begin_backward(self):
+        """first backward after zero_grad(): clear the flat gradient buffer with ONE memset and re-attach every
+        optimiser parameter's .grad view; from then on all kernels accumulate (+=)."""
+        self._ensure_flat()
+        ps = [p for p in self._ordered_params() if id(p) in self._opt_param_ids]
+        if ps[0].grad is None or ps[0].grad.data_ptr() != self.grad_view(ps[0]).data_ptr():
+            self._flat_grad.zero_()
+            for p in ps:
+                p.grad = self.grad_view(p)
+
+    # num_batches_tracked is bumped on the host and flushed lazily (29 tiny device ops per forward otherwise)
+    def _nbt_tick(self):
+        self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+
+    def flush_nbt(self):
+        n = getattr(self, "_nbt_pending", 0)
+        if n:
+            for m in self.modules():
+                if isinstance(m, BNP) and getattr(m, "_live", False):
+                    m.num_batches_tracked += n
+            self._nbt_pending = 0
+
+    def state_dict(self, *a, **k):
+        self.flush_nbt()
+        return super().state_dict(*a, **k)
+
+    def _packed(self, key, p, fn):
+        ver = (p._version, self._bump, p.data_ptr())
+        hit = self._pack_cache.get(key)
+        if hit is None or hit[0] != ver:
+            hit = (ver, fn())
+            self._pack_cache[key] = hit
+        return hit[1]
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._bump += 1
+        return r
+
+    def next_seed(self):
+        self._drop_seed = (self._drop_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self._drop_seed
+
+
+class NetFn(torch.autograd.Function):
+    """One autograd node for a whole network call.  `anchor` is any trainable parameter: it makes the
+    output require grad; parameter gradients are written by the kernels straight into the flat
+    gradient buffer (p.grad views), so backward returns None for it."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, net):
+        out, saved = net._forward_impl(x, save=True)
+        ctx.net = net
+        ctx.saved = saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ctx.net._backward_impl(ctx.saved, dout)
+        ctx.saved = None
+        return None, None, None

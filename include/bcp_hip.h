@@ -65,19 +65,20 @@ int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8_or_null, float* out_f32_o
 /* ---- masked Dice + CE "mix_loss" (utils/BCP_utils.py:58-69 + utils/losses.py:47-77 [flavour LA, C=2];
  *      ACDC_BCP_train.py:167-179 + utils/losses.py:102-134 [flavour ACDC, C=4]).  mask_or_null: explicit uint8 mask
  *      (1 = image term) or NULL to use the box.  out3: LA {loss, ce, dice}; ACDC {dice, ce, (dice+ce)/2}.
- *      bwd writes d(g_dice*dice + g_ce*ce)/dlogits (LA: pass g_dice = g_ce = 0.5*upstream). */
+ *      bwd writes d(g_dice*dice + g_ce*ce)/dlogits (LA: g_dice = g_ce = 0.5); g_dev_or_null = device float[2] of upstream
+ *      gradients multiplied in on the device, so autograd never has to read a scalar back. */
 size_t bcp_mixloss_workspace_bytes(int N, int C);
 int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6,
                     int N, int D, int H, int W, int C, int flavour, float w_img, float w_patch, void* workspace, float* out3,
                     void* stream);
 int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6,
-                    int N, int D, int H, int W, int C, int flavour, const void* workspace, float g_dice, float g_ce, float* dlogits,
-                    void* stream);
+                    int N, int D, int H, int W, int C, int flavour, const void* workspace, float g_dice, float g_ce, const float* g_dev_or_null,
+                    float* dlogits, void* stream);
 
 /* ---- norm + activation (+Dropout3d channel scale, +elementwise dropout mask, +residual)
  *      (nn.BatchNorm3d/2d train mode networks/VNet.py:18-26, networks/unet.py:21-28; nn.InstanceNorm3d pancreas/Vnet.py:93;
  *      ReLU / LeakyReLU(0.01); Dropout3d VNet.py:165,211; Dropout unet.py:23; skip add VNet.py:220-233).
- *      G = 1: BatchNorm over all rows; G = N: InstanceNorm.  stats = float[4][G][C] {mean, rstd, scale, shift}. */
+ *      G = 1: BatchNorm over all rows; G = N: InstanceNorm.  stats = float[4][G][C] {mean, rstd, scale = gamma*rstd, beta}; z = (y - mean)*scale + beta. */
 size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C);
 int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,

@@ -1,0 +1,154 @@
+"""Whole-network / whole-step parity checks shared by the simulator tests (CPU) and the -m gpu tests.
+
+Gradient tolerances (measured, see DESIGN.md "parity"): in the reference's own arithmetic a ReLU whose
+pre-activation is within an ulp of zero flips between fp32 and fp64 runs; with ~1e7 units a handful of
+flips moves every weight-gradient tensor by 1e-3..1e-2 relative -- the fp32 torch reference itself sits
+at 4e-3 (median, per tensor) from its fp64 twin.  So:
+  * STANDARD regime (golden vectors): logits rtol 2e-4, loss 1e-5, gradients within 3e-2 rel-L2.
+  * SMOOTH regime (all BN betas = +5, every ReLU active): no kinks, gradients must match the fp64 oracle
+    to 1e-4 rel-L2 per tensor (north_star), which pins the backward wiring and formulas exactly.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+import bcp_oracle as O
+import kernel_checks as K
+from bcp_amd.utils import BCP_utils as BU
+
+
+def load_params(net, P):
+    net.load_state_dict({k: P[k].clone() for k in net.state_dict()})
+    return net
+
+
+def make_vnet(P, dev, ops, variant="la", has_dropout=True):
+    from bcp_amd.networks.VNet import VNet
+    norm = "batchnorm" if variant == "la" else "instancenorm"
+    net = VNet(n_channels=1, n_classes=2, normalization=norm, has_dropout=has_dropout and variant == "la", variant=variant).to(dev)
+    load_params(net, P).flatten_()
+    if dev.type == "cpu":
+        net.set_ops(ops)
+        BU.set_test_ops(ops)
+    net.train()
+    return net
+
+
+def oracle_grads(P, x, tgt, dm, variant="la", dtype=torch.float64):
+    Pd = {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+    Q = O._with_grad(Pd, set(O.trainable_keys(Pd)))
+    out = O.vnet_forward(Q, x.to(dtype), dm, True, variant)
+    loss = O.sup_loss_la(out, tgt)
+    loss.backward()
+    return out.detach(), float(loss), {k: Q[k].grad for k in Q if getattr(Q[k], "grad", None) is not None}
+
+
+def is_prenorm_bias(name, params):
+    """conv bias feeding a norm layer: exact gradient 0 (we write 0; the reference holds rounding noise)"""
+    if not name.endswith(".bias"):
+        return False
+    w = params.get(name[:-5] + ".weight")
+    return w is not None and w.dim() >= 4 and "out_conv" not in name and not name.startswith("branchs.0.1") and "conv1x1" not in name
+
+
+def check_vnet_golden_tiny(ops, dev, golden_dir):
+    g = np.load(os.path.join(golden_dir, "vnet_la_tiny.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))
+    P = O.init_params(O.vnet_param_shapes(), seed=meta["vnet_la_tiny"]["param_seed"], random_affine=True)
+    net = make_vnet(P, dev, ops)
+    net.drop_masks = {"x5": torch.from_numpy(g["drop_x5"]), "x9": torch.from_numpy(g["drop_x9"])}
+    out, _ = net(torch.from_numpy(g["x"]).to(dev))
+    K.close(out, torch.from_numpy(g["logits"]), rtol=2e-4, msg="vnet logits")
+    loss = BU.sup_loss(out, torch.from_numpy(g["tgt"]).to(dev))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5, (float(loss.detach()), float(g["loss"]))
+    loss.backward()
+    params = dict(net.named_parameters())
+    for n_, st in zip([str(n) for n in g["grad_names"]], g["grad_stats"]):
+        gr = params[n_].grad
+        assert gr is not None, n_
+        l2 = float(gr.double().norm())
+        if is_prenorm_bias(n_, params):
+            assert l2 <= 1e-6 and st[2] < 1e-4, (n_, l2, st[2])
+            continue
+        assert abs(l2 - st[2]) / max(st[2], 1e-12) < 3e-2, (n_, l2, st[2])
+    for key, name in (("grad_block_one_w", "encoder.block_one.conv.0.weight"), ("grad_block_nine_w", "decoder.block_nine.conv.0.weight"),
+                      ("grad_five_up_w", "decoder.block_five_up.conv.0.weight"), ("grad_one_dw_w", "encoder.block_one_dw.conv.0.weight"),
+                      ("grad_out_conv_w", "decoder.out_conv.weight"), ("grad_bn1_w", "encoder.block_one.conv.1.weight")):
+        r = K.rel_l2(params[name].grad, torch.from_numpy(g[key]))
+        assert r < 3e-2, (name, r)
+    sd = net.state_dict()
+    K.close(sd["encoder.block_one.conv.1.running_mean"], torch.from_numpy(g["rm_block_one"]), msg="running_mean")
+    K.close(sd["decoder.block_nine.conv.1.running_var"], torch.from_numpy(g["rv_block_nine"]), msg="running_var")
+    assert int(sd["encoder.block_one.conv.1.num_batches_tracked"]) == 1
+
+
+def check_vnet_smooth(ops, dev, shape=(32, 32, 16), variant="la", seed=3, N=1):
+    """every ReLU active (beta = +5): gradients vs the fp64 oracle to 1e-4 per tensor"""
+    rng = np.random.default_rng(seed)
+    P = O.init_params(O.vnet_param_shapes(variant=variant), seed=seed + 100, random_affine=True)
+    for k in list(P):
+        if k.endswith(".bias") and (k[:-5] + ".running_mean") in P:
+            P[k] = torch.full_like(P[k], 5.0)
+    x = torch.from_numpy(rng.standard_normal((N, 1) + shape, dtype=np.float32))
+    tgt = torch.from_numpy(rng.integers(0, 2, (N,) + shape))
+    dm = None
+    if variant == "la":
+        dm = {"x5": torch.from_numpy((rng.random((N, 256)) < 0.5).astype(np.float32)), "x9": torch.from_numpy((rng.random((N, 16)) < 0.5).astype(np.float32))}
+    o64, l64, g64 = oracle_grads(P, x, tgt, dm, variant)
+    net = make_vnet(P, dev, ops, variant)
+    net.drop_masks = dm
+    r = net(x.to(dev))
+    out = r[0]
+    loss = BU.sup_loss(out, tgt.to(dev))
+    loss.backward()
+    assert K.rel_l2(out, o64) < 1e-4
+    assert abs(float(loss.detach()) - l64) < 1e-5
+    params = dict(net.named_parameters())
+    worst = ("", 0.0)
+    for k, gref in g64.items():
+        if is_prenorm_bias(k, params) or float(gref.norm()) < 1e-7:
+            continue
+        if variant != "la":  # InstanceNorm net has no betas: kinks stay, keep the loose bound
+            bound = 3e-2
+        else:
+            bound = 1e-4
+        r = K.rel_l2(params[k].grad, gref)
+        if r > worst[1]:
+            worst = (k, r)
+        assert r < bound, (k, r)
+    return worst
+
+
+def check_la_step(ops, dev, golden_dir):
+    """3 self-training steps through the drop-in API (teacher fwd, pseudo-label, CC, box mix, student fwd/bwd,
+    mix_loss, SGD, EMA) vs the trajectory recorded from the reference's own functions (la_traj.npz)."""
+    from bcp_amd import train_step
+    g = np.load(os.path.join(golden_dir, "la_traj.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["la_traj"]
+    P = O.init_params(O.vnet_param_shapes(), seed=meta["param_seed"], random_affine=True)
+    model, ema = make_vnet(P, dev, ops), make_vnet(P, dev, ops)
+    for p in ema.parameters():
+        p.detach_()
+    vol, lab = O.synth_la_batch(4, shape=tuple(meta["shape"]), seed=meta["data_seed"])
+    vol, lab = vol.to(dev), lab.to(dev)
+    opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for it in range(meta["steps"]):
+        drops = {}
+        for j, k in enumerate(("t_a", "t_b", "s_l", "s_u")):
+            v = torch.from_numpy(g["drops"][it, j])
+            drops[k] = {"x5": v[:256].view(1, 256), "x9": v[256:].view(1, 16)}
+        r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=tuple(int(v) for v in g["boxes"][it]), drops=drops)
+        ref = g["traj"][it]
+        assert abs(float(r["loss"]) - ref[0]) < 1e-4 and abs(float(r["loss_l"]) - ref[1]) < 1e-4 and abs(float(r["loss_u"]) - ref[2]) < 1e-4, (it, r, ref)
+        assert abs(float(r["plab_a"].sum()) - ref[3]) <= 2 and abs(float(r["plab_b"].sum()) - ref[4]) <= 2
+    names = json.load(open(os.path.join(golden_dir, "meta.json")))["vnet_la_param_names"][:60]
+    sdm, sde = model.state_dict(), ema.state_dict()
+    for k, st in zip(names, g["final_w_stats"]):
+        a = sdm[k].double()
+        assert abs(float(a.abs().sum()) - st[1]) / max(st[1], 1e-9) < 1e-3, k
+    for k, st in zip(names, g["final_ema_stats"]):
+        a = sde[k].double()
+        assert abs(float(a.abs().sum()) - st[1]) / max(st[1], 1e-9) < 1e-4, k
+    K.close(sde["decoder.block_nine.conv.1.running_mean"], torch.from_numpy(g["final_ema_rm"]), rtol=1e-3, msg="teacher running_mean")

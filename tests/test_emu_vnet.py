@@ -1,0 +1,20 @@
+"""Whole-network parity on the host simulator (CPU): the HIP-scheduled V-Net forward + hand-scheduled backward
+and the LA self-training step against the oracle / the reference's golden vectors."""
+import torch
+
+import net_checks as NC
+from test_emu_kernels import emu_ops  # noqa: F401  (fixture)
+
+CPU = torch.device("cpu")
+
+
+def test_vnet_la_golden_tiny(emu_ops, golden_dir):
+    NC.check_vnet_golden_tiny(emu_ops, CPU, golden_dir)
+
+
+def test_vnet_la_smooth_grads(emu_ops):
+    NC.check_vnet_smooth(emu_ops, CPU, shape=(32, 32, 16), N=2)
+
+
+def test_vnet_pancreas_smooth(emu_ops):
+    NC.check_vnet_smooth(emu_ops, CPU, shape=(32, 32, 32), variant="pancreas")
