@@ -102,21 +102,39 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
   }
 }
 
-// forward finalize: one thread per (g, c)
-__global__ void k_norm_finalize(const double* __restrict__ partial, int nb, int G, int C, long long rows_per_group,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                float* __restrict__ running_mean, float* __restrict__ running_var, float momentum, float eps,
-                                float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
-                                float* __restrict__ shift) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G * C) return;
-  const int g = idx / C, c = idx % C;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) {
+// Sum the per-block partials of 16 channels of one group: 256 threads = 16 channels x 16 block-slots, LDS tree.
+// (a single thread walking ~1000 partials serially cost more than the streaming pass itself)
+__device__ __forceinline__ bool reduce_partials(const double* __restrict__ partial, int nb, int C, int g, int c, int slot,
+                                                double& s1, double& s2) {
+  __shared__ double red[256][2];
+  double a1 = 0.0, a2 = 0.0;
+  for (int b = slot; b < nb; b += 16) {
     const double* p = partial + (((long long)g * nb + b) * C + c) * 2;
-    s1 += p[0];
-    s2 += p[1];
+    a1 += p[0];
+    a2 += p[1];
   }
+  red[threadIdx.x][0] = a1;
+  red[threadIdx.x][1] = a2;
+  __syncthreads();
+  if (slot != 0) return false;
+  s1 = 0.0; s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { s1 += red[k * 16 + (threadIdx.x & 15)][0]; s2 += red[k * 16 + (threadIdx.x & 15)][1]; }
+  return true;
+}
+
+// forward finalize: block = (group g, 16-channel chunk)
+__global__ __launch_bounds__(256) void k_norm_finalize(const double* __restrict__ partial, int nb, int G, int C,
+                                                       long long rows_per_group, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ running_mean,
+                                                       float* __restrict__ running_var, float momentum, float eps,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
+                                                       float* __restrict__ shift) {
+  const int chunks = C >> 4;
+  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), slot = threadIdx.x >> 4;
+  double s1, s2;
+  if (!reduce_partials(partial, nb, C, g, c, slot, s1, s2)) return;
+  const int idx = g * C + c;
   const double n = (double)rows_per_group;
   const double m = s1 / n;
   double var = s2 / n - m * m;
@@ -136,18 +154,15 @@ __global__ void k_norm_finalize(const double* __restrict__ partial, int nb, int 
 }
 
 // backward finalize: dgamma/dbeta (+= or =) and the two per-(g,c) means used by the apply pass
-__global__ void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, int G, int C, long long rows_per_group,
-                                    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-                                    float* __restrict__ c1, float* __restrict__ c2) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= G * C) return;
-  const int g = idx / C, c = idx % C;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nb; ++b) {
-    const double* p = partial + (((long long)g * nb + b) * C + c) * 2;
-    s1 += p[0];
-    s2 += p[1];
-  }
+__global__ __launch_bounds__(256) void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, int G, int C,
+                                                           long long rows_per_group, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate, float* __restrict__ c1,
+                                                           float* __restrict__ c2) {
+  const int chunks = C >> 4;
+  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), slot = threadIdx.x >> 4;
+  double s1, s2;
+  if (!reduce_partials(partial, nb, C, g, c, slot, s1, s2)) return;
+  const int idx = g * C + c;
   c1[idx] = (float)(s1 / (double)rows_per_group);
   c2[idx] = (float)(s2 / (double)rows_per_group);
   if (dgamma && g == 0) {
@@ -163,12 +178,13 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
                                                     const float* __restrict__ residual, NormEpilogue ep, long long rows,
                                                     long long rows_per_group, int C, float* __restrict__ out) {
   const int C4 = C >> 2;
+  const int c4_shift = 31 - __clz(C4);   // C is a power of two (checked on the host)
   const long long nvec = rows * C4;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const long long row = i / C4;
-    const int col = (int)(i - row * C4);
-    const long long g = row / rows_per_group;
+    const long long row = i >> c4_shift;
+    const int col = (int)(i & (C4 - 1));
+    const long long g = (rows_per_group == rows) ? 0 : row / rows_per_group;
     const float4 v = ld4(y + i * 4);
     const float4 sc = ld4(scale + g * C + col * 4), sh = ld4(shift + g * C + col * 4), mu = ld4(mean + g * C + col * 4);
     float o[4] = {act_fwd((v.x - mu.x) * sc.x + sh.x, ep.act), act_fwd((v.y - mu.y) * sc.y + sh.y, ep.act),
@@ -198,12 +214,13 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
                                                         NormEpilogue ep, long long rows, long long rows_per_group, int C,
                                                         float* __restrict__ dy) {
   const int C4 = C >> 2;
+  const int c4_shift = 31 - __clz(C4);   // C is a power of two (checked on the host)
   const long long nvec = rows * C4;
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const long long row = i / C4;
-    const int col = (int)(i - row * C4);
-    const long long g = row / rows_per_group;
+    const long long row = i >> c4_shift;
+    const int col = (int)(i & (C4 - 1));
+    const long long g = (rows_per_group == rows) ? 0 : row / rows_per_group;
     const long long gc = g * C + col * 4;
     const float4 v = ld4(y + i * 4), d4 = ld4(da + i * 4);
     const float4 sc = ld4(scale + gc), sh = ld4(shift + gc), mu = ld4(mean + gc), rs = ld4(rstd + gc);
@@ -261,7 +278,7 @@ extern "C" size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int 
 
 static int check_norm_args(const char* fn, int G, long long rows_per_group, int C) {
   BCP_REQUIRE(G >= 1 && rows_per_group >= 1, "%s: bad extents", fn);
-  BCP_REQUIRE(C >= 16 && C <= 1024 && (C % 4) == 0 && 256 % (C / 4) == 0, "%s: C=%d unsupported (need C in {16,32,64,...,1024})", fn, C);
+  BCP_REQUIRE(C >= 16 && C <= 1024 && (C & (C - 1)) == 0, "%s: C=%d unsupported (need a power of two in 16..1024)", fn, C);
   return BCP_OK;
 }
 
@@ -280,7 +297,7 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   hipLaunchKernelGGL((k_col_partial<0>), dim3(nb, G), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, rows_per_group, C, partial);
-  hipLaunchKernelGGL(k_norm_finalize, dim3(cdiv(G * C, 256)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
+  hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
   const long long rows = (long long)G * rows_per_group;
   hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, scale, shift, mean, residual, ep, rows,
@@ -305,7 +322,7 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   float* c2 = c1 + (long long)G * C;
   hipLaunchKernelGGL((k_col_partial<1>), dim3(nb, G), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, rows_per_group, C,
                      partial);
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(cdiv(G * C, 256)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
                      dbeta, accumulate, c1, c2);
   const long long rows = (long long)G * rows_per_group;
   hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, da, scale, shift, mean, rstd, c1,

@@ -1,0 +1,161 @@
+"""The BCP self-training step as the reference's loops run it (LA_BCP_train.py:233-276,
+pancreas/train_pancreas.py:144-171, ACDC_BCP_train.py:353-390), expressed over the drop-in API.
+bench.py, the train scripts and the parity tests all call these functions, so the thing that is timed
+is the thing that is tested.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import hip_ops as H
+from .hip_ops import Ops
+from .utils import BCP_utils as BU
+
+
+def _ops_for(t):
+    return BU._ops_for(t)
+
+
+# ------------------------------------------------------------------------------------------ pseudo labels
+def get_cut_mask(out, thres=0.5, nms=0, connect_mode=None):
+    """LA_BCP_train.py:57-63 / pancreas_utils.py:275-281: softmax -> (p>=thres) -> channel 1 [-> largest CC].
+    Returns uint8 [N,X,Y,Z] on the device (the reference returns int64 / float32 of the same values);
+    connect_mode None = full connectivity (skimage default, 26), 2 = 18, 1 = 6."""
+    cl = BU._as_cl(out)
+    ops = _ops_for(cl)
+    seg = ops.plabel_bin(cl, thres)
+    if nms:
+        conn = {None: 3, 3: 3, 2: 2, 1: 1}[connect_mode]
+        seg = ops.cc_largest(seg, 1, conn)
+    return seg
+
+
+def get_ACDC_masks(output, nms=0):
+    """ACDC_BCP_train.py:112-117: softmax -> argmax [-> per-class largest 8-connected component] -> uint8 [N,H,W]"""
+    cl = BU._as_cl(output)
+    ops = _ops_for(cl)
+    seg = ops.plabel_argmax4(cl)            # [N,1,H,W]
+    if nms:
+        seg = ops.cc_largest(seg, 3, 2)
+    return seg.view(seg.shape[0], seg.shape[2], seg.shape[3])
+
+
+# ------------------------------------------------------------------------------------------ optimisers
+class FlatSGD:
+    """torch.optim.SGD(momentum, weight_decay) semantics (LA_BCP_train.py:218) as ONE launch over the flat
+    trainable buffer of a HipNet; parameters whose grad is None in the reference (the unused heads) are
+    outside that buffer, exactly as torch skips them."""
+
+    def __init__(self, model, lr=0.01, momentum=0.9, weight_decay=1e-4):
+        self.model = model
+        self.param_groups = [{"lr": lr, "momentum": momentum, "weight_decay": weight_decay}]
+        self.buf = None
+        self.steps = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def step(self):
+        g = self.param_groups[0]
+        p, gr = self.model.flat_trainable()
+        if self.buf is None:
+            self.buf = torch.zeros_like(p)
+        _ops_for(p).sgd(p, gr, self.buf, g["lr"], g["momentum"], g["weight_decay"], first_step=(self.steps == 0), grad_scale=self.grad_scale)
+        self.steps += 1
+        self.model.bump()
+
+    def state_dict(self):
+        return {"buf": self.buf, "steps": self.steps, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        self.buf, self.steps, self.param_groups = sd["buf"], sd["steps"], sd["param_groups"]
+
+
+class FlatAdam:
+    """torch.optim.Adam(lr) defaults (pancreas/dataloaders.py:182) over the flat trainable buffer"""
+
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        self.model = model
+        self.param_groups = [{"lr": lr, "betas": betas, "eps": eps}]
+        self.m = self.v = None
+        self.steps = 0
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    def step(self):
+        g = self.param_groups[0]
+        p, gr = self.model.flat_trainable()
+        if self.m is None:
+            self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
+        self.steps += 1
+        _ops_for(p).adam(p, gr, self.m, self.v, g["lr"], self.steps, g["betas"][0], g["betas"][1], g["eps"], grad_scale=self.grad_scale)
+        self.model.bump()
+
+
+# ------------------------------------------------------------------------------------------ LA / pancreas step
+def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
+                       u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None):
+    """One self-training iteration, LA_BCP_train.py:235-270 (variant 'pancreas': train_pancreas.py:145-171).
+
+    volume_batch [B,1,X,Y,Z] float32 laid out lab_a|lab_b|unlab_a|unlab_b, label_batch [B,X,Y,Z].
+    box: explicit (w,h,z,pw,ph,pz) for parity runs, else drawn by context_mask from np.random as the
+    reference does.  drops: optional injected Dropout3d keep-masks {'t_a','t_b','s_l','s_u'}.
+    dp: optional bcp_amd.dp.DataParallel (gradient all-reduce before the optimiser step).
+    Returns device scalars; nothing here synchronises with the host."""
+    sub_bs = int(labeled_bs / 2)
+    img_a, img_b = volume_batch[:sub_bs], volume_batch[sub_bs:labeled_bs]
+    lab_a, lab_b = label_batch[:sub_bs], label_batch[sub_bs:labeled_bs]
+    unimg_a, unimg_b = volume_batch[labeled_bs:labeled_bs + sub_bs], volume_batch[labeled_bs + sub_bs:]
+    drops = drops or {}
+    with torch.no_grad():
+        ema_model.drop_masks = drops.get("t_a")
+        unoutput_a = ema_model(unimg_a)[0]
+        ema_model.drop_masks = drops.get("t_b")
+        unoutput_b = ema_model(unimg_b)[0]
+        plab_a = get_cut_mask(unoutput_a, nms=1, connect_mode=connect_mode)
+        plab_b = get_cut_mask(unoutput_b, nms=1, connect_mode=connect_mode)
+        if box is None:
+            if variant == "la":
+                img_mask, loss_mask = BU.context_mask(img_a, mask_ratio)
+            else:
+                from .pancreas.pancreas_utils import generate_mask
+                img_mask, loss_mask = generate_mask(img_a, 64)
+        else:
+            sp = tuple(volume_batch.shape[2:])
+            img_mask = BU.BoxMask(box, sp, None, False, volume_batch.device)
+            loss_mask = BU.BoxMask(box, sp, sub_bs, False, volume_batch.device)
+    if variant == "la":
+        mixl_img = img_a * img_mask + unimg_a * (1 - img_mask)
+        mixu_img = unimg_b * img_mask + img_b * (1 - img_mask)
+    else:  # pancreas direction table, train_pancreas.py:155-156
+        mixl_img = unimg_a * img_mask + img_b * (1 - img_mask)
+        mixu_img = img_a * img_mask + unimg_b * (1 - img_mask)
+    model.drop_masks = drops.get("s_l")
+    outputs_l = model(mixl_img)[0]
+    if variant == "la":
+        loss_l = BU.mix_loss(outputs_l, lab_a, plab_a, loss_mask, u_weight=u_weight)
+    else:
+        loss_l = BU.mix_loss(outputs_l, plab_a, lab_b, loss_mask, unlab=True)
+    model.drop_masks = drops.get("s_u")
+    outputs_u = model(mixu_img)[0]
+    if variant == "la":
+        loss_u = BU.mix_loss(outputs_u, plab_b, lab_b, loss_mask, u_weight=u_weight, unlab=True)
+    else:
+        loss_u = BU.mix_loss(outputs_u, lab_a, plab_b, loss_mask)
+    loss = loss_l + loss_u
+    optimizer.zero_grad()
+    loss.backward()
+    if dp is not None:
+        dp.allreduce_grads(model, optimizer)
+    optimizer.step()
+    BU.update_ema_variables(model, ema_model, alpha)
+    model.drop_masks = None
+    ema_model.drop_masks = None
+    return dict(loss=loss.detach(), loss_l=loss_l.detach(), loss_u=loss_u.detach(), plab_a=plab_a, plab_b=plab_b,
+                outputs_l=outputs_l.detach(), outputs_u=outputs_u.detach())

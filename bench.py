@@ -1,0 +1,175 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric: training volumes/sec of the BCP self-training step on the LA 3-D V-Net
+(112x112x80 patches), per-GPU batch 4 (2 labeled + 2 unlabeled; BASELINE.json configs[1]), synthetic data,
+fp32, random-init weights, everything inside the timed region that the reference's loop does per iteration
+(LA_BCP_train.py:235-270): teacher forward x2, pseudo-label + largest-CC x2, box draw, copy-paste mix x2,
+student forward x2, masked Dice+CE x2, backward, [gradient all-reduce when N>1], SGD, EMA.
+
+  python bench.py [--gpus N --steps K --warmup W]
+  N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (k_conv3_mfma, the fp32-MFMA implicit-GEMM
+3x3x3 conv at the 16->16 @112x112x80 layer: 13.87 GFLOP algorithmic per launch) timed with HIP events on
+the launch stream in this process; `cpu_baseline` = the oracle (CPU restatement of the reference,
+oracle/bcp_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+STEP_GFLOP_PER_VOLUME = 160.0       # 1/2 teacher fwd + 1/2 student fwd+bwd per input volume
+
+
+def build_models(dev, seed):
+    from bcp_amd.networks.net_factory import net_factory
+    torch.manual_seed(seed)
+    model = net_factory(net_type="VNet", in_chns=1, class_num=2, mode="train")
+    ema_model = net_factory(net_type="VNet", in_chns=1, class_num=2, mode="train")
+    for p in ema_model.parameters():
+        p.detach_()
+    ema_model.load_state_dict(model.state_dict())   # the reference loads both from the same checkpoint (LA:220-222)
+    model.train()
+    ema_model.train()
+    return model, ema_model
+
+
+def dominant_kernel_roofline(dev):
+    """k_conv3_mfma<3,4,4,16,1,27> at the block_nine shape, HIP events on the launch stream"""
+    from bcp_amd.hip_ops import Ops
+    ops = Ops.product()
+    sp, C = (112, 112, 80), 16
+    x = torch.randn(1, *sp, C, device=dev)
+    w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
+    b = torch.zeros(C, device=dev)
+    wf, _ = ops.conv3_pack(w, 3)
+    y = torch.empty(1, *sp, C, device=dev)
+    for _ in range(3):
+        ops.conv3_fwd(x, wf, b, C, 3, out=y)
+    e0, e1 = ops.event(), ops.event()
+    iters = 20
+    ops.event_record(e0, x)
+    for _ in range(iters):
+        ops.conv3_fwd(x, wf, b, C, 3, out=y)
+    ops.event_record(e1, x)
+    ms = ops.event_elapsed_ms(e0, e1) / iters
+    flops = 2.0 * sp[0] * sp[1] * sp[2] * 27 * C * C
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "k_conv3_mfma<3,4,4,16,1,27> 16->16 @112x112x80", "achieved": round(ach, 2),
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            "flop_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": None}
+
+
+def cpu_baseline(batch, labeled_bs):
+    """the oracle's self-training step on the host cores: 1 warm-up + timed steps until ~20 s"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import bcp_oracle as O  # checker / baseline only
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shapes = O.vnet_param_shapes()
+    Ps = O.init_params(shapes, seed=1337)
+    Pt = {k: v.clone() for k, v in Ps.items()}
+    tkeys = O.trainable_keys(shapes)
+    vol, lab = O.synth_la_batch(batch, seed=1337)
+    rng = np.random.default_rng(0)
+    box = O.box_la(lambda lo, hi: int(rng.integers(lo, hi)))
+    bufs = {}
+    times = []
+    t_start = time.time()
+    for it in range(4):
+        drops = {k: {"x5": torch.from_numpy((rng.random((labeled_bs // 2, 256)) < 0.5).astype(np.float32)),
+                     "x9": torch.from_numpy((rng.random((labeled_bs // 2, 16)) < 0.5).astype(np.float32))} for k in ("t_a", "t_b", "s_l", "s_u")}
+        t0 = time.time()
+        r = O.la_self_train_step(Ps, Pt, vol, lab, box, drops, labeled_bs // 2)
+        O.sgd_step(Ps, r["grads"], bufs, tkeys, lr=0.01)
+        O.ema_params(Ps, Pt, tkeys, 0.99)
+        times.append(time.time() - t0)
+        if it >= 1 and time.time() - t_start > 20:
+            break
+    steady = times[1:] if len(times) > 1 else times
+    sec = float(np.median(steady))
+    return {"value": round(batch / sec, 3), "unit": "volumes/s", "cores": cores, "kind": "port",
+            "sample": f"{len(steady)} timed self-train step(s) (batch {batch}, 112x112x80) after 1 warm-up, torch-CPU oracle, {cores} threads",
+            "sec_per_step": round(sec, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch_size", type=int, default=4, help="per-GPU batch (BASELINE.json configs[1]: 4)")
+    ap.add_argument("--labeled_bs", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from bcp_amd import synth, train_step
+    from bcp_amd.dp import DataParallel
+    from bcp_amd.hip_ops import Ops
+
+    dp = DataParallel()
+    assert dp.world == args.gpus or (args.gpus == 1 and dp.world == 1), f"--gpus {args.gpus} but WORLD_SIZE={dp.world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev = torch.device("cuda", dp.local_rank)
+    torch.cuda.set_device(dev)
+    Ops.product()
+    seed = 1337 + dp.rank
+    np.random.seed(seed)            # context_mask draws from the global numpy RNG as the reference does
+    model, ema_model = build_models(dev, 1337)
+    dp.broadcast_params(model)
+    dp.broadcast_params(ema_model)
+    opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    vol, lab = synth.la_batch(args.batch_size, seed=seed)
+    vol, lab = vol.to(dev), lab.to(dev)
+
+    def step():
+        return train_step.la_self_train_step(model, ema_model, opt, vol, lab, args.labeled_bs, dp=dp if dp.enabled else None)
+
+    for _ in range(args.warmup):
+        step()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    dp.barrier()
+    dt = time.perf_counter() - t0
+    dt = dp.max_over_ranks(dt)
+    loss = float(r["loss"])
+    assert np.isfinite(loss), "non-finite loss in the timed region"
+
+    if dp.rank == 0:
+        ms = dt / args.steps * 1e3
+        global_batch = args.batch_size * dp.world
+        value = global_batch * args.steps / dt
+        roof = dominant_kernel_roofline(dev)
+        step_tflops = value * STEP_GFLOP_PER_VOLUME / 1e3 / dp.world
+        out = {
+            "metric": "training volumes/sec (LA 112x112x80 V-Net, BCP self-training step)",
+            "value": round(value, 3), "unit": "volumes/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"LA 3D V-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), "
+                                   "112x112x80 patches, SGD m0.9 wd1e-4, EMA 0.99 (BASELINE.json configs[1])",
+                       "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6)},
+            "roofline": roof,
+            "step_flops": {"gflop_per_volume": STEP_GFLOP_PER_VOLUME, "achieved_tflops_per_gpu": round(step_tflops, 2),
+                           "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
+        }
+        if dp.world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch_size, args.labeled_bs)
+        print(json.dumps(out), flush=True)
+    dp.shutdown()
+
+
+if __name__ == "__main__":
+    main()

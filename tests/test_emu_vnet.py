@@ -18,3 +18,7 @@ def test_vnet_la_smooth_grads(emu_ops):
 
 def test_vnet_pancreas_smooth(emu_ops):
     NC.check_vnet_smooth(emu_ops, CPU, shape=(32, 32, 32), variant="pancreas")
+
+
+def test_la_self_train_trajectory(emu_ops, golden_dir):
+    NC.check_la_step(emu_ops, CPU, golden_dir)

@@ -1,0 +1,70 @@
+"""-m gpu: the HIP V-Net and the LA self-training step on a real MI355X vs the oracle and the golden vectors
+captured from the reference (same checks as tests/test_emu_vnet.py, plus config-shape cases)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bcp_oracle as O
+import kernel_checks as K
+import net_checks as NC
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bcp_amd.hip_ops import Ops
+    return Ops.product()
+
+
+def test_vnet_la_golden_tiny(ops, golden_dir):
+    NC.check_vnet_golden_tiny(ops, DEV, golden_dir)
+
+
+def test_vnet_la_smooth_grads(ops):
+    NC.check_vnet_smooth(ops, DEV, shape=(48, 48, 32), N=2)
+
+
+def test_vnet_pancreas_smooth(ops):
+    NC.check_vnet_smooth(ops, DEV, shape=(32, 32, 32), variant="pancreas")
+
+
+def test_la_self_train_trajectory(ops, golden_dir):
+    NC.check_la_step(ops, DEV, golden_dir)
+
+
+def test_vnet_la_full_shape_vs_reference_golden(ops, golden_dir):
+    """112x112x80 forward + backward vs the checksums recorded from the reference (vnet_la_full.npz)"""
+    g = np.load(os.path.join(golden_dir, "vnet_la_full.npz"))
+    m = json.load(open(os.path.join(golden_dir, "meta.json")))["vnet_la_full"]
+    P = O.init_params(O.vnet_param_shapes(), seed=m["param_seed"], random_affine=True)
+    x, lab = O.synth_la_batch(1, seed=m["data_seed"])
+    net = NC.make_vnet(P, DEV, ops)
+    net.drop_masks = {"x5": torch.from_numpy(g["drop_x5"]), "x9": torch.from_numpy(g["drop_x9"])}
+    out, _ = net(x.to(DEV))
+    from bcp_amd.utils import BCP_utils as BU
+    loss = BU.sup_loss(out, lab.to(DEV))
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5, (float(loss.detach()), float(g["loss"]))
+    o = out.detach().double().reshape(-1).cpu()
+    st = g["logits_stats"]
+    assert abs(float(o.abs().sum()) - st[1]) / st[1] < 1e-5 and abs(float((o * o).sum().sqrt()) - st[2]) / st[2] < 1e-5
+    idx = torch.linspace(0, o.numel() - 1, 4096).long()
+    K.close(out.detach().reshape(-1).cpu()[idx], torch.from_numpy(g["logits_sample"]), rtol=2e-4, msg="logits sample")
+    # Dice of the thresholded prediction vs the synthetic label: HIP vs reference-arithmetic oracle (north_star: 1e-4)
+    Po = {k: v.clone() for k, v in P.items()}
+    oo = O.vnet_forward(Po, x, {"x5": torch.from_numpy(g["drop_x5"]), "x9": torch.from_numpy(g["drop_x9"])}, True, "la")
+    d_ref = O.dice_metric(O.get_cut_mask(oo), lab)
+    from bcp_amd import train_step
+    d_hip = O.dice_metric(train_step.get_cut_mask(out.detach()).cpu(), lab)
+    assert abs(d_ref - d_hip) < 1e-4, (d_ref, d_hip)
+    loss.backward()
+    params = dict(net.named_parameters())
+    for n_, stg in zip([str(n) for n in g["grad_names"]], g["grad_stats"]):
+        if NC.is_prenorm_bias(n_, params):
+            continue
+        l2 = float(params[n_].grad.double().norm())
+        assert abs(l2 - stg[2]) / max(stg[2], 1e-12) < 3e-2, (n_, l2, stg[2])
