@@ -87,22 +87,26 @@ class HipNet(nn.Module):
         return list(self.parameters())
 
     def flatten_(self):
-        """(re)locate every parameter inside one contiguous fp32 buffer, in registration order"""
+        """(re)locate every parameter AND every float buffer (BN running stats) inside one contiguous fp32 buffer:
+        [ optimiser parameters | other parameters (unused heads) | float buffers ], registration order inside
+        each part.  One launch then covers SGD (first part), the parameter EMA (first two) or the state_dict EMA
+        of the ACDC script (all three)."""
         ps = self._ordered_params()
+        bufs = [b for b in self.buffers() if b.is_floating_point()]
         dev = ps[0].device
-        total = sum(p.numel() for p in ps)
-        # 16-B alignment of every view: pad each tensor to a multiple of 4 floats
+        items = list(ps) + bufs
         offs, off = [], 0
-        for p in ps:
+        for t in items:
             offs.append(off)
-            off += (p.numel() + 3) // 4 * 4
+            off += (t.numel() + 3) // 4 * 4      # 16-B alignment of every view
         flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        for p, o in zip(ps, offs):
-            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
-            p.data = flat[o:o + p.numel()].view(p.shape)
+        for t, o in zip(items, offs):
+            flat[o:o + t.numel()].copy_(t.data.reshape(-1))
+            t.data = flat[o:o + t.numel()].view(t.shape)
         self._flat = flat
-        self._flat_grad = torch.zeros_like(flat)
-        self._offs = {id(p): o for p, o in zip(ps, offs)}
+        self._offs = {id(t): o for t, o in zip(items, offs)}
+        self._n_param_flat = offs[len(ps)] if bufs else off
+        self._flat_grad = torch.zeros(self._n_param_flat, dtype=torch.float32, device=dev)
         n_train = 0
         for p, o in zip(ps, offs):
             if id(p) in self._opt_param_ids:
@@ -119,8 +123,20 @@ class HipNet(nn.Module):
             last = ps[-1]
             if last.data_ptr() != self._flat.data_ptr() + 4 * self._offs[id(last)]:
                 self.flatten_()
+            else:
+                for b in self.buffers():
+                    if b.is_floating_point():
+                        if b.data_ptr() != self._flat.data_ptr() + 4 * self._offs.get(id(b), -1):
+                            self.flatten_()
+                        break
 
     def flat_params(self):
+        """all parameters (optimiser part + unused heads): what `for p in model.parameters()` walks"""
+        self._ensure_flat()
+        return self._flat[:self._n_param_flat]
+
+    def flat_state(self):
+        """parameters + float buffers: what state_dict() holds, minus the int64 num_batches_tracked"""
         self._ensure_flat()
         return self._flat
 
@@ -158,17 +174,19 @@ class HipNet(nn.Module):
             for p in ps:
                 p.grad = self.grad_view(p)
 
-    # num_batches_tracked is bumped on the host and flushed lazily (29 tiny device ops per forward otherwise)
+    # num_batches_tracked: every live BN layer is bumped once per training forward, so ONE host-side integer
+    # stands for all of them and is written to the buffers only when a state_dict is taken (29 tiny device ops
+    # per forward otherwise).  momentum is fixed (0.1), so the value never feeds back into the arithmetic.
     def _nbt_tick(self):
-        self._nbt_pending = getattr(self, "_nbt_pending", 0) + 1
+        self._nbt = getattr(self, "_nbt", 0) + 1
+        self._nbt_dirty = True
 
     def flush_nbt(self):
-        n = getattr(self, "_nbt_pending", 0)
-        if n:
+        if getattr(self, "_nbt_dirty", False):
             for m in self.modules():
                 if isinstance(m, BNP) and getattr(m, "_live", False):
-                    m.num_batches_tracked += n
-            self._nbt_pending = 0
+                    m.num_batches_tracked.fill_(self._nbt)
+            self._nbt_dirty = False
 
     def state_dict(self, *a, **k):
         self.flush_nbt()
@@ -185,6 +203,11 @@ class HipNet(nn.Module):
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self._bump += 1
+        for m in self.modules():
+            if isinstance(m, BNP) and getattr(m, "_live", False):
+                self._nbt = int(m.num_batches_tracked)
+                self._nbt_dirty = False
+                break
         return r
 
     def next_seed(self):

@@ -1,0 +1,191 @@
+"""2-D U-Net on the MI355X kernels -- drop-in for the reference's networks/unet.py:UNet_2d (ACDC).
+
+Same constructor, same 226 state_dict keys / parameter order, `net(x) -> logits [N,4,H,W]`.  Layout is NHWC
+fp32 ([N,1,H,W,C] physically: the 3-D kernels run with D = 1, KD = 1).
+
+Topology (networks/unet.py:15-57, 80-86, 104-116): ConvBlock = conv3x3 -> BN -> LeakyReLU(0.01) -> Dropout(p) ->
+conv3x3 -> BN -> LeakyReLU; encoder in_conv(1->16, p=.05), down1..4 = MaxPool2d(2) + ConvBlock (32,64,128,256;
+p = .1,.2,.3,.5); decoder up1..4 = conv1x1 (halve C) -> bilinear x2 (align_corners=True) -> cat([skip, up]) ->
+ConvBlock(p=0); out_conv 3x3 16->4.  The upsample writes directly into its half of the concat buffer.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import hip_ops as H
+from ._hipnet import BNP, ConvP, HipNet, Holder, NetFn, Seq, contrastive_heads
+
+FT = [16, 32, 64, 128, 256]
+DROP = [0.05, 0.1, 0.2, 0.3, 0.5]
+
+
+class _CB:
+    """one ConvBlock: two (conv, bn) pairs + its dropout probability and mask key"""
+
+    def __init__(self, cin, cout, p, dkey):
+        self.cin, self.cout, self.p, self.dkey = cin, cout, p, dkey
+        self.c1, self.b1 = ConvP((cout, cin, 3, 3), cin * 9, cout), BNP(cout)
+        self.c2, self.b2 = ConvP((cout, cout, 3, 3), cout * 9, cout), BNP(cout)
+        self.b1._live = self.b2._live = True
+
+    def module(self):
+        h = Holder()
+        h.conv_conv = Seq([(0, self.c1), (1, self.b1), (4, self.c2), (5, self.b2)])
+        return h
+
+
+class UNet_2d(HipNet):
+    def __init__(self, in_chns, class_num):
+        super().__init__()
+        assert in_chns == 1, "the ACDC hot path is single-channel"
+        self.n_classes = class_num
+        enc, dec = Holder(), Holder()
+        self._enc = [_CB(in_chns, FT[0], DROP[0], "d0")] + [_CB(FT[i - 1], FT[i], DROP[i], f"d{i}") for i in range(1, 5)]
+        enc.in_conv = self._enc[0].module()
+        for i in range(1, 5):
+            d = Holder()
+            d.maxpool_conv = Seq([(1, self._enc[i].module())])
+            setattr(enc, f"down{i}", d)
+        self._up = []
+        for i in range(1, 5):
+            c1, c2 = FT[5 - i], FT[4 - i]
+            u = Holder()
+            pw = ConvP((c2, c1, 1, 1), c1, c2)
+            cb = _CB(2 * c2, c2, 0.0, None)
+            u.conv1x1 = pw
+            u.conv = cb.module()
+            setattr(dec, f"up{i}", u)
+            self._up.append((pw, cb, c1, c2))
+        dec.out_conv = ConvP((class_num, FT[0], 3, 3), FT[0] * 9, class_num)
+        self.encoder, self.decoder = enc, dec
+        contrastive_heads(self, 4)
+        object.__setattr__(self, "_out", dec.out_conv)
+        ids = set()
+        for cb in self._enc + [u[1] for u in self._up]:
+            for m in (cb.c1, cb.b1, cb.c2, cb.b2):
+                ids.add(id(m.weight)); ids.add(id(m.bias))
+        for pw, _, _, _ in self._up:
+            ids.add(id(pw.weight)); ids.add(id(pw.bias))
+        ids.add(id(self._out.weight)); ids.add(id(self._out.bias))
+        self._opt_param_ids = ids
+        self._prenorm_bias_ids = set(id(m.bias) for cb in self._enc + [u[1] for u in self._up] for m in (cb.c1, cb.c2))
+
+    # ------------------------------------------------------------------ public call
+    def forward(self, x):
+        N = x.shape[0]
+        assert x.dim() == 4 and x.shape[1] == 1, "expected [N,1,H,W]"
+        self._ensure_flat()
+        xcl = x.contiguous().view(N, 1, x.shape[2], x.shape[3], 1)
+        anchor = self._enc[0].c1.weight
+        if torch.is_grad_enabled() and anchor.requires_grad:
+            out = NetFn.apply(xcl, anchor, self)
+        else:
+            out, _ = self._forward_impl(xcl, save=False)
+        return out.permute(0, 4, 1, 2, 3).squeeze(2)   # logical [N,4,H,W]
+
+    # ------------------------------------------------------------------ pieces
+    def _elem_mask(self, cb, shape, dev):
+        if cb.p <= 0.0 or not self.training:
+            return None
+        if self.drop_masks is not None:
+            m = self.drop_masks[cb.dkey]                       # logical [N,C,H,W] keep mask
+            return m.to(dev).permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(torch.uint8)
+        m = torch.empty(shape, dtype=torch.uint8, device=dev)
+        return self.ops.bernoulli(m, 1.0 - cb.p, 1.0, self.next_seed())
+
+    def _convblock_fwd(self, cb, tag, h, save, saved):
+        ops = self.ops
+        if cb.cin == 1:
+            y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
+        else:
+            wf, _ = self._packed((tag, 1), cb.c1.weight, lambda: ops.conv3_pack(cb.c1.weight.data, 1))
+            y1 = ops.conv3_fwd(h, wf, cb.c1.bias.data, cb.cout, 1)
+        em = self._elem_mask(cb, y1.shape, h.device)
+        a1, st1 = ops.norm_fwd(y1, 1, cb.b1.weight.data, cb.b1.bias.data, cb.b1.running_mean, cb.b1.running_var, H.ACT_LRELU,
+                               elem_mask=em, elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
+        wf2, _ = self._packed((tag, 2), cb.c2.weight, lambda: ops.conv3_pack(cb.c2.weight.data, 1))
+        y2 = ops.conv3_fwd(a1, wf2, cb.c2.bias.data, cb.cout, 1)
+        a2, st2 = ops.norm_fwd(y2, 1, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU)
+        if save:
+            saved[tag] = (h, y1, st1, em, a1, y2, st2)
+        return a2
+
+    def _convblock_bwd(self, cb, tag, da2, saved, need_dx):
+        ops = self.ops
+        h, y1, st1, em, a1, y2, st2 = saved[tag]
+        dy2 = ops.norm_bwd(y2, da2, 1, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
+        ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
+        _, wd2 = self._packed((tag, 2), cb.c2.weight, lambda: ops.conv3_pack(cb.c2.weight.data, 1))
+        da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
+        dy1 = ops.norm_bwd(y1, da1, 1, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em,
+                           elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
+        if cb.cin == 1:
+            ops.conv3_c1_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
+            return None
+        ops.conv3_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
+        if not need_dx:
+            return None
+        _, wd1 = self._packed((tag, 1), cb.c1.weight, lambda: ops.conv3_pack(cb.c1.weight.data, 1))
+        return ops.conv3_fwd(dy1, wd1, None, cb.cin, 1)
+
+    # ------------------------------------------------------------------ schedule
+    def _forward_impl(self, xcl, save):
+        ops = self.ops
+        saved = {} if save else None
+        N = xcl.shape[0]
+        xs = [self._convblock_fwd(self._enc[0], "e0", xcl, save, saved)]
+        for i in range(1, 5):
+            pooled = ops.maxpool2d_fwd(xs[-1])
+            xs.append(self._convblock_fwd(self._enc[i], f"e{i}", pooled, save, saved))
+        h = xs[4]
+        for i, (pw, cb, c1, c2) in enumerate(self._up, start=1):
+            bp = self._packed((f"pw{i}", 0), pw.weight, lambda pw=pw, c1=c1, c2=c2: ops.k2_pack(pw.weight.data, c1, c2, H.PACK_PW_FWD))
+            z = ops.pw_fwd(h, bp, pw.bias.data, c2)
+            skip = xs[4 - i]
+            cat = torch.empty((N, 1, skip.shape[2], skip.shape[3], 2 * c2), dtype=torch.float32, device=xcl.device)
+            ops.copy_channels(skip, cat, c2, 0, 0)
+            ops.bilinear2x_fwd(z, cat, c2)
+            if save:
+                saved[f"pw{i}"] = (h,)
+            h = self._convblock_fwd(cb, f"u{i}", cat, save, saved)
+        wf, _ = self._packed(("out", 0), self._out.weight, lambda: ops.conv3_pack(self._out.weight.data, 1))
+        logits = ops.conv3_fwd(h, wf, self._out.bias.data, self.n_classes, 1)
+        if self.training:
+            self._nbt_tick()
+        if save:
+            saved["out"] = (h,)
+            saved["xs"] = xs
+        return logits, saved
+
+    def _backward_impl(self, saved, dout):
+        ops = self.ops
+        dlogits = dout if dout.is_contiguous() else dout.contiguous()
+        self.begin_backward()
+        (h_last,) = saved["out"]
+        xs = saved["xs"]
+        ops.conv3_wgrad(h_last, dlogits, self._out.weight.grad, 1, accumulate=True)
+        ops.colsum(dlogits, self._out.bias.grad, accumulate=True)
+        _, wd = self._packed(("out", 0), self._out.weight, lambda: ops.conv3_pack(self._out.weight.data, 1))
+        dh = ops.conv3_fwd(dlogits, wd, None, FT[0], 1)
+        skip_grads = {}
+        for i in range(4, 0, -1):
+            pw, cb, c1, c2 = self._up[i - 1]
+            dcat = self._convblock_bwd(cb, f"u{i}", dh, saved, True)          # [N,1,H,W,2*c2]
+            skip_grads[4 - i] = (dcat, c2)                                       # first c2 channels belong to xs[4-i]
+            dz = ops.bilinear2x_bwd(dcat, c2, c2)
+            (h_in,) = saved[f"pw{i}"]
+            ops.k2_wgrad(h_in, dz, pw.weight.grad, H.WG_PW, accumulate=True)
+            ops.colsum(dz, pw.bias.grad, accumulate=True)
+            bpd = self._packed((f"pw{i}", 1), pw.weight, lambda pw=pw, c1=c1, c2=c2: ops.k2_pack(pw.weight.data, c1, c2, H.PACK_PW_DGRAD))
+            dh = ops.pw_fwd(dz, bpd, None, c1)
+        # dh = gradient w.r.t. x4; walk the encoder upwards
+        for i in range(4, 0, -1):
+            dpool = self._convblock_bwd(self._enc[i], f"e{i}", dh, saved, True)
+            dx = torch.empty_like(xs[i - 1])
+            ops.maxpool2d_bwd(xs[i - 1], dpool, dx)
+            dcat, c2 = skip_grads[i - 1]
+            ops.copy_channels(dcat, dx, c2, 0, 0, accumulate=True)               # join the decoder-side skip gradient
+            dh = dx
+        self._convblock_bwd(self._enc[0], "e0", dh, saved, False)
+        return None

@@ -159,3 +159,83 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
     ema_model.drop_masks = None
     return dict(loss=loss.detach(), loss_l=loss_l.detach(), loss_u=loss_u.detach(), plab_a=plab_a, plab_b=plab_b,
                 outputs_l=outputs_l.detach(), outputs_u=outputs_u.detach())
+
+
+# ------------------------------------------------------------------------------------------ ACDC
+def generate_mask(img):
+    """ACDC_BCP_train.py:131-140: 2/3 x 2/3 zero box, two np.random.randint draws (w then h)."""
+    batch_size, channel, img_x, img_y = img.shape[0], img.shape[1], img.shape[2], img.shape[3]
+    patch_x, patch_y = int(img_x * 2 / 3), int(img_y * 2 / 3)
+    w = np.random.randint(0, img_x - patch_x)
+    h = np.random.randint(0, img_y - patch_y)
+    box = (w, h, patch_x, patch_y)
+    return BU.BoxMask(box, (img_x, img_y), None, False, img.device), BU.BoxMask(box, (img_x, img_y), batch_size, False, img.device)
+
+
+def acdc_mix_loss(output, img_l, patch_l, mask, l_weight=1.0, u_weight=0.5, unlab=False):
+    """ACDC_BCP_train.py:167-179 -> (loss_dice, loss_ce)"""
+    image_weight, patch_weight = l_weight, u_weight
+    if unlab:
+        image_weight, patch_weight = u_weight, l_weight
+    cl = BU._as_cl(output)
+    ops = _ops_for(cl)
+    N, sp = cl.shape[0], tuple(output.shape[2:])
+    box6, m8 = BU._mask_args(mask, ops, N, sp)
+    return BU._MixLossFn.apply(cl, BU._labels_u8(ops, img_l, N, sp), BU._labels_u8(ops, patch_l, N, sp), box6, m8, H.LOSS_ACDC,
+                               float(image_weight), float(patch_weight))
+
+
+@torch.no_grad()
+def update_model_ema(model, ema_model, alpha):
+    """ACDC_BCP_train.py:123-129: EMA over the whole state_dict (parameters AND BN buffers).  One launch over
+    the flat state; the int64 num_batches_tracked goes through float32 and is truncated, as load_state_dict does."""
+    src, dst = model.flat_state(), ema_model.flat_state()
+    _ops_for(dst).ema(dst, src, alpha)
+    ema_model.bump()
+    a, b = float(getattr(ema_model, "_nbt", 0)), float(getattr(model, "_nbt", 0))
+    ema_model._nbt = int(np.float32(np.float32(alpha) * np.float32(a)) + np.float32(np.float32(1 - alpha) * np.float32(b)))
+    ema_model._nbt_dirty = True
+
+
+def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
+                         u_weight=0.5, alpha=0.99, dp=None):
+    """One ACDC self-training iteration, ACDC_BCP_train.py:355-390."""
+    bs = volume_batch.shape[0]
+    lsub, usub = int(labeled_bs / 2), int((bs - labeled_bs) / 2)
+    img_a, img_b = volume_batch[:lsub], volume_batch[lsub:labeled_bs]
+    uimg_a, uimg_b = volume_batch[labeled_bs:labeled_bs + usub], volume_batch[labeled_bs + usub:]
+    lab_a, lab_b = label_batch[:lsub], label_batch[lsub:labeled_bs]
+    drops = drops or {}
+    with torch.no_grad():
+        ema_model.drop_masks = drops.get("t_a")
+        pre_a = ema_model(uimg_a)
+        ema_model.drop_masks = drops.get("t_b")
+        pre_b = ema_model(uimg_b)
+        plab_a = get_ACDC_masks(pre_a, nms=1)
+        plab_b = get_ACDC_masks(pre_b, nms=1)
+        if box is None:
+            img_mask, loss_mask = generate_mask(img_a)
+        else:
+            sp = tuple(volume_batch.shape[2:])
+            img_mask, loss_mask = BU.BoxMask(box, sp, None, False, volume_batch.device), BU.BoxMask(box, sp, lsub, False, volume_batch.device)
+    net_input_unl = uimg_a * img_mask + img_a * (1 - img_mask)
+    net_input_l = img_b * img_mask + uimg_b * (1 - img_mask)
+    model.drop_masks = drops.get("s_unl")
+    out_unl = model(net_input_unl)
+    unl_dice, unl_ce = acdc_mix_loss(out_unl, plab_a, lab_a, loss_mask, u_weight=u_weight, unlab=True)
+    model.drop_masks = drops.get("s_l")
+    out_l = model(net_input_l)
+    l_dice, l_ce = acdc_mix_loss(out_l, lab_b, plab_b, loss_mask, u_weight=u_weight)
+    loss_ce = unl_ce + l_ce
+    loss_dice = unl_dice + l_dice
+    loss = (loss_dice + loss_ce) / 2
+    optimizer.zero_grad()
+    loss.backward()
+    if dp is not None:
+        dp.allreduce_grads(model, optimizer)
+    optimizer.step()
+    update_model_ema(model, ema_model, alpha)
+    model.drop_masks = None
+    ema_model.drop_masks = None
+    return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach(), plab_a=plab_a, plab_b=plab_b,
+                out_unl=out_unl.detach(), out_l=out_l.detach())

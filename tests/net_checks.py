@@ -157,3 +157,122 @@ def check_la_step(ops, dev, golden_dir):
         a = sde[k].double()
         assert abs(float(a.abs().sum()) - st[1]) / max(st[1], 1e-9) < 1e-4, k
     K.close(sde["decoder.block_nine.conv.1.running_mean"], torch.from_numpy(g["final_ema_rm"]), rtol=1e-3, msg="teacher running_mean")
+
+
+# ------------------------------------------------------------------------------------------ U-Net / ACDC
+def make_unet(P, dev, ops):
+    from bcp_amd.networks.unet import UNet_2d
+    net = UNet_2d(in_chns=1, class_num=4).to(dev)
+    load_params(net, P).flatten_()
+    if dev.type == "cpu":
+        net.set_ops(ops)
+        BU.set_test_ops(ops)
+    net.train()
+    return net
+
+
+def _unpack(bits, shape):
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.unpackbits(bits)[:n].reshape(shape).astype(np.float32))
+
+
+def unet_drops(src, n, hw, prefix=None):
+    dm, off = {}, 0
+    for i, c in enumerate(O.UNET_CH):
+        shp = (n, c, hw[0] >> i, hw[1] >> i)
+        if prefix is not None:
+            dm[f"d{i}"] = _unpack(src[f"{prefix}{i}"], shp)
+        else:
+            nb = (int(np.prod(shp)) + 7) // 8
+            dm[f"d{i}"] = _unpack(src[off:off + nb], shp)
+            off += nb
+    return dm
+
+
+def check_unet_golden_tiny(ops, dev, golden_dir):
+    from bcp_amd import train_step
+    g = np.load(os.path.join(golden_dir, "unet_tiny.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "meta.json")))["unet_tiny"]
+    P = O.init_params(O.unet_param_shapes(), seed=meta["param_seed"], random_affine=True)
+    net = make_unet(P, dev, ops)
+    net.drop_masks = unet_drops(g, 2, (64, 64), prefix="drop_d")
+    out = net(torch.from_numpy(g["x"]).to(dev))
+    K.close(out, torch.from_numpy(g["logits"]), rtol=2e-4, msg="unet logits")
+    tgt = torch.from_numpy(g["tgt"]).to(dev)
+    w, h, pw, ph = meta["mask_box"]
+    lm = BU.BoxMask((w, h, pw, ph), (64, 64), 2, False, dev)
+    d, c = train_step.acdc_mix_loss(out, tgt, (tgt + 1) % 4, lm, u_weight=0.5)
+    loss = (d + c) / 2
+    assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5, (float(loss.detach()), float(g["loss"]))
+    loss.backward()
+    params = dict(net.named_parameters())
+    for n_, st in zip([str(n) for n in g["grad_names"]], g["grad_stats"]):
+        gr = params[n_].grad
+        assert gr is not None, n_
+        l2 = float(gr.double().norm())
+        if is_prenorm_bias(n_, params):
+            assert l2 <= 1e-6, (n_, l2)
+            continue
+        assert abs(l2 - st[2]) / max(st[2], 1e-12) < 3e-2, (n_, l2, st[2])
+    for key, name in (("grad_in_conv_w", "encoder.in_conv.conv_conv.0.weight"), ("grad_up4_1x1_w", "decoder.up4.conv1x1.weight"),
+                      ("grad_out_conv_w", "decoder.out_conv.weight")):
+        assert K.rel_l2(params[name].grad, torch.from_numpy(g[key])) < 3e-2, name
+    sd = net.state_dict()
+    K.close(sd["encoder.in_conv.conv_conv.1.running_var"], torch.from_numpy(g["rv_in"]), msg="running_var")
+
+
+def check_unet_smooth(ops, dev, hw=(64, 64), N=2, seed=4):
+    """all LeakyReLUs on their positive branch (beta = +5): gradients vs the fp64 oracle to 1e-4 per tensor"""
+    from bcp_amd import train_step
+    rng = np.random.default_rng(seed)
+    P = O.init_params(O.unet_param_shapes(), seed=seed + 100, random_affine=True)
+    for k in list(P):
+        if k.endswith(".bias") and (k[:-5] + ".running_mean") in P and "head" not in k and "selector" not in k:
+            P[k] = torch.full_like(P[k], 5.0)
+    x = torch.from_numpy(rng.random((N, 1) + hw, dtype=np.float32))
+    tgt = torch.from_numpy(rng.integers(0, 4, (N,) + hw))
+    dm = {f"d{i}": torch.from_numpy((rng.random((N, c, hw[0] >> i, hw[1] >> i)) >= p).astype(np.float32)) for i, (c, p) in enumerate(zip(O.UNET_CH, O.UNET_DROP))}
+    box = (5, 9, int(hw[0] * 2 / 3), int(hw[1] * 2 / 3))
+    _, lm = O.box_to_mask(box, hw, N)
+    Pd = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in P.items()}
+    Q = O._with_grad(Pd, set(O.trainable_keys(Pd)))
+    o64 = O.unet_forward(Q, x.double(), dm, True)
+    d, c = O.mix_loss_acdc(o64, tgt, (tgt + 1) % 4, lm, u_weight=0.5, unlab=True)
+    ((d + c) / 2).backward()
+    net = make_unet(P, dev, ops)
+    net.drop_masks = dm
+    out = net(x.to(dev))
+    dd, cc = train_step.acdc_mix_loss(out, tgt.to(dev), ((tgt + 1) % 4).to(dev), BU.BoxMask(box, hw, N, False, dev), u_weight=0.5, unlab=True)
+    ((dd + cc) / 2).backward()
+    assert K.rel_l2(out, o64.detach()) < 1e-4
+    assert abs(float(dd.detach()) - float(d)) < 1e-5 and abs(float(cc.detach()) - float(c)) < 1e-5
+    params = dict(net.named_parameters())
+    for k in O.trainable_keys(P):
+        gref = Q[k].grad
+        if gref is None or is_prenorm_bias(k, params) or float(gref.norm()) < 1e-7:
+            continue
+        r = K.rel_l2(params[k].grad, gref)
+        assert r < 1e-4, (k, r)
+
+
+def check_acdc_step(ops, dev, golden_dir):
+    from bcp_amd import train_step
+    g = np.load(os.path.join(golden_dir, "acdc_traj.npz"))
+    m = json.load(open(os.path.join(golden_dir, "meta.json")))["acdc_traj"]
+    P = O.init_params(O.unet_param_shapes(), seed=m["param_seed"], random_affine=True)
+    model, ema = make_unet(P, dev, ops), make_unet(P, dev, ops)
+    for p in ema.parameters():
+        p.detach_()
+    vol, lab = O.synth_acdc_batch(8, shape=tuple(m["shape"]), seed=m["data_seed"])
+    vol, lab = vol.to(dev), lab.to(dev)
+    opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for it in range(m["steps"]):
+        drops = {k: unet_drops(g["dropbits"][it, j], 2, tuple(m["shape"])) for j, k in enumerate(("t_a", "t_b", "s_unl", "s_l"))}
+        r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=tuple(int(v) for v in g["boxes"][it]), drops=drops)
+        ref = g["traj"][it]
+        tol = (1e-5, 2e-4)[it]
+        assert abs(float(r["loss"]) - ref[0]) < tol and abs(float(r["loss_dice"]) - ref[1]) < tol and abs(float(r["loss_ce"]) - ref[2]) < tol, (it, float(r["loss"]), ref)
+        for key, j in (("plab_a", 3), ("plab_b", 4)):
+            assert abs(float(r[key].float().sum()) - ref[j]) <= max(2.0, 0.01 * ref[j]), (it, key)
+    sde = ema.state_dict()
+    K.close(sde["encoder.in_conv.conv_conv.1.running_mean"], torch.from_numpy(g["final_ema_rm"]), rtol=1e-3, msg="teacher running_mean")
