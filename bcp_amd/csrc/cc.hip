@@ -2,13 +2,22 @@
 //
 // Reference: LargestCC_pancreas (LA_BCP_train.py:65-77, 26-connectivity; pancreas_utils.py:284-296,
 // connectivity=2 -> 18), get_ACDC_2DLargestCC (ACDC_BCP_train.py:89-109, 8-connectivity per class 1..3).
-// The reference copies every pseudo-label to the host, runs skimage.measure.label on one CPU
-// thread and copies back -- the pipeline stall of the step.  Here: lock-free union-find
-// (atomicMin link-to-smaller-root), so a component's root is its FIRST voxel in raster order;
-// "largest, ties -> lowest label id" (np.argmax(np.bincount(...)[1:])+1) therefore becomes one
-// 64-bit atomicMax on key = size<<32 | ~root.  Multi-class maps are labelled in one pass
-// (neighbours join only when their class is equal), which equals the reference's per-class loop
-// because classes are disjoint.  No host sync anywhere.
+// The reference copies every pseudo-label to the host, runs skimage.measure.label on one CPU thread and
+// copies back -- the pipeline stall of the step.  Here everything stays on the device, no host sync:
+//
+//   1. k_cc_local   one workgroup per 4x8x16 (2-D: 1x16x32) tile: union-find of the tile in LDS
+//                   (ds atomics), component sizes counted in LDS; writes L[v] = global index of the
+//                   voxel's tile-local root and lsize[root] = local component size.
+//   2. k_cc_border  unions across tile faces only (global atomicMin link-to-smaller-root).
+//   3. k_cc_count   one global atomicAdd per TILE-LOCAL root into its global root (a percolating blob
+//                   costs ~#tiles atomics on its root word instead of one per voxel).
+//   4. k_cc_select  roots only: 64-bit atomicMax on key = size<<32 | ~root.
+//   5. k_cc_write   keep voxels whose root is the selected one.
+//
+// Links always point to the smaller index, so a component's root is its FIRST voxel in raster order and
+// "largest, ties -> lowest label id" (np.argmax(np.bincount(labels.flat)[1:])+1 over raster-ordered labels)
+// is exactly the atomicMax above.  Multi-class maps are labelled in one pass (neighbours join only when
+// their class is equal) == the reference's per-class loop, because classes are disjoint.
 #include "common.h"
 #include "../../include/bcp_hip.h"
 
@@ -32,44 +41,118 @@ __device__ __forceinline__ void uf_union(int* L, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_cc_init(const uint8_t* __restrict__ seg, int* __restrict__ L, int* __restrict__ size,
-                                                 long long n) {
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-    L[v] = seg[v] ? (int)v : -1;
-    size[v] = 0;
+struct CcDims { int N, D, H, W, tiles_d, tiles_h, tiles_w, conn; };
+
+// forward half of the neighbourhood (linear offset > 0), filtered by connectivity
+template <class F>
+__device__ __forceinline__ void for_fwd_neighbours(int conn, F&& body) {
+  for (int dd = 0; dd <= 1; ++dd)
+    for (int dh = -1; dh <= 1; ++dh)
+      for (int dw = -1; dw <= 1; ++dw) {
+        if (dd == 0 && (dh < 0 || (dh == 0 && dw <= 0))) continue;
+        if ((dd != 0) + (dh != 0) + (dw != 0) > conn) continue;
+        body(dd, dh, dw);
+      }
+}
+
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ seg, int* __restrict__ L, int* __restrict__ lsize,
+                                                  int* __restrict__ size, CcDims cd) {
+  constexpr int TV = TD * TH * TW;
+  static_assert(TV == 512, "two voxels per thread");
+  __shared__ int Ls[TV];
+  __shared__ int Cnt[TV];
+  __shared__ uint8_t Ss[TV];
+  const int tw = blockIdx.x % cd.tiles_w, th = (blockIdx.x / cd.tiles_w) % cd.tiles_h;
+  const int td = (blockIdx.x / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d, n = blockIdx.x / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
+  const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+  const long long nbase = (long long)n * cd.D * cd.H * cd.W;
+  int gidx[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * 256;
+    const int lw = i % TW, lh = (i / TW) % TH, ld = i / (TW * TH);
+    const int d = d0 + ld, h = h0 + lh, w = w0 + lw;
+    const bool in = d < cd.D && h < cd.H && w < cd.W;
+    gidx[u] = in ? (int)(nbase + ((long long)d * cd.H + h) * cd.W + w) : -1;
+    const uint8_t s = in ? seg[gidx[u]] : 0;
+    Ss[i] = s;
+    Ls[i] = s ? i : -1;
+    Cnt[i] = 0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * 256;
+    const uint8_t cls = Ss[i];
+    if (cls) {
+      const int lw = i % TW, lh = (i / TW) % TH, ld = i / (TW * TH);
+      for_fwd_neighbours(cd.conn, [&](int dd, int dh, int dw) {
+        const int d2 = ld + dd, h2 = lh + dh, w2 = lw + dw;
+        if (d2 < TD && h2 >= 0 && h2 < TH && w2 >= 0 && w2 < TW) {
+          const int j = (d2 * TH + h2) * TW + w2;
+          if (Ss[j] == cls) uf_union(Ls, i, j);
+        }
+      });
+    }
+  }
+  __syncthreads();
+  int root[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * 256;
+    root[u] = -1;
+    if (Ss[i]) {
+      root[u] = uf_find(Ls, i);
+      atomicAdd(&Cnt[root[u]], 1);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = threadIdx.x + u * 256;
+    if (gidx[u] < 0) continue;
+    int lab = -1, ls = 0;
+    if (root[u] >= 0) {
+      const int r = root[u];
+      const int rw = r % TW, rh = (r / TW) % TH, rd = r / (TW * TH);
+      lab = (int)(nbase + ((long long)(d0 + rd) * cd.H + (h0 + rh)) * cd.W + (w0 + rw));
+      if (r == i) ls = Cnt[i];
+    }
+    L[gidx[u]] = lab;
+    lsize[gidx[u]] = ls;
+    size[gidx[u]] = 0;
   }
 }
 
-// conn: maximum number of non-zero offset components (3D: 1 -> 6-conn, 2 -> 18, 3 -> 26; 2D (D==1): 1 -> 4, 2 -> 8)
-__global__ __launch_bounds__(256) void k_cc_merge(const uint8_t* __restrict__ seg, int* __restrict__ L, int N, int D, int H, int W,
-                                                  int conn) {
-  const long long V = (long long)D * H * W, total = V * N;
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ seg, int* __restrict__ L, CcDims cd) {
+  const long long V = (long long)cd.D * cd.H * cd.W, total = V * cd.N;
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < total; v += (long long)gridDim.x * blockDim.x) {
     const uint8_t cls = seg[v];
     if (!cls) continue;
-    const long long r = v % V;
-    const int w = (int)(r % W), h = (int)((r / W) % H), d = (int)(r / ((long long)W * H));
-    // forward half of the neighbourhood: linear offset > 0
-    for (int dd = 0; dd <= 1; ++dd)
-      for (int dh = -1; dh <= 1; ++dh)
-        for (int dw = -1; dw <= 1; ++dw) {
-          if (dd == 0 && (dh < 0 || (dh == 0 && dw <= 0))) continue;
-          const int nz = (dd != 0) + (dh != 0) + (dw != 0);
-          if (nz > conn) continue;
-          const int d2 = d + dd, h2 = h + dh, w2 = w + dw;
-          if (d2 >= D || h2 < 0 || h2 >= H || w2 < 0 || w2 >= W) continue;
-          const long long u = v + ((long long)dd * H + dh) * W + dw;
+    const int r = (int)(v % V);
+    const int w = r % cd.W, h = (r / cd.W) % cd.H, d = r / (cd.W * cd.H);
+    const int lw = w % TW, lh = h % TH, ld = d % TD;
+    if (ld != TD - 1 && lh != 0 && lh != TH - 1 && lw != 0 && lw != TW - 1) continue;   // interior: all forward neighbours are in-tile
+    for_fwd_neighbours(cd.conn, [&](int dd, int dh, int dw) {
+      const int d2 = d + dd, h2 = h + dh, w2 = w + dw;
+      if (d2 < cd.D && h2 >= 0 && h2 < cd.H && w2 >= 0 && w2 < cd.W) {
+        const bool same_tile = (ld + dd < TD) && (lh + dh >= 0) && (lh + dh < TH) && (lw + dw >= 0) && (lw + dw < TW);
+        if (!same_tile) {
+          const long long u = v + ((long long)dd * cd.H + dh) * cd.W + dw;
           if (seg[u] == cls) uf_union(L, (int)v, (int)u);
         }
+      }
+    });
   }
 }
 
-__global__ __launch_bounds__(256) void k_cc_flatten(int* __restrict__ L, int* __restrict__ size, long long n) {
+__global__ __launch_bounds__(256) void k_cc_count(const int* __restrict__ L, const int* __restrict__ lsize, int* __restrict__ size,
+                                                  long long n) {
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-    if (L[v] < 0) continue;
-    const int r = uf_find(L, (int)v);
-    atomicAdd(&size[r], 1);
-    // no path write here: other threads still walk the forest; roots are re-found in the write pass
+    const int ls = lsize[v];
+    if (ls > 0) atomicAdd(&size[uf_find(L, (int)v)], ls);
   }
 }
 
@@ -77,7 +160,7 @@ __global__ __launch_bounds__(256) void k_cc_select(const uint8_t* __restrict__ s
                                                    const int* __restrict__ size, unsigned long long* __restrict__ best, long long V,
                                                    long long n, int nclass) {
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
-    if (L[v] != (int)v) continue;  // roots only
+    if (L[v] != (int)v) continue;  // global roots only
     const int sample = (int)(v / V);
     const unsigned long long key = ((unsigned long long)(unsigned)size[v] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)v);
     atomicMax(&best[(long long)sample * nclass + (seg[v] - 1)], key);
@@ -107,7 +190,7 @@ using namespace bcp;
 
 extern "C" size_t bcp_cc_workspace_bytes(int N, int D, int H, int W, int nclass) {
   const size_t n = (size_t)N * D * H * W;
-  return n * 2 * sizeof(int) + (size_t)N * nclass * sizeof(unsigned long long) + 64;
+  return n * 3 * sizeof(int) + (size_t)N * nclass * sizeof(unsigned long long) + 64;
 }
 
 extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f32, int N, int D, int H, int W, int nclass,
@@ -119,14 +202,24 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
   BCP_REQUIRE(n < (1LL << 31), "bcp_cc_largest: volume too large for 32-bit labels");
   hipStream_t s = (hipStream_t)stream;
   int* L = reinterpret_cast<int*>(workspace);
-  int* size = L + n;
+  int* lsize = L + n;
+  int* size = lsize + n;
   unsigned long long* best =
       reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(size + n) + 15) & ~(uintptr_t)15);
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
   hipMemsetAsync(best, 0, (size_t)N * nclass * sizeof(unsigned long long), s);
-  hipLaunchKernelGGL(k_cc_init, dim3(grid), dim3(256), 0, s, seg, L, size, n);
-  hipLaunchKernelGGL(k_cc_merge, dim3(grid), dim3(256), 0, s, seg, L, N, D, H, W, connectivity);
-  hipLaunchKernelGGL(k_cc_flatten, dim3(grid), dim3(256), 0, s, L, size, n);
+  CcDims cd;
+  cd.N = N; cd.D = D; cd.H = H; cd.W = W; cd.conn = connectivity;
+  if (D > 1) {
+    cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 8); cd.tiles_w = cdiv(W, 16);
+    hipLaunchKernelGGL((k_cc_local<4, 8, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_border<4, 8, 16>), dim3(grid), dim3(256), 0, s, seg, L, cd);
+  } else {
+    cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 32);
+    hipLaunchKernelGGL((k_cc_local<1, 16, 32>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_border<1, 16, 32>), dim3(grid), dim3(256), 0, s, seg, L, cd);
+  }
+  hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, L, lsize, size, n);
   hipLaunchKernelGGL(k_cc_select, dim3(grid), dim3(256), 0, s, seg, L, size, best, V, n, nclass);
   hipLaunchKernelGGL(k_cc_write, dim3(grid), dim3(256), 0, s, seg, L, best, out_u8, out_f32, V, n, nclass);
   BCP_CHECK_LAUNCH("bcp_cc_largest");

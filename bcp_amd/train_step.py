@@ -149,12 +149,15 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
     else:
         loss_u = BU.mix_loss(outputs_u, lab_a, plab_b, loss_mask)
     loss = loss_l + loss_u
-    optimizer.zero_grad()
-    loss.backward()
-    if dp is not None:
-        dp.allreduce_grads(model, optimizer)
-    optimizer.step()
-    BU.update_ema_variables(model, ema_model, alpha)
+    if optimizer is None:      # gradient-only mode (DP equivalence tests): caller owns zero_grad / step / EMA
+        loss.backward()
+    else:
+        optimizer.zero_grad()
+        loss.backward()
+        if dp is not None:
+            dp.allreduce_grads(model, optimizer)
+        optimizer.step()
+        BU.update_ema_variables(model, ema_model, alpha)
     model.drop_masks = None
     ema_model.drop_masks = None
     return dict(loss=loss.detach(), loss_l=loss_l.detach(), loss_u=loss_u.detach(), plab_a=plab_a, plab_b=plab_b,

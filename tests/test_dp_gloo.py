@@ -1,0 +1,90 @@
+"""Data-parallel path (bcp_amd/dp.py) with world_size 2 over gloo on CPU: N ranks == N sequential micro-batches
+with averaged gradients (BatchNorm statistics stay rank-local).  The kernels run on the host
+simulator here; the collective, the flat gradient bucket, the 1/world scaling inside the fused SGD launch and
+the EMA are the product code."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "_emu", "libbcp_emu.so")
+SHAPE = (32, 32, 16)
+
+
+def _setup():
+    for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import bcp_oracle as O
+    import net_checks as NC
+    from bcp_amd import _lib, train_step
+    from bcp_amd.hip_ops import Ops
+    ops = Ops(_lib.Binding(EMU), allow_cpu=True)
+    return O, NC, train_step, ops
+
+
+def _inputs(O, rank):
+    vol, lab = O.synth_la_batch(4, shape=SHAPE, seed=100 + rank)
+    rng = np.random.default_rng(200 + rank)
+    drops = {k: {"x5": torch.from_numpy((rng.random((1, 256)) < 0.5).astype(np.float32)),
+                 "x9": torch.from_numpy((rng.random((1, 16)) < 0.5).astype(np.float32))} for k in ("t_a", "t_b", "s_l", "s_u")}
+    box = (2 + rank, 4, 1 + rank, 21, 21, 10)
+    return vol, lab, drops, box
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ["BCP_EMU_THREADS"] = "4"
+    torch.set_num_threads(2)
+    O, NC, train_step, ops = _setup()
+    from bcp_amd.dp import DataParallel
+    dp = DataParallel(backend="gloo")
+    P = O.init_params(O.vnet_param_shapes(), seed=7 + rank, random_affine=True)   # different per rank: broadcast must fix it
+    model, ema = NC.make_vnet(P, torch.device("cpu"), ops), NC.make_vnet(P, torch.device("cpu"), ops)
+    dp.broadcast_params(model)
+    dp.broadcast_params(ema)
+    opt = train_step.FlatSGD(model, lr=0.01)
+    vol, lab, drops, box = _inputs(O, rank)
+    r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=box, drops=drops, dp=dp)
+    torch.save({"flat": model.flat_params().clone(), "ema": ema.flat_params().clone(), "loss": float(r["loss"])}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dp.shutdown()
+
+
+@pytest.mark.slow
+def test_dp2_equals_two_averaged_microbatches(tmp_path):
+    if not os.path.exists(EMU):
+        import subprocess
+        subprocess.check_call([os.path.join(ROOT, "tools", "emu", "build_emu.sh")])
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    assert torch.equal(r0["flat"], r1["flat"]), "students must be identical on every rank after the step"
+    assert torch.equal(r0["ema"], r1["ema"]), "teachers stay identical because the students do"
+    # single-process reference: two micro-batches from the same start, gradients averaged, one SGD step
+    O, NC, train_step, ops = _setup()
+    P = O.init_params(O.vnet_param_shapes(), seed=7, random_affine=True)   # rank 0's weights were broadcast
+    dev = torch.device("cpu")
+    grads, losses = [], []
+    for rank in range(2):
+        m, e = NC.make_vnet(P, dev, ops), NC.make_vnet(P, dev, ops)
+        vol, lab, drops, box = _inputs(O, rank)
+        r = train_step.la_self_train_step(m, e, None, vol, lab, 2, box=box, drops=drops)
+        grads.append(m.flat_trainable()[1].clone())
+        losses.append(float(r["loss"]))
+    m = NC.make_vnet(P, dev, ops)
+    opt = train_step.FlatSGD(m, lr=0.01)
+    m.begin_backward()
+    m.flat_trainable()[1].copy_(grads[0] + grads[1])
+    opt.grad_scale = 0.5
+    opt.step()
+    assert abs(losses[0] - r0["loss"]) < 1e-6 and abs(losses[1] - r1["loss"]) < 1e-6
+    diff = float((m.flat_params() - r0["flat"]).abs().max())
+    assert diff < 1e-7, f"DP step differs from the averaged-micro-batch step by {diff}"
