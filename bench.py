@@ -68,11 +68,30 @@ def dominant_kernel_roofline(dev):
             "flop_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": None}
 
 
+def usable_cores():
+    """threads this process may really use: scheduler affinity and the cgroup CPU quota, not os.cpu_count()
+    (a container that reports 256 CPUs but owns 16 would otherwise be oversubscribed 16x)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(float(q[0]) / float(q[1]))))
+    except Exception:
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except Exception:
+            pass
+    return max(1, min(n, 64))   # torch-CPU convs stop scaling long before 64 threads
+
+
 def cpu_baseline(batch, labeled_bs):
     """the oracle's self-training step on the host cores: 1 warm-up + timed steps until ~20 s"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bcp_oracle as O  # checker / baseline only
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     shapes = O.vnet_param_shapes()
     Ps = O.init_params(shapes, seed=1337)
@@ -84,7 +103,7 @@ def cpu_baseline(batch, labeled_bs):
     bufs = {}
     times = []
     t_start = time.time()
-    for it in range(4):
+    for it in range(3):
         drops = {k: {"x5": torch.from_numpy((rng.random((labeled_bs // 2, 256)) < 0.5).astype(np.float32)),
                      "x9": torch.from_numpy((rng.random((labeled_bs // 2, 16)) < 0.5).astype(np.float32))} for k in ("t_a", "t_b", "s_l", "s_u")}
         t0 = time.time()
@@ -92,7 +111,8 @@ def cpu_baseline(batch, labeled_bs):
         O.sgd_step(Ps, r["grads"], bufs, tkeys, lr=0.01)
         O.ema_params(Ps, Pt, tkeys, 0.99)
         times.append(time.time() - t0)
-        if it >= 1 and time.time() - t_start > 20:
+        print(f"[bench] cpu_baseline step {it}: {times[-1]:.2f} s ({cores} threads)", file=sys.stderr, flush=True)
+        if time.time() - t_start > 25:
             break
     steady = times[1:] if len(times) > 1 else times
     sec = float(np.median(steady))
