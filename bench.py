@@ -185,6 +185,7 @@ def main():
             "step_flops": {"gflop_per_volume": STEP_GFLOP_PER_VOLUME, "achieved_tflops_per_gpu": round(step_tflops, 2),
                            "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
         }
+        print(f"[bench] gpu: {value:.2f} volumes/s, {ms:.2f} ms/step, dominant kernel {roof['achieved']} TFLOP/s", file=sys.stderr, flush=True)
         if dp.world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch_size, args.labeled_bs)
         print(json.dumps(out), flush=True)
