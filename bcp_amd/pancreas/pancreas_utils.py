@@ -1,0 +1,16 @@
+"""Counterparts of the hot-path helpers in the reference's code/pancreas/pancreas_utils.py."""
+import numpy as np
+
+from ..train_step import get_cut_mask  # noqa: F401  (:275-281; connect_mode=2 -> 18-connectivity)
+from ..utils import BCP_utils as BU
+from ..utils.BCP_utils import update_ema_variables  # noqa: F401  (:299-302)
+
+
+def generate_mask(img, patch_size):
+    """:187-200 -- one patch_size^3 zero box in a 96^3 ones volume, three np.random.randint draws (w, h, z)"""
+    batch_l = img.shape[0]
+    w = np.random.randint(0, 96 - patch_size)
+    h = np.random.randint(0, 96 - patch_size)
+    z = np.random.randint(0, 96 - patch_size)
+    box = (w, h, z, patch_size, patch_size, patch_size)
+    return BU.BoxMask(box, (96, 96, 96), None, False, img.device), BU.BoxMask(box, (96, 96, 96), batch_l, False, img.device)

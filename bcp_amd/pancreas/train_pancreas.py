@@ -1,0 +1,99 @@
+"""Counterpart of code/pancreas/train_pancreas.py (ema_cutmix :103-179, pretrain :50-101) on synthetic 96^3 data.
+Module-level constants mirror :22-48.  Four streams (lab_a, lab_b, unlab_a, unlab_b) of `batch_size` samples
+each, Adam(1e-3), u_weight left at mix_loss's default 0.5 exactly as the reference calls it (:160,164).
+
+  python -m bcp_amd.pancreas.train_pancreas --pretraining_epochs 1 --self_training_epochs 1 --steps_per_epoch 3
+"""
+import argparse
+import logging
+import sys
+
+import numpy as np
+import torch
+
+from bcp_amd import synth, train_step
+from bcp_amd.pancreas.Vnet import create_Vnet
+from bcp_amd.pancreas.pancreas_utils import generate_mask, get_cut_mask, update_ema_variables
+from bcp_amd.utils.BCP_utils import mix_loss, sup_loss
+
+seed_test = 2020
+batch_size, lr = 2, 1e-3
+pretraining_epochs, self_training_epochs = 60, 200
+alpha = 0.99
+label_percent = 20
+connect_mode = 2
+patch_size = 64
+
+
+def _streams(device, n=4, bs=2, seed=seed_test):
+    vols, labs = synth.la_batch(n * bs, shape=(96, 96, 96), seed=seed)
+    vols, labs = vols.to(device), labs.to(device)
+    return [(vols[i * bs:(i + 1) * bs], labs[i * bs:(i + 1) * bs]) for i in range(n)]
+
+
+def pretrain(net1, optimizer, streams, steps):
+    net1.train()
+    for step in range(steps):
+        (img_a, lab_a), (img_b, lab_b) = streams[0], streams[1]
+        img_mask, loss_mask = generate_mask(img_a, patch_size)
+        img = img_a * img_mask + img_b * (1 - img_mask)
+        lab = lab_a * img_mask + lab_b * (1 - img_mask)
+        out = net1(img)[0]
+        loss = sup_loss(out, lab)            # (CE + dice) / 2, train_pancreas.py:90-92
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+    return loss
+
+
+def ema_cutmix(net, ema_net, optimizer, streams, steps):
+    net.train()
+    ema_net.train()
+    for step in range(steps):
+        (img_a, lab_a), (img_b, lab_b), (unimg_a, _), (unimg_b, _) = streams
+        with torch.no_grad():
+            unimg_a_out = ema_net(unimg_a)[0]
+            unimg_b_out = ema_net(unimg_b)[0]
+            uimg_a_plab = get_cut_mask(unimg_a_out, nms=True, connect_mode=connect_mode)
+            uimg_b_plab = get_cut_mask(unimg_b_out, nms=True, connect_mode=connect_mode)
+            img_mask, loss_mask = generate_mask(img_a, patch_size)
+        net3_input_l = unimg_a * img_mask + img_b * (1 - img_mask)
+        net3_input_unlab = img_a * img_mask + unimg_b * (1 - img_mask)
+        mix_output_l = net(net3_input_l)[0]
+        loss_1 = mix_loss(mix_output_l, uimg_a_plab, lab_b, loss_mask, unlab=True)
+        mix_output_2 = net(net3_input_unlab)[0]
+        loss_2 = mix_loss(mix_output_2, lab_a, uimg_b_plab, loss_mask)
+        loss = loss_1 + loss_2
+        optimizer.zero_grad()
+        loss.backward()
+        optimizer.step()
+        update_ema_variables(net, ema_net, alpha)
+    return loss
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--pretraining_epochs", type=int, default=pretraining_epochs)
+    ap.add_argument("--self_training_epochs", type=int, default=self_training_epochs)
+    ap.add_argument("--steps_per_epoch", type=int, default=10)
+    ap.add_argument("--batch_size", type=int, default=batch_size)
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, stream=sys.stdout)
+    np.random.seed(seed_test)
+    torch.manual_seed(seed_test)
+    device = torch.device("cuda", torch.cuda.current_device())
+    net, ema_net = create_Vnet(), create_Vnet(ema=True)
+    ema_net.load_state_dict(net.state_dict())
+    optimizer = train_step.FlatAdam(net, lr=lr)
+    streams = _streams(device, 4, args.batch_size)
+    for ep in range(args.pretraining_epochs):
+        loss = pretrain(net, optimizer, streams, args.steps_per_epoch)
+        logging.info("pretrain epoch %d loss %f", ep + 1, float(loss))
+    ema_net.load_state_dict(net.state_dict())
+    for ep in range(args.self_training_epochs):
+        loss = ema_cutmix(net, ema_net, optimizer, streams, args.steps_per_epoch)
+        logging.info("self-train epoch %d loss %f", ep + 1, float(loss))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,61 @@
+"""-m gpu: U-Net (ACDC) parity on the MI355X (same checks as tests/test_emu_unet.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import bcp_oracle as O
+import kernel_checks as K
+import net_checks as NC
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from bcp_amd.hip_ops import Ops
+    return Ops.product()
+
+
+def test_unet_golden_tiny(ops, golden_dir):
+    NC.check_unet_golden_tiny(ops, DEV, golden_dir)
+
+
+def test_unet_smooth_grads(ops):
+    NC.check_unet_smooth(ops, DEV, hw=(128, 128), N=2)
+
+
+def test_acdc_self_train_trajectory(ops, golden_dir):
+    NC.check_acdc_step(ops, DEV, golden_dir)
+
+
+def test_unet_full_shape_vs_reference_golden(ops, golden_dir):
+    """6 x 256x256 slices (BASELINE.json configs[3] per-call shape) vs the reference's recorded checksums"""
+    from bcp_amd import train_step
+    from bcp_amd.utils import BCP_utils as BU
+    g = np.load(os.path.join(golden_dir, "unet_full.npz"))
+    m = json.load(open(os.path.join(golden_dir, "meta.json")))["unet_full"]
+    P = O.init_params(O.unet_param_shapes(), seed=m["param_seed"], random_affine=True)
+    x, lab = O.synth_acdc_batch(6, seed=m["data_seed"])
+    rng = np.random.default_rng(m["drop_seed"])
+    dm = {f"d{i}": torch.from_numpy((rng.random((6, c, 256 >> i, 256 >> i)) >= p).astype(np.float32)) for i, (c, p) in enumerate(zip(O.UNET_CH, O.UNET_DROP))}
+    net = NC.make_unet(P, DEV, ops)
+    net.drop_masks = dm
+    out = net(x.to(DEV))
+    w, h, pw, ph = m["mask_box"]
+    lab = lab.to(DEV)
+    d, c = train_step.acdc_mix_loss(out, lab, (lab + 1) % 4, BU.BoxMask((w, h, pw, ph), (256, 256), 6, False, DEV), u_weight=0.5, unlab=True)
+    assert abs(float(d.detach()) - float(g["dice"])) < 1e-5 and abs(float(c.detach()) - float(g["ce"])) < 1e-5
+    o = out.detach().double().reshape(-1).cpu()
+    st = g["logits_stats"]
+    assert abs(float(o.abs().sum()) - st[1]) / st[1] < 1e-5
+    ((d + c) / 2).backward()
+    params = dict(net.named_parameters())
+    for n_, stg in zip([str(n) for n in g["grad_names"]], g["grad_stats"]):
+        if NC.is_prenorm_bias(n_, params):
+            continue
+        l2 = float(params[n_].grad.double().norm())
+        assert abs(l2 - stg[2]) / max(stg[2], 1e-12) < 3e-2, (n_, l2, stg[2])
