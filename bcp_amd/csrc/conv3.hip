@@ -20,6 +20,7 @@
 // so every wave issues MT*NT*4 back-to-back MFMAs per tap per (MT+NT) ds_read_b128.
 #include "common.h"
 #include "../../include/bcp_hip.h"
+#include <cstdlib>
 
 namespace bcp {
 
@@ -93,7 +94,8 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   constexpr int WSTAGE4 = WT * 4 * CT;          // float4s per weight stage
   constexpr int NW4 = (WSTAGE4 + 255) / 256;    // per-thread prefetch registers
 
-  HIP_DYNAMIC_SHARED(float, smem)
+  HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
+  float* smem = reinterpret_cast<float*>(smem4);
   float* Xs = smem;                             // [HV][XS]
   float* Ws = smem + TL::HV * XS;               // [NBUF][WT][4][CT][4]
 
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
         }
       }
       const float* Wb = Ws + (st & (NBUF - 1)) * WSTAGE4 * 4;
-#pragma unroll
+#pragma unroll (WT > 9 ? 9 : WT)
       for (int tl = 0; tl < WT; ++tl) {
         const int toff = TL::tapoff(st * WT + tl) * XS;
         float4 a[MT], b[NT];
@@ -197,6 +199,153 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward / dgrad, "resident" variant: persistent workgroups keep the WHOLE packed weight slab of their
+// 16*NT output channels (all taps, all cin chunks) in LDS and walk a strided list of spatial tiles; the
+// input halo of the NEXT (tile, cin-chunk) work item is fetched into registers while the MFMAs of the
+// current one run, then dropped into the single LDS halo buffer between two barriers.  Versus the
+// streaming kernel above this removes the per-tile weight reload (27.6 KB x 3920 tiles for the 16->16
+// layer) and overlaps HBM/L2 latency with the matrix pipe instead of serialising load -> compute.
+// Used whenever T*Cin16*16*NT*4 B of weights + one halo fit in the 160 KB LDS.
+// ------------------------------------------------------------------------------------------------
+template <int KD, int TD, int TH, int TW, int NT>
+__global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd,
+                                                   int n_tiles, int accumulate) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
+  constexpr int NX4 = (TL::HV * 4 + 255) / 256;      // halo float4s per thread
+  constexpr int NACC = (MT * NT == 1) ? 2 : 1;       // a lone accumulator would serialise on the 40-cycle MFMA latency
+
+  HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
+  float* smem = reinterpret_cast<float*>(smem4);
+  const int nch = cd.Cin16 >> 4;
+  float* Ws = smem;                                  // [nch][T][4][CT][4]
+  float* Xs = smem + (size_t)nch * T * 4 * CT * 4;   // [HV][XS]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int cout0 = blockIdx.y * CT;
+  const int cin4 = cd.Cin16 >> 2;
+
+  // resident weights: Wp[tap][cin4][Cout16][4] -> Ws[chunk][tap][cig][co][4]
+  for (int q = threadIdx.x; q < nch * T * 4 * CT; q += 256) {
+    const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
+    st4(Ws + (size_t)q * 4, ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
+  }
+
+  int voff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
+
+  f32x4 acc[NACC][MT][NT];
+#pragma unroll
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // work items of this block: (tile, chunk), tile = blockIdx.x, blockIdx.x + gridDim.x, ...
+  int tile = blockIdx.x, ch = 0;
+  if (tile >= n_tiles) return;
+  {
+    int n, d0, h0, w0;
+    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+    load_halo<TL>(X, Xs, cd, n, d0, h0, w0, 0);
+  }
+  __syncthreads();
+  for (;;) {
+    // next work item
+    int ntile = tile, nchk = ch + 1;
+    if (nchk == nch) { nchk = 0; ntile = tile + gridDim.x; }
+    const bool has_next = ntile < n_tiles;
+    float4 pre[NX4];
+    if (has_next) {
+      int n2, d2, h2, w2;
+      tile_origin(cd, ntile, TD, TH, TW, n2, d2, h2, w2);
+#pragma unroll
+      for (int u = 0; u < NX4; ++u) {
+        const int q = threadIdx.x + u * 256;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < TL::HV * 4) {
+          const int hv = q >> 2, part = q & 3;
+          const int hw = hv % TL::HW, hh = (hv / TL::HW) % TL::HH, hd = hv / (TL::HW * TL::HH);
+          const int d = d2 - TL::PD + hd, h = h2 - 1 + hh, w = w2 - 1 + hw;
+          const int c = nchk * 16 + part * 4;
+          if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)w < (unsigned)cd.W && c < cd.Cin)
+            v = ld4(X + ((((long long)n2 * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cin + c);
+        }
+        pre[u] = v;
+      }
+    }
+    // MFMAs of the current item
+    const float* Wc = Ws + (size_t)ch * T * 4 * CT * 4;
+    // partial unroll: a full 27-tap unroll makes hipcc split the ds_read_b128 fragments into read2_b32/b64 pairs
+#pragma unroll 9
+    for (int tap = 0; tap < T; ++tap) {
+      const int toff = TL::tapoff(tap) * XS;
+      float4 a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + toff);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wc + ((tap * 4 + lg) * CT + nt * 16 + li) * 4);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
+          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
+          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
+          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
+        }
+    }
+    if (ch == nch - 1) {
+      int n, d0, h0, w0;
+      tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = (wave * MT + mt) * 16 + lg * 4 + r;
+          const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+          const int d = d0 + td, h = h0 + th, w = w0 + tw;
+          if (d < cd.D && h < cd.H && w < cd.W) {
+            float* yrow = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              const int co = cout0 + nt * 16 + li;
+              if (co < cd.Cout) {
+                float v = acc[0][mt][nt][r];
+                if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
+                if (bias) v += bias[co];
+                if (accumulate) v += yrow[co];
+                yrow[co] = v;
+              }
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (!has_next) break;
+    __syncthreads();   // every wave is done reading the halo buffer
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      if (q < TL::HV * 4) st4(Xs + (q >> 2) * XS + (q & 3) * 4, pre[u]);
+    }
+    __syncthreads();
+    tile = ntile;
+    ch = nchk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // wgrad: dW[tap][ci][co] = sum_v X[v + off(tap)][ci] * dY[v][co]
 // GEMM per tap with M = 16 ci (one chunk), N = 16*NT co, K = voxels.  Lane (i, g) supplies
 // A[ci i][vox g] and B[vox g][co i] per k-step of 4 voxels -- plain ds_read_b32 from the
@@ -214,7 +363,8 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   constexpr int TPW = (T + 3) / 4;                      // taps per wave
   constexpr int YS = (CT % 32 == 0) ? CT + 16 : CT;     // dY tile row stride (bank spread for the 4 k-groups)
 
-  HIP_DYNAMIC_SHARED(float, smem)
+  HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
+  float* smem = reinterpret_cast<float*>(smem4);
   float* Xs = smem;                 // [HV][XS]
   float* Ys = smem + TL::HV * XS;   // [M][YS]
 
@@ -338,8 +488,8 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
   using TL = Tile<KD, TD, TH, TW>;
   static_assert(TL::M == 256, "one voxel per thread");
   constexpr int T = TL::T;
-  __shared__ float Xs[TL::HV];
-  __shared__ float Ws[T * 16];
+  __shared__ __attribute__((aligned(16))) float Xs[TL::HV];
+  __shared__ __attribute__((aligned(16))) float Ws[T * 16];
   int n, d0, h0, w0;
   tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
   for (int q = threadIdx.x; q < TL::HV; q += 256) {
@@ -382,8 +532,8 @@ __global__ __launch_bounds__(256) void k_conv3_c1_wgrad(const float* __restrict_
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int T = TL::T, M = TL::M;
   constexpr int NO = (T * 16 + 255) / 256;  // outputs per thread
-  __shared__ float Xs[TL::HV];
-  __shared__ float Ys[M * 16];
+  __shared__ __attribute__((aligned(16))) float Xs[TL::HV];
+  __shared__ __attribute__((aligned(16))) float Ys[M * 16];
   float acc[NO];
   int otap[NO], oco[NO];
 #pragma unroll
@@ -445,6 +595,25 @@ static int launch_fwd(const float* X, const float* Wp, const float* bias, float*
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const dim3 grid(cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, cd.Cout16 / (NT * 16));
   hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate);
+  return 0;
+}
+
+template <int KD, int TD, int TH, int TW, int NT>
+static int launch_res(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, hipStream_t s) {
+  using TL = Tile<KD, TD, TH, TW>;
+  const int nch = cd.Cin16 / 16;
+  const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + (size_t)TL::HV * XS) * sizeof(float);
+  cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
+  const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+  const int slabs = cd.Cout16 / (NT * 16);
+  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+  int P = (256 * (per_cu > 2 ? 2 : per_cu)) / slabs;           // persistent workgroups per slab
+  if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
+  if (P < 1) P = 1;
+  if (P > tiles) P = tiles;
+  auto kfn = k_conv3_res<KD, TD, TH, TW, NT>;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, dim3(P, slabs), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate);
   return 0;
 }
 
@@ -521,6 +690,38 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
     launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (hipStream_t)stream);             \
     done = true;                                                                                               \
   }
+#define BCP_RES_CASE(KD_, TD_, TH_, TW_, NT_)                                                                  \
+  if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_ && r.NT == NT_) {                               \
+    launch_res<KD_, TD_, TH_, TW_, NT_>(x, wp, bias, y, cd, accumulate, (hipStream_t)stream);                  \
+    done = true;                                                                                               \
+  }
+
+// resident-weight variant: tile by problem size, widest channel slab whose weights + one halo fit in LDS
+static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, int Cout16) {
+  r.KD = KD;
+  const long long vox = (long long)N * D * H * W;
+  if (KD == 3) {
+    r.TD = 4; r.TH = 4;
+    r.TW = vox >= 256LL * 1024 ? 16 : (vox >= 64LL * 1024 ? 8 : 4);
+  } else {
+    r.TD = 1;
+    if (vox >= 128LL * 1024) { r.TH = 16; r.TW = 16; } else { r.TH = 8; r.TW = 8; }
+  }
+  const int PD = KD == 3 ? 1 : 0;
+  const long long hv = (long long)(r.TD + 2 * PD) * (r.TH + 2) * (r.TW + 2);
+  const long long tiles = (long long)N * cdiv(D, r.TD) * cdiv(H, r.TH) * cdiv(W, r.TW);
+  for (int nt = 4; nt >= 1; nt >>= 1) {
+    if (Cout16 % (nt * 16)) continue;
+    const long long lds = ((long long)KD * 9 * Cin16 * nt * 16 + hv * XS) * 4;
+    if (lds > 158 * 1024) continue;
+    if (nt > 1 && tiles * (Cout16 / (nt * 16)) < 512) continue;   // keep >= 2 work items per CU
+    r.NT = nt;
+    const int mt = (r.TD * r.TH * r.TW) / 64;
+    if (mt * nt < 2) return false;                                // one MFMA tile per wave per tap: the streaming kernel's 2-slab blocks are faster
+    return tiles * (Cout16 / (nt * 16)) >= 192;                   // too few items: the streaming kernel's finer grid wins
+  }
+  return false;
+}
 
 extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
                              int Cout, int KD, int accumulate, void* stream) {
@@ -531,14 +732,24 @@ extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias,
   BCP_REQUIRE(aligned16(x) && aligned16(wp), "bcp_conv3_fwd: x / wp must be 16-B aligned");
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
-  const Cfg c = choose_cfg(KD, N, D, H, W, cd.Cout16);
   bool done = false;
-  BCP_FWD_CASE(3, 4, 4, 16, 1, 27) BCP_FWD_CASE(3, 4, 4, 16, 2, 9) BCP_FWD_CASE(3, 4, 4, 16, 4, 3)
-  BCP_FWD_CASE(3, 4, 8, 8, 1, 27) BCP_FWD_CASE(3, 4, 8, 8, 2, 9) BCP_FWD_CASE(3, 4, 8, 8, 4, 3)
-  BCP_FWD_CASE(3, 4, 4, 4, 1, 27) BCP_FWD_CASE(3, 4, 4, 4, 2, 9) BCP_FWD_CASE(3, 4, 4, 4, 4, 3)
-  BCP_FWD_CASE(1, 1, 16, 16, 1, 9) BCP_FWD_CASE(1, 1, 16, 16, 2, 9) BCP_FWD_CASE(1, 1, 16, 16, 4, 3)
-  BCP_FWD_CASE(1, 1, 8, 8, 1, 9) BCP_FWD_CASE(1, 1, 8, 8, 2, 9) BCP_FWD_CASE(1, 1, 8, 8, 4, 3)
-  BCP_REQUIRE(done, "bcp_conv3_fwd: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
+  Cfg r;
+  if (choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
+    BCP_RES_CASE(3, 4, 4, 16, 1) BCP_RES_CASE(3, 4, 4, 16, 2)
+    BCP_RES_CASE(3, 4, 4, 8, 1) BCP_RES_CASE(3, 4, 4, 8, 2) BCP_RES_CASE(3, 4, 4, 8, 4)
+    BCP_RES_CASE(3, 4, 4, 4, 1) BCP_RES_CASE(3, 4, 4, 4, 2) BCP_RES_CASE(3, 4, 4, 4, 4)
+    BCP_RES_CASE(1, 1, 16, 16, 1) BCP_RES_CASE(1, 1, 16, 16, 2) BCP_RES_CASE(1, 1, 16, 16, 4)
+    BCP_RES_CASE(1, 1, 8, 8, 1) BCP_RES_CASE(1, 1, 8, 8, 2) BCP_RES_CASE(1, 1, 8, 8, 4)
+  }
+  if (!done) {
+    const Cfg c = choose_cfg(KD, N, D, H, W, cd.Cout16);
+    BCP_FWD_CASE(3, 4, 4, 16, 1, 27) BCP_FWD_CASE(3, 4, 4, 16, 2, 9) BCP_FWD_CASE(3, 4, 4, 16, 4, 3)
+    BCP_FWD_CASE(3, 4, 8, 8, 1, 27) BCP_FWD_CASE(3, 4, 8, 8, 2, 9) BCP_FWD_CASE(3, 4, 8, 8, 4, 3)
+    BCP_FWD_CASE(3, 4, 4, 4, 1, 27) BCP_FWD_CASE(3, 4, 4, 4, 2, 9) BCP_FWD_CASE(3, 4, 4, 4, 4, 3)
+    BCP_FWD_CASE(1, 1, 16, 16, 1, 9) BCP_FWD_CASE(1, 1, 16, 16, 2, 9) BCP_FWD_CASE(1, 1, 16, 16, 4, 3)
+    BCP_FWD_CASE(1, 1, 8, 8, 1, 9) BCP_FWD_CASE(1, 1, 8, 8, 2, 9) BCP_FWD_CASE(1, 1, 8, 8, 4, 3)
+    BCP_REQUIRE(done, "bcp_conv3_fwd: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
+  }
   BCP_CHECK_LAUNCH("bcp_conv3_fwd");
   return BCP_OK;
 }

@@ -48,8 +48,8 @@ template <int NT>
 __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restrict__ Bp, const float* __restrict__ bias,
                                                  RowMap C, int M, int K, int N, int bias_mod, int accumulate) {
   constexpr int CT = NT * 16;
-  __shared__ float As[64 * AS];
-  __shared__ float Bs[4 * CT * 4];
+  __shared__ __attribute__((aligned(16))) float As[64 * AS];
+  __shared__ __attribute__((aligned(16))) float Bs[4 * CT * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * CT;
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void k_gemm_tn(RowMap A, RowMap B, float* __re
   constexpr int CT = NT * 16;
   constexpr int AS2 = 64 + 16;                          // [row][64 k] + bank spread
   constexpr int BS2 = (CT % 32 == 0) ? CT + 16 : CT;    // [row][CT n]
-  __shared__ float As[64 * AS2];
-  __shared__ float Bs[64 * BS2];
+  __shared__ __attribute__((aligned(16))) float As[64 * AS2];
+  __shared__ __attribute__((aligned(16))) float Bs[64 * BS2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int grp = blockIdx.x, k0 = blockIdx.y * 64, n0 = blockIdx.z * CT;

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void k_norm_finalize(const double* __restrict_
                                                        const float* __restrict__ beta, float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, float momentum, float eps,
                                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
-                                                       float* __restrict__ shift) {
+                                                       float* __restrict__ shift, float* __restrict__ var_unb) {
   const int chunks = C >> 4;
   const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), slot = threadIdx.x >> 4;
   double s1, s2;
@@ -145,11 +145,23 @@ __global__ __launch_bounds__(256) void k_norm_finalize(const double* __restrict_
   const double ga = gamma ? (double)gamma[c] : 1.0, be = beta ? (double)beta[c] : 0.0;
   scale[idx] = (float)(ga * r);
   shift[idx] = (float)be;   // z = (y - mean) * scale + beta: subtract the mean FIRST (no cancellation against mean*scale)
-  if (running_mean && g == 0) {
-    // torch: running = (1-momentum)*running + momentum*stat, with the UNBIASED variance
-    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-    running_mean[c] = (float)((1.0 - (double)momentum) * (double)running_mean[c] + (double)momentum * m);
-    running_var[c] = (float)((1.0 - (double)momentum) * (double)running_var[c] + (double)momentum * unb);
+  var_unb[idx] = (float)(n > 1.0 ? var * n / (n - 1.0) : var);   // torch's running_var uses the UNBIASED variance
+}
+
+// running = (1-momentum)*running + momentum*stat, applied group after group IN ORDER: a call with G groups is
+// bit-for-bit G consecutive BatchNorm calls (the BCP step normalises its two student / teacher batches separately).
+__device__ __forceinline__ void update_running(const float* __restrict__ mean, const float* __restrict__ var_unb, int G, int C,
+                                               float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double rm = (double)running_mean[c], rv = (double)running_var[c];
+    for (int g = 0; g < G; ++g) {
+      rm = (1.0 - (double)momentum) * rm + (double)momentum * (double)mean[g * C + c];
+      rv = (1.0 - (double)momentum) * rv + (double)momentum * (double)var_unb[g * C + c];
+      rm = (double)(float)rm;   // the reference rounds to fp32 after every call
+      rv = (double)(float)rv;
+    }
+    running_mean[c] = (float)rm;
+    running_var[c] = (float)rv;
   }
 }
 
@@ -157,7 +169,7 @@ __global__ __launch_bounds__(256) void k_norm_finalize(const double* __restrict_
 __global__ __launch_bounds__(256) void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, int G, int C,
                                                            long long rows_per_group, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ c1,
-                                                           float* __restrict__ c2) {
+                                                           float* __restrict__ c2, float* __restrict__ raw /* [2][G][C] */) {
   const int chunks = C >> 4;
   const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), slot = threadIdx.x >> 4;
   double s1, s2;
@@ -165,10 +177,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_finalize(const double* __restr
   const int idx = g * C + c;
   c1[idx] = (float)(s1 / (double)rows_per_group);
   c2[idx] = (float)(s2 / (double)rows_per_group);
-  if (dgamma && g == 0) {
-    dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)s2;
-    dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)s1;
-  }
+  raw[idx] = (float)s1;
+  raw[(long long)G * C + idx] = (float)s2;
 }
 
 // ------------------------------------------------------------------ apply passes
@@ -176,7 +186,10 @@ __global__ __launch_bounds__(256) void k_norm_bwd_finalize(const double* __restr
 __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                                     const float* __restrict__ residual, NormEpilogue ep, long long rows,
-                                                    long long rows_per_group, int C, float* __restrict__ out) {
+                                                    long long rows_per_group, int C, float* __restrict__ out,
+                                                    const float* __restrict__ var_unb, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var, float momentum) {
+  if (blockIdx.x == 0 && running_mean) update_running(mean, var_unb, (int)(rows / rows_per_group), C, running_mean, running_var, momentum);
   const int C4 = C >> 2;
   const int c4_shift = 31 - __clz(C4);   // C is a power of two (checked on the host)
   const long long nvec = rows * C4;
@@ -212,7 +225,17 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ c1, const float* __restrict__ c2,
                                                         NormEpilogue ep, long long rows, long long rows_per_group, int C,
-                                                        float* __restrict__ dy) {
+                                                        float* __restrict__ dy, const float* __restrict__ raw,
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+  if (blockIdx.x == 0 && dgamma) {   // parameter gradients: sum the groups in order (deterministic)
+    const int G = (int)(rows / rows_per_group);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      float gb = accumulate ? dbeta[c] : 0.f, gg = accumulate ? dgamma[c] : 0.f;
+      for (int g = 0; g < G; ++g) { gb += raw[g * C + c]; gg += raw[(long long)G * C + g * C + c]; }
+      dbeta[c] = gb;
+      dgamma[c] = gg;
+    }
+  }
   const int C4 = C >> 2;
   const int c4_shift = 31 - __clz(C4);   // C is a power of two (checked on the host)
   const long long nvec = rows * C4;
@@ -273,7 +296,7 @@ using namespace bcp;
 extern "C" size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C) {
   if (G < 1 || C < 16 || rows_per_group < 1) return 0;
   // per-block fp64 partials, then the two per-(g,c) backward means (c1, c2)
-  return (size_t)G * norm_blocks(rows_per_group, C) * C * 2 * sizeof(double) + (size_t)2 * G * C * sizeof(float);
+  return (size_t)G * norm_blocks(rows_per_group, C) * C * 2 * sizeof(double) + (size_t)4 * G * C * sizeof(float);
 }
 
 static int check_norm_args(const char* fn, int G, long long rows_per_group, int C) {
@@ -285,7 +308,7 @@ static int check_norm_args(const char* fn, int G, long long rows_per_group, int 
 extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int act,
                             const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale,
-                            const float* residual, float* stats /* [4][G][C]: mean, rstd, scale, shift */, void* workspace,
+                            const float* residual, float* stats /* [5][G][C]: mean, rstd, scale, beta, unbiased var */, void* workspace,
                             float* out, void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(y && stats && workspace && out, "bcp_norm_fwd: null pointer");
@@ -295,13 +318,14 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
   double* partial = reinterpret_cast<double*>(workspace);
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
+  float* var_unb = stats + 4LL * G * C;
   hipLaunchKernelGGL((k_col_partial<0>), dim3(nb, G), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, rows_per_group, C, partial);
   hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
-                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift);
+                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
   const long long rows = (long long)G * rows_per_group;
   hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, scale, shift, mean, residual, ep, rows,
-                     rows_per_group, C, out);
+                     rows_per_group, C, out, var_unb, running_mean, running_var, momentum);
   BCP_CHECK_LAUNCH("bcp_norm_fwd");
   return BCP_OK;
 }
@@ -320,13 +344,14 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   // c1/c2 live behind the partials in the workspace
   float* c1 = reinterpret_cast<float*>(partial + (size_t)G * nb * C * 2);
   float* c2 = c1 + (long long)G * C;
+  float* raw = c2 + (long long)G * C;
   hipLaunchKernelGGL((k_col_partial<1>), dim3(nb, G), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, rows_per_group, C,
                      partial);
   hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
-                     dbeta, accumulate, c1, c2);
+                     dbeta, accumulate, c1, c2, raw);
   const long long rows = (long long)G * rows_per_group;
   hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, da, scale, shift, mean, rstd, c1,
-                     c2, ep, rows, rows_per_group, C, dy);
+                     c2, ep, rows, rows_per_group, C, dy, raw, dgamma, dbeta, accumulate);
   BCP_CHECK_LAUNCH("bcp_norm_bwd");
   return BCP_OK;
 }

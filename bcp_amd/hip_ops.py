@@ -125,10 +125,10 @@ class Ops:
                     float(w_img), float(w_patch), _p(ws), _p(out3), self.stream(logits))
         return out3, ws
 
-    def mixloss_bwd(self, logits, img_l, patch_l, box6, flavour, ws, g_dice, g_ce, mask=None, g_dev=None):
-        self._chk(logits, img_l, patch_l, mask)
+    def mixloss_bwd(self, logits, img_l, patch_l, box6, flavour, ws, g_dice, g_ce, mask=None, g_dev=None, out=None):
+        self._chk(logits, img_l, patch_l, mask, out)
         N, D, H, W, Cc = logits.shape
-        dlogits = torch.empty_like(logits)
+        dlogits = torch.empty_like(logits) if out is None else out
         self.b.call("bcp_mixloss_bwd", _p(logits), _p(img_l), _p(patch_l), _p(mask), self.box_arg(box6), N, D, H, W, Cc, flavour,
                     _p(ws), float(g_dice), float(g_ce), _p(g_dev), _p(dlogits), self.stream(logits))
         return dlogits
@@ -136,7 +136,8 @@ class Ops:
     # ------------------------------------------------------------------ norm
     def norm_fwd(self, y, G, gamma, beta, rmean, rvar, act, out=None, chan_scale=None, elem_mask=None, elem_scale=1.0,
                  residual=None, momentum=0.1, eps=1e-5):
-        """y [N,D,H,W,C] -> (a, stats[4,G,C]).  G = 1: BatchNorm; G = N: InstanceNorm."""
+        """y [N,D,H,W,C] -> (a, stats[5,G,C]).  G = 1: BatchNorm; G = N (no affine): InstanceNorm; G > 1 with affine:
+        G consecutive BatchNorm calls in one launch."""
         self._chk(y, gamma, beta, rmean, rvar, chan_scale, elem_mask, residual)
         N = y.shape[0]
         Cc = y.shape[-1]
@@ -145,7 +146,7 @@ class Ops:
         rps = rows // N
         nbytes = self.b.call("bcp_norm_workspace_bytes", G, rpg, Cc)
         ws = self.workspace("norm", nbytes, y)
-        stats = torch.empty((4, G, Cc), dtype=torch.float32, device=y.device)
+        stats = torch.empty((5, G, Cc), dtype=torch.float32, device=y.device)
         if out is None:
             out = torch.empty_like(y)
         self.b.call("bcp_norm_fwd", _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps), act,

@@ -128,13 +128,18 @@ class VNet(HipNet):
         self._opt_param_ids = ids
 
     # ------------------------------------------------------------------ public call
-    def forward(self, input, turnoff_drop=False):
+    def forward(self, input, turnoff_drop=False, groups=1):
+        """groups > 1: `input` holds `groups` consecutive sub-batches that the reference would push through the net in
+        separate calls (LA_BCP_train.py:241-242, 252-253); they are normalised separately (grouped BatchNorm) but every
+        layer is ONE launch over all of them -- identical results, half the launches, twice the work per launch."""
         x = input
         N = x.shape[0]
         assert x.dim() == 5 and x.shape[1] == 1, "expected [N,1,X,Y,Z]"
         self._ensure_flat()
         xcl = x.contiguous().view(N, x.shape[2], x.shape[3], x.shape[4], 1)
         self._turnoff_drop = bool(turnoff_drop)
+        assert N % groups == 0
+        self._groups = int(groups)
         if torch.is_grad_enabled() and any(p.requires_grad for p in (self._layers[0].conv.weight,)):
             out = NetFn.apply(xcl, self._layers[0].conv.weight, self)
         else:
@@ -157,7 +162,7 @@ class VNet(HipNet):
     def _forward_impl(self, xcl, save):
         ops = self.ops
         N = xcl.shape[0]
-        G = 1 if self.norm == "batchnorm" else N
+        G = getattr(self, "_groups", 1) if self.norm == "batchnorm" else N
         h = xcl
         skips = []
         saved = []
@@ -184,10 +189,11 @@ class VNet(HipNet):
             else:
                 a, stats = ops.norm_fwd(y, G, None, None, None, None, H.ACT_RELU, chan_scale=cs, residual=res)
             if save:
-                saved.append((h, y, stats, cs))
+                saved.append((h, y, stats, cs, G))
             h = a
         if self.norm == "batchnorm" and self.training:
-            self._nbt_tick()
+            for _ in range(G):
+                self._nbt_tick()
         logits = ops.pw16_fwd(h, self._out.weight.data, self._out.bias.data, self.n_classes)
         if save:
             saved.append((h,))
@@ -195,7 +201,7 @@ class VNet(HipNet):
 
     def _backward_impl(self, saved, dout):
         ops = self.ops
-        G = 1 if self.norm == "batchnorm" else saved[0][0].shape[0]
+        G = saved[0][4]
         dlogits = dout if dout.is_contiguous() else dout.contiguous()
         self.begin_backward()
         (h_last,) = saved[-1]
@@ -203,7 +209,7 @@ class VNet(HipNet):
         skip_grads = []
         for li in range(len(self._layers) - 1, -1, -1):
             L = self._layers[li]
-            x_in, y, stats, cs = saved[li]
+            x_in, y, stats, cs, _ = saved[li]
             w = L.conv.weight
             da = dh
             if L.skip_pop:

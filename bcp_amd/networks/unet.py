@@ -72,8 +72,11 @@ class UNet_2d(HipNet):
         self._prenorm_bias_ids = set(id(m.bias) for cb in self._enc + [u[1] for u in self._up] for m in (cb.c1, cb.c2))
 
     # ------------------------------------------------------------------ public call
-    def forward(self, x):
+    def forward(self, x, groups=1):
+        """groups: see networks/VNet.py:forward -- `groups` sub-batches normalised separately, launched together"""
         N = x.shape[0]
+        assert N % groups == 0
+        self._groups = int(groups)
         assert x.dim() == 4 and x.shape[1] == 1, "expected [N,1,H,W]"
         self._ensure_flat()
         xcl = x.contiguous().view(N, 1, x.shape[2], x.shape[3], 1)
@@ -102,23 +105,24 @@ class UNet_2d(HipNet):
             wf, _ = self._packed((tag, 1), cb.c1.weight, lambda: ops.conv3_pack(cb.c1.weight.data, 1))
             y1 = ops.conv3_fwd(h, wf, cb.c1.bias.data, cb.cout, 1)
         em = self._elem_mask(cb, y1.shape, h.device)
-        a1, st1 = ops.norm_fwd(y1, 1, cb.b1.weight.data, cb.b1.bias.data, cb.b1.running_mean, cb.b1.running_var, H.ACT_LRELU,
+        G = getattr(self, "_groups", 1)
+        a1, st1 = ops.norm_fwd(y1, G, cb.b1.weight.data, cb.b1.bias.data, cb.b1.running_mean, cb.b1.running_var, H.ACT_LRELU,
                                elem_mask=em, elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
         wf2, _ = self._packed((tag, 2), cb.c2.weight, lambda: ops.conv3_pack(cb.c2.weight.data, 1))
         y2 = ops.conv3_fwd(a1, wf2, cb.c2.bias.data, cb.cout, 1)
-        a2, st2 = ops.norm_fwd(y2, 1, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU)
+        a2, st2 = ops.norm_fwd(y2, G, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU)
         if save:
-            saved[tag] = (h, y1, st1, em, a1, y2, st2)
+            saved[tag] = (h, y1, st1, em, a1, y2, st2, G)
         return a2
 
     def _convblock_bwd(self, cb, tag, da2, saved, need_dx):
         ops = self.ops
-        h, y1, st1, em, a1, y2, st2 = saved[tag]
-        dy2 = ops.norm_bwd(y2, da2, 1, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
+        h, y1, st1, em, a1, y2, st2, G = saved[tag]
+        dy2 = ops.norm_bwd(y2, da2, G, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
         ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
         _, wd2 = self._packed((tag, 2), cb.c2.weight, lambda: ops.conv3_pack(cb.c2.weight.data, 1))
         da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
-        dy1 = ops.norm_bwd(y1, da1, 1, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em,
+        dy1 = ops.norm_bwd(y1, da1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em,
                            elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
         if cb.cin == 1:
             ops.conv3_c1_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
@@ -152,7 +156,8 @@ class UNet_2d(HipNet):
         wf, _ = self._packed(("out", 0), self._out.weight, lambda: ops.conv3_pack(self._out.weight.data, 1))
         logits = ops.conv3_fwd(h, wf, self._out.bias.data, self.n_classes, 1)
         if self.training:
-            self._nbt_tick()
+            for _ in range(getattr(self, "_groups", 1)):
+                self._nbt_tick()
         if save:
             saved["out"] = (h,)
             saved["xs"] = xs

@@ -100,26 +100,42 @@ class FlatAdam:
 
 # ------------------------------------------------------------------------------------------ LA / pancreas step
 def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
-                       u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None):
+                       u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None, grouped=True):
     """One self-training iteration, LA_BCP_train.py:235-270 (variant 'pancreas': train_pancreas.py:145-171).
 
     volume_batch [B,1,X,Y,Z] float32 laid out lab_a|lab_b|unlab_a|unlab_b, label_batch [B,X,Y,Z].
     box: explicit (w,h,z,pw,ph,pz) for parity runs, else drawn by context_mask from np.random as the
     reference does.  drops: optional injected Dropout3d keep-masks {'t_a','t_b','s_l','s_u'}.
     dp: optional bcp_amd.dp.DataParallel (gradient all-reduce before the optimiser step).
+    grouped: launch the two teacher batches (and the two student batches) as ONE grouped forward each -- separately
+    normalised exactly like the reference's two calls, but half the launches (False: two calls, as the scripts read).
     Returns device scalars; nothing here synchronises with the host."""
     sub_bs = int(labeled_bs / 2)
     img_a, img_b = volume_batch[:sub_bs], volume_batch[sub_bs:labeled_bs]
     lab_a, lab_b = label_batch[:sub_bs], label_batch[sub_bs:labeled_bs]
     unimg_a, unimg_b = volume_batch[labeled_bs:labeled_bs + sub_bs], volume_batch[labeled_bs + sub_bs:]
     drops = drops or {}
+
+    def cat_drops(k1, k2):
+        d1, d2 = drops.get(k1), drops.get(k2)
+        if d1 is None and d2 is None:
+            return None
+        return {k: torch.cat([d1[k], d2[k]]) for k in d1}
+
     with torch.no_grad():
-        ema_model.drop_masks = drops.get("t_a")
-        unoutput_a = ema_model(unimg_a)[0]
-        ema_model.drop_masks = drops.get("t_b")
-        unoutput_b = ema_model(unimg_b)[0]
-        plab_a = get_cut_mask(unoutput_a, nms=1, connect_mode=connect_mode)
-        plab_b = get_cut_mask(unoutput_b, nms=1, connect_mode=connect_mode)
+        if grouped:
+            # the two teacher batches are adjacent in volume_batch: ONE grouped forward, separately normalised
+            ema_model.drop_masks = cat_drops("t_a", "t_b")
+            unout = ema_model(volume_batch[labeled_bs:], groups=2)[0]
+            plab = get_cut_mask(unout, nms=1, connect_mode=connect_mode)
+            plab_a, plab_b = plab[:sub_bs], plab[sub_bs:]
+        else:
+            ema_model.drop_masks = drops.get("t_a")
+            unoutput_a = ema_model(unimg_a)[0]
+            ema_model.drop_masks = drops.get("t_b")
+            unoutput_b = ema_model(unimg_b)[0]
+            plab_a = get_cut_mask(unoutput_a, nms=1, connect_mode=connect_mode)
+            plab_b = get_cut_mask(unoutput_b, nms=1, connect_mode=connect_mode)
         if box is None:
             if variant == "la":
                 img_mask, loss_mask = BU.context_mask(img_a, mask_ratio)
@@ -130,24 +146,29 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
             sp = tuple(volume_batch.shape[2:])
             img_mask = BU.BoxMask(box, sp, None, False, volume_batch.device)
             loss_mask = BU.BoxMask(box, sp, sub_bs, False, volume_batch.device)
+    # direction tables: LA_BCP_train.py:248-251 / train_pancreas.py:155-156
+    pairs = ((img_a, unimg_a), (unimg_b, img_b)) if variant == "la" else ((unimg_a, img_b), (img_a, unimg_b))
     if variant == "la":
-        mixl_img = img_a * img_mask + unimg_a * (1 - img_mask)
-        mixu_img = unimg_b * img_mask + img_b * (1 - img_mask)
-    else:  # pancreas direction table, train_pancreas.py:155-156
-        mixl_img = unimg_a * img_mask + img_b * (1 - img_mask)
-        mixu_img = img_a * img_mask + unimg_b * (1 - img_mask)
-    model.drop_masks = drops.get("s_l")
-    outputs_l = model(mixl_img)[0]
-    if variant == "la":
-        loss_l = BU.mix_loss(outputs_l, lab_a, plab_a, loss_mask, u_weight=u_weight)
+        terms = ((lab_a, plab_a, 1.0, u_weight), (plab_b, lab_b, u_weight, 1.0))       # mix_loss(.., u_weight) / (.., unlab=True)
     else:
-        loss_l = BU.mix_loss(outputs_l, plab_a, lab_b, loss_mask, unlab=True)
-    model.drop_masks = drops.get("s_u")
-    outputs_u = model(mixu_img)[0]
-    if variant == "la":
-        loss_u = BU.mix_loss(outputs_u, plab_b, lab_b, loss_mask, u_weight=u_weight, unlab=True)
+        terms = ((plab_a, lab_b, 0.5, 1.0), (lab_a, plab_b, 1.0, 0.5))                 # train_pancreas.py:160,164 (default u_weight)
+    if grouped:
+        mixed = torch.empty((2 * sub_bs,) + tuple(volume_batch.shape[1:]), dtype=volume_batch.dtype, device=volume_batch.device)
+        BU.mix(pairs[0][0], pairs[0][1], img_mask, out=mixed[:sub_bs])
+        BU.mix(pairs[1][0], pairs[1][1], img_mask, out=mixed[sub_bs:])
+        model.drop_masks = cat_drops("s_l", "s_u")
+        outputs = model(mixed, groups=2)[0]
+        loss_l, loss_u = BU.mix_loss_pair(outputs, terms[0], terms[1], loss_mask)
+        outputs_l, outputs_u = outputs[:sub_bs], outputs[sub_bs:]
     else:
-        loss_u = BU.mix_loss(outputs_u, lab_a, plab_b, loss_mask)
+        mixl_img = pairs[0][0] * img_mask + pairs[0][1] * (1 - img_mask)
+        mixu_img = pairs[1][0] * img_mask + pairs[1][1] * (1 - img_mask)
+        model.drop_masks = drops.get("s_l")
+        outputs_l = model(mixl_img)[0]
+        loss_l = BU.mix_loss(outputs_l, terms[0][0], terms[0][1], loss_mask, l_weight=terms[0][2], u_weight=terms[0][3])
+        model.drop_masks = drops.get("s_u")
+        outputs_u = model(mixu_img)[0]
+        loss_u = BU.mix_loss(outputs_u, terms[1][0], terms[1][1], loss_mask, l_weight=terms[1][2], u_weight=terms[1][3])
     loss = loss_l + loss_u
     if optimizer is None:      # gradient-only mode (DP equivalence tests): caller owns zero_grad / step / EMA
         loss.backward()
@@ -201,34 +222,59 @@ def update_model_ema(model, ema_model, alpha):
 
 
 def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
-                         u_weight=0.5, alpha=0.99, dp=None):
-    """One ACDC self-training iteration, ACDC_BCP_train.py:355-390."""
+                         u_weight=0.5, alpha=0.99, dp=None, grouped=True):
+    """One ACDC self-training iteration, ACDC_BCP_train.py:355-390 (grouped: see la_self_train_step; needs
+    labeled_bs == batch - labeled_bs so that both halves have equal size)."""
     bs = volume_batch.shape[0]
     lsub, usub = int(labeled_bs / 2), int((bs - labeled_bs) / 2)
+    grouped = grouped and lsub == usub
     img_a, img_b = volume_batch[:lsub], volume_batch[lsub:labeled_bs]
     uimg_a, uimg_b = volume_batch[labeled_bs:labeled_bs + usub], volume_batch[labeled_bs + usub:]
     lab_a, lab_b = label_batch[:lsub], label_batch[lsub:labeled_bs]
     drops = drops or {}
+
+    def cat_drops(k1, k2):
+        d1, d2 = drops.get(k1), drops.get(k2)
+        if d1 is None and d2 is None:
+            return None
+        return {k: torch.cat([d1[k], d2[k]]) for k in d1}
+
     with torch.no_grad():
-        ema_model.drop_masks = drops.get("t_a")
-        pre_a = ema_model(uimg_a)
-        ema_model.drop_masks = drops.get("t_b")
-        pre_b = ema_model(uimg_b)
-        plab_a = get_ACDC_masks(pre_a, nms=1)
-        plab_b = get_ACDC_masks(pre_b, nms=1)
+        if grouped:
+            ema_model.drop_masks = cat_drops("t_a", "t_b")
+            pre = ema_model(volume_batch[labeled_bs:], groups=2)
+            plab = get_ACDC_masks(pre, nms=1)
+            plab_a, plab_b = plab[:usub], plab[usub:]
+        else:
+            ema_model.drop_masks = drops.get("t_a")
+            pre_a = ema_model(uimg_a)
+            ema_model.drop_masks = drops.get("t_b")
+            pre_b = ema_model(uimg_b)
+            plab_a = get_ACDC_masks(pre_a, nms=1)
+            plab_b = get_ACDC_masks(pre_b, nms=1)
         if box is None:
             img_mask, loss_mask = generate_mask(img_a)
         else:
             sp = tuple(volume_batch.shape[2:])
             img_mask, loss_mask = BU.BoxMask(box, sp, None, False, volume_batch.device), BU.BoxMask(box, sp, lsub, False, volume_batch.device)
-    net_input_unl = uimg_a * img_mask + img_a * (1 - img_mask)
-    net_input_l = img_b * img_mask + uimg_b * (1 - img_mask)
-    model.drop_masks = drops.get("s_unl")
-    out_unl = model(net_input_unl)
-    unl_dice, unl_ce = acdc_mix_loss(out_unl, plab_a, lab_a, loss_mask, u_weight=u_weight, unlab=True)
-    model.drop_masks = drops.get("s_l")
-    out_l = model(net_input_l)
-    l_dice, l_ce = acdc_mix_loss(out_l, lab_b, plab_b, loss_mask, u_weight=u_weight)
+    if grouped:
+        mixed = torch.empty((2 * lsub,) + tuple(volume_batch.shape[1:]), dtype=volume_batch.dtype, device=volume_batch.device)
+        BU.mix(uimg_a, img_a, img_mask, out=mixed[:lsub])      # net_input_unl, ACDC_BCP_train.py:372
+        BU.mix(img_b, uimg_b, img_mask, out=mixed[lsub:])      # net_input_l,   :373
+        model.drop_masks = cat_drops("s_unl", "s_l")
+        out = model(mixed, groups=2)
+        unl_dice, unl_ce, l_dice, l_ce = BU.mix_loss_pair(out, (plab_a, lab_a, u_weight, 1.0), (lab_b, plab_b, 1.0, u_weight), loss_mask,
+                                                          flavour=H.LOSS_ACDC)
+        out_unl, out_l = out[:lsub], out[lsub:]
+    else:
+        net_input_unl = uimg_a * img_mask + img_a * (1 - img_mask)
+        net_input_l = img_b * img_mask + uimg_b * (1 - img_mask)
+        model.drop_masks = drops.get("s_unl")
+        out_unl = model(net_input_unl)
+        unl_dice, unl_ce = acdc_mix_loss(out_unl, plab_a, lab_a, loss_mask, u_weight=u_weight, unlab=True)
+        model.drop_masks = drops.get("s_l")
+        out_l = model(net_input_l)
+        l_dice, l_ce = acdc_mix_loss(out_l, lab_b, plab_b, loss_mask, u_weight=u_weight)
     loss_ce = unl_ce + l_ce
     loss_dice = unl_dice + l_dice
     loss = (loss_dice + loss_ce) / 2

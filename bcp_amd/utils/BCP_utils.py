@@ -97,7 +97,7 @@ class _Masked:
         return self.t * self.mask.tensor(self.t.device, self.t.dtype)
 
 
-def mix(a, b, mask: BoxMask):
+def mix(a, b, mask: BoxMask, out=None):
     """a*mask + b*(1-mask) (LA_BCP_train.py:248-251): `a` outside the box, `b` inside."""
     if a.dtype != torch.float32 or a.dim() not in (4, 5) or a.shape[1] != 1:
         m = mask.tensor(a.device, a.dtype) if not mask.complement else (1 - mask).tensor(a.device, a.dtype)
@@ -106,8 +106,9 @@ def mix(a, b, mask: BoxMask):
     N = a.shape[0]
     sp = tuple(a.shape[2:])
     cl_shape = (N,) + ((1,) + sp if len(sp) == 2 else sp) + (1,)
-    out = ops.mix_box(a.contiguous().view(cl_shape), b.contiguous().view(cl_shape), mask.box6())
-    return out.view(a.shape)
+    o = ops.mix_box(a.contiguous().view(cl_shape), b.contiguous().view(cl_shape), mask.box6(),
+                    out=None if out is None else out.view(cl_shape))
+    return o.view(a.shape)
 
 
 _CPU_OPS = None
@@ -181,6 +182,59 @@ class _MixLossFn(torch.autograd.Function):
             gc = gs[1].reshape(1).to(torch.float32) if gs[1] is not None else z
             d = ops.mixloss_bwd(logits_cl, img_l, patch_l, box6, flavour, ws, 1.0, 1.0, mask=mask_u8, g_dev=torch.cat([gd, gc]).contiguous())
         return d, None, None, None, None, None, None, None
+
+
+class _MixLossPairFn(torch.autograd.Function):
+    """Both mix_loss terms of a BCP step on the two halves of ONE logits tensor (grouped forward): the backward
+    kernels write their halves of a single gradient buffer, so autograd never pads / adds slice gradients."""
+
+    @staticmethod
+    def forward(ctx, logits_cl, lab1, plab1, lab2, plab2, box6, mask_u8, flavour, w1, w2):
+        ops = _ops_for(logits_cl)
+        n = logits_cl.shape[0] // 2
+        a, b = logits_cl[:n], logits_cl[n:]
+        o1, ws1 = ops.mixloss_fwd(a, lab1, plab1, box6, flavour, w1[0], w1[1], mask=mask_u8)
+        o2, ws2 = ops.mixloss_fwd(b, lab2, plab2, box6, flavour, w2[0], w2[1], mask=mask_u8)
+        ctx.save_for_backward(logits_cl, lab1, plab1, lab2, plab2, ws1, ws2)
+        ctx.meta = (box6, mask_u8, flavour)
+        if flavour == H.LOSS_LA:
+            return o1[0], o2[0]
+        return o1[0], o1[1], o2[0], o2[1]
+
+    @staticmethod
+    def backward(ctx, *gs):
+        logits_cl, lab1, plab1, lab2, plab2, ws1, ws2 = ctx.saved_tensors
+        box6, mask_u8, flavour = ctx.meta
+        ops = _ops_for(logits_cl)
+        n = logits_cl.shape[0] // 2
+        d = torch.empty_like(logits_cl)
+        z = torch.zeros(1, dtype=torch.float32, device=logits_cl.device)
+
+        def gv(g):
+            return g.reshape(1).to(torch.float32) if g is not None else z
+
+        if flavour == H.LOSS_LA:
+            pairs = ((gv(gs[0]), gv(gs[0]), 0.5), (gv(gs[1]), gv(gs[1]), 0.5))
+        else:
+            pairs = ((gv(gs[0]), gv(gs[1]), 1.0), (gv(gs[2]), gv(gs[3]), 1.0))
+        for half, (lab, plab, ws, (gd, gc, k)) in enumerate(((lab1, plab1, ws1, pairs[0]), (lab2, plab2, ws2, pairs[1]))):
+            sl = slice(0, n) if half == 0 else slice(n, 2 * n)
+            ops.mixloss_bwd(logits_cl[sl], lab, plab, box6, flavour, ws, k, k, mask=mask_u8, g_dev=torch.cat([gd, gc]).contiguous(),
+                            out=d[sl])
+        return (d,) + (None,) * 9
+
+
+def mix_loss_pair(out, first, second, mask, flavour=H.LOSS_LA):
+    """`out` = logits of a grouped forward over [batch1; batch2]; `first` / `second` = (img_l, patch_l, w_img, w_patch)
+    for each half.  LA: returns (loss_1, loss_2); ACDC: (dice_1, ce_1, dice_2, ce_2)."""
+    cl = _as_cl(out)
+    ops = _ops_for(cl)
+    N, sp = cl.shape[0] // 2, tuple(out.shape[2:])
+    box6, m8 = _mask_args(mask, ops, N, sp)
+    l1, p1, w1a, w1b = first
+    l2, p2, w2a, w2b = second
+    return _MixLossPairFn.apply(cl, _labels_u8(ops, l1, N, sp), _labels_u8(ops, p1, N, sp), _labels_u8(ops, l2, N, sp),
+                                _labels_u8(ops, p2, N, sp), box6, m8, flavour, (float(w1a), float(w1b)), (float(w2a), float(w2b)))
 
 
 def _mask_args(mask, ops, N, sp):

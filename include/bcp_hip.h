@@ -78,7 +78,10 @@ int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* pa
 /* ---- norm + activation (+Dropout3d channel scale, +elementwise dropout mask, +residual)
  *      (nn.BatchNorm3d/2d train mode networks/VNet.py:18-26, networks/unet.py:21-28; nn.InstanceNorm3d pancreas/Vnet.py:93;
  *      ReLU / LeakyReLU(0.01); Dropout3d VNet.py:165,211; Dropout unet.py:23; skip add VNet.py:220-233).
- *      G = 1: BatchNorm over all rows; G = N: InstanceNorm.  stats = float[4][G][C] {mean, rstd, scale = gamma*rstd, beta}; z = (y - mean)*scale + beta. */
+ *      G = 1: BatchNorm over all rows; G = N without gamma/beta: InstanceNorm; G > 1 WITH gamma/beta/running stats: "grouped
+ *      BatchNorm" = G consecutive BatchNorm calls in one launch (statistics per group, running stats updated group after
+ *      group in order) -- how the two student / teacher batches of a BCP step are normalised separately yet launched together.
+ *      stats = float[5][G][C] {mean, rstd, scale = gamma*rstd, beta, unbiased var}; z = (y - mean)*scale + beta. */
 size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C);
 int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,

@@ -185,6 +185,32 @@ def check_norm(ops, dev):
             close(dg, 2 * gamma.grad, rtol=2e-4, msg="dgamma accumulate")
 
 
+def check_norm_grouped(ops, dev):
+    """G groups WITH affine == G consecutive BatchNorm calls: statistics per group, running stats updated in order,
+    parameter gradients summed over the groups"""
+    rng = np.random.default_rng(14)
+    N, Cc, sp, G = 4, 32, (3, 4, 5), 2
+    y = (R(rng, N, Cc, *sp) * 1.3 - 0.2).requires_grad_(True)
+    gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cc).astype(np.float32)).requires_grad_(True)
+    beta = torch.from_numpy(rng.uniform(-0.3, 0.3, Cc).astype(np.float32)).requires_grad_(True)
+    rm_ref, rv_ref = torch.zeros(Cc), torch.ones(Cc)
+    outs = [F.relu(F.batch_norm(y[g * 2:(g + 1) * 2], rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)) for g in range(G)]
+    a_ref = torch.cat(outs)
+    da = R(rng, N, Cc, *sp)
+    a_ref.backward(da)
+    rmd, rvd = torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)
+    ycl = to_cl(y.detach()).to(dev)
+    a, stats = ops.norm_fwd(ycl, G, gamma.detach().to(dev), beta.detach().to(dev), rmd, rvd, H.ACT_RELU)
+    close(from_cl(a), a_ref, msg="grouped BN fwd")
+    close(rmd, rm_ref, rtol=1e-5, msg="grouped running_mean (sequential update)")
+    close(rvd, rv_ref, rtol=1e-5, msg="grouped running_var")
+    dg, db = torch.zeros(Cc).to(dev), torch.zeros(Cc).to(dev)
+    dy = ops.norm_bwd(ycl, to_cl(da).to(dev), G, stats, H.ACT_RELU, dg, db, False)
+    close(from_cl(dy), y.grad, rtol=2e-4, msg="grouped BN dy")
+    close(dg, gamma.grad, rtol=2e-4, msg="grouped dgamma")
+    close(db, beta.grad, rtol=2e-4, msg="grouped dbeta")
+
+
 CONV3_CASES = (
     # (N, Cin, Cout, spatial, KD)
     (1, 16, 16, (4, 4, 16), 3),       # exactly one 4x4x16 tile
@@ -387,4 +413,25 @@ def check_optim(ops, dev):
     assert torch.equal(ops.to_u8(lab.float().to(dev)).cpu(), lab.to(torch.uint8))
 
 
-ALL_CHECKS = ("mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")
+CONV3_RES_CASES = (
+    # shapes that route to the resident-weight persistent kernel (tiles x slabs >= 192)
+    (1, 16, 16, (16, 16, 48), 3),     # 4x4x4 tiles, 1 chunk
+    (1, 32, 32, (14, 17, 50), 3),     # 2 chunks, 2 slabs, partial tiles
+    (1, 64, 64, (12, 12, 24), 3),     # 4 chunks, 4 slabs
+    (2, 16, 32, (1, 72, 64), 1),      # 2-D, 8x8 tiles
+    (1, 32, 16, (34, 36, 56), 3),     # >= 64K voxels: 4x4x8 tiles (M = 128)
+)
+
+
+def check_conv3_res(ops, dev):
+    """resident-weight kernel, with the persistent grid forced small so every block walks several tiles"""
+    import os
+    os.environ["BCP_CONV3_P"] = "7"
+    try:
+        check_conv3(ops, dev, cases=CONV3_RES_CASES)
+    finally:
+        del os.environ["BCP_CONV3_P"]
+    check_conv3(ops, dev, cases=CONV3_RES_CASES[:2])
+
+
+ALL_CHECKS = ("conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")

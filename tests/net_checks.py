@@ -121,6 +121,35 @@ def check_vnet_smooth(ops, dev, shape=(32, 32, 16), variant="la", seed=3, N=1):
     return worst
 
 
+def check_grouped_equals_separate(ops, dev):
+    """one grouped forward/backward over [x1; x2] == two separate calls (what the reference does): logits, BN
+    running statistics and accumulated gradients"""
+    rng = np.random.default_rng(21)
+    P = O.init_params(O.vnet_param_shapes(), seed=77, random_affine=True)
+    x = torch.from_numpy(rng.standard_normal((2, 1, 32, 32, 16), dtype=np.float32)).to(dev)
+    tgt = torch.from_numpy(rng.integers(0, 2, (2, 32, 32, 16))).to(dev)
+    dm = {"x5": torch.from_numpy((rng.random((2, 256)) < 0.5).astype(np.float32)), "x9": torch.from_numpy((rng.random((2, 16)) < 0.5).astype(np.float32))}
+    a, b = make_vnet(P, dev, ops), make_vnet(P, dev, ops)
+    a.drop_masks = dm
+    oa = a(x, groups=2)[0]
+    (BU.sup_loss(oa[:1], tgt[:1]) + BU.sup_loss(oa[1:], tgt[1:])).backward()
+    outs = []
+    for i in range(2):
+        b.drop_masks = {k: v[i:i + 1] for k, v in dm.items()}
+        o = b(x[i:i + 1])[0]
+        outs.append(o.detach())
+        BU.sup_loss(o, tgt[i:i + 1]).backward()
+    K.close(oa.detach(), torch.cat(outs), rtol=1e-5, msg="grouped logits")
+    sa, sb = a.state_dict(), b.state_dict()
+    for k in sa:
+        if "running" in k:
+            K.close(sa[k], sb[k], rtol=1e-5, msg=k)
+        if k.endswith("num_batches_tracked") and (k.startswith("encoder") or k.startswith("decoder")):
+            assert int(sa[k]) == int(sb[k]) == 2, k
+    ga, gb = a.flat_trainable()[1], b.flat_trainable()[1]
+    assert K.rel_l2(ga, gb) < 1e-5, K.rel_l2(ga, gb)
+
+
 def check_la_step(ops, dev, golden_dir):
     """3 self-training steps through the drop-in API (teacher fwd, pseudo-label, CC, box mix, student fwd/bwd,
     mix_loss, SGD, EMA) vs the trajectory recorded from the reference's own functions (la_traj.npz)."""

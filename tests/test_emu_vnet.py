@@ -22,3 +22,7 @@ def test_vnet_pancreas_smooth(emu_ops):
 
 def test_la_self_train_trajectory(emu_ops, golden_dir):
     NC.check_la_step(emu_ops, CPU, golden_dir)
+
+
+def test_grouped_forward_equals_separate_calls(emu_ops):
+    NC.check_grouped_equals_separate(emu_ops, CPU)

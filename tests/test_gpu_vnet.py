@@ -68,3 +68,7 @@ def test_vnet_la_full_shape_vs_reference_golden(ops, golden_dir):
             continue
         l2 = float(params[n_].grad.double().norm())
         assert abs(l2 - stg[2]) / max(stg[2], 1e-12) < 3e-2, (n_, l2, stg[2])
+
+
+def test_grouped_forward_equals_separate_calls(ops):
+    NC.check_grouped_equals_separate(ops, DEV)
