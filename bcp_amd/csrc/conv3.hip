@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   constexpr int NBUF = (S > 1) ? 2 : 1;
   constexpr int WSTAGE4 = WT * 4 * CT;          // float4s per weight stage
   constexpr int NW4 = (WSTAGE4 + 255) / 256;    // per-thread prefetch registers
+  constexpr int NACC = (MT * NT == 1) ? 2 : 1;  // a lone accumulator would serialise on the 40-cycle MFMA latency
 
   HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
   float* smem = reinterpret_cast<float*>(smem4);
@@ -110,14 +111,19 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[NACC][MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
+  for (int a = 0; a < NACC; ++a)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // split-K: blockIdx.z owns a contiguous range of cin chunks and writes its own partial slab (summed by k_sum_slabs)
   const int nchunks = cd.Cin16 >> 4;
-  for (int cc = 0; cc < nchunks; ++cc) {
+  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
+  Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
+  for (int cc = c_begin; cc < c_end; ++cc) {
     __syncthreads();  // everyone is done with the previous chunk's LDS contents
     load_halo<TL>(X, Xs, cd, n, d0, h0, w0, cc);
     // weight stage 0 of this chunk
@@ -153,10 +159,10 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
           }
       }
       if (S > 1) {
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
         for (int nt = 0; nt < NT; ++nt) {
           const int co = cout0 + nt * 16 + li;
           if (co < cd.Cout) {
-            float v = acc[mt][nt][r];
+            float v = acc[0][mt][nt][r];
+            if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
             if (bias) v += bias[co];
             if (accumulate) v += yrow[co];
             yrow[co] = v;
@@ -195,6 +202,16 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
         }
       }
     }
+  }
+}
+
+// y (+)= bias + sum_k part[k]   (split-K epilogue of the streaming kernel; deep V-Net levels only: <= 1 MB)
+__global__ __launch_bounds__(256) void k_sum_slabs(const float* __restrict__ part, int SK, long long n, int C,
+                                                   const float* __restrict__ bias, float* __restrict__ y, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float s = bias ? bias[i % C] : 0.f;
+    for (int k = 0; k < SK; ++k) s += part[k * n + i];
+    y[i] = accumulate ? y[i] + s : s;
   }
 }
 
@@ -362,6 +379,9 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   constexpr int T = TL::T, CT = NT * 16, M = TL::M;
   constexpr int TPW = (T + 3) / 4;                      // taps per wave
   constexpr int YS = (CT % 32 == 0) ? CT + 16 : CT;     // dY tile row stride (bank spread for the 4 k-groups)
+  constexpr int NX4 = (TL::HV * 4 + 255) / 256;         // halo float4s per thread
+  constexpr int NY4 = (M * (CT / 4) + 255) / 256;       // dY-tile float4s per thread
+  static_assert(TW % 4 == 0, "a k-step is 4 consecutive voxels of one tile row");
 
   HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
   float* smem = reinterpret_cast<float*>(smem4);
@@ -380,47 +400,97 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int toff[TPW];
+  // per-lane parts of the LDS addresses; the (row, kw) parts are wave-uniform scalars
+  int xoff[TPW];
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int tap = wave + 4 * t;
-    toff[t] = (tap < T ? TL::tapoff(tap) : 0) * XS + li;
+    xoff[t] = ((tap < T ? TL::tapoff(tap) : 0) + lg) * XS + li;
   }
+  const int yoff = lg * YS + li;
 
   int t_end = (grp + 1) * tiles_per_group;
   if (t_end > tiles_total) t_end = tiles_total;
-  for (int tile = grp * tiles_per_group; tile < t_end; ++tile) {
+  int tile = grp * tiles_per_group;
+  if (tile >= t_end) return;
+
+  float4 px[NX4], py[NY4];
+  auto fetch = [&](int tl) {   // global -> registers for tile tl
     int n, d0, h0, w0;
-    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
-    __syncthreads();
-    load_halo<TL>(X, Xs, cd, n, d0, h0, w0, cc);
-    for (int q = threadIdx.x; q < M * (CT / 4); q += 256) {
-      const int m = q / (CT / 4), c4 = q % (CT / 4);
-      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-      const int d = d0 + td, h = h0 + th, w = w0 + tw;
-      const int co = cout0 + c4 * 4;
+    tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
+#pragma unroll
+    for (int u = 0; u < NX4; ++u) {
+      const int q = threadIdx.x + u * 256;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (d < cd.D && h < cd.H && w < cd.W && co < cd.Cout)
-        v = ld4(dY + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout + co);
-      st4(Ys + m * YS + c4 * 4, v);
+      if (q < TL::HV * 4) {
+        const int hv = q >> 2, part = q & 3;
+        const int hw = hv % TL::HW, hh = (hv / TL::HW) % TL::HH, hd = hv / (TL::HW * TL::HH);
+        const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
+        const int c = cc * 16 + part * 4;
+        if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)w < (unsigned)cd.W && c < cd.Cin)
+          v = ld4(X + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cin + c);
+      }
+      px[u] = v;
     }
-    __syncthreads();
-#pragma unroll 2
-    for (int k = 0; k < M / 4; ++k) {
-      const int m = k * 4 + lg;
-      const int vx = TL::voff(m) * XS;
-      float b[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[m * YS + nt * 16 + li];
+    for (int u = 0; u < NY4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < M * (CT / 4)) {
+        const int m = q / (CT / 4), c4 = q % (CT / 4);
+        const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+        const int d = d0 + td, h = h0 + th, w = w0 + tw;
+        const int co = cout0 + c4 * 4;
+        if (d < cd.D && h < cd.H && w < cd.W && co < cd.Cout)
+          v = ld4(dY + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout + co);
+      }
+      py[u] = v;
+    }
+  };
+  auto stash = [&]() {         // registers -> LDS
 #pragma unroll
-      for (int t = 0; t < TPW; ++t) {
-        if (wave + 4 * t < T) {  // wave-uniform
-          const float a = Xs[vx + toff[t]];
+    for (int u = 0; u < NX4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      if (q < TL::HV * 4) st4(Xs + (q >> 2) * XS + (q & 3) * 4, px[u]);
+    }
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[t][nt], 0, 0, 0);
+    for (int u = 0; u < NY4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      if (q < M * (CT / 4)) st4(Ys + (q / (CT / 4)) * YS + (q % (CT / 4)) * 4, py[u]);
+    }
+  };
+
+  fetch(tile);
+  stash();
+  __syncthreads();
+  for (;;) {
+    const bool has_next = tile + 1 < t_end;
+    if (has_next) fetch(tile + 1);           // loads stay in flight under the MFMAs below
+#pragma unroll 1
+    for (int row = 0; row < M / TW; ++row) {
+      const int th = row % TH, td = row / TH;
+      const int xrow = ((td * TL::HH + th) * TL::HW) * XS;   // wave-uniform
+#pragma unroll
+      for (int kw = 0; kw < TW / 4; ++kw) {
+        const int m0 = row * TW + kw * 4;
+        float b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[m0 * YS + yoff + nt * 16];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+          if (wave + 4 * t < T) {  // wave-uniform
+            const float a = Xs[xrow + kw * 4 * XS + xoff[t]];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[t][nt], 0, 0, 0);
+          }
         }
       }
     }
+    if (!has_next) break;
+    __syncthreads();
+    stash();
+    __syncthreads();
+    ++tile;
   }
   // partial[grp][tap][ci][co]: lane (li, lg) holds ci = lg*4 + r (rows), co = li (cols)
   float* P = partial + (long long)grp * T * cd.Cin16 * cd.Cout16;
@@ -437,20 +507,30 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   }
 }
 
-// dW_torch[co][ci][tap] (+)= sum_g partial[g][tap][ci][co]
+// dW_torch[co][ci][tap] (+)= sum_g partial[g][tap][ci][co].  One block per (ci, 64-wide co slab): the [T][64] tile is
+// read with co fastest (coalesced), transposed through LDS and written as T-contiguous runs per (co, ci).
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ partial, float* __restrict__ dW, int G, int T,
                                                       int Cin, int Cout, int Cin16, int Cout16, int accumulate) {
-  const long long total = (long long)T * Cin * Cout;
+  __shared__ float tile[27 * 65];
+  const int ci = blockIdx.x, co0 = blockIdx.y * 64;
   const long long slab = (long long)T * Cin16 * Cout16;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int co = (int)(i % Cout);
-    const int ci = (int)((i / Cout) % Cin);
-    const int tap = (int)(i / ((long long)Cout * Cin));
-    const float* p = partial + ((long long)tap * Cin16 + ci) * Cout16 + co;
+  for (int q = threadIdx.x; q < T * 64; q += 256) {
+    const int col = q & 63, tap = q >> 6;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += p[g * slab];
-    float* o = dW + ((long long)co * Cin + ci) * T + tap;
-    *o = accumulate ? (*o + s) : s;
+    if (co0 + col < Cout) {
+      const float* p = partial + ((long long)tap * Cin16 + ci) * Cout16 + co0 + col;
+      for (int g = 0; g < G; ++g) s += p[g * slab];
+    }
+    tile[tap * 65 + col] = s;
+  }
+  __syncthreads();
+  for (int q = threadIdx.x; q < T * 64; q += 256) {
+    const int tap = q % T, col = q / T;
+    if (co0 + col < Cout) {
+      float* o = dW + ((long long)(co0 + col) * Cin + ci) * T + tap;
+      const float v = tile[tap * 65 + col];
+      *o = accumulate ? (*o + v) : v;
+    }
   }
 }
 
@@ -585,16 +665,30 @@ __global__ __launch_bounds__(256) void k_conv3_c1_wgrad(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 struct Cfg { int KD, TD, TH, TW, NT, WT; };
 
+static int split_k(long long blocks, int nch) {   // deep levels: too few tiles to fill 256 CUs -> split the cin chunks
+  if (blocks > 256 || nch < 4) return 1;
+  int sk = nch / 2;
+  if (sk > 4) sk = 4;
+  return sk;
+}
+
 template <int KD, int TD, int TH, int TW, int NT, int WT>
-static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, hipStream_t s) {
+static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int S = TL::T / WT, NBUF = S > 1 ? 2 : 1;
   const size_t lds = (size_t)(TL::HV * XS + NBUF * WT * 4 * NT * 16 * 4) * sizeof(float);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   auto kfn = k_conv3_mfma<KD, TD, TH, TW, NT, WT>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const dim3 grid(cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, cd.Cout16 / (NT * 16));
-  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate);
+  const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / (NT * 16);
+  const int sk = ws ? split_k((long long)gx * gy, cd.Cin16 / 16) : 1;
+  if (sk == 1) {
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate);
+  } else {
+    const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, 0);
+    hipLaunchKernelGGL(k_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y, accumulate);
+  }
   return 0;
 }
 
@@ -650,7 +744,8 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   const long long tiles = (long long)N * cdiv(D, c.TD) * cdiv(H, c.TH) * cdiv(W, c.TW);
   int nt = (M == 256) ? 4 : 4;
   while (nt > 1 && (Cout16 % (nt * 16) != 0)) nt >>= 1;
-  while (nt > 1 && tiles * (Cout16 / (nt * 16)) < 256) nt >>= 1;  // more blocks for small problems
+  const long long want = tiles < 256 ? 512 : 256;                 // tiny spatial extents: >= 2 blocks per CU
+  while (nt > 1 && tiles * (Cout16 / (nt * 16)) < want) nt >>= 1;  // more blocks for small problems
   c.NT = nt;
   c.WT = 0;
   return c;
@@ -687,7 +782,7 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
 
 #define BCP_FWD_CASE(KD_, TD_, TH_, TW_, NT_, WT_)                                                             \
   if (c.KD == KD_ && c.TD == TD_ && c.TH == TH_ && c.TW == TW_ && c.NT == NT_) {                               \
-    launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (hipStream_t)stream);             \
+    launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (float*)workspace, (hipStream_t)stream);             \
     done = true;                                                                                               \
   }
 #define BCP_RES_CASE(KD_, TD_, TH_, TW_, NT_)                                                                  \
@@ -723,8 +818,14 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
   return false;
 }
 
+extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD) {
+  // split-K partial slabs (only taken for grids of <= 256 blocks): at most 4 copies of the output
+  const long long n = (long long)N * D * H * W * Cout;
+  return n <= (1LL << 20) ? (size_t)(4 * n * sizeof(float)) : 0;
+}
+
 extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
-                             int Cout, int KD, int accumulate, void* stream) {
+                             int Cout, int KD, int accumulate, void* workspace, void* stream) {
   BCP_REQUIRE(x && wp && y, "bcp_conv3_fwd: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd: bad extents");
   BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd: KD=1 needs D=1");
@@ -809,10 +910,8 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   BCP_WG_CASE(1, 1, 8, 8, 1) BCP_WG_CASE(1, 1, 8, 8, 2) BCP_WG_CASE(1, 1, 8, 8, 4)
   BCP_REQUIRE(done, "bcp_conv3_wgrad: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
   const int T = KD * 9;
-  const long long total = (long long)T * Cin * Cout;
-  const int grid = (int)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256);
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(grid), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout, cd.Cin16, cd.Cout16,
-                     accumulate);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(Cin, cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout, cd.Cin16,
+                     cd.Cout16, accumulate);
   BCP_CHECK_LAUNCH("bcp_conv3_wgrad");
   return BCP_OK;
 }
@@ -859,8 +958,7 @@ extern "C" int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, in
     hipLaunchKernelGGL((k_conv3_c1_wgrad<1, 1, 16, 16>), dim3(G), dim3(256), 0, (hipStream_t)stream, x, dy, ws, cd, tiles, tpg);
   }
   const int T = KD * 9;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(cdiv(T * 16, 256)), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16,
-                     accumulate);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(1, 1), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16, accumulate);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_wgrad");
   return BCP_OK;
 }

@@ -185,7 +185,9 @@ class Ops:
         N, D, H, W, Cin = x.shape
         if out is None:
             out = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=x.device)
-        self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), self.stream(x))
+        nbytes = self.b.call("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cin, Cout, KD)
+        ws = self.workspace("conv3", nbytes, x) if nbytes else None
+        self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), self.stream(x))
         return out
 
     def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):

@@ -97,8 +97,9 @@ int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_grou
  *      bcp_conv3_fwd(dy -> dx, Cin/Cout swapped).  Channel counts must be multiples of 4 (padded to 16 inside). */
 size_t bcp_conv3_packed_weight_floats(int Cin, int Cout, int KD);
 int bcp_conv3_pack_weight(const float* w, float* wp_fwd_or_null, float* wp_dgrad_or_null, int Cin, int Cout, int KD, void* stream);
+size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD); /* split-K slabs of the deep levels; may be 0 */
 int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin, int Cout,
-                  int KD, int accumulate, void* stream);
+                  int KD, int accumulate, void* workspace_or_null, void* stream);
 size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD);
 int bcp_conv3_wgrad(const float* x, const float* dy, float* dw /*[Cout][Cin][KD*9]*/, int N, int D, int H, int W, int Cin, int Cout,
                     int KD, int accumulate, void* workspace, void* stream);
