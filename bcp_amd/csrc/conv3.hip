@@ -476,13 +476,13 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
         float b[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[m0 * YS + yoff + nt * 16];
+        // no per-tap guard here: a wave whose last tap slot is past T (27 = 4*7 - 1) recomputes tap 0 into an accumulator
+        // that is never stored -- 1/28 wasted MFMAs instead of predicated MFMAs and accumulator shuffles
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-          if (wave + 4 * t < T) {  // wave-uniform
-            const float a = Xs[xrow + kw * 4 * XS + xoff[t]];
+          const float a = Xs[xrow + kw * 4 * XS + xoff[t]];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[t][nt], 0, 0, 0);
-          }
+          for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[t][nt], 0, 0, 0);
         }
       }
     }
@@ -531,6 +531,29 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
       const float v = tile[tap * 65 + col];
       *o = accumulate ? (*o + v) : v;
     }
+  }
+}
+
+// Many-group variant (shallow layers: one cin chunk x one slab => hundreds of spatial groups): one block per
+// (ci, 64-wide co slab, tap); 256 threads = 64 co x 4 group-slots, LDS sum over the slots.  Same fixed summation order
+// every run (deterministic).
+__global__ __launch_bounds__(256) void k_wgrad_reduce_deep(const float* __restrict__ partial, float* __restrict__ dW, int G, int T,
+                                                           int Cin, int Cout, int Cin16, int Cout16, int accumulate) {
+  __shared__ float red[4][64];
+  const int ci = blockIdx.x, co0 = blockIdx.y * 64, tap = blockIdx.z;
+  const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const long long slab = (long long)T * Cin16 * Cout16;
+  float s = 0.f;
+  if (co0 + col < Cout) {
+    const float* p = partial + ((long long)tap * Cin16 + ci) * Cout16 + co0 + col;
+    for (int g = slot; g < G; g += 4) s += p[g * slab];
+  }
+  red[slot][col] = s;
+  __syncthreads();
+  if (slot == 0 && co0 + col < Cout) {
+    const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    float* o = dW + ((long long)(co0 + col) * Cin + ci) * T + tap;
+    *o = accumulate ? (*o + v) : v;
   }
 }
 
@@ -744,7 +767,7 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   const long long tiles = (long long)N * cdiv(D, c.TD) * cdiv(H, c.TH) * cdiv(W, c.TW);
   int nt = (M == 256) ? 4 : 4;
   while (nt > 1 && (Cout16 % (nt * 16) != 0)) nt >>= 1;
-  const long long want = tiles < 256 ? 512 : 256;                 // tiny spatial extents: >= 2 blocks per CU
+  const long long want = tiles <= 128 ? 512 : 256;                // tiny spatial extents: >= 2 blocks per CU
   while (nt > 1 && tiles * (Cout16 / (nt * 16)) < want) nt >>= 1;  // more blocks for small problems
   c.NT = nt;
   c.WT = 0;
@@ -910,8 +933,12 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   BCP_WG_CASE(1, 1, 8, 8, 1) BCP_WG_CASE(1, 1, 8, 8, 2) BCP_WG_CASE(1, 1, 8, 8, 4)
   BCP_REQUIRE(done, "bcp_conv3_wgrad: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
   const int T = KD * 9;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(Cin, cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout, cd.Cin16,
-                     cd.Cout16, accumulate);
+  if (G >= 32)
+    hipLaunchKernelGGL(k_wgrad_reduce_deep, dim3(Cin, cdiv(Cout, 64), T), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout,
+                       cd.Cin16, cd.Cout16, accumulate);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(Cin, cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout, cd.Cin16,
+                       cd.Cout16, accumulate);
   BCP_CHECK_LAUNCH("bcp_conv3_wgrad");
   return BCP_OK;
 }
@@ -958,7 +985,10 @@ extern "C" int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, in
     hipLaunchKernelGGL((k_conv3_c1_wgrad<1, 1, 16, 16>), dim3(G), dim3(256), 0, (hipStream_t)stream, x, dy, ws, cd, tiles, tpg);
   }
   const int T = KD * 9;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(1, 1), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16, accumulate);
+  if (G >= 32)
+    hipLaunchKernelGGL(k_wgrad_reduce_deep, dim3(1, 1, T), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16, accumulate);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(1, 1), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16, accumulate);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_wgrad");
   return BCP_OK;
 }
