@@ -581,6 +581,27 @@ __global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w,
   }
 }
 
+// all conv layers of a network in ONE launch (blockIdx.y = descriptor): 80 five-microsecond pack launches per step otherwise
+struct PackDesc { const float* w; float* wp; int Cout, Cin, T, K16, N16, dgrad; };
+__global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const long long total = (long long)d.T * d.K16 * d.N16;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k4 = (int)(i & 3);
+    const int nn = (int)((i >> 2) % d.N16);
+    const int kq = (int)((i / (4LL * d.N16)) % (d.K16 / 4));
+    const int t = (int)(i / ((long long)d.K16 * d.N16));
+    const int kk = kq * 4 + k4;
+    float v = 0.f;
+    if (!d.dgrad) {
+      if (kk < d.Cin && nn < d.Cout) v = d.w[((long long)nn * d.Cin + kk) * d.T + t];
+    } else {
+      if (kk < d.Cout && nn < d.Cin) v = d.w[((long long)kk * d.Cin + nn) * d.T + (d.T - 1 - t)];
+    }
+    d.wp[i] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // first layer: Cin = 1 -> Cout = 16 (HBM-bound: 4 B in, 64 B out per voxel).  Direct VALU kernel:
 // the single-channel halo sits in LDS, each thread owns one voxel and 16 accumulators.
@@ -751,14 +772,23 @@ static int launch_wgrad(const float* X, const float* dY, float* partial, ConvDim
 
 // tile / blocking choice: big tiles while the grid still fills 256 CUs, otherwise 64-voxel tiles
 // and narrower channel slabs (deep V-Net levels are tiny GEMMs).
-static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16) {
+static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16, bool for_wgrad = false) {
   Cfg c;
   c.KD = KD;
   const long long vox = (long long)N * D * H * W;
   if (KD == 3) {
     if (vox >= 256LL * 1024) { c.TD = 4; c.TH = 4; c.TW = 16; }
     else if (vox >= 64LL * 1024) { c.TD = 4; c.TH = 8; c.TW = 8; }
-    else { c.TD = 4; c.TH = 4; c.TW = 4; }
+    else {
+      // deep V-Net levels (14x14x10, 7x7x5, ...): partial tiles waste up to half of the MFMA work, so pick the 64-voxel
+      // tile shape that covers the volume with the fewest tiles (wgrad needs TW % 4 == 0)
+      static const int cand[4][3] = {{4, 4, 4}, {2, 8, 4}, {2, 16, 2}, {8, 8, 1}};
+      long long best = -1;
+      for (int k = 0; k < (for_wgrad ? 2 : 4); ++k) {
+        const long long t = (long long)cdiv(D, cand[k][0]) * cdiv(H, cand[k][1]) * cdiv(W, cand[k][2]);
+        if (best < 0 || t < best) { best = t; c.TD = cand[k][0]; c.TH = cand[k][1]; c.TW = cand[k][2]; }
+      }
+    }
   } else {
     c.TD = 1;
     if (vox >= 128LL * 1024) { c.TH = 16; c.TW = 16; } else { c.TH = 8; c.TW = 8; }
@@ -800,6 +830,15 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
   if (wp_fwd) hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_fwd, Cout, Cin, T, Ci16, Co16, 0);
   if (wp_dgrad) hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_dgrad, Cout, Cin, T, Co16, Ci16, 1);
   BCP_CHECK_LAUNCH("bcp_conv3_pack_weight");
+  return BCP_OK;
+}
+
+// descs: device array of n {const float* w; float* wp; int Cout, Cin, T, K16, N16, dgrad} (40 B each, see bcp_hip.h)
+extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
+  BCP_REQUIRE(descs_dev && n > 0, "bcp_conv3_pack_many: bad argument");
+  static_assert(sizeof(PackDesc) == 40, "descriptor layout is part of the ABI");
+  hipLaunchKernelGGL(k_pack_conv3_many, dim3(64, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
+  BCP_CHECK_LAUNCH("bcp_conv3_pack_many");
   return BCP_OK;
 }
 
@@ -870,6 +909,9 @@ extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias,
     BCP_FWD_CASE(3, 4, 4, 16, 1, 27) BCP_FWD_CASE(3, 4, 4, 16, 2, 9) BCP_FWD_CASE(3, 4, 4, 16, 4, 3)
     BCP_FWD_CASE(3, 4, 8, 8, 1, 27) BCP_FWD_CASE(3, 4, 8, 8, 2, 9) BCP_FWD_CASE(3, 4, 8, 8, 4, 3)
     BCP_FWD_CASE(3, 4, 4, 4, 1, 27) BCP_FWD_CASE(3, 4, 4, 4, 2, 9) BCP_FWD_CASE(3, 4, 4, 4, 4, 3)
+    BCP_FWD_CASE(3, 2, 8, 4, 1, 27) BCP_FWD_CASE(3, 2, 8, 4, 2, 9) BCP_FWD_CASE(3, 2, 8, 4, 4, 3)
+    BCP_FWD_CASE(3, 2, 16, 2, 1, 27) BCP_FWD_CASE(3, 2, 16, 2, 2, 9) BCP_FWD_CASE(3, 2, 16, 2, 4, 3)
+    BCP_FWD_CASE(3, 8, 8, 1, 1, 27) BCP_FWD_CASE(3, 8, 8, 1, 2, 9) BCP_FWD_CASE(3, 8, 8, 1, 4, 3)
     BCP_FWD_CASE(1, 1, 16, 16, 1, 9) BCP_FWD_CASE(1, 1, 16, 16, 2, 9) BCP_FWD_CASE(1, 1, 16, 16, 4, 3)
     BCP_FWD_CASE(1, 1, 8, 8, 1, 9) BCP_FWD_CASE(1, 1, 8, 8, 2, 9) BCP_FWD_CASE(1, 1, 8, 8, 4, 3)
     BCP_REQUIRE(done, "bcp_conv3_fwd: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
@@ -890,7 +932,7 @@ static int wgrad_groups(const Cfg& c, int N, int D, int H, int W, int Cin16, int
 }
 
 static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
-  Cfg c = choose_cfg(KD, N, D, H, W, Cout16);
+  Cfg c = choose_cfg(KD, N, D, H, W, Cout16, true);
   // accumulators: TPW * NT * 4 regs (TPW = 7 for 27 taps) -> cap NT at 4; small problems keep NT from choose_cfg
   if (c.NT > 4) c.NT = 4;
   return c;
@@ -929,6 +971,7 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   BCP_WG_CASE(3, 4, 4, 16, 1) BCP_WG_CASE(3, 4, 4, 16, 2) BCP_WG_CASE(3, 4, 4, 16, 4)
   BCP_WG_CASE(3, 4, 8, 8, 1) BCP_WG_CASE(3, 4, 8, 8, 2) BCP_WG_CASE(3, 4, 8, 8, 4)
   BCP_WG_CASE(3, 4, 4, 4, 1) BCP_WG_CASE(3, 4, 4, 4, 2) BCP_WG_CASE(3, 4, 4, 4, 4)
+  BCP_WG_CASE(3, 2, 8, 4, 1) BCP_WG_CASE(3, 2, 8, 4, 2) BCP_WG_CASE(3, 2, 8, 4, 4)
   BCP_WG_CASE(1, 1, 16, 16, 1) BCP_WG_CASE(1, 1, 16, 16, 2) BCP_WG_CASE(1, 1, 16, 16, 4)
   BCP_WG_CASE(1, 1, 8, 8, 1) BCP_WG_CASE(1, 1, 8, 8, 2) BCP_WG_CASE(1, 1, 8, 8, 4)
   BCP_REQUIRE(done, "bcp_conv3_wgrad: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);

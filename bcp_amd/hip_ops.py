@@ -180,6 +180,11 @@ class Ops:
         self.b.call("bcp_conv3_pack_weight", _p(w), _p(wf), _p(wd), Cin, Cout, KD, self.stream(w))
         return wf, wd
 
+    def conv3_pack_many(self, descs, n):
+        """descs: uint8 device tensor holding n 40-byte descriptors (networks/_hipnet.py builds it)"""
+        self._chk(descs)
+        self.b.call("bcp_conv3_pack_many", _p(descs), int(n), self.stream(descs))
+
     def conv3_fwd(self, x, wp, bias, Cout, KD, out=None, accumulate=False):
         self._chk(x, wp, bias)
         N, D, H, W, Cin = x.shape

@@ -126,6 +126,9 @@ class VNet(HipNet):
                 ids.add(id(L.bn.weight)); ids.add(id(L.bn.bias))
         ids.add(id(self._out.weight)); ids.add(id(self._out.bias))
         self._opt_param_ids = ids
+        for li, L in enumerate(self._layers):
+            if L.kind == "c3":
+                self.register_conv3(("c3", li), L.conv.weight, 3)
 
     # ------------------------------------------------------------------ public call
     def forward(self, input, turnoff_drop=False, groups=1):
@@ -173,7 +176,7 @@ class VNet(HipNet):
             if L.kind == "c1":
                 y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
             elif L.kind == "c3":
-                wf, _ = self._packed(("c3", li), w, lambda w=w: ops.conv3_pack(w.data, 3))
+                wf, _ = self.conv3_packed(("c3", li), save)
                 y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)
             elif L.kind == "dw":
                 bp = self._packed(("dwf", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_DOWN_FWD))
@@ -226,7 +229,7 @@ class VNet(HipNet):
                 dh = None
             elif L.kind == "c3":
                 ops.conv3_wgrad(x_in, dy, gw, 3, accumulate=acc)
-                _, wd = self._packed(("c3", li), w, lambda w=w: ops.conv3_pack(w.data, 3))
+                _, wd = self.conv3_packed(("c3", li), True)
                 dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
             elif L.kind == "dw":
                 ops.k2_wgrad(x_in, dy, gw, H.WG_DOWN, accumulate=acc)

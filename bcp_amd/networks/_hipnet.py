@@ -192,6 +192,56 @@ class HipNet(nn.Module):
         self.flush_nbt()
         return super().state_dict(*a, **k)
 
+    # ---- all 3x3(x3) conv weights are packed by ONE launch per (network, weight version)
+    def register_conv3(self, key, weight, KD):
+        """called by the network constructors for every MFMA conv layer; returns nothing, see conv3_packed()"""
+        if not hasattr(self, "_c3"):
+            self._c3 = []
+        self._c3.append((key, weight, KD))
+
+    def _build_pack_tables(self):
+        import struct
+        dev = self._flat.device
+        sizes = []
+        for _, w, KD in self._c3:
+            Cout, Cin = w.shape[0], w.shape[1]
+            K16, N16 = (Cin + 15) // 16 * 16, (Cout + 15) // 16 * 16
+            sizes.append(KD * 9 * K16 * N16)
+        total = sum(sizes)
+        self._pack_buf = torch.empty(2 * total, dtype=torch.float32, device=dev)
+        self._pack_views = {}
+        fwd_desc, all_desc = b"", b""
+        off = 0
+        for (key, w, KD), n in zip(self._c3, sizes):
+            Cout, Cin = w.shape[0], w.shape[1]
+            K16, N16 = (Cin + 15) // 16 * 16, (Cout + 15) // 16 * 16
+            wf, wd = self._pack_buf[off:off + n], self._pack_buf[total + off:total + off + n]
+            self._pack_views[key] = (wf, wd)
+            d_f = struct.pack("<QQiiiiii", w.data_ptr(), wf.data_ptr(), Cout, Cin, KD * 9, K16, N16, 0)
+            d_d = struct.pack("<QQiiiiii", w.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, N16, K16, 1)
+            fwd_desc += d_f
+            all_desc += d_f + d_d
+            off += n
+        self._desc_fwd = torch.frombuffer(bytearray(fwd_desc), dtype=torch.uint8).to(dev)
+        self._desc_all = torch.frombuffer(bytearray(all_desc), dtype=torch.uint8).to(dev)
+        self._pack_state = None
+        self._pack_ptr = self._flat.data_ptr()
+
+    def conv3_packed(self, key, need_dgrad):
+        """(wp_fwd, wp_dgrad) of layer `key`, repacking EVERY layer in one launch when any weight changed"""
+        if getattr(self, "_pack_ptr", None) != self._flat.data_ptr():
+            self._build_pack_tables()
+        ver = (self._bump, sum(w._version for _, w, _ in self._c3))
+        st = self._pack_state
+        if st is None or st[0] != ver or (need_dgrad and not st[1]):
+            n = len(self._c3)
+            if need_dgrad:
+                self.ops.conv3_pack_many(self._desc_all, 2 * n)
+            else:
+                self.ops.conv3_pack_many(self._desc_fwd, n)
+            self._pack_state = (ver, need_dgrad or (st is not None and st[0] == ver and st[1]))
+        return self._pack_views[key]
+
     def _packed(self, key, p, fn):
         ver = (p._version, self._bump, p.data_ptr())
         hit = self._pack_cache.get(key)

@@ -69,6 +69,11 @@ class UNet_2d(HipNet):
             ids.add(id(pw.weight)); ids.add(id(pw.bias))
         ids.add(id(self._out.weight)); ids.add(id(self._out.bias))
         self._opt_param_ids = ids
+        for tag, cb in [(f"e{i}", c) for i, c in enumerate(self._enc)] + [(f"u{i}", u[1]) for i, u in enumerate(self._up, start=1)]:
+            if cb.cin != 1:
+                self.register_conv3((tag, 1), cb.c1.weight, 1)
+            self.register_conv3((tag, 2), cb.c2.weight, 1)
+        self.register_conv3(("out", 0), self._out.weight, 1)
         self._prenorm_bias_ids = set(id(m.bias) for cb in self._enc + [u[1] for u in self._up] for m in (cb.c1, cb.c2))
 
     # ------------------------------------------------------------------ public call
@@ -102,13 +107,13 @@ class UNet_2d(HipNet):
         if cb.cin == 1:
             y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
         else:
-            wf, _ = self._packed((tag, 1), cb.c1.weight, lambda: ops.conv3_pack(cb.c1.weight.data, 1))
+            wf, _ = self.conv3_packed((tag, 1), save)
             y1 = ops.conv3_fwd(h, wf, cb.c1.bias.data, cb.cout, 1)
         em = self._elem_mask(cb, y1.shape, h.device)
         G = getattr(self, "_groups", 1)
         a1, st1 = ops.norm_fwd(y1, G, cb.b1.weight.data, cb.b1.bias.data, cb.b1.running_mean, cb.b1.running_var, H.ACT_LRELU,
                                elem_mask=em, elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
-        wf2, _ = self._packed((tag, 2), cb.c2.weight, lambda: ops.conv3_pack(cb.c2.weight.data, 1))
+        wf2, _ = self.conv3_packed((tag, 2), save)
         y2 = ops.conv3_fwd(a1, wf2, cb.c2.bias.data, cb.cout, 1)
         a2, st2 = ops.norm_fwd(y2, G, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU)
         if save:
@@ -120,7 +125,7 @@ class UNet_2d(HipNet):
         h, y1, st1, em, a1, y2, st2, G = saved[tag]
         dy2 = ops.norm_bwd(y2, da2, G, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
         ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
-        _, wd2 = self._packed((tag, 2), cb.c2.weight, lambda: ops.conv3_pack(cb.c2.weight.data, 1))
+        _, wd2 = self.conv3_packed((tag, 2), True)
         da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
         dy1 = ops.norm_bwd(y1, da1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em,
                            elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
@@ -130,7 +135,7 @@ class UNet_2d(HipNet):
         ops.conv3_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
         if not need_dx:
             return None
-        _, wd1 = self._packed((tag, 1), cb.c1.weight, lambda: ops.conv3_pack(cb.c1.weight.data, 1))
+        _, wd1 = self.conv3_packed((tag, 1), True)
         return ops.conv3_fwd(dy1, wd1, None, cb.cin, 1)
 
     # ------------------------------------------------------------------ schedule
@@ -153,7 +158,7 @@ class UNet_2d(HipNet):
             if save:
                 saved[f"pw{i}"] = (h,)
             h = self._convblock_fwd(cb, f"u{i}", cat, save, saved)
-        wf, _ = self._packed(("out", 0), self._out.weight, lambda: ops.conv3_pack(self._out.weight.data, 1))
+        wf, _ = self.conv3_packed(("out", 0), save)
         logits = ops.conv3_fwd(h, wf, self._out.bias.data, self.n_classes, 1)
         if self.training:
             for _ in range(getattr(self, "_groups", 1)):
@@ -171,7 +176,7 @@ class UNet_2d(HipNet):
         xs = saved["xs"]
         ops.conv3_wgrad(h_last, dlogits, self._out.weight.grad, 1, accumulate=True)
         ops.colsum(dlogits, self._out.bias.grad, accumulate=True)
-        _, wd = self._packed(("out", 0), self._out.weight, lambda: ops.conv3_pack(self._out.weight.data, 1))
+        _, wd = self.conv3_packed(("out", 0), True)
         dh = ops.conv3_fwd(dlogits, wd, None, FT[0], 1)
         skip_grads = {}
         for i in range(4, 0, -1):

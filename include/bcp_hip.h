@@ -97,6 +97,10 @@ int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_grou
  *      bcp_conv3_fwd(dy -> dx, Cin/Cout swapped).  Channel counts must be multiples of 4 (padded to 16 inside). */
 size_t bcp_conv3_packed_weight_floats(int Cin, int Cout, int KD);
 int bcp_conv3_pack_weight(const float* w, float* wp_fwd_or_null, float* wp_dgrad_or_null, int Cin, int Cout, int KD, void* stream);
+/* every conv layer of a network in one launch: descs = device array of n packed structs (40 B, 8-B aligned):
+ * { const float* w; float* wp; int Cout, Cin, T, K16, N16, dgrad; }  with T = KD*9, K16/N16 = GEMM K/N extents padded to 16
+ * (fwd: K16 = Cin16, N16 = Cout16; dgrad: K16 = Cout16, N16 = Cin16). */
+int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream);
 size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD); /* split-K slabs of the deep levels; may be 0 */
 int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin, int Cout,
                   int KD, int accumulate, void* workspace_or_null, void* stream);

@@ -219,6 +219,8 @@ CONV3_CASES = (
     (1, 64, 64, (4, 4, 4), 3),
     (1, 32, 16, (6, 5, 7), 3),        # Cin != Cout, odd dims
     (1, 128, 128, (3, 3, 2), 3),      # deep level, tiny spatial
+    (2, 64, 64, (14, 14, 10), 3),     # LA level 4 extent: tile (2,16,2) for fwd, (2,8,4) for wgrad
+    (1, 32, 48, (7, 7, 5), 3),        # LA level 5 extent: tile (8,8,1)
     (2, 16, 16, (1, 16, 16), 1),      # 2-D
     (1, 32, 64, (1, 9, 11), 1),
     (1, 16, 4, (1, 8, 8), 1),         # U-Net out_conv: Cout = 4 (padded to 16 inside)
