@@ -59,8 +59,8 @@ class Ops:
         return None
 
     def workspace(self, key, nbytes, like):
-        """grow-only scratch buffer per (key, device)"""
-        k = (key, like.device)
+        """grow-only scratch buffer per (key, device, stream): two streams never share scratch"""
+        k = (key, like.device, torch.cuda.current_stream(like.device).cuda_stream if like.is_cuda else 0)
         w = self._ws.get(k)
         if w is None or w.numel() < nbytes:
             w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)

@@ -17,6 +17,16 @@ def _ops_for(t):
     return BU._ops_for(t)
 
 
+_SIDE = {}
+
+
+def _side_stream(t):
+    s = _SIDE.get(t.device)
+    if s is None:
+        s = _SIDE[t.device] = torch.cuda.Stream(device=t.device)
+    return s
+
+
 # ------------------------------------------------------------------------------------------ pseudo labels
 def get_cut_mask(out, thres=0.5, nms=0, connect_mode=None):
     """LA_BCP_train.py:57-63 / pancreas_utils.py:275-281: softmax -> (p>=thres) -> channel 1 [-> largest CC].
@@ -100,7 +110,8 @@ class FlatAdam:
 
 # ------------------------------------------------------------------------------------------ LA / pancreas step
 def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
-                       u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None, grouped=True):
+                       u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None, grouped=True,
+                       overlap=True):
     """One self-training iteration, LA_BCP_train.py:235-270 (variant 'pancreas': train_pancreas.py:145-171).
 
     volume_batch [B,1,X,Y,Z] float32 laid out lab_a|lab_b|unlab_a|unlab_b, label_batch [B,X,Y,Z].
@@ -122,12 +133,23 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
             return None
         return {k: torch.cat([d1[k], d2[k]]) for k in d1}
 
+    # The student's INPUTS do not depend on the pseudo-labels (only its loss does), so the teacher forward + pseudo-label
+    # + largest-CC chain runs on a side stream underneath the copy-paste mix and the student forward.
+    side = _side_stream(volume_batch) if (grouped and overlap and volume_batch.is_cuda) else None
     with torch.no_grad():
         if grouped:
             # the two teacher batches are adjacent in volume_batch: ONE grouped forward, separately normalised
             ema_model.drop_masks = cat_drops("t_a", "t_b")
-            unout = ema_model(volume_batch[labeled_bs:], groups=2)[0]
-            plab = get_cut_mask(unout, nms=1, connect_mode=connect_mode)
+            if side is not None:
+                main = torch.cuda.current_stream(volume_batch.device)
+                side.wait_stream(main)               # last step's EMA (and this step's inputs) are ordered before the teacher
+                with torch.cuda.stream(side):
+                    unout = ema_model(volume_batch[labeled_bs:], groups=2)[0]
+                    plab = get_cut_mask(unout, nms=1, connect_mode=connect_mode)
+                plab.record_stream(main)
+            else:
+                unout = ema_model(volume_batch[labeled_bs:], groups=2)[0]
+                plab = get_cut_mask(unout, nms=1, connect_mode=connect_mode)
             plab_a, plab_b = plab[:sub_bs], plab[sub_bs:]
         else:
             ema_model.drop_masks = drops.get("t_a")
@@ -158,6 +180,8 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         BU.mix(pairs[1][0], pairs[1][1], img_mask, out=mixed[sub_bs:])
         model.drop_masks = cat_drops("s_l", "s_u")
         outputs = model(mixed, groups=2)[0]
+        if side is not None:
+            torch.cuda.current_stream(volume_batch.device).wait_stream(side)   # pseudo-labels are needed from here on
         loss_l, loss_u = BU.mix_loss_pair(outputs, terms[0], terms[1], loss_mask)
         outputs_l, outputs_u = outputs[:sub_bs], outputs[sub_bs:]
     else:
