@@ -224,20 +224,28 @@ class VNet(HipNet):
             gw, acc = w.grad, True
             # conv biases feed a norm: their gradient is identically zero (DESIGN.md "bias gradients"); the flat
             # gradient buffer was cleared by begin_backward(), nothing to add.
+            # The weight gradient of a layer has no consumer inside the backward pass: it runs on a side stream underneath
+            # the dgrad -> norm_bwd critical path (the deep levels' kernels are too small to fill 256 CUs on their own).
+            with self._wgrad_stream(dy, x_in):
+                if L.kind == "c1":
+                    ops.conv3_c1_wgrad(x_in, dy, gw, 3, accumulate=acc)
+                elif L.kind == "c3":
+                    ops.conv3_wgrad(x_in, dy, gw, 3, accumulate=acc)
+                elif L.kind == "dw":
+                    ops.k2_wgrad(x_in, dy, gw, H.WG_DOWN, accumulate=acc)
+                else:
+                    ops.k2_wgrad(x_in, dy, gw, H.WG_UP, accumulate=acc)
             if L.kind == "c1":
-                ops.conv3_c1_wgrad(x_in, dy, gw, 3, accumulate=acc)
                 dh = None
             elif L.kind == "c3":
-                ops.conv3_wgrad(x_in, dy, gw, 3, accumulate=acc)
                 _, wd = self.conv3_packed(("c3", li), True)
                 dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
             elif L.kind == "dw":
-                ops.k2_wgrad(x_in, dy, gw, H.WG_DOWN, accumulate=acc)
                 bp = self._packed(("dwd", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_DOWN_DGRAD))
                 sg = skip_grads.pop()        # x_in is a skip source: join the decoder-side gradient in place
                 dh = ops.down_dgrad(dy, bp, L.cin, out=sg, accumulate=True)
             else:
-                ops.k2_wgrad(x_in, dy, gw, H.WG_UP, accumulate=acc)
                 bp = self._packed(("upd", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_UP_DGRAD))
                 dh = ops.up_dgrad(dy, bp, L.cin)
+        self._join_wgrad_stream(dlogits)
         return None

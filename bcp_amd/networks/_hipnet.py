@@ -260,6 +260,44 @@ class HipNet(nn.Module):
                 break
         return r
 
+    # ---- side stream for weight gradients (no consumer inside the backward pass)
+    class _OnSide:
+        def __init__(self, net, tensors):
+            self.net, self.tensors = net, tensors
+            self.ctx = None
+
+        def __enter__(self):
+            t = self.tensors[0]
+            if not t.is_cuda or not self.net.overlap_wgrad:
+                return self
+            main = torch.cuda.current_stream(t.device)
+            side = self.net._side_streams.get(t.device)
+            if side is None:
+                side = self.net._side_streams[t.device] = torch.cuda.Stream(device=t.device)
+            side.wait_stream(main)                 # dy (and the zeroed gradient buffer) are ready
+            for x in self.tensors:
+                x.record_stream(side)              # keep the allocator from recycling them under the side stream
+            self.ctx = torch.cuda.stream(side)
+            self.ctx.__enter__()
+            return self
+
+        def __exit__(self, *a):
+            if self.ctx is not None:
+                self.ctx.__exit__(*a)
+            return False
+
+    overlap_wgrad = True
+    _side_streams = {}
+
+    def _wgrad_stream(self, *tensors):
+        return HipNet._OnSide(self, tensors)
+
+    def _join_wgrad_stream(self, like):
+        if like.is_cuda and self.overlap_wgrad:
+            side = self._side_streams.get(like.device)
+            if side is not None:
+                torch.cuda.current_stream(like.device).wait_stream(side)
+
     def next_seed(self):
         self._drop_seed = (self._drop_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._drop_seed
