@@ -25,7 +25,7 @@ def test_unet_golden_tiny(ops, golden_dir):
 
 
 def test_unet_smooth_grads(ops):
-    NC.check_unet_smooth(ops, DEV, hw=(128, 128), N=2)
+    NC.check_unet_smooth(ops, DEV, hw=(64, 64), N=2)
 
 
 def test_acdc_self_train_trajectory(ops, golden_dir):

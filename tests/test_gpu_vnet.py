@@ -26,11 +26,11 @@ def test_vnet_la_golden_tiny(ops, golden_dir):
 
 
 def test_vnet_la_smooth_grads(ops):
-    NC.check_vnet_smooth(ops, DEV, shape=(48, 48, 32), N=2)
+    NC.check_vnet_smooth(ops, DEV, shape=(32, 32, 16), N=2)
 
 
 def test_vnet_pancreas_smooth(ops):
-    NC.check_vnet_smooth(ops, DEV, shape=(32, 32, 32), variant="pancreas")
+    NC.check_vnet_smooth(ops, DEV, shape=(16, 16, 16), variant="pancreas")
 
 
 def test_la_self_train_trajectory(ops, golden_dir):
