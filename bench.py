@@ -8,7 +8,7 @@ student forward x2, masked Dice+CE x2, backward, [gradient all-reduce when N>1],
   python bench.py [--gpus N --steps K --warmup W]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (k_conv3_mfma, the fp32-MFMA implicit-GEMM
+Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (k_conv3_res, the fp32-MFMA implicit-GEMM
 3x3x3 conv at the 16->16 @112x112x80 layer: 13.87 GFLOP algorithmic per launch) timed with HIP events on
 the launch stream in this process; `cpu_baseline` = the oracle (CPU restatement of the reference,
 oracle/bcp_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
@@ -63,9 +63,22 @@ def dominant_kernel_roofline(dev):
     ms = ops.event_elapsed_ms(e0, e1) / iters
     flops = 2.0 * sp[0] * sp[1] * sp[2] * 27 * C * C
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_conv3_mfma<3,4,4,16,1,27> 16->16 @112x112x80", "achieved": round(ach, 2),
+    return {"bound": "mfma", "kernel": "k_conv3_res<3,4,4,16,1> (3x3x3 conv 16->16 @112x112x80, fwd/dgrad)", "achieved": round(ach, 2),
             "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "flop_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": None}
+            "flop_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": pmc_traffic()}
+
+
+def pmc_traffic():
+    """HBM bytes per launch of the same kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in
+    separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams).  bench.py cannot run
+    the profiler itself; null when the file is absent."""
+    p = os.path.join(ROOT, "profiles", "r01_pmc_conv3_c16.json")
+    try:
+        d = json.load(open(p))["res"]
+        return {"bytes_per_launch": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), "fetch_kb_raw": d["FETCH_SIZE"],
+                "write_kb": d["WRITE_SIZE"], "algorithmic_bytes": 2 * 1003520 * 16 * 4 + 27 * 16 * 16 * 4, "source": "profiles/r01_pmc_conv3_c16.json"}
+    except Exception:
+        return None
 
 
 def usable_cores():
