@@ -39,13 +39,15 @@ _SIGS = {
     "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P]),
     "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, P, P]),
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
-    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P]),
+    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, P]),
     "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, P]),
     "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
     "bcp_conv3_pack_weight": (I, [P, P, P, I, I, I, P]),
     "bcp_conv3_pack_many": (I, [P, I, P]),
     "bcp_conv3_fwd_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "bcp_conv3_stat_rows": (I, [I, I, I, I, I, I, I, I, I]),
+    "bcp_conv3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
     "bcp_conv3_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
     "bcp_conv3_c1_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
@@ -96,14 +98,16 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n != "bcp_version"}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows")}
+        self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
 
     def last_error(self) -> str:
         return self.cdll.bcp_last_error().decode("utf-8", "replace")
 
     def call(self, name: str, *args):
-        rc = getattr(self.cdll, name)(*args)
-        if name in self._status_fns and rc != 0:
+        fn, is_status = self._fns[name]
+        rc = fn(*args)
+        if rc and is_status:
             raise BcpError(f"{name} failed ({rc}): {self.last_error()}")
         return rc
 

@@ -79,13 +79,49 @@ __device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, 
   w0 = tw * TW;
 }
 
+// Fused BatchNorm / InstanceNorm statistics: the conv epilogue already holds y = conv + bias in registers, so the
+// per-channel (sum, sum of squares) partials the norm needs are produced here instead of by a second pass over y
+// (csrc/norm.hip k_col_partial<0>).  partial[g][row][C][2] doubles, fp64 accumulation as in the standalone pass.
+struct StatsArg {
+  double* partial;       // nullptr: disabled
+  int rows;              // rows per group (nb of the norm finalize)
+  int tiles_per_group;   // spatial tiles per normalisation group (tiles are sample-major)
+  int C;                 // channel count of the partial rows (= Cout)
+};
+
+// block-wide sum over the 4 lg lane groups and the 4 waves, then one (s1, s2) pair per channel of the slab
+template <int NT>
+__device__ __forceinline__ void stats_flush(double (&s1)[NT], double (&s2)[NT], double* __restrict__ Ss /* [4][NT*16][2] */,
+                                            double* __restrict__ dst_row /* &partial[g][row][0][0] */, int cout0, int Cout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    double a = s1[nt], b = s2[nt];
+    a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+    b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+    if (lg == 0) { Ss[(wave * NT * 16 + nt * 16 + li) * 2] = a; Ss[(wave * NT * 16 + nt * 16 + li) * 2 + 1] = b; }
+    s1[nt] = 0.0; s2[nt] = 0.0;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NT * 16 && cout0 + (int)threadIdx.x < Cout) {
+    const int c = threadIdx.x;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += Ss[(w * NT * 16 + c) * 2]; b += Ss[(w * NT * 16 + c) * 2 + 1]; }
+    dst_row[(cout0 + c) * 2] = a;
+    dst_row[(cout0 + c) * 2 + 1] = b;
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
 // ------------------------------------------------------------------------------------------------
 template <int KD, int TD, int TH, int TW, int NT, int WT>
 __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X, const float* __restrict__ Wp,
                                                     const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd,
-                                                    int accumulate) {
+                                                    int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
   constexpr int S = T / WT;                     // weight stages per cin chunk
@@ -99,6 +135,7 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   float* smem = reinterpret_cast<float*>(smem4);
   float* Xs = smem;                             // [HV][XS]
   float* Ws = smem + TL::HV * XS;               // [NBUF][WT][4][CT][4]
+  double* Ss = reinterpret_cast<double*>(Ws + NBUF * WSTAGE4 * 4);   // [4][CT][2] statistics scratch (16-B aligned)
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -180,6 +217,9 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   }
 
   // epilogue: lane (li, lg) holds rows (voxels) lg*4+r, column (cout) li of each 16x16 tile
+  double s1[NT], s2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -198,10 +238,16 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
             if (bias) v += bias[co];
             if (accumulate) v += yrow[co];
             yrow[co] = v;
+            s1[nt] += (double)v;
+            s2[nt] += (double)v * (double)v;
           }
         }
       }
     }
+  }
+  if (st.partial) {
+    const int g = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
+    stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)g * st.rows + row) * st.C * 2, cout0, cd.Cout);
   }
 }
 
@@ -227,7 +273,7 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float* __restrict__ par
 template <int KD, int TD, int TH, int TW, int NT>
 __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, const float* __restrict__ Wp,
                                                    const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd,
-                                                   int n_tiles, int accumulate) {
+                                                   int n_tiles, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
   constexpr int NX4 = (TL::HV * 4 + 255) / 256;      // halo float4s per thread
@@ -238,6 +284,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   const int nch = cd.Cin16 >> 4;
   float* Ws = smem;                                  // [nch][T][4][CT][4]
   float* Xs = smem + (size_t)nch * T * 4 * CT * 4;   // [HV][XS]
+  double* Ss = reinterpret_cast<double*>(Xs + TL::HV * XS);   // [4][CT][2] statistics scratch
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -265,6 +312,10 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   // work items of this block: (tile, chunk), tile = blockIdx.x, blockIdx.x + gridDim.x, ...
   int tile = blockIdx.x, ch = 0;
   if (tile >= n_tiles) return;
+  double s1[NT], s2[NT];                             // fused norm statistics of the current group
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
+  int cur_g = st.partial ? tile / st.tiles_per_group : 0;
   {
     int n, d0, h0, w0;
     tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
@@ -319,6 +370,10 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
     if (ch == nch - 1) {
       int n, d0, h0, w0;
       tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+      if (st.partial && tile / st.tiles_per_group != cur_g) {   // tiles are visited in increasing order: groups never come back
+        stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+        cur_g = tile / st.tiles_per_group;
+      }
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -337,6 +392,8 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
                 if (bias) v += bias[co];
                 if (accumulate) v += yrow[co];
                 yrow[co] = v;
+                s1[nt] += (double)v;
+                s2[nt] += (double)v * (double)v;
               }
             }
           }
@@ -349,7 +406,10 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    if (!has_next) break;
+    if (!has_next) {
+      if (st.partial) stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+      break;
+    }
     __syncthreads();   // every wave is done reading the halo buffer
 #pragma unroll
     for (int u = 0; u < NX4; ++u) {
@@ -717,30 +777,36 @@ static int split_k(long long blocks, int nch) {   // deep levels: too few tiles 
 }
 
 template <int KD, int TD, int TH, int TW, int NT, int WT>
-static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws, hipStream_t s) {
+static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
+                      double* stat_partial, int G, bool dry, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int S = TL::T / WT, NBUF = S > 1 ? 2 : 1;
-  const size_t lds = (size_t)(TL::HV * XS + NBUF * WT * 4 * NT * 16 * 4) * sizeof(float);
+  const size_t lds = (size_t)(TL::HV * XS + NBUF * WT * 4 * NT * 16 * 4) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   auto kfn = k_conv3_mfma<KD, TD, TH, TW, NT, WT>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / (NT * 16);
   const int sk = ws ? split_k((long long)gx * gy, cd.Cin16 / 16) : 1;
+  StatsArg st{nullptr, 0, 1, cd.Cout};
+  if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
+  if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
   if (sk == 1) {
-    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate);
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);
   } else {
     const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
-    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, 0);
+    StatsArg none{nullptr, 0, 1, cd.Cout};
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, 0, none);
     hipLaunchKernelGGL(k_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y, accumulate);
   }
-  return 0;
+  return st.partial ? st.rows : 0;
 }
 
 template <int KD, int TD, int TH, int TW, int NT>
-static int launch_res(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, hipStream_t s) {
+static int launch_res(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate,
+                      double* stat_partial, int G, bool dry, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   const int nch = cd.Cin16 / 16;
-  const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + (size_t)TL::HV * XS) * sizeof(float);
+  const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + (size_t)TL::HV * XS) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
   const int slabs = cd.Cout16 / (NT * 16);
@@ -749,10 +815,18 @@ static int launch_res(const float* X, const float* Wp, const float* bias, float*
   if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
   if (P < 1) P = 1;
   if (P > tiles) P = tiles;
+  StatsArg st{nullptr, 0, 1, cd.Cout};
+  const bool stats_ok = G > 0 && tiles % G == 0;
+  if (dry) return stats_ok ? P : 0;
+  if (stats_ok && stat_partial) {
+    st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G;
+    // a persistent block only writes the groups it visited: start from zeros
+    hipMemsetAsync(stat_partial, 0, (size_t)G * P * cd.Cout * 2 * sizeof(double), s);
+  }
   auto kfn = k_conv3_res<KD, TD, TH, TW, NT>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(P, slabs), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate);
-  return 0;
+  hipLaunchKernelGGL(kfn, dim3(P, slabs), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st);
+  return st.partial ? P : 0;
 }
 
 template <int KD, int TD, int TH, int TW, int NT>
@@ -844,12 +918,12 @@ extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
 
 #define BCP_FWD_CASE(KD_, TD_, TH_, TW_, NT_, WT_)                                                             \
   if (c.KD == KD_ && c.TD == TD_ && c.TH == TH_ && c.TW == TW_ && c.NT == NT_) {                               \
-    launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (float*)workspace, (hipStream_t)stream);             \
+    rows = launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (float*)workspace, stat_partial, G, dry, (hipStream_t)stream); \
     done = true;                                                                                               \
   }
 #define BCP_RES_CASE(KD_, TD_, TH_, TW_, NT_)                                                                  \
   if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_ && r.NT == NT_) {                               \
-    launch_res<KD_, TD_, TH_, TW_, NT_>(x, wp, bias, y, cd, accumulate, (hipStream_t)stream);                  \
+    rows = launch_res<KD_, TD_, TH_, TW_, NT_>(x, wp, bias, y, cd, accumulate, stat_partial, G, dry, (hipStream_t)stream); \
     done = true;                                                                                               \
   }
 
@@ -869,7 +943,7 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
   const long long tiles = (long long)N * cdiv(D, r.TD) * cdiv(H, r.TH) * cdiv(W, r.TW);
   for (int nt = 4; nt >= 1; nt >>= 1) {
     if (Cout16 % (nt * 16)) continue;
-    const long long lds = ((long long)KD * 9 * Cin16 * nt * 16 + hv * XS) * 4;
+    const long long lds = ((long long)KD * 9 * Cin16 * nt * 16 + hv * XS) * 4 + 4 * nt * 16 * 2 * 8;
     if (lds > 158 * 1024) continue;
     if (nt > 1 && tiles * (Cout16 / (nt * 16)) < 512) continue;   // keep >= 2 work items per CU
     r.NT = nt;
@@ -886,16 +960,14 @@ extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int 
   return n <= (1LL << 20) ? (size_t)(4 * n * sizeof(float)) : 0;
 }
 
-extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
-                             int Cout, int KD, int accumulate, void* workspace, void* stream) {
-  BCP_REQUIRE(x && wp && y, "bcp_conv3_fwd: null pointer");
-  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd: bad extents");
-  BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd: KD=1 needs D=1");
-  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd: Cin=%d must be a multiple of 4 (Cin=1 has its own entry point)", Cin);
-  BCP_REQUIRE(aligned16(x) && aligned16(wp), "bcp_conv3_fwd: x / wp must be 16-B aligned");
+// shared by the launch and by the statistics-rows query: returns the number of partial rows per group the chosen kernel
+// writes (0: this shape does not support fused statistics, e.g. split-K), or a negative error
+static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout,
+                          int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream) {
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
   bool done = false;
+  int rows = 0;
   Cfg r;
   if (choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
     BCP_RES_CASE(3, 4, 4, 16, 1) BCP_RES_CASE(3, 4, 4, 16, 2)
@@ -916,7 +988,44 @@ extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias,
     BCP_FWD_CASE(1, 1, 8, 8, 1, 9) BCP_FWD_CASE(1, 1, 8, 8, 2, 9) BCP_FWD_CASE(1, 1, 8, 8, 4, 3)
     BCP_REQUIRE(done, "bcp_conv3_fwd: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
   }
+  return rows;
+}
+
+extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                             int Cout, int KD, int accumulate, void* workspace, void* stream) {
+  BCP_REQUIRE(x && wp && y, "bcp_conv3_fwd: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd: bad extents");
+  BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd: KD=1 needs D=1");
+  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd: Cin=%d must be a multiple of 4 (Cin=1 has its own entry point)", Cin);
+  BCP_REQUIRE(aligned16(x) && aligned16(wp), "bcp_conv3_fwd: x / wp must be 16-B aligned");
+  const int rc = conv3_fwd_impl(x, wp, bias, y, N, D, H, W, Cin, Cout, KD, accumulate, workspace, nullptr, 0, false, stream);
+  if (rc < 0) return rc;
   BCP_CHECK_LAUNCH("bcp_conv3_fwd");
+  return BCP_OK;
+}
+
+// Fused variant: also emits the per-channel (sum, sum of squares) partials of y for `groups` normalisation groups
+// (groups consecutive sample ranges).  rows = bcp_conv3_stat_rows(...) partial rows per group are written into
+// stat_partial[groups][rows][Cout][2] doubles; rows == 0 means "not available for this shape": run bcp_conv3_fwd and
+// let bcp_norm_fwd compute its own statistics.
+extern "C" int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace) {
+  if (Cin % 4 || Cin < 4 || groups < 1) return 0;
+  static float dummy;
+  const int rc = conv3_fwd_impl(nullptr, nullptr, nullptr, nullptr, N, D, H, W, Cin, Cout, KD, 0, has_workspace ? &dummy : nullptr, nullptr,
+                                groups, true, nullptr);
+  return rc < 0 ? 0 : rc;
+}
+
+extern "C" int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                                   int Cout, int KD, void* workspace, double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(x && wp && y && stat_partial, "bcp_conv3_fwd_stats: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0 && groups >= 1, "bcp_conv3_fwd_stats: bad extents");
+  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd_stats: Cin=%d must be a multiple of 4", Cin);
+  BCP_REQUIRE(aligned16(x) && aligned16(wp), "bcp_conv3_fwd_stats: x / wp must be 16-B aligned");
+  const int rc = conv3_fwd_impl(x, wp, bias, y, N, D, H, W, Cin, Cout, KD, 0, workspace, stat_partial, groups, false, stream);
+  if (rc < 0) return rc;
+  BCP_REQUIRE(rc > 0, "bcp_conv3_fwd_stats: fused statistics unavailable for this shape (check bcp_conv3_stat_rows first)");
+  BCP_CHECK_LAUNCH("bcp_conv3_fwd_stats");
   return BCP_OK;
 }
 

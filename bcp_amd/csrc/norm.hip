@@ -309,7 +309,7 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
                             float* running_mean, float* running_var, float momentum, float eps, int act,
                             const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale,
                             const float* residual, float* stats /* [5][G][C]: mean, rstd, scale, beta, unbiased var */, void* workspace,
-                            float* out, void* stream) {
+                            const double* partial_in, int nb_in, float* out, void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(y && stats && workspace && out, "bcp_norm_fwd: null pointer");
   BCP_REQUIRE(aligned16(y) && aligned16(out) && aligned16(stats), "bcp_norm_fwd: alignment");
@@ -319,8 +319,14 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   double* partial = reinterpret_cast<double*>(workspace);
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float* var_unb = stats + 4LL * G * C;
-  hipLaunchKernelGGL((k_col_partial<0>), dim3(nb, G), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, rows_per_group, C, partial);
+  if (partial_in) {   // statistics partials were produced by the conv epilogue (bcp_conv3_fwd_stats)
+    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
+  } else {
+    hipLaunchKernelGGL((k_col_partial<0>), dim3(nb, G), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, rows_per_group, C, partial);
+  }
+  if (!partial_in)
   hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
   const long long rows = (long long)G * rows_per_group;

@@ -35,6 +35,7 @@ class Ops:
         self.b = binding
         self.allow_cpu = allow_cpu
         self._ws = {}
+        self._wsz = {}
         self._box_cache = {}
 
     @classmethod
@@ -55,12 +56,20 @@ class Ops:
 
     def stream(self, t):
         if t.is_cuda:
-            return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+            return C.c_void_p(torch._C._cuda_getCurrentRawStream(t.device.index))
         return None
+
+    def _ws_bytes(self, fn, *args):
+        """`*_workspace_bytes` answers depend on the shape only: one ctypes round trip per distinct shape"""
+        key = (fn,) + args
+        v = self._wsz.get(key)
+        if v is None:
+            v = self._wsz[key] = int(self.b.call(fn, *args))
+        return v
 
     def workspace(self, key, nbytes, like):
         """grow-only scratch buffer per (key, device, stream): two streams never share scratch"""
-        k = (key, like.device, torch.cuda.current_stream(like.device).cuda_stream if like.is_cuda else 0)
+        k = (key, like.device, torch._C._cuda_getCurrentRawStream(like.device.index) if like.is_cuda else 0)
         w = self._ws.get(k)
         if w is None or w.numel() < nbytes:
             w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
@@ -107,7 +116,7 @@ class Ops:
         """seg uint8 [N,D,H,W] -> (uint8 same shape, optional float32 copy)"""
         self._chk(seg)
         N, D, H, W = seg.shape
-        nbytes = self.b.call("bcp_cc_workspace_bytes", N, D, H, W, nclass)
+        nbytes = self._ws_bytes("bcp_cc_workspace_bytes", N, D, H, W, nclass)
         ws = self.workspace("cc", nbytes, seg)
         out = torch.empty_like(seg)
         outf = torch.empty(seg.shape, dtype=torch.float32, device=seg.device) if want_f32 else None
@@ -118,7 +127,7 @@ class Ops:
         """-> (out3 float32[3] on device, workspace tensor to hand to mixloss_bwd)"""
         self._chk(logits, img_l, patch_l, mask)
         N, D, H, W, Cc = logits.shape
-        nbytes = self.b.call("bcp_mixloss_workspace_bytes", N, Cc)
+        nbytes = self._ws_bytes("bcp_mixloss_workspace_bytes", N, Cc)
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=logits.device)  # kept alive for backward
         out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
         self.b.call("bcp_mixloss_fwd", _p(logits), _p(img_l), _p(patch_l), _p(mask), self.box_arg(box6), N, D, H, W, Cc, flavour,
@@ -135,7 +144,7 @@ class Ops:
 
     # ------------------------------------------------------------------ norm
     def norm_fwd(self, y, G, gamma, beta, rmean, rvar, act, out=None, chan_scale=None, elem_mask=None, elem_scale=1.0,
-                 residual=None, momentum=0.1, eps=1e-5):
+                 residual=None, momentum=0.1, eps=1e-5, partial=None, nb=0):
         """y [N,D,H,W,C] -> (a, stats[5,G,C]).  G = 1: BatchNorm; G = N (no affine): InstanceNorm; G > 1 with affine:
         G consecutive BatchNorm calls in one launch."""
         self._chk(y, gamma, beta, rmean, rvar, chan_scale, elem_mask, residual)
@@ -144,13 +153,14 @@ class Ops:
         rows = y.numel() // Cc
         rpg = rows // G
         rps = rows // N
-        nbytes = self.b.call("bcp_norm_workspace_bytes", G, rpg, Cc)
+        nbytes = self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc)
         ws = self.workspace("norm", nbytes, y)
         stats = torch.empty((5, G, Cc), dtype=torch.float32, device=y.device)
         if out is None:
             out = torch.empty_like(y)
         self.b.call("bcp_norm_fwd", _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps), act,
-                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws), _p(out), self.stream(y))
+                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws), _p(partial), int(nb), _p(out),
+                    self.stream(y))
         return out, stats
 
     def norm_bwd(self, y, da, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
@@ -161,7 +171,7 @@ class Ops:
         rows = y.numel() // Cc
         rpg = rows // G
         rps = rows // N
-        nbytes = self.b.call("bcp_norm_workspace_bytes", G, rpg, Cc)
+        nbytes = self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc)
         ws = self.workspace("norm", nbytes, y)
         if out is None:
             out = torch.empty_like(y)
@@ -190,17 +200,31 @@ class Ops:
         N, D, H, W, Cin = x.shape
         if out is None:
             out = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=x.device)
-        nbytes = self.b.call("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cin, Cout, KD)
+        nbytes = self._ws_bytes("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cin, Cout, KD)
         ws = self.workspace("conv3", nbytes, x) if nbytes else None
         self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), self.stream(x))
         return out
+
+    def conv3_fwd_stats(self, x, wp, bias, Cout, KD, groups):
+        """conv + fused norm statistics -> (y, partial, rows); rows == 0: statistics not fused for this shape (partial None)"""
+        self._chk(x, wp, bias)
+        N, D, H, W, Cin = x.shape
+        nbytes = self._ws_bytes("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cin, Cout, KD)
+        rows = self._ws_bytes("bcp_conv3_stat_rows", N, D, H, W, Cin, Cout, KD, groups, 1 if nbytes else 0)
+        if rows == 0:
+            return self.conv3_fwd(x, wp, bias, Cout, KD), None, 0
+        ws = self.workspace("conv3", nbytes, x) if nbytes else None
+        out = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=x.device)
+        part = self.workspace(("statpart", rows), groups * rows * Cout * 16, x)
+        self.b.call("bcp_conv3_fwd_stats", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, _p(ws), _p(part), groups, self.stream(x))
+        return out, part, rows
 
     def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):
         """dw: torch-layout gradient tensor [Cout,Cin,(3,)3,3], written (or += when accumulate)"""
         self._chk(x, dy, dw)
         N, D, H, W, Cin = x.shape
         Cout = dy.shape[-1]
-        nbytes = self.b.call("bcp_conv3_wgrad_workspace_bytes", N, D, H, W, Cin, Cout, KD)
+        nbytes = self._ws_bytes("bcp_conv3_wgrad_workspace_bytes", N, D, H, W, Cin, Cout, KD)
         ws = self.workspace("wgrad", nbytes, x)
         self.b.call("bcp_conv3_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), self.stream(x))
         return dw
@@ -217,7 +241,7 @@ class Ops:
     def conv3_c1_wgrad(self, x, dy, dw, KD, accumulate=False):
         self._chk(x, dy, dw)
         N, D, H, W, _ = x.shape
-        nbytes = self.b.call("bcp_conv3_wgrad_workspace_bytes", N, D, H, W, 1, 16, KD)
+        nbytes = self._ws_bytes("bcp_conv3_wgrad_workspace_bytes", N, D, H, W, 1, 16, KD)
         ws = self.workspace("wgrad", nbytes, x)
         self.b.call("bcp_conv3_c1_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, KD, int(bool(accumulate)), _p(ws), self.stream(x))
         return dw
@@ -283,7 +307,7 @@ class Ops:
             M, K, Nn = N * (D // 2) * (H // 2) * (W // 2), Cin, 8 * Cout
         else:
             M, K, Nn = N * D * H * W, Cin, Cout
-        nbytes = self.b.call("bcp_tn_workspace_bytes", M, K, Nn)
+        nbytes = self._ws_bytes("bcp_tn_workspace_bytes", M, K, Nn)
         ws = self.workspace("wgrad", nbytes, x)
         self.b.call("bcp_k2_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, Cin, Cout, kind, int(bool(accumulate)), _p(ws), self.stream(x))
         return dw

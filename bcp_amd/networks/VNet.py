@@ -171,13 +171,14 @@ class VNet(HipNet):
         saved = []
         for li, L in enumerate(self._layers):
             w, b = L.conv.weight, L.conv.bias
+            part, nb = None, 0
             if L.skip_push:
                 skips.append(h)
             if L.kind == "c1":
                 y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
             elif L.kind == "c3":
                 wf, _ = self.conv3_packed(("c3", li), save)
-                y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)
+                y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
             elif L.kind == "dw":
                 bp = self._packed(("dwf", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_DOWN_FWD))
                 y = ops.down_fwd(h, bp, b.data, L.cout)
@@ -188,9 +189,9 @@ class VNet(HipNet):
             cs = self._chan_scale(L, N, xcl.device)
             if L.bn is not None:
                 a, stats = ops.norm_fwd(y, G, L.bn.weight.data, L.bn.bias.data, L.bn.running_mean, L.bn.running_var, H.ACT_RELU,
-                                        chan_scale=cs, residual=res)
+                                        chan_scale=cs, residual=res, partial=part, nb=nb)
             else:
-                a, stats = ops.norm_fwd(y, G, None, None, None, None, H.ACT_RELU, chan_scale=cs, residual=res)
+                a, stats = ops.norm_fwd(y, G, None, None, None, None, H.ACT_RELU, chan_scale=cs, residual=res, partial=part, nb=nb)
             if save:
                 saved.append((h, y, stats, cs, G))
             h = a

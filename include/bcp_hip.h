@@ -85,8 +85,8 @@ int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* pa
 size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C);
 int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
-                 const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace, float* out,
-                 void* stream);
+                 const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace,
+                 const double* partial_in_or_null /* [G][nb_in][C][2] from bcp_conv3_fwd_stats */, int nb_in, float* out, void* stream);
 int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
                  const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
                  float* dbeta, int accumulate, void* workspace, float* dy, void* stream);
@@ -104,6 +104,12 @@ int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream);
 size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD); /* split-K slabs of the deep levels; may be 0 */
 int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin, int Cout,
                   int KD, int accumulate, void* workspace_or_null, void* stream);
+/* fused variant: the conv epilogue also emits the (sum, sum^2) partials of y that bcp_norm_fwd needs, for `groups`
+ * consecutive sample ranges; rows = bcp_conv3_stat_rows(...) (0: unavailable for this shape -> use bcp_conv3_fwd);
+ * stat_partial = double[groups][rows][Cout][2], handed to bcp_norm_fwd as partial_in with nb_in = rows. */
+int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace);
+int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin,
+                        int Cout, int KD, void* workspace_or_null, double* stat_partial, int groups, void* stream);
 size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD);
 int bcp_conv3_wgrad(const float* x, const float* dy, float* dw /*[Cout][Cin][KD*9]*/, int N, int D, int H, int W, int Cin, int Cout,
                     int KD, int accumulate, void* workspace, void* stream);

@@ -436,4 +436,38 @@ def check_conv3_res(ops, dev):
     check_conv3(ops, dev, cases=CONV3_RES_CASES[:2])
 
 
-ALL_CHECKS = ("conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")
+def check_conv3_stats(ops, dev):
+    """fused epilogue statistics: sum over the partial rows == per-group column sums / sums of squares of y"""
+    import os
+    rng = np.random.default_rng(15)
+    for (N, Cin, Cout, sp, KD, G, P) in ((2, 16, 16, (16, 16, 48), 3, 2, "5"), (4, 32, 32, (8, 12, 20), 3, 2, "3"), (2, 16, 32, (1, 40, 48), 1, 2, None),
+                                          (2, 64, 64, (5, 6, 7), 3, 1, None), (2, 16, 16, (6, 5, 9), 3, 2, None)):
+        two_d = KD == 1
+        x = R(rng, N, Cin, *(sp[1:] if two_d else sp))
+        w = R(rng, Cout, Cin, *((3, 3) if two_d else (3, 3, 3))) * 0.1
+        b = R(rng, Cout) * 0.1
+        y_ref = F.conv2d(x, w, b, padding=1) if two_d else F.conv3d(x, w, b, padding=1)
+        wf, _ = ops.conv3_pack(w.to(dev).contiguous(), KD)
+        if P:
+            os.environ["BCP_CONV3_P"] = P
+        try:
+            y, part, rows = ops.conv3_fwd_stats(to_cl(x).to(dev), wf, b.to(dev), Cout, KD, G)
+        finally:
+            os.environ.pop("BCP_CONV3_P", None)
+        close(from_cl(y, two_d), y_ref, msg="conv3_fwd_stats y")
+        if (Cin, sp) == (64, (5, 6, 7)):   # split-K shape: statistics are not fused, the caller falls back to the standalone pass
+            assert rows == 0 and part is None
+            continue
+        assert rows > 0, "these shapes must support fused statistics"
+        pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
+        yg = y_ref.double().transpose(0, 1).reshape(Cout, G, -1)
+        close(pt[..., 0], yg.sum(2).t(), rtol=1e-6, msg="fused sum")
+        close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-6, msg="fused sum of squares")
+        # and the norm driven by those partials equals the norm that computes its own statistics
+        g1, b1 = torch.ones(Cout).to(dev), torch.zeros(Cout).to(dev)
+        a1, _ = ops.norm_fwd(y, G, g1, b1, torch.zeros(Cout).to(dev), torch.ones(Cout).to(dev), H.ACT_RELU, partial=part, nb=rows)
+        a2, _ = ops.norm_fwd(y, G, g1, b1, torch.zeros(Cout).to(dev), torch.ones(Cout).to(dev), H.ACT_RELU)
+        close(a1, a2, rtol=1e-6, msg="norm from fused partials")
+
+
+ALL_CHECKS = ("conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")
