@@ -21,10 +21,18 @@
 #include "common.h"
 #include "../../include/bcp_hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace bcp {
 
 static constexpr int XS = 20;  // LDS floats per halo voxel: 16 channels + 4 pad (16-B aligned rows)
+
+// Measurement-only ablation switches for tools/ablate_conv.py (what bounds k_conv3_res?); the product build has 0.
+//   1: no global halo prefetch   2: no epilogue stores / statistics   4: no LDS halo refill + barriers
+//   8: A fragments not re-read from LDS per tap   16: B fragments not re-read per tap
+#ifndef BCP_ABLATE
+#define BCP_ABLATE 0
+#endif
 
 template <int KD, int TD, int TH, int TW>
 struct Tile {
@@ -276,8 +284,14 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
                                                    int n_tiles, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
-  constexpr int NX4 = (TL::HV * 4 + 255) / 256;      // halo float4s per thread
   constexpr int NACC = (MT * NT == 1) ? 2 : 1;       // a lone accumulator would serialise on the 40-cycle MFMA latency
+  // Halo fetch mapping: a halo "row" is one (hd, hh) line of HW voxels = RW float4 columns; a pass moves RPP rows with
+  // threads (r0, col).  A thread's column is fixed for the whole launch, so everything but the tile origin is computed
+  // once: per-pass global offsets grel[], the LDS slot, and per tile one uniform 64-bit row-validity mask (SALU) -- the
+  // per-tile vector work of a fetch is 2 VALU per float4 instead of the ~25 of a div/mod + 3 range checks per element.
+  constexpr int RW = TL::HW * 4, RPP = 256 / RW, HR = TL::HD * TL::HH, NP = (HR + RPP - 1) / RPP;
+  static_assert(HR <= 64 && RW <= 256, "halo rows must fit the 64-bit validity mask");
+  constexpr bool ROWS4 = (TW % 4 == 0);              // an accumulator's 4 rows are 4 consecutive voxels along w
 
   HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
   float* smem = reinterpret_cast<float*>(smem4);
@@ -301,6 +315,31 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
 
+  // launch-invariant halo fetch constants of this thread
+  const int f_r0 = threadIdx.x / RW, f_col = threadIdx.x - f_r0 * RW;
+  const int f_hw = f_col >> 2, f_part = f_col & 3;
+  const bool f_act = (int)threadIdx.x < RPP * RW;
+  unsigned grel[NP];
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    const int row = u * RPP + f_r0, hd = row / TL::HH, hh = row - hd * TL::HH;
+    grel[u] = (unsigned)(((hd * cd.H + hh) * cd.W + f_hw) * cd.Cin + f_part * 4);
+  }
+  float* const f_lds = Xs + (f_r0 * TL::HW + f_hw) * XS + f_part * 4;
+
+  // launch-invariant epilogue constants: output offsets of the accumulator rows, bias of this lane's column(s)
+  unsigned yoff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m0 = (wave * MT + mt) * 16 + lg * 4;
+    const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
+    yoff[mt] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + li);
+  }
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && cout0 + nt * 16 + li < cd.Cout) ? bias[cout0 + nt * 16 + li] : 0.f;
+  const bool slab_full = cout0 + CT <= cd.Cout;
+
   f32x4 acc[NACC][MT][NT];
 #pragma unroll
   for (int a = 0; a < NACC; ++a)
@@ -308,6 +347,34 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fetch the halo of work item (tile t, cin chunk c) into registers; zero outside the volume / beyond Cin
+  auto fetch = [&](int t, int c, float4 (&pre)[NP]) {
+    int n2, d2, h2, w2;
+    tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
+    // uniform: valid hh range, valid hd range -> one bit per halo row
+    const int hlo = (h2 >= 1) ? 0 : 1 - h2, hhi = (cd.H - h2 + 1 < TL::HH) ? cd.H - h2 + 1 : TL::HH;
+    const int dlo = (d2 >= TL::PD) ? 0 : TL::PD - d2, dhi = (cd.D - d2 + TL::PD < TL::HD) ? cd.D - d2 + TL::PD : TL::HD;
+    const unsigned mh = (hhi > hlo) ? (((1u << hhi) - 1u) & ~((1u << hlo) - 1u)) : 0u;
+    unsigned long long M = 0;
+#pragma unroll
+    for (int hd = 0; hd < TL::HD; ++hd)
+      if (hd >= dlo && hd < dhi) M |= (unsigned long long)mh << (hd * TL::HH);
+    const bool col_ok = f_act && (unsigned)(w2 - 1 + f_hw) < (unsigned)cd.W && c * 16 + f_part * 4 < cd.Cin;
+    const unsigned long long Mt = col_ok ? (M >> f_r0) : 0ull;
+    const float* xb = X + ((((long long)n2 * cd.D + (d2 - TL::PD)) * cd.H + (h2 - 1)) * cd.W + (w2 - 1)) * cd.Cin + c * 16;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((Mt >> (u * RPP)) & 1ull) v = ld4(xb + grel[u]);
+      pre[u] = v;
+    }
+  };
+  auto stash = [&](const float4 (&pre)[NP]) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (f_act && u * RPP + f_r0 < HR) st4(f_lds + u * RPP * TL::HW * XS, pre[u]);
+  };
 
   // work items of this block: (tile, chunk), tile = blockIdx.x, blockIdx.x + gridDim.x, ...
   int tile = blockIdx.x, ch = 0;
@@ -317,9 +384,9 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
   int cur_g = st.partial ? tile / st.tiles_per_group : 0;
   {
-    int n, d0, h0, w0;
-    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
-    load_halo<TL>(X, Xs, cd, n, d0, h0, w0, 0);
+    float4 pre[NP];
+    fetch(tile, 0, pre);
+    stash(pre);
   }
   __syncthreads();
   for (;;) {
@@ -327,25 +394,12 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
     int ntile = tile, nchk = ch + 1;
     if (nchk == nch) { nchk = 0; ntile = tile + gridDim.x; }
     const bool has_next = ntile < n_tiles;
-    float4 pre[NX4];
-    if (has_next) {
-      int n2, d2, h2, w2;
-      tile_origin(cd, ntile, TD, TH, TW, n2, d2, h2, w2);
+    float4 pre[NP];
+    if (BCP_ABLATE & 1) {
 #pragma unroll
-      for (int u = 0; u < NX4; ++u) {
-        const int q = threadIdx.x + u * 256;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (q < TL::HV * 4) {
-          const int hv = q >> 2, part = q & 3;
-          const int hw = hv % TL::HW, hh = (hv / TL::HW) % TL::HH, hd = hv / (TL::HW * TL::HH);
-          const int d = d2 - TL::PD + hd, h = h2 - 1 + hh, w = w2 - 1 + hw;
-          const int c = nchk * 16 + part * 4;
-          if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)w < (unsigned)cd.W && c < cd.Cin)
-            v = ld4(X + ((((long long)n2 * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cin + c);
-        }
-        pre[u] = v;
-      }
+      for (int u = 0; u < NP; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (has_next && !(BCP_ABLATE & 1)) fetch(ntile, nchk, pre);
     // MFMAs of the current item
     const float* Wc = Ws + (size_t)ch * T * 4 * CT * 4;
     // partial unroll: a full 27-tap unroll makes hipcc split the ds_read_b128 fragments into read2_b32/b64 pairs
@@ -354,9 +408,9 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
       const int toff = TL::tapoff(tap) * XS;
       float4 a[MT], b[NT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + toff);
+      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + ((BCP_ABLATE & 8) ? 0 : toff));
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wc + ((tap * 4 + lg) * CT + nt * 16 + li) * 4);
+      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wc + ((((BCP_ABLATE & 16) ? 0 : tap) * 4 + lg) * CT + nt * 16 + li) * 4);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -367,6 +421,14 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
           acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
         }
     }
+    if ((BCP_ABLATE & 2) && ch == nch - 1) {   // keep the accumulators alive without the epilogue's address math / stores
+      float t = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) t += acc[0][mt][nt][0] + acc[0][mt][nt][1] + acc[0][mt][nt][2] + acc[0][mt][nt][3];
+      if (t == 1.2345e-30f) Y[threadIdx.x] = t;
+    } else
     if (ch == nch - 1) {
       int n, d0, h0, w0;
       tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
@@ -374,26 +436,50 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
         stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
         cur_g = tile / st.tiles_per_group;
       }
+      const bool full = ROWS4 && slab_full && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
+      if (full) {
+        // whole tile inside the volume: uniform base + launch-invariant lane offsets, no index math per row
+        float* yb = Y + ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout + cout0;
+        auto rows = [&](auto with_stats) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = (wave * MT + mt) * 16 + lg * 4 + r;
-          const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-          const int d = d0 + td, h = h0 + th, w = w0 + tw;
-          if (d < cd.D && h < cd.H && w < cd.W) {
-            float* yrow = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout;
+            for (int r = 0; r < 4; ++r) {
+              float* p = yb + r * cd.Cout + yoff[mt];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-              const int co = cout0 + nt * 16 + li;
-              if (co < cd.Cout) {
+              for (int nt = 0; nt < NT; ++nt) {
                 float v = acc[0][mt][nt][r];
                 if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
-                if (bias) v += bias[co];
-                if (accumulate) v += yrow[co];
-                yrow[co] = v;
-                s1[nt] += (double)v;
-                s2[nt] += (double)v * (double)v;
+                v += bv[nt];
+                if (accumulate) v += p[nt * 16];
+                p[nt * 16] = v;
+                if (decltype(with_stats)::value) { s1[nt] += (double)v; s2[nt] += (double)v * (double)v; }
+              }
+            }
+        };
+        if (st.partial) rows(std::true_type{}); else rows(std::false_type{});
+      } else {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int m = (wave * MT + mt) * 16 + lg * 4 + r;
+            const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+            const int d = d0 + td, h = h0 + th, w = w0 + tw;
+            if (d < cd.D && h < cd.H && w < cd.W) {
+              float* yrow = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout;
+#pragma unroll
+              for (int nt = 0; nt < NT; ++nt) {
+                const int co = cout0 + nt * 16 + li;
+                if (co < cd.Cout) {
+                  float v = acc[0][mt][nt][r];
+                  if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
+                  v += bv[nt];
+                  if (accumulate) v += yrow[co];
+                  yrow[co] = v;
+                  s1[nt] += (double)v;
+                  s2[nt] += (double)v * (double)v;
+                }
               }
             }
           }
@@ -410,13 +496,11 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
       if (st.partial) stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
       break;
     }
-    __syncthreads();   // every wave is done reading the halo buffer
-#pragma unroll
-    for (int u = 0; u < NX4; ++u) {
-      const int q = threadIdx.x + u * 256;
-      if (q < TL::HV * 4) st4(Xs + (q >> 2) * XS + (q & 3) * 4, pre[u]);
+    if (!(BCP_ABLATE & 4)) {
+      __syncthreads();   // every wave is done reading the halo buffer
+      stash(pre);
+      __syncthreads();
     }
-    __syncthreads();
     tile = ntile;
     ch = nchk;
   }

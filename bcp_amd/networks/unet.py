@@ -104,18 +104,20 @@ class UNet_2d(HipNet):
 
     def _convblock_fwd(self, cb, tag, h, save, saved):
         ops = self.ops
+        G = getattr(self, "_groups", 1)
+        part1, nb1 = None, 0
         if cb.cin == 1:
             y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
         else:
             wf, _ = self.conv3_packed((tag, 1), save)
-            y1 = ops.conv3_fwd(h, wf, cb.c1.bias.data, cb.cout, 1)
+            y1, part1, nb1 = ops.conv3_fwd_stats(h, wf, cb.c1.bias.data, cb.cout, 1, G)
         em = self._elem_mask(cb, y1.shape, h.device)
-        G = getattr(self, "_groups", 1)
         a1, st1 = ops.norm_fwd(y1, G, cb.b1.weight.data, cb.b1.bias.data, cb.b1.running_mean, cb.b1.running_var, H.ACT_LRELU,
-                               elem_mask=em, elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
+                               elem_mask=em, elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0, partial=part1, nb=nb1)
         wf2, _ = self.conv3_packed((tag, 2), save)
-        y2 = ops.conv3_fwd(a1, wf2, cb.c2.bias.data, cb.cout, 1)
-        a2, st2 = ops.norm_fwd(y2, G, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU)
+        y2, part2, nb2 = ops.conv3_fwd_stats(a1, wf2, cb.c2.bias.data, cb.cout, 1, G)
+        a2, st2 = ops.norm_fwd(y2, G, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU,
+                               partial=part2, nb=nb2)
         if save:
             saved[tag] = (h, y1, st1, em, a1, y2, st2, G)
         return a2
@@ -124,16 +126,18 @@ class UNet_2d(HipNet):
         ops = self.ops
         h, y1, st1, em, a1, y2, st2, G = saved[tag]
         dy2 = ops.norm_bwd(y2, da2, G, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
-        ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
+        with self._wgrad_stream(dy2, a1):      # weight gradients run underneath the dgrad -> norm_bwd chain (VNet.py)
+            ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
         _, wd2 = self.conv3_packed((tag, 2), True)
         da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
         dy1 = ops.norm_bwd(y1, da1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em,
                            elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
-        if cb.cin == 1:
-            ops.conv3_c1_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
-            return None
-        ops.conv3_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
-        if not need_dx:
+        with self._wgrad_stream(dy1, h):
+            if cb.cin == 1:
+                ops.conv3_c1_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
+            else:
+                ops.conv3_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
+        if cb.cin == 1 or not need_dx:
             return None
         _, wd1 = self.conv3_packed((tag, 1), True)
         return ops.conv3_fwd(dy1, wd1, None, cb.cin, 1)
@@ -174,8 +178,9 @@ class UNet_2d(HipNet):
         self.begin_backward()
         (h_last,) = saved["out"]
         xs = saved["xs"]
-        ops.conv3_wgrad(h_last, dlogits, self._out.weight.grad, 1, accumulate=True)
-        ops.colsum(dlogits, self._out.bias.grad, accumulate=True)
+        with self._wgrad_stream(dlogits, h_last):
+            ops.conv3_wgrad(h_last, dlogits, self._out.weight.grad, 1, accumulate=True)
+            ops.colsum(dlogits, self._out.bias.grad, accumulate=True)
         _, wd = self.conv3_packed(("out", 0), True)
         dh = ops.conv3_fwd(dlogits, wd, None, FT[0], 1)
         skip_grads = {}
@@ -185,8 +190,9 @@ class UNet_2d(HipNet):
             skip_grads[4 - i] = (dcat, c2)                                       # first c2 channels belong to xs[4-i]
             dz = ops.bilinear2x_bwd(dcat, c2, c2)
             (h_in,) = saved[f"pw{i}"]
-            ops.k2_wgrad(h_in, dz, pw.weight.grad, H.WG_PW, accumulate=True)
-            ops.colsum(dz, pw.bias.grad, accumulate=True)
+            with self._wgrad_stream(dz, h_in):
+                ops.k2_wgrad(h_in, dz, pw.weight.grad, H.WG_PW, accumulate=True)
+                ops.colsum(dz, pw.bias.grad, accumulate=True)
             bpd = self._packed((f"pw{i}", 1), pw.weight, lambda pw=pw, c1=c1, c2=c2: ops.k2_pack(pw.weight.data, c1, c2, H.PACK_PW_DGRAD))
             dh = ops.pw_fwd(dz, bpd, None, c1)
         # dh = gradient w.r.t. x4; walk the encoder upwards
@@ -198,4 +204,5 @@ class UNet_2d(HipNet):
             ops.copy_channels(dcat, dx, c2, 0, 0, accumulate=True)               # join the decoder-side skip gradient
             dh = dx
         self._convblock_bwd(self._enc[0], "e0", dh, saved, False)
+        self._join_wgrad_stream(dlogits)
         return None

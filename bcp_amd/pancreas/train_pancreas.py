@@ -46,7 +46,7 @@ def pretrain(net1, optimizer, streams, steps):
     return loss
 
 
-def ema_cutmix(net, ema_net, optimizer, streams, steps):
+def ema_cutmix(net, ema_net, optimizer, streams, steps, dp=None):
     net.train()
     ema_net.train()
     for step in range(steps):
@@ -66,6 +66,8 @@ def ema_cutmix(net, ema_net, optimizer, streams, steps):
         loss = loss_1 + loss_2
         optimizer.zero_grad()
         loss.backward()
+        if dp is not None:
+            dp.allreduce_grads(net, optimizer)
         optimizer.step()
         update_ema_variables(net, ema_net, alpha)
     return loss

@@ -134,15 +134,96 @@ def cpu_baseline(batch, labeled_bs):
             "sec_per_step": round(sec, 3)}
 
 
+def secondary(args):
+    """ACDC 2-D U-Net (configs[3]: batch 24 256x256, SGD, state-dict EMA) and pancreas IN-V-Net (configs[4]: 96^3, Adam) self-training
+    steps: same timing contract and JSON shape as the LA line, without the dominant-kernel / CPU legs (those belong to the
+    headline metric)."""
+    from bcp_amd import synth, train_step
+    from bcp_amd.dp import DataParallel
+    from bcp_amd.hip_ops import Ops
+
+    dp = DataParallel()
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    dev = torch.device("cuda", dp.local_rank)
+    torch.cuda.set_device(dev)
+    Ops.product()
+    seed = 1337 + dp.rank
+    np.random.seed(seed)
+    torch.manual_seed(1337)
+    if args.workload == "acdc":
+        from bcp_amd.networks.net_factory import BCP_net
+        model, ema_model = BCP_net(in_chns=1, class_num=4), BCP_net(in_chns=1, class_num=4, ema=True)
+        ema_model.load_state_dict(model.state_dict())
+        model.train(); ema_model.train()
+        dp.broadcast_params(model); dp.broadcast_params(ema_model)
+        opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        vol, lab = synth.acdc_batch(args.batch_size, seed=seed)
+        vol, lab = vol.to(dev), lab.to(dev)
+        unit, what = "slices/s", f"ACDC 2D U-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), 256x256 slices, SGD, state-dict EMA (BASELINE.json configs[3])"
+        gflop_per_item = 5.90 * 2          # SURVEY 8a A2: 5.90 GFLOP fwd / slice; step = 1/2 teacher fwd + 1/2 (fwd + 2x bwd) per input slice
+
+        def step():
+            return train_step.acdc_self_train_step(model, ema_model, opt, vol, lab, args.labeled_bs, dp=dp if dp.enabled else None)
+    else:
+        from bcp_amd.pancreas import train_pancreas as TP
+        from bcp_amd.pancreas.Vnet import create_Vnet
+        model, ema_model = create_Vnet(), create_Vnet(ema=True)
+        ema_model.load_state_dict(model.state_dict())
+        dp.broadcast_params(model); dp.broadcast_params(ema_model)
+        opt = train_step.FlatAdam(model, lr=1e-3)
+        assert args.batch_size % 4 == 0, "pancreas: four equal streams (lab_a, lab_b, unlab_a, unlab_b)"
+        streams = TP._streams(dev, 4, args.batch_size // 4, seed=seed)
+        unit, what = "volumes/s", f"Pancreas IN-V-Net BCP self-train step, per-GPU 4 streams x {args.batch_size // 4}, 96^3 patches, Adam 1e-3 (BASELINE.json configs[4])"
+        gflop_per_item = 70.72 * 2
+
+        def step():
+            return {"loss": TP.ema_cutmix(model, ema_model, opt, streams, 1, dp=dp if dp.enabled else None)}
+
+    for _ in range(args.warmup):
+        step()
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dp.barrier()
+    dt = dp.max_over_ranks(time.perf_counter() - t0)
+    loss = float(r["loss"])
+    assert np.isfinite(loss), "non-finite loss in the timed region"
+    if dp.rank == 0:
+        gb = args.batch_size * dp.world
+        value = gb * args.steps / dt
+        tf = value * gflop_per_item / 1e3 / dp.world
+        print(json.dumps({
+            "metric": f"training {unit.split('/')[0]}/sec ({args.workload} BCP self-training step)", "value": round(value, 3), "unit": unit,
+            "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": what, "global_batch": gb, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6)},
+            "step_flops": {"gflop_per_item": gflop_per_item, "achieved_tflops_per_gpu": round(tf, 2),
+                           "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}}), flush=True)
+    dp.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch_size", type=int, default=4, help="per-GPU batch (BASELINE.json configs[1]: 4)")
-    ap.add_argument("--labeled_bs", type=int, default=2)
+    ap.add_argument("--workload", choices=["la", "acdc", "pancreas"], default="la",
+                    help="la = BASELINE.json's metric (configs[1]); acdc / pancreas = the north_star's secondary lines (configs[3], [4])")
+    ap.add_argument("--batch_size", type=int, default=None, help="per-GPU batch (la: 4 = configs[1]; acdc: 24 = configs[3]; pancreas: 4)")
+    ap.add_argument("--labeled_bs", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.batch_size is None:
+        args.batch_size = {"la": 4, "acdc": 24, "pancreas": 4}[args.workload]
+    if args.labeled_bs is None:
+        args.labeled_bs = args.batch_size // 2
+    if args.workload != "la":
+        return secondary(args)
 
     from bcp_amd import synth, train_step
     from bcp_amd.dp import DataParallel
