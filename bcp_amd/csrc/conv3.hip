@@ -60,22 +60,6 @@ struct ConvDims {
   int tiles_d, tiles_h, tiles_w;
 };
 
-// stage one 16-channel chunk of the input halo of tile (n, d0, h0, w0) into LDS (zero outside the volume)
-template <class TL>
-__device__ __forceinline__ void load_halo(const float* __restrict__ X, float* __restrict__ Xs, const ConvDims& cd, int n,
-                                          int d0, int h0, int w0, int cc) {
-  for (int q = threadIdx.x; q < TL::HV * 4; q += 256) {
-    const int hv = q >> 2, part = q & 3;
-    const int hw = hv % TL::HW, hh = (hv / TL::HW) % TL::HH, hd = hv / (TL::HW * TL::HH);
-    const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-    const int c = cc * 16 + part * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)w < (unsigned)cd.W && c < cd.Cin)
-      v = ld4(X + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cin + c);
-    st4(Xs + hv * XS + part * 4, v);
-  }
-}
-
 __device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, int TH, int TW, int& n, int& d0, int& h0,
                                             int& w0) {
   const int tw = bx % cd.tiles_w;
@@ -86,6 +70,73 @@ __device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, 
   h0 = th * TH;
   w0 = tw * TW;
 }
+
+// Halo fetch with launch-invariant indexing.  A halo "row" is one (hd, hh) line of HW voxels = RW float4 columns; a
+// pass moves RPP rows with threads (r0, col).  A thread's column is fixed for the whole launch, so everything but the
+// tile origin is computed once: the per-pass global offsets grel[] and the LDS slot; per tile there is one uniform
+// 64-bit row-validity mask (SALU).  Per-tile vector work of a fetch: ~2 VALU per float4 (was ~25: div/mod of the flat
+// index + three range checks + 64-bit address arithmetic per element).
+template <class TL>
+struct HaloFetch {
+  static constexpr int RW = TL::HW * 4, RPP = 256 / RW, HR = TL::HD * TL::HH, NP = (HR + RPP - 1) / RPP;
+  static_assert(HR <= 128 && RW <= 256, "halo rows must fit the 128-bit validity mask");
+  int r0, hw, part;
+  bool act;
+  unsigned grel[NP];
+  float* lds;
+
+  __device__ __forceinline__ void init(const ConvDims& cd, float* Xs) {
+    r0 = threadIdx.x / RW;
+    const int col = threadIdx.x - r0 * RW;
+    hw = col >> 2;
+    part = col & 3;
+    act = (int)threadIdx.x < RPP * RW;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int row = u * RPP + r0, hd = row / TL::HH, hh = row - hd * TL::HH;
+      grel[u] = (unsigned)(((hd * cd.H + hh) * cd.W + hw) * cd.Cin + part * 4);
+    }
+    lds = Xs + (r0 * TL::HW + hw) * XS + part * 4;
+  }
+  // halo of the tile at (n, d0, h0, w0), cin chunk c -> registers; zero outside the volume / beyond Cin
+  __device__ __forceinline__ void fetch(const float* __restrict__ X, const ConvDims& cd, int n, int d0, int h0, int w0, int c,
+                                        float4 (&pre)[NP]) const {
+    // uniform: valid hh range, valid hd range -> one bit per halo row
+    const int hlo = (h0 >= 1) ? 0 : 1 - h0, hhi = (cd.H - h0 + 1 < TL::HH) ? cd.H - h0 + 1 : TL::HH;
+    const int dlo = (d0 >= TL::PD) ? 0 : TL::PD - d0, dhi = (cd.D - d0 + TL::PD < TL::HD) ? cd.D - d0 + TL::PD : TL::HD;
+    const unsigned mh = (hhi > hlo) ? (((1u << hhi) - 1u) & ~((1u << hlo) - 1u)) : 0u;
+    unsigned long long M0 = 0, M1 = 0;   // bit (hd * HH + hh), rows 0..63 / 64..127
+#pragma unroll
+    for (int hd = 0; hd < TL::HD; ++hd) {
+      constexpr int HHc = TL::HH;
+      const int pos = hd * HHc;
+      if (hd >= dlo && hd < dhi) {
+        if (pos < 64) M0 |= (unsigned long long)mh << pos;
+        if (pos < 64 && pos + HHc > 64) M1 |= (unsigned long long)mh >> (64 - pos);
+        if (pos >= 64) M1 |= (unsigned long long)mh << (pos - 64);
+      }
+    }
+    const bool col_ok = act && (unsigned)(w0 - 1 + hw) < (unsigned)cd.W && c * 16 + part * 4 < cd.Cin;
+    unsigned long long Mt0 = M0 >> r0, Mt1 = 0;
+    if (HR > 64) {
+      if (r0) Mt0 |= M1 << (64 - r0);
+      Mt1 = M1 >> r0;
+    }
+    if (!col_ok) { Mt0 = 0; Mt1 = 0; }
+    const float* xb = X + ((((long long)n * cd.D + (d0 - TL::PD)) * cd.H + (h0 - 1)) * cd.W + (w0 - 1)) * cd.Cin + c * 16;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (((u * RPP < 64 ? Mt0 >> ((u * RPP) & 63) : Mt1 >> ((u * RPP - 64) & 63)) & 1ull)) v = ld4(xb + grel[u]);
+      pre[u] = v;
+    }
+  }
+  __device__ __forceinline__ void stash(const float4 (&pre)[NP]) const {
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (act && u * RPP + r0 < HR) st4(lds + u * RPP * TL::HW * XS, pre[u]);
+  }
+};
 
 // Fused BatchNorm / InstanceNorm statistics: the conv epilogue already holds y = conv + bias in registers, so the
 // per-channel (sum, sum of squares) partials the norm needs are produced here instead of by a second pass over y
@@ -155,6 +206,8 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   int voff[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
+  HaloFetch<TL> hf;
+  hf.init(cd, Xs);
 
   f32x4 acc[NACC][MT][NT];
 #pragma unroll
@@ -170,7 +223,11 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
   for (int cc = c_begin; cc < c_end; ++cc) {
     __syncthreads();  // everyone is done with the previous chunk's LDS contents
-    load_halo<TL>(X, Xs, cd, n, d0, h0, w0, cc);
+    {
+      float4 pre[HaloFetch<TL>::NP];
+      hf.fetch(X, cd, n, d0, h0, w0, cc, pre);
+      hf.stash(pre);
+    }
     // weight stage 0 of this chunk
     for (int q = threadIdx.x; q < WSTAGE4; q += 256) {
       const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
@@ -228,6 +285,32 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   double s1[NT], s2[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
+  const bool full = (TW % 4 == 0) && cout0 + CT <= cd.Cout && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
+  if (full) {   // whole tile inside the volume: uniform base + per-lane row offsets, no per-row index math
+    float* yb = Y + ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout + cout0 + li;
+    auto rows = [&](auto with_stats) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m0 = (wave * MT + mt) * 16 + lg * 4;
+        const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
+        float* p0 = yb + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* p = p0 + r * cd.Cout;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float v = acc[0][mt][nt][r];
+            if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
+            if (bias) v += bias[cout0 + nt * 16 + li];
+            if (accumulate) v += p[nt * 16];
+            p[nt * 16] = v;
+            if (decltype(with_stats)::value) { s1[nt] += (double)v; s2[nt] += (double)v * (double)v; }
+          }
+        }
+      }
+    };
+    if (st.partial) rows(std::true_type{}); else rows(std::false_type{});
+  } else
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -285,12 +368,8 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
   constexpr int NACC = (MT * NT == 1) ? 2 : 1;       // a lone accumulator would serialise on the 40-cycle MFMA latency
-  // Halo fetch mapping: a halo "row" is one (hd, hh) line of HW voxels = RW float4 columns; a pass moves RPP rows with
-  // threads (r0, col).  A thread's column is fixed for the whole launch, so everything but the tile origin is computed
-  // once: per-pass global offsets grel[], the LDS slot, and per tile one uniform 64-bit row-validity mask (SALU) -- the
-  // per-tile vector work of a fetch is 2 VALU per float4 instead of the ~25 of a div/mod + 3 range checks per element.
-  constexpr int RW = TL::HW * 4, RPP = 256 / RW, HR = TL::HD * TL::HH, NP = (HR + RPP - 1) / RPP;
-  static_assert(HR <= 64 && RW <= 256, "halo rows must fit the 64-bit validity mask");
+  using HF = HaloFetch<TL>;
+  constexpr int NP = HF::NP;
   constexpr bool ROWS4 = (TW % 4 == 0);              // an accumulator's 4 rows are 4 consecutive voxels along w
 
   HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
@@ -315,17 +394,8 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
 
-  // launch-invariant halo fetch constants of this thread
-  const int f_r0 = threadIdx.x / RW, f_col = threadIdx.x - f_r0 * RW;
-  const int f_hw = f_col >> 2, f_part = f_col & 3;
-  const bool f_act = (int)threadIdx.x < RPP * RW;
-  unsigned grel[NP];
-#pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    const int row = u * RPP + f_r0, hd = row / TL::HH, hh = row - hd * TL::HH;
-    grel[u] = (unsigned)(((hd * cd.H + hh) * cd.W + f_hw) * cd.Cin + f_part * 4);
-  }
-  float* const f_lds = Xs + (f_r0 * TL::HW + f_hw) * XS + f_part * 4;
+  HF hf;
+  hf.init(cd, Xs);
 
   // launch-invariant epilogue constants: output offsets of the accumulator rows, bias of this lane's column(s)
   unsigned yoff[MT];
@@ -348,33 +418,12 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // fetch the halo of work item (tile t, cin chunk c) into registers; zero outside the volume / beyond Cin
   auto fetch = [&](int t, int c, float4 (&pre)[NP]) {
     int n2, d2, h2, w2;
     tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
-    // uniform: valid hh range, valid hd range -> one bit per halo row
-    const int hlo = (h2 >= 1) ? 0 : 1 - h2, hhi = (cd.H - h2 + 1 < TL::HH) ? cd.H - h2 + 1 : TL::HH;
-    const int dlo = (d2 >= TL::PD) ? 0 : TL::PD - d2, dhi = (cd.D - d2 + TL::PD < TL::HD) ? cd.D - d2 + TL::PD : TL::HD;
-    const unsigned mh = (hhi > hlo) ? (((1u << hhi) - 1u) & ~((1u << hlo) - 1u)) : 0u;
-    unsigned long long M = 0;
-#pragma unroll
-    for (int hd = 0; hd < TL::HD; ++hd)
-      if (hd >= dlo && hd < dhi) M |= (unsigned long long)mh << (hd * TL::HH);
-    const bool col_ok = f_act && (unsigned)(w2 - 1 + f_hw) < (unsigned)cd.W && c * 16 + f_part * 4 < cd.Cin;
-    const unsigned long long Mt = col_ok ? (M >> f_r0) : 0ull;
-    const float* xb = X + ((((long long)n2 * cd.D + (d2 - TL::PD)) * cd.H + (h2 - 1)) * cd.W + (w2 - 1)) * cd.Cin + c * 16;
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((Mt >> (u * RPP)) & 1ull) v = ld4(xb + grel[u]);
-      pre[u] = v;
-    }
+    hf.fetch(X, cd, n2, d2, h2, w2, c, pre);
   };
-  auto stash = [&](const float4 (&pre)[NP]) {
-#pragma unroll
-    for (int u = 0; u < NP; ++u)
-      if (f_act && u * RPP + f_r0 < HR) st4(f_lds + u * RPP * TL::HW * XS, pre[u]);
-  };
+  auto stash = [&](const float4 (&pre)[NP]) { hf.stash(pre); };
 
   // work items of this block: (tile, chunk), tile = blockIdx.x, blockIdx.x + gridDim.x, ...
   int tile = blockIdx.x, ch = 0;
@@ -523,7 +572,6 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   constexpr int T = TL::T, CT = NT * 16, M = TL::M;
   constexpr int TPW = (T + 3) / 4;                      // taps per wave
   constexpr int YS = (CT % 32 == 0) ? CT + 16 : CT;     // dY tile row stride (bank spread for the 4 k-groups)
-  constexpr int NX4 = (TL::HV * 4 + 255) / 256;         // halo float4s per thread
   constexpr int NY4 = (M * (CT / 4) + 255) / 256;       // dY-tile float4s per thread
   static_assert(TW % 4 == 0, "a k-step is 4 consecutive voxels of one tile row");
 
@@ -558,23 +606,33 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   int tile = grp * tiles_per_group;
   if (tile >= t_end) return;
 
-  float4 px[NX4], py[NY4];
+  using HF = HaloFetch<TL>;
+  HF hf;
+  hf.init(cd, Xs);
+  // dY tile: float4 q of the [M][CT] tile, launch-invariant offsets for tiles that lie wholly inside the volume
+  unsigned yrel[NY4];
+#pragma unroll
+  for (int u = 0; u < NY4; ++u) {
+    const int q = threadIdx.x + u * 256;
+    const int m = q / (CT / 4), c4 = q % (CT / 4);
+    const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+    yrel[u] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + c4 * 4);
+  }
+  const bool slab_full = cout0 + CT <= cd.Cout;
+  float4 px[HF::NP], py[NY4];
   auto fetch = [&](int tl) {   // global -> registers for tile tl
     int n, d0, h0, w0;
     tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
+    hf.fetch(X, cd, n, d0, h0, w0, cc, px);
+    if (slab_full && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W) {   // uniform
+      const float* yb = dY + ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout + cout0;
 #pragma unroll
-    for (int u = 0; u < NX4; ++u) {
-      const int q = threadIdx.x + u * 256;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < TL::HV * 4) {
-        const int hv = q >> 2, part = q & 3;
-        const int hw = hv % TL::HW, hh = (hv / TL::HW) % TL::HH, hd = hv / (TL::HW * TL::HH);
-        const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, w = w0 - 1 + hw;
-        const int c = cc * 16 + part * 4;
-        if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)w < (unsigned)cd.W && c < cd.Cin)
-          v = ld4(X + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cin + c);
+      for (int u = 0; u < NY4; ++u) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((int)threadIdx.x + u * 256 < M * (CT / 4)) v = ld4(yb + yrel[u]);
+        py[u] = v;
       }
-      px[u] = v;
+      return;
     }
 #pragma unroll
     for (int u = 0; u < NY4; ++u) {
@@ -592,11 +650,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
     }
   };
   auto stash = [&]() {         // registers -> LDS
-#pragma unroll
-    for (int u = 0; u < NX4; ++u) {
-      const int q = threadIdx.x + u * 256;
-      if (q < TL::HV * 4) st4(Xs + (q >> 2) * XS + (q & 3) * 4, px[u]);
-    }
+    hf.stash(px);
 #pragma unroll
     for (int u = 0; u < NY4; ++u) {
       const int q = threadIdx.x + u * 256;
