@@ -258,6 +258,29 @@ def check_conv3(ops, dev, cases=CONV3_CASES):
         close(dw, 2 * w.grad, rtol=2e-4, msg=tag + " wgrad accumulate")
 
 
+def check_pack_many(ops, dev):
+    """all layers of a net in one launch == the single-layer packer, bit for bit (fwd and dgrad flavours, padded channel counts)"""
+    import struct
+    rng = np.random.default_rng(11)
+    layers = [(16, 16, 3), (32, 16, 3), (48, 64, 3), (4, 16, 1), (32, 2, 1), (16, 20, 3)]       # (Cout, Cin, KD)
+    ws, outs, desc = [], [], b""
+    for Cout, Cin, KD in layers:
+        w = R(rng, Cout, Cin, *((3, 3) if KD == 1 else (3, 3, 3))).to(dev).contiguous()
+        K16, N16 = (Cin + 15) // 16 * 16, (Cout + 15) // 16 * 16
+        n = KD * 9 * K16 * N16
+        wf = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
+        wd = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
+        desc += struct.pack("<QQiiiiii", w.data_ptr(), wf.data_ptr(), Cout, Cin, KD * 9, K16, N16, 0)
+        desc += struct.pack("<QQiiiiii", w.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, N16, K16, 1)
+        ws.append((w, KD)); outs.append((wf, wd))
+    d = torch.frombuffer(bytearray(desc), dtype=torch.uint8).to(dev)
+    ops.conv3_pack_many(d, 2 * len(layers))
+    for (w, KD), (wf, wd) in zip(ws, outs):
+        rf, rd = ops.conv3_pack(w, KD)
+        assert torch.equal(wf.cpu(), rf.flatten().cpu()), f"pack_many fwd {tuple(w.shape)}"
+        assert torch.equal(wd.cpu(), rd.flatten().cpu()), f"pack_many dgrad {tuple(w.shape)}"
+
+
 def check_conv3_c1(ops, dev):
     rng = np.random.default_rng(6)
     for (N, sp, KD) in ((1, (5, 6, 18), 3), (2, (4, 4, 16), 3), (2, (1, 17, 20), 1)):
@@ -470,4 +493,4 @@ def check_conv3_stats(ops, dev):
         close(a1, a2, rtol=1e-6, msg="norm from fused partials")
 
 
-ALL_CHECKS = ("conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")
+ALL_CHECKS = ("pack_many", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")
