@@ -27,78 +27,125 @@ struct NormEpilogue {
 
 // ------------------------------------------------------------------ column reductions
 // MODE 0: (sum x, sum x^2) of y.   MODE 1: (sum dz, sum dz*xhat) for the backward pass.
+//
+// All three streaming kernels below walk "segments": a segment is a run of rows that shares every per-channel
+// parameter -- one normalisation group, or one sample of it when a per-(sample, channel) Dropout3d scale is present.
+// blockIdx.y = segment, so group / sample indices are block-uniform, a thread's float4 column never changes, and the
+// per-channel parameters are loaded ONCE into registers; the element loop is 4-way unrolled with the loads up front
+// (memory-level parallelism for an HBM stream) and contains no division.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y, const float* __restrict__ da,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     NormEpilogue ep, long long rows_per_group, int C,
-                                                     double* __restrict__ partial /* [G][nb][C][2] */) {
+                                                     NormEpilogue ep, long long seg_rows, int spg /* segments per group */, int C,
+                                                     double* __restrict__ partial /* [G][spg * gridDim.x][C][2] */) {
+  constexpr int U = 4;
   const int C4 = C >> 2;
   const int col = threadIdx.x % C4;        // float4 column
   const int slot = threadIdx.x / C4;       // row slot within a pass
   const int slots = 256 / C4;
-  const int g = blockIdx.y, nb = gridDim.x;
-  const long long chunk = (rows_per_group + nb - 1) / nb;
+  const int seg = blockIdx.y, g = seg / spg, nbps = gridDim.x;
+  const long long chunk = (seg_rows + nbps - 1) / nbps;
   const long long r0 = (long long)blockIdx.x * chunk;
   long long r1 = r0 + chunk;
-  if (r1 > rows_per_group) r1 = rows_per_group;
-  const long long gbase = (long long)g * rows_per_group;
+  if (r1 > seg_rows) r1 = seg_rows;
+  const long long sbase = (long long)seg * seg_rows;
 
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0), mu = sh, rs = sc;
+  float scv[4] = {1, 1, 1, 1}, shv[4] = {0, 0, 0, 0}, muv[4] = {0, 0, 0, 0}, rsv[4] = {1, 1, 1, 1}, csv[4] = {1, 1, 1, 1};
   if (MODE == 1) {
-    sc = ld4(scale + (long long)g * C + col * 4);
-    sh = ld4(shift + (long long)g * C + col * 4);
-    mu = ld4(mean + (long long)g * C + col * 4);
-    rs = ld4(rstd + (long long)g * C + col * 4);
+    const float4 sc = ld4(scale + (long long)g * C + col * 4), sh = ld4(shift + (long long)g * C + col * 4);
+    const float4 mu = ld4(mean + (long long)g * C + col * 4), rs = ld4(rstd + (long long)g * C + col * 4);
+    scv[0] = sc.x; scv[1] = sc.y; scv[2] = sc.z; scv[3] = sc.w;
+    shv[0] = sh.x; shv[1] = sh.y; shv[2] = sh.z; shv[3] = sh.w;
+    muv[0] = mu.x; muv[1] = mu.y; muv[2] = mu.z; muv[3] = mu.w;
+    rsv[0] = rs.x; rsv[1] = rs.y; rsv[2] = rs.z; rsv[3] = rs.w;
+    if (ep.chan_scale) {
+      const float4 c4 = ld4(ep.chan_scale + (sbase / ep.rows_per_sample) * C + col * 4);
+      csv[0] = c4.x; csv[1] = c4.y; csv[2] = c4.z; csv[3] = c4.w;
+    }
   }
-  if (slot < slots) {
-    for (long long r = r0 + slot; r < r1; r += slots) {
-      const long long row = gbase + r;
-      const float4 v = ld4(y + row * C + col * 4);
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      if (MODE == 0) {
+  auto accum = [&](const float4& v, const float4& d4, const uchar4& m4) {
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+    if (MODE == 0) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { s1[k] += (double)vv[k]; s2[k] += (double)vv[k] * (double)vv[k]; }
-      } else {
-        const float4 d4 = ld4(da + row * C + col * 4);
-        float dz[4] = {d4.x, d4.y, d4.z, d4.w};
-        const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-        const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-        float cs[4] = {1.f, 1.f, 1.f, 1.f};
-        if (ep.chan_scale) {
-          const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + col * 4);
-          cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
-        }
-        if (ep.elem_mask) {
-          const uchar4 m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + row * C + col * 4);
-          cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
-          cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
-        }
+      for (int k = 0; k < 4; ++k) { s1[k] += (double)vv[k]; s2[k] += (double)vv[k] * (double)vv[k]; }
+    } else {
+      const float dz[4] = {d4.x, d4.y, d4.z, d4.w};
+      float cs[4] = {csv[0], csv[1], csv[2], csv[3]};
+      if (ep.elem_mask) {
+        cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
+        cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
+      }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float z = (vv[k] - muv[k]) * scv[k] + shv[k];
-          const float g1 = dz[k] * cs[k] * act_grad(z, ep.act);
-          const float xh = (vv[k] - muv[k]) * rsv[k];
-          s1[k] += (double)g1;
-          s2[k] += (double)g1 * (double)xh;
-        }
+      for (int k = 0; k < 4; ++k) {
+        const float z = (vv[k] - muv[k]) * scv[k] + shv[k];
+        const float g1 = dz[k] * cs[k] * act_grad(z, ep.act);
+        const float xh = (vv[k] - muv[k]) * rsv[k];
+        s1[k] += (double)g1;
+        s2[k] += (double)g1 * (double)xh;
       }
     }
-  }
-  __shared__ double red[256][8];
+  };
+  if (slot < slots) {
+    long long r = r0 + slot;
+    for (; r + (long long)(U - 1) * slots < r1; r += (long long)U * slots) {
+      float4 v[U], d4[U];
+      uchar4 m4[U];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) { red[threadIdx.x][k] = s1[k]; red[threadIdx.x][4 + k] = s2[k]; }
+      for (int u = 0; u < U; ++u) {
+        const long long e = ((sbase + r + (long long)u * slots) * C4 + col) * 4;
+        v[u] = ld4(y + e);
+        if (MODE == 1) {
+          d4[u] = ld4(da + e);
+          if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + e);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) accum(v[u], d4[u], m4[u]);
+    }
+    for (; r < r1; r += slots) {
+      const long long e = ((sbase + r) * C4 + col) * 4;
+      float4 d4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      uchar4 m4 = make_uchar4(0, 0, 0, 0);
+      const float4 v = ld4(y + e);
+      if (MODE == 1) {
+        d4 = ld4(da + e);
+        if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + e);
+      }
+      accum(v, d4, m4);
+    }
+  }
+  // block reduce over the row slots: xor-shuffles inside a wave (lanes with equal column are C4 apart), then one LDS hop
+  // over the <= 4 waves.  (The previous version let C4 threads walk all 256/C4 slots serially -- for C = 16 that tail
+  // took as long as the streaming loop itself.)
+  double acc8[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
+  for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc8[k] += __shfl_xor(acc8[k], off);
+  }
+  constexpr int NE = 4;                                   // LDS entries: one per wave (C4 <= 64) or per 64-column slice
+  __shared__ double red[NE][64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool leader = (C4 >= 64) || lane < C4;
+  if (leader) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[wave][lane][k] = acc8[k];
+  }
   __syncthreads();
   if ((int)threadIdx.x < C4) {
-    double a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
-    for (int s = 0; s < slots; ++s) {
+    // C4 <= 64: column col lives at lane col of every wave.  C4 = 128 / 256: column col lives in wave (col / 64) + j * (C4 / 64)
+    double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int wpr = C4 >= 64 ? C4 / 64 : 1;               // waves per row slot
+    const int w0 = C4 >= 64 ? col / 64 : 0;
+    for (int w = w0; w < 4; w += wpr) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { a1[k] += red[s * C4 + col][k]; a2[k] += red[s * C4 + col][4 + k]; }
+      for (int k = 0; k < 8; ++k) a[k] += red[w][col & 63][k];
     }
-    double* out = partial + (((long long)g * nb + blockIdx.x) * C + col * 4) * 2;
+    const long long prow = (long long)g * spg * nbps + (long long)(seg - g * spg) * nbps + blockIdx.x;
+    double* out = partial + (prow * C + col * 4) * 2;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { out[k * 2] = a1[k]; out[k * 2 + 1] = a2[k]; }
+    for (int k = 0; k < 4; ++k) { out[k * 2] = a[k]; out[k * 2 + 1] = a[4 + k]; }
   }
 }
 
@@ -182,40 +229,57 @@ __global__ __launch_bounds__(256) void k_norm_bwd_finalize(const double* __restr
 }
 
 // ------------------------------------------------------------------ apply passes
-// a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]
+// a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]      (segments: see k_col_partial)
 __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ mean,
-                                                    const float* __restrict__ residual, NormEpilogue ep, long long rows,
-                                                    long long rows_per_group, int C, float* __restrict__ out,
+                                                    const float* __restrict__ residual, NormEpilogue ep, long long seg_rows,
+                                                    int spg, int G, int C, float* __restrict__ out,
                                                     const float* __restrict__ var_unb, float* __restrict__ running_mean,
                                                     float* __restrict__ running_var, float momentum) {
-  if (blockIdx.x == 0 && running_mean) update_running(mean, var_unb, (int)(rows / rows_per_group), C, running_mean, running_var, momentum);
+  constexpr int U = 4;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && running_mean) update_running(mean, var_unb, G, C, running_mean, running_var, momentum);
   const int C4 = C >> 2;
-  const int c4_shift = 31 - __clz(C4);   // C is a power of two (checked on the host)
-  const long long nvec = rows * C4;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const long long row = i >> c4_shift;
-    const int col = (int)(i & (C4 - 1));
-    const long long g = (rows_per_group == rows) ? 0 : row / rows_per_group;
-    const float4 v = ld4(y + i * 4);
-    const float4 sc = ld4(scale + g * C + col * 4), sh = ld4(shift + g * C + col * 4), mu = ld4(mean + g * C + col * 4);
+  const int col = threadIdx.x & (C4 - 1);          // C4 is a power of two dividing 256: fixed for the whole loop
+  const int seg = blockIdx.y, g = seg / spg;
+  const long long nv = seg_rows * C4, base = (long long)seg * nv;
+  const long long stride = (long long)gridDim.x * 256;
+  const float4 sc = ld4(scale + (long long)g * C + col * 4), sh = ld4(shift + (long long)g * C + col * 4);
+  const float4 mu = ld4(mean + (long long)g * C + col * 4);
+  float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (ep.chan_scale) cs = ld4(ep.chan_scale + (((long long)seg * seg_rows) / ep.rows_per_sample) * C + col * 4);
+  auto one = [&](long long i, const float4& v, const float4& r4, const uchar4& m4) {
     float o[4] = {act_fwd((v.x - mu.x) * sc.x + sh.x, ep.act), act_fwd((v.y - mu.y) * sc.y + sh.y, ep.act),
                   act_fwd((v.z - mu.z) * sc.z + sh.z, ep.act), act_fwd((v.w - mu.w) * sc.w + sh.w, ep.act)};
-    if (ep.chan_scale) {
-      const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + col * 4);
-      o[0] *= c4.x; o[1] *= c4.y; o[2] *= c4.z; o[3] *= c4.w;
-    }
+    if (ep.chan_scale) { o[0] *= cs.x; o[1] *= cs.y; o[2] *= cs.z; o[3] *= cs.w; }
     if (ep.elem_mask) {
-      const uchar4 m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
       o[0] *= m4.x ? ep.elem_scale : 0.f; o[1] *= m4.y ? ep.elem_scale : 0.f;
       o[2] *= m4.z ? ep.elem_scale : 0.f; o[3] *= m4.w ? ep.elem_scale : 0.f;
     }
-    if (residual) {
-      const float4 r4 = ld4(residual + i * 4);
-      o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w;
-    }
+    if (residual) { o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w; }
     st4(out + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+  };
+  long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; j + (U - 1) * stride < nv; j += U * stride) {
+    float4 v[U], r4[U];
+    uchar4 m4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = base + j + u * stride;
+      v[u] = ld4(y + i * 4);
+      if (residual) r4[u] = ld4(residual + i * 4);
+      if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(base + j + u * stride, v[u], r4[u], m4[u]);
+  }
+  for (; j < nv; j += stride) {
+    const long long i = base + j;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 m4 = make_uchar4(0, 0, 0, 0);
+    const float4 v = ld4(y + i * 4);
+    if (residual) r4 = ld4(residual + i * 4);
+    if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+    one(i, v, r4, m4);
   }
 }
 
@@ -224,11 +288,11 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd,
                                                         const float* __restrict__ c1, const float* __restrict__ c2,
-                                                        NormEpilogue ep, long long rows, long long rows_per_group, int C,
+                                                        NormEpilogue ep, long long seg_rows, int spg, int G, int C,
                                                         float* __restrict__ dy, const float* __restrict__ raw,
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
-  if (blockIdx.x == 0 && dgamma) {   // parameter gradients: sum the groups in order (deterministic)
-    const int G = (int)(rows / rows_per_group);
+  constexpr int U = 4;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {   // parameter gradients: sum the groups in order (deterministic)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float gb = accumulate ? dbeta[c] : 0.f, gg = accumulate ? dgamma[c] : 0.f;
       for (int g = 0; g < G; ++g) { gb += raw[g * C + c]; gg += raw[(long long)G * C + g * C + c]; }
@@ -237,31 +301,25 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
     }
   }
   const int C4 = C >> 2;
-  const int c4_shift = 31 - __clz(C4);   // C is a power of two (checked on the host)
-  const long long nvec = rows * C4;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) {
-    const long long row = i >> c4_shift;
-    const int col = (int)(i & (C4 - 1));
-    const long long g = (rows_per_group == rows) ? 0 : row / rows_per_group;
-    const long long gc = g * C + col * 4;
-    const float4 v = ld4(y + i * 4), d4 = ld4(da + i * 4);
-    const float4 sc = ld4(scale + gc), sh = ld4(shift + gc), mu = ld4(mean + gc), rs = ld4(rstd + gc);
-    const float4 k1 = ld4(c1 + gc), k2 = ld4(c2 + gc);
-    float cs[4] = {1.f, 1.f, 1.f, 1.f};
-    if (ep.chan_scale) {
-      const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + col * 4);
-      cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
-    }
+  const int col = threadIdx.x & (C4 - 1);
+  const int seg = blockIdx.y, g = seg / spg;
+  const long long nv = seg_rows * C4, base = (long long)seg * nv;
+  const long long stride = (long long)gridDim.x * 256;
+  const long long gc = (long long)g * C + col * 4;
+  const float4 sc = ld4(scale + gc), sh = ld4(shift + gc), mu = ld4(mean + gc), rs = ld4(rstd + gc);
+  const float4 k1 = ld4(c1 + gc), k2 = ld4(c2 + gc);
+  float4 csl = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (ep.chan_scale) csl = ld4(ep.chan_scale + (((long long)seg * seg_rows) / ep.rows_per_sample) * C + col * 4);
+  const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+  const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+  const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
+  auto one = [&](long long i, const float4& v, const float4& d4, const uchar4& m4) {
+    float cs[4] = {csl.x, csl.y, csl.z, csl.w};
     if (ep.elem_mask) {
-      const uchar4 m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
       cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
       cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
     }
     const float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
-    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
-    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
-    const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
     float o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -271,6 +329,27 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
       o[k] = scv[k] * (dz - k1v[k] - xh * k2v[k]);
     }
     st4(dy + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+  };
+  long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; j + (U - 1) * stride < nv; j += U * stride) {
+    float4 v[U], d4[U];
+    uchar4 m4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long i = base + j + u * stride;
+      v[u] = ld4(y + i * 4);
+      d4[u] = ld4(da + i * 4);
+      if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(base + j + u * stride, v[u], d4[u], m4[u]);
+  }
+  for (; j < nv; j += stride) {
+    const long long i = base + j;
+    uchar4 m4 = make_uchar4(0, 0, 0, 0);
+    const float4 v = ld4(y + i * 4), d4 = ld4(da + i * 4);
+    if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+    one(i, v, d4, m4);
   }
 }
 
@@ -283,11 +362,25 @@ static inline int norm_blocks(long long rows_per_group, int C) {
   return (int)nb;
 }
 
-static inline int apply_grid(long long nvec) {
-  long long g = (nvec + 255) / 256;
-  if (g > 2048) g = 2048;
+static inline int apply_grid(long long nvec, int nseg) {
+  long long g = (nvec + 256 * 4 - 1) / (256 * 4);          // 4 float4 per thread per trip
+  const long long cap = 2048 / nseg < 1 ? 1 : 2048 / nseg;
+  if (g > cap) g = cap;
   return (int)(g < 1 ? 1 : g);
 }
+
+// segments (see k_col_partial): the finer of (group, sample) when a per-sample channel scale is present
+struct Segs { long long seg_rows; int spg; int nbps; };
+static inline Segs make_segs(int G, long long rows_per_group, int C, const NormEpilogue& ep) {
+  Segs sg{rows_per_group, 1, norm_blocks(rows_per_group, C)};
+  if (ep.chan_scale && ep.rows_per_sample < rows_per_group) {
+    sg.seg_rows = ep.rows_per_sample;
+    sg.spg = (int)(rows_per_group / ep.rows_per_sample);
+    sg.nbps = sg.nbps / sg.spg < 1 ? 1 : sg.nbps / sg.spg;
+  }
+  return sg;
+}
+static constexpr int kMaxSamplesPerGroup = 64;
 
 }  // namespace bcp
 
@@ -296,7 +389,7 @@ using namespace bcp;
 extern "C" size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C) {
   if (G < 1 || C < 16 || rows_per_group < 1) return 0;
   // per-block fp64 partials, then the two per-(g,c) backward means (c1, c2)
-  return (size_t)G * norm_blocks(rows_per_group, C) * C * 2 * sizeof(double) + (size_t)4 * G * C * sizeof(float);
+  return (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2 * sizeof(double) + (size_t)4 * G * C * sizeof(float);
 }
 
 static int check_norm_args(const char* fn, int G, long long rows_per_group, int C) {
@@ -314,8 +407,11 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   BCP_REQUIRE(y && stats && workspace && out, "bcp_norm_fwd: null pointer");
   BCP_REQUIRE(aligned16(y) && aligned16(out) && aligned16(stats), "bcp_norm_fwd: alignment");
   hipStream_t s = (hipStream_t)stream;
-  const int nb = norm_blocks(rows_per_group, C);
   NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
+              "bcp_norm_fwd: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
+  const Segs sg = make_segs(G, rows_per_group, C, ep);
+  const int nseg = G * sg.spg, nb = sg.nbps * sg.spg;
   double* partial = reinterpret_cast<double*>(workspace);
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float* var_unb = stats + 4LL * G * C;
@@ -323,15 +419,13 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
     hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
   } else {
-    hipLaunchKernelGGL((k_col_partial<0>), dim3(nb, G), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, rows_per_group, C, partial);
+    hipLaunchKernelGGL((k_col_partial<0>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial);
+    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
+                       running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
   }
-  if (!partial_in)
-  hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
-                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
-  const long long rows = (long long)G * rows_per_group;
-  hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, scale, shift, mean, residual, ep, rows,
-                     rows_per_group, C, out, var_unb, running_mean, running_var, momentum);
+  hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, scale, shift, mean, residual,
+                     ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum);
   BCP_CHECK_LAUNCH("bcp_norm_fwd");
   return BCP_OK;
 }
@@ -343,21 +437,23 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   if (int rc = check_norm_args("bcp_norm_bwd", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(y && da && stats && workspace && dy, "bcp_norm_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  const int nb = norm_blocks(rows_per_group, C);
   NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
+              "bcp_norm_bwd: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
+  const Segs sg = make_segs(G, rows_per_group, C, ep);
+  const int nseg = G * sg.spg, nb = sg.nbps * sg.spg;
   double* partial = reinterpret_cast<double*>(workspace);
   const float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   // c1/c2 live behind the partials in the workspace
-  float* c1 = reinterpret_cast<float*>(partial + (size_t)G * nb * C * 2);
+  float* c1 = reinterpret_cast<float*>(partial + (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2);
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
-  hipLaunchKernelGGL((k_col_partial<1>), dim3(nb, G), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, rows_per_group, C,
-                     partial);
+  hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
+                     C, partial);
   hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
                      dbeta, accumulate, c1, c2, raw);
-  const long long rows = (long long)G * rows_per_group;
-  hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(rows * (C / 4))), dim3(256), 0, s, y, da, scale, shift, mean, rstd, c1,
-                     c2, ep, rows, rows_per_group, C, dy, raw, dgamma, dbeta, accumulate);
+  hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da, scale, shift, mean,
+                     rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate);
   BCP_CHECK_LAUNCH("bcp_norm_bwd");
   return BCP_OK;
 }

@@ -138,7 +138,10 @@ def check_norm(ops, dev):
     rng = np.random.default_rng(4)
     for (N, Cc, sp, act, use_cs, use_res, G) in ((2, 16, (4, 6, 8), H.ACT_RELU, True, True, 1), (1, 64, (2, 4, 4), H.ACT_RELU, False, False, 1),
                                                   (3, 32, (1, 8, 8), H.ACT_LRELU, False, False, 1), (2, 32, (4, 4, 4), H.ACT_RELU, False, False, 2),
-                                                  (1, 256, (2, 2, 2), H.ACT_RELU, True, False, 1)):
+                                                  (1, 256, (2, 2, 2), H.ACT_RELU, True, False, 1),
+                                                  (2, 16, (7, 15, 21), H.ACT_RELU, True, True, 1),      # unrolled main loop + tails, 2 samples in 1 group
+                                                  (4, 16, (5, 9, 12), H.ACT_LRELU, False, False, 4),
+                                                  (1, 512, (1, 3, 5), H.ACT_RELU, False, False, 1)):   # InstanceNorm (G = N)
         y = (R(rng, N, Cc, *sp) * 1.7 + 0.4).requires_grad_(True)
         gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cc).astype(np.float32)).requires_grad_(True)
         beta = torch.from_numpy(rng.uniform(-0.3, 0.3, Cc).astype(np.float32)).requires_grad_(True)
