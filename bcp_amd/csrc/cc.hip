@@ -163,7 +163,10 @@ __global__ __launch_bounds__(256) void k_cc_select(const uint8_t* __restrict__ s
     if (L[v] != (int)v) continue;  // global roots only
     const int sample = (int)(v / V);
     const unsigned long long key = ((unsigned long long)(unsigned)size[v] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)v);
-    atomicMax(&best[(long long)sample * nclass + (seg[v] - 1)], key);
+    // noise maps have ~10^5 roots hammering N*nclass words: the running maximum only grows, so a plain (racy but
+    // monotone) read filters out almost every candidate before it becomes an atomic
+    unsigned long long* slot = &best[(long long)sample * nclass + (seg[v] - 1)];
+    if (key > *reinterpret_cast<volatile unsigned long long*>(slot)) atomicMax(slot, key);
   }
 }
 

@@ -11,6 +11,7 @@
 // TN kernel:  P[k][n] = sum_m A(m, k) * B(m, n)                (weight gradients; M = voxels)
 // Both use v_mfma_f32_16x16x4_f32; lane (i = l&15, g = l>>4).
 #include "common.h"
+#include <cstdlib>
 #include "../../include/bcp_hip.h"
 
 namespace bcp {
@@ -19,6 +20,12 @@ enum { MAP_PLAIN = 0, MAP_PATCH = 1 };
 
 // Row map: logical matrix [M][L]; PLAIN: p + m*L + q.  PATCH: m indexes a coarse voxel of a fine
 // [N][D][H][W][Cs] tensor, q = s*Cs + c with s = (pd*2 + ph)*2 + pw.
+//
+// Index-math discipline (measured: the first version spent ~1500 VALU instructions per lane per block on runtime
+// integer divisions in base()/off() and ran the HBM-bound top-level layers at 0.8-1.7 TB/s): base() -- three div/mod
+// pairs -- is evaluated at most once per row per block (row tables in LDS for the TN kernel, one row + carry-increments
+// in the NN epilogue); off16() is only ever called with block-uniform arguments, because Cs % 16 == 0 makes every
+// aligned 16-column group lie inside one patch segment.
 struct RowMap {
   float* p;
   int mode;
@@ -31,69 +38,120 @@ struct RowMap {
     const int wc = m % Wc, hc = (m / Wc) % Hc, dc = (m / (Wc * Hc)) % Dc, n = m / (Wc * Hc * Dc);
     return ((((long long)n * D + 2 * dc) * H + 2 * hc) * W + 2 * wc) * Cs;
   }
-  __device__ __forceinline__ long long off(int q) const {   // add to base(m) for logical column q (PATCH: within one segment run)
-    if (mode == MAP_PLAIN) return q;
-    const int s = q / Cs, c = q - s * Cs;
+  // offset of the aligned 16-column group starting at logical column q16 (q16 % 16 == 0): uniform when q16 is
+  __device__ __forceinline__ long long off16(int q16) const {
+    if (mode == MAP_PLAIN) return q16;
+    const int s = q16 / Cs, c = q16 - s * Cs;
     const int pw = s & 1, ph = (s >> 1) & 1, pd = s >> 2;
     return (((long long)pd * H + ph) * W + pw) * Cs + c;
   }
+  // bases of 4 consecutive rows m..m+3 with one decomposition + carries (m % 4 == 0 is NOT required)
+  __device__ __forceinline__ void base4(int m, long long (&b)[4]) const {
+    if (mode == MAP_PLAIN) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) b[r] = (long long)(m + r) * L;
+      return;
+    }
+    const int Wc = W >> 1, Hc = H >> 1, Dc = D >> 1;
+    int wc = m % Wc, hc = (m / Wc) % Hc, dc = (m / (Wc * Hc)) % Dc, n = m / (Wc * Hc * Dc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      b[r] = ((((long long)n * D + 2 * dc) * H + 2 * hc) * W + 2 * wc) * Cs;
+      if (++wc == Wc) { wc = 0; if (++hc == Hc) { hc = 0; if (++dc == Dc) { dc = 0; ++n; } } }
+    }
+  }
 };
 
-static constexpr int AS = 20;  // LDS row stride of the A chunk (16 + 4 pad)
+static constexpr int KC = 32;       // k per pipeline stage of the NN kernel
+static constexpr int AS = KC + 4;   // LDS row stride of the A chunk (+4 pad keeps rows 16-B aligned and spreads banks)
 
 // ------------------------------------------------------------------------------------------------
-// NN: block = 64 rows x (16*NT) cols, waves split the rows (one 16-row m-tile each).
+// NN: block = 64 rows x (16*NT) cols, waves split the rows (one 16-row m-tile each); K walks in stages of 32 with the
+// next stage's A rows and B slab fetched into registers underneath the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restrict__ Bp, const float* __restrict__ bias,
                                                  RowMap C, int M, int K, int N, int bias_mod, int accumulate) {
   constexpr int CT = NT * 16;
+  constexpr int NB4 = (8 * CT + 255) / 256;          // B float4s per thread per stage
   __shared__ __attribute__((aligned(16))) float As[64 * AS];
-  __shared__ __attribute__((aligned(16))) float Bs[4 * CT * 4];
+  __shared__ __attribute__((aligned(16))) float Bs[8 * CT * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * 64, n0 = blockIdx.y * CT;
 
-  // staging role: thread -> (row, 16-B part)
+  // staging role: thread -> (row, 16-B part of a 16-k half stage)
   const int srow = threadIdx.x >> 2, spart = threadIdx.x & 3;
   const bool srow_ok = (m0 + srow) < M;
-  const long long sbase = srow_ok ? A.base(m0 + srow) : 0;
+  const float* arow = A.p + (srow_ok ? A.base(m0 + srow) : 0) + spart * 4;
 
   f32x4 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int kc = 0; kc < K; kc += 16) {
-    __syncthreads();
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (srow_ok) v = ld4(A.p + sbase + A.off(kc + spart * 4));
-    st4(As + srow * AS + spart * 4, v);
-    for (int q = threadIdx.x; q < 4 * CT; q += 256) {
-      const int co = q % CT, kq = q / CT;
-      st4(Bs + q * 4, ld4(Bp + (((long long)(kc >> 2) + kq) * N + n0 + co) * 4));
-    }
-    __syncthreads();
-    const float4 a = ld4(As + (wave * 16 + li) * AS + lg * 4);
+  float4 pa[2], pb[NB4];
+  auto fetch = [&](int kc) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float4 b = ld4(Bs + ((lg * CT) + nt * 16 + li) * 4);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nt], 0, 0, 0);
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nt], 0, 0, 0);
+    for (int h = 0; h < 2; ++h) {
+      pa[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (srow_ok && kc + 16 * h < K) pa[h] = ld4(arow + A.off16(kc + 16 * h));   // off16 argument is block-uniform
     }
-  }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int m = m0 + wave * 16 + lg * 4 + r;
-    if (m < M) {
-      const long long cb = C.base(m);
+    for (int u = 0; u < NB4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < 8 * CT) {
+        const int co = q % CT, kq = q / CT;
+        if (kc + kq * 4 < K) pb[u] = ld4(Bp + (((long long)(kc >> 2) + kq) * N + n0 + co) * 4);
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) st4(As + srow * AS + h * 16 + spart * 4, pa[h]);
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      if (q < 8 * CT) st4(Bs + q * 4, pb[u]);
+    }
+  };
+
+  fetch(0);
+  stash();
+  __syncthreads();
+  for (int kc = 0; kc < K; kc += KC) {
+    const bool has_next = kc + KC < K;
+    if (has_next) fetch(kc + KC);
+#pragma unroll
+    for (int kq = 0; kq < KC / 16; ++kq) {           // 16 k per (a, b) fragment pair
+      const float4 a = ld4(As + (wave * 16 + li) * AS + kq * 16 + lg * 4);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int n = n0 + nt * 16 + li;
-        float* o = C.p + cb + C.off(n);
-        float v = acc[nt][r];
-        if (bias) v += bias[n % bias_mod];
+        const float4 b = ld4(Bs + (((kq * 4 + lg) * CT) + nt * 16 + li) * 4);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nt], 0, 0, 0);
+      }
+    }
+    if (!has_next) break;
+    __syncthreads();
+    stash();
+    __syncthreads();
+  }
+  // epilogue: lane (li, lg) holds rows m0 + wave*16 + lg*4 + r, column n0 + nt*16 + li
+  long long cb[4];
+  const int mr = m0 + wave * 16 + lg * 4;
+  C.base4(mr < M ? mr : 0, cb);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const long long coff = C.off16(n0 + nt * 16) + li;                  // block-uniform + lane
+    const float bv = bias ? bias[(n0 + nt * 16) % bias_mod + li] : 0.f;  // bias_mod % 16 == 0
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (mr + r < M) {
+        float* o = C.p + cb[r] + coff;
+        float v = acc[nt][r] + bv;
         if (accumulate) v += *o;
         *o = v;
       }
@@ -104,6 +162,8 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
 // ------------------------------------------------------------------------------------------------
 // TN: P[grp][k][n] = sum over the group's rows of A(m,k) * B(m,n).  Block = (row group, 64 k, 16*NT n);
 // wave w owns k-subtile w.  Per k-step of 4 rows: lane (i, g) supplies A(row g, k i) and B(row g, n i).
+// Row bases of a 64-row chunk are computed once (64 + 64 threads) into an LDS table; the next chunk is fetched
+// into registers underneath the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(256) void k_gemm_tn(RowMap A, RowMap B, float* __restrict__ partial, int M, int K, int N,
@@ -111,8 +171,10 @@ __global__ __launch_bounds__(256) void k_gemm_tn(RowMap A, RowMap B, float* __re
   constexpr int CT = NT * 16;
   constexpr int AS2 = 64 + 16;                          // [row][64 k] + bank spread
   constexpr int BS2 = (CT % 32 == 0) ? CT + 16 : CT;    // [row][CT n]
+  constexpr int NB4 = (64 * (CT / 4) + 255) / 256;      // B float4s per thread per chunk
   __shared__ __attribute__((aligned(16))) float As[64 * AS2];
   __shared__ __attribute__((aligned(16))) float Bs[64 * BS2];
+  __shared__ long long rbase[2][2][64];                 // [parity][A/B][row]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int grp = blockIdx.x, k0 = blockIdx.y * 64, n0 = blockIdx.z * CT;
@@ -124,22 +186,61 @@ __global__ __launch_bounds__(256) void k_gemm_tn(RowMap A, RowMap B, float* __re
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // launch-invariant column offsets of this thread's float4s
+  const int apart = threadIdx.x & 15, arow0 = threadIdx.x >> 4;          // A: rows arow0 + 16u, k = k0 + apart*4
+  const bool ak_ok = k0 + apart * 4 < K;
+  const long long acol = A.off16(k0 + (apart >> 2) * 16) + (apart & 3) * 4;
+  long long bcol[NB4];
+  int brow[NB4];
+#pragma unroll
+  for (int u = 0; u < NB4; ++u) {
+    const int q = threadIdx.x + u * 256;
+    const int part = q % (CT / 4);
+    brow[u] = q / (CT / 4);
+    bcol[u] = B.off16(n0 + (part >> 2) * 16) + (part & 3) * 4;
+  }
+  auto bases = [&](int rc, int par) {     // threads 0..63: A rows, 64..127: B rows
+    if (threadIdx.x < 128) {
+      const int row = threadIdx.x & 63;
+      const int m = rc + row < r_end ? rc + row : r_begin;
+      rbase[par][threadIdx.x >> 6][row] = (threadIdx.x < 64) ? A.base(m) : B.base(m);
+    }
+  };
+  float4 pa[4], pb[NB4];
+  auto fetch = [&](int rc, int par) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = arow0 + 16 * u;
+      pa[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (rc + row < r_end && ak_ok) pa[u] = ld4(A.p + rbase[par][0][row] + acol);
+    }
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (brow[u] < 64 && rc + brow[u] < r_end) pb[u] = ld4(B.p + rbase[par][1][brow[u]] + bcol[u]);
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4(As + (arow0 + 16 * u) * AS2 + apart * 4, pa[u]);
+#pragma unroll
+    for (int u = 0; u < NB4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      if (brow[u] < 64) st4(Bs + brow[u] * BS2 + (q % (CT / 4)) * 4, pb[u]);
+    }
+  };
+
+  if (r_begin >= r_end) return;
+  bases(r_begin, 0);
+  __syncthreads();
+  fetch(r_begin, 0);
+  stash();
+  if (r_begin + 64 < r_end) bases(r_begin + 64, 1);
+  __syncthreads();
+  int par = 1;
   for (int rc = r_begin; rc < r_end; rc += 64) {
-    __syncthreads();
-    // A chunk: 64 rows x 64 k  = 1024 float4
-    for (int q = threadIdx.x; q < 64 * 16; q += 256) {
-      const int row = q >> 4, part = q & 15;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rc + row < r_end && k0 + part * 4 < K) v = ld4(A.p + A.base(rc + row) + A.off(k0 + part * 4));
-      st4(As + row * AS2 + part * 4, v);
-    }
-    for (int q = threadIdx.x; q < 64 * (CT / 4); q += 256) {
-      const int row = q / (CT / 4), part = q % (CT / 4);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (rc + row < r_end) v = ld4(B.p + B.base(rc + row) + B.off(n0 + part * 4));
-      st4(Bs + row * BS2 + part * 4, v);
-    }
-    __syncthreads();
+    const bool has_next = rc + 64 < r_end;
+    if (has_next) fetch(rc + 64, par);                 // table `par` was filled before the last barrier
 #pragma unroll 4
     for (int kk = 0; kk < 16; ++kk) {
       const int row = kk * 4 + lg;
@@ -148,6 +249,12 @@ __global__ __launch_bounds__(256) void k_gemm_tn(RowMap A, RowMap B, float* __re
       for (int nt = 0; nt < NT; ++nt)
         acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, Bs[row * BS2 + nt * 16 + li], acc[nt], 0, 0, 0);
     }
+    if (!has_next) break;
+    __syncthreads();
+    stash();
+    if (rc + 128 < r_end) bases(rc + 128, par ^ 1);
+    __syncthreads();
+    par ^= 1;
   }
   float* P = partial + (long long)grp * K * N;
 #pragma unroll
@@ -162,15 +269,29 @@ __global__ __launch_bounds__(256) void k_gemm_tn(RowMap A, RowMap B, float* __re
 // out[ (k1*ok1 + k2*ok2 + n1*on1 + n2*on2) ] (+)= sum_g partial[g][k][n],  k = k1*K2 + k2, n = n1*N2 + n2
 struct Idx4 { int K2, N2; long long sk1, sk2, sn1, sn2; };
 
+// block = 16 consecutive outputs x 16 group-slots: the G partial slabs are summed by 16 threads per output (fixed order:
+// deterministic) instead of one thread walking all of them (G is 256 at the top V-Net level: 256 dependent loads).
 __global__ __launch_bounds__(256) void k_tn_reduce(const float* __restrict__ partial, float* __restrict__ out, int G, int K, int N,
                                                    Idx4 ix, int accumulate) {
+  __shared__ float red[16][17];
   const long long total = (long long)K * N;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % N), k = (int)(i / N);
+  const int col = threadIdx.x & 15, slot = threadIdx.x >> 4;
+  for (long long i0 = (long long)blockIdx.x * 16; i0 < total; i0 += (long long)gridDim.x * 16) {
+    const long long i = i0 + col;
     float s = 0.f;
-    for (int g = 0; g < G; ++g) s += partial[(long long)g * total + i];
-    float* o = out + (k / ix.K2) * ix.sk1 + (k % ix.K2) * ix.sk2 + (n / ix.N2) * ix.sn1 + (n % ix.N2) * ix.sn2;
-    *o = accumulate ? (*o + s) : s;
+    if (i < total)
+      for (int g = slot; g < G; g += 16) s += partial[(long long)g * total + i];
+    red[slot][col] = s;
+    __syncthreads();
+    if (slot == 0 && i < total) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][col];
+      const int n = (int)(i % N), k = (int)(i / N);
+      float* o = out + (k / ix.K2) * ix.sk1 + (k % ix.K2) * ix.sk2 + (n / ix.N2) * ix.sn1 + (n % ix.N2) * ix.sn2;
+      *o = accumulate ? (*o + t) : t;
+    }
+    __syncthreads();
   }
 }
 
@@ -277,11 +398,19 @@ __global__ void k_pw16_finalize(const double* __restrict__ accum, float* __restr
 
 // column sums of a [rows][C] matrix (bias gradients of convs that are NOT followed by a norm)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, long long rows, int C, double* __restrict__ accum) {
-  // thread t owns column t % C (C <= 256, 256 % C == 0)
+  // thread t owns column t % C (C <= 256, 256 % C == 0); block-level sum first, then ONE atomic per column per block
+  // (every thread used to issue its own fp64 atomic: 131k atomics onto C words)
+  __shared__ double red[256];
   const int col = threadIdx.x % C, slot = threadIdx.x / C, slots = 256 / C;
   double s = 0.0;
   for (long long r = (long long)blockIdx.x * slots + slot; r < rows; r += (long long)gridDim.x * slots) s += (double)x[r * C + col];
-  atomicAdd(&accum[col], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    double t = 0.0;
+    for (int k = 0; k < slots; ++k) t += red[k * C + col];
+    atomicAdd(&accum[col], t);
+  }
 }
 __global__ void k_colsum_finalize(const double* __restrict__ accum, float* __restrict__ out, int C, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,6 +446,7 @@ static int tn_groups(int M, int K, int N, int nt) {
   const int chan_blocks = cdiv(K, 64) * (N / (nt * 16));
   int g = cdiv(512, chan_blocks);
   const int max_g = cdiv(M, 64);
+  if (const char* e = getenv("BCP_TN_GROUPS")) { const int v = atoi(e); if (v > 0 && v < g) g = v; }   // tests: force multi-chunk groups
   if (g > max_g) g = max_g;
   if (g < 1) g = 1;
   return g;
@@ -337,7 +467,7 @@ static int launch_tn(RowMap A, RowMap B, float* partial, float* out, int M, int 
   else if (nt == 2) hipLaunchKernelGGL((k_gemm_tn<2>), grid, dim3(256), 0, s, A, B, partial, M, K, N, rpg);
   else hipLaunchKernelGGL((k_gemm_tn<1>), grid, dim3(256), 0, s, A, B, partial, M, K, N, rpg);
   const long long total = (long long)K * N;
-  hipLaunchKernelGGL(k_tn_reduce, dim3((int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, s, partial,
+  hipLaunchKernelGGL(k_tn_reduce, dim3((int)((total + 15) / 16 > 4096 ? 4096 : (total + 15) / 16)), dim3(256), 0, s, partial,
                      out, G, K, N, ix, accumulate);
   return 0;
 }

@@ -88,29 +88,45 @@ __global__ __launch_bounds__(256) void k_bilinear2x_fwd(const float* __restrict_
 // dx[h][w] = sum over output pixels whose stencil touches (h, w) of weight * dy  (gather; deterministic)
 __global__ __launch_bounds__(256) void k_bilinear2x_bwd(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W,
                                                         int C, int lddy, int dy_off) {
-  const int Ho = 2 * H, Wo = 2 * W;
-  const long long total = (long long)N * H * W * C;
+  const int Ho = 2 * H, Wo = 2 * W, C4 = C >> 2;
+  const long long total = (long long)N * H * W * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int w = (int)((i / C) % W), h = (int)((i / ((long long)C * W)) % H), n = (int)(i / ((long long)C * W * H));
-    // output rows whose source coordinate lies in (h-1, h+1): o in [2h-3, 2h+3] is a safe superset for scale (H-1)/(2H-1) in (0, 0.5]
-    float s = 0.f;
-    for (int ho = max(0, 2 * h - 3); ho <= min(Ho - 1, 2 * h + 4); ++ho) {
-      const Lerp lh = lerp_ac(ho, H, Ho);
-      float wh = 0.f;
-      if (lh.i0 == h) wh += lh.l0;
-      if (lh.i1 == h) wh += lh.l1;
-      if (wh == 0.f) continue;
-      for (int wo = max(0, 2 * w - 3); wo <= min(Wo - 1, 2 * w + 4); ++wo) {
-        const Lerp lw = lerp_ac(wo, W, Wo);
-        float ww = 0.f;
-        if (lw.i0 == w) ww += lw.l0;
-        if (lw.i1 == w) ww += lw.l1;
-        if (ww == 0.f) continue;
-        s += wh * ww * dy[(((long long)n * Ho + ho) * Wo + wo) * lddy + dy_off + c];
+    const int c4 = (int)(i % C4);
+    const int w = (int)((i / C4) % W), h = (int)((i / ((long long)C4 * W)) % H), n = (int)(i / ((long long)C4 * W * H));
+    // output rows / columns whose source coordinate lies in (h-1, h+1): o in [2h-3, 2h+4] is a safe superset for the
+    // align_corners scale (H-1)/(2H-1) in (0, 0.5]; the 8 row and 8 column weights are evaluated once each
+    float wr[8], wc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ho = 2 * h - 3 + k, wo = 2 * w - 3 + k;
+      float a = 0.f, b = 0.f;
+      if (ho >= 0 && ho < Ho) {
+        const Lerp l = lerp_ac(ho, H, Ho);
+        if (l.i0 == h) a += l.l0;
+        if (l.i1 == h) a += l.l1;
+      }
+      if (wo >= 0 && wo < Wo) {
+        const Lerp l = lerp_ac(wo, W, Wo);
+        if (l.i0 == w) b += l.l0;
+        if (l.i1 == w) b += l.l1;
+      }
+      wr[k] = a;
+      wc[k] = b;
+    }
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      if (wr[k] == 0.f) continue;
+      const float* row = dy + (((long long)n * Ho + (2 * h - 3 + k)) * Wo) * lddy + dy_off + c4 * 4;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (wc[j] == 0.f) continue;
+        const float4 v = ld4(row + (long long)(2 * w - 3 + j) * lddy);
+        const float f = wr[k] * wc[j];
+        s.x += f * v.x; s.y += f * v.y; s.z += f * v.z; s.w += f * v.w;
       }
     }
-    dx[i] = s;
+    st4(dx + i * 4, s);
   }
 }
 
@@ -163,8 +179,8 @@ extern "C" int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W,
   return BCP_OK;
 }
 extern "C" int bcp_bilinear2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, int lddy, int dy_off, void* stream) {
-  BCP_REQUIRE(dy && dx && N > 0, "bcp_bilinear2x_bwd: bad argument");
-  hipLaunchKernelGGL(k_bilinear2x_bwd, dim3(sgrid((long long)N * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C, lddy,
+  BCP_REQUIRE(dy && dx && N > 0 && C % 4 == 0 && lddy % 4 == 0 && dy_off % 4 == 0, "bcp_bilinear2x_bwd: bad argument");
+  hipLaunchKernelGGL(k_bilinear2x_bwd, dim3(sgrid((long long)N * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, dy, dx, N, H, W, C, lddy,
                      dy_off);
   BCP_CHECK_LAUNCH("bcp_bilinear2x_bwd");
   return BCP_OK;

@@ -306,7 +306,7 @@ def check_conv3_c1(ops, dev):
 
 def check_k2(ops, dev):
     rng = np.random.default_rng(7)
-    for (N, Cin, Cout, sp) in ((1, 16, 32, (4, 6, 8)), (2, 32, 64, (2, 4, 6)), (1, 128, 256, (2, 2, 2))):
+    for (N, Cin, Cout, sp) in ((1, 16, 32, (4, 6, 8)), (2, 32, 64, (2, 4, 6)), (1, 128, 256, (2, 2, 2)), (1, 16, 16, (10, 12, 14)), (2, 32, 16, (8, 6, 10))):
         # down conv
         x = R(rng, N, Cin, *sp).requires_grad_(True)
         w = (R(rng, Cout, Cin, 2, 2, 2) * 0.1).requires_grad_(True)
@@ -451,6 +451,16 @@ CONV3_RES_CASES = (
 )
 
 
+def check_k2_chunks(ops, dev):
+    """weight-gradient GEMMs with ONE row group, so every block walks several 64-row chunks (prefetch / row-table pipeline)"""
+    import os
+    os.environ["BCP_TN_GROUPS"] = "1"
+    try:
+        check_k2(ops, dev)
+    finally:
+        del os.environ["BCP_TN_GROUPS"]
+
+
 def check_conv3_res(ops, dev):
     """resident-weight kernel, with the persistent grid forced small so every block walks several tiles"""
     import os
@@ -496,4 +506,4 @@ def check_conv3_stats(ops, dev):
         close(a1, a2, rtol=1e-6, msg="norm from fused partials")
 
 
-ALL_CHECKS = ("pack_many", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "pool2d", "optim")
+ALL_CHECKS = ("pack_many", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
