@@ -53,6 +53,8 @@ _SIGS = {
     "bcp_conv3_c1_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "bcp_conv3_c1_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_k2_pack_weight": (I, [P, P, I, I, I, P]),
+    "bcp_k2_pack_desc": (I, [P, P, I, I, I, P]),
+    "bcp_k2_pack_many": (I, [P, I, P]),
     "bcp_down_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),
     "bcp_down_dgrad": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "bcp_up_fwd": (I, [P, P, P, P, I, I, I, I, I, I, P]),

@@ -185,7 +185,7 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
   constexpr int S = T / WT;                     // weight stages per cin chunk
   static_assert(T % WT == 0, "WT must divide the tap count");
-  constexpr int NBUF = 2;                       // weight stages ping-pong across items (and across chunks)
+  constexpr int NBUF = (S > 1) ? 2 : 1;
   constexpr int WSTAGE4 = WT * 4 * CT;          // float4s per weight stage
   constexpr int NW4 = (WSTAGE4 + 255) / 256;    // per-thread prefetch registers
   constexpr int NACC = (MT * NT == 1) ? 2 : 1;  // a lone accumulator would serialise on the 40-cycle MFMA latency
@@ -221,76 +221,68 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   const int nchunks = cd.Cin16 >> 4;
   const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
   Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
-  // Flat software pipeline over (cin chunk, weight stage) items: the weights of the NEXT item and -- from the first
-  // stage of a chunk on -- the halo of the NEXT chunk travel global -> registers underneath the MFMAs of the current item
-  // and are dropped into LDS at the item boundary (weights: the other buffer; halo: the single buffer, between barriers).
-  // The deep V-Net levels run 8-16 chunks per block: fetching each chunk synchronously exposed ~2 us of latency per
-  // chunk against ~1.5 us of MFMA work.
-  auto wfetch = [&](int cc, int st, float4 (&pre)[NW4]) {
-#pragma unroll
-    for (int u = 0; u < NW4; ++u) {
-      const int q = threadIdx.x + u * 256;
-      if (q < WSTAGE4) {
-        const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
-        pre[u] = ld4(Wp + ((((long long)(st * WT + tl) * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
-      }
+  // One cin chunk at a time, halo and first weight stage loaded synchronously: latency is hidden by co-resident blocks.
+  // (A flat register-prefetch pipeline over (chunk, stage) items was measured SLOWER at the in-step batch of 2 -- 83 vs
+  // 77 us at C=64, 65 vs 57 us at C=128: its second weight buffer and prefetch registers cost more occupancy than the
+  // exposed latency they removed.)
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    __syncthreads();  // everyone is done with the previous chunk's LDS contents
+    {
+      float4 pre[HaloFetch<TL>::NP];
+      hf.fetch(X, cd, n, d0, h0, w0, cc, pre);
+      hf.stash(pre);
     }
-  };
-  auto wstash = [&](float* Wn, const float4 (&pre)[NW4]) {
-#pragma unroll
-    for (int u = 0; u < NW4; ++u) {
-      const int q = threadIdx.x + u * 256;
-      if (q < WSTAGE4) st4(Wn + q * 4, pre[u]);
+    // weight stage 0 of this chunk
+    for (int q = threadIdx.x; q < WSTAGE4; q += 256) {
+      const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
+      st4(Ws + q * 4, ld4(Wp + ((((long long)tl * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
     }
-  };
-  float4 hpre[HaloFetch<TL>::NP];
-  {
-    float4 pre[NW4];
-    hf.fetch(X, cd, n, d0, h0, w0, c_begin, hpre);
-    wfetch(c_begin, 0, pre);
-    hf.stash(hpre);
-    wstash(Ws, pre);
-  }
-  __syncthreads();
-  const int n_items = (c_end - c_begin) * S;
-  int cc = c_begin, stg = 0;
+    __syncthreads();
 #pragma unroll 1
-  for (int it = 0; it < n_items; ++it) {
-    int ncc = cc, nst = stg + 1;
-    if (nst == S) { nst = 0; ncc = cc + 1; }
-    const bool has_next = it + 1 < n_items;
-    float4 pre[NW4];
-    if (has_next) wfetch(ncc, nst, pre);
-    if (stg == 0 && cc + 1 < c_end) hf.fetch(X, cd, n, d0, h0, w0, cc + 1, hpre);
-    const float* Wb = Ws + (it & 1) * WSTAGE4 * 4;
-#pragma unroll (WT > 9 ? 9 : WT)
-    for (int tl = 0; tl < WT; ++tl) {
-      const int toff = TL::tapoff(stg * WT + tl) * XS;
-      float4 a[MT], b[NT];
+    for (int st = 0; st < S; ++st) {
+      float4 pre[NW4];
+      if (S > 1 && st + 1 < S) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + toff);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wb + ((tl * 4 + lg) * CT + nt * 16 + li) * 4);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
-          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
-          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
-          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
+        for (int u = 0; u < NW4; ++u) {
+          const int q = threadIdx.x + u * 256;
+          if (q < WSTAGE4) {
+            const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
+            const int tap = (st + 1) * WT + tl;
+            pre[u] = ld4(Wp + ((((long long)tap * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
+          }
         }
-    }
-    if (has_next) {
-      wstash(Ws + ((it + 1) & 1) * WSTAGE4 * 4, pre);      // the other buffer: its readers finished before the last barrier
-      if (nst == 0) {                                      // chunk boundary: the single halo buffer is replaced
-        __syncthreads();
-        hf.stash(hpre);
       }
-      __syncthreads();
+      const float* Wb = Ws + (st & (NBUF - 1)) * WSTAGE4 * 4;
+#pragma unroll (WT > 9 ? 9 : WT)
+      for (int tl = 0; tl < WT; ++tl) {
+        const int toff = TL::tapoff(st * WT + tl) * XS;
+        float4 a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + toff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wb + ((tl * 4 + lg) * CT + nt * 16 + li) * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
+          }
+      }
+      if (S > 1) {
+        if (st + 1 < S) {
+          float* Wn = Ws + ((st + 1) & 1) * WSTAGE4 * 4;
+#pragma unroll
+          for (int u = 0; u < NW4; ++u) {
+            const int q = threadIdx.x + u * 256;
+            if (q < WSTAGE4) st4(Wn + q * 4, pre[u]);
+          }
+        }
+        __syncthreads();
+      }
     }
-    cc = ncc;
-    stg = nst;
   }
 
   // epilogue: lane (li, lg) holds rows (voxels) lg*4+r, column (cout) li of each 16x16 tile
@@ -793,21 +785,25 @@ __global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w,
 
 // all conv layers of a network in ONE launch (blockIdx.y = descriptor): 80 five-microsecond pack launches per step otherwise
 struct PackDesc { const float* w; float* wp; int Cout, Cin, T, K16, N16, dgrad; };
+static constexpr int kMaxPackDescs = 512;
 // Work unit = one 16 x 16 (k, n) block of one layer, all taps: the 16 source rows are runs of 16*T contiguous floats
 // (coalesced reads), transposed through LDS, written as 256-B runs.  Units are dealt round-robin to the blocks, so the
 // 256-channel layers (256 units each) no longer serialise on a fixed 64 blocks of scattered 4-byte gathers.
 __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restrict__ descs, int n) {
   __shared__ float tile[16 * 16 * 27];
-  int total = 0;
-  for (int i = 0; i < n; ++i) total += (descs[i].K16 >> 4) * (descs[i].N16 >> 4);
+  __shared__ int ubeg[kMaxPackDescs + 1];           // exclusive prefix sums of the per-layer unit counts
+  // (scanning the descriptor array in global memory per unit cost ~80 dependent scalar loads = 15+ us per unit)
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int i = 0; i < n; ++i) { ubeg[i] = t; t += (descs[i].K16 >> 4) * (descs[i].N16 >> 4); }
+    ubeg[n] = t;
+  }
+  __syncthreads();
+  const int total = ubeg[n];
   for (int unit = blockIdx.x; unit < total; unit += gridDim.x) {
-    int di = 0, u = unit;
-    for (;;) {
-      const int cnt = (descs[di].K16 >> 4) * (descs[di].N16 >> 4);
-      if (u < cnt) break;
-      u -= cnt;
-      ++di;
-    }
+    int lo = 0, hi = n;                             // largest di with ubeg[di] <= unit
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ubeg[mid] <= unit) lo = mid; else hi = mid; }
+    const int di = lo, u = unit - ubeg[lo];
     const PackDesc d = descs[di];
     const int nb = d.N16 >> 4, k0 = (u / nb) * 16, n0 = (u % nb) * 16, T = d.T;
     // source rows: fwd w[nn][kk..][t] (row = nn, inner = kk = cin); dgrad w[kk][nn..][t] (row = kk = cout, inner = nn = cin)
@@ -948,7 +944,7 @@ template <int KD, int TD, int TH, int TW, int NT, int WT>
 static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
                       double* stat_partial, int G, bool dry, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
-  constexpr int NBUF = 2;
+  constexpr int S = TL::T / WT, NBUF = S > 1 ? 2 : 1;
   const size_t lds = (size_t)(TL::HV * XS + NBUF * WT * 4 * NT * 16 * 4) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   auto kfn = k_conv3_mfma<KD, TD, TH, TW, NT, WT>;
@@ -1077,7 +1073,7 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
 
 // descs: device array of n {const float* w; float* wp; int Cout, Cin, T, K16, N16, dgrad} (40 B each, see bcp_hip.h)
 extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
-  BCP_REQUIRE(descs_dev && n > 0, "bcp_conv3_pack_many: bad argument");
+  BCP_REQUIRE(descs_dev && n > 0 && n <= kMaxPackDescs, "bcp_conv3_pack_many: need 1..%d descriptors", kMaxPackDescs);
   static_assert(sizeof(PackDesc) == 40, "descriptor layout is part of the ABI");
   hipLaunchKernelGGL(k_pack_conv3_many, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n);
   BCP_CHECK_LAUNCH("bcp_conv3_pack_many");

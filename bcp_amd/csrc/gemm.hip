@@ -11,6 +11,7 @@
 // TN kernel:  P[k][n] = sum_m A(m, k) * B(m, n)                (weight gradients; M = voxels)
 // Both use v_mfma_f32_16x16x4_f32; lane (i = l&15, g = l>>4).
 #include "common.h"
+#include <cstring>
 #include <cstdlib>
 #include "../../include/bcp_hip.h"
 
@@ -306,6 +307,18 @@ __global__ __launch_bounds__(256) void k_pack_gemm_b(const float* __restrict__ w
   }
 }
 
+struct GemmPackDesc { const float* w; float* bp; int K, N; Idx4 ix; };   // 64 bytes (ABI: bcp_k2_pack_desc fills it)
+__global__ __launch_bounds__(256) void k_pack_gemm_b_many(const GemmPackDesc* __restrict__ descs) {
+  const GemmPackDesc d = descs[blockIdx.y];
+  const long long total = (long long)d.K * d.N;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int k4 = (int)(i & 3);
+    const int n = (int)((i >> 2) % d.N);
+    const int k = (int)(i / (4LL * d.N)) * 4 + k4;
+    d.bp[i] = d.w[(k / d.ix.K2) * d.ix.sk1 + (k % d.ix.K2) * d.ix.sk2 + (n / d.ix.N2) * d.ix.sn1 + (n % d.ix.N2) * d.ix.sn2];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // 16 -> CO (<= 4) pointwise output conv: y[v][co] = b[co] + sum_ci x[v][ci] w[co][ci]
 // ------------------------------------------------------------------------------------------------
@@ -477,11 +490,7 @@ static int launch_tn(RowMap A, RowMap B, float* partial, float* out, int M, int 
 using namespace bcp;
 
 // kind: which GEMM the packed matrix feeds (see include/bcp_hip.h)
-extern "C" int bcp_k2_pack_weight(const float* w, float* bp, int Cin, int Cout, int kind, void* stream) {
-  BCP_REQUIRE(w && bp && Cin > 0 && Cout > 0, "bcp_k2_pack_weight: bad argument");
-  BCP_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "bcp_k2_pack_weight: channels must be multiples of 16");
-  int K, N;
-  Idx4 ix;
+static int k2_pack_geometry(int Cin, int Cout, int kind, int& K, int& N, Idx4& ix) {
   switch (kind) {
     case BCP_PACK_DOWN_FWD:    // w[co][ci][s]: B[k = s*Cin + ci][n = co]
       K = 8 * Cin; N = Cout; ix = {Cin, Cout, 1, 8, 0, (long long)Cin * 8}; break;
@@ -495,12 +504,42 @@ extern "C" int bcp_k2_pack_weight(const float* w, float* bp, int Cin, int Cout, 
       K = Cin; N = Cout; ix = {Cin, Cout, 0, 1, 0, (long long)Cin}; break;
     case BCP_PACK_PW_DGRAD:    // B[k = co][n = ci] = w[co][ci]
       K = Cout; N = Cin; ix = {Cout, Cin, 0, (long long)Cin, 0, 1}; break;
-    default: BCP_REQUIRE(false, "bcp_k2_pack_weight: unknown kind %d", kind);
+    default: return -1;
   }
+  return 0;
+}
+
+// kind: which GEMM the packed matrix feeds (see include/bcp_hip.h)
+extern "C" int bcp_k2_pack_weight(const float* w, float* bp, int Cin, int Cout, int kind, void* stream) {
+  BCP_REQUIRE(w && bp && Cin > 0 && Cout > 0, "bcp_k2_pack_weight: bad argument");
+  BCP_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "bcp_k2_pack_weight: channels must be multiples of 16");
+  int K, N;
+  Idx4 ix;
+  BCP_REQUIRE(k2_pack_geometry(Cin, Cout, kind, K, N, ix) == 0, "bcp_k2_pack_weight: unknown kind %d", kind);
   const long long total = (long long)K * N;
   hipLaunchKernelGGL(k_pack_gemm_b, dim3((int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, bp, K, N, ix);
   BCP_CHECK_LAUNCH("bcp_k2_pack_weight");
+  return BCP_OK;
+}
+
+// All k2 / 1x1 layers of a network in one launch: the host fills one 64-byte descriptor per (layer, kind) with
+// bcp_k2_pack_desc, keeps the array in device memory and calls bcp_k2_pack_many whenever the weights changed.
+extern "C" int bcp_k2_pack_desc(const float* w, float* bp, int Cin, int Cout, int kind, void* desc_out /* 64 bytes, host */) {
+  BCP_REQUIRE(w && bp && desc_out && Cin > 0 && Cout > 0, "bcp_k2_pack_desc: bad argument");
+  BCP_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "bcp_k2_pack_desc: channels must be multiples of 16");
+  static_assert(sizeof(GemmPackDesc) == 64, "descriptor layout is part of the ABI");
+  GemmPackDesc d;
+  d.w = w; d.bp = bp;
+  BCP_REQUIRE(k2_pack_geometry(Cin, Cout, kind, d.K, d.N, d.ix) == 0, "bcp_k2_pack_desc: unknown kind %d", kind);
+  memcpy(desc_out, &d, sizeof(d));
+  return BCP_OK;
+}
+
+extern "C" int bcp_k2_pack_many(const void* descs_dev, int n, void* stream) {
+  BCP_REQUIRE(descs_dev && n > 0, "bcp_k2_pack_many: bad argument");
+  hipLaunchKernelGGL(k_pack_gemm_b_many, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const GemmPackDesc*)descs_dev);
+  BCP_CHECK_LAUNCH("bcp_k2_pack_many");
   return BCP_OK;
 }
 

@@ -253,6 +253,17 @@ class Ops:
         self.b.call("bcp_k2_pack_weight", _p(w), _p(bp), Cin, Cout, kind, self.stream(w))
         return bp
 
+    def k2_pack_desc(self, w, bp, Cin, Cout, kind):
+        """64-byte descriptor (bytes) of one (weight, packed matrix, kind) for k2_pack_many"""
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        self.b.call("bcp_k2_pack_desc", _p(w), _p(bp), Cin, Cout, kind, ctypes.addressof(buf))
+        return buf.raw
+
+    def k2_pack_many(self, descs, n):
+        self._chk(descs)
+        self.b.call("bcp_k2_pack_many", _p(descs), int(n), self.stream(descs))
+
     def down_fwd(self, x, bp, bias, Cout, out=None):
         self._chk(x, bp, bias)
         N, D, H, W, Cin = x.shape

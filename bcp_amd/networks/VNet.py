@@ -129,6 +129,10 @@ class VNet(HipNet):
         for li, L in enumerate(self._layers):
             if L.kind == "c3":
                 self.register_conv3(("c3", li), L.conv.weight, 3)
+            elif L.kind == "dw":
+                self.register_k2(("k2", li), L.conv.weight, L.cin, L.cout, H.PACK_DOWN_FWD, H.PACK_DOWN_DGRAD)
+            elif L.kind == "up":
+                self.register_k2(("k2", li), L.conv.weight, L.cin, L.cout, H.PACK_UP_FWD, H.PACK_UP_DGRAD)
 
     # ------------------------------------------------------------------ public call
     def forward(self, input, turnoff_drop=False, groups=1):
@@ -180,10 +184,10 @@ class VNet(HipNet):
                 wf, _ = self.conv3_packed(("c3", li), save)
                 y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
             elif L.kind == "dw":
-                bp = self._packed(("dwf", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_DOWN_FWD))
+                bp, _ = self.k2_packed(("k2", li), save)
                 y = ops.down_fwd(h, bp, b.data, L.cout)
             else:
-                bp = self._packed(("upf", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_UP_FWD))
+                bp, _ = self.k2_packed(("k2", li), save)
                 y = ops.up_fwd(h, bp, b.data, L.cout)
             res = skips.pop() if L.skip_pop else None
             cs = self._chan_scale(L, N, xcl.device)
@@ -242,11 +246,11 @@ class VNet(HipNet):
                 _, wd = self.conv3_packed(("c3", li), True)
                 dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
             elif L.kind == "dw":
-                bp = self._packed(("dwd", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_DOWN_DGRAD))
+                _, bp = self.k2_packed(("k2", li), True)
                 sg = skip_grads.pop()        # x_in is a skip source: join the decoder-side gradient in place
                 dh = ops.down_dgrad(dy, bp, L.cin, out=sg, accumulate=True)
             else:
-                bp = self._packed(("upd", li), w, lambda w=w, L=L: ops.k2_pack(w.data, L.cin, L.cout, H.PACK_UP_DGRAD))
+                _, bp = self.k2_packed(("k2", li), True)
                 dh = ops.up_dgrad(dy, bp, L.cin)
         self._join_wgrad_stream(dlogits)
         return None

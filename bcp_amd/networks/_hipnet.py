@@ -242,6 +242,48 @@ class HipNet(nn.Module):
             self._pack_state = (ver, need_dgrad or (st is not None and st[0] == ver and st[1]))
         return self._pack_views[key]
 
+    # ---- same for the k2s2 / 1x1 GEMM weights: (fwd kind, dgrad kind) per layer, one launch per weight version
+    def register_k2(self, key, weight, Cin, Cout, kind_fwd, kind_dgrad):
+        if not hasattr(self, "_k2"):
+            self._k2 = []
+        self._k2.append((key, weight, Cin, Cout, kind_fwd, kind_dgrad))
+
+    def _build_k2_tables(self):
+        dev = self._flat.device
+        total = sum(w.numel() for _, w, *_ in self._k2)
+        self._k2_buf = torch.empty(2 * total, dtype=torch.float32, device=dev)
+        self._k2_views = {}
+        fwd_desc, all_desc = b"", b""
+        off = 0
+        for key, w, Cin, Cout, kf, kd in self._k2:
+            n = w.numel()
+            bf, bd = self._k2_buf[off:off + n], self._k2_buf[total + off:total + off + n]
+            self._k2_views[key] = (bf, bd)
+            d_f = self.ops.k2_pack_desc(w.data, bf, Cin, Cout, kf)
+            d_d = self.ops.k2_pack_desc(w.data, bd, Cin, Cout, kd)
+            fwd_desc += d_f
+            all_desc += d_f + d_d
+            off += n
+        self._k2_desc_fwd = torch.frombuffer(bytearray(fwd_desc), dtype=torch.uint8).to(dev)
+        self._k2_desc_all = torch.frombuffer(bytearray(all_desc), dtype=torch.uint8).to(dev)
+        self._k2_state = None
+        self._k2_ptr = self._flat.data_ptr()
+
+    def k2_packed(self, key, need_dgrad):
+        """(B_fwd, B_dgrad) of k2 / 1x1 layer `key`, repacking every such layer in one launch when any weight changed"""
+        if getattr(self, "_k2_ptr", None) != self._flat.data_ptr():
+            self._build_k2_tables()
+        ver = (self._bump, sum(w._version for _, w, *_ in self._k2))
+        st = self._k2_state
+        if st is None or st[0] != ver or (need_dgrad and not st[1]):
+            n = len(self._k2)
+            if need_dgrad:
+                self.ops.k2_pack_many(self._k2_desc_all, 2 * n)
+            else:
+                self.ops.k2_pack_many(self._k2_desc_fwd, n)
+            self._k2_state = (ver, need_dgrad or (st is not None and st[0] == ver and st[1]))
+        return self._k2_views[key]
+
     def _packed(self, key, p, fn):
         ver = (p._version, self._bump, p.data_ptr())
         hit = self._pack_cache.get(key)

@@ -74,6 +74,8 @@ class UNet_2d(HipNet):
                 self.register_conv3((tag, 1), cb.c1.weight, 1)
             self.register_conv3((tag, 2), cb.c2.weight, 1)
         self.register_conv3(("out", 0), self._out.weight, 1)
+        for i, (pw, _, c1, c2) in enumerate(self._up, start=1):
+            self.register_k2(("pw", i), pw.weight, c1, c2, H.PACK_PW_FWD, H.PACK_PW_DGRAD)
         self._prenorm_bias_ids = set(id(m.bias) for cb in self._enc + [u[1] for u in self._up] for m in (cb.c1, cb.c2))
 
     # ------------------------------------------------------------------ public call
@@ -153,7 +155,7 @@ class UNet_2d(HipNet):
             xs.append(self._convblock_fwd(self._enc[i], f"e{i}", pooled, save, saved))
         h = xs[4]
         for i, (pw, cb, c1, c2) in enumerate(self._up, start=1):
-            bp = self._packed((f"pw{i}", 0), pw.weight, lambda pw=pw, c1=c1, c2=c2: ops.k2_pack(pw.weight.data, c1, c2, H.PACK_PW_FWD))
+            bp, _ = self.k2_packed(("pw", i), save)
             z = ops.pw_fwd(h, bp, pw.bias.data, c2)
             skip = xs[4 - i]
             cat = torch.empty((N, 1, skip.shape[2], skip.shape[3], 2 * c2), dtype=torch.float32, device=xcl.device)
@@ -193,7 +195,7 @@ class UNet_2d(HipNet):
             with self._wgrad_stream(dz, h_in):
                 ops.k2_wgrad(h_in, dz, pw.weight.grad, H.WG_PW, accumulate=True)
                 ops.colsum(dz, pw.bias.grad, accumulate=True)
-            bpd = self._packed((f"pw{i}", 1), pw.weight, lambda pw=pw, c1=c1, c2=c2: ops.k2_pack(pw.weight.data, c1, c2, H.PACK_PW_DGRAD))
+            _, bpd = self.k2_packed(("pw", i), True)
             dh = ops.pw_fwd(dz, bpd, None, c1)
         # dh = gradient w.r.t. x4; walk the encoder upwards
         for i in range(4, 0, -1):

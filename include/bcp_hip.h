@@ -121,6 +121,11 @@ int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, int N, int D,
 /* ---- k=2,s=2 conv (networks/VNet.py:74), k=2,s=2 transposed conv (networks/VNet.py:101), 1x1 conv (networks/unet.py:48).
  *      (D,H,W) are always the FINE grid dims.  Packed B matrices via bcp_k2_pack_weight(kind). */
 int bcp_k2_pack_weight(const float* w, float* bp /*K*N floats*/, int Cin, int Cout, int kind, void* stream);
+/* Every k2 / 1x1 layer of a network in ONE launch: bcp_k2_pack_desc fills a 64-byte descriptor (host memory) for
+ * (w, bp, kind); the caller concatenates them, keeps the array in device memory and calls bcp_k2_pack_many(descs, n)
+ * whenever the weights changed (i.e. once per training step). */
+int bcp_k2_pack_desc(const float* w, float* bp, int Cin, int Cout, int kind, void* desc_out /*64 bytes, host*/);
+int bcp_k2_pack_many(const void* descs_dev, int n, void* stream);
 int bcp_down_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 int bcp_down_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 int bcp_up_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, void* stream);

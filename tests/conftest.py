@@ -11,7 +11,22 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cores():
+    """threads this process may really use: scheduler affinity and the cgroup CPU quota, not os.cpu_count() -- the GPU box
+    reports 256 CPUs but owns 16; torch's default thread count then oversubscribes the oracle's CPU convs 16x"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q[0] != "max":
+            n = min(n, max(1, int(float(q[0]) / float(q[1]))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def pytest_configure(config):
+    import torch
+    torch.set_num_threads(_usable_cores())
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
 

@@ -30,7 +30,7 @@ def test_vnet_la_smooth_grads(ops):
 
 
 def test_vnet_pancreas_smooth(ops):
-    NC.check_vnet_smooth(ops, DEV, shape=(16, 16, 16), variant="pancreas")
+    NC.check_vnet_smooth(ops, DEV, shape=(32, 32, 32), variant="pancreas")
 
 
 def test_la_self_train_trajectory(ops, golden_dir):

@@ -12,7 +12,7 @@ from bcp_amd import _lib  # noqa: E402
 from bcp_amd.hip_ops import Ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-shapes = {"16": (16, (112, 112, 80), 1), "32": (32, (56, 56, 40), 2), "64": (64, (28, 28, 20), 2), "128": (128, (14, 14, 10), 2)}
+shapes = {"16": (16, (112, 112, 80), 1), "32": (32, (56, 56, 40), 2), "64": (64, (28, 28, 20), 2), "128": (128, (14, 14, 10), 2), "256": (256, (7, 7, 5), 2)}
 which = sys.argv[1:] or ["16", "32"]
 libs = [("product", _lib.LIB_PATH)] + sorted((os.path.basename(p)[11:-3], p) for p in glob.glob(os.path.join(ROOT, "tools", "_abl", "libbcp_abl_*.so")))
 for wname in which:
