@@ -9,7 +9,7 @@ import torch
 
 import bcp_oracle as O
 
-torch.set_num_threads(max(1, os.cpu_count() or 1))
+# thread count: tests/conftest.py caps torch at the cores this process may really use (cgroup quota / affinity)
 
 
 def _load(golden_dir, name):
