@@ -229,6 +229,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_finalize(const double* __restr
 }
 
 // ------------------------------------------------------------------ apply passes
+// row-reversed position of float4 index p inside a segment (same column): (rows-1-r)*C4 + col
+#define REV(p) (nv - C4 - (p) + 2 * col)
 // a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]      (segments: see k_col_partial)
 __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ mean,
@@ -258,22 +260,24 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
     if (residual) { o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w; }
     st4(out + i * 4, make_float4(o[0], o[1], o[2], o[3]));
   };
+  // Back to front: the statistics pass (or the conv epilogue) that ran just before this kernel swept the tensor front to
+  // back, so its tail is what the 256 MB memory-side cache still holds.  (col stays fixed: nv and stride are multiples of C4.)
   long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   for (; j + (U - 1) * stride < nv; j += U * stride) {
     float4 v[U], r4[U];
     uchar4 m4[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long i = base + j + u * stride;
+      const long long i = base + REV(j + u * stride);
       v[u] = ld4(y + i * 4);
       if (residual) r4[u] = ld4(residual + i * 4);
       if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) one(base + j + u * stride, v[u], r4[u], m4[u]);
+    for (int u = 0; u < U; ++u) one(base + REV(j + u * stride), v[u], r4[u], m4[u]);
   }
   for (; j < nv; j += stride) {
-    const long long i = base + j;
+    const long long i = base + REV(j);
     float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
     uchar4 m4 = make_uchar4(0, 0, 0, 0);
     const float4 v = ld4(y + i * 4);
@@ -336,16 +340,16 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
     uchar4 m4[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long i = base + j + u * stride;
+      const long long i = base + REV(j + u * stride);
       v[u] = ld4(y + i * 4);
       d4[u] = ld4(da + i * 4);
       if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) one(base + j + u * stride, v[u], d4[u], m4[u]);
+    for (int u = 0; u < U; ++u) one(base + REV(j + u * stride), v[u], d4[u], m4[u]);
   }
   for (; j < nv; j += stride) {
-    const long long i = base + j;
+    const long long i = base + REV(j);
     uchar4 m4 = make_uchar4(0, 0, 0, 0);
     const float4 v = ld4(y + i * 4), d4 = ld4(da + i * 4);
     if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
