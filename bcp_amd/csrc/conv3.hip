@@ -429,9 +429,21 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   };
   auto stash = [&](const float4 (&pre)[NP]) { hf.stash(pre); };
 
-  // work items of this block: (tile, chunk), tile = blockIdx.x, blockIdx.x + gridDim.x, ...
-  int tile = blockIdx.x, ch = 0;
-  if (tile >= n_tiles) return;
+  // Work items of this block: (tile, chunk).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with
+  // its own 4 MB L2), so workgroup b runs on XCD b % 8.  Each XCD owns ONE contiguous eighth of the (d-major) tile list and
+  // its workgroups walk it side by side -- the tiles in flight on an XCD are spatial neighbours and their halo overlap
+  // (2.5x over-read per tile) hits that XCD's L2 instead of going back to the fabric.
+  int tile, t_end, t_step;
+  if (gridDim.x % 8 == 0 && !(BCP_ABLATE & 256)) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    t_step = gridDim.x >> 3;
+    tile = (int)((long long)n_tiles * xcd / 8) + j;
+    t_end = (int)((long long)n_tiles * (xcd + 1) / 8);
+  } else {
+    tile = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
+  }
+  int ch = 0;
+  if (tile >= t_end) return;
   double s1[NT], s2[NT];                             // fused norm statistics of the current group
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
@@ -445,8 +457,8 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   for (;;) {
     // next work item
     int ntile = tile, nchk = ch + 1;
-    if (nchk == nch) { nchk = 0; ntile = tile + gridDim.x; }
-    const bool has_next = ntile < n_tiles;
+    if (nchk == nch) { nchk = 0; ntile = tile + t_step; }
+    const bool has_next = ntile < t_end;
     float4 pre[NP];
     if (BCP_ABLATE & 1) {
 #pragma unroll

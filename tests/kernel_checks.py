@@ -464,11 +464,12 @@ def check_k2_chunks(ops, dev):
 def check_conv3_res(ops, dev):
     """resident-weight kernel, with the persistent grid forced small so every block walks several tiles"""
     import os
-    os.environ["BCP_CONV3_P"] = "7"
-    try:
-        check_conv3(ops, dev, cases=CONV3_RES_CASES)
-    finally:
-        del os.environ["BCP_CONV3_P"]
+    for P in ("7", "16"):      # 16: a multiple of 8 takes the XCD-aware tile order
+        os.environ["BCP_CONV3_P"] = P
+        try:
+            check_conv3(ops, dev, cases=CONV3_RES_CASES)
+        finally:
+            del os.environ["BCP_CONV3_P"]
     check_conv3(ops, dev, cases=CONV3_RES_CASES[:2])
 
 
@@ -476,7 +477,7 @@ def check_conv3_stats(ops, dev):
     """fused epilogue statistics: sum over the partial rows == per-group column sums / sums of squares of y"""
     import os
     rng = np.random.default_rng(15)
-    for (N, Cin, Cout, sp, KD, G, P) in ((2, 16, 16, (16, 16, 48), 3, 2, "5"), (4, 32, 32, (8, 12, 20), 3, 2, "3"), (2, 16, 32, (1, 40, 48), 1, 2, None),
+    for (N, Cin, Cout, sp, KD, G, P) in ((2, 16, 16, (16, 16, 48), 3, 2, "5"), (2, 16, 16, (16, 16, 48), 3, 2, "8"), (4, 32, 32, (8, 12, 20), 3, 2, "3"), (4, 32, 32, (8, 12, 20), 3, 2, "16"), (2, 16, 32, (1, 40, 48), 1, 2, None),
                                           (2, 64, 64, (5, 6, 7), 3, 1, None), (2, 16, 16, (6, 5, 9), 3, 2, None)):
         two_d = KD == 1
         x = R(rng, N, Cin, *(sp[1:] if two_d else sp))
