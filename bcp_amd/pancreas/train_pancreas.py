@@ -25,10 +25,17 @@ connect_mode = 2
 patch_size = 64
 
 
+class _Streams(list):
+    """the four loader streams (lab_a, lab_b, unlab_a, unlab_b) as views of ONE resident batch (.vols / .labs), so the
+    grouped step can hand the teacher / student their two sub-batches without a concatenation"""
+
+
 def _streams(device, n=4, bs=2, seed=seed_test):
     vols, labs = synth.la_batch(n * bs, shape=(96, 96, 96), seed=seed)
     vols, labs = vols.to(device), labs.to(device)
-    return [(vols[i * bs:(i + 1) * bs], labs[i * bs:(i + 1) * bs]) for i in range(n)]
+    st = _Streams((vols[i * bs:(i + 1) * bs], labs[i * bs:(i + 1) * bs]) for i in range(n))
+    st.vols, st.labs, st.bs = vols, labs, bs
+    return st
 
 
 def pretrain(net1, optimizer, streams, steps):
@@ -46,9 +53,19 @@ def pretrain(net1, optimizer, streams, steps):
     return loss
 
 
-def ema_cutmix(net, ema_net, optimizer, streams, steps, dp=None):
+def ema_cutmix(net, ema_net, optimizer, streams, steps, dp=None, grouped=None):
+    """train_pancreas.py:103-179.  grouped (default: whenever the streams are views of one batch): the two teacher calls
+    and the two student calls of an iteration are launched as one grouped forward each (train_step.la_self_train_step,
+    variant 'pancreas') -- InstanceNorm statistics are per sample, so this is the same arithmetic in half the launches."""
     net.train()
     ema_net.train()
+    if grouped is None:
+        grouped = isinstance(streams, _Streams) and len(streams) == 4
+    if grouped:
+        for step in range(steps):
+            r = train_step.la_self_train_step(net, ema_net, optimizer, streams.vols, streams.labs, 2 * streams.bs, variant="pancreas",
+                                              connect_mode=connect_mode, alpha=alpha, dp=dp)
+        return r["loss"]
     for step in range(steps):
         (img_a, lab_a), (img_b, lab_b), (unimg_a, _), (unimg_b, _) = streams
         with torch.no_grad():

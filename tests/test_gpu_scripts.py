@@ -26,3 +26,29 @@ def test_acdc_script(tmp_path, monkeypatch):
 def test_pancreas_script():
     from bcp_amd.pancreas import train_pancreas as T
     T.main(["--pretraining_epochs", "1", "--self_training_epochs", "1", "--steps_per_epoch", "2", "--batch_size", "1"])
+
+
+def test_pancreas_grouped_step_matches_two_calls():
+    """ema_cutmix with the teacher / student sub-batches launched as one grouped forward each == the script's four
+    separate network calls (InstanceNorm statistics are per sample); only the order in which the two students' weight
+    gradients are added differs, so parameters agree to fp32 rounding after a step"""
+    import numpy as np
+    from bcp_amd import train_step
+    from bcp_amd.pancreas import train_pancreas as T
+    from bcp_amd.pancreas.Vnet import create_Vnet
+    dev = torch.device("cuda", 0)
+    res = []
+    for grouped in (True, False):
+        np.random.seed(7)
+        torch.manual_seed(7)
+        net, ema = create_Vnet(), create_Vnet(ema=True)
+        ema.load_state_dict(net.state_dict())
+        opt = train_step.FlatAdam(net, lr=1e-3)
+        streams = T._streams(dev, 4, 1, seed=11)
+        loss = T.ema_cutmix(net, ema, opt, streams, 1, grouped=grouped)
+        res.append((float(loss), net.flat_params().clone(), ema.flat_params().clone()))
+    (l0, p0, e0), (l1, p1, e1) = res
+    assert abs(l0 - l1) < 1e-5, (l0, l1)
+    # Adam's first step moves every weight by ~lr * sign(g): compare the updates, not the weights
+    assert float((p0 - p1).abs().max()) < 2e-3 and float((p0 - p1).abs().mean()) < 2e-5
+    assert float((e0 - e1).abs().max()) < 1e-4
