@@ -839,17 +839,20 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
-// first layer: Cin = 1 -> Cout = 16 (HBM-bound: 4 B in, 64 B out per voxel).  Direct VALU kernel:
-// the single-channel halo sits in LDS, each thread owns one voxel and 16 accumulators.
+// first layer: Cin = 1 -> Cout = 16 (HBM-bound: 4 B in, 64 B out per voxel).  Still a matrix product -- voxels x taps
+// times taps x 16 channels -- so it runs on the matrix cores as well: A[vox][tap] is read straight out of the
+// single-channel LDS halo at shifted offsets, B[tap][co] sits in registers, K = T taps padded to a multiple of 4 with
+// zero weights.  (The first version did 432 VALU FMAs per voxel with one LDS broadcast read per FMA: 5x off the HBM
+// roofline.)
 // ------------------------------------------------------------------------------------------------
 template <int KD, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, const float* __restrict__ w /*[16][1][T]*/,
                                                   const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd) {
   using TL = Tile<KD, TD, TH, TW>;
-  static_assert(TL::M == 256, "one voxel per thread");
-  constexpr int T = TL::T;
+  constexpr int T = TL::T, MT = TL::MT, KS = (T + 3) / 4;
   __shared__ __attribute__((aligned(16))) float Xs[TL::HV];
-  __shared__ __attribute__((aligned(16))) float Ws[T * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
   int n, d0, h0, w0;
   tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
   for (int q = threadIdx.x; q < TL::HV; q += 256) {
@@ -860,84 +863,140 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
       v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
     Xs[q] = v;
   }
-  for (int q = threadIdx.x; q < T * 16; q += 256) Ws[q] = w[(q & 15) * T + (q >> 4)];  // -> [tap][co]
-  __syncthreads();
-  const int m = threadIdx.x;
-  const int base = TL::voff(m);
-  float acc[16];
+  // lane (li, lg): B[k = lg][co = li] of k-step ks is the weight of tap 4*ks + lg
+  float wv[KS];
+  int toff[KS];
 #pragma unroll
-  for (int c = 0; c < 16; ++c) acc[c] = bias ? bias[c] : 0.f;
-#pragma unroll
-  for (int tap = 0; tap < T; ++tap) {
-    const float x = Xs[base + TL::tapoff(tap)];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = fmaf(x, Ws[tap * 16 + c], acc[c]);
+  for (int ks = 0; ks < KS; ++ks) {
+    const int tap = ks * 4 + lg;
+    wv[ks] = tap < T ? w[li * T + tap] : 0.f;
+    toff[ks] = tap < T ? TL::tapoff(tap) : 0;
   }
-  const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-  const int d = d0 + td, h = h0 + th, wq = w0 + tw;
-  if (d < cd.D && h < cd.H && wq < cd.W) {
-    float* y = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16;
+  const float bv = bias ? bias[li] : 0.f;
+  __syncthreads();
+  const bool full = (TW % 4 == 0) && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
 #pragma unroll
-    for (int c = 0; c < 16; c += 4) st4(y + c, make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]));
+  for (int mt = 0; mt < MT; ++mt) {
+    const int vo = TL::voff((wave * MT + mt) * 16 + li);   // A[vox = li][k = lg]
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[vo + toff[ks]], wv[ks], acc, 0, 0, 0);
+    // D[vox = lg*4 + r][co = li]
+    const int m0 = (wave * MT + mt) * 16 + lg * 4;
+    if (full) {
+      const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
+      float* p = Y + ((((long long)n * cd.D + d0 + td) * cd.H + h0 + th) * cd.W + w0 + tw) * 16 + li;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) p[r * 16] = acc[r] + bv;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + r;
+        const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+        const int d = d0 + td, h = h0 + th, wq = w0 + tw;
+        if (d < cd.D && h < cd.H && wq < cd.W) Y[((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16 + li] = acc[r] + bv;
+      }
+    }
   }
 }
 
-// wgrad of the Cin = 1 layer: dW[co][0][tap] = sum_v x[v+off] * dY[v][co].  Thread q < T*16 owns output
-// (tap, co) and walks the tile's voxels out of LDS; blocks loop over a tile group, partials reduced by
-// k_wgrad_reduce (Cin16 = 1 there).
+// wgrad of the Cin = 1 layer: dW[co][0][tap] = sum_v x[v + off(tap)] * dY[v][co] -- a (taps x voxels) x (voxels x 16)
+// product: M = taps (two 16-row MFMA tiles, rows >= T unused), N = 16 channels, K = voxels.  The four waves split the
+// voxels of a tile; a block walks a group of tiles with the next tile's x halo and dY rows prefetched into registers,
+// sums its four wave accumulators through LDS at the end and writes one partial [T][16] slab (reduced deterministically
+// by k_wgrad_reduce(_deep), Cin16 = 1 there).  This layer's weight gradient is the LAST kernel of the backward pass --
+// nothing is left to overlap it with, so its 0.2 ms (VALU version) sat on the step's critical path.
 template <int KD, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void k_conv3_c1_wgrad(const float* __restrict__ X, const float* __restrict__ dY,
                                                         float* __restrict__ partial, ConvDims cd, int tiles_total,
                                                         int tiles_per_group) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int T = TL::T, M = TL::M;
-  constexpr int NO = (T * 16 + 255) / 256;  // outputs per thread
+  static_assert(M == 256 && T <= 32, "four waves x 64 voxels, two 16-tap MFMA row tiles");
+  constexpr int NXS = (TL::HV + 255) / 256;            // halo floats per thread
   __shared__ __attribute__((aligned(16))) float Xs[TL::HV];
   __shared__ __attribute__((aligned(16))) float Ys[M * 16];
-  float acc[NO];
-  int otap[NO], oco[NO];
-#pragma unroll
-  for (int u = 0; u < NO; ++u) {
-    acc[u] = 0.f;
-    const int o = threadIdx.x + u * 256;
-    otap[u] = (o < T * 16) ? TL::tapoff(o >> 4) : 0;
-    oco[u] = o & 15;
-  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
   const int grp = blockIdx.x;
   int t_end = (grp + 1) * tiles_per_group;
   if (t_end > tiles_total) t_end = tiles_total;
-  for (int tile = grp * tiles_per_group; tile < t_end; ++tile) {
+  int tile = grp * tiles_per_group;
+  if (tile >= t_end) return;
+
+  int aoff[2];                                         // lane's tap offset for the two row tiles (tap = tt*16 + li)
+#pragma unroll
+  for (int tt = 0; tt < 2; ++tt) aoff[tt] = (tt * 16 + li < T) ? TL::tapoff(tt * 16 + li) : 0;
+  f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+
+  float px[NXS];
+  float4 py[4];
+  auto fetch = [&](int tl) {
     int n, d0, h0, w0;
-    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
-    __syncthreads();
-    for (int q = threadIdx.x; q < TL::HV; q += 256) {
-      const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
-      const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
+    tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
+#pragma unroll
+    for (int u = 0; u < NXS; ++u) {
+      const int q = threadIdx.x + u * 256;
       float v = 0.f;
-      if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
-        v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
-      Xs[q] = v;
+      if (q < TL::HV) {
+        const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
+        const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
+        if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
+          v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
+      }
+      px[u] = v;
     }
-    for (int q = threadIdx.x; q < M * 4; q += 256) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = threadIdx.x + u * 256;            // M * 4 float4s
       const int m = q >> 2, c4 = q & 3;
       const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
       const int d = d0 + td, h = h0 + th, wq = w0 + tw;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (d < cd.D && h < cd.H && wq < cd.W) v = ld4(dY + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16 + c4 * 4);
-      st4(Ys + m * 16 + c4 * 4, v);
+      py[u] = v;
     }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int u = 0; u < NXS; ++u) {
+      const int q = threadIdx.x + u * 256;
+      if (q < TL::HV) Xs[q] = px[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) st4(Ys + (threadIdx.x + u * 256) * 4, py[u]);
+  };
+
+  fetch(tile);
+  stash();
+  __syncthreads();
+  for (;;) {
+    const bool has_next = tile + 1 < t_end;
+    if (has_next) fetch(tile + 1);
+#pragma unroll 4
+    for (int ks = 0; ks < 16; ++ks) {                  // this wave's 64 voxels, 4 per k-step
+      const int v = wave * 64 + ks * 4 + lg;           // A[tap = li][k = lg], B[k = lg][co = li]
+      const int vo = TL::voff(v);
+      const float b = Ys[v * 16 + li];
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[vo + aoff[0]], b, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[vo + aoff[1]], b, acc[1], 0, 0, 0);
+    }
+    if (!has_next) break;
     __syncthreads();
-    for (int m = 0; m < M; ++m) {
-      const int vx = TL::voff(m);
-#pragma unroll
-      for (int u = 0; u < NO; ++u) acc[u] = fmaf(Xs[vx + otap[u]], Ys[m * 16 + oco[u]], acc[u]);
-    }
+    stash();
+    __syncthreads();
+    ++tile;
   }
+  // D[tap = tt*16 + lg*4 + r][co = li]: sum the four waves, write partial[grp][tap][ci = 0][co]
+  __syncthreads();
+  float* red = Ys;                                     // [4 waves][32 taps][16]
 #pragma unroll
-  for (int u = 0; u < NO; ++u) {
-    const int o = threadIdx.x + u * 256;
-    if (o < T * 16) partial[(long long)grp * T * 16 + o] = acc[u];  // [grp][tap][ci=0][co]
-  }
+  for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wave * 32 + tt * 16 + lg * 4 + r) * 16 + li] = acc[tt][r];
+  __syncthreads();
+  for (int o = threadIdx.x; o < T * 16; o += 256)
+    partial[(long long)grp * T * 16 + o] = (red[o] + red[512 + o]) + (red[1024 + o] + red[1536 + o]);
 }
 
 // ------------------------------------------------------------------------------------------------
