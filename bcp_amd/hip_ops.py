@@ -21,7 +21,9 @@ CAST_I64_U8, CAST_F32_U8, CAST_U8_F32, CAST_U8_I64 = range(4)
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    # plain int: the bound functions declare c_void_p argtypes, ctypes converts (an explicit c_void_p object per pointer
+    # was 10 % of the host time of a step)
+    return None if t is None else t.data_ptr()
 
 
 class Ops:
@@ -56,7 +58,7 @@ class Ops:
 
     def stream(self, t):
         if t.is_cuda:
-            return C.c_void_p(torch._C._cuda_getCurrentRawStream(t.device.index))
+            return torch._C._cuda_getCurrentRawStream(t.device.index)
         return None
 
     def _ws_bytes(self, fn, *args):

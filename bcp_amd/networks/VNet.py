@@ -143,6 +143,7 @@ class VNet(HipNet):
         N = x.shape[0]
         assert x.dim() == 5 and x.shape[1] == 1, "expected [N,1,X,Y,Z]"
         self._ensure_flat()
+        self.refresh_weights_version()
         xcl = x.contiguous().view(N, x.shape[2], x.shape[3], x.shape[4], 1)
         self._turnoff_drop = bool(turnoff_drop)
         assert N % groups == 0

@@ -84,7 +84,14 @@ class HipNet(nn.Module):
         return self
 
     def _ordered_params(self):
-        return list(self.parameters())
+        # the module tree is fixed after construction: walk it once (nn.Module.parameters() re-walks every submodule and
+        # hashes every tensor -- 36 % of the host time of a training step when called 7x per step)
+        ps = self.__dict__.get("_plist")
+        if ps is None:
+            ps = list(self.parameters())
+            object.__setattr__(self, "_plist", ps)
+            object.__setattr__(self, "_first_fbuf", next((b for b in self.buffers() if b.is_floating_point()), None))
+        return ps
 
     def flatten_(self):
         """(re)locate every parameter AND every float buffer (BN running stats) inside one contiguous fp32 buffer:
@@ -107,6 +114,9 @@ class HipNet(nn.Module):
         self._offs = {id(t): o for t, o in zip(items, offs)}
         self._n_param_flat = offs[len(ps)] if bufs else off
         self._flat_grad = torch.zeros(self._n_param_flat, dtype=torch.float32, device=dev)
+        self._grad_views = {id(p): self._flat_grad[o:o + p.numel()].view(p.shape) for p, o in zip(ps, offs)}
+        self._opt_plist = [p for p in ps if id(p) in self._opt_param_ids]
+        self._grads_stale = True
         n_train = 0
         for p, o in zip(ps, offs):
             if id(p) in self._opt_param_ids:
@@ -124,11 +134,9 @@ class HipNet(nn.Module):
             if last.data_ptr() != self._flat.data_ptr() + 4 * self._offs[id(last)]:
                 self.flatten_()
             else:
-                for b in self.buffers():
-                    if b.is_floating_point():
-                        if b.data_ptr() != self._flat.data_ptr() + 4 * self._offs.get(id(b), -1):
-                            self.flatten_()
-                        break
+                b = self._first_fbuf
+                if b is not None and b.data_ptr() != self._flat.data_ptr() + 4 * self._offs.get(id(b), -1):
+                    self.flatten_()
 
     def flat_params(self):
         """all parameters (optimiser part + unused heads): what `for p in model.parameters()` walks"""
@@ -151,8 +159,7 @@ class HipNet(nn.Module):
         return self._flat[:n], self._flat_grad[:n]
 
     def grad_view(self, p):
-        o = self._offs[id(p)]
-        return self._flat_grad[o:o + p.numel()].view(p.shape)
+        return self._grad_views[id(p)]
 
     def attach_grad(self, p):
         """-> (grad tensor, accumulate?)  first touch after zero_grad() re-attaches the flat view"""
@@ -163,16 +170,24 @@ class HipNet(nn.Module):
 
     def bump(self):
         self._bump += 1
+        object.__setattr__(self, "_wver", None)
 
     def begin_backward(self):
         """first backward after zero_grad(): clear the flat gradient buffer with ONE memset and re-attach every
         optimiser parameter's .grad view; from then on all kernels accumulate (+=)."""
         self._ensure_flat()
-        ps = [p for p in self._ordered_params() if id(p) in self._opt_param_ids]
+        ps = self._opt_plist
         if ps[0].grad is None or ps[0].grad.data_ptr() != self.grad_view(ps[0]).data_ptr():
-            self._flat_grad.zero_()
+            self._flat_grad.zero_()        # a foreign optimiser set the grads to None: re-attach the flat views
             for p in ps:
                 p.grad = self.grad_view(p)
+        elif self._grads_stale:
+            self._flat_grad.zero_()        # FlatSGD / FlatAdam.zero_grad(): the views stay attached, one memset clears them
+        self._grads_stale = False
+
+    def mark_grads_stale(self):
+        """zero_grad() of the flat optimisers: O(1) on the host -- the next backward clears the flat buffer with one memset"""
+        self._grads_stale = True
 
     # num_batches_tracked: every live BN layer is bumped once per training forward, so ONE host-side integer
     # stands for all of them and is written to the buffers only when a state_dict is taken (29 tiny device ops
@@ -227,11 +242,29 @@ class HipNet(nn.Module):
         self._pack_state = None
         self._pack_ptr = self._flat.data_ptr()
 
+    def _weights_version(self):
+        """(bump counter, sum of tensor versions of every packed weight): recomputed once per network call
+        (refresh_weights_version(), called by forward()), not once per layer"""
+        v = self.__dict__.get("_wver")
+        if v is None:
+            v = self.refresh_weights_version()
+        return v
+
+    def refresh_weights_version(self):
+        tot = 0
+        for _, w, _ in getattr(self, "_c3", ()):
+            tot += w._version
+        for _, w, *_ in getattr(self, "_k2", ()):
+            tot += w._version
+        v = (self._bump, tot)
+        object.__setattr__(self, "_wver", v)
+        return v
+
     def conv3_packed(self, key, need_dgrad):
         """(wp_fwd, wp_dgrad) of layer `key`, repacking EVERY layer in one launch when any weight changed"""
         if getattr(self, "_pack_ptr", None) != self._flat.data_ptr():
             self._build_pack_tables()
-        ver = (self._bump, sum(w._version for _, w, _ in self._c3))
+        ver = self._weights_version()
         st = self._pack_state
         if st is None or st[0] != ver or (need_dgrad and not st[1]):
             n = len(self._c3)
@@ -273,7 +306,7 @@ class HipNet(nn.Module):
         """(B_fwd, B_dgrad) of k2 / 1x1 layer `key`, repacking every such layer in one launch when any weight changed"""
         if getattr(self, "_k2_ptr", None) != self._flat.data_ptr():
             self._build_k2_tables()
-        ver = (self._bump, sum(w._version for _, w, *_ in self._k2))
+        ver = self._weights_version()
         st = self._k2_state
         if st is None or st[0] != ver or (need_dgrad and not st[1]):
             n = len(self._k2)
@@ -294,7 +327,7 @@ class HipNet(nn.Module):
 
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
-        self._bump += 1
+        self.bump()
         for m in self.modules():
             if isinstance(m, BNP) and getattr(m, "_live", False):
                 self._nbt = int(m.num_batches_tracked)

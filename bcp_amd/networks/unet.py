@@ -86,6 +86,7 @@ class UNet_2d(HipNet):
         self._groups = int(groups)
         assert x.dim() == 4 and x.shape[1] == 1, "expected [N,1,H,W]"
         self._ensure_flat()
+        self.refresh_weights_version()
         xcl = x.contiguous().view(N, 1, x.shape[2], x.shape[3], 1)
         anchor = self._enc[0].c1.weight
         if torch.is_grad_enabled() and anchor.requires_grad:

@@ -65,8 +65,9 @@ class FlatSGD:
         self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=True):
-        for p in self.model.parameters():
-            p.grad = None
+        # the reference drops / zeroes 150 gradient tensors here; ours all live in one flat buffer that the next backward
+        # clears with a single memset (HipNet.begin_backward) -- nothing to do per parameter
+        self.model.mark_grads_stale()
 
     def step(self):
         g = self.param_groups[0]
@@ -95,8 +96,9 @@ class FlatAdam:
         self.grad_scale = 1.0
 
     def zero_grad(self, set_to_none=True):
-        for p in self.model.parameters():
-            p.grad = None
+        # the reference drops / zeroes 150 gradient tensors here; ours all live in one flat buffer that the next backward
+        # clears with a single memset (HipNet.begin_backward) -- nothing to do per parameter
+        self.model.mark_grads_stale()
 
     def step(self):
         g = self.param_groups[0]
