@@ -26,10 +26,13 @@
 namespace bcp {
 
 static constexpr int XS = 20;  // LDS floats per halo voxel: 16 channels + 4 pad (16-B aligned rows)
+// halo row stride of the wgrad kernel (ds_read_b32, lane (li = channel, lg = voxel))
+static constexpr int XSW = 20;   // measured: 16 (conflict-free b32 reads) is 6 % SLOWER at C=16 -- LDS conflicts are not what bounds wgrad
 
 // Measurement-only ablation switches for tools/ablate_conv.py (what bounds k_conv3_res?); the product build has 0.
 //   1: no global halo prefetch   2: no epilogue stores / statistics   4: no LDS halo refill + barriers
-//   8: A fragments not re-read from LDS per tap   16: B fragments not re-read per tap
+//   8: A fragments not re-read from LDS per tap   16: B fragments not re-read per tap   256: linear (not XCD-aware) tile order
+//   wgrad: 512: no global fetch   1024: no LDS refill + barriers   2048 / 4096: A / B operand address not advanced
 #ifndef BCP_ABLATE
 #define BCP_ABLATE 0
 #endif
@@ -76,7 +79,7 @@ __device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, 
 // tile origin is computed once: the per-pass global offsets grel[] and the LDS slot; per tile there is one uniform
 // 64-bit row-validity mask (SALU).  Per-tile vector work of a fetch: ~2 VALU per float4 (was ~25: div/mod of the flat
 // index + three range checks + 64-bit address arithmetic per element).
-template <class TL>
+template <class TL, int XSP = XS>
 struct HaloFetch {
   static constexpr int RW = TL::HW * 4, RPP = 256 / RW, HR = TL::HD * TL::HH, NP = (HR + RPP - 1) / RPP;
   static_assert(HR <= 128 && RW <= 256, "halo rows must fit the 128-bit validity mask");
@@ -96,7 +99,7 @@ struct HaloFetch {
       const int row = u * RPP + r0, hd = row / TL::HH, hh = row - hd * TL::HH;
       grel[u] = (unsigned)(((hd * cd.H + hh) * cd.W + hw) * cd.Cin + part * 4);
     }
-    lds = Xs + (r0 * TL::HW + hw) * XS + part * 4;
+    lds = Xs + (r0 * TL::HW + hw) * XSP + part * 4;
   }
   // halo of the tile at (n, d0, h0, w0), cin chunk c -> registers; zero outside the volume / beyond Cin
   __device__ __forceinline__ void fetch(const float* __restrict__ X, const ConvDims& cd, int n, int d0, int h0, int w0, int c,
@@ -134,7 +137,7 @@ struct HaloFetch {
   __device__ __forceinline__ void stash(const float4 (&pre)[NP]) const {
 #pragma unroll
     for (int u = 0; u < NP; ++u)
-      if (act && u * RPP + r0 < HR) st4(lds + u * RPP * TL::HW * XS, pre[u]);
+      if (act && u * RPP + r0 < HR) st4(lds + u * RPP * TL::HW * XSP, pre[u]);
   }
 };
 
@@ -593,8 +596,8 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
 
   HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
   float* smem = reinterpret_cast<float*>(smem4);
-  float* Xs = smem;                 // [HV][XS]
-  float* Ys = smem + TL::HV * XS;   // [M][YS]
+  float* Xs = smem;                 // [HV][XSW]
+  float* Ys = smem + TL::HV * XSW;  // [M][YS]
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
     const int tap = wave + 4 * t;
-    xoff[t] = ((tap < T ? TL::tapoff(tap) : 0) + lg) * XS + li;
+    xoff[t] = ((tap < T ? TL::tapoff(tap) : 0) + lg) * XSW + li;
   }
   const int yoff = lg * YS + li;
 
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   int tile = grp * tiles_per_group;
   if (tile >= t_end) return;
 
-  using HF = HaloFetch<TL>;
+  using HF = HaloFetch<TL, XSW>;
   HF hf;
   hf.init(cd, Xs);
   // dY tile: float4 q of the [M][CT] tile, launch-invariant offsets for tiles that lie wholly inside the volume
@@ -679,31 +682,33 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   __syncthreads();
   for (;;) {
     const bool has_next = tile + 1 < t_end;
-    if (has_next) fetch(tile + 1);           // loads stay in flight under the MFMAs below
+    if (has_next && !(BCP_ABLATE & 512)) fetch(tile + 1);           // loads stay in flight under the MFMAs below
 #pragma unroll 1
     for (int row = 0; row < M / TW; ++row) {
       const int th = row % TH, td = row / TH;
-      const int xrow = ((td * TL::HH + th) * TL::HW) * XS;   // wave-uniform
+      const int xrow = ((td * TL::HH + th) * TL::HW) * XSW;   // wave-uniform
 #pragma unroll
       for (int kw = 0; kw < TW / 4; ++kw) {
         const int m0 = row * TW + kw * 4;
         float b[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[m0 * YS + yoff + nt * 16];
+        for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[((BCP_ABLATE & 4096) ? 0 : m0 * YS) + yoff + nt * 16];
         // no per-tap guard here: a wave whose last tap slot is past T (27 = 4*7 - 1) recomputes tap 0 into an accumulator
         // that is never stored -- 1/28 wasted MFMAs instead of predicated MFMAs and accumulator shuffles
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-          const float a = Xs[xrow + kw * 4 * XS + xoff[t]];
+          const float a = Xs[((BCP_ABLATE & 2048) ? 0 : xrow + kw * 4 * XSW) + xoff[t]];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[t][nt], 0, 0, 0);
         }
       }
     }
     if (!has_next) break;
-    __syncthreads();
-    stash();
-    __syncthreads();
+    if (!(BCP_ABLATE & 1024)) {
+      __syncthreads();
+      stash();
+      __syncthreads();
+    }
     ++tile;
   }
   // partial[grp][tap][ci][co]: lane (li, lg) holds ci = lg*4 + r (rows), co = li (cols)
@@ -749,26 +754,48 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
 }
 
 // Many-group variant (shallow layers: one cin chunk x one slab => hundreds of spatial groups): one block per
-// (ci, 64-wide co slab, tap); 256 threads = 64 co x 4 group-slots, LDS sum over the slots.  Same fixed summation order
-// every run (deterministic).
+// (ci, CW-wide co slab, tap); 256 threads = CW co x (256 / CW) group-slots, 4 independent loads in flight per thread,
+// LDS sum over the slots in a fixed order (deterministic).  CW = 16 for the 16-channel layers: with a fixed 64-wide
+// slab three quarters of the block idled and each thread walked 128 slabs one load at a time (31 us per reduce,
+// ~18 % of the 16->16 weight gradient).
+template <int CW>
 __global__ __launch_bounds__(256) void k_wgrad_reduce_deep(const float* __restrict__ partial, float* __restrict__ dW, int G, int T,
                                                            int Cin, int Cout, int Cin16, int Cout16, int accumulate) {
-  __shared__ float red[4][64];
-  const int ci = blockIdx.x, co0 = blockIdx.y * 64, tap = blockIdx.z;
-  const int col = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  constexpr int SL = 256 / CW;
+  __shared__ float red[SL][CW];
+  const int ci = blockIdx.x, co0 = blockIdx.y * CW, tap = blockIdx.z;
+  const int col = threadIdx.x % CW, slot = threadIdx.x / CW;
   const long long slab = (long long)T * Cin16 * Cout16;
-  float s = 0.f;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (co0 + col < Cout) {
     const float* p = partial + ((long long)tap * Cin16 + ci) * Cout16 + co0 + col;
-    for (int g = slot; g < G; g += 4) s += p[g * slab];
+    int g = slot;
+    for (; g + 3 * SL < G; g += 4 * SL) {
+      const float a = p[(long long)g * slab], b = p[(long long)(g + SL) * slab];
+      const float c = p[(long long)(g + 2 * SL) * slab], d = p[(long long)(g + 3 * SL) * slab];
+      s0 += a; s1 += b; s2 += c; s3 += d;
+    }
+    for (; g < G; g += SL) s0 += p[(long long)g * slab];
   }
-  red[slot][col] = s;
+  red[slot][col] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (slot == 0 && co0 + col < Cout) {
-    const float v = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < SL; ++k) v += red[k][col];
     float* o = dW + ((long long)(co0 + col) * Cin + ci) * T + tap;
     *o = accumulate ? (*o + v) : v;
   }
+}
+
+static void launch_reduce_deep(const float* ws, float* dw, int G, int T, int Cin, int Cout, int Cin16, int Cout16, int accumulate,
+                               hipStream_t s) {
+  if (Cout <= 16)
+    hipLaunchKernelGGL((k_wgrad_reduce_deep<16>), dim3(Cin, cdiv(Cout, 16), T), dim3(256), 0, s, ws, dw, G, T, Cin, Cout, Cin16, Cout16, accumulate);
+  else if (Cout <= 32)
+    hipLaunchKernelGGL((k_wgrad_reduce_deep<32>), dim3(Cin, cdiv(Cout, 32), T), dim3(256), 0, s, ws, dw, G, T, Cin, Cout, Cin16, Cout16, accumulate);
+  else
+    hipLaunchKernelGGL((k_wgrad_reduce_deep<64>), dim3(Cin, cdiv(Cout, 64), T), dim3(256), 0, s, ws, dw, G, T, Cin, Cout, Cin16, Cout16, accumulate);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1068,7 +1095,7 @@ template <int KD, int TD, int TH, int TW, int NT>
 static int launch_wgrad(const float* X, const float* dY, float* partial, ConvDims cd, int groups, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int CT = NT * 16, YS = (CT % 32 == 0) ? CT + 16 : CT;
-  const size_t lds = (size_t)(TL::HV * XS + TL::M * YS) * sizeof(float);
+  const size_t lds = (size_t)(TL::HV * XSW + TL::M * YS) * sizeof(float);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
   const int tpg = cdiv(tiles, groups);
@@ -1321,8 +1348,7 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   BCP_REQUIRE(done, "bcp_conv3_wgrad: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
   const int T = KD * 9;
   if (G >= 32)
-    hipLaunchKernelGGL(k_wgrad_reduce_deep, dim3(Cin, cdiv(Cout, 64), T), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout,
-                       cd.Cin16, cd.Cout16, accumulate);
+    launch_reduce_deep(ws, dw, G, T, Cin, Cout, cd.Cin16, cd.Cout16, accumulate, (hipStream_t)stream);
   else
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(Cin, cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout, cd.Cin16,
                        cd.Cout16, accumulate);
@@ -1373,7 +1399,7 @@ extern "C" int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, in
   }
   const int T = KD * 9;
   if (G >= 32)
-    hipLaunchKernelGGL(k_wgrad_reduce_deep, dim3(1, 1, T), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16, accumulate);
+    launch_reduce_deep(ws, dw, G, T, 1, 16, 1, 16, accumulate, (hipStream_t)stream);
   else
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(1, 1), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16, accumulate);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_wgrad");

@@ -33,4 +33,13 @@ for wname in which:
             ops.conv3_fwd(x, wf, b, C, 3, out=y)
         ops.event_record(e1, x)
         ms = ops.event_elapsed_ms(e0, e1) / 20
-        print(f"C={C:3d} N={N} abl={name:8s} {ms * 1e3:8.1f} us  {flops / ms / 1e9:7.1f} TF/s", flush=True)
+        dy = torch.randn(N, *sp, C, device=dev)
+        dw = torch.empty_like(w)
+        for _ in range(3):
+            ops.conv3_wgrad(x, dy, dw, 3)
+        ops.event_record(e0, x)
+        for _ in range(20):
+            ops.conv3_wgrad(x, dy, dw, 3)
+        ops.event_record(e1, x)
+        msw = ops.event_elapsed_ms(e0, e1) / 20
+        print(f"C={C:3d} N={N} abl={name:8s} fwd {ms * 1e3:8.1f} us {flops / ms / 1e9:7.1f} TF/s | wgrad {msw * 1e3:8.1f} us {flops / msw / 1e9:7.1f} TF/s", flush=True)
