@@ -18,7 +18,7 @@ from bcp_amd import train_step
 from bcp_amd.dataloaders.dataset import SyntheticLA, TwoStreamBatchSampler, batches
 from bcp_amd.networks.net_factory import net_factory
 from bcp_amd.train_step import get_cut_mask
-from bcp_amd.utils import ramps
+from bcp_amd.utils import ramps, test_3d_patch
 from bcp_amd.utils.BCP_utils import context_mask, mix_loss, update_ema_variables
 from bcp_amd.utils.losses import sup_loss_parts
 
@@ -48,6 +48,8 @@ parser.add_argument('--loss_weight', type=float, default=0.5, help='loss weight 
 # -- additions of this build
 parser.add_argument('--fused_optimizer', type=int, default=1, help='1: one-launch FlatSGD; 0: torch.optim.SGD on the same parameters')
 parser.add_argument('--log_every', type=int, default=50, help='host sync + log cadence (the reference syncs every iteration)')
+parser.add_argument('--val_every', type=int, default=200, help='sliding-window validation cadence (LA_BCP_train.py:174,279: every 200 iterations)')
+parser.add_argument('--val_cases', type=int, default=2, help='synthetic validation volumes (the reference walks the LA test list)')
 
 patch_size = (112, 112, 80)
 num_classes = 2
@@ -78,6 +80,15 @@ def _optimizer(args, model):
     return torch.optim.SGD(model.parameters(), lr=args.base_lr, momentum=0.9, weight_decay=0.0001)
 
 
+def _val_cases(args, device):
+    """stand-in for the LA test list (utils/test_3d_patch.py:22-25): volumes a little larger than the patch, so the sliding
+    window takes several positions per axis"""
+    from bcp_amd import synth
+    shape = (patch_size[0] + 16, patch_size[1] + 8, patch_size[2] + 8)
+    vols, labs = synth.la_batch(max(args.val_cases, 1), shape=shape, seed=args.seed + 99)
+    return [(vols[i, 0].to(device), labs[i].to(device)) for i in range(args.val_cases)]
+
+
 def pre_train(args, snapshot_path, device):
     model = net_factory(net_type=args.model, in_chns=1, class_num=num_classes, mode="train")
     db_train = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed)
@@ -89,6 +100,8 @@ def pre_train(args, snapshot_path, device):
     model.train()
     logging.info("{} iterations per epoch".format(len(batch_sampler)))
     iter_num = 0
+    best_dice = 0
+    val_cases = _val_cases(args, device) if args.val_every > 0 else []
     max_epoch = args.pre_max_iteration // len(batch_sampler) + 1
     for epoch_num in range(max_epoch):
         for sampled_batch in batches(db_train, batch_sampler):
@@ -109,11 +122,22 @@ def pre_train(args, snapshot_path, device):
             optimizer.step()
             if iter_num % args.log_every == 0:
                 logging.info('iteration %d : loss: %03f, loss_dice: %03f, loss_ce: %03f' % (iter_num, loss, loss_dice, loss_ce))
+            if args.val_every > 0 and iter_num % args.val_every == 0:       # LA_BCP_train.py:174-187
+                model.eval()
+                dice_sample = test_3d_patch.var_all_case_LA(model, num_classes=num_classes, patch_size=patch_size, stride_xy=18, stride_z=4,
+                                                            cases=val_cases)
+                if dice_sample > best_dice:
+                    best_dice = round(dice_sample, 4)
+                    save_net_opt(model, optimizer, os.path.join(snapshot_path, 'iter_{}_dice_{}.pth'.format(iter_num, best_dice)))
+                    save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
+                    logging.info("save best model, dice %f" % best_dice)
+                model.train()
             if iter_num >= args.pre_max_iteration:
                 break
         if iter_num >= args.pre_max_iteration:
             break
-    save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
+    if best_dice == 0:   # no validation ran (or none improved): keep the last weights so that self-training can start
+        save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
 
 
 def self_train(args, pre_snapshot_path, self_snapshot_path, device):
@@ -134,6 +158,8 @@ def self_train(args, pre_snapshot_path, self_snapshot_path, device):
     ema_model.train()
     logging.info("{} iterations per epoch".format(len(batch_sampler)))
     iter_num = 0
+    best_dice = 0
+    val_cases = _val_cases(args, device) if args.val_every > 0 else []
     max_epoch = args.self_max_iteration // len(batch_sampler) + 1
     lr_ = args.base_lr
     for epoch in range(max_epoch):
@@ -168,6 +194,17 @@ def self_train(args, pre_snapshot_path, self_snapshot_path, device):
 
             update_ema_variables(model, ema_model, 0.99)
 
+            if args.val_every > 0 and iter_num % args.val_every == 0:       # LA_BCP_train.py:279-293
+                model.eval()
+                dice_sample = test_3d_patch.var_all_case_LA(model, num_classes=num_classes, patch_size=patch_size, stride_xy=18, stride_z=4,
+                                                            cases=val_cases)
+                if dice_sample > best_dice:
+                    best_dice = round(dice_sample, 4)
+                    torch.save(model.state_dict(), os.path.join(self_snapshot_path, 'iter_{}_dice_{}.pth'.format(iter_num, best_dice)))
+                    torch.save(model.state_dict(), os.path.join(self_snapshot_path, '{}_best_model.pth'.format(args.model)))
+                    logging.info("save best model, dice %f" % best_dice)
+                model.train()
+
             # change lr
             if iter_num % 2500 == 0:
                 lr_ = args.base_lr * 0.1 ** (iter_num // 2500)
@@ -177,7 +214,8 @@ def self_train(args, pre_snapshot_path, self_snapshot_path, device):
                 break
         if iter_num >= args.self_max_iteration:
             break
-    torch.save(model.state_dict(), os.path.join(self_snapshot_path, '{}_best_model.pth'.format(args.model)))
+    if best_dice == 0:
+        torch.save(model.state_dict(), os.path.join(self_snapshot_path, '{}_best_model.pth'.format(args.model)))
 
 
 def main(argv=None):

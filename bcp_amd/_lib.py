@@ -73,6 +73,10 @@ _SIGS = {
     "bcp_ema": (I, [P, P, L, C.c_double, P]),
     "bcp_sgd": (I, [P, P, P, P, L, F, F, F, F, I, C.c_double, P]),
     "bcp_adam": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
+    "bcp_norm_eval": (I, [P, L, I, P, P, P, P, F, I, P, P, P]),
+    "bcp_sw_accumulate": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "bcp_sw_finish": (I, [P, P, P, L, F, P]),
+    "bcp_overlap_counts": (I, [P, P, L, P, P]),
     "bcp_cast": (I, [P, P, L, I, P]),
     "bcp_axpy": (I, [P, P, L, F, P]),
     "bcp_bernoulli": (I, [P, L, F, F, I, U64, P]),

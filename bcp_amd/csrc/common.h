@@ -48,6 +48,12 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
 // block-wide sum of NV doubles per thread (blockDim.x == 256, 4 waves); result valid in thread 0.
 template <int NV>
 __device__ __forceinline__ void block_sum_256(double (&v)[NV], double* lds /* [4*NV] */) {

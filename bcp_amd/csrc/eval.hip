@@ -1,0 +1,130 @@
+// bcp_amd/csrc/eval.hip -- validation path on the device: eval-mode BatchNorm, the sliding-window
+// accumulation of utils/test_3d_patch.py:test_single_case, and the Dice metric.
+//
+// Reference: nn.BatchNorm3d/2d in eval() mode (running statistics; networks/VNet.py:18-26 under model.eval()),
+// test_single_case (utils/test_3d_patch.py:82-141): per patch softmax -> class-1 probability added into score_map and
+// a visit count, score_map / cnt, label = score > 0.5; medpy.metric.binary.dc (2|A&B| / (|A| + |B|)).
+#include "common.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+// a = act((y - running_mean) * gamma / sqrt(running_var + eps) + beta) [+ residual]
+__global__ __launch_bounds__(256) void k_norm_eval(const float* __restrict__ y, long long rows, int C, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ rmean,
+                                                   const float* __restrict__ rvar, float eps, int act,
+                                                   const float* __restrict__ residual, float* __restrict__ out) {
+  const int C4 = C >> 2;
+  const int col = threadIdx.x % C4;             // 256 % C4 == 0 and the stride below is a multiple of C4: fixed column
+  const float4 mu = ld4(rmean + col * 4), va = ld4(rvar + col * 4);
+  float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (gamma) ga = ld4(gamma + col * 4);
+  if (beta) be = ld4(beta + col * 4);
+  // torch: invstd = 1 / sqrt(var + eps) in the compute type (fp32), then (x - mean) * invstd * weight + bias
+  const float sx = ga.x * (1.f / sqrtf(va.x + eps)), sy = ga.y * (1.f / sqrtf(va.y + eps));
+  const float sz = ga.z * (1.f / sqrtf(va.z + eps)), sw = ga.w * (1.f / sqrtf(va.w + eps));
+  const long long nv = rows * C4, stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nv; i += stride) {
+    const float4 v = ld4(y + i * 4);
+    float4 o = make_float4(act_fwd((v.x - mu.x) * sx + be.x, act), act_fwd((v.y - mu.y) * sy + be.y, act),
+                           act_fwd((v.z - mu.z) * sz + be.z, act), act_fwd((v.w - mu.w) * sw + be.w, act));
+    if (residual) {
+      const float4 r = ld4(residual + i * 4);
+      o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+    }
+    st4(out + i * 4, o);
+  }
+}
+
+// score[x0+i][y0+j][z0+k] += softmax(logits[i][j][k][:])[cls];  cnt[...] += 1        (one patch, C in {2, 4})
+template <int C>
+__global__ __launch_bounds__(256) void k_sw_accumulate(const float* __restrict__ logits, float* __restrict__ score,
+                                                       float* __restrict__ cnt, int Y, int Z, int px, int py, int pz, int x0,
+                                                       int y0, int z0, int cls) {
+  const long long n = (long long)px * py * pz;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % pz), j = (int)((i / pz) % py), ii = (int)(i / ((long long)pz * py));
+    float l[C];
+    float m = -3.4e38f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { l[c] = logits[i * C + c]; m = fmaxf(m, l[c]); }
+    float den = 0.f, num = 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) { const float e = expf(l[c] - m); den += e; if (c == cls) num = e; }
+    const long long o = ((long long)(x0 + ii) * Y + (y0 + j)) * Z + (z0 + k);
+    score[o] += num / den;
+    cnt[o] += 1.f;
+  }
+}
+
+// score /= cnt;  label = score > thres
+__global__ __launch_bounds__(256) void k_sw_finish(float* __restrict__ score, const float* __restrict__ cnt, uint8_t* __restrict__ label,
+                                                   long long n, float thres) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float s = score[i] / cnt[i];
+    score[i] = s;
+    label[i] = s > thres ? 1 : 0;
+  }
+}
+
+// counts[0] = |A & B|, counts[1] = |A|, counts[2] = |B|   (A = pred != 0, B = gt != 0); integer atomics: deterministic
+__global__ __launch_bounds__(256) void k_overlap_counts(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, long long n,
+                                                        unsigned long long* __restrict__ counts) {
+  unsigned long long c0 = 0, c1 = 0, c2 = 0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const bool x = a[i] != 0, y = b[i] != 0;
+    c0 += (x && y); c1 += x; c2 += y;
+  }
+  c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&counts[0], c0); atomicAdd(&counts[1], c1); atomicAdd(&counts[2], c2);
+  }
+}
+
+static inline int egrid(long long n) {
+  long long g = (n + 255) / 256;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace bcp
+
+using namespace bcp;
+
+extern "C" int bcp_norm_eval(const float* y, long long rows, int C, const float* gamma, const float* beta, const float* running_mean,
+                             const float* running_var, float eps, int act, const float* residual, float* out, void* stream) {
+  BCP_REQUIRE(y && running_mean && running_var && out && rows > 0, "bcp_norm_eval: bad argument");
+  BCP_REQUIRE(C >= 16 && C <= 1024 && (C & (C - 1)) == 0, "bcp_norm_eval: C=%d unsupported (need a power of two in 16..1024)", C);
+  hipLaunchKernelGGL(k_norm_eval, dim3(egrid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, y, rows, C, gamma, beta, running_mean,
+                     running_var, eps, act, residual, out);
+  BCP_CHECK_LAUNCH("bcp_norm_eval");
+  return BCP_OK;
+}
+
+extern "C" int bcp_sw_accumulate(const float* logits, float* score, float* cnt, int X, int Y, int Z, int px, int py, int pz, int x0, int y0,
+                                 int z0, int C, int cls, void* stream) {
+  BCP_REQUIRE(logits && score && cnt, "bcp_sw_accumulate: null pointer");
+  BCP_REQUIRE(x0 >= 0 && y0 >= 0 && z0 >= 0 && x0 + px <= X && y0 + py <= Y && z0 + pz <= Z && cls >= 0 && cls < C,
+              "bcp_sw_accumulate: patch outside the volume");
+  const long long n = (long long)px * py * pz;
+  if (C == 2) hipLaunchKernelGGL((k_sw_accumulate<2>), dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, logits, score, cnt, Y, Z, px, py, pz, x0, y0, z0, cls);
+  else if (C == 4) hipLaunchKernelGGL((k_sw_accumulate<4>), dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, logits, score, cnt, Y, Z, px, py, pz, x0, y0, z0, cls);
+  else BCP_REQUIRE(false, "bcp_sw_accumulate: C=%d unsupported (2 or 4)", C);
+  BCP_CHECK_LAUNCH("bcp_sw_accumulate");
+  return BCP_OK;
+}
+
+extern "C" int bcp_sw_finish(float* score, const float* cnt, uint8_t* label, long long n, float thres, void* stream) {
+  BCP_REQUIRE(score && cnt && label && n > 0, "bcp_sw_finish: bad argument");
+  hipLaunchKernelGGL(k_sw_finish, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, score, cnt, label, n, thres);
+  BCP_CHECK_LAUNCH("bcp_sw_finish");
+  return BCP_OK;
+}
+
+// counts: device uint64[3], zeroed here
+extern "C" int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, unsigned long long* counts, void* stream) {
+  BCP_REQUIRE(pred && gt && counts && n > 0, "bcp_overlap_counts: bad argument");
+  hipMemsetAsync(counts, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream);
+  hipLaunchKernelGGL(k_overlap_counts, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, counts);
+  BCP_CHECK_LAUNCH("bcp_overlap_counts");
+  return BCP_OK;
+}

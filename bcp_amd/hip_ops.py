@@ -165,6 +165,38 @@ class Ops:
                     self.stream(y))
         return out, stats
 
+    def norm_eval(self, y, gamma, beta, rmean, rvar, act, residual=None, eps=1e-5, out=None):
+        """eval-mode BatchNorm (running statistics, no update) + activation [+ residual]"""
+        self._chk(y, gamma, beta, rmean, rvar, residual)
+        Cc = y.shape[-1]
+        if out is None:
+            out = torch.empty_like(y)
+        self.b.call("bcp_norm_eval", _p(y), y.numel() // Cc, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(eps), act, _p(residual),
+                    _p(out), self.stream(y))
+        return out
+
+    def sw_accumulate(self, logits_patch, score, cnt, origin, cls=1):
+        """logits_patch [px,py,pz,C] (one patch), score / cnt [X,Y,Z] float32: score[origin + ijk] += softmax(...)[cls], cnt += 1"""
+        self._chk(logits_patch, score, cnt)
+        px, py, pz, Cc = logits_patch.shape
+        X, Y, Z = score.shape
+        self.b.call("bcp_sw_accumulate", _p(logits_patch), _p(score), _p(cnt), X, Y, Z, px, py, pz, int(origin[0]), int(origin[1]),
+                    int(origin[2]), Cc, int(cls), self.stream(score))
+
+    def sw_finish(self, score, cnt, thres=0.5):
+        """score /= cnt in place; -> uint8 label map (score > thres)"""
+        self._chk(score, cnt)
+        label = torch.empty(score.shape, dtype=torch.uint8, device=score.device)
+        self.b.call("bcp_sw_finish", _p(score), _p(cnt), _p(label), score.numel(), float(thres), self.stream(score))
+        return label
+
+    def overlap_counts(self, pred, gt):
+        """-> int64[3] device tensor {|A & B|, |A|, |B|} of two uint8 masks"""
+        self._chk(pred, gt)
+        counts = torch.empty(3, dtype=torch.int64, device=pred.device)
+        self.b.call("bcp_overlap_counts", _p(pred), _p(gt), pred.numel(), _p(counts), self.stream(pred))
+        return counts
+
     def norm_bwd(self, y, da, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
                  elem_scale=1.0, out=None):
         self._chk(y, da, stats, dgamma, dbeta, chan_scale, elem_mask)

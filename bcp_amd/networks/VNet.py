@@ -148,8 +148,8 @@ class VNet(HipNet):
         self._turnoff_drop = bool(turnoff_drop)
         assert N % groups == 0
         self._groups = int(groups)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in (self._layers[0].conv.weight,)):
-            out = NetFn.apply(xcl, self._layers[0].conv.weight, self)
+        if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in (self._layers[0].conv.weight,)):
+            out = NetFn.apply(xcl, self._layers[0].conv.weight, self)   # eval() is forward-only (validation, test_3d_patch)
         else:
             out, _ = self._forward_impl(xcl, save=False)
         logits = out.permute(0, 4, 1, 2, 3)  # logical [N,C,X,Y,Z], channels_last_3d strides
@@ -183,7 +183,10 @@ class VNet(HipNet):
                 y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
             elif L.kind == "c3":
                 wf, _ = self.conv3_packed(("c3", li), save)
-                y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
+                if self.training or L.bn is None:
+                    y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
+                else:
+                    y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)          # eval-mode BatchNorm needs no batch statistics
             elif L.kind == "dw":
                 bp, _ = self.k2_packed(("k2", li), save)
                 y = ops.down_fwd(h, bp, b.data, L.cout)
@@ -192,7 +195,10 @@ class VNet(HipNet):
                 y = ops.up_fwd(h, bp, b.data, L.cout)
             res = skips.pop() if L.skip_pop else None
             cs = self._chan_scale(L, N, xcl.device)
-            if L.bn is not None:
+            if L.bn is not None and not self.training:
+                # model.eval(): running statistics, no update (validation / sliding-window inference)
+                a, stats = ops.norm_eval(y, L.bn.weight.data, L.bn.bias.data, L.bn.running_mean, L.bn.running_var, H.ACT_RELU, residual=res), None
+            elif L.bn is not None:
                 a, stats = ops.norm_fwd(y, G, L.bn.weight.data, L.bn.bias.data, L.bn.running_mean, L.bn.running_var, H.ACT_RELU,
                                         chan_scale=cs, residual=res, partial=part, nb=nb)
             else:

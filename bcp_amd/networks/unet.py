@@ -89,7 +89,7 @@ class UNet_2d(HipNet):
         self.refresh_weights_version()
         xcl = x.contiguous().view(N, 1, x.shape[2], x.shape[3], 1)
         anchor = self._enc[0].c1.weight
-        if torch.is_grad_enabled() and anchor.requires_grad:
+        if self.training and torch.is_grad_enabled() and anchor.requires_grad:
             out = NetFn.apply(xcl, anchor, self)
         else:
             out, _ = self._forward_impl(xcl, save=False)
@@ -108,6 +108,14 @@ class UNet_2d(HipNet):
     def _convblock_fwd(self, cb, tag, h, save, saved):
         ops = self.ops
         G = getattr(self, "_groups", 1)
+        if not self.training:      # model.eval(): running statistics, no dropout (val_2d / test scripts)
+            if cb.cin == 1:
+                y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
+            else:
+                y1 = ops.conv3_fwd(h, self.conv3_packed((tag, 1), False)[0], cb.c1.bias.data, cb.cout, 1)
+            a1 = ops.norm_eval(y1, cb.b1.weight.data, cb.b1.bias.data, cb.b1.running_mean, cb.b1.running_var, H.ACT_LRELU)
+            y2 = ops.conv3_fwd(a1, self.conv3_packed((tag, 2), False)[0], cb.c2.bias.data, cb.cout, 1)
+            return ops.norm_eval(y2, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU)
         part1, nb1 = None, 0
         if cb.cin == 1:
             y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)

@@ -159,6 +159,21 @@ int bcp_sgd(float* p, const float* g, float* buf, float* ema_or_null, long long 
 int bcp_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
              float grad_scale, void* stream);
 
+/* ---- validation path on the device
+ *      bcp_norm_eval: BatchNorm in eval() mode -- running statistics, no update (networks/VNet.py:18-26 under model.eval());
+ *        a = act((y - running_mean) * gamma / sqrt(running_var + eps) + beta) [+ residual]; gamma / beta nullable.
+ *      bcp_sw_accumulate / bcp_sw_finish: the sliding-window bookkeeping of utils/test_3d_patch.py:test_single_case
+ *        (:117-136): score[x0+i][y0+j][z0+k] += softmax(logits_patch[i][j][k])[cls], cnt += 1; then score /= cnt and
+ *        label = score > thres.  logits_patch is [px][py][pz][C] (C = 2 or 4), score / cnt are [X][Y][Z] float32.
+ *      bcp_overlap_counts: counts = {|A & B|, |A|, |B|} (device uint64[3], zeroed by the call) for the Dice / Jaccard metrics
+ *        (medpy.metric.binary.dc / jc as used by utils/test_3d_patch.py:29-33,180-186). */
+int bcp_norm_eval(const float* y, long long rows, int C, const float* gamma_or_null, const float* beta_or_null, const float* running_mean,
+                  const float* running_var, float eps, int act, const float* residual_or_null, float* out, void* stream);
+int bcp_sw_accumulate(const float* logits_patch, float* score, float* cnt, int X, int Y, int Z, int px, int py, int pz, int x0, int y0,
+                      int z0, int C, int cls, void* stream);
+int bcp_sw_finish(float* score, const float* cnt, uint8_t* label, long long n, float thres, void* stream);
+int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, unsigned long long* counts, void* stream);
+
 /* ---- small utilities ---------------------------------------------------------------------------- */
 int bcp_cast(const void* in, void* out, long long n, int kind, void* stream);
 int bcp_axpy(float* y, const float* x, long long n, float a, void* stream);

@@ -631,3 +631,65 @@ def synth_acdc_batch(batch, shape=(256, 256), seed=1337):
             lab[b][d2 <= (rr * base) ** 2] = c
         img[b, 0] = 0.6 * img[b, 0] + 0.1 * lab[b]
     return torch.from_numpy(img), torch.from_numpy(lab)
+
+
+# ------------------------------------------------------------------------------------------ validation (8f-1)
+def sliding_window_la(P, image, stride_xy, stride_z, patch_size, variant="la"):
+    """utils/test_3d_patch.py:82-141 test_single_case with the V-Net in eval() mode (running statistics, no dropout).
+    image: numpy [W,H,D].  Returns (label_map int64 [W,H,D], score_map float32 [W,H,D]) -- the reference's
+    score_map[0] (all its channels hold the class-1 probability, :131)."""
+    import math
+    image = np.asarray(image, dtype=np.float32)
+    w, h, d = image.shape
+    pads = []
+    for size, p in zip((w, h, d), patch_size):
+        tot = max(p - size, 0)
+        pads.append((tot // 2, tot - tot // 2))                                    # :98-100
+    add_pad = any(l or r for l, r in pads)
+    if add_pad:
+        image = np.pad(image, pads, mode="constant", constant_values=0)           # :101-102
+    ww, hh, dd = image.shape
+    sx = math.ceil((ww - patch_size[0]) / stride_xy) + 1                           # :105-107
+    sy = math.ceil((hh - patch_size[1]) / stride_xy) + 1
+    sz = math.ceil((dd - patch_size[2]) / stride_z) + 1
+    score = np.zeros(image.shape, dtype=np.float32)
+    cnt = np.zeros(image.shape, dtype=np.float32)
+    for x in range(sx):
+        xs = min(stride_xy * x, ww - patch_size[0])
+        for y in range(sy):
+            ys = min(stride_xy * y, hh - patch_size[1])
+            for z in range(sz):
+                zs = min(stride_z * z, dd - patch_size[2])
+                patch = torch.from_numpy(image[xs:xs + patch_size[0], ys:ys + patch_size[1], zs:zs + patch_size[2]][None, None].copy())
+                with torch.no_grad():
+                    logits = vnet_forward(P, patch, None, False, variant, has_dropout=False)
+                    prob = F.softmax(logits, dim=1)[0, 1].numpy()                  # :124-128
+                sl = (slice(xs, xs + patch_size[0]), slice(ys, ys + patch_size[1]), slice(zs, zs + patch_size[2]))
+                score[sl] += prob
+                cnt[sl] += 1
+    score = score / cnt                                                            # :134
+    label = (score > 0.5).astype(np.int64)                                         # :135
+    if add_pad:
+        sl = tuple(slice(l, l + s) for (l, _), s in zip(pads, (w, h, d)))
+        label, score = label[sl], score[sl]
+    return label, score
+
+
+def eval_params(seed, variant="la"):
+    """random-init V-Net weights + NON-trivial running statistics (eval-mode BatchNorm must use them): the parameter set of
+    tests/golden/sw_la.npz (oracle/make_golden_eval.py)"""
+    P = init_params(vnet_param_shapes(variant=variant), seed=seed, random_affine=True)
+    rng = np.random.default_rng(seed + 1)
+    for k in P:
+        if k.endswith("running_mean"):
+            P[k] = torch.from_numpy(rng.normal(0.0, 0.2, tuple(P[k].shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            P[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(P[k].shape)).astype(np.float32))
+    return P
+
+
+def dice_binary(pred, gt):
+    """medpy.metric.binary.dc: 2|A&B| / (|A| + |B|), 0.0 for two empty masks"""
+    a, b = np.asarray(pred) != 0, np.asarray(gt) != 0
+    den = int(a.sum()) + int(b.sum())
+    return 2.0 * int((a & b).sum()) / den if den else 0.0

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Golden vector for the validation path: the REFERENCE's utils/test_3d_patch.py:test_single_case driving the
+REFERENCE V-Net in eval() mode on a small random volume.  Runs only in the build container (imports /root/reference through
+oracle/make_golden.py's stubs); writes tests/golden/sw_la.npz (inputs + outputs: data, no reference source).
+
+  python oracle/make_golden_eval.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as MG  # noqa: E402  (installs the stubs, imports the reference)
+import bcp_oracle as O  # noqa: E402
+
+np.int = int  # the reference still spells `astype(np.int)` (test_3d_patch.py:135); numpy >= 1.24 dropped the alias
+from utils import test_3d_patch as ref_t3d  # noqa: E402
+
+SEED = 2024
+PATCH, STRIDE_XY, STRIDE_Z = (32, 32, 16), 6, 4
+SHAPE = (28, 40, 20)      # narrower than the patch along W: exercises the zero padding (:91-104)
+
+
+def main():
+    P = O.eval_params(SEED)
+    net = MG.ref_vnet_la({k: v.clone() for k, v in P.items()})
+    MG.set_drop_la(net, None)
+    net.eval()
+    rng = np.random.default_rng(SEED + 2)
+    image = rng.standard_normal(SHAPE).astype(np.float32)
+    label_map, score_map = ref_t3d.test_single_case(net, image, STRIDE_XY, STRIDE_Z, PATCH, num_classes=2)
+    gt = (rng.random(SHAPE) < 0.4).astype(np.uint8)
+    inter = int(((label_map != 0) & (gt != 0)).sum())
+    dice = 2.0 * inter / (int((label_map != 0).sum()) + int(gt.sum()))
+    out = os.path.join(HERE, "..", "tests", "golden", "sw_la.npz")
+    np.savez_compressed(out, image=image, label_map=label_map.astype(np.uint8), score_map=score_map[0].astype(np.float32), gt=gt,
+                        dice=np.float64(dice), seed=np.int64(SEED), patch=np.array(PATCH), stride=np.array([STRIDE_XY, STRIDE_Z]))
+    print("wrote", os.path.normpath(out), "fg fraction", float(label_map.mean()), "dice vs random gt", dice,
+          "score range", float(score_map.min()), float(score_map.max()))
+
+
+if __name__ == "__main__":
+    main()

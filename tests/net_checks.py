@@ -308,3 +308,51 @@ def check_acdc_step(ops, dev, golden_dir):
             assert abs(float(r[key].float().sum()) - ref[j]) <= max(4.0, 0.03 * ref[j]), (it, key)
     sde = ema.state_dict()
     K.close(sde["encoder.in_conv.conv_conv.1.running_mean"], torch.from_numpy(g["final_ema_rm"]), rtol=1e-3, msg="teacher running_mean")
+
+
+def check_sliding_window(ops, dev, golden_dir):
+    """validation path: eval-mode V-Net + sliding-window accumulation on the device vs the REFERENCE's
+    test_single_case output (tests/golden/sw_la.npz, made by oracle/make_golden_eval.py) and vs the oracle restatement"""
+    from bcp_amd.utils import test_3d_patch as T3
+    g = np.load(os.path.join(golden_dir, "sw_la.npz"))
+    P = O.eval_params(int(g["seed"]))
+    net = make_vnet(P, dev, ops)
+    rm0 = net.state_dict()["encoder.block_one.conv.1.running_mean"].clone()
+    patch, (sxy, sz) = tuple(int(v) for v in g["patch"]), (int(v) for v in g["stride"])
+    label, score = T3.test_single_case(net, g["image"], sxy, sz, patch, num_classes=2, batch=4)
+    assert net.training, "test_single_case must restore train() mode"
+    assert torch.equal(net.state_dict()["encoder.block_one.conv.1.running_mean"], rm0), "eval-mode BatchNorm must not touch the running statistics"
+    score, label = score[0].cpu().numpy(), label.cpu().numpy()
+    assert score.shape == g["score_map"].shape and label.shape == g["label_map"].shape
+    err = np.abs(score - g["score_map"]).max()
+    assert err < 2e-5, f"score map vs reference: {err:.3e}"
+    border = np.abs(g["score_map"] - 0.5) < 1e-4          # voxels within rounding of the 0.5 threshold may legitimately flip
+    assert np.array_equal(label[~border], g["label_map"][~border])
+    dc, jc = T3.dice_jaccard(torch.from_numpy(g["label_map"]).to(dev), torch.from_numpy(g["gt"]).to(dev))
+    assert abs(dc - float(g["dice"])) < 1e-12 and 0.0 < jc < dc
+    # batch size must not change anything (eval-mode BatchNorm is per element)
+    label1, score1 = T3.test_single_case(net, g["image"], *(int(v) for v in g["stride"]), patch, num_classes=2, batch=1)
+    assert float((score1[0].cpu() - torch.from_numpy(score)).abs().max()) < 1e-6
+    mean_dice = T3.var_all_case_LA(net, 2, patch, *(int(v) for v in g["stride"]), cases=[(g["image"], g["gt"])])
+    assert abs(mean_dice - O.dice_binary(label, g["gt"])) < 1e-3
+
+
+def check_unet_eval(ops, dev, seed=5):
+    """model.eval() U-Net forward (running statistics, no dropout) vs the oracle; the running statistics stay untouched"""
+    rng = np.random.default_rng(seed)
+    P = O.init_params(O.unet_param_shapes(), seed=seed + 50, random_affine=True)
+    for k in P:
+        if k.endswith("running_mean"):
+            P[k] = torch.from_numpy(rng.normal(0.0, 0.2, tuple(P[k].shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            P[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(P[k].shape)).astype(np.float32))
+    x = torch.from_numpy(rng.standard_normal((3, 1, 32, 48), dtype=np.float32))
+    ref = O.unet_forward({k: v.clone() for k, v in P.items()}, x, None, train=False)
+    net = make_unet(P, dev, ops)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
+    net.eval()
+    out = net(x.to(dev))
+    K.close(out, ref, rtol=2e-5, msg="unet eval logits")
+    for k, v in net.state_dict().items():
+        if "running" in k:
+            assert torch.equal(v, sd0[k]), k

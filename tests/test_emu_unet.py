@@ -28,3 +28,7 @@ def test_unet_smooth_grads(emu_ops):
 
 def test_acdc_self_train_trajectory(emu_ops, golden_dir):
     NC.check_acdc_step(emu_ops, CPU, golden_dir)
+
+
+def test_unet_eval_mode(emu_ops):
+    NC.check_unet_eval(emu_ops, CPU)

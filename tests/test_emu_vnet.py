@@ -26,3 +26,7 @@ def test_la_self_train_trajectory(emu_ops, golden_dir):
 
 def test_grouped_forward_equals_separate_calls(emu_ops):
     NC.check_grouped_equals_separate(emu_ops, CPU)
+
+
+def test_sliding_window_validation(emu_ops, golden_dir):
+    NC.check_sliding_window(emu_ops, CPU, golden_dir)

@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 def test_la_script(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     from bcp_amd import LA_BCP_train as T
-    T.main(["--labelnum", "8", "--batch_size", "4", "--labeled_bs", "2", "--pre_max_iteration", "3", "--self_max_iteration", "4", "--log_every", "1"])
+    T.main(["--labelnum", "8", "--batch_size", "4", "--labeled_bs", "2", "--pre_max_iteration", "3", "--self_max_iteration", "4", "--log_every", "1",
+            "--val_every", "2", "--val_cases", "1"])       # sliding-window validation (eval-mode net) twice per phase
     sd = torch.load(tmp_path / "model/BCP/LA_BCP_8_labeled/self_train/VNet_best_model.pth")
     assert len(sd) == 259 and all(torch.isfinite(v.float()).all() for v in sd.values())
 

@@ -59,3 +59,7 @@ def test_unet_full_shape_vs_reference_golden(ops, golden_dir):
             continue
         l2 = float(params[n_].grad.double().norm())
         assert abs(l2 - stg[2]) / max(stg[2], 1e-12) < 3e-2, (n_, l2, stg[2])
+
+
+def test_unet_eval_mode(ops):
+    NC.check_unet_eval(ops, DEV)

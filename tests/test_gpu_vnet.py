@@ -72,3 +72,7 @@ def test_vnet_la_full_shape_vs_reference_golden(ops, golden_dir):
 
 def test_grouped_forward_equals_separate_calls(ops):
     NC.check_grouped_equals_separate(ops, DEV)
+
+
+def test_sliding_window_validation(ops, golden_dir):
+    NC.check_sliding_window(ops, DEV, golden_dir)

@@ -268,3 +268,14 @@ def test_acdc_trajectory(golden_dir, meta):
     for k, st in zip(meta["unet_param_names"][:40], g["final_w_stats"]):
         np.testing.assert_allclose(stats(Ps[k]), st, rtol=1e-4, atol=1e-6, err_msg=k)
     np.testing.assert_allclose(Pt["encoder.in_conv.conv_conv.1.running_mean"].numpy(), g["final_ema_rm"], rtol=1e-4, atol=1e-6)
+
+
+def test_sliding_window_oracle_vs_reference(golden_dir):
+    """oracle restatement of utils/test_3d_patch.py:test_single_case (eval-mode V-Net) vs the reference's own output"""
+    g = np.load(os.path.join(golden_dir, "sw_la.npz"))
+    P = O.eval_params(int(g["seed"]))
+    label, score = O.sliding_window_la(P, g["image"], int(g["stride"][0]), int(g["stride"][1]), tuple(int(v) for v in g["patch"]))
+    assert np.abs(score - g["score_map"]).max() < 2e-6
+    border = np.abs(g["score_map"] - 0.5) < 1e-5
+    assert np.array_equal(label[~border].astype(np.uint8), g["label_map"][~border])
+    assert abs(O.dice_binary(g["label_map"], g["gt"]) - float(g["dice"])) < 1e-12
