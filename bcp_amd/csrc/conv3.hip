@@ -832,10 +832,14 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
   __shared__ float tile[16 * 16 * 27];
   __shared__ int ubeg[kMaxPackDescs + 1];           // exclusive prefix sums of the per-layer unit counts
   // (scanning the descriptor array in global memory per unit cost ~80 dependent scalar loads = 15+ us per unit)
+  // counts loaded in parallel (one descriptor per thread), prefix-summed out of LDS: a single thread walking the
+  // descriptors paid one dependent global-load latency per layer (~80 us for 84 descriptors, in EVERY block)
+  for (int i = threadIdx.x; i < n; i += blockDim.x) ubeg[i + 1] = (descs[i].K16 >> 4) * (descs[i].N16 >> 4);
+  __syncthreads();
   if (threadIdx.x == 0) {
     int t = 0;
-    for (int i = 0; i < n; ++i) { ubeg[i] = t; t += (descs[i].K16 >> 4) * (descs[i].N16 >> 4); }
-    ubeg[n] = t;
+    ubeg[0] = 0;
+    for (int i = 1; i <= n; ++i) { t += ubeg[i]; ubeg[i] = t; }
   }
   __syncthreads();
   const int total = ubeg[n];

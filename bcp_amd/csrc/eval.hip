@@ -128,3 +128,49 @@ extern "C" int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long l
   BCP_CHECK_LAUNCH("bcp_overlap_counts");
   return BCP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Device-side input pipeline for LA: RandomRotFlip + RandomCrop (dataloaders/dataset.py:52-59, 173-214)
+// as ONE gather: dst[i][j][l] = pad(flip(rot90(src, k), axis))[w1+i][h1+j][d1+l], zero in the padding.
+// ------------------------------------------------------------------------------------------------
+namespace bcp {
+template <typename T>
+__global__ __launch_bounds__(256) void k_crop_rotflip(const T* __restrict__ src, T* __restrict__ dst, int n0, int n1, int n2, int k,
+                                                      int axis, int pw, int ph, int pd, int w1, int h1, int d1, int P0, int P1, int P2) {
+  const int b0 = (k & 1) ? n1 : n0, b1 = (k & 1) ? n0 : n1;      // shape of rot90(src, k) in the (0, 1) plane
+  const long long n = (long long)P0 * P1 * P2;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+    const int l = (int)(q % P2), j = (int)((q / P2) % P1), i = (int)(q / ((long long)P2 * P1));
+    int a = i + w1 - pw, b = j + h1 - ph;                          // coordinates in flip(rot90(src))
+    const int c = l + d1 - pd;
+    T v = 0;
+    if (a >= 0 && a < b0 && b >= 0 && b < b1 && c >= 0 && c < n2) {
+      if (axis == 0) a = b0 - 1 - a; else b = b1 - 1 - b;         // undo np.flip
+      int s0, s1;                                                  // undo np.rot90(m, k, axes=(0, 1))
+      switch (k & 3) {
+        case 0: s0 = a; s1 = b; break;
+        case 1: s0 = b; s1 = n1 - 1 - a; break;
+        case 2: s0 = n0 - 1 - a; s1 = n1 - 1 - b; break;
+        default: s0 = n0 - 1 - b; s1 = a; break;
+      }
+      v = src[((long long)s0 * n1 + s1) * n2 + c];
+    }
+    dst[q] = v;
+  }
+}
+}  // namespace bcp
+
+extern "C" int bcp_crop_rotflip(const void* src, void* dst, int elem_bytes, int n0, int n1, int n2, int k, int flip_axis, int pw, int ph,
+                                int pd, int w1, int h1, int d1, int P0, int P1, int P2, void* stream) {
+  BCP_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n2 > 0 && P0 > 0 && P1 > 0 && P2 > 0, "bcp_crop_rotflip: bad argument");
+  BCP_REQUIRE((flip_axis == 0 || flip_axis == 1) && k >= 0 && k < 4 && (elem_bytes == 4 || elem_bytes == 1), "bcp_crop_rotflip: bad mode");
+  const long long n = (long long)P0 * P1 * P2;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((k_crop_rotflip<float>), dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, n0, n1,
+                       n2, k, flip_axis, pw, ph, pd, w1, h1, d1, P0, P1, P2);
+  else
+    hipLaunchKernelGGL((k_crop_rotflip<uint8_t>), dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (uint8_t*)dst, n0,
+                       n1, n2, k, flip_axis, pw, ph, pd, w1, h1, d1, P0, P1, P2);
+  BCP_CHECK_LAUNCH("bcp_crop_rotflip");
+  return BCP_OK;
+}

@@ -197,6 +197,16 @@ class Ops:
         self.b.call("bcp_overlap_counts", _p(pred), _p(gt), pred.numel(), _p(counts), self.stream(pred))
         return counts
 
+    def crop_rotflip(self, src, patch, k, flip_axis, pads, origin):
+        """src [n0,n1,n2] float32 or uint8 -> [P0,P1,P2]: RandomRotFlip + RandomCrop (dataloaders/dataset.py) as one gather"""
+        self._chk(src)
+        assert src.dtype in (torch.float32, torch.uint8)
+        dst = torch.empty(tuple(patch), dtype=src.dtype, device=src.device)
+        n0, n1, n2 = src.shape
+        self.b.call("bcp_crop_rotflip", _p(src), _p(dst), src.element_size(), n0, n1, n2, int(k), int(flip_axis), int(pads[0]), int(pads[1]),
+                    int(pads[2]), int(origin[0]), int(origin[1]), int(origin[2]), int(patch[0]), int(patch[1]), int(patch[2]), self.stream(src))
+        return dst
+
     def norm_bwd(self, y, da, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
                  elem_scale=1.0, out=None):
         self._chk(y, da, stats, dgamma, dbeta, chan_scale, elem_mask)

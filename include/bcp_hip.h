@@ -174,6 +174,12 @@ int bcp_sw_accumulate(const float* logits_patch, float* score, float* cnt, int X
 int bcp_sw_finish(float* score, const float* cnt, uint8_t* label, long long n, float thres, void* stream);
 int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, unsigned long long* counts, void* stream);
 
+/* ---- device-side input pipeline, LA: RandomRotFlip + RandomCrop of dataloaders/dataset.py:52-59,173-214 as one
+ *      gather: dst[P0][P1][P2] = pad(flip(rot90(src[n0][n1][n2], k, axes=(0,1)), flip_axis), (pw,ph,pd))[w1:, h1:, d1:];
+ *      elem_bytes = 4 (float32 image) or 1 (uint8 label).  The caller draws k, flip_axis, w1, h1, d1 (np.random, reference order). */
+int bcp_crop_rotflip(const void* src, void* dst, int elem_bytes, int n0, int n1, int n2, int k, int flip_axis, int pw, int ph, int pd,
+                     int w1, int h1, int d1, int P0, int P1, int P2, void* stream);
+
 /* ---- small utilities ---------------------------------------------------------------------------- */
 int bcp_cast(const void* in, void* out, long long n, int kind, void* stream);
 int bcp_axpy(float* y, const float* x, long long n, float a, void* stream);

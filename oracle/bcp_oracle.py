@@ -693,3 +693,23 @@ def dice_binary(pred, gt):
     a, b = np.asarray(pred) != 0, np.asarray(gt) != 0
     den = int(a.sum()) + int(b.sum())
     return 2.0 * int((a & b).sum()) / den if den else 0.0
+
+
+def la_rotflip_crop(image, label, output_size, randint):
+    """RandomRotFlip + RandomCrop of the LA pipeline (dataloaders/dataset.py:52-59, 184-214) with an injectable randint
+    (called in the reference's order: k, axis, w1, h1, d1).  numpy in, numpy out."""
+    k = randint(0, 4)                                                               # :53
+    image, label = np.rot90(image, k), np.rot90(label, k)                           # :54-55
+    axis = randint(0, 2)                                                            # :56
+    image, label = np.flip(image, axis=axis).copy(), np.flip(label, axis=axis).copy()
+    P = output_size
+    if label.shape[0] <= P[0] or label.shape[1] <= P[1] or label.shape[2] <= P[2]:  # :190-198
+        pw = max((P[0] - label.shape[0]) // 2 + 3, 0)
+        ph = max((P[1] - label.shape[1]) // 2 + 3, 0)
+        pd = max((P[2] - label.shape[2]) // 2 + 3, 0)
+        image = np.pad(image, [(pw, pw), (ph, ph), (pd, pd)], mode="constant", constant_values=0)
+        label = np.pad(label, [(pw, pw), (ph, ph), (pd, pd)], mode="constant", constant_values=0)
+    w, h, d = image.shape
+    w1, h1, d1 = randint(0, w - P[0]), randint(0, h - P[1]), randint(0, d - P[2])   # :202-204
+    sl = (slice(w1, w1 + P[0]), slice(h1, h1 + P[1]), slice(d1, d1 + P[2]))
+    return image[sl], label[sl]

@@ -42,5 +42,33 @@ def main():
           "score range", float(score_map.min()), float(score_map.max()))
 
 
+def main_aug():
+    """G10: the REFERENCE's RandomRotFlip + RandomCrop classes (dataloaders/dataset.py) on seeded volumes, np.random seeded per case"""
+    from dataloaders import dataset as ref_ds
+    rng = np.random.default_rng(SEED + 7)
+    cases = []
+    P = (24, 20, 16)
+    for ci, shape in enumerate([(40, 36, 30), (30, 44, 16), (20, 22, 12), (24, 20, 16)]):   # plain, d == P (pad), all smaller (pad), equal (pad)
+        image = rng.standard_normal(shape).astype(np.float32)
+        label = (rng.random(shape) < 0.3).astype(np.uint8)
+        for rep in range(3):
+            seed = 100 * ci + rep
+            np.random.seed(seed)
+            out = ref_ds.RandomCrop(P)(ref_ds.RandomRotFlip()({"image": image, "label": label}))
+            cases.append((ci, seed, out["image"].astype(np.float32), out["label"].astype(np.uint8)))
+        cases_in = locals().setdefault("_ins", {})
+        cases_in[ci] = (image, label)
+    out = os.path.join(HERE, "..", "tests", "golden", "aug_la.npz")
+    d = {"patch": np.array(P), "n_cases": np.int64(len(cases))}
+    for ci, (image, label) in locals()["_ins"].items():
+        d[f"in_image_{ci}"], d[f"in_label_{ci}"] = image, label
+    for i, (ci, seed, img, lab) in enumerate(cases):
+        d[f"case_{i}"] = np.array([ci, seed])
+        d[f"out_image_{i}"], d[f"out_label_{i}"] = img, lab
+    np.savez_compressed(out, **d)
+    print("wrote", os.path.normpath(out), len(cases), "cases")
+
+
 if __name__ == "__main__":
     main()
+    main_aug()
