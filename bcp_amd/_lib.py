@@ -40,12 +40,13 @@ _SIGS = {
     "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, P, P]),
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
     "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, P]),
-    "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, P]),
+    "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, I, P, P]),
     "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
     "bcp_conv3_pack_weight": (I, [P, P, P, I, I, I, P]),
     "bcp_conv3_pack_many": (I, [P, I, P]),
     "bcp_conv3_fwd_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "bcp_conv3_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, P, I, P, I, P]),
     "bcp_conv3_stat_rows": (I, [I, I, I, I, I, I, I, I, I]),
     "bcp_conv3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
     "bcp_conv3_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),

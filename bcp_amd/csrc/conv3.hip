@@ -144,12 +144,46 @@ struct HaloFetch {
 // Fused BatchNorm / InstanceNorm statistics: the conv epilogue already holds y = conv + bias in registers, so the
 // per-channel (sum, sum of squares) partials the norm needs are produced here instead of by a second pass over y
 // (csrc/norm.hip k_col_partial<0>).  partial[g][row][C][2] doubles, fp64 accumulation as in the standalone pass.
+//
+// Backward flavour (dgrad epilogue, yprev != nullptr): the conv output is da, the gradient w.r.t. the PREVIOUS layer's
+// activation a = act((y - mean) * scale + beta); the two sums its norm backward needs -- sum dz and sum dz * xhat with
+// dz = da * act'(z) -- are accumulated here from da (in registers) and y (one extra read in an MFMA-bound kernel), so
+// the standalone statistics pass over (y, da) (csrc/norm.hip k_col_partial<1>, the largest HBM pass on the step's
+// critical path) disappears.
 struct StatsArg {
   double* partial;       // nullptr: disabled
   int rows;              // rows per group (nb of the norm finalize)
   int tiles_per_group;   // spatial tiles per normalisation group (tiles are sample-major)
   int C;                 // channel count of the partial rows (= Cout)
+  const float* yprev;    // backward flavour: pre-norm output of the previous layer, same shape as this conv's output
+  const float* pstats;   // its norm statistics [mean | rstd | scale | shift][G][C]
+  int G, act;
 };
+
+struct BwdCtx { const float* yprev; const float* pstats; int act; };   // host side: backward-statistics request
+struct BwdCol { float mu, sc, sh, rs; };
+__device__ __forceinline__ BwdCol load_bwd_col(const StatsArg& st, int g, int c) {
+  BwdCol k{0.f, 1.f, 0.f, 1.f};
+  if (st.yprev && c < st.C) {
+    const long long gc = (long long)g * st.C + c, GC = (long long)st.G * st.C;
+    k.mu = st.pstats[gc]; k.rs = st.pstats[GC + gc]; k.sc = st.pstats[2 * GC + gc]; k.sh = st.pstats[3 * GC + gc];
+  }
+  return k;
+}
+// MODE 1: forward statistics of v;  MODE 2: backward statistics of da = v given y = yv
+template <int MODE>
+__device__ __forceinline__ void stat_add(double& s1, double& s2, float v, float yv, const BwdCol& k, int act) {
+  if (MODE == 1) {
+    s1 += (double)v;
+    s2 += (double)v * (double)v;
+  } else if (MODE == 2) {
+    const float z = (yv - k.mu) * k.sc + k.sh;
+    const float g1 = v * act_grad(z, act);
+    const float xh = (yv - k.mu) * k.rs;
+    s1 += (double)g1;
+    s2 += (double)g1 * (double)xh;
+  }
+}
 
 // block-wide sum over the 4 lg lane groups and the 4 waves, then one (s1, s2) pair per channel of the slab
 template <int NT>
@@ -293,56 +327,41 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
   const bool full = (TW % 4 == 0) && cout0 + CT <= cd.Cout && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
-  if (full) {   // whole tile inside the volume: uniform base + per-lane row offsets, no per-row index math
-    float* yb = Y + ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout + cout0 + li;
-    auto rows = [&](auto with_stats) {
+  const int sgrp = st.partial ? blockIdx.x / st.tiles_per_group : 0;
+  BwdCol kc[NT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m0 = (wave * MT + mt) * 16 + lg * 4;
-        const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
-        float* p0 = yb + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);
+  for (int nt = 0; nt < NT; ++nt) kc[nt] = load_bwd_col(st, sgrp, cout0 + nt * 16 + li);
+  const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
+  auto rows = [&](auto mode_tag) {
+    constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float* p = p0 + r * cd.Cout;
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = (wave * MT + mt) * 16 + lg * 4 + r;
+        const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+        const int d = d0 + td, h = h0 + th, w = w0 + tw;
+        if (full || (d < cd.D && h < cd.H && w < cd.W)) {
+          const long long ro = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);   // uniform base + 32-bit row offset
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            float v = acc[0][mt][nt][r];
-            if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
-            if (bias) v += bias[cout0 + nt * 16 + li];
-            if (accumulate) v += p[nt * 16];
-            p[nt * 16] = v;
-            if (decltype(with_stats)::value) { s1[nt] += (double)v; s2[nt] += (double)v * (double)v; }
-          }
-        }
-      }
-    };
-    if (st.partial) rows(std::true_type{}); else rows(std::false_type{});
-  } else
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = (wave * MT + mt) * 16 + lg * 4 + r;
-      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-      const int d = d0 + td, h = h0 + th, w = w0 + tw;
-      if (d < cd.D && h < cd.H && w < cd.W) {
-        float* yrow = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int co = cout0 + nt * 16 + li;
-          if (co < cd.Cout) {
-            float v = acc[0][mt][nt][r];
-            if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
-            if (bias) v += bias[co];
-            if (accumulate) v += yrow[co];
-            yrow[co] = v;
-            s1[nt] += (double)v;
-            s2[nt] += (double)v * (double)v;
+            const int co = cout0 + nt * 16 + li;
+            if (full || co < cd.Cout) {
+              float v = acc[0][mt][nt][r];
+              if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
+              if (bias) v += bias[co];
+              if (accumulate) v += Y[ro + co];
+              Y[ro + co] = v;
+              stat_add<MODE>(s1[nt], s2[nt], v, MODE == 2 ? st.yprev[ro + co] : 0.f, kc[nt], st.act);
+            }
           }
         }
       }
     }
-  }
+  };
+  if (!st.partial) rows(std::integral_constant<int, 0>{});
+  else if (!st.yprev) rows(std::integral_constant<int, 1>{});
+  else rows(std::integral_constant<int, 2>{});
   if (st.partial) {
     const int g = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
     stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)g * st.rows + row) * st.C * 2, cout0, cd.Cout);
@@ -451,6 +470,9 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
   int cur_g = st.partial ? tile / st.tiles_per_group : 0;
+  BwdCol kc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) kc[nt] = load_bwd_col(st, cur_g, cout0 + nt * 16 + li);
   {
     float4 pre[NP];
     fetch(tile, 0, pre);
@@ -503,12 +525,26 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
       if (st.partial && tile / st.tiles_per_group != cur_g) {   // tiles are visited in increasing order: groups never come back
         stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
         cur_g = tile / st.tiles_per_group;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) kc[nt] = load_bwd_col(st, cur_g, cout0 + nt * 16 + li);
       }
       const bool full = ROWS4 && slab_full && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
-      if (full) {
-        // whole tile inside the volume: uniform base + launch-invariant lane offsets, no index math per row
-        float* yb = Y + ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout + cout0;
-        auto rows = [&](auto with_stats) {
+      const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
+      auto rows = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        if (full) {
+          // whole tile inside the volume: uniform base + launch-invariant lane offsets, no index math per row
+          float* yb = Y + tile_base + cout0;
+          const float* ypb = (MODE == 2) ? st.yprev + tile_base + cout0 : nullptr;
+          float yv[MT][4][NT];
+          if (MODE == 2) {   // all y loads of the tile up front: one latency, not sixteen
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) yv[mt][r][nt] = ypb[r * cd.Cout + yoff[mt] + nt * 16];
+          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -521,38 +557,39 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
                 v += bv[nt];
                 if (accumulate) v += p[nt * 16];
                 p[nt * 16] = v;
-                if (decltype(with_stats)::value) { s1[nt] += (double)v; s2[nt] += (double)v * (double)v; }
+                stat_add<MODE>(s1[nt], s2[nt], v, MODE == 2 ? yv[mt][r][nt] : 0.f, kc[nt], st.act);
               }
             }
-        };
-        if (st.partial) rows(std::true_type{}); else rows(std::false_type{});
-      } else {
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
+          for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int m = (wave * MT + mt) * 16 + lg * 4 + r;
-            const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-            const int d = d0 + td, h = h0 + th, w = w0 + tw;
-            if (d < cd.D && h < cd.H && w < cd.W) {
-              float* yrow = Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout;
+            for (int r = 0; r < 4; ++r) {
+              const int m = (wave * MT + mt) * 16 + lg * 4 + r;
+              const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+              const int d = d0 + td, h = h0 + th, w = w0 + tw;
+              if (d < cd.D && h < cd.H && w < cd.W) {
+                const long long ro = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);
 #pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                const int co = cout0 + nt * 16 + li;
-                if (co < cd.Cout) {
-                  float v = acc[0][mt][nt][r];
-                  if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
-                  v += bv[nt];
-                  if (accumulate) v += yrow[co];
-                  yrow[co] = v;
-                  s1[nt] += (double)v;
-                  s2[nt] += (double)v * (double)v;
+                for (int nt = 0; nt < NT; ++nt) {
+                  const int co = cout0 + nt * 16 + li;
+                  if (co < cd.Cout) {
+                    float v = acc[0][mt][nt][r];
+                    if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
+                    v += bv[nt];
+                    if (accumulate) v += Y[ro + co];
+                    Y[ro + co] = v;
+                    stat_add<MODE>(s1[nt], s2[nt], v, MODE == 2 ? st.yprev[ro + co] : 0.f, kc[nt], st.act);
+                  }
                 }
               }
             }
           }
         }
-      }
+      };
+      if (!st.partial) rows(std::integral_constant<int, 0>{});
+      else if (!st.yprev) rows(std::integral_constant<int, 1>{});
+      else rows(std::integral_constant<int, 2>{});
 #pragma unroll
       for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -1044,7 +1081,7 @@ static int split_k(long long blocks, int nch) {   // deep levels: too few tiles 
 
 template <int KD, int TD, int TH, int TW, int NT, int WT>
 static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
-                      double* stat_partial, int G, bool dry, hipStream_t s) {
+                      double* stat_partial, int G, BwdCtx bw, bool dry, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int S = TL::T / WT, NBUF = S > 1 ? 2 : 1;
   const size_t lds = (size_t)(TL::HV * XS + NBUF * WT * 4 * NT * 16 * 4) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
@@ -1053,14 +1090,17 @@ static int launch_fwd(const float* X, const float* Wp, const float* bias, float*
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / (NT * 16);
   const int sk = ws ? split_k((long long)gx * gy, cd.Cin16 / 16) : 1;
-  StatsArg st{nullptr, 0, 1, cd.Cout};
-  if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
+  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
+  if (sk == 1 && G > 0 && gx % G == 0) {
+    st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial;
+    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;
+  }
   if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
   if (sk == 1) {
     hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);
   } else {
     const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
-    StatsArg none{nullptr, 0, 1, cd.Cout};
+    StatsArg none{nullptr, 0, 1, cd.Cout, nullptr, nullptr, 1, 0};
     hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, 0, none);
     hipLaunchKernelGGL(k_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y, accumulate);
   }
@@ -1069,7 +1109,7 @@ static int launch_fwd(const float* X, const float* Wp, const float* bias, float*
 
 template <int KD, int TD, int TH, int TW, int NT>
 static int launch_res(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate,
-                      double* stat_partial, int G, bool dry, hipStream_t s) {
+                      double* stat_partial, int G, BwdCtx bw, bool dry, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   const int nch = cd.Cin16 / 16;
   const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + (size_t)TL::HV * XS) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
@@ -1081,11 +1121,12 @@ static int launch_res(const float* X, const float* Wp, const float* bias, float*
   if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
   if (P < 1) P = 1;
   if (P > tiles) P = tiles;
-  StatsArg st{nullptr, 0, 1, cd.Cout};
+  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
   const bool stats_ok = G > 0 && tiles % G == 0;
   if (dry) return stats_ok ? P : 0;
   if (stats_ok && stat_partial) {
     st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G;
+    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;
     // a persistent block only writes the groups it visited: start from zeros
     hipMemsetAsync(stat_partial, 0, (size_t)G * P * cd.Cout * 2 * sizeof(double), s);
   }
@@ -1184,12 +1225,12 @@ extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
 
 #define BCP_FWD_CASE(KD_, TD_, TH_, TW_, NT_, WT_)                                                             \
   if (c.KD == KD_ && c.TD == TD_ && c.TH == TH_ && c.TW == TW_ && c.NT == NT_) {                               \
-    rows = launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (float*)workspace, stat_partial, G, dry, (hipStream_t)stream); \
+    rows = launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (float*)workspace, stat_partial, G, bw, dry, (hipStream_t)stream); \
     done = true;                                                                                               \
   }
 #define BCP_RES_CASE(KD_, TD_, TH_, TW_, NT_)                                                                  \
   if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_ && r.NT == NT_) {                               \
-    rows = launch_res<KD_, TD_, TH_, TW_, NT_>(x, wp, bias, y, cd, accumulate, stat_partial, G, dry, (hipStream_t)stream); \
+    rows = launch_res<KD_, TD_, TH_, TW_, NT_>(x, wp, bias, y, cd, accumulate, stat_partial, G, bw, dry, (hipStream_t)stream); \
     done = true;                                                                                               \
   }
 
@@ -1229,7 +1270,8 @@ extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int 
 // shared by the launch and by the statistics-rows query: returns the number of partial rows per group the chosen kernel
 // writes (0: this shape does not support fused statistics, e.g. split-K), or a negative error
 static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout,
-                          int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream) {
+                          int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream,
+                          BwdCtx bw = BwdCtx{nullptr, nullptr, 0}) {
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
   bool done = false;
@@ -1274,6 +1316,24 @@ extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias,
 // (groups consecutive sample ranges).  rows = bcp_conv3_stat_rows(...) partial rows per group are written into
 // stat_partial[groups][rows][Cout][2] doubles; rows == 0 means "not available for this shape": run bcp_conv3_fwd and
 // let bcp_norm_fwd compute its own statistics.
+// dgrad + the statistics of the PREVIOUS layer's norm backward: da = conv(dy, wp_dgrad) (+= when accumulate), and
+// partial[g][row][C][2] = per-block (sum dz, sum dz * xhat) with dz = da * act'((yprev - mean) * scale + beta) -- hand the
+// partials to bcp_norm_bwd(partial_in, nb_in) instead of letting it re-read (yprev, da).  Shapes / rows: as
+// bcp_conv3_fwd_stats with (Cin, Cout) = (layer's Cout, layer's Cin); pstats = the stats tensor bcp_norm_fwd wrote for yprev.
+extern "C" int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout,
+                                        int KD, int accumulate, void* workspace, const float* yprev, const float* pstats, int act,
+                                        double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(dy && wp_dgrad && da && yprev && pstats && stat_partial, "bcp_conv3_dgrad_bwdstats: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0 && groups >= 1, "bcp_conv3_dgrad_bwdstats: bad extents");
+  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_dgrad_bwdstats: Cin=%d must be a multiple of 4", Cin);
+  BCP_REQUIRE(aligned16(dy) && aligned16(wp_dgrad), "bcp_conv3_dgrad_bwdstats: dy / wp must be 16-B aligned");
+  const int rc = conv3_fwd_impl(dy, wp_dgrad, nullptr, da, N, D, H, W, Cin, Cout, KD, accumulate, workspace, stat_partial, groups, false,
+                                stream, BwdCtx{yprev, pstats, act});
+  if (rc < 0) return rc;
+  BCP_REQUIRE(rc > 0, "bcp_conv3_dgrad_bwdstats: fused statistics unavailable for this shape (check bcp_conv3_stat_rows first)");
+  BCP_CHECK_LAUNCH("bcp_conv3_dgrad_bwdstats");
+  return BCP_OK;
+}
 extern "C" int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace) {
   if (Cin % 4 || Cin < 4 || groups < 1) return 0;
   static float dummy;

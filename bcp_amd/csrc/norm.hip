@@ -436,8 +436,8 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
 
 extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats,
                             int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
-                            float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy,
-                            void* stream) {
+                            float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                            const double* partial_in, int nb_in, float* dy, void* stream) {
   if (int rc = check_norm_args("bcp_norm_bwd", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(y && da && stats && workspace && dy, "bcp_norm_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -452,10 +452,16 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   float* c1 = reinterpret_cast<float*>(partial + (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2);
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
-  hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
-                     C, partial);
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
-                     dbeta, accumulate, c1, c2, raw);
+  if (partial_in) {   // (sum dz, sum dz * xhat) partials came out of the dgrad conv's epilogue (bcp_conv3_dgrad_bwdstats)
+    BCP_REQUIRE(!chan_scale && !elem_mask && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
+    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
+                       dbeta, accumulate, c1, c2, raw);
+  } else {
+    hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
+                       C, partial);
+    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
+                       dbeta, accumulate, c1, c2, raw);
+  }
   hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da, scale, shift, mean,
                      rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate);
   BCP_CHECK_LAUNCH("bcp_norm_bwd");

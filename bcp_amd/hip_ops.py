@@ -208,7 +208,7 @@ class Ops:
         return dst
 
     def norm_bwd(self, y, da, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
-                 elem_scale=1.0, out=None):
+                 elem_scale=1.0, out=None, partial=None, nb=0):
         self._chk(y, da, stats, dgamma, dbeta, chan_scale, elem_mask)
         N = y.shape[0]
         Cc = y.shape[-1]
@@ -220,7 +220,7 @@ class Ops:
         if out is None:
             out = torch.empty_like(y)
         self.b.call("bcp_norm_bwd", _p(y), _p(da), G, rpg, Cc, _p(stats), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale),
-                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(out), self.stream(y))
+                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(partial), int(nb), _p(out), self.stream(y))
         return out
 
     # ------------------------------------------------------------------ 3x3(x3) conv
@@ -262,6 +262,22 @@ class Ops:
         part = self.workspace(("statpart", rows), groups * rows * Cout * 16, x)
         self.b.call("bcp_conv3_fwd_stats", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, _p(ws), _p(part), groups, self.stream(x))
         return out, part, rows
+
+    def conv3_dgrad_bwdstats(self, dy, wp_dgrad, Cin_out, KD, yprev, pstats, act, groups):
+        """dgrad + the previous layer's norm-backward statistics -> (da, partial, rows); rows == 0: not fused for this
+        shape (plain dgrad, partial None).  yprev / pstats: the previous layer's pre-norm output and its stats[5,G,C]."""
+        self._chk(dy, wp_dgrad, yprev, pstats)
+        N, D, H, W, Cin = dy.shape
+        nbytes = self._ws_bytes("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cin, Cin_out, KD)
+        rows = self._ws_bytes("bcp_conv3_stat_rows", N, D, H, W, Cin, Cin_out, KD, groups, 1 if nbytes else 0)
+        if rows == 0:
+            return self.conv3_fwd(dy, wp_dgrad, None, Cin_out, KD), None, 0
+        ws = self.workspace("conv3", nbytes, dy) if nbytes else None
+        da = torch.empty((N, D, H, W, Cin_out), dtype=torch.float32, device=dy.device)
+        part = self.workspace(("bstatpart", rows), groups * rows * Cin_out * 16, dy)
+        self.b.call("bcp_conv3_dgrad_bwdstats", _p(dy), _p(wp_dgrad), _p(da), N, D, H, W, Cin, Cin_out, KD, 0, _p(ws), _p(yprev), _p(pstats),
+                    int(act), _p(part), groups, self.stream(dy))
+        return da, part, rows
 
     def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):
         """dw: torch-layout gradient tensor [Cout,Cin,(3,)3,3], written (or += when accumulate)"""

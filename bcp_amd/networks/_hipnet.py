@@ -362,6 +362,7 @@ class HipNet(nn.Module):
             return False
 
     overlap_wgrad = True
+    fuse_bwd_stats = True      # norm-backward statistics in the dgrad conv epilogue (bcp_conv3_dgrad_bwdstats)
     _side_streams = {}
 
     def _wgrad_stream(self, *tensors):

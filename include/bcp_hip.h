@@ -89,7 +89,9 @@ int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const f
                  const double* partial_in_or_null /* [G][nb_in][C][2] from bcp_conv3_fwd_stats */, int nb_in, float* out, void* stream);
 int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
                  const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
-                 float* dbeta, int accumulate, void* workspace, float* dy, void* stream);
+                 float* dbeta, int accumulate, void* workspace, const double* partial_in_or_null, int nb_in, float* dy, void* stream);
+/* partial_in: (sum dz, sum dz*xhat) partials [G][nb_in][C][2] produced by bcp_conv3_dgrad_bwdstats -- the statistics pass
+ * over (y, da) is skipped (not available together with chan_scale / elem_mask). */
 
 /* ---- 3x3x3 / 3x3 convolution, pad 1 (nn.Conv3d networks/VNet.py:17, nn.Conv2d networks/unet.py:19-25) on fp32 MFMA.
  *      KD = 3 (3-D) or 1 (2-D, D = 1).  Weights are packed once per optimizer step from the torch layout
@@ -107,6 +109,12 @@ int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, fl
 /* fused variant: the conv epilogue also emits the (sum, sum^2) partials of y that bcp_norm_fwd needs, for `groups`
  * consecutive sample ranges; rows = bcp_conv3_stat_rows(...) (0: unavailable for this shape -> use bcp_conv3_fwd);
  * stat_partial = double[groups][rows][Cout][2], handed to bcp_norm_fwd as partial_in with nb_in = rows. */
+/* dgrad of layer L+1 fused with the statistics of layer L's norm backward: da = conv(dy, wp_dgrad) and partial[g][row][C][2] =
+ * (sum dz, sum dz * xhat), dz = da * act'((yprev - mean) * scale + beta); (Cin, Cout) here = (layer L+1's Cout, its Cin = C of
+ * yprev); pstats = the float[5][G][C] tensor bcp_norm_fwd wrote for yprev; rows as bcp_conv3_stat_rows. */
+int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout, int KD,
+                             int accumulate, void* workspace_or_null, const float* yprev, const float* pstats, int act,
+                             double* stat_partial, int groups, void* stream);
 int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace);
 int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin,
                         int Cout, int KD, void* workspace_or_null, double* stat_partial, int groups, void* stream);

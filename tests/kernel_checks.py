@@ -473,6 +473,43 @@ def check_conv3_res(ops, dev):
     check_conv3(ops, dev, cases=CONV3_RES_CASES[:2])
 
 
+def check_conv3_bwdstats(ops, dev):
+    """dgrad epilogue statistics: the partial rows sum to (sum dz, sum dz*xhat) of the previous layer's norm backward,
+    da equals the plain dgrad, and bcp_norm_bwd(partial_in) == bcp_norm_bwd on (y, da)"""
+    import os
+    rng = np.random.default_rng(21)
+    for (N, C0, C1, sp, KD, G, P, act) in ((2, 16, 16, (16, 16, 48), 3, 2, "5", H.ACT_RELU), (2, 16, 16, (16, 16, 48), 3, 2, "8", H.ACT_RELU),
+                                           (4, 32, 32, (8, 12, 20), 3, 2, "16", H.ACT_RELU), (2, 32, 16, (1, 40, 48), 1, 2, None, H.ACT_LRELU),
+                                           (2, 16, 16, (6, 5, 9), 3, 1, None, H.ACT_RELU), (2, 32, 32, (8, 8, 8), 3, 2, None, H.ACT_RELU)):
+        two_d = KD == 1
+        xs = sp[1:] if two_d else sp
+        # previous layer: y_prev [N, C0, ...] -> norm (G groups) -> act -> a; this layer: conv C0 -> C1; dy arrives for it
+        yprev = (R(rng, N, C0, *xs) * 1.3 + 0.2)
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, C0).astype(np.float32))
+        beta = torch.from_numpy(rng.uniform(-0.3, 0.3, C0).astype(np.float32))
+        w = R(rng, C1, C0, *((3, 3) if two_d else (3, 3, 3))) * 0.1
+        dy = R(rng, N, C1, *xs)
+        ycl = to_cl(yprev).to(dev)
+        a, stats = ops.norm_fwd(ycl, G, gamma.to(dev), beta.to(dev), torch.zeros(C0).to(dev), torch.ones(C0).to(dev), act)
+        _, wd = ops.conv3_pack(w.to(dev).contiguous(), KD)
+        dycl = to_cl(dy).to(dev)
+        da_plain = ops.conv3_fwd(dycl, wd, None, C0, KD)
+        if P:
+            os.environ["BCP_CONV3_P"] = P
+        try:
+            da, part, rows = ops.conv3_dgrad_bwdstats(dycl, wd, C0, KD, ycl, stats, act, G)
+        finally:
+            os.environ.pop("BCP_CONV3_P", None)
+        assert rows > 0, f"shape {sp} must support fused backward statistics"
+        assert torch.equal(da.cpu(), da_plain.cpu()), "fused dgrad must be bit-identical to the plain dgrad"
+        dg0, db0 = torch.zeros(C0).to(dev), torch.zeros(C0).to(dev)
+        dg1, db1 = torch.zeros(C0).to(dev), torch.zeros(C0).to(dev)
+        d_ref = ops.norm_bwd(ycl, da_plain, G, stats, act, dg0, db0, False)
+        d_fus = ops.norm_bwd(ycl, da, G, stats, act, dg1, db1, False, partial=part, nb=rows)
+        close(d_fus, d_ref, rtol=2e-6, msg=f"norm_bwd with fused statistics {sp} G={G}")
+        close(dg1, dg0, rtol=2e-6, msg="dgamma"); close(db1, db0, rtol=2e-6, msg="dbeta")
+
+
 def check_conv3_stats(ops, dev):
     """fused epilogue statistics: sum over the partial rows == per-group column sums / sums of squares of y"""
     import os
@@ -532,4 +569,4 @@ def check_augment(ops, dev, golden_dir):
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"])
 
 
-ALL_CHECKS = ("augment", "pack_many", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
