@@ -17,6 +17,7 @@ from bcp_amd import train_step
 from bcp_amd.dataloaders.dataset import SyntheticACDC, TwoStreamBatchSampler, batches
 from bcp_amd.networks.net_factory import BCP_net
 from bcp_amd.train_step import acdc_mix_loss as mix_loss, generate_mask, get_ACDC_masks, update_model_ema
+from bcp_amd.utils import val_2d
 
 parser = argparse.ArgumentParser()
 parser.add_argument('--root_path', type=str, default='/data/byh_data/SSNet_data/ACDC', help='Name of Experiment')
@@ -41,6 +42,8 @@ parser.add_argument('--consistency_rampup', type=float, default=200.0, help='con
 parser.add_argument('--magnitude', type=float, default='6.0', help='magnitude')
 parser.add_argument('--s_param', type=int, default=6, help='multinum of random masks')
 parser.add_argument('--log_every', type=int, default=50)
+parser.add_argument('--val_every', type=int, default=200, help='validation cadence (ACDC_BCP_train.py:273,402: every 200 iterations)')
+parser.add_argument('--val_cases', type=int, default=2, help='synthetic validation volumes (the reference walks its val list)')
 
 
 def patients_to_slices(dataset, patiens_num):
@@ -71,6 +74,25 @@ def _loader(args, device):
     return db_train, TwoStreamBatchSampler(labeled_idxs, unlabeled_idxs, args.batch_size, args.batch_size - args.labeled_bs)
 
 
+def _val_set(args, device):
+    """stand-in for BaseDataSets(split='val'): volumes of 8 slices at the training resolution"""
+    from bcp_amd import synth
+    out = []
+    for i in range(args.val_cases):
+        vols, labs = synth.acdc_batch(8, shape=tuple(args.patch_size), seed=args.seed + 500 + i)
+        out.append((vols[:, 0].unsqueeze(0).to(device), labs.unsqueeze(0).to(device)))       # [1,S,X,Y]
+    return out
+
+
+def _validate(model, val_set, num_classes):
+    """ACDC_BCP_train.py:274-283: per-class (dice, hd95) averaged over the validation volumes -> mean Dice"""
+    metric_list = 0.0
+    for image, label in val_set:
+        metric_list = metric_list + np.array(val_2d.test_single_volume(image, label, model, classes=num_classes), dtype=np.float64)
+    metric_list = metric_list / max(len(val_set), 1)
+    return float(np.mean(metric_list, axis=0)[0])
+
+
 def pre_train(args, snapshot_path, device):
     labeled_sub_bs = int(args.labeled_bs / 2)
     model = BCP_net(in_chns=1, class_num=args.num_classes)
@@ -78,6 +100,8 @@ def pre_train(args, snapshot_path, device):
     optimizer = train_step.FlatSGD(model, lr=args.base_lr, momentum=0.9, weight_decay=0.0001)
     model.train()
     iter_num = 0
+    best_performance = 0.0
+    val_set = _val_set(args, device) if args.val_every > 0 else []
     while iter_num < args.pre_iterations:
         for sampled_batch in batches(db_train, batch_sampler):
             volume_batch, label_batch = sampled_batch['image'], sampled_batch['label']
@@ -95,9 +119,17 @@ def pre_train(args, snapshot_path, device):
             iter_num += 1
             if iter_num % args.log_every == 0:
                 logging.info('iteration %d: loss: %f, mix_dice: %f, mix_ce: %f' % (iter_num, loss, loss_dice, loss_ce))
+            if args.val_every > 0 and iter_num % args.val_every == 0:            # ACDC_BCP_train.py:273-295
+                performance = _validate(model, val_set, args.num_classes)
+                if performance > best_performance:
+                    best_performance = performance
+                    save_net_opt(model, optimizer, os.path.join(snapshot_path, 'iter_{}_dice_{}.pth'.format(iter_num, round(best_performance, 4))))
+                    save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
+                logging.info('iteration %d : mean_dice : %f' % (iter_num, performance))
             if iter_num >= args.pre_iterations:
                 break
-    save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
+    if best_performance == 0.0:
+        save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
 
 
 def self_train(args, pre_snapshot_path, snapshot_path, device):
@@ -112,6 +144,8 @@ def self_train(args, pre_snapshot_path, snapshot_path, device):
     model.train()
     ema_model.train()
     iter_num = 0
+    best_performance = 0.0
+    val_set = _val_set(args, device) if args.val_every > 0 else []
     while iter_num < args.max_iterations:
         for sampled_batch in batches(db_train, batch_sampler):
             volume_batch, label_batch = sampled_batch['image'], sampled_batch['label']
@@ -140,9 +174,17 @@ def self_train(args, pre_snapshot_path, snapshot_path, device):
             update_model_ema(model, ema_model, 0.99)
             if iter_num % args.log_every == 0:
                 logging.info('iteration %d: loss: %f, mix_dice: %f, mix_ce: %f' % (iter_num, loss, loss_dice, loss_ce))
+            if args.val_every > 0 and iter_num % args.val_every == 0:            # ACDC_BCP_train.py:402-424
+                performance = _validate(model, val_set, args.num_classes)
+                if performance > best_performance:
+                    best_performance = performance
+                    torch.save(model.state_dict(), os.path.join(snapshot_path, 'iter_{}_dice_{}.pth'.format(iter_num, round(best_performance, 4))))
+                    torch.save(model.state_dict(), os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
+                logging.info('iteration %d : mean_dice : %f' % (iter_num, performance))
             if iter_num >= args.max_iterations:
                 break
-    torch.save(model.state_dict(), os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
+    if best_performance == 0.0:
+        torch.save(model.state_dict(), os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
 
 
 def main(argv=None):

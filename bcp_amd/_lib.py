@@ -77,7 +77,7 @@ _SIGS = {
     "bcp_norm_eval": (I, [P, L, I, P, P, P, P, F, I, P, P, P]),
     "bcp_sw_accumulate": (I, [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P]),
     "bcp_sw_finish": (I, [P, P, P, L, F, P]),
-    "bcp_overlap_counts": (I, [P, P, L, P, P]),
+    "bcp_overlap_counts": (I, [P, P, L, I, P, P]),
     "bcp_crop_rotflip": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
     "bcp_cast": (I, [P, P, L, I, P]),
     "bcp_axpy": (I, [P, P, L, F, P]),

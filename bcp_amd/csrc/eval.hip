@@ -67,12 +67,12 @@ __global__ __launch_bounds__(256) void k_sw_finish(float* __restrict__ score, co
   }
 }
 
-// counts[0] = |A & B|, counts[1] = |A|, counts[2] = |B|   (A = pred != 0, B = gt != 0); integer atomics: deterministic
-__global__ __launch_bounds__(256) void k_overlap_counts(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, long long n,
+// counts[0] = |A & B|, counts[1] = |A|, counts[2] = |B|   (A = pred != 0, B = gt != 0, or == cls when cls > 0); integer atomics: deterministic
+__global__ __launch_bounds__(256) void k_overlap_counts(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, long long n, int cls,
                                                         unsigned long long* __restrict__ counts) {
   unsigned long long c0 = 0, c1 = 0, c2 = 0;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const bool x = a[i] != 0, y = b[i] != 0;
+    const bool x = cls ? a[i] == cls : a[i] != 0, y = cls ? b[i] == cls : b[i] != 0;
     c0 += (x && y); c1 += x; c2 += y;
   }
   c0 = wave_sum(c0); c1 = wave_sum(c1); c2 = wave_sum(c2);
@@ -121,10 +121,10 @@ extern "C" int bcp_sw_finish(float* score, const float* cnt, uint8_t* label, lon
 }
 
 // counts: device uint64[3], zeroed here
-extern "C" int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, unsigned long long* counts, void* stream) {
-  BCP_REQUIRE(pred && gt && counts && n > 0, "bcp_overlap_counts: bad argument");
+extern "C" int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, int cls, unsigned long long* counts, void* stream) {
+  BCP_REQUIRE(pred && gt && counts && n > 0 && cls >= 0 && cls < 256, "bcp_overlap_counts: bad argument");
   hipMemsetAsync(counts, 0, 3 * sizeof(unsigned long long), (hipStream_t)stream);
-  hipLaunchKernelGGL(k_overlap_counts, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, counts);
+  hipLaunchKernelGGL(k_overlap_counts, dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, pred, gt, n, cls, counts);
   BCP_CHECK_LAUNCH("bcp_overlap_counts");
   return BCP_OK;
 }

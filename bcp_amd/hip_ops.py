@@ -190,11 +190,11 @@ class Ops:
         self.b.call("bcp_sw_finish", _p(score), _p(cnt), _p(label), score.numel(), float(thres), self.stream(score))
         return label
 
-    def overlap_counts(self, pred, gt):
-        """-> int64[3] device tensor {|A & B|, |A|, |B|} of two uint8 masks"""
+    def overlap_counts(self, pred, gt, cls=0):
+        """-> int64[3] device tensor {|A & B|, |A|, |B|} of two uint8 maps (A = pred != 0 / == cls, B = gt likewise)"""
         self._chk(pred, gt)
         counts = torch.empty(3, dtype=torch.int64, device=pred.device)
-        self.b.call("bcp_overlap_counts", _p(pred), _p(gt), pred.numel(), _p(counts), self.stream(pred))
+        self.b.call("bcp_overlap_counts", _p(pred), _p(gt), pred.numel(), int(cls), _p(counts), self.stream(pred))
         return counts
 
     def crop_rotflip(self, src, patch, k, flip_axis, pads, origin):

@@ -86,7 +86,7 @@ def dice_jaccard(pred, gt):
         device = pred.device if isinstance(pred, torch.Tensor) else (gt.device if isinstance(gt, torch.Tensor) else torch.device("cpu"))
     p = _to_dev(pred, device, torch.uint8).contiguous()
     g = (_to_dev(gt, device, torch.float32) != 0).to(torch.uint8).contiguous()
-    c = _ops_for(p).overlap_counts(p, g).tolist()     # the only host read of the validation pass
+    c = _ops_for(p).overlap_counts(p, g, 0).tolist()     # the only host read of the validation pass
     inter, a, b = c
     dc = 2.0 * inter / (a + b) if (a + b) > 0 else 0.0
     jc = inter / (a + b - inter) if (a + b - inter) > 0 else 0.0

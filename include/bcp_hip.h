@@ -180,7 +180,8 @@ int bcp_norm_eval(const float* y, long long rows, int C, const float* gamma_or_n
 int bcp_sw_accumulate(const float* logits_patch, float* score, float* cnt, int X, int Y, int Z, int px, int py, int pz, int x0, int y0,
                       int z0, int C, int cls, void* stream);
 int bcp_sw_finish(float* score, const float* cnt, uint8_t* label, long long n, float thres, void* stream);
-int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, unsigned long long* counts, void* stream);
+int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, int cls /* 0: != 0; > 0: == cls */, unsigned long long* counts,
+                       void* stream);
 
 /* ---- device-side input pipeline, LA: RandomRotFlip + RandomCrop of dataloaders/dataset.py:52-59,173-214 as one
  *      gather: dst[P0][P1][P2] = pad(flip(rot90(src[n0][n1][n2], k, axes=(0,1)), flip_axis), (pw,ph,pd))[w1:, h1:, d1:];

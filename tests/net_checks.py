@@ -356,3 +356,33 @@ def check_unet_eval(ops, dev, seed=5):
     for k, v in net.state_dict().items():
         if "running" in k:
             assert torch.equal(v, sd0[k]), k
+
+
+def check_val_2d(ops, dev, seed=9):
+    """utils/val_2d.py:test_single_volume counterpart: eval-mode U-Net over a volume's slices, per-class Dice vs the oracle
+    (torch eval forward + argmax + numpy Dice), device path (slice size == patch size) and host-zoom path"""
+    from bcp_amd.utils import val_2d as V
+    rng = np.random.default_rng(seed)
+    P = O.init_params(O.unet_param_shapes(), seed=seed + 50, random_affine=True)
+    for k in P:
+        if k.endswith("running_mean"):
+            P[k] = torch.from_numpy(rng.normal(0.0, 0.2, tuple(P[k].shape)).astype(np.float32))
+        elif k.endswith("running_var"):
+            P[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(P[k].shape)).astype(np.float32))
+    net = make_unet(P, dev, ops)
+    for shape, patch in (((5, 32, 48), (32, 48)), ((3, 24, 40), (32, 48))):
+        image = torch.from_numpy(rng.standard_normal((1,) + shape, dtype=np.float32))
+        label = torch.from_numpy(rng.integers(0, 4, (1,) + shape).astype(np.uint8))
+        got = V.test_single_volume(image, label, net, 4, patch_size=patch, batch=2)
+        # oracle: the reference's loop (val_2d.py:20-40) with the oracle's eval-mode forward
+        from scipy.ndimage import zoom
+        pred = np.zeros(shape, dtype=np.uint8)
+        for i in range(shape[0]):
+            sl = zoom(image[0, i].numpy(), (patch[0] / shape[1], patch[1] / shape[2]), order=0)
+            out = O.unet_forward({k: v.clone() for k, v in P.items()}, torch.from_numpy(sl)[None, None], None, train=False)
+            o = torch.argmax(torch.softmax(out, dim=1), dim=1)[0].numpy()
+            pred[i] = zoom(o, (shape[1] / patch[0], shape[2] / patch[1]), order=0)
+        for c in range(1, 4):
+            ref = O.dice_binary(pred == c, label[0].numpy() == c) if (pred == c).sum() > 0 else 0
+            assert abs(got[c - 1][0] - ref) < 5e-3, (shape, c, got[c - 1][0], ref)   # a logit tie may flip a pixel
+    assert net.training

@@ -32,3 +32,7 @@ def test_acdc_self_train_trajectory(emu_ops, golden_dir):
 
 def test_unet_eval_mode(emu_ops):
     NC.check_unet_eval(emu_ops, CPU)
+
+
+def test_val_2d_single_volume(emu_ops):
+    NC.check_val_2d(emu_ops, CPU)

@@ -19,7 +19,8 @@ def test_la_script(tmp_path, monkeypatch):
 def test_acdc_script(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     from bcp_amd import ACDC_BCP_train as T
-    T.main(["--labelnum", "7", "--batch_size", "24", "--labeled_bs", "12", "--pre_iterations", "3", "--max_iterations", "3", "--log_every", "1"])
+    T.main(["--labelnum", "7", "--batch_size", "24", "--labeled_bs", "12", "--pre_iterations", "3", "--max_iterations", "3", "--log_every", "1",
+            "--val_every", "2", "--val_cases", "1"])
     sd = torch.load(tmp_path / "model/BCP/ACDC_BCP_7_labeled/self_train/unet_best_model.pth")
     assert len(sd) == 226 and all(torch.isfinite(v.float()).all() for v in sd.values())
 

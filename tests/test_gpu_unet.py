@@ -63,3 +63,7 @@ def test_unet_full_shape_vs_reference_golden(ops, golden_dir):
 
 def test_unet_eval_mode(ops):
     NC.check_unet_eval(ops, DEV)
+
+
+def test_val_2d_single_volume(ops):
+    NC.check_val_2d(ops, DEV)
