@@ -13,12 +13,13 @@ dev = torch.device("cuda:0")
 which = sys.argv[1] if len(sys.argv) > 1 else "16"
 shapes = {"16": (16, (112, 112, 80)), "32": (32, (56, 56, 40)), "64": (64, (28, 28, 20)), "128": (128, (14, 14, 10)), "256": (256, (7, 7, 5))}
 C, sp = shapes[which]
-x = torch.randn(1, *sp, C, device=dev)
-dy = torch.randn(1, *sp, C, device=dev)
+NB = 2   # the in-step launch shape: grouped batch of 2
+x = torch.randn(NB, *sp, C, device=dev)
+dy = torch.randn(NB, *sp, C, device=dev)
 w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
 b = torch.zeros(C, device=dev)
 wf, wd = ops.conv3_pack(w, 3)
-y = torch.empty(1, *sp, C, device=dev)
+y = torch.empty(NB, *sp, C, device=dev)
 dw = torch.empty_like(w)
 for _ in range(5):
     ops.conv3_fwd(x, wf, b, C, 3, out=y)
