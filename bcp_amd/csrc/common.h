@@ -36,6 +36,14 @@ void set_error(const char* fmt, ...);
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: a wave with global loads in
+// flight (the helper waves of k_conv3_ws prefetching the next halo) would park at the barrier for a full HBM round trip and
+// hold every other wave of the workgroup with it.  Here the wave waits for its own LDS operations (lgkmcnt) and joins the
+// barrier; registers being filled by outstanding global loads are private and need no fence.
+#ifndef BCP_LDS_BARRIER
+#define BCP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 // ---- wavefront (64-lane) reductions; every lane of the wave must call.
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

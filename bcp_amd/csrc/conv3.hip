@@ -32,6 +32,7 @@ static constexpr int XSW = 20;   // measured: 16 (conflict-free b32 reads) is 6 
 // Measurement-only ablation switches for tools/ablate_conv.py (what bounds k_conv3_res?); the product build has 0.
 //   1: no global halo prefetch   2: no epilogue stores / statistics   4: no LDS halo refill + barriers
 //   8: A fragments not re-read from LDS per tap   16: B fragments not re-read per tap   256: linear (not XCD-aware) tile order
+//   ws: 8192: MFMA waves do not re-read operands   16384: helper waves idle
 //   wgrad: 512: no global fetch   1024: no LDS refill + barriers   2048 / 4096: A / B operand address not advanced
 #ifndef BCP_ABLATE
 #define BCP_ABLATE 0
@@ -88,18 +89,24 @@ struct HaloFetch {
   unsigned grel[NP];
   float* lds;
 
-  __device__ __forceinline__ void init(const ConvDims& cd, float* Xs) {
-    r0 = threadIdx.x / RW;
-    const int col = threadIdx.x - r0 * RW;
+  __device__ __forceinline__ void init(const ConvDims& cd, float* Xs, int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;      // 256 fetching threads; the wave-specialised kernel passes its helper-local id
+    r0 = tid / RW;
+    const int col = tid - r0 * RW;
     hw = col >> 2;
     part = col & 3;
-    act = (int)threadIdx.x < RPP * RW;
+    act = tid < RPP * RW;
 #pragma unroll
     for (int u = 0; u < NP; ++u) {
       const int row = u * RPP + r0, hd = row / TL::HH, hh = row - hd * TL::HH;
       grel[u] = (unsigned)(((hd * cd.H + hh) * cd.W + hw) * cd.Cin + part * 4);
     }
     lds = Xs + (r0 * TL::HW + hw) * XSP + part * 4;
+  }
+  __device__ __forceinline__ void stash_to(float* Xbuf, const float* Xbase, const float4 (&pre)[NP]) const {   // other halo buffer
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (act && u * RPP + r0 < HR) st4(Xbuf + (lds - Xbase) + u * RPP * TL::HW * XSP, pre[u]);
   }
   // halo of the tile at (n, d0, h0, w0), cin chunk c -> registers; zero outside the volume / beyond Cin
   __device__ __forceinline__ void fetch(const float* __restrict__ X, const ConvDims& cd, int n, int d0, int h0, int w0, int c,
@@ -608,6 +615,223 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
     }
     tile = ntile;
     ch = nchk;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward / dgrad, WAVE-SPECIALISED resident variant (full tiles only).  Workgroup = 8 waves: waves 0-3 do nothing but
+// ds_read + MFMA on the current halo buffer; waves 4-7 ("helpers") do everything else underneath them -- fetch the next
+// work item's halo (global -> registers -> the OTHER LDS halo buffer) and write the previous tile's output (accumulators
+// handed over through an LDS staging tile, stored as 16-B-per-lane coalesced rows, bias / += / norm statistics applied
+// there).  In k_conv3_res the same four waves alternate between these phases and the phases of the two co-resident
+// workgroups do not hide under each other (measured: 2 vs 1 workgroup per CU = 6 %); here the matrix pipe of every SIMD has
+// one wave that never leaves the tap loop except for two barriers and 16 ds_writes per tile.
+// LDS: weights + 2 halo buffers + staging (152 KB for 16->16 with 4x4x16 tiles, 123 KB for 32->32 with 4x4x8): one
+// workgroup per CU.
+// ------------------------------------------------------------------------------------------------
+template <int KD, int TD, int TH, int TW, int NT>
+__global__ __launch_bounds__(512) void k_conv3_ws(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                  const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd, int n_tiles,
+                                                  int accumulate, StatsArg st) {
+  using TL = Tile<KD, TD, TH, TW>;
+  using HF = HaloFetch<TL>;
+  constexpr int MT = TL::MT, T = TL::T, CT = NT * 16, M = TL::M, NP = HF::NP;
+  constexpr int SS = CT + 4;                         // staging row stride (floats): 16-B aligned rows, 2-way conflicts at most
+  constexpr int C4 = CT / 4;                         // float4 columns of an output row
+  constexpr int NQ = (M * C4) / 256;                 // output float4s per helper thread
+  constexpr int NACC = (MT * NT == 1) ? 2 : 1;
+  static_assert((M * C4) % 256 == 0 && 256 % C4 == 0, "helper epilogue mapping");
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  float* smem = reinterpret_cast<float*>(smem4);
+  const int nch = cd.Cin16 >> 4;
+  float* Ws = smem;                                              // [nch][T][4][CT][4]
+  float* Xs0 = smem + (size_t)nch * T * 4 * CT * 4;              // [2][HV][XS]
+  float* Stg = Xs0 + 2 * TL::HV * XS;                            // [M][SS]
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int li = lane & 15, lg = lane >> 4;
+  const bool mma = wave < 4;
+  const int htid = tid - 256;
+  const int cout0 = blockIdx.y * CT;
+  const int cin4 = cd.Cin16 >> 2;
+
+  for (int q = tid; q < nch * T * 4 * CT; q += 512) {
+    const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
+    st4(Ws + (size_t)q * 4, ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
+  }
+
+  // ---- work list (same XCD-aware order as k_conv3_res)
+  int tile, t_end, t_step;
+  if (gridDim.x % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    t_step = gridDim.x >> 3;
+    tile = (int)((long long)n_tiles * xcd / 8) + j;
+    t_end = (int)((long long)n_tiles * (xcd + 1) / 8);
+  } else {
+    tile = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
+  }
+  if (tile >= t_end) return;
+
+  // ---- role state
+  int voff[MT];
+  f32x4 acc[NACC][MT][NT];
+  HF hf;
+  unsigned yoffh[NQ];
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+  if (mma) {
+    __builtin_amdgcn_s_setprio(3);   // the issue arbiter prefers the MFMA wave of a SIMD over its helper wave
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  } else {
+    hf.init(cd, Xs0, htid);
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int q = htid + u * 256, m = q / C4, c4 = q % C4;
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      yoffh[u] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + c4 * 4);
+    }
+    if (bias) bv = ld4(bias + cout0 + (htid % C4) * 4);
+  }
+
+  auto fetch = [&](int t, int c, float4 (&pre)[NP]) {
+    int n2, d2, h2, w2;
+    tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
+    hf.fetch(X, cd, n2, d2, h2, w2, c, pre);
+  };
+  // helper: write the staged tile `t` to global memory (full tiles only: uniform base + launch-invariant offsets)
+  int cur_g = st.partial ? tile / st.tiles_per_group : 0;
+  auto flush_stats = [&](int g) {          // one partial row per helper WAVE: rows = 4 * gridDim.x per group
+    double v[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
+    for (int off = C4; off < 64; off <<= 1) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += __shfl_xor(v[k], off);
+    }
+    if (lane < C4) {
+      double* dst = st.partial + (((long long)g * st.rows + blockIdx.x * 4 + (wave - 4)) * st.C + cout0 + lane * 4) * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { dst[k * 2] = v[k]; dst[k * 2 + 1] = v[4 + k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
+  };
+  auto store_tile = [&](int t) {
+    int n, d0, h0, w0;
+    tile_origin(cd, t, TD, TH, TW, n, d0, h0, w0);
+    if (st.partial && t / st.tiles_per_group != cur_g) { flush_stats(cur_g); cur_g = t / st.tiles_per_group; }
+    float* yb = Y + ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout + cout0;
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int q = htid + u * 256;
+      float4 v = ld4(Stg + (q / C4) * SS + (q % C4) * 4);
+      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+      float* p = yb + yoffh[u];
+      if (accumulate) { const float4 o = ld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+      st4(p, v);
+      if (st.partial) {
+        s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x; s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
+        s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z; s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+      }
+    }
+  };
+
+  // ---- prologue: first halo into buffer 0, second one in flight
+  int ch = 0, buf = 0;
+  float4 pre[NP];
+  if (!mma) {
+    fetch(tile, 0, pre);
+    hf.stash_to(Xs0, Xs0, pre);
+  }
+  __syncthreads();
+  int ntile = tile, nchk = 1;
+  if (nchk == nch) { nchk = 0; ntile = tile + t_step; }
+  bool has_next = ntile < t_end;
+  if (!mma && has_next) fetch(ntile, nchk, pre);
+  int staged_tile = -1;                    // tile whose accumulators sit in the staging buffer (uniform)
+
+  for (;;) {
+    if (mma) {
+      const float* Xc = Xs0 + buf * TL::HV * XS;
+      const float* Wc = Ws + (size_t)ch * T * 4 * CT * 4;
+      // the only MFMA wave of its SIMD: the next tap's fragments are read BEFORE this tap's MFMAs are issued, so the LDS
+      // round trip sits under 16 MFMAs instead of in front of them (sched_barrier keeps hipcc from sinking the reads)
+      float4 a[MT], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xc + voff[mt] + TL::tapoff(0) * XS);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wc + (lg * CT + nt * 16 + li) * 4);
+#pragma unroll 9
+      for (int tap = 0; tap < T; ++tap) {
+        float4 an[MT], bn[NT];
+        if (tap + 1 < T) {
+          const int toff = TL::tapoff(tap + 1) * XS;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) an[mt] = (BCP_ABLATE & 8192) ? a[mt] : ld4(Xc + voff[mt] + toff);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) bn[nt] = (BCP_ABLATE & 8192) ? b[nt] : ld4(Wc + (((tap + 1) * 4 + lg) * CT + nt * 16 + li) * 4);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < T) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
+        }
+      }
+    } else if (!(BCP_ABLATE & 16384)) {
+      if (staged_tile >= 0) store_tile(staged_tile);             // previous tile's output, underneath the MFMAs above
+      if (has_next) {
+        hf.stash_to(Xs0 + (buf ^ 1) * TL::HV * XS, Xs0, pre);    // next item's halo -> the other buffer
+        int t2 = ntile, c2 = nchk + 1;
+        if (c2 == nch) { c2 = 0; t2 = ntile + t_step; }
+        if (t2 < t_end) fetch(t2, c2, pre);                      // the item after that: in flight for a whole item
+      }
+    }
+    BCP_LDS_BARRIER();   // B2: helpers are done with the staging tile; the other halo buffer is filled (their global loads stay in flight)
+    const bool tile_done = ch == nch - 1;
+    if (mma && tile_done) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[0][mt][nt][r];
+            if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
+            Stg[((wave * MT + mt) * 16 + lg * 4 + r) * SS + nt * 16 + li] = v;
+          }
+#pragma unroll
+          for (int a = 0; a < NACC; ++a) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    staged_tile = tile_done ? tile : -1;
+    BCP_LDS_BARRIER();   // B1: staging visible to the helpers; everyone switches halo buffers
+    if (!has_next) break;
+    tile = ntile; ch = nchk; buf ^= 1;
+    nchk = ch + 1; ntile = tile;
+    if (nchk == nch) { nchk = 0; ntile = tile + t_step; }
+    has_next = ntile < t_end;
+  }
+  if (!mma) {
+    if (staged_tile >= 0) store_tile(staged_tile);
+    if (st.partial) flush_stats(cur_g);
   }
 }
 
@@ -1137,6 +1361,32 @@ static int launch_res(const float* X, const float* Wp, const float* bias, float*
 }
 
 template <int KD, int TD, int TH, int TW, int NT>
+static int launch_ws(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate,
+                     double* stat_partial, int G, bool dry, hipStream_t s) {
+  using TL = Tile<KD, TD, TH, TW>;
+  const int nch = cd.Cin16 / 16;
+  const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + 2 * (size_t)TL::HV * XS + (size_t)TL::M * (NT * 16 + 4)) * sizeof(float);
+  cd.tiles_d = cd.D / TD; cd.tiles_h = cd.H / TH; cd.tiles_w = cd.W / TW;      // full tiles only (checked by choose_ws)
+  const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+  const int slabs = cd.Cout16 / (NT * 16);
+  int P = 256 / slabs;                                                          // one 8-wave workgroup per CU
+  if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }
+  if (P < 1) P = 1;
+  if (P > tiles) P = tiles;
+  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
+  const bool stats_ok = G > 0 && tiles % G == 0;
+  if (dry) return stats_ok ? 4 * P : 0;
+  if (stats_ok && stat_partial) {
+    st.partial = stat_partial; st.rows = 4 * P; st.tiles_per_group = tiles / G;   // one partial row per helper wave
+    hipMemsetAsync(stat_partial, 0, (size_t)G * 4 * P * cd.Cout * 2 * sizeof(double), s);
+  }
+  auto kfn = k_conv3_ws<KD, TD, TH, TW, NT>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, dim3(P, slabs), dim3(512), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st);
+  return st.partial ? 4 * P : 0;
+}
+
+template <int KD, int TD, int TH, int TW, int NT>
 static int launch_wgrad(const float* X, const float* dY, float* partial, ConvDims cd, int groups, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int CT = NT * 16, YS = (CT % 32 == 0) ? CT + 16 : CT;
@@ -1261,6 +1511,40 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
   return false;
 }
 
+// wave-specialised variant: 16- / 32-channel-in layers whose volume is an exact multiple of the tile (no partial tiles) and
+// whose weights + two halo buffers + staging fit the LDS.  BCP_CONV3_WS=0 disables it (A/B measurements).
+static bool choose_ws(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, int Cout, int Cout16, bool bwd_stats) {
+  // Measured on the MI355X (16->16 @112x112x80): 143-148 us against 140-142 us for k_conv3_res, 9.64 vs 9.46 ms per LA step --
+  // moving the non-MFMA phases to helper waves does not free the matrix pipe (the isolated tap loop, tools/probe/
+  // mfma_lds_probe.hip, tops out at 122 / 134 TFLOP/s with 1 / 2 workgroups per CU and zero global traffic).  The kernel
+  // is therefore OFF by default: BCP_CONV3_WS=1 enables it, "force" (tests) also lifts the minimum problem size.
+  const char* e = getenv("BCP_CONV3_WS");
+  const bool enabled = e && (e[0] == '1' || e[0] == 'f'), force = e && e[0] == 'f';
+  if (!enabled || bwd_stats || Cout != Cout16 || Cin16 > 32) return false;
+  r.KD = KD; r.NT = 1; r.WT = 0;
+  const long long vox = (long long)N * D * H * W;
+  if (KD == 3) {
+    r.TD = 4; r.TH = 4;
+    r.TW = vox >= 256LL * 1024 ? 16 : (vox >= 64LL * 1024 ? 8 : 4);
+  } else {
+    r.TD = 1;
+    if (vox >= 128LL * 1024) { r.TH = 16; r.TW = 16; } else { r.TH = 8; r.TW = 8; }
+  }
+  if (D % r.TD || H % r.TH || W % r.TW) return false;
+  const int PD = KD == 3 ? 1 : 0;
+  const long long hv = (long long)(r.TD + 2 * PD) * (r.TH + 2) * (r.TW + 2), m = (long long)r.TD * r.TH * r.TW;
+  const long long lds = ((long long)KD * 9 * Cin16 * 16 + 2 * hv * XS + m * 20) * 4;
+  if (lds > 160 * 1024) return false;
+  const long long tiles = (long long)N * (D / r.TD) * (H / r.TH) * (W / r.TW);
+  return force || tiles * (Cout16 / 16) >= 512;      // >= 2 work items per workgroup
+}
+
+#define BCP_WS_CASE(KD_, TD_, TH_, TW_)                                                                        \
+  if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_) {                                              \
+    rows = launch_ws<KD_, TD_, TH_, TW_, 1>(x, wp, bias, y, cd, accumulate, stat_partial, G, dry, (hipStream_t)stream); \
+    done = true;                                                                                               \
+  }
+
 extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD) {
   // split-K partial slabs (only taken for grids of <= 256 blocks): at most 4 copies of the output
   const long long n = (long long)N * D * H * W * Cout;
@@ -1277,7 +1561,11 @@ static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, fl
   bool done = false;
   int rows = 0;
   Cfg r;
-  if (choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
+  if (choose_ws(r, KD, N, D, H, W, cd.Cin16, Cout, cd.Cout16, bw.yprev != nullptr)) {
+    BCP_WS_CASE(3, 4, 4, 16) BCP_WS_CASE(3, 4, 4, 8) BCP_WS_CASE(3, 4, 4, 4)
+    BCP_WS_CASE(1, 1, 16, 16) BCP_WS_CASE(1, 1, 8, 8)
+  }
+  if (!done && choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
     BCP_RES_CASE(3, 4, 4, 16, 1) BCP_RES_CASE(3, 4, 4, 16, 2)
     BCP_RES_CASE(3, 4, 4, 8, 1) BCP_RES_CASE(3, 4, 4, 8, 2) BCP_RES_CASE(3, 4, 4, 8, 4)
     BCP_RES_CASE(3, 4, 4, 4, 1) BCP_RES_CASE(3, 4, 4, 4, 2) BCP_RES_CASE(3, 4, 4, 4, 4)

@@ -461,6 +461,52 @@ def check_k2_chunks(ops, dev):
         del os.environ["BCP_TN_GROUPS"]
 
 
+CONV3_WS_CASES = (
+    (2, 16, 16, (8, 8, 32), 3),       # 4x4x4 tiles (small volume), 2 samples
+    (1, 16, 16, (4, 8, 48), 3),
+    (2, 32, 32, (8, 8, 16), 3),       # two cin chunks, two cout slabs
+    (1, 32, 16, (8, 12, 8), 3),
+    (2, 16, 16, (1, 16, 32), 1),      # 2-D, 8x8 tiles
+    (1, 16, 32, (1, 32, 16), 1),
+)
+
+
+def check_conv3_ws(ops, dev):
+    """wave-specialised resident kernel (4 MFMA waves + 4 helper waves per workgroup), forced on for small full-tile shapes;
+    few persistent workgroups so that each walks several (tile, chunk) items; fused statistics through the helper waves"""
+    import os
+    os.environ["BCP_CONV3_WS"] = "force"
+    try:
+        for P in ("3", "8", None):
+            if P:
+                os.environ["BCP_CONV3_P"] = P
+            try:
+                check_conv3(ops, dev, cases=CONV3_WS_CASES)
+            finally:
+                os.environ.pop("BCP_CONV3_P", None)
+        rng = np.random.default_rng(31)
+        for (N, Cin, Cout, sp, KD, G) in ((2, 16, 16, (8, 8, 32), 3, 2), (4, 32, 32, (8, 8, 16), 3, 2), (2, 16, 16, (1, 16, 32), 1, 1)):
+            two_d = KD == 1
+            x = R(rng, N, Cin, *(sp[1:] if two_d else sp))
+            w = R(rng, Cout, Cin, *((3, 3) if two_d else (3, 3, 3))) * 0.1
+            b = R(rng, Cout) * 0.1
+            y_ref = F.conv2d(x, w, b, padding=1) if two_d else F.conv3d(x, w, b, padding=1)
+            wf, _ = ops.conv3_pack(w.to(dev).contiguous(), KD)
+            os.environ["BCP_CONV3_P"] = "5"
+            try:
+                y, part, rows = ops.conv3_fwd_stats(to_cl(x).to(dev), wf, b.to(dev), Cout, KD, G)
+            finally:
+                os.environ.pop("BCP_CONV3_P", None)
+            close(from_cl(y, two_d), y_ref, msg="conv3_ws fwd_stats y")
+            assert rows == 20, rows          # 4 helper waves x 5 workgroups
+            pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
+            yg = y_ref.double().transpose(0, 1).reshape(Cout, G, -1)
+            close(pt[..., 0], yg.sum(2).t(), rtol=1e-6, msg="ws fused sum")
+            close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-6, msg="ws fused sum of squares")
+    finally:
+        os.environ.pop("BCP_CONV3_WS", None)
+
+
 def check_conv3_res(ops, dev):
     """resident-weight kernel, with the persistent grid forced small so every block walks several tiles"""
     import os
@@ -569,4 +615,4 @@ def check_augment(ops, dev, golden_dir):
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"])
 
 
-ALL_CHECKS = ("augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_ws", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")

@@ -30,6 +30,8 @@
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __shared__ static thread_local
+// LDS-only workgroup barrier of the product code (common.h): a plain barrier on the host
+#define BCP_LDS_BARRIER() ::bcpemu::block_sync()
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::bcpemu::dyn_lds());
 
 typedef void* hipStream_t;
