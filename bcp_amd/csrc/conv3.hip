@@ -21,11 +21,15 @@
 #include "common.h"
 #include "../../include/bcp_hip.h"
 #include <cstdlib>
+#include <cstdio>
 #include <type_traits>
 
 namespace bcp {
 
-static constexpr int XS = 20;  // LDS floats per halo voxel: 16 channels + 4 pad (16-B aligned rows)
+#ifndef BCP_XS
+#define BCP_XS 20
+#endif
+static constexpr int XS = BCP_XS;  // LDS floats per halo voxel: 16 channels + 4 pad (16-B aligned rows)
 // halo row stride of the wgrad kernel (ds_read_b32, lane (li = channel, lg = voxel))
 static constexpr int XSW = 20;   // measured: 16 (conflict-free b32 reads) is 6 % SLOWER at C=16 -- LDS conflicts are not what bounds wgrad
 
@@ -1432,6 +1436,12 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16, bool for_w
   while (nt > 1 && tiles * (Cout16 / (nt * 16)) < want) nt >>= 1;  // more blocks for small problems
   c.NT = nt;
   c.WT = 0;
+  if (!for_wgrad) {
+    if (const char* e = getenv("BCP_CONV3_CFG")) {   // measurements: "TD,TH,TW,NT" forces the streaming kernel's tile / slab width
+      int td, th, tw, n2;
+      if (sscanf(e, "%d,%d,%d,%d", &td, &th, &tw, &n2) == 4 && Cout16 % (n2 * 16) == 0) { c.TD = td; c.TH = th; c.TW = tw; c.NT = n2; }
+    }
+  }
   return c;
 }
 

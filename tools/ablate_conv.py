@@ -1,7 +1,10 @@
-"""Measurement only: time conv3 fwd at the V-Net layer shapes with each ablated library built by tools/ablate_conv.sh.
-   python tools/ablate_conv.py [C ...]"""
+"""Measurement only: A/B timing of conv3 fwd / wgrad at the V-Net layer shapes across library variants (the product library
+plus every tools/_abl/libbcp_abl_*.so built by tools/ablate_conv.sh or by hand with -D switches).  Variants are INTERLEAVED
+round-robin over several rounds and the median per variant is reported: back-to-back blocks of one variant each were biased by
+clock / thermal drift by +-5 %.   python tools/ablate_conv.py [C ...]"""
 import glob
 import os
+import statistics
 import sys
 
 import torch
@@ -12,34 +15,42 @@ from bcp_amd import _lib  # noqa: E402
 from bcp_amd.hip_ops import Ops  # noqa: E402
 
 dev = torch.device("cuda:0")
-shapes = {"16": (16, (112, 112, 80), 1), "32": (32, (56, 56, 40), 2), "64": (64, (28, 28, 20), 2), "128": (128, (14, 14, 10), 2), "256": (256, (7, 7, 5), 2)}
-which = sys.argv[1:] or ["16", "32"]
+shapes = {"16": (16, (112, 112, 80), 1), "16x2": (16, (112, 112, 80), 2), "32": (32, (56, 56, 40), 2), "64": (64, (28, 28, 20), 2),
+          "128": (128, (14, 14, 10), 2), "256": (256, (7, 7, 5), 2)}
+which = sys.argv[1:] or ["16x2", "32"]
 libs = [("product", _lib.LIB_PATH)] + sorted((os.path.basename(p)[11:-3], p) for p in glob.glob(os.path.join(ROOT, "tools", "_abl", "libbcp_abl_*.so")))
+ROUNDS, ITERS = 7, 10
 for wname in which:
     C, sp, N = shapes[wname]
     x = torch.randn(N, *sp, C, device=dev)
+    dy = torch.randn(N, *sp, C, device=dev)
     w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
     b = torch.zeros(C, device=dev)
     y = torch.empty(N, *sp, C, device=dev)
+    dw = torch.empty_like(w)
     flops = 2.0 * N * sp[0] * sp[1] * sp[2] * 27 * C * C
+    opsl = []
     for name, path in libs:
         ops = Ops(_lib.Binding(path), allow_cpu=False)
         wf, _ = ops.conv3_pack(w, 3)
+        opsl.append((name, ops, wf, ops.event(), ops.event()))
         for _ in range(3):
             ops.conv3_fwd(x, wf, b, C, 3, out=y)
-        e0, e1 = ops.event(), ops.event()
-        ops.event_record(e0, x)
-        for _ in range(20):
-            ops.conv3_fwd(x, wf, b, C, 3, out=y)
-        ops.event_record(e1, x)
-        ms = ops.event_elapsed_ms(e0, e1) / 20
-        dy = torch.randn(N, *sp, C, device=dev)
-        dw = torch.empty_like(w)
-        for _ in range(3):
             ops.conv3_wgrad(x, dy, dw, 3)
-        ops.event_record(e0, x)
-        for _ in range(20):
-            ops.conv3_wgrad(x, dy, dw, 3)
-        ops.event_record(e1, x)
-        msw = ops.event_elapsed_ms(e0, e1) / 20
-        print(f"C={C:3d} N={N} abl={name:8s} fwd {ms * 1e3:8.1f} us {flops / ms / 1e9:7.1f} TF/s | wgrad {msw * 1e3:8.1f} us {flops / msw / 1e9:7.1f} TF/s", flush=True)
+    tf, tw = {n: [] for n, *_ in opsl}, {n: [] for n, *_ in opsl}
+    for r in range(ROUNDS):
+        for name, ops, wf, e0, e1 in opsl:
+            ops.event_record(e0, x)
+            for _ in range(ITERS):
+                ops.conv3_fwd(x, wf, b, C, 3, out=y)
+            ops.event_record(e1, x)
+            tf[name].append(ops.event_elapsed_ms(e0, e1) / ITERS)
+            ops.event_record(e0, x)
+            for _ in range(ITERS):
+                ops.conv3_wgrad(x, dy, dw, 3)
+            ops.event_record(e1, x)
+            tw[name].append(ops.event_elapsed_ms(e0, e1) / ITERS)
+    for name, *_ in opsl:
+        mf, mw = statistics.median(tf[name]), statistics.median(tw[name])
+        print(f"C={C:3d} N={N} {name:10s} fwd {mf * 1e3:7.1f} us {flops / mf / 1e9:6.1f} TF/s (min {min(tf[name]) * 1e3:6.1f}) | "
+              f"wgrad {mw * 1e3:7.1f} us {flops / mw / 1e9:6.1f} TF/s (min {min(tw[name]) * 1e3:6.1f})", flush=True)
