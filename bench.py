@@ -73,13 +73,13 @@ def pmc_traffic():
     """HBM-side bytes per launch of the same kernel from the committed rocprofv3 --pmc passes (tools/collect_pmc.sh: FETCH_SIZE
     and WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams).  bench.py
     cannot run the profiler itself; null when the file is absent."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_conv3_c16_v2.json")
+    p = os.path.join(ROOT, "profiles", "r01_pmc_conv3_c16_v3.json")
     try:
         d = json.load(open(p))["k_conv3_res<3,4,4,16,1>"]
         return {"bytes_per_launch": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), "fetch_kb_raw": d["FETCH_SIZE"],
                 "write_kb": d["WRITE_SIZE"], "algorithmic_bytes": 2 * 2 * 1003520 * 16 * 4 + 27 * 16 * 16 * 4,
                 "mfma_busy_frac": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 4),
-                "source": "profiles/r01_pmc_conv3_c16_v2.json"}
+                "source": "profiles/r01_pmc_conv3_c16_v3.json"}
     except Exception:
         return None
 
