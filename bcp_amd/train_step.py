@@ -248,7 +248,7 @@ def update_model_ema(model, ema_model, alpha):
 
 
 def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
-                         u_weight=0.5, alpha=0.99, dp=None, grouped=True):
+                         u_weight=0.5, alpha=0.99, dp=None, grouped=True, overlap=True):
     """One ACDC self-training iteration, ACDC_BCP_train.py:355-390 (grouped: see la_self_train_step; needs
     labeled_bs == batch - labeled_bs so that both halves have equal size)."""
     bs = volume_batch.shape[0]
@@ -265,11 +265,20 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
             return None
         return {k: torch.cat([d1[k], d2[k]]) for k in d1}
 
+    side = _side_stream(volume_batch) if (grouped and overlap and volume_batch.is_cuda) else None
     with torch.no_grad():
         if grouped:
             ema_model.drop_masks = cat_drops("t_a", "t_b")
-            pre = ema_model(volume_batch[labeled_bs:], groups=2)
-            plab = get_ACDC_masks(pre, nms=1)
+            if side is not None:     # teacher forward -> pseudo-label -> per-class CC underneath the student forward (see la_self_train_step)
+                main = torch.cuda.current_stream(volume_batch.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    pre = ema_model(volume_batch[labeled_bs:], groups=2)
+                    plab = get_ACDC_masks(pre, nms=1)
+                plab.record_stream(main)
+            else:
+                pre = ema_model(volume_batch[labeled_bs:], groups=2)
+                plab = get_ACDC_masks(pre, nms=1)
             plab_a, plab_b = plab[:usub], plab[usub:]
         else:
             ema_model.drop_masks = drops.get("t_a")
@@ -289,6 +298,8 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
         BU.mix(img_b, uimg_b, img_mask, out=mixed[lsub:])      # net_input_l,   :373
         model.drop_masks = cat_drops("s_unl", "s_l")
         out = model(mixed, groups=2)
+        if side is not None:
+            torch.cuda.current_stream(volume_batch.device).wait_stream(side)   # pseudo-labels are needed from here on
         unl_dice, unl_ce, l_dice, l_ce = BU.mix_loss_pair(out, (plab_a, lab_a, u_weight, 1.0), (lab_b, plab_b, 1.0, u_weight), loss_mask,
                                                           flavour=H.LOSS_ACDC)
         out_unl, out_l = out[:lsub], out[lsub:]
