@@ -156,17 +156,37 @@ __global__ __launch_bounds__(256) void k_cc_count(const int* __restrict__ L, con
   }
 }
 
+// blockIdx.y = sample: every thread keeps a running maximum per class, the block reduces them (64-bit max over shuffles +
+// one LDS hop) and issues ONE atomicMax per class.  (Noise maps have ~10^5 roots; one atomic -- or even one racy read -- per
+// root on N * nclass hot words cost 0.43 ms per ACDC step.)
 __global__ __launch_bounds__(256) void k_cc_select(const uint8_t* __restrict__ seg, const int* __restrict__ L,
                                                    const int* __restrict__ size, unsigned long long* __restrict__ best, long long V,
                                                    long long n, int nclass) {
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
+  __shared__ unsigned long long red[4][8];
+  const int sample = blockIdx.y;
+  unsigned long long loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long base = (long long)sample * V;
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < V; r += (long long)gridDim.x * blockDim.x) {
+    const long long v = base + r;
     if (L[v] != (int)v) continue;  // global roots only
-    const int sample = (int)(v / V);
     const unsigned long long key = ((unsigned long long)(unsigned)size[v] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)v);
-    // noise maps have ~10^5 roots hammering N*nclass words: the running maximum only grows, so a plain (racy but
-    // monotone) read filters out almost every candidate before it becomes an atomic
-    unsigned long long* slot = &best[(long long)sample * nclass + (seg[v] - 1)];
-    if (key > *reinterpret_cast<volatile unsigned long long*>(slot)) atomicMax(slot, key);
+    const int c = seg[v] - 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k == c && key > loc[k]) loc[k] = key;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < nclass; ++k) {
+    unsigned long long m = loc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if (lane == 0) red[wave][k] = m;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nclass) {
+    unsigned long long m = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) m = red[w][threadIdx.x] > m ? red[w][threadIdx.x] : m;
+    if (m) atomicMax(&best[(long long)sample * nclass + threadIdx.x], m);
   }
 }
 
@@ -223,7 +243,11 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
     hipLaunchKernelGGL((k_cc_border<1, 16, 32>), dim3(grid), dim3(256), 0, s, seg, L, cd);
   }
   hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, L, lsize, size, n);
-  hipLaunchKernelGGL(k_cc_select, dim3(grid), dim3(256), 0, s, seg, L, size, best, V, n, nclass);
+  {
+    int gx = (int)((V + 255) / 256 / 4);      // ~4 voxels per thread
+    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    hipLaunchKernelGGL(k_cc_select, dim3(gx, N), dim3(256), 0, s, seg, L, size, best, V, n, nclass);
+  }
   hipLaunchKernelGGL(k_cc_write, dim3(grid), dim3(256), 0, s, seg, L, best, out_u8, out_f32, V, n, nclass);
   BCP_CHECK_LAUNCH("bcp_cc_largest");
   return BCP_OK;

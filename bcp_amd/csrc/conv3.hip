@@ -475,6 +475,15 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   } else {
     tile = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
   }
+  if (st.partial && (int)threadIdx.x < CT && cout0 + (int)threadIdx.x < cd.Cout) {
+    // a persistent workgroup only flushes the groups it visits: its rows of the other groups must read as zero.  Written
+    // here by the same threads that later flush (program order), instead of a hipMemsetAsync per conv launch (36 ten-
+    // microsecond fills per ACDC step on the critical path)
+    for (int g = 0; g < st.G; ++g) {
+      double* z = st.partial + (((long long)g * st.rows + blockIdx.x) * st.C + cout0 + threadIdx.x) * 2;
+      z[0] = 0.0; z[1] = 0.0;
+    }
+  }
   int ch = 0;
   if (tile >= t_end) return;
   double s1[NT], s2[NT];                             // fused norm statistics of the current group
@@ -1354,9 +1363,7 @@ static int launch_res(const float* X, const float* Wp, const float* bias, float*
   if (dry) return stats_ok ? P : 0;
   if (stats_ok && stat_partial) {
     st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G;
-    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;
-    // a persistent block only writes the groups it visited: start from zeros
-    hipMemsetAsync(stat_partial, 0, (size_t)G * P * cd.Cout * 2 * sizeof(double), s);
+    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;   // (rows of unvisited groups are zeroed by the kernel itself)
   }
   auto kfn = k_conv3_res<KD, TD, TH, TW, NT>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
