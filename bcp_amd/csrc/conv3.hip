@@ -269,10 +269,67 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
   const int nchunks = cd.Cin16 >> 4;
   const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
   Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
-  // One cin chunk at a time, halo and first weight stage loaded synchronously: latency is hidden by co-resident blocks.
-  // (A flat register-prefetch pipeline over (chunk, stage) items was measured SLOWER at the in-step batch of 2 -- 83 vs
-  // 77 us at C=64, 65 vs 57 us at C=128: its second weight buffer and prefetch registers cost more occupancy than the
-  // exposed latency they removed.)
+  // One cin chunk at a time.  With a single weight stage per chunk (S == 1: the deep 64-voxel-tile configurations, 8-16
+  // chunks per block) the NEXT chunk's halo and weights travel global -> registers underneath the MFMAs of the current
+  // chunk and are dropped into the SAME LDS buffers between two barriers -- no extra LDS, so the 3 workgroups per CU stay.
+  // (A first attempt that double-buffered the weight stage in LDS lost one resident workgroup per CU and was slower at the
+  // in-step batch of 2: 83 vs 77 us at C=64, 65 vs 57 us at C=128.)
+  if (S == 1) {
+    float4 hpre[HaloFetch<TL>::NP], wpre[NW4];
+    auto wfetch = [&](int cc) {
+#pragma unroll
+      for (int u = 0; u < NW4; ++u) {
+        const int q = threadIdx.x + u * 256;
+        if (q < WSTAGE4) {
+          const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
+          wpre[u] = ld4(Wp + ((((long long)tl * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
+        }
+      }
+    };
+    auto wstash = [&]() {
+#pragma unroll
+      for (int u = 0; u < NW4; ++u) {
+        const int q = threadIdx.x + u * 256;
+        if (q < WSTAGE4) st4(Ws + q * 4, wpre[u]);
+      }
+    };
+    hf.fetch(X, cd, n, d0, h0, w0, c_begin, hpre);
+    wfetch(c_begin);
+    hf.stash(hpre);
+    wstash();
+    __syncthreads();
+    for (int cc = c_begin; cc < c_end; ++cc) {
+      const bool has_next = cc + 1 < c_end;
+      if (has_next) {
+        hf.fetch(X, cd, n, d0, h0, w0, cc + 1, hpre);
+        wfetch(cc + 1);
+      }
+#pragma unroll (WT > 9 ? 9 : WT)
+      for (int tl = 0; tl < WT; ++tl) {
+        const int toff = TL::tapoff(tl) * XS;
+        float4 a[MT], b[NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + toff);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Ws + ((tl * 4 + lg) * CT + nt * 16 + li) * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
+            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
+            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
+          }
+      }
+      if (has_next) {
+        __syncthreads();
+        hf.stash(hpre);
+        wstash();
+        __syncthreads();
+      }
+    }
+  } else
   for (int cc = c_begin; cc < c_end; ++cc) {
     __syncthreads();  // everyone is done with the previous chunk's LDS contents
     {
