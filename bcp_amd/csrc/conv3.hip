@@ -1730,8 +1730,12 @@ static int wgrad_groups(const Cfg& c, int N, int D, int H, int W, int Cin16, int
 
 static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   Cfg c = choose_cfg(KD, N, D, H, W, Cout16, true);
-  // accumulators: TPW * NT * 4 regs (TPW = 7 for 27 taps) -> cap NT at 4; small problems keep NT from choose_cfg
-  if (c.NT > 4) c.NT = 4;
+  // accumulators: TPW * NT * 4 regs (TPW = 7 for 27 taps) -> cap NT at 4; small problems keep NT from choose_cfg.
+  // (Measured: forcing the widest slab at the deep levels -- more MFMAs per staged tile but fewer, longer blocks -- is
+  // slower: C=128 wgrad 82 / 85 / 106 us and C=256 57 / 58 / 65 us for NT = 1 / 2 / 4.)
+  int nt = c.NT > 4 ? 4 : c.NT;
+  if (const char* e = getenv("BCP_WGRAD_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && Cout16 % (v * 16) == 0) nt = v; }
+  c.NT = nt;
   return c;
 }
 
