@@ -1733,7 +1733,7 @@ static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   // accumulators: TPW * NT * 4 regs (TPW = 7 for 27 taps) -> cap NT at 4; small problems keep NT from choose_cfg.
   // (Measured: forcing the widest slab at the deep levels -- more MFMAs per staged tile but fewer, longer blocks -- is
   // slower: C=128 wgrad 82 / 85 / 106 us and C=256 57 / 58 / 65 us for NT = 1 / 2 / 4.)
-  int nt = c.NT > 4 ? 4 : c.NT;
+  int nt = c.NT > 2 ? 2 : c.NT;     // C=64: 75 us with 2-slab blocks vs 79 us with 4 (two workgroups per CU instead of one)
   if (const char* e = getenv("BCP_WGRAD_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && Cout16 % (v * 16) == 0) nt = v; }
   c.NT = nt;
   return c;
