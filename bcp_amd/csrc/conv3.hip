@@ -1572,7 +1572,9 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
   const int PD = KD == 3 ? 1 : 0;
   const long long hv = (long long)(r.TD + 2 * PD) * (r.TH + 2) * (r.TW + 2);
   const long long tiles = (long long)N * cdiv(D, r.TD) * cdiv(H, r.TH) * cdiv(W, r.TW);
-  for (int nt = 4; nt >= 1; nt >>= 1) {
+  int nt_max = 4;
+  if (const char* e = getenv("BCP_RES_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nt_max = v; }   // measurements
+  for (int nt = nt_max; nt >= 1; nt >>= 1) {
     if (Cout16 % (nt * 16)) continue;
     const long long lds = ((long long)KD * 9 * Cin16 * nt * 16 + hv * XS) * 4 + 4 * nt * 16 * 2 * 8;
     if (lds > 158 * 1024) continue;
