@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
       hf.fetch(X, cd, n, d0, h0, w0, cc, pre);
       hf.stash(pre);
     }
-    // weight stage 0 of this chunk
+    // weight stage 0 of this chunk  (an explicit loads-then-stores version was measured slower at C=64: 75.7 vs 70 us)
     for (int q = threadIdx.x; q < WSTAGE4; q += 256) {
       const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
       st4(Ws + q * 4, ld4(Wp + ((((long long)tl * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
@@ -478,10 +478,28 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   const int cout0 = blockIdx.y * CT;
   const int cin4 = cd.Cin16 >> 2;
 
-  // resident weights: Wp[tap][cin4][Cout16][4] -> Ws[chunk][tap][cig][co][4]
-  for (int q = threadIdx.x; q < nch * T * 4 * CT; q += 256) {
-    const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
-    st4(Ws + (size_t)q * 4, ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
+  // resident weights: Wp[tap][cin4][Cout16][4] -> Ws[chunk][tap][cig][co][4].  Eight loads in flight per thread before the
+  // first store: a load -> store loop pays one L2 round trip per iteration (7 for the 16->16 layer, 27 for 32->32 x 2 slabs)
+  // on every launch, with the matrix pipe idle
+  {
+    constexpr int WB = 8;
+    const int total = nch * T * 4 * CT;
+    for (int q0 = threadIdx.x; q0 < total; q0 += 256 * WB) {
+      float4 wv[WB];
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int q = q0 + u * 256;
+        if (q < total) {
+          const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
+          wv[u] = ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < WB; ++u) {
+        const int q = q0 + u * 256;
+        if (q < total) st4(Ws + (size_t)q * 4, wv[u]);
+      }
+    }
   }
 
   int voff[MT];
