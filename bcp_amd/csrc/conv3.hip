@@ -478,30 +478,6 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   const int cout0 = blockIdx.y * CT;
   const int cin4 = cd.Cin16 >> 2;
 
-  // resident weights: Wp[tap][cin4][Cout16][4] -> Ws[chunk][tap][cig][co][4].  Eight loads in flight per thread before the
-  // first store: a load -> store loop pays one L2 round trip per iteration (7 for the 16->16 layer, 27 for 32->32 x 2 slabs)
-  // on every launch, with the matrix pipe idle
-  {
-    constexpr int WB = 8;
-    const int total = nch * T * 4 * CT;
-    for (int q0 = threadIdx.x; q0 < total; q0 += 256 * WB) {
-      float4 wv[WB];
-#pragma unroll
-      for (int u = 0; u < WB; ++u) {
-        const int q = q0 + u * 256;
-        if (q < total) {
-          const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
-          wv[u] = ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < WB; ++u) {
-        const int q = q0 + u * 256;
-        if (q < total) st4(Ws + (size_t)q * 4, wv[u]);
-      }
-    }
-  }
-
   int voff[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
@@ -570,7 +546,30 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   for (int nt = 0; nt < NT; ++nt) kc[nt] = load_bwd_col(st, cur_g, cout0 + nt * 16 + li);
   {
     float4 pre[NP];
-    fetch(tile, 0, pre);
+    fetch(tile, 0, pre);     // first halo in flight while the weights below are fetched: one exposed round trip, not two
+    // resident weights: Wp[tap][cin4][Cout16][4] -> Ws[chunk][tap][cig][co][4].  Eight loads in flight per thread before the
+    // first store: a load -> store loop pays one L2 round trip per iteration (7 for the 16->16 layer, 27 for 32->32 x 2 slabs)
+    // on every launch, with the matrix pipe idle
+    {
+      constexpr int WB = 8;
+      const int total = nch * T * 4 * CT;
+      for (int q0 = threadIdx.x; q0 < total; q0 += 256 * WB) {
+        float4 wv[WB];
+  #pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const int q = q0 + u * 256;
+          if (q < total) {
+            const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
+            wv[u] = ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
+          }
+        }
+  #pragma unroll
+        for (int u = 0; u < WB; ++u) {
+          const int q = q0 + u * 256;
+          if (q < total) st4(Ws + (size_t)q * 4, wv[u]);
+        }
+      }
+    }
     stash(pre);
   }
   __syncthreads();
