@@ -1384,6 +1384,7 @@ __global__ __launch_bounds__(256) void k_conv3_c1_wgrad(const float* __restrict_
 struct Cfg { int KD, TD, TH, TW, NT, WT; };
 
 static int split_k(long long blocks, int nch) {   // deep levels: too few tiles to fill 256 CUs -> split the cin chunks
+  if (const char* e = getenv("BCP_SPLITK")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= nch) return v; }   // measurements
   if (blocks > 256 || nch < 4) return 1;
   int sk = nch / 2;
   if (sk > 4) sk = 4;
