@@ -19,6 +19,7 @@
 // is exactly the atomicMax above.  Multi-class maps are labelled in one pass (neighbours join only when
 // their class is equal) == the reference's per-class loop, because classes are disjoint.
 #include "common.h"
+#include <cstdlib>
 #include "../../include/bcp_hip.h"
 
 namespace bcp {
@@ -58,8 +59,8 @@ __device__ __forceinline__ void for_fwd_neighbours(int conn, F&& body) {
 template <int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ seg, int* __restrict__ L, int* __restrict__ lsize,
                                                   int* __restrict__ size, CcDims cd) {
-  constexpr int TV = TD * TH * TW;
-  static_assert(TV == 512, "two voxels per thread");
+  constexpr int TV = TD * TH * TW, VPT = TV / 256;
+  static_assert(TV % 256 == 0, "a whole number of voxels per thread");
   __shared__ int Ls[TV];
   __shared__ int Cnt[TV];
   __shared__ uint8_t Ss[TV];
@@ -67,9 +68,9 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ se
   const int td = (blockIdx.x / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d, n = blockIdx.x / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
   const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
   const long long nbase = (long long)n * cd.D * cd.H * cd.W;
-  int gidx[2];
+  int gidx[VPT];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < VPT; ++u) {
     const int i = threadIdx.x + u * 256;
     const int lw = i % TW, lh = (i / TW) % TH, ld = i / (TW * TH);
     const int d = d0 + ld, h = h0 + lh, w = w0 + lw;
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ se
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < VPT; ++u) {
     const int i = threadIdx.x + u * 256;
     const uint8_t cls = Ss[i];
     if (cls) {
@@ -97,9 +98,9 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ se
     }
   }
   __syncthreads();
-  int root[2];
+  int root[VPT];
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < VPT; ++u) {
     const int i = threadIdx.x + u * 256;
     root[u] = -1;
     if (Ss[i]) {
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ se
   }
   __syncthreads();
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < VPT; ++u) {
     const int i = threadIdx.x + u * 256;
     if (gidx[u] < 0) continue;
     int lab = -1, ls = 0;
@@ -233,10 +234,22 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
   hipMemsetAsync(best, 0, (size_t)N * nclass * sizeof(unsigned long long), s);
   CcDims cd;
   cd.N = N; cd.D = D; cd.H = H; cd.W = W; cd.conn = connectivity;
-  if (D > 1) {
+  // local tiles: 8x16x16 / 32x64 voxels (8 per thread) when the volume has at least ~2 such tiles per CU, else 4x8x16 / 16x32;
+  // bigger tiles leave fewer voxels on tile faces for the global-atomic border pass (51 % -> 33 % in 3-D)
+  const char* e = getenv("BCP_CC_TILE");
+  const bool big = e ? e[0] == 'b' : (n >= 512LL * 2048);
+  if (D > 1 && big) {
+    cd.tiles_d = cdiv(D, 8); cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16);
+    hipLaunchKernelGGL((k_cc_local<8, 16, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_border<8, 16, 16>), dim3(grid), dim3(256), 0, s, seg, L, cd);
+  } else if (D > 1) {
     cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 8); cd.tiles_w = cdiv(W, 16);
     hipLaunchKernelGGL((k_cc_local<4, 8, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
     hipLaunchKernelGGL((k_cc_border<4, 8, 16>), dim3(grid), dim3(256), 0, s, seg, L, cd);
+  } else if (big) {
+    cd.tiles_d = 1; cd.tiles_h = cdiv(H, 32); cd.tiles_w = cdiv(W, 64);
+    hipLaunchKernelGGL((k_cc_local<1, 32, 64>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_border<1, 32, 64>), dim3(grid), dim3(256), 0, s, seg, L, cd);
   } else {
     cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 32);
     hipLaunchKernelGGL((k_cc_local<1, 16, 32>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);

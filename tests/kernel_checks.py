@@ -98,6 +98,17 @@ def check_cc(ops, dev, golden_dir):
     for conn, oc in ((3, None), (2, 2), (1, 1)):
         ref = O.largest_cc(seg.long(), oc)
         assert torch.equal(ops.cc_largest(seg.to(dev), 1, conn).cpu().float(), ref)
+    # the big-tile variant (8x16x16 / 32x64 local tiles, chosen automatically for large volumes) must give the same answers
+    import os
+    os.environ["BCP_CC_TILE"] = "big"
+    try:
+        for conn, oc in ((3, None), (2, 2), (1, 1)):
+            assert torch.equal(ops.cc_largest(seg.to(dev), 1, conn).cpu().float(), O.largest_cc(seg.long(), oc))
+        for conn, key in ((3, "cc26"), (2, "cc18"), (1, "cc6")):
+            assert np.array_equal(ops.cc_largest(cut.to(dev).contiguous(), 1, conn).cpu().numpy(), g[key]), f"big-tile cc {key}"
+        assert np.array_equal(ops.cc_largest(am.to(dev), 3, 2).cpu().numpy()[:, 0], g["argmax_cc"])
+    finally:
+        del os.environ["BCP_CC_TILE"]
 
 
 def check_mixloss(ops, dev, golden_dir):
