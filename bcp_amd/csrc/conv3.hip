@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256) void k_sum_slabs(const float* __restrict__ par
 template <int KD, int TD, int TH, int TW, int NT>
 __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, const float* __restrict__ Wp,
                                                    const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd,
-                                                   int n_tiles, int accumulate, StatsArg st) {
+                                                   int n_tiles, int accumulate, StatsArg st, int csplit) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, CT = NT * 16;
   constexpr int NACC = (MT * NT == 1) ? 2 : 1;       // a lone accumulator would serialise on the 40-cycle MFMA latency
@@ -468,7 +468,12 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 
   HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
   float* smem = reinterpret_cast<float*>(smem4);
-  const int nch = cd.Cin16 >> 4;
+  // split-K over cin chunks (deep levels, whose full weight slab does not fit the LDS): blockIdx.z owns chunks
+  // [c_begin, c_begin + nch) and writes its own partial output slab (summed -- with bias / += -- by k_sum_slabs)
+  const int nch_all = cd.Cin16 >> 4;
+  const int c_begin = (int)((long long)nch_all * blockIdx.z / csplit);
+  const int nch = (int)((long long)nch_all * (blockIdx.z + 1) / csplit) - c_begin;
+  Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
   float* Ws = smem;                                  // [nch][T][4][CT][4]
   float* Xs = smem + (size_t)nch * T * 4 * CT * 4;   // [HV][XS]
   double* Ss = reinterpret_cast<double*>(Xs + TL::HV * XS);   // [4][CT][2] statistics scratch
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   auto fetch = [&](int t, int c, float4 (&pre)[NP]) {
     int n2, d2, h2, w2;
     tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
-    hf.fetch(X, cd, n2, d2, h2, w2, c, pre);
+    hf.fetch(X, cd, n2, d2, h2, w2, c_begin + c, pre);
   };
   auto stash = [&](const float4 (&pre)[NP]) { hf.stash(pre); };
 
@@ -560,7 +565,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
           const int q = q0 + u * 256;
           if (q < total) {
             const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
-            wv[u] = ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
+            wv[u] = ld4(Wp + ((((long long)tap * cin4 + (c_begin + ch) * 4 + cig) * cd.Cout16) + cout0 + co) * 4);
           }
         }
   #pragma unroll
@@ -1421,20 +1426,21 @@ static int launch_fwd(const float* X, const float* Wp, const float* bias, float*
 
 template <int KD, int TD, int TH, int TW, int NT>
 static int launch_res(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate,
-                      double* stat_partial, int G, BwdCtx bw, bool dry, hipStream_t s) {
+                      double* stat_partial, int G, BwdCtx bw, bool dry, hipStream_t s, int csplit = 1, float* ws = nullptr) {
   using TL = Tile<KD, TD, TH, TW>;
-  const int nch = cd.Cin16 / 16;
+  const int nch = cdiv(cd.Cin16 / 16, csplit);          // resident chunks per workgroup
   const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + (size_t)TL::HV * XS) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
   const int slabs = cd.Cout16 / (NT * 16);
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
-  int P = (256 * (per_cu > 2 ? 2 : per_cu)) / slabs;           // persistent workgroups per slab
+  int P = (256 * (per_cu > 3 ? 3 : per_cu)) / (slabs * csplit);   // persistent workgroups per (slab, chunk group)
+  if (csplit == 1 && per_cu > 2) P = 512 / slabs;
   if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
   if (P < 1) P = 1;
   if (P > tiles) P = tiles;
   StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
-  const bool stats_ok = G > 0 && tiles % G == 0;
+  const bool stats_ok = G > 0 && tiles % G == 0 && csplit == 1;
   if (dry) return stats_ok ? P : 0;
   if (stats_ok && stat_partial) {
     st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G;
@@ -1442,7 +1448,13 @@ static int launch_res(const float* X, const float* Wp, const float* bias, float*
   }
   auto kfn = k_conv3_res<KD, TD, TH, TW, NT>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(P, slabs), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st);
+  if (csplit == 1) {
+    hipLaunchKernelGGL(kfn, dim3(P, slabs, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st, 1);
+  } else {
+    const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
+    hipLaunchKernelGGL(kfn, dim3(P, slabs, csplit), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, tiles, 0, st, csplit);
+    hipLaunchKernelGGL(k_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, csplit, n, cd.Cout, bias, Y, accumulate);
+  }
   return st.partial ? P : 0;
 }
 
@@ -1605,6 +1617,33 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
   return false;
 }
 
+// resident weights + split-K over cin chunks: the deep levels (Cin >= 128), whose full weight slab (221 KB per 16 output
+// channels at 128 -> 128) does not fit the LDS.  Two chunks (55 KB) stay resident per workgroup, the chunk groups go to
+// blockIdx.z, every workgroup walks its share of the 64-voxel tiles with the register-prefetch pipeline of k_conv3_res, and
+// k_sum_slabs adds the partial outputs.  Versus the streaming kernel: no weight reload per (tile, chunk) and no exposed L2 round
+// trip per chunk.  Only without fused statistics (dgrad, eval forward).
+static bool choose_res_split(Cfg& r, int& csplit, int KD, int N, int D, int H, int W, int Cin16, int Cout16, bool has_ws, bool want_stats) {
+  // Measured (batch 2): C=128 62 us (2 chunks resident) / 57 us (1 chunk) vs 56 us for the streaming kernel, C=256 40 vs 34 us:
+  // no gain, so it is OFF unless BCP_RES_SPLIT=<chunks resident per workgroup> asks for it (tests do).
+  const char* e = getenv("BCP_RES_SPLIT");
+  if (!e || e[0] == '0' || !has_ws || want_stats || KD != 3 || Cin16 < 128) return false;
+  r = choose_cfg(KD, N, D, H, W, Cout16);      // best-fit 64-voxel tile
+  if (r.TD * r.TH * r.TW != 64) return false;
+  r.NT = 1;
+  const int nch = Cin16 / 16;
+  csplit = nch / 2;
+  if (e && e[0] >= '1' && e[0] <= '9') csplit = nch / (e[0] - '0');     // measurements: chunks resident per workgroup
+  if (csplit > 8) csplit = 8;
+  if (csplit < 2) return false;
+  return true;
+}
+#define BCP_RESK_CASE(KD_, TD_, TH_, TW_)                                                                      \
+  if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_) {                                              \
+    rows = launch_res<KD_, TD_, TH_, TW_, 1>(x, wp, bias, y, cd, accumulate, nullptr, 0, bw, dry, (hipStream_t)stream, csplit, \
+                                             (float*)workspace);                                              \
+    done = true;                                                                                               \
+  }
+
 // wave-specialised variant: 16- / 32-channel-in layers whose volume is an exact multiple of the tile (no partial tiles) and
 // whose weights + two halo buffers + staging fit the LDS.  BCP_CONV3_WS=0 disables it (A/B measurements).
 static bool choose_ws(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, int Cout, int Cout16, bool bwd_stats) {
@@ -1640,9 +1679,9 @@ static bool choose_ws(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, int
   }
 
 extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD) {
-  // split-K partial slabs (only taken for grids of <= 256 blocks): at most 4 copies of the output
+  // split-K partial slabs (deep levels only): at most 8 copies of the output
   const long long n = (long long)N * D * H * W * Cout;
-  return n <= (1LL << 20) ? (size_t)(4 * n * sizeof(float)) : 0;
+  return n <= (1LL << 20) ? (size_t)(8 * n * sizeof(float)) : 0;
 }
 
 // shared by the launch and by the statistics-rows query: returns the number of partial rows per group the chosen kernel
@@ -1665,6 +1704,10 @@ static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, fl
     BCP_RES_CASE(3, 4, 4, 4, 1) BCP_RES_CASE(3, 4, 4, 4, 2) BCP_RES_CASE(3, 4, 4, 4, 4)
     BCP_RES_CASE(1, 1, 16, 16, 1) BCP_RES_CASE(1, 1, 16, 16, 2) BCP_RES_CASE(1, 1, 16, 16, 4)
     BCP_RES_CASE(1, 1, 8, 8, 1) BCP_RES_CASE(1, 1, 8, 8, 2) BCP_RES_CASE(1, 1, 8, 8, 4)
+  }
+  int csplit = 1;
+  if (!done && !dry && choose_res_split(r, csplit, KD, N, D, H, W, cd.Cin16, cd.Cout16, workspace != nullptr, stat_partial != nullptr || G > 0)) {
+    BCP_RESK_CASE(3, 2, 16, 2) BCP_RESK_CASE(3, 8, 8, 1) BCP_RESK_CASE(3, 2, 8, 4) BCP_RESK_CASE(3, 4, 4, 4)
   }
   if (!done) {
     const Cfg c = choose_cfg(KD, N, D, H, W, cd.Cout16);

@@ -232,7 +232,9 @@ CONV3_CASES = (
     (2, 32, 32, (4, 8, 8), 3),
     (1, 64, 64, (4, 4, 4), 3),
     (1, 32, 16, (6, 5, 7), 3),        # Cin != Cout, odd dims
-    (1, 128, 128, (3, 3, 2), 3),      # deep level, tiny spatial
+    (1, 128, 128, (3, 3, 2), 3),      # deep level, tiny spatial (resident weights + split-K over cin chunks)
+    (2, 128, 144, (6, 14, 5), 3),     # deep level: several 64-voxel tiles per persistent workgroup, partial tiles, 4 chunk groups
+    (1, 256, 128, (7, 7, 5), 3),      # 16 cin chunks -> 8 chunk groups
     (2, 64, 64, (14, 14, 10), 3),     # LA level 4 extent: tile (2,16,2) for fwd, (2,8,4) for wgrad
     (1, 32, 48, (7, 7, 5), 3),        # LA level 5 extent: tile (8,8,1)
     (2, 16, 16, (1, 16, 16), 1),      # 2-D
@@ -482,6 +484,18 @@ CONV3_WS_CASES = (
 )
 
 
+def check_conv3_res_split(ops, dev):
+    """resident weights + split-K over cin chunks at the deep levels (off by default: measured no faster than the streaming
+    kernel), forced on"""
+    import os
+    for v in ("1", "2"):
+        os.environ["BCP_RES_SPLIT"] = v
+        try:
+            check_conv3(ops, dev, cases=[c for c in CONV3_CASES if c[1] >= 128])
+        finally:
+            del os.environ["BCP_RES_SPLIT"]
+
+
 def check_conv3_ws(ops, dev):
     """wave-specialised resident kernel (4 MFMA waves + 4 helper waves per workgroup), forced on for small full-tile shapes;
     few persistent workgroups so that each walks several (tile, chunk) items; fused statistics through the helper waves"""
@@ -626,4 +640,4 @@ def check_augment(ops, dev, golden_dir):
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"])
 
 
-ALL_CHECKS = ("augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_ws", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_ws", "conv3_res_split", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
