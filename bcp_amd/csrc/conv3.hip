@@ -1797,6 +1797,13 @@ static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   // (Measured: forcing the widest slab at the deep levels -- more MFMAs per staged tile but fewer, longer blocks -- is
   // slower: C=128 wgrad 82 / 85 / 106 us and C=256 57 / 58 / 65 us for NT = 1 / 2 / 4.)
   int nt = c.NT > 2 ? 2 : c.NT;     // C=64: 75 us with 2-slab blocks vs 79 us with 4 (two workgroups per CU instead of one)
+  // mid level (2 x 56x56x40, C=32): 128-voxel tiles -- 140 us vs 158 us with 4x8x8 and 143 us with 4x4x4.  (The 16-channel
+  // level keeps 4x4x16: 259 us vs 286 / 283 / 314 us for 4x4x8 / 4x8x8 / 4x4x4.)
+  if (KD == 3 && c.TD == 4 && c.TH == 8 && c.TW == 8) { c.TH = 4; }
+  if (const char* e = getenv("BCP_WGRAD_TILE")) {   // measurements: "TD,TH,TW"
+    int td, th, tw;
+    if (sscanf(e, "%d,%d,%d", &td, &th, &tw) == 3) { c.TD = td; c.TH = th; c.TW = tw; }
+  }
   if (const char* e = getenv("BCP_WGRAD_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && Cout16 % (v * 16) == 0) nt = v; }
   c.NT = nt;
   return c;
@@ -1834,6 +1841,7 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   int G = 0;
   BCP_WG_CASE(3, 4, 4, 16, 1) BCP_WG_CASE(3, 4, 4, 16, 2) BCP_WG_CASE(3, 4, 4, 16, 4)
   BCP_WG_CASE(3, 4, 8, 8, 1) BCP_WG_CASE(3, 4, 8, 8, 2) BCP_WG_CASE(3, 4, 8, 8, 4)
+  BCP_WG_CASE(3, 4, 4, 8, 1) BCP_WG_CASE(3, 4, 4, 8, 2) BCP_WG_CASE(3, 4, 4, 8, 4)
   BCP_WG_CASE(3, 4, 4, 4, 1) BCP_WG_CASE(3, 4, 4, 4, 2) BCP_WG_CASE(3, 4, 4, 4, 4)
   BCP_WG_CASE(3, 2, 8, 4, 1) BCP_WG_CASE(3, 2, 8, 4, 2) BCP_WG_CASE(3, 2, 8, 4, 4)
   BCP_WG_CASE(1, 1, 16, 16, 1) BCP_WG_CASE(1, 1, 16, 16, 2) BCP_WG_CASE(1, 1, 16, 16, 4)

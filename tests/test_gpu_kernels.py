@@ -37,6 +37,7 @@ def test_arch_is_gfx950(gpu_ops):
 def test_conv3_config_shapes(gpu_ops):
     """LA config-size layers (bigger tiles, multi-wave grids) vs torch CPU"""
     cases = ((1, 16, 16, (24, 20, 48), 3), (1, 32, 32, (16, 24, 24), 3), (1, 64, 64, (12, 12, 12), 3), (1, 256, 256, (7, 7, 5), 3),
+             (1, 32, 32, (42, 44, 38), 3),   # 64K..256K voxels: the 4x8x8 forward / 4x4x8 wgrad tiles
              (2, 16, 16, (1, 64, 48), 1), (2, 128, 128, (1, 32, 32), 1))
     K.check_conv3(gpu_ops, torch.device("cuda:0"), cases=cases)
 
