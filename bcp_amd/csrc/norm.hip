@@ -149,38 +149,51 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
   }
 }
 
-// Sum the per-block partials of 16 channels of one group: 256 threads = 16 channels x 16 block-slots, LDS tree.
-// (a single thread walking ~1000 partials serially cost more than the streaming pass itself)
-__device__ __forceinline__ bool reduce_partials(const double* __restrict__ partial, int nb, int C, int g, int c, int slot,
+// Sum the per-block partials of 16 channels of one group: 1024 threads = 32 doubles (16 channels x {s1, s2}, one 256-byte
+// row of the partial table) x 32 row-slots, four independent loads in flight per thread, then an LDS tree.  Threads 0..15
+// return true with the two sums of channel chunk*16 + tid.  (A single thread walking ~1000 partials serially cost more than
+// the streaming pass itself; 16 slots with one load in flight left this kernel at ~8 us on the step's critical path.)
+constexpr int kFinalizeThreads = 1024;
+__device__ __forceinline__ bool reduce_partials(const double* __restrict__ partial, int nb, int C, int g, int chunk,
                                                 double& s1, double& s2) {
-  __shared__ double red[256][2];
-  double a1 = 0.0, a2 = 0.0;
-  for (int b = slot; b < nb; b += 16) {
-    const double* p = partial + (((long long)g * nb + b) * C + c) * 2;
-    a1 += p[0];
-    a2 += p[1];
+  __shared__ double red[32][33];
+  __shared__ double fin[32];
+  const int e = threadIdx.x & 31, slot = threadIdx.x >> 5;
+  const double* p = partial + ((long long)g * nb * C + chunk * 16) * 2 + e;
+  const long long rs = (long long)C * 2;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int b = slot;
+  for (; b + 96 < nb; b += 128) {
+    const double v0 = p[b * rs], v1 = p[(b + 32) * rs], v2 = p[(b + 64) * rs], v3 = p[(b + 96) * rs];
+    a0 += v0; a1 += v1; a2 += v2; a3 += v3;
   }
-  red[threadIdx.x][0] = a1;
-  red[threadIdx.x][1] = a2;
+  for (; b < nb; b += 32) a0 += p[b * rs];
+  red[slot][e] = (a0 + a1) + (a2 + a3);
   __syncthreads();
-  if (slot != 0) return false;
-  s1 = 0.0; s2 = 0.0;
+  if (threadIdx.x < 32) {
+    double t0 = 0.0, t1 = 0.0;
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { s1 += red[k * 16 + (threadIdx.x & 15)][0]; s2 += red[k * 16 + (threadIdx.x & 15)][1]; }
+    for (int k = 0; k < 32; k += 2) { t0 += red[k][e]; t1 += red[k + 1][e]; }
+    fin[e] = t0 + t1;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 16) return false;
+  s1 = fin[threadIdx.x * 2];
+  s2 = fin[threadIdx.x * 2 + 1];
   return true;
 }
 
 // forward finalize: block = (group g, 16-channel chunk)
-__global__ __launch_bounds__(256) void k_norm_finalize(const double* __restrict__ partial, int nb, int G, int C,
+__global__ __launch_bounds__(kFinalizeThreads) void k_norm_finalize(const double* __restrict__ partial, int nb, int G, int C,
                                                        long long rows_per_group, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, float momentum, float eps,
                                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                                        float* __restrict__ shift, float* __restrict__ var_unb) {
   const int chunks = C >> 4;
-  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), slot = threadIdx.x >> 4;
+  const int g = blockIdx.x / chunks, chunk = blockIdx.x % chunks, c = chunk * 16 + (threadIdx.x & 15);
   double s1, s2;
-  if (!reduce_partials(partial, nb, C, g, c, slot, s1, s2)) return;
+  if (!reduce_partials(partial, nb, C, g, chunk, s1, s2)) return;
   const int idx = g * C + c;
   const double n = (double)rows_per_group;
   const double m = s1 / n;
@@ -213,14 +226,14 @@ __device__ __forceinline__ void update_running(const float* __restrict__ mean, c
 }
 
 // backward finalize: dgamma/dbeta (+= or =) and the two per-(g,c) means used by the apply pass
-__global__ __launch_bounds__(256) void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, int G, int C,
+__global__ __launch_bounds__(kFinalizeThreads) void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, int G, int C,
                                                            long long rows_per_group, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ c1,
                                                            float* __restrict__ c2, float* __restrict__ raw /* [2][G][C] */) {
   const int chunks = C >> 4;
-  const int g = blockIdx.x / chunks, c = (blockIdx.x % chunks) * 16 + (threadIdx.x & 15), slot = threadIdx.x >> 4;
+  const int g = blockIdx.x / chunks, chunk = blockIdx.x % chunks, c = chunk * 16 + (threadIdx.x & 15);
   double s1, s2;
-  if (!reduce_partials(partial, nb, C, g, c, slot, s1, s2)) return;
+  if (!reduce_partials(partial, nb, C, g, chunk, s1, s2)) return;
   const int idx = g * C + c;
   c1[idx] = (float)(s1 / (double)rows_per_group);
   c2[idx] = (float)(s2 / (double)rows_per_group);
@@ -420,12 +433,12 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float* var_unb = stats + 4LL * G * C;
   if (partial_in) {   // statistics partials were produced by the conv epilogue (bcp_conv3_fwd_stats)
-    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
+    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
   } else {
     hipLaunchKernelGGL((k_col_partial<0>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial);
-    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
+    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
   }
   hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, scale, shift, mean, residual,
@@ -454,12 +467,12 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   float* raw = c2 + (long long)G * C;
   if (partial_in) {   // (sum dz, sum dz * xhat) partials came out of the dgrad conv's epilogue (bcp_conv3_dgrad_bwdstats)
     BCP_REQUIRE(!chan_scale && !elem_mask && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
-    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
+    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw);
   } else {
     hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
                        C, partial);
-    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(256), 0, s, partial, nb, G, C, rows_per_group, dgamma,
+    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw);
   }
   hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da, scale, shift, mean,
