@@ -269,5 +269,6 @@ class VNet(HipNet):
             else:
                 _, bp = self.k2_packed(("k2", li), True)
                 dh = ops.up_dgrad(dy, bp, L.cin)
+            self._grads_final_from(w, dy)
         self._join_wgrad_stream(dlogits)
         return None

@@ -380,6 +380,17 @@ class HipNet(nn.Module):
             if side is not None:
                 torch.cuda.current_stream(like.device).wait_stream(side)
 
+    # ---- data parallelism: bucketed gradient all-reduce underneath the rest of the backward pass (bcp_amd/dp.py).
+    # The backward walks the layers in reverse registration order, so once layer L is done the flat gradient buffer is final
+    # from L's first parameter to its end; the hook (set by DataParallel.arm for the step's single backward) may start
+    # reducing that suffix while the shallower layers are still being differentiated.
+    _grad_bucket_hook = None
+
+    def _grads_final_from(self, p, like):
+        hook = self._grad_bucket_hook
+        if hook is not None:
+            hook(self, self._offs[id(p)], like)
+
     def next_seed(self):
         self._drop_seed = (self._drop_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._drop_seed

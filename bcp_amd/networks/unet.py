@@ -210,6 +210,7 @@ class UNet_2d(HipNet):
                 ops.colsum(dz, pw.bias.grad, accumulate=True)
             _, bpd = self.k2_packed(("pw", i), True)
             dh = ops.pw_fwd(dz, bpd, None, c1)
+            self._grads_final_from(pw.weight, dz)
         # dh = gradient w.r.t. x4; walk the encoder upwards
         for i in range(4, 0, -1):
             dpool = self._convblock_bwd(self._enc[i], f"e{i}", dh, saved, True)
@@ -218,6 +219,7 @@ class UNet_2d(HipNet):
             dcat, c2 = skip_grads[i - 1]
             ops.copy_channels(dcat, dx, c2, 0, 0, accumulate=True)               # join the decoder-side skip gradient
             dh = dx
+            self._grads_final_from(self._enc[i].c1.weight, dx)
         self._convblock_bwd(self._enc[0], "e0", dh, saved, False)
         self._join_wgrad_stream(dlogits)
         return None

@@ -200,6 +200,8 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         loss.backward()
     else:
         optimizer.zero_grad()
+        if dp is not None and grouped:
+            dp.arm(model)              # ONE backward in this step: gradient buckets go out underneath it
         loss.backward()
         if dp is not None:
             dp.allreduce_grads(model, optimizer)
@@ -316,6 +318,8 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
     loss_dice = unl_dice + l_dice
     loss = (loss_dice + loss_ce) / 2
     optimizer.zero_grad()
+    if dp is not None:
+        dp.arm(model)                  # one backward covers both student batches (grouped or not: `loss` sums their terms)
     loss.backward()
     if dp is not None:
         dp.allreduce_grads(model, optimizer)

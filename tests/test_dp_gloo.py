@@ -51,7 +51,8 @@ def _worker(rank, world, port, out_dir):
     opt = train_step.FlatSGD(model, lr=0.01)
     vol, lab, drops, box = _inputs(O, rank)
     r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=box, drops=drops, dp=dp)
-    torch.save({"flat": model.flat_params().clone(), "ema": ema.flat_params().clone(), "loss": float(r["loss"])}, os.path.join(out_dir, f"rank{rank}.pt"))
+    torch.save({"flat": model.flat_params().clone(), "ema": ema.flat_params().clone(), "loss": float(r["loss"]),
+                "collectives": dp.n_collectives}, os.path.join(out_dir, f"rank{rank}.pt"))
     dp.shutdown()
 
 
@@ -68,6 +69,7 @@ def test_dp2_equals_two_averaged_microbatches(tmp_path):
     r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
     assert torch.equal(r0["flat"], r1["flat"]), "students must be identical on every rank after the step"
     assert torch.equal(r0["ema"], r1["ema"]), "teachers stay identical because the students do"
+    assert r0["collectives"] == r1["collectives"] >= 3, "37.8 MB of gradients in >= 8 MB buckets: several collectives, same count on every rank"
     # single-process reference: two micro-batches from the same start, gradients averaged, one SGD step
     O, NC, train_step, ops = _setup()
     P = O.init_params(O.vnet_param_shapes(), seed=7, random_affine=True)   # rank 0's weights were broadcast
@@ -88,3 +90,46 @@ def test_dp2_equals_two_averaged_microbatches(tmp_path):
     assert abs(losses[0] - r0["loss"]) < 1e-6 and abs(losses[1] - r1["loss"]) < 1e-6
     diff = float((m.flat_params() - r0["flat"]).abs().max())
     assert diff < 1e-7, f"DP step differs from the averaged-micro-batch step by {diff}"
+
+
+def _worker_acdc(rank, world, port, out_dir, bucket_mb):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BCP_DP_BUCKET_MB=bucket_mb)
+    os.environ["BCP_EMU_THREADS"] = "4"
+    torch.set_num_threads(2)
+    O, NC, train_step, ops = _setup()
+    from bcp_amd.dp import DataParallel
+    dp = DataParallel(backend="gloo")
+    P = O.init_params(O.unet_param_shapes(), seed=11 + rank, random_affine=True)
+    model, ema = NC.make_unet(P, torch.device("cpu"), ops), NC.make_unet(P, torch.device("cpu"), ops)
+    for p in ema.parameters():
+        p.detach_()
+    dp.broadcast_params(model)
+    dp.broadcast_params(ema)
+    opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    vol, lab = O.synth_acdc_batch(8, shape=(64, 64), seed=300 + rank)
+    rng = np.random.default_rng(400 + rank)
+    drops = {k: {f"d{i}": torch.from_numpy((rng.random((2, c, 64 >> i, 64 >> i)) < 0.8).astype(np.float32)) for i, c in enumerate(O.UNET_CH)}
+             for k in ("t_a", "t_b", "s_unl", "s_l")}
+    r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=(5 + rank, 9, 42, 42), drops=drops, dp=dp)
+    # parameters only: BatchNorm running statistics are rank-local (dp.py), and update_model_ema carries them into the teacher
+    torch.save({"flat": model.flat_params().clone(), "ema": ema.flat_params().clone(), "loss": float(r["loss"]),
+                "collectives": dp.n_collectives}, os.path.join(out_dir, f"acdc{bucket_mb}_rank{rank}.pt"))
+    dp.shutdown()
+
+
+def test_dp2_unet_buckets_equal_single_allreduce(tmp_path):
+    """2-D U-Net (7.26 MB of gradients): 1 MB buckets started inside the backward pass == one all-reduce after it, bit for bit,
+    and both ranks end the step with the same student and teacher"""
+    out = {}
+    for mb in ("1", "0"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_worker_acdc, args=(2, port, str(tmp_path), mb), nprocs=2, join=True)
+        out[mb] = [torch.load(tmp_path / f"acdc{mb}_rank{r}.pt") for r in range(2)]
+        assert torch.equal(out[mb][0]["flat"], out[mb][1]["flat"]) and torch.equal(out[mb][0]["ema"], out[mb][1]["ema"])
+    assert out["1"][0]["collectives"] >= 3 and out["0"][0]["collectives"] == 1
+    assert torch.equal(out["1"][0]["flat"], out["0"][0]["flat"]), "bucketed and single all-reduce must give identical steps"
+    assert out["1"][0]["loss"] == out["0"][0]["loss"]
