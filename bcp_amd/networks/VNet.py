@@ -214,6 +214,16 @@ class VNet(HipNet):
             saved.append((h,))
         return logits, saved
 
+    def _grad_stages(self):
+        st = []
+        for li in range(len(self._layers) - 1, -1, -1):
+            L = self._layers[li]
+            ps = [L.conv.weight, L.conv.bias] + ([L.bn.weight, L.bn.bias] if L.bn is not None else [])
+            if li == len(self._layers) - 1:
+                ps += [self._out.weight, self._out.bias]
+            st.append((L.conv.weight, ps))
+        return st
+
     def _backward_impl(self, saved, dout):
         ops = self.ops
         G = saved[0][4]

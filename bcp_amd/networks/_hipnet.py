@@ -386,10 +386,35 @@ class HipNet(nn.Module):
     # reducing that suffix while the shallower layers are still being differentiated.
     _grad_bucket_hook = None
 
+    def _grad_stages(self):
+        """[(marker parameter, [parameters whose gradients are final once the marker's layer is done]), ...] in backward order"""
+        raise NotImplementedError
+
+    def _bucket_plan(self):
+        """marker parameter id -> first element of the flat gradient buffer that is final at that point of the backward pass.
+        Checked, not assumed: a suffix [lo, end) is handed out only if the parameters living there are exactly the ones
+        processed so far; a network whose registration order is not its layer order gets an empty plan (one all-reduce at the end)."""
+        cached = self.__dict__.get("_bplan")
+        if cached is not None and cached[0] is self._offs:
+            return cached[1]
+        offs = sorted(self._offs[id(p)] for p in self._opt_plist)
+        plan, done, lo = {}, 0, None
+        for marker, ps in self._grad_stages():
+            done += len(ps)
+            lo = min([self._offs[id(q)] for q in ps] + ([lo] if lo is not None else []))
+            if len(offs) - done < 0 or offs[len(offs) - done] != lo:
+                plan = {}
+                break
+            plan[id(marker)] = lo
+        object.__setattr__(self, "_bplan", (self._offs, plan))
+        return plan
+
     def _grads_final_from(self, p, like):
         hook = self._grad_bucket_hook
         if hook is not None:
-            hook(self, self._offs[id(p)], like)
+            lo = self._bucket_plan().get(id(p))
+            if lo is not None:
+                hook(self, lo, like)
 
     def next_seed(self):
         self._drop_seed = (self._drop_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF

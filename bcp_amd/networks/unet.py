@@ -187,6 +187,17 @@ class UNet_2d(HipNet):
             saved["xs"] = xs
         return logits, saved
 
+    def _grad_stages(self):
+        def cbp(cb):
+            return [m_.weight for m_ in (cb.c1, cb.b1, cb.c2, cb.b2)] + [m_.bias for m_ in (cb.c1, cb.b1, cb.c2, cb.b2)]
+        st = []
+        for i in range(4, 0, -1):
+            pw, cb = self._up[i - 1][0], self._up[i - 1][1]
+            st.append((pw.weight, [pw.weight, pw.bias] + cbp(cb) + ([self._out.weight, self._out.bias] if i == 4 else [])))
+        for i in range(4, 0, -1):
+            st.append((self._enc[i].c1.weight, cbp(self._enc[i])))
+        return st
+
     def _backward_impl(self, saved, dout):
         ops = self.ops
         dlogits = dout if dout.is_contiguous() else dout.contiguous()
