@@ -98,10 +98,16 @@ def check_cc(ops, dev, golden_dir):
     for conn, oc in ((3, None), (2, 2), (1, 1)):
         ref = O.largest_cc(seg.long(), oc)
         assert torch.equal(ops.cc_largest(seg.to(dev), 1, conn).cpu().float(), ref)
+    # noise maps (what a random-init teacher emits): one percolating component chained through every tile + thousands of specks
+    noise = torch.from_numpy((rng.random((2, 20, 40, 36)) < 0.5).astype(np.uint8))
+    for conn, oc in ((3, None), (2, 2), (1, 1)):
+        assert torch.equal(ops.cc_largest(noise.to(dev), 1, conn).cpu().float(), O.largest_cc(noise.long(), oc)), f"noise cc conn={conn}"
     # the big-tile variant (8x16x16 / 32x64 local tiles, chosen automatically for large volumes) must give the same answers
     import os
     os.environ["BCP_CC_TILE"] = "big"
     try:
+        for conn, oc in ((3, None), (1, 1)):
+            assert torch.equal(ops.cc_largest(noise.to(dev), 1, conn).cpu().float(), O.largest_cc(noise.long(), oc)), f"big-tile noise cc conn={conn}"
         for conn, oc in ((3, None), (2, 2), (1, 1)):
             assert torch.equal(ops.cc_largest(seg.to(dev), 1, conn).cpu().float(), O.largest_cc(seg.long(), oc))
         for conn, key in ((3, "cc26"), (2, "cc18"), (1, "cc6")):

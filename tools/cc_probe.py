@@ -1,0 +1,19 @@
+"""measurement only: the largest-CC chain on pseudo-label-like inputs (run under rocprofv3 --kernel-trace --stats)"""
+import sys, torch
+sys.path.insert(0, "/root/repo")
+from bcp_amd.hip_ops import Ops
+ops = Ops.product(); dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(0)
+for p in (0.5, 0.1):
+    seg = (torch.rand(2, 112, 112, 80, generator=g) < p).to(torch.uint8).to(dev)
+    for _ in range(10):
+        ops.cc_largest(seg, 1, 3)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for p in (0.5, 0.1):
+    seg = (torch.rand(2, 112, 112, 80, generator=g) < p).to(torch.uint8).to(dev)
+    e0.record()
+    for _ in range(20):
+        ops.cc_largest(seg, 1, 3)
+    e1.record(); torch.cuda.synchronize()
+    print(f"p={p}: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per cc_largest")
