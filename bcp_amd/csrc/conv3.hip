@@ -300,12 +300,12 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
     __syncthreads();
     for (int cc = c_begin; cc < c_end; ++cc) {
       const bool has_next = cc + 1 < c_end;
-      if (has_next) {
+      if (has_next && !(BCP_ABLATE & 32768)) {     // (ablation 32768: every chunk reuses the first chunk's registers -- no global loads)
         hf.fetch(X, cd, n, d0, h0, w0, cc + 1, hpre);
         wfetch(cc + 1);
       }
 #pragma unroll (WT > 9 ? 9 : WT)
-      for (int tl = 0; tl < WT; ++tl) {
+      for (int tl = 0; tl < ((BCP_ABLATE & 65536) ? 1 : WT); ++tl) {    // (ablation 65536: one tap per chunk -- the load pipeline alone)
         const int toff = TL::tapoff(tl) * XS;
         float4 a[MT], b[NT];
 #pragma unroll
@@ -1797,9 +1797,10 @@ static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   // (Measured: forcing the widest slab at the deep levels -- more MFMAs per staged tile but fewer, longer blocks -- is
   // slower: C=128 wgrad 82 / 85 / 106 us and C=256 57 / 58 / 65 us for NT = 1 / 2 / 4.)
   int nt = c.NT > 2 ? 2 : c.NT;     // C=64: 75 us with 2-slab blocks vs 79 us with 4 (two workgroups per CU instead of one)
-  // mid level (2 x 56x56x40, C=32): 128-voxel tiles -- 140 us vs 158 us with 4x8x8 and 143 us with 4x4x4.  (The 16-channel
-  // level keeps 4x4x16: 259 us vs 286 / 283 / 314 us for 4x4x8 / 4x8x8 / 4x4x4.)
-  if (KD == 3 && c.TD == 4 && c.TH == 8 && c.TW == 8) { c.TH = 4; }
+  // Tile sweep (BCP_WGRAD_TILE): the mid level (2 x 56x56x40, C=32) runs 140 us ALONE with 4x4x8 tiles against 158 us with
+  // 4x8x8 -- but inside the step, next to the dgrad / norm-backward kernels of the main stream, the 256-voxel tile wins
+  // (8.95 vs 9.02 ms per step, interleaved A/B of the two libraries): 4x8x8 stays.  The 16-channel level keeps 4x4x16
+  // (259 us vs 286 / 283 / 314 us for 4x4x8 / 4x8x8 / 4x4x4).
   if (const char* e = getenv("BCP_WGRAD_TILE")) {   // measurements: "TD,TH,TW"
     int td, th, tw;
     if (sscanf(e, "%d,%d,%d", &td, &th, &tw) == 3) { c.TD = td; c.TH = th; c.TW = tw; }
