@@ -94,3 +94,62 @@ def test_full_size_properties(gpu_ops):
     ops.ema(p, q, 0.0)
     assert torch.equal(p, q)
     torch.cuda.synchronize()
+
+
+def test_full_size_properties_acdc(gpu_ops):
+    """BASELINE.json's ACDC size (grouped batch of 12 slices, 256 x 256, the U-Net's 16-channel level): size-independent
+    properties + torch's own elementwise / pooling kernels on the same device as a second opinion"""
+    import torch.nn.functional as F
+    ops, dev = gpu_ops, torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    N, H, W, C = 12, 256, 256, 16
+    x1 = torch.randn(N, 1, H, W, C, generator=g).to(dev)
+    x2 = torch.randn(N, 1, H, W, C, generator=g).to(dev)
+    d = torch.randn(N, 1, H, W, C, generator=g).to(dev)
+    w = (torch.randn(C, C, 3, 3, generator=g) * 0.08).to(dev)
+    wf, wd = ops.conv3_pack(w, 1)
+    # (1) 3x3 conv: linearity of both packs, adjointness of fwd / dgrad / wgrad
+    for pack in (wf, wd):
+        y12 = ops.conv3_fwd(x1 + x2, pack, None, C, 1)
+        ysum = ops.conv3_fwd(x1, pack, None, C, 1) + ops.conv3_fwd(x2, pack, None, C, 1)
+        assert float((y12 - ysum).abs().max()) < 2e-5 * float(ysum.abs().max())
+    y, dx = ops.conv3_fwd(x1, wf, None, C, 1), ops.conv3_fwd(d, wd, None, C, 1)
+    dw = torch.zeros_like(w)
+    ops.conv3_wgrad(x1, d, dw, 1)
+    lhs = float((y.double() * d.double()).sum())
+    r1, r2 = float((x1.double() * dx.double()).sum()), float((w.double() * dw.double()).sum())
+    assert abs(lhs - r1) < 5e-2 and abs(lhs - r2) < 5e-2, (lhs, r1, r2)      # ~1.3e7 O(1) products: sqrt(n) * eps * sigma ~ 1e-2
+    # (2) MaxPool2d(2) and its backward == torch's kernels on the same tensors (NCHW views of the NHWC buffers), bit for bit
+    xn = x1[:, 0].permute(0, 3, 1, 2).requires_grad_(True)
+    yp = ops.maxpool2d_fwd(x1)
+    yt = F.max_pool2d(xn, 2)
+    assert torch.equal(yp[:, 0].permute(0, 3, 1, 2), yt)
+    dyp = torch.randn(N, 1, H // 2, W // 2, C, generator=g).to(dev)
+    yt.backward(dyp[:, 0].permute(0, 3, 1, 2))
+    dxp = ops.maxpool2d_bwd(x1, dyp, torch.empty_like(x1))
+    assert torch.equal(dxp[:, 0].permute(0, 3, 1, 2), xn.grad)
+    # (3) bilinear x2 (align_corners=True): vs torch within fp32 rounding; backward is its adjoint
+    xs = torch.randn(N, 1, H // 2, W // 2, C, generator=g).to(dev)
+    buf = torch.zeros(N, 1, H, W, C, device=dev)
+    ops.bilinear2x_fwd(xs, buf, 0)
+    ref = F.interpolate(xs[:, 0].permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=True)
+    assert float((buf[:, 0].permute(0, 3, 1, 2) - ref).abs().max()) < 1e-5
+    dxs = ops.bilinear2x_bwd(d, 0, C)
+    a1, a2 = float((buf.double() * d.double()).sum()), float((xs.double() * dxs.double()).sum())
+    assert abs(a1 - a2) < 2e-2, (a1, a2)
+    # (4) pseudo-labels: softmax -> first-max argmax == torch.argmax of the logits (softmax is monotone; random logits have no ties)
+    lo = torch.randn(N, 1, H, W, 4, generator=g).to(dev)
+    pl = ops.plabel_argmax4(lo)
+    assert torch.equal(pl.long(), lo.argmax(-1))
+    # (5) per-class largest connected component (8-connectivity): idempotent, a subset, never empty for a class that is present
+    cc1 = ops.cc_largest(pl, 3, 2)
+    cc2 = ops.cc_largest(cc1, 3, 2)
+    assert torch.equal(cc1, cc2) and bool(((cc1 == pl) | (cc1 == 0)).all())
+    for c in (1, 2, 3):
+        per_slice = (cc1 == c).flatten(1).sum(1)
+        assert bool((per_slice > 0).all()) and bool((per_slice <= (pl == c).flatten(1).sum(1)).all())
+    # (6) the two complementary copy-paste mixes partition their inputs
+    a, b = torch.randn(N, 1, H, W, 1, generator=g).to(dev), torch.randn(N, 1, H, W, 1, generator=g).to(dev)
+    box = (0, 40, 31, 1, 170, 170)
+    assert torch.equal(ops.mix_box(a, b, box) + ops.mix_box(b, a, box), a + b)
+    torch.cuda.synchronize()
