@@ -337,7 +337,10 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
       hf.fetch(X, cd, n, d0, h0, w0, cc, pre);
       hf.stash(pre);
     }
-    // weight stage 0 of this chunk  (an explicit loads-then-stores version was measured slower at C=64: 75.7 vs 70 us)
+    // weight stage 0 of this chunk  (an explicit loads-then-stores version was measured slower at C=64: 75.7 vs 70 us; so was
+    // carrying the NEXT chunk's halo + stage-0 weights in registers under the last stage's MFMAs -- 75.8 vs 71.4 us at C=64,
+    // 9.00 vs 8.96 ms per step: with 2-3 workgroups per CU the other workgroups' MFMAs already cover this round trip, and the
+    // extra live registers cost more than the latency they hide)
     for (int q = threadIdx.x; q < WSTAGE4; q += 256) {
       const int co = q % CT, cig = (q / CT) & 3, tl = q / (4 * CT);
       st4(Ws + q * 4, ld4(Wp + ((((long long)tl * cin4 + cc * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
