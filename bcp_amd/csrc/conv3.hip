@@ -1439,6 +1439,10 @@ static int launch_res(const float* X, const float* Wp, const float* bias, float*
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
   int P = (256 * (per_cu > 3 ? 3 : per_cu)) / (slabs * csplit);   // persistent workgroups per (slab, chunk group)
   if (csplit == 1 && per_cu > 2) P = 512 / slabs;
+  if (const char* e = getenv("BCP_RES_PCU")) {   // measurements: persistent workgroups per CU (1..4, as far as the LDS allows)
+    const int v = atoi(e);
+    if (csplit == 1 && v >= 1 && v <= 4 && v <= per_cu) P = 256 * v / slabs;
+  }
   if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
   if (P < 1) P = 1;
   if (P > tiles) P = tiles;
