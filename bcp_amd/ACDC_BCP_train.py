@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from bcp_amd import train_step
-from bcp_amd.dataloaders.dataset import SyntheticACDC, TwoStreamBatchSampler, batches
+from bcp_amd.dataloaders.dataset import DeviceRandomGenerator, SyntheticACDC, TwoStreamBatchSampler, batches
 from bcp_amd.networks.net_factory import BCP_net
 from bcp_amd.train_step import acdc_mix_loss as mix_loss, generate_mask, get_ACDC_masks, update_model_ema
 from bcp_amd.utils import val_2d
@@ -43,6 +43,7 @@ parser.add_argument('--magnitude', type=float, default='6.0', help='magnitude')
 parser.add_argument('--s_param', type=int, default=6, help='multinum of random masks')
 parser.add_argument('--log_every', type=int, default=50)
 parser.add_argument('--val_every', type=int, default=200, help='validation cadence (ACDC_BCP_train.py:273,402: every 200 iterations)')
+parser.add_argument('--augment', action='store_true', help='raw-size slices + the device-side RandomGenerator (rot90 / flip / rotate + zoom, dataloaders/dataset.py)')
 parser.add_argument('--val_cases', type=int, default=2, help='synthetic validation volumes (the reference walks its val list)')
 
 
@@ -67,7 +68,9 @@ def load_net_opt(net, optimizer, path):
 
 
 def _loader(args, device):
-    db_train = SyntheticACDC(num=1312, shape=tuple(args.patch_size), device=device, seed=args.seed)
+    db_train = SyntheticACDC(num=1312, shape=tuple(args.patch_size), device=device, seed=args.seed,
+                             transform=DeviceRandomGenerator(args.patch_size) if args.augment else None,   # RandomGenerator (:209-211)
+                             raw_shape=(216, 248))
     labeled_slice = patients_to_slices(args.root_path, args.labelnum)
     labeled_idxs = list(range(0, labeled_slice))
     unlabeled_idxs = list(range(labeled_slice, len(db_train)))

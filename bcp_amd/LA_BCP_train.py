@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from bcp_amd import train_step
-from bcp_amd.dataloaders.dataset import SyntheticLA, TwoStreamBatchSampler, batches
+from bcp_amd.dataloaders.dataset import DeviceRotFlipCrop, SyntheticLA, TwoStreamBatchSampler, batches
 from bcp_amd.networks.net_factory import net_factory
 from bcp_amd.train_step import get_cut_mask
 from bcp_amd.utils import ramps, test_3d_patch
@@ -49,6 +49,7 @@ parser.add_argument('--loss_weight', type=float, default=0.5, help='loss weight 
 parser.add_argument('--fused_optimizer', type=int, default=1, help='1: one-launch FlatSGD; 0: torch.optim.SGD on the same parameters')
 parser.add_argument('--log_every', type=int, default=50, help='host sync + log cadence (the reference syncs every iteration)')
 parser.add_argument('--val_every', type=int, default=200, help='sliding-window validation cadence (LA_BCP_train.py:174,279: every 200 iterations)')
+parser.add_argument('--augment', action='store_true', help='cases larger than the patch + the device-side RandomRotFlip / RandomCrop (dataloaders/dataset.py)')
 parser.add_argument('--val_cases', type=int, default=2, help='synthetic validation volumes (the reference walks the LA test list)')
 
 patch_size = (112, 112, 80)
@@ -91,7 +92,9 @@ def _val_cases(args, device):
 
 def pre_train(args, snapshot_path, device):
     model = net_factory(net_type=args.model, in_chns=1, class_num=num_classes, mode="train")
-    db_train = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed)
+    db_train = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed,
+                           transform=DeviceRotFlipCrop(patch_size) if args.augment else None,     # RandomRotFlip -> RandomCrop -> ToTensor (:122-126)
+                           raw_shape=(patch_size[0] + 12, patch_size[1] + 10, patch_size[2] + 8))
     labeled_idxs = list(range(args.labelnum))
     unlabeled_idxs = list(range(args.labelnum, args.max_samples))
     batch_sampler = TwoStreamBatchSampler(labeled_idxs, unlabeled_idxs, args.batch_size, args.batch_size - args.labeled_bs)
@@ -145,7 +148,9 @@ def self_train(args, pre_snapshot_path, self_snapshot_path, device):
     ema_model = net_factory(net_type=args.model, in_chns=1, class_num=num_classes, mode="train")
     for param in ema_model.parameters():
         param.detach_()   # ema_model set
-    db_train = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed)
+    db_train = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed,
+                           transform=DeviceRotFlipCrop(patch_size) if args.augment else None,     # RandomRotFlip -> RandomCrop -> ToTensor (:122-126)
+                           raw_shape=(patch_size[0] + 12, patch_size[1] + 10, patch_size[2] + 8))
     labeled_idxs = list(range(args.labelnum))
     unlabeled_idxs = list(range(args.labelnum, args.max_samples))
     batch_sampler = TwoStreamBatchSampler(labeled_idxs, unlabeled_idxs, args.batch_size, args.batch_size - args.labeled_bs)

@@ -79,6 +79,7 @@ _SIGS = {
     "bcp_sw_finish": (I, [P, P, P, L, F, P]),
     "bcp_overlap_counts": (I, [P, P, L, I, P, P]),
     "bcp_crop_rotflip": (I, [P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, P]),
+    "bcp_acdc_augment": (I, [P, P, I, I, I, I, I, I, P, I, I, P]),
     "bcp_cast": (I, [P, P, L, I, P]),
     "bcp_axpy": (I, [P, P, L, F, P]),
     "bcp_bernoulli": (I, [P, L, F, F, I, U64, P]),

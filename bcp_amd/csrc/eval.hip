@@ -174,3 +174,78 @@ extern "C" int bcp_crop_rotflip(const void* src, void* dst, int elem_bytes, int 
   BCP_CHECK_LAUNCH("bcp_crop_rotflip");
   return BCP_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Device-side input pipeline for ACDC: RandomGenerator of dataloaders/dataset.py:52-88 -- either
+// rot90 + flip, or a rotation by a whole number of degrees (scipy.ndimage.rotate, order=0, reshape=False, cval 0), or nothing --
+// followed by the nearest-neighbour zoom to the training resolution (scipy.ndimage.zoom, order=0) as ONE gather.
+// The coordinate arithmetic restates scipy 1.15's NI_ZoomShift / NI_GeometricTransform for order 0 in fp64, operation for
+// operation (no FMA contraction): zoom source = floor(o * (in - 1) / (out - 1) + 0.5); rotation source = floor(c + 0.5) with
+// c = ((0 + x * m0) + y * m1) + offset, outside [0, len - 1] -> cval.  Pinned against the reference's class (which calls scipy)
+// by tests/golden/aug_acdc.npz.
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+namespace bcp {
+struct Affine2 { double m00, m01, m10, m11, o0, o1, zx, zy; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_acdc_augment(const T* __restrict__ src, T* __restrict__ dst, int H, int W, int mode, int k,
+                                                      int axis, Affine2 A, int OH, int OW) {
+  const int IH = (mode == 1 && (k & 1)) ? W : H, IW = (mode == 1 && (k & 1)) ? H : W;   // shape after the first stage
+  const long long n = (long long)OH * OW;
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x) {
+    const int u = (int)(q / OW), v = (int)(q % OW);
+    // zoom (order 0): nearest source pixel in the intermediate image
+    const double cx = (double)u * A.zx, cy = (double)v * A.zy;
+    int a = (int)floor(cx + 0.5), b = (int)floor(cy + 0.5);
+    a = a < 0 ? 0 : (a > IH - 1 ? IH - 1 : a);
+    b = b < 0 ? 0 : (b > IW - 1 ? IW - 1 : b);
+    T val = 0;
+    if (mode == 0) {
+      val = src[(long long)a * W + b];
+    } else if (mode == 1) {
+      if (axis == 0) a = IH - 1 - a; else b = IW - 1 - b;          // undo np.flip
+      int s0, s1;                                                  // undo np.rot90(m, k)
+      switch (k & 3) {
+        case 0: s0 = a; s1 = b; break;
+        case 1: s0 = b; s1 = W - 1 - a; break;
+        case 2: s0 = H - 1 - a; s1 = W - 1 - b; break;
+        default: s0 = H - 1 - b; s1 = a; break;
+      }
+      val = src[(long long)s0 * W + s1];
+    } else {
+      const double x = (double)a, y = (double)b;
+      double c0 = 0.0, c1 = 0.0;
+      c0 = c0 + x * A.m00; c0 = c0 + y * A.m01; c0 = c0 + A.o0;
+      c1 = c1 + x * A.m10; c1 = c1 + y * A.m11; c1 = c1 + A.o1;
+      if (!(c0 < 0.0 || c0 > (double)(H - 1) || c1 < 0.0 || c1 > (double)(W - 1))) {
+        const int p = (int)floor(c0 + 0.5), r = (int)floor(c1 + 0.5);
+        val = src[(long long)p * W + r];
+      }
+    }
+    dst[q] = val;
+  }
+}
+}  // namespace bcp
+
+extern "C" int bcp_acdc_augment(const void* src, void* dst, int elem_bytes, int H, int W, int mode, int k, int flip_axis,
+                                const double* affine6, int OH, int OW, void* stream) {
+  BCP_REQUIRE(src && dst && H > 1 && W > 1 && OH > 1 && OW > 1, "bcp_acdc_augment: bad extents (every side must be > 1)");
+  BCP_REQUIRE(mode >= 0 && mode <= 2 && (elem_bytes == 4 || elem_bytes == 1), "bcp_acdc_augment: bad mode");
+  BCP_REQUIRE(mode != 1 || ((flip_axis == 0 || flip_axis == 1) && k >= 0 && k < 4), "bcp_acdc_augment: bad rot90 / flip arguments");
+  BCP_REQUIRE(mode != 2 || affine6, "bcp_acdc_augment: the rotation needs its matrix and offset (host pointer to 6 doubles)");
+  Affine2 A{1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 0.0};
+  if (mode == 2) { A.m00 = affine6[0]; A.m01 = affine6[1]; A.m10 = affine6[2]; A.m11 = affine6[3]; A.o0 = affine6[4]; A.o1 = affine6[5]; }
+  const int IH = (mode == 1 && (k & 1)) ? W : H, IW = (mode == 1 && (k & 1)) ? H : W;
+  A.zx = (double)(IH - 1) / (double)(OH - 1);
+  A.zy = (double)(IW - 1) / (double)(OW - 1);
+  const long long n = (long long)OH * OW;
+  if (elem_bytes == 4)
+    hipLaunchKernelGGL((k_acdc_augment<float>), dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, H, W, mode,
+                       k, flip_axis, A, OH, OW);
+  else
+    hipLaunchKernelGGL((k_acdc_augment<uint8_t>), dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src, (uint8_t*)dst, H, W,
+                       mode, k, flip_axis, A, OH, OW);
+  BCP_CHECK_LAUNCH("bcp_acdc_augment");
+  return BCP_OK;
+}

@@ -49,30 +49,43 @@ class TwoStreamBatchSampler(Sampler):
 
 
 class SyntheticLA(Dataset):
-    """80 synthetic LA-like cases (112x112x80 crops), generated once and kept on the device"""
+    """80 synthetic LA-like cases, generated once and kept on the device.  Without a transform the cases already have the
+    training patch shape (112x112x80); with one (DeviceRotFlipCrop: the reference's RandomRotFlip -> RandomCrop -> ToTensor,
+    LA_BCP_train.py:122-126) they are generated at `raw_shape` and every __getitem__ runs the transform on the device."""
 
-    def __init__(self, num=80, shape=(112, 112, 80), device="cpu", seed=1337, distinct=8):
-        vols, labs = synth.la_batch(distinct, shape=shape, seed=seed)
+    def __init__(self, num=80, shape=(112, 112, 80), device="cpu", seed=1337, distinct=8, transform=None, raw_shape=None):
+        vols, labs = synth.la_batch(distinct, shape=raw_shape if (transform is not None and raw_shape) else shape, seed=seed)
         self.vols, self.labs, self.num, self.distinct = vols.to(device), labs.to(device), num, distinct
+        self.transform = transform
+        self.labs8 = self.labs.to(torch.uint8) if transform is not None else None
 
     def __len__(self):
         return self.num
 
     def __getitem__(self, idx):
         j = idx % self.distinct
+        if self.transform is not None:
+            return self.transform({"image": self.vols[j, 0], "label": self.labs8[j]})
         return {"image": self.vols[j], "label": self.labs[j]}
 
 
 class SyntheticACDC(Dataset):
-    def __init__(self, num=1312, shape=(256, 256), device="cpu", seed=1337, distinct=32):
-        vols, labs = synth.acdc_batch(distinct, shape=shape, seed=seed)
+    """synthetic ACDC-like slices on the device; with a transform (DeviceRandomGenerator: the reference's RandomGenerator,
+    ACDC_BCP_train.py:209-211) they are generated at `raw_shape` and zoomed to the training resolution per __getitem__."""
+
+    def __init__(self, num=1312, shape=(256, 256), device="cpu", seed=1337, distinct=32, transform=None, raw_shape=None):
+        vols, labs = synth.acdc_batch(distinct, shape=raw_shape if (transform is not None and raw_shape) else shape, seed=seed)
         self.vols, self.labs, self.num, self.distinct = vols.to(device), labs.to(device), num, distinct
+        self.transform = transform
+        self.labs8 = self.labs.to(torch.uint8) if transform is not None else None
 
     def __len__(self):
         return self.num
 
     def __getitem__(self, idx):
         j = idx % self.distinct
+        if self.transform is not None:
+            return self.transform({"image": self.vols[j, 0], "label": self.labs8[j]})
         return {"image": self.vols[j], "label": self.labs[j]}
 
 
@@ -119,3 +132,46 @@ class DeviceRotFlipCrop:
         img = ops.crop_rotflip(image.contiguous(), self.output_size, k, axis, pads, org)
         lab = ops.crop_rotflip(label.contiguous(), self.output_size, k, axis, pads, org)
         return {"image": img.unsqueeze(0), "label": lab}
+
+
+class DeviceRandomGenerator:
+    """RandomGenerator(output_size) of the reference's ACDC pipeline (dataloaders/dataset.py:69-88; ACDC_BCP_train.py:209-211) on
+    a device-resident slice: with probability 1/2 rot90 + flip (np.random k, axis), else with probability 1/2 a rotation by a
+    whole number of degrees in [-20, 20) (scipy.ndimage.rotate, order=0), then the nearest-neighbour zoom to `output_size`.
+    The draws come from python's `random` and `np.random` in the reference's order; the data movement is ONE gather kernel per
+    tensor (csrc/eval.hip k_acdc_augment) that restates scipy's order-0 coordinate arithmetic in fp64 -- no host copy of the
+    slice, no intermediate rotated / zoomed arrays.
+
+    sample: {'image': float32 [H,W] device tensor, 'label': uint8 [H,W]} -> {'image': [1,OH,OW] float32, 'label': [OH,OW] uint8}"""
+
+    def __init__(self, output_size):
+        self.output_size = tuple(int(v) for v in output_size)
+
+    @staticmethod
+    def draw(shape):
+        """-> (mode, k, axis, affine6): the random.random / np.random draws of RandomGenerator.__call__"""
+        import random
+        if random.random() > 0.5:
+            k = int(np.random.randint(0, 4))
+            axis = int(np.random.randint(0, 2))
+            return 1, k, axis, None
+        if random.random() > 0.5:
+            from scipy import special          # the two functions scipy.ndimage.rotate builds its matrix from
+            angle = int(np.random.randint(-20, 20))
+            c, s = float(special.cosdg(angle)), float(special.sindg(angle))
+            m = np.array([[c, s], [-s, c]])
+            ctr = (np.asarray(shape, dtype=np.float64) - 1) / 2
+            off = ctr - m @ ctr
+            return 2, 0, 0, [m[0, 0], m[0, 1], m[1, 0], m[1, 1], off[0], off[1]]
+        return 0, 0, 0, None
+
+    def __call__(self, sample):
+        from ..utils.BCP_utils import _cpu_ops
+        from ..hip_ops import Ops
+        image, label = sample["image"], sample["label"]
+        ops = Ops.product() if image.is_cuda else _cpu_ops()
+        mode, k, axis, aff = self.draw(tuple(image.shape))
+        img = ops.acdc_augment(image.contiguous(), self.output_size, mode, k, axis, aff)
+        lab = ops.acdc_augment(label.contiguous(), self.output_size, mode, k, axis, aff)
+        return {"image": img.unsqueeze(0), "label": lab}
+

@@ -207,6 +207,16 @@ class Ops:
                     int(pads[2]), int(origin[0]), int(origin[1]), int(origin[2]), int(patch[0]), int(patch[1]), int(patch[2]), self.stream(src))
         return dst
 
+    def acdc_augment(self, src, out_hw, mode, k=0, flip_axis=0, affine6=None):
+        """RandomGenerator's data movement (dataset.py:69-88) for one 2-D tensor: src [H,W] float32 / uint8 -> [OH,OW]"""
+        self._chk(src)
+        Hh, Ww = src.shape
+        dst = torch.empty((int(out_hw[0]), int(out_hw[1])), dtype=src.dtype, device=src.device)
+        aff = (C.c_double * 6)(*[float(v) for v in affine6]) if affine6 is not None else None
+        self.b.call("bcp_acdc_augment", _p(src), _p(dst), src.element_size(), Hh, Ww, int(mode), int(k), int(flip_axis), aff,
+                    int(out_hw[0]), int(out_hw[1]), self.stream(src))
+        return dst
+
     def norm_bwd(self, y, da, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
                  elem_scale=1.0, out=None, partial=None, nb=0):
         self._chk(y, da, stats, dgamma, dbeta, chan_scale, elem_mask)

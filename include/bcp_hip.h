@@ -189,6 +189,15 @@ int bcp_overlap_counts(const uint8_t* pred, const uint8_t* gt, long long n, int 
 int bcp_crop_rotflip(const void* src, void* dst, int elem_bytes, int n0, int n1, int n2, int k, int flip_axis, int pw, int ph, int pd,
                      int w1, int h1, int d1, int P0, int P1, int P2, void* stream);
 
+/* ---- device-side input pipeline, ACDC: RandomGenerator of dataloaders/dataset.py:69-88 as one gather:
+ *      dst[OH][OW] = zoom_nearest(stage1(src[H][W])), stage1 = identity (mode 0) | flip(rot90(src, k), flip_axis) (mode 1,
+ *      dataset.py:52-59) | scipy.ndimage.rotate(src, angle, order=0, reshape=False) (mode 2, dataset.py:62-66; affine6 = HOST
+ *      pointer to {m00, m01, m10, m11, off0, off1} of scipy's rotation, computed by the caller with scipy.special.cosdg / sindg).
+ *      elem_bytes = 4 (float32 image) or 1 (uint8 label).  The caller draws the random numbers (random.random / np.random,
+ *      reference order). */
+int bcp_acdc_augment(const void* src, void* dst, int elem_bytes, int H, int W, int mode, int k, int flip_axis, const double* affine6,
+                     int OH, int OW, void* stream);
+
 /* ---- small utilities ---------------------------------------------------------------------------- */
 int bcp_cast(const void* in, void* out, long long n, int kind, void* stream);
 int bcp_axpy(float* y, const float* x, long long n, float a, void* stream);

@@ -713,3 +713,55 @@ def la_rotflip_crop(image, label, output_size, randint):
     w1, h1, d1 = randint(0, w - P[0]), randint(0, h - P[1]), randint(0, d - P[2])   # :202-204
     sl = (slice(w1, w1 + P[0]), slice(h1, h1 + P[1]), slice(d1, d1 + P[2]))
     return image[sl], label[sl]
+
+
+def _nearest_zoom(a, out_hw):
+    """scipy.ndimage.zoom(a, (OH / H, OW / W), order=0) restated: source index = floor(o * (in - 1) / (out - 1) + 0.5)
+    (scipy 1.15 NI_ZoomShift, grid_mode=False; pinned by tests/golden/aug_acdc.npz)"""
+    H, W = a.shape
+    OH, OW = out_hw
+    px = np.floor(np.arange(OH, dtype=np.float64) * ((H - 1) / (OH - 1)) + 0.5).astype(np.int64)
+    py = np.floor(np.arange(OW, dtype=np.float64) * ((W - 1) / (OW - 1)) + 0.5).astype(np.int64)
+    return a[px[:, None], py[None, :]]
+
+
+def rotate_affine(angle_deg, shape):
+    """matrix and offset scipy.ndimage.rotate(reshape=False) hands to affine_transform: {m00, m01, m10, m11, off0, off1}"""
+    from scipy import special        # cosdg / sindg (cephes, degree arguments) are what scipy.ndimage.rotate itself calls
+    c, s = float(special.cosdg(angle_deg)), float(special.sindg(angle_deg))
+    m = np.array([[c, s], [-s, c]])
+    ctr = (np.asarray(shape, dtype=np.float64) - 1) / 2
+    off = ctr - m @ ctr
+    return [m[0, 0], m[0, 1], m[1, 0], m[1, 1], off[0], off[1]]
+
+
+def _nearest_rotate(a, angle_deg):
+    """scipy.ndimage.rotate(a, angle, order=0, reshape=False) restated (NI_GeometricTransform, mode='constant', cval=0):
+    c = ((0 + x * m0) + y * m1) + offset per axis; outside [0, len - 1] -> 0; else a[floor(c + 0.5)]"""
+    H, W = a.shape
+    m00, m01, m10, m11, o0, o1 = rotate_affine(angle_deg, (H, W))
+    x = np.arange(H, dtype=np.float64)[:, None]
+    y = np.arange(W, dtype=np.float64)[None, :]
+    c0 = ((0.0 + x * m00) + y * m01) + o0
+    c1 = ((0.0 + x * m10) + y * m11) + o1
+    ok = ~((c0 < 0) | (c0 > H - 1) | (c1 < 0) | (c1 > W - 1))
+    p = np.floor(c0 + 0.5).astype(np.int64).clip(0, H - 1)
+    q = np.floor(c1 + 0.5).astype(np.int64).clip(0, W - 1)
+    return np.where(ok, a[p, q], np.zeros((), dtype=a.dtype))
+
+
+def acdc_random_generator(image, label, output_size, rand, randint):
+    """RandomGenerator.__call__ of the ACDC pipeline (dataloaders/dataset.py:69-88; helpers :52-66) with injectable random
+    sources, called in the reference's order: rand() [python random.random], then either randint k, axis (rot_flip) or
+    rand(), randint angle (rotate).  numpy in -> (float32 [1,OH,OW], uint8 [OH,OW])."""
+    if rand() > 0.5:                                                            # :78-79
+        k = randint(0, 4)
+        image, label = np.rot90(image, k), np.rot90(label, k)
+        axis = randint(0, 2)
+        image, label = np.flip(image, axis=axis).copy(), np.flip(label, axis=axis).copy()
+    elif rand() > 0.5:                                                          # :80-81
+        angle = randint(-20, 20)
+        image, label = _nearest_rotate(image, angle), _nearest_rotate(label, angle)
+    image = _nearest_zoom(image, output_size)                                   # :82-84
+    label = _nearest_zoom(label, output_size)
+    return image.astype(np.float32)[None], label.astype(np.uint8)               # :85-86

@@ -69,6 +69,42 @@ def main_aug():
     print("wrote", os.path.normpath(out), len(cases), "cases")
 
 
+def main_aug_acdc():
+    """G11: the REFERENCE's RandomGenerator (dataloaders/dataset.py:69-88: python random + np.random + scipy rotate / zoom) on seeded
+    slices of ACDC-like shapes; seeds chosen so that all three branches (rot90 + flip, rotate, neither) occur"""
+    import random
+    from dataloaders import dataset as ref_ds
+    rng = np.random.default_rng(SEED + 11)
+    OUT = (64, 72)
+    gen = ref_ds.RandomGenerator(OUT)
+    d, n, branches = {"out_hw": np.array(OUT)}, 0, []
+    for ci, shape in enumerate([(54, 64), (64, 54), (39, 47), (80, 91), (64, 72)]):
+        image = rng.random(shape).astype(np.float32)                         # ACDC slices are min-max normalised floats
+        label = (rng.random(shape) * 4).astype(np.uint8)
+        # smooth-ish labels: blocks of 3 x 3 so that nearest-neighbour picks are visible as structure, not noise
+        label = np.kron(label[::3, ::3], np.ones((3, 3), dtype=np.uint8))[:shape[0], :shape[1]]
+        label = np.pad(label, ((0, shape[0] - label.shape[0]), (0, shape[1] - label.shape[1])))
+        d[f"in_image_{ci}"], d[f"in_label_{ci}"] = image, label
+        for rep in range(6):
+            seed = 1000 * ci + rep
+            random.seed(seed)
+            np.random.seed(seed)
+            r1 = random.random()
+            br = "rotflip" if r1 > 0.5 else ("rotate" if random.random() > 0.5 else "none")
+            branches.append(br)
+            random.seed(seed)
+            np.random.seed(seed)
+            out = gen({"image": image, "label": label})
+            d[f"case_{n}"] = np.array([ci, seed])
+            d[f"out_image_{n}"], d[f"out_label_{n}"] = out["image"].numpy(), out["label"].numpy()
+            n += 1
+    d["n_cases"] = np.int64(n)
+    out = os.path.join(HERE, "..", "tests", "golden", "aug_acdc.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", os.path.normpath(out), n, "cases; branches:", {b: branches.count(b) for b in set(branches)})
+
+
 if __name__ == "__main__":
     main()
     main_aug()
+    main_aug_acdc()

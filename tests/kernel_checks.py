@@ -646,4 +646,39 @@ def check_augment(ops, dev, golden_dir):
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"])
 
 
-ALL_CHECKS = ("augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_ws", "conv3_res_split", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+def check_augment_acdc(ops, dev, golden_dir):
+    """device-side RandomGenerator (ACDC) == the REFERENCE's class (python random + np.random + scipy rotate / zoom,
+    tests/golden/aug_acdc.npz: 15 rot90+flip, 7 rotate, 8 plain cases over 5 slice shapes), bit for bit, and == the oracle"""
+    import os
+    import random
+    import bcp_oracle as O
+    from bcp_amd.dataloaders.dataset import DeviceRandomGenerator
+    from bcp_amd.utils import BCP_utils as BU
+    if dev.type == "cpu":
+        BU.set_test_ops(ops)
+    g = np.load(os.path.join(golden_dir, "aug_acdc.npz"))
+    out_hw = tuple(int(v) for v in g["out_hw"])
+    tf = DeviceRandomGenerator(out_hw)
+    for i in range(int(g["n_cases"])):
+        ci, seed = (int(v) for v in g[f"case_{i}"])
+        image, label = g[f"in_image_{ci}"], g[f"in_label_{ci}"]
+        random.seed(seed)
+        np.random.seed(seed)
+        out = tf({"image": torch.from_numpy(image).to(dev), "label": torch.from_numpy(label).to(dev)})
+        assert tuple(out["image"].shape) == (1,) + out_hw and out["label"].dtype == torch.uint8
+        assert np.array_equal(out["image"].cpu().numpy(), g[f"out_image_{i}"]), f"ACDC augment image case {i}"
+        assert np.array_equal(out["label"].cpu().numpy(), g[f"out_label_{i}"]), f"ACDC augment label case {i}"
+        random.seed(seed)
+        np.random.seed(seed)
+        oi, ol = O.acdc_random_generator(image, label, out_hw, random.random, lambda lo, hi: int(np.random.randint(lo, hi)))
+        assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"]), f"oracle case {i}"
+    # every whole-degree angle the reference can draw, on an odd-sized slice: the gather == the oracle's restatement of scipy
+    rng = np.random.default_rng(12)
+    img = rng.random((45, 52)).astype(np.float32)
+    for angle in range(-20, 20):
+        aff = O.rotate_affine(angle, img.shape)
+        got = ops.acdc_augment(torch.from_numpy(img).to(dev), (64, 64), 2, 0, 0, aff).cpu().numpy()
+        assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
+
+
+ALL_CHECKS = ("augment_acdc", "augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_ws", "conv3_res_split", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")

@@ -29,7 +29,7 @@ def emu_ops():
 @pytest.mark.parametrize("name", K.ALL_CHECKS)
 def test_emu(emu_ops, golden_dir, name):
     fn = getattr(K, "check_" + name)
-    if name in ("plabel", "cc", "mixloss", "augment"):
+    if name in ("plabel", "cc", "mixloss", "augment", "augment_acdc"):
         fn(emu_ops, torch.device("cpu"), golden_dir)
     else:
         fn(emu_ops, torch.device("cpu"))

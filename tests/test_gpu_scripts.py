@@ -25,6 +25,18 @@ def test_acdc_script(tmp_path, monkeypatch):
     assert len(sd) == 226 and all(torch.isfinite(v.float()).all() for v in sd.values())
 
 
+def test_scripts_with_device_input_pipeline(tmp_path, monkeypatch):
+    """--augment: raw-size synthetic cases + the device-side transforms (DeviceRotFlipCrop / DeviceRandomGenerator)
+    in front of the same loops"""
+    monkeypatch.chdir(tmp_path)
+    from bcp_amd import ACDC_BCP_train as TA
+    from bcp_amd import LA_BCP_train as TL
+    TL.main(["--labelnum", "8", "--batch_size", "4", "--labeled_bs", "2", "--pre_max_iteration", "2", "--self_max_iteration", "2", "--log_every", "1",
+             "--augment", "--exp", "aug"])
+    TA.main(["--labelnum", "7", "--batch_size", "24", "--labeled_bs", "12", "--pre_iterations", "2", "--max_iterations", "2", "--log_every", "1",
+             "--augment", "--exp", "aug"])
+
+
 def test_pancreas_script():
     from bcp_amd.pancreas import train_pancreas as T
     T.main(["--pretraining_epochs", "1", "--self_training_epochs", "1", "--steps_per_epoch", "2", "--batch_size", "1"])

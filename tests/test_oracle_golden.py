@@ -279,3 +279,26 @@ def test_sliding_window_oracle_vs_reference(golden_dir):
     border = np.abs(g["score_map"] - 0.5) < 1e-5
     assert np.array_equal(label[~border].astype(np.uint8), g["label_map"][~border])
     assert abs(O.dice_binary(g["label_map"], g["gt"]) - float(g["dice"])) < 1e-12
+
+
+def test_input_pipelines_oracle_vs_reference(golden_dir):
+    """8f-4: the oracle's restatements of the LA (RandomRotFlip + RandomCrop) and ACDC (RandomGenerator: rot90 / flip, scipy
+    rotate + zoom at order 0) transforms == the reference's classes on the same random state (goldens made by
+    oracle/make_golden_eval.py from the imported reference)"""
+    import random
+    g = np.load(os.path.join(golden_dir, "aug_la.npz"))
+    P = tuple(int(v) for v in g["patch"])
+    for i in range(int(g["n_cases"])):
+        ci, seed = (int(v) for v in g[f"case_{i}"])
+        np.random.seed(seed)
+        oi, ol = O.la_rotflip_crop(g[f"in_image_{ci}"], g[f"in_label_{ci}"], P, lambda lo, hi: int(np.random.randint(lo, hi)))
+        assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"]), i
+    g = np.load(os.path.join(golden_dir, "aug_acdc.npz"))
+    out_hw = tuple(int(v) for v in g["out_hw"])
+    for i in range(int(g["n_cases"])):
+        ci, seed = (int(v) for v in g[f"case_{i}"])
+        random.seed(seed)
+        np.random.seed(seed)
+        oi, ol = O.acdc_random_generator(g[f"in_image_{ci}"], g[f"in_label_{ci}"], out_hw, random.random,
+                                         lambda lo, hi: int(np.random.randint(lo, hi)))
+        assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"]), i
