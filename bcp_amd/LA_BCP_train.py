@@ -124,7 +124,7 @@ def pre_train(args, snapshot_path, device):
             loss.backward()
             optimizer.step()
             if iter_num % args.log_every == 0:
-                logging.info('iteration %d : loss: %03f, loss_dice: %03f, loss_ce: %03f' % (iter_num, loss, loss_dice, loss_ce))
+                logging.info('iteration %d : loss: %03f, loss_dice: %03f, loss_ce: %03f' % (iter_num, float(loss.detach()), float(loss_dice.detach()), float(loss_ce.detach())))
             if args.val_every > 0 and iter_num % args.val_every == 0:       # LA_BCP_train.py:174-187
                 model.eval()
                 dice_sample = test_3d_patch.var_all_case_LA(model, num_classes=num_classes, patch_size=patch_size, stride_xy=18, stride_z=4,

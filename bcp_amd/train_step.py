@@ -109,6 +109,15 @@ class FlatAdam:
         _ops_for(p).adam(p, gr, self.m, self.v, g["lr"], self.steps, g["betas"][0], g["betas"][1], g["eps"], grad_scale=self.grad_scale)
         self.model.bump()
 
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": self.param_groups}
+
+    def load_state_dict(self, sd):
+        # (clones: the reference loads ONE checkpoint's optimiser state twice, train_pancreas.py:116-117)
+        self.m = None if sd["m"] is None else sd["m"].clone()
+        self.v = None if sd["v"] is None else sd["v"].clone()
+        self.steps, self.param_groups = sd["steps"], sd["param_groups"]
+
 
 # ------------------------------------------------------------------------------------------ LA / pancreas step
 def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,

@@ -32,10 +32,11 @@ def _to_dev(a, device, dtype):
     return a.to(device=device, dtype=dtype)
 
 
-def test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=1, batch=4, device=None):
-    """utils/test_3d_patch.py:82-141.  image: [W,H,D] numpy array or tensor.  Returns (label_map uint8 [W,H,D],
-    score_map float32 [num_classes,W,H,D]) as tensors on the model's device (all channels of score_map hold the class-1
-    probability, exactly as the reference's broadcast add at :131 leaves them)."""
+def sliding_window_scores(model, image, stride_xy, stride_z, patch_size, classes=(1,), batch=4, device=None):
+    """the shared core of the reference's two test_single_case flavours (utils/test_3d_patch.py:82-141, pancreas/test_util.py:88-148):
+    zero-pad up to the patch size, walk the patch grid, run the eval-mode net on `batch` patches per call, accumulate the softmax
+    probability of every class in `classes` and the visit counts on the device.
+    -> (scores: one float32 [WW,HH,DD] SUM per requested class, cnt, crop) with crop = the slices that undo the padding (or None)."""
     if device is None:
         device = next(model.parameters()).device
     image = _to_dev(image, device, torch.float32)
@@ -52,8 +53,9 @@ def test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=
     sy = math.ceil((hh - patch_size[1]) / stride_xy) + 1
     sz = math.ceil((dd - patch_size[2]) / stride_z) + 1
     ops = _ops_for(image)
-    score = torch.zeros((ww, hh, dd), dtype=torch.float32, device=device)
+    scores = [torch.zeros((ww, hh, dd), dtype=torch.float32, device=device) for _ in classes]
     cnt = torch.zeros((ww, hh, dd), dtype=torch.float32, device=device)
+    scratch = torch.zeros((ww, hh, dd), dtype=torch.float32, device=device) if len(classes) > 1 else None
     origins = [(min(stride_xy * x, ww - patch_size[0]), min(stride_xy * y, hh - patch_size[1]), min(stride_z * z, dd - patch_size[2]))
                for x in range(sx) for y in range(sy) for z in range(sz)]
     was_training = model.training
@@ -68,13 +70,22 @@ def test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=
                 cl = logits.permute(0, 2, 3, 4, 1)
                 cl = cl if cl.is_contiguous() else cl.contiguous()
                 for b, org in enumerate(chunk):                                  # patches overlap: accumulate in stream order
-                    ops.sw_accumulate(cl[b], score, cnt, org, cls=1)
+                    for ci, c in enumerate(classes):                             # (the kernel counts a visit per call: only the first class's counts are kept)
+                        ops.sw_accumulate(cl[b], scores[ci], cnt if ci == 0 else scratch, org, cls=c)
     finally:
         model.train(was_training)
-    label = ops.sw_finish(score, cnt, 0.5)
-    if add_pad:
-        sl = tuple(slice(l, l + s) for (l, _), s in zip(pads, (w, h, d)))
-        label, score = label[sl].contiguous(), score[sl].contiguous()
+    crop = tuple(slice(l, l + s) for (l, _), s in zip(pads, (w, h, d))) if add_pad else None
+    return scores, cnt, crop
+
+
+def test_single_case(model, image, stride_xy, stride_z, patch_size, num_classes=1, batch=4, device=None):
+    """utils/test_3d_patch.py:82-141.  image: [W,H,D] numpy array or tensor.  Returns (label_map uint8 [W,H,D],
+    score_map float32 [num_classes,W,H,D]) as tensors on the model's device (all channels of score_map hold the class-1
+    probability, exactly as the reference's broadcast add at :131 leaves them)."""
+    (score,), cnt, crop = sliding_window_scores(model, image, stride_xy, stride_z, patch_size, (1,), batch, device)
+    label = _ops_for(score).sw_finish(score, cnt, 0.5)
+    if crop is not None:
+        label, score = label[crop].contiguous(), score[crop].contiguous()
     score_map = score.unsqueeze(0).expand(max(1, num_classes), -1, -1, -1)
     return label, score_map
 

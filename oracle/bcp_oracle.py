@@ -675,6 +675,47 @@ def sliding_window_la(P, image, stride_xy, stride_z, patch_size, variant="la"):
     return label, score
 
 
+def sliding_window_pancreas(P, image, stride_xy, stride_z, patch_size):
+    """pancreas/test_util.py:88-148 test_single_case (TMI=0) with the IN-V-Net in eval() mode: BOTH softmax channels are
+    accumulated, label = argmax over the averaged scores (first max wins: class 1 only where its score is strictly larger).
+    image: numpy [W,H,D].  Returns (label_map int64 [W,H,D], score_map float32 [2,W,H,D])."""
+    import math
+    image = np.asarray(image, dtype=np.float32)
+    w, h, d = image.shape
+    pads = []
+    for size, p in zip((w, h, d), patch_size):
+        tot = max(p - size, 0)
+        pads.append((tot // 2, tot - tot // 2))                                    # :108-110
+    add_pad = any(l or r for l, r in pads)
+    if add_pad:
+        image = np.pad(image, pads, mode="constant", constant_values=0)           # :111-112
+    ww, hh, dd = image.shape
+    sx = math.ceil((ww - patch_size[0]) / stride_xy) + 1                           # :115-117
+    sy = math.ceil((hh - patch_size[1]) / stride_xy) + 1
+    sz = math.ceil((dd - patch_size[2]) / stride_z) + 1
+    score = np.zeros((2,) + image.shape, dtype=np.float32)
+    cnt = np.zeros(image.shape, dtype=np.float32)
+    for x in range(sx):
+        xs = min(stride_xy * x, ww - patch_size[0])
+        for y in range(sy):
+            ys = min(stride_xy * y, hh - patch_size[1])
+            for z in range(sz):
+                zs = min(stride_z * z, dd - patch_size[2])
+                patch = torch.from_numpy(image[xs:xs + patch_size[0], ys:ys + patch_size[1], zs:zs + patch_size[2]][None, None].copy())
+                with torch.no_grad():
+                    logits = vnet_forward(P, patch, None, False, "pancreas", has_dropout=False)
+                    prob = F.softmax(logits, dim=1)[0].numpy()                     # :134-137
+                sl = (slice(None), slice(xs, xs + patch_size[0]), slice(ys, ys + patch_size[1]), slice(zs, zs + patch_size[2]))
+                score[sl] += prob
+                cnt[sl[1:]] += 1
+    score = score / cnt[None]                                                      # :142
+    label = np.argmax(score, axis=0)                                               # :143
+    if add_pad:
+        sl = tuple(slice(l, l + s) for (l, _), s in zip(pads, (w, h, d)))
+        label, score = label[sl], score[(slice(None),) + sl]
+    return label, score
+
+
 def eval_params(seed, variant="la"):
     """random-init V-Net weights + NON-trivial running statistics (eval-mode BatchNorm must use them): the parameter set of
     tests/golden/sw_la.npz (oracle/make_golden_eval.py)"""

@@ -104,7 +104,26 @@ def main_aug_acdc():
     print("wrote", os.path.normpath(out), n, "cases; branches:", {b: branches.count(b) for b in set(branches)})
 
 
+def main_sw_pancreas():
+    """G12: the REFERENCE's pancreas/test_util.py:test_single_case driving the REFERENCE IN-V-Net (pancreas/Vnet.py) in eval mode"""
+    ref_tu = MG._load(os.path.join(MG.REF, "pancreas", "test_util.py"), "ref_pancreas_test_util")
+    P = O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=SEED + 20, random_affine=True)
+    net = MG.ref_pvnet.VNet()
+    net.load_state_dict(MG.clone_params(P), strict=True)
+    net.eval()
+    rng = np.random.default_rng(SEED + 21)
+    shape, patch, sxy, sz = (36, 40, 30), (32, 32, 32), 6, 4      # D < patch: the zero-padding branch (:103-112)
+    image = rng.standard_normal(shape).astype(np.float32)
+    with torch.no_grad():
+        label_map, score_map = ref_tu.test_single_case(net, image, sxy, sz, patch, num_classes=2)
+    out = os.path.join(HERE, "..", "tests", "golden", "sw_pancreas.npz")
+    np.savez_compressed(out, image=image, label_map=label_map.astype(np.uint8), score_map=score_map.astype(np.float32),
+                        seed=np.int64(SEED + 20), patch=np.array(patch), stride=np.array([sxy, sz]))
+    print("wrote", os.path.normpath(out), "fg fraction", float(label_map.mean()), "score range", float(score_map.min()), float(score_map.max()))
+
+
 if __name__ == "__main__":
     main()
     main_aug()
     main_aug_acdc()
+    main_sw_pancreas()

@@ -337,6 +337,26 @@ def check_sliding_window(ops, dev, golden_dir):
     assert abs(mean_dice - O.dice_binary(label, g["gt"])) < 1e-3
 
 
+def check_sliding_window_pancreas(ops, dev, golden_dir):
+    """pancreas validation path: IN-V-Net + two-channel sliding window + argmax on the device vs the REFERENCE's
+    pancreas/test_util.py:test_single_case (tests/golden/sw_pancreas.npz) and vs the oracle restatement"""
+    from bcp_amd.pancreas import test_util as PT
+    g = np.load(os.path.join(golden_dir, "sw_pancreas.npz"))
+    P = O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=int(g["seed"]), random_affine=True)
+    net = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+    patch, (sxy, sz) = tuple(int(v) for v in g["patch"]), (int(v) for v in g["stride"])
+    label, score = PT.test_single_case(net, g["image"], sxy, sz, patch, num_classes=2, batch=3)
+    assert net.training, "test_single_case must restore train() mode"
+    score, label = score.cpu().numpy(), label.cpu().numpy()
+    assert score.shape == g["score_map"].shape and label.shape == g["label_map"].shape
+    err = np.abs(score - g["score_map"]).max()
+    assert err < 2e-5, f"score map vs reference: {err:.3e}"
+    border = np.abs(g["score_map"][1] - g["score_map"][0]) < 2e-4     # voxels within rounding of a tie may legitimately flip
+    assert np.array_equal(label[~border], g["label_map"][~border]) and border.mean() < 0.01
+    (avg, lst) = PT.test_calculate_metric(net, [(g["image"], g["label_map"])], num_classes=2, dim=patch, s_xy=int(g["stride"][0]), s_z=int(g["stride"][1]))
+    assert avg[0] > 0.99 and len(lst) == 1 and net.training      # the prediction against the reference's own label map
+
+
 def check_unet_eval(ops, dev, seed=5):
     """model.eval() U-Net forward (running statistics, no dropout) vs the oracle; the running statistics stay untouched"""
     rng = np.random.default_rng(seed)

@@ -30,3 +30,8 @@ def test_grouped_forward_equals_separate_calls(emu_ops):
 
 def test_sliding_window_validation(emu_ops, golden_dir):
     NC.check_sliding_window(emu_ops, CPU, golden_dir)
+
+
+def test_sliding_window_validation_pancreas(emu_ops, golden_dir):
+    NC.check_sliding_window_pancreas(emu_ops, CPU, golden_dir)
+

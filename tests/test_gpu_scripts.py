@@ -37,9 +37,17 @@ def test_scripts_with_device_input_pipeline(tmp_path, monkeypatch):
              "--augment", "--exp", "aug"])
 
 
-def test_pancreas_script():
+def test_pancreas_script(tmp_path):
     from bcp_amd.pancreas import train_pancreas as T
     T.main(["--pretraining_epochs", "1", "--self_training_epochs", "1", "--steps_per_epoch", "2", "--batch_size", "1"])
+    # with the validation gate (pancreas/test_util.py:test_calculate_metric, sliding window over a 104x100x96 case) and the
+    # reference's checkpoint hand-off: best pre-trained {'net','opt','epoch'} -> both nets -> best self-trained {'net'}
+    T.main(["--pretraining_epochs", "2", "--self_training_epochs", "2", "--steps_per_epoch", "1", "--batch_size", "1", "--val_every", "1",
+            "--val_stride", "48", "48", "--result_dir", str(tmp_path / "cutmix")])
+    pre = torch.load(tmp_path / "cutmix/pretrain/best_ema20_pre.pth")
+    assert set(pre) == {"net", "opt", "epoch"} and len(pre["net"]) == 60
+    st = torch.load(tmp_path / "cutmix/self_train/best_ema_20_self.pth")
+    assert len(st["net"]) == 60 and all(torch.isfinite(v.float()).all() for v in st["net"].values())
 
 
 def test_pancreas_grouped_step_matches_two_calls():

@@ -76,3 +76,8 @@ def test_grouped_forward_equals_separate_calls(ops):
 
 def test_sliding_window_validation(ops, golden_dir):
     NC.check_sliding_window(ops, DEV, golden_dir)
+
+
+def test_sliding_window_validation_pancreas(ops, golden_dir):
+    NC.check_sliding_window_pancreas(ops, DEV, golden_dir)
+

@@ -281,6 +281,16 @@ def test_sliding_window_oracle_vs_reference(golden_dir):
     assert abs(O.dice_binary(g["label_map"], g["gt"]) - float(g["dice"])) < 1e-12
 
 
+def test_sliding_window_pancreas_oracle_vs_reference(golden_dir):
+    """oracle restatement of pancreas/test_util.py:test_single_case (two channels, argmax) vs the reference's own output"""
+    g = np.load(os.path.join(golden_dir, "sw_pancreas.npz"))
+    P = O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=int(g["seed"]), random_affine=True)
+    label, score = O.sliding_window_pancreas(P, g["image"], int(g["stride"][0]), int(g["stride"][1]), tuple(int(v) for v in g["patch"]))
+    assert score.shape == g["score_map"].shape and np.abs(score - g["score_map"]).max() < 2e-6
+    border = np.abs(g["score_map"][1] - g["score_map"][0]) < 2e-5
+    assert np.array_equal(label[~border].astype(np.uint8), g["label_map"][~border])
+
+
 def test_input_pipelines_oracle_vs_reference(golden_dir):
     """8f-4: the oracle's restatements of the LA (RandomRotFlip + RandomCrop) and ACDC (RandomGenerator: rot90 / flip, scipy
     rotate + zoom at order 0) transforms == the reference's classes on the same random state (goldens made by
