@@ -2,10 +2,11 @@
 
   test_single_volume(image [1,S,X,Y], label [1,S,X,Y], model, classes, patch_size=[256,256]) -> [(dice, hd95)] * (classes-1)
 
-Slices whose size equals patch_size (the ACDC training resolution) never leave the device: all slices of the volume go through
-the net in batches (eval-mode BatchNorm is per element, so batching changes nothing), softmax + argmax is the pseudo-label kernel
-(first maximum wins, as torch.argmax), per-class overlap counts are integer atomics.  Other sizes take the reference's route --
-scipy.ndimage.zoom(order=0) on the host, as val_2d.py:26,35 do.  hd95 is medpy CPU code: reported as nan.
+Nothing leaves the device: slices of another size than patch_size are zoomed to it and the label maps back with the same
+nearest-neighbour gather that restates scipy.ndimage.zoom(order=0) (val_2d.py:26,35; csrc/eval.hip k_acdc_augment), all slices
+of the volume go through the net in batches (eval-mode BatchNorm is per element, so batching changes nothing), softmax + argmax
+is the pseudo-label kernel (first maximum wins, as torch.argmax), per-class overlap counts are integer atomics.
+hd95 is medpy CPU code: reported as nan.
 """
 from __future__ import annotations
 
@@ -39,26 +40,23 @@ def test_single_volume(image, label, model, classes, patch_size=(256, 256), batc
     model.eval()
     try:
         with torch.no_grad():
-            if (x, y) == tuple(patch_size):
-                preds = []
-                for i in range(0, S, batch):
-                    out = model(image[i:i + batch].unsqueeze(1))
-                    out = out[0] if isinstance(out, (tuple, list)) else out
-                    cl = out.permute(0, 2, 3, 1).unsqueeze(1)                   # physical [B,1,X,Y,C]
-                    preds.append(ops.plabel_argmax4(cl if cl.is_contiguous() else cl.contiguous())[:, 0])
-                prediction = torch.cat(preds)
-            else:
-                from scipy.ndimage import zoom
-                img = image.cpu().numpy()
-                prediction = np.zeros((S, x, y), dtype=np.uint8)
-                for ind in range(S):
-                    sl = zoom(img[ind], (patch_size[0] / x, patch_size[1] / y), order=0)                      # :26
-                    out = model(torch.from_numpy(sl).to(device)[None, None].float())
-                    out = out[0] if isinstance(out, (tuple, list)) else out
-                    cl = out.permute(0, 2, 3, 1).unsqueeze(1)
-                    o = ops.plabel_argmax4(cl if cl.is_contiguous() else cl.contiguous())[0, 0].cpu().numpy()
-                    prediction[ind] = zoom(o, (x / patch_size[0], y / patch_size[1]), order=0)                # :35
-                prediction = torch.from_numpy(prediction).to(device)
+            # other slice sizes: the reference zooms every slice to the training resolution and the label map back, both with
+            # scipy.ndimage.zoom(order=0) (val_2d.py:26,35) -- here the same nearest-neighbour gathers on the device
+            # (bcp_acdc_augment mode 0, bit-identical to scipy's order-0 zoom: tests/golden/aug_acdc.npz)
+            resize = (x, y) != tuple(patch_size)
+            preds = []
+            for i in range(0, S, batch):
+                sl = image[i:i + batch]
+                if resize:
+                    sl = torch.stack([ops.acdc_augment(s.contiguous(), patch_size, 0) for s in sl])
+                out = model(sl.unsqueeze(1))
+                out = out[0] if isinstance(out, (tuple, list)) else out
+                cl = out.permute(0, 2, 3, 1).unsqueeze(1)                   # physical [B,1,X,Y,C]
+                lab = ops.plabel_argmax4(cl if cl.is_contiguous() else cl.contiguous())[:, 0]
+                if resize:
+                    lab = torch.stack([ops.acdc_augment(o.contiguous(), (x, y), 0) for o in lab])
+                preds.append(lab)
+            prediction = torch.cat(preds)
     finally:
         model.train(was_training)
     gt = label.to(torch.uint8).contiguous()
