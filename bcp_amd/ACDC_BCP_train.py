@@ -121,7 +121,7 @@ def pre_train(args, snapshot_path, device):
             optimizer.step()
             iter_num += 1
             if iter_num % args.log_every == 0:
-                logging.info('iteration %d: loss: %f, mix_dice: %f, mix_ce: %f' % (iter_num, loss, loss_dice, loss_ce))
+                logging.info('iteration %d: loss: %f, mix_dice: %f, mix_ce: %f' % (iter_num, float(loss.detach()), float(loss_dice.detach()), float(loss_ce.detach())))
             if args.val_every > 0 and iter_num % args.val_every == 0:            # ACDC_BCP_train.py:273-295
                 performance = _validate(model, val_set, args.num_classes)
                 if performance > best_performance:
@@ -176,7 +176,7 @@ def self_train(args, pre_snapshot_path, snapshot_path, device):
             iter_num += 1
             update_model_ema(model, ema_model, 0.99)
             if iter_num % args.log_every == 0:
-                logging.info('iteration %d: loss: %f, mix_dice: %f, mix_ce: %f' % (iter_num, loss, loss_dice, loss_ce))
+                logging.info('iteration %d: loss: %f, mix_dice: %f, mix_ce: %f' % (iter_num, float(loss.detach()), float(loss_dice.detach()), float(loss_ce.detach())))
             if args.val_every > 0 and iter_num % args.val_every == 0:            # ACDC_BCP_train.py:402-424
                 performance = _validate(model, val_set, args.num_classes)
                 if performance > best_performance:

@@ -195,7 +195,7 @@ def self_train(args, pre_snapshot_path, self_snapshot_path, device):
             loss.backward()
             optimizer.step()
             if iter_num % args.log_every == 0:
-                logging.info('iteration %d : loss: %03f, loss_l: %03f, loss_u: %03f' % (iter_num, loss, loss_l, loss_u))
+                logging.info('iteration %d : loss: %03f, loss_l: %03f, loss_u: %03f' % (iter_num, float(loss.detach()), float(loss_l.detach()), float(loss_u.detach())))
 
             update_ema_variables(model, ema_model, 0.99)
 
