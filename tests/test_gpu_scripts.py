@@ -118,3 +118,66 @@ def test_dp_bucketed_allreduce_over_rccl_one_rank():
     env = dict(os.environ, BCP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _DP1], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "DP1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_DP2 = r"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["BCP_ROOT"]); sys.path.insert(0, os.path.join(os.environ["BCP_ROOT"], "oracle"))
+import bcp_oracle as O
+from bcp_amd import train_step
+from bcp_amd.dp import DataParallel
+from bcp_amd.networks.VNet import VNet
+rank = int(os.environ["RANK"])
+dev = torch.device("cuda", 0); torch.cuda.set_device(dev)
+dp = DataParallel(backend="gloo")                  # two ranks share the one GPU of the box: gloo moves the CUDA buckets through the host
+P = O.init_params(O.vnet_param_shapes(), seed=7 + rank, random_affine=True)      # different per rank: the broadcast must fix it
+nets = []
+for _ in range(2):
+    n = VNet(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True).to(dev)
+    n.load_state_dict({k: P[k].clone() for k in n.state_dict()})
+    nets.append(n.flatten_().train())
+model, ema = nets
+for p in ema.parameters():
+    p.detach_()
+dp.broadcast_params(model); dp.broadcast_params(ema)
+opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+vol, lab = O.synth_la_batch(4, shape=(32, 32, 16), seed=100 + rank)
+vol, lab = vol.to(dev), lab.to(dev)
+for m in (model, ema):
+    m._drop_seed = 5 + rank
+np.random.seed(11 + rank)
+for it in range(3):
+    r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(2 + rank, 4, 1 + it, 21, 21, 10), dp=dp)
+torch.cuda.synchronize()
+torch.save({"flat": model.flat_params().cpu(), "ema": ema.flat_params().cpu(), "loss": float(r["loss"]), "n": dp.n_collectives},
+           os.path.join(os.environ["BCP_OUT"], f"r{rank}_mb{os.environ['BCP_DP_BUCKET_MB']}.pt"))
+dp.shutdown()
+"""
+
+
+def test_dp_two_ranks_on_one_gpu_buckets_equal_single_allreduce(tmp_path):
+    """two REAL ranks (two processes, gloo over CUDA tensors, sharing cuda:0) run three LA steps with the bucketed exchange issued
+    from inside the backward pass next to the weight-gradient side stream: both ranks end with identical students and teachers,
+    and the result equals, bit for bit, the run with ONE all-reduce after the backward pass (BCP_DP_BUCKET_MB=0)"""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mb in ("8", "0"):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs = []
+        for rank in range(2):
+            env = dict(os.environ, BCP_ROOT=root, BCP_OUT=str(tmp_path), RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2",
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BCP_DP_BUCKET_MB=mb)
+            procs.append(subprocess.Popen([sys.executable, "-c", _DP2], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+        outs = [p.communicate(timeout=600)[0] for p in procs]
+        assert all(p.returncode == 0 for p in procs), "\n".join(o[-3000:] for o in outs)
+        res[mb] = [torch.load(tmp_path / f"r{r}_mb{mb}.pt") for r in range(2)]
+        assert torch.equal(res[mb][0]["flat"], res[mb][1]["flat"]) and torch.equal(res[mb][0]["ema"], res[mb][1]["ema"])
+    assert res["8"][0]["n"] >= 9 and res["0"][0]["n"] == 3
+    assert torch.equal(res["8"][0]["flat"], res["0"][0]["flat"]) and res["8"][0]["loss"] == res["0"][0]["loss"]
