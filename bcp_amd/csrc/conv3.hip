@@ -1808,6 +1808,11 @@ static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   // 4x8x8 -- but inside the step, next to the dgrad / norm-backward kernels of the main stream, the 256-voxel tile wins
   // (8.95 vs 9.02 ms per step, interleaved A/B of the two libraries): 4x8x8 stays.  The 16-channel level keeps 4x4x16
   // (259 us vs 286 / 283 / 314 us for 4x4x8 / 4x8x8 / 4x4x4).
+  // 2-D (ACDC) levels below 128 K pixels: choose_cfg hands out 8x8 tiles for the forward grid's sake, but a weight-gradient
+  // block gets its parallelism from the (cin chunk, cout slab) grid, and with 9 taps an 8x8 tile is only 288 MFMAs per staged
+  // halo + dY tile: 16x16 tiles run 52 / 61 / 54 us instead of 58 / 66 / 66 us at 64 / 128 / 256 channels, and the ACDC step
+  // 5.45 instead of 5.68 ms.
+  if (KD == 1 && H >= 16 && W >= 16) { c.TH = 16; c.TW = 16; }
   if (const char* e = getenv("BCP_WGRAD_TILE")) {   // measurements: "TD,TH,TW"
     int td, th, tw;
     if (sscanf(e, "%d,%d,%d", &td, &th, &tw) == 3) { c.TD = td; c.TH = th; c.TW = tw; }
