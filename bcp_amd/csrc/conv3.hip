@@ -1604,7 +1604,12 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
     r.TW = vox >= 256LL * 1024 ? 16 : (vox >= 64LL * 1024 ? 8 : 4);
   } else {
     r.TD = 1;
-    if (vox >= 128LL * 1024) { r.TH = 16; r.TW = 16; } else { r.TH = 8; r.TW = 8; }
+    // 16x16 tiles from 10 K pixels per launch on (the 64^2 and 32^2 U-Net levels at a grouped batch of 12): ALONE the 8x8-tile
+    // kernels with their wider slabs are faster (48 vs 67 us at 64 channels), inside the ACDC step the 16x16 ones win
+    // (5.35 vs 5.43 ms, interleaved A/B; thresholds 128 K / 40 K / 10 K / 1 K pixels: 5.43 / 5.39 / 5.35 / 5.36 ms)
+    long long thr = 10000;
+    if (const char* e = getenv("BCP_RES_TILE2D_VOX")) thr = atoll(e);   // measurements
+    if (vox >= thr && H >= 16 && W >= 16) { r.TH = 16; r.TW = 16; } else { r.TH = 8; r.TW = 8; }
   }
   const int PD = KD == 3 ? 1 : 0;
   const long long hv = (long long)(r.TD + 2 * PD) * (r.TH + 2) * (r.TW + 2);
