@@ -1818,9 +1818,11 @@ static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   // halo + dY tile: 16x16 tiles run 52 / 61 / 54 us instead of 58 / 66 / 66 us at 64 / 128 / 256 channels, and the ACDC step
   // 5.45 instead of 5.68 ms.
   if (KD == 1 && H >= 16 && W >= 16) { c.TH = 16; c.TW = 16; }
-  if (const char* e = getenv("BCP_WGRAD_TILE")) {   // measurements: "TD,TH,TW"
+  if (const char* e = getenv("BCP_WGRAD_TILE")) {   // measurements: "TD,TH,TW[,min_voxels,max_voxels]" (range: one level only)
     int td, th, tw;
-    if (sscanf(e, "%d,%d,%d", &td, &th, &tw) == 3) { c.TD = td; c.TH = th; c.TW = tw; }
+    long long lo = 0, hi = 1LL << 60;
+    const long long vox = (long long)N * D * H * W;
+    if (sscanf(e, "%d,%d,%d,%lld,%lld", &td, &th, &tw, &lo, &hi) >= 3 && vox >= lo && vox <= hi) { c.TD = td; c.TH = th; c.TW = tw; }
   }
   if (const char* e = getenv("BCP_WGRAD_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && Cout16 % (v * 16) == 0) nt = v; }
   c.NT = nt;
