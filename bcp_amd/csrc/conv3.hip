@@ -714,6 +714,239 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward / dgrad of the 16 -> 16 layers, "three-piece" variant (EXPERIMENTAL, BCP_CONV3_B6=1): the fp32
+// operands are split into three bf16 pieces each (8 + 8 + 8 mantissa bits: x = p0 + p1 + p2 up to ~2^-26 |x|) when they
+// enter the LDS, and the tap loop runs on the bf16 matrix pipe -- six v_mfma_f32_16x16x32_bf16 products per K = 32 block
+// (a0b0, a0b1, a1b0, a0b2, a1b1, a2b0; the dropped cross terms are below 2^-24 of the product), fp32 accumulation inside
+// the matrix core.  One MFMA covers TWO taps x 16 input channels; an odd tap count is padded with a zero-weight tap.
+// Everything around the tap loop (persistent workgroups, XCD-aware tile order, register-prefetched halo, fused statistics
+// epilogue) is k_conv3_res.  Measured tap loop in isolation (tools/probe/mfma_bf16split_probe.hip): 209-215 fp32-equivalent
+// TFLOP/s against 123-134 for the 16x16x4_f32 loop.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int XSB = 24;   // bf16 elements per halo voxel row: 16 channels + 8 pad (48 B: conflict-free 16-B fragment reads)
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+// x -> three bf16 pieces, largest first
+__device__ __forceinline__ void split3(float x, unsigned short (&p)[3]) {
+  p[0] = f32_to_bf16_rne(x);
+  float r = x - bf16_to_f32(p[0]);
+  p[1] = f32_to_bf16_rne(r);
+  r -= bf16_to_f32(p[1]);
+  p[2] = f32_to_bf16_rne(r);
+}
+// four consecutive channels of one voxel / weight row -> the three piece planes (8-byte stores)
+__device__ __forceinline__ void split_store4(const float4& v, unsigned short* base, int plane_stride) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  unsigned short q[4][3];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) split3(x[k], q[k]);
+#pragma unroll
+  for (int s = 0; s < 3; ++s) {
+    uint2 w;
+    w.x = (unsigned)q[0][s] | ((unsigned)q[1][s] << 16);
+    w.y = (unsigned)q[2][s] | ((unsigned)q[3][s] << 16);
+    *reinterpret_cast<uint2*>(base + (size_t)s * plane_stride) = w;
+  }
+}
+
+template <int KD, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void k_conv3_b6(const float* __restrict__ X, const float* __restrict__ Wp,
+                                                  const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd,
+                                                  int n_tiles, int accumulate, StatsArg st) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int MT = TL::MT, T = TL::T, TP = (T + 1) / 2, CT = 16, NT = 1;
+  using HF = HaloFetch<TL>;
+  constexpr int NP = HF::NP;
+  constexpr bool ROWS4 = (TW % 4 == 0);
+  constexpr int WPLANE = TP * 16 * 32, XPLANE = TL::HV * XSB;     // bf16 elements per piece plane
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  unsigned short* Wb = reinterpret_cast<unsigned short*>(smem4);   // [3][TP][16 cout][32 k]: k = (tap & 1) * 16 + cin
+  unsigned short* Xb = Wb + 3 * WPLANE;                            // [3][HV][XSB]
+  double* Ss = reinterpret_cast<double*>(Xb + 3 * XPLANE);         // [4][CT][2] statistics scratch (3 * XPLANE * 2 B is a multiple of 16)
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int cout0 = 0;
+  const int cin4 = cd.Cin16 >> 2;
+
+  int voff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XSB + (lg & 1) * 8;
+
+  HF hf;
+  hf.init(cd, reinterpret_cast<float*>(smem4));      // (its LDS slot pointer is not used: the stash below writes the bf16 planes)
+
+  unsigned yoff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m0 = (wave * MT + mt) * 16 + lg * 4;
+    const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
+    yoff[mt] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + li);
+  }
+  float bv[NT];
+  bv[0] = (bias && li < cd.Cout) ? bias[li] : 0.f;
+  const bool slab_full = CT <= cd.Cout;
+
+  f32x4 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto fetch = [&](int t, float4 (&pre)[NP]) {
+    int n2, d2, h2, w2;
+    tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
+    hf.fetch(X, cd, n2, d2, h2, w2, 0, pre);
+  };
+  auto stash = [&](const float4 (&pre)[NP]) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (hf.act && u * HF::RPP + hf.r0 < HF::HR)
+        split_store4(pre[u], Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
+  };
+
+  int tile, t_end, t_step;
+  if (gridDim.x % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    t_step = gridDim.x >> 3;
+    tile = (int)((long long)n_tiles * xcd / 8) + j;
+    t_end = (int)((long long)n_tiles * (xcd + 1) / 8);
+  } else {
+    tile = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
+  }
+  if (st.partial && (int)threadIdx.x < CT && (int)threadIdx.x < cd.Cout) {
+    for (int g = 0; g < st.G; ++g) {
+      double* z = st.partial + (((long long)g * st.rows + blockIdx.x) * st.C + threadIdx.x) * 2;
+      z[0] = 0.0; z[1] = 0.0;
+    }
+  }
+  if (tile >= t_end) return;
+  double s1[NT], s2[NT];
+  s1[0] = 0.0; s2[0] = 0.0;
+  int cur_g = st.partial ? tile / st.tiles_per_group : 0;
+  BwdCol kc[NT];
+  kc[0] = load_bwd_col(st, cur_g, li);
+  {
+    float4 pre[NP];
+    fetch(tile, pre);
+    // resident weights: Wp[tap][cin4][Cout16][4] (fp32 pack) -> three bf16 planes Wb[piece][tap / 2][cout][(tap & 1) * 16 + cin]
+    for (int q = threadIdx.x; q < T * 4 * CT; q += 256) {
+      const int co = q % CT, cig = (q / CT) & 3, tap = q / (4 * CT);
+      const float4 wv = ld4(Wp + ((((long long)tap * cin4 + cig) * cd.Cout16) + cout0 + co) * 4);
+      split_store4(wv, Wb + ((tap >> 1) * 16 + co) * 32 + (tap & 1) * 16 + cig * 4, WPLANE);
+    }
+    if (T & 1) {   // zero-weight pad tap: second half of the last pair
+      for (int q = threadIdx.x; q < 3 * 16 * 4; q += 256) {
+        const int s = q / 64, co = (q / 4) % 16, c4 = q % 4;
+        uint2 z;
+        z.x = 0u; z.y = 0u;
+        *reinterpret_cast<uint2*>(Wb + (size_t)s * WPLANE + ((TP - 1) * 16 + co) * 32 + 16 + c4 * 4) = z;
+      }
+    }
+    stash(pre);
+  }
+  __syncthreads();
+  for (;;) {
+    const int ntile = tile + t_step;
+    const bool has_next = ntile < t_end;
+    float4 pre[NP];
+    if (has_next) fetch(ntile, pre);
+#pragma unroll 2
+    for (int tp = 0; tp < TP; ++tp) {
+      // lanes 0-31 (k 0..15) carry tap 2*tp, lanes 32-63 (k 16..31) tap 2*tp+1 (the pad tap reads tap T-1's voxels against zero weights)
+      const int tA = TL::tapoff(2 * tp), tB = TL::tapoff(2 * tp + 1 < T ? 2 * tp + 1 : T - 1);
+      const int toff = ((lg >> 1) ? tB : tA) * XSB;
+      bf16x8 a[MT][3], b[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
+        b[s] = *reinterpret_cast<const bf16x8*>(Wb + s * WPLANE + (tp * 16 + li) * 32 + lg * 8);
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[0], acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[1], acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[0], acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[2], acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[1], acc[mt], 0, 0, 0);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2], b[0], acc[mt], 0, 0, 0);
+      }
+    }
+    {
+      int n, d0, h0, w0;
+      tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+      if (st.partial && tile / st.tiles_per_group != cur_g) {
+        stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+        cur_g = tile / st.tiles_per_group;
+        kc[0] = load_bwd_col(st, cur_g, li);
+      }
+      const bool full = ROWS4 && slab_full && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
+      const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
+      auto rows = [&](auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        if (full) {
+          float* yb = Y + tile_base;
+          const float* ypb = (MODE == 2) ? st.yprev + tile_base : nullptr;
+          float yv[MT][4];
+          if (MODE == 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) yv[mt][r] = ypb[r * cd.Cout + yoff[mt]];
+          }
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* p = yb + r * cd.Cout + yoff[mt];
+              float v = acc[mt][r] + bv[0];
+              if (accumulate) v += p[0];
+              p[0] = v;
+              stat_add<MODE>(s1[0], s2[0], v, MODE == 2 ? yv[mt][r] : 0.f, kc[0], st.act);
+            }
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int m = (wave * MT + mt) * 16 + lg * 4 + r;
+              const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+              const int d = d0 + td, h = h0 + th, w = w0 + tw;
+              if (d < cd.D && h < cd.H && w < cd.W && li < cd.Cout) {
+                const long long ro = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);
+                float v = acc[mt][r] + bv[0];
+                if (accumulate) v += Y[ro + li];
+                Y[ro + li] = v;
+                stat_add<MODE>(s1[0], s2[0], v, MODE == 2 ? st.yprev[ro + li] : 0.f, kc[0], st.act);
+              }
+            }
+          }
+        }
+      };
+      if (!st.partial) rows(std::integral_constant<int, 0>{});
+      else if (!st.yprev) rows(std::integral_constant<int, 1>{});
+      else rows(std::integral_constant<int, 2>{});
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    if (!has_next) {
+      if (st.partial) stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+      break;
+    }
+    __syncthreads();   // every wave is done reading the halo planes
+    stash(pre);
+    __syncthreads();
+    tile = ntile;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // forward / dgrad, WAVE-SPECIALISED resident variant (full tiles only).  Workgroup = 8 waves: waves 0-3 do nothing but
 // ds_read + MFMA on the current halo buffer; waves 4-7 ("helpers") do everything else underneath them -- fetch the next
 // work item's halo (global -> registers -> the OTHER LDS halo buffer) and write the previous tile's output (accumulators
@@ -1465,6 +1698,32 @@ static int launch_res(const float* X, const float* Wp, const float* bias, float*
   return st.partial ? P : 0;
 }
 
+// three-piece bf16 variant of the 16 -> 16 resident conv (k_conv3_b6): one persistent workgroup per CU (137 KB of LDS in 3-D)
+template <int KD, int TD, int TH, int TW>
+static int launch_b6(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, double* stat_partial,
+                     int G, BwdCtx bw, bool dry, hipStream_t s) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int TP = (TL::T + 1) / 2;
+  const size_t lds = (size_t)(3 * TP * 16 * 32 + 3 * TL::HV * XSB) * sizeof(unsigned short) + 4 * 16 * 2 * sizeof(double);
+  cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
+  const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
+  int P = 256 * (per_cu > 2 ? 2 : per_cu);
+  if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
+  if (P > tiles) P = tiles;
+  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
+  const bool stats_ok = G > 0 && tiles % G == 0;
+  if (dry) return stats_ok ? P : 0;
+  if (stats_ok && stat_partial) {
+    st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G;
+    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;
+  }
+  auto kfn = k_conv3_b6<KD, TD, TH, TW>;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, dim3(P, 1, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st);
+  return st.partial ? P : 0;
+}
+
 template <int KD, int TD, int TH, int TW, int NT>
 static int launch_ws(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate,
                      double* stat_partial, int G, bool dry, hipStream_t s) {
@@ -1709,6 +1968,15 @@ static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, fl
   if (choose_ws(r, KD, N, D, H, W, cd.Cin16, Cout, cd.Cout16, bw.yprev != nullptr)) {
     BCP_WS_CASE(3, 4, 4, 16) BCP_WS_CASE(3, 4, 4, 8) BCP_WS_CASE(3, 4, 4, 4)
     BCP_WS_CASE(1, 1, 16, 16) BCP_WS_CASE(1, 1, 8, 8)
+  }
+  // experimental: the 16 -> 16 layers on the bf16 matrix pipe with three-piece operands (k_conv3_b6), BCP_CONV3_B6=1
+  if (!done && cd.Cin16 == 16 && cd.Cout16 == 16) {
+    const char* e = getenv("BCP_CONV3_B6");
+    if (e && e[0] == '1') {
+      if (KD == 3) rows = launch_b6<3, 4, 4, 16>(x, wp, bias, y, cd, accumulate, stat_partial, G, bw, dry, (hipStream_t)stream);
+      else rows = launch_b6<1, 1, 16, 16>(x, wp, bias, y, cd, accumulate, stat_partial, G, bw, dry, (hipStream_t)stream);
+      done = true;
+    }
   }
   if (!done && choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
     BCP_RES_CASE(3, 4, 4, 16, 1) BCP_RES_CASE(3, 4, 4, 16, 2)

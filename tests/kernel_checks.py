@@ -646,6 +646,51 @@ def check_augment(ops, dev, golden_dir):
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"])
 
 
+def check_conv3_b6(ops, dev):
+    """EXPERIMENTAL k_conv3_b6 (BCP_CONV3_B6=1): the 16 -> 16 conv with fp32 operands split into three bf16 pieces on the bf16
+    matrix pipe must be fp32-EQUIVALENT -- its error against an fp64 reference stays at the level of the fp32-MFMA kernel's --
+    for the forward (bias), the dgrad pack (accumulate), partial tiles, multi-tile persistent loops and the fused statistics"""
+    import os
+    rng = np.random.default_rng(21)
+    cases = ((2, (9, 10, 35), 3, 2, "3"), (1, (8, 8, 32), 3, 1, None), (3, (1, 20, 37), 1, 3, "2"), (2, (1, 32, 32), 1, 2, None))
+    for (N, sp, KD, G, P) in cases:
+        two_d = KD == 1
+        C = 16
+        x = R(rng, N, C, *(sp[1:] if two_d else sp))
+        w = R(rng, C, C, *((3, 3) if two_d else (3, 3, 3))) * 0.1
+        b = R(rng, C) * 0.1
+        conv = F.conv2d if two_d else F.conv3d
+        y64 = conv(x.double(), w.double(), b.double(), padding=1)
+        wf, wd = ops.conv3_pack(w.to(dev).contiguous(), KD)
+        xcl = to_cl(x).to(dev)
+        y32 = from_cl(ops.conv3_fwd(xcl, wf, b.to(dev), C, KD), two_d).cpu().double()      # the fp32-MFMA kernels
+        if P:
+            os.environ["BCP_CONV3_P"] = P
+        os.environ["BCP_CONV3_B6"] = "1"
+        try:
+            y, part, rows = ops.conv3_fwd_stats(xcl, wf, b.to(dev), C, KD, G)
+            dy = R(rng, *y64.shape)
+            dx0 = to_cl(R(rng, *x.shape)).to(dev)
+            dx = ops.conv3_fwd(to_cl(dy).to(dev), wd, None, C, KD, out=dx0.clone(), accumulate=True)
+        finally:
+            os.environ.pop("BCP_CONV3_B6", None)
+            os.environ.pop("BCP_CONV3_P", None)
+        yb = from_cl(y, two_d).cpu().double()
+        scale = float(y64.abs().max())
+        e32, eb6 = float((y32 - y64).abs().max()) / scale, float((yb - y64).abs().max()) / scale
+        assert eb6 < 2e-6 and eb6 < 3 * e32 + 2e-7, f"b6 forward is not fp32-equivalent: {eb6:.2e} vs fp32 kernel {e32:.2e} ({sp})"
+        assert rows > 0
+        pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * C * 16]), dtype=torch.float64).view(G, rows, C, 2).sum(1)
+        yg = y64.transpose(0, 1).reshape(C, G, -1)
+        close(pt[..., 0], yg.sum(2).t(), rtol=2e-6, msg="b6 fused sum")
+        close(pt[..., 1], (yg * yg).sum(2).t(), rtol=2e-6, msg="b6 fused sum of squares")
+        xg = x.double().requires_grad_(True)
+        conv(xg, w.double(), None, padding=1).backward(dy.double())
+        ref = xg.grad + from_cl(dx0, two_d).cpu().double()
+        edx = float((from_cl(dx, two_d).cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert edx < 2e-6, f"b6 dgrad + accumulate: {edx:.2e} ({sp})"
+
+
 def check_augment_acdc(ops, dev, golden_dir):
     """device-side RandomGenerator (ACDC) == the REFERENCE's class (python random + np.random + scipy rotate / zoom,
     tests/golden/aug_acdc.npz: 15 rot90+flip, 7 rotate, 8 plain cases over 5 slice shapes), bit for bit, and == the oracle"""
@@ -681,4 +726,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("augment_acdc", "augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_ws", "conv3_res_split", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("conv3_b6", "augment_acdc", "augment", "pack_many", "conv3_bwdstats", "conv3_stats", "conv3_ws", "conv3_res_split", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")

@@ -122,6 +122,28 @@ f32x16 mfma_32x32x2(float a, float b, f32x16 cacc) {
   return cacc;
 }
 
+f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 cacc) {
+  // v_mfma_f32_16x16x32_bf16: lane l supplies A[i=l&15][k=(l>>4)*8+j] and B[k=(l>>4)*8+j][col=l&15], j = 0..7;
+  // D: col = l&15, row = (l>>4)*4 + r.  bf16 x bf16 products are exact in fp32; the 32-term sum + C is modelled in
+  // fp64 and rounded once (the matrix core keeps more than fp32 inside the dot product; tests compare with tolerances).
+  WaveScratch& w = my_wave();
+  unsigned p = next_phase();
+  int l = lane_id();
+  memcpy(w.a16[p][l], &a, 16);
+  memcpy(w.b16[p][l], &b, 16);
+  wave_sync();
+  auto bf = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; };
+  int col = l & 15, rg = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int row = rg * 4 + r;
+    double acc = (double)cacc[r];
+    for (int kg = 0; kg < 4; ++kg)
+      for (int j = 0; j < 8; ++j) acc += (double)bf(w.a16[p][kg * 16 + row][j]) * (double)bf(w.b16[p][kg * 16 + col][j]);
+    cacc[r] = (float)acc;
+  }
+  return cacc;
+}
+
 static void fiber_entry() {
   BlockCtx* c = g_ctx;
   (*c->body)();

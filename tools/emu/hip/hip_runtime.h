@@ -91,6 +91,7 @@ struct Fiber {
 
 struct WaveScratch {
   float a[2][64], b[2][64];
+  uint16_t a16[2][64][8], b16[2][64][8];   // bf16 operand fragments (v_mfma_f32_16x16x32_bf16)
   uint64_t u[2][64];
   unsigned phase;          // per-lane phase counters live in lane_phase
   unsigned arrived;        // lanes arrived at current wave sync
@@ -140,6 +141,8 @@ template <class T> inline T shfl_generic(T v, int src_lane) {
 
 f32x4 mfma_16x16x4(float a, float b, f32x4 c);
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c);
 
 }  // namespace bcpemu
 
@@ -264,6 +267,7 @@ using std::min;
 // ---- MFMA builtins (the product code calls the real __builtin_amdgcn_* names)
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) ::bcpemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::bcpemu::mfma_32x32x2((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) ::bcpemu::mfma_16x16x32_bf16((a), (b), (c))
 #define __builtin_amdgcn_readfirstlane(v) (::bcpemu::shfl_generic((int)(v), 0))
 #define __builtin_amdgcn_s_barrier() ::bcpemu::block_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
