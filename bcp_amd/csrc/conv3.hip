@@ -855,30 +855,47 @@ __global__ __launch_bounds__(256) void k_conv3_b6(const float* __restrict__ X, c
     const int ntile = tile + t_step;
     const bool has_next = ntile < t_end;
     float4 pre[NP];
-    if (has_next) fetch(ntile, pre);
+    // The tap loop keeps ~120 operand registers in flight; with the next halo's 48 prefetch registers live across ALL of it the
+    // compiler parks them in AGPRs right after the loads -- a vmcnt(0) wait at the top of every tile (measured: 169 of 323 us).
+    // So the prefetch is issued with LATE pairs still to go: enough MFMA time (~0.6 us per pair) to cover the round trip, and the
+    // registers are live only there.
+    constexpr int LATE = TP > 6 ? 6 : TP - 1;
+    auto pairs = [&](int tp0, int tp1) {
 #pragma unroll 2
-    for (int tp = 0; tp < TP; ++tp) {
-      // lanes 0-31 (k 0..15) carry tap 2*tp, lanes 32-63 (k 16..31) tap 2*tp+1 (the pad tap reads tap T-1's voxels against zero weights)
-      const int tA = TL::tapoff(2 * tp), tB = TL::tapoff(2 * tp + 1 < T ? 2 * tp + 1 : T - 1);
-      const int toff = ((lg >> 1) ? tB : tA) * XSB;
-      bf16x8 a[MT][3], b[3];
+      for (int tp = tp0; tp < tp1; ++tp) {
+        // lanes 0-31 (k 0..15) carry tap 2*tp, lanes 32-63 (k 16..31) tap 2*tp+1 (the pad tap reads tap T-1's voxels against zero weights)
+        const int tA = TL::tapoff(2 * tp), tB = TL::tapoff(2 * tp + 1 < T ? 2 * tp + 1 : T - 1);
+        const int toff = ((lg >> 1) ? tB : tA) * XSB;
+        bf16x8 a[MT][3], b[3];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < 3; ++s) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
-        b[s] = *reinterpret_cast<const bf16x8*>(Wb + s * WPLANE + (tp * 16 + li) * 32 + lg * 8);
+          for (int mt = 0; mt < MT; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
+          b[s] = *reinterpret_cast<const bf16x8*>(Wb + s * WPLANE + (tp * 16 + li) * 32 + lg * 8);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[0], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[1], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[0], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[2], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[1], acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2], b[0], acc[mt], 0, 0, 0);
+        }
       }
+    };
+    pairs(0, TP - LATE);
+    if (BCP_ABLATE & 524288) {            // (ablation bits 131072 / 262144 / 524288: no epilogue / no refill / no global prefetch)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[0], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[1], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[0], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[2], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[1], acc[mt], 0, 0, 0);
-        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2], b[0], acc[mt], 0, 0, 0);
-      }
-    }
-    {
+      for (int u = 0; u < NP; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else if (has_next) fetch(ntile, pre);
+    pairs(TP - LATE, TP);
+    if (BCP_ABLATE & 131072) {
+      float t = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) t += acc[mt][0] + acc[mt][1] + acc[mt][2] + acc[mt][3];
+      if (t == 1.2345e-30f) Y[threadIdx.x] = t;
+    } else {
       int n, d0, h0, w0;
       tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
       if (st.partial && tile / st.tiles_per_group != cur_g) {
@@ -939,9 +956,11 @@ __global__ __launch_bounds__(256) void k_conv3_b6(const float* __restrict__ X, c
       if (st.partial) stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
       break;
     }
-    __syncthreads();   // every wave is done reading the halo planes
-    stash(pre);
-    __syncthreads();
+    if (!(BCP_ABLATE & 262144)) {
+      __syncthreads();   // every wave is done reading the halo planes
+      stash(pre);
+      __syncthreads();
+    }
     tile = ntile;
   }
 }
