@@ -534,12 +534,21 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  unsigned vmask = ~0u;
   auto fetch = [&](int t, int c, float4 (&pre)[NP]) {
     int n2, d2, h2, w2;
     tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
-    hf.fetch(X, cd, n2, d2, h2, w2, c_begin + c, pre);
+    if (BCP_ABLATE & 1048576) vmask = hf.fetch_nb(X, cd, n2, d2, h2, w2, c_begin + c, pre);   // (measurement: branch-free fetch)
+    else hf.fetch(X, cd, n2, d2, h2, w2, c_begin + c, pre);
   };
-  auto stash = [&](const float4 (&pre)[NP]) { hf.stash(pre); };
+  auto stash = [&](const float4 (&pre)[NP]) {
+    if (BCP_ABLATE & 1048576) {
+      float4 q[NP];
+#pragma unroll
+      for (int u = 0; u < NP; ++u) q[u] = ((vmask >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      hf.stash(q);
+    } else hf.stash(pre);
+  };
 
   // Work items of this block: (tile, chunk).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with
   // its own 4 MB L2), so workgroup b runs on XCD b % 8.  Each XCD owns ONE contiguous eighth of the (d-major) tile list and
