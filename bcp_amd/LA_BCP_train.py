@@ -1,9 +1,10 @@
-"""Counterpart of the reference's code/LA_BCP_train.py: same CLI flags and defaults (:32-55), same loop
-structure (pre_train :118-195, self_train :198-348), same callee names -- resolved against the HIP-backed
-modules of this package.  Data: the LA h5 files are not part of the build, so the default dataset is the
-synthetic stand-in (dataloaders/dataset.py:SyntheticLA); TensorBoard snapshots (:294-340) are out of scope.
+"""The LA train script of this build: the reference's command line (code/LA_BCP_train.py:32-54 -- every flag with its default)
+and its two phases -- pre_train (:118-195) and self_train (:197-340) with the same iteration counts, LR schedule, validation
+cadence and checkpoint files -- driving the fused step functions of bcp_amd/train_step.py (one grouped teacher forward, one
+grouped student forward / backward per iteration).  Synthetic LA-like cases stand in for the h5 dataset
+(dataloaders/dataset.py:SyntheticLA); TensorBoard snapshots (:294-340) are out of scope.
 
-  python -m bcp_amd.LA_BCP_train --labelnum 8 --batch_size 4 --labeled_bs 2 --pre_max_iteration 20 --self_max_iteration 40
+  python -m bcp_amd.LA_BCP_train --labelnum 8 --pre_max_iteration 20 --self_max_iteration 20
 """
 import argparse
 import logging
@@ -17,58 +18,48 @@ import torch
 from bcp_amd import train_step
 from bcp_amd.dataloaders.dataset import DeviceRotFlipCrop, SyntheticLA, TwoStreamBatchSampler, batches
 from bcp_amd.networks.net_factory import net_factory
-from bcp_amd.train_step import get_cut_mask
 from bcp_amd.utils import ramps, test_3d_patch
-from bcp_amd.utils.BCP_utils import context_mask, mix_loss, update_ema_variables
-from bcp_amd.utils.losses import sup_loss_parts
 
+# (flag, type, default) -- the reference's CLI, then this build's additions
+_REFERENCE_FLAGS = (
+    ("root_path", str, "/data/byh_data/SSNet_data/LA"), ("exp", str, "BCP"), ("model", str, "VNet"),
+    ("pre_max_iteration", int, 2000), ("self_max_iteration", int, 15000), ("max_samples", int, 80),
+    ("labeled_bs", int, 4), ("batch_size", int, 8), ("base_lr", float, 0.01), ("deterministic", int, 1),
+    ("labelnum", int, 8), ("gpu", str, "1"), ("seed", int, 1337), ("consistency", float, 1.0),
+    ("consistency_rampup", float, 40.0), ("magnitude", float, 10.0), ("u_weight", float, 0.5),
+    ("mask_ratio", float, 2 / 3), ("u_alpha", float, 2.0), ("loss_weight", float, 0.5),
+)
+_BUILD_FLAGS = (
+    ("fused_optimizer", int, 1, "1: the one-launch flat SGD; 0: torch.optim.SGD on the same parameters"),
+    ("log_every", int, 50, "log (and synchronise with the host) every N iterations; the reference does so every iteration"),
+    ("val_every", int, 200, "sliding-window validation cadence (the reference: every 200 iterations, :174,279)"),
+    ("val_cases", int, 2, "synthetic validation volumes (the reference walks the LA test list)"),
+)
 parser = argparse.ArgumentParser()
-parser.add_argument('--root_path', type=str, default='/data/byh_data/SSNet_data/LA', help='Name of Dataset')
-parser.add_argument('--exp', type=str, default='BCP', help='exp_name')
-parser.add_argument('--model', type=str, default='VNet', help='model_name')
-parser.add_argument('--pre_max_iteration', type=int, default=2000, help='maximum pre-train iteration to train')
-parser.add_argument('--self_max_iteration', type=int, default=15000, help='maximum self-train iteration to train')
-parser.add_argument('--max_samples', type=int, default=80, help='maximum samples to train')
-parser.add_argument('--labeled_bs', type=int, default=4, help='batch_size of labeled data per gpu')
-parser.add_argument('--batch_size', type=int, default=8, help='batch_size per gpu')
-parser.add_argument('--base_lr', type=float, default=0.01, help='maximum epoch number to train')
-parser.add_argument('--deterministic', type=int, default=1, help='whether use deterministic training')
-parser.add_argument('--labelnum', type=int, default=8, help='trained samples')
-parser.add_argument('--gpu', type=str, default='1', help='GPU to use')
-parser.add_argument('--seed', type=int, default=1337, help='random seed')
-parser.add_argument('--consistency', type=float, default=1.0, help='consistency')
-parser.add_argument('--consistency_rampup', type=float, default=40.0, help='consistency_rampup')
-parser.add_argument('--magnitude', type=float, default='10.0', help='magnitude')
-# -- setting of BCP
-parser.add_argument('--u_weight', type=float, default=0.5, help='weight of unlabeled pixels')
-parser.add_argument('--mask_ratio', type=float, default=2 / 3, help='ratio of mask/image')
-# -- setting of mixup
-parser.add_argument('--u_alpha', type=float, default=2.0, help='unlabeled image ratio of mixuped image')
-parser.add_argument('--loss_weight', type=float, default=0.5, help='loss weight of unimage term')
-# -- additions of this build
-parser.add_argument('--fused_optimizer', type=int, default=1, help='1: one-launch FlatSGD; 0: torch.optim.SGD on the same parameters')
-parser.add_argument('--log_every', type=int, default=50, help='host sync + log cadence (the reference syncs every iteration)')
-parser.add_argument('--val_every', type=int, default=200, help='sliding-window validation cadence (LA_BCP_train.py:174,279: every 200 iterations)')
-parser.add_argument('--augment', action='store_true', help='cases larger than the patch + the device-side RandomRotFlip / RandomCrop (dataloaders/dataset.py)')
-parser.add_argument('--val_cases', type=int, default=2, help='synthetic validation volumes (the reference walks the LA test list)')
+for _name, _type, _default in _REFERENCE_FLAGS:
+    parser.add_argument("--" + _name, type=_type, default=_default)
+for _name, _type, _default, _help in _BUILD_FLAGS:
+    parser.add_argument("--" + _name, type=_type, default=_default, help=_help)
+parser.add_argument("--augment", action="store_true",
+                    help="cases larger than the patch + the device-side RandomRotFlip / RandomCrop (dataloaders/dataset.py)")
 
 patch_size = (112, 112, 80)
 num_classes = 2
 
 
 def save_net_opt(net, optimizer, path):
-    torch.save({'net': net.state_dict(), 'opt': optimizer.state_dict()}, str(path))
+    """{'net', 'opt'} checkpoints, as the reference writes them (:79-84)"""
+    torch.save({"net": net.state_dict(), "opt": optimizer.state_dict()}, str(path))
 
 
 def load_net_opt(net, optimizer, path):
-    state = torch.load(str(path))
-    net.load_state_dict(state['net'])
-    optimizer.load_state_dict(state['opt'])
+    ckpt = torch.load(str(path))
+    net.load_state_dict(ckpt["net"])
+    optimizer.load_state_dict(ckpt["opt"])
 
 
 def load_net(net, path):
-    state = torch.load(str(path))
-    net.load_state_dict(state['net'])
+    net.load_state_dict(torch.load(str(path))["net"])
 
 
 def get_current_consistency_weight(args, epoch):
@@ -81,6 +72,17 @@ def _optimizer(args, model):
     return torch.optim.SGD(model.parameters(), lr=args.base_lr, momentum=0.9, weight_decay=0.0001)
 
 
+def _data(args, device):
+    """the labeled / unlabeled two-stream sampler over the (synthetic) training cases (:137-147)"""
+    db = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed,
+                     transform=DeviceRotFlipCrop(patch_size) if args.augment else None,     # RandomRotFlip -> RandomCrop -> ToTensor (:122-126)
+                     raw_shape=(patch_size[0] + 12, patch_size[1] + 10, patch_size[2] + 8))
+    labeled, unlabeled = list(range(args.labelnum)), list(range(args.labelnum, args.max_samples))
+    sampler = TwoStreamBatchSampler(labeled, unlabeled, args.batch_size, args.batch_size - args.labeled_bs)
+    logging.info("{} iterations per epoch".format(len(sampler)))
+    return db, sampler
+
+
 def _val_cases(args, device):
     """stand-in for the LA test list (utils/test_3d_patch.py:22-25): volumes a little larger than the patch, so the sliding
     window takes several positions per axis"""
@@ -90,155 +92,101 @@ def _val_cases(args, device):
     return [(vols[i, 0].to(device), labs[i].to(device)) for i in range(args.val_cases)]
 
 
+class _BestModel:
+    """validation every `val_every` iterations; a better mean Dice writes iter_<n>_dice_<d>.pth and <model>_best_model.pth
+    (:174-187 with the optimiser state, :279-293 weights only)"""
+
+    def __init__(self, args, device, snapshot_path, with_optimizer):
+        self.args, self.path, self.with_opt = args, snapshot_path, with_optimizer
+        self.cases = _val_cases(args, device) if args.val_every > 0 else []
+        self.best = 0
+
+    def _write(self, model, optimizer, name):
+        target = os.path.join(self.path, name)
+        if self.with_opt:
+            save_net_opt(model, optimizer, target)
+        else:
+            torch.save(model.state_dict(), target)
+
+    def maybe(self, iter_num, model, optimizer):
+        a = self.args
+        if a.val_every <= 0 or iter_num % a.val_every:
+            return
+        dice = test_3d_patch.var_all_case_LA(model, num_classes=num_classes, patch_size=patch_size, stride_xy=18, stride_z=4, cases=self.cases)
+        if dice > self.best:
+            self.best = round(dice, 4)
+            self._write(model, optimizer, "iter_{}_dice_{}.pth".format(iter_num, self.best))
+            self._write(model, optimizer, "{}_best_model.pth".format(a.model))
+            logging.info("save best model, dice %f" % self.best)
+
+    def finish(self, model, optimizer):
+        if self.best == 0:   # no validation ran (or none improved): keep the last weights so that the next phase can start
+            self._write(model, optimizer, "{}_best_model.pth".format(self.args.model))
+
+
 def pre_train(args, snapshot_path, device):
     model = net_factory(net_type=args.model, in_chns=1, class_num=num_classes, mode="train")
-    db_train = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed,
-                           transform=DeviceRotFlipCrop(patch_size) if args.augment else None,     # RandomRotFlip -> RandomCrop -> ToTensor (:122-126)
-                           raw_shape=(patch_size[0] + 12, patch_size[1] + 10, patch_size[2] + 8))
-    labeled_idxs = list(range(args.labelnum))
-    unlabeled_idxs = list(range(args.labelnum, args.max_samples))
-    batch_sampler = TwoStreamBatchSampler(labeled_idxs, unlabeled_idxs, args.batch_size, args.batch_size - args.labeled_bs)
-    sub_bs = int(args.labeled_bs / 2)
+    db_train, sampler = _data(args, device)
     optimizer = _optimizer(args, model)
     model.train()
-    logging.info("{} iterations per epoch".format(len(batch_sampler)))
+    keeper = _BestModel(args, device, snapshot_path, with_optimizer=True)
     iter_num = 0
-    best_dice = 0
-    val_cases = _val_cases(args, device) if args.val_every > 0 else []
-    max_epoch = args.pre_max_iteration // len(batch_sampler) + 1
-    for epoch_num in range(max_epoch):
-        for sampled_batch in batches(db_train, batch_sampler):
-            volume_batch, label_batch = sampled_batch['image'][:args.labeled_bs], sampled_batch['label'][:args.labeled_bs]
-            img_a, img_b = volume_batch[:sub_bs], volume_batch[sub_bs:]
-            lab_a, lab_b = label_batch[:sub_bs], label_batch[sub_bs:]
-            with torch.no_grad():
-                img_mask, loss_mask = context_mask(img_a, args.mask_ratio)
-            """Mix Input"""
-            volume_batch = img_a * img_mask + img_b * (1 - img_mask)
-            label_batch = lab_a * img_mask + lab_b * (1 - img_mask)
-            outputs, _ = model(volume_batch)
-            loss_ce, loss_dice = sup_loss_parts(outputs, label_batch)
-            loss = (loss_ce + loss_dice) / 2
+    while iter_num < args.pre_max_iteration:
+        for sampled in batches(db_train, sampler):
+            r = train_step.la_pre_train_step(model, optimizer, sampled["image"][:args.labeled_bs], sampled["label"][:args.labeled_bs], args.mask_ratio)
             iter_num += 1
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
             if iter_num % args.log_every == 0:
-                logging.info('iteration %d : loss: %03f, loss_dice: %03f, loss_ce: %03f' % (iter_num, float(loss.detach()), float(loss_dice.detach()), float(loss_ce.detach())))
-            if args.val_every > 0 and iter_num % args.val_every == 0:       # LA_BCP_train.py:174-187
-                model.eval()
-                dice_sample = test_3d_patch.var_all_case_LA(model, num_classes=num_classes, patch_size=patch_size, stride_xy=18, stride_z=4,
-                                                            cases=val_cases)
-                if dice_sample > best_dice:
-                    best_dice = round(dice_sample, 4)
-                    save_net_opt(model, optimizer, os.path.join(snapshot_path, 'iter_{}_dice_{}.pth'.format(iter_num, best_dice)))
-                    save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
-                    logging.info("save best model, dice %f" % best_dice)
-                model.train()
+                logging.info("iteration %d : loss: %03f, loss_dice: %03f, loss_ce: %03f" % (iter_num, float(r["loss"]), float(r["loss_dice"]), float(r["loss_ce"])))
+            keeper.maybe(iter_num, model, optimizer)
             if iter_num >= args.pre_max_iteration:
                 break
-        if iter_num >= args.pre_max_iteration:
-            break
-    if best_dice == 0:   # no validation ran (or none improved): keep the last weights so that self-training can start
-        save_net_opt(model, optimizer, os.path.join(snapshot_path, '{}_best_model.pth'.format(args.model)))
+    keeper.finish(model, optimizer)
 
 
 def self_train(args, pre_snapshot_path, self_snapshot_path, device):
     model = net_factory(net_type=args.model, in_chns=1, class_num=num_classes, mode="train")
     ema_model = net_factory(net_type=args.model, in_chns=1, class_num=num_classes, mode="train")
-    for param in ema_model.parameters():
-        param.detach_()   # ema_model set
-    db_train = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed,
-                           transform=DeviceRotFlipCrop(patch_size) if args.augment else None,     # RandomRotFlip -> RandomCrop -> ToTensor (:122-126)
-                           raw_shape=(patch_size[0] + 12, patch_size[1] + 10, patch_size[2] + 8))
-    labeled_idxs = list(range(args.labelnum))
-    unlabeled_idxs = list(range(args.labelnum, args.max_samples))
-    batch_sampler = TwoStreamBatchSampler(labeled_idxs, unlabeled_idxs, args.batch_size, args.batch_size - args.labeled_bs)
-    sub_bs = int(args.labeled_bs / 2)
+    for p in ema_model.parameters():
+        p.detach_()                     # the teacher never sees a gradient
+    db_train, sampler = _data(args, device)
     optimizer = _optimizer(args, model)
-    pretrained_model = os.path.join(pre_snapshot_path, f'{args.model}_best_model.pth')
-    load_net(model, pretrained_model)
-    load_net(ema_model, pretrained_model)
+    start = os.path.join(pre_snapshot_path, f"{args.model}_best_model.pth")
+    load_net(model, start)              # student and teacher both start from the pre-trained weights (:220-222)
+    load_net(ema_model, start)
     model.train()
     ema_model.train()
-    logging.info("{} iterations per epoch".format(len(batch_sampler)))
+    keeper = _BestModel(args, device, self_snapshot_path, with_optimizer=False)
     iter_num = 0
-    best_dice = 0
-    val_cases = _val_cases(args, device) if args.val_every > 0 else []
-    max_epoch = args.self_max_iteration // len(batch_sampler) + 1
-    lr_ = args.base_lr
-    for epoch in range(max_epoch):
-        for sampled_batch in batches(db_train, batch_sampler):
-            volume_batch, label_batch = sampled_batch['image'], sampled_batch['label']
-            img_a, img_b = volume_batch[:sub_bs], volume_batch[sub_bs:args.labeled_bs]
-            lab_a, lab_b = label_batch[:sub_bs], label_batch[sub_bs:args.labeled_bs]
-            unimg_a, unimg_b = volume_batch[args.labeled_bs:args.labeled_bs + sub_bs], volume_batch[args.labeled_bs + sub_bs:]
-            with torch.no_grad():
-                unoutput_a, _ = ema_model(unimg_a)
-                unoutput_b, _ = ema_model(unimg_b)
-                plab_a = get_cut_mask(unoutput_a, nms=1)
-                plab_b = get_cut_mask(unoutput_b, nms=1)
-                img_mask, loss_mask = context_mask(img_a, args.mask_ratio)
-            consistency_weight = get_current_consistency_weight(args, iter_num // 150)  # logged only, as in the reference
-
-            mixl_img = img_a * img_mask + unimg_a * (1 - img_mask)
-            mixu_img = unimg_b * img_mask + img_b * (1 - img_mask)
-            outputs_l, _ = model(mixl_img)
-            outputs_u, _ = model(mixu_img)
-            loss_l = mix_loss(outputs_l, lab_a, plab_a, loss_mask, u_weight=args.u_weight)
-            loss_u = mix_loss(outputs_u, plab_b, lab_b, loss_mask, u_weight=args.u_weight, unlab=True)
-
-            loss = loss_l + loss_u
-
+    while iter_num < args.self_max_iteration:
+        for sampled in batches(db_train, sampler):
+            get_current_consistency_weight(args, iter_num // 150)   # computed and logged only, as in the reference (:246)
+            r = train_step.la_self_train_step(model, ema_model, optimizer, sampled["image"], sampled["label"], args.labeled_bs,
+                                              u_weight=args.u_weight, mask_ratio=args.mask_ratio, alpha=0.99)
             iter_num += 1
-            optimizer.zero_grad()
-            loss.backward()
-            optimizer.step()
             if iter_num % args.log_every == 0:
-                logging.info('iteration %d : loss: %03f, loss_l: %03f, loss_u: %03f' % (iter_num, float(loss.detach()), float(loss_l.detach()), float(loss_u.detach())))
-
-            update_ema_variables(model, ema_model, 0.99)
-
-            if args.val_every > 0 and iter_num % args.val_every == 0:       # LA_BCP_train.py:279-293
-                model.eval()
-                dice_sample = test_3d_patch.var_all_case_LA(model, num_classes=num_classes, patch_size=patch_size, stride_xy=18, stride_z=4,
-                                                            cases=val_cases)
-                if dice_sample > best_dice:
-                    best_dice = round(dice_sample, 4)
-                    torch.save(model.state_dict(), os.path.join(self_snapshot_path, 'iter_{}_dice_{}.pth'.format(iter_num, best_dice)))
-                    torch.save(model.state_dict(), os.path.join(self_snapshot_path, '{}_best_model.pth'.format(args.model)))
-                    logging.info("save best model, dice %f" % best_dice)
-                model.train()
-
-            # change lr
-            if iter_num % 2500 == 0:
-                lr_ = args.base_lr * 0.1 ** (iter_num // 2500)
-                for param_group in optimizer.param_groups:
-                    param_group['lr'] = lr_
+                logging.info("iteration %d : loss: %03f, loss_l: %03f, loss_u: %03f" % (iter_num, float(r["loss"]), float(r["loss_l"]), float(r["loss_u"])))
+            keeper.maybe(iter_num, model, optimizer)
+            if iter_num % 2500 == 0:    # step decay (:273-276)
+                for group in optimizer.param_groups:
+                    group["lr"] = args.base_lr * 0.1 ** (iter_num // 2500)
             if iter_num >= args.self_max_iteration:
                 break
-        if iter_num >= args.self_max_iteration:
-            break
-    if best_dice == 0:
-        torch.save(model.state_dict(), os.path.join(self_snapshot_path, '{}_best_model.pth'.format(args.model)))
+    keeper.finish(model, optimizer)
 
 
 def main(argv=None):
     args = parser.parse_args(argv)
     if args.deterministic:
-        torch.manual_seed(args.seed)
-        random.seed(args.seed)
-        np.random.seed(args.seed)
+        for seed_fn in (torch.manual_seed, random.seed, np.random.seed):
+            seed_fn(args.seed)
     device = torch.device("cuda", torch.cuda.current_device())
-    pre_snapshot_path = "./model/BCP/LA_{}_{}_labeled/pre_train".format(args.exp, args.labelnum)
-    self_snapshot_path = "./model/BCP/LA_{}_{}_labeled/self_train".format(args.exp, args.labelnum)
-    print("Starting BCP training.")
-    for snapshot_path in [pre_snapshot_path, self_snapshot_path]:
-        os.makedirs(snapshot_path, exist_ok=True)
-    logging.basicConfig(level=logging.INFO, format='[%(asctime)s.%(msecs)03d] %(message)s', datefmt='%H:%M:%S', stream=sys.stdout)
+    phase_dirs = ["./model/BCP/LA_{}_{}_labeled/{}".format(args.exp, args.labelnum, phase) for phase in ("pre_train", "self_train")]
+    for d in phase_dirs:
+        os.makedirs(d, exist_ok=True)
+    logging.basicConfig(level=logging.INFO, format="[%(asctime)s.%(msecs)03d] %(message)s", datefmt="%H:%M:%S", stream=sys.stdout)
     logging.info(str(args))
-    pre_train(args, pre_snapshot_path, device)
-    self_train(args, pre_snapshot_path, self_snapshot_path, device)
+    pre_train(args, phase_dirs[0], device)
+    self_train(args, phase_dirs[0], phase_dirs[1], device)
 
 
 if __name__ == "__main__":

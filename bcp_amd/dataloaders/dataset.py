@@ -3,8 +3,6 @@
 `primary_batch_size` labeled indices (one pass over a permutation per epoch) followed by
 `secondary_batch_size` unlabeled indices (endless permutations); `len` = n_labeled // primary_batch_size.
 The draws come from the global np.random stream, interleaved with the box draws, as in the reference."""
-import itertools
-
 import numpy as np
 import torch
 from torch.utils.data import Dataset
@@ -13,39 +11,49 @@ from torch.utils.data.sampler import Sampler
 from .. import synth
 
 
-def iterate_once(iterable):
-    return np.random.permutation(iterable)
+class _EndlessPermutations:
+    """the unlabeled stream: indices served from one np.random.permutation after another; a new permutation is drawn only when
+    the current one runs out (so a batch may straddle two of them), exactly when the reference's lazy generator chain draws it"""
 
+    def __init__(self, indices):
+        self.indices, self.pending = indices, []
 
-def iterate_eternally(indices):
-    def infinite_shuffles():
-        while True:
-            yield np.random.permutation(indices)
-    return itertools.chain.from_iterable(infinite_shuffles())
-
-
-def grouper(iterable, n):
-    args = [iter(iterable)] * n
-    return zip(*args)
+    def take(self, n):
+        out = []
+        while len(out) < n:
+            if not self.pending:
+                self.pending = list(np.random.permutation(self.indices))
+            room = n - len(out)
+            out.extend(self.pending[:room])
+            self.pending = self.pending[room:]
+        return tuple(out)
 
 
 class TwoStreamBatchSampler(Sampler):
+    """dataloaders/dataset.py:280-307 (+ helpers :340-355): batch = `batch_size - secondary_batch_size` labeled indices then
+    `secondary_batch_size` unlabeled ones; an epoch = one pass over ONE permutation of the labeled indices (a remainder that does
+    not fill a batch is dropped), the unlabeled permutations restart with every epoch.  RNG order per epoch (global np.random):
+    the labeled permutation when iteration starts, the first unlabeled permutation when the first batch is assembled.
+    Pinned against the reference's class on seeded streams (tests/golden/sampler.npz)."""
+
     def __init__(self, primary_indices, secondary_indices, batch_size, secondary_batch_size):
-        self.primary_indices = primary_indices
-        self.secondary_indices = secondary_indices
+        self.primary_indices, self.secondary_indices = primary_indices, secondary_indices
         self.secondary_batch_size = secondary_batch_size
         self.primary_batch_size = batch_size - secondary_batch_size
-        assert len(self.primary_indices) >= self.primary_batch_size > 0
-        assert len(self.secondary_indices) >= self.secondary_batch_size > 0
-
-    def __iter__(self):
-        primary_iter = iterate_once(self.primary_indices)
-        secondary_iter = iterate_eternally(self.secondary_indices)
-        return (primary_batch + secondary_batch for (primary_batch, secondary_batch)
-                in zip(grouper(primary_iter, self.primary_batch_size), grouper(secondary_iter, self.secondary_batch_size)))
+        if not 0 < self.primary_batch_size <= len(primary_indices):
+            raise AssertionError("not enough labeled samples for one batch")
+        if not 0 < self.secondary_batch_size <= len(secondary_indices):
+            raise AssertionError("not enough unlabeled samples for one batch")
 
     def __len__(self):
         return len(self.primary_indices) // self.primary_batch_size
+
+    def __iter__(self):
+        labeled = np.random.permutation(self.primary_indices)
+        unlabeled = _EndlessPermutations(self.secondary_indices)
+        pb = self.primary_batch_size
+        for k in range(len(self)):
+            yield tuple(labeled[k * pb:(k + 1) * pb]) + unlabeled.take(self.secondary_batch_size)
 
 
 class SyntheticLA(Dataset):

@@ -9,12 +9,10 @@ from ..utils.BCP_utils import update_ema_variables  # noqa: F401  (:299-302)
 
 def generate_mask(img, patch_size):
     """:187-200 -- one patch_size^3 zero box in a 96^3 ones volume, three np.random.randint draws (w, h, z)"""
-    batch_l = img.shape[0]
-    w = np.random.randint(0, 96 - patch_size)
-    h = np.random.randint(0, 96 - patch_size)
-    z = np.random.randint(0, 96 - patch_size)
-    box = (w, h, z, patch_size, patch_size, patch_size)
-    return BU.BoxMask(box, (96, 96, 96), None, False, img.device), BU.BoxMask(box, (96, 96, 96), batch_l, False, img.device)
+    origin = tuple(int(np.random.randint(0, 96 - patch_size)) for _ in range(3))      # w, h, z: drawn in this order
+    box = origin + (patch_size,) * 3
+    vol = (96, 96, 96)
+    return BU.BoxMask(box, vol, None, False, img.device), BU.BoxMask(box, vol, img.shape[0], False, img.device)
 
 
 def save_net_opt(net, optimizer, path, epoch):

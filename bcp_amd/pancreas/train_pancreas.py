@@ -13,8 +13,6 @@ import torch
 
 from bcp_amd import synth, train_step
 from bcp_amd.pancreas.Vnet import create_Vnet
-from bcp_amd.pancreas.pancreas_utils import generate_mask, get_cut_mask, update_ema_variables
-from bcp_amd.utils.BCP_utils import mix_loss, sup_loss
 
 seed_test = 2020
 batch_size, lr = 2, 1e-3
@@ -39,55 +37,31 @@ def _streams(device, n=4, bs=2, seed=seed_test):
 
 
 def pretrain(net1, optimizer, streams, steps):
+    """train_pancreas.py:50-101: copy-paste of the two labeled streams, supervised (CE + Dice) / 2"""
     net1.train()
-    for step in range(steps):
-        (img_a, lab_a), (img_b, lab_b) = streams[0], streams[1]
-        img_mask, loss_mask = generate_mask(img_a, patch_size)
-        img = img_a * img_mask + img_b * (1 - img_mask)
-        lab = lab_a * img_mask + lab_b * (1 - img_mask)
-        out = net1(img)[0]
-        loss = sup_loss(out, lab)            # (CE + dice) / 2, train_pancreas.py:90-92
-        optimizer.zero_grad()
-        loss.backward()
-        optimizer.step()
-    return loss
+    vols, labs = torch.cat([streams[0][0], streams[1][0]]), torch.cat([streams[0][1], streams[1][1]])
+    for _ in range(steps):
+        r = train_step.la_pre_train_step(net1, optimizer, vols, labs, variant="pancreas")
+    return r["loss"]
 
 
 def ema_cutmix(net, ema_net, optimizer, streams, steps, dp=None, grouped=None):
-    """train_pancreas.py:103-179.  grouped (default: whenever the streams are views of one batch): the two teacher calls
-    and the two student calls of an iteration are launched as one grouped forward each (train_step.la_self_train_step,
-    variant 'pancreas') -- InstanceNorm statistics are per sample, so this is the same arithmetic in half the launches."""
+    """train_pancreas.py:103-179 through train_step.la_self_train_step(variant='pancreas').  grouped (default: whenever the four
+    streams are views of one resident batch): the two teacher calls and the two student calls of an iteration are launched as one
+    grouped forward each -- InstanceNorm statistics are per sample, so this is the same arithmetic in half the launches;
+    grouped=False issues the reference's four separate network calls."""
     net.train()
     ema_net.train()
+    if isinstance(streams, _Streams) and len(streams) == 4:
+        vols, labs, bs = streams.vols, streams.labs, streams.bs
+    else:
+        vols, labs, bs = torch.cat([s_[0] for s_ in streams]), torch.cat([s_[1] for s_ in streams]), streams[0][0].shape[0]
     if grouped is None:
-        grouped = isinstance(streams, _Streams) and len(streams) == 4
-    if grouped:
-        for step in range(steps):
-            r = train_step.la_self_train_step(net, ema_net, optimizer, streams.vols, streams.labs, 2 * streams.bs, variant="pancreas",
-                                              connect_mode=connect_mode, alpha=alpha, dp=dp)
-        return r["loss"]
-    for step in range(steps):
-        (img_a, lab_a), (img_b, lab_b), (unimg_a, _), (unimg_b, _) = streams
-        with torch.no_grad():
-            unimg_a_out = ema_net(unimg_a)[0]
-            unimg_b_out = ema_net(unimg_b)[0]
-            uimg_a_plab = get_cut_mask(unimg_a_out, nms=True, connect_mode=connect_mode)
-            uimg_b_plab = get_cut_mask(unimg_b_out, nms=True, connect_mode=connect_mode)
-            img_mask, loss_mask = generate_mask(img_a, patch_size)
-        net3_input_l = unimg_a * img_mask + img_b * (1 - img_mask)
-        net3_input_unlab = img_a * img_mask + unimg_b * (1 - img_mask)
-        mix_output_l = net(net3_input_l)[0]
-        loss_1 = mix_loss(mix_output_l, uimg_a_plab, lab_b, loss_mask, unlab=True)
-        mix_output_2 = net(net3_input_unlab)[0]
-        loss_2 = mix_loss(mix_output_2, lab_a, uimg_b_plab, loss_mask)
-        loss = loss_1 + loss_2
-        optimizer.zero_grad()
-        loss.backward()
-        if dp is not None:
-            dp.allreduce_grads(net, optimizer)
-        optimizer.step()
-        update_ema_variables(net, ema_net, alpha)
-    return loss
+        grouped = True
+    for _ in range(steps):
+        r = train_step.la_self_train_step(net, ema_net, optimizer, vols, labs, 2 * bs, variant="pancreas", connect_mode=connect_mode,
+                                          alpha=alpha, dp=dp, grouped=grouped)
+    return r["loss"]
 
 
 def _val_set(device, n, seed=seed_test + 77):

@@ -222,6 +222,33 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
                 outputs_l=outputs_l.detach(), outputs_u=outputs_u.detach())
 
 
+def la_pre_train_step(model, optimizer, volume_batch, label_batch, mask_ratio=2 / 3, box=None, variant="la"):
+    """One pre-training iteration, LA_BCP_train.py:150-167 (variant 'pancreas': train_pancreas.py:83-97, a 64^3 box): the two
+    halves of the LABELED batch are copy-pasted into each other (images and labels alike), the loss is the supervised
+    (CE + Dice) / 2.  Returns device scalars."""
+    from .utils.losses import sup_loss_parts
+    sub_bs = volume_batch.shape[0] // 2
+    img_a, img_b = volume_batch[:sub_bs], volume_batch[sub_bs:2 * sub_bs]
+    lab_a, lab_b = label_batch[:sub_bs], label_batch[sub_bs:2 * sub_bs]
+    with torch.no_grad():
+        if box is None and variant == "pancreas":
+            from .pancreas.pancreas_utils import generate_mask as pancreas_mask
+            img_mask, _ = pancreas_mask(img_a, 64)
+        elif box is None:
+            img_mask, _ = BU.context_mask(img_a, mask_ratio)
+        else:
+            img_mask = BU.BoxMask(box, tuple(volume_batch.shape[2:]), None, False, volume_batch.device)
+    mixed_img = img_a * img_mask + img_b * (1 - img_mask)
+    mixed_lab = lab_a * img_mask + lab_b * (1 - img_mask)
+    outputs = model(mixed_img)[0]
+    loss_ce, loss_dice = sup_loss_parts(outputs, mixed_lab)
+    loss = (loss_ce + loss_dice) / 2
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return dict(loss=loss.detach(), loss_ce=loss_ce.detach(), loss_dice=loss_dice.detach())
+
+
 # ------------------------------------------------------------------------------------------ ACDC
 def generate_mask(img):
     """ACDC_BCP_train.py:131-140: 2/3 x 2/3 zero box, two np.random.randint draws (w then h)."""
@@ -338,3 +365,25 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
     ema_model.drop_masks = None
     return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach(), plab_a=plab_a, plab_b=plab_b,
                 out_unl=out_unl.detach(), out_l=out_l.detach())
+
+
+def acdc_pre_train_step(model, optimizer, volume_batch, label_batch, box=None):
+    """One ACDC pre-training iteration, ACDC_BCP_train.py:236-256: image a with a box of image b pasted in, trained against both
+    label maps through mix_loss(u_weight=1.0, unlab=True); loss = (dice + ce) / 2"""
+    sub_bs = volume_batch.shape[0] // 2
+    img_a, img_b = volume_batch[:sub_bs], volume_batch[sub_bs:2 * sub_bs]
+    lab_a, lab_b = label_batch[:sub_bs], label_batch[sub_bs:2 * sub_bs]
+    if box is None:
+        img_mask, loss_mask = generate_mask(img_a)
+    else:
+        sp = tuple(volume_batch.shape[2:])
+        img_mask, loss_mask = BU.BoxMask(box, sp, None, False, volume_batch.device), BU.BoxMask(box, sp, sub_bs, False, volume_batch.device)
+    net_input = img_a * img_mask + img_b * (1 - img_mask)
+    out = model(net_input)
+    loss_dice, loss_ce = acdc_mix_loss(out, lab_a, lab_b, loss_mask, u_weight=1.0, unlab=True)
+    loss = (loss_dice + loss_ce) / 2
+    optimizer.zero_grad()
+    loss.backward()
+    optimizer.step()
+    return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach())
+

@@ -1,10 +1,10 @@
-"""utils/ramps.py:19-26 of the reference (the value is logged by the train scripts, never applied to the loss)."""
-import numpy as np
+"""The consistency ramp of the reference (utils/ramps.py:19-26): exp(-5 (1 - t)^2) with t = clip(step / length, 0, 1).  The train
+scripts compute and log it; it never multiplies a loss term of the BCP step."""
+import math
 
 
 def sigmoid_rampup(current, rampup_length):
     if rampup_length == 0:
         return 1.0
-    current = np.clip(current, 0.0, rampup_length)
-    phase = 1.0 - current / rampup_length
-    return float(np.exp(-5.0 * phase * phase))
+    t = min(max(float(current), 0.0), float(rampup_length)) / float(rampup_length)
+    return math.exp(-5.0 * (1.0 - t) ** 2)

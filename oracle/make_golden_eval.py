@@ -122,8 +122,26 @@ def main_sw_pancreas():
     print("wrote", os.path.normpath(out), "fg fraction", float(label_map.mean()), "score range", float(score_map.min()), float(score_map.max()))
 
 
+def main_sampler():
+    """G13: the REFERENCE's TwoStreamBatchSampler (dataloaders/dataset.py:280-307) -- batches drawn under seeded np.random for the LA
+    (8 labeled of 80, batch 4 / 2 labeled; 16 of 80, batch 8 / 4) and ACDC (136 of 1312, batch 24 / 12) configurations, two epochs each"""
+    from dataloaders import dataset as ref_ds
+    d = {}
+    for ci, (n_lab, n_all, bs, sec_bs, seed) in enumerate([(8, 80, 4, 2, 1337), (16, 80, 8, 4, 7), (136, 1312, 24, 12, 1337), (5, 23, 5, 3, 3)]):
+        np.random.seed(seed)
+        sampler = ref_ds.TwoStreamBatchSampler(list(range(n_lab)), list(range(n_lab, n_all)), bs, sec_bs)
+        epochs = [np.array([list(b) for b in sampler], dtype=np.int64) for _ in range(2)]
+        d[f"cfg_{ci}"] = np.array([n_lab, n_all, bs, sec_bs, seed, len(sampler)])
+        d[f"epoch0_{ci}"], d[f"epoch1_{ci}"] = epochs
+    d["n"] = np.int64(4)
+    out = os.path.join(HERE, "..", "tests", "golden", "sampler.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", os.path.normpath(out), [d[f"epoch0_{i}"].shape for i in range(4)])
+
+
 if __name__ == "__main__":
     main()
     main_aug()
     main_aug_acdc()
     main_sw_pancreas()
+    main_sampler()

@@ -312,3 +312,19 @@ def test_input_pipelines_oracle_vs_reference(golden_dir):
         oi, ol = O.acdc_random_generator(g[f"in_image_{ci}"], g[f"in_label_{ci}"], out_hw, random.random,
                                          lambda lo, hi: int(np.random.randint(lo, hi)))
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"]), i
+
+
+def test_two_stream_sampler_vs_reference(golden_dir):
+    """A12: bcp_amd's TwoStreamBatchSampler == the reference's class, batch for batch, over two epochs on the same seeded np.random
+    stream, for the LA / ACDC configurations and a ragged one (5 labeled of 23, batch 5 / 3: remainder dropped, unlabeled batches
+    straddling permutations)"""
+    from bcp_amd.dataloaders.dataset import TwoStreamBatchSampler
+    g = np.load(os.path.join(golden_dir, "sampler.npz"))
+    for ci in range(int(g["n"])):
+        n_lab, n_all, bs, sec_bs, seed, length = (int(v) for v in g[f"cfg_{ci}"])
+        np.random.seed(seed)
+        sampler = TwoStreamBatchSampler(list(range(n_lab)), list(range(n_lab, n_all)), bs, sec_bs)
+        assert len(sampler) == length
+        for ep in range(2):
+            got = np.array([list(b) for b in sampler], dtype=np.int64)
+            assert np.array_equal(got, g[f"epoch{ep}_{ci}"]), (ci, ep)
