@@ -36,3 +36,32 @@ def test_unet_eval_mode(emu_ops):
 
 def test_val_2d_single_volume(emu_ops):
     NC.check_val_2d(emu_ops, CPU)
+
+
+def test_update_model_ema_state_dict_semantics(emu_ops):
+    """A10 (ACDC flavour): update_model_ema averages the WHOLE state_dict -- parameters, BatchNorm running statistics, and the int64
+    num_batches_tracked, which goes through float32 and is truncated on load (ACDC_BCP_train.py:123-129) -- vs the oracle"""
+    import numpy as np
+    import bcp_oracle as O
+    from bcp_amd import train_step
+    rng = np.random.default_rng(31)
+    Ps, Pt = O.init_params(O.unet_param_shapes(), seed=41, random_affine=True), O.init_params(O.unet_param_shapes(), seed=42, random_affine=True)
+    for P, nbt in ((Ps, 3), (Pt, 250)):
+        for k in P:
+            if k.endswith("running_mean"):
+                P[k] = torch.from_numpy(rng.normal(0.0, 0.3, tuple(P[k].shape)).astype(np.float32))
+            elif k.endswith("running_var"):
+                P[k] = torch.from_numpy(rng.uniform(0.5, 1.5, tuple(P[k].shape)).astype(np.float32))
+            elif k.endswith("num_batches_tracked"):
+                P[k] = torch.tensor(nbt, dtype=torch.int64)
+    student, teacher = NC.make_unet(Ps, CPU, emu_ops), NC.make_unet(Pt, CPU, emu_ops)
+    for _ in range(2):                      # twice: the truncated counter feeds the next update
+        train_step.update_model_ema(student, teacher, 0.99)
+        O.ema_state_dict(Ps, Pt, 0.99)
+    sd = teacher.state_dict()
+    live = [k for k in sd if k.startswith("encoder") or k.startswith("decoder")]
+    for k in live:
+        if k.endswith("num_batches_tracked"):
+            assert int(sd[k]) == int(Pt[k]), (k, int(sd[k]), int(Pt[k]))
+        else:
+            assert torch.equal(sd[k], Pt[k]), k       # one multiply-add per element in fp32 on both sides: bit-exact
