@@ -48,7 +48,9 @@ int bcp_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on
 int bcp_event_destroy(void* ev);
 
 /* ---- bidirectional copy-paste mix: a*mask + b*(1-mask)  (LA_BCP_train.py:248-251, ACDC_BCP_train.py:372-373,
- *      train_pancreas.py:155-156; mask from utils/BCP_utils.py:18-28 context_mask / ACDC generate_mask) ------- */
+ *      train_pancreas.py:155-156; mask from utils/BCP_utils.py:18-28 context_mask / ACDC generate_mask).
+ *      16-byte vector path only: W * C must be a multiple of 4 (80, 96 and 256 in the reference's configurations); other extents are
+ *      rejected with BCP_EINVAL. */
 int bcp_mix_box(const float* a, const float* b, float* out, int N, int D, int H, int W, int C, const int* box6, void* stream);
 
 /* ---- pseudo-labels (LA_BCP_train.py:57-60 get_cut_mask; ACDC_BCP_train.py:112-114 get_ACDC_masks) ---------- */

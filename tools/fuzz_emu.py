@@ -1,0 +1,121 @@
+"""Randomised shape fuzzing of the C-ABI kernels on the host simulator (test infrastructure; not part of the pytest suites).
+Draws ragged shapes / channel counts the fixed cases do not hit and runs the same checks against torch CPU / the oracle:
+   python tools/fuzz_emu.py [seconds] [seed]
+Prints every failing case; exit code = number of failures."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import kernel_checks as K  # noqa: E402
+import bcp_oracle as O  # noqa: E402
+from bcp_amd import _lib  # noqa: E402
+from bcp_amd.hip_ops import Ops  # noqa: E402
+from bcp_amd.utils import BCP_utils as BU  # noqa: E402
+import bcp_amd.hip_ops as H  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+rng = np.random.default_rng(seed)
+ops = Ops(_lib.Binding(os.path.join(ROOT, "tests", "_emu", "libbcp_emu.so")), allow_cpu=True)
+BU.set_test_ops(ops)
+dev = torch.device("cpu")
+fails, runs = [], 0
+t0 = time.time()
+
+
+def attempt(tag, fn):
+    global runs
+    runs += 1
+    try:
+        fn()
+    except _lib.BcpError as e:            # a shape the ABI rejects loudly is not a failure
+        print("rejected", tag, str(e)[:120], flush=True)
+    except AssertionError as e:
+        fails.append((tag, str(e)[:200]))
+        print("FAIL", tag, str(e)[:200], flush=True)
+
+
+while time.time() - t0 < budget:
+    kind = rng.integers(0, 5)
+    if kind == 0:     # 3x3x3 / 3x3 conv: fwd, dgrad, wgrad
+        KD = 3 if rng.random() < 0.7 else 1
+        deep = rng.random() < 0.15        # deep levels: many channels (streaming kernel, split-K, wgrad deep reduce), tiny extents
+        cin, cout = int(rng.choice([128, 144, 256] if deep else [4, 8, 16, 20, 32, 48, 64])), int(rng.choice([128, 256] if deep else [4, 8, 16, 20, 32, 64]))
+        if deep:
+            sp = (int(rng.integers(1, 5)), int(rng.integers(1, 8)), int(rng.integers(1, 8))) if KD == 3 else (1, int(rng.integers(1, 12)), int(rng.integers(1, 12)))
+        else:
+            sp = (int(rng.integers(1, 9)), int(rng.integers(1, 12)), int(rng.integers(1, 21))) if KD == 3 else (1, int(rng.integers(1, 24)), int(rng.integers(1, 40)))
+        case = (int(rng.integers(1, 4)), cin, cout, sp, KD)
+        attempt(f"conv3 {case}", lambda: K.check_conv3(ops, dev, cases=[case]))
+    elif kind == 1:   # largest connected component vs the oracle
+        D, Hh, W = int(rng.integers(1, 12)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        p = float(rng.choice([0.1, 0.3, 0.5, 0.7]))
+        seg = torch.from_numpy((rng.random((int(rng.integers(1, 3)), D, Hh, W)) < p).astype(np.uint8))
+        conn = int(rng.integers(1, 4))
+        big = rng.random() < 0.5
+        def cc():
+            if big:
+                os.environ["BCP_CC_TILE"] = "big"
+            try:
+                got = ops.cc_largest(seg, 1, conn).float()
+            finally:
+                os.environ.pop("BCP_CC_TILE", None)
+            assert torch.equal(got, O.largest_cc(seg.long(), None if conn == 3 else conn)), "cc mismatch"
+        attempt(f"cc {tuple(seg.shape)} p={p} conn={conn} big={big}", cc)
+    elif kind == 2:   # norm fwd / bwd, random groups and channels
+        C = int(rng.choice([16, 32, 64, 128]))
+        G = int(rng.choice([1, 2, 3]))
+        rows = int(rng.integers(2, 400))
+        x = K.R(rng, G * rows, C)
+        def norm():
+            y = x.clone().requires_grad_(True)
+            gam, bet = K.R(rng, C) * 0.5 + 1.0, K.R(rng, C) * 0.1
+            ref = torch.cat([torch.relu(torch.nn.functional.batch_norm(y[g * rows:(g + 1) * rows], None, None, gam, bet, True, 0.1, 1e-5)) for g in range(G)])
+            da = K.R(rng, *ref.shape)
+            ref.backward(da)
+            xv = x.view(G, rows, 1, 1, C) if False else x.view(G * rows, 1, 1, 1, C)
+            a, st = ops.norm_fwd(x.view(G, rows, 1, 1, C).reshape(G, rows, 1, 1, C), G, gam, bet, torch.zeros(C), torch.ones(C), H.ACT_RELU)
+            K.close(a.reshape(-1, C), ref, rtol=2e-4, msg="norm fwd")
+            dg, db = torch.zeros(C), torch.zeros(C)
+            dy = ops.norm_bwd(x.view(G, rows, 1, 1, C), da.view(G, rows, 1, 1, C), G, st, H.ACT_RELU, dg, db, False)
+            if rows > 2:
+                K.close(dy.reshape(-1, C), y.grad, rtol=2e-3, msg="norm bwd")
+        attempt(f"norm C={C} G={G} rows={rows}", norm)
+    elif kind == 3:   # copy-paste mix with random boxes (incl. degenerate ones)
+        sp = (int(rng.integers(1, 10)), int(rng.integers(1, 20)), int(rng.integers(1, 20)))
+        a, b = K.R(rng, 2, *sp, 1), K.R(rng, 2, *sp, 1)
+        o = [int(rng.integers(0, s)) for s in sp]
+        e = [int(rng.integers(0, s - oo + 1)) for s, oo in zip(sp, o)]
+        def mix():
+            got = ops.mix_box(a, b, tuple(o) + tuple(e))
+            m = torch.ones(sp)
+            m[o[0]:o[0] + e[0], o[1]:o[1] + e[1], o[2]:o[2] + e[2]] = 0
+            ref = a * m.view(1, *sp, 1) + b * (1 - m.view(1, *sp, 1))
+            assert torch.equal(got, ref), "mix mismatch"
+        attempt(f"mix {sp} box={o + e}", mix)
+    else:             # ACDC augment gather vs the oracle's scipy restatement
+        Hh, W = int(rng.integers(2, 70)), int(rng.integers(2, 70))
+        out_hw = (int(rng.integers(2, 80)), int(rng.integers(2, 80)))
+        img = rng.random((Hh, W)).astype(np.float32)
+        mode = int(rng.integers(0, 3))
+        k, axis, ang = int(rng.integers(0, 4)), int(rng.integers(0, 2)), int(rng.integers(-20, 20))
+        def aug():
+            if mode == 0:
+                ref = O._nearest_zoom(img, out_hw)
+                got = ops.acdc_augment(torch.from_numpy(img), out_hw, 0)
+            elif mode == 1:
+                ref = O._nearest_zoom(np.flip(np.rot90(img, k), axis=axis).copy(), out_hw)
+                got = ops.acdc_augment(torch.from_numpy(img), out_hw, 1, k, axis)
+            else:
+                ref = O._nearest_zoom(O._nearest_rotate(img, ang), out_hw)
+                got = ops.acdc_augment(torch.from_numpy(img), out_hw, 2, 0, 0, O.rotate_affine(ang, img.shape))
+            assert np.array_equal(got.numpy(), ref), "augment mismatch"
+        attempt(f"augment {Hh}x{W}->{out_hw} mode={mode} k={k} axis={axis} ang={ang}", aug)
+print(f"{runs} cases, {len(fails)} failures in {time.time() - t0:.0f} s")
+sys.exit(len(fails))
