@@ -323,9 +323,13 @@ def check_conv3_c1(ops, dev):
         close(dw, w.grad, rtol=2e-4, msg=f"conv3_c1 wgrad {sp}")
 
 
-def check_k2(ops, dev):
+K2_CASES = ((1, 16, 32, (4, 6, 8)), (2, 32, 64, (2, 4, 6)), (1, 128, 256, (2, 2, 2)), (1, 16, 16, (10, 12, 14)), (2, 32, 16, (8, 6, 10)))
+PW_CASES = ((2, 64, 32, (8, 8)), (3, 256, 128, (4, 4)))
+
+
+def check_k2(ops, dev, cases=K2_CASES, pw_cases=PW_CASES):
     rng = np.random.default_rng(7)
-    for (N, Cin, Cout, sp) in ((1, 16, 32, (4, 6, 8)), (2, 32, 64, (2, 4, 6)), (1, 128, 256, (2, 2, 2)), (1, 16, 16, (10, 12, 14)), (2, 32, 16, (8, 6, 10))):
+    for (N, Cin, Cout, sp) in cases:
         # down conv
         x = R(rng, N, Cin, *sp).requires_grad_(True)
         w = (R(rng, Cout, Cin, 2, 2, 2) * 0.1).requires_grad_(True)
@@ -361,7 +365,7 @@ def check_k2(ops, dev):
         ops.k2_wgrad(x2cl, dy2cl, dw2, H.WG_UP)
         close(dw2, w2.grad, rtol=2e-4, msg="up wgrad")
     # 1x1 conv (U-Net decoder) fwd / dgrad / wgrad, bias grad via colsum
-    for (N, Cin, Cout, hw) in ((2, 64, 32, (8, 8)), (3, 256, 128, (4, 4))):
+    for (N, Cin, Cout, hw) in pw_cases:
         x = R(rng, N, Cin, *hw).requires_grad_(True)
         w = (R(rng, Cout, Cin, 1, 1) * 0.1).requires_grad_(True)
         b = (R(rng, Cout) * 0.1).requires_grad_(True)

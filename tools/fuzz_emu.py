@@ -42,7 +42,7 @@ def attempt(tag, fn):
 
 
 while time.time() - t0 < budget:
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 8)
     if kind == 0:     # 3x3x3 / 3x3 conv: fwd, dgrad, wgrad
         KD = 3 if rng.random() < 0.7 else 1
         deep = rng.random() < 0.15        # deep levels: many channels (streaming kernel, split-K, wgrad deep reduce), tiny extents
@@ -99,6 +99,47 @@ while time.time() - t0 < budget:
             ref = a * m.view(1, *sp, 1) + b * (1 - m.view(1, *sp, 1))
             assert torch.equal(got, ref), "mix mismatch"
         attempt(f"mix {sp} box={o + e}", mix)
+    elif kind == 5:   # k2s2 down / up convs and the 1x1 conv: fwd, dgrad, wgrad
+        cin, cout = int(rng.choice([16, 32, 64, 128])), int(rng.choice([16, 32, 64, 128, 256]))
+        sp = tuple(int(2 * rng.integers(1, 8)) for _ in range(3))
+        case = (int(rng.integers(1, 3)), cin, cout, sp)
+        pw = (int(rng.integers(1, 4)), int(rng.choice([32, 64, 128, 256])), int(rng.choice([16, 32, 64, 128])), (int(rng.integers(1, 12)), int(rng.integers(1, 12))))
+        chunks = rng.random() < 0.3
+        def k2():
+            if chunks:
+                os.environ["BCP_TN_GROUPS"] = "1"
+            try:
+                K.check_k2(ops, dev, cases=[case], pw_cases=[pw])
+            finally:
+                os.environ.pop("BCP_TN_GROUPS", None)
+        attempt(f"k2 {case} pw {pw} one-group={chunks}", k2)
+    elif kind == 6:   # MaxPool2d(2) / bilinear x2 (align_corners) and their backward passes vs torch
+        import torch.nn.functional as F
+        N, C, Hh, W = int(rng.integers(1, 4)), int(rng.choice([16, 32, 64])), int(2 * rng.integers(1, 12)), int(2 * rng.integers(1, 12))
+        def pool():
+            x = K.R(rng, N, C, Hh, W).requires_grad_(True)
+            yr = F.max_pool2d(x, 2)
+            dy = K.R(rng, *yr.shape)
+            yr.backward(dy)
+            xcl = K.to_cl(x.detach())
+            assert torch.equal(K.from_cl(ops.maxpool2d_fwd(xcl), True), yr.detach()), "maxpool fwd"
+            assert torch.equal(K.from_cl(ops.maxpool2d_bwd(xcl, K.to_cl(dy), torch.empty_like(xcl)), True), x.grad), "maxpool bwd"
+            xs = K.R(rng, N, C, Hh // 2 + 1, W // 2 + 1).requires_grad_(True)
+            up = F.interpolate(xs, scale_factor=2, mode="bilinear", align_corners=True)
+            du = K.R(rng, *up.shape)
+            up.backward(du)
+            buf = torch.zeros(N, 1, up.shape[2], up.shape[3], C)
+            ops.bilinear2x_fwd(K.to_cl(xs.detach()), buf, 0)
+            K.close(K.from_cl(buf, True), up, msg="bilinear fwd")
+            K.close(K.from_cl(ops.bilinear2x_bwd(K.to_cl(du), 0, C), True), xs.grad, msg="bilinear bwd")
+        attempt(f"pool2d N={N} C={C} {Hh}x{W}", pool)
+    elif kind == 7:   # pseudo-labels vs torch (ties excluded: random logits)
+        n = int(rng.integers(1, 5000))
+        lo2, lo4 = K.R(rng, 1, 1, 1, n, 2), K.R(rng, 1, 1, 1, n, 4)
+        def pl():
+            assert torch.equal(ops.plabel_bin(lo2, 0.5).long(), (torch.softmax(lo2, -1)[..., 1] >= 0.5).long()), "plabel_bin"
+            assert torch.equal(ops.plabel_argmax4(lo4).long(), torch.softmax(lo4, -1).argmax(-1)), "plabel_argmax4"
+        attempt(f"plabel n={n}", pl)
     else:             # ACDC augment gather vs the oracle's scipy restatement
         Hh, W = int(rng.integers(2, 70)), int(rng.integers(2, 70))
         out_hw = (int(rng.integers(2, 80)), int(rng.integers(2, 80)))
