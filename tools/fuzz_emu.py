@@ -42,7 +42,7 @@ def attempt(tag, fn):
 
 
 while time.time() - t0 < budget:
-    kind = rng.integers(0, 8)
+    kind = rng.integers(0, 9)
     if kind == 0:     # 3x3x3 / 3x3 conv: fwd, dgrad, wgrad
         KD = 3 if rng.random() < 0.7 else 1
         deep = rng.random() < 0.15        # deep levels: many channels (streaming kernel, split-K, wgrad deep reduce), tiny extents
@@ -140,6 +140,34 @@ while time.time() - t0 < budget:
             assert torch.equal(ops.plabel_bin(lo2, 0.5).long(), (torch.softmax(lo2, -1)[..., 1] >= 0.5).long()), "plabel_bin"
             assert torch.equal(ops.plabel_argmax4(lo4).long(), torch.softmax(lo4, -1).argmax(-1)), "plabel_argmax4"
         attempt(f"plabel n={n}", pl)
+    elif kind == 8:   # masked Dice + CE (both flavours), value and d/dlogits vs the oracle, random boxes incl. empty / full ones
+        from bcp_amd import train_step
+        three_d = rng.random() < 0.5
+        N = int(rng.integers(1, 4))
+        sp = (int(rng.integers(1, 7)), int(rng.integers(1, 10)), int(4 * rng.integers(1, 6))) if three_d else (int(rng.integers(1, 14)), int(4 * rng.integers(1, 8)))
+        Cc = 2 if three_d else 4
+        o = [int(rng.integers(0, d)) for d in sp]
+        e = [int(rng.integers(0, d - oo + 1)) for d, oo in zip(sp, o)]
+        unlab = bool(rng.random() < 0.5)
+        def ml():
+            logits = K.R(rng, N, Cc, *sp)
+            a, b = torch.from_numpy(rng.integers(0, Cc, (N,) + sp)), torch.from_numpy(rng.integers(0, Cc, (N,) + sp))
+            box = tuple(o) + tuple(e)
+            dense = O.box_to_mask(box, sp, N)[1].to(torch.float32)
+            lo_ref = logits.clone().requires_grad_(True)
+            lo_hip = logits.clone().requires_grad_(True)
+            if three_d:
+                ref = O.mix_loss_la(lo_ref, a, b, dense, u_weight=0.5, unlab=unlab)
+                got = BU.mix_loss(lo_hip, a, b, BU.BoxMask(box, sp, N, False, dev), u_weight=0.5, unlab=unlab)
+                ref.backward(); got.backward()
+                assert abs(float(got.detach()) - float(ref.detach())) < 2e-5, (float(got.detach()), float(ref.detach()))
+            else:
+                rd, rc = O.mix_loss_acdc(lo_ref, a, b, dense, u_weight=0.5, unlab=unlab)
+                gd, gc = train_step.acdc_mix_loss(lo_hip, a, b, BU.BoxMask(box, sp, N, False, dev), u_weight=0.5, unlab=unlab)
+                (rd + rc).backward(); (gd + gc).backward()
+                assert abs(float(gd.detach()) - float(rd.detach())) < 2e-5 and abs(float(gc.detach()) - float(rc.detach())) < 2e-5
+            K.close(lo_hip.grad, lo_ref.grad, rtol=2e-4, atol_scale=1e-4, msg="dloss/dlogits")
+        attempt(f"mixloss {'la' if three_d else 'acdc'} N={N} {sp} box={o + e} unlab={unlab}", ml)
     else:             # ACDC augment gather vs the oracle's scipy restatement
         Hh, W = int(rng.integers(2, 70)), int(rng.integers(2, 70))
         out_hw = (int(rng.integers(2, 80)), int(rng.integers(2, 80)))
