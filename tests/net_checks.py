@@ -192,6 +192,49 @@ def check_la_step(ops, dev, golden_dir):
 
 
 # ------------------------------------------------------------------------------------------ U-Net / ACDC
+def check_pre_train_steps(ops, dev):
+    """the pre-training step functions the train scripts call (LA_BCP_train.py:150-167, ACDC_BCP_train.py:236-256): loss and the
+    updated weights after one SGD step vs the oracle (labeled halves copy-pasted into each other, supervised / mix loss)"""
+    from bcp_amd import train_step
+    rng = np.random.default_rng(17)
+    # ---- LA: V-Net, images AND labels mixed, (CE + Dice) / 2
+    shape, box = (32, 32, 16), (3, 5, 2, 21, 21, 10)
+    P = O.init_params(O.vnet_param_shapes(), seed=61, random_affine=True)
+    vol, lab = O.synth_la_batch(2, shape=shape, seed=62)
+    dm = {"x5": torch.from_numpy((rng.random((1, 256)) < 0.5).astype(np.float32)), "x9": torch.from_numpy((rng.random((1, 16)) < 0.5).astype(np.float32))}
+    img_mask, _ = O.box_to_mask(box, shape, 1)
+    keys = set(O.trainable_keys(P))
+    Q = O._with_grad({k: v.clone() for k, v in P.items()}, keys)
+    out = O.vnet_forward(Q, O.mix(vol[:1], vol[1:], img_mask), dm, True, "la")
+    ref = O.sup_loss_la(out, O.mix(lab[:1], lab[1:], img_mask))
+    ref.backward()
+    net = make_vnet(P, dev, ops)
+    net.drop_masks = dm
+    opt = train_step.FlatSGD(net, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    r = train_step.la_pre_train_step(net, opt, vol.to(dev), lab.to(dev), box=box)
+    assert abs(float(r["loss"]) - float(ref.detach())) < 1e-5, (float(r["loss"]), float(ref.detach()))
+    sd = net.state_dict()
+    for k in ("decoder.block_nine.conv.0.weight", "decoder.out_conv.weight", "encoder.block_five.conv.0.weight"):
+        upd = P[k] - 0.01 * (Q[k].grad + 1e-4 * P[k])            # first SGD step: buf = g + wd * p
+        K.close(sd[k] - P[k], upd - P[k], rtol=3e-2, atol_scale=3e-2, msg=f"LA pre-train update {k}")
+    # ---- ACDC: U-Net, image a with a box of image b, mix_loss(u_weight=1.0, unlab=True) against both label maps
+    hw, box2 = (64, 64), (9, 13, 42, 42)
+    Pu = O.init_params(O.unet_param_shapes(), seed=71, random_affine=True)
+    vol2, lab2 = O.synth_acdc_batch(4, shape=hw, seed=72)
+    bits = rng.integers(0, 256, size=4 * 2 * sum(c * (hw[0] >> i) * (hw[1] >> i) for i, c in enumerate(O.UNET_CH)) // 8 + 64, dtype=np.uint8)
+    dmu = unet_drops(bits, 2, hw)
+    m2, lm2 = O.box_to_mask(box2, hw, 2)
+    Qu = O._with_grad({k: v.clone() for k, v in Pu.items()}, set(O.trainable_keys(Pu)))
+    outu = O.unet_forward(Qu, O.mix(vol2[:2], vol2[2:], m2), dmu, True)
+    rd, rc = O.mix_loss_acdc(outu, lab2[:2], lab2[2:], lm2, u_weight=1.0, unlab=True)
+    unet = make_unet(Pu, dev, ops)
+    unet.drop_masks = dmu
+    optu = train_step.FlatSGD(unet, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    ru = train_step.acdc_pre_train_step(unet, optu, vol2.to(dev), lab2.to(dev), box=box2)
+    assert abs(float(ru["loss_dice"]) - float(rd.detach())) < 1e-5 and abs(float(ru["loss_ce"]) - float(rc.detach())) < 1e-5
+    assert abs(float(ru["loss"]) - float(((rd + rc) / 2).detach())) < 1e-5
+
+
 def make_unet(P, dev, ops):
     from bcp_amd.networks.unet import UNet_2d
     net = UNet_2d(in_chns=1, class_num=4).to(dev)

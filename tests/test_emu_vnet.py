@@ -35,3 +35,7 @@ def test_sliding_window_validation(emu_ops, golden_dir):
 def test_sliding_window_validation_pancreas(emu_ops, golden_dir):
     NC.check_sliding_window_pancreas(emu_ops, CPU, golden_dir)
 
+
+def test_pre_train_steps(emu_ops):
+    NC.check_pre_train_steps(emu_ops, CPU)
+

@@ -81,3 +81,7 @@ def test_sliding_window_validation(ops, golden_dir):
 def test_sliding_window_validation_pancreas(ops, golden_dir):
     NC.check_sliding_window_pancreas(ops, DEV, golden_dir)
 
+
+def test_pre_train_steps(ops):
+    NC.check_pre_train_steps(ops, DEV)
+
