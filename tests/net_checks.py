@@ -216,7 +216,7 @@ def check_pre_train_steps(ops, dev):
     sd = net.state_dict()
     for k in ("decoder.block_nine.conv.0.weight", "decoder.out_conv.weight", "encoder.block_five.conv.0.weight"):
         upd = P[k] - 0.01 * (Q[k].grad + 1e-4 * P[k])            # first SGD step: buf = g + wd * p
-        K.close(sd[k] - P[k], upd - P[k], rtol=3e-2, atol_scale=3e-2, msg=f"LA pre-train update {k}")
+        K.close(sd[k].cpu() - P[k], upd - P[k], rtol=3e-2, atol_scale=3e-2, msg=f"LA pre-train update {k}")
     # ---- ACDC: U-Net, image a with a box of image b, mix_loss(u_weight=1.0, unlab=True) against both label maps
     hw, box2 = (64, 64), (9, 13, 42, 42)
     Pu = O.init_params(O.unet_param_shapes(), seed=71, random_affine=True)
