@@ -192,6 +192,29 @@ def check_la_step(ops, dev, golden_dir):
 
 
 # ------------------------------------------------------------------------------------------ U-Net / ACDC
+def check_la_step_batch8(ops, dev):
+    """the reference's default LA batch layout (--batch_size 8 --labeled_bs 4: sub-batches of TWO volumes, so every grouped
+    BatchNorm group holds two samples and Dropout3d masks differ per sample) vs the oracle: loss, pseudo-labels, gradients"""
+    from bcp_amd import train_step
+    rng = np.random.default_rng(5)
+    shape, sub = (32, 32, 16), 2
+    P = O.init_params(O.vnet_param_shapes(), seed=81, random_affine=True)
+    vol, lab = O.synth_la_batch(4 * sub, shape=shape, seed=82)
+    drops = {k: {"x5": torch.from_numpy((rng.random((sub, 256)) < 0.5).astype(np.float32)),
+                 "x9": torch.from_numpy((rng.random((sub, 16)) < 0.5).astype(np.float32))} for k in ("t_a", "t_b", "s_l", "s_u")}
+    box = (3, 5, 2, 21, 21, 10)
+    ro = O.la_self_train_step({k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in P.items()}, vol, lab, box, drops, sub)
+    model, ema = make_vnet(P, dev, ops), make_vnet(P, dev, ops)
+    for p in ema.parameters():
+        p.detach_()
+    r = train_step.la_self_train_step(model, ema, None, vol.to(dev), lab.to(dev), 2 * sub, box=box, drops=drops)
+    assert abs(float(r["loss"]) - float(ro["loss"])) < 1e-5
+    assert int((r["plab_a"].cpu().float() != ro["plab_a"]).sum() + (r["plab_b"].cpu().float() != ro["plab_b"]).sum()) <= 4
+    params = dict(model.named_parameters())
+    for k in ("decoder.out_conv.weight", "decoder.block_nine.conv.0.weight", "encoder.block_one.conv.0.weight"):
+        assert K.rel_l2(params[k].grad, ro["grads"][k]) < 3e-2, k
+
+
 def check_pre_train_steps(ops, dev):
     """the pre-training step functions the train scripts call (LA_BCP_train.py:150-167, ACDC_BCP_train.py:236-256): loss and the
     updated weights after one SGD step vs the oracle (labeled halves copy-pasted into each other, supervised / mix loss)"""

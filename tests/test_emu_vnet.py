@@ -39,3 +39,7 @@ def test_sliding_window_validation_pancreas(emu_ops, golden_dir):
 def test_pre_train_steps(emu_ops):
     NC.check_pre_train_steps(emu_ops, CPU)
 
+
+def test_la_step_reference_default_batch(emu_ops):
+    NC.check_la_step_batch8(emu_ops, CPU)
+
