@@ -215,6 +215,29 @@ def check_la_step_batch8(ops, dev):
         assert K.rel_l2(params[k].grad, ro["grads"][k]) < 3e-2, k
 
 
+def check_pancreas_step(ops, dev):
+    """the pancreas flavour of the self-training step (train_pancreas.py:145-171: IN-V-Net, 18-connectivity CC, its own mix directions --
+    unlabeled image a with a box of labeled image b, labeled image a with a box of unlabeled b -- and loss terms) vs the oracle,
+    grouped and as four separate calls"""
+    from bcp_amd import train_step
+    shape, box = (32, 32, 32), (4, 6, 3, 20, 20, 20)
+    P = O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=91, random_affine=True)
+    vol, lab = O.synth_la_batch(4, shape=shape, seed=92)
+    ro = O.la_self_train_step({k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in P.items()}, vol, lab, box, {}, 1,
+                              variant="pancreas", connectivity=2)
+    for grouped in (True, False):
+        model = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+        ema = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+        for p in ema.parameters():
+            p.detach_()
+        r = train_step.la_self_train_step(model, ema, None, vol.to(dev), lab.to(dev), 2, box=box, variant="pancreas", connect_mode=2, grouped=grouped)
+        assert abs(float(r["loss"]) - float(ro["loss"])) < 1e-5 and abs(float(r["loss_l"]) - float(ro["loss_l"])) < 1e-5, (grouped, float(r["loss"]), float(ro["loss"]))
+        assert int((r["plab_a"].cpu().float() != ro["plab_a"]).sum() + (r["plab_b"].cpu().float() != ro["plab_b"]).sum()) <= 4
+        params = dict(model.named_parameters())
+        for k in ("branchs.0.1.weight", "branchs.0.0.conv.0.weight", "block_one.conv.0.weight"):
+            assert K.rel_l2(params[k].grad, ro["grads"][k]) < 3e-2, (grouped, k)
+
+
 def check_pre_train_steps(ops, dev):
     """the pre-training step functions the train scripts call (LA_BCP_train.py:150-167, ACDC_BCP_train.py:236-256): loss and the
     updated weights after one SGD step vs the oracle (labeled halves copy-pasted into each other, supervised / mix loss)"""

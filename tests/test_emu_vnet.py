@@ -43,3 +43,7 @@ def test_pre_train_steps(emu_ops):
 def test_la_step_reference_default_batch(emu_ops):
     NC.check_la_step_batch8(emu_ops, CPU)
 
+
+def test_pancreas_self_train_step(emu_ops):
+    NC.check_pancreas_step(emu_ops, CPU)
+
