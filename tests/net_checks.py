@@ -215,7 +215,7 @@ def check_la_step_batch8(ops, dev):
         assert K.rel_l2(params[k].grad, ro["grads"][k]) < 3e-2, k
 
 
-def check_pancreas_step(ops, dev):
+def check_pancreas_step(ops, dev, modes=(True, False)):
     """the pancreas flavour of the self-training step (train_pancreas.py:145-171: IN-V-Net, 18-connectivity CC, its own mix directions --
     unlabeled image a with a box of labeled image b, labeled image a with a box of unlabeled b -- and loss terms) vs the oracle,
     grouped and as four separate calls"""
@@ -225,7 +225,7 @@ def check_pancreas_step(ops, dev):
     vol, lab = O.synth_la_batch(4, shape=shape, seed=92)
     ro = O.la_self_train_step({k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in P.items()}, vol, lab, box, {}, 1,
                               variant="pancreas", connectivity=2)
-    for grouped in (True, False):
+    for grouped in modes:
         model = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
         ema = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
         for p in ema.parameters():

@@ -45,5 +45,5 @@ def test_la_step_reference_default_batch(emu_ops):
 
 
 def test_pancreas_self_train_step(emu_ops):
-    NC.check_pancreas_step(emu_ops, CPU)
+    NC.check_pancreas_step(emu_ops, CPU, modes=(True,))   # (grouped == four separate calls is a GPU test: tests/test_gpu_scripts.py)
 

@@ -85,3 +85,11 @@ def test_sliding_window_validation_pancreas(ops, golden_dir):
 def test_pre_train_steps(ops):
     NC.check_pre_train_steps(ops, DEV)
 
+
+def test_pancreas_self_train_step(ops):
+    NC.check_pancreas_step(ops, DEV)
+
+
+def test_la_step_reference_default_batch(ops):
+    NC.check_la_step_batch8(ops, DEV)
+
