@@ -24,6 +24,7 @@ SZ = C.c_size_t
 # name -> (restype, argtypes)
 _SIGS = {
     "bcp_version": (I, []),
+    "bcp_set_option": (I, [C.c_char_p, C.c_char_p]),
     "bcp_last_error": (C.c_char_p, []),
     "bcp_device_arch": (I, [C.c_char_p, I]),
     "bcp_event_create": (I, [C.POINTER(P)]),
@@ -46,7 +47,6 @@ _SIGS = {
     "bcp_conv3_pack_many": (I, [P, I, P]),
     "bcp_conv3_fwd_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
-    "bcp_conv3_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, P, I, P, I, P]),
     "bcp_conv3_stat_rows": (I, [I, I, I, I, I, I, I, I, I]),
     "bcp_conv3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
     "bcp_conv3_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
@@ -112,6 +112,12 @@ class Binding:
 
     def last_error(self) -> str:
         return self.cdll.bcp_last_error().decode("utf-8", "replace")
+
+    def set_option(self, name: str, value="") -> None:
+        """tuning / test switch of the library (bcp_set_option); value: int, sequence of ints, or "" = default"""
+        if isinstance(value, (tuple, list)):
+            value = ",".join(str(int(v)) for v in value)
+        self.call("bcp_set_option", name.encode(), str(value).encode())
 
     def call(self, name: str, *args):
         fn, is_status = self._fns[name]

@@ -11,9 +11,42 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+Options& options() {
+  static Options o;
+  return o;
+}
 }  // namespace bcp
 
-extern "C" int bcp_version(void) { return 100; }
+extern "C" int bcp_version(void) { return 200; }
+
+// name = one of the Options fields (common.h); value = decimal integer(s), comma separated for the array-valued options;
+// an empty value restores the default.  Not thread-safe against concurrent launches: set options before the work starts.
+extern "C" int bcp_set_option(const char* name, const char* value) {
+  BCP_REQUIRE(name && value, "bcp_set_option: null argument");
+  bcp::Options& o = bcp::options();
+  const bcp::Options def;
+  long long v[5] = {0, 0, 0, 0, 0};
+  const int n = sscanf(value, "%lld,%lld,%lld,%lld,%lld", &v[0], &v[1], &v[2], &v[3], &v[4]);
+  const bool reset = n <= 0;
+#define BCP_OPT_INT(field) if (!strcmp(name, #field)) { o.field = reset ? def.field : (int)v[0]; return BCP_OK; }
+  BCP_OPT_INT(conv3_p) BCP_OPT_INT(splitk) BCP_OPT_INT(res_pcu) BCP_OPT_INT(res_nt) BCP_OPT_INT(wgrad_nt)
+  BCP_OPT_INT(tn_groups) BCP_OPT_INT(cc_tile) BCP_OPT_INT(conv3_p8) BCP_OPT_INT(wgrad_p8)
+#undef BCP_OPT_INT
+  if (!strcmp(name, "res_tile2d_vox")) { o.res_tile2d_vox = reset ? def.res_tile2d_vox : v[0]; return BCP_OK; }
+  if (!strcmp(name, "conv3_cfg")) {
+    BCP_REQUIRE(reset || n == 4, "bcp_set_option: conv3_cfg wants TD,TH,TW,NT");
+    for (int i = 0; i < 4; ++i) o.conv3_cfg[i] = reset ? 0 : (int)v[i];
+    return BCP_OK;
+  }
+  if (!strcmp(name, "wgrad_tile")) {
+    BCP_REQUIRE(reset || n >= 3, "bcp_set_option: wgrad_tile wants TD,TH,TW[,min_voxels,max_voxels]");
+    for (int i = 0; i < 5; ++i) o.wgrad_tile[i] = def.wgrad_tile[i];
+    for (int i = 0; i < n && !reset; ++i) o.wgrad_tile[i] = v[i];
+    return BCP_OK;
+  }
+  bcp::set_error("bcp_set_option: unknown option '%s'", name);
+  return BCP_EINVAL;
+}
 extern "C" const char* bcp_last_error(void) { return bcp::g_err; }
 
 extern "C" int bcp_device_arch(char* buf, int n) {

@@ -293,8 +293,8 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
   cd.N = N; cd.D = D; cd.H = H; cd.W = W; cd.conn = connectivity;
   // local tiles: 8x16x16 / 32x64 voxels (8 per thread) when the volume has at least ~2 such tiles per CU, else 4x8x16 / 16x32;
   // bigger tiles leave fewer voxels on tile faces for the global-atomic border pass (51 % -> 33 % in 3-D)
-  const char* e = getenv("BCP_CC_TILE");
-  const bool big = e ? e[0] == 'b' : (n >= 512LL * 2048);
+  const int tile_opt = options().cc_tile;   // 0: by size, 1: small tiles, 2: big tiles (tests / measurements)
+  const bool big = tile_opt ? tile_opt == 2 : (n >= 512LL * 2048);
   if (D > 1 && big) {
     cd.tiles_d = cdiv(D, 8); cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16);
     hipLaunchKernelGGL((k_cc_local<8, 16, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);

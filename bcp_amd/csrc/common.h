@@ -33,6 +33,24 @@ void set_error(const char* fmt, ...);
     }                                                                   \
   } while (0)
 
+// Process-wide tuning / test switches.  Set ONLY through bcp_set_option() (include/bcp_hip.h): the launch paths never read
+// the environment (round 1 called getenv() up to 15 times per launch).  0 / empty = automatic choice.
+struct Options {
+  int conv3_p = 0;          // cap on persistent workgroups of the resident / pipeline convs (tests: force multi-tile loops)
+  int splitk = 0;           // streaming conv: split-K factor 1..4
+  int res_pcu = 0;          // resident conv: persistent workgroups per CU 1..4
+  int res_nt = 0;           // resident conv: widest channel slab (1, 2, 4)
+  long long res_tile2d_vox = 10000;   // 2-D resident conv: 16x16 tiles from this many pixels per launch on
+  int conv3_cfg[4] = {0, 0, 0, 0};    // streaming conv: TD, TH, TW, NT
+  int wgrad_nt = 0;
+  long long wgrad_tile[5] = {0, 0, 0, 0, 1LL << 60};   // TD, TH, TW, min voxels, max voxels
+  int tn_groups = 0;        // k2s2 / 1x1 weight-gradient GEMM: cap on voxel groups (tests: force multi-chunk groups)
+  int cc_tile = 0;          // largest-CC tile flavour
+  int conv3_p8 = 1;         // persistent 8-wave pipeline conv: 0 off, 1 where it is the measured winner, 2 wherever it is valid
+  int wgrad_p8 = 1;         // same for the weight-gradient kernels
+};
+Options& options();
+
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -18,229 +18,12 @@
 // weights stream through a double-buffered LDS stage of WT taps.  fp32 MFMA is slow enough
 // (32 cycles / instruction / SIMD) that LDS bandwidth is not the limiter; the structure is chosen
 // so every wave issues MT*NT*4 back-to-back MFMAs per tap per (MT+NT) ds_read_b128.
-#include "common.h"
+#include "conv3_defs.h"
 #include "../../include/bcp_hip.h"
 #include <cstdlib>
 #include <cstdio>
-#include <type_traits>
 
 namespace bcp {
-
-#ifndef BCP_XS
-#define BCP_XS 20
-#endif
-static constexpr int XS = BCP_XS;  // LDS floats per halo voxel: 16 channels + 4 pad (16-B aligned rows)
-// halo row stride of the wgrad kernel (ds_read_b32, lane (li = channel, lg = voxel))
-static constexpr int XSW = 20;   // measured: 16 (conflict-free b32 reads) is 6 % SLOWER at C=16 -- LDS conflicts are not what bounds wgrad
-
-// Measurement-only ablation switches for tools/ablate_conv.py (what bounds k_conv3_res?); the product build has 0.
-//   1: no global halo prefetch   2: no epilogue stores / statistics   4: no LDS halo refill + barriers
-//   8: A fragments not re-read from LDS per tap   16: B fragments not re-read per tap   256: linear (not XCD-aware) tile order
-//   ws: 8192: MFMA waves do not re-read operands   16384: helper waves idle
-//   wgrad: 512: no global fetch   1024: no LDS refill + barriers   2048 / 4096: A / B operand address not advanced
-#ifndef BCP_ABLATE
-#define BCP_ABLATE 0
-#endif
-
-template <int KD, int TD, int TH, int TW>
-struct Tile {
-  static constexpr int M = TD * TH * TW;
-  static constexpr int MT = M / 64;
-  static constexpr int PD = (KD == 3) ? 1 : 0;
-  static constexpr int HD = TD + 2 * PD, HH = TH + 2, HW = TW + 2;
-  static constexpr int HV = HD * HH * HW;
-  static constexpr int T = KD * 9;
-  static_assert(M % 64 == 0, "tile must hold a multiple of 64 voxels");
-  __device__ static __forceinline__ int voff(int m) {  // halo-local voxel index of tile voxel m at tap (0,0,0)
-    const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-    return (td * HH + th) * HW + tw;
-  }
-  __device__ static __forceinline__ int tapoff(int tap) {
-    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
-    return (kd * HH + kh) * HW + kw;
-  }
-};
-
-struct ConvDims {
-  int N, D, H, W;
-  int Cin, Cout;        // real channel counts (row strides of X and Y)
-  int Cin16, Cout16;    // padded to multiples of 16 (packed-weight extents)
-  int tiles_d, tiles_h, tiles_w;
-};
-
-__device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, int TH, int TW, int& n, int& d0, int& h0,
-                                            int& w0) {
-  const int tw = bx % cd.tiles_w;
-  const int th = (bx / cd.tiles_w) % cd.tiles_h;
-  const int td = (bx / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d;
-  n = bx / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
-  d0 = td * TD;
-  h0 = th * TH;
-  w0 = tw * TW;
-}
-
-// Halo fetch with launch-invariant indexing.  A halo "row" is one (hd, hh) line of HW voxels = RW float4 columns; a
-// pass moves RPP rows with threads (r0, col).  A thread's column is fixed for the whole launch, so everything but the
-// tile origin is computed once: the per-pass global offsets grel[] and the LDS slot; per tile there is one uniform
-// 64-bit row-validity mask (SALU).  Per-tile vector work of a fetch: ~2 VALU per float4 (was ~25: div/mod of the flat
-// index + three range checks + 64-bit address arithmetic per element).
-template <class TL, int XSP = XS>
-struct HaloFetch {
-  static constexpr int RW = TL::HW * 4, RPP = 256 / RW, HR = TL::HD * TL::HH, NP = (HR + RPP - 1) / RPP;
-  static_assert(HR <= 128 && RW <= 256, "halo rows must fit the 128-bit validity mask");
-  int r0, hw, part;
-  bool act;
-  unsigned grel[NP];
-  float* lds;
-
-  __device__ __forceinline__ void init(const ConvDims& cd, float* Xs, int tid = -1) {
-    if (tid < 0) tid = threadIdx.x;      // 256 fetching threads; the wave-specialised kernel passes its helper-local id
-    r0 = tid / RW;
-    const int col = tid - r0 * RW;
-    hw = col >> 2;
-    part = col & 3;
-    act = tid < RPP * RW;
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      const int row = u * RPP + r0, hd = row / TL::HH, hh = row - hd * TL::HH;
-      grel[u] = (unsigned)(((hd * cd.H + hh) * cd.W + hw) * cd.Cin + part * 4);
-    }
-    lds = Xs + (r0 * TL::HW + hw) * XSP + part * 4;
-  }
-  __device__ __forceinline__ void stash_to(float* Xbuf, const float* Xbase, const float4 (&pre)[NP]) const {   // other halo buffer
-#pragma unroll
-    for (int u = 0; u < NP; ++u)
-      if (act && u * RPP + r0 < HR) st4(Xbuf + (lds - Xbase) + u * RPP * TL::HW * XSP, pre[u]);
-  }
-  // halo of the tile at (n, d0, h0, w0), cin chunk c -> registers; zero outside the volume / beyond Cin
-  __device__ __forceinline__ void fetch(const float* __restrict__ X, const ConvDims& cd, int n, int d0, int h0, int w0, int c,
-                                        float4 (&pre)[NP]) const {
-    // uniform: valid hh range, valid hd range -> one bit per halo row
-    const int hlo = (h0 >= 1) ? 0 : 1 - h0, hhi = (cd.H - h0 + 1 < TL::HH) ? cd.H - h0 + 1 : TL::HH;
-    const int dlo = (d0 >= TL::PD) ? 0 : TL::PD - d0, dhi = (cd.D - d0 + TL::PD < TL::HD) ? cd.D - d0 + TL::PD : TL::HD;
-    const unsigned mh = (hhi > hlo) ? (((1u << hhi) - 1u) & ~((1u << hlo) - 1u)) : 0u;
-    unsigned long long M0 = 0, M1 = 0;   // bit (hd * HH + hh), rows 0..63 / 64..127
-#pragma unroll
-    for (int hd = 0; hd < TL::HD; ++hd) {
-      constexpr int HHc = TL::HH;
-      const int pos = hd * HHc;
-      if (hd >= dlo && hd < dhi) {
-        if (pos < 64) M0 |= (unsigned long long)mh << pos;
-        if (pos < 64 && pos + HHc > 64) M1 |= (unsigned long long)mh >> (64 - pos);
-        if (pos >= 64) M1 |= (unsigned long long)mh << (pos - 64);
-      }
-    }
-    const bool col_ok = act && (unsigned)(w0 - 1 + hw) < (unsigned)cd.W && c * 16 + part * 4 < cd.Cin;
-    unsigned long long Mt0 = M0 >> r0, Mt1 = 0;
-    if (HR > 64) {
-      if (r0) Mt0 |= M1 << (64 - r0);
-      Mt1 = M1 >> r0;
-    }
-    if (!col_ok) { Mt0 = 0; Mt1 = 0; }
-    const float* xb = X + ((((long long)n * cd.D + (d0 - TL::PD)) * cd.H + (h0 - 1)) * cd.W + (w0 - 1)) * cd.Cin + c * 16;
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (((u * RPP < 64 ? Mt0 >> ((u * RPP) & 63) : Mt1 >> ((u * RPP - 64) & 63)) & 1ull)) v = ld4(xb + grel[u]);
-      pre[u] = v;
-    }
-  }
-  __device__ __forceinline__ void stash(const float4 (&pre)[NP]) const {
-#pragma unroll
-    for (int u = 0; u < NP; ++u)
-      if (act && u * RPP + r0 < HR) st4(lds + u * RPP * TL::HW * XSP, pre[u]);
-  }
-  // Branch-free flavour: every load is issued (rows outside the volume read the tile-independent safe address X) and the
-  // validity bits come back as a mask that the consumer applies when it finally touches the registers.  With `if (valid)
-  // v = load` the compiler may wait for each load at the merge point of its branch -- twelve serialised round trips per tile
-  // in a kernel that has no second workgroup on the CU to hide them (k_conv3_b6).
-  __device__ __forceinline__ unsigned fetch_nb(const float* __restrict__ X, const ConvDims& cd, int n, int d0, int h0, int w0, int c,
-                                               float4 (&pre)[NP]) const {
-    const int hlo = (h0 >= 1) ? 0 : 1 - h0, hhi = (cd.H - h0 + 1 < TL::HH) ? cd.H - h0 + 1 : TL::HH;
-    const int dlo = (d0 >= TL::PD) ? 0 : TL::PD - d0, dhi = (cd.D - d0 + TL::PD < TL::HD) ? cd.D - d0 + TL::PD : TL::HD;
-    const bool col_ok = act && (unsigned)(w0 - 1 + hw) < (unsigned)cd.W && c * 16 + part * 4 < cd.Cin;
-    const float* xb = X + ((((long long)n * cd.D + (d0 - TL::PD)) * cd.H + (h0 - 1)) * cd.W + (w0 - 1)) * cd.Cin + c * 16;
-    unsigned vmask = 0;
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      const int row = u * RPP + r0, hd = row / TL::HH, hh = row - hd * TL::HH;
-      const bool ok = col_ok && row < HR && hd >= dlo && hd < dhi && hh >= hlo && hh < hhi;
-      pre[u] = ld4(ok ? xb + grel[u] : X);
-      vmask |= (ok ? 1u : 0u) << u;
-    }
-    return vmask;
-  }
-};
-
-// Fused BatchNorm / InstanceNorm statistics: the conv epilogue already holds y = conv + bias in registers, so the
-// per-channel (sum, sum of squares) partials the norm needs are produced here instead of by a second pass over y
-// (csrc/norm.hip k_col_partial<0>).  partial[g][row][C][2] doubles, fp64 accumulation as in the standalone pass.
-//
-// Backward flavour (dgrad epilogue, yprev != nullptr): the conv output is da, the gradient w.r.t. the PREVIOUS layer's
-// activation a = act((y - mean) * scale + beta); the two sums its norm backward needs -- sum dz and sum dz * xhat with
-// dz = da * act'(z) -- are accumulated here from da (in registers) and y (one extra read in an MFMA-bound kernel), so
-// the standalone statistics pass over (y, da) (csrc/norm.hip k_col_partial<1>, the largest HBM pass on the step's
-// critical path) disappears.
-struct StatsArg {
-  double* partial;       // nullptr: disabled
-  int rows;              // rows per group (nb of the norm finalize)
-  int tiles_per_group;   // spatial tiles per normalisation group (tiles are sample-major)
-  int C;                 // channel count of the partial rows (= Cout)
-  const float* yprev;    // backward flavour: pre-norm output of the previous layer, same shape as this conv's output
-  const float* pstats;   // its norm statistics [mean | rstd | scale | shift][G][C]
-  int G, act;
-};
-
-struct BwdCtx { const float* yprev; const float* pstats; int act; };   // host side: backward-statistics request
-struct BwdCol { float mu, sc, sh, rs; };
-__device__ __forceinline__ BwdCol load_bwd_col(const StatsArg& st, int g, int c) {
-  BwdCol k{0.f, 1.f, 0.f, 1.f};
-  if (st.yprev && c < st.C) {
-    const long long gc = (long long)g * st.C + c, GC = (long long)st.G * st.C;
-    k.mu = st.pstats[gc]; k.rs = st.pstats[GC + gc]; k.sc = st.pstats[2 * GC + gc]; k.sh = st.pstats[3 * GC + gc];
-  }
-  return k;
-}
-// MODE 1: forward statistics of v;  MODE 2: backward statistics of da = v given y = yv
-template <int MODE>
-__device__ __forceinline__ void stat_add(double& s1, double& s2, float v, float yv, const BwdCol& k, int act) {
-  if (MODE == 1) {
-    s1 += (double)v;
-    s2 += (double)v * (double)v;
-  } else if (MODE == 2) {
-    const float z = (yv - k.mu) * k.sc + k.sh;
-    const float g1 = v * act_grad(z, act);
-    const float xh = (yv - k.mu) * k.rs;
-    s1 += (double)g1;
-    s2 += (double)g1 * (double)xh;
-  }
-}
-
-// block-wide sum over the 4 lg lane groups and the 4 waves, then one (s1, s2) pair per channel of the slab
-template <int NT>
-__device__ __forceinline__ void stats_flush(double (&s1)[NT], double (&s2)[NT], double* __restrict__ Ss /* [4][NT*16][2] */,
-                                            double* __restrict__ dst_row /* &partial[g][row][0][0] */, int cout0, int Cout) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    double a = s1[nt], b = s2[nt];
-    a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
-    b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
-    if (lg == 0) { Ss[(wave * NT * 16 + nt * 16 + li) * 2] = a; Ss[(wave * NT * 16 + nt * 16 + li) * 2 + 1] = b; }
-    s1[nt] = 0.0; s2[nt] = 0.0;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < NT * 16 && cout0 + (int)threadIdx.x < Cout) {
-    const int c = threadIdx.x;
-    double a = 0.0, b = 0.0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) { a += Ss[(w * NT * 16 + c) * 2]; b += Ss[(w * NT * 16 + c) * 2 + 1]; }
-    dst_row[(cout0 + c) * 2] = a;
-    dst_row[(cout0 + c) * 2 + 1] = b;
-  }
-  __syncthreads();
-}
 
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
@@ -320,12 +103,12 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
     __syncthreads();
     for (int cc = c_begin; cc < c_end; ++cc) {
       const bool has_next = cc + 1 < c_end;
-      if (has_next && !(BCP_ABLATE & 32768)) {     // (ablation 32768: every chunk reuses the first chunk's registers -- no global loads)
+      if (has_next) {
         hf.fetch(X, cd, n, d0, h0, w0, cc + 1, hpre);
         wfetch(cc + 1);
       }
 #pragma unroll (WT > 9 ? 9 : WT)
-      for (int tl = 0; tl < ((BCP_ABLATE & 65536) ? 1 : WT); ++tl) {    // (ablation 65536: one tap per chunk -- the load pipeline alone)
+      for (int tl = 0; tl < WT; ++tl) {
         const int toff = TL::tapoff(tl) * XS;
         float4 a[MT], b[NT];
 #pragma unroll
@@ -418,10 +201,6 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
   const bool full = (TW % 4 == 0) && cout0 + CT <= cd.Cout && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
-  const int sgrp = st.partial ? blockIdx.x / st.tiles_per_group : 0;
-  BwdCol kc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) kc[nt] = load_bwd_col(st, sgrp, cout0 + nt * 16 + li);
   const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
   auto rows = [&](auto mode_tag) {
     constexpr int MODE = decltype(mode_tag)::value;
@@ -443,7 +222,7 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
               if (bias) v += bias[co];
               if (accumulate) v += Y[ro + co];
               Y[ro + co] = v;
-              stat_add<MODE>(s1[nt], s2[nt], v, MODE == 2 ? st.yprev[ro + co] : 0.f, kc[nt], st.act);
+              stat_add<MODE>(s1[nt], s2[nt], v);
             }
           }
         }
@@ -451,8 +230,7 @@ __global__ __launch_bounds__(256) void k_conv3_mfma(const float* __restrict__ X,
     }
   };
   if (!st.partial) rows(std::integral_constant<int, 0>{});
-  else if (!st.yprev) rows(std::integral_constant<int, 1>{});
-  else rows(std::integral_constant<int, 2>{});
+  else rows(std::integral_constant<int, 1>{});
   if (st.partial) {
     const int g = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
     stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)g * st.rows + row) * st.C * 2, cout0, cd.Cout);
@@ -534,28 +312,19 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  unsigned vmask = ~0u;
   auto fetch = [&](int t, int c, float4 (&pre)[NP]) {
     int n2, d2, h2, w2;
     tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
-    if (BCP_ABLATE & 1048576) vmask = hf.fetch_nb(X, cd, n2, d2, h2, w2, c_begin + c, pre);   // (measurement: branch-free fetch)
-    else hf.fetch(X, cd, n2, d2, h2, w2, c_begin + c, pre);
+    hf.fetch(X, cd, n2, d2, h2, w2, c_begin + c, pre);
   };
-  auto stash = [&](const float4 (&pre)[NP]) {
-    if (BCP_ABLATE & 1048576) {
-      float4 q[NP];
-#pragma unroll
-      for (int u = 0; u < NP; ++u) q[u] = ((vmask >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-      hf.stash(q);
-    } else hf.stash(pre);
-  };
+  auto stash = [&](const float4 (&pre)[NP]) { hf.stash(pre); };
 
   // Work items of this block: (tile, chunk).  XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with
   // its own 4 MB L2), so workgroup b runs on XCD b % 8.  Each XCD owns ONE contiguous eighth of the (d-major) tile list and
   // its workgroups walk it side by side -- the tiles in flight on an XCD are spatial neighbours and their halo overlap
   // (2.5x over-read per tile) hits that XCD's L2 instead of going back to the fabric.
   int tile, t_end, t_step;
-  if (gridDim.x % 8 == 0 && !(BCP_ABLATE & 256)) {
+  if (gridDim.x % 8 == 0) {
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     t_step = gridDim.x >> 3;
     tile = (int)((long long)n_tiles * xcd / 8) + j;
@@ -578,9 +347,6 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
   int cur_g = st.partial ? tile / st.tiles_per_group : 0;
-  BwdCol kc[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) kc[nt] = load_bwd_col(st, cur_g, cout0 + nt * 16 + li);
   {
     float4 pre[NP];
     fetch(tile, 0, pre);     // first halo in flight while the weights below are fetched: one exposed round trip, not two
@@ -616,11 +382,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
     if (nchk == nch) { nchk = 0; ntile = tile + t_step; }
     const bool has_next = ntile < t_end;
     float4 pre[NP];
-    if (BCP_ABLATE & 1) {
-#pragma unroll
-      for (int u = 0; u < NP; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (has_next && !(BCP_ABLATE & 1)) fetch(ntile, nchk, pre);
+    if (has_next) fetch(ntile, nchk, pre);
     // MFMAs of the current item
     const float* Wc = Ws + (size_t)ch * T * 4 * CT * 4;
     // partial unroll: a full 27-tap unroll makes hipcc split the ds_read_b128 fragments into read2_b32/b64 pairs
@@ -629,9 +391,9 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
       const int toff = TL::tapoff(tap) * XS;
       float4 a[MT], b[NT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + ((BCP_ABLATE & 8) ? 0 : toff));
+      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xs + voff[mt] + toff);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wc + ((((BCP_ABLATE & 16) ? 0 : tap) * 4 + lg) * CT + nt * 16 + li) * 4);
+      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wc + ((tap * 4 + lg) * CT + nt * 16 + li) * 4);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -642,22 +404,12 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
           acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
         }
     }
-    if ((BCP_ABLATE & 2) && ch == nch - 1) {   // keep the accumulators alive without the epilogue's address math / stores
-      float t = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) t += acc[0][mt][nt][0] + acc[0][mt][nt][1] + acc[0][mt][nt][2] + acc[0][mt][nt][3];
-      if (t == 1.2345e-30f) Y[threadIdx.x] = t;
-    } else
     if (ch == nch - 1) {
       int n, d0, h0, w0;
       tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
       if (st.partial && tile / st.tiles_per_group != cur_g) {   // tiles are visited in increasing order: groups never come back
         stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
         cur_g = tile / st.tiles_per_group;
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) kc[nt] = load_bwd_col(st, cur_g, cout0 + nt * 16 + li);
       }
       const bool full = ROWS4 && slab_full && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
       const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
@@ -666,16 +418,6 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
         if (full) {
           // whole tile inside the volume: uniform base + launch-invariant lane offsets, no index math per row
           float* yb = Y + tile_base + cout0;
-          const float* ypb = (MODE == 2) ? st.yprev + tile_base + cout0 : nullptr;
-          float yv[MT][4][NT];
-          if (MODE == 2) {   // all y loads of the tile up front: one latency, not sixteen
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) yv[mt][r][nt] = ypb[r * cd.Cout + yoff[mt] + nt * 16];
-          }
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -688,7 +430,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
                 v += bv[nt];
                 if (accumulate) v += p[nt * 16];
                 p[nt * 16] = v;
-                stat_add<MODE>(s1[nt], s2[nt], v, MODE == 2 ? yv[mt][r][nt] : 0.f, kc[nt], st.act);
+                stat_add<MODE>(s1[nt], s2[nt], v);
               }
             }
         } else {
@@ -710,7 +452,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
                     v += bv[nt];
                     if (accumulate) v += Y[ro + co];
                     Y[ro + co] = v;
-                    stat_add<MODE>(s1[nt], s2[nt], v, MODE == 2 ? st.yprev[ro + co] : 0.f, kc[nt], st.act);
+                    stat_add<MODE>(s1[nt], s2[nt], v);
                   }
                 }
               }
@@ -719,8 +461,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
         }
       };
       if (!st.partial) rows(std::integral_constant<int, 0>{});
-      else if (!st.yprev) rows(std::integral_constant<int, 1>{});
-      else rows(std::integral_constant<int, 2>{});
+      else rows(std::integral_constant<int, 1>{});
 #pragma unroll
       for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -732,489 +473,11 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
       if (st.partial) stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
       break;
     }
-    if (!(BCP_ABLATE & 4)) {
-      __syncthreads();   // every wave is done reading the halo buffer
-      stash(pre);
-      __syncthreads();
-    }
+    __syncthreads();   // every wave is done reading the halo buffer
+    stash(pre);
+    __syncthreads();
     tile = ntile;
     ch = nchk;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward / dgrad of the 16 -> 16 layers, "three-piece" variant (EXPERIMENTAL, BCP_CONV3_B6=1): the fp32
-// operands are split into three bf16 pieces each (8 + 8 + 8 mantissa bits: x = p0 + p1 + p2 up to ~2^-26 |x|) when they
-// enter the LDS, and the tap loop runs on the bf16 matrix pipe -- six v_mfma_f32_16x16x32_bf16 products per K = 32 block
-// (a0b0, a0b1, a1b0, a0b2, a1b1, a2b0; the dropped cross terms are below 2^-24 of the product), fp32 accumulation inside
-// the matrix core.  One MFMA covers TWO taps x 16 input channels; an odd tap count is padded with a zero-weight tap.
-// Everything around the tap loop (persistent workgroups, XCD-aware tile order, register-prefetched halo, fused statistics
-// epilogue) is k_conv3_res.  Measured tap loop in isolation (tools/probe/mfma_bf16split_probe.hip): 209-215 fp32-equivalent
-// TFLOP/s against 123-134 for the 16x16x4_f32 loop.
-// ------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int XSB = 24;   // bf16 elements per halo voxel row: 16 channels + 8 pad (48 B: conflict-free 16-B fragment reads)
-
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
-  unsigned u = __float_as_uint(x);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
-// x -> three bf16 pieces, largest first
-__device__ __forceinline__ void split3(float x, unsigned short (&p)[3]) {
-  p[0] = f32_to_bf16_rne(x);
-  float r = x - bf16_to_f32(p[0]);
-  p[1] = f32_to_bf16_rne(r);
-  r -= bf16_to_f32(p[1]);
-  p[2] = f32_to_bf16_rne(r);
-}
-// four consecutive channels of one voxel / weight row -> the three piece planes (8-byte stores)
-__device__ __forceinline__ void split_store4(const float4& v, unsigned short* base, int plane_stride) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-  unsigned short q[4][3];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) split3(x[k], q[k]);
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    uint2 w;
-    w.x = (unsigned)q[0][s] | ((unsigned)q[1][s] << 16);
-    w.y = (unsigned)q[2][s] | ((unsigned)q[3][s] << 16);
-    *reinterpret_cast<uint2*>(base + (size_t)s * plane_stride) = w;
-  }
-}
-
-template <int KD, int TD, int TH, int TW>
-__global__ __launch_bounds__(256) void k_conv3_b6(const float* __restrict__ X, const float* __restrict__ Wp,
-                                                  const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd,
-                                                  int n_tiles, int accumulate, StatsArg st) {
-  using TL = Tile<KD, TD, TH, TW>;
-  constexpr int MT = TL::MT, T = TL::T, TP = (T + 1) / 2, CT = 16, NT = 1;
-  using HF = HaloFetch<TL>;
-  constexpr int NP = HF::NP;
-  constexpr bool ROWS4 = (TW % 4 == 0);
-  constexpr int WPLANE = TP * 16 * 32, XPLANE = TL::HV * XSB;     // bf16 elements per piece plane
-
-  HIP_DYNAMIC_SHARED(float4, smem4)
-  unsigned short* Wb = reinterpret_cast<unsigned short*>(smem4);   // [3][TP][16 cout][32 k]: k = (tap & 1) * 16 + cin
-  unsigned short* Xb = Wb + 3 * WPLANE;                            // [3][HV][XSB]
-  double* Ss = reinterpret_cast<double*>(Xb + 3 * XPLANE);         // [4][CT][2] statistics scratch (3 * XPLANE * 2 B is a multiple of 16)
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int cout0 = 0;
-  const int cin4 = cd.Cin16 >> 2;
-
-  int voff[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XSB + (lg & 1) * 8;
-
-  HF hf;
-  hf.init(cd, reinterpret_cast<float*>(smem4));      // (its LDS slot pointer is not used: the stash below writes the bf16 planes)
-
-  unsigned yoff[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int m0 = (wave * MT + mt) * 16 + lg * 4;
-    const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
-    yoff[mt] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + li);
-  }
-  float bv[NT];
-  bv[0] = (bias && li < cd.Cout) ? bias[li] : 0.f;
-  const bool slab_full = CT <= cd.Cout;
-
-  f32x4 acc[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  unsigned vmask = 0;                                // validity bits of the prefetched halo rows (fetch_nb)
-  auto fetch = [&](int t, float4 (&pre)[NP]) {
-    int n2, d2, h2, w2;
-    tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
-    // (3-D: one workgroup per CU, nothing else hides a serialised load chain: 316 -> 254 us.  The 2-D tile has two workgroups per CU
-    // and is faster with the branchy fetch, which skips rows outside the volume: 39 vs 53 us)
-    if (KD == 3) vmask = hf.fetch_nb(X, cd, n2, d2, h2, w2, 0, pre);
-    else { hf.fetch(X, cd, n2, d2, h2, w2, 0, pre); vmask = ~0u; }
-  };
-  auto stash = [&](const float4 (&pre)[NP]) {
-#pragma unroll
-    for (int u = 0; u < NP; ++u)
-      if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
-        const float4 v = ((vmask >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
-      }
-  };
-
-  int tile, t_end, t_step;
-  if (gridDim.x % 8 == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    t_step = gridDim.x >> 3;
-    tile = (int)((long long)n_tiles * xcd / 8) + j;
-    t_end = (int)((long long)n_tiles * (xcd + 1) / 8);
-  } else {
-    tile = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
-  }
-  if (st.partial && (int)threadIdx.x < CT && (int)threadIdx.x < cd.Cout) {
-    for (int g = 0; g < st.G; ++g) {
-      double* z = st.partial + (((long long)g * st.rows + blockIdx.x) * st.C + threadIdx.x) * 2;
-      z[0] = 0.0; z[1] = 0.0;
-    }
-  }
-  if (tile >= t_end) return;
-  double s1[NT], s2[NT];
-  s1[0] = 0.0; s2[0] = 0.0;
-  int cur_g = st.partial ? tile / st.tiles_per_group : 0;
-  BwdCol kc[NT];
-  kc[0] = load_bwd_col(st, cur_g, li);
-  {
-    float4 pre[NP];
-    fetch(tile, pre);
-    // resident weights: Wp[tap][cin4][Cout16][4] (fp32 pack) -> three bf16 planes Wb[piece][tap / 2][cout][(tap & 1) * 16 + cin]
-    for (int q = threadIdx.x; q < T * 4 * CT; q += 256) {
-      const int co = q % CT, cig = (q / CT) & 3, tap = q / (4 * CT);
-      const float4 wv = ld4(Wp + ((((long long)tap * cin4 + cig) * cd.Cout16) + cout0 + co) * 4);
-      split_store4(wv, Wb + ((tap >> 1) * 16 + co) * 32 + (tap & 1) * 16 + cig * 4, WPLANE);
-    }
-    if (T & 1) {   // zero-weight pad tap: second half of the last pair
-      for (int q = threadIdx.x; q < 3 * 16 * 4; q += 256) {
-        const int s = q / 64, co = (q / 4) % 16, c4 = q % 4;
-        uint2 z;
-        z.x = 0u; z.y = 0u;
-        *reinterpret_cast<uint2*>(Wb + (size_t)s * WPLANE + ((TP - 1) * 16 + co) * 32 + 16 + c4 * 4) = z;
-      }
-    }
-    stash(pre);
-  }
-  __syncthreads();
-  for (;;) {
-    const int ntile = tile + t_step;
-    const bool has_next = ntile < t_end;
-    float4 pre[NP];
-    // The tap loop keeps ~120 operand registers in flight; with the next halo's 48 prefetch registers live across ALL of it the
-    // compiler parks them in AGPRs right after the loads -- a vmcnt(0) wait at the top of every tile (measured: 169 of 323 us).
-    // So the prefetch is issued with LATE pairs still to go: enough MFMA time (~0.6 us per pair) to cover the round trip, and the
-    // registers are live only there.
-    constexpr int LATE = TP > 6 ? 6 : TP - 1;
-    auto pairs = [&](int tp0, int tp1) {
-#pragma unroll 2
-      for (int tp = tp0; tp < tp1; ++tp) {
-        // lanes 0-31 (k 0..15) carry tap 2*tp, lanes 32-63 (k 16..31) tap 2*tp+1 (the pad tap reads tap T-1's voxels against zero weights)
-        const int tA = TL::tapoff(2 * tp), tB = TL::tapoff(2 * tp + 1 < T ? 2 * tp + 1 : T - 1);
-        const int toff = ((lg >> 1) ? tB : tA) * XSB;
-        bf16x8 a[MT][3], b[3];
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
-          b[s] = *reinterpret_cast<const bf16x8*>(Wb + s * WPLANE + (tp * 16 + li) * 32 + lg * 8);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[0], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[1], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[0], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][0], b[2], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][1], b[1], acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][2], b[0], acc[mt], 0, 0, 0);
-        }
-      }
-    };
-    pairs(0, TP - LATE);
-    if (BCP_ABLATE & 524288) {            // (ablation bits 131072 / 262144 / 524288: no epilogue / no refill / no global prefetch)
-#pragma unroll
-      for (int u = 0; u < NP; ++u) pre[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      vmask = 0;
-    } else if (has_next) fetch(ntile, pre);
-    pairs(TP - LATE, TP);
-    if (BCP_ABLATE & 131072) {
-      float t = 0.f;
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) t += acc[mt][0] + acc[mt][1] + acc[mt][2] + acc[mt][3];
-      if (t == 1.2345e-30f) Y[threadIdx.x] = t;
-    } else {
-      int n, d0, h0, w0;
-      tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
-      if (st.partial && tile / st.tiles_per_group != cur_g) {
-        stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
-        cur_g = tile / st.tiles_per_group;
-        kc[0] = load_bwd_col(st, cur_g, li);
-      }
-      const bool full = ROWS4 && slab_full && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
-      const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
-      auto rows = [&](auto mode_tag) {
-        constexpr int MODE = decltype(mode_tag)::value;
-        if (full) {
-          float* yb = Y + tile_base;
-          const float* ypb = (MODE == 2) ? st.yprev + tile_base : nullptr;
-          float yv[MT][4];
-          if (MODE == 2) {
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) yv[mt][r] = ypb[r * cd.Cout + yoff[mt]];
-          }
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* p = yb + r * cd.Cout + yoff[mt];
-              float v = acc[mt][r] + bv[0];
-              if (accumulate) v += p[0];
-              p[0] = v;
-              stat_add<MODE>(s1[0], s2[0], v, MODE == 2 ? yv[mt][r] : 0.f, kc[0], st.act);
-            }
-        } else {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int m = (wave * MT + mt) * 16 + lg * 4 + r;
-              const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-              const int d = d0 + td, h = h0 + th, w = w0 + tw;
-              if (d < cd.D && h < cd.H && w < cd.W && li < cd.Cout) {
-                const long long ro = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);
-                float v = acc[mt][r] + bv[0];
-                if (accumulate) v += Y[ro + li];
-                Y[ro + li] = v;
-                stat_add<MODE>(s1[0], s2[0], v, MODE == 2 ? st.yprev[ro + li] : 0.f, kc[0], st.act);
-              }
-            }
-          }
-        }
-      };
-      if (!st.partial) rows(std::integral_constant<int, 0>{});
-      else if (!st.yprev) rows(std::integral_constant<int, 1>{});
-      else rows(std::integral_constant<int, 2>{});
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    if (!has_next) {
-      if (st.partial) stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
-      break;
-    }
-    if (!(BCP_ABLATE & 262144)) {
-      __syncthreads();   // every wave is done reading the halo planes
-      stash(pre);
-      __syncthreads();
-    }
-    tile = ntile;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward / dgrad, WAVE-SPECIALISED resident variant (full tiles only).  Workgroup = 8 waves: waves 0-3 do nothing but
-// ds_read + MFMA on the current halo buffer; waves 4-7 ("helpers") do everything else underneath them -- fetch the next
-// work item's halo (global -> registers -> the OTHER LDS halo buffer) and write the previous tile's output (accumulators
-// handed over through an LDS staging tile, stored as 16-B-per-lane coalesced rows, bias / += / norm statistics applied
-// there).  In k_conv3_res the same four waves alternate between these phases and the phases of the two co-resident
-// workgroups do not hide under each other (measured: 2 vs 1 workgroup per CU = 6 %); here the matrix pipe of every SIMD has
-// one wave that never leaves the tap loop except for two barriers and 16 ds_writes per tile.
-// LDS: weights + 2 halo buffers + staging (152 KB for 16->16 with 4x4x16 tiles, 123 KB for 32->32 with 4x4x8): one
-// workgroup per CU.
-// ------------------------------------------------------------------------------------------------
-template <int KD, int TD, int TH, int TW, int NT>
-__global__ __launch_bounds__(512) void k_conv3_ws(const float* __restrict__ X, const float* __restrict__ Wp,
-                                                  const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd, int n_tiles,
-                                                  int accumulate, StatsArg st) {
-  using TL = Tile<KD, TD, TH, TW>;
-  using HF = HaloFetch<TL>;
-  constexpr int MT = TL::MT, T = TL::T, CT = NT * 16, M = TL::M, NP = HF::NP;
-  constexpr int SS = CT + 4;                         // staging row stride (floats): 16-B aligned rows, 2-way conflicts at most
-  constexpr int C4 = CT / 4;                         // float4 columns of an output row
-  constexpr int NQ = (M * C4) / 256;                 // output float4s per helper thread
-  constexpr int NACC = (MT * NT == 1) ? 2 : 1;
-  static_assert((M * C4) % 256 == 0 && 256 % C4 == 0, "helper epilogue mapping");
-
-  HIP_DYNAMIC_SHARED(float4, smem4)
-  float* smem = reinterpret_cast<float*>(smem4);
-  const int nch = cd.Cin16 >> 4;
-  float* Ws = smem;                                              // [nch][T][4][CT][4]
-  float* Xs0 = smem + (size_t)nch * T * 4 * CT * 4;              // [2][HV][XS]
-  float* Stg = Xs0 + 2 * TL::HV * XS;                            // [M][SS]
-
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int li = lane & 15, lg = lane >> 4;
-  const bool mma = wave < 4;
-  const int htid = tid - 256;
-  const int cout0 = blockIdx.y * CT;
-  const int cin4 = cd.Cin16 >> 2;
-
-  for (int q = tid; q < nch * T * 4 * CT; q += 512) {
-    const int co = q % CT, cig = (q / CT) & 3, tap = (q / (4 * CT)) % T, ch = q / (4 * CT * T);
-    st4(Ws + (size_t)q * 4, ld4(Wp + ((((long long)tap * cin4 + ch * 4 + cig) * cd.Cout16) + cout0 + co) * 4));
-  }
-
-  // ---- work list (same XCD-aware order as k_conv3_res)
-  int tile, t_end, t_step;
-  if (gridDim.x % 8 == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    t_step = gridDim.x >> 3;
-    tile = (int)((long long)n_tiles * xcd / 8) + j;
-    t_end = (int)((long long)n_tiles * (xcd + 1) / 8);
-  } else {
-    tile = blockIdx.x; t_end = n_tiles; t_step = gridDim.x;
-  }
-  if (tile >= t_end) return;
-
-  // ---- role state
-  int voff[MT];
-  f32x4 acc[NACC][MT][NT];
-  HF hf;
-  unsigned yoffh[NQ];
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-  if (mma) {
-    __builtin_amdgcn_s_setprio(3);   // the issue arbiter prefers the MFMA wave of a SIMD over its helper wave
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + li) * XS + lg * 4;
-#pragma unroll
-    for (int a = 0; a < NACC; ++a)
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  } else {
-    hf.init(cd, Xs0, htid);
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int q = htid + u * 256, m = q / C4, c4 = q % C4;
-      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-      yoffh[u] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + c4 * 4);
-    }
-    if (bias) bv = ld4(bias + cout0 + (htid % C4) * 4);
-  }
-
-  auto fetch = [&](int t, int c, float4 (&pre)[NP]) {
-    int n2, d2, h2, w2;
-    tile_origin(cd, t, TD, TH, TW, n2, d2, h2, w2);
-    hf.fetch(X, cd, n2, d2, h2, w2, c, pre);
-  };
-  // helper: write the staged tile `t` to global memory (full tiles only: uniform base + launch-invariant offsets)
-  int cur_g = st.partial ? tile / st.tiles_per_group : 0;
-  auto flush_stats = [&](int g) {          // one partial row per helper WAVE: rows = 4 * gridDim.x per group
-    double v[8] = {s1[0], s1[1], s1[2], s1[3], s2[0], s2[1], s2[2], s2[3]};
-    for (int off = C4; off < 64; off <<= 1) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) v[k] += __shfl_xor(v[k], off);
-    }
-    if (lane < C4) {
-      double* dst = st.partial + (((long long)g * st.rows + blockIdx.x * 4 + (wave - 4)) * st.C + cout0 + lane * 4) * 2;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { dst[k * 2] = v[k]; dst[k * 2 + 1] = v[4 + k]; }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { s1[k] = 0.0; s2[k] = 0.0; }
-  };
-  auto store_tile = [&](int t) {
-    int n, d0, h0, w0;
-    tile_origin(cd, t, TD, TH, TW, n, d0, h0, w0);
-    if (st.partial && t / st.tiles_per_group != cur_g) { flush_stats(cur_g); cur_g = t / st.tiles_per_group; }
-    float* yb = Y + ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout + cout0;
-#pragma unroll
-    for (int u = 0; u < NQ; ++u) {
-      const int q = htid + u * 256;
-      float4 v = ld4(Stg + (q / C4) * SS + (q % C4) * 4);
-      v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-      float* p = yb + yoffh[u];
-      if (accumulate) { const float4 o = ld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-      st4(p, v);
-      if (st.partial) {
-        s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x; s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
-        s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z; s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
-      }
-    }
-  };
-
-  // ---- prologue: first halo into buffer 0, second one in flight
-  int ch = 0, buf = 0;
-  float4 pre[NP];
-  if (!mma) {
-    fetch(tile, 0, pre);
-    hf.stash_to(Xs0, Xs0, pre);
-  }
-  __syncthreads();
-  int ntile = tile, nchk = 1;
-  if (nchk == nch) { nchk = 0; ntile = tile + t_step; }
-  bool has_next = ntile < t_end;
-  if (!mma && has_next) fetch(ntile, nchk, pre);
-  int staged_tile = -1;                    // tile whose accumulators sit in the staging buffer (uniform)
-
-  for (;;) {
-    if (mma) {
-      const float* Xc = Xs0 + buf * TL::HV * XS;
-      const float* Wc = Ws + (size_t)ch * T * 4 * CT * 4;
-      // the only MFMA wave of its SIMD: the next tap's fragments are read BEFORE this tap's MFMAs are issued, so the LDS
-      // round trip sits under 16 MFMAs instead of in front of them (sched_barrier keeps hipcc from sinking the reads)
-      float4 a[MT], b[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) a[mt] = ld4(Xc + voff[mt] + TL::tapoff(0) * XS);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wc + (lg * CT + nt * 16 + li) * 4);
-#pragma unroll 9
-      for (int tap = 0; tap < T; ++tap) {
-        float4 an[MT], bn[NT];
-        if (tap + 1 < T) {
-          const int toff = TL::tapoff(tap + 1) * XS;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) an[mt] = (BCP_ABLATE & 8192) ? a[mt] : ld4(Xc + voff[mt] + toff);
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) bn[nt] = (BCP_ABLATE & 8192) ? b[nt] : ld4(Wc + (((tap + 1) * 4 + lg) * CT + nt * 16 + li) * 4);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
-            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
-            acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
-            acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
-          }
-        __builtin_amdgcn_sched_barrier(0);
-        if (tap + 1 < T) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt] = an[mt];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) b[nt] = bn[nt];
-        }
-      }
-    } else if (!(BCP_ABLATE & 16384)) {
-      if (staged_tile >= 0) store_tile(staged_tile);             // previous tile's output, underneath the MFMAs above
-      if (has_next) {
-        hf.stash_to(Xs0 + (buf ^ 1) * TL::HV * XS, Xs0, pre);    // next item's halo -> the other buffer
-        int t2 = ntile, c2 = nchk + 1;
-        if (c2 == nch) { c2 = 0; t2 = ntile + t_step; }
-        if (t2 < t_end) fetch(t2, c2, pre);                      // the item after that: in flight for a whole item
-      }
-    }
-    BCP_LDS_BARRIER();   // B2: helpers are done with the staging tile; the other halo buffer is filled (their global loads stay in flight)
-    const bool tile_done = ch == nch - 1;
-    if (mma && tile_done) {
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float v = acc[0][mt][nt][r];
-            if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
-            Stg[((wave * MT + mt) * 16 + lg * 4 + r) * SS + nt * 16 + li] = v;
-          }
-#pragma unroll
-          for (int a = 0; a < NACC; ++a) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-    }
-    staged_tile = tile_done ? tile : -1;
-    BCP_LDS_BARRIER();   // B1: staging visible to the helpers; everyone switches halo buffers
-    if (!has_next) break;
-    tile = ntile; ch = nchk; buf ^= 1;
-    nchk = ch + 1; ntile = tile;
-    if (nchk == nch) { nchk = 0; ntile = tile + t_step; }
-    has_next = ntile < t_end;
-  }
-  if (!mma) {
-    if (staged_tile >= 0) store_tile(staged_tile);
-    if (st.partial) flush_stats(cur_g);
   }
 }
 
@@ -1326,7 +589,7 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
   __syncthreads();
   for (;;) {
     const bool has_next = tile + 1 < t_end;
-    if (has_next && !(BCP_ABLATE & 512)) fetch(tile + 1);           // loads stay in flight under the MFMAs below
+    if (has_next) fetch(tile + 1);           // loads stay in flight under the MFMAs below
 #pragma unroll 1
     for (int row = 0; row < M / TW; ++row) {
       const int th = row % TH, td = row / TH;
@@ -1336,23 +599,21 @@ __global__ __launch_bounds__(256) void k_conv3_wgrad(const float* __restrict__ X
         const int m0 = row * TW + kw * 4;
         float b[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[((BCP_ABLATE & 4096) ? 0 : m0 * YS) + yoff + nt * 16];
+        for (int nt = 0; nt < NT; ++nt) b[nt] = Ys[m0 * YS + yoff + nt * 16];
         // no per-tap guard here: a wave whose last tap slot is past T (27 = 4*7 - 1) recomputes tap 0 into an accumulator
         // that is never stored -- 1/28 wasted MFMAs instead of predicated MFMAs and accumulator shuffles
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-          const float a = Xs[((BCP_ABLATE & 2048) ? 0 : xrow + kw * 4 * XSW) + xoff[t]];
+          const float a = Xs[xrow + kw * 4 * XSW + xoff[t]];
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b[nt], acc[t][nt], 0, 0, 0);
         }
       }
     }
     if (!has_next) break;
-    if (!(BCP_ABLATE & 1024)) {
-      __syncthreads();
-      stash();
-      __syncthreads();
-    }
+    __syncthreads();
+    stash();
+    __syncthreads();
     ++tile;
   }
   // partial[grp][tap][ci][co]: lane (li, lg) holds ci = lg*4 + r (rows), co = li (cols)
@@ -1677,10 +938,10 @@ __global__ __launch_bounds__(256) void k_conv3_c1_wgrad(const float* __restrict_
 // ------------------------------------------------------------------------------------------------
 // host-side dispatch
 // ------------------------------------------------------------------------------------------------
-struct Cfg { int KD, TD, TH, TW, NT, WT; };
 
 static int split_k(long long blocks, int nch) {   // deep levels: too few tiles to fill 256 CUs -> split the cin chunks
-  if (const char* e = getenv("BCP_SPLITK")) { const int v = atoi(e); if (v >= 1 && v <= 4 && v <= nch) return v; }   // measurements
+  const int f = options().splitk;
+  if (f >= 1 && f <= 4 && f <= nch) return f;
   if (blocks > 256 || nch < 4) return 1;
   int sk = nch / 2;
   if (sk > 4) sk = 4;
@@ -1689,7 +950,7 @@ static int split_k(long long blocks, int nch) {   // deep levels: too few tiles 
 
 template <int KD, int TD, int TH, int TW, int NT, int WT>
 static int launch_fwd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
-                      double* stat_partial, int G, BwdCtx bw, bool dry, hipStream_t s) {
+                      double* stat_partial, int G, bool dry, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int S = TL::T / WT, NBUF = S > 1 ? 2 : 1;
   const size_t lds = (size_t)(TL::HV * XS + NBUF * WT * 4 * NT * 16 * 4) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
@@ -1698,17 +959,14 @@ static int launch_fwd(const float* X, const float* Wp, const float* bias, float*
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / (NT * 16);
   const int sk = ws ? split_k((long long)gx * gy, cd.Cin16 / 16) : 1;
-  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
-  if (sk == 1 && G > 0 && gx % G == 0) {
-    st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial;
-    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;
-  }
+  StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
+  if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
   if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
   if (sk == 1) {
     hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);
   } else {
     const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
-    StatsArg none{nullptr, 0, 1, cd.Cout, nullptr, nullptr, 1, 0};
+    StatsArg none{nullptr, 0, 1, cd.Cout, 1};
     hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, 0, none);
     hipLaunchKernelGGL(k_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y, accumulate);
   }
@@ -1717,92 +975,29 @@ static int launch_fwd(const float* X, const float* Wp, const float* bias, float*
 
 template <int KD, int TD, int TH, int TW, int NT>
 static int launch_res(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate,
-                      double* stat_partial, int G, BwdCtx bw, bool dry, hipStream_t s, int csplit = 1, float* ws = nullptr) {
+                      double* stat_partial, int G, bool dry, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
-  const int nch = cdiv(cd.Cin16 / 16, csplit);          // resident chunks per workgroup
+  const int nch = cd.Cin16 / 16;                        // resident chunks per workgroup
   const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + (size_t)TL::HV * XS) * sizeof(float) + 4 * NT * 16 * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
   const int slabs = cd.Cout16 / (NT * 16);
   const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
-  int P = (256 * (per_cu > 3 ? 3 : per_cu)) / (slabs * csplit);   // persistent workgroups per (slab, chunk group)
-  if (csplit == 1 && per_cu > 2) P = 512 / slabs;
-  if (const char* e = getenv("BCP_RES_PCU")) {   // measurements: persistent workgroups per CU (1..4, as far as the LDS allows)
-    const int v = atoi(e);
-    if (csplit == 1 && v >= 1 && v <= 4 && v <= per_cu) P = 256 * v / slabs;
-  }
-  if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
+  int P = (256 * (per_cu > 3 ? 3 : per_cu)) / slabs;    // persistent workgroups per slab
+  if (per_cu > 2) P = 512 / slabs;
+  const Options& o = options();
+  if (o.res_pcu >= 1 && o.res_pcu <= 4 && o.res_pcu <= per_cu) P = 256 * o.res_pcu / slabs;
+  if (o.conv3_p > 0 && o.conv3_p < P) P = o.conv3_p;    // tests: force multi-tile loops
   if (P < 1) P = 1;
   if (P > tiles) P = tiles;
-  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
-  const bool stats_ok = G > 0 && tiles % G == 0 && csplit == 1;
+  StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
+  const bool stats_ok = G > 0 && tiles % G == 0;
   if (dry) return stats_ok ? P : 0;
-  if (stats_ok && stat_partial) {
-    st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G;
-    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;   // (rows of unvisited groups are zeroed by the kernel itself)
-  }
+  if (stats_ok && stat_partial) { st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G; }   // (rows of unvisited groups are zeroed by the kernel itself)
   auto kfn = k_conv3_res<KD, TD, TH, TW, NT>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (csplit == 1) {
-    hipLaunchKernelGGL(kfn, dim3(P, slabs, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st, 1);
-  } else {
-    const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
-    hipLaunchKernelGGL(kfn, dim3(P, slabs, csplit), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, tiles, 0, st, csplit);
-    hipLaunchKernelGGL(k_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, csplit, n, cd.Cout, bias, Y, accumulate);
-  }
+  hipLaunchKernelGGL(kfn, dim3(P, slabs, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st, 1);
   return st.partial ? P : 0;
-}
-
-// three-piece bf16 variant of the 16 -> 16 resident conv (k_conv3_b6): one persistent workgroup per CU (137 KB of LDS in 3-D)
-template <int KD, int TD, int TH, int TW>
-static int launch_b6(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, double* stat_partial,
-                     int G, BwdCtx bw, bool dry, hipStream_t s) {
-  using TL = Tile<KD, TD, TH, TW>;
-  constexpr int TP = (TL::T + 1) / 2;
-  const size_t lds = (size_t)(3 * TP * 16 * 32 + 3 * TL::HV * XSB) * sizeof(unsigned short) + 4 * 16 * 2 * sizeof(double);
-  cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
-  const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
-  const int per_cu = (int)((160 * 1024) / lds) < 1 ? 1 : (int)((160 * 1024) / lds);
-  int P = 256 * (per_cu > 2 ? 2 : per_cu);
-  if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }  // tests: force multi-tile loops
-  if (P > tiles) P = tiles;
-  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
-  const bool stats_ok = G > 0 && tiles % G == 0;
-  if (dry) return stats_ok ? P : 0;
-  if (stats_ok && stat_partial) {
-    st.partial = stat_partial; st.rows = P; st.tiles_per_group = tiles / G;
-    st.yprev = bw.yprev; st.pstats = bw.pstats; st.act = bw.act;
-  }
-  auto kfn = k_conv3_b6<KD, TD, TH, TW>;
-  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(P, 1, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st);
-  return st.partial ? P : 0;
-}
-
-template <int KD, int TD, int TH, int TW, int NT>
-static int launch_ws(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate,
-                     double* stat_partial, int G, bool dry, hipStream_t s) {
-  using TL = Tile<KD, TD, TH, TW>;
-  const int nch = cd.Cin16 / 16;
-  const size_t lds = ((size_t)nch * TL::T * 4 * NT * 16 * 4 + 2 * (size_t)TL::HV * XS + (size_t)TL::M * (NT * 16 + 4)) * sizeof(float);
-  cd.tiles_d = cd.D / TD; cd.tiles_h = cd.H / TH; cd.tiles_w = cd.W / TW;      // full tiles only (checked by choose_ws)
-  const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
-  const int slabs = cd.Cout16 / (NT * 16);
-  int P = 256 / slabs;                                                          // one 8-wave workgroup per CU
-  if (const char* e = getenv("BCP_CONV3_P")) { const int v = atoi(e); if (v > 0 && v < P) P = v; }
-  if (P < 1) P = 1;
-  if (P > tiles) P = tiles;
-  StatsArg st{nullptr, 0, 1, cd.Cout, nullptr, nullptr, G > 0 ? G : 1, 0};
-  const bool stats_ok = G > 0 && tiles % G == 0;
-  if (dry) return stats_ok ? 4 * P : 0;
-  if (stats_ok && stat_partial) {
-    st.partial = stat_partial; st.rows = 4 * P; st.tiles_per_group = tiles / G;   // one partial row per helper wave
-    hipMemsetAsync(stat_partial, 0, (size_t)G * 4 * P * cd.Cout * 2 * sizeof(double), s);
-  }
-  auto kfn = k_conv3_ws<KD, TD, TH, TW, NT>;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(P, slabs), dim3(512), lds, s, X, Wp, bias, Y, cd, tiles, accumulate, st);
-  return st.partial ? 4 * P : 0;
 }
 
 template <int KD, int TD, int TH, int TW, int NT>
@@ -1845,20 +1040,26 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16, bool for_w
   }
   const int M = c.TD * c.TH * c.TW;
   const long long tiles = (long long)N * cdiv(D, c.TD) * cdiv(H, c.TH) * cdiv(W, c.TW);
-  int nt = (M == 256) ? 4 : 4;
+  int nt = 4;
   while (nt > 1 && (Cout16 % (nt * 16) != 0)) nt >>= 1;
   const long long want = tiles <= 128 ? 512 : 256;                // tiny spatial extents: >= 2 blocks per CU
   while (nt > 1 && tiles * (Cout16 / (nt * 16)) < want) nt >>= 1;  // more blocks for small problems
+  (void)M;
   c.NT = nt;
   c.WT = 0;
   if (!for_wgrad) {
-    if (const char* e = getenv("BCP_CONV3_CFG")) {   // measurements: "TD,TH,TW,NT" forces the streaming kernel's tile / slab width
-      int td, th, tw, n2;
-      if (sscanf(e, "%d,%d,%d,%d", &td, &th, &tw, &n2) == 4 && Cout16 % (n2 * 16) == 0) { c.TD = td; c.TH = th; c.TW = tw; c.NT = n2; }
-    }
+    const int* f = options().conv3_cfg;   // measurements: forces the streaming kernel's tile / slab width
+    if (f[0] > 0 && Cout16 % (f[3] * 16) == 0) { c.TD = f[0]; c.TH = f[1]; c.TW = f[2]; c.NT = f[3]; }
   }
   return c;
 }
+
+// the persistent 8-wave pipeline kernels (conv3p.hip)
+int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
+           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled);
+int p8_wgrad(const float* x, const float* dy, float* dw, const ConvDims& cd, int KD, int accumulate, void* workspace, hipStream_t s,
+             bool* handled);
+size_t p8_wgrad_workspace_bytes(const ConvDims& cd, int KD);
 
 }  // namespace bcp
 
@@ -1900,12 +1101,12 @@ extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
 
 #define BCP_FWD_CASE(KD_, TD_, TH_, TW_, NT_, WT_)                                                             \
   if (c.KD == KD_ && c.TD == TD_ && c.TH == TH_ && c.TW == TW_ && c.NT == NT_) {                               \
-    rows = launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (float*)workspace, stat_partial, G, bw, dry, (hipStream_t)stream); \
+    rows = launch_fwd<KD_, TD_, TH_, TW_, NT_, WT_>(x, wp, bias, y, cd, accumulate, (float*)workspace, stat_partial, G, dry, (hipStream_t)stream); \
     done = true;                                                                                               \
   }
 #define BCP_RES_CASE(KD_, TD_, TH_, TW_, NT_)                                                                  \
   if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_ && r.NT == NT_) {                               \
-    rows = launch_res<KD_, TD_, TH_, TW_, NT_>(x, wp, bias, y, cd, accumulate, stat_partial, G, bw, dry, (hipStream_t)stream); \
+    rows = launch_res<KD_, TD_, TH_, TW_, NT_>(x, wp, bias, y, cd, accumulate, stat_partial, G, dry, (hipStream_t)stream); \
     done = true;                                                                                               \
   }
 
@@ -1921,15 +1122,14 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
     // 16x16 tiles from 10 K pixels per launch on (the 64^2 and 32^2 U-Net levels at a grouped batch of 12): ALONE the 8x8-tile
     // kernels with their wider slabs are faster (48 vs 67 us at 64 channels), inside the ACDC step the 16x16 ones win
     // (5.35 vs 5.43 ms, interleaved A/B; thresholds 128 K / 40 K / 10 K / 1 K pixels: 5.43 / 5.39 / 5.35 / 5.36 ms)
-    long long thr = 10000;
-    if (const char* e = getenv("BCP_RES_TILE2D_VOX")) thr = atoll(e);   // measurements
+    const long long thr = options().res_tile2d_vox;
     if (vox >= thr && H >= 16 && W >= 16) { r.TH = 16; r.TW = 16; } else { r.TH = 8; r.TW = 8; }
   }
   const int PD = KD == 3 ? 1 : 0;
   const long long hv = (long long)(r.TD + 2 * PD) * (r.TH + 2) * (r.TW + 2);
   const long long tiles = (long long)N * cdiv(D, r.TD) * cdiv(H, r.TH) * cdiv(W, r.TW);
   int nt_max = 4;
-  if (const char* e = getenv("BCP_RES_NT")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) nt_max = v; }   // measurements
+  { const int v = options().res_nt; if (v == 1 || v == 2 || v == 4) nt_max = v; }
   for (int nt = nt_max; nt >= 1; nt >>= 1) {
     if (Cout16 % (nt * 16)) continue;
     const long long lds = ((long long)KD * 9 * Cin16 * nt * 16 + hv * XS) * 4 + 4 * nt * 16 * 2 * 8;
@@ -1943,67 +1143,6 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
   return false;
 }
 
-// resident weights + split-K over cin chunks: the deep levels (Cin >= 128), whose full weight slab (221 KB per 16 output
-// channels at 128 -> 128) does not fit the LDS.  Two chunks (55 KB) stay resident per workgroup, the chunk groups go to
-// blockIdx.z, every workgroup walks its share of the 64-voxel tiles with the register-prefetch pipeline of k_conv3_res, and
-// k_sum_slabs adds the partial outputs.  Versus the streaming kernel: no weight reload per (tile, chunk) and no exposed L2 round
-// trip per chunk.  Only without fused statistics (dgrad, eval forward).
-static bool choose_res_split(Cfg& r, int& csplit, int KD, int N, int D, int H, int W, int Cin16, int Cout16, bool has_ws, bool want_stats) {
-  // Measured (batch 2): C=128 62 us (2 chunks resident) / 57 us (1 chunk) vs 56 us for the streaming kernel, C=256 40 vs 34 us:
-  // no gain, so it is OFF unless BCP_RES_SPLIT=<chunks resident per workgroup> asks for it (tests do).
-  const char* e = getenv("BCP_RES_SPLIT");
-  if (!e || e[0] == '0' || !has_ws || want_stats || KD != 3 || Cin16 < 128) return false;
-  r = choose_cfg(KD, N, D, H, W, Cout16);      // best-fit 64-voxel tile
-  if (r.TD * r.TH * r.TW != 64) return false;
-  r.NT = 1;
-  const int nch = Cin16 / 16;
-  csplit = nch / 2;
-  if (e && e[0] >= '1' && e[0] <= '9') csplit = nch / (e[0] - '0');     // measurements: chunks resident per workgroup
-  if (csplit > 8) csplit = 8;
-  if (csplit < 2) return false;
-  return true;
-}
-#define BCP_RESK_CASE(KD_, TD_, TH_, TW_)                                                                      \
-  if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_) {                                              \
-    rows = launch_res<KD_, TD_, TH_, TW_, 1>(x, wp, bias, y, cd, accumulate, nullptr, 0, bw, dry, (hipStream_t)stream, csplit, \
-                                             (float*)workspace);                                              \
-    done = true;                                                                                               \
-  }
-
-// wave-specialised variant: 16- / 32-channel-in layers whose volume is an exact multiple of the tile (no partial tiles) and
-// whose weights + two halo buffers + staging fit the LDS.  BCP_CONV3_WS=0 disables it (A/B measurements).
-static bool choose_ws(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, int Cout, int Cout16, bool bwd_stats) {
-  // Measured on the MI355X (16->16 @112x112x80): 143-148 us against 140-142 us for k_conv3_res, 9.64 vs 9.46 ms per LA step --
-  // moving the non-MFMA phases to helper waves does not free the matrix pipe (the isolated tap loop, tools/probe/
-  // mfma_lds_probe.hip, tops out at 122 / 134 TFLOP/s with 1 / 2 workgroups per CU and zero global traffic).  The kernel
-  // is therefore OFF by default: BCP_CONV3_WS=1 enables it, "force" (tests) also lifts the minimum problem size.
-  const char* e = getenv("BCP_CONV3_WS");
-  const bool enabled = e && (e[0] == '1' || e[0] == 'f'), force = e && e[0] == 'f';
-  if (!enabled || bwd_stats || Cout != Cout16 || Cin16 > 32) return false;
-  r.KD = KD; r.NT = 1; r.WT = 0;
-  const long long vox = (long long)N * D * H * W;
-  if (KD == 3) {
-    r.TD = 4; r.TH = 4;
-    r.TW = vox >= 256LL * 1024 ? 16 : (vox >= 64LL * 1024 ? 8 : 4);
-  } else {
-    r.TD = 1;
-    if (vox >= 128LL * 1024) { r.TH = 16; r.TW = 16; } else { r.TH = 8; r.TW = 8; }
-  }
-  if (D % r.TD || H % r.TH || W % r.TW) return false;
-  const int PD = KD == 3 ? 1 : 0;
-  const long long hv = (long long)(r.TD + 2 * PD) * (r.TH + 2) * (r.TW + 2), m = (long long)r.TD * r.TH * r.TW;
-  const long long lds = ((long long)KD * 9 * Cin16 * 16 + 2 * hv * XS + m * 20) * 4;
-  if (lds > 160 * 1024) return false;
-  const long long tiles = (long long)N * (D / r.TD) * (H / r.TH) * (W / r.TW);
-  return force || tiles * (Cout16 / 16) >= 512;      // >= 2 work items per workgroup
-}
-
-#define BCP_WS_CASE(KD_, TD_, TH_, TW_)                                                                        \
-  if (r.KD == KD_ && r.TD == TD_ && r.TH == TH_ && r.TW == TW_) {                                              \
-    rows = launch_ws<KD_, TD_, TH_, TW_, 1>(x, wp, bias, y, cd, accumulate, stat_partial, G, dry, (hipStream_t)stream); \
-    done = true;                                                                                               \
-  }
-
 extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD) {
   // split-K partial slabs (deep levels only): at most 8 copies of the output
   const long long n = (long long)N * D * H * W * Cout;
@@ -2013,36 +1152,20 @@ extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int 
 // shared by the launch and by the statistics-rows query: returns the number of partial rows per group the chosen kernel
 // writes (0: this shape does not support fused statistics, e.g. split-K), or a negative error
 static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout,
-                          int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream,
-                          BwdCtx bw = BwdCtx{nullptr, nullptr, 0}) {
+                          int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream) {
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
   bool done = false;
   int rows = 0;
   Cfg r;
-  if (choose_ws(r, KD, N, D, H, W, cd.Cin16, Cout, cd.Cout16, bw.yprev != nullptr)) {
-    BCP_WS_CASE(3, 4, 4, 16) BCP_WS_CASE(3, 4, 4, 8) BCP_WS_CASE(3, 4, 4, 4)
-    BCP_WS_CASE(1, 1, 16, 16) BCP_WS_CASE(1, 1, 8, 8)
-  }
-  // experimental: the 16 -> 16 layers on the bf16 matrix pipe with three-piece operands (k_conv3_b6), BCP_CONV3_B6=1
-  if (!done && cd.Cin16 == 16 && cd.Cout16 == 16) {
-    const char* e = getenv("BCP_CONV3_B6");
-    if (e && e[0] == '1') {
-      if (KD == 3) rows = launch_b6<3, 4, 4, 16>(x, wp, bias, y, cd, accumulate, stat_partial, G, bw, dry, (hipStream_t)stream);
-      else rows = launch_b6<1, 1, 16, 16>(x, wp, bias, y, cd, accumulate, stat_partial, G, bw, dry, (hipStream_t)stream);
-      done = true;
-    }
-  }
-  if (!done && choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
+  rows = p8_fwd(x, wp, bias, y, cd, KD, accumulate, workspace, stat_partial, G, dry, (hipStream_t)stream, &done);
+  if (done) return rows;
+  if (choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
     BCP_RES_CASE(3, 4, 4, 16, 1) BCP_RES_CASE(3, 4, 4, 16, 2)
     BCP_RES_CASE(3, 4, 4, 8, 1) BCP_RES_CASE(3, 4, 4, 8, 2) BCP_RES_CASE(3, 4, 4, 8, 4)
     BCP_RES_CASE(3, 4, 4, 4, 1) BCP_RES_CASE(3, 4, 4, 4, 2) BCP_RES_CASE(3, 4, 4, 4, 4)
     BCP_RES_CASE(1, 1, 16, 16, 1) BCP_RES_CASE(1, 1, 16, 16, 2) BCP_RES_CASE(1, 1, 16, 16, 4)
     BCP_RES_CASE(1, 1, 8, 8, 1) BCP_RES_CASE(1, 1, 8, 8, 2) BCP_RES_CASE(1, 1, 8, 8, 4)
-  }
-  int csplit = 1;
-  if (!done && !dry && choose_res_split(r, csplit, KD, N, D, H, W, cd.Cin16, cd.Cout16, workspace != nullptr, stat_partial != nullptr || G > 0)) {
-    BCP_RESK_CASE(3, 2, 16, 2) BCP_RESK_CASE(3, 8, 8, 1) BCP_RESK_CASE(3, 2, 8, 4) BCP_RESK_CASE(3, 4, 4, 4)
   }
   if (!done) {
     const Cfg c = choose_cfg(KD, N, D, H, W, cd.Cout16);
@@ -2076,24 +1199,6 @@ extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias,
 // (groups consecutive sample ranges).  rows = bcp_conv3_stat_rows(...) partial rows per group are written into
 // stat_partial[groups][rows][Cout][2] doubles; rows == 0 means "not available for this shape": run bcp_conv3_fwd and
 // let bcp_norm_fwd compute its own statistics.
-// dgrad + the statistics of the PREVIOUS layer's norm backward: da = conv(dy, wp_dgrad) (+= when accumulate), and
-// partial[g][row][C][2] = per-block (sum dz, sum dz * xhat) with dz = da * act'((yprev - mean) * scale + beta) -- hand the
-// partials to bcp_norm_bwd(partial_in, nb_in) instead of letting it re-read (yprev, da).  Shapes / rows: as
-// bcp_conv3_fwd_stats with (Cin, Cout) = (layer's Cout, layer's Cin); pstats = the stats tensor bcp_norm_fwd wrote for yprev.
-extern "C" int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout,
-                                        int KD, int accumulate, void* workspace, const float* yprev, const float* pstats, int act,
-                                        double* stat_partial, int groups, void* stream) {
-  BCP_REQUIRE(dy && wp_dgrad && da && yprev && pstats && stat_partial, "bcp_conv3_dgrad_bwdstats: null pointer");
-  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0 && groups >= 1, "bcp_conv3_dgrad_bwdstats: bad extents");
-  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_dgrad_bwdstats: Cin=%d must be a multiple of 4", Cin);
-  BCP_REQUIRE(aligned16(dy) && aligned16(wp_dgrad), "bcp_conv3_dgrad_bwdstats: dy / wp must be 16-B aligned");
-  const int rc = conv3_fwd_impl(dy, wp_dgrad, nullptr, da, N, D, H, W, Cin, Cout, KD, accumulate, workspace, stat_partial, groups, false,
-                                stream, BwdCtx{yprev, pstats, act});
-  if (rc < 0) return rc;
-  BCP_REQUIRE(rc > 0, "bcp_conv3_dgrad_bwdstats: fused statistics unavailable for this shape (check bcp_conv3_stat_rows first)");
-  BCP_CHECK_LAUNCH("bcp_conv3_dgrad_bwdstats");
-  return BCP_OK;
-}
 extern "C" int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace) {
   if (Cin % 4 || Cin < 4 || groups < 1) return 0;
   static float dummy;
@@ -2132,7 +1237,7 @@ static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   // (Measured: forcing the widest slab at the deep levels -- more MFMAs per staged tile but fewer, longer blocks -- is
   // slower: C=128 wgrad 82 / 85 / 106 us and C=256 57 / 58 / 65 us for NT = 1 / 2 / 4.)
   int nt = c.NT > 2 ? 2 : c.NT;     // C=64: 75 us with 2-slab blocks vs 79 us with 4 (two workgroups per CU instead of one)
-  // Tile sweep (BCP_WGRAD_TILE): the mid level (2 x 56x56x40, C=32) runs 140 us ALONE with 4x4x8 tiles against 158 us with
+  // Tile sweep (option wgrad_tile): the mid level (2 x 56x56x40, C=32) runs 140 us ALONE with 4x4x8 tiles against 158 us with
   // 4x8x8 -- but inside the step, next to the dgrad / norm-backward kernels of the main stream, the 256-voxel tile wins
   // (8.95 vs 9.02 ms per step, interleaved A/B of the two libraries): 4x8x8 stays.  The 16-channel level keeps 4x4x16
   // (259 us vs 286 / 283 / 314 us for 4x4x8 / 4x8x8 / 4x4x4).
@@ -2141,13 +1246,12 @@ static Cfg choose_wgrad_cfg(int KD, int N, int D, int H, int W, int Cout16) {
   // halo + dY tile: 16x16 tiles run 52 / 61 / 54 us instead of 58 / 66 / 66 us at 64 / 128 / 256 channels, and the ACDC step
   // 5.45 instead of 5.68 ms.
   if (KD == 1 && H >= 16 && W >= 16) { c.TH = 16; c.TW = 16; }
-  if (const char* e = getenv("BCP_WGRAD_TILE")) {   // measurements: "TD,TH,TW[,min_voxels,max_voxels]" (range: one level only)
-    int td, th, tw;
-    long long lo = 0, hi = 1LL << 60;
+  const Options& o = options();
+  if (o.wgrad_tile[0] > 0) {   // measurements: TD,TH,TW[,min_voxels,max_voxels] (range: one level only)
     const long long vox = (long long)N * D * H * W;
-    if (sscanf(e, "%d,%d,%d,%lld,%lld", &td, &th, &tw, &lo, &hi) >= 3 && vox >= lo && vox <= hi) { c.TD = td; c.TH = th; c.TW = tw; }
+    if (vox >= o.wgrad_tile[3] && vox <= o.wgrad_tile[4]) { c.TD = (int)o.wgrad_tile[0]; c.TH = (int)o.wgrad_tile[1]; c.TW = (int)o.wgrad_tile[2]; }
   }
-  if (const char* e = getenv("BCP_WGRAD_NT")) { const int v = atoi(e); if ((v == 1 || v == 2 || v == 4) && Cout16 % (v * 16) == 0) nt = v; }
+  { const int v = o.wgrad_nt; if ((v == 1 || v == 2 || v == 4) && Cout16 % (v * 16) == 0) nt = v; }
   c.NT = nt;
   return c;
 }
@@ -2159,9 +1263,12 @@ extern "C" size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, in
     int g = tiles < 512 ? tiles : 512;
     return (size_t)g * KD * 9 * 16 * sizeof(float);
   }
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
   const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, Co16);
   const int g = wgrad_groups(c, N, D, H, W, Ci16, Co16);
-  return (size_t)g * KD * 9 * Ci16 * Co16 * sizeof(float);
+  const size_t a = (size_t)g * KD * 9 * Ci16 * Co16 * sizeof(float), b = p8_wgrad_workspace_bytes(cd, KD);
+  return a > b ? a : b;
 }
 
 #define BCP_WG_CASE(KD_, TD_, TH_, TW_, NT_)                                                     \
@@ -2177,10 +1284,18 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   BCP_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "bcp_conv3_wgrad: Cin/Cout must be multiples of 4");
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
+  bool done = false;
+  {
+    const int rc = p8_wgrad(x, dy, dw, cd, KD, accumulate, workspace, (hipStream_t)stream, &done);
+    if (done) {
+      if (rc < 0) return rc;
+      BCP_CHECK_LAUNCH("bcp_conv3_wgrad");
+      return BCP_OK;
+    }
+  }
   const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, cd.Cout16);
   const int groups = wgrad_groups(c, N, D, H, W, cd.Cin16, cd.Cout16);
   float* ws = reinterpret_cast<float*>(workspace);
-  bool done = false;
   int G = 0;
   BCP_WG_CASE(3, 4, 4, 16, 1) BCP_WG_CASE(3, 4, 4, 16, 2) BCP_WG_CASE(3, 4, 4, 16, 4)
   BCP_WG_CASE(3, 4, 8, 8, 1) BCP_WG_CASE(3, 4, 8, 8, 2) BCP_WG_CASE(3, 4, 8, 8, 4)

@@ -1,0 +1,173 @@
+// bcp_amd/csrc/conv3_defs.h -- tile geometry, halo fetch and fused-statistics helpers shared by the 3x3(x3) convolution
+// kernels (conv3.hip: streaming / resident / wgrad kernels; conv3p.hip: the persistent 8-wave pipeline kernels).
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+namespace bcp {
+
+#ifndef BCP_XS
+#define BCP_XS 20
+#endif
+static constexpr int XS = BCP_XS;  // LDS floats per halo voxel: 16 channels + 4 pad (16-B aligned rows)
+// halo row stride of the wgrad kernel (ds_read_b32, lane (li = channel, lg = voxel))
+static constexpr int XSW = 20;   // measured: 16 (conflict-free b32 reads) is 6 % SLOWER at C=16 -- LDS conflicts are not what bounds wgrad
+
+
+template <int KD, int TD, int TH, int TW>
+struct Tile {
+  static constexpr int M = TD * TH * TW;
+  static constexpr int MT = M / 64;
+  static constexpr int PD = (KD == 3) ? 1 : 0;
+  static constexpr int HD = TD + 2 * PD, HH = TH + 2, HW = TW + 2;
+  static constexpr int HV = HD * HH * HW;
+  static constexpr int T = KD * 9;
+  static_assert(M % 64 == 0, "tile must hold a multiple of 64 voxels");
+  __device__ static __forceinline__ int voff(int m) {  // halo-local voxel index of tile voxel m at tap (0,0,0)
+    const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+    return (td * HH + th) * HW + tw;
+  }
+  __device__ static __forceinline__ int tapoff(int tap) {
+    const int kw = tap % 3, kh = (tap / 3) % 3, kd = tap / 9;
+    return (kd * HH + kh) * HW + kw;
+  }
+};
+
+struct ConvDims {
+  int N, D, H, W;
+  int Cin, Cout;        // real channel counts (row strides of X and Y)
+  int Cin16, Cout16;    // padded to multiples of 16 (packed-weight extents)
+  int tiles_d, tiles_h, tiles_w;
+};
+
+__device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, int TH, int TW, int& n, int& d0, int& h0,
+                                            int& w0) {
+  const int tw = bx % cd.tiles_w;
+  const int th = (bx / cd.tiles_w) % cd.tiles_h;
+  const int td = (bx / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d;
+  n = bx / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
+  d0 = td * TD;
+  h0 = th * TH;
+  w0 = tw * TW;
+}
+
+// Halo fetch with launch-invariant indexing.  A halo "row" is one (hd, hh) line of HW voxels = RW float4 columns; a
+// pass moves RPP rows with threads (r0, col).  A thread's column is fixed for the whole launch, so everything but the
+// tile origin is computed once: the per-pass global offsets grel[] and the LDS slot; per tile there is one uniform
+// 64-bit row-validity mask (SALU).  Per-tile vector work of a fetch: ~2 VALU per float4 (was ~25: div/mod of the flat
+// index + three range checks + 64-bit address arithmetic per element).
+template <class TL, int XSP = XS>
+struct HaloFetch {
+  static constexpr int RW = TL::HW * 4, RPP = 256 / RW, HR = TL::HD * TL::HH, NP = (HR + RPP - 1) / RPP;
+  static_assert(HR <= 128 && RW <= 256, "halo rows must fit the 128-bit validity mask");
+  int r0, hw, part;
+  bool act;
+  unsigned grel[NP];
+  float* lds;
+
+  __device__ __forceinline__ void init(const ConvDims& cd, float* Xs, int tid = -1) {
+    if (tid < 0) tid = threadIdx.x;      // 256 fetching threads; the wave-specialised kernel passes its helper-local id
+    r0 = tid / RW;
+    const int col = tid - r0 * RW;
+    hw = col >> 2;
+    part = col & 3;
+    act = tid < RPP * RW;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int row = u * RPP + r0, hd = row / TL::HH, hh = row - hd * TL::HH;
+      grel[u] = (unsigned)(((hd * cd.H + hh) * cd.W + hw) * cd.Cin + part * 4);
+    }
+    lds = Xs + (r0 * TL::HW + hw) * XSP + part * 4;
+  }
+  __device__ __forceinline__ void stash_to(float* Xbuf, const float* Xbase, const float4 (&pre)[NP]) const {   // other halo buffer
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (act && u * RPP + r0 < HR) st4(Xbuf + (lds - Xbase) + u * RPP * TL::HW * XSP, pre[u]);
+  }
+  // halo of the tile at (n, d0, h0, w0), cin chunk c -> registers; zero outside the volume / beyond Cin
+  __device__ __forceinline__ void fetch(const float* __restrict__ X, const ConvDims& cd, int n, int d0, int h0, int w0, int c,
+                                        float4 (&pre)[NP]) const {
+    // uniform: valid hh range, valid hd range -> one bit per halo row
+    const int hlo = (h0 >= 1) ? 0 : 1 - h0, hhi = (cd.H - h0 + 1 < TL::HH) ? cd.H - h0 + 1 : TL::HH;
+    const int dlo = (d0 >= TL::PD) ? 0 : TL::PD - d0, dhi = (cd.D - d0 + TL::PD < TL::HD) ? cd.D - d0 + TL::PD : TL::HD;
+    const unsigned mh = (hhi > hlo) ? (((1u << hhi) - 1u) & ~((1u << hlo) - 1u)) : 0u;
+    unsigned long long M0 = 0, M1 = 0;   // bit (hd * HH + hh), rows 0..63 / 64..127
+#pragma unroll
+    for (int hd = 0; hd < TL::HD; ++hd) {
+      constexpr int HHc = TL::HH;
+      const int pos = hd * HHc;
+      if (hd >= dlo && hd < dhi) {
+        if (pos < 64) M0 |= (unsigned long long)mh << pos;
+        if (pos < 64 && pos + HHc > 64) M1 |= (unsigned long long)mh >> (64 - pos);
+        if (pos >= 64) M1 |= (unsigned long long)mh << (pos - 64);
+      }
+    }
+    const bool col_ok = act && (unsigned)(w0 - 1 + hw) < (unsigned)cd.W && c * 16 + part * 4 < cd.Cin;
+    unsigned long long Mt0 = M0 >> r0, Mt1 = 0;
+    if (HR > 64) {
+      if (r0) Mt0 |= M1 << (64 - r0);
+      Mt1 = M1 >> r0;
+    }
+    if (!col_ok) { Mt0 = 0; Mt1 = 0; }
+    const float* xb = X + ((((long long)n * cd.D + (d0 - TL::PD)) * cd.H + (h0 - 1)) * cd.W + (w0 - 1)) * cd.Cin + c * 16;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (((u * RPP < 64 ? Mt0 >> ((u * RPP) & 63) : Mt1 >> ((u * RPP - 64) & 63)) & 1ull)) v = ld4(xb + grel[u]);
+      pre[u] = v;
+    }
+  }
+  __device__ __forceinline__ void stash(const float4 (&pre)[NP]) const {
+#pragma unroll
+    for (int u = 0; u < NP; ++u)
+      if (act && u * RPP + r0 < HR) st4(lds + u * RPP * TL::HW * XSP, pre[u]);
+  }
+};
+
+// Fused BatchNorm / InstanceNorm statistics: the conv epilogue already holds y = conv + bias in registers, so the
+// per-channel (sum, sum of squares) partials the norm needs are produced here instead of by a second pass over y
+// (csrc/norm.hip k_col_partial<0>).  partial[g][row][C][2] doubles, fp64 accumulation as in the standalone pass.
+struct StatsArg {
+  double* partial;       // nullptr: disabled
+  int rows;              // rows per group (nb of the norm finalize)
+  int tiles_per_group;   // spatial tiles per normalisation group (tiles are sample-major)
+  int C;                 // channel count of the partial rows (= Cout)
+  int G;                 // normalisation groups
+};
+template <int MODE>
+__device__ __forceinline__ void stat_add(double& s1, double& s2, float v) {
+  if (MODE == 1) {
+    s1 += (double)v;
+    s2 += (double)v * (double)v;
+  }
+}
+
+// block-wide sum over the 4 lg lane groups and the 4 waves, then one (s1, s2) pair per channel of the slab
+template <int NT>
+__device__ __forceinline__ void stats_flush(double (&s1)[NT], double (&s2)[NT], double* __restrict__ Ss /* [4][NT*16][2] */,
+                                            double* __restrict__ dst_row /* &partial[g][row][0][0] */, int cout0, int Cout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    double a = s1[nt], b = s2[nt];
+    a += __shfl_xor(a, 16); a += __shfl_xor(a, 32);
+    b += __shfl_xor(b, 16); b += __shfl_xor(b, 32);
+    if (lg == 0) { Ss[(wave * NT * 16 + nt * 16 + li) * 2] = a; Ss[(wave * NT * 16 + nt * 16 + li) * 2 + 1] = b; }
+    s1[nt] = 0.0; s2[nt] = 0.0;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < NT * 16 && cout0 + (int)threadIdx.x < Cout) {
+    const int c = threadIdx.x;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += Ss[(w * NT * 16 + c) * 2]; b += Ss[(w * NT * 16 + c) * 2 + 1]; }
+    dst_row[(cout0 + c) * 2] = a;
+    dst_row[(cout0 + c) * 2 + 1] = b;
+  }
+  __syncthreads();
+}
+
+struct Cfg { int KD, TD, TH, TW, NT, WT; };
+
+}  // namespace bcp

@@ -459,7 +459,7 @@ static int tn_groups(int M, int K, int N, int nt) {
   const int chan_blocks = cdiv(K, 64) * (N / (nt * 16));
   int g = cdiv(512, chan_blocks);
   const int max_g = cdiv(M, 64);
-  if (const char* e = getenv("BCP_TN_GROUPS")) { const int v = atoi(e); if (v > 0 && v < g) g = v; }   // tests: force multi-chunk groups
+  { const int v = options().tn_groups; if (v > 0 && v < g) g = v; }   // tests: force multi-chunk groups
   if (g > max_g) g = max_g;
   if (g < 1) g = 1;
   return g;

@@ -47,6 +47,11 @@ class Ops:
         return cls._product
 
     # ------------------------------------------------------------------ helpers
+    def set_option(self, name, value=""):
+        """library tuning / test switch (bcp_set_option); cached shape queries depend on the options: drop them"""
+        self.b.set_option(name, value)
+        self._wsz.clear()
+
     def _chk(self, *ts):
         for t in ts:
             if t is None:
@@ -272,22 +277,6 @@ class Ops:
         part = self.workspace(("statpart", rows), groups * rows * Cout * 16, x)
         self.b.call("bcp_conv3_fwd_stats", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, _p(ws), _p(part), groups, self.stream(x))
         return out, part, rows
-
-    def conv3_dgrad_bwdstats(self, dy, wp_dgrad, Cin_out, KD, yprev, pstats, act, groups):
-        """dgrad + the previous layer's norm-backward statistics -> (da, partial, rows); rows == 0: not fused for this
-        shape (plain dgrad, partial None).  yprev / pstats: the previous layer's pre-norm output and its stats[5,G,C]."""
-        self._chk(dy, wp_dgrad, yprev, pstats)
-        N, D, H, W, Cin = dy.shape
-        nbytes = self._ws_bytes("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cin, Cin_out, KD)
-        rows = self._ws_bytes("bcp_conv3_stat_rows", N, D, H, W, Cin, Cin_out, KD, groups, 1 if nbytes else 0)
-        if rows == 0:
-            return self.conv3_fwd(dy, wp_dgrad, None, Cin_out, KD), None, 0
-        ws = self.workspace("conv3", nbytes, dy) if nbytes else None
-        da = torch.empty((N, D, H, W, Cin_out), dtype=torch.float32, device=dy.device)
-        part = self.workspace(("bstatpart", rows), groups * rows * Cin_out * 16, dy)
-        self.b.call("bcp_conv3_dgrad_bwdstats", _p(dy), _p(wp_dgrad), _p(da), N, D, H, W, Cin, Cin_out, KD, 0, _p(ws), _p(yprev), _p(pstats),
-                    int(act), _p(part), groups, self.stream(dy))
-        return da, part, rows
 
     def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):
         """dw: torch-layout gradient tensor [Cout,Cin,(3,)3,3], written (or += when accumulate)"""

@@ -232,7 +232,6 @@ class VNet(HipNet):
         (h_last,) = saved[-1]
         dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
         skip_grads = []
-        pending = None      # fused backward statistics for the layer about to be processed
         for li in range(len(self._layers) - 1, -1, -1):
             L = self._layers[li]
             x_in, y, stats, cs, _ = saved[li]
@@ -240,12 +239,10 @@ class VNet(HipNet):
             da = dh
             if L.skip_pop:
                 skip_grads.append(da)       # d(out)/d(skip) = identity: the skip source gets `da` itself
-            part, nb = pending if pending is not None else (None, 0)
-            pending = None
             if L.bn is not None:
-                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, L.bn.weight.grad, L.bn.bias.grad, True, chan_scale=cs, partial=part, nb=nb)
+                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, L.bn.weight.grad, L.bn.bias.grad, True, chan_scale=cs)
             else:
-                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, None, None, False, chan_scale=cs, partial=part, nb=nb)
+                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, None, None, False, chan_scale=cs)
             gw, acc = w.grad, True
             # conv biases feed a norm: their gradient is identically zero (DESIGN.md "bias gradients"); the flat
             # gradient buffer was cleared by begin_backward(), nothing to add.
@@ -264,14 +261,7 @@ class VNet(HipNet):
                 dh = None
             elif L.kind == "c3":
                 _, wd = self.conv3_packed(("c3", li), True)
-                prev = saved[li - 1] if li > 0 else None
-                if self.fuse_bwd_stats and prev is not None and prev[2] is not None and prev[3] is None:
-                    # this dgrad produces da for layer li-1, whose norm backward needs (sum dz, sum dz*xhat): accumulate them
-                    # in the epilogue (one read of y_{li-1}) instead of a separate pass over (y_{li-1}, da)
-                    dh, bpart, brows = ops.conv3_dgrad_bwdstats(dy, wd, L.cin, 3, prev[1], prev[2], H.ACT_RELU, prev[4])
-                    pending = (bpart, brows) if brows else None
-                else:
-                    dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
+                dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
             elif L.kind == "dw":
                 _, bp = self.k2_packed(("k2", li), True)
                 sg = skip_grads.pop()        # x_in is a skip source: join the decoder-side gradient in place

@@ -364,11 +364,6 @@ class HipNet(nn.Module):
             return False
 
     overlap_wgrad = True
-    # norm-backward statistics in the dgrad conv epilogue (bcp_conv3_dgrad_bwdstats).  Measured (MI355X, LA step, 60 steps,
-    # twice): 9.48 / 9.47 ms fused vs 9.39 / 9.36 ms unfused -- per layer the fusion saves 6-33 us of statistics pass but adds
-    # 3-12 us to a dgrad conv that sits on the critical path, and the finalize launch stays.  Off by default; the kernels and
-    # tests stay (BCP_FUSE_BWD_STATS=1 turns it on).
-    fuse_bwd_stats = os.environ.get("BCP_FUSE_BWD_STATS", "0") == "1"
     _side_streams = {}
 
     def _wgrad_stream(self, *tensors):

@@ -140,13 +140,9 @@ class UNet_2d(HipNet):
         with self._wgrad_stream(dy2, a1):      # weight gradients run underneath the dgrad -> norm_bwd chain (VNet.py)
             ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
         _, wd2 = self.conv3_packed((tag, 2), True)
-        bpart, brows = None, 0
-        if em is None and self.fuse_bwd_stats:     # no dropout between the two convs (decoder blocks): statistics of b1's
-            da1, bpart, brows = ops.conv3_dgrad_bwdstats(dy2, wd2, cb.cout, 1, y1, st1, H.ACT_LRELU, G)   # backward in the dgrad epilogue
-        else:
-            da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
+        da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
         dy1 = ops.norm_bwd(y1, da1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em,
-                           elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0, partial=bpart if brows else None, nb=brows)
+                           elem_scale=1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0)
         with self._wgrad_stream(dy1, h):
             if cb.cin == 1:
                 ops.conv3_c1_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)

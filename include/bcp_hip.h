@@ -39,6 +39,11 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ---- library ------------------------------------------------------------------------------- */
 int bcp_version(void);
 const char* bcp_last_error(void);
+/* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
+ * (csrc/common.h: conv3_p, splitk, res_pcu, res_nt, res_tile2d_vox, conv3_cfg, wgrad_nt, wgrad_tile, tn_groups, cc_tile,
+ * conv3_p8, wgrad_p8); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
+ * HOST strings.  Set options before work is enqueued, not concurrently with launches. */
+int bcp_set_option(const char* name, const char* value);
 /* writes the gcnArchName of the current device ("gfx950...") */
 int bcp_device_arch(char* buf, int n);
 /* hipEvent-based timing on an arbitrary stream (bench.py uses it for per-kernel roofline numbers) */
@@ -111,12 +116,6 @@ int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, fl
 /* fused variant: the conv epilogue also emits the (sum, sum^2) partials of y that bcp_norm_fwd needs, for `groups`
  * consecutive sample ranges; rows = bcp_conv3_stat_rows(...) (0: unavailable for this shape -> use bcp_conv3_fwd);
  * stat_partial = double[groups][rows][Cout][2], handed to bcp_norm_fwd as partial_in with nb_in = rows. */
-/* dgrad of layer L+1 fused with the statistics of layer L's norm backward: da = conv(dy, wp_dgrad) and partial[g][row][C][2] =
- * (sum dz, sum dz * xhat), dz = da * act'((yprev - mean) * scale + beta); (Cin, Cout) here = (layer L+1's Cout, its Cin = C of
- * yprev); pstats = the float[5][G][C] tensor bcp_norm_fwd wrote for yprev; rows as bcp_conv3_stat_rows. */
-int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout, int KD,
-                             int accumulate, void* workspace_or_null, const float* yprev, const float* pstats, int act,
-                             double* stat_partial, int groups, void* stream);
 int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace);
 int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin,
                         int Cout, int KD, void* workspace_or_null, double* stat_partial, int groups, void* stream);

@@ -1,0 +1,88 @@
+"""Isolated timings of the 3x3x3 conv kernels at the LA V-Net's in-step launch shapes (grouped batch of 2), A/B over
+library options (bcp_set_option), interleaved rounds, HIP events on the launch stream.
+Usage: python tools/bench_conv.py [--rounds 5] [--iters 20] [--json out.json] [--variants "name:opt=val,opt=val;..."]"""
+import argparse
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bcp_amd.hip_ops import Ops  # noqa: E402
+
+LEVELS = [(16, (112, 112, 80)), (32, (56, 56, 40)), (64, (28, 28, 20)), (128, (14, 14, 10)), (256, (7, 7, 5))]
+
+
+def timeit(ops, fn, like, iters):
+    e0, e1 = ops.event(), ops.event()
+    ops.event_record(e0, like)
+    for _ in range(iters):
+        fn()
+    ops.event_record(e1, like)
+    return ops.event_elapsed_ms(e0, e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_conv.json"))
+    ap.add_argument("--variants", default="old:conv3_p8=0,wgrad_p8=0;new:conv3_p8=1,wgrad_p8=1")
+    ap.add_argument("--ops", default="fwd_stats,dgrad,wgrad")
+    ap.add_argument("--levels", default="16,32,64,128,256")
+    a = ap.parse_args()
+    variants = []
+    for v in a.variants.split(";"):
+        name, _, opts = v.partition(":")
+        variants.append((name, [tuple(o.split("=")) for o in opts.split(",") if o]))
+    ops = Ops.product()
+    dev = torch.device("cuda:0")
+    N = a.batch
+    want = set(a.ops.split(","))
+    lv = set(int(x) for x in a.levels.split(","))
+    res = {}
+    for C, sp in LEVELS:
+        if C not in lv:
+            continue
+        x = torch.randn(N, *sp, C, device=dev)
+        dy = torch.randn(N, *sp, C, device=dev)
+        w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
+        b = torch.zeros(C, device=dev)
+        wf, wd = ops.conv3_pack(w, 3)
+        y = torch.empty(N, *sp, C, device=dev)
+        dw = torch.empty_like(w)
+        flops = 2.0 * N * sp[0] * sp[1] * sp[2] * 27 * C * C
+        fns = {}
+        if "fwd_stats" in want:
+            fns["fwd_stats"] = lambda: ops.conv3_fwd_stats(x, wf, b, C, 3, N)
+        if "dgrad" in want:
+            fns["dgrad"] = lambda: ops.conv3_fwd(dy, wd, None, C, 3, out=y)
+        if "wgrad" in want:
+            fns["wgrad"] = lambda: ops.conv3_wgrad(x, dy, dw, 3)
+        times = {(op, vn): [] for op in fns for vn, _ in variants}
+        for r in range(a.rounds + 1):
+            for vn, opts in variants:
+                for k, v in opts:
+                    ops.set_option(k, v)
+                for op, fn in fns.items():
+                    fn(); fn()
+                    t = timeit(ops, fn, x, a.iters)
+                    if r:
+                        times[(op, vn)].append(t)
+                for k, _ in opts:
+                    ops.set_option(k)
+        for (op, vn), ts in times.items():
+            med = statistics.median(ts)
+            res[f"{op}/C{C}/{vn}"] = {"us": med * 1e3, "tflops": flops / med / 1e9, "min_us": min(ts) * 1e3, "frac_157": flops / med / 1e9 / 157.3}
+            print(f"{op:10s} C={C:3d} {vn:8s} {med * 1e3:8.1f} us  {flops / med / 1e9:7.1f} TFLOP/s  (min {min(ts) * 1e3:.1f})", flush=True)
+    os.makedirs(os.path.dirname(a.json), exist_ok=True)
+    with open(a.json, "w") as f:
+        json.dump(res, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -61,11 +61,11 @@ while time.time() - t0 < budget:
         big = rng.random() < 0.5
         def cc():
             if big:
-                os.environ["BCP_CC_TILE"] = "big"
+                ops.set_option("cc_tile", 2)
             try:
                 got = ops.cc_largest(seg, 1, conn).float()
             finally:
-                os.environ.pop("BCP_CC_TILE", None)
+                ops.set_option("cc_tile")
             assert torch.equal(got, O.largest_cc(seg.long(), None if conn == 3 else conn)), "cc mismatch"
         attempt(f"cc {tuple(seg.shape)} p={p} conn={conn} big={big}", cc)
     elif kind == 2:   # norm fwd / bwd, random groups and channels
@@ -107,11 +107,11 @@ while time.time() - t0 < budget:
         chunks = rng.random() < 0.3
         def k2():
             if chunks:
-                os.environ["BCP_TN_GROUPS"] = "1"
+                ops.set_option("tn_groups", 1)
             try:
                 K.check_k2(ops, dev, cases=[case], pw_cases=[pw])
             finally:
-                os.environ.pop("BCP_TN_GROUPS", None)
+                ops.set_option("tn_groups")
         attempt(f"k2 {case} pw {pw} one-group={chunks}", k2)
     elif kind == 6:   # MaxPool2d(2) / bilinear x2 (align_corners) and their backward passes vs torch
         import torch.nn.functional as F
