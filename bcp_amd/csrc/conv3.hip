@@ -265,7 +265,6 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   constexpr int NACC = (MT * NT == 1) ? 2 : 1;       // a lone accumulator would serialise on the 40-cycle MFMA latency
   using HF = HaloFetch<TL>;
   constexpr int NP = HF::NP;
-  constexpr bool ROWS4 = (TW % 4 == 0);              // an accumulator's 4 rows are 4 consecutive voxels along w
 
   HIP_DYNAMIC_SHARED(float4, smem4)   // float4 element type => 16-B aligned base, so ld4/st4 become ds_read/write_b128
   float* smem = reinterpret_cast<float*>(smem4);
@@ -291,17 +290,23 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   HF hf;
   hf.init(cd, Xs);
 
-  // launch-invariant epilogue constants: output offsets of the accumulator rows, bias of this lane's column(s)
+  // The MFMA is issued as D = W^T (16 cout x 4 cin) * X (4 cin x 16 voxels): lane (li, lg) then holds voxel li of the M tile and
+  // the FOUR CONSECUTIVE output channels lg*4 .. lg*4+3, so the epilogue is one 16-byte store per (M tile, slab) instead of
+  // four 4-byte stores.  Measured (tools/probe/issue_cost_probe.hip): next to fp32 MFMAs a global store costs the issuing
+  // wave ~160-320 matrix-pipe cycles WHATEVER its width -- sixteen dword stores per tile were ~18 % of the 16 -> 16 layer.
+  // launch-invariant epilogue constants: output offset of this lane's voxel in every M tile, bias of its four channels
   unsigned yoff[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int m0 = (wave * MT + mt) * 16 + lg * 4;
+    const int m0 = (wave * MT + mt) * 16 + li;
     const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
-    yoff[mt] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + li);
+    yoff[mt] = (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout + lg * 4);
   }
-  float bv[NT];
+  float bv[NT][4];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && cout0 + nt * 16 + li < cd.Cout) ? bias[cout0 + nt * 16 + li] : 0.f;
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) bv[nt][r] = (bias && cout0 + nt * 16 + lg * 4 + r < cd.Cout) ? bias[cout0 + nt * 16 + lg * 4 + r] : 0.f;
   const bool slab_full = cout0 + CT <= cd.Cout;
 
   f32x4 acc[NACC][MT][NT];
@@ -343,9 +348,11 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
   }
   int ch = 0;
   if (tile >= t_end) return;
-  double s1[NT], s2[NT];                             // fused norm statistics of the current group
+  double s1[NT][4], s2[NT][4];                       // fused norm statistics of the current group: this lane's 4 channels per slab
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
   int cur_g = st.partial ? tile / st.tiles_per_group : 0;
   {
     float4 pre[NP];
@@ -398,70 +405,75 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].x, b[nt].x, acc[0][mt][nt], 0, 0, 0);
-          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].y, b[nt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
-          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].z, b[nt].z, acc[0][mt][nt], 0, 0, 0);
-          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt].w, b[nt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
+          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].x, a[mt].x, acc[0][mt][nt], 0, 0, 0);
+          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].y, a[mt].y, acc[NACC - 1][mt][nt], 0, 0, 0);
+          acc[0][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].z, a[mt].z, acc[0][mt][nt], 0, 0, 0);
+          acc[NACC - 1][mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[nt].w, a[mt].w, acc[NACC - 1][mt][nt], 0, 0, 0);
         }
     }
     if (ch == nch - 1) {
       int n, d0, h0, w0;
       tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
       if (st.partial && tile / st.tiles_per_group != cur_g) {   // tiles are visited in increasing order: groups never come back
-        stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+        stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
         cur_g = tile / st.tiles_per_group;
       }
-      const bool full = ROWS4 && slab_full && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
+      const bool full = slab_full && (cd.Cout & 3) == 0 && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
       const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
-      auto rows = [&](auto mode_tag) {
+      auto rows = [&](auto mode_tag, auto acc_tag) __attribute__((always_inline)) {
         constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool ACCUM = decltype(acc_tag)::value;   // compile-time: a conditional read-modify-write serialises every store behind a vmcnt(0)
         if (full) {
-          // whole tile inside the volume: uniform base + launch-invariant lane offsets, no index math per row
+          // whole tile inside the volume: uniform base + launch-invariant lane offsets, one 16-byte store per (M tile, slab)
           float* yb = Y + tile_base + cout0;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float* p = yb + r * cd.Cout + yoff[mt];
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                float v = acc[0][mt][nt][r];
-                if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
-                v += bv[nt];
-                if (accumulate) v += p[nt * 16];
-                p[nt * 16] = v;
-                stat_add<MODE>(s1[nt], s2[nt], v);
-              }
+            for (int nt = 0; nt < NT; ++nt) {
+              float* p = yb + yoff[mt] + nt * 16;
+              float4 v;
+              v.x = acc[0][mt][nt][0] + (NACC == 2 ? acc[NACC - 1][mt][nt][0] : 0.f) + bv[nt][0];
+              v.y = acc[0][mt][nt][1] + (NACC == 2 ? acc[NACC - 1][mt][nt][1] : 0.f) + bv[nt][1];
+              v.z = acc[0][mt][nt][2] + (NACC == 2 ? acc[NACC - 1][mt][nt][2] : 0.f) + bv[nt][2];
+              v.w = acc[0][mt][nt][3] + (NACC == 2 ? acc[NACC - 1][mt][nt][3] : 0.f) + bv[nt][3];
+              if (ACCUM) { const float4 o = ld4(p); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+              st4(p, v);
+              stat_add<MODE>(s1[nt][0], s2[nt][0], v.x); stat_add<MODE>(s1[nt][1], s2[nt][1], v.y);
+              stat_add<MODE>(s1[nt][2], s2[nt][2], v.z); stat_add<MODE>(s1[nt][3], s2[nt][3], v.w);
             }
         } else {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
+            const int m = (wave * MT + mt) * 16 + li;
+            const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+            const int d = d0 + td, h = h0 + th, w = w0 + tw;
+            if (d < cd.D && h < cd.H && w < cd.W) {
+              const long long ro = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int m = (wave * MT + mt) * 16 + lg * 4 + r;
-              const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-              const int d = d0 + td, h = h0 + th, w = w0 + tw;
-              if (d < cd.D && h < cd.H && w < cd.W) {
-                const long long ro = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout);
+              for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                  const int co = cout0 + nt * 16 + li;
+                for (int r = 0; r < 4; ++r) {
+                  const int co = cout0 + nt * 16 + lg * 4 + r;
                   if (co < cd.Cout) {
                     float v = acc[0][mt][nt][r];
                     if (NACC == 2) v += acc[NACC - 1][mt][nt][r];
-                    v += bv[nt];
-                    if (accumulate) v += Y[ro + co];
+                    v += bv[nt][r];
+                    if (ACCUM) v += Y[ro + co];
                     Y[ro + co] = v;
-                    stat_add<MODE>(s1[nt], s2[nt], v);
+                    stat_add<MODE>(s1[nt][r], s2[nt][r], v);
                   }
                 }
-              }
             }
           }
         }
       };
-      if (!st.partial) rows(std::integral_constant<int, 0>{});
-      else rows(std::integral_constant<int, 1>{});
+      if (accumulate) {
+        if (!st.partial) rows(std::integral_constant<int, 0>{}, std::true_type{});
+        else rows(std::integral_constant<int, 1>{}, std::true_type{});
+      } else {
+        if (!st.partial) rows(std::integral_constant<int, 0>{}, std::false_type{});
+        else rows(std::integral_constant<int, 1>{}, std::false_type{});
+      }
 #pragma unroll
       for (int a = 0; a < NACC; ++a)
 #pragma unroll
@@ -470,7 +482,7 @@ __global__ __launch_bounds__(256) void k_conv3_res(const float* __restrict__ X, 
           for (int nt = 0; nt < NT; ++nt) acc[a][mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     if (!has_next) {
-      if (st.partial) stats_flush<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+      if (st.partial) stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
       break;
     }
     __syncthreads();   // every wave is done reading the halo buffer

@@ -168,6 +168,34 @@ __device__ __forceinline__ void stats_flush(double (&s1)[NT], double (&s2)[NT], 
   __syncthreads();
 }
 
+// transposed accumulators (lane = voxel li, channels lg*4 + r): sum over the 16 voxel lanes, then over the 4 waves
+template <int NT>
+__device__ __forceinline__ void stats_flush_t(double (&s1)[NT][4], double (&s2)[NT][4], double* __restrict__ Ss /* [4][NT*16][2] */,
+                                              double* __restrict__ dst_row /* &partial[g][row][0][0] */, int cout0, int Cout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double a = s1[nt][r], b = s2[nt][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if (li == 0) { Ss[(wave * NT * 16 + nt * 16 + lg * 4 + r) * 2] = a; Ss[(wave * NT * 16 + nt * 16 + lg * 4 + r) * 2 + 1] = b; }
+      s1[nt][r] = 0.0; s2[nt][r] = 0.0;
+    }
+  __syncthreads();
+  if ((int)threadIdx.x < NT * 16 && cout0 + (int)threadIdx.x < Cout) {
+    const int c = threadIdx.x;
+    double a = 0.0, b = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += Ss[(w * NT * 16 + c) * 2]; b += Ss[(w * NT * 16 + c) * 2 + 1]; }
+    dst_row[(cout0 + c) * 2] = a;
+    dst_row[(cout0 + c) * 2 + 1] = b;
+  }
+  __syncthreads();
+}
+
 struct Cfg { int KD, TD, TH, TW, NT, WT; };
 
 }  // namespace bcp

@@ -37,6 +37,13 @@ namespace bcp {
 
 enum { P8_BRICK = 0, P8_FLAT = 1 };
 
+// Measurement-only switches (tools/ablate_p8.sh builds variants of the library; the product build has 0):
+//   1: no epilogue (stores / statistics)   2: no halo prefetch + stash inside the loop   4: no weight prefetch + stash
+//   8: no MFMA stage body
+#ifndef P8_ABLATE
+#define P8_ABLATE 0
+#endif
+
 struct P8Args {
   const float* X;
   const float* Wp;
@@ -87,7 +94,8 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   float* Wbuf = smem + 2 * av * 16;                              // [NWB][WT][4][BN][4]
   double* Ss = reinterpret_cast<double*>(Wbuf + NWB * WST4 * 4); // [WM][BN][2]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: the tile arithmetic below stays on the scalar unit
   const int li = lane & 15, lg = lane >> 4;
   const int wm = wave % WM, wn = wave / WM;
   const int cout0 = blockIdx.y * BN;
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   const int nch_all = cd.Cin16 >> 4;
   const int c0 = (int)((long long)nch_all * blockIdx.z / gridDim.z), c1 = (int)((long long)nch_all * (blockIdx.z + 1) / gridDim.z);
   const int nch = c1 - c0;
-  const bool resident = nch * S <= NWB;            // every weight stage of this workgroup has its own LDS buffer: load once
+  (void)nch;
   float* Y = a.Y + (long long)blockIdx.z * a.slab_stride;
 
   // ---- items of this workgroup (XCD-aware: each XCD walks one contiguous eighth of the list, its workgroups side by side)
@@ -122,7 +130,7 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   unsigned wrel[NW4];
 #pragma unroll
   for (int u = 0; u < NW4; ++u) {
-    const int q = tid + u * 512;
+    const int q = (tid + u * 512 < WST4) ? tid + u * 512 : tid;      // tail threads repeat their first float4: no predicates
     const int co = q % BN, cig = (q / BN) & 3, tl = q / (4 * BN);
     const int kd = tl % KD, kw = (tl / KD) % 3, khl = tl / (3 * KD);
     const int tap0 = (KD == 3 ? kd * 9 : 0) + khl * 3 + kw;
@@ -137,7 +145,7 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   if constexpr (MODE == P8_BRICK) {
 #pragma unroll
     for (int u = 0; u < AU; ++u) {
-      const int r = tid + u * 512;
+      const int r = (tid + u * 512 < HVB * 4) ? tid + u * 512 : tid;   // tail threads repeat their first float4
       const int hv = r >> 2, part = r & 3;
       ahd[u] = hv / 36; ahh[u] = (hv / 6) % 6; ahw[u] = hv % 6;
       arel[u] = (unsigned)(((ahd[u] * cd.H + ahh[u]) * cd.W + ahw[u]) * cd.Cin + part * 4);
@@ -158,6 +166,8 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   const int bbase = (lg * BN + wn * NT * 16 + li) * 4;   // B fragment of local tap 0; + tl * 4 * BN * 4 per tap, + nt * 64
 
   f32x4 acc[MT][NT];
+  f32x4 acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};   // MT * NT == 1: a lone accumulator would serialise on the 40-cycle MFMA latency
+  constexpr bool TWOACC = (MT * NT == 1);
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -170,20 +180,23 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   }
 
   // ---- staging helpers
+  // Every load is issued unconditionally (invalid lanes read the tile-independent safe address X) and the validity bits are
+  // applied when the registers are finally stored to LDS one stage later: `v = 0; if (ok) v = load` makes hipcc wait for each
+  // load at the merge point of its branch, i.e. one exposed L2 / HBM round trip per float4 at the top of every stage.
   float4 wreg[NW4], areg[NA4];
-  auto wfetch = [&](int c, int s) {
+  unsigned aok = 0;
+  auto wfetch = [&](int c, int s) __attribute__((always_inline)) {
     const float* wb = a.Wp + (long long)s * w_stage_step + (long long)c * w_chunk_step + (long long)cout0 * 4;
 #pragma unroll
-    for (int u = 0; u < NW4; ++u)
-      if (tid + u * 512 < WST4) wreg[u] = ld4(wb + wrel[u]);
+    for (int u = 0; u < NW4; ++u) wreg[u] = ld4(wb + wrel[u]);
   };
-  auto wstash = [&](float* dst) {
+  auto wstash = [&](float* dst) __attribute__((always_inline)) {
 #pragma unroll
-    for (int u = 0; u < NW4; ++u)
-      if (tid + u * 512 < WST4) st4(dst + (tid + u * 512) * 4, wreg[u]);
+    for (int u = 0; u < NW4; ++u) st4(dst + ((tid + u * 512 < WST4) ? tid + u * 512 : tid) * 4, wreg[u]);
   };
-  auto afetch = [&](int t, int c) {
+  auto afetch = [&](int t, int c) __attribute__((always_inline)) {
     const bool cok = c * 16 + apart * 4 < cd.Cin;
+    aok = 0;
     if constexpr (MODE == P8_BRICK) {
       const int g = t / a.items_per_group, lb0 = (t - g * a.items_per_group) * NB;
 #pragma unroll
@@ -196,11 +209,10 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
         const float* xb = a.X + ((((long long)n * cd.D + (d0 - 1)) * cd.H + (h0 - 1)) * cd.W + (w0 - 1)) * cd.Cin + c * 16;
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          const bool ok = bok && cok && tid + u * 512 < HVB * 4 && (unsigned)(d0 - 1 + ahd[u]) < (unsigned)cd.D &&
+          const bool ok = bok && cok && (unsigned)(d0 - 1 + ahd[u]) < (unsigned)cd.D &&
                           (unsigned)(h0 - 1 + ahh[u]) < (unsigned)cd.H && (unsigned)(w0 - 1 + ahw[u]) < (unsigned)cd.W;
-          if (ok) v = ld4(xb + arel[u]);
-          areg[b * AU + u] = v;
+          areg[b * AU + u] = ld4(ok ? xb + arel[u] : a.X);
+          aok |= (ok ? 1u : 0u) << (b * AU + u);
         }
       }
     } else {
@@ -208,30 +220,32 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
       const float* xb = a.X + ((long long)n * a.V + (m0 - a.R)) * cd.Cin + c * 16 + apart * 4;
 #pragma unroll
       for (int u = 0; u < NA4; ++u) {
-        const int rv = (tid + u * 512) >> 2;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (cok && rv < av && (unsigned)(m0 - a.R + rv) < (unsigned)a.V) v = ld4(xb + (long long)rv * cd.Cin);
-        areg[u] = v;
+        const int f = (tid + u * 512 < av * 4) ? tid + u * 512 : (av - 1) * 4 + apart;   // tail threads repeat the last voxel
+        const int rv = f >> 2;
+        const bool ok = cok && (unsigned)(m0 - a.R + rv) < (unsigned)a.V;
+        areg[u] = ld4(ok ? xb + (long long)rv * cd.Cin : a.X);
+        aok |= (ok ? 1u : 0u) << u;
       }
     }
   };
-  auto astash = [&](float* dst) {
+  auto astash = [&](float* dst) __attribute__((always_inline)) {
     if constexpr (MODE == P8_BRICK) {
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
         for (int u = 0; u < AU; ++u)
-          if (tid + u * 512 < HVB * 4) st4(dst + b * HVB * 16 + (tid + u * 512) * 4, areg[b * AU + u]);
+          st4(dst + b * HVB * 16 + ((tid + u * 512 < HVB * 4) ? tid + u * 512 : tid) * 4,
+              ((aok >> (b * AU + u)) & 1u) ? areg[b * AU + u] : make_float4(0.f, 0.f, 0.f, 0.f));
     } else {
 #pragma unroll
       for (int u = 0; u < NA4; ++u)
-        if (((tid + u * 512) >> 2) < av) st4(dst + (tid + u * 512) * 4, areg[u]);
+        st4(dst + ((tid + u * 512 < av * 4) ? tid + u * 512 : (av - 1) * 4 + apart) * 4, ((aok >> u) & 1u) ? areg[u] : make_float4(0.f, 0.f, 0.f, 0.f));
     }
   };
 
   // FLAT: per M tile of this lane, bit tl of amask = "tap tl stays inside the sample" (and the voxel itself exists)
   unsigned amask[MT];
-  auto flat_masks = [&](int t) {
+  auto flat_masks = [&](int t) __attribute__((always_inline)) {
     const int n = t / a.tiles_per_sample, m0 = (t - n * a.tiles_per_sample) * BM;
     (void)n;
 #pragma unroll
@@ -261,7 +275,7 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
   int cur_g = st.partial ? tile / a.items_per_group : 0;
-  auto stats_flush8 = [&](int g) {
+  auto stats_flush8 = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       double x = s1[nt], y = s2[nt];
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   };
 
   // ---- epilogue of one item: accumulators -> Y (+ bias, += when asked), statistics, accumulators = 0
-  auto epilogue = [&](int t) {
+  auto epilogue = [&](int t) __attribute__((always_inline)) {
     const bool want_stats = st.partial != nullptr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -318,8 +332,371 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
           for (int r = 0; r < 4; ++r) {
             if (rok[r]) {
               float* p = Y + row0 + (long long)r * rstep + co;
+              float v = acc[mt][nt][r];
+              if (TWOACC) v += acc1[r];
+              v += bv[nt];
+              *p = v;
+              if (want_stats) { s1[nt] += (double)v; s2[nt] += (double)v * (double)v; }
+            }
+          }
+        }
+        acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    acc1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+  };
+
+  // ---- one stage of MFMAs out of LDS.  Explicit software pipeline: the operand fragments of micro-step j + 1 (one tap) are
+  // read from LDS BEFORE the MFMAs of micro-step j are issued (two register sets; sched_barrier keeps hipcc from sinking the
+  // reads back to their first use).  A tap is only 4 * MT * NT MFMAs = 128 .. 512 matrix-pipe cycles: with reads issued
+  // just-in-time the two waves of a SIMD cannot cover the LDS round trip (measured, first version of this kernel: the
+  // 128-channel level ran its stages at 60 % of the MFMA rate, the 64-channel level at 84 %).
+  auto compute = [&](const float* Ab, const float* Wb, int s) __attribute__((always_inline)) {
+    if constexpr (MODE == P8_BRICK) {
+      float4 ap[2][MT + 2], bb[2][NT];
+      auto ldA = [&](int grp, int set) __attribute__((always_inline)) {      // the MT + 2 d-planes this wave's d-slices touch through the three kd taps of (kh, kw)
+        const int kh = s * KHS + grp / 3, kw = grp % 3;
+#pragma unroll
+        for (int p = 0; p < MT + 2; ++p) ap[set][p] = ld4(Ab + abase + ((p * 6 + kh) * 6 + kw) * 16);
+      };
+      auto ldB = [&](int tl, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bb[set][nt] = ld4(Wb + tl * 4 * BN * 4 + bbase + nt * 64);
+      };
+      ldA(0, 0);
+      ldB(0, 0);
+#pragma unroll
+      for (int tl = 0; tl < WT; ++tl) {       // tl = (khl * 3 + kw) * 3 + kd
+        const int grp = tl / 3, kd = tl % 3;
+        if (tl + 1 < WT) {
+          if ((tl + 1) % 3 == 0) ldA(grp + 1, (grp + 1) & 1);
+          ldB(tl + 1, (tl + 1) & 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float4 av4 = ap[grp & 1][mt + kd], bv4 = bb[tl & 1][nt];
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.x, bv4.x, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.y, bv4.y, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.z, bv4.z, acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.w, bv4.w, acc[mt][nt], 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      const int hw = cd.H * cd.W;
+      float4 aa[2][MT], bb[2][NT];
+      auto ldAB = [&](int tl, int set) __attribute__((always_inline)) {      // tl = (khl * 3 + kw) * KD + kd
+        const int kd = tl % KD, kw = (tl / KD) % 3, kh = s * KHS + tl / (3 * KD);
+        const int off = ((kd - PD) * hw + (kh - 1) * cd.W + (kw - 1)) * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) aa[set][mt] = ld4(Ab + abase + mt * GM0_STRIDE + off);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bb[set][nt] = ld4(Wb + tl * 4 * BN * 4 + bbase + nt * 64);
+      };
+      ldAB(0, 0);
+#pragma unroll
+      for (int tl = 0; tl < WT; ++tl) {
+        if (tl + 1 < WT) ldAB(tl + 1, (tl + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const int tg = s * WT + tl;           // global tap index in mask order ((kh * 3 + kw) * KD + kd)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          float4 av4 = aa[tl & 1][mt];
+          if (!((amask[mt] >> tg) & 1u)) av4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const float4 bv4 = bb[tl & 1][nt];
+            if constexpr (TWOACC) {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.x, bv4.x, acc[mt][nt], 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.y, bv4.y, acc1, 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.z, bv4.z, acc[mt][nt], 0, 0, 0);
+              acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.w, bv4.w, acc1, 0, 0, 0);
+            } else {
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.x, bv4.x, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.y, bv4.y, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.z, bv4.z, acc[mt][nt], 0, 0, 0);
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.w, bv4.w, acc[mt][nt], 0, 0, 0);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ---- the stage sequence.  Control flow is arranged so that every prefetch (issue -> stash) is STRAIGHT-LINE code: a chunk
+  // is S stages unrolled at compile time, all chunks but the last of the workgroup run through chunk_body<false>, the last one
+  // through chunk_body<true> (no prefetch).  With `if (has_next) fetch ... if (has_next) stash` hipcc's wait-count pass cannot
+  // prove on the loop back edge that the prefetch registers have landed and drains vmcnt to 0 -- i.e. the epilogue's stores --
+  // at the top of every stage (measured: the 16-channel layer at 64 % instead of 79 %).
+  constexpr bool RES = (NWB == 1);                 // single weight stage in total (checked by the host): loaded once
+  int c = c0, k = 0;                               // chunk counter k: halo buffer k & 1, weight buffer (k * S + s) & 1
+  afetch(tile, c);
+  wfetch(c, 0);
+  wstash(Wbuf);
+  astash(Abuf);
+  if (MODE == P8_FLAT) flat_masks(tile);
+  BCP_LDS_BARRIER();
+
+  auto chunk_body = [&](auto last_tag, int nt_, int nc) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_tag)::value;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      const int q = k * S + s;
+      const bool more = !LAST || s + 1 < S;        // a stage follows inside this workgroup (compile time per unrolled s)
+      if (more && !RES && !(P8_ABLATE & 4)) {
+        if (s + 1 < S) wfetch(c, s + 1); else wfetch(nc, 0);
+      }
+      if (!LAST && s == S - 1 && !(P8_ABLATE & 2)) afetch(nt_, nc);
+      if (!(P8_ABLATE & 8)) compute(Abuf + (k & 1) * av * 16, Wbuf + (RES ? 0 : (q & 1)) * WST4 * 4, s);
+      if (more && !RES && !(P8_ABLATE & 4)) wstash(Wbuf + ((q + 1) & 1) * WST4 * 4);
+      if (!LAST && s == S - 1 && !(P8_ABLATE & 2)) astash(Abuf + ((k + 1) & 1) * av * 16);
+      if (s == S - 1 && c == c1 - 1) {             // item complete
+        if (st.partial) {
+          const int g = tile / a.items_per_group;
+          if (g != cur_g) { stats_flush8(cur_g); cur_g = g; }
+        }
+        if (!(P8_ABLATE & 1)) epilogue(tile);
+        else if (acc[0][0][0] == 1.2345e-30f) Y[tid] = acc[0][0][1];   // keep the accumulators alive
+        if (MODE == P8_FLAT && !LAST) flat_masks(nt_);
+      }
+      if (more) BCP_LDS_BARRIER();
+    }
+  };
+  for (;;) {
+    int nc = c + 1, nt_ = tile;
+    if (nc == c1) { nc = c0; nt_ = tile + t_step; }
+    if (nt_ >= t_end) break;
+    chunk_body(std::integral_constant<bool, false>{}, nt_, nc);
+    ++k;
+    c = nc; tile = nt_;
+  }
+  chunk_body(std::integral_constant<bool, true>{}, tile, c);
+  if (st.partial) stats_flush8(cur_g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PING-PONG variant (BRICK mode).  Measured with the lock-step kernel above (tools/ablate_p8.sh): everything that is not an
+// MFMA -- tile arithmetic, the halo / weight prefetch and its LDS stores, the epilogue's stores and statistics -- costs
+// 119 / 34 / 15 us per launch at the 16 / 32 / 64-channel levels and NONE of it hides under the 188 / 98 / 47 us of MFMA work:
+// the eight waves of a workgroup march through the same phases between the same barriers, so both waves of a SIMD leave the
+// matrix pipe idle at the same time.  Here the workgroup is two GROUPS of four waves (one wave per SIMD each) that work on
+// different items and strictly alternate roles, one barrier per phase:
+//     phase 2j     group 0: MFMAs of its stage j          group 1: epilogue of its finished item, prefetch + stash of its
+//     phase 2j + 1 group 1: MFMAs of its stage j                   next halo (own buffer) and -- group 1 only -- of the weights
+//                  group 0: epilogue / halo prefetch               of stage j + 1 (shared, double-buffered)
+// so the matrix pipe of every SIMD always has exactly one wave in a pure LDS-read + MFMA loop (software-pipelined: the
+// fragments of tap t + 1 are read before the MFMAs of tap t) while its partner does everything else.  Both groups walk the
+// same (item, chunk, tap-group) stage sequence on different bricks, which is what lets them share the weight stages.
+// ------------------------------------------------------------------------------------------------
+struct FastDiv {   // n / d for 0 <= n < 2^31 (host: make_fastdiv)
+  unsigned m; int sh;
+  __device__ __forceinline__ int div(int n) const { return sh < 0 ? n : (int)(__umulhi((unsigned)n, m) >> sh); }
+};
+static FastDiv make_fastdiv(int d) {
+  FastDiv f;
+  if (d <= 1) { f.m = 0; f.sh = -1; return f; }
+  int s = 0;
+  while ((1LL << s) < d) ++s;
+  f.m = (unsigned)(((1ULL << (31 + s)) / (unsigned)d) + 1ULL);
+  f.sh = s - 1;
+  return f;
+}
+
+struct PPArgs {
+  const float* X;
+  const float* Wp;
+  const float* bias;
+  float* Y;
+  ConvDims cd;
+  int n_items;            // workgroup items = pairs of group items
+  int gipg;               // group items per statistics group (even)
+  int bricks_per_group;   // bricks of one statistics group
+  int bd, bh, bw, spg;    // bricks per sample along d / h / w; samples per statistics group
+  FastDiv f_gipg, f_bps, f_bhw, f_bw;
+  int accumulate;
+  long long slab_stride;
+  double* stat_partial;   // [G][rows = gridDim.x][C][2] or nullptr
+  int G;
+};
+
+template <int GM, int GN, int MT, int NT, int WT, int NWB>
+__global__ __launch_bounds__(512) void k_c3pp(PPArgs a) {
+  constexpr int T = 27, S = T / WT, KHS = WT / 9, HVB = 216;
+  constexpr int NBG = GM * MT / 4;                 // bricks of a group item
+  constexpr int BN = GN * NT * 16;
+  constexpr int AG = NBG * HVB * 16;               // floats of one group's halo buffer
+  constexpr int AU = (HVB * 4 + 255) / 256;        // float4 slots per thread and brick (256 threads per group)
+  constexpr int WST4 = WT * 4 * BN, NW4 = (WST4 + 255) / 256;
+  constexpr bool RES = (NWB == 1);
+  constexpr int NSLOT = 4;                         // statistics groups a workgroup may touch
+  static_assert(GM * GN == 4 && (GM * MT) % 4 == 0 && 4 % MT == 0 && T % WT == 0 && WT % 9 == 0, "bad configuration");
+  const ConvDims& cd = a.cd;
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  float* smem = reinterpret_cast<float*>(smem4);
+  float* Abuf = smem;                                             // [2 groups][NBG][216][16]
+  float* Wbuf = smem + 2 * AG;                                    // [NWB][WT][4][BN][4]
+  double* Ss = reinterpret_cast<double*>(Wbuf + NWB * WST4 * 4);  // [NSLOT][8 waves][NT * 16][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, gtid = tid & 255;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wg = wave & 3;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wg % GM, wn = wg / GM;
+  const int cout0 = blockIdx.y * BN;
+  const int cin4 = cd.Cin16 >> 2;
+  const int nch_all = cd.Cin16 >> 4;
+  const int c0 = (int)((long long)nch_all * blockIdx.z / gridDim.z), c1 = (int)((long long)nch_all * (blockIdx.z + 1) / gridDim.z);
+  float* Y = a.Y + (long long)blockIdx.z * a.slab_stride;
+  float* Ag = Abuf + grp * AG;
+
+  // ---- items of this workgroup (XCD-aware, as k_c3p)
+  int t_first, t_end, t_step;
+  if (gridDim.x % 8 == 0) {
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    t_step = gridDim.x >> 3;
+    t_first = (int)((long long)a.n_items * xcd / 8) + j;
+    t_end = (int)((long long)a.n_items * (xcd + 1) / 8);
+  } else {
+    t_first = blockIdx.x; t_end = a.n_items; t_step = gridDim.x;
+  }
+  const bool want_stats = a.stat_partial != nullptr;
+  {   // statistics scratch: every (slot, wave) slice starts at zero
+    for (int i = tid; i < NSLOT * 8 * NT * 16 * 2; i += 512) Ss[i] = 0.0;
+  }
+  const int n_my = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;
+  const int g_first = (2 * t_first) / (a.gipg > 0 ? a.gipg : 1);   // first statistics group this workgroup touches
+
+  // ---- launch-invariant staging maps (256 threads of a group)
+  unsigned wrel[NW4];
+#pragma unroll
+  for (int u = 0; u < NW4; ++u) {
+    const int q = (gtid + u * 256 < WST4) ? gtid + u * 256 : gtid;
+    const int co = q % BN, cig = (q / BN) & 3, tl = q / (4 * BN);
+    const int kd = tl % 3, kw = (tl / 3) % 3, khl = tl / 9;
+    const int tap0 = kd * 9 + khl * 3 + kw;
+    wrel[u] = (unsigned)((((long long)tap0 * cin4 + cig) * cd.Cout16 + co) * 4);
+  }
+  const long long w_stage_step = (long long)KHS * 3 * cin4 * cd.Cout16 * 4, w_chunk_step = (long long)4 * cd.Cout16 * 4;
+  unsigned arel[AU];
+  int ahd[AU], ahh[AU], ahw[AU];
+#pragma unroll
+  for (int u = 0; u < AU; ++u) {
+    const int r = (gtid + u * 256 < HVB * 4) ? gtid + u * 256 : gtid;
+    const int hv = r >> 2, part = r & 3;
+    ahd[u] = hv / 36; ahh[u] = (hv / 6) % 6; ahw[u] = hv % 6;
+    arel[u] = (unsigned)(((ahd[u] * cd.H + ahh[u]) * cd.W + ahw[u]) * cd.Cin + part * 4);
+  }
+  const int apart = gtid & 3;
+
+  // ---- per-lane operand addressing
+  const int gm0 = wm * MT;
+  const int abase = ((gm0 >> 2) * HVB + ((gm0 & 3) * 6 + (li >> 2)) * 6 + (li & 3)) * 16 + lg * 4;
+  const int bbase = (lg * BN + wn * NT * 16 + li) * 4;
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int co = cout0 + wn * NT * 16 + nt * 16 + li;
+    bv[nt] = (a.bias && co < cd.Cout) ? a.bias[co] : 0.f;
+  }
+  double s1[NT], s2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
+
+  // group item gi -> statistics group, first brick, validity
+  struct Geo { int n, d0, h0, w0; bool ok; };
+  auto brick_geo = [&](int gi, int b) __attribute__((always_inline)) {
+    const int sg = a.f_gipg.div(gi), lb = (gi - sg * a.gipg) * NBG + b;
+    const int ns = a.f_bps.div(lb), rb = lb - ns * (a.bd * a.bh * a.bw);
+    const int di = a.f_bhw.div(rb), r2 = rb - di * (a.bh * a.bw);
+    const int hi = a.f_bw.div(r2), wi = r2 - hi * a.bw;
+    Geo g;
+    g.n = sg * a.spg + ns; g.d0 = di * 4; g.h0 = hi * 4; g.w0 = wi * 4; g.ok = lb < a.bricks_per_group;
+    return g;
+  };
+
+  float4 wreg[NW4], areg[NBG * AU];
+  unsigned aok = 0;
+  auto wfetch = [&](int c, int s) __attribute__((always_inline)) {
+    const float* wb = a.Wp + (long long)s * w_stage_step + (long long)c * w_chunk_step + (long long)cout0 * 4;
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) wreg[u] = ld4(wb + wrel[u]);
+  };
+  auto wstash = [&](float* dst) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) st4(dst + ((gtid + u * 256 < WST4) ? gtid + u * 256 : gtid) * 4, wreg[u]);
+  };
+  auto afetch = [&](int gi, int c) __attribute__((always_inline)) {
+    const bool cok = c * 16 + apart * 4 < cd.Cin;
+    aok = 0;
+#pragma unroll
+    for (int b = 0; b < NBG; ++b) {
+      const Geo g = brick_geo(gi, b);
+      const float* xb = a.X + ((((long long)g.n * cd.D + (g.d0 - 1)) * cd.H + (g.h0 - 1)) * cd.W + (g.w0 - 1)) * cd.Cin + c * 16;
+#pragma unroll
+      for (int u = 0; u < AU; ++u) {
+        const bool ok = g.ok && cok && (unsigned)(g.d0 - 1 + ahd[u]) < (unsigned)cd.D && (unsigned)(g.h0 - 1 + ahh[u]) < (unsigned)cd.H &&
+                        (unsigned)(g.w0 - 1 + ahw[u]) < (unsigned)cd.W;
+        areg[b * AU + u] = ld4(ok ? xb + arel[u] : a.X);
+        aok |= (ok ? 1u : 0u) << (b * AU + u);
+      }
+    }
+  };
+  auto astash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int b = 0; b < NBG; ++b)
+#pragma unroll
+      for (int u = 0; u < AU; ++u)
+        st4(Ag + b * HVB * 16 + ((gtid + u * 256 < HVB * 4) ? gtid + u * 256 : gtid) * 4,
+            ((aok >> (b * AU + u)) & 1u) ? areg[b * AU + u] : make_float4(0.f, 0.f, 0.f, 0.f));
+  };
+
+  int cur_slot = -1;   // statistics slot (group - g_first) of the sums in s1 / s2
+  auto stats_dump = [&]() __attribute__((always_inline)) {   // this wave's sums of its current statistics group -> its LDS slice
+    if (cur_slot < 0) return;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      double x = s1[nt], y = s2[nt];
+      x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
+      y += __shfl_xor(y, 16); y += __shfl_xor(y, 32);
+      if (lg == 0) {
+        double* d = Ss + ((((long long)cur_slot * 8 + wave) * NT + nt) * 16 + li) * 2;
+        d[0] = x; d[1] = y;
+      }
+      s1[nt] = 0.0; s2[nt] = 0.0;
+    }
+  };
+
+  auto epilogue = [&](int gi) __attribute__((always_inline)) {
+    if (want_stats) {
+      const int slot = a.f_gipg.div(gi) - g_first;
+      if (slot != cur_slot) { stats_dump(); cur_slot = slot < NSLOT ? slot : NSLOT - 1; }
+    }
+    const Geo g = brick_geo(gi, gm0 >> 2);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int d = g.d0 + ((gm0 + mt) & 3), h = g.h0 + lg;
+      const bool ok = g.ok && d < cd.D && h < cd.H;
+      const long long row0 = ((((long long)g.n * cd.D + d) * cd.H + h) * cd.W + g.w0) * cd.Cout;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int co = cout0 + wn * NT * 16 + nt * 16 + li;
+        if (co < cd.Cout) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (ok && g.w0 + r < cd.W) {
+              float* p = Y + row0 + (long long)r * cd.Cout + co;
               float v = acc[mt][nt][r] + bv[nt];
-              if (a.accumulate) v += *p;
               *p = v;
               if (want_stats) { s1[nt] += (double)v; s2[nt] += (double)v * (double)v; }
             }
@@ -330,116 +707,111 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
     }
   };
 
-  // ---- one stage of MFMAs out of LDS
-  auto compute = [&](const float* Ab, const float* Wb, int s) {
-    if constexpr (MODE == P8_BRICK) {
+  auto compute = [&](const float* Wb, int s) __attribute__((always_inline)) {
+    float4 ap[2][MT + 2], bb[2][NT];
+    auto ldA = [&](int kg, int set) __attribute__((always_inline)) {
+      const int kh = s * KHS + kg / 3, kw = kg % 3;
 #pragma unroll
-      for (int khl = 0; khl < KHS; ++khl) {
-        const int kh = s * KHS + khl;
+      for (int p = 0; p < MT + 2; ++p) ap[set][p] = ld4(Ag + abase + ((p * 6 + kh) * 6 + kw) * 16);
+    };
+    auto ldB = [&](int tl, int set) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          // the MT + 2 d-planes this wave's d-slices touch through the three kd taps of (kh, kw)
-          float4 ap[MT + 2];
+      for (int nt = 0; nt < NT; ++nt) bb[set][nt] = ld4(Wb + tl * 4 * BN * 4 + bbase + nt * 64);
+    };
+    ldA(0, 0);
+    ldB(0, 0);
 #pragma unroll
-          for (int p = 0; p < MT + 2; ++p) ap[p] = ld4(Ab + abase + ((p * 6 + kh) * 6 + kw) * 16);
+    for (int tl = 0; tl < WT; ++tl) {       // tl = (khl * 3 + kw) * 3 + kd
+      const int kg = tl / 3, kd = tl % 3;
+      if (tl + 1 < WT) {
+        if ((tl + 1) % 3 == 0) ldA(kg + 1, (kg + 1) & 1);
+        ldB(tl + 1, (tl + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int kd = 0; kd < 3; ++kd) {
-            const int tl = (khl * 3 + kw) * 3 + kd;
-            float4 b[NT];
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wb + tl * 4 * BN * 4 + bbase + nt * 64);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[mt + kd].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[mt + kd].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[mt + kd].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[mt + kd].w, b[nt].w, acc[mt][nt], 0, 0, 0);
-              }
-          }
+        for (int nt = 0; nt < NT; ++nt) {
+          const float4 av4 = ap[kg & 1][mt + kd], bv4 = bb[tl & 1][nt];
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.x, bv4.x, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.y, bv4.y, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.z, bv4.z, acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.w, bv4.w, acc[mt][nt], 0, 0, 0);
         }
-      }
-    } else {
-      const int hw = cd.H * cd.W;
-#pragma unroll
-      for (int khl = 0; khl < KHS; ++khl) {
-        const int kh = s * KHS + khl;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-          for (int kd = 0; kd < KD; ++kd) {
-            const int tl = (khl * 3 + kw) * KD + kd, tg = (kh * 3 + kw) * KD + kd;
-            const int off = ((kd - PD) * hw + (kh - 1) * cd.W + (kw - 1)) * 16;
-            float4 av4[MT], b[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              av4[mt] = ld4(Ab + abase + mt * GM0_STRIDE + off);
-              if (!((amask[mt] >> tg) & 1u)) av4[mt] = make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = ld4(Wb + tl * 4 * BN * 4 + bbase + nt * 64);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt) {
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[mt].x, b[nt].x, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[mt].y, b[nt].y, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[mt].z, b[nt].z, acc[mt][nt], 0, 0, 0);
-                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4[mt].w, b[nt].w, acc[mt][nt], 0, 0, 0);
-              }
-          }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
-  // ---- prologue: first halo + first weight stage(s)
-  int c = c0, s = 0, k = 0, q = 0;
-  afetch(tile, c);
-  if (resident) {
-    for (int i = 0; i < nch * S; ++i) {
-      wfetch(c0 + i / S, i % S);
-      wstash(Wbuf + i * WST4 * 4);
+  if (n_my > 0) {
+    const int nch = c1 - c0, spi = nch * S;      // stages per item
+    const int J = n_my * spi;                    // stages of each group
+    // stage j of a group = (its item j / spi, chunk c0 + (j % spi) / S, tap group j % S)
+    auto chunk_start = [&](int j) __attribute__((always_inline)) { return S == 1 || (j % S) == 0; };
+    auto fetch_chunk_of = [&](int j) __attribute__((always_inline)) {
+      const int it = j / spi, r = j - it * spi;
+      afetch(2 * (t_first + it * t_step) + grp, c0 + r / S);
+    };
+    auto fetch_weights_of = [&](int j) __attribute__((always_inline)) {
+      const int r = j % spi;
+      wfetch(c0 + r / S, r % S);
+    };
+    // ---- prologue.  Prefetch distance is TWO phases: what a group stores to LDS in a non-compute phase was requested in its
+    // previous non-compute phase and stayed in registers through its compute phase (a same-phase request -> store exposes the
+    // L2 / HBM latency: measured 334 us instead of 305 us for the 16-channel layer).
+    if (grp == 0) {
+      fetch_chunk_of(0); astash();
+      if (1 < J && chunk_start(1)) fetch_chunk_of(1);
+    } else {
+      wfetch(c0, 0); wstash(Wbuf);
+      fetch_chunk_of(0);
+      if (!RES && 1 < J) fetch_weights_of(1);
     }
-  } else {
-    wfetch(c, 0);
-    wstash(Wbuf);
-  }
-  astash(Abuf);
-  if (MODE == P8_FLAT) flat_masks(tile);
-  BCP_LDS_BARRIER();
-
-  for (;;) {
-    // next stage
-    int ns = s + 1, nc = c, nt_ = tile;
-    if (ns == S) { ns = 0; nc = c + 1; }
-    if (nc == c1) { nc = c0; nt_ = tile + t_step; }
-    const bool has_next = nt_ < t_end;
-    const bool new_chunk = has_next && ns == 0;
-    if (has_next) {
-      if (!resident) wfetch(nc, ns);
-      if (new_chunk) afetch(nt_, nc);
-    }
-    compute(Abuf + (k & 1) * av * 16, Wbuf + (resident ? ((c - c0) * S + s) : (q & 1)) * WST4 * 4, s);
-    if (has_next) {
-      if (!resident) wstash(Wbuf + ((q + 1) & 1) * WST4 * 4);
-      if (new_chunk) astash(Abuf + ((k + 1) & 1) * av * 16);
-    }
-    if (c == c1 - 1 && s == S - 1) {            // item complete
-      if (st.partial) {
-        const int g = tile / a.items_per_group;
-        if (g != cur_g) { stats_flush8(cur_g); cur_g = g; }
-      }
-      epilogue(tile);
-      if (MODE == P8_FLAT && has_next) flat_masks(nt_);
-    }
-    if (!has_next) break;
     BCP_LDS_BARRIER();
-    if (new_chunk) ++k;
-    ++q;
-    s = ns; c = nc; tile = nt_;
+
+    int cj = 0, cs = 0;                          // next stage of this group, its tap group
+    for (int p = 0; p <= 2 * J; ++p) {
+      if (((p & 1) == grp)) {
+        if (cj < J && !(P8_ABLATE & 8)) compute(Wbuf + (RES ? 0 : (cj & 1)) * WST4 * 4, cs);
+        if (cj < J) { ++cj; if (++cs == S) cs = 0; }
+      } else if (!(P8_ABLATE & 16)) {
+        // cj = the stage this group computes in the next phase; cj - 1 = the one it has just computed
+        if (cj < J && chunk_start(cj) && !(grp == 0 && cj == 0) && !(P8_ABLATE & 2)) astash();   // requested one non-compute phase ago
+        const int jw = (p >> 1) + 1;             // group 1, phase 2j: the weights of stage j + 1 go to LDS, those of j + 2 are requested
+        if (!RES && grp == 1 && jw < J) wstash(Wbuf + (jw & 1) * WST4 * 4);
+        if (cj > 0 && (cj % spi) == 0 && !(P8_ABLATE & 1)) epilogue(2 * (t_first + (cj / spi - 1) * t_step) + grp);
+        if (cj + 1 < J && chunk_start(cj + 1) && !(P8_ABLATE & 2)) fetch_chunk_of(cj + 1);
+        if (!RES && grp == 1 && jw + 1 < J) fetch_weights_of(jw + 1);
+      }
+      if (p < 2 * J) BCP_LDS_BARRIER();
+    }
   }
-  if (st.partial) stats_flush8(cur_g);
+  if (P8_ABLATE & 17) {   // measurement builds without the epilogue: keep every accumulator alive
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(Y + ((long long)(blockIdx.x * 512 + tid) * MT * NT + mt * NT + nt) * 4) = acc[mt][nt];
+  }
+  // ---- statistics: per-wave slices -> one partial row per workgroup and touched group (deterministic order)
+  if (want_stats) {
+    stats_dump();
+    __syncthreads();
+    for (int i = tid; i < a.G * BN; i += 512) {
+      const int g = i / BN, c = i % BN, slot = g - g_first;
+      if (cout0 + c < cd.Cout) {
+        const int wn_c = c / (NT * 16), cc2 = c % (NT * 16);
+        double x = 0.0, y = 0.0;          // groups this workgroup never touched read as zero
+        if (slot >= 0 && slot < NSLOT) {
+          for (int w = 0; w < 8; ++w) {
+            if (((w & 3) / GM) != wn_c) continue;          // waves of the other channel half hold other channels
+            const double* d = Ss + (((long long)slot * 8 + w) * NT * 16 + cc2) * 2;
+            x += d[0]; y += d[1];
+          }
+        }
+        double* dst = a.stat_partial + (((long long)g * gridDim.x + blockIdx.x) * cd.Cout + cout0 + c) * 2;
+        dst[0] = x; dst[1] = y;
+      }
+    }
+  }
 }
 
 // y (+)= bias + sum_k part[k]  (split-K epilogue; deep levels only: <= 1 MB)
@@ -488,10 +860,8 @@ static bool p8_plan(P8Plan& pl, const ConvDims& cd, int KD, int G, bool want_sta
   a.cd = cd;
   int BM, BN, NB = 0, WT, NWB;
   const int nch = cd.Cin16 / 16;
-  if (KD == 3 && cd.Cout16 == 16 && cd.Cin16 == 16 && (force ? o.conv3_p8 == 2 : vox >= 256LL * 1024)) { pl.cfg = 0; pl.mode = P8_BRICK; BM = 256; BN = 16; NB = 4; WT = 27; NWB = 1; }
-  else if (KD == 3 && cd.Cout16 % 32 == 0 && cd.Cout16 % 64 != 0 && (force ? o.conv3_p8 == 2 : vox >= 64LL * 1024)) { pl.cfg = 1; pl.mode = P8_BRICK; BM = 256; BN = 32; NB = 4; WT = 9; NWB = 2; }
-  else if (KD == 3 && cd.Cout16 % 64 == 0 && (force ? o.conv3_p8 == 2 : (vox >= 16LL * 1024 && 64 + 2 * R > kFlatAvMax))) { pl.cfg = 2; pl.mode = P8_BRICK; BM = 128; BN = 64; NB = 2; WT = 9; NWB = 2; }
-  else if (cd.Cout16 % 32 == 0 && 64 + 2 * R <= kFlatAvMax && (force || KD == 3)) { pl.cfg = KD == 3 ? 3 : 4; pl.mode = P8_FLAT; BM = 64; BN = 32; WT = KD == 3 ? 27 : 9; NWB = 2; }
+  (void)vox;
+  if (cd.Cout16 % 32 == 0 && 64 + 2 * R <= kFlatAvMax && (force || KD == 3)) { pl.cfg = KD == 3 ? 3 : 4; pl.mode = P8_FLAT; BM = 64; BN = 32; WT = KD == 3 ? 27 : 9; NWB = 2; }
   else return false;
   pl.slabs = cd.Cout16 / BN;
   pl.ksplit = 1;
@@ -537,11 +907,86 @@ static bool p8_plan(P8Plan& pl, const ConvDims& cd, int KD, int G, bool want_sta
   return true;
 }
 
+template <int GM, int GN, int MT, int NT, int WT, int NWB>
+static void pp_launch(const PPArgs& a, int P, int slabs, int ksplit, hipStream_t s) {
+  constexpr int NBG = GM * MT / 4, BN = GN * NT * 16;
+  const size_t lds = ((size_t)2 * NBG * 216 * 16 + (size_t)NWB * WT * 4 * BN * 4) * sizeof(float) + (size_t)4 * 8 * NT * 16 * 2 * sizeof(double);
+  auto kfn = k_c3pp<GM, GN, MT, NT, WT, NWB>;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(kfn, dim3(P, slabs, ksplit), dim3(512), lds, s, a);
+}
+
+// ping-pong configurations (BRICK): 0: BN 16 (16 -> 16 channels, single resident stage)  1: BN 32  2: BN 64
+static bool pp_plan(int& cfg, PPArgs& a, int& P, int& slabs, int& ksplit, int& stat_rows, const ConvDims& cd, int KD, int G, bool has_ws) {
+  const Options& o = options();
+  if (o.conv3_p8 == 0 || o.conv3_p8 == 3 || KD != 3) return false;
+  const bool force = o.conv3_p8 == 2;
+  const long long vps = (long long)cd.D * cd.H * cd.W, vox = vps * cd.N;
+  const int nch = cd.Cin16 / 16;
+  int NBG, BN;
+  if (cd.Cout16 == 16 && cd.Cin16 == 16 && (force || vox >= 256LL * 1024)) { cfg = 0; NBG = 2; BN = 16; }
+  else if (cd.Cout16 % 32 == 0 && cd.Cout16 % 64 != 0 && (force || vox >= 64LL * 1024)) { cfg = 1; NBG = 2; BN = 32; }
+  else if (cd.Cout16 % 64 == 0 && (force || vox >= 16LL * 1024)) { cfg = 2; NBG = 1; BN = 64; }
+  else return false;
+  if (G > 4 || (G > 0 && cd.N % G)) return false;          // statistics slots of a workgroup
+  a.cd = cd;
+  a.bd = cdiv(cd.D, 4); a.bh = cdiv(cd.H, 4); a.bw = cdiv(cd.W, 4);
+  const long long covered = (long long)a.bd * a.bh * a.bw * 64;
+  if (!force && covered * 4 > vps * 5) return false;       // partial bricks would waste more than a quarter of the MFMA rows
+  const int groups = G > 0 ? G : 1;
+  a.spg = cd.N / groups;
+  a.G = groups;
+  a.bricks_per_group = a.spg * a.bd * a.bh * a.bw;
+  a.gipg = 2 * cdiv(cdiv(a.bricks_per_group, NBG), 2);
+  a.n_items = groups * a.gipg / 2;
+  a.f_gipg = make_fastdiv(a.gipg); a.f_bps = make_fastdiv(a.bd * a.bh * a.bw); a.f_bhw = make_fastdiv(a.bh * a.bw); a.f_bw = make_fastdiv(a.bw);
+  slabs = cd.Cout16 / BN;
+  ksplit = 1;
+  if (has_ws && nch >= 2) {
+    int ks = 256 / (a.n_items * slabs);
+    if (ks > nch) ks = nch;
+    if (ks > 8) ks = 8;
+    if (ks >= 2) ksplit = ks;
+    if (o.splitk >= 1 && o.splitk <= 8 && o.splitk <= nch) ksplit = o.splitk;
+  }
+  if (cfg == 0 && nch != 1) return false;
+  int maxP = 256 / (slabs * ksplit);
+  if (maxP < 1) maxP = 1;
+  P = a.n_items < maxP ? a.n_items : maxP;
+  if (o.conv3_p > 0 && o.conv3_p < P) P = o.conv3_p;
+  stat_rows = ksplit == 1 ? P : 0;
+  return true;
+}
+
 int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
            double* stat_partial, int G, bool dry, hipStream_t s, bool* handled) {
   P8Plan pl;
   *handled = false;
   const bool want_stats = G > 0;
+  // "+=" into y is left to the kernels of conv3.hip: a conditional read-modify-write in the epilogue makes hipcc put a
+  // vmcnt(0) in front of EVERY store (eight serialised store round trips per item, measured 2.3 us of a 3 us phase)
+  if (accumulate) return 0;
+  {
+    PPArgs pa;
+    int cfg = 0, P = 0, slabs = 0, ksplit = 1, stat_rows = 0;
+    if (pp_plan(cfg, pa, P, slabs, ksplit, stat_rows, cd, KD, G, workspace != nullptr)) {
+      *handled = true;
+      if (dry) return want_stats ? stat_rows : 0;
+      const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
+      pa.X = x; pa.Wp = wp; pa.Y = y; pa.bias = bias; pa.accumulate = accumulate; pa.slab_stride = 0;
+      pa.stat_partial = (want_stats && stat_partial && stat_rows > 0) ? stat_partial : nullptr;
+      if (ksplit > 1) { pa.Y = (float*)workspace; pa.bias = nullptr; pa.accumulate = 0; pa.slab_stride = n; }
+      switch (cfg) {
+        case 0: pp_launch<4, 1, 2, 1, 27, 1>(pa, P, slabs, ksplit, s); break;
+        case 1: pp_launch<2, 2, 4, 1, 9, 2>(pa, P, slabs, ksplit, s); break;
+        default: pp_launch<2, 2, 2, 2, 9, 2>(pa, P, slabs, ksplit, s); break;
+      }
+      if (ksplit > 1)
+        hipLaunchKernelGGL(k_p8_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
+                           ksplit, n, cd.Cout, bias, y, accumulate);
+      return pa.stat_partial ? stat_rows : 0;
+    }
+  }
   if (!p8_plan(pl, cd, KD, G, want_stats, workspace != nullptr)) return 0;
   *handled = true;
   if (dry) return want_stats ? pl.stat_rows : 0;
@@ -552,9 +997,6 @@ int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const C
   const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
   if (pl.ksplit > 1) { a.Y = (float*)workspace; a.bias = nullptr; a.accumulate = 0; a.slab_stride = n; }
   switch (pl.cfg) {
-    case 0: p8_launch<3, P8_BRICK, 8, 1, 2, 1, 4, 27, 1, 0>(pl, s); break;
-    case 1: p8_launch<3, P8_BRICK, 4, 2, 4, 1, 4, 9, 2, 0>(pl, s); break;
-    case 2: p8_launch<3, P8_BRICK, 4, 2, 2, 2, 2, 9, 2, 0>(pl, s); break;
     case 3: p8_launch<3, P8_FLAT, 4, 2, 1, 1, 0, 27, 2, kFlatAvMax>(pl, s); break;
     case 4: p8_launch<1, P8_FLAT, 4, 2, 1, 1, 0, 9, 2, kFlatAvMax>(pl, s); break;
     default: set_error("p8_fwd: bad plan"); return BCP_EUNSUP;

@@ -34,12 +34,17 @@ def main():
     ap.add_argument("--variants", default="old:conv3_p8=0,wgrad_p8=0;new:conv3_p8=1,wgrad_p8=1")
     ap.add_argument("--ops", default="fwd_stats,dgrad,wgrad")
     ap.add_argument("--levels", default="16,32,64,128,256")
+    ap.add_argument("--lib", default="", help="library variant to load instead of the product libbcp_hip.so (measurements)")
     a = ap.parse_args()
     variants = []
     for v in a.variants.split(";"):
         name, _, opts = v.partition(":")
         variants.append((name, [tuple(o.split("=")) for o in opts.split(",") if o]))
-    ops = Ops.product()
+    if a.lib:
+        from bcp_amd import _lib
+        ops = Ops(_lib.Binding(a.lib))
+    else:
+        ops = Ops.product()
     dev = torch.device("cuda:0")
     N = a.batch
     want = set(a.ops.split(","))

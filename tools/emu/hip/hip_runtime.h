@@ -290,4 +290,5 @@ inline unsigned long long atomicMax(unsigned long long* p, unsigned long long v)
   while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_SEQ_CST, __ATOMIC_RELAXED)) {}
   return old;
 }
+inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
 inline int __clz(int x) { return x ? __builtin_clz((unsigned)x) : 32; }
