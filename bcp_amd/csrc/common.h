@@ -47,6 +47,7 @@ struct Options {
   int tn_groups = 0;        // k2s2 / 1x1 weight-gradient GEMM: cap on voxel groups (tests: force multi-chunk groups)
   int cc_tile = 0;          // largest-CC tile flavour
   int conv3_p8 = 1;         // persistent 8-wave pipeline conv: 0 off, 1 where it is the measured winner, 2 wherever it is valid
+  int conv3_p8_cfgs = 3;    // automatic choice: bit 0 = BN 32 bricks, bit 1 = BN 64 bricks, bit 2 = flat tiles.  Measured in the LA step (interleaved A/B, ms per step): none 9.03, flat only 9.19, BN 64 only 8.90, BN 32 only 8.99 -- the flat kernel is 18 % faster ALONE at the 128-channel level but its one-workgroup-per-CU grid keeps the other stream's kernels off the CUs
   int wgrad_p8 = 1;         // same for the weight-gradient kernels
 };
 Options& options();

@@ -478,342 +478,6 @@ __global__ __launch_bounds__(512) void k_c3p(P8Args a) {
   if (st.partial) stats_flush8(cur_g);
 }
 
-// ------------------------------------------------------------------------------------------------
-// PING-PONG variant (BRICK mode).  Measured with the lock-step kernel above (tools/ablate_p8.sh): everything that is not an
-// MFMA -- tile arithmetic, the halo / weight prefetch and its LDS stores, the epilogue's stores and statistics -- costs
-// 119 / 34 / 15 us per launch at the 16 / 32 / 64-channel levels and NONE of it hides under the 188 / 98 / 47 us of MFMA work:
-// the eight waves of a workgroup march through the same phases between the same barriers, so both waves of a SIMD leave the
-// matrix pipe idle at the same time.  Here the workgroup is two GROUPS of four waves (one wave per SIMD each) that work on
-// different items and strictly alternate roles, one barrier per phase:
-//     phase 2j     group 0: MFMAs of its stage j          group 1: epilogue of its finished item, prefetch + stash of its
-//     phase 2j + 1 group 1: MFMAs of its stage j                   next halo (own buffer) and -- group 1 only -- of the weights
-//                  group 0: epilogue / halo prefetch               of stage j + 1 (shared, double-buffered)
-// so the matrix pipe of every SIMD always has exactly one wave in a pure LDS-read + MFMA loop (software-pipelined: the
-// fragments of tap t + 1 are read before the MFMAs of tap t) while its partner does everything else.  Both groups walk the
-// same (item, chunk, tap-group) stage sequence on different bricks, which is what lets them share the weight stages.
-// ------------------------------------------------------------------------------------------------
-struct FastDiv {   // n / d for 0 <= n < 2^31 (host: make_fastdiv)
-  unsigned m; int sh;
-  __device__ __forceinline__ int div(int n) const { return sh < 0 ? n : (int)(__umulhi((unsigned)n, m) >> sh); }
-};
-static FastDiv make_fastdiv(int d) {
-  FastDiv f;
-  if (d <= 1) { f.m = 0; f.sh = -1; return f; }
-  int s = 0;
-  while ((1LL << s) < d) ++s;
-  f.m = (unsigned)(((1ULL << (31 + s)) / (unsigned)d) + 1ULL);
-  f.sh = s - 1;
-  return f;
-}
-
-struct PPArgs {
-  const float* X;
-  const float* Wp;
-  const float* bias;
-  float* Y;
-  ConvDims cd;
-  int n_items;            // workgroup items = pairs of group items
-  int gipg;               // group items per statistics group (even)
-  int bricks_per_group;   // bricks of one statistics group
-  int bd, bh, bw, spg;    // bricks per sample along d / h / w; samples per statistics group
-  FastDiv f_gipg, f_bps, f_bhw, f_bw;
-  int accumulate;
-  long long slab_stride;
-  double* stat_partial;   // [G][rows = gridDim.x][C][2] or nullptr
-  int G;
-};
-
-template <int GM, int GN, int MT, int NT, int WT, int NWB>
-__global__ __launch_bounds__(512) void k_c3pp(PPArgs a) {
-  constexpr int T = 27, S = T / WT, KHS = WT / 9, HVB = 216;
-  constexpr int NBG = GM * MT / 4;                 // bricks of a group item
-  constexpr int BN = GN * NT * 16;
-  constexpr int AG = NBG * HVB * 16;               // floats of one group's halo buffer
-  constexpr int AU = (HVB * 4 + 255) / 256;        // float4 slots per thread and brick (256 threads per group)
-  constexpr int WST4 = WT * 4 * BN, NW4 = (WST4 + 255) / 256;
-  constexpr bool RES = (NWB == 1);
-  constexpr int NSLOT = 4;                         // statistics groups a workgroup may touch
-  static_assert(GM * GN == 4 && (GM * MT) % 4 == 0 && 4 % MT == 0 && T % WT == 0 && WT % 9 == 0, "bad configuration");
-  const ConvDims& cd = a.cd;
-
-  HIP_DYNAMIC_SHARED(float4, smem4)
-  float* smem = reinterpret_cast<float*>(smem4);
-  float* Abuf = smem;                                             // [2 groups][NBG][216][16]
-  float* Wbuf = smem + 2 * AG;                                    // [NWB][WT][4][BN][4]
-  double* Ss = reinterpret_cast<double*>(Wbuf + NWB * WST4 * 4);  // [NSLOT][8 waves][NT * 16][2]
-
-  const int tid = threadIdx.x, lane = tid & 63, gtid = tid & 255;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2, wg = wave & 3;
-  const int li = lane & 15, lg = lane >> 4;
-  const int wm = wg % GM, wn = wg / GM;
-  const int cout0 = blockIdx.y * BN;
-  const int cin4 = cd.Cin16 >> 2;
-  const int nch_all = cd.Cin16 >> 4;
-  const int c0 = (int)((long long)nch_all * blockIdx.z / gridDim.z), c1 = (int)((long long)nch_all * (blockIdx.z + 1) / gridDim.z);
-  float* Y = a.Y + (long long)blockIdx.z * a.slab_stride;
-  float* Ag = Abuf + grp * AG;
-
-  // ---- items of this workgroup (XCD-aware, as k_c3p)
-  int t_first, t_end, t_step;
-  if (gridDim.x % 8 == 0) {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    t_step = gridDim.x >> 3;
-    t_first = (int)((long long)a.n_items * xcd / 8) + j;
-    t_end = (int)((long long)a.n_items * (xcd + 1) / 8);
-  } else {
-    t_first = blockIdx.x; t_end = a.n_items; t_step = gridDim.x;
-  }
-  const bool want_stats = a.stat_partial != nullptr;
-  {   // statistics scratch: every (slot, wave) slice starts at zero
-    for (int i = tid; i < NSLOT * 8 * NT * 16 * 2; i += 512) Ss[i] = 0.0;
-  }
-  const int n_my = t_first < t_end ? (t_end - t_first + t_step - 1) / t_step : 0;
-  const int g_first = (2 * t_first) / (a.gipg > 0 ? a.gipg : 1);   // first statistics group this workgroup touches
-
-  // ---- launch-invariant staging maps (256 threads of a group)
-  unsigned wrel[NW4];
-#pragma unroll
-  for (int u = 0; u < NW4; ++u) {
-    const int q = (gtid + u * 256 < WST4) ? gtid + u * 256 : gtid;
-    const int co = q % BN, cig = (q / BN) & 3, tl = q / (4 * BN);
-    const int kd = tl % 3, kw = (tl / 3) % 3, khl = tl / 9;
-    const int tap0 = kd * 9 + khl * 3 + kw;
-    wrel[u] = (unsigned)((((long long)tap0 * cin4 + cig) * cd.Cout16 + co) * 4);
-  }
-  const long long w_stage_step = (long long)KHS * 3 * cin4 * cd.Cout16 * 4, w_chunk_step = (long long)4 * cd.Cout16 * 4;
-  unsigned arel[AU];
-  int ahd[AU], ahh[AU], ahw[AU];
-#pragma unroll
-  for (int u = 0; u < AU; ++u) {
-    const int r = (gtid + u * 256 < HVB * 4) ? gtid + u * 256 : gtid;
-    const int hv = r >> 2, part = r & 3;
-    ahd[u] = hv / 36; ahh[u] = (hv / 6) % 6; ahw[u] = hv % 6;
-    arel[u] = (unsigned)(((ahd[u] * cd.H + ahh[u]) * cd.W + ahw[u]) * cd.Cin + part * 4);
-  }
-  const int apart = gtid & 3;
-
-  // ---- per-lane operand addressing
-  const int gm0 = wm * MT;
-  const int abase = ((gm0 >> 2) * HVB + ((gm0 & 3) * 6 + (li >> 2)) * 6 + (li & 3)) * 16 + lg * 4;
-  const int bbase = (lg * BN + wn * NT * 16 + li) * 4;
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float bv[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int co = cout0 + wn * NT * 16 + nt * 16 + li;
-    bv[nt] = (a.bias && co < cd.Cout) ? a.bias[co] : 0.f;
-  }
-  double s1[NT], s2[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) { s1[nt] = 0.0; s2[nt] = 0.0; }
-
-  // group item gi -> statistics group, first brick, validity
-  struct Geo { int n, d0, h0, w0; bool ok; };
-  auto brick_geo = [&](int gi, int b) __attribute__((always_inline)) {
-    const int sg = a.f_gipg.div(gi), lb = (gi - sg * a.gipg) * NBG + b;
-    const int ns = a.f_bps.div(lb), rb = lb - ns * (a.bd * a.bh * a.bw);
-    const int di = a.f_bhw.div(rb), r2 = rb - di * (a.bh * a.bw);
-    const int hi = a.f_bw.div(r2), wi = r2 - hi * a.bw;
-    Geo g;
-    g.n = sg * a.spg + ns; g.d0 = di * 4; g.h0 = hi * 4; g.w0 = wi * 4; g.ok = lb < a.bricks_per_group;
-    return g;
-  };
-
-  float4 wreg[NW4], areg[NBG * AU];
-  unsigned aok = 0;
-  auto wfetch = [&](int c, int s) __attribute__((always_inline)) {
-    const float* wb = a.Wp + (long long)s * w_stage_step + (long long)c * w_chunk_step + (long long)cout0 * 4;
-#pragma unroll
-    for (int u = 0; u < NW4; ++u) wreg[u] = ld4(wb + wrel[u]);
-  };
-  auto wstash = [&](float* dst) __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < NW4; ++u) st4(dst + ((gtid + u * 256 < WST4) ? gtid + u * 256 : gtid) * 4, wreg[u]);
-  };
-  auto afetch = [&](int gi, int c) __attribute__((always_inline)) {
-    const bool cok = c * 16 + apart * 4 < cd.Cin;
-    aok = 0;
-#pragma unroll
-    for (int b = 0; b < NBG; ++b) {
-      const Geo g = brick_geo(gi, b);
-      const float* xb = a.X + ((((long long)g.n * cd.D + (g.d0 - 1)) * cd.H + (g.h0 - 1)) * cd.W + (g.w0 - 1)) * cd.Cin + c * 16;
-#pragma unroll
-      for (int u = 0; u < AU; ++u) {
-        const bool ok = g.ok && cok && (unsigned)(g.d0 - 1 + ahd[u]) < (unsigned)cd.D && (unsigned)(g.h0 - 1 + ahh[u]) < (unsigned)cd.H &&
-                        (unsigned)(g.w0 - 1 + ahw[u]) < (unsigned)cd.W;
-        areg[b * AU + u] = ld4(ok ? xb + arel[u] : a.X);
-        aok |= (ok ? 1u : 0u) << (b * AU + u);
-      }
-    }
-  };
-  auto astash = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int b = 0; b < NBG; ++b)
-#pragma unroll
-      for (int u = 0; u < AU; ++u)
-        st4(Ag + b * HVB * 16 + ((gtid + u * 256 < HVB * 4) ? gtid + u * 256 : gtid) * 4,
-            ((aok >> (b * AU + u)) & 1u) ? areg[b * AU + u] : make_float4(0.f, 0.f, 0.f, 0.f));
-  };
-
-  int cur_slot = -1;   // statistics slot (group - g_first) of the sums in s1 / s2
-  auto stats_dump = [&]() __attribute__((always_inline)) {   // this wave's sums of its current statistics group -> its LDS slice
-    if (cur_slot < 0) return;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      double x = s1[nt], y = s2[nt];
-      x += __shfl_xor(x, 16); x += __shfl_xor(x, 32);
-      y += __shfl_xor(y, 16); y += __shfl_xor(y, 32);
-      if (lg == 0) {
-        double* d = Ss + ((((long long)cur_slot * 8 + wave) * NT + nt) * 16 + li) * 2;
-        d[0] = x; d[1] = y;
-      }
-      s1[nt] = 0.0; s2[nt] = 0.0;
-    }
-  };
-
-  auto epilogue = [&](int gi) __attribute__((always_inline)) {
-    if (want_stats) {
-      const int slot = a.f_gipg.div(gi) - g_first;
-      if (slot != cur_slot) { stats_dump(); cur_slot = slot < NSLOT ? slot : NSLOT - 1; }
-    }
-    const Geo g = brick_geo(gi, gm0 >> 2);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int d = g.d0 + ((gm0 + mt) & 3), h = g.h0 + lg;
-      const bool ok = g.ok && d < cd.D && h < cd.H;
-      const long long row0 = ((((long long)g.n * cd.D + d) * cd.H + h) * cd.W + g.w0) * cd.Cout;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int co = cout0 + wn * NT * 16 + nt * 16 + li;
-        if (co < cd.Cout) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (ok && g.w0 + r < cd.W) {
-              float* p = Y + row0 + (long long)r * cd.Cout + co;
-              float v = acc[mt][nt][r] + bv[nt];
-              *p = v;
-              if (want_stats) { s1[nt] += (double)v; s2[nt] += (double)v * (double)v; }
-            }
-          }
-        }
-        acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
-    }
-  };
-
-  auto compute = [&](const float* Wb, int s) __attribute__((always_inline)) {
-    float4 ap[2][MT + 2], bb[2][NT];
-    auto ldA = [&](int kg, int set) __attribute__((always_inline)) {
-      const int kh = s * KHS + kg / 3, kw = kg % 3;
-#pragma unroll
-      for (int p = 0; p < MT + 2; ++p) ap[set][p] = ld4(Ag + abase + ((p * 6 + kh) * 6 + kw) * 16);
-    };
-    auto ldB = [&](int tl, int set) __attribute__((always_inline)) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bb[set][nt] = ld4(Wb + tl * 4 * BN * 4 + bbase + nt * 64);
-    };
-    ldA(0, 0);
-    ldB(0, 0);
-#pragma unroll
-    for (int tl = 0; tl < WT; ++tl) {       // tl = (khl * 3 + kw) * 3 + kd
-      const int kg = tl / 3, kd = tl % 3;
-      if (tl + 1 < WT) {
-        if ((tl + 1) % 3 == 0) ldA(kg + 1, (kg + 1) & 1);
-        ldB(tl + 1, (tl + 1) & 1);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const float4 av4 = ap[kg & 1][mt + kd], bv4 = bb[tl & 1][nt];
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.x, bv4.x, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.y, bv4.y, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.z, bv4.z, acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av4.w, bv4.w, acc[mt][nt], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  if (n_my > 0) {
-    const int nch = c1 - c0, spi = nch * S;      // stages per item
-    const int J = n_my * spi;                    // stages of each group
-    // stage j of a group = (its item j / spi, chunk c0 + (j % spi) / S, tap group j % S)
-    auto chunk_start = [&](int j) __attribute__((always_inline)) { return S == 1 || (j % S) == 0; };
-    auto fetch_chunk_of = [&](int j) __attribute__((always_inline)) {
-      const int it = j / spi, r = j - it * spi;
-      afetch(2 * (t_first + it * t_step) + grp, c0 + r / S);
-    };
-    auto fetch_weights_of = [&](int j) __attribute__((always_inline)) {
-      const int r = j % spi;
-      wfetch(c0 + r / S, r % S);
-    };
-    // ---- prologue.  Prefetch distance is TWO phases: what a group stores to LDS in a non-compute phase was requested in its
-    // previous non-compute phase and stayed in registers through its compute phase (a same-phase request -> store exposes the
-    // L2 / HBM latency: measured 334 us instead of 305 us for the 16-channel layer).
-    if (grp == 0) {
-      fetch_chunk_of(0); astash();
-      if (1 < J && chunk_start(1)) fetch_chunk_of(1);
-    } else {
-      wfetch(c0, 0); wstash(Wbuf);
-      fetch_chunk_of(0);
-      if (!RES && 1 < J) fetch_weights_of(1);
-    }
-    BCP_LDS_BARRIER();
-
-    int cj = 0, cs = 0;                          // next stage of this group, its tap group
-    for (int p = 0; p <= 2 * J; ++p) {
-      if (((p & 1) == grp)) {
-        if (cj < J && !(P8_ABLATE & 8)) compute(Wbuf + (RES ? 0 : (cj & 1)) * WST4 * 4, cs);
-        if (cj < J) { ++cj; if (++cs == S) cs = 0; }
-      } else if (!(P8_ABLATE & 16)) {
-        // cj = the stage this group computes in the next phase; cj - 1 = the one it has just computed
-        if (cj < J && chunk_start(cj) && !(grp == 0 && cj == 0) && !(P8_ABLATE & 2)) astash();   // requested one non-compute phase ago
-        const int jw = (p >> 1) + 1;             // group 1, phase 2j: the weights of stage j + 1 go to LDS, those of j + 2 are requested
-        if (!RES && grp == 1 && jw < J) wstash(Wbuf + (jw & 1) * WST4 * 4);
-        if (cj > 0 && (cj % spi) == 0 && !(P8_ABLATE & 1)) epilogue(2 * (t_first + (cj / spi - 1) * t_step) + grp);
-        if (cj + 1 < J && chunk_start(cj + 1) && !(P8_ABLATE & 2)) fetch_chunk_of(cj + 1);
-        if (!RES && grp == 1 && jw + 1 < J) fetch_weights_of(jw + 1);
-      }
-      if (p < 2 * J) BCP_LDS_BARRIER();
-    }
-  }
-  if (P8_ABLATE & 17) {   // measurement builds without the epilogue: keep every accumulator alive
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(Y + ((long long)(blockIdx.x * 512 + tid) * MT * NT + mt * NT + nt) * 4) = acc[mt][nt];
-  }
-  // ---- statistics: per-wave slices -> one partial row per workgroup and touched group (deterministic order)
-  if (want_stats) {
-    stats_dump();
-    __syncthreads();
-    for (int i = tid; i < a.G * BN; i += 512) {
-      const int g = i / BN, c = i % BN, slot = g - g_first;
-      if (cout0 + c < cd.Cout) {
-        const int wn_c = c / (NT * 16), cc2 = c % (NT * 16);
-        double x = 0.0, y = 0.0;          // groups this workgroup never touched read as zero
-        if (slot >= 0 && slot < NSLOT) {
-          for (int w = 0; w < 8; ++w) {
-            if (((w & 3) / GM) != wn_c) continue;          // waves of the other channel half hold other channels
-            const double* d = Ss + (((long long)slot * 8 + w) * NT * 16 + cc2) * 2;
-            x += d[0]; y += d[1];
-          }
-        }
-        double* dst = a.stat_partial + (((long long)g * gridDim.x + blockIdx.x) * cd.Cout + cout0 + c) * 2;
-        dst[0] = x; dst[1] = y;
-      }
-    }
-  }
-}
-
 // y (+)= bias + sum_k part[k]  (split-K epilogue; deep levels only: <= 1 MB)
 __global__ __launch_bounds__(256) void k_p8_sum_slabs(const float* __restrict__ part, int SK, long long n, int C,
                                                       const float* __restrict__ bias, float* __restrict__ y, int accumulate) {
@@ -860,9 +524,12 @@ static bool p8_plan(P8Plan& pl, const ConvDims& cd, int KD, int G, bool want_sta
   a.cd = cd;
   int BM, BN, NB = 0, WT, NWB;
   const int nch = cd.Cin16 / 16;
-  (void)vox;
-  if (cd.Cout16 % 32 == 0 && 64 + 2 * R <= kFlatAvMax && (force || KD == 3)) { pl.cfg = KD == 3 ? 3 : 4; pl.mode = P8_FLAT; BM = 64; BN = 32; WT = KD == 3 ? 27 : 9; NWB = 2; }
+  if (KD == 3 && o.conv3_p8 == 2 && cd.Cout16 == 16 && cd.Cin16 == 16) { pl.cfg = 0; pl.mode = P8_BRICK; BM = 256; BN = 16; NB = 4; WT = 27; NWB = 1; }
+  else if (KD == 3 && cd.Cout16 % 32 == 0 && cd.Cout16 % 64 != 0 && (force ? o.conv3_p8 == 2 : vox >= 64LL * 1024)) { pl.cfg = 1; pl.mode = P8_BRICK; BM = 256; BN = 32; NB = 4; WT = 9; NWB = 2; }
+  else if (KD == 3 && cd.Cout16 % 64 == 0 && (force ? o.conv3_p8 == 2 : (vox >= 16LL * 1024 && 64 + 2 * R > kFlatAvMax))) { pl.cfg = 2; pl.mode = P8_BRICK; BM = 128; BN = 64; NB = 2; WT = 9; NWB = 2; }
+  else if (cd.Cout16 % 32 == 0 && 64 + 2 * R <= kFlatAvMax && (force || KD == 3)) { pl.cfg = KD == 3 ? 3 : 4; pl.mode = P8_FLAT; BM = 64; BN = 32; WT = KD == 3 ? 27 : 9; NWB = 2; }
   else return false;
+  if (!force && !((o.conv3_p8_cfgs >> (pl.cfg == 1 ? 0 : pl.cfg == 2 ? 1 : 2)) & 1)) return false;
   pl.slabs = cd.Cout16 / BN;
   pl.ksplit = 1;
   const int spg = G > 0 ? cd.N / G : cd.N;           // samples per statistics group (G = 0: no statistics, one group)
@@ -907,57 +574,6 @@ static bool p8_plan(P8Plan& pl, const ConvDims& cd, int KD, int G, bool want_sta
   return true;
 }
 
-template <int GM, int GN, int MT, int NT, int WT, int NWB>
-static void pp_launch(const PPArgs& a, int P, int slabs, int ksplit, hipStream_t s) {
-  constexpr int NBG = GM * MT / 4, BN = GN * NT * 16;
-  const size_t lds = ((size_t)2 * NBG * 216 * 16 + (size_t)NWB * WT * 4 * BN * 4) * sizeof(float) + (size_t)4 * 8 * NT * 16 * 2 * sizeof(double);
-  auto kfn = k_c3pp<GM, GN, MT, NT, WT, NWB>;
-  hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(kfn, dim3(P, slabs, ksplit), dim3(512), lds, s, a);
-}
-
-// ping-pong configurations (BRICK): 0: BN 16 (16 -> 16 channels, single resident stage)  1: BN 32  2: BN 64
-static bool pp_plan(int& cfg, PPArgs& a, int& P, int& slabs, int& ksplit, int& stat_rows, const ConvDims& cd, int KD, int G, bool has_ws) {
-  const Options& o = options();
-  if (o.conv3_p8 == 0 || o.conv3_p8 == 3 || KD != 3) return false;
-  const bool force = o.conv3_p8 == 2;
-  const long long vps = (long long)cd.D * cd.H * cd.W, vox = vps * cd.N;
-  const int nch = cd.Cin16 / 16;
-  int NBG, BN;
-  if (cd.Cout16 == 16 && cd.Cin16 == 16 && (force || vox >= 256LL * 1024)) { cfg = 0; NBG = 2; BN = 16; }
-  else if (cd.Cout16 % 32 == 0 && cd.Cout16 % 64 != 0 && (force || vox >= 64LL * 1024)) { cfg = 1; NBG = 2; BN = 32; }
-  else if (cd.Cout16 % 64 == 0 && (force || vox >= 16LL * 1024)) { cfg = 2; NBG = 1; BN = 64; }
-  else return false;
-  if (G > 4 || (G > 0 && cd.N % G)) return false;          // statistics slots of a workgroup
-  a.cd = cd;
-  a.bd = cdiv(cd.D, 4); a.bh = cdiv(cd.H, 4); a.bw = cdiv(cd.W, 4);
-  const long long covered = (long long)a.bd * a.bh * a.bw * 64;
-  if (!force && covered * 4 > vps * 5) return false;       // partial bricks would waste more than a quarter of the MFMA rows
-  const int groups = G > 0 ? G : 1;
-  a.spg = cd.N / groups;
-  a.G = groups;
-  a.bricks_per_group = a.spg * a.bd * a.bh * a.bw;
-  a.gipg = 2 * cdiv(cdiv(a.bricks_per_group, NBG), 2);
-  a.n_items = groups * a.gipg / 2;
-  a.f_gipg = make_fastdiv(a.gipg); a.f_bps = make_fastdiv(a.bd * a.bh * a.bw); a.f_bhw = make_fastdiv(a.bh * a.bw); a.f_bw = make_fastdiv(a.bw);
-  slabs = cd.Cout16 / BN;
-  ksplit = 1;
-  if (has_ws && nch >= 2) {
-    int ks = 256 / (a.n_items * slabs);
-    if (ks > nch) ks = nch;
-    if (ks > 8) ks = 8;
-    if (ks >= 2) ksplit = ks;
-    if (o.splitk >= 1 && o.splitk <= 8 && o.splitk <= nch) ksplit = o.splitk;
-  }
-  if (cfg == 0 && nch != 1) return false;
-  int maxP = 256 / (slabs * ksplit);
-  if (maxP < 1) maxP = 1;
-  P = a.n_items < maxP ? a.n_items : maxP;
-  if (o.conv3_p > 0 && o.conv3_p < P) P = o.conv3_p;
-  stat_rows = ksplit == 1 ? P : 0;
-  return true;
-}
-
 int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
            double* stat_partial, int G, bool dry, hipStream_t s, bool* handled) {
   P8Plan pl;
@@ -966,27 +582,6 @@ int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const C
   // "+=" into y is left to the kernels of conv3.hip: a conditional read-modify-write in the epilogue makes hipcc put a
   // vmcnt(0) in front of EVERY store (eight serialised store round trips per item, measured 2.3 us of a 3 us phase)
   if (accumulate) return 0;
-  {
-    PPArgs pa;
-    int cfg = 0, P = 0, slabs = 0, ksplit = 1, stat_rows = 0;
-    if (pp_plan(cfg, pa, P, slabs, ksplit, stat_rows, cd, KD, G, workspace != nullptr)) {
-      *handled = true;
-      if (dry) return want_stats ? stat_rows : 0;
-      const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
-      pa.X = x; pa.Wp = wp; pa.Y = y; pa.bias = bias; pa.accumulate = accumulate; pa.slab_stride = 0;
-      pa.stat_partial = (want_stats && stat_partial && stat_rows > 0) ? stat_partial : nullptr;
-      if (ksplit > 1) { pa.Y = (float*)workspace; pa.bias = nullptr; pa.accumulate = 0; pa.slab_stride = n; }
-      switch (cfg) {
-        case 0: pp_launch<4, 1, 2, 1, 27, 1>(pa, P, slabs, ksplit, s); break;
-        case 1: pp_launch<2, 2, 4, 1, 9, 2>(pa, P, slabs, ksplit, s); break;
-        default: pp_launch<2, 2, 2, 2, 9, 2>(pa, P, slabs, ksplit, s); break;
-      }
-      if (ksplit > 1)
-        hipLaunchKernelGGL(k_p8_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, (const float*)workspace,
-                           ksplit, n, cd.Cout, bias, y, accumulate);
-      return pa.stat_partial ? stat_rows : 0;
-    }
-  }
   if (!p8_plan(pl, cd, KD, G, want_stats, workspace != nullptr)) return 0;
   *handled = true;
   if (dry) return want_stats ? pl.stat_rows : 0;
@@ -997,6 +592,9 @@ int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const C
   const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
   if (pl.ksplit > 1) { a.Y = (float*)workspace; a.bias = nullptr; a.accumulate = 0; a.slab_stride = n; }
   switch (pl.cfg) {
+    case 0: p8_launch<3, P8_BRICK, 8, 1, 2, 1, 4, 27, 1, 0>(pl, s); break;
+    case 1: p8_launch<3, P8_BRICK, 4, 2, 4, 1, 4, 9, 2, 0>(pl, s); break;
+    case 2: p8_launch<3, P8_BRICK, 4, 2, 2, 2, 2, 9, 2, 0>(pl, s); break;
     case 3: p8_launch<3, P8_FLAT, 4, 2, 1, 1, 0, 27, 2, kFlatAvMax>(pl, s); break;
     case 4: p8_launch<1, P8_FLAT, 4, 2, 1, 1, 0, 9, 2, kFlatAvMax>(pl, s); break;
     default: set_error("p8_fwd: bad plan"); return BCP_EUNSUP;

@@ -220,7 +220,15 @@ def main():
     ap.add_argument("--batch_size", type=int, default=None, help="per-GPU batch (la: 4 = configs[1]; acdc: 24 = configs[3]; pancreas: 4)")
     ap.add_argument("--labeled_bs", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="library tuning switch (bcp_set_option) for A/B measurements; the product defaults need none")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline launches (A/B runs)")
     args = ap.parse_args()
+    if args.opt:
+        from bcp_amd.hip_ops import Ops as _Ops
+        for kv in args.opt:
+            k, _, v = kv.partition("=")
+            _Ops.product().set_option(k, v)
     if args.batch_size is None:
         args.batch_size = {"la": 4, "acdc": 24, "pancreas": 4}[args.workload]
     if args.labeled_bs is None:
@@ -269,7 +277,7 @@ def main():
         ms = dt / args.steps * 1e3
         global_batch = args.batch_size * dp.world
         value = global_batch * args.steps / dt
-        roof = dominant_kernel_roofline(dev)
+        roof = dominant_kernel_roofline(dev) if not args.no_roofline else {"achieved": None}
         step_tflops = value * STEP_GFLOP_PER_VOLUME / 1e3 / dp.world
         out = {
             "metric": "training volumes/sec (LA 112x112x80 V-Net, BCP self-training step)",
