@@ -100,6 +100,7 @@ class _BestModel:
         self.args, self.path, self.with_opt = args, snapshot_path, with_optimizer
         self.cases = _val_cases(args, device) if args.val_every > 0 else []
         self.best = 0
+        self.validated = False
 
     def _write(self, model, optimizer, name):
         target = os.path.join(self.path, name)
@@ -113,6 +114,7 @@ class _BestModel:
         if a.val_every <= 0 or iter_num % a.val_every:
             return
         dice = test_3d_patch.var_all_case_LA(model, num_classes=num_classes, patch_size=patch_size, stride_xy=18, stride_z=4, cases=self.cases)
+        self.validated = True
         if dice > self.best:
             self.best = round(dice, 4)
             self._write(model, optimizer, "iter_{}_dice_{}.pth".format(iter_num, self.best))
@@ -120,7 +122,11 @@ class _BestModel:
             logging.info("save best model, dice %f" % self.best)
 
     def finish(self, model, optimizer):
-        if self.best == 0:   # no validation ran (or none improved): keep the last weights so that the next phase can start
+        if self.best == 0:   # no checkpoint was written: keep the last weights so that the next phase can start
+            if self.validated:
+                logging.warning("validation ran but never scored above 0: %s_best_model.pth holds the LAST weights, not a best model", self.args.model)
+            else:
+                logging.info("no validation ran (--val_every 0): %s_best_model.pth holds the last weights", self.args.model)
             self._write(model, optimizer, "{}_best_model.pth".format(self.args.model))
 
 

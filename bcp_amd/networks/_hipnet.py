@@ -71,7 +71,7 @@ class HipNet(nn.Module):
         self._pack_cache = {}
         self._bump = 0               # incremented when the flat buffer is modified outside torch (fused SGD / EMA)
         self.drop_masks = None       # injectable dropout keep-masks (parity runs)
-        self._drop_seed = 0x9E3779B97F4A7C15
+        self._drop_seed = None       # dropout stream of THIS instance: seeded lazily from torch's generator (see next_seed)
 
     # ------------------------------------------------------------------ ops / storage
     @property
@@ -411,7 +411,25 @@ class HipNet(nn.Module):
             if lo is not None:
                 hook(self, lo, like)
 
+    _instances = 0   # per-process instance counter: every network gets its own dropout stream
+
+    def seed_dropout(self, seed=None):
+        """(re)seed this network's dropout stream.  Default: torch's seed (so --seed / torch.manual_seed govern dropout as in
+        the reference, which draws its masks from the torch RNG), mixed with a per-process instance number (student and
+        teacher -- and the pre-training / self-training models -- draw INDEPENDENT masks, as two nn.Dropout modules do) and with
+        the data-parallel rank (one stream per replica, bcp_amd/dp.py)."""
+        if seed is None:
+            HipNet._instances += 1
+            seed = (torch.initial_seed() & 0xFFFFFFFFFFFFFFFF) ^ (HipNet._instances * 0x9E3779B97F4A7C15) ^ (int(os.environ.get("RANK", "0")) * 0xD1B54A32D192ED03)
+        z = (int(seed) + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF        # splitmix64 finaliser: nearby seeds -> unrelated streams
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+        self._drop_seed = z ^ (z >> 31)
+        return self
+
     def next_seed(self):
+        if self._drop_seed is None:
+            self.seed_dropout()
         self._drop_seed = (self._drop_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return self._drop_seed
 

@@ -15,24 +15,37 @@ def generate_mask(img, patch_size):
     return BU.BoxMask(box, vol, None, False, img.device), BU.BoxMask(box, vol, img.shape[0], False, img.device)
 
 
+# The reference builds the pancreas net as nn.DataParallel(VNet()) (pancreas/dataloaders.py:11-14), so every key of its
+# checkpoints carries a "module." prefix.  Ours is a bare network: checkpoints are WRITTEN with the prefix (the reference's
+# load_net / load_net_opt take them as they are) and READ with or without it.
+def _to_ref_keys(sd):
+    return {"module." + k: v for k, v in sd.items()}
+
+
+def _from_ref_keys(sd):
+    if sd and all(k.startswith("module.") for k in sd):
+        return {k[len("module."):]: v for k, v in sd.items()}
+    return sd
+
+
 def save_net_opt(net, optimizer, path, epoch):
-    """:160-166 -- {'net', 'opt', 'epoch'}"""
-    torch.save({"net": net.state_dict(), "opt": optimizer.state_dict(), "epoch": epoch}, str(path))
+    """:160-166 -- {'net', 'opt', 'epoch'}; 'opt' in torch.optim's state_dict layout (train_step.FlatAdam.state_dict)"""
+    torch.save({"net": _to_ref_keys(net.state_dict()), "opt": optimizer.state_dict(), "epoch": epoch}, str(path))
 
 
 def load_net_opt(net, optimizer, path):
     """:169-172"""
-    state = torch.load(str(path))
-    net.load_state_dict(state["net"])
+    state = torch.load(str(path), weights_only=False)
+    net.load_state_dict(_from_ref_keys(state["net"]))
     optimizer.load_state_dict(state["opt"])
 
 
 def save_net(net, path):
     """:175-179"""
-    torch.save({"net": net.state_dict()}, str(path))
+    torch.save({"net": _to_ref_keys(net.state_dict())}, str(path))
 
 
 def load_net(net, path):
     """:182-184"""
-    net.load_state_dict(torch.load(str(path))["net"])
+    net.load_state_dict(_from_ref_keys(torch.load(str(path), weights_only=False)["net"]))
 

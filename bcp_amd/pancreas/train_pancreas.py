@@ -79,7 +79,7 @@ def main(argv=None):
     ap.add_argument("--self_training_epochs", type=int, default=self_training_epochs)
     ap.add_argument("--steps_per_epoch", type=int, default=10)
     ap.add_argument("--batch_size", type=int, default=batch_size)
-    ap.add_argument("--val_every", type=int, default=0, help="validate every N epochs (reference: pretrain_save_step = st_save_step = 20); 0 = off")
+    ap.add_argument("--val_every", type=int, default=20, help="validate every N epochs (the reference's pretrain_save_step = st_save_step = 20, train_pancreas.py:36-37: gates best_ema*_pre.pth and the restart from it); 0 = off")
     ap.add_argument("--val_cases", type=int, default=1)
     ap.add_argument("--val_stride", type=int, nargs=2, default=[18, 4], help="sliding-window strides (xy, z); test_calculate_metric's defaults")
     ap.add_argument("--result_dir", type=str, default="result/cutmix")

@@ -52,6 +52,23 @@ def get_ACDC_masks(output, nms=0):
 
 
 # ------------------------------------------------------------------------------------------ optimisers
+def _opt_param_slices(model):
+    """[(index in model.parameters(), flat offset, parameter)] of the parameters the optimiser steps (the flat trainable
+    prefix).  Indices follow `model.parameters()` -- the order torch.optim numbers them in a state_dict -- so an 'opt' entry
+    written by the reference's save_net_opt (LA_BCP_train.py:79-84, ACDC_BCP_train.py:60-64, pancreas_utils.py:160-168)
+    maps onto the flat buffers and back."""
+    model._ensure_flat()
+    out = []
+    for i, q in enumerate(model._ordered_params()):
+        if id(q) in model._opt_param_ids:
+            out.append((i, model._offs[id(q)], q))
+    return out
+
+
+def _n_params(model):
+    return len(model._ordered_params())
+
+
 class FlatSGD:
     """torch.optim.SGD(momentum, weight_decay) semantics (LA_BCP_train.py:218) as ONE launch over the flat
     trainable buffer of a HipNet; parameters whose grad is None in the reference (the unused heads) are
@@ -79,10 +96,35 @@ class FlatSGD:
         self.model.bump()
 
     def state_dict(self):
-        return {"buf": self.buf, "steps": self.steps, "param_groups": self.param_groups}
+        """torch.optim.SGD's layout: {'state': {i: {'momentum_buffer': tensor}}, 'param_groups': [{..., 'params': [0..n-1]}]}
+        with per-parameter VIEWS of the flat momentum buffer (no state before the first step, as in torch)."""
+        g = self.param_groups[0]
+        state = {}
+        if self.buf is not None and self.steps > 0:
+            for i, off, q in _opt_param_slices(self.model):
+                state[i] = {"momentum_buffer": self.buf[off:off + q.numel()].view(q.shape)}
+        group = {"lr": g["lr"], "momentum": g["momentum"], "dampening": 0, "weight_decay": g["weight_decay"], "nesterov": False,
+                 "maximize": False, "foreach": None, "differentiable": False, "fused": None, "params": list(range(_n_params(self.model)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.buf, self.steps, self.param_groups = sd["buf"], sd["steps"], sd["param_groups"]
+        """accepts torch.optim.SGD's state_dict (the reference's checkpoints) -- and, for files written by round 1 of this
+        package, the old private {'buf','steps','param_groups'} layout"""
+        if "state" not in sd:
+            self.buf, self.steps = sd["buf"], sd["steps"]
+            self.param_groups = [dict(sd["param_groups"][0])]
+            return
+        g = sd["param_groups"][0]
+        self.param_groups = [{"lr": g["lr"], "momentum": g["momentum"], "weight_decay": g["weight_decay"]}]
+        p, _ = self.model.flat_trainable()
+        self.buf = torch.zeros_like(p)
+        self.steps = 0
+        st = sd["state"]
+        for i, off, q in _opt_param_slices(self.model):
+            e = st.get(i, st.get(str(i)))
+            if e is not None and e.get("momentum_buffer") is not None:
+                self.buf[off:off + q.numel()].copy_(e["momentum_buffer"].reshape(-1).to(self.buf.device, torch.float32))
+                self.steps = max(self.steps, 1)      # momentum is live: the next step is not a "first step"
 
 
 class FlatAdam:
@@ -110,13 +152,38 @@ class FlatAdam:
         self.model.bump()
 
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "steps": self.steps, "param_groups": self.param_groups}
+        """torch.optim.Adam's layout: state[i] = {'step', 'exp_avg', 'exp_avg_sq'} (views of the flat moment buffers)"""
+        g = self.param_groups[0]
+        state = {}
+        if self.m is not None and self.steps > 0:
+            for i, off, q in _opt_param_slices(self.model):
+                state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.m[off:off + q.numel()].view(q.shape),
+                            "exp_avg_sq": self.v[off:off + q.numel()].view(q.shape)}
+        group = {"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(_n_params(self.model)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        # (clones: the reference loads ONE checkpoint's optimiser state twice, train_pancreas.py:116-117)
-        self.m = None if sd["m"] is None else sd["m"].clone()
-        self.v = None if sd["v"] is None else sd["v"].clone()
-        self.steps, self.param_groups = sd["steps"], sd["param_groups"]
+        """torch.optim.Adam's state_dict (copied: the reference loads ONE checkpoint's optimiser state into two optimisers,
+        train_pancreas.py:116-117), or round 1's private {'m','v','steps','param_groups'} layout"""
+        if "state" not in sd:
+            self.m = None if sd["m"] is None else sd["m"].clone()
+            self.v = None if sd["v"] is None else sd["v"].clone()
+            self.steps, self.param_groups = sd["steps"], [dict(sd["param_groups"][0])]
+            return
+        g = sd["param_groups"][0]
+        self.param_groups = [{"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"]}]
+        p, _ = self.model.flat_trainable()
+        self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
+        self.steps = 0
+        st = sd["state"]
+        for i, off, q in _opt_param_slices(self.model):
+            e = st.get(i, st.get(str(i)))
+            if e is not None:
+                self.m[off:off + q.numel()].copy_(e["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
+                self.v[off:off + q.numel()].copy_(e["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
+                self.steps = max(self.steps, int(float(e["step"])))
 
 
 # ------------------------------------------------------------------------------------------ LA / pancreas step
@@ -184,7 +251,7 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
     if variant == "la":
         terms = ((lab_a, plab_a, 1.0, u_weight), (plab_b, lab_b, u_weight, 1.0))       # mix_loss(.., u_weight) / (.., unlab=True)
     else:
-        terms = ((plab_a, lab_b, 0.5, 1.0), (lab_a, plab_b, 1.0, 0.5))                 # train_pancreas.py:160,164 (default u_weight)
+        terms = ((plab_a, lab_b, u_weight, 1.0), (lab_a, plab_b, 1.0, u_weight))       # train_pancreas.py:160,164 (the reference passes no u_weight: mix_loss's default 0.5 = ours)
     if grouped:
         mixed = torch.empty((2 * sub_bs,) + tuple(volume_batch.shape[1:]), dtype=volume_batch.dtype, device=volume_batch.device)
         BU.mix(pairs[0][0], pairs[0][1], img_mask, out=mixed[:sub_bs])

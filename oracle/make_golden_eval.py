@@ -139,9 +139,63 @@ def main_sampler():
     print("wrote", os.path.normpath(out), [d[f"epoch0_{i}"].shape for i in range(4)])
 
 
+def main_opt_layout():
+    """the LAYOUT of the 'opt' entry of the reference's {'net','opt'} checkpoints (LA_BCP_train.py:79-84,
+    ACDC_BCP_train.py:60-64: torch.optim.SGD over model.parameters(); pancreas: torch.optim.Adam, pancreas/dataloaders.py:182)
+    after one real backward + step of the REFERENCE networks: which parameter indices carry state, the param_group fields, the
+    state entry names.  Data only (indices / names / shapes), written as JSON."""
+    import io
+    import json
+    out = {}
+    P = O.eval_params(SEED)
+    net = MG.ref_vnet_la({k: v.clone() for k, v in P.items()})
+    MG.set_drop_la(net, None)
+    opt = torch.optim.SGD(net.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0001)     # LA_BCP_train.py:218
+    x = torch.from_numpy(np.random.default_rng(SEED).standard_normal((2, 1, 16, 16, 16)).astype(np.float32))
+    y = net(x)[0]
+    y.square().mean().backward()
+    opt.step()
+    buf = io.BytesIO()
+    torch.save({"net": net.state_dict(), "opt": opt.state_dict()}, buf)       # == save_net_opt's payload
+    sd = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)["opt"]
+    params = list(net.parameters())
+    out["la_sgd"] = {"n_params": len(params), "state_indices": sorted(int(k) for k in sd["state"]),
+                     "state_entry_keys": sorted(next(iter(sd["state"].values())).keys()),
+                     "param_group": {k: v for k, v in sd["param_groups"][0].items() if k != "params"},
+                     "params_field": [int(sd["param_groups"][0]["params"][0]), int(sd["param_groups"][0]["params"][-1]), len(sd["param_groups"][0]["params"])],
+                     "shapes_first5": [list(sd["state"][i]["momentum_buffer"].shape) for i in sorted(sd["state"])[:5]]}
+    netu, _ = MG.ref_unet({k: v.clone() for k, v in O.init_params(O.unet_param_shapes(), seed=SEED).items()})
+    optu = torch.optim.SGD(netu.parameters(), lr=0.01, momentum=0.9, weight_decay=0.0001)   # ACDC_BCP_train.py:223
+    yu = netu(torch.from_numpy(np.random.default_rng(SEED + 1).random((2, 1, 32, 32)).astype(np.float32)))
+    yu.square().mean().backward()
+    optu.step()
+    sdu = optu.state_dict()
+    out["acdc_sgd"] = {"n_params": len(list(netu.parameters())), "state_indices": sorted(int(k) for k in sdu["state"])}
+    netp = MG.ref_pvnet.VNet()                                                          # pancreas/dataloaders.py:11 (before DataParallel)
+    netp.load_state_dict(O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=SEED), strict=True)
+    netp.train()
+    if True:
+        optp = torch.optim.Adam(netp.parameters(), lr=1e-3)
+        yp = netp(torch.from_numpy(np.random.default_rng(SEED + 2).standard_normal((1, 1, 32, 32, 32)).astype(np.float32)))[0]
+        yp.square().mean().backward()
+        optp.step()
+        sdp = optp.state_dict()
+        out["pancreas_adam"] = {"n_params": len(list(netp.parameters())), "state_indices": sorted(int(k) for k in sdp["state"]),
+                                "state_entry_keys": sorted(next(iter(sdp["state"].values())).keys()),
+                                "param_group": {k: (list(v) if isinstance(v, tuple) else v) for k, v in sdp["param_groups"][0].items() if k != "params"}}
+    path = os.path.join(HERE, "..", "tests", "golden", "opt_layout.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print("wrote", os.path.normpath(path), {k: (v["n_params"], len(v["state_indices"])) for k, v in out.items()})
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "opt":
+        main_opt_layout()
+        sys.exit(0)
     main()
     main_aug()
     main_aug_acdc()
     main_sw_pancreas()
     main_sampler()
+    main_opt_layout()

@@ -495,3 +495,103 @@ def check_val_2d(ops, dev, seed=9):
             ref = O.dice_binary(pred == c, label[0].numpy() == c) if (pred == c).sum() > 0 else 0
             assert abs(got[c - 1][0] - ref) < 5e-3, (shape, c, got[c - 1][0], ref)   # a logit tie may flip a pixel
     assert net.training
+
+
+def check_opt_state_compat(ops, dev, golden_dir, variant="la"):
+    """the 'opt' entry of a {'net','opt'} checkpoint is interchangeable with the reference's in BOTH directions.
+    torch.optim.SGD / Adam over `model.parameters()` is exactly what the reference's save_net_opt serialises
+    (LA_BCP_train.py:79-84, ACDC_BCP_train.py:60-64, pancreas_utils.py:160-166); tests/golden/opt_layout.json pins the layout
+    the REFERENCE networks produce (which indices carry state, the field names).  Checked: (1) a torch-written state loads into
+    the flat optimiser and the next step equals torch's; (2) the flat optimiser's state_dict has the reference's layout and
+    loads into a fresh torch optimiser whose next step equals ours."""
+    import io
+    from bcp_amd import train_step
+    layout = json.load(open(os.path.join(golden_dir, "opt_layout.json")))
+    adam = variant == "pancreas"
+    lay = layout["pancreas_adam" if adam else "la_sgd"]
+    P = O.init_params(O.vnet_param_shapes(variant=variant), seed=41)
+    net = make_vnet(P, dev, ops, variant=variant)
+    names = [n for n, _ in net.named_parameters()]
+    assert len(names) == lay["n_params"], "parameters() must enumerate what the reference's does"
+    rng = np.random.default_rng(77)
+    ref_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in net.parameters()]
+    mk = (lambda ps: torch.optim.Adam(ps, lr=1e-3)) if adam else (lambda ps: torch.optim.SGD(ps, lr=0.01, momentum=0.9, weight_decay=1e-4))
+    opt_ref = mk(ref_params)
+    idx = lay["state_indices"]
+
+    def grads(scale):
+        return {i: torch.from_numpy(rng.standard_normal(tuple(ref_params[i].shape)).astype(np.float32)) * scale for i in idx}
+
+    def ref_step(g):
+        for i, p in enumerate(ref_params):
+            p.grad = g[i].clone() if i in g else None
+        opt_ref.step()
+
+    def set_flat_grads(g):
+        _, gr = net.flat_trainable()
+        for i, off, q in train_step._opt_param_slices(net):
+            gr[off:off + q.numel()].copy_(g[i].reshape(-1).to(dev))
+
+    ref_step(grads(1.0))
+    buf = io.BytesIO()
+    torch.save({"opt": opt_ref.state_dict()}, buf)                      # what save_net_opt writes for 'opt'
+    sd_ref = torch.load(io.BytesIO(buf.getvalue()), weights_only=False)["opt"]
+    assert sorted(int(k) for k in sd_ref["state"]) == idx, "torch here and the reference fixture agree on which parameters carry state"
+    # (1) reference -> ours
+    with torch.no_grad():
+        for p, r in zip(net.parameters(), ref_params):
+            p.copy_(r.detach().to(dev))
+    net.bump()
+    fo = (train_step.FlatAdam(net, lr=1e-3) if adam else train_step.FlatSGD(net, lr=0.5, momentum=0.1, weight_decay=0.0))
+    fo.load_state_dict(sd_ref)                                          # lr / momentum / wd come from the checkpoint, as in torch
+    g2 = grads(0.5)
+    set_flat_grads(g2)
+    fo.step()
+    ref_step(g2)
+    for n, p, r in zip(names, net.parameters(), ref_params):
+        K.close(p.detach(), r.detach(), rtol=2e-6, atol_scale=1e-6, msg=f"step after loading a torch 'opt' state: {n}")
+    # (2) ours -> reference
+    sd = fo.state_dict()
+    assert sorted(sd["state"].keys()) == idx and sorted(next(iter(sd["state"].values())).keys()) == lay["state_entry_keys"]
+    assert set(sd["param_groups"][0].keys()) >= set(lay["param_group"].keys()) | {"params"}
+    assert sd["param_groups"][0]["params"] == list(range(lay["n_params"]))
+    buf = io.BytesIO()
+    torch.save({"opt": sd}, buf)
+    fresh = [torch.nn.Parameter(r.detach().clone()) for r in ref_params]
+    opt2 = mk(fresh)
+    opt2.load_state_dict(torch.load(io.BytesIO(buf.getvalue()), weights_only=False)["opt"])
+    g3 = grads(0.25)
+    for i, p in enumerate(fresh):
+        p.grad = g3[i].clone() if i in g3 else None
+    opt2.step()
+    set_flat_grads(g3)
+    fo.step()
+    for n, p, r in zip(names, net.parameters(), fresh):
+        K.close(p.detach(), r.detach(), rtol=2e-6, atol_scale=1e-6, msg=f"torch step after loading OUR 'opt' state: {n}")
+
+
+def check_dropout_streams(dev):
+    """every network owns a dropout stream seeded from torch's generator -- student and teacher draw independent
+    masks, torch.manual_seed reproduces them, data-parallel ranks differ"""
+    from bcp_amd.networks.VNet import VNet
+    from bcp_amd.networks._hipnet import HipNet
+
+    def two(seed):
+        torch.manual_seed(seed)
+        HipNet._instances = 0
+        a = VNet(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+        b = VNet(n_channels=1, n_classes=2, normalization="batchnorm", has_dropout=True)
+        return [a.next_seed() for _ in range(3)], [b.next_seed() for _ in range(3)]
+
+    a1, b1 = two(1337)
+    a2, b2 = two(1337)
+    a3, _ = two(1338)
+    assert a1 == a2 and b1 == b2, "torch.manual_seed must reproduce the dropout streams"
+    assert a1 != b1 and not set(a1) & set(b1), "student and teacher must not share a dropout stream"
+    assert a1 != a3, "--seed must change the dropout stream"
+    os.environ["RANK"] = "1"
+    try:
+        r1, _ = two(1337)
+    finally:
+        del os.environ["RANK"]
+    assert r1 != a1, "data-parallel ranks must draw different masks"

@@ -47,3 +47,15 @@ def test_la_step_reference_default_batch(emu_ops):
 def test_pancreas_self_train_step(emu_ops):
     NC.check_pancreas_step(emu_ops, CPU, modes=(True,))   # (grouped == four separate calls is a GPU test: tests/test_gpu_scripts.py)
 
+
+
+def test_optimizer_state_is_torch_format_la(emu_ops, golden_dir):
+    NC.check_opt_state_compat(emu_ops, CPU, golden_dir, variant="la")
+
+
+def test_optimizer_state_is_torch_format_pancreas(emu_ops, golden_dir):
+    NC.check_opt_state_compat(emu_ops, CPU, golden_dir, variant="pancreas")
+
+
+def test_dropout_streams_are_per_network():
+    NC.check_dropout_streams(CPU)

@@ -93,3 +93,9 @@ def test_pancreas_self_train_step(ops):
 def test_la_step_reference_default_batch(ops):
     NC.check_la_step_batch8(ops, DEV)
 
+
+
+def test_optimizer_state_is_torch_format(ops, golden_dir):
+    """{'net','opt'} checkpoints interchange with torch.optim (= the reference's save_net_opt) on the device"""
+    NC.check_opt_state_compat(ops, DEV, golden_dir, variant="la")
+    NC.check_opt_state_compat(ops, DEV, golden_dir, variant="pancreas")
