@@ -25,6 +25,12 @@ SZ = C.c_size_t
 _SIGS = {
     "bcp_version": (I, []),
     "bcp_set_option": (I, [C.c_char_p, C.c_char_p]),
+    "bcp_comm_available": (I, []),
+    "bcp_comm_unique_id": (I, [P]),
+    "bcp_comm_init_rank": (I, [C.POINTER(P), I, I, P]),
+    "bcp_comm_count": (I, [P, C.POINTER(I)]),
+    "bcp_allreduce_f32": (I, [P, P, C.c_longlong, P]),
+    "bcp_comm_destroy": (I, [P]),
     "bcp_last_error": (C.c_char_p, []),
     "bcp_device_arch": (I, [C.c_char_p, I]),
     "bcp_event_create": (I, [C.POINTER(P)]),
@@ -107,7 +113,7 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
 
     def last_error(self) -> str:

@@ -1,22 +1,115 @@
 """Data parallelism for the BCP step: one process per GPU, every rank holds a full
 student + teacher replica and its own micro-batch / box / dropout stream; the ONLY exchange is the
-all-reduce (sum) of the flat fp32 gradient buffer per step over RCCL (torch.distributed backend "nccl" on
-ROCm; "gloo" in the CPU tests) -- a few >= 8 MB buckets in reverse layer order, started while the backward pass
-is still running -- scaled by 1/world inside the fused SGD launch.  BatchNorm statistics stay
-rank-local (DDP convention; the reference's only multi-GPU code, nn.DataParallel in
+all-reduce (sum) of the flat fp32 gradient buffer per step over RCCL -- a few >= 8 MB buckets in reverse layer
+order, started while the backward pass is still running -- scaled by 1/world inside the fused SGD launch.
+BatchNorm statistics stay rank-local (DDP convention; the reference's only multi-GPU code, nn.DataParallel in
 pancreas/dataloaders.py:14, also normalises per replica).  Teachers stay identical because the students
-do.  N ranks == N sequential micro-batches with averaged gradients (tests/test_dp_gloo.py)."""
+do.  N ranks == N sequential micro-batches with averaged gradients (tests/test_dp_gloo.py).
+
+Transports (BCP_DP_BACKEND, default "rccl" on a GPU):
+  * "rccl": the library's own communicator -- bcp_comm_init_rank / bcp_allreduce_f32 (include/bcp_hip.h, csrc/comm.hip:
+    ncclAllReduce on a stream we own); the 128-byte unique id travels from rank 0 through a file under BCP_DP_ID_DIR
+    (default /tmp) named after the launch (MASTER_PORT + TORCHELASTIC_RUN_ID).  torch.distributed is not imported.
+  * "nccl" / "gloo": torch.distributed process groups ("nccl" IS RCCL on ROCm; "gloo" runs the CPU tests).
+"""
 from __future__ import annotations
 
+import ctypes as C
 import os
+import time
 
 import torch
-import torch.distributed as dist
+
+
+class _RcclAbi:
+    """RCCL through the C ABI: communicator + one stream for the collectives"""
+
+    def __init__(self, world, rank, local_rank):
+        from . import _lib
+        self.b = _lib.product()
+        if not self.b.call("bcp_comm_available"):
+            raise RuntimeError("librccl.so could not be loaded")
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        ident = (C.c_char * 128)()
+        tag = f"{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{world}"
+        path = os.path.join(os.environ.get("BCP_DP_ID_DIR", "/tmp"), f"bcp_rccl_id_{tag}")
+        if rank == 0:
+            self.b.call("bcp_comm_unique_id", C.cast(ident, C.c_void_p))
+            tmp = path + f".{os.getpid()}"
+            with open(tmp, "wb") as f:
+                f.write(bytes(ident))
+            os.replace(tmp, path)                    # atomic: readers never see a half-written id
+        else:
+            t0 = time.time()
+            while True:
+                try:
+                    if os.path.getmtime(path) >= t0 - 600 and os.path.getsize(path) == 128:
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > 120:
+                    raise RuntimeError(f"rank {rank}: no RCCL unique id at {path} after 120 s")
+                time.sleep(0.01)
+            C.memmove(ident, open(path, "rb").read(), 128)
+        comm = C.c_void_p()
+        self.b.call("bcp_comm_init_rank", C.byref(comm), world, rank, C.cast(ident, C.c_void_p))
+        self.comm = comm
+        self.stream = torch.cuda.Stream(device=self.dev)
+        self.world, self.rank, self._path = world, rank, path
+        self.barrier()                               # every rank has read the id: rank 0 may remove the file
+        if rank == 0:
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def count(self):
+        n = C.c_int(0)
+        self.b.call("bcp_comm_count", self.comm, C.byref(n))
+        return int(n.value)
+
+    def all_reduce_async(self, t):
+        """sum `t` in place over the ranks on the communicator's stream, ordered after the current stream; returns an event"""
+        cur = torch.cuda.current_stream(t.device)
+        self.stream.wait_stream(cur)
+        t.record_stream(self.stream)
+        self.b.call("bcp_allreduce_f32", self.comm, t.data_ptr(), t.numel(), self.stream.cuda_stream)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
+
+    def all_reduce(self, t):
+        self.all_reduce_async(t).wait()              # the CURRENT STREAM waits (no host sync)
+
+    def barrier(self):
+        t = torch.ones(1, dtype=torch.float32, device=self.dev)
+        self.all_reduce(t)
+        torch.cuda.current_stream(self.dev).synchronize()
+
+    def broadcast(self, t, src=0):
+        f = t if t.dtype == torch.float32 else t.to(torch.float32)
+        if self.rank != src:
+            f.zero_()
+        self.all_reduce(f.view(-1))
+        if f is not t:
+            t.copy_(f)
+
+    def max_f64(self, v):
+        t = torch.zeros(self.world, dtype=torch.float32, device=self.dev)
+        t[self.rank] = float(v)
+        self.all_reduce(t)
+        return float(t.max().item())
+
+    def shutdown(self):
+        torch.cuda.synchronize(self.dev)
+        self.b.call("bcp_comm_destroy", self.comm)
+        self.comm = None
 
 
 class DataParallel:
     def __init__(self, backend=None, force=False):
-        """force: build the process group even for WORLD_SIZE=1 (a one-rank RCCL communicator: the collective is the identity,
+        """force: build the communicator even for WORLD_SIZE=1 (a one-rank RCCL communicator: the collective is the identity,
         but the stream ordering of the bucketed exchange is the real one -- tests/test_gpu_scripts.py)"""
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
@@ -25,23 +118,53 @@ class DataParallel:
         self.bucket_bytes = int(float(os.environ.get("BCP_DP_BUCKET_MB", "8")) * (1 << 20))
         self.n_collectives = 0
         self._works, self._armed, self._hi = [], False, 0
-        if self.enabled and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29500")
-            if backend is None:
-                backend = "nccl" if torch.cuda.is_available() else "gloo"
+        self.abi = None
+        self.backend = None
+        if not self.enabled:
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = os.environ.get("BCP_DP_BACKEND") or ("rccl" if torch.cuda.is_available() else "gloo")
+        self.backend = backend
+        if backend == "rccl":
+            self.abi = _RcclAbi(self.world, self.rank, self.local_rank)
+            return
+        import torch.distributed as dist
+        if not dist.is_initialized():
             if backend == "nccl":
                 torch.cuda.set_device(self.local_rank)
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
+
+    def ranks_seen(self) -> int:
+        """how many ranks the communicator really spans (bench.py reports it so that a multi-GPU number can be checked)"""
+        if not self.enabled:
+            return 1
+        if self.abi is not None:
+            t = torch.ones(1, dtype=torch.float32, device=self.abi.dev)
+            self.abi.all_reduce(t)
+            n = int(round(float(t.item())))
+            assert n == self.abi.count(), "all-reduce of ones and ncclCommCount disagree"
+            return n
+        import torch.distributed as dist
+        t = torch.ones(1, dtype=torch.float32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t)
+        return int(round(float(t.item())))
 
     def broadcast_params(self, model):
         """rank 0's weights (and BN buffers) everywhere, once at start"""
         if not self.enabled:
             return
         flat = model.flat_params()
-        dist.broadcast(flat, src=0)
-        for b in model.buffers():
-            dist.broadcast(b, src=0)
+        if self.abi is not None:
+            self.abi.broadcast(flat)
+            for b in model.buffers():
+                self.abi.broadcast(b)
+        else:
+            import torch.distributed as dist
+            dist.broadcast(flat, src=0)
+            for b in model.buffers():
+                dist.broadcast(b, src=0)
         model.bump()
 
     # ---- gradient exchange.  Default: buckets of >= bucket_mb MB, reduced in reverse layer order while the backward pass is
@@ -51,7 +174,7 @@ class DataParallel:
     def arm(self, model):
         """call right before the step's single loss.backward(): the network reports, layer by layer, how much of the flat
         gradient buffer is final, and suffixes of at least `bucket_mb` are all-reduced asynchronously from then on.  On a GPU
-        the collective is ordered after the weight-gradient side stream and runs on the process group's own stream
+        the collective is ordered after the weight-gradient side stream and runs on the communicator's own stream
         underneath the remaining dgrad / norm-backward kernels (xGMI ring time hidden behind the shallow, expensive levels:
         the deep levels hold 80 % of the V-Net's parameters and are differentiated first)."""
         self._works, self._armed = [], False
@@ -68,6 +191,12 @@ class DataParallel:
         self._launch(model, lo, self._hi, like, overlapped=True)
         self._hi = lo
 
+    def _all_reduce_async(self, g):
+        if self.abi is not None:
+            return self.abi.all_reduce_async(g)
+        import torch.distributed as dist
+        return dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+
     def _launch(self, model, lo, hi, like, overlapped):
         g = model.flat_grads()[lo:hi]
         side = model._side_streams.get(like.device) if (overlapped and like.is_cuda and model.overlap_wgrad) else None
@@ -76,9 +205,9 @@ class DataParallel:
             # stream: order the collective after both (the side stream's later weight gradients need later dy anyway)
             side.wait_stream(torch.cuda.current_stream(like.device))
             with torch.cuda.stream(side):
-                self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+                self._works.append(self._all_reduce_async(g))
         else:
-            self._works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True))
+            self._works.append(self._all_reduce_async(g))
         self.n_collectives += 1
 
     def allreduce_grads(self, model, optimizer=None):
@@ -94,10 +223,14 @@ class DataParallel:
             if self._hi > 0:
                 self._launch(model, 0, self._hi, g, overlapped=False)
             for w in self._works:
-                w.wait()                 # nccl: the current stream waits for the collective; gloo: the host does
+                w.wait()                 # rccl / nccl: the current stream waits for the collective; gloo: the host does
             self._works = []
         else:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            if self.abi is not None:
+                self.abi.all_reduce(g)
+            else:
+                import torch.distributed as dist
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
             self.n_collectives += 1
         if optimizer is not None and hasattr(optimizer, "grad_scale"):
             optimizer.grad_scale = 1.0 / self.world
@@ -105,16 +238,31 @@ class DataParallel:
             g.mul_(1.0 / self.world)
 
     def barrier(self):
-        if self.enabled:
+        if not self.enabled:
+            return
+        if self.abi is not None:
+            self.abi.barrier()
+        else:
+            import torch.distributed as dist
             dist.barrier()
 
     def max_over_ranks(self, value: float) -> float:
         if not self.enabled:
             return value
+        if self.abi is not None:
+            return self.abi.max_f64(value)
+        import torch.distributed as dist
         t = torch.tensor([value], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
     def shutdown(self):
-        if self.enabled and dist.is_initialized():
+        if not self.enabled:
+            return
+        if self.abi is not None:
+            self.abi.shutdown()
+            self.abi = None
+            return
+        import torch.distributed as dist
+        if dist.is_initialized():
             dist.destroy_process_group()

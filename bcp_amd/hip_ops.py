@@ -501,3 +501,63 @@ class Ops:
         ms = C.c_float()
         self.b.call("bcp_event_elapsed_ms", e0, e1, C.byref(ms))
         return ms.value
+
+
+# ---------------------------------------------------------------------------------------------- measurement hooks
+# bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
+# (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
+_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "conv3_pack_many",
+             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
+             "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
+             "copy_channels", "ema", "sgd", "adam")
+
+
+def _profiled(name, fn):
+    def wrapper(self, *a, **k):
+        prof = self._prof
+        if prof is None:
+            return fn(self, *a, **k)
+        ts = [t for t in a if isinstance(t, torch.Tensor)]
+        like = ts[0]
+        e0, e1 = self._prof_event(), self._prof_event()
+        self.event_record(e0, like)
+        r = fn(self, *a, **k)
+        self.event_record(e1, like)
+        extra = tuple(x for x in a if isinstance(x, int))[:3]
+        prof.append((name, tuple(tuple(t.shape) for t in ts[:3]), extra, e0, e1))
+        return r
+    wrapper.__name__ = name
+    wrapper.__doc__ = fn.__doc__
+    return wrapper
+
+
+def _install_profile_hooks():
+    Ops._prof = None
+    Ops._prof_pool = None
+
+    def _prof_event(self):
+        if self._prof_pool:
+            return self._prof_pool.pop()
+        return self.event()
+
+    def profile_begin(self):
+        """start recording (op, shapes, HIP events) of every profiled op"""
+        self._prof = []
+        if self._prof_pool is None:
+            self._prof_pool = []
+
+    def profile_end(self):
+        """-> [(op, shapes, ints, milliseconds)] in call order; the caller must have synchronised the device"""
+        rec, self._prof = self._prof, None
+        out = []
+        for name, shapes, extra, e0, e1 in rec:
+            out.append((name, shapes, extra, self.event_elapsed_ms(e0, e1)))
+            self._prof_pool.append(e0); self._prof_pool.append(e1)
+        return out
+
+    Ops._prof_event, Ops.profile_begin, Ops.profile_end = _prof_event, profile_begin, profile_end
+    for n in _PROFILED:
+        setattr(Ops, n, _profiled(n, getattr(Ops, n)))
+
+
+_install_profile_hooks()

@@ -5,13 +5,20 @@ fp32, random-init weights, everything inside the timed region that the reference
 (LA_BCP_train.py:235-270): teacher forward x2, pseudo-label + largest-CC x2, box draw, copy-paste mix x2,
 student forward x2, masked Dice+CE x2, backward, [gradient all-reduce when N>1], SGD, EMA.
 
-  python bench.py [--gpus N --steps K --warmup W]
+  python bench.py [--gpus N --steps K --warmup W] [--workload la|acdc|pancreas]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0).  `roofline` = the dominant kernel (k_conv3_res, the fp32-MFMA implicit-GEMM
-3x3x3 conv at the 16->16 @112x112x80 layer: 13.87 GFLOP algorithmic per launch) timed with HIP events on
-the launch stream in this process; `cpu_baseline` = the oracle (CPU restatement of the reference,
-oracle/bcp_oracle.py) timed on this box's host cores on a bounded sample of the same workload.
+Prints ONE JSON line (rank 0):
+  value         whole-job items/s over the K timed steps (inputs resident in HBM; barrier + synchronize on both sides, max over ranks)
+  kernels       per-op table of the step (top entries by time per step): HIP events on the launch stream around every op of
+                `--profile-steps` additional steps run right after the timed region (the timed region itself carries no events:
+                ~600 event records per step would cost the GPU queue ~5 % of a step); algorithmic FLOP or bytes per launch,
+                average microseconds, achieved TFLOP/s or GB/s, fraction of the fp32-MFMA / HBM peak
+  roofline      the MFMA-bound entry of that table with the LARGEST share of the step (not a hand-picked layer), plus the HBM-side
+                bytes of the same kernel from the committed rocprofv3 --pmc passes when profiles/ holds them
+  cpu_baseline  the oracle (CPU restatement of the reference, oracle/bcp_oracle.py) on this box's host cores: median of >= 5 timed
+                steps after 2 warm-ups (rank 0, N = 1 only)
+  ranks_seen    N > 1: all-reduce of ones over the communicator (= the ranks RCCL really spans)
 """
 import argparse
 import json
@@ -26,6 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0               # same guide: HBM3E spec (6290 GB/s measured with a float4 copy)
 STEP_GFLOP_PER_VOLUME = 160.0       # 1/2 teacher fwd + 1/2 student fwd+bwd per input volume
 
 
@@ -42,48 +50,132 @@ def build_models(dev, seed):
     return model, ema_model
 
 
-def dominant_kernel_roofline(dev):
-    """k_conv3_res<3,4,4,16,1> at the shape the step launches it with -- the 16->16 layer at 112x112x80 over the grouped
-    batch of 2 (the two teacher / student sub-batches go through every layer as ONE launch) -- HIP events on the launch stream"""
+# ------------------------------------------------------------------------------------------------ per-op table
+def _numel(s):
+    n = 1
+    for v in s:
+        n *= v
+    return n
+
+
+def _work(name, shapes, ints):
+    """algorithmic work of one call: (bound, flops, bytes).  SURVEY.md 8d / DESIGN.md section 3: every tensor read / written once"""
+    s0 = shapes[0] if shapes else ()
+    if name in ("conv3_fwd", "conv3_fwd_stats"):          # (x [N,D,H,W,Cin], wp, [bias]); ints = (Cout, KD)
+        cout, kd = ints[0], ints[1]
+        vox = _numel(s0[:-1])
+        return "mfma", 2.0 * vox * kd * 9 * s0[-1] * cout, 4.0 * (_numel(s0) + vox * cout)
+    if name == "conv3_wgrad":                              # (x, dy, dw); ints = (KD,)
+        vox = _numel(s0[:-1])
+        return "mfma", 2.0 * vox * ints[0] * 9 * s0[-1] * shapes[1][-1], 4.0 * (_numel(s0) + _numel(shapes[1]))
+    if name in ("conv3_c1_fwd", "conv3_c1_wgrad"):         # Cin = 1 -> 16: HBM-bound (AI 12.7)
+        vox = _numel(s0[:-1])
+        return "hbm", 2.0 * vox * ints[0] * 9 * 16, 4.0 * vox * 17
+    if name in ("down_fwd", "up_fwd", "down_dgrad", "up_dgrad", "pw_fwd"):   # k2s2 / 1x1 GEMMs: (x, packed B, [bias]); ints = (Cout,)
+        cout = ints[0]
+        vin = _numel(s0[:-1])
+        k = 1 if name == "pw_fwd" else 8
+        vout = vin * 8 if name in ("up_fwd", "down_dgrad") else (vin // 8 if name in ("down_fwd", "up_dgrad") else vin)
+        fl = 2.0 * min(vin, vout) * k * s0[-1] * cout
+        by = 4.0 * (_numel(s0) + vout * cout)
+        return ("hbm" if fl / by < 20 else "mfma"), fl, by
+    if name == "k2_wgrad":
+        fl = 2.0 * min(_numel(s0[:-1]), _numel(shapes[1][:-1])) * 8 * s0[-1] * shapes[1][-1]
+        by = 4.0 * (_numel(s0) + _numel(shapes[1]))
+        return ("hbm" if fl / by < 20 else "mfma"), fl, by
+    if name == "norm_fwd":                                 # statistics (fused into the conv when possible) + apply: read y twice, write a
+        return "hbm", 0.0, 12.0 * _numel(s0)
+    if name == "norm_bwd":                                 # statistics pass over (y, da) + apply pass reading both, writing dy
+        return "hbm", 0.0, 20.0 * _numel(s0)
+    if name == "pw16_fwd":
+        return "hbm", 0.0, 4.0 * (_numel(s0) + _numel(s0[:-1]) * (ints[0] if ints else 2))
+    if name == "pw16_bwd":
+        return "hbm", 0.0, 4.0 * (2 * _numel(s0) + _numel(shapes[1]))
+    if name == "mixloss_fwd":
+        return "hbm", 0.0, _numel(s0) * 4.0 + 2.0 * _numel(s0[:-1])
+    if name == "mixloss_bwd":
+        return "hbm", 0.0, _numel(s0) * 8.0 + 2.0 * _numel(s0[:-1])
+    if name == "mix_box":
+        return "hbm", 0.0, 12.0 * _numel(s0)
+    if name == "plabel_bin":
+        return "hbm", 0.0, 4.0 * _numel(s0) + _numel(s0[:-1])
+    if name == "ema":
+        return "hbm", 0.0, 12.0 * _numel(s0)
+    if name == "sgd":
+        return "hbm", 0.0, 20.0 * _numel(s0)
+    if name == "adam":
+        return "hbm", 0.0, 28.0 * _numel(s0)
+    return None, 0.0, 0.0
+
+
+def op_table(records, steps, step_ms, top=14):
+    agg = {}
+    for name, shapes, ints, ms in records:
+        a = agg.setdefault((name, shapes[:2], ints[:2]), [0, 0.0, shapes, ints])
+        a[0] += 1
+        a[1] += ms
+    rows = []
+    for (name, _, _), (calls, tot, shapes, ints) in agg.items():
+        bound, fl, by = _work(name, shapes, ints)
+        avg = tot / calls
+        row = {"op": name, "shape": "x".join(str(v) for v in shapes[0]) if shapes else "", "launches_per_step": round(calls / steps, 2),
+               "avg_us": round(avg * 1e3, 1), "ms_per_step": round(tot / steps, 4), "share_of_step": round(tot / steps / step_ms, 4), "bound": bound}
+        if bound == "mfma":
+            tf = fl / (avg * 1e-3) / 1e12
+            row.update({"flop_per_launch": fl, "achieved_tflops": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
+        elif bound == "hbm":
+            gbs = by / (avg * 1e-3) / 1e9
+            row.update({"bytes_per_launch": by, "achieved_gbs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    return rows[:top], rows
+
+
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (tools/collect_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate
+    runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams).  bench.py cannot run the profiler itself;
+    null when profiles/ holds no entry for this op."""
+    for fn in ("r02_pmc_ops.json",):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", fn)))
+        except Exception:
+            continue
+        e = d.get(kernel_key)
+        if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            return {"bytes_per_launch": int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024), "fetch_kb_raw": e["FETCH_SIZE"], "write_kb": e["WRITE_SIZE"],
+                    "source": "profiles/" + fn}
+    return None
+
+
+def roofline_from(rows, bound="mfma"):
+    cand = [r for r in rows if r.get("bound") == bound]
+    if not cand:
+        return None
+    r = max(cand, key=lambda q: q["ms_per_step"])
+    key = f"{r['op']}[{r['shape']}]"
+    if bound == "mfma":
+        return {"bound": "mfma", "kernel": key, "achieved": r["achieved_tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
+                "flop_per_launch": r["flop_per_launch"], "avg_launch_ms": round(r["avg_us"] / 1e3, 4), "launches_per_step": r["launches_per_step"],
+                "share_of_step": r["share_of_step"], "traffic": pmc_traffic(key),
+                "how": "HIP events on the launch stream around every launch of this op inside profiled steps run right after the timed region"}
+    return {"bound": "hbm", "kernel": key, "achieved": r["achieved_gbs"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": r["frac"],
+            "bytes_per_launch": r["bytes_per_launch"], "avg_launch_ms": round(r["avg_us"] / 1e3, 4), "traffic": pmc_traffic(key)}
+
+
+def profile_steps(step, n):
     from bcp_amd.hip_ops import Ops
     ops = Ops.product()
-    N, sp, C = 2, (112, 112, 80), 16
-    x = torch.randn(N, *sp, C, device=dev)
-    w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
-    b = torch.zeros(C, device=dev)
-    wf, _ = ops.conv3_pack(w, 3)
-    y = torch.empty(N, *sp, C, device=dev)
-    for _ in range(3):
-        ops.conv3_fwd(x, wf, b, C, 3, out=y)
-    e0, e1 = ops.event(), ops.event()
-    iters = 20
-    ops.event_record(e0, x)
-    for _ in range(iters):
-        ops.conv3_fwd(x, wf, b, C, 3, out=y)
-    ops.event_record(e1, x)
-    ms = ops.event_elapsed_ms(e0, e1) / iters
-    flops = 2.0 * N * sp[0] * sp[1] * sp[2] * 27 * C * C
-    ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "k_conv3_res<3,4,4,16,1> (3x3x3 conv 16->16 @112x112x80 x batch 2 as launched in the step, fwd/dgrad)",
-            "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-            "flop_per_launch": flops, "avg_launch_ms": round(ms, 4), "traffic": pmc_traffic()}
+    torch.cuda.synchronize()
+    ops.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    return ops.profile_end(), ms
 
 
-def pmc_traffic():
-    """HBM-side bytes per launch of the same kernel from the committed rocprofv3 --pmc passes (tools/collect_pmc.sh: FETCH_SIZE
-    and WRITE_SIZE in separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams).  bench.py
-    cannot run the profiler itself; null when the file is absent."""
-    p = os.path.join(ROOT, "profiles", "r01_pmc_conv3_c16_v3.json")
-    try:
-        d = json.load(open(p))["k_conv3_res<3,4,4,16,1>"]
-        return {"bytes_per_launch": int((2 * d["FETCH_SIZE"] + d["WRITE_SIZE"]) * 1024), "fetch_kb_raw": d["FETCH_SIZE"],
-                "write_kb": d["WRITE_SIZE"], "algorithmic_bytes": 2 * 2 * 1003520 * 16 * 4 + 27 * 16 * 16 * 4,
-                "mfma_busy_frac": round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (d["GRBM_GUI_ACTIVE"] / 8), 4),
-                "source": "profiles/r01_pmc_conv3_c16_v3.json"}
-    except Exception:
-        return None
-
-
+# ------------------------------------------------------------------------------------------------ CPU baseline
 def usable_cores():
     """threads this process may really use: scheduler affinity and the cgroup CPU quota, not os.cpu_count()
     (a container that reports 256 CPUs but owns 16 would otherwise be oversubscribed 16x)"""
@@ -103,55 +195,84 @@ def usable_cores():
     return max(1, min(n, 64))   # torch-CPU convs stop scaling long before 64 threads
 
 
-def cpu_baseline(batch, labeled_bs):
-    """the oracle's self-training step on the host cores: 1 warm-up + timed steps until ~20 s"""
+def cpu_baseline(workload, batch, labeled_bs, budget_s=45.0):
+    """the oracle's self-training step (forward x2 teacher, CC, mix, student forward / backward, optimiser, EMA) on the host cores:
+    2 warm-ups, then the median of >= 5 timed steps (fewer only if the time budget runs out -- said in `sample`)"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import bcp_oracle as O  # checker / baseline only
     cores = usable_cores()
     torch.set_num_threads(cores)
-    shapes = O.vnet_param_shapes()
+    rng = np.random.default_rng(0)
+    if workload == "acdc":
+        shapes = O.unet_param_shapes()
+        vol, lab = O.synth_acdc_batch(batch, seed=1337)
+        box = O.box_acdc(lambda lo, hi: int(rng.integers(lo, hi)))
+        unit, what = "slices/s", f"batch {batch}, 256x256"
+    elif workload == "pancreas":
+        shapes = O.vnet_param_shapes(variant="pancreas")
+        vol, lab = O.synth_la_batch(batch, shape=(96, 96, 96), seed=1337)
+        box = O.box_pancreas(lambda lo, hi: int(rng.integers(lo, hi)))
+        unit, what = "volumes/s", f"batch {batch}, 96^3"
+    else:
+        shapes = O.vnet_param_shapes()
+        vol, lab = O.synth_la_batch(batch, seed=1337)
+        box = O.box_la(lambda lo, hi: int(rng.integers(lo, hi)))
+        unit, what = "volumes/s", f"batch {batch}, 112x112x80"
     Ps = O.init_params(shapes, seed=1337)
     Pt = {k: v.clone() for k, v in Ps.items()}
     tkeys = O.trainable_keys(shapes)
-    vol, lab = O.synth_la_batch(batch, seed=1337)
-    rng = np.random.default_rng(0)
-    box = O.box_la(lambda lo, hi: int(rng.integers(lo, hi)))
-    bufs = {}
-    times = []
+    bufs, times = {}, []
+    sub = labeled_bs // 2
     t_start = time.time()
-    for it in range(3):
-        drops = {k: {"x5": torch.from_numpy((rng.random((labeled_bs // 2, 256)) < 0.5).astype(np.float32)),
-                     "x9": torch.from_numpy((rng.random((labeled_bs // 2, 16)) < 0.5).astype(np.float32))} for k in ("t_a", "t_b", "s_l", "s_u")}
+    warm, want = 2, 5
+    for it in range(warm + 9):
         t0 = time.time()
-        r = O.la_self_train_step(Ps, Pt, vol, lab, box, drops, labeled_bs // 2)
-        O.sgd_step(Ps, r["grads"], bufs, tkeys, lr=0.01)
-        O.ema_params(Ps, Pt, tkeys, 0.99)
+        if workload == "acdc":
+            r = O.acdc_self_train_step(Ps, Pt, vol, lab, box, {}, sub, (batch - labeled_bs) // 2)
+            O.sgd_step(Ps, r["grads"], bufs, tkeys, lr=0.01)
+            O.ema_state_dict(Ps, Pt, 0.99)
+        elif workload == "pancreas":
+            r = O.la_self_train_step(Ps, Pt, vol, lab, box, {}, sub, variant="pancreas", connectivity=2)
+            O.adam_step(Ps, r["grads"], bufs, tkeys)
+            O.ema_params(Ps, Pt, tkeys, 0.99)
+        else:
+            drops = {k: {"x5": torch.from_numpy((rng.random((sub, 256)) < 0.5).astype(np.float32)),
+                         "x9": torch.from_numpy((rng.random((sub, 16)) < 0.5).astype(np.float32))} for k in ("t_a", "t_b", "s_l", "s_u")}
+            r = O.la_self_train_step(Ps, Pt, vol, lab, box, drops, sub)
+            O.sgd_step(Ps, r["grads"], bufs, tkeys, lr=0.01)
+            O.ema_params(Ps, Pt, tkeys, 0.99)
         times.append(time.time() - t0)
         print(f"[bench] cpu_baseline step {it}: {times[-1]:.2f} s ({cores} threads)", file=sys.stderr, flush=True)
-        if time.time() - t_start > 25:
+        timed = len(times) - warm
+        if timed >= want and (timed >= 7 or time.time() - t_start > budget_s * 0.6):
             break
-    steady = times[1:] if len(times) > 1 else times
+        if time.time() - t_start > budget_s and timed >= 1:
+            break
+    steady = times[warm:] if len(times) > warm else times[-1:]
     sec = float(np.median(steady))
-    return {"value": round(batch / sec, 3), "unit": "volumes/s", "cores": cores, "kind": "port",
-            "sample": f"{len(steady)} timed self-train step(s) (batch {batch}, 112x112x80) after 1 warm-up, torch-CPU oracle, {cores} threads",
-            "sec_per_step": round(sec, 3)}
+    return {"value": round(batch / sec, 3), "unit": unit, "cores": cores, "kind": "port",
+            "sample": f"median of {len(steady)} timed self-train steps ({what}) after {min(warm, len(times) - len(steady))} warm-ups, torch-CPU oracle "
+                      f"(oracle/bcp_oracle.py), {cores} threads", "sec_per_step": round(sec, 3),
+            "sec_per_step_all": [round(t, 3) for t in steady]}
 
 
-def secondary(args):
-    """ACDC 2-D U-Net (configs[3]: batch 24 256x256, SGD, state-dict EMA) and pancreas IN-V-Net (configs[4]: 96^3, Adam) self-training
-    steps: same timing contract and JSON shape as the LA line, without the dominant-kernel / CPU legs (those belong to the
-    headline metric)."""
+# ------------------------------------------------------------------------------------------------ workloads
+def make_workload(args, dp, dev):
     from bcp_amd import synth, train_step
-    from bcp_amd.dp import DataParallel
-    from bcp_amd.hip_ops import Ops
-
-    dp = DataParallel()
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    dev = torch.device("cuda", dp.local_rank)
-    torch.cuda.set_device(dev)
-    Ops.product()
     seed = 1337 + dp.rank
-    np.random.seed(seed)
+    np.random.seed(seed)            # context_mask draws from the global numpy RNG as the reference does
+    if args.workload == "la":
+        model, ema_model = build_models(dev, 1337)
+        dp.broadcast_params(model); dp.broadcast_params(ema_model)
+        opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        vol, lab = synth.la_batch(args.batch_size, seed=seed)
+        vol, lab = vol.to(dev), lab.to(dev)
+
+        def step():
+            return train_step.la_self_train_step(model, ema_model, opt, vol, lab, args.labeled_bs, dp=dp if dp.enabled else None)
+        return step, {"metric": "training volumes/sec (LA 112x112x80 V-Net, BCP self-training step)", "unit": "volumes/s",
+                      "what": f"LA 3D V-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), 112x112x80 patches, "
+                              "SGD m0.9 wd1e-4, EMA 0.99 (BASELINE.json configs[1])", "gflop_per_item": STEP_GFLOP_PER_VOLUME}
     torch.manual_seed(1337)
     if args.workload == "acdc":
         from bcp_amd.networks.net_factory import BCP_net
@@ -162,52 +283,27 @@ def secondary(args):
         opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
         vol, lab = synth.acdc_batch(args.batch_size, seed=seed)
         vol, lab = vol.to(dev), lab.to(dev)
-        unit, what = "slices/s", f"ACDC 2D U-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), 256x256 slices, SGD, state-dict EMA (BASELINE.json configs[3])"
-        gflop_per_item = 5.90 * 2          # 5.90 GFLOP fwd / slice; step = 1/2 teacher fwd + 1/2 (fwd + 2x bwd) per input slice
 
         def step():
             return train_step.acdc_self_train_step(model, ema_model, opt, vol, lab, args.labeled_bs, dp=dp if dp.enabled else None)
-    else:
-        from bcp_amd.pancreas import train_pancreas as TP
-        from bcp_amd.pancreas.Vnet import create_Vnet
-        model, ema_model = create_Vnet(), create_Vnet(ema=True)
-        ema_model.load_state_dict(model.state_dict())
-        dp.broadcast_params(model); dp.broadcast_params(ema_model)
-        opt = train_step.FlatAdam(model, lr=1e-3)
-        assert args.batch_size % 4 == 0, "pancreas: four equal streams (lab_a, lab_b, unlab_a, unlab_b)"
-        streams = TP._streams(dev, 4, args.batch_size // 4, seed=seed)
-        unit, what = "volumes/s", f"Pancreas IN-V-Net BCP self-train step, per-GPU 4 streams x {args.batch_size // 4}, 96^3 patches, Adam 1e-3 (BASELINE.json configs[4])"
-        gflop_per_item = 70.72 * 2
+        return step, {"metric": "training slices/sec (ACDC 256x256 U-Net, BCP self-training step)", "unit": "slices/s",
+                      "what": f"ACDC 2D U-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), 256x256 slices, SGD, "
+                              "state-dict EMA (BASELINE.json configs[3])",
+                      "gflop_per_item": 5.90 * 2}   # 5.90 GFLOP fwd / slice; step = 1/2 teacher fwd + 1/2 (fwd + 2x bwd) per input slice
+    from bcp_amd.pancreas import train_pancreas as TP
+    from bcp_amd.pancreas.Vnet import create_Vnet
+    model, ema_model = create_Vnet(), create_Vnet(ema=True)
+    ema_model.load_state_dict(model.state_dict())
+    dp.broadcast_params(model); dp.broadcast_params(ema_model)
+    opt = train_step.FlatAdam(model, lr=1e-3)
+    assert args.batch_size % 4 == 0, "pancreas: four equal streams (lab_a, lab_b, unlab_a, unlab_b)"
+    streams = TP._streams(dev, 4, args.batch_size // 4, seed=seed)
 
-        def step():
-            return {"loss": TP.ema_cutmix(model, ema_model, opt, streams, 1, dp=dp if dp.enabled else None)}
-
-    for _ in range(args.warmup):
-        step()
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
-    t_enq = time.perf_counter() - t0
-    torch.cuda.synchronize()
-    dp.barrier()
-    dt = dp.max_over_ranks(time.perf_counter() - t0)
-    loss = float(r["loss"])
-    assert np.isfinite(loss), "non-finite loss in the timed region"
-    if dp.rank == 0:
-        gb = args.batch_size * dp.world
-        value = gb * args.steps / dt
-        tf = value * gflop_per_item / 1e3 / dp.world
-        print(json.dumps({
-            "metric": f"training {unit.split('/')[0]}/sec ({args.workload} BCP self-training step)", "value": round(value, 3), "unit": unit,
-            "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3),
-            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": what, "global_batch": gb, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6)},
-            "step_flops": {"gflop_per_item": gflop_per_item, "achieved_tflops_per_gpu": round(tf, 2),
-                           "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}}), flush=True)
-    dp.shutdown()
+    def step():
+        return {"loss": TP.ema_cutmix(model, ema_model, opt, streams, 1, dp=dp if dp.enabled else None)}
+    return step, {"metric": "training volumes/sec (Pancreas 96^3 IN-V-Net, BCP self-training step)", "unit": "volumes/s",
+                  "what": f"Pancreas IN-V-Net BCP self-train step, per-GPU 4 streams x {args.batch_size // 4}, 96^3 patches, Adam 1e-3 "
+                          "(BASELINE.json configs[4])", "gflop_per_item": 70.72 * 2}
 
 
 def main():
@@ -220,23 +316,18 @@ def main():
     ap.add_argument("--batch_size", type=int, default=None, help="per-GPU batch (la: 4 = configs[1]; acdc: 24 = configs[3]; pancreas: 4)")
     ap.add_argument("--labeled_bs", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=3, help="steps run with per-op HIP events after the timed region (0: no kernels table)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning switch (bcp_set_option) for A/B measurements; the product defaults need none")
-    ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel roofline launches (A/B runs)")
+    ap.add_argument("--no-roofline", action="store_true", help="same as --profile-steps 0 (A/B runs)")
     args = ap.parse_args()
-    if args.opt:
-        from bcp_amd.hip_ops import Ops as _Ops
-        for kv in args.opt:
-            k, _, v = kv.partition("=")
-            _Ops.product().set_option(k, v)
     if args.batch_size is None:
         args.batch_size = {"la": 4, "acdc": 24, "pancreas": 4}[args.workload]
     if args.labeled_bs is None:
         args.labeled_bs = args.batch_size // 2
-    if args.workload != "la":
-        return secondary(args)
+    if args.no_roofline:
+        args.profile_steps = 0
 
-    from bcp_amd import synth, train_step
     from bcp_amd.dp import DataParallel
     from bcp_amd.hip_ops import Ops
 
@@ -245,18 +336,12 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = torch.device("cuda", dp.local_rank)
     torch.cuda.set_device(dev)
-    Ops.product()
-    seed = 1337 + dp.rank
-    np.random.seed(seed)            # context_mask draws from the global numpy RNG as the reference does
-    model, ema_model = build_models(dev, 1337)
-    dp.broadcast_params(model)
-    dp.broadcast_params(ema_model)
-    opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
-    vol, lab = synth.la_batch(args.batch_size, seed=seed)
-    vol, lab = vol.to(dev), lab.to(dev)
-
-    def step():
-        return train_step.la_self_train_step(model, ema_model, opt, vol, lab, args.labeled_bs, dp=dp if dp.enabled else None)
+    ops = Ops.product()
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        ops.set_option(k, v)
+    step, info = make_workload(args, dp, dev)
+    ranks_seen = dp.ranks_seen()
 
     for _ in range(args.warmup):
         step()
@@ -273,28 +358,39 @@ def main():
     loss = float(r["loss"])
     assert np.isfinite(loss), "non-finite loss in the timed region"
 
+    rows_top, rows_all, prof_ms = [], [], None
+    if args.profile_steps > 0:
+        recs, prof_ms = profile_steps(step, args.profile_steps)
+        rows_top, rows_all = op_table(recs, args.profile_steps, dt / args.steps * 1e3)
+    dp.barrier()
+
     if dp.rank == 0:
         ms = dt / args.steps * 1e3
         global_batch = args.batch_size * dp.world
         value = global_batch * args.steps / dt
-        roof = dominant_kernel_roofline(dev) if not args.no_roofline else {"achieved": None}
-        step_tflops = value * STEP_GFLOP_PER_VOLUME / 1e3 / dp.world
+        step_tflops = value * info["gflop_per_item"] / 1e3 / dp.world
         out = {
-            "metric": "training volumes/sec (LA 112x112x80 V-Net, BCP self-training step)",
-            "value": round(value, 3), "unit": "volumes/s", "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"LA 3D V-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), "
-                                   "112x112x80 patches, SGD m0.9 wd1e-4, EMA 0.99 (BASELINE.json configs[1])",
-                       "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6)},
-            "roofline": roof,
-            "step_flops": {"gflop_per_volume": STEP_GFLOP_PER_VOLUME, "achieved_tflops_per_gpu": round(step_tflops, 2),
+            "metric": info["metric"], "value": round(value, 3), "unit": info["unit"], "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6)},
+            "ranks_seen": ranks_seen,
+            "step_flops": {"gflop_per_item": info["gflop_per_item"], "achieved_tflops_per_gpu": round(step_tflops, 2),
                            "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
         }
-        print(f"[bench] gpu: {value:.2f} volumes/s, {ms:.2f} ms/step (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step), "
-              f"dominant kernel {roof['achieved']} TFLOP/s", file=sys.stderr, flush=True)
+        if rows_all:
+            out["roofline"] = roofline_from(rows_all, "mfma")
+            out["roofline_hbm"] = roofline_from(rows_all, "hbm")
+            out["kernels"] = rows_top
+            out["kernels_note"] = (f"{args.profile_steps} profiled steps of {prof_ms:.2f} ms after the timed region; ms_per_step sums over streams "
+                                   "(teacher / student / weight-gradient streams overlap), so shares add up to more than 1")
+        else:
+            out["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+        r0 = out["roofline"] or {}
+        print(f"[bench] gpu: {value:.2f} {info['unit']}, {ms:.2f} ms/step (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step), "
+              f"dominant MFMA op {r0.get('kernel')} {r0.get('achieved')} TFLOP/s", file=sys.stderr, flush=True)
         if dp.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.batch_size, args.labeled_bs)
+            out["cpu_baseline"] = cpu_baseline(args.workload, args.batch_size, args.labeled_bs)
         print(json.dumps(out), flush=True)
     dp.shutdown()
 

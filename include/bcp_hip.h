@@ -7,7 +7,9 @@
  * Conventions
  *   - every function returns 0 (BCP_OK) or a negative BCP_E* code; bcp_last_error() (thread-local)
  *     explains the last failure.  Nothing throws, nothing calls exit().
- *   - all pointers are DEVICE pointers owned by the caller (outputs and workspaces included);
+ *   - all pointers are DEVICE pointers owned by the caller (outputs and workspaces included), EXCEPT the small host-side
+ *     arguments that say so in their comment: `box6` / `affine6` (six ints / doubles read when the call is made), option and
+ *     error strings, and the bcp_comm_* handles;
  *     `*_workspace_bytes` tells how much scratch an op needs.  The library allocates nothing and
  *     never synchronises: work is enqueued on `stream` (a hipStream_t passed as void*).
  *   - activations are channels-last fp32: [N][D][H][W][C] (2-D: D = 1).  float* must be 16-B aligned.
@@ -56,7 +58,7 @@ int bcp_event_destroy(void* ev);
  *      train_pancreas.py:155-156; mask from utils/BCP_utils.py:18-28 context_mask / ACDC generate_mask).
  *      16-byte vector path only: W * C must be a multiple of 4 (80, 96 and 256 in the reference's configurations); other extents are
  *      rejected with BCP_EINVAL. */
-int bcp_mix_box(const float* a, const float* b, float* out, int N, int D, int H, int W, int C, const int* box6, void* stream);
+int bcp_mix_box(const float* a, const float* b, float* out, int N, int D, int H, int W, int C, const int* box6 /* HOST */, void* stream);
 
 /* ---- pseudo-labels (LA_BCP_train.py:57-60 get_cut_mask; ACDC_BCP_train.py:112-114 get_ACDC_masks) ---------- */
 int bcp_plabel_bin(const float* logits /*[n_vox][2]*/, uint8_t* out, long long n_vox, float thres, void* stream);
@@ -75,10 +77,10 @@ int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8_or_null, float* out_f32_o
  *      bwd writes d(g_dice*dice + g_ce*ce)/dlogits (LA: g_dice = g_ce = 0.5); g_dev_or_null = device float[2] of upstream
  *      gradients multiplied in on the device, so autograd never has to read a scalar back. */
 size_t bcp_mixloss_workspace_bytes(int N, int C);
-int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6,
+int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6 /* HOST */,
                     int N, int D, int H, int W, int C, int flavour, float w_img, float w_patch, void* workspace, float* out3,
                     void* stream);
-int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6,
+int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6 /* HOST */,
                     int N, int D, int H, int W, int C, int flavour, const void* workspace, float g_dice, float g_ce, const float* g_dev_or_null,
                     float* dlogits, void* stream);
 
@@ -203,6 +205,20 @@ int bcp_acdc_augment(const void* src, void* dst, int elem_bytes, int H, int W, i
 int bcp_cast(const void* in, void* out, long long n, int kind, void* stream);
 int bcp_axpy(float* y, const float* x, long long n, float a, void* stream);
 int bcp_bernoulli(void* out, long long n, float p_keep, float keep_value, int as_u8, unsigned long long seed, void* stream);
+
+/* ---- data-parallel gradient exchange: all-reduce (sum, in place) of the flat fp32 gradient buffer over RCCL /
+ *      xGMI.  No reference counterpart for LA / ACDC (its only multi-GPU code is nn.DataParallel, pancreas/dataloaders.py:14);
+ *      this is the exchange a one-process-per-GPU run needs between loss.backward() and optimizer.step()
+ *      (LA_BCP_train.py:265-267).  librccl.so is dlopen()ed on first use.  `comm`, `id128`, `world` are HOST pointers;
+ *      `buf` is a DEVICE pointer; the collective is enqueued on `stream` and nothing synchronises the host.
+ *      Bootstrap: rank 0 calls bcp_comm_unique_id and hands the 128 bytes to every rank (file, TCP store, ...); every rank
+ *      then calls bcp_comm_init_rank (collective). */
+int bcp_comm_available(void);                                  /* 1 when librccl.so could be loaded */
+int bcp_comm_unique_id(void* id128);
+int bcp_comm_init_rank(void** comm, int world, int rank, const void* id128);
+int bcp_comm_count(void* comm, int* world);                    /* ranks the communicator really spans */
+int bcp_allreduce_f32(void* comm, float* buf, long long n, void* stream);
+int bcp_comm_destroy(void* comm);
 
 #ifdef __cplusplus
 }

@@ -115,9 +115,11 @@ def test_dp_bucketed_allreduce_over_rccl_one_rank():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BCP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", _DP1], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "DP1 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    # "rccl": the library's own communicator through the C ABI (bcp_comm_init_rank / bcp_allreduce_f32); "nccl": torch.distributed
+    for backend in ("rccl", "nccl"):
+        env = dict(os.environ, BCP_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0", BCP_DP_BACKEND=backend)
+        r = subprocess.run([sys.executable, "-c", _DP1], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DP1 OK" in r.stdout, backend + ": " + r.stdout[-2000:] + r.stderr[-4000:]
 
 
 _DP2 = r"""

@@ -7,7 +7,7 @@ OUT="$ROOT/tests/_emu"
 mkdir -p "$OUT"
 CXX=/opt/rocm/lib/llvm/bin/clang++
 [ -x "$CXX" ] || CXX=clang++
-SRCS="api elementwise loss norm conv3 conv3p gemm cc pool2d eval"
+SRCS="api elementwise loss norm conv3 conv3p gemm cc pool2d eval comm"
 OBJS=""
 for s in $SRCS; do
   $CXX -x c++ -O2 -std=c++17 -fPIC -w -I "$ROOT/tools/emu" -c "$ROOT/bcp_amd/csrc/$s.hip" -o "$OUT/$s.o" &
@@ -15,5 +15,5 @@ for s in $SRCS; do
 done
 $CXX -O2 -std=c++17 -fPIC -w -I "$ROOT/tools/emu" -c "$ROOT/tools/emu/emu_runtime.cpp" -o "$OUT/emu_runtime.o" &
 wait
-$CXX -shared -o "$OUT/libbcp_emu.so" $OBJS "$OUT/emu_runtime.o" -lpthread
+$CXX -shared -o "$OUT/libbcp_emu.so" $OBJS "$OUT/emu_runtime.o" -lpthread -ldl
 echo "built $OUT/libbcp_emu.so"
