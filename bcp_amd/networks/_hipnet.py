@@ -442,6 +442,8 @@ class NetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, net):
         out, saved = net._forward_impl(x, save=True)
+        if getattr(net, "_keep_saved", False):      # parity tests: expose (y, stats) per layer -> activation patterns (tests/net_checks.py)
+            net._last_saved = saved
         ctx.net = net
         ctx.saved = saved
         return out

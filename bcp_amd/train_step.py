@@ -189,12 +189,15 @@ class FlatAdam:
 # ------------------------------------------------------------------------------------------ LA / pancreas step
 def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
                        u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None, grouped=True,
-                       overlap=True):
+                       overlap=True, plabs=None):
     """One self-training iteration, LA_BCP_train.py:235-270 (variant 'pancreas': train_pancreas.py:145-171).
 
     volume_batch [B,1,X,Y,Z] float32 laid out lab_a|lab_b|unlab_a|unlab_b, label_batch [B,X,Y,Z].
     box: explicit (w,h,z,pw,ph,pz) for parity runs, else drawn by context_mask from np.random as the
     reference does.  drops: optional injected Dropout3d keep-masks {'t_a','t_b','s_l','s_u'}.
+    plabs: parity hook like `box` / `drops` -- (plab_a, plab_b) uint8 pseudo-labels the student is trained on INSTEAD of the
+    teacher's (which are still computed and returned as 'plab_a' / 'plab_b'): takes the discrete pseudo-label bifurcations out
+    of a multi-step comparison (tests/net_checks.py:check_la_traj5).
     dp: optional bcp_amd.dp.DataParallel (gradient all-reduce before the optimiser step).
     grouped: launch the two teacher batches (and the two student batches) as ONE grouped forward each -- separately
     normalised exactly like the reference's two calls, but half the launches (False: two calls, as the scripts read).
@@ -246,6 +249,9 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
             sp = tuple(volume_batch.shape[2:])
             img_mask = BU.BoxMask(box, sp, None, False, volume_batch.device)
             loss_mask = BU.BoxMask(box, sp, sub_bs, False, volume_batch.device)
+    own_plabs = (plab_a, plab_b)
+    if plabs is not None:
+        plab_a, plab_b = plabs[0].to(volume_batch.device), plabs[1].to(volume_batch.device)
     # direction tables: LA_BCP_train.py:248-251 / train_pancreas.py:155-156
     pairs = ((img_a, unimg_a), (unimg_b, img_b)) if variant == "la" else ((unimg_a, img_b), (img_a, unimg_b))
     if variant == "la":
@@ -285,7 +291,7 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         BU.update_ema_variables(model, ema_model, alpha)
     model.drop_masks = None
     ema_model.drop_masks = None
-    return dict(loss=loss.detach(), loss_l=loss_l.detach(), loss_u=loss_u.detach(), plab_a=plab_a, plab_b=plab_b,
+    return dict(loss=loss.detach(), loss_l=loss_l.detach(), loss_u=loss_u.detach(), plab_a=own_plabs[0], plab_b=own_plabs[1],
                 outputs_l=outputs_l.detach(), outputs_u=outputs_u.detach())
 
 

@@ -220,12 +220,15 @@ def _next(pre):
     return f"{head}.{int(idx) + 1}"
 
 
-def vnet_forward(P, x, drop_masks=None, train=True, variant="la", has_dropout=True):
+def vnet_forward(P, x, drop_masks=None, train=True, variant="la", has_dropout=True, act_masks=None):
     """LA V-Net forward (networks/VNet.py:167-186, 213-239, 286-290) or pancreas V-Net
     (pancreas/Vnet.py:137-194).  Returns logits [N,ncls,X,Y,Z].
 
     drop_masks: None (no dropout) or dict {'x5': [N,256] 0/1, 'x9': [N,16] 0/1} keep-masks of
     the two Dropout3d(p=0.5) sites (VNet.py:182-183, 236-237); kept channels are scaled by 2.
+    act_masks: test hook -- one boolean tensor per norm layer, in execution order: ReLU(z) is evaluated as z * mask, i.e. the
+    network is linearised on a GIVEN activation pattern (the one another fp32 implementation took), which removes the
+    "pre-activation within an ulp of zero flips" noise from a gradient comparison without touching anything else.
     """
     la = variant == "la"
     norm = "batchnorm" if la else "instancenorm"
@@ -240,8 +243,14 @@ def vnet_forward(P, x, drop_masks=None, train=True, variant="la", has_dropout=Tr
             y = F.conv3d(h, w, b, stride=2)
         else:
             y = F.conv_transpose3d(h, w, b, stride=2)
-        return F.relu(_norm_act(y, P, _next(pre), norm, train))
+        z = _norm_act(y, P, _next(pre), norm, train)
+        if act_masks is not None:
+            m = act_masks[len(used)].to(z.dtype)
+            used.append(1)
+            return z * m
+        return F.relu(z)
 
+    used = []
     feats = {}
     h = x
     skips = []
@@ -270,24 +279,39 @@ def vnet_forward(P, x, drop_masks=None, train=True, variant="la", has_dropout=Tr
     return F.conv3d(h, P["branchs.0.1.weight"], P["branchs.0.1.bias"])
 
 
-def unet_forward(P, x, drop_masks=None, train=True):
+def unet_forward(P, x, drop_masks=None, train=True, act_masks=None, pool_idx=None):
     """UNet_2d forward (networks/unet.py:15-57, 80-86, 104-116, 254-257): logits [N,4,H,W].
 
     drop_masks: None or dict {'d0'..'d4': keep-mask tensors shaped like the activation they
     gate} for the five encoder nn.Dropout(p) sites (elementwise; kept values scaled 1/(1-p));
     decoder ConvBlocks use p=0.0."""
 
+    used = []
+
+    def lrelu(z):
+        if act_masks is None:
+            return F.leaky_relu(z, 0.01)
+        m = act_masks[len(used)].to(z.dtype)      # act_masks: see vnet_forward (here: slope 1 where set, 0.01 elsewhere)
+        used.append(1)
+        return z * (m + 0.01 * (1.0 - m))
+
     def convblock(pre, h, dkey, p):
         y = F.conv2d(h, P[f"{pre}.conv_conv.0.weight"], P[f"{pre}.conv_conv.0.bias"], padding=1)
-        y = F.leaky_relu(_norm_act(y, P, f"{pre}.conv_conv.1", "batchnorm", train), 0.01)
+        y = lrelu(_norm_act(y, P, f"{pre}.conv_conv.1", "batchnorm", train))
         if drop_masks is not None and dkey is not None and p > 0:
             y = y * drop_masks[dkey].to(y.dtype) / (1.0 - p)
         y = F.conv2d(y, P[f"{pre}.conv_conv.4.weight"], P[f"{pre}.conv_conv.4.bias"], padding=1)
-        return F.leaky_relu(_norm_act(y, P, f"{pre}.conv_conv.5", "batchnorm", train), 0.01)
+        return lrelu(_norm_act(y, P, f"{pre}.conv_conv.5", "batchnorm", train))
+
+    def pool(h, i):
+        if pool_idx is None:
+            return F.max_pool2d(h, 2)
+        idx = pool_idx[i]                          # test hook: the window winners ANOTHER implementation picked (flat H*W indices,
+        return h.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)   # as F.max_pool2d(return_indices=True) numbers them)
 
     xs = [convblock("encoder.in_conv", x, "d0", UNET_DROP[0])]
     for i in range(1, 5):
-        xs.append(convblock(f"encoder.down{i}.maxpool_conv.1", F.max_pool2d(xs[-1], 2), f"d{i}", UNET_DROP[i]))
+        xs.append(convblock(f"encoder.down{i}.maxpool_conv.1", pool(xs[-1], i - 1), f"d{i}", UNET_DROP[i]))
     h = xs[4]
     for i in range(1, 5):
         h = F.conv2d(h, P[f"decoder.up{i}.conv1x1.weight"], P[f"decoder.up{i}.conv1x1.bias"])

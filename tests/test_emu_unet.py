@@ -65,3 +65,11 @@ def test_update_model_ema_state_dict_semantics(emu_ops):
             assert int(sd[k]) == int(Pt[k]), (k, int(sd[k]), int(Pt[k]))
         else:
             assert torch.equal(sd[k], Pt[k]), k       # one multiply-add per element in fp32 on both sides: bit-exact
+
+
+def test_acdc_five_step_trajectory(emu_ops, golden_dir):
+    NC.check_acdc_traj5(emu_ops, CPU, golden_dir)
+
+
+def test_unet_standard_regime_gradients_on_hip_pattern(emu_ops):
+    NC.check_unet_pattern_grads(emu_ops, CPU)

@@ -59,3 +59,15 @@ def test_optimizer_state_is_torch_format_pancreas(emu_ops, golden_dir):
 
 def test_dropout_streams_are_per_network():
     NC.check_dropout_streams(CPU)
+
+
+def test_la_five_step_trajectory(emu_ops, golden_dir):
+    NC.check_la_traj5(emu_ops, CPU, golden_dir)
+
+
+def test_vnet_la_standard_regime_gradients_on_hip_pattern(emu_ops):
+    NC.check_vnet_pattern_grads(emu_ops, CPU, "la", (32, 32, 16))
+
+
+def test_vnet_pancreas_standard_regime_gradients_on_hip_pattern(emu_ops):
+    NC.check_vnet_pattern_grads(emu_ops, CPU, "pancreas", (32, 32, 32))

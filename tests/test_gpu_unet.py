@@ -67,3 +67,17 @@ def test_unet_eval_mode(ops):
 
 def test_val_2d_single_volume(ops):
     NC.check_val_2d(ops, DEV)
+
+
+def test_acdc_five_step_trajectory(ops, golden_dir):
+    rep = []
+    try:
+        NC.check_acdc_traj5(ops, DEV, golden_dir, report=rep)
+    finally:
+        for r in rep:
+            print("acdc step %d: |hip-ref32| %.2e  |hip-ref64| %.2e  ref drift %.2e  plab sum diff %g (ref %g)" % r)
+
+
+def test_standard_regime_gradients_on_hip_activation_pattern(ops):
+    print("unet", NC.check_unet_pattern_grads(ops, DEV))
+    print("unet 128x96", NC.check_unet_pattern_grads(ops, DEV, hw=(128, 96), seed=22))

@@ -99,3 +99,22 @@ def test_optimizer_state_is_torch_format(ops, golden_dir):
     """{'net','opt'} checkpoints interchange with torch.optim (= the reference's save_net_opt) on the device"""
     NC.check_opt_state_compat(ops, DEV, golden_dir, variant="la")
     NC.check_opt_state_compat(ops, DEV, golden_dir, variant="pancreas")
+
+
+def test_la_five_step_trajectory(ops, golden_dir):
+    """K = 5 at two fixture sizes; bounds = twice the reference's own fp32-vs-fp64 drift, see check_la_traj5"""
+    for fx in ("la_traj5.npz", "la_traj5m.npz"):
+        rep = []
+        try:
+            NC.check_la_traj5(ops, DEV, golden_dir, report=rep, fixture=fx)
+        finally:
+            for r in rep:
+                print(fx, "step %d: |hip-ref32| %.2e  |hip-ref64| %.2e  ref drift %.2e  own plab xor %g (ref %g)" % r)
+
+
+def test_standard_regime_gradients_on_hip_activation_pattern(ops):
+    """every gradient tensor of the LA and the InstanceNorm V-Net to 1e-4 rel-L2 of the difference vs the fp64 oracle linearised
+    on the activation pattern the HIP forward took (no smooth-regime crutch): small and a mid-size volume"""
+    print("la", NC.check_vnet_pattern_grads(ops, DEV, "la", (32, 32, 16)))
+    print("pancreas", NC.check_vnet_pattern_grads(ops, DEV, "pancreas", (32, 32, 32)))
+    print("la 64x48x32", NC.check_vnet_pattern_grads(ops, DEV, "la", (64, 48, 32), seed=21))

@@ -1,0 +1,99 @@
+"""Launch every op family of the LA step at its in-step shape a few times, in a fixed order, for rocprofv3 --pmc passes
+(tools/collect_pmc_ops.sh).  Between two ops a MARKER launch (k_ema on 64 elements) lets tools/pmc_ops_summary.py cut the
+dispatch list into per-op segments, so counters are summed over ALL kernels an op launches (e.g. norm_fwd = statistics +
+finalize + apply) and divided by the repetitions.  Writes the op list to <out>/ops.json.
+
+  python tools/prof_ops.py <out_dir> [reps]"""
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bcp_amd import hip_ops as H  # noqa: E402
+from bcp_amd.hip_ops import Ops  # noqa: E402
+
+out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc_ops"
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+os.makedirs(out_dir, exist_ok=True)
+ops = Ops.product()
+dev = torch.device("cuda:0")
+mk_a, mk_b = torch.zeros(64, device=dev), torch.zeros(64, device=dev)
+N = 2
+LEVELS = [(16, (112, 112, 80)), (32, (56, 56, 40)), (64, (28, 28, 20)), (128, (14, 14, 10)), (256, (7, 7, 5))]
+plan = []
+
+
+def run(key, fn, work):
+    ops.ema(mk_a, mk_b, 0.5)   # marker: the warm-up segment starts (first-call allocations, weight packs -- not counted)
+    fn()
+    torch.cuda.synchronize()
+    ops.ema(mk_a, mk_b, 0.5)   # marker: the measured segment starts
+    for _ in range(reps):
+        fn()
+    plan.append({"op": key, "reps": reps, **work})
+
+
+for C, sp in LEVELS:
+    x = torch.randn(N, *sp, C, device=dev)
+    dy = torch.randn(N, *sp, C, device=dev)
+    w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
+    b = torch.zeros(C, device=dev)
+    wf, wd = ops.conv3_pack(w, 3)
+    y = torch.empty(N, *sp, C, device=dev)
+    dw = torch.empty_like(w)
+    vox = N * sp[0] * sp[1] * sp[2]
+    fl = 2.0 * vox * 27 * C * C
+    tag = "x".join(str(v) for v in (N, *sp, C))
+    run(f"conv3_fwd_stats[{tag}]", lambda: ops.conv3_fwd_stats(x, wf, b, C, 3, N), {"flop": fl, "bytes": 8.0 * vox * C})
+    run(f"conv3_fwd[{tag}]", lambda: ops.conv3_fwd(dy, wd, None, C, 3, out=y), {"flop": fl, "bytes": 8.0 * vox * C})
+    run(f"conv3_wgrad[{tag}]", lambda: ops.conv3_wgrad(x, dy, dw, 3), {"flop": fl, "bytes": 8.0 * vox * C})
+    g, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    a = torch.empty_like(y)
+    st = [None]
+
+    def nf():
+        st[0] = ops.norm_fwd(x, N, g, be, rm, rv, H.ACT_RELU, out=a)[1]
+    run(f"norm_fwd[{tag}]", nf, {"flop": 0, "bytes": 12.0 * vox * C})
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    run(f"norm_bwd[{tag}]", lambda: ops.norm_bwd(x, dy, N, st[0], H.ACT_RELU, dg, db, True, out=a), {"flop": 0, "bytes": 20.0 * vox * C})
+
+sp = (112, 112, 80)
+vox = N * sp[0] * sp[1] * sp[2]
+x1 = torch.randn(N, *sp, 1, device=dev)
+w1 = torch.randn(16, 1, 3, 3, 3, device=dev)
+y16 = torch.empty(N, *sp, 16, device=dev)
+run("conv3_c1_fwd[2x112x112x80x1]", lambda: ops.conv3_c1_fwd(x1, w1, None, 3, out=y16), {"flop": 2.0 * vox * 27 * 16, "bytes": 4.0 * vox * 17})
+wdn = torch.randn(32, 16, 2, 2, 2, device=dev)
+bp = ops.k2_pack(wdn, 16, 32, H.PACK_DOWN_FWD)
+yd = torch.empty(N, 56, 56, 40, 32, device=dev)
+run("down_fwd[2x112x112x80x16]", lambda: ops.down_fwd(y16, bp, None, 32, out=yd), {"flop": 2.0 * yd.numel() * 128, "bytes": 4.0 * (y16.numel() + yd.numel())})
+wup = torch.randn(32, 16, 2, 2, 2, device=dev)
+bpu = ops.k2_pack(wup, 32, 16, H.PACK_UP_FWD)
+run("up_fwd[2x56x56x40x32]", lambda: ops.up_fwd(yd, bpu, None, 16, out=y16), {"flop": 2.0 * yd.numel() * 128, "bytes": 4.0 * (y16.numel() + yd.numel())})
+dwd = torch.empty_like(wdn)
+run("k2_wgrad[2x112x112x80x16]", lambda: ops.k2_wgrad(y16, yd, dwd, H.WG_DOWN), {"flop": 2.0 * yd.numel() * 128, "bytes": 4.0 * (y16.numel() + yd.numel())})
+wo = torch.randn(2, 16, 1, 1, 1, device=dev)
+lo = torch.empty(N, *sp, 2, device=dev)
+run("pw16_fwd[2x112x112x80x16]", lambda: ops.pw16_fwd(y16, wo, None, 2, out=lo), {"flop": 0, "bytes": 4.0 * (y16.numel() + lo.numel())})
+la = (torch.rand(N, *sp, device=dev) > 0.9).to(torch.uint8)
+box = (10, 20, 5, 74, 74, 53)
+ws3 = [None]
+
+
+def mf():
+    ws3[0] = ops.mixloss_fwd(lo, la, la, box, H.LOSS_LA, 1.0, 0.5)[1]
+run("mixloss_fwd[2x112x112x80x2]", mf, {"flop": 0, "bytes": 10.0 * vox})
+run("mixloss_bwd[2x112x112x80x2]", lambda: ops.mixloss_bwd(lo, la, la, box, H.LOSS_LA, ws3[0], 0.5, 0.5), {"flop": 0, "bytes": 18.0 * vox})
+run("mix_box[2x112x112x80x1]", lambda: ops.mix_box(x1, x1, box), {"flop": 0, "bytes": 12.0 * vox})
+n = 9457318
+p, gq, bu, em = (torch.randn(n, device=dev) for _ in range(4))
+run("sgd[9457318]", lambda: ops.sgd(p, gq, bu, 0.01, 0.9, 1e-4, False), {"flop": 0, "bytes": 20.0 * n})
+run("ema[9457318]", lambda: ops.ema(em, p, 0.99), {"flop": 0, "bytes": 12.0 * n})
+ops.ema(mk_a, mk_b, 0.5)   # closing marker
+torch.cuda.synchronize()
+json.dump(plan, open(os.path.join(out_dir, "ops.json"), "w"), indent=1)
+print("ops:", len(plan))
