@@ -561,6 +561,7 @@ static bool p8_plan(P8Plan& pl, const ConvDims& cd, int KD, int G, bool want_sta
     if (ks >= 2) pl.ksplit = ks;
     if (o.splitk >= 1 && o.splitk <= 8 && o.splitk <= nch) pl.ksplit = o.splitk;
   }
+  if (!force && pl.mode == P8_FLAT && pl.ksplit > 1 && !((o.conv3_p8_cfgs >> 3) & 1)) return false;   // bit 3: flat tiles WITH split-K (slab sum + a separate statistics pass)
   if (NWB == 1 && cdiv(nch, pl.ksplit) * (KD * 9 / WT) > 1) return false;
   int maxP = 256 / (pl.slabs * pl.ksplit);
   if (maxP < 1) maxP = 1;

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_crop_rotflip(const T* __restrict__ src,
     const int c = l + d1 - pd;
     T v = 0;
     if (a >= 0 && a < b0 && b >= 0 && b < b1 && c >= 0 && c < n2) {
-      if (axis == 0) a = b0 - 1 - a; else b = b1 - 1 - b;         // undo np.flip
+      if (axis == 0) a = b0 - 1 - a; else if (axis == 1) b = b1 - 1 - b;   // undo np.flip (axis -1: no flip)
       int s0, s1;                                                  // undo np.rot90(m, k, axes=(0, 1))
       switch (k & 3) {
         case 0: s0 = a; s1 = b; break;
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_crop_rotflip(const T* __restrict__ src,
 extern "C" int bcp_crop_rotflip(const void* src, void* dst, int elem_bytes, int n0, int n1, int n2, int k, int flip_axis, int pw, int ph,
                                 int pd, int w1, int h1, int d1, int P0, int P1, int P2, void* stream) {
   BCP_REQUIRE(src && dst && n0 > 0 && n1 > 0 && n2 > 0 && P0 > 0 && P1 > 0 && P2 > 0, "bcp_crop_rotflip: bad argument");
-  BCP_REQUIRE((flip_axis == 0 || flip_axis == 1) && k >= 0 && k < 4 && (elem_bytes == 4 || elem_bytes == 1), "bcp_crop_rotflip: bad mode");
+  BCP_REQUIRE((flip_axis >= -1 && flip_axis <= 1) && k >= 0 && k < 4 && (elem_bytes == 4 || elem_bytes == 1), "bcp_crop_rotflip: bad mode");
   const long long n = (long long)P0 * P1 * P2;
   if (elem_bytes == 4)
     hipLaunchKernelGGL((k_crop_rotflip<float>), dim3(egrid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, n0, n1,

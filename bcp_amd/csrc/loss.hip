@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
     if (mk) {
       t = mk[v] ? 0 : 1;
     } else {
-      const int w = (int)(v % W);
-      const int h = (int)((v / W) % H);
-      const int d = (int)(v / ((long long)W * H));
+      const unsigned vu = (unsigned)v, q1 = vu / (unsigned)W;          // V < 2^31 (checked by the entry point): 32-bit divisions
+      const int w = (int)(vu - q1 * (unsigned)W);
+      const int d = (int)(q1 / (unsigned)H);
+      const int h = (int)(q1 - (unsigned)d * (unsigned)H);
       t = in_box(d, h, w, box.v) ? 1 : 0;
     }
     const int y = t ? lb[v] : la[v];
@@ -121,13 +122,34 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
     if (lane == 0) { red[wid][2 * C * 3 + t * 2] = r1; red[wid][2 * C * 3 + t * 2 + 1] = r2; }
   }
   __syncthreads();
+  // one row of per-block partials [n][block][2*C*3 quantities of sample n | 4 CE / count values]: no atomics -- 2048 blocks
+  // adding into the same 28 fp64 addresses serialised in L2 for ~40 us at the LA size -- and a fixed summation order
   const int nq = 2 * C * 3 + 4;
+  if ((int)threadIdx.x < nq)
+    acc[((long long)n * gridDim.x + blockIdx.x) * nq + threadIdx.x] =
+        red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int C, bool ACDC>
+__global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict__ partial, int nb, double* __restrict__ acc, int N) {
+  // block n: the nb (<= 256) per-block rows of sample n -> acc[n][2*C*3] and tailp[n][4], in a fixed order (thread = row)
+  constexpr int nq = 2 * C * 3 + 4;
+  __shared__ double wred[4][nq];
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const double* row = partial + ((long long)n * nb + threadIdx.x) * nq;
+  double v[nq];
+#pragma unroll
+  for (int q = 0; q < nq; ++q) v[q] = ((int)threadIdx.x < nb) ? row[q] : 0.0;
+#pragma unroll
+  for (int q = 0; q < nq; ++q) {
+    const double r = wave_sum(v[q]);
+    if (lane == 0) wred[wid][q] = r;
+  }
+  __syncthreads();
   if ((int)threadIdx.x < nq) {
-    const double r = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-    if ((int)threadIdx.x < 2 * C * 3)
-      atomicAdd(&acc[(long long)n * 2 * C * 3 + threadIdx.x], r);
-    else
-      atomicAdd(&acc[(long long)N * 2 * C * 3 + (threadIdx.x - 2 * C * 3)], r);
+    const double t = wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
+    if ((int)threadIdx.x < 2 * C * 3) acc[(long long)n * 2 * C * 3 + threadIdx.x] = t;
+    else acc[(long long)N * 2 * C * 3 + (long long)n * 4 + (threadIdx.x - 2 * C * 3)] = t;
   }
 }
 
@@ -136,8 +158,10 @@ template <int C, bool ACDC>
 __global__ void k_mixloss_finalize(const double* __restrict__ acc, float* __restrict__ coef, float* __restrict__ out, int N,
                                    float w_img, float w_patch) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double tail[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int n = 0; n < N; ++n)
+    for (int q = 0; q < 4; ++q) tail[q] += acc[(long long)N * 2 * C * 3 + (long long)n * 4 + q];
   const double wt[2] = {(double)w_img, (double)w_patch};
-  const double* tail = acc + (long long)N * 2 * C * 3;
   double dice_total = 0.0, ce_total = 0.0;
   for (int t = 0; t < 2; ++t) {
     const double cecoef = wt[t] / (tail[t * 2 + 1] + 1e-16);
@@ -221,9 +245,10 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
     if (mk) {
       t = mk[v] ? 0 : 1;
     } else {
-      const int w = (int)(v % W);
-      const int h = (int)((v / W) % H);
-      const int d = (int)(v / ((long long)W * H));
+      const unsigned vu = (unsigned)v, q1 = vu / (unsigned)W;          // V < 2^31 (checked by the entry point): 32-bit divisions
+      const int w = (int)(vu - q1 * (unsigned)W);
+      const int d = (int)(q1 / (unsigned)H);
+      const int h = (int)(q1 - (unsigned)d * (unsigned)H);
       t = in_box(d, h, w, box.v) ? 1 : 0;
     }
     const int y = t ? lb[v] : la[v];
@@ -246,6 +271,8 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
   }
 }
 
+constexpr int kLossPartialRows = 256;   // forward blocks per sample = rows of per-block partials the finalize kernel sums
+
 static inline int loss_grid(long long V) {
   long long g = (V + 255) / 256;
   if (g > 1024) g = 1024;
@@ -260,12 +287,12 @@ static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* 
   bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
   bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
-  const size_t acc_bytes = ((size_t)N * 2 * C * 3 + 4) * sizeof(double);
-  hipMemsetAsync(acc, 0, acc_bytes, s);
   const long long V = (long long)D * H * W;
-  hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(loss_grid(V), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
-                     W, acc, N);
-  hipLaunchKernelGGL((k_mixloss_finalize<C, ACDC>), dim3(1), dim3(64), 0, s, acc, coef, out, N, w_img, w_patch);
+  const int nb = loss_grid(V) < kLossPartialRows ? loss_grid(V) : kLossPartialRows;
+  hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(nb, N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H, W, acc, N);
+  double* red = acc + (size_t)N * kLossPartialRows * (2 * C * 3 + 4);          // [N][2*C*3] | [N][4]
+  hipLaunchKernelGGL((k_mixloss_reduce<C, ACDC>), dim3(N), dim3(256), 0, s, acc, nb, red, N);
+  hipLaunchKernelGGL((k_mixloss_finalize<C, ACDC>), dim3(1), dim3(64), 0, s, red, coef, out, N, w_img, w_patch);
   return 0;
 }
 
@@ -288,13 +315,13 @@ using namespace bcp;
 
 extern "C" size_t bcp_mixloss_workspace_bytes(int N, int C) {
   // [acc doubles | coef floats], both 16-B aligned
-  const size_t acc = ((size_t)N * 2 * C * 3 + 4) * sizeof(double);
+  const size_t acc = (size_t)N * (kLossPartialRows + 1) * (2 * C * 3 + 4) * sizeof(double);   // per-block rows + the reduced row per sample
   const size_t coef = ((size_t)N * 2 * C * 2 + 2) * sizeof(float);
   return ((acc + 15) / 16) * 16 + ((coef + 15) / 16) * 16;
 }
 
 static inline float* coef_ptr(void* ws, int N, int C) {
-  const size_t acc = ((size_t)N * 2 * C * 3 + 4) * sizeof(double);
+  const size_t acc = (size_t)N * (kLossPartialRows + 1) * (2 * C * 3 + 4) * sizeof(double);   // per-block rows + the reduced row per sample
   return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((acc + 15) / 16) * 16);
 }
 
@@ -302,7 +329,7 @@ extern "C" int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const 
                                const int* box6, int N, int D, int H, int W, int C, int flavour, float w_img, float w_patch,
                                void* workspace, float* out3, void* stream) {
   BCP_REQUIRE(logits && img_l && patch_l && box6 && workspace && out3, "bcp_mixloss_fwd: null pointer");
-  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "bcp_mixloss_fwd: bad extents");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_mixloss_fwd: bad extents");
   BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4),
               "bcp_mixloss_fwd: flavour/C combination unsupported (LA: C=2, ACDC: C=4), got flavour=%d C=%d", flavour, C);
   double* acc = reinterpret_cast<double*>(workspace);
@@ -321,6 +348,7 @@ extern "C" int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const 
                                const int* box6, int N, int D, int H, int W, int C, int flavour, const void* workspace,
                                float g_dice, float g_ce, const float* g_dev_or_null, float* dlogits, void* stream) {
   BCP_REQUIRE(logits && img_l && patch_l && box6 && workspace && dlogits, "bcp_mixloss_bwd: null pointer");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_mixloss_bwd: bad extents");
   BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4), "bcp_mixloss_bwd: flavour/C");
   const float* coef = coef_ptr(const_cast<void*>(workspace), N, C);
   if (flavour == BCP_LOSS_LA)

@@ -36,11 +36,34 @@ def _streams(device, n=4, bs=2, seed=seed_test):
     return st
 
 
+class _LoaderStreams:
+    """--device_input_pipeline 1: the reference's four loaders (pancreas/dataloaders.py:185-195: lab_a, lab_b = the labeled list
+    forwards / reversed with RandomCrop(96^3); unlab_a, unlab_b = the unlabeled list forwards / reversed with CenterCrop) over
+    device-resident synthetic cases -- every call draws the next batch of each and crops it on the device."""
+
+    def __init__(self, device, bs, n_cases=4):
+        from bcp_amd.pancreas.dataloaders import SyntheticPancreas
+        self.sets = [SyntheticPancreas("train_lab", device, n_cases), SyntheticPancreas("train_lab", device, n_cases, reverse=True),
+                     SyntheticPancreas("train_unlab", device, n_cases), SyntheticPancreas("train_unlab", device, n_cases, reverse=True)]
+        self.bs, self.at = bs, 0
+
+    def __call__(self):
+        items = [[ds[(self.at * self.bs + i) % len(ds)] for i in range(self.bs)] for ds in self.sets]
+        self.at += 1
+        vols = torch.stack([it[0] for its in items for it in its])
+        labs = torch.stack([it[1] for its in items for it in its]).long()
+        bs = self.bs
+        st = _Streams((vols[i * bs:(i + 1) * bs], labs[i * bs:(i + 1) * bs]) for i in range(4))
+        st.vols, st.labs, st.bs = vols, labs, bs
+        return st
+
+
 def pretrain(net1, optimizer, streams, steps):
     """train_pancreas.py:50-101: copy-paste of the two labeled streams, supervised (CE + Dice) / 2"""
     net1.train()
-    vols, labs = torch.cat([streams[0][0], streams[1][0]]), torch.cat([streams[0][1], streams[1][1]])
     for _ in range(steps):
+        st = streams() if callable(streams) else streams
+        vols, labs = torch.cat([st[0][0], st[1][0]]), torch.cat([st[0][1], st[1][1]])
         r = train_step.la_pre_train_step(net1, optimizer, vols, labs, variant="pancreas")
     return r["loss"]
 
@@ -52,13 +75,14 @@ def ema_cutmix(net, ema_net, optimizer, streams, steps, dp=None, grouped=None):
     grouped=False issues the reference's four separate network calls."""
     net.train()
     ema_net.train()
-    if isinstance(streams, _Streams) and len(streams) == 4:
-        vols, labs, bs = streams.vols, streams.labs, streams.bs
-    else:
-        vols, labs, bs = torch.cat([s_[0] for s_ in streams]), torch.cat([s_[1] for s_ in streams]), streams[0][0].shape[0]
     if grouped is None:
         grouped = True
     for _ in range(steps):
+        st = streams() if callable(streams) else streams
+        if isinstance(st, _Streams) and len(st) == 4:
+            vols, labs, bs = st.vols, st.labs, st.bs
+        else:
+            vols, labs, bs = torch.cat([s_[0] for s_ in st]), torch.cat([s_[1] for s_ in st]), st[0][0].shape[0]
         r = train_step.la_self_train_step(net, ema_net, optimizer, vols, labs, 2 * bs, variant="pancreas", connect_mode=connect_mode,
                                           alpha=alpha, dp=dp, grouped=grouped)
     return r["loss"]
@@ -83,6 +107,7 @@ def main(argv=None):
     ap.add_argument("--val_cases", type=int, default=1)
     ap.add_argument("--val_stride", type=int, nargs=2, default=[18, 4], help="sliding-window strides (xy, z); test_calculate_metric's defaults")
     ap.add_argument("--result_dir", type=str, default="result/cutmix")
+    ap.add_argument("--device_input_pipeline", type=int, default=0, help="1: draw every batch from the four loader streams of the reference (RandomCrop / CenterCrop to 96^3, pancreas/dataloaders.py) with the crops done on the device")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, stream=sys.stdout)
     np.random.seed(seed_test)
@@ -91,7 +116,7 @@ def main(argv=None):
     net, ema_net = create_Vnet(), create_Vnet(ema=True)
     ema_net.load_state_dict(net.state_dict())
     optimizer = train_step.FlatAdam(net, lr=lr)
-    streams = _streams(device, 4, args.batch_size)
+    streams = _LoaderStreams(device, args.batch_size) if args.device_input_pipeline else _streams(device, 4, args.batch_size)
     val = _val_set(device, args.val_cases) if args.val_every else None
     pre_dir, st_dir = Path(args.result_dir) / "pretrain", Path(args.result_dir) / "self_train"
     if val is not None:

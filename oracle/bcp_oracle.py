@@ -780,6 +780,22 @@ def la_rotflip_crop(image, label, output_size, randint):
     return image[sl], label[sl]
 
 
+def pancreas_crop(samples, output_size, randint=None):
+    """RandomCrop (randint given; called in the reference's order w1, h1, d1) / CenterCrop (randint None) of the pancreas pipeline
+    (pancreas/dataloaders.py:22-91): pad ALL axes by (P - n) // 2 + 1 per side when any axis is <= the patch, then crop.
+    numpy in, numpy out."""
+    P, x = output_size, samples[0]
+    if x.shape[0] <= P[0] or x.shape[1] <= P[1] or x.shape[2] <= P[2]:              # :34-40
+        pads = [(max((P[i] - x.shape[i]) // 2 + 1, 0),) * 2 for i in range(3)]
+        samples = [np.pad(s, pads, mode="constant", constant_values=0) for s in samples]
+    w, h, d = samples[0].shape
+    if randint is not None:                                                         # :43-45
+        w1, h1, d1 = randint(0, w - P[0]), randint(0, h - P[1]), randint(0, d - P[2])
+    else:                                                                           # :76-78
+        w1, h1, d1 = int(round((w - P[0]) / 2.)), int(round((h - P[1]) / 2.)), int(round((d - P[2]) / 2.))
+    return [s[w1:w1 + P[0], h1:h1 + P[1], d1:d1 + P[2]] for s in samples]
+
+
 def _nearest_zoom(a, out_hw):
     """scipy.ndimage.zoom(a, (OH / H, OW / W), order=0) restated: source index = floor(o * (in - 1) / (out - 1) + 0.5)
     (scipy 1.15 NI_ZoomShift, grid_mode=False; pinned by tests/golden/aug_acdc.npz)"""

@@ -13,6 +13,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
+ARGV = list(sys.argv)        # make_golden resets sys.argv for the reference's argparse
 import make_golden as MG  # noqa: E402  (installs the stubs, imports the reference)
 import bcp_oracle as O  # noqa: E402
 
@@ -139,6 +140,35 @@ def main_sampler():
     print("wrote", os.path.normpath(out), [d[f"epoch0_{i}"].shape for i in range(4)])
 
 
+def main_aug_pancreas():
+    """G14: the REFERENCE's pancreas RandomCrop / CenterCrop classes (pancreas/dataloaders.py:22-91) on seeded volumes -- larger than
+    the patch, equal to it along one axis (<= triggers the padding of ALL axes), and smaller.  The module's h5py / torchvision
+    imports are make_golden's empty stubs; the two classes exercised use numpy only."""
+    ref_pdl = MG._load(os.path.join(MG.REF, "pancreas", "dataloaders.py"), "ref_pancreas_dataloaders")
+    rng = np.random.default_rng(SEED + 14)
+    P = (12, 10, 8)
+    d, n = {"patch": np.array(P)}, 0
+    for ci, shape in enumerate([(17, 14, 11), (12, 13, 10), (9, 12, 5), (13, 11, 9)]):
+        image = rng.standard_normal(shape).astype(np.float32)
+        label = (rng.random(shape) < 0.3).astype(np.uint8)
+        d[f"in_image_{ci}"], d[f"in_label_{ci}"] = image, label
+        for rep in range(3):
+            seed = 500 * ci + rep
+            np.random.seed(seed)
+            oi, ol = ref_pdl.RandomCrop(P)([image, label.astype(np.float32)])
+            d[f"case_{n}"] = np.array([ci, seed, 0])
+            d[f"out_image_{n}"], d[f"out_label_{n}"] = oi.astype(np.float32), ol.astype(np.uint8)
+            n += 1
+        oi, ol = ref_pdl.CenterCrop(P)([image, label.astype(np.float32)])
+        d[f"case_{n}"] = np.array([ci, 0, 1])
+        d[f"out_image_{n}"], d[f"out_label_{n}"] = oi.astype(np.float32), ol.astype(np.uint8)
+        n += 1
+    d["n_cases"] = np.int64(n)
+    out = os.path.join(HERE, "..", "tests", "golden", "aug_pancreas.npz")
+    np.savez_compressed(out, **d)
+    print("wrote", os.path.normpath(out), n, "cases")
+
+
 def main_opt_layout():
     """the LAYOUT of the 'opt' entry of the reference's {'net','opt'} checkpoints (LA_BCP_train.py:79-84,
     ACDC_BCP_train.py:60-64: torch.optim.SGD over model.parameters(); pancreas: torch.optim.Adam, pancreas/dataloaders.py:182)
@@ -190,12 +220,16 @@ def main_opt_layout():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "opt":
+    if len(ARGV) > 1 and ARGV[1] == "opt":
         main_opt_layout()
+        sys.exit(0)
+    if len(ARGV) > 1 and ARGV[1] == "aug_pancreas":
+        main_aug_pancreas()
         sys.exit(0)
     main()
     main_aug()
     main_aug_acdc()
     main_sw_pancreas()
     main_sampler()
+    main_aug_pancreas()
     main_opt_layout()

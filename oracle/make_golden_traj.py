@@ -20,11 +20,20 @@ import bcp_oracle as O  # noqa: E402
 
 OUT = os.path.join(HERE, "..", "tests", "golden")
 STEPS = 5
+ENSEMBLE = 8
 
 
-def la(dtype, forced=None, shape=(32, 32, 16)):
-    """forced: per-step (plab_a, plab_b) to use INSTEAD of the run's own pseudo-labels (its own are still computed and returned)"""
+def la(dtype, forced=None, shape=(32, 32, 16), jitter=None):
+    """forced: per-step (plab_a, plab_b) to use INSTEAD of the run's own pseudo-labels (its own are still computed and returned).
+    jitter: None, or a seed -- every floating-point parameter is moved by -1 / 0 / +1 ulp (x *= 1 + s * 2^-23) before the run: a
+    stand-in for "another fp32 implementation of the same arithmetic", whose results differ from the reference's by roundings"""
     P0 = O.init_params(O.vnet_param_shapes(), seed=41, random_affine=True)
+    if jitter is not None:
+        rj = np.random.default_rng(9000 + jitter)
+        for k, v in P0.items():
+            if v.is_floating_point() and "running" not in k:
+                sgn = torch.from_numpy(rj.integers(-1, 2, size=tuple(v.shape)).astype(np.float32))
+                P0[k] = (v.double() * (1.0 + sgn.double() * 2.0 ** -23)).float()
     cast = (lambda P: {k: (v.to(dtype) if v.is_floating_point() else v.clone()) for k, v in P.items()})
     model, ema = MG.ref_vnet_la(cast(P0)), MG.ref_vnet_la(cast(P0))
     if dtype == torch.float64:
@@ -120,12 +129,21 @@ def la_fixture(name, shape):
     # is what a second fp32 implementation (same forcing) can be held to.  plab_xor = voxels on which the forced fp64 run's OWN
     # pseudo-labels differ from the fp32 run's (the reference's own disagreement, voxel by voxel).
     t64f, _, _, plabs64 = la(torch.float64, forced=plabs, shape=shape)
+    # ONE fp32 run is one sample of a chaotic process (the drift grows ~10x per step): ENSEMBLE = the reference's fp32 run repeated
+    # with every parameter moved by <= 1 ulp, forced onto the same pseudo-labels -- the spread of "an fp32 implementation of this
+    # arithmetic" around the fp64 trajectory.  drift_ens[member, step] = max |loss terms - traj64f|; member 0 = the unjittered run.
+    ens = [np.abs(t32[:, :3] - t64f[:, :3]).max(1)]
+    for j in range(ENSEMBLE):
+        tj, _, _, _ = la(torch.float32, forced=plabs, shape=shape, jitter=j)
+        ens.append(np.abs(tj[:, :3] - t64f[:, :3]).max(1))
+    ens = np.array(ens)
     pb = np.array([[np.packbits(pa.numpy().astype(np.uint8).ravel()), np.packbits(pbb.numpy().astype(np.uint8).ravel())] for pa, pbb in plabs])
     xor = np.array([float((a32 != a64.to(a32.dtype)).sum() + (b32 != b64.to(b32.dtype)).sum()) for (a32, b32), (a64, b64) in zip(plabs, plabs64)])
-    np.savez_compressed(os.path.join(OUT, name), traj=t32, traj64=t64, traj64f=t64f, boxes=boxes, plab_bits=pb, plab_xor=xor,
+    np.savez_compressed(os.path.join(OUT, name), traj=t32, traj64=t64, traj64f=t64f, drift_ens=ens, boxes=boxes, plab_bits=pb, plab_xor=xor,
                         drops=np.array([[np.concatenate([d[k]["x5"].numpy().ravel(), d[k]["x9"].numpy().ravel()]) for k in ("t_a", "t_b", "s_l", "s_u")]
                                         for d in drops]), param_seed=np.int64(41), data_seed=np.int64(77), shape=np.array(shape))
     print(name, "free   |loss32 - loss64| per step:", np.abs(t32[:, 0] - t64[:, 0]), "plab count diff:", np.abs(t32[:, 3:] - t64[:, 3:]).sum(1))
+    print(name, "ensemble drift per step: max", ens.max(0), "median", np.median(ens, 0))
     print(name, "forced |loss32 - loss64f| per step:", np.abs(t32[:, :3] - t64f[:, :3]).max(1), "own plab xor:", xor, "plab sums", t32[:, 3:].sum(1))
 
 

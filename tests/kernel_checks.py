@@ -621,6 +621,32 @@ def check_augment(ops, dev, golden_dir):
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"])
 
 
+def check_augment_pancreas(ops, dev, golden_dir):
+    """device-side pancreas RandomCrop / CenterCrop (pancreas/dataloaders.py:22-91) == the REFERENCE's classes on the
+    same np.random state (tests/golden/aug_pancreas.npz: larger than / equal to / smaller than the patch), bit for bit, and ==
+    the oracle restatement"""
+    import os
+    import bcp_oracle as O
+    from bcp_amd.pancreas import dataloaders as PD
+    from bcp_amd.utils import BCP_utils as BU
+    if dev.type == "cpu":
+        BU.set_test_ops(ops)
+    g = np.load(os.path.join(golden_dir, "aug_pancreas.npz"))
+    P = tuple(int(v) for v in g["patch"])
+    for i in range(int(g["n_cases"])):
+        ci, seed, center = (int(v) for v in g[f"case_{i}"])
+        image, label = g[f"in_image_{ci}"], g[f"in_label_{ci}"]
+        np.random.seed(seed)
+        tf = PD.CenterCrop(P) if center else PD.RandomCrop(P)
+        img, lab = PD.ToTensor()(tf([torch.from_numpy(image).to(dev), torch.from_numpy(label).to(dev)]))
+        assert tuple(img.shape) == (1,) + P and lab.dtype == torch.uint8
+        assert np.array_equal(img[0].cpu().numpy(), g[f"out_image_{i}"]), f"pancreas crop image case {i}"
+        assert np.array_equal(lab.cpu().numpy(), g[f"out_label_{i}"]), f"pancreas crop label case {i}"
+        np.random.seed(seed)
+        oi, ol = O.pancreas_crop([image, label], P, None if center else (lambda lo, hi: int(np.random.randint(lo, hi))))
+        assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"])
+
+
 def check_augment_acdc(ops, dev, golden_dir):
     """device-side RandomGenerator (ACDC) == the REFERENCE's class (python random + np.random + scipy rotate / zoom,
     tests/golden/aug_acdc.npz: 15 rot90+flip, 7 rotate, 8 plain cases over 5 slice shapes), bit for bit, and == the oracle"""
@@ -656,4 +682,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("augment_acdc", "augment", "pack_many", "conv3_p8", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_p8", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")

@@ -29,7 +29,7 @@ def emu_ops():
 @pytest.mark.parametrize("name", K.ALL_CHECKS)
 def test_emu(emu_ops, golden_dir, name):
     fn = getattr(K, "check_" + name)
-    if name in ("plabel", "cc", "mixloss", "augment", "augment_acdc"):
+    if name in ("plabel", "cc", "mixloss", "augment", "augment_acdc", "augment_pancreas"):
         fn(emu_ops, torch.device("cpu"), golden_dir)
     else:
         fn(emu_ops, torch.device("cpu"))
@@ -41,3 +41,23 @@ def test_abi_symbols_exported(emu_ops):
     hdr = open(os.path.join(ROOT, "include", "bcp_hip.h")).read()
     declared = set(re.findall(r"\b(bcp_[a-z0-9_]+)\s*\(", hdr))
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_pancreas_loader_streams(emu_ops):
+    """the four loader streams of pancreas/dataloaders.py:185-195 over device-resident cases: forwards / reversed lists, RandomCrop for
+    the labeled pair, CenterCrop for the unlabeled pair, labels stay integer"""
+    import numpy as np
+    from bcp_amd.utils import BCP_utils as BU
+    from bcp_amd.pancreas.train_pancreas import _LoaderStreams
+    from bcp_amd.pancreas.dataloaders import SyntheticPancreas
+    BU.set_test_ops(emu_ops)
+    np.random.seed(3)
+    ls = _LoaderStreams(torch.device("cpu"), 1, n_cases=2)
+    st = ls()
+    assert tuple(st.vols.shape) == (4, 1, 96, 96, 96) and tuple(st.labs.shape) == (4, 96, 96, 96) and st.labs.dtype == torch.int64
+    ds = SyntheticPancreas("train_unlab", "cpu", 2)
+    a, _ = ds[0]
+    assert torch.equal(st[2][0][0], a)                                  # unlab_a: case 0, centre crop (no random draw)
+    rv = SyntheticPancreas("train_unlab", "cpu", 2, reverse=True)
+    assert torch.equal(st[3][0][0], rv[0][0]) and torch.equal(rv[0][0], ds[1][0])   # unlab_b walks the list backwards
+    assert len(SyntheticPancreas("train_lab", "cpu", 2)) == 20 and len(SyntheticPancreas("train_lab", "cpu", 2, labelp=20)) == 10

@@ -71,3 +71,7 @@ def test_vnet_la_standard_regime_gradients_on_hip_pattern(emu_ops):
 
 def test_vnet_pancreas_standard_regime_gradients_on_hip_pattern(emu_ops):
     NC.check_vnet_pattern_grads(emu_ops, CPU, "pancreas", (32, 32, 32))
+
+
+def test_la_loop_body_as_the_reference_writes_it(emu_ops, golden_dir):
+    NC.check_la_unfused_loop(emu_ops, CPU, golden_dir, steps=2)

@@ -44,6 +44,9 @@ def test_pancreas_script(tmp_path):
     # reference's checkpoint hand-off: best pre-trained {'net','opt','epoch'} -> both nets -> best self-trained {'net'}
     T.main(["--pretraining_epochs", "2", "--self_training_epochs", "2", "--steps_per_epoch", "1", "--batch_size", "1", "--val_every", "1",
             "--val_stride", "48", "48", "--result_dir", str(tmp_path / "cutmix")])
+    # the four loader streams of the reference with the crops done on the device (pancreas/dataloaders.py RandomCrop / CenterCrop)
+    T.main(["--pretraining_epochs", "1", "--self_training_epochs", "1", "--steps_per_epoch", "2", "--batch_size", "1", "--val_every", "0",
+            "--device_input_pipeline", "1"])
     pre = torch.load(tmp_path / "cutmix/pretrain/best_ema20_pre.pth")
     assert set(pre) == {"net", "opt", "epoch"} and len(pre["net"]) == 60
     st = torch.load(tmp_path / "cutmix/self_train/best_ema_20_self.pth")

@@ -118,3 +118,21 @@ def test_standard_regime_gradients_on_hip_activation_pattern(ops):
     print("la", NC.check_vnet_pattern_grads(ops, DEV, "la", (32, 32, 16)))
     print("pancreas", NC.check_vnet_pattern_grads(ops, DEV, "pancreas", (32, 32, 32)))
     print("la 64x48x32", NC.check_vnet_pattern_grads(ops, DEV, "la", (64, 48, 32), seed=21))
+
+
+def test_la_loop_body_as_the_reference_writes_it(ops, golden_dir):
+    """the import-swap claim of INTEGRATION.md: unfused calls, dense masks, torch.optim.SGD, update_ema_variables"""
+    NC.check_la_unfused_loop(ops, DEV, golden_dir, steps=3)
+
+
+def test_la_full_size_self_train_step_vs_oracle(ops):
+    """configs[1]: batch 4 (labeled_bs 2), 112x112x80, one whole step against the fp32 oracle run beside it"""
+    rep = {}
+    NC.check_la_step_full(ops, DEV, report=rep)
+    print("full-size step:", rep)
+
+
+def test_la_full_size_gradients_on_hip_activation_pattern(ops):
+    """configs[1] volume size (112x112x80): every gradient tensor of the V-Net to 1e-4 rel-L2 of the difference vs the fp64 oracle
+    linearised on the activation pattern of the HIP forward"""
+    print("la 112x112x80", NC.check_vnet_pattern_grads(ops, DEV, "la", (112, 112, 80), seed=31, N=1))

@@ -303,6 +303,13 @@ def test_input_pipelines_oracle_vs_reference(golden_dir):
         np.random.seed(seed)
         oi, ol = O.la_rotflip_crop(g[f"in_image_{ci}"], g[f"in_label_{ci}"], P, lambda lo, hi: int(np.random.randint(lo, hi)))
         assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"]), i
+    g = np.load(os.path.join(golden_dir, "aug_pancreas.npz"))          # pancreas RandomCrop / CenterCrop (pancreas/dataloaders.py:22-91)
+    P = tuple(int(v) for v in g["patch"])
+    for i in range(int(g["n_cases"])):
+        ci, seed, center = (int(v) for v in g[f"case_{i}"])
+        np.random.seed(seed)
+        oi, ol = O.pancreas_crop([g[f"in_image_{ci}"], g[f"in_label_{ci}"]], P, None if center else (lambda lo, hi: int(np.random.randint(lo, hi))))
+        assert np.array_equal(oi, g[f"out_image_{i}"]) and np.array_equal(ol, g[f"out_label_{i}"]), i
     g = np.load(os.path.join(golden_dir, "aug_acdc.npz"))
     out_hw = tuple(int(v) for v in g["out_hw"])
     for i in range(int(g["n_cases"])):
