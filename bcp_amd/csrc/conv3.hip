@@ -655,7 +655,16 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ 
     float s = 0.f;
     if (co0 + col < Cout) {
       const float* p = partial + ((long long)tap * Cin16 + ci) * Cout16 + co0 + col;
-      for (int g = 0; g < G; ++g) s += p[g * slab];
+      // four independent partial sums: one dependent add chain over the G slabs serialised the loads (17.7 us for 14 MB at the
+      // 128-channel level, a quarter of the weight-gradient kernel it follows)
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int g = 0;
+      for (; g + 3 < G; g += 4) {
+        const float a = p[g * slab], b = p[(g + 1) * slab], c = p[(g + 2) * slab], d = p[(g + 3) * slab];
+        s0 += a; s1 += b; s2 += c; s3 += d;
+      }
+      for (; g < G; ++g) s0 += p[g * slab];
+      s = (s0 + s1) + (s2 + s3);
     }
     tile[tap * 65 + col] = s;
   }
@@ -737,6 +746,26 @@ __global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w,
     }
     wp[i] = v;
   }
+  // three-piece bf16 section behind the fp32 pack (conv3b.hip): Wb[k / 16][pair][piece][n (N16)][32: (tap & 1) * 16 + k % 16]
+  const int TP = (T + 1) / 2;
+  unsigned short* wb = reinterpret_cast<unsigned short*>(wp + total);
+  const long long tb16 = (long long)TP * K16 * N16 * 2;          // (value, piece) triples: one per (chunk, pair, n, j)
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tb16; i += (long long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 31);
+    const int nn = (int)((i >> 5) % N16);
+    const int tp = (int)((i / (32LL * N16)) % TP);
+    const int ch = (int)(i / (32LL * N16 * TP));
+    const int t = 2 * tp + (j >> 4), kk = ch * 16 + (j & 15);
+    float v = 0.f;
+    if (t < T) {
+      if (!dgrad) { if (kk < Cin && nn < Cout) v = w[((long long)nn * Cin + kk) * T + t]; }
+      else if (kk < Cout && nn < Cin) v = w[((long long)kk * Cin + nn) * T + (T - 1 - t)];
+    }
+    unsigned short pc[3];
+    split3_bf16(v, pc);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) wb[((((long long)ch * TP + tp) * 3 + q) * N16 + nn) * 32 + j] = pc[q];
+  }
 }
 
 // all conv layers of a network in ONE launch (blockIdx.y = descriptor): 80 five-microsecond pack launches per step otherwise
@@ -781,6 +810,24 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
       const int kk = kq * 4 + k4;
       const float v = d.dgrad ? tile[(kk * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk) * T + t];
       d.wp[(((long long)t * (d.K16 >> 2) + (k0 >> 2) + kq) * d.N16 + n0 + nn) * 4 + k4] = v;
+    }
+    {  // three-piece bf16 section (see k_pack_conv3): this unit = chunk k0 / 16, columns n0 .. n0 + 15; two k per thread and step
+      const int TP = (T + 1) / 2, ch = k0 >> 4;
+      unsigned* wb = reinterpret_cast<unsigned*>(d.wp + (long long)T * d.K16 * d.N16);
+      for (int q = threadIdx.x; q < TP * 16 * 16; q += 256) {
+        const int j2 = q & 15, nn = (q >> 4) & 15, tp = q >> 8;
+        unsigned short pa[3], pb[3];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int j = j2 * 2 + e, t = 2 * tp + (j >> 4), kk = j & 15;
+          float v = 0.f;
+          if (t < T) v = d.dgrad ? tile[(kk * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk) * T + t];
+          split3_bf16(v, e ? pb : pa);
+        }
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          wb[(((((long long)ch * TP + tp) * 3 + pc) * d.N16 + n0 + nn) * 32 + j2 * 2) >> 1] = (unsigned)pa[pc] | ((unsigned)pb[pc] << 16);
+      }
     }
     __syncthreads();
   }
@@ -1072,6 +1119,9 @@ int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const C
 int p8_wgrad(const float* x, const float* dy, float* dw, const ConvDims& cd, int KD, int accumulate, void* workspace, hipStream_t s,
              bool* handled);
 size_t p8_wgrad_workspace_bytes(const ConvDims& cd, int KD);
+// conv3b.hip: fp32 numerics on the bf16 matrix pipe (three-piece operands)
+int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
+           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled);
 
 }  // namespace bcp
 
@@ -1086,8 +1136,9 @@ static int fill_dims(ConvDims& cd, int N, int D, int H, int W, int Cin, int Cout
 }
 
 extern "C" size_t bcp_conv3_packed_weight_floats(int Cin, int Cout, int KD) {
-  const int K16 = (Cin + 15) / 16 * 16, N16 = (Cout + 15) / 16 * 16;
-  return (size_t)KD * 9 * K16 * N16;
+  // fp32 pack [T][K16 / 4][N16][4] followed by the three-piece bf16 pack [K16 / 16][TP][3][N16][32] (2 B elements) of conv3b.hip
+  const int K16 = (Cin + 15) / 16 * 16, N16 = (Cout + 15) / 16 * 16, T = KD * 9, TP = (T + 1) / 2;
+  return (size_t)(T + 3 * TP) * K16 * N16;
 }
 
 extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad, int Cin, int Cout, int KD, void* stream) {
@@ -1170,6 +1221,8 @@ static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, fl
   bool done = false;
   int rows = 0;
   Cfg r;
+  rows = b6_fwd(x, wp, bias, y, cd, KD, accumulate, workspace, stat_partial, G, dry, (hipStream_t)stream, &done);
+  if (done) return rows;
   rows = p8_fwd(x, wp, bias, y, cd, KD, accumulate, workspace, stat_partial, G, dry, (hipStream_t)stream, &done);
   if (done) return rows;
   if (choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {

@@ -117,6 +117,45 @@ struct HaloFetch {
       pre[u] = v;
     }
   }
+  // Branch-free variant: EVERY load is issued (rows outside the volume read the tensor's first element instead) and the
+  // returned bit mask says which registers hold halo data; the caller applies it when the registers are consumed.  `if (valid)
+  // v = load` compiles to a branch per row, and hipcc's wait-count pass, which does not follow paths, then drains vmcnt in front
+  // of the block -- fatal for a prefetch issued in the middle of a pipelined loop.  Offsets are 32-bit (tensors < 2^32 floats).
+  __device__ __forceinline__ unsigned fetch_nb(const float* __restrict__ X, const ConvDims& cd, int n, int d0, int h0, int w0, int c,
+                                               float4 (&pre)[NP]) const {
+    static_assert(NP <= 32, "validity bits of a fetch must fit 32 bits");
+    const int hlo = (h0 >= 1) ? 0 : 1 - h0, hhi = (cd.H - h0 + 1 < TL::HH) ? cd.H - h0 + 1 : TL::HH;
+    const int dlo = (d0 >= TL::PD) ? 0 : TL::PD - d0, dhi = (cd.D - d0 + TL::PD < TL::HD) ? cd.D - d0 + TL::PD : TL::HD;
+    const unsigned mh = (hhi > hlo) ? (((1u << hhi) - 1u) & ~((1u << hlo) - 1u)) : 0u;
+    unsigned long long M0 = 0, M1 = 0;
+#pragma unroll
+    for (int hd = 0; hd < TL::HD; ++hd) {
+      constexpr int HHc = TL::HH;
+      const int pos = hd * HHc;
+      if (hd >= dlo && hd < dhi) {
+        if (pos < 64) M0 |= (unsigned long long)mh << pos;
+        if (pos < 64 && pos + HHc > 64) M1 |= (unsigned long long)mh >> (64 - pos);
+        if (pos >= 64) M1 |= (unsigned long long)mh << (pos - 64);
+      }
+    }
+    const bool col_ok = act && (unsigned)(w0 - 1 + hw) < (unsigned)cd.W && c * 16 + part * 4 < cd.Cin;
+    unsigned long long Mt0 = M0 >> r0, Mt1 = 0;
+    if (HR > 64) {
+      if (r0) Mt0 |= M1 << (64 - r0);
+      Mt1 = M1 >> r0;
+    }
+    if (!col_ok) { Mt0 = 0; Mt1 = 0; }
+    const unsigned boff = (unsigned)(((((long long)n * cd.D + (d0 - TL::PD)) * cd.H + (h0 - 1)) * cd.W + (w0 - 1)) * cd.Cin + c * 16);
+    unsigned vm = 0;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const unsigned bit = (unsigned)((u * RPP < 64 ? Mt0 >> ((u * RPP) & 63) : Mt1 >> ((u * RPP - 64) & 63)) & 1ull);
+      const unsigned off = bit ? boff + grel[u] : 0u;
+      pre[u] = ld4(X + off);
+      vm |= bit << u;
+    }
+    return vm;
+  }
   __device__ __forceinline__ void stash(const float4 (&pre)[NP]) const {
 #pragma unroll
     for (int u = 0; u < NP; ++u)
@@ -194,6 +233,50 @@ __device__ __forceinline__ void stats_flush_t(double (&s1)[NT][4], double (&s2)[
     dst_row[(cout0 + c) * 2 + 1] = b;
   }
   __syncthreads();
+}
+
+// x -> three bf16 pieces, largest first: x = p0 + p1 + p2 up to 2^-26 |x| (round to nearest even at every level; the two
+// subtractions are exact).  Integer arithmetic: bit-identical to v_cvt_pk_bf16_f32 for finite values.
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float x) {
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void split3_bf16(float x, unsigned short (&p)[3]) {
+  p[0] = f32_to_bf16_rne(x);
+  float r = x - bf16_to_f32(p[0]);
+  p[1] = f32_to_bf16_rne(r);
+  r -= bf16_to_f32(p[1]);
+  p[2] = f32_to_bf16_rne(r);
+}
+
+// two floats -> packed bf16 pair (low half = a), round to nearest even: v_cvt_pk_bf16_f32 (the host simulator supplies BCP_CVT_PK_BF16)
+#ifndef BCP_CVT_PK_BF16
+typedef __bf16 bcp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float bcp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  const bcp_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bcp_bf16x2));
+}
+#else
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) { return BCP_CVT_PK_BF16(a, b); }
+#endif
+// four consecutive channels of one voxel row -> the three piece planes (8-byte stores): 6 conversions + 8 unpacks + 8 subtractions
+__device__ __forceinline__ void split_store4(const float4& v, unsigned short* base, int plane_stride) {
+  unsigned h0 = cvt_pk_bf16(v.x, v.y), h1 = cvt_pk_bf16(v.z, v.w);
+  float r0 = v.x - __uint_as_float(h0 << 16), r1 = v.y - __uint_as_float(h0 & 0xffff0000u);
+  float r2 = v.z - __uint_as_float(h1 << 16), r3 = v.w - __uint_as_float(h1 & 0xffff0000u);
+  uint2 w;
+  w.x = h0; w.y = h1;
+  *reinterpret_cast<uint2*>(base) = w;
+  h0 = cvt_pk_bf16(r0, r1); h1 = cvt_pk_bf16(r2, r3);
+  r0 -= __uint_as_float(h0 << 16); r1 -= __uint_as_float(h0 & 0xffff0000u);
+  r2 -= __uint_as_float(h1 << 16); r3 -= __uint_as_float(h1 & 0xffff0000u);
+  w.x = h0; w.y = h1;
+  *reinterpret_cast<uint2*>(base + plane_stride) = w;
+  w.x = cvt_pk_bf16(r0, r1); w.y = cvt_pk_bf16(r2, r3);
+  *reinterpret_cast<uint2*>(base + 2 * plane_stride) = w;
 }
 
 struct Cfg { int KD, TD, TH, TW, NT, WT; };

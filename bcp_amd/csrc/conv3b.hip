@@ -1,0 +1,339 @@
+// bcp_amd/csrc/conv3b.hip -- 3x3x3 / 3x3 convolution (forward and dgrad) with fp32 numerics on the BF16 matrix pipe.
+//
+// v_mfma_f32_16x16x4_f32 issues once per 32 cycles per SIMD and -- measured on gfx950 (tools/probe/overlap_probe.hip) -- shares
+// its issue time with every VALU / LDS / VMEM instruction of the SIMD, so the fp32 kernels of conv3.hip / conv3p.hip stop near
+// 100-110 TFLOP/s.  Here both operands are split into THREE bf16 pieces when they enter the LDS (8 + 8 + 8 mantissa bits:
+// x = p0 + p1 + p2 up to 2^-26 |x|) and the tap loop issues six v_mfma_f32_16x16x32_bf16 per K = 32 block
+//     a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0        (dropped cross terms < 2^-24 of the product)
+// with fp32 accumulation inside the matrix core: bf16 x bf16 products are exact in fp32, so the result differs from the fp32-MFMA
+// kernels only by the summation order and the dropped 2^-24 terms -- fp32-equivalent (tests/kernel_checks.py check_conv3_b6:
+// error vs fp64 within 3x of the fp32 kernel's).  Six such MFMAs take ~102 cycles against 256 for the eight 16x16x4_f32 they
+// replace, and the bf16 MFMA leaves issue slots for the LDS reads / VALU around it.
+//
+// One MFMA covers TWO taps x 16 input channels (lanes lg 0-1: tap A, lanes lg 2-3: tap B); an odd tap count is padded with a
+// zero-weight tap.  Workgroup = 256 threads = 4 waves along M, tile TD x TH x TW voxels (M = 64 * MT) x 16 * NT channels;
+// LDS: the halo of one 16-channel chunk as three bf16 planes [HV][16] (32-byte rows; the MFMA rows of an m-tile are permuted so
+// that the 16-byte fragment reads are conflict-free, see b6_row) and a double-buffered weight stage of SP tap pairs
+// [piece][pair][cout][32 k] copied from the pre-split bf16 pack the weight packer writes behind the fp32 pack.  Two workgroups per
+// CU: one computes while the other refills (the halo split is ~22 VALU per float4: v_cvt_pk_bf16_f32).
+//
+// Reference ops: nn.Conv3d(k=3,pad=1) networks/VNet.py:17, nn.Conv2d(k=3,pad=1) networks/unet.py:19-25 and their backward.
+#include "conv3_defs.h"
+#include "../../include/bcp_hip.h"
+
+// measurement only (tools/ablate_b6.sh): compile parts of k_c3b out -- 1 no epilogue stores, 2 no halo fetch / split, 4 no weight
+// stages, 8 no MFMAs, 16 no stage barriers, 32 fragment reads hoisted out of the stage loop.  The product is built with 0.
+#ifndef B6_ABLATE
+#define B6_ABLATE 0
+#endif
+
+namespace bcp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+static constexpr int XSB = 16;   // bf16 elements per halo voxel row: 32-byte rows, no padding (see b6_row)
+
+// ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32
+// (/opt/skills/guides/MI355X_MICROARCH.md, LDS table) -- i.e. MFMA rows {0-3, 12-15} of one k half together with rows {4-11} of the
+// other.  With 32-byte voxel rows a group is conflict-free when the halo row indices of each of the two row sets are distinct
+// mod 8: b6_row maps MFMA row i of a 16-voxel m-tile to the tile voxel (w fastest) so that each set is ONE run of 8 voxels along
+// W (TW = 8), or two runs of 4 two H-rows apart (TW = 4; halo rows 6 apart: 0-3 and 12-15 mod 8); TW = 16 needs no permutation.
+// (The natural order costs 8-12 LDS cycles per read instead of 4: measured, the tap loop was LDS-bound at 2x its MFMA time.)
+template <int TW>
+__device__ __forceinline__ constexpr int b6_row(int i) {
+  return TW >= 16 ? i : TW == 8 ? (i < 4 ? i : (i >= 12 ? i - 8 : i + 4)) : (i < 8 ? i : (i < 12 ? i + 4 : i - 4));
+}
+
+template <int KD, int TD, int TH, int TW, int NT, int SP>
+__global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
+                                             float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int MT = TL::MT, T = TL::T, TP = (T + 1) / 2, CT = NT * 16;
+  constexpr int S = ((TP + SP - 1) / SP + 1) & ~1;             // weight stages per cin chunk, even (2-D: one all-zero pad stage)
+  static_assert(S >= 4, "the stage pipeline needs four weight stages per chunk");
+  constexpr int XPLANE = TL::HV * XSB;                         // bf16 elements per halo piece plane
+  constexpr int WPLANE = SP * CT * 32;                         // bf16 elements per weight piece plane of one stage
+  constexpr int WSTAGE = 3 * WPLANE;                           // one stage buffer
+  constexpr int NW4 = (SP * 12 * CT + 255) / 256;              // 16-byte pieces of a stage per thread
+  using HF = HaloFetch<TL>;
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
+  unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][SP][CT][32]
+  double* Ss = reinterpret_cast<double*>(Wb + 2 * WSTAGE);         // [4][CT][2] statistics scratch
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  int n, d0, h0, w0;
+  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
+  const int cout0 = blockIdx.y * CT;
+  const int cin4 = cd.Cin16 >> 2;
+
+  int voff[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) voff[mt] = TL::voff((wave * MT + mt) * 16 + b6_row<TW>(li)) * XSB + (lg & 1) * 8;
+  // weight rows [cout][32 k] = 64 B: the 16-byte k quarter q of cout c sits at position q ^ (c & 8 ? 2 : 0) -- conflict-free fragment reads
+  const int woff = li * 32 + ((lg ^ ((li & 8) ? 2 : 0)) * 8);
+  HF hf;
+  hf.init(cd, reinterpret_cast<float*>(smem4));      // (its fp32 LDS slot is not used: the stash below writes the bf16 planes)
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // split-K: blockIdx.z owns a contiguous range of cin chunks and writes its own partial slab (summed by k_sum_slabs)
+  const int nchunks = cd.Cin16 >> 4;
+  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
+  Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
+
+  // stage `sg` of chunk `cc`: tap pairs sg*SP .. sg*SP+SP-1 of the pre-split pack Wb16[chunk][pair][piece][Cout16][32] (bf16, behind the
+  // fp32 pack: bcp_conv3_packed_weight_floats); 16-byte piece q of the stage = (pair, piece, cout, k quarter)
+  const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  // (branch-free: every thread loads -- slots past the stage re-read its first pieces, pairs past TP re-read the last pair -- and
+  //  wstash drops / zeroes what is not wanted; a predicated load would cost a vmcnt(0) per stage, see fetch_nb)
+  auto wfetch = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) {
+      const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
+      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
+      const int tp = sg * SP + pr < TP ? sg * SP + pr : TP - 1;
+      wpre[u] = *reinterpret_cast<const float4*>(Wb16 + ((((long long)cc * TP + tp) * 3 + sp) * cd.Cout16 + cout0 + co) * 32 + kq * 8);
+    }
+  };
+  auto wstash = [&](unsigned short* Wbuf, int sg, const float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
+      const float4 v = (sg * SP + pr < TP) ? wpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);       // pad pairs: zero weights
+      if (q < SP * 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
+    }
+  };
+  unsigned hvm = 0;                                  // validity bits of the halo rows in flight (fetch_nb)
+  auto hfetch = [&](int cc, float4 (&pre)[HF::NP]) __attribute__((always_inline)) {
+    if (!(B6_ABLATE & 2)) hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, cc, pre);
+  };
+  auto hstash = [&](const float4 (&pre)[HF::NP]) __attribute__((always_inline)) {
+    if (B6_ABLATE & 2) return;
+#pragma unroll
+    for (int u = 0; u < HF::NP; ++u)
+      if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
+        const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_store4(v, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
+      }
+  };
+
+  // Weight stage sg of a chunk lives in LDS buffer sg & 1 (S is even).  Two stages are in flight in registers (a stage is ~0.35 us
+  // of MFMAs -- less than an L2 round trip, so a one-stage prefetch distance stalled every stage): register set W1 carries the odd
+  // stages, W0 the even ones; a set is refilled with the stage three ahead right after its own stage went to the LDS, so no
+  // register is ever copied.  NOTHING in the loop is a conditional load: hipcc's wait-count pass does not follow paths and answers
+  // a predicated load (or a rotating register copy) with vmcnt(0) -- a full round trip per stage.  Stages past the end of the
+  // block re-read its last stage (never stashed); the next chunk's halo is fetched between two copies of the stage loop.
+  // Barriers inside the loop order LDS traffic only (BCP_LDS_BARRIER): the global loads stay in flight across them.
+  auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {     // stage sg (may run past S) of chunk cc
+    if (sg >= S) { sg -= S; ++cc; }
+    if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
+    if (!(B6_ABLATE & 4)) wfetch(cc, sg, wpre);
+  };
+  constexpr int HPF = S - 4;                         // even stage of a chunk in front of which the next chunk's halo is fetched
+  float4 hpre[HF::NP], W0[NW4], W1[NW4];
+  hfetch(c_begin, hpre);
+  wfetch_at(c_begin, 0, W0);
+  wfetch_at(c_begin, 1, W1);
+  hstash(hpre);
+  if (!(B6_ABLATE & 4)) wstash(Wb, 0, W0);
+  wfetch_at(c_begin, 2, W0);
+  BCP_LDS_BARRIER();
+
+  bf16x8 abl_a[MT][3], abl_b[NT][3];                 // (measurement only, B6_ABLATE & 32)
+  if (B6_ABLATE & 32) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) abl_a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) abl_b[nt][s] = *reinterpret_cast<const bf16x8*>(Wb + s * WPLANE + nt * 16 * 32 + woff);
+    }
+  }
+  auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
+    const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
+#pragma unroll
+    for (int pr = 0; pr < SP; ++pr) {
+      const int tp = sg * SP + pr;
+      if (tp < TP && !(B6_ABLATE & 8)) {     // uniform
+        // lanes lg 0-1 (k 0..15) carry tap 2*tp, lanes lg 2-3 (k 16..31) tap 2*tp+1 (the pad tap reads tap T-1's voxels against zero weights)
+        const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
+        const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
+        const int toff = ((lg >> 1) ? tB : tA) * XSB;
+        bf16x8 a[MT][3], b[NT][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a[mt][s] = (B6_ABLATE & 32) ? abl_a[mt][s] : *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b[nt][s] = (B6_ABLATE & 32) ? abl_b[nt][s] : *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + (pr * CT + nt * 16) * 32 + woff);
+        }
+        // D = W^T-tile x X-tile: rows = output channels, columns = voxels, so that a lane ends up with FOUR CONSECUTIVE channels of
+        // one voxel (one 16-byte store).  Smallest terms first; the six products of an accumulator are spread over the MT*NT accumulators.
+#define BCP_B6(I, J)                                                                                            \
+  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)            \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][J], a[mt][I], acc[mt][nt], 0, 0, 0);
+        BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
+#undef BCP_B6
+      }
+    }
+    // the next stage's weights -> the other buffer (last read one stage ago: every wave has passed the barrier that ended that stage)
+    if (!(B6_ABLATE & 4) && (sg + 1 < S || cc + 1 < c_end)) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
+    wfetch_at(cc, sg + 3, Wn);
+    if (sg + 1 < S && !(B6_ABLATE & 16)) BCP_LDS_BARRIER();               // (a chunk boundary brings its own)
+  };
+#pragma unroll 1
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    if (cc > c_begin) {
+      BCP_LDS_BARRIER();                             // every wave is done with the previous chunk's halo planes
+      hstash(hpre);
+      BCP_LDS_BARRIER();
+    }
+#pragma unroll 1
+    for (int sg = 0; sg < HPF; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+    hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (the last chunk re-reads its own halo: no conditional load)
+#pragma unroll 1
+    for (int sg = HPF; sg < S; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+  }
+
+  // epilogue: lane (li, lg) holds voxel b6_row(li) of each m-tile, channels lg*4 .. lg*4+3 of each 16-channel n-tile
+  double s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
+  const bool full = cout0 + CT <= cd.Cout && (cd.Cout & 3) == 0 && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
+  const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
+  float bv[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = cout0 + nt * 16 + lg * 4 + r;
+      bv[nt][r] = (bias && co < cd.Cout) ? bias[co] : 0.f;
+    }
+  auto rows = [&](auto mode_tag, auto acc_tag) __attribute__((always_inline)) {
+    constexpr int MODE = decltype(mode_tag)::value;
+    constexpr bool ACCUM = decltype(acc_tag)::value;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = (wave * MT + mt) * 16 + b6_row<TW>(li);
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int d = d0 + td, h = h0 + th, w = w0 + tw;
+      float* yrow = Y + tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout) + cout0 + lg * 4;
+      if (full) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float4 v = make_float4(acc[mt][nt][0] + bv[nt][0], acc[mt][nt][1] + bv[nt][1], acc[mt][nt][2] + bv[nt][2], acc[mt][nt][3] + bv[nt][3]);
+          if (ACCUM) { const float4 o = ld4(yrow + nt * 16); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+          if (!(B6_ABLATE & 1) || v.x == 1.2345e-30f) st4(yrow + nt * 16, v);
+          stat_add<MODE>(s1[nt][0], s2[nt][0], v.x); stat_add<MODE>(s1[nt][1], s2[nt][1], v.y);
+          stat_add<MODE>(s1[nt][2], s2[nt][2], v.z); stat_add<MODE>(s1[nt][3], s2[nt][3], v.w);
+        }
+      } else if (d < cd.D && h < cd.H && w < cd.W) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int co = cout0 + nt * 16 + lg * 4 + r;
+            if (co < cd.Cout) {
+              float v = acc[mt][nt][r] + bv[nt][r];
+              if (ACCUM) v += yrow[nt * 16 + r];
+              if (!(B6_ABLATE & 1) || v == 1.2345e-30f) yrow[nt * 16 + r] = v;
+              stat_add<MODE>(s1[nt][r], s2[nt][r], v);
+            }
+          }
+      }
+    }
+  };
+  if (!st.partial) {
+    if (accumulate) rows(std::integral_constant<int, 0>{}, std::true_type{});
+    else rows(std::integral_constant<int, 0>{}, std::false_type{});
+  } else rows(std::integral_constant<int, 1>{}, std::false_type{});       // the statistics variant never accumulates (bcp_conv3_fwd_stats)
+  if (st.partial) {
+    const int gg = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
+    BCP_LDS_BARRIER();                           // the scratch below aliases nothing, but waves may still be in the last stage
+    stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_b6_sum_slabs(const float* __restrict__ part, int K, long long n, int Cout,
+                                                      const float* __restrict__ bias, float* __restrict__ y, int accumulate) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = bias ? bias[i % Cout] : 0.f;
+    for (int k = 0; k < K; ++k) v += part[(long long)k * n + i];
+    y[i] = accumulate ? y[i] + v : v;
+  }
+}
+
+template <int KD, int TD, int TH, int TW, int NT, int SP>
+static int b6_launch(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
+                     double* stat_partial, int G, bool dry, hipStream_t s) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int CT = NT * 16;
+  const size_t lds = (size_t)3 * TL::HV * XSB * 2 + (size_t)2 * 3 * SP * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
+  cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
+  auto kfn = k_c3b<KD, TD, TH, TW, NT, SP>;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / CT;
+  const int nch = cd.Cin16 / 16;
+  int sk = 1;
+  const bool ws_fits = ws && (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout <= (1LL << 20);     // bcp_conv3_fwd_workspace_bytes
+  if (ws_fits && (long long)gx * gy <= 256 && nch >= 4) { sk = nch / 2; if (sk > 4) sk = 4; }
+  { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
+  StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
+  if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
+  if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
+  if (sk == 1) {
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);
+  } else {
+    const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
+    StatsArg none{nullptr, 0, 1, cd.Cout, 1};
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, 0, none);
+    hipLaunchKernelGGL(k_b6_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y,
+                       accumulate);
+  }
+  return st.partial ? st.rows : 0;
+}
+
+// Forward / dgrad on the bf16 pipe where option conv3_b6 allows it.  Returns the statistics rows (as conv3_fwd_impl does);
+// *handled = false leaves the shape to the fp32 kernels.
+int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
+           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled) {
+  *handled = false;
+  const Options& o = options();
+  if (o.conv3_b6 == 0) return 0;
+  const long long vox = (long long)cd.N * cd.D * cd.H * cd.W;
+  float* ws = (float*)workspace;
+  int rows = 0;
+  if (KD == 3) {
+    if (cd.Cout16 % 64 == 0 && (o.conv3_b6 >= 2 || (o.conv3_b6_levels & 2 && vox >= 16LL * 1024))) {
+      // 128-voxel tiles, 64-channel slab; 4x4x8 or 4x8x4, whichever wastes less of its tiles on this volume
+      const long long w8 = (long long)cdiv(cd.D, 4) * cdiv(cd.H, 4) * cdiv(cd.W, 8), w4 = (long long)cdiv(cd.D, 4) * cdiv(cd.H, 8) * cdiv(cd.W, 4);
+      if (w8 <= w4) rows = b6_launch<3, 4, 4, 8, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      else rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      *handled = true;
+    } else if (cd.Cout16 % 32 == 0 && cd.Cout16 % 64 != 0 && (o.conv3_b6 >= 2 || (o.conv3_b6_levels & 1 && vox >= 16LL * 1024))) {
+      if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      *handled = true;
+    }
+  } else {
+    if (cd.Cout16 % 64 == 0 && o.conv3_b6 >= 2) {
+      rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      *handled = true;
+    } else if (cd.Cout16 % 32 == 0 && o.conv3_b6 >= 2) {
+      rows = b6_launch<1, 1, 8, 16, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      *handled = true;
+    }
+  }
+  return rows;
+}
+
+}  // namespace bcp

