@@ -50,6 +50,8 @@ struct Options {
   int conv3_p8_cfgs = 3;    // automatic choice: bit 0 = BN 32 bricks, bit 1 = BN 64 bricks, bit 2 = flat tiles.  Measured in the LA step (interleaved A/B, ms per step): none 9.03, flat only 9.19, BN 64 only 8.90, BN 32 only 8.99 -- the flat kernel is 18 % faster ALONE at the 128-channel level but its one-workgroup-per-CU grid keeps the other stream's kernels off the CUs
   int conv3_b6 = 1;         // fp32 conv on the bf16 matrix pipe (three-piece operands, conv3b.hip): 0 off, 1 where measured faster, 2 wherever valid
   int conv3_b6_levels = 3;  // automatic choice (conv3_b6 = 1): bit 0 = 32-channel slabs (256-voxel tiles), bit 1 = 64-channel slabs.  LA step, interleaved A/B (ms per step): off 8.87, 32-channel level 8.32, + 64-channel level 8.05 -- the latter although ALONE that kernel is slower than the exclusive pipeline kernel it replaces (66-71 vs 61 us): two workgroups per CU leave room for the other stream
+  int conv3_b6_minvox = 2048;    // automatic choice: smallest launch (voxels, batch included) that goes to the bf16-pipe kernels
+  int conv3_b6_cfg64 = 0;   // measurements: tile / slab variant of the 64-channel bf16-pipe instances
   int wgrad_p8 = 1;         // same for the weight-gradient kernels
 };
 Options& options();

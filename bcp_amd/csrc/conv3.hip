@@ -1272,6 +1272,19 @@ extern "C" int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout
   return rc < 0 ? 0 : rc;
 }
 
+// which matrix pipe serves bcp_conv3_fwd / _fwd_stats for this shape under the current options: 0 = v_mfma_f32_16x16x4_f32 (fp32
+// operands), 1 = v_mfma_f32_16x16x32_bf16 with three-piece operands (conv3b.hip; fp32-equivalent results, six MFMAs per K = 32 block).
+// For the measurement record (bench.py prices the two against different peaks); no launch.
+extern "C" size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Cout, int KD) {
+  if (Cin % 4 || Cin < 4) return 0;
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  bool handled = false;
+  static float dummy;
+  b6_fwd(nullptr, nullptr, nullptr, nullptr, cd, KD, 0, &dummy, nullptr, 0, true, nullptr, &handled);
+  return handled ? 1 : 0;
+}
+
 extern "C" int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
                                    int Cout, int KD, void* workspace, double* stat_partial, int groups, void* stream) {
   BCP_REQUIRE(x && wp && y && stat_partial, "bcp_conv3_fwd_stats: null pointer");

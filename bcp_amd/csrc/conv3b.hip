@@ -313,16 +313,38 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
   float* ws = (float*)workspace;
   int rows = 0;
   if (KD == 3) {
-    if (cd.Cout16 % 64 == 0 && (o.conv3_b6 >= 2 || (o.conv3_b6_levels & 2 && vox >= 16LL * 1024))) {
-      // 128-voxel tiles, 64-channel slab; 4x4x8 or 4x8x4, whichever wastes less of its tiles on this volume
-      const long long w8 = (long long)cdiv(cd.D, 4) * cdiv(cd.H, 4) * cdiv(cd.W, 8), w4 = (long long)cdiv(cd.D, 4) * cdiv(cd.H, 8) * cdiv(cd.W, 4);
-      if (w8 <= w4) rows = b6_launch<3, 4, 4, 8, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-      else rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-      *handled = true;
-    } else if (cd.Cout16 % 32 == 0 && cd.Cout16 % 64 != 0 && (o.conv3_b6 >= 2 || (o.conv3_b6_levels & 1 && vox >= 16LL * 1024))) {
-      if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-      else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-      *handled = true;
+    const bool forced = o.conv3_b6 >= 2;
+    if (cd.Cout16 == 16 && cd.Cin16 == 16) {
+      if (o.conv3_b6 >= 3 || (o.conv3_b6 == 1 && (o.conv3_b6_levels & 4) && vox >= 256LL * 1024)) {
+        rows = b6_launch<3, 4, 8, 8, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        *handled = true;
+      }
+    } else if (cd.Cout16 % 64 == 0) {
+      if (forced || ((o.conv3_b6_levels & 2) && vox >= o.conv3_b6_minvox)) {
+        // 64-channel slabs.  Mid level (>= 16 K voxels): 64-voxel 4x4x4 tiles -- they tile 28x28x20 exactly and give 490 workgroups
+        // (128-voxel tiles: 280 workgroups, one per CU, nothing to overlap with: 66-71 us against 47-51 us).  Deep level
+        // (14x14x10, from 2 K voxels): 2x8x4 tiles (37 % padding; 4x8x4 wastes 57 %): 40 us against 52 us for the fp32 kernel, LA step
+        // 7.90 against 7.97 ms.  The 7x7x5 level stays with the fp32 kernel (35 vs 32 us).
+        const int v = o.conv3_b6_cfg64;             // measurement switch
+        if (vox >= 16LL * 1024) {
+          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        } else {
+          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else if (v == 5) rows = b6_launch<3, 2, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else rows = b6_launch<3, 2, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        }
+        *handled = true;
+      }
+    } else if (cd.Cout16 % 32 == 0) {
+      if (forced || ((o.conv3_b6_levels & 1) && vox >= o.conv3_b6_minvox)) {
+        if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        *handled = true;
+      }
     }
   } else {
     if (cd.Cout16 % 64 == 0 && o.conv3_b6 >= 2) {

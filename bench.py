@@ -33,6 +33,10 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3        # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense BF16 MFMA peak
+# csrc/conv3b.hip computes the fp32 convolution with SIX bf16 MFMAs per K = 32 block (three-piece operands, fp32 accumulate):
+# its roofline in fp32-equivalent TFLOP/s is the bf16 peak / 6
+PEAK_BF16X3_F32EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_HBM_GBS = 8000.0               # same guide: HBM3E spec (6290 GB/s measured with a float4 copy)
 STEP_GFLOP_PER_VOLUME = 160.0       # 1/2 teacher fwd + 1/2 student fwd+bwd per input volume
 
@@ -108,6 +112,16 @@ def _work(name, shapes, ints):
     return None, 0.0, 0.0
 
 
+def _conv3_path(xshape, ints):
+    """1 when the library serves this conv shape on the bf16 pipe (bcp_conv3_fwd_path, no launch)"""
+    try:
+        from bcp_amd.hip_ops import Ops
+        N, D, H, W, Cin = xshape
+        return int(Ops.product().b.call("bcp_conv3_fwd_path", int(N), int(D), int(H), int(W), int(Cin), int(ints[0]), int(ints[1]))) == 1
+    except Exception:
+        return False
+
+
 def op_table(records, steps, step_ms, top=14):
     agg = {}
     for name, shapes, ints, ms in records:
@@ -122,7 +136,11 @@ def op_table(records, steps, step_ms, top=14):
                "avg_us": round(avg * 1e3, 1), "ms_per_step": round(tot / steps, 4), "share_of_step": round(tot / steps / step_ms, 4), "bound": bound}
         if bound == "mfma":
             tf = fl / (avg * 1e-3) / 1e12
-            row.update({"flop_per_launch": fl, "achieved_tflops": round(tf, 2), "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
+            pipe, peak = "f32", PEAK_F32_MFMA_TFLOPS
+            if name in ("conv3_fwd", "conv3_fwd_stats") and shapes and len(shapes[0]) == 5 and _conv3_path(shapes[0], ints):
+                pipe, peak = "bf16x3 (fp32-equivalent, 6 bf16 MFMAs per product)", PEAK_BF16X3_F32EQ_TFLOPS
+            row.update({"flop_per_launch": fl, "achieved_tflops": round(tf, 2), "pipe": pipe, "peak_tflops": round(peak, 1), "frac": round(tf / peak, 4),
+                        "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
         elif bound == "hbm":
             gbs = by / (avg * 1e-3) / 1e9
             row.update({"bytes_per_launch": by, "achieved_gbs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
@@ -154,7 +172,8 @@ def roofline_from(rows, bound="mfma"):
     r = max(cand, key=lambda q: q["ms_per_step"])
     key = f"{r['op']}[{r['shape']}]"
     if bound == "mfma":
-        return {"bound": "mfma", "kernel": key, "achieved": r["achieved_tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
+        return {"bound": "mfma", "kernel": key, "achieved": r["achieved_tflops"], "peak": r["peak_tflops"], "unit": "TFLOP/s", "frac": r["frac"],
+                "pipe": r["pipe"], "frac_of_f32_mfma_peak": r["frac_of_f32_mfma_peak"],
                 "flop_per_launch": r["flop_per_launch"], "avg_launch_ms": round(r["avg_us"] / 1e3, 4), "launches_per_step": r["launches_per_step"],
                 "share_of_step": r["share_of_step"], "traffic": pmc_traffic(key),
                 "how": "HIP events on the launch stream around every launch of this op inside profiled steps run right after the timed region"}
@@ -373,7 +392,10 @@ def main():
             "metric": info["metric"], "value": round(value, 3), "unit": info["unit"], "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6)},
+            "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6),
+                       "arithmetic": "fp32 tensors, fp32 accumulation; the 32- to 128-channel 3x3x3 convolutions (forward / dgrad) take their fp32 operands as "
+                                     "three bf16 pieces each and run six bf16 MFMAs per product block (csrc/conv3b.hip): fp32-equivalent results -- same parity "
+                                     "tolerances as the fp32-MFMA kernels (tests/kernel_checks.py check_conv3_b6, tests/test_gpu_vnet.py)"},
             "ranks_seen": ranks_seen,
             "step_flops": {"gflop_per_item": info["gflop_per_item"], "achieved_tflops_per_gpu": round(step_tflops, 2),
                            "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
