@@ -52,6 +52,9 @@ struct Options {
   int conv3_b6_levels = 3;  // automatic choice (conv3_b6 = 1): bit 0 = 32-channel slabs (256-voxel tiles), bit 1 = 64-channel slabs.  LA step, interleaved A/B (ms per step): off 8.87, 32-channel level 8.32, + 64-channel level 8.05 -- the latter although ALONE that kernel is slower than the exclusive pipeline kernel it replaces (66-71 vs 61 us): two workgroups per CU leave room for the other stream
   int conv3_b6_minvox = 2048;    // automatic choice: smallest launch (voxels, batch included) that goes to the bf16-pipe kernels
   int conv3_b6_cfg64 = 0;   // measurements: tile / slab variant of the 64-channel bf16-pipe instances
+  int wgrad_b6 = 1;         // weight gradient on the bf16 matrix pipe (conv3bw.hip): 0 off, 1 where measured faster, 2 wherever valid.  LA step (interleaved A/B): off 7.82 ms, 32/64-channel levels 7.52, + 128-channel level 7.38
+  int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)
+  int wgrad_b6_levels = 7;  // bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
   int wgrad_p8 = 1;         // same for the weight-gradient kernels
 };
 Options& options();

@@ -1119,7 +1119,9 @@ int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const C
 int p8_wgrad(const float* x, const float* dy, float* dw, const ConvDims& cd, int KD, int accumulate, void* workspace, hipStream_t s,
              bool* handled);
 size_t p8_wgrad_workspace_bytes(const ConvDims& cd, int KD);
-// conv3b.hip: fp32 numerics on the bf16 matrix pipe (three-piece operands)
+// conv3b.hip / conv3bw.hip: fp32 numerics on the bf16 matrix pipe (three-piece operands)
+int b6_wgrad(const float* x, const float* dy, float* partial, const ConvDims& cd, int KD, hipStream_t s);
+size_t b6_wgrad_workspace_bytes(const ConvDims& cd, int KD);
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
            double* stat_partial, int G, bool dry, hipStream_t s, bool* handled);
 
@@ -1345,8 +1347,8 @@ extern "C" size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, in
   fill_dims(cd, N, D, H, W, Cin, Cout);
   const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, Co16);
   const int g = wgrad_groups(c, N, D, H, W, Ci16, Co16);
-  const size_t a = (size_t)g * KD * 9 * Ci16 * Co16 * sizeof(float), b = p8_wgrad_workspace_bytes(cd, KD);
-  return a > b ? a : b;
+  const size_t a = (size_t)g * KD * 9 * Ci16 * Co16 * sizeof(float), b = p8_wgrad_workspace_bytes(cd, KD), c6 = b6_wgrad_workspace_bytes(cd, KD);
+  return a > b ? (a > c6 ? a : c6) : (b > c6 ? b : c6);
 }
 
 #define BCP_WG_CASE(KD_, TD_, TH_, TW_, NT_)                                                     \
@@ -1374,7 +1376,9 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, cd.Cout16);
   const int groups = wgrad_groups(c, N, D, H, W, cd.Cin16, cd.Cout16);
   float* ws = reinterpret_cast<float*>(workspace);
-  int G = 0;
+  int G = b6_wgrad(x, dy, ws, cd, KD, (hipStream_t)stream);      // partial slabs from the bf16-pipe kernel (conv3bw.hip), when it takes the shape
+  if (G > 0) done = true;
+  if (!done) {
   BCP_WG_CASE(3, 4, 4, 16, 1) BCP_WG_CASE(3, 4, 4, 16, 2) BCP_WG_CASE(3, 4, 4, 16, 4)
   BCP_WG_CASE(3, 4, 8, 8, 1) BCP_WG_CASE(3, 4, 8, 8, 2) BCP_WG_CASE(3, 4, 8, 8, 4)
   BCP_WG_CASE(3, 4, 4, 8, 1) BCP_WG_CASE(3, 4, 4, 8, 2) BCP_WG_CASE(3, 4, 4, 8, 4)
@@ -1382,6 +1386,7 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   BCP_WG_CASE(3, 2, 8, 4, 1) BCP_WG_CASE(3, 2, 8, 4, 2) BCP_WG_CASE(3, 2, 8, 4, 4)
   BCP_WG_CASE(1, 1, 16, 16, 1) BCP_WG_CASE(1, 1, 16, 16, 2) BCP_WG_CASE(1, 1, 16, 16, 4)
   BCP_WG_CASE(1, 1, 8, 8, 1) BCP_WG_CASE(1, 1, 8, 8, 2) BCP_WG_CASE(1, 1, 8, 8, 4)
+  }
   BCP_REQUIRE(done, "bcp_conv3_wgrad: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
   const int T = KD * 9;
   if (G >= 32)

@@ -1,0 +1,258 @@
+// bcp_amd/csrc/conv3bw.hip -- weight gradient of the 3x3x3 / 3x3 convolution with fp32 numerics on the BF16 matrix pipe.
+//
+//     dW[tap][ci][co] = sum over voxels v of  X[v + off(tap)][ci] * dY[v][co]
+//
+// Same arithmetic as conv3b.hip: both operands enter the LDS as THREE bf16 pieces (x = p0 + p1 + p2 up to 2^-26 |x|) and every
+// K = 32 block takes six v_mfma_f32_16x16x32_bf16 (a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0, fp32 accumulation in the matrix
+// core) -- fp32-equivalent, ~2.5x fewer matrix-pipe cycles than the eight v_mfma_f32_16x16x4_f32 it replaces, and bf16 MFMAs leave
+// issue slots for the LDS / VALU work around them, which fp32 MFMAs on gfx950 do not (tools/probe/overlap_probe.hip).
+//
+// GEMM view per tap: rows = 16 input channels (one chunk), columns = 16 * NT output channels, K = voxels.  The MFMA wants, per
+// lane, 8 consecutive K values of ONE channel -- but both tensors are channel-innermost, in HBM and in the LDS ([voxel][16 ci]
+// halo planes as in conv3b.hip, [voxel][CT co] gradient-tile planes).  ds_read_b64_tr_b16 closes the gap: within a 16-lane group,
+// lane i receives as element j the (i & 3)-th bf16 of the 8 bytes addressed by lane 4 j + (i >> 2) (measured:
+// tools/probe/tr_probe.hip).  With lane a pointing at (voxel a >> 2, channel quad a & 3) every lane i ends up with channel i of
+// four consecutive voxels -- a transposed fragment straight out of the row-major image, and a tap shift is just a different row
+// address (no shifted copies, no alignment problem: rows are 32 bytes).  Two such reads make one 8-element MFMA operand; K slot
+// r * 4 + j of lane group lg is voxel r * 16 + lg * 4 + j of the 32-voxel K block, for X and dY alike, which keeps each read's 16
+// voxels contiguous (conflict-free).
+//
+// Workgroup = 256 threads = 4 waves; the waves split the taps (wave w owns taps w, w + 4, ...), every wave walks all voxels of the
+// tile; a workgroup loops over a group of spatial tiles for one (cin chunk, cout slab) and writes ONE partial [T][16][CT] slab,
+// summed by k_wgrad_reduce(_deep) of conv3.hip (deterministic, no atomics).  Two workgroups per CU.
+//
+// Reference op: autograd of nn.Conv3d(k=3,pad=1) / nn.Conv2d(k=3,pad=1) (networks/VNet.py:17, networks/unet.py:19-25).
+#include "conv3_defs.h"
+#include "../../include/bcp_hip.h"
+
+namespace bcp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#ifndef BCP_DS_READ_TR16_B64      // (the host simulator supplies its own)
+typedef short bcp_s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 ds_read_tr16(const unsigned short* p) {
+  return __builtin_bit_cast(bf16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) bcp_s16x4*)p));
+}
+#else
+__device__ __forceinline__ bf16x4 ds_read_tr16(const unsigned short* p) {
+  const unsigned long long u = BCP_DS_READ_TR16_B64(p);
+  return __builtin_bit_cast(bf16x4, u);
+}
+#endif
+__device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+template <int KD, int TD, int TH, int TW, int NT>
+__global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ partial,
+                                            ConvDims cd, int tiles_total, int tiles_per_group) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int T = TL::T, CT = NT * 16, M = TL::M, KB = M / 32;
+  constexpr int TPW = (T + 3) / 4;                      // taps per wave
+  constexpr int XPLANE = TL::HV * 16;                   // bf16 elements per halo piece plane ([HV][16])
+  constexpr int YS = CT + 16;                           // gradient-tile row stride (bank spread of the transposed reads)
+  constexpr int YPLANE = M * YS;
+  constexpr int NY4 = (M * (CT / 4) + 255) / 256;       // dY-tile float4 per thread
+  static_assert(TW % 4 == 0 && M % 32 == 0, "a transposed read covers 4 consecutive voxels of a W row");
+  using HF = HaloFetch<TL>;
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][16]
+  unsigned short* Yb = Xb + 3 * XPLANE;                            // [3][M][YS]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int cc = blockIdx.y;                 // cin chunk
+  const int cout0 = blockIdx.z * CT;
+  const int grp = blockIdx.x;
+
+  f32x4 acc[TPW][NT];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // per-lane source addresses of the transposed reads: lane (li, lg) points at voxel r*16 + lg*4 + (li >> 2) of K block kb,
+  // channel quad li & 3
+  int xo[KB][2], yo[KB][2];
+#pragma unroll
+  for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int m = kb * 32 + r * 16 + lg * 4 + (li >> 2);
+      xo[kb][r] = TL::voff(m) * 16 + (li & 3) * 4;
+      yo[kb][r] = m * YS + (li & 3) * 4;
+    }
+  int toff[TPW];                                     // halo row offset of this wave's taps (a slot past T recomputes tap 0: never stored)
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = wave + 4 * t;
+    toff[t] = (tap < T ? TL::tapoff(tap) : 0) * 16;
+  }
+
+  int t_end = (grp + 1) * tiles_per_group;
+  if (t_end > tiles_total) t_end = tiles_total;
+  int tile = grp * tiles_per_group;
+  if (tile >= t_end) return;
+
+  HF hf;
+  hf.init(cd, reinterpret_cast<float*>(smem4));      // (its fp32 LDS slot is not used)
+  const bool slab_full = cout0 + CT <= cd.Cout;
+  float4 px[HF::NP], py[NY4];
+  unsigned xvm = 0, yvm = 0;                          // validity bits of the registers in flight
+  // global -> registers, branch-free (see HaloFetch::fetch_nb): rows outside the volume read element 0 and are zeroed at the stash
+  auto fetch = [&](int tl) __attribute__((always_inline)) {
+    int n, d0, h0, w0;
+    tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
+    xvm = hf.fetch_nb(X, cd, n, d0, h0, w0, cc, px);
+    yvm = 0;
+#pragma unroll
+    for (int u = 0; u < NY4; ++u) {
+      const int q = (threadIdx.x + u * 256) % (M * (CT / 4));
+      const int m = q / (CT / 4), c4 = q % (CT / 4);
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int d = d0 + td, h = h0 + th, w = w0 + tw;
+      const int co = cout0 + c4 * 4;
+      const unsigned ok = (d < cd.D && h < cd.H && w < cd.W && (slab_full || co < cd.Cout)) ? 1u : 0u;
+      const unsigned off = ok ? (unsigned)(((((long long)n * cd.D + d) * cd.H + h) * cd.W + w) * cd.Cout + co) : 0u;
+      py[u] = ld4(dY + off);
+      yvm |= ok << u;
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < HF::NP; ++u)
+      if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
+        const float4 v = ((xvm >> u) & 1u) ? px[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_store4(v, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * 16 + hf.part * 4, XPLANE);
+      }
+#pragma unroll
+    for (int u = 0; u < NY4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      if (q < M * (CT / 4)) {
+        const float4 v = ((yvm >> u) & 1u) ? py[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_store4(v, Yb + (q / (CT / 4)) * YS + (q % (CT / 4)) * 4, YPLANE);
+      }
+    }
+  };
+
+  fetch(tile);
+  stash();
+  BCP_LDS_BARRIER();
+  for (;;) {
+    const bool has_next = tile + 1 < t_end;
+    fetch(has_next ? tile + 1 : tile);       // (the last tile re-reads itself: no conditional load in the loop)
+#pragma unroll 1
+    for (int kb = 0; kb < KB; ++kb) {
+      bf16x8 b[NT][3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          b[nt][s] = cat8(ds_read_tr16(Yb + s * YPLANE + yo[kb][0] + nt * 16), ds_read_tr16(Yb + s * YPLANE + yo[kb][1] + nt * 16));
+#pragma unroll
+      for (int t = 0; t < TPW; ++t) {
+        bf16x8 a[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+          a[s] = cat8(ds_read_tr16(Xb + s * XPLANE + xo[kb][0] + toff[t]), ds_read_tr16(Xb + s * XPLANE + xo[kb][1] + toff[t]));
+        // rows = input channels (A = X^T fragment), columns = output channels (B = dY fragment); smallest terms first
+#define BCP_W6(I, J)                                                                                                   \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                      \
+      acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[I], b[nt][J], acc[t][nt], 0, 0, 0);
+        BCP_W6(2, 0) BCP_W6(1, 1) BCP_W6(0, 2) BCP_W6(1, 0) BCP_W6(0, 1) BCP_W6(0, 0)
+#undef BCP_W6
+      }
+    }
+    if (!has_next) break;
+    BCP_LDS_BARRIER();                        // every wave is done reading the planes
+    stash();
+    BCP_LDS_BARRIER();
+    ++tile;
+  }
+  // partial[grp][tap][ci][co]: lane (li, lg) holds ci = lg*4 + r (rows), co = li (columns)
+  float* P = partial + (long long)grp * T * cd.Cin16 * cd.Cout16;
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int tap = wave + 4 * t;
+    if (tap < T) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          P[((long long)tap * cd.Cin16 + cc * 16 + lg * 4 + r) * cd.Cout16 + cout0 + nt * 16 + li] = acc[t][nt][r];
+    }
+  }
+}
+
+struct W6Plan { int cfg, TD, TH, TW, NT, groups; };
+
+static bool w6_plan(W6Plan& p, const ConvDims& cd, int KD) {
+  const Options& o = options();
+  if (o.wgrad_b6 == 0 || cd.Cin16 % 16 || cd.Cout16 % 16) return false;
+  if (cd.Cout16 % 32 && !(o.wgrad_b6 >= 2 || (o.wgrad_b6_levels & 4))) return false;      // 16-channel slabs: see wgrad_b6_levels
+  const long long vox = (long long)cd.N * cd.D * cd.H * cd.W;
+  const bool forced = o.wgrad_b6 >= 2;
+  if (KD == 3) {
+    if (!forced && vox < o.wgrad_b6_minvox) return false;
+    if (cd.W % 8 == 0 || cd.W >= 32) { p.cfg = 0; p.TD = 4; p.TH = 4; p.TW = 8; }      // 128 voxels
+    else { p.cfg = 1; p.TD = 4; p.TH = 8; p.TW = 4; }
+    if (vox < 16LL * 1024) { p.cfg = 2; p.TD = 2; p.TH = 8; p.TW = 4; }                 // deep level: 64 voxels
+  } else {
+    if (!forced) return false;
+    p.cfg = 3; p.TD = 1; p.TH = 8; p.TW = 16;
+  }
+  p.NT = cd.Cout16 % 32 ? 1 : 2;
+  const int tiles = cd.N * cdiv(cd.D, p.TD) * cdiv(cd.H, p.TH) * cdiv(cd.W, p.TW);
+  const int chan_blocks = (cd.Cin16 / 16) * (cd.Cout16 / (p.NT * 16));
+  int g = cdiv(512, chan_blocks);
+  if (g > tiles) g = tiles;
+  if (g < 1) g = 1;
+  const int tpg = cdiv(tiles, g);
+  p.groups = cdiv(tiles, tpg);
+  return true;
+}
+
+size_t b6_wgrad_workspace_bytes(const ConvDims& cd, int KD) {
+  W6Plan p;
+  if (!w6_plan(p, cd, KD)) return 0;
+  return (size_t)p.groups * KD * 9 * cd.Cin16 * cd.Cout16 * sizeof(float);
+}
+
+template <int KD, int TD, int TH, int TW, int NT>
+static int w6_launch(const float* X, const float* dY, float* partial, ConvDims cd, int groups, hipStream_t s) {
+  using TL = Tile<KD, TD, TH, TW>;
+  constexpr int CT = NT * 16;
+  const size_t lds = (size_t)3 * TL::HV * 16 * 2 + (size_t)3 * TL::M * (CT + 16) * 2;
+  cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
+  const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+  const int tpg = cdiv(tiles, groups);
+  auto kfn = k_w6<KD, TD, TH, TW, NT>;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const dim3 grid(cdiv(tiles, tpg), cd.Cin16 / 16, cd.Cout16 / CT);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, dY, partial, cd, tiles, tpg);
+  return cdiv(tiles, tpg);
+}
+
+// Partial weight-gradient slabs on the bf16 pipe where option wgrad_b6 allows it: returns the number of slabs written to
+// `partial` ([G][T][Cin16][Cout16], for k_wgrad_reduce(_deep)), 0 when the shape is left to the fp32 kernels.
+int b6_wgrad(const float* x, const float* dy, float* partial, const ConvDims& cd, int KD, hipStream_t s) {
+  W6Plan p;
+  if (!w6_plan(p, cd, KD)) return 0;
+  if (p.NT == 1) {
+    switch (p.cfg) {
+      case 0: return w6_launch<3, 4, 4, 8, 1>(x, dy, partial, cd, p.groups, s);
+      case 1: return w6_launch<3, 4, 8, 4, 1>(x, dy, partial, cd, p.groups, s);
+      case 2: return w6_launch<3, 2, 8, 4, 1>(x, dy, partial, cd, p.groups, s);
+      default: return w6_launch<1, 1, 8, 16, 1>(x, dy, partial, cd, p.groups, s);
+    }
+  }
+  switch (p.cfg) {
+    case 0: return w6_launch<3, 4, 4, 8, 2>(x, dy, partial, cd, p.groups, s);
+    case 1: return w6_launch<3, 4, 8, 4, 2>(x, dy, partial, cd, p.groups, s);
+    case 2: return w6_launch<3, 2, 8, 4, 2>(x, dy, partial, cd, p.groups, s);
+    default: return w6_launch<1, 1, 8, 16, 2>(x, dy, partial, cd, p.groups, s);
+  }
+}
+
+}  // namespace bcp

@@ -523,6 +523,7 @@ CONV3_B6_CASES = (
     (2, 64, 64, (4, 8, 12), 3),       # 4x8x4 tiles, 64-channel slab, one pair per stage
     (1, 32, 128, (6, 9, 5), 3),       # two slabs, partial tiles
     (1, 20, 32, (4, 4, 8), 3),        # Cin padded to 32
+    (2, 16, 16, (4, 8, 8), 3),        # 16-channel slab: weight gradient only (one n-tile per wave)
     (2, 64, 32, (1, 12, 20), 1),      # 2-D: 8x16 tiles, 5 tap pairs (one zero-weight pad tap)
     (1, 32, 64, (1, 8, 16), 1),
 )
@@ -533,6 +534,7 @@ def check_conv3_b6(ops, dev):
     on (conv3_b6 = 2): forward, dgrad, += and split-K vs torch CPU at the ordinary fp32 tolerance; fused statistics; and the
     accuracy claim itself -- the error against an fp64 convolution stays within 3x of the fp32-MFMA kernel's on the same data"""
     ops.set_option("conv3_b6", 2)
+    ops.set_option("wgrad_b6", 2)           # csrc/conv3bw.hip: the weight gradient on the same pipe (transposed LDS reads)
     try:
         check_conv3(ops, dev, cases=CONV3_B6_CASES)
         for sk in (2, 4):
@@ -543,6 +545,7 @@ def check_conv3_b6(ops, dev):
                 ops.set_option("splitk")
     finally:
         ops.set_option("conv3_b6")
+        ops.set_option("wgrad_b6")
     rng = np.random.default_rng(41)
     for (N, Cin, Cout, sp, KD, G) in ((4, 32, 32, (4, 8, 8), 3, 2), (2, 64, 64, (4, 8, 8), 3, 2), (2, 32, 64, (1, 16, 16), 1, 1)):
         two_d = KD == 1

@@ -86,9 +86,11 @@ def test_standard_regime_gradients_on_hip_activation_pattern(ops):
 def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
     """the 2-D instances of csrc/conv3b.hip (off by default) forced on: golden tiny U-Net, pattern gradients 1e-4, five-step trajectory"""
     ops.set_option("conv3_b6", 2)
+    ops.set_option("wgrad_b6", 2)      # csrc/conv3bw.hip: the weight gradients too
     try:
         NC.check_unet_golden_tiny(ops, DEV, golden_dir)
         print("unet", NC.check_unet_pattern_grads(ops, DEV))
         NC.check_acdc_traj5(ops, DEV, golden_dir)
     finally:
         ops.set_option("conv3_b6")
+        ops.set_option("wgrad_b6")

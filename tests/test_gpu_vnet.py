@@ -144,6 +144,7 @@ def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
     checks are repeated: golden tiny net, every gradient tensor to 1e-4 on the HIP activation pattern (BatchNorm and
     InstanceNorm V-Net), the five-step trajectory."""
     ops.set_option("conv3_b6", 2)
+    ops.set_option("wgrad_b6", 2)      # csrc/conv3bw.hip: the weight gradients too
     try:
         NC.check_vnet_golden_tiny(ops, DEV, golden_dir)
         print("la", NC.check_vnet_pattern_grads(ops, DEV, "la", (32, 32, 16)))
@@ -152,3 +153,4 @@ def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
         NC.check_la_traj5(ops, DEV, golden_dir, fixture="la_traj5m.npz")
     finally:
         ops.set_option("conv3_b6")
+        ops.set_option("wgrad_b6")

@@ -144,6 +144,23 @@ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 cacc) {
   return cacc;
 }
 
+uint64_t ds_read_tr16_b64(const void* ptr) {
+  WaveScratch& w = my_wave();
+  unsigned p = next_phase();
+  int l = lane_id();
+  uint64_t mine;
+  memcpy(&mine, ptr, 8);
+  w.u[p][l] = mine;
+  wave_sync();
+  uint64_t out = 0;
+  const int g0 = l & ~15, i = l & 15;
+  for (int j = 0; j < 4; ++j) {
+    const uint64_t src = w.u[p][g0 + 4 * j + (i >> 2)];
+    out |= ((src >> (16 * (i & 3))) & 0xFFFFull) << (16 * j);
+  }
+  return out;
+}
+
 static void fiber_entry() {
   BlockCtx* c = g_ctx;
   (*c->body)();

@@ -34,6 +34,9 @@
 #define BCP_LDS_BARRIER() ::bcpemu::block_sync()
 // v_cvt_pk_bf16_f32 (round to nearest even, finite values): software on the host
 static inline unsigned bcpemu_rne_bf16(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; }
+// ds_read_b64_tr_b16: lane i of a 16-lane group gets element (i & 3) of the 8 bytes addressed by lane 4 j + (i >> 2) as its element j
+// (measured on gfx950: tools/probe/tr_probe.hip)
+#define BCP_DS_READ_TR16_B64(p) ::bcpemu::ds_read_tr16_b64(p)
 #define BCP_CVT_PK_BF16(a, b) (bcpemu_rne_bf16(a) | (bcpemu_rne_bf16(b) << 16))
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::bcpemu::dyn_lds());
 
@@ -146,6 +149,7 @@ f32x4 mfma_16x16x4(float a, float b, f32x4 c);
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c);
+uint64_t ds_read_tr16_b64(const void* p);   // ds_read_b64_tr_b16
 
 }  // namespace bcpemu
 
