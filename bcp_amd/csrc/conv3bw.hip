@@ -199,7 +199,7 @@ static bool w6_plan(W6Plan& p, const ConvDims& cd, int KD) {
     else { p.cfg = 1; p.TD = 4; p.TH = 8; p.TW = 4; }
     if (vox < 16LL * 1024) { p.cfg = 2; p.TD = 2; p.TH = 8; p.TW = 4; }                 // deep level: 64 voxels
   } else {
-    if (!forced) return false;
+    if (!forced && !((o.wgrad_b6_levels & 8) && vox >= o.wgrad_b6_minvox)) return false;
     p.cfg = 3; p.TD = 1; p.TH = 8; p.TW = 16;
   }
   p.NT = cd.Cout16 % 32 ? 1 : 2;

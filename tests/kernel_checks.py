@@ -543,6 +543,11 @@ def check_conv3_b6(ops, dev):
                 check_conv3(ops, dev, cases=[CONV3_B6_CASES[2]])
             finally:
                 ops.set_option("splitk")
+        ops.set_option("conv3_b6_direct", 1)        # k_c3d: weight fragments straight from the pre-split pack, no stage barriers
+        try:
+            check_conv3(ops, dev, cases=CONV3_B6_CASES)
+        finally:
+            ops.set_option("conv3_b6_direct")
     finally:
         ops.set_option("conv3_b6")
         ops.set_option("wgrad_b6")
