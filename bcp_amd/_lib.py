@@ -50,6 +50,7 @@ _SIGS = {
     "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, I, P, P]),
     "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
     "bcp_conv3_fwd_path": (SZ, [I, I, I, I, I, I, I]),
+    "bcp_conv3_wgrad_path": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_pack_weight": (I, [P, P, P, I, I, I, P]),
     "bcp_conv3_pack_many": (I, [P, I, P]),
     "bcp_conv3_fwd_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),

@@ -1287,6 +1287,12 @@ extern "C" size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Co
   return handled ? 1 : 0;
 }
 
+extern "C" size_t bcp_conv3_wgrad_path(int N, int D, int H, int W, int Cin, int Cout, int KD) {
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  return b6_wgrad_workspace_bytes(cd, KD) > 0 ? 1 : 0;       // conv3bw.hip takes the shape
+}
+
 extern "C" int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
                                    int Cout, int KD, void* workspace, double* stat_partial, int groups, void* stream) {
   BCP_REQUIRE(x && wp && y && stat_partial, "bcp_conv3_fwd_stats: null pointer");

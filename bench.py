@@ -112,11 +112,13 @@ def _work(name, shapes, ints):
     return None, 0.0, 0.0
 
 
-def _conv3_path(xshape, ints):
-    """1 when the library serves this conv shape on the bf16 pipe (bcp_conv3_fwd_path, no launch)"""
+def _conv3_path(xshape, ints, wgrad_cout=None):
+    """1 when the library serves this conv shape on the bf16 pipe (bcp_conv3_fwd_path / bcp_conv3_wgrad_path, no launch)"""
     try:
         from bcp_amd.hip_ops import Ops
         N, D, H, W, Cin = xshape
+        if wgrad_cout is not None:
+            return int(Ops.product().b.call("bcp_conv3_wgrad_path", int(N), int(D), int(H), int(W), int(Cin), int(wgrad_cout), int(ints[0]))) == 1
         return int(Ops.product().b.call("bcp_conv3_fwd_path", int(N), int(D), int(H), int(W), int(Cin), int(ints[0]), int(ints[1]))) == 1
     except Exception:
         return False
@@ -137,7 +139,12 @@ def op_table(records, steps, step_ms, top=14):
         if bound == "mfma":
             tf = fl / (avg * 1e-3) / 1e12
             pipe, peak = "f32", PEAK_F32_MFMA_TFLOPS
-            if name in ("conv3_fwd", "conv3_fwd_stats") and shapes and len(shapes[0]) == 5 and _conv3_path(shapes[0], ints):
+            on_bf16 = False
+            if name in ("conv3_fwd", "conv3_fwd_stats") and shapes and len(shapes[0]) == 5:
+                on_bf16 = _conv3_path(shapes[0], ints)
+            elif name == "conv3_wgrad" and len(shapes) > 1 and len(shapes[0]) == 5:
+                on_bf16 = _conv3_path(shapes[0], ints, wgrad_cout=shapes[1][-1])
+            if on_bf16:
                 pipe, peak = "bf16x3 (fp32-equivalent, 6 bf16 MFMAs per product)", PEAK_BF16X3_F32EQ_TFLOPS
             row.update({"flop_per_launch": fl, "achieved_tflops": round(tf, 2), "pipe": pipe, "peak_tflops": round(peak, 1), "frac": round(tf / peak, 4),
                         "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})

@@ -124,6 +124,7 @@ int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_nu
 /* which matrix pipe serves bcp_conv3_fwd / bcp_conv3_fwd_stats for this shape under the current options (no launch): 0 = fp32 MFMA
  * (v_mfma_f32_16x16x4_f32), 1 = bf16 MFMA with three-piece operands (fp32-equivalent results; csrc/conv3b.hip).  Measurement record only. */
 size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Cout, int KD);
+size_t bcp_conv3_wgrad_path(int N, int D, int H, int W, int Cin, int Cout, int KD);   /* the same for bcp_conv3_wgrad (csrc/conv3bw.hip) */
 size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD);
 int bcp_conv3_wgrad(const float* x, const float* dy, float* dw /*[Cout][Cin][KD*9]*/, int N, int D, int H, int W, int Cin, int Cout,
                     int KD, int accumulate, void* workspace, void* stream);
