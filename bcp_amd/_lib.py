@@ -117,6 +117,7 @@ class Binding:
             fn.argtypes = args
         self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
+        self._rec = None          # a bcp_amd.plan.LaunchPlan while a network pass is being recorded
 
     def last_error(self) -> str:
         return self.cdll.bcp_last_error().decode("utf-8", "replace")
@@ -132,7 +133,12 @@ class Binding:
         rc = fn(*args)
         if rc and is_status:
             raise BcpError(f"{name} failed ({rc}): {self.last_error()}")
+        if is_status and self._rec is not None:       # launches only: size / shape queries are pure
+            self._rec.add_call(name, fn, args)
         return rc
+
+    def check_replayed(self, rc):
+        raise BcpError(f"a replayed launch failed ({rc}): {self.last_error()}")
 
 
 _product = None

@@ -39,6 +39,7 @@ class Ops:
         self._ws = {}
         self._wsz = {}
         self._box_cache = {}
+        self._rec_plan = None     # set by bcp_amd.plan.recording
 
     @classmethod
     def product(cls) -> "Ops":
@@ -51,6 +52,8 @@ class Ops:
         """library tuning / test switch (bcp_set_option); cached shape queries depend on the options: drop them"""
         self.b.set_option(name, value)
         self._wsz.clear()
+        from . import plan
+        plan.invalidate_all()      # recorded launch plans carry kernel choices and workspace sizes of the old options
 
     def _chk(self, *ts):
         for t in ts:
@@ -76,6 +79,10 @@ class Ops:
 
     def workspace(self, key, nbytes, like):
         """grow-only scratch buffer per (key, device, stream): two streams never share scratch"""
+        if self._rec_plan is not None:
+            # a recorded pass owns its scratch: the shared grow-only buffers may be re-allocated later by another shape, and a
+            # plan's pointers must stay valid for its whole life (torch.empty is the recording's capturing version)
+            return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=like.device)
         k = (key, like.device, torch._C._cuda_getCurrentRawStream(like.device.index) if like.is_cuda else 0)
         w = self._ws.get(k)
         if w is None or w.numel() < nbytes:

@@ -151,7 +151,7 @@ class VNet(HipNet):
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in (self._layers[0].conv.weight,)):
             out = NetFn.apply(xcl, self._layers[0].conv.weight, self)   # eval() is forward-only (validation, test_3d_patch)
         else:
-            out, _ = self._forward_impl(xcl, save=False)
+            out, _ = self._run_forward(xcl, False)
         logits = out.permute(0, 4, 1, 2, 3)  # logical [N,C,X,Y,Z], channels_last_3d strides
         if self.variant == "la":
             return logits, None   # second value (pooled x5) is dead in every train script (LA_BCP_train.py:158,252)

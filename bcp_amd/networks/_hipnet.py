@@ -351,6 +351,9 @@ class HipNet(nn.Module):
             if side is None:
                 side = self.net._side_streams[t.device] = torch.cuda.Stream(device=t.device)
             side.wait_stream(main)                 # dy (and the zeroed gradient buffer) are ready
+            rec = self.net.ops.b._rec
+            if rec is not None:
+                rec.add_py(side.wait_stream, main)     # (a replayed pass works on static tensors: no record_stream)
             for x in self.tensors:
                 x.record_stream(side)              # keep the allocator from recycling them under the side stream
             self.ctx = torch.cuda.stream(side)
@@ -372,7 +375,11 @@ class HipNet(nn.Module):
         if like.is_cuda and self.overlap_wgrad:
             side = self._side_streams.get(like.device)
             if side is not None:
-                torch.cuda.current_stream(like.device).wait_stream(side)
+                main = torch.cuda.current_stream(like.device)
+                main.wait_stream(side)
+                rec = self.ops.b._rec
+                if rec is not None:
+                    rec.add_py(main.wait_stream, side)
 
     # ---- data parallelism: bucketed gradient all-reduce underneath the rest of the backward pass (bcp_amd/dp.py).
     # The backward walks the layers in reverse registration order, so once layer L is done the flat gradient buffer is final
@@ -409,6 +416,14 @@ class HipNet(nn.Module):
             lo = self._bucket_plan().get(id(p))
             if lo is not None:
                 hook(self, lo, like)
+                rec = self.ops.b._rec
+                if rec is not None:
+                    rec.add_py(self._replay_bucket_hook, lo, like)
+
+    def _replay_bucket_hook(self, lo, like):
+        hook = self._grad_bucket_hook          # the hook armed for THIS step (DataParallel.arm), not the one seen while recording
+        if hook is not None:
+            hook(self, lo, like)
 
     _instances = 0   # per-process instance counter: every network gets its own dropout stream
 
@@ -433,6 +448,104 @@ class HipNet(nn.Module):
         return self._drop_seed
 
 
+    # ---- recorded launch plans (bcp_amd/plan.py): a training-mode pass is recorded once per (shape, groups, mode, stream) and
+    # replayed afterwards -- one ctypes call per launch, no Python per layer
+    use_plans = True
+
+    def _plan_ok(self, x):
+        from .. import plan
+        return (plan.ENABLED and self.use_plans and self.training and self.drop_masks is None and not getattr(self, "_keep_saved", False)
+                and (x.is_cuda or self.ops.allow_cpu) and self.ops.b._rec is None)
+
+    def _ensure_packed(self, need_dgrad):
+        """weight packs depend on the weights' version, not on the pass: (re)pack eagerly, outside any plan"""
+        c3 = getattr(self, "_c3", None)
+        if c3:
+            self.conv3_packed(c3[0][0], need_dgrad)
+        k2 = getattr(self, "_k2", None)
+        if k2:
+            self.k2_packed(k2[0][0], need_dgrad)
+
+    def _plans_for(self):
+        from .. import plan
+        st = self.__dict__.get("_plan_state")
+        tag = (plan.epoch(), self._flat.data_ptr(), self._flat_grad.data_ptr() if self._flat_grad is not None else 0)
+        if st is None or st[0] != tag:
+            st = (tag, {})
+            object.__setattr__(self, "_plan_state", st)
+        return st[1]
+
+    def _run_forward(self, xcl, save):
+        if not self._plan_ok(xcl):
+            return self._forward_impl(xcl, save)
+        from .. import plan
+        self._ensure_flat()
+        plans = self._plans_for()
+        key = ("f", tuple(xcl.shape), getattr(self, "_groups", 1), bool(save), bool(getattr(self, "_turnoff_drop", False)), self.ops.stream(xcl))
+        pl = plans.get(key)
+        if pl is not None and pl.busy:
+            # the plan's static activations belong to a forward whose backward has not run yet (the unfused loop calls the student
+            # twice per step): this call must not overwrite them
+            return self._forward_impl(xcl, save)
+        self._ensure_packed(save)
+        if pl is None:
+            pl = plan.LaunchPlan()
+            pl.static_in = torch.empty_like(xcl)
+            pl.static_in.copy_(xcl)
+            t0 = getattr(self, "_nbt", 0)
+            with plan.recording(self.ops, pl):
+                pl.result = self._forward_impl(pl.static_in, save)
+            pl.ticks = getattr(self, "_nbt", 0) - t0
+            plans[key] = pl
+        else:
+            pl.static_in.copy_(xcl)
+            pl.replay([self.next_seed() for _ in pl.seed_slots], self.ops.b.check_replayed)
+            for _ in range(pl.ticks):
+                self._nbt_tick()
+        out, saved = pl.result
+        if save:
+            pl.busy = True
+            saved_ref = _PlanSaved(saved, pl)
+            return out.detach(), saved_ref
+        return out.clone(), None            # forward-only (teacher): the caller may hold the logits across the next call
+
+    def _run_backward(self, saved, dout):
+        if not isinstance(saved, _PlanSaved):
+            return self._backward_impl(saved, dout)
+        from .. import plan
+        fwd, saved = saved.plan, saved.saved
+        try:
+            if not self._plan_ok(dout):
+                return self._backward_impl(saved, dout)
+            plans = self._plans_for()
+            key = ("b", id(saved), tuple(dout.shape), self.ops.stream(dout), self._grad_bucket_hook is not None)
+            pl = plans.get(key)
+            self._ensure_packed(True)
+            if pl is None:
+                pl = plan.LaunchPlan()
+                pl.static_in = torch.empty(tuple(dout.shape), dtype=dout.dtype, device=dout.device)
+                pl.static_in.copy_(dout)
+                pl.keep.append(saved)           # the forward plan's tensors this pass reads
+                with plan.recording(self.ops, pl):
+                    self._backward_impl(saved, pl.static_in)
+                plans[key] = pl
+            else:
+                pl.static_in.copy_(dout)
+                self.begin_backward()
+                pl.replay((), self.ops.b.check_replayed)
+        finally:
+            fwd.busy = False
+        return None
+
+
+class _PlanSaved:
+    """what NetFn keeps between forward and backward when the forward came from a launch plan"""
+    __slots__ = ("saved", "plan")
+
+    def __init__(self, saved, plan):
+        self.saved, self.plan = saved, plan
+
+
 class NetFn(torch.autograd.Function):
     """One autograd node for a whole network call.  `anchor` is any trainable parameter: it makes the
     output require grad; parameter gradients are written by the kernels straight into the flat
@@ -440,7 +553,7 @@ class NetFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, anchor, net):
-        out, saved = net._forward_impl(x, save=True)
+        out, saved = net._run_forward(x, True)
         if getattr(net, "_keep_saved", False):      # parity tests: expose (y, stats) per layer -> activation patterns (tests/net_checks.py)
             net._last_saved = saved
         ctx.net = net
@@ -449,6 +562,6 @@ class NetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        ctx.net._backward_impl(ctx.saved, dout)
+        ctx.net._run_backward(ctx.saved, dout)
         ctx.saved = None
         return None, None, None

@@ -92,7 +92,7 @@ class UNet_2d(HipNet):
         if self.training and torch.is_grad_enabled() and anchor.requires_grad:
             out = NetFn.apply(xcl, anchor, self)
         else:
-            out, _ = self._forward_impl(xcl, save=False)
+            out, _ = self._run_forward(xcl, False)
         return out.permute(0, 4, 1, 2, 3).squeeze(2)   # logical [N,4,H,W]
 
     # ------------------------------------------------------------------ pieces

@@ -900,3 +900,54 @@ def check_unet_pattern_grads(ops, dev, hw=(64, 64), N=2, seed=12, bound=1e-4):
             worst = (k, r)
         assert r < bound, (k, r)
     return worst
+
+
+# ------------------------------------------------------------------------------------------ launch plans
+def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True))):
+    """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net
+    (grouped and as the reference's four separate calls -- the second student call must not reuse the busy plan), the pancreas
+    V-Net and the ACDC U-Net, live Dropout / Dropout3d (the seeds are patched into the recorded launches), weights, teacher
+    weights and running statistics compared after the last step"""
+    from bcp_amd import plan, train_step
+
+    def run(enabled, what, grouped):
+        plan.ENABLED = enabled
+        try:
+            torch.manual_seed(5)
+            np.random.seed(5)
+            if what == "acdc":
+                P = O.init_params(O.unet_param_shapes(), seed=51, random_affine=True)
+                model, ema = make_unet(P, dev, ops), make_unet(P, dev, ops)
+                vol, lab = O.synth_acdc_batch(8, shape=(64, 64), seed=78)
+            else:
+                shape = (32, 32, 16) if what == "la" else (32, 32, 32)
+                P = O.init_params(O.vnet_param_shapes(variant=what), seed=41, random_affine=True)
+                model, ema = make_vnet(P, dev, ops, what), make_vnet(P, dev, ops, what)
+                vol, lab = O.synth_la_batch(4, shape=shape, seed=77)
+            model.seed_dropout(11)
+            ema.seed_dropout(12)
+            for p in ema.parameters():
+                p.detach_()
+            vol, lab = vol.to(dev), lab.to(dev)
+            opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+            losses = []
+            for _ in range(steps):
+                if what == "acdc":
+                    r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=(9, 13, 42, 42))
+                else:
+                    r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), variant=what,
+                                                      connect_mode=2 if what != "la" else None, grouped=grouped)
+                losses.append(float(r["loss"]))
+            n_plans = len(model.__dict__.get("_plan_state", (None, {}))[1])
+            return losses, {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}, {k: v.detach().clone().cpu() for k, v in ema.state_dict().items()}, n_plans
+        finally:
+            plan.ENABLED = True
+
+    for what, grouped in cases:
+        a, b = run(False, what, grouped), run(True, what, grouped)
+        assert a[3] == 0 and b[3] >= 2, (what, a[3], b[3])           # the second run really replayed (forward + backward plans)
+        assert a[0] == b[0], (what, grouped, a[0], b[0])
+        for k in a[1]:
+            assert torch.equal(a[1][k], b[1][k]), (what, "student", k)
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), (what, "teacher", k)

@@ -75,3 +75,9 @@ def test_vnet_pancreas_standard_regime_gradients_on_hip_pattern(emu_ops):
 
 def test_la_loop_body_as_the_reference_writes_it(emu_ops, golden_dir):
     NC.check_la_unfused_loop(emu_ops, CPU, golden_dir, steps=2)
+
+
+def test_recorded_launch_plans_equal_eager_path(emu_ops):
+    from bcp_amd.utils import BCP_utils as BU
+    BU.set_test_ops(emu_ops)
+    NC.check_launch_plans(emu_ops, CPU, steps=2, cases=(("la", True), ("la", False)))      # (all four workloads: the GPU suite)

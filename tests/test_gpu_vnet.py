@@ -154,3 +154,8 @@ def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
     finally:
         ops.set_option("conv3_b6")
         ops.set_option("wgrad_b6")
+
+
+def test_recorded_launch_plans_equal_eager_path(ops):
+    """bcp_amd/plan.py: replayed passes == the eager Python path, bit for bit (LA grouped / unfused, pancreas, ACDC; live dropout)"""
+    NC.check_launch_plans(ops, DEV)
