@@ -36,7 +36,7 @@ Rccl* rccl() {
     tried = true;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {
-      r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
       if (r.lib) break;
     }
     if (r.lib) {

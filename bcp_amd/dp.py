@@ -32,7 +32,9 @@ class _RcclAbi:
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         ident = (C.c_char * 128)()
-        tag = f"{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{world}"
+        # one file per LAUNCH: port, elastic run id, world size and the launcher's pid (all ranks of a torchrun / spawn share their
+        # parent) -- a file left behind by a crashed earlier launch can never be mistaken for this one's
+        tag = f"{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{world}_{os.environ.get('BCP_DP_LAUNCH_ID', os.getppid())}"
         path = os.path.join(os.environ.get("BCP_DP_ID_DIR", "/tmp"), f"bcp_rccl_id_{tag}")
         if rank == 0:
             self.b.call("bcp_comm_unique_id", C.cast(ident, C.c_void_p))
@@ -128,8 +130,14 @@ class DataParallel:
             backend = os.environ.get("BCP_DP_BACKEND") or ("rccl" if torch.cuda.is_available() else "gloo")
         self.backend = backend
         if backend == "rccl":
-            self.abi = _RcclAbi(self.world, self.rank, self.local_rank)
-            return
+            from . import _lib
+            if _lib.product().call("bcp_comm_available"):
+                self.abi = _RcclAbi(self.world, self.rank, self.local_rank)
+                return
+            # librccl.so cannot be dlopen()ed on this box (the same on every rank): torch.distributed's bundled RCCL instead
+            import sys
+            print("[bcp_amd.dp] librccl.so not loadable through the C ABI -- falling back to torch.distributed 'nccl'", file=sys.stderr)
+            backend = self.backend = "nccl"
         import torch.distributed as dist
         if not dist.is_initialized():
             if backend == "nccl":
