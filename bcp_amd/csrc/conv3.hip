@@ -811,22 +811,27 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
       const float v = d.dgrad ? tile[(kk * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk) * T + t];
       d.wp[(((long long)t * (d.K16 >> 2) + (k0 >> 2) + kq) * d.N16 + n0 + nn) * 4 + k4] = v;
     }
-    {  // three-piece bf16 section (see k_pack_conv3): this unit = chunk k0 / 16, columns n0 .. n0 + 15; two k per thread and step
+    {  // three-piece bf16 section (see k_pack_conv3): this unit = chunk k0 / 16, columns n0 .. n0 + 15; two k per thread and step:
+       // exactly one packed pair per piece (v_cvt_pk_bf16_f32; the integer split of the first version cost 80 of the launch's 150 us)
       const int TP = (T + 1) / 2, ch = k0 >> 4;
       unsigned* wb = reinterpret_cast<unsigned*>(d.wp + (long long)T * d.K16 * d.N16);
       for (int q = threadIdx.x; q < TP * 16 * 16; q += 256) {
         const int j2 = q & 15, nn = (q >> 4) & 15, tp = q >> 8;
-        unsigned short pa[3], pb[3];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int j = j2 * 2 + e, t = 2 * tp + (j >> 4), kk = j & 15;
-          float v = 0.f;
-          if (t < T) v = d.dgrad ? tile[(kk * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk) * T + t];
-          split3_bf16(v, e ? pb : pa);
+        const int t = 2 * tp + (j2 >> 3), kk = (j2 * 2) & 15;
+        float v0 = 0.f, v1 = 0.f;
+        if (t < T) {
+          v0 = d.dgrad ? tile[(kk * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk) * T + t];
+          v1 = d.dgrad ? tile[((kk + 1) * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk + 1) * T + t];
         }
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          wb[(((((long long)ch * TP + tp) * 3 + pc) * d.N16 + n0 + nn) * 32 + j2 * 2) >> 1] = (unsigned)pa[pc] | ((unsigned)pb[pc] << 16);
+        unsigned* o = wb + ((((((long long)ch * TP + tp) * 3) * d.N16 + n0 + nn) * 32 + j2 * 2) >> 1);
+        const long long ps = ((long long)d.N16 * 32) >> 1;             // piece stride in packed pairs
+        unsigned h = cvt_pk_bf16(v0, v1);
+        o[0] = h;
+        v0 -= __uint_as_float(h << 16); v1 -= __uint_as_float(h & 0xffff0000u);
+        h = cvt_pk_bf16(v0, v1);
+        o[ps] = h;
+        v0 -= __uint_as_float(h << 16); v1 -= __uint_as_float(h & 0xffff0000u);
+        o[2 * ps] = cvt_pk_bf16(v0, v1);
       }
     }
     __syncthreads();

@@ -19,6 +19,8 @@ Prints ONE JSON line (rank 0):
   cpu_baseline  the oracle (CPU restatement of the reference, oracle/bcp_oracle.py) on this box's host cores: median of >= 5 timed
                 steps after 2 warm-ups (rank 0, N = 1 only)
   ranks_seen    N > 1: all-reduce of ones over the communicator (= the ranks RCCL really spans)
+  host_ms_per_step_empty_queue   host cost of one step (median of 5, queue drained before each); host_enqueue_ms_per_step is the
+                timed loop's enqueue time and includes launch-queue back-pressure
 """
 import argparse
 import json
@@ -191,14 +193,21 @@ def roofline_from(rows, bound="mfma"):
 def profile_steps(step, n):
     from bcp_amd.hip_ops import Ops
     ops = Ops.product()
+    from bcp_amd import plan
     torch.cuda.synchronize()
-    ops.profile_begin()
-    t0 = time.perf_counter()
-    for _ in range(n):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / n * 1e3
-    return ops.profile_end(), ms
+    plan.ENABLED = False          # the per-op events live in the Python wrappers the recorded launch plans bypass: profile the eager path
+    try:
+        step()                    # (first eager pass after replays: allocator warm-up, not profiled)
+        torch.cuda.synchronize()
+        ops.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / n * 1e3
+        return ops.profile_end(), ms
+    finally:
+        plan.ENABLED = True
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline
@@ -383,6 +392,16 @@ def main():
     dt = dp.max_over_ranks(dt)
     loss = float(r["loss"])
     assert np.isfinite(loss), "non-finite loss in the timed region"
+    # host cost of ONE step with an empty queue (t_enq above includes back-pressure: once the host runs ahead, hipLaunchKernel
+    # blocks on the full queue and "enqueue time" just tracks the GPU)
+    host_one = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        step()
+        host_one.append(time.perf_counter() - h0)
+    torch.cuda.synchronize()
+    host_ms = sorted(host_one)[len(host_one) // 2] * 1e3
 
     rows_top, rows_all, prof_ms = [], [], None
     if args.profile_steps > 0:
@@ -397,7 +416,7 @@ def main():
         step_tflops = value * info["gflop_per_item"] / 1e3 / dp.world
         out = {
             "metric": info["metric"], "value": round(value, 3), "unit": info["unit"], "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "host_ms_per_step_empty_queue": round(host_ms, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6),
                        "arithmetic": "fp32 tensors, fp32 accumulation; the 32- to 128-channel 3x3x3 convolutions (forward / dgrad) take their fp32 operands as "
