@@ -46,16 +46,12 @@ __device__ __forceinline__ constexpr int b6_row(int i) {
 // epilogue shared by the bf16-pipe forward kernels: lane (li, lg) holds voxel b6_row(li) of each m-tile, channels lg*4 .. lg*4+3 of
 // each 16-channel n-tile (D = W^T-tile x X-tile), so a lane stores 16 bytes per (m-tile, n-tile)
 template <class TL, int TD, int TH, int TW, int NT>
-__device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
-                                            int n, int d0, int h0, int w0, int cout0, int accumulate, const StatsArg& st, double* Ss) {
+__device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[TL::MT][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
+                                              int n, int d0, int h0, int w0, int cout0, int accumulate, bool want_stats,
+                                              double (&s1)[NT][4], double (&s2)[NT][4]) {
   constexpr int MT = TL::MT, CT = NT * 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  double s1[NT][4], s2[NT][4];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
   const bool full = cout0 + CT <= cd.Cout && (cd.Cout & 3) == 0 && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
   const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
   float bv[NT][4];
@@ -100,10 +96,22 @@ __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __r
       }
     }
   };
-  if (!st.partial) {
+  if (!want_stats) {
     if (accumulate) rows(std::integral_constant<int, 0>{}, std::true_type{});
     else rows(std::integral_constant<int, 0>{}, std::false_type{});
   } else rows(std::integral_constant<int, 1>{}, std::false_type{});       // the statistics variant never accumulates (bcp_conv3_fwd_stats)
+}
+
+// one tile per workgroup (k_c3b): store + one statistics row per tile
+template <class TL, int TD, int TH, int TW, int NT>
+__device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
+                                            int n, int d0, int h0, int w0, int cout0, int accumulate, const StatsArg& st, double* Ss) {
+  double s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
+  b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st.partial != nullptr, s1, s2);
   if (st.partial) {
     const int gg = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
     BCP_LDS_BARRIER();                           // the scratch below aliases nothing, but waves may still be in the last stage
@@ -280,9 +288,9 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
 // waves run free and the matrix pipe always finds one with work; k_c3b synchronises its four waves after every tap pair (~0.35 us)
 // to hand the weight buffers over.  The pair loop is fully unrolled (compile-time tap offsets and register sets).
 // ------------------------------------------------------------------------------------------------
-template <int KD, int TD, int TH, int TW, int NT>
+template <int KD, int TD, int TH, int TW, int NT, bool PER>
 __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
-                                             float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
+                                             float* __restrict__ Y, ConvDims cd, int n_tiles, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, TP = (T + 1) / 2, TPE = (TP + 1) & ~1, CT = NT * 16;
   constexpr int XPLANE = TL::HV * XSB;
@@ -292,10 +300,8 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
   double* Ss = reinterpret_cast<double*>(Xb + 3 * XPLANE);         // [4][CT][2] statistics scratch
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  int n, d0, h0, w0;
-  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
   const int cout0 = blockIdx.y * CT;
 
   int voff[MT];
@@ -312,7 +318,32 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
 
   const int nchunks = cd.Cin16 >> 4;
   const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
+  const int nch = c_end - c_begin;
   Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
+
+  // PERSISTENT: this workgroup owns tiles blockIdx.x, blockIdx.x + gridDim.x, ...; work item `it` = (tile it / nch, chunk it % nch) of
+  // that list.  The halo of item it + 1 -- the NEXT TILE's first chunk after a tile's last -- travels under item it's tap pairs, so
+  // the fetch latency of a tile's first halo and the epilogue stores of the previous tile overlap with MFMAs (the 16-channel
+  // level has ONE chunk per tile: without this a workgroup's life is prologue + epilogue).
+  // (PER = false: one tile per workgroup -- the 32-channel-slab instances, whose persistent form needs 355 VGPRs and would drop to
+  //  one workgroup per CU: 102-109 vs 78-84 us)
+  const int my_tiles = !PER ? 1 : ((int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0);
+  const int n_items = my_tiles * nch;
+  if (n_items == 0) return;
+
+  // statistics: one row per (group, workgroup); rows this workgroup never reaches must read as zero
+  const bool want_stats = PER && st.partial != nullptr;
+  if (want_stats && (int)threadIdx.x < CT && cout0 + (int)threadIdx.x < cd.Cout) {
+    for (int g = 0; g < st.G; ++g) {
+      double* z = st.partial + (((long long)g * st.rows + blockIdx.x) * st.C + cout0 + threadIdx.x) * 2;
+      z[0] = 0.0; z[1] = 0.0;
+    }
+  }
+  double s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
 
   // lane (li, lg): output channel li of n-tile nt, k quarter lg of pre-split pack row [chunk][pair][piece][cout][32 k]
   const unsigned short* Wl = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16) + (long long)(cout0 + li) * 32 + lg * 8;
@@ -326,6 +357,13 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   };
   unsigned hvm = 0;
   float4 hpre[HF::NP];
+  auto hfetch_item = [&](int it) __attribute__((always_inline)) {      // (past the end: re-read the last item, no conditional load)
+    const int itc = it < n_items ? it : n_items - 1;
+    const int tl = blockIdx.x + (itc / nch) * gridDim.x;
+    int n, d0, h0, w0;
+    tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
+    hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, c_begin + itc % nch, hpre);
+  };
   auto hstash = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int u = 0; u < HF::NP; ++u)
@@ -336,25 +374,27 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   };
 
   bf16x8 B0[NT][3], B1[NT][3];
-  hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, c_begin, hpre);
+  hfetch_item(0);
   bload(c_begin, 0, B0);
   hstash();
   BCP_LDS_BARRIER();
-  constexpr int HPF = TPE >= 6 ? TPE - 4 : 0;        // pair in front of which the next chunk's halo is fetched
+  constexpr int HPF = TPE >= 6 ? TPE - 4 : 0;        // pair in front of which the next item's halo is fetched
+  int cur_g = want_stats ? (int)blockIdx.x / st.tiles_per_group : 0;
 #pragma unroll 1
-  for (int cc = c_begin; cc < c_end; ++cc) {
-    if (cc > c_begin) {
-      BCP_LDS_BARRIER();                             // every wave is done with the previous chunk's halo planes
+  for (int it = 0; it < n_items; ++it) {
+    if (it > 0) {
+      BCP_LDS_BARRIER();                             // every wave is done with the previous item's halo planes
       hstash();
       BCP_LDS_BARRIER();
     }
-    const int ccn = cc + 1 < c_end ? cc + 1 : cc;    // (past the end: re-read the last chunk, no conditional load)
+    const int cc = c_begin + it % nch;
+    const int ccn = c_begin + (it + 1 < n_items ? (it + 1) % nch : it % nch);
 #pragma unroll
     for (int tp = 0; tp < TPE; ++tp) {
-      // the next pair's weight fragments (next chunk's pair 0 after the last one) into the other register set
+      // the next pair's weight fragments (the next item's pair 0 after the last one) into the other register set
       if (tp & 1) { if (tp + 1 < TPE) bload(cc, tp + 1, B0); else bload(ccn, 0, B0); }
       else bload(cc, tp + 1, B1);
-      if (tp == HPF) hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, ccn, hpre);
+      if (tp == HPF) hfetch_item(it + 1);
       if (tp < TP) {
         const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
         const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
@@ -373,9 +413,31 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
 #undef BCP_B6
       }
     }
+    if (it % nch == nch - 1) {                       // the tile is complete: store it (uniform branch; stores only, no loads to wait for)
+      const int tl = blockIdx.x + (it / nch) * gridDim.x;
+      int n, d0, h0, w0;
+      tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
+      if (!PER) {
+        BCP_LDS_BARRIER();
+        b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss);      // one statistics row per tile
+        return;
+      }
+      if (want_stats && tl / st.tiles_per_group != cur_g) {
+        BCP_LDS_BARRIER();
+        stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+        cur_g = tl / st.tiles_per_group;
+      }
+      b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, want_stats, s1, s2);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
   }
-  BCP_LDS_BARRIER();
-  b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss);
+  if (want_stats) {
+    BCP_LDS_BARRIER();
+    stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_b6_sum_slabs(const float* __restrict__ part, int K, long long n, int Cout,
@@ -394,10 +456,10 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   constexpr int CT = NT * 16;
   // k_c3d only where a wave's weight traffic is small next to its MFMAs: 256-voxel tiles with a 32-channel slab (6 KB per 48 MFMAs;
   // the 64-voxel / 64-channel instances would pull 12 KB per 24 MFMAs through L1: 79-84 vs 47-51 us)
-  const bool direct = options().conv3_b6_direct != 0 && (options().conv3_b6_direct >= 2 || (TL::MT == 4 && NT == 2));
+  const bool direct = options().conv3_b6_direct != 0 && (options().conv3_b6_direct >= 2 || (TL::MT == 4 && NT <= 2));
   const size_t lds = (size_t)3 * TL::HV * XSB * 2 + (direct ? 0 : (size_t)2 * 3 * SP * CT * 32 * 2) + (size_t)4 * CT * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
-  auto kfn = direct ? k_c3d<KD, TD, TH, TW, NT> : k_c3b<KD, TD, TH, TW, NT, SP>;
+  auto kfn = k_c3b<KD, TD, TH, TW, NT, SP>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / CT;
   const int nch = cd.Cin16 / 16;
@@ -407,6 +469,30 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
   StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
   if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
+  if (direct) {
+    // persistent grid (16-channel slabs): tiles dealt round-robin to P workgroups (two per CU), balanced: every workgroup gets
+    // cdiv(tiles, slots) tiles; 32-channel slabs: one tile per workgroup (register budget, see k_c3d)
+    constexpr bool PER = NT == 1;
+    const int slots = 512 / (gy * sk) > 0 ? 512 / (gy * sk) : 1;
+    const int per = PER ? cdiv(gx, slots) : 1;
+    int P = cdiv(gx, per);
+    if (PER && options().conv3_p > 0 && options().conv3_p < P) P = options().conv3_p;      // tests: few workgroups, many tiles each
+    StatsArg sd{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
+    if (sk == 1 && G > 0 && gx % G == 0) { sd.rows = PER ? P : gx / G; sd.tiles_per_group = gx / G; sd.partial = stat_partial; }
+    if (dry) return (sk == 1 && G > 0 && gx % G == 0) ? (PER ? P : gx / G) : 0;
+    auto kd = k_c3d<KD, TD, TH, TW, NT, PER>;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (sk == 1) {
+      hipLaunchKernelGGL(kd, dim3(P, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, gx, accumulate, sd);
+    } else {
+      const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
+      StatsArg none{nullptr, 0, 1, cd.Cout, 1};
+      hipLaunchKernelGGL(kd, dim3(P, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, gx, 0, none);
+      hipLaunchKernelGGL(k_b6_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y,
+                         accumulate);
+    }
+    return sd.partial ? sd.rows : 0;
+  }
   if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
   if (sk == 1) {
     hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);

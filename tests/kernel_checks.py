@@ -543,11 +543,14 @@ def check_conv3_b6(ops, dev):
                 check_conv3(ops, dev, cases=[CONV3_B6_CASES[2]])
             finally:
                 ops.set_option("splitk")
-        ops.set_option("conv3_b6_direct", 1)        # k_c3d: weight fragments straight from the pre-split pack, no stage barriers
-        try:
-            check_conv3(ops, dev, cases=CONV3_B6_CASES)
-        finally:
-            ops.set_option("conv3_b6_direct")
+        for direct, P in ((2, None), (2, 2), (0, None)):      # k_c3d everywhere (persistent; P = 2: many tiles per workgroup) / k_c3b everywhere
+            ops.set_option("conv3_b6_direct", direct)
+            if P:
+                ops.set_option("conv3_p", P)
+            try:
+                check_conv3(ops, dev, cases=CONV3_B6_CASES)
+            finally:
+                ops.set_option("conv3_b6_direct"); ops.set_option("conv3_p")
     finally:
         ops.set_option("conv3_b6")
         ops.set_option("wgrad_b6")
@@ -560,12 +563,21 @@ def check_conv3_b6(ops, dev):
         conv = F.conv2d if two_d else F.conv3d
         y64 = conv(x.double(), w.double(), b.double(), padding=1)
         wf, _ = ops.conv3_pack(w.to(dev).contiguous(), KD)
-        ops.set_option("conv3_b6", 2)
-        ops.set_option("splitk", 1)
-        try:
-            y, part, rows = ops.conv3_fwd_stats(to_cl(x).to(dev), wf, b.to(dev), Cout, KD, G)
-        finally:
-            ops.set_option("conv3_b6"); ops.set_option("splitk")
+        for P in (None, 3):          # 3: the persistent kernel walks several tiles per workgroup and crosses statistics groups
+          ops.set_option("conv3_b6", 2)
+          ops.set_option("splitk", 1)
+          if P:
+              ops.set_option("conv3_p", P)
+          try:
+              y, part, rows = ops.conv3_fwd_stats(to_cl(x).to(dev), wf, b.to(dev), Cout, KD, G)
+          finally:
+              ops.set_option("conv3_b6"); ops.set_option("splitk"); ops.set_option("conv3_p")
+          assert rows > 0
+          close(from_cl(y, two_d), y64, msg="b6 conv3_fwd_stats y")
+          pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
+          yg = y64.transpose(0, 1).reshape(Cout, G, -1)
+          close(pt[..., 0], yg.sum(2).t(), rtol=1e-5, msg="b6 fused sum")
+          close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-5, msg="b6 fused sum of squares")
         assert rows > 0
         pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
         yg = y64.transpose(0, 1).reshape(Cout, G, -1)
