@@ -29,6 +29,17 @@ def pytest_configure(config):
     torch.set_num_threads(_usable_cores())
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running CPU test")
+    config.addinivalue_line("markers", "extended: simulator twin of a test the GPU suite always runs; skipped in the default CPU run to keep it "
+                                       "to a few minutes (BCP_EXTENDED=1 runs them)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if os.environ.get("BCP_EXTENDED") == "1":
+        return
+    skip = pytest.mark.skip(reason="simulator twin of a GPU-suite test (BCP_EXTENDED=1 to run)")
+    for it in items:
+        if "extended" in it.keywords:
+            it.add_marker(skip)
 
 
 @pytest.fixture(scope="session")

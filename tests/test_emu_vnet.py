@@ -1,5 +1,6 @@
 """Whole-network parity on the host simulator (CPU): the HIP-scheduled V-Net forward + hand-scheduled backward
 and the LA self-training step against the oracle / the reference's golden vectors."""
+import pytest
 import torch
 
 import net_checks as NC
@@ -20,10 +21,12 @@ def test_vnet_pancreas_smooth(emu_ops):
     NC.check_vnet_smooth(emu_ops, CPU, shape=(32, 32, 32), variant="pancreas")
 
 
+@pytest.mark.extended
 def test_la_self_train_trajectory(emu_ops, golden_dir):
     NC.check_la_step(emu_ops, CPU, golden_dir)
 
 
+@pytest.mark.extended
 def test_grouped_forward_equals_separate_calls(emu_ops):
     NC.check_grouped_equals_separate(emu_ops, CPU)
 
@@ -32,6 +35,7 @@ def test_sliding_window_validation(emu_ops, golden_dir):
     NC.check_sliding_window(emu_ops, CPU, golden_dir)
 
 
+@pytest.mark.extended
 def test_sliding_window_validation_pancreas(emu_ops, golden_dir):
     NC.check_sliding_window_pancreas(emu_ops, CPU, golden_dir)
 
@@ -40,6 +44,7 @@ def test_pre_train_steps(emu_ops):
     NC.check_pre_train_steps(emu_ops, CPU)
 
 
+@pytest.mark.extended
 def test_la_step_reference_default_batch(emu_ops):
     NC.check_la_step_batch8(emu_ops, CPU)
 
@@ -80,4 +85,4 @@ def test_la_loop_body_as_the_reference_writes_it(emu_ops, golden_dir):
 def test_recorded_launch_plans_equal_eager_path(emu_ops):
     from bcp_amd.utils import BCP_utils as BU
     BU.set_test_ops(emu_ops)
-    NC.check_launch_plans(emu_ops, CPU, steps=2, cases=(("la", True), ("la", False)))      # (all four workloads: the GPU suite)
+    NC.check_launch_plans(emu_ops, CPU, steps=2, cases=(("la", False),))      # unfused: plan + busy-plan fallback (all four workloads: the GPU suite)
