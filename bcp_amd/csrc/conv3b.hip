@@ -349,6 +349,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   const unsigned short* Wl = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16) + (long long)(cout0 + li) * 32 + lg * 8;
   const long long piece_stride = (long long)cd.Cout16 * 32;
   auto bload = [&](int cc, int tp, bf16x8 (&b)[NT][3]) __attribute__((always_inline)) {
+    if (B6_ABLATE & 4) return;
     const unsigned short* p = Wl + ((long long)cc * TP + (tp < TP ? tp : TP - 1)) * 3 * piece_stride;
 #pragma unroll
     for (int s = 0; s < 3; ++s)
@@ -358,6 +359,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   unsigned hvm = 0;
   float4 hpre[HF::NP];
   auto hfetch_item = [&](int it) __attribute__((always_inline)) {      // (past the end: re-read the last item, no conditional load)
+    if (B6_ABLATE & 2) return;
     const int itc = it < n_items ? it : n_items - 1;
     const int tl = blockIdx.x + (itc / nch) * gridDim.x;
     int n, d0, h0, w0;
@@ -365,6 +367,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
     hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, c_begin + itc % nch, hpre);
   };
   auto hstash = [&]() __attribute__((always_inline)) {
+    if (B6_ABLATE & 2) return;
 #pragma unroll
     for (int u = 0; u < HF::NP; ++u)
       if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
@@ -374,6 +377,12 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   };
 
   bf16x8 B0[NT][3], B1[NT][3];
+  if (B6_ABLATE & 4) {
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) { B0[nt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * 64 + nt * 8 + lane); B1[nt][s] = B0[nt][s]; }
+  }
   hfetch_item(0);
   bload(c_begin, 0, B0);
   hstash();
@@ -395,7 +404,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
       if (tp & 1) { if (tp + 1 < TPE) bload(cc, tp + 1, B0); else bload(ccn, 0, B0); }
       else bload(cc, tp + 1, B1);
       if (tp == HPF) hfetch_item(it + 1);
-      if (tp < TP) {
+      if (tp < TP && !(B6_ABLATE & 8)) {
         const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
         const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
         const int toff = ((lg >> 1) ? tB : tA) * XSB;
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
+          for (int mt = 0; mt < MT; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toff));
         // an odd tap count: the second half of the last pair multiplies tap T-1's voxels by the pack's zero weights
 #define BCP_B6(BS, I, J)                                                                                        \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)            \
