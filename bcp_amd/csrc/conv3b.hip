@@ -449,6 +449,202 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// FLAT variant for the deep levels (14x14x10, 7x7x5, 12^3, 6^3 ...): the M dimension is BM = 64 CONSECUTIVE voxels of one sample
+// (flat index over D*H*W) instead of a brick, so nothing is lost to tile padding (2x8x4 bricks waste 37 % of 14x14x10 and 109 % of
+// 7x7x5).  The halo is the flat voxel range [m0 - R, m0 + BM + R), R = H*W + W + 1 (one row of 32 bytes per voxel and piece, as in
+// k_c3b); a tap is a row offset kd*H*W + kh*W + kw.  Neighbours that wrap around a row / plane end -- or leave the volume -- are
+// not zero in a flat range: each lane carries the 27 validity bits of ITS voxel and clears the A fragment of an invalid (voxel,
+// tap) with v_cndmask (12 per fragment triple: bf16 MFMAs leave the issue slots for that; on the fp32 pipe the same masks cost more
+// than the padding they saved).  Everything else is k_c3b: weight stages of SP tap pairs in LDS, the stage pipeline, split-K.
+// ------------------------------------------------------------------------------------------------
+template <int KD, int NT, int SP, int AVMAX>
+__global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
+                                             float* __restrict__ Y, ConvDims cd, int tiles_per_sample, int accumulate, StatsArg st) {
+  constexpr int BM = 64, T = KD * 9, TP = (T + 1) / 2, CT = NT * 16, PD = KD == 3 ? 1 : 0;
+  constexpr int S = ((TP + SP - 1) / SP + 1) & ~1;
+  static_assert(S >= 4, "the stage pipeline needs four weight stages per chunk");
+  constexpr int XPLANE = AVMAX * XSB;
+  constexpr int WPLANE = SP * CT * 32;
+  constexpr int WSTAGE = 3 * WPLANE;
+  constexpr int NW4 = (SP * 12 * CT + 255) / 256;
+  constexpr int NP = (AVMAX * 4 + 255) / 256;                  // halo float4 per thread (row, 4-channel part)
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][AVMAX][XSB]
+  unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][SP][CT][32]
+  double* Ss = reinterpret_cast<double*>(Wb + 2 * WSTAGE);         // [4][CT][2] statistics scratch
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
+  const int R = PD * HW + cd.W + 1, AV = BM + 2 * R;               // AV <= AVMAX (checked by the launcher)
+  const int n = blockIdx.x / tiles_per_sample, m0 = (blockIdx.x % tiles_per_sample) * BM;
+  const int cout0 = blockIdx.y * CT;
+
+  // this lane's voxel (one m-tile per wave), its halo row and the validity bits of its 27 neighbours
+  const int ml = wave * 16 + li, mv = m0 + ml;
+  const int vrow = (ml + R) * XSB + (lg & 1) * 8;
+  unsigned vbits = 0;
+  {
+    const int w = mv % cd.W, h = (mv / cd.W) % cd.H, d = mv / HW;
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const int kw = t % 3, kh = (t / 3) % 3, kd = t / 9;
+      const bool ok = (unsigned)(w + kw - 1) < (unsigned)cd.W && (unsigned)(h + kh - 1) < (unsigned)cd.H && (unsigned)(d + kd - PD) < (unsigned)cd.D;
+      vbits |= (ok ? 1u : 0u) << t;
+    }
+    if (mv >= V) vbits = 0;
+  }
+  const int woff = li * 32 + ((lg ^ ((li & 8) ? 2 : 0)) * 8);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = cd.Cin16 >> 4;
+  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
+  Y += (long long)blockIdx.z * cd.N * V * cd.Cout;
+
+  const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  auto wfetch = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) {
+      const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
+      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
+      const int tp = sg * SP + pr < TP ? sg * SP + pr : TP - 1;
+      wpre[u] = *reinterpret_cast<const float4*>(Wb16 + ((((long long)cc * TP + tp) * 3 + sp) * cd.Cout16 + cout0 + co) * 32 + kq * 8);
+    }
+  };
+  auto wstash = [&](unsigned short* Wbuf, int sg, const float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
+      const float4 v = (sg * SP + pr < TP) ? wpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < SP * 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
+    }
+  };
+  // halo: row r of the flat range = voxel m0 - R + r of sample n (zero outside [0, V) and beyond Cin); branch-free loads
+  unsigned hvm = 0;
+  const long long xbase = (long long)n * V * cd.Cin;
+  auto hfetch = [&](int cc, float4 (&pre)[NP]) __attribute__((always_inline)) {
+    hvm = 0;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int q = threadIdx.x + u * 256, r = q >> 2, part = q & 3;
+      const int gm = m0 - R + r;
+      const unsigned ok = (r < AV && (unsigned)gm < (unsigned)V && cc * 16 + part * 4 < cd.Cin) ? 1u : 0u;
+      const unsigned off = ok ? (unsigned)(xbase + (long long)gm * cd.Cin + cc * 16 + part * 4) : 0u;
+      pre[u] = ld4(X + off);
+      hvm |= ok << u;
+    }
+  };
+  auto hstash = [&](const float4 (&pre)[NP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int q = threadIdx.x + u * 256, r = q >> 2, part = q & 3;
+      if (r < AV) {
+        const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_store4(v, Xb + r * XSB + part * 4, XPLANE);
+      }
+    }
+  };
+  auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+    if (sg >= S) { sg -= S; ++cc; }
+    if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
+    wfetch(cc, sg, wpre);
+  };
+  constexpr int HPF = S - 4;
+  float4 hpre[NP], W0[NW4], W1[NW4];
+  hfetch(c_begin, hpre);
+  wfetch_at(c_begin, 0, W0);
+  wfetch_at(c_begin, 1, W1);
+  hstash(hpre);
+  wstash(Wb, 0, W0);
+  wfetch_at(c_begin, 2, W0);
+  BCP_LDS_BARRIER();
+
+  auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
+    const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
+#pragma unroll
+    for (int pr = 0; pr < SP; ++pr) {
+      const int tp = sg * SP + pr;
+      if (tp < TP) {     // uniform
+        const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
+        const int oA = ((t0 / 9) - PD) * HW + ((t0 / 3) % 3 - 1) * cd.W + (t0 % 3 - 1);      // wave-uniform row offsets of the two taps
+        const int oB = ((t1 / 9) - PD) * HW + ((t1 / 3) % 3 - 1) * cd.W + (t1 % 3 - 1);
+        const int toff = ((lg >> 1) ? oB : oA) * XSB;
+        const bool ok = (((lg >> 1) ? (vbits >> t1) : (vbits >> t0)) & 1u) != 0;
+        bf16x8 a[3], b[NT][3];
+        const bf16x8 zero = __builtin_bit_cast(bf16x8, make_float4(0.f, 0.f, 0.f, 0.f));
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + vrow + toff);
+          a[s] = ok ? v : zero;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + (pr * CT + nt * 16) * 32 + woff);
+        }
+#define BCP_B6(I, J)                                                                                            \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                              \
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][J], a[I], acc[nt], 0, 0, 0);
+        BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
+#undef BCP_B6
+      }
+    }
+    if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
+    wfetch_at(cc, sg + 3, Wn);
+    if (sg + 1 < S) BCP_LDS_BARRIER();
+  };
+#pragma unroll 1
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    if (cc > c_begin) {
+      BCP_LDS_BARRIER();
+      hstash(hpre);
+      BCP_LDS_BARRIER();
+    }
+#pragma unroll 1
+    for (int sg = 0; sg < HPF; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+    hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);
+#pragma unroll 1
+    for (int sg = HPF; sg < S; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+  }
+
+  // epilogue: lane (li, lg) holds voxel m0 + wave*16 + li, channels lg*4 .. lg*4+3 of each n-tile: 16-byte stores into flat rows
+  double s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
+  const bool vec = cout0 + CT <= cd.Cout && (cd.Cout & 3) == 0;     // uniform
+  const bool want_stats = st.partial != nullptr;
+  if (mv < V) {
+    float* yrow = Y + ((long long)n * V + mv) * cd.Cout + cout0 + lg * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cout0 + nt * 16 + lg * 4 + r;
+        float v = acc[nt][r] + ((bias && co < cd.Cout) ? bias[co] : 0.f);
+        if (accumulate && co < cd.Cout) v += yrow[nt * 16 + r];
+        acc[nt][r] = v;
+        if (want_stats && co < cd.Cout) { s1[nt][r] += (double)v; s2[nt][r] += (double)v * (double)v; }
+      }
+      if (vec) st4(yrow + nt * 16, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (cout0 + nt * 16 + lg * 4 + r < cd.Cout) yrow[nt * 16 + r] = acc[nt][r];
+      }
+    }
+  }
+  if (want_stats) {
+    const int gg = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
+    BCP_LDS_BARRIER();
+    stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_b6_sum_slabs(const float* __restrict__ part, int K, long long n, int Cout,
                                                       const float* __restrict__ bias, float* __restrict__ y, int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -515,6 +711,38 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   return st.partial ? st.rows : 0;
 }
 
+static constexpr int kB6FlatAvMax = 384;    // flat halo rows (BM + 2 R) the flat instances hold: 3 x 384 x 32 B = 36 KB
+
+template <int KD, int NT, int SP>
+static int b6_launch_flat(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
+                          double* stat_partial, int G, bool dry, hipStream_t s) {
+  constexpr int CT = NT * 16, BM = 64;
+  const int V = cd.D * cd.H * cd.W, tps = cdiv(V, BM);
+  const size_t lds = (size_t)3 * kB6FlatAvMax * XSB * 2 + (size_t)2 * 3 * SP * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
+  auto kfn = k_c3f<KD, NT, SP, kB6FlatAvMax>;
+  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const int gx = cd.N * tps, gy = cd.Cout16 / CT;
+  const int nch = cd.Cin16 / 16;
+  int sk = 1;
+  const bool ws_fits = ws && (long long)cd.N * V * cd.Cout <= (1LL << 20);
+  if (ws_fits && (long long)gx * gy <= 256 && nch >= 4) { sk = nch / 2; if (sk > 4) sk = 4; }
+  { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
+  StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
+  const bool stats_ok = sk == 1 && G > 0 && cd.N % G == 0;        // tiles are sample-major and never straddle samples
+  if (stats_ok) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
+  if (dry) return stats_ok ? gx / G : 0;
+  if (sk == 1) {
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, tps, accumulate, st);
+  } else {
+    const long long n = (long long)cd.N * V * cd.Cout;
+    StatsArg none{nullptr, 0, 1, cd.Cout, 1};
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, tps, 0, none);
+    hipLaunchKernelGGL(k_b6_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y,
+                       accumulate);
+  }
+  return st.partial ? st.rows : 0;
+}
+
 // Forward / dgrad on the bf16 pipe where option conv3_b6 allows it.  Returns the statistics rows (as conv3_fwd_impl does);
 // *handled = false leaves the shape to the fp32 kernels.
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
@@ -544,6 +772,12 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
           else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
           else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
           else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        } else if (o.conv3_b6_flat && 64 + 2 * (cd.H * cd.W + cd.W + 1) <= kB6FlatAvMax) {
+          // flat 64-voxel tiles; narrower slabs for the smallest volumes (7x7x5: 8 tiles) so that the grid still covers the CUs
+          const int nt = o.conv3_b6_flat >= 2 ? (o.conv3_b6_flat == 2 ? 2 : 1) : (vox >= 2048 ? 4 : 2);
+          if (nt == 4) rows = b6_launch_flat<3, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else if (nt == 2) rows = b6_launch_flat<3, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          else rows = b6_launch_flat<3, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
         } else {
           if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
           else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);

@@ -543,6 +543,18 @@ def check_conv3_b6(ops, dev):
                 check_conv3(ops, dev, cases=[CONV3_B6_CASES[2]])
             finally:
                 ops.set_option("splitk")
+        ops.set_option("conv3_b6_flat", 1)          # k_c3f: flat 64-voxel tiles + per-lane validity masks (deep levels, 64-channel slabs)
+        try:
+            check_conv3(ops, dev, cases=((2, 64, 64, (4, 8, 12), 3), (1, 32, 128, (6, 9, 5), 3), (1, 64, 64, (7, 7, 5), 3), (2, 32, 64, (5, 6, 7), 3),
+                                         (3, 64, 64, (3, 3, 3), 3)))
+            for sk in (2, 4):
+                ops.set_option("splitk", sk)
+                try:
+                    check_conv3(ops, dev, cases=((2, 64, 64, (7, 7, 5), 3),))
+                finally:
+                    ops.set_option("splitk")
+        finally:
+            ops.set_option("conv3_b6_flat")
         for direct, P in ((2, None), (2, 2), (0, None)):      # k_c3d everywhere (persistent; P = 2: many tiles per workgroup) / k_c3b everywhere
             ops.set_option("conv3_b6_direct", direct)
             if P:
@@ -563,15 +575,19 @@ def check_conv3_b6(ops, dev):
         conv = F.conv2d if two_d else F.conv3d
         y64 = conv(x.double(), w.double(), b.double(), padding=1)
         wf, _ = ops.conv3_pack(w.to(dev).contiguous(), KD)
-        for P in (None, 3):          # 3: the persistent kernel walks several tiles per workgroup and crosses statistics groups
+        for P in (None, 3, "flat"):  # 3: the persistent kernel walks several tiles per workgroup and crosses statistics groups; flat: k_c3f
+          if P == "flat" and (KD != 3 or Cout % 64):
+              continue
           ops.set_option("conv3_b6", 2)
           ops.set_option("splitk", 1)
-          if P:
+          if P == "flat":
+              ops.set_option("conv3_b6_flat", 1)
+          elif P:
               ops.set_option("conv3_p", P)
           try:
               y, part, rows = ops.conv3_fwd_stats(to_cl(x).to(dev), wf, b.to(dev), Cout, KD, G)
           finally:
-              ops.set_option("conv3_b6"); ops.set_option("splitk"); ops.set_option("conv3_p")
+              ops.set_option("conv3_b6"); ops.set_option("splitk"); ops.set_option("conv3_p"); ops.set_option("conv3_b6_flat")
           assert rows > 0
           close(from_cl(y, two_d), y64, msg="b6 conv3_fwd_stats y")
           pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
