@@ -46,8 +46,6 @@ struct Options {
   long long wgrad_tile[5] = {0, 0, 0, 0, 1LL << 60};   // TD, TH, TW, min voxels, max voxels
   int tn_groups = 0;        // k2s2 / 1x1 weight-gradient GEMM: cap on voxel groups (tests: force multi-chunk groups)
   int cc_tile = 0;          // largest-CC tile flavour
-  int conv3_p8 = 1;         // persistent 8-wave pipeline conv: 0 off, 1 where it is the measured winner, 2 wherever it is valid
-  int conv3_p8_cfgs = 3;    // automatic choice: bit 0 = BN 32 bricks, bit 1 = BN 64 bricks, bit 2 = flat tiles.  Measured in the LA step (interleaved A/B, ms per step): none 9.03, flat only 9.19, BN 64 only 8.90, BN 32 only 8.99 -- the flat kernel is 18 % faster ALONE at the 128-channel level but its one-workgroup-per-CU grid keeps the other stream's kernels off the CUs
   int conv3_b6 = 1;         // fp32 conv on the bf16 matrix pipe (three-piece operands, conv3b.hip): 0 off, 1 where measured faster, 2 wherever valid
   int conv3_b6_levels = 15;  // automatic choice (conv3_b6 = 1): bit 0 = 32-channel slabs (256-voxel tiles), bit 1 = 64-channel slabs, bit 2 = the 16 -> 16 layers (persistent k_c3d with cross-tile halo prefetch: 176 vs 243-258 us alone, step 7.00 vs 7.18 ms; one tile per workgroup it was 209-228 us and no step gain), bit 3 = the 2-D instances (ACDC step 5.18 -> 4.24 ms together with the weight gradients).  LA step, interleaved A/B (ms per step): off 8.87, 32-channel level 8.32, + 64-channel level 8.05 -- the latter although ALONE that kernel is slower than the exclusive pipeline kernel it replaces (66-71 vs 61 us): two workgroups per CU leave room for the other stream
   int conv3_b6_minvox = 256;     // automatic choice: smallest launch (voxels, batch included) that goes to the bf16-pipe kernels
@@ -57,7 +55,6 @@ struct Options {
   int wgrad_b6 = 1;         // weight gradient on the bf16 matrix pipe (conv3bw.hip): 0 off, 1 where measured faster, 2 wherever valid.  LA step (interleaved A/B): off 7.82 ms, 32/64-channel levels 7.52, + 128-channel level 7.38
   int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
-  int wgrad_p8 = 1;         // same for the weight-gradient kernels
 };
 Options& options();
 

@@ -1118,12 +1118,6 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16, bool for_w
   return c;
 }
 
-// the persistent 8-wave pipeline kernels (conv3p.hip)
-int p8_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
-           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled);
-int p8_wgrad(const float* x, const float* dy, float* dw, const ConvDims& cd, int KD, int accumulate, void* workspace, hipStream_t s,
-             bool* handled);
-size_t p8_wgrad_workspace_bytes(const ConvDims& cd, int KD);
 // conv3b.hip / conv3bw.hip: fp32 numerics on the bf16 matrix pipe (three-piece operands)
 int b6_wgrad(const float* x, const float* dy, float* partial, const ConvDims& cd, int KD, hipStream_t s);
 size_t b6_wgrad_workspace_bytes(const ConvDims& cd, int KD);
@@ -1229,8 +1223,6 @@ static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, fl
   int rows = 0;
   Cfg r;
   rows = b6_fwd(x, wp, bias, y, cd, KD, accumulate, workspace, stat_partial, G, dry, (hipStream_t)stream, &done);
-  if (done) return rows;
-  rows = p8_fwd(x, wp, bias, y, cd, KD, accumulate, workspace, stat_partial, G, dry, (hipStream_t)stream, &done);
   if (done) return rows;
   if (choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
     BCP_RES_CASE(3, 4, 4, 16, 1) BCP_RES_CASE(3, 4, 4, 16, 2)
@@ -1358,8 +1350,8 @@ extern "C" size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, in
   fill_dims(cd, N, D, H, W, Cin, Cout);
   const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, Co16);
   const int g = wgrad_groups(c, N, D, H, W, Ci16, Co16);
-  const size_t a = (size_t)g * KD * 9 * Ci16 * Co16 * sizeof(float), b = p8_wgrad_workspace_bytes(cd, KD), c6 = b6_wgrad_workspace_bytes(cd, KD);
-  return a > b ? (a > c6 ? a : c6) : (b > c6 ? b : c6);
+  const size_t a = (size_t)g * KD * 9 * Ci16 * Co16 * sizeof(float), c6 = b6_wgrad_workspace_bytes(cd, KD);
+  return a > c6 ? a : c6;
 }
 
 #define BCP_WG_CASE(KD_, TD_, TH_, TW_, NT_)                                                     \
@@ -1376,14 +1368,6 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
   bool done = false;
-  {
-    const int rc = p8_wgrad(x, dy, dw, cd, KD, accumulate, workspace, (hipStream_t)stream, &done);
-    if (done) {
-      if (rc < 0) return rc;
-      BCP_CHECK_LAUNCH("bcp_conv3_wgrad");
-      return BCP_OK;
-    }
-  }
   const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, cd.Cout16);
   const int groups = wgrad_groups(c, N, D, H, W, cd.Cin16, cd.Cout16);
   float* ws = reinterpret_cast<float*>(workspace);

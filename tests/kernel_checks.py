@@ -484,7 +484,8 @@ def check_k2_chunks(ops, dev):
 
 def check_conv3_res(ops, dev):
     """resident-weight kernel, with the persistent grid forced small so every block walks several tiles"""
-    ops.set_option("conv3_p8", 0)      # the 4-wave kernels of conv3.hip (the pipeline kernels have their own checks)
+    ops.set_option("conv3_b6", 0)      # the fp32-MFMA kernels of conv3.hip (the bf16-pipe kernels have their own checks)
+    ops.set_option("wgrad_b6", 0)
     try:
         for P in (7, 16):      # 16: a multiple of 8 takes the XCD-aware tile order
             ops.set_option("conv3_p", P)
@@ -494,26 +495,8 @@ def check_conv3_res(ops, dev):
                 ops.set_option("conv3_p")
         check_conv3(ops, dev, cases=CONV3_RES_CASES[:2])
     finally:
-        ops.set_option("conv3_p8")
-
-
-CONV3_P8_CASES = (
-    # (N, Cin, Cout, spatial, KD): every pipeline configuration, full and partial bricks, sample-straddling items
-    (2, 16, 16, (8, 12, 16), 3),      # BN 16: resident single stage, 4-brick items
-    (1, 16, 16, (6, 7, 9), 3),        # partial bricks
-    (2, 32, 32, (8, 8, 12), 3),       # BN 32: 2 chunks x 3 stages
-    (1, 16, 32, (5, 8, 8), 3),
-    (2, 64, 64, (4, 8, 12), 3),       # BN 64: 4 chunks, 2-brick items
-    (1, 32, 128, (4, 4, 12), 3),      # two 64-channel slabs
-    (3, 64, 64, (4, 4, 4), 3),        # odd brick count: the last item is half empty
-)
-CONV3_P8_FLAT_CASES = (
-    (2, 128, 128, (5, 6, 7), 3),      # flat M tiles (BM 64 x BN 32), split-K
-    (2, 64, 32, (7, 7, 5), 3),
-    (1, 32, 64, (3, 14, 10), 3),
-    (2, 16, 32, (1, 9, 20), 1),       # 2-D
-    (1, 48, 96, (2, 4, 30), 3),       # 3 cin chunks, 3 slabs
-)
+        ops.set_option("conv3_b6")
+        ops.set_option("wgrad_b6")
 
 
 CONV3_B6_CASES = (
@@ -599,63 +582,16 @@ def check_conv3_b6(ops, dev):
         yg = y64.transpose(0, 1).reshape(Cout, G, -1)
         close(pt[..., 0], yg.sum(2).t(), rtol=1e-5, msg="b6 fused sum")
         close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-5, msg="b6 fused sum of squares")
-        ops.set_option("conv3_p8", 0)
+        ops.set_option("conv3_b6", 0)          # the fp32-MFMA kernel on the same data
         try:
             y32 = ops.conv3_fwd(to_cl(x).to(dev), wf, b.to(dev), Cout, KD)
         finally:
-            ops.set_option("conv3_p8")
+            ops.set_option("conv3_b6")
         e6 = float((from_cl(y, two_d).double().cpu() - y64).abs().max())
         e32 = float((from_cl(y32, two_d).double().cpu() - y64).abs().max())
         scale = float(y64.abs().max())
         assert e6 <= 3.0 * e32 + 1e-7 * scale, f"b6 error vs fp64 {e6:.3e} (fp32-MFMA kernel: {e32:.3e}, output scale {scale:.3e})"
-        assert not torch.equal(y.cpu(), y32.cpu()) or True
-
-
-def check_conv3_p8(ops, dev):
-    """persistent 8-wave pipeline kernels (conv3p.hip), forced on for small shapes: conv3_p8 = 2 prefers the BRICK
-    configurations, 3 the FLAT one; small persistent grids so that every workgroup walks several items"""
-    for mode, cases in ((2, CONV3_P8_CASES), (3, CONV3_P8_FLAT_CASES), (3, CONV3_P8_CASES[2:5])):
-        ops.set_option("conv3_p8", mode)
-        try:
-            for P in (None, 2, 8):
-                if P:
-                    ops.set_option("conv3_p", P)
-                try:
-                    check_conv3(ops, dev, cases=cases)
-                finally:
-                    ops.set_option("conv3_p")
-            for sk in (1, 2):
-                ops.set_option("splitk", sk)
-                try:
-                    check_conv3(ops, dev, cases=[c for c in cases if c[1] >= 32][:2])
-                finally:
-                    ops.set_option("splitk")
-        finally:
-            ops.set_option("conv3_p8")
-    # fused statistics through the pipeline kernels
-    rng = np.random.default_rng(33)
-    for mode, (N, Cin, Cout, sp, KD, G, P) in ((2, (2, 16, 16, (8, 8, 12), 3, 2, 2)), (2, (4, 32, 32, (4, 8, 12), 3, 2, 3)), (2, (3, 64, 64, (4, 4, 8), 3, 3, None)),
-                                            (3, (4, 64, 32, (3, 5, 7), 3, 2, 2)), (3, (2, 32, 64, (1, 10, 12), 1, 1, None))):
-        two_d = KD == 1
-        x = R(rng, N, Cin, *(sp[1:] if two_d else sp))
-        w = R(rng, Cout, Cin, *((3, 3) if two_d else (3, 3, 3))) * 0.1
-        b = R(rng, Cout) * 0.1
-        y_ref = F.conv2d(x, w, b, padding=1) if two_d else F.conv3d(x, w, b, padding=1)
-        wf, _ = ops.conv3_pack(w.to(dev).contiguous(), KD)
-        ops.set_option("conv3_p8", mode)
-        ops.set_option("splitk", 1)
-        if P:
-            ops.set_option("conv3_p", P)
-        try:
-            y, part, rows = ops.conv3_fwd_stats(to_cl(x).to(dev), wf, b.to(dev), Cout, KD, G)
-        finally:
-            ops.set_option("conv3_p"); ops.set_option("conv3_p8"); ops.set_option("splitk")
-        close(from_cl(y, two_d), y_ref, msg="p8 conv3_fwd_stats y")
-        assert rows > 0, "the pipeline kernels fuse the statistics when they do not split K"
-        pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
-        yg = y_ref.double().transpose(0, 1).reshape(Cout, G, -1)
-        close(pt[..., 0], yg.sum(2).t(), rtol=1e-6, msg="p8 fused sum")
-        close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-6, msg="p8 fused sum of squares")
+        assert not torch.equal(y.cpu(), y32.cpu()), "the comparison kernel must be the fp32-MFMA one, not the bf16-pipe kernel again"
 
 
 def check_conv3_stats(ops, dev):
@@ -777,4 +713,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_p8", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")

@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=2)
     ap.add_argument("--json", default=os.path.join(ROOT, "gpurun_out", "bench_conv.json"))
-    ap.add_argument("--variants", default="old:conv3_p8=0,wgrad_p8=0;new:conv3_p8=1,wgrad_p8=1")
+    ap.add_argument("--variants", default="fp32:conv3_b6=0,wgrad_b6=0;bf16pipe:conv3_b6=1,wgrad_b6=1")
     ap.add_argument("--ops", default="fwd_stats,dgrad,wgrad")
     ap.add_argument("--levels", default="16,32,64,128,256")
     ap.add_argument("--lib", default="", help="library variant to load instead of the product libbcp_hip.so (measurements)")
