@@ -2,6 +2,7 @@
 import json
 import os
 
+import pytest
 import torch
 
 import net_checks as NC
@@ -67,6 +68,7 @@ def test_update_model_ema_state_dict_semantics(emu_ops):
             assert torch.equal(sd[k], Pt[k]), k       # one multiply-add per element in fp32 on both sides: bit-exact
 
 
+@pytest.mark.extended
 def test_acdc_five_step_trajectory(emu_ops, golden_dir):
     NC.check_acdc_traj5(emu_ops, CPU, golden_dir)
 

@@ -66,6 +66,7 @@ def test_dropout_streams_are_per_network():
     NC.check_dropout_streams(CPU)
 
 
+@pytest.mark.extended
 def test_la_five_step_trajectory(emu_ops, golden_dir):
     NC.check_la_traj5(emu_ops, CPU, golden_dir)
 
