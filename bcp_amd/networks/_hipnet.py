@@ -503,11 +503,12 @@ class HipNet(nn.Module):
             for _ in range(pl.ticks):
                 self._nbt_tick()
         out, saved = pl.result
+        # the logits leave the plan as a COPY (16 MB at the LA size): callers may hold them across the next replay (logging, the
+        # reference's unfused loop), and a replay overwrites the plan's static tensors in place
         if save:
             pl.busy = True
-            saved_ref = _PlanSaved(saved, pl)
-            return out.detach(), saved_ref
-        return out.clone(), None            # forward-only (teacher): the caller may hold the logits across the next call
+            return out.clone(), _PlanSaved(saved, pl)
+        return out.clone(), None
 
     def _run_backward(self, saved, dout):
         if not isinstance(saved, _PlanSaved):
