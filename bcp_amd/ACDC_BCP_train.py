@@ -15,7 +15,7 @@ import sys
 import numpy as np
 import torch
 
-from bcp_amd import train_step
+from bcp_amd import plan, train_step
 from bcp_amd.dataloaders.dataset import DeviceRandomGenerator, SyntheticACDC, TwoStreamBatchSampler, batches
 from bcp_amd.networks.net_factory import BCP_net
 from bcp_amd.utils import val_2d
@@ -175,6 +175,7 @@ def main(argv=None):
         for seed_fn in (torch.manual_seed, random.seed, np.random.seed):
             seed_fn(args.seed)
     device = torch.device("cuda", torch.cuda.current_device())
+    plan.use_real_stream(device)      # recorded network passes become HIP graph launches on a capturable stream (bcp_amd/plan.py)
     phase_dirs = ["./model/BCP/ACDC_{}_{}_labeled/{}".format(args.exp, args.labelnum, phase) for phase in ("pre_train", "self_train")]
     for d in phase_dirs:
         os.makedirs(d, exist_ok=True)

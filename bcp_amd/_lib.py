@@ -73,6 +73,8 @@ _SIGS = {
     "bcp_k2_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
     "bcp_pw16_fwd": (I, [P, P, P, P, L, I, P]),
     "bcp_pw16_bwd": (I, [P, P, P, P, P, P, L, I, I, P, P]),
+    "bcp_pw16_fwd_norm": (I, [P, P, P, I, I, I, P, P, P, L, I, P]),
+    "bcp_pw16_bwd_norm": (I, [P, P, P, I, I, I, P, P, P, P, P, L, I, I, P, P]),
     "bcp_colsum": (I, [P, L, I, P, I, P, P]),
     "bcp_maxpool2d_fwd": (I, [P, P, I, I, I, I, P]),
     "bcp_maxpool2d_bwd": (I, [P, P, P, I, I, I, I, I, P]),
@@ -91,6 +93,12 @@ _SIGS = {
     "bcp_cast": (I, [P, P, L, I, P]),
     "bcp_axpy": (I, [P, P, L, F, P]),
     "bcp_bernoulli": (I, [P, L, F, F, I, U64, P]),
+    "bcp_bernoulli_dev": (I, [P, L, F, F, I, P, P]),
+    "bcp_store_u64": (I, [P, I, P, P]),
+    "bcp_graph_begin_capture": (I, [P]),
+    "bcp_graph_end_capture": (I, [P, C.POINTER(P)]),
+    "bcp_graph_launch": (I, [P, P]),
+    "bcp_graph_destroy": (I, [P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())

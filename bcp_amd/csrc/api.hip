@@ -85,3 +85,38 @@ extern "C" int bcp_event_destroy(void* ev) {
   hipEventDestroy((hipEvent_t)ev);
   return BCP_OK;
 }
+
+// ---- HIP graphs: a recorded launch plan (bcp_amd/plan.py) replayed under stream capture becomes ONE graph launch per network pass.
+// Relaxed capture mode: the host framework's allocator may run on other threads while the pass is being captured.
+extern "C" int bcp_graph_begin_capture(void* stream) {
+  BCP_REQUIRE(stream, "bcp_graph_begin_capture: the default (null) stream cannot be captured");
+  const hipError_t e = hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed);
+  if (e != hipSuccess) { bcp::set_error("hipStreamBeginCapture: %s", hipGetErrorString(e)); return BCP_ELAUNCH; }
+  return BCP_OK;
+}
+
+extern "C" int bcp_graph_end_capture(void* stream, void** graph_exec) {
+  BCP_REQUIRE(stream && graph_exec, "bcp_graph_end_capture: null");
+  *graph_exec = nullptr;
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &g);
+  if (e != hipSuccess || !g) { bcp::set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); (void)hipGetLastError(); return BCP_ELAUNCH; }
+  hipGraphExec_t x = nullptr;
+  e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+  hipGraphDestroy(g);
+  if (e != hipSuccess || !x) { bcp::set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); (void)hipGetLastError(); return BCP_ELAUNCH; }
+  *graph_exec = (void*)x;
+  return BCP_OK;
+}
+
+extern "C" int bcp_graph_launch(void* graph_exec, void* stream) {
+  BCP_REQUIRE(graph_exec, "bcp_graph_launch: null");
+  const hipError_t e = hipGraphLaunch((hipGraphExec_t)graph_exec, (hipStream_t)stream);
+  if (e != hipSuccess) { bcp::set_error("hipGraphLaunch: %s", hipGetErrorString(e)); return BCP_ELAUNCH; }
+  return BCP_OK;
+}
+
+extern "C" int bcp_graph_destroy(void* graph_exec) {
+  if (graph_exec) hipGraphExecDestroy((hipGraphExec_t)graph_exec);
+  return BCP_OK;
+}

@@ -172,8 +172,11 @@ __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
+// seed_dev != nullptr: the seed lives in device memory (a launch captured in a HIP graph keeps its arguments; the seed still changes
+// every pass -- bcp_store_u64 writes it ahead of the graph launch)
 __global__ __launch_bounds__(256) void k_bernoulli_f32(float* __restrict__ out, long long n, float p_keep, float keep_value,
-                                                       unsigned seed_lo, unsigned seed_hi) {
+                                                       unsigned seed_lo, unsigned seed_hi, const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) { const unsigned long long s = *seed_dev; seed_lo = (unsigned)s; seed_hi = (unsigned)(s >> 32); }
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const unsigned h = mix32((unsigned)i ^ mix32(seed_lo + 0x9e3779b9u * (unsigned)(i >> 32)) ^ seed_hi);
@@ -182,7 +185,8 @@ __global__ __launch_bounds__(256) void k_bernoulli_f32(float* __restrict__ out, 
   }
 }
 __global__ __launch_bounds__(256) void k_bernoulli_u8(uint8_t* __restrict__ out, long long n, float p_keep,
-                                                      unsigned seed_lo, unsigned seed_hi) {
+                                                      unsigned seed_lo, unsigned seed_hi, const unsigned long long* __restrict__ seed_dev) {
+  if (seed_dev) { const unsigned long long s = *seed_dev; seed_lo = (unsigned)s; seed_hi = (unsigned)(s >> 32); }
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const unsigned h = mix32((unsigned)i ^ mix32(seed_lo + 0x9e3779b9u * (unsigned)(i >> 32)) ^ seed_hi);
@@ -280,16 +284,43 @@ extern "C" int bcp_axpy(float* y, const float* x, long long n, float a, void* st
   return BCP_OK;
 }
 
+static void bernoulli_launch(void* out, long long n, float p_keep, float keep_value, int as_u8, unsigned long long seed,
+                             const unsigned long long* seed_dev, hipStream_t s) {
+  const dim3 g(stream_grid(n, 256)), b(256);
+  if (as_u8)
+    hipLaunchKernelGGL(k_bernoulli_u8, g, b, 0, s, (uint8_t*)out, n, p_keep, (unsigned)seed, (unsigned)(seed >> 32), seed_dev);
+  else
+    hipLaunchKernelGGL(k_bernoulli_f32, g, b, 0, s, (float*)out, n, p_keep, keep_value, (unsigned)seed, (unsigned)(seed >> 32), seed_dev);
+}
+
 extern "C" int bcp_bernoulli(void* out, long long n, float p_keep, float keep_value, int as_u8, unsigned long long seed,
                              void* stream) {
   BCP_REQUIRE(out && n > 0, "bcp_bernoulli: bad argument");
-  const dim3 g(stream_grid(n, 256)), b(256);
-  if (as_u8)
-    hipLaunchKernelGGL(k_bernoulli_u8, g, b, 0, (hipStream_t)stream, (uint8_t*)out, n, p_keep, (unsigned)seed,
-                       (unsigned)(seed >> 32));
-  else
-    hipLaunchKernelGGL(k_bernoulli_f32, g, b, 0, (hipStream_t)stream, (float*)out, n, p_keep, keep_value, (unsigned)seed,
-                       (unsigned)(seed >> 32));
+  bernoulli_launch(out, n, p_keep, keep_value, as_u8, seed, nullptr, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_bernoulli");
+  return BCP_OK;
+}
+
+extern "C" int bcp_bernoulli_dev(void* out, long long n, float p_keep, float keep_value, int as_u8, const unsigned long long* seed_dev,
+                                 void* stream) {
+  BCP_REQUIRE(out && n > 0 && seed_dev, "bcp_bernoulli_dev: bad argument");
+  bernoulli_launch(out, n, p_keep, keep_value, as_u8, 0ull, seed_dev, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_bernoulli_dev");
+  return BCP_OK;
+}
+
+namespace bcp {
+struct U64x16 { unsigned long long v[16]; };
+__global__ void k_store_u64(unsigned long long* __restrict__ dst, int n, U64x16 vals) {
+  if ((int)threadIdx.x < n) dst[threadIdx.x] = vals.v[threadIdx.x];
+}
+}  // namespace bcp
+
+extern "C" int bcp_store_u64(unsigned long long* dst, int n, const unsigned long long* host_values, void* stream) {
+  BCP_REQUIRE(dst && host_values && n >= 1 && n <= 16, "bcp_store_u64: 1..16 values (they travel as kernel arguments)");
+  bcp::U64x16 v{};
+  for (int i = 0; i < n; ++i) v.v[i] = host_values[i];
+  hipLaunchKernelGGL(bcp::k_store_u64, dim3(1), dim3(64), 0, (hipStream_t)stream, dst, n, v);
+  BCP_CHECK_LAUNCH("bcp_store_u64");
   return BCP_OK;
 }

@@ -322,12 +322,34 @@ __global__ __launch_bounds__(256) void k_pack_gemm_b_many(const GemmPackDesc* __
 // ------------------------------------------------------------------------------------------------
 // 16 -> CO (<= 4) pointwise output conv: y[v][co] = b[co] + sum_ci x[v][ci] w[co][ci]
 // ------------------------------------------------------------------------------------------------
-template <int CO>
+// Optional prologue of the two kernels below: x is the RAW output of the last 3x3x3 conv and the head applies that layer's
+// normalisation + activation + Dropout3d channel scale itself -- a = act((x - mean) * scale + shift) * cs, the arithmetic of
+// k_norm_apply (norm.hip) -- so the 16-channel activation at full resolution is never written or re-read (128 MB each way at the LA
+// size, twice per step).  stats = [5][G][16] as bcp_norm_fwd leaves them.
+struct PwNorm {
+  const float* stats;          // nullptr: plain 1x1 conv on x
+  const float* chan_scale;     // nullable [N][16]
+  long long vps;               // voxels per sample
+  int G, spg;                  // normalisation groups, samples per group
+  int act;
+};
+static constexpr int kPwMaxN = 32;
+
+template <int CO, bool NORM>
 __global__ __launch_bounds__(256) void k_pw16_fwd(const float* __restrict__ x, const float* __restrict__ w,
-                                                  const float* __restrict__ bias, float* __restrict__ y, long long nvox) {
+                                                  const float* __restrict__ bias, float* __restrict__ y, long long nvox, PwNorm pn) {
   __shared__ float Ws[CO * 16 + CO];
+  __shared__ float Ns[NORM ? kPwMaxN * 64 : 1];      // per sample: mean, scale, shift, chan_scale x 16 channels
   if ((int)threadIdx.x < CO * 16) Ws[threadIdx.x] = w[threadIdx.x];
   if ((int)threadIdx.x < CO) Ws[CO * 16 + threadIdx.x] = bias ? bias[threadIdx.x] : 0.f;
+  if (NORM) {
+    const int N = pn.G * pn.spg;
+    for (int i = threadIdx.x; i < N * 64; i += 256) {
+      const int n = i >> 6, k = (i >> 4) & 3, c = i & 15, g = n / pn.spg;
+      const int plane = k == 0 ? 0 : (k == 1 ? 2 : 3);                       // stats planes: mean, rstd, scale, shift, var
+      Ns[i] = k < 3 ? pn.stats[((long long)plane * pn.G + g) * 16 + c] : (pn.chan_scale ? pn.chan_scale[n * 16 + c] : 1.f);
+    }
+  }
   __syncthreads();
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < nvox; v += (long long)gridDim.x * blockDim.x) {
     float xv[16];
@@ -335,6 +357,11 @@ __global__ __launch_bounds__(256) void k_pw16_fwd(const float* __restrict__ x, c
     for (int c = 0; c < 16; c += 4) {
       const float4 t = ld4(x + v * 16 + c);
       xv[c] = t.x; xv[c + 1] = t.y; xv[c + 2] = t.z; xv[c + 3] = t.w;
+    }
+    if (NORM) {
+      const float* q = Ns + (int)((unsigned long long)v / (unsigned long long)pn.vps) * 64;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xv[c] = act_fwd((xv[c] - q[c]) * q[16 + c] + q[32 + c], pn.act) * q[48 + c];
     }
 #pragma unroll
     for (int co = 0; co < CO; ++co) {
@@ -347,13 +374,22 @@ __global__ __launch_bounds__(256) void k_pw16_fwd(const float* __restrict__ x, c
 }
 
 // backward: dx[v][ci] = sum_co dy[v][co] w[co][ci];  acc (fp64 atomics): dw[co][ci], db[co]
-template <int CO>
+template <int CO, bool NORM>
 __global__ __launch_bounds__(256) void k_pw16_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                   const float* __restrict__ w, float* __restrict__ dx,
-                                                  double* __restrict__ accum /* [CO*16 + CO] */, long long nvox) {
+                                                  double* __restrict__ accum /* [CO*16 + CO] */, long long nvox, PwNorm pn) {
   __shared__ float Ws[CO * 16];
   __shared__ double red[4][CO * 16 + CO];
+  __shared__ float Ns[NORM ? kPwMaxN * 64 : 1];
   if ((int)threadIdx.x < CO * 16) Ws[threadIdx.x] = w[threadIdx.x];
+  if (NORM) {
+    const int N = pn.G * pn.spg;
+    for (int i = threadIdx.x; i < N * 64; i += 256) {
+      const int n = i >> 6, k = (i >> 4) & 3, c = i & 15, g = n / pn.spg;
+      const int plane = k == 0 ? 0 : (k == 1 ? 2 : 3);
+      Ns[i] = k < 3 ? pn.stats[((long long)plane * pn.G + g) * 16 + c] : (pn.chan_scale ? pn.chan_scale[n * 16 + c] : 1.f);
+    }
+  }
   __syncthreads();
   float gw[CO][16], gb[CO];
 #pragma unroll
@@ -368,6 +404,11 @@ __global__ __launch_bounds__(256) void k_pw16_bwd(const float* __restrict__ x, c
     for (int c = 0; c < 16; c += 4) {
       const float4 t = ld4(x + v * 16 + c);
       xv[c] = t.x; xv[c + 1] = t.y; xv[c + 2] = t.z; xv[c + 3] = t.w;
+    }
+    if (NORM) {      // the head's input activation, recomputed from the raw conv output (it was never stored)
+      const float* q = Ns + (int)((unsigned long long)v / (unsigned long long)pn.vps) * 64;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) xv[c] = act_fwd((xv[c] - q[c]) * q[16 + c] + q[32 + c], pn.act) * q[48 + c];
     }
 #pragma unroll
     for (int co = 0; co < CO; ++co) dv[co] = dy[v * CO + co];
@@ -641,29 +682,81 @@ extern "C" int bcp_k2_wgrad(const float* x, const float* dy, float* dw, int N, i
   return BCP_OK;
 }
 
+static int pw16_fwd_impl(const char* who, const float* x, const float* w, const float* bias, float* y, long long nvox, int Cout, const PwNorm& pn,
+                         hipStream_t s) {
+  const int grid = (int)((nvox + 255) / 256 > 2048 ? 2048 : (nvox + 255) / 256);
+  if (pn.stats) {
+    if (Cout == 2) hipLaunchKernelGGL((k_pw16_fwd<2, true>), dim3(grid), dim3(256), 0, s, x, w, bias, y, nvox, pn);
+    else if (Cout == 4) hipLaunchKernelGGL((k_pw16_fwd<4, true>), dim3(grid), dim3(256), 0, s, x, w, bias, y, nvox, pn);
+    else BCP_REQUIRE(false, "%s: Cout=%d unsupported (2 or 4)", who, Cout);
+  } else {
+    if (Cout == 2) hipLaunchKernelGGL((k_pw16_fwd<2, false>), dim3(grid), dim3(256), 0, s, x, w, bias, y, nvox, pn);
+    else if (Cout == 4) hipLaunchKernelGGL((k_pw16_fwd<4, false>), dim3(grid), dim3(256), 0, s, x, w, bias, y, nvox, pn);
+    else BCP_REQUIRE(false, "%s: Cout=%d unsupported (2 or 4)", who, Cout);
+  }
+  return BCP_OK;
+}
+
 extern "C" int bcp_pw16_fwd(const float* x, const float* w, const float* bias, float* y, long long nvox, int Cout, void* stream) {
   BCP_REQUIRE(x && w && y && nvox > 0, "bcp_pw16_fwd: bad argument");
-  const int grid = (int)((nvox + 255) / 256 > 2048 ? 2048 : (nvox + 255) / 256);
-  if (Cout == 2) hipLaunchKernelGGL((k_pw16_fwd<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, nvox);
-  else if (Cout == 4) hipLaunchKernelGGL((k_pw16_fwd<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, x, w, bias, y, nvox);
-  else BCP_REQUIRE(false, "bcp_pw16_fwd: Cout=%d unsupported (2 or 4)", Cout);
+  if (int rc = pw16_fwd_impl("bcp_pw16_fwd", x, w, bias, y, nvox, Cout, PwNorm{nullptr, nullptr, 1, 1, 1, 0}, (hipStream_t)stream)) return rc;
   BCP_CHECK_LAUNCH("bcp_pw16_fwd");
   return BCP_OK;
 }
 
+static bool pw_norm_args(PwNorm& pn, const float* stats, const float* chan_scale, int N, int G, long long nvox, int act) {
+  if (!stats || N < 1 || G < 1 || N % G || N > kPwMaxN || nvox % N) return false;
+  pn = PwNorm{stats, chan_scale, nvox / N, G, N / G, act};
+  return true;
+}
+
+extern "C" int bcp_pw16_fwd_norm(const float* x_raw, const float* stats, const float* chan_scale, int N, int G, int act, const float* w,
+                                 const float* bias, float* y, long long nvox, int Cout, void* stream) {
+  BCP_REQUIRE(x_raw && w && y && nvox > 0, "bcp_pw16_fwd_norm: bad argument");
+  PwNorm pn;
+  BCP_REQUIRE(pw_norm_args(pn, stats, chan_scale, N, G, nvox, act), "bcp_pw16_fwd_norm: needs stats, 1 <= N <= %d samples in G | N groups", kPwMaxN);
+  if (int rc = pw16_fwd_impl("bcp_pw16_fwd_norm", x_raw, w, bias, y, nvox, Cout, pn, (hipStream_t)stream)) return rc;
+  BCP_CHECK_LAUNCH("bcp_pw16_fwd_norm");
+  return BCP_OK;
+}
+
 // workspace: (Cout*16 + Cout) doubles
+static int pw16_bwd_impl(const char* who, const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long nvox,
+                         int Cout, int accumulate, void* workspace, const PwNorm& pn, hipStream_t s) {
+  double* acc = reinterpret_cast<double*>(workspace);
+  hipMemsetAsync(acc, 0, (size_t)(Cout * 17) * sizeof(double), s);
+  const int grid = (int)((nvox + 255) / 256 > 1024 ? 1024 : (nvox + 255) / 256);
+  if (pn.stats) {
+    if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd<2, true>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox, pn);
+    else if (Cout == 4) hipLaunchKernelGGL((k_pw16_bwd<4, true>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox, pn);
+    else BCP_REQUIRE(false, "%s: Cout=%d unsupported (2 or 4)", who, Cout);
+  } else {
+    if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd<2, false>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox, pn);
+    else if (Cout == 4) hipLaunchKernelGGL((k_pw16_bwd<4, false>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox, pn);
+    else BCP_REQUIRE(false, "%s: Cout=%d unsupported (2 or 4)", who, Cout);
+  }
+  hipLaunchKernelGGL(k_pw16_finalize, dim3(1), dim3(128), 0, s, acc, dw, db, Cout, accumulate);
+  return BCP_OK;
+}
+
 extern "C" int bcp_pw16_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long nvox,
                             int Cout, int accumulate, void* workspace, void* stream) {
   BCP_REQUIRE(x && dy && w && dx && dw && db && workspace && nvox > 0, "bcp_pw16_bwd: bad argument");
-  double* acc = reinterpret_cast<double*>(workspace);
-  hipStream_t s = (hipStream_t)stream;
-  hipMemsetAsync(acc, 0, (size_t)(Cout * 17) * sizeof(double), s);
-  const int grid = (int)((nvox + 255) / 256 > 1024 ? 1024 : (nvox + 255) / 256);
-  if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd<2>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox);
-  else if (Cout == 4) hipLaunchKernelGGL((k_pw16_bwd<4>), dim3(grid), dim3(256), 0, s, x, dy, w, dx, acc, nvox);
-  else BCP_REQUIRE(false, "bcp_pw16_bwd: Cout=%d unsupported (2 or 4)", Cout);
-  hipLaunchKernelGGL(k_pw16_finalize, dim3(1), dim3(128), 0, s, acc, dw, db, Cout, accumulate);
+  if (int rc = pw16_bwd_impl("bcp_pw16_bwd", x, dy, w, dx, dw, db, nvox, Cout, accumulate, workspace, PwNorm{nullptr, nullptr, 1, 1, 1, 0},
+                             (hipStream_t)stream)) return rc;
   BCP_CHECK_LAUNCH("bcp_pw16_bwd");
+  return BCP_OK;
+}
+
+// x_raw = the raw conv output the forward consumed (bcp_pw16_fwd_norm); dx = gradient w.r.t. the ACTIVATION (hand it to bcp_norm_bwd)
+extern "C" int bcp_pw16_bwd_norm(const float* x_raw, const float* stats, const float* chan_scale, int N, int G, int act, const float* dy,
+                                 const float* w, float* dx, float* dw, float* db, long long nvox, int Cout, int accumulate, void* workspace,
+                                 void* stream) {
+  BCP_REQUIRE(x_raw && dy && w && dx && dw && db && workspace && nvox > 0, "bcp_pw16_bwd_norm: bad argument");
+  PwNorm pn;
+  BCP_REQUIRE(pw_norm_args(pn, stats, chan_scale, N, G, nvox, act), "bcp_pw16_bwd_norm: needs stats, 1 <= N <= %d samples in G | N groups", kPwMaxN);
+  if (int rc = pw16_bwd_impl("bcp_pw16_bwd_norm", x_raw, dy, w, dx, dw, db, nvox, Cout, accumulate, workspace, pn, (hipStream_t)stream)) return rc;
+  BCP_CHECK_LAUNCH("bcp_pw16_bwd_norm");
   return BCP_OK;
 }
 

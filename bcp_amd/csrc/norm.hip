@@ -245,6 +245,11 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_norm_bwd_finalize(const do
 // row-reversed position of float4 index p inside a segment (same column): (rows-1-r)*C4 + col
 #define REV(p) (nv - C4 - (p) + 2 * col)
 // a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]      (segments: see k_col_partial)
+__global__ __launch_bounds__(256) void k_norm_running_only(const float* __restrict__ mean, const float* __restrict__ var_unb, int G, int C,
+                                                           float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
+  update_running(mean, var_unb, G, C, running_mean, running_var, momentum);
+}
+
 __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y, const float* __restrict__ scale,
                                                     const float* __restrict__ shift, const float* __restrict__ mean,
                                                     const float* __restrict__ residual, NormEpilogue ep, long long seg_rows,
@@ -421,8 +426,9 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
                             const float* residual, float* stats /* [5][G][C]: mean, rstd, scale, beta, unbiased var */, void* workspace,
                             const double* partial_in, int nb_in, float* out, void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd", G, rows_per_group, C)) return rc;
-  BCP_REQUIRE(y && stats && workspace && out, "bcp_norm_fwd: null pointer");
-  BCP_REQUIRE(aligned16(y) && aligned16(out) && aligned16(stats), "bcp_norm_fwd: alignment");
+  BCP_REQUIRE(y && stats && workspace, "bcp_norm_fwd: null pointer");
+  BCP_REQUIRE(aligned16(y) && (!out || aligned16(out)) && aligned16(stats), "bcp_norm_fwd: alignment");
+  BCP_REQUIRE(out || !residual, "bcp_norm_fwd: statistics-only mode (out = NULL) takes no residual");
   hipStream_t s = (hipStream_t)stream;
   NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
   BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
@@ -441,8 +447,11 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
     hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
   }
-  hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, scale, shift, mean, residual,
-                     ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum);
+  if (out)
+    hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, scale, shift, mean, residual,
+                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum);
+  else if (running_mean)   // statistics only: the consumer applies the normalisation itself (bcp_pw16_fwd_norm); the apply pass also carries the running-statistics update
+    hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
   BCP_CHECK_LAUNCH("bcp_norm_fwd");
   return BCP_OK;
 }

@@ -158,9 +158,10 @@ class Ops:
 
     # ------------------------------------------------------------------ norm
     def norm_fwd(self, y, G, gamma, beta, rmean, rvar, act, out=None, chan_scale=None, elem_mask=None, elem_scale=1.0,
-                 residual=None, momentum=0.1, eps=1e-5, partial=None, nb=0):
+                 residual=None, momentum=0.1, eps=1e-5, partial=None, nb=0, stats_only=False):
         """y [N,D,H,W,C] -> (a, stats[5,G,C]).  G = 1: BatchNorm; G = N (no affine): InstanceNorm; G > 1 with affine:
-        G consecutive BatchNorm calls in one launch."""
+        G consecutive BatchNorm calls in one launch.  stats_only: statistics (and the running-statistics update) without the
+        apply pass -- the consumer normalises on its way in (pw16_fwd_norm); returns (None, stats)."""
         self._chk(y, gamma, beta, rmean, rvar, chan_scale, elem_mask, residual)
         N = y.shape[0]
         Cc = y.shape[-1]
@@ -170,7 +171,9 @@ class Ops:
         nbytes = self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc)
         ws = self.workspace("norm", nbytes, y)
         stats = torch.empty((5, G, Cc), dtype=torch.float32, device=y.device)
-        if out is None:
+        if stats_only:
+            assert out is None and residual is None and elem_mask is None
+        elif out is None:
             out = torch.empty_like(y)
         self.b.call("bcp_norm_fwd", _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps), act,
                     _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws), _p(partial), int(nb), _p(out),
@@ -412,6 +415,31 @@ class Ops:
         self.b.call("bcp_pw16_bwd", _p(x), _p(dy), _p(w), _p(dx), _p(dw), _p(db), nvox, Cout, int(bool(accumulate)), _p(ws), self.stream(x))
         return dx
 
+    def pw16_fwd_norm(self, y_raw, stats, chan_scale, G, act, w, bias, Cout, out=None):
+        """the 1x1x1 head on act(norm(y_raw)) * chan_scale without materialising that activation (bcp_pw16_fwd_norm)"""
+        self._chk(y_raw, stats, chan_scale, w, bias)
+        assert y_raw.shape[-1] == 16
+        N = y_raw.shape[0]
+        nvox = y_raw.numel() // 16
+        if out is None:
+            out = torch.empty(tuple(y_raw.shape[:-1]) + (Cout,), dtype=torch.float32, device=y_raw.device)
+        self.b.call("bcp_pw16_fwd_norm", _p(y_raw), _p(stats), _p(chan_scale), N, G, act, _p(w), _p(bias), _p(out), nvox, Cout,
+                    self.stream(y_raw))
+        return out
+
+    def pw16_bwd_norm(self, y_raw, stats, chan_scale, G, act, dy, w, dw, db, accumulate=False, dx=None):
+        """backward of pw16_fwd_norm: dw / db from the recomputed activation; returns its gradient (input of norm_bwd)"""
+        self._chk(y_raw, stats, chan_scale, dy, w, dw, db)
+        Cout = dy.shape[-1]
+        N = y_raw.shape[0]
+        nvox = y_raw.numel() // 16
+        if dx is None:
+            dx = torch.empty_like(y_raw)
+        ws = self.workspace("pw16", Cout * 17 * 8, y_raw)
+        self.b.call("bcp_pw16_bwd_norm", _p(y_raw), _p(stats), _p(chan_scale), N, G, act, _p(dy), _p(w), _p(dx), _p(dw), _p(db), nvox, Cout,
+                    int(bool(accumulate)), _p(ws), self.stream(y_raw))
+        return dx
+
     def colsum(self, x, out, accumulate=False):
         self._chk(x, out)
         Cc = x.shape[-1]
@@ -493,8 +521,29 @@ class Ops:
         self.b.call("bcp_axpy", _p(y), _p(x), y.numel(), float(a), self.stream(y))
         return y
 
+    def store_u64(self, dst, values, like):
+        """dst[i] = values[i] (<= 16 host integers as kernel arguments): the dropout seed table of a launch plan"""
+        n = len(values)
+        arr = (C.c_ulonglong * n)(*[int(v) & 0xFFFFFFFFFFFFFFFF for v in values])
+        fn, _ = self.b._fns["bcp_store_u64"]            # never recorded: it runs ahead of every replay
+        rc = fn(dst.data_ptr(), n, arr, self.stream(like))
+        if rc:
+            raise _lib.BcpError(f"bcp_store_u64 failed ({rc}): {self.b.last_error()}")
+
     def bernoulli(self, out, p_keep, keep_value, seed):
         self._chk(out)
+        pl = self._rec_plan
+        if pl is not None:          # inside a recorded pass the seed is read from the plan's device table (bcp_amd/plan.py)
+            slot = pl.seed_slot(out.device)
+            n = pl.n_seeds - 1
+            fn, _ = self.b._fns["bcp_store_u64"]
+            arr = (C.c_ulonglong * 1)(int(seed) & 0xFFFFFFFFFFFFFFFF)
+            rc = fn(slot, 1, arr, self.stream(out))
+            if rc:
+                raise _lib.BcpError(f"bcp_store_u64 failed ({rc}): {self.b.last_error()}")
+            self.b.call("bcp_bernoulli_dev", _p(out), out.numel(), float(p_keep), float(keep_value), int(out.dtype == torch.uint8), slot,
+                        self.stream(out))
+            return out
         self.b.call("bcp_bernoulli", _p(out), out.numel(), float(p_keep), float(keep_value), int(out.dtype == torch.uint8), int(seed),
                     self.stream(out))
         return out

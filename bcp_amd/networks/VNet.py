@@ -31,6 +31,8 @@ class _Layer:
 
 
 class VNet(HipNet):
+    fuse_head = True     # the 1x1x1 head applies the last conv's norm + ReLU + Dropout3d itself (bcp_pw16_fwd_norm); False: separate apply pass
+
     def __init__(self, n_channels=3, n_classes=2, n_filters=16, normalization="none", has_dropout=False, has_residual=False,
                  variant="la"):
         super().__init__()
@@ -174,6 +176,9 @@ class VNet(HipNet):
         h = xcl
         skips = []
         saved = []
+        last = len(self._layers) - 1
+        Ll = self._layers[last]
+        fuse_head = (self.fuse_head and self.training and Ll.kind == "c3" and Ll.cout == 16 and not Ll.skip_pop and N <= 32)
         for li, L in enumerate(self._layers):
             w, b = L.conv.weight, L.conv.bias
             part, nb = None, 0
@@ -195,7 +200,12 @@ class VNet(HipNet):
                 y = ops.up_fwd(h, bp, b.data, L.cout)
             res = skips.pop() if L.skip_pop else None
             cs = self._chan_scale(L, N, xcl.device)
-            if L.bn is not None and not self.training:
+            if li == last and fuse_head:
+                # the head normalises on its way in: block_nine's 16-channel activation is never written (statistics only here)
+                bn = L.bn
+                a, stats = ops.norm_fwd(y, G, *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var) if bn is not None else (None,) * 4),
+                                        H.ACT_RELU, chan_scale=cs, partial=part, nb=nb, stats_only=True)
+            elif L.bn is not None and not self.training:
                 # model.eval(): running statistics, no update (validation / sliding-window inference)
                 a, stats = ops.norm_eval(y, L.bn.weight.data, L.bn.bias.data, L.bn.running_mean, L.bn.running_var, H.ACT_RELU, residual=res), None
             elif L.bn is not None:
@@ -209,9 +219,12 @@ class VNet(HipNet):
         if self.norm == "batchnorm" and self.training:
             for _ in range(G):
                 self._nbt_tick()
-        logits = ops.pw16_fwd(h, self._out.weight.data, self._out.bias.data, self.n_classes)
+        if fuse_head:
+            logits = ops.pw16_fwd_norm(y, stats, cs, G, H.ACT_RELU, self._out.weight.data, self._out.bias.data, self.n_classes)
+        else:
+            logits = ops.pw16_fwd(h, self._out.weight.data, self._out.bias.data, self.n_classes)
         if save:
-            saved.append((h,))
+            saved.append((h,))          # None when the head is fused: the backward recomputes it from saved[last]
         return logits, saved
 
     def _grad_stages(self):
@@ -230,7 +243,12 @@ class VNet(HipNet):
         dlogits = dout if dout.is_contiguous() else dout.contiguous()
         self.begin_backward()
         (h_last,) = saved[-1]
-        dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
+        if h_last is None:
+            _, y9, st9, cs9, _ = saved[len(self._layers) - 1]
+            dh = ops.pw16_bwd_norm(y9, st9, cs9, G, H.ACT_RELU, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad,
+                                   accumulate=True)
+        else:
+            dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
         skip_grads = []
         for li in range(len(self._layers) - 1, -1, -1):
             L = self._layers[li]

@@ -418,7 +418,7 @@ class HipNet(nn.Module):
                 hook(self, lo, like)
                 rec = self.ops.b._rec
                 if rec is not None:
-                    rec.add_py(self._replay_bucket_hook, lo, like)
+                    rec.add_py(self._replay_bucket_hook, lo, like, capturable=False)
 
     def _replay_bucket_hook(self, lo, like):
         hook = self._grad_bucket_hook          # the hook armed for THIS step (DataParallel.arm), not the one seen while recording
@@ -499,7 +499,7 @@ class HipNet(nn.Module):
             plans[key] = pl
         else:
             pl.static_in.copy_(xcl)
-            pl.replay([self.next_seed() for _ in pl.seed_slots], self.ops.b.check_replayed)
+            pl.replay(self.ops, [self.next_seed() for _ in range(pl.n_seeds)], xcl)
             for _ in range(pl.ticks):
                 self._nbt_tick()
         out, saved = pl.result
@@ -533,7 +533,7 @@ class HipNet(nn.Module):
             else:
                 pl.static_in.copy_(dout)
                 self.begin_backward()
-                pl.replay((), self.ops.b.check_replayed)
+                pl.replay(self.ops, (), dout)
         finally:
             fwd.busy = False
         return None

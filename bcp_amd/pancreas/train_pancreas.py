@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-from bcp_amd import synth, train_step
+from bcp_amd import plan, synth, train_step
 from bcp_amd.pancreas.Vnet import create_Vnet
 
 seed_test = 2020
@@ -113,6 +113,7 @@ def main(argv=None):
     np.random.seed(seed_test)
     torch.manual_seed(seed_test)
     device = torch.device("cuda", torch.cuda.current_device())
+    plan.use_real_stream(device)      # recorded network passes become HIP graph launches on a capturable stream
     net, ema_net = create_Vnet(), create_Vnet(ema=True)
     ema_net.load_state_dict(net.state_dict())
     optimizer = train_step.FlatAdam(net, lr=lr)

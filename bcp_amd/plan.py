@@ -6,9 +6,11 @@ while `Binding.call` records every launch -- the ctypes function and its argumen
 kept alive by the plan, so all recorded device pointers stay valid.  Every later pass replays the list: one `fn(*args)` per launch,
 no shape arithmetic, no `torch.empty`, no wrapper layers (bench: host enqueue of the LA step 5.3 -> see DESIGN.md section 8).
 
-What varies between passes is patched in place: the Dropout3d / Dropout seeds (argument slots of the recorded `bcp_bernoulli`
-launches, refilled from the network's seed stream in recording order) and the input, which is copied into the plan's static input
-buffer (one device copy).  Stream-ordering calls (`wait_stream`) and data-parallel bucket hooks are recorded as Python callables in
+What varies between passes lives in device memory: the Dropout3d / Dropout seeds (the recorded draws are `bcp_bernoulli_dev`
+launches reading the plan's seed table, which one `bcp_store_u64` launch refills from the network's seed stream before a replay)
+and the input, which is copied into the plan's static input buffer (one device copy).  So a recorded pass is a constant launch
+sequence -- and when the caller runs on a real (non-null) stream, the first replay runs under HIP stream capture and every later
+pass is ONE `hipGraphLaunch` (`bcp_graph_launch`), side-stream weight gradients included (event fork / join is captured).  Stream-ordering calls (`wait_stream`) and data-parallel bucket hooks are recorded as Python callables in
 place.  Weight packing is NOT recorded: it depends on the weights' version and runs eagerly before a replay.
 
 The reference has no counterpart (its host path is PyTorch's eager dispatch); this is the "launch plan" of VERDICT r01 item 4.
@@ -18,6 +20,7 @@ import contextlib
 import torch
 
 ENABLED = True          # module switch (tests compare a replayed step with an eager one)
+GRAPHS = True           # capture a plan's second pass in a HIP graph when the caller runs on a real (non-null) stream
 _EPOCH = [0]            # bumped when library options change: every plan recorded before is dropped
 
 
@@ -30,35 +33,100 @@ def epoch():
 
 
 class LaunchPlan:
-    __slots__ = ("entries", "keep", "seed_slots", "static_in", "result", "ticks", "n_calls", "busy")
+    __slots__ = ("entries", "keep", "n_seeds", "seed_dev", "static_in", "result", "ticks", "n_calls", "busy", "graph", "graph_state",
+                 "capturable", "_owner")
+
+    MAX_SEEDS = 16
 
     def __init__(self):
         self.entries = []        # [callable, [args...]]
         self.keep = []           # every tensor allocated while recording (pointers inside `entries` refer to them)
-        self.seed_slots = []     # (entry index, argument index) of the dropout seeds, in recording order
+        self.n_seeds = 0         # Dropout3d / Dropout draws of the pass; their seeds live in `seed_dev` (device memory) so that the
+        self.seed_dev = None     #   recorded launches -- and a graph captured from them -- never change: bcp_bernoulli_dev
         self.static_in = None
         self.result = None
         self.ticks = 0
         self.n_calls = 0
         self.busy = False        # a forward plan whose saved activations a pending backward still needs
+        self.graph = None        # hipGraphExec_t of the captured pass (GRAPHS)
+        self.graph_state = 0     # 0: capture not tried yet, 1: captured, -1: stays a per-launch replay
+        self.capturable = True
+        self._owner = None
 
     # called by Binding.call while recording
     def add_call(self, name, fn, args):
-        if name == "bcp_bernoulli":
-            self.seed_slots.append((len(self.entries), 5))       # (out, n, p_keep, keep_value, as_u8, SEED, stream)
         self.entries.append([fn, list(args)])
         self.n_calls += 1
 
-    def add_py(self, fn, *args):
+    def add_py(self, fn, *args, capturable=True):
+        """a Python callable in launch order: stream ordering (event record / wait: fine under stream capture) or, with
+        capturable=False, something a graph must not swallow (the data-parallel bucket hook: it changes per step)"""
         self.entries.append([fn, list(args)])
+        if not capturable:
+            self.capturable = False
 
-    def replay(self, seeds, check):
-        for (i, j), s in zip(self.seed_slots, seeds):
-            self.entries[i][1][j] = s
+    def seed_slot(self, device):
+        """device address of the next dropout seed of this pass (recording)"""
+        if self.seed_dev is None:
+            self.seed_dev = torch.zeros(self.MAX_SEEDS, dtype=torch.int64, device=device)
+        assert self.n_seeds < self.MAX_SEEDS, "more dropout draws per pass than a plan holds seeds for"
+        self.n_seeds += 1
+        return self.seed_dev.data_ptr() + 8 * (self.n_seeds - 1)
+
+    def run_entries(self, check):
         for fn, args in self.entries:
             rc = fn(*args)
             if rc:
                 check(rc)
+
+    def replay(self, ops, seeds, like):
+        """one pass: refresh the seeds, then either the captured graph (one call) or the recorded launches one by one"""
+        b = ops.b
+        if self.n_seeds:
+            ops.store_u64(self.seed_dev, seeds, like)
+        if self.graph is not None:
+            b.call("bcp_graph_launch", self.graph, ops.stream(like))
+            return
+        if self.graph_state == 0 and GRAPHS and self.capturable and like.is_cuda:
+            self.graph_state = -1
+            stream = ops.stream(like)
+            if stream:                                   # the null stream cannot be captured: run the step on a real stream to get graphs
+                self.graph = _capture(self, b, stream)
+                if self.graph is not None:
+                    self.graph_state = 1
+                    self._owner = b
+                    b.call("bcp_graph_launch", self.graph, stream)
+                    return
+        self.run_entries(b.check_replayed)
+
+    def __del__(self):
+        g, b = getattr(self, "graph", None), getattr(self, "_owner", None)
+        if g is not None and b is not None:
+            try:
+                b.cdll.bcp_graph_destroy(g)
+            except Exception:
+                pass
+
+
+def _capture(pl, b, stream):
+    """replay the recorded launches under stream capture -> hipGraphExec_t, or None (the plan stays a per-launch replay)"""
+    import ctypes as C
+    if b.cdll.bcp_graph_begin_capture(stream):
+        return None
+    err = None
+    try:
+        pl.run_entries(b.check_replayed)
+    except Exception as e:          # the capture must be closed whatever happened
+        err = e
+    handle = C.c_void_p()
+    rc = b.cdll.bcp_graph_end_capture(stream, C.byref(handle))
+    if err is not None:
+        if not rc and handle.value:
+            b.cdll.bcp_graph_destroy(handle)
+        raise err
+    if rc or not handle.value:
+        return None
+    return handle
 
 
 @contextlib.contextmanager
@@ -99,3 +167,13 @@ def suspended(ops):
         yield
     finally:
         b._rec = prev
+
+
+def use_real_stream(device):
+    """make a non-null stream the current one on `device` (no-op when it already is): the null stream cannot be captured, so the
+    training scripts and bench.py call this once before their loop to get graph replays"""
+    if torch.cuda.is_available() and torch.device(device).type == "cuda":
+        if torch.cuda.current_stream(device).cuda_stream == 0:
+            s = torch.cuda.Stream(device=device)
+            s.wait_stream(torch.cuda.current_stream(device))
+            torch.cuda.set_stream(s)

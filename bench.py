@@ -371,9 +371,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     dev = torch.device("cuda", dp.local_rank)
     torch.cuda.set_device(dev)
+    from bcp_amd import plan
+    plan.use_real_stream(dev)       # as the training scripts do: network passes replay as HIP graphs (the null stream cannot be captured)
     ops = Ops.product()
     for kv in args.opt:
         k, _, v = kv.partition("=")
+        if k == "graphs":             # host-side switch (bcp_amd/plan.py)
+            plan.GRAPHS = bool(int(v))
+            continue
+        if k == "fuse_head":          # host-side switch (networks/VNet.py), not a library option
+            from bcp_amd.networks.VNet import VNet
+            VNet.fuse_head = bool(int(v))
+            continue
         ops.set_option(k, v)
     step, info = make_workload(args, dp, dev)
     ranks_seen = dp.ranks_seen()

@@ -154,6 +154,14 @@ int bcp_k2_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H
 int bcp_pw16_fwd(const float* x, const float* w, const float* bias_or_null, float* y, long long nvox, int Cout, void* stream);
 int bcp_pw16_bwd(const float* x, const float* dy, const float* w, float* dx, float* dw, float* db, long long nvox, int Cout,
                  int accumulate, void* workspace, void* stream);
+/* The same head with the LAST 3x3x3 conv's normalisation + activation + Dropout3d channel scale applied on the way in: x_raw is the raw
+ * conv output, stats = [5][G][16] as bcp_norm_fwd(out = NULL: statistics only) leaves them, chan_scale nullable [N][16] -- the
+ * 16-channel activation at full resolution is never materialised (networks/VNet.py:213-216 out_conv after block_nine + dropout).
+ * bcp_pw16_bwd_norm recomputes it for the weight gradient and returns dx = gradient w.r.t. that activation (for bcp_norm_bwd). */
+int bcp_pw16_fwd_norm(const float* x_raw, const float* stats, const float* chan_scale, int N, int G, int act, const float* w, const float* bias,
+                      float* y, long long nvox, int Cout, void* stream);
+int bcp_pw16_bwd_norm(const float* x_raw, const float* stats, const float* chan_scale, int N, int G, int act, const float* dy, const float* w,
+                      float* dx, float* dw, float* db, long long nvox, int Cout, int accumulate, void* workspace, void* stream);
 /* column sums of [rows][C] (bias gradients of convs not followed by a norm); workspace = C doubles */
 int bcp_colsum(const float* x, long long rows, int C, float* out, int accumulate, void* workspace, void* stream);
 
@@ -211,6 +219,18 @@ int bcp_acdc_augment(const void* src, void* dst, int elem_bytes, int H, int W, i
 int bcp_cast(const void* in, void* out, long long n, int kind, void* stream);
 int bcp_axpy(float* y, const float* x, long long n, float a, void* stream);
 int bcp_bernoulli(void* out, long long n, float p_keep, float keep_value, int as_u8, unsigned long long seed, void* stream);
+/* The same draw with the seed read from DEVICE memory at run time (a launch captured in a HIP graph keeps its arguments), and the
+ * store that refreshes such seeds: host_values is a HOST pointer to n <= 16 values, which travel as kernel arguments. */
+int bcp_bernoulli_dev(void* out, long long n, float p_keep, float keep_value, int as_u8, const unsigned long long* seed_dev, void* stream);
+int bcp_store_u64(unsigned long long* dst, int n, const unsigned long long* host_values, void* stream);
+
+/* ---- HIP graphs (no reference counterpart: its host path is PyTorch's eager dispatch).  Everything launched on `stream` (and on
+ * streams that fork from / join it through events) between begin and end becomes one executable graph; bcp_graph_launch replays it
+ * with one call.  Used by bcp_amd/plan.py for whole network passes. */
+int bcp_graph_begin_capture(void* stream);
+int bcp_graph_end_capture(void* stream, void** graph_exec);
+int bcp_graph_launch(void* graph_exec, void* stream);
+int bcp_graph_destroy(void* graph_exec);
 
 /* ---- data-parallel gradient exchange: all-reduce (sum, in place) of the flat fp32 gradient buffer over RCCL /
  *      xGMI.  No reference counterpart for LA / ACDC (its only multi-GPU code is nn.DataParallel, pancreas/dataloaders.py:14);

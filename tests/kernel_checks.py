@@ -401,6 +401,42 @@ def check_k2(ops, dev, cases=K2_CASES, pw_cases=PW_CASES):
     close(db, b.grad, rtol=2e-4, msg="pw16 db")
 
 
+def check_pw16_norm(ops, dev):
+    """the 16 -> C head that normalises on its way in (bcp_pw16_fwd_norm / _bwd_norm) against the two-launch composition
+    norm_fwd -> pw16_fwd: same statistics, same per-element arithmetic -> logits and gradients agree to rounding of the
+    compiler's contraction choices; the running statistics update is the one the apply pass would have made."""
+    rng = np.random.default_rng(31)
+    for (N, G, Cout, affine, drop) in ((4, 2, 2, True, True), (2, 2, 2, False, False), (4, 1, 4, True, False), (3, 3, 2, False, True)):
+        y = (R(rng, N, 5, 6, 8, 16) * 1.7 + 0.3).to(dev)
+        gamma = (R(rng, 16) * 0.3 + 1).to(dev) if affine else None
+        beta = (R(rng, 16) * 0.2).to(dev) if affine else None
+        rm = [torch.zeros(16).to(dev) for _ in range(2)] if affine else [None, None]
+        rv = [torch.ones(16).to(dev) for _ in range(2)] if affine else [None, None]
+        cs = ((torch.from_numpy(rng.integers(0, 2, (N, 16))).float() * 2).to(dev)) if drop else None
+        w = (R(rng, Cout, 16, 1, 1, 1) * 0.3).to(dev).contiguous()
+        b = (R(rng, Cout) * 0.1).to(dev)
+        dlog = R(rng, N, 5, 6, 8, Cout).to(dev)
+        a, st = ops.norm_fwd(y, G, gamma, beta, rm[0], rv[0], H.ACT_RELU, chan_scale=cs)
+        ref = ops.pw16_fwd(a, w, b, Cout)
+        dw0, db0 = torch.zeros_like(w), torch.zeros(Cout).to(dev)
+        dx0 = ops.pw16_bwd(a, dlog, w, dw0, db0)
+        none, st1 = ops.norm_fwd(y, G, gamma, beta, rm[1], rv[1], H.ACT_RELU, chan_scale=cs, stats_only=True)
+        assert none is None and torch.equal(st, st1), "statistics-only norm_fwd: different statistics"
+        if affine:
+            assert torch.equal(rm[0], rm[1]) and torch.equal(rv[0], rv[1]), "statistics-only norm_fwd: running statistics differ"
+            assert float(rm[1].abs().max()) > 0
+        got = ops.pw16_fwd_norm(y, st1, cs, G, H.ACT_RELU, w, b, Cout)
+        close(got, ref, rtol=1e-5, msg=f"pw16_fwd_norm N={N} G={G}")
+        dw1, db1 = torch.zeros_like(w), torch.zeros(Cout).to(dev)
+        dx1 = ops.pw16_bwd_norm(y, st1, cs, G, H.ACT_RELU, dlog, w, dw1, db1)
+        assert torch.equal(dx1, dx0), "pw16_bwd_norm: dx"
+        close(dw1, dw0, rtol=1e-5, msg="pw16_bwd_norm dw")
+        close(db1, db0, rtol=1e-6, msg="pw16_bwd_norm db")
+        # accumulate flag
+        dx2 = ops.pw16_bwd_norm(y, st1, cs, G, H.ACT_RELU, dlog, w, dw1, db1, accumulate=True)
+        close(dw1, 2 * dw0, rtol=1e-5, msg="pw16_bwd_norm accumulate")
+
+
 def check_pool2d(ops, dev):
     rng = np.random.default_rng(8)
     x = R(rng, 2, 16, 8, 12).requires_grad_(True)
@@ -713,4 +749,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pool2d", "optim")
+ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")

@@ -909,7 +909,7 @@ def check_unet_pattern_grads(ops, dev, hw=(64, 64), N=2, seed=12, bound=1e-4):
 
 
 # ------------------------------------------------------------------------------------------ launch plans
-def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True))):
+def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=False):
     """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net
     (grouped and as the reference's four separate calls -- the second student call must not reuse the busy plan), the pancreas
     V-Net and the ACDC U-Net, live Dropout / Dropout3d (the seeds are patched into the recorded launches), weights, teacher
@@ -917,6 +917,18 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
     from bcp_amd import plan, train_step
 
     def run(enabled, what, grouped):
+        if enabled and graphs:
+            # graphs=True (GPU only): the replayed run lives on a real stream, so the first replay of every pass is captured and
+            # the later ones are single hipGraphLaunch calls (side-stream weight gradients inside the graph)
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                r = run_(enabled, what, grouped)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            return r
+        return run_(enabled, what, grouped)
+
+    def run_(enabled, what, grouped):
         plan.ENABLED = enabled
         try:
             torch.manual_seed(5)
@@ -944,7 +956,12 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
                     r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), variant=what,
                                                       connect_mode=2 if what != "la" else None, grouped=grouped)
                 losses.append(float(r["loss"]))
+            plans = list(model.__dict__.get("_plan_state", (None, {}))[1].values()) + list(ema.__dict__.get("_plan_state", (None, {}))[1].values())
             n_plans = len(model.__dict__.get("_plan_state", (None, {}))[1])
+            if enabled and graphs:
+                assert steps >= 3
+                n_graph = sum(1 for p in plans if p.graph is not None)
+                assert n_graph >= 3, (what, grouped, [p.graph_state for p in plans])      # teacher forward, student forward, backward
             return losses, {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}, {k: v.detach().clone().cpu() for k, v in ema.state_dict().items()}, n_plans
         finally:
             plan.ENABLED = True
@@ -957,3 +974,40 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
             assert torch.equal(a[1][k], b[1][k]), (what, "student", k)
         for k in a[2]:
             assert torch.equal(a[2][k], b[2][k]), (what, "teacher", k)
+
+
+def check_fused_head(ops, dev, steps=2):
+    """the head that normalises on its way in (VNet.fuse_head, bcp_pw16_fwd_norm / _bwd_norm) against the separate apply pass:
+    self-training steps of the LA (BatchNorm, Dropout3d live, grouped) and pancreas (InstanceNorm) V-Nets from the same seeds;
+    the two differ only in instruction contraction inside one kernel, so losses and weights agree to rounding."""
+    from bcp_amd import train_step
+
+    def run(fuse, what):
+        torch.manual_seed(5)
+        np.random.seed(5)
+        shape = (32, 32, 16) if what == "la" else (32, 32, 32)
+        P = O.init_params(O.vnet_param_shapes(variant=what), seed=43, random_affine=True)
+        model, ema = make_vnet(P, dev, ops, what), make_vnet(P, dev, ops, what)
+        model.fuse_head = ema.fuse_head = fuse
+        vol, lab = O.synth_la_batch(4, shape=shape, seed=79)
+        model.seed_dropout(11)
+        ema.seed_dropout(12)
+        for p in ema.parameters():
+            p.detach_()
+        vol, lab = vol.to(dev), lab.to(dev)
+        opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+        losses = []
+        for _ in range(steps):
+            r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), variant=what,
+                                              connect_mode=2 if what != "la" else None, grouped=True)
+            losses.append(float(r["loss"]))
+        return losses, {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+
+    for what in ("la", "pancreas"):
+        a, b = run(False, what), run(True, what)
+        for la_, lb_ in zip(a[0], b[0]):
+            assert abs(la_ - lb_) <= 2e-5 * abs(la_), (what, a[0], b[0])
+        for k in a[1]:
+            if a[1][k].dtype.is_floating_point:
+                d = float((a[1][k] - b[1][k]).abs().max())
+                assert d <= 2e-5 * max(float(a[1][k].abs().max()), 1e-3), (what, k, d)

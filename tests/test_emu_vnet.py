@@ -87,3 +87,8 @@ def test_recorded_launch_plans_equal_eager_path(emu_ops):
     from bcp_amd.utils import BCP_utils as BU
     BU.set_test_ops(emu_ops)
     NC.check_launch_plans(emu_ops, CPU, steps=2, cases=(("la", False),))      # unfused: plan + busy-plan fallback (all four workloads: the GPU suite)
+
+
+def test_head_fused_with_last_norm_equals_separate_apply(emu_ops):
+    """VNet.fuse_head: block_nine's norm + ReLU + Dropout3d applied inside the 1x1x1 head (its activation never stored)"""
+    NC.check_fused_head(emu_ops, CPU, steps=1)

@@ -159,3 +159,14 @@ def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
 def test_recorded_launch_plans_equal_eager_path(ops):
     """bcp_amd/plan.py: replayed passes == the eager Python path, bit for bit (LA grouped / unfused, pancreas, ACDC; live dropout)"""
     NC.check_launch_plans(ops, DEV)
+
+
+def test_graph_replays_equal_eager_path(ops):
+    """on a real stream the recorded passes are captured: hipGraphLaunch per network pass == the eager path, bit for bit"""
+    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True), ("acdc", True)), graphs=True)
+
+
+@pytest.mark.gpu
+def test_head_fused_with_last_norm_equals_separate_apply(ops):
+    """VNet.fuse_head: block_nine's norm + ReLU + Dropout3d applied inside the 1x1x1 head (its activation never stored)"""
+    NC.check_fused_head(ops, DEV)
