@@ -9,8 +9,9 @@ no shape arithmetic, no `torch.empty`, no wrapper layers (bench: host enqueue of
 What varies between passes lives in device memory: the Dropout3d / Dropout seeds (the recorded draws are `bcp_bernoulli_dev`
 launches reading the plan's seed table, which one `bcp_store_u64` launch refills from the network's seed stream before a replay)
 and the input, which is copied into the plan's static input buffer (one device copy).  So a recorded pass is a constant launch
-sequence -- and when the caller runs on a real (non-null) stream, the first replay runs under HIP stream capture and every later
-pass is ONE `hipGraphLaunch` (`bcp_graph_launch`), side-stream weight gradients included (event fork / join is captured).  Stream-ordering calls (`wait_stream`) and data-parallel bucket hooks are recorded as Python callables in
+sequence -- and when the caller runs on a real (non-null) stream, the first replay of a FORWARD pass runs under HIP stream capture
+and every later one is ONE `hipGraphLaunch` (`bcp_graph_launch`).  The backward pass captures too (event fork / join onto the
+weight-gradient side stream included; GRAPHS = 2) but is slower as a graph than as a replay -- see GRAPHS below.  Stream-ordering calls (`wait_stream`) and data-parallel bucket hooks are recorded as Python callables in
 place.  Weight packing is NOT recorded: it depends on the weights' version and runs eagerly before a replay.
 
 The reference has no counterpart (its host path is PyTorch's eager dispatch); this is the "launch plan" of VERDICT r01 item 4.
@@ -20,7 +21,12 @@ import contextlib
 import torch
 
 ENABLED = True          # module switch (tests compare a replayed step with an eager one)
-GRAPHS = True           # capture a plan's second pass in a HIP graph when the caller runs on a real (non-null) stream
+# Capture a plan's second pass in a HIP graph when the caller runs on a real (non-null) stream.  1: forward passes only; 2: also the
+# backward pass.  Measured on MI355X (LA step, same box, interleaved): per-launch replay 6.89 ms / host 2.6-3.0 ms; forward graphs
+# 6.90 ms / host 1.8-2.2 ms; forward + backward graphs 7.66-7.71 ms / host 1.5-1.8 ms -- inside a graph the weight-gradient branch no
+# longer overlaps the dgrad -> norm chain the way the side stream does, which costs more GPU time than the host saves (the step is
+# GPU-bound).  So the backward stays a per-launch replay.
+GRAPHS = 1
 _EPOCH = [0]            # bumped when library options change: every plan recorded before is dropped
 
 
@@ -34,7 +40,7 @@ def epoch():
 
 class LaunchPlan:
     __slots__ = ("entries", "keep", "n_seeds", "seed_dev", "static_in", "result", "ticks", "n_calls", "busy", "graph", "graph_state",
-                 "capturable", "_owner")
+                 "capturable", "n_py", "_owner")
 
     MAX_SEEDS = 16
 
@@ -51,6 +57,7 @@ class LaunchPlan:
         self.graph = None        # hipGraphExec_t of the captured pass (GRAPHS)
         self.graph_state = 0     # 0: capture not tried yet, 1: captured, -1: stays a per-launch replay
         self.capturable = True
+        self.n_py = 0            # stream-ordering entries: > 0 = the pass forks onto a side stream (backward: weight gradients)
         self._owner = None
 
     # called by Binding.call while recording
@@ -62,6 +69,7 @@ class LaunchPlan:
         """a Python callable in launch order: stream ordering (event record / wait: fine under stream capture) or, with
         capturable=False, something a graph must not swallow (the data-parallel bucket hook: it changes per step)"""
         self.entries.append([fn, list(args)])
+        self.n_py += 1
         if not capturable:
             self.capturable = False
 
@@ -87,7 +95,7 @@ class LaunchPlan:
         if self.graph is not None:
             b.call("bcp_graph_launch", self.graph, ops.stream(like))
             return
-        if self.graph_state == 0 and GRAPHS and self.capturable and like.is_cuda:
+        if self.graph_state == 0 and GRAPHS and self.capturable and like.is_cuda and (GRAPHS >= 2 or self.n_py == 0):
             self.graph_state = -1
             stream = ops.stream(like)
             if stream:                                   # the null stream cannot be captured: run the step on a real stream to get graphs

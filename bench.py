@@ -377,7 +377,7 @@ def main():
     for kv in args.opt:
         k, _, v = kv.partition("=")
         if k == "graphs":             # host-side switch (bcp_amd/plan.py)
-            plan.GRAPHS = bool(int(v))
+            plan.GRAPHS = int(v)
             continue
         if k == "fuse_head":          # host-side switch (networks/VNet.py), not a library option
             from bcp_amd.networks.VNet import VNet

@@ -930,6 +930,9 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
 
     def run_(enabled, what, grouped):
         plan.ENABLED = enabled
+        level0 = plan.GRAPHS
+        if graphs:
+            plan.GRAPHS = int(graphs)      # 1: forward passes (the default), 2: the backward pass with its side-stream fork / join too
         try:
             torch.manual_seed(5)
             np.random.seed(5)
@@ -961,10 +964,11 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
             if enabled and graphs:
                 assert steps >= 3
                 n_graph = sum(1 for p in plans if p.graph is not None)
-                assert n_graph >= 3, (what, grouped, [p.graph_state for p in plans])      # teacher forward, student forward, backward
+                assert n_graph >= 1 + int(graphs), (what, grouped, [p.graph_state for p in plans])      # teacher forward, student forward[, backward]
             return losses, {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}, {k: v.detach().clone().cpu() for k, v in ema.state_dict().items()}, n_plans
         finally:
             plan.ENABLED = True
+            plan.GRAPHS = level0
 
     for what, grouped in cases:
         a, b = run(False, what, grouped), run(True, what, grouped)

@@ -163,7 +163,8 @@ def test_recorded_launch_plans_equal_eager_path(ops):
 
 def test_graph_replays_equal_eager_path(ops):
     """on a real stream the recorded passes are captured: hipGraphLaunch per network pass == the eager path, bit for bit"""
-    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True), ("acdc", True)), graphs=True)
+    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True), ("acdc", True)), graphs=1)
+    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("acdc", True)), graphs=2)      # + the backward pass (not the default: plan.py)
 
 
 @pytest.mark.gpu
