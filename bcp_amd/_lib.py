@@ -99,9 +99,57 @@ _SIGS = {
     "bcp_graph_end_capture": (I, [P, C.POINTER(P)]),
     "bcp_graph_launch": (I, [P, P]),
     "bcp_graph_destroy": (I, [P]),
+    "bcp_replay_create": (I, [C.POINTER(P)]),
+    "bcp_replay_add": (I, [P, P, C.c_char_p, P, I]),
+    "bcp_replay_run": (I, [P]),
+    "bcp_replay_count": (I, [P]),
+    "bcp_replay_destroy": (I, [P]),
+    "bcp_stream_wait_stream": (I, [P, P]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGS.keys())
+
+
+def _arg_class(t):
+    if t is I:
+        return "i"
+    if t is L:
+        return "l"
+    if t is F:
+        return "f"
+    if t is C.c_double:
+        return "d"
+    if t is U64:
+        return "u"
+    if t is SZ:
+        return "z"
+    return "p"          # void*, char*, POINTER(...)
+
+
+def shape_of(name):
+    """argument-class string of an entry point ("ppplf..."): how bcp_replay_add (csrc/replay.hip) is told to call it"""
+    return "".join(_arg_class(t) for t in _SIGS[name][1])
+
+
+_PACK = {"i": "<q", "l": "<q", "p": "<Q", "u": "<Q", "z": "<Q", "d": "<d"}
+
+
+def pack_slots(shape, args):
+    """the 8-byte argument images bcp_replay_add copies (ints sign-extended, floats in the low four bytes)"""
+    import struct
+    out = bytearray()
+    for c, v in zip(shape, args):
+        if hasattr(v, "value"):          # a ctypes scalar / pointer object
+            v = v.value
+        if c == "f":
+            out += struct.pack("<fI", float(v), 0)
+        elif c == "d":
+            out += struct.pack("<d", float(v))
+        elif c in ("p", "u", "z"):
+            out += struct.pack("<Q", int(v or 0) & 0xFFFFFFFFFFFFFFFF)
+        else:
+            out += struct.pack("<q", int(v))
+    return bytes(out)
 
 
 class BcpError(RuntimeError):
@@ -123,7 +171,7 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
         self._rec = None          # a bcp_amd.plan.LaunchPlan while a network pass is being recorded
 

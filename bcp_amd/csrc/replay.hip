@@ -1,0 +1,101 @@
+// Launch-plan replay in C: a recorded network pass (bcp_amd/plan.py) is a constant list of C-ABI calls; bcp_replay_run walks it with
+// one call from the host language instead of one foreign-function call per launch.  Also the stream fork / join the backward pass
+// uses for its weight-gradient side stream, so that the whole pass -- ordering included -- lives in the list.
+// No reference counterpart: the reference's host path is PyTorch's eager dispatch.
+#include <cstring>
+#include <vector>
+
+#include "common.h"
+
+namespace bcp {
+
+union Slot {
+  void* p;
+  long long l;
+  int i;
+  float f;
+  double d;
+  unsigned long long u;
+  size_t z;
+};
+static_assert(sizeof(Slot) == 8, "argument images are 8 bytes");
+
+typedef int (*Caller)(void* fn, const Slot* a);
+
+#define BCP_SHAPE(name, types, args) \
+  static int call_##name(void* fn, const Slot* a) { return reinterpret_cast<int(*) types>(fn) args; }
+#include "replay_shapes.inc"
+#undef BCP_SHAPE
+
+struct ShapeRow { const char* name; Caller call; };
+static const ShapeRow kShapes[] = {
+#define BCP_SHAPE(name, types, args) {#name, &call_##name},
+#include "replay_shapes.inc"
+#undef BCP_SHAPE
+};
+
+constexpr int kMaxArgs = 24;
+struct Entry {
+  Caller call;
+  void* fn;
+  Slot a[kMaxArgs];
+};
+struct Replay { std::vector<Entry> e; };
+
+// events for bcp_stream_wait_stream: a wait takes the state of the event's LAST record at the time of the call, so a small ring
+// can be re-recorded freely
+constexpr int kEvRing = 64;
+static hipEvent_t g_ev[kEvRing];
+static int g_ev_next = 0;
+static bool g_ev_ready = false;
+
+}  // namespace bcp
+
+extern "C" int bcp_replay_create(void** h) {
+  BCP_REQUIRE(h, "bcp_replay_create: null");
+  *h = new bcp::Replay();
+  return BCP_OK;
+}
+
+extern "C" int bcp_replay_add(void* h, void* fn, const char* shape, const void* slots, int nargs) {
+  BCP_REQUIRE(h && fn && shape && (slots || nargs == 0), "bcp_replay_add: null");
+  BCP_REQUIRE(nargs >= 0 && nargs <= bcp::kMaxArgs && (int)strlen(shape) == nargs, "bcp_replay_add: %d arguments for shape \"%s\"", nargs, shape);
+  bcp::Entry e{};
+  for (const bcp::ShapeRow& r : bcp::kShapes)
+    if (!strcmp(r.name, shape)) { e.call = r.call; break; }
+  BCP_REQUIRE(e.call, "bcp_replay_add: no caller for the argument shape \"%s\" (regenerate csrc/replay_shapes.inc: tools/gen_replay_shapes.py)", shape);
+  e.fn = fn;
+  if (nargs) memcpy(e.a, slots, (size_t)nargs * sizeof(bcp::Slot));
+  static_cast<bcp::Replay*>(h)->e.push_back(e);
+  return BCP_OK;
+}
+
+extern "C" int bcp_replay_count(void* h) { return h ? (int)static_cast<bcp::Replay*>(h)->e.size() : 0; }
+
+extern "C" int bcp_replay_run(void* h) {
+  BCP_REQUIRE(h, "bcp_replay_run: null");
+  for (const bcp::Entry& e : static_cast<bcp::Replay*>(h)->e)
+    if (const int rc = e.call(e.fn, e.a)) return rc;        // the failing entry point has set the error text
+  return BCP_OK;
+}
+
+extern "C" int bcp_replay_destroy(void* h) {
+  delete static_cast<bcp::Replay*>(h);
+  return BCP_OK;
+}
+
+// `waiter` does not run past this point before everything enqueued on `signaller` so far has finished
+extern "C" int bcp_stream_wait_stream(void* waiter, void* signaller) {
+  if (waiter == signaller) return BCP_OK;
+  if (!bcp::g_ev_ready) {
+    for (int i = 0; i < bcp::kEvRing; ++i)
+      if (hipEventCreateWithFlags(&bcp::g_ev[i], hipEventDisableTiming) != hipSuccess) { bcp::set_error("hipEventCreateWithFlags failed"); return BCP_ELAUNCH; }
+    bcp::g_ev_ready = true;
+  }
+  hipEvent_t ev = bcp::g_ev[bcp::g_ev_next];
+  bcp::g_ev_next = (bcp::g_ev_next + 1) % bcp::kEvRing;
+  hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
+  if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+  if (e != hipSuccess) { bcp::set_error("bcp_stream_wait_stream: %s", hipGetErrorString(e)); return BCP_ELAUNCH; }
+  return BCP_OK;
+}

@@ -350,10 +350,11 @@ class HipNet(nn.Module):
             side = self.net._side_streams.get(t.device)
             if side is None:
                 side = self.net._side_streams[t.device] = torch.cuda.Stream(device=t.device)
-            side.wait_stream(main)                 # dy (and the zeroed gradient buffer) are ready
-            rec = self.net.ops.b._rec
-            if rec is not None:
-                rec.add_py(side.wait_stream, main)     # (a replayed pass works on static tensors: no record_stream)
+            b = self.net.ops.b
+            if b._rec is not None:                 # recorded pass: the fork is an entry of the launch list (bcp_stream_wait_stream)
+                b.call("bcp_stream_wait_stream", side.cuda_stream, main.cuda_stream)
+            else:
+                side.wait_stream(main)             # dy (and the zeroed gradient buffer) are ready
             for x in self.tensors:
                 x.record_stream(side)              # keep the allocator from recycling them under the side stream
             self.ctx = torch.cuda.stream(side)
@@ -376,10 +377,10 @@ class HipNet(nn.Module):
             side = self._side_streams.get(like.device)
             if side is not None:
                 main = torch.cuda.current_stream(like.device)
-                main.wait_stream(side)
-                rec = self.ops.b._rec
-                if rec is not None:
-                    rec.add_py(main.wait_stream, side)
+                if self.ops.b._rec is not None:
+                    self.ops.b.call("bcp_stream_wait_stream", main.cuda_stream, side.cuda_stream)
+                else:
+                    main.wait_stream(side)
 
     # ---- data parallelism: bucketed gradient all-reduce underneath the rest of the backward pass (bcp_amd/dp.py).
     # The backward walks the layers in reverse registration order, so once layer L is done the flat gradient buffer is final

@@ -27,6 +27,7 @@ ENABLED = True          # module switch (tests compare a replayed step with an e
 # longer overlaps the dgrad -> norm chain the way the side stream does, which costs more GPU time than the host saves (the step is
 # GPU-bound).  So the backward stays a per-launch replay.
 GRAPHS = 1
+C_REPLAY = True         # replay runs of recorded launches from C (bcp_replay_run: one foreign call per run); False: one ctypes call per launch
 _EPOCH = [0]            # bumped when library options change: every plan recorded before is dropped
 
 
@@ -40,12 +41,12 @@ def epoch():
 
 class LaunchPlan:
     __slots__ = ("entries", "keep", "n_seeds", "seed_dev", "static_in", "result", "ticks", "n_calls", "busy", "graph", "graph_state",
-                 "capturable", "n_py", "_owner")
+                 "capturable", "forks", "_owner", "segs", "_handles")
 
     MAX_SEEDS = 16
 
     def __init__(self):
-        self.entries = []        # [callable, [args...]]
+        self.entries = []        # [callable, [args...], entry-point name | None for a Python callable]
         self.keep = []           # every tensor allocated while recording (pointers inside `entries` refer to them)
         self.n_seeds = 0         # Dropout3d / Dropout draws of the pass; their seeds live in `seed_dev` (device memory) so that the
         self.seed_dev = None     #   recorded launches -- and a graph captured from them -- never change: bcp_bernoulli_dev
@@ -57,19 +58,22 @@ class LaunchPlan:
         self.graph = None        # hipGraphExec_t of the captured pass (GRAPHS)
         self.graph_state = 0     # 0: capture not tried yet, 1: captured, -1: stays a per-launch replay
         self.capturable = True
-        self.n_py = 0            # stream-ordering entries: > 0 = the pass forks onto a side stream (backward: weight gradients)
+        self.forks = False       # the pass forks onto a side stream (backward: weight gradients)
         self._owner = None
+        self.segs = None         # compiled form of `entries` (compile)
+        self._handles = []
 
     # called by Binding.call while recording
     def add_call(self, name, fn, args):
-        self.entries.append([fn, list(args)])
+        self.entries.append([fn, list(args), name])
         self.n_calls += 1
+        if name == "bcp_stream_wait_stream":
+            self.forks = True
 
     def add_py(self, fn, *args, capturable=True):
-        """a Python callable in launch order: stream ordering (event record / wait: fine under stream capture) or, with
-        capturable=False, something a graph must not swallow (the data-parallel bucket hook: it changes per step)"""
-        self.entries.append([fn, list(args)])
-        self.n_py += 1
+        """a Python callable in launch order; capturable=False: something a graph must not swallow (the data-parallel bucket
+        hook: it changes per step).  Stream ordering is NOT one of these: it is a recorded bcp_stream_wait_stream launch."""
+        self.entries.append([fn, list(args), None])
         if not capturable:
             self.capturable = False
 
@@ -81,8 +85,31 @@ class LaunchPlan:
         self.n_seeds += 1
         return self.seed_dev.data_ptr() + 8 * (self.n_seeds - 1)
 
+    def compile(self, b):
+        """runs of consecutive C-ABI launches -> one bcp_replay_run each (csrc/replay.hip); Python callables stay in between"""
+        import ctypes as C
+        from . import _lib
+        segs, cur = [], None
+        run = b._fns["bcp_replay_run"][0]
+        for fn, args, name in self.entries:
+            if name is None or not C_REPLAY:
+                cur = None
+                segs.append((fn, args))
+                continue
+            if cur is None:
+                cur = C.c_void_p()
+                if b.cdll.bcp_replay_create(C.byref(cur)):
+                    raise _lib.BcpError(b.last_error())
+                self._handles.append(cur)
+                self._owner = b
+                segs.append((run, [cur]))
+            shape = _lib.shape_of(name)
+            if b.cdll.bcp_replay_add(cur, C.cast(fn, C.c_void_p), shape.encode(), _lib.pack_slots(shape, args), len(args)):
+                raise _lib.BcpError(f"{name}: {b.last_error()}")
+        self.segs = segs
+
     def run_entries(self, check):
-        for fn, args in self.entries:
+        for fn, args in self.segs:
             rc = fn(*args)
             if rc:
                 check(rc)
@@ -90,12 +117,14 @@ class LaunchPlan:
     def replay(self, ops, seeds, like):
         """one pass: refresh the seeds, then either the captured graph (one call) or the recorded launches one by one"""
         b = ops.b
+        if self.segs is None:
+            self.compile(b)
         if self.n_seeds:
             ops.store_u64(self.seed_dev, seeds, like)
         if self.graph is not None:
             b.call("bcp_graph_launch", self.graph, ops.stream(like))
             return
-        if self.graph_state == 0 and GRAPHS and self.capturable and like.is_cuda and (GRAPHS >= 2 or self.n_py == 0):
+        if self.graph_state == 0 and GRAPHS and self.capturable and like.is_cuda and (GRAPHS >= 2 or not self.forks):
             self.graph_state = -1
             stream = ops.stream(like)
             if stream:                                   # the null stream cannot be captured: run the step on a real stream to get graphs
@@ -109,11 +138,13 @@ class LaunchPlan:
 
     def __del__(self):
         g, b = getattr(self, "graph", None), getattr(self, "_owner", None)
-        if g is not None and b is not None:
-            try:
+        try:
+            if g is not None and b is not None:
                 b.cdll.bcp_graph_destroy(g)
-            except Exception:
-                pass
+            for h in getattr(self, "_handles", ()):
+                b.cdll.bcp_replay_destroy(h)
+        except Exception:
+            pass
 
 
 def _capture(pl, b, stream):

@@ -232,6 +232,19 @@ int bcp_graph_end_capture(void* stream, void** graph_exec);
 int bcp_graph_launch(void* graph_exec, void* stream);
 int bcp_graph_destroy(void* graph_exec);
 
+/* ---- launch-plan replay in C (no reference counterpart).  A recorded network pass is a constant list of calls to the entry points
+ * above: bcp_replay_add appends one -- fn = the entry point's address, shape = its argument classes, one character each (p pointer,
+ * i int, l long long, f float, d double, u unsigned long long, z size_t), slots = nargs 8-byte argument images (HOST pointer, copied:
+ * ints sign-extended, floats in the low four bytes) -- and bcp_replay_run makes the calls in order, returning the first non-zero
+ * status.  Shapes outside csrc/replay_shapes.inc (generated from the binding table) are refused with BCP_EUNSUP-style errors. */
+int bcp_replay_create(void** handle);
+int bcp_replay_add(void* handle, void* fn, const char* shape, const void* slots, int nargs);
+int bcp_replay_count(void* handle);
+int bcp_replay_run(void* handle);
+int bcp_replay_destroy(void* handle);
+/* stream ordering inside such a list: `waiter` waits for everything enqueued on `signaller` so far (event record + wait; capturable) */
+int bcp_stream_wait_stream(void* waiter, void* signaller);
+
 /* ---- data-parallel gradient exchange: all-reduce (sum, in place) of the flat fp32 gradient buffer over RCCL /
  *      xGMI.  No reference counterpart for LA / ACDC (its only multi-GPU code is nn.DataParallel, pancreas/dataloaders.py:14);
  *      this is the exchange a one-process-per-GPU run needs between loss.backward() and optimizer.step()

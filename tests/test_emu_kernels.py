@@ -61,3 +61,36 @@ def test_pancreas_loader_streams(emu_ops):
     rv = SyntheticPancreas("train_unlab", "cpu", 2, reverse=True)
     assert torch.equal(st[3][0][0], rv[0][0]) and torch.equal(rv[0][0], ds[1][0])   # unlab_b walks the list backwards
     assert len(SyntheticPancreas("train_lab", "cpu", 2)) == 20 and len(SyntheticPancreas("train_lab", "cpu", 2, labelp=20)) == 10
+
+
+def test_replay_shapes_table_is_current():
+    """bcp_amd/csrc/replay_shapes.inc is generated from the binding table: a changed signature must regenerate it"""
+    import subprocess, sys
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "gen_replay_shapes.py"), "--check"]) == 0
+
+
+def test_replay_list_calls_with_typed_arguments(emu_ops):
+    """bcp_replay_add / bcp_replay_run (csrc/replay.hip): pointer, long long, int, float and double arguments arrive intact, calls run
+    in order, an unknown shape and a failing entry are reported"""
+    import ctypes as C
+    b = emu_ops.b
+    y, x = torch.arange(8, dtype=torch.float32), torch.ones(8)
+    p, q = torch.zeros(8), torch.full((8,), 2.0)
+    h = C.c_void_p()
+    assert b.cdll.bcp_replay_create(C.byref(h)) == 0
+    for name, args in (("bcp_axpy", (y.data_ptr(), x.data_ptr(), 8, 0.5, None)),          # y += 0.5 x        (p p l f p)
+                       ("bcp_axpy", (y.data_ptr(), x.data_ptr(), 8, -0.25, None)),        # y -= 0.25 x
+                       ("bcp_ema", (p.data_ptr(), q.data_ptr(), 8, 0.75, None))):         # p = .75 p + .25 q  (p p l d p)
+        shape = _lib.shape_of(name)
+        fn = b._fns[name][0]
+        assert b.cdll.bcp_replay_add(h, C.cast(fn, C.c_void_p), shape.encode(), _lib.pack_slots(shape, args), len(args)) == 0
+    assert b.cdll.bcp_replay_count(h) == 3
+    assert b.cdll.bcp_replay_run(h) == 0
+    assert torch.equal(y, torch.arange(8, dtype=torch.float32) + 0.25) and torch.equal(p, torch.full((8,), 0.5))
+    assert b.cdll.bcp_replay_run(h) == 0
+    assert torch.equal(y, torch.arange(8, dtype=torch.float32) + 0.5) and torch.equal(p, torch.full((8,), 0.875))
+    assert b.cdll.bcp_replay_add(h, C.cast(b._fns["bcp_axpy"][0], C.c_void_p), b"pq", b"\0" * 16, 2) != 0 and "shape" in b.last_error()
+    bad = _lib.pack_slots("pplfp", (0, 0, 8, 1.0, None))                                 # null tensors: bcp_axpy refuses
+    assert b.cdll.bcp_replay_add(h, C.cast(b._fns["bcp_axpy"][0], C.c_void_p), b"pplfp", bad, 5) == 0
+    assert b.cdll.bcp_replay_run(h) != 0
+    b.cdll.bcp_replay_destroy(h)

@@ -7,7 +7,7 @@ OUT="$ROOT/tests/_emu"
 mkdir -p "$OUT"
 CXX=/opt/rocm/lib/llvm/bin/clang++
 [ -x "$CXX" ] || CXX=clang++
-SRCS="api elementwise loss norm conv3 conv3b conv3bw gemm cc pool2d eval comm"
+SRCS="api elementwise loss norm conv3 conv3b conv3bw gemm cc pool2d eval comm replay"
 OBJS=""
 for s in $SRCS; do
   $CXX -x c++ -O2 -std=c++17 -fPIC -w -I "$ROOT/tools/emu" -c "$ROOT/bcp_amd/csrc/$s.hip" -o "$OUT/$s.o" &

@@ -63,6 +63,9 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+enum { hipEventDisableTiming = 2 };
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = nullptr; return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 // HIP graphs do not exist on the host simulator: capture reports failure and the caller keeps its per-launch replay
 typedef void* hipGraph_t;
 typedef void* hipGraphExec_t;
