@@ -97,6 +97,10 @@ def _work(name, shapes, ints):
         return "hbm", 0.0, 4.0 * (_numel(s0) + _numel(s0[:-1]) * (ints[0] if ints else 2))
     if name == "pw16_bwd":
         return "hbm", 0.0, 4.0 * (2 * _numel(s0) + _numel(shapes[1]))
+    if name == "pw16_fwd_norm":                            # (y_raw, stats, [chan_scale]); ints = (G, act, Cout): read y, write logits
+        return "hbm", 0.0, 4.0 * (_numel(s0) + _numel(s0[:-1]) * (ints[2] if len(ints) > 2 else 2))
+    if name == "pw16_bwd_norm":                            # read y and dlogits, write d(activation)
+        return "hbm", 0.0, 4.0 * (2 * _numel(s0) + _numel(s0[:-1]) * 2)
     if name == "mixloss_fwd":
         return "hbm", 0.0, _numel(s0) * 4.0 + 2.0 * _numel(s0[:-1])
     if name == "mixloss_bwd":

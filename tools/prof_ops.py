@@ -79,6 +79,8 @@ run("k2_wgrad[2x112x112x80x16]", lambda: ops.k2_wgrad(y16, yd, dwd, H.WG_DOWN), 
 wo = torch.randn(2, 16, 1, 1, 1, device=dev)
 lo = torch.empty(N, *sp, 2, device=dev)
 run("pw16_fwd[2x112x112x80x16]", lambda: ops.pw16_fwd(y16, wo, None, 2, out=lo), {"flop": 0, "bytes": 4.0 * (y16.numel() + lo.numel())})
+st16 = ops.norm_fwd(y16, N, None, None, None, None, H.ACT_RELU, stats_only=True)[1]
+run("pw16_fwd_norm[2x112x112x80x16]", lambda: ops.pw16_fwd_norm(y16, st16, None, N, H.ACT_RELU, wo, None, 2, out=lo), {"flop": 0, "bytes": 4.0 * (y16.numel() + lo.numel())})
 la = (torch.rand(N, *sp, device=dev) > 0.9).to(torch.uint8)
 box = (10, 20, 5, 74, 74, 53)
 ws3 = [None]
