@@ -64,9 +64,16 @@ def load_net_opt(net, optimizer, path):
 
 
 def _loader(args, device):
-    db = SyntheticACDC(num=1312, shape=tuple(args.patch_size), device=device, seed=args.seed,
-                       transform=DeviceRandomGenerator(args.patch_size) if args.augment else None,   # RandomGenerator (:209-211)
-                       raw_shape=(216, 248))
+    """BaseDataSets(split='train') over --root_path when its train_slices.list exists (h5 slices read once into a device-resident
+    cache, dataloaders/h5_datasets.py), synthetic slices otherwise (:209-224)"""
+    if os.path.exists(os.path.join(args.root_path, "train_slices.list")):
+        from bcp_amd.dataloaders.h5_datasets import BaseDataSets
+        db = BaseDataSets(base_dir=args.root_path, split="train", num=None, transform=DeviceRandomGenerator(args.patch_size), device=device)
+    else:
+        logging.info("no {}/train_slices.list: synthetic ACDC-like slices".format(args.root_path))
+        db = SyntheticACDC(num=1312, shape=tuple(args.patch_size), device=device, seed=args.seed,
+                           transform=DeviceRandomGenerator(args.patch_size) if args.augment else None,   # RandomGenerator (:209-211)
+                           raw_shape=(216, 248))
     n_labeled = patients_to_slices(args.root_path, args.labelnum)
     sampler = TwoStreamBatchSampler(list(range(n_labeled)), list(range(n_labeled, len(db))), args.batch_size, args.batch_size - args.labeled_bs)
     return db, sampler

@@ -73,10 +73,16 @@ def _optimizer(args, model):
 
 
 def _data(args, device):
-    """the labeled / unlabeled two-stream sampler over the (synthetic) training cases (:137-147)"""
-    db = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed,
-                     transform=DeviceRotFlipCrop(patch_size) if args.augment else None,     # RandomRotFlip -> RandomCrop -> ToTensor (:122-126)
-                     raw_shape=(patch_size[0] + 12, patch_size[1] + 10, patch_size[2] + 8))
+    """the labeled / unlabeled two-stream sampler over the training cases (:137-147): the LA h5 set under --root_path when its
+    train.list exists (read once into a device-resident cache, dataloaders/h5_datasets.py), synthetic cases otherwise"""
+    if os.path.exists(os.path.join(args.root_path, "train.list")):
+        from bcp_amd.dataloaders.h5_datasets import LAHeart
+        db = LAHeart(base_dir=args.root_path, split="train", num=args.max_samples, transform=DeviceRotFlipCrop(patch_size), device=device)
+    else:
+        logging.info("no {}/train.list: synthetic LA-like cases".format(args.root_path))
+        db = SyntheticLA(num=args.max_samples, shape=patch_size, device=device, seed=args.seed,
+                         transform=DeviceRotFlipCrop(patch_size) if args.augment else None,     # RandomRotFlip -> RandomCrop -> ToTensor (:122-126)
+                         raw_shape=(patch_size[0] + 12, patch_size[1] + 10, patch_size[2] + 8))
     labeled, unlabeled = list(range(args.labelnum)), list(range(args.labelnum, args.max_samples))
     sampler = TwoStreamBatchSampler(labeled, unlabeled, args.batch_size, args.batch_size - args.labeled_bs)
     logging.info("{} iterations per epoch".format(len(sampler)))

@@ -1,8 +1,8 @@
 """Device-side counterparts of the transforms in the reference's code/pancreas/dataloaders.py (:22-100): RandomCrop / CenterCrop /
 ToTensor on a device-resident case.  The random draws come from np.random in the reference's order (w1, h1, d1 on the padded
 shape); the data movement is ONE gather kernel per tensor (csrc/eval.hip k_crop_rotflip with k = 0, flip_axis = -1) -- no host
-copy of the volume, no padded intermediate.  The h5 readers / file lists of the reference's `Pancreas` dataset are out of scope
-(the synthetic cases already live in HBM)."""
+copy of the volume, no padded intermediate.  `Pancreas` reads the reference's case files (h5, through
+dataloaders/h5_datasets.read_h5) into a device-resident cache; `SyntheticPancreas` stands in when no file list exists."""
 import numpy as np
 import torch
 
@@ -94,3 +94,40 @@ class SyntheticPancreas:
         j = (n - idx % n - 1) if self.reverse else idx % n
         image, label = self.to_tensor(self.crop([self.vols[j], self.labs8[j]]))
         return image, label
+
+
+def get_dataset_path(list_dir, dataset="pancreas", labelp="10percent"):
+    """:103-106 -- the three list files of a split; the reference hard-codes its own home directory, here it is an argument"""
+    return ["/".join([str(list_dir), dataset, labelp, f]) for f in ("train_lab.txt", "train_unlab.txt", "test.txt")]
+
+
+class Pancreas:
+    """the reference's `Pancreas` dataset (:110-170) over a device-resident cache: list file per split, `<base_dir>/<line>` case
+    paths, split -> transform (train_lab: RandomCrop(96^3); train_unlab / test: CenterCrop(96^3)), `reverse` indexing, the
+    `__len__` multipliers of the labeled split (x10 at 10 %, x5 at 20 %).  Returns (image [1,96,96,96] float32, label uint8)."""
+
+    def __init__(self, base_dir, name, split, no_crop=False, labelp=10, reverse=False, TTA=False, list_dir=None, device="cpu",
+                 patch=(96, 96, 96)):
+        from ..dataloaders.h5_datasets import _DeviceCache, _lines
+        self._base_dir = str(base_dir)
+        self.split, self.reverse = split, reverse
+        self.labelp = "20percent" if labelp == 20 else "10percent"
+        paths = get_dataset_path(list_dir if list_dir is not None else self._base_dir, name, self.labelp)
+        data_path = paths[0] if split == "train_lab" else (paths[1] if split == "train_unlab" else paths[2])
+        self.crop = RandomCrop(patch) if split == "train_lab" else CenterCrop(patch)
+        self.to_tensor = ToTensor()
+        self.image_list = [self._base_dir + "/{}".format(item) for item in _lines(data_path)]
+        self._cache = _DeviceCache(device)
+        print("Split : {}, total {} samples".format(split, len(self.image_list)))
+
+    def __len__(self):
+        if self.split == "train_lab":
+            return len(self.image_list) * (5 if self.labelp == "20percent" else 10)
+        return len(self.image_list)
+
+    def __getitem__(self, idx):
+        n = len(self.image_list)
+        path = self.image_list[n - idx % n - 1] if self.reverse else self.image_list[idx % n]
+        image, label = self._cache.get(path)
+        image_, label_ = self.to_tensor(self.crop([image, label]))
+        return image_, label_

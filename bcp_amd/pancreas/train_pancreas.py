@@ -41,10 +41,14 @@ class _LoaderStreams:
     forwards / reversed with RandomCrop(96^3); unlab_a, unlab_b = the unlabeled list forwards / reversed with CenterCrop) over
     device-resident synthetic cases -- every call draws the next batch of each and crops it on the device."""
 
-    def __init__(self, device, bs, n_cases=4):
-        from bcp_amd.pancreas.dataloaders import SyntheticPancreas
-        self.sets = [SyntheticPancreas("train_lab", device, n_cases), SyntheticPancreas("train_lab", device, n_cases, reverse=True),
-                     SyntheticPancreas("train_unlab", device, n_cases), SyntheticPancreas("train_unlab", device, n_cases, reverse=True)]
+    def __init__(self, device, bs, n_cases=4, data_root=None, list_dir=None, split_name="pancreas", labelp=10):
+        from bcp_amd.pancreas.dataloaders import Pancreas, SyntheticPancreas
+        if data_root and list_dir:        # the reference's h5 cases, read once into a device-resident cache (:185-195)
+            mk = lambda split, rev: Pancreas(data_root, split_name, split=split, labelp=labelp, reverse=rev, list_dir=list_dir, device=device)
+            self.sets = [mk("train_lab", False), mk("train_lab", True), mk("train_unlab", False), mk("train_unlab", True)]
+        else:
+            self.sets = [SyntheticPancreas("train_lab", device, n_cases), SyntheticPancreas("train_lab", device, n_cases, reverse=True),
+                         SyntheticPancreas("train_unlab", device, n_cases), SyntheticPancreas("train_unlab", device, n_cases, reverse=True)]
         self.bs, self.at = bs, 0
 
     def __call__(self):
@@ -107,6 +111,9 @@ def main(argv=None):
     ap.add_argument("--val_cases", type=int, default=1)
     ap.add_argument("--val_stride", type=int, nargs=2, default=[18, 4], help="sliding-window strides (xy, z); test_calculate_metric's defaults")
     ap.add_argument("--result_dir", type=str, default="result/cutmix")
+    ap.add_argument("--data_root", type=str, default="", help="directory of the pancreas h5 cases (the reference's data_root, train_pancreas.py:41); with --list_dir: train on them")
+    ap.add_argument("--list_dir", type=str, default="", help="directory holding <split_name>/<10|20>percent/{train_lab,train_unlab,test}.txt (the reference hard-codes its own, pancreas/dataloaders.py:103-106)")
+    ap.add_argument("--labelp", type=int, default=10)
     ap.add_argument("--device_input_pipeline", type=int, default=0, help="1: draw every batch from the four loader streams of the reference (RandomCrop / CenterCrop to 96^3, pancreas/dataloaders.py) with the crops done on the device")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, stream=sys.stdout)
@@ -117,7 +124,10 @@ def main(argv=None):
     net, ema_net = create_Vnet(), create_Vnet(ema=True)
     ema_net.load_state_dict(net.state_dict())
     optimizer = train_step.FlatAdam(net, lr=lr)
-    streams = _LoaderStreams(device, args.batch_size) if args.device_input_pipeline else _streams(device, 4, args.batch_size)
+    if args.data_root and args.list_dir:
+        streams = _LoaderStreams(device, args.batch_size, data_root=args.data_root, list_dir=args.list_dir, labelp=args.labelp)
+    else:
+        streams = _LoaderStreams(device, args.batch_size) if args.device_input_pipeline else _streams(device, 4, args.batch_size)
     val = _val_set(device, args.val_cases) if args.val_every else None
     pre_dir, st_dir = Path(args.result_dir) / "pretrain", Path(args.result_dir) / "self_train"
     if val is not None:
