@@ -17,6 +17,7 @@ static constexpr int XSW = 20;   // measured: 16 (conflict-free b32 reads) is 6 
 template <int KD, int TD, int TH, int TW>
 struct Tile {
   static constexpr int M = TD * TH * TW;
+  static constexpr int TD_ = TD, TH_ = TH, TW_ = TW;
   static constexpr int MT = M / 64;
   static constexpr int PD = (KD == 3) ? 1 : 0;
   static constexpr int HD = TD + 2 * PD, HH = TH + 2, HW = TW + 2;

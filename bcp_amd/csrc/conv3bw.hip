@@ -43,6 +43,17 @@ __device__ __forceinline__ bf16x4 ds_read_tr16(const unsigned short* p) {
 #endif
 __device__ __forceinline__ bf16x8 cat8(bf16x4 lo, bf16x4 hi) { return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7); }
 
+template <class TL>
+constexpr int w6_voff(int m) {                       // Tile::voff as a constant expression
+  return ((m / (TL::TW_ * TL::TH_)) * TL::HH + (m / TL::TW_) % TL::TH_) * TL::HW + m % TL::TW_;
+}
+template <class TL>
+constexpr bool w6_voff_linear() {
+  for (int m = 0; m < TL::M; ++m)
+    if (w6_voff<TL>(m) != w6_voff<TL>(m % 32) + (m / 32) * w6_voff<TL>(32)) return false;
+  return true;
+}
+
 template <int KD, int TD, int TH, int TW, int NT>
 __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ partial,
                                             ConvDims cd, int tiles_total, int tiles_per_group) {
@@ -74,15 +85,19 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
 
   // per-lane source addresses of the transposed reads: lane (li, lg) points at voxel r*16 + lg*4 + (li >> 2) of K block kb,
   // channel quad li & 3
-  int xo[KB][2], yo[KB][2];
+  // A K block is 32 consecutive tile voxels and every tile shape used here has 32 | TW * TH (or, 2-D, 32 = two W rows), so the
+  // halo offset of voxel kb * 32 + j is voff(j) + kb * voff(32): two base addresses per operand and a constant step -- no
+  // per-block address table (indexed by the runtime kb it lived in scratch memory for the TW = 4 tiles: two scratch loads at the
+  // head of every K block, on the critical path of the LDS reads).
+  constexpr int XSTEP = w6_voff<TL>(32) * 16, YSTEP = 32 * YS;
+  static_assert(w6_voff_linear<TL>(), "k_w6: halo offsets must be linear in the K block");
+  int xo[2], yo[2];
 #pragma unroll
-  for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int m = kb * 32 + r * 16 + lg * 4 + (li >> 2);
-      xo[kb][r] = TL::voff(m) * 16 + (li & 3) * 4;
-      yo[kb][r] = m * YS + (li & 3) * 4;
-    }
+  for (int r = 0; r < 2; ++r) {
+    const int m = r * 16 + lg * 4 + (li >> 2);
+    xo[r] = TL::voff(m) * 16 + (li & 3) * 4;
+    yo[r] = m * YS + (li & 3) * 4;
+  }
   int toff[TPW];                                     // halo row offset of this wave's taps (a slot past T recomputes tap 0: never stored)
 #pragma unroll
   for (int t = 0; t < TPW; ++t) {
@@ -144,18 +159,20 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
     fetch(has_next ? tile + 1 : tile);       // (the last tile re-reads itself: no conditional load in the loop)
 #pragma unroll 1
     for (int kb = 0; kb < KB; ++kb) {
+      const unsigned short* Yk = Yb + kb * YSTEP;
+      const unsigned short* Xk = Xb + kb * XSTEP;
       bf16x8 b[NT][3];
 #pragma unroll
       for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          b[nt][s] = cat8(ds_read_tr16(Yb + s * YPLANE + yo[kb][0] + nt * 16), ds_read_tr16(Yb + s * YPLANE + yo[kb][1] + nt * 16));
+          b[nt][s] = cat8(ds_read_tr16(Yk + s * YPLANE + yo[0] + nt * 16), ds_read_tr16(Yk + s * YPLANE + yo[1] + nt * 16));
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
         bf16x8 a[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
-          a[s] = cat8(ds_read_tr16(Xb + s * XPLANE + xo[kb][0] + toff[t]), ds_read_tr16(Xb + s * XPLANE + xo[kb][1] + toff[t]));
+          a[s] = cat8(ds_read_tr16(Xk + s * XPLANE + xo[0] + toff[t]), ds_read_tr16(Xk + s * XPLANE + xo[1] + toff[t]));
         // rows = input channels (A = X^T fragment), columns = output channels (B = dY fragment); smallest terms first
 #define BCP_W6(I, J)                                                                                                   \
   _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                      \
