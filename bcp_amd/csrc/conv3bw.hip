@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
   for (;;) {
     const bool has_next = tile + 1 < t_end;
     fetch(has_next ? tile + 1 : tile);       // (the last tile re-reads itself: no conditional load in the loop)
-#pragma unroll 1
+#pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const unsigned short* Yk = Yb + kb * YSTEP;
       const unsigned short* Xk = Xb + kb * XSTEP;
