@@ -723,10 +723,18 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * tps, gy = cd.Cout16 / CT;
   const int nch = cd.Cin16 / 16;
+  // split-K over the cin chunks: a deep-level workgroup's life is a serial chain of weight stages (one barrier per tap pair), so the
+  // chain is cut as short as the grid allows -- the largest power of two (<= 8, >= 2 chunks per workgroup) that keeps the launch
+  // within the 512 co-resident workgroup slots; measured alone (fwd + statistics, us): 256 channels batch 2 / 4: 31.3 -> 25.8 /
+  // 40.7 -> 34.3 (with 64-channel slabs at batch 4); 128 channels batch 4: 67.2 -> 59.4 (split 2: 496 workgroups instead of 992)
   int sk = 1;
   const bool ws_fits = ws && (long long)cd.N * V * cd.Cout <= (1LL << 20);
-  if (ws_fits && (long long)gx * gy <= 256 && nch >= 4) { sk = nch / 2; if (sk > 4) sk = 4; }
+  if (ws_fits && nch >= 4) {
+    const int cap = nch / 2 < 8 ? nch / 2 : 8;
+    while (sk * 2 <= cap && (long long)gx * gy * sk * 2 <= 512) sk *= 2;
+  }
   { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
+  { const int f = options().conv3_b6_flat_sk; if (ws_fits && f >= 1 && f <= 8 && f <= nch) sk = f; }      // measurement override
   StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
   const bool stats_ok = sk == 1 && G > 0 && cd.N % G == 0;        // tiles are sample-major and never straddle samples
   if (stats_ok) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
@@ -773,8 +781,11 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
           else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
           else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
         } else if (o.conv3_b6_flat && 64 + 2 * (cd.H * cd.W + cd.W + 1) <= kB6FlatAvMax) {
-          // flat 64-voxel tiles; narrower slabs for the smallest volumes (7x7x5: 8 tiles) so that the grid still covers the CUs
-          const int nt = o.conv3_b6_flat >= 2 ? (o.conv3_b6_flat == 2 ? 2 : 1) : (vox >= 2048 ? 4 : 2);
+          // flat 64-voxel tiles; narrower slabs for the smallest volumes (7x7x5: 8 tiles) so that the grid still covers the CUs at the
+          // split-K the launcher picks
+          const long long gx8 = (long long)cd.N * cdiv(cd.D * cd.H * cd.W, 64) * (cd.Cout16 / 64) * 8;     // workgroups with 64-channel slabs at split 8
+          const int nt = o.conv3_b6_flat >= 2 ? (o.conv3_b6_flat == 2 ? 2 : (o.conv3_b6_flat == 4 ? 4 : 1))
+                                              : ((vox >= 2048 || (cd.Cin16 >= 256 && gx8 >= 512)) ? 4 : 2);
           if (nt == 4) rows = b6_launch_flat<3, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
           else if (nt == 2) rows = b6_launch_flat<3, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
           else rows = b6_launch_flat<3, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
