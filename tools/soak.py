@@ -5,12 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from bcp_amd import synth, train_step
 from bcp_amd.hip_ops import Ops
-dev = torch.device("cuda:0"); torch.cuda.set_device(dev); Ops.product(); np.random.seed(1)
+from bcp_amd import plan
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev); plan.use_real_stream(dev); Ops.product(); np.random.seed(1)   # real stream: forward passes replay as HIP graphs
 model, ema = bench.build_models(dev, 1337)
 opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
 vol, lab = synth.la_batch(4, seed=1337); vol, lab = vol.to(dev), lab.to(dev)
 losses, mem = [], []
-for it in range(300):
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+for it in range(N):
     r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2)
     if it % 50 == 49:
         torch.cuda.synchronize()
