@@ -15,10 +15,13 @@ from bcp_amd.hip_ops import Ops
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EMU = os.path.join(ROOT, "tests", "_emu", "libbcp_emu.so")
+EMU_OVERRIDE = os.environ.get("BCP_EMU_LIB")      # tools/emu/run_asan.sh: the AddressSanitizer build of the simulator
 
 
 @pytest.fixture(scope="session")
 def emu_ops():
+    if EMU_OVERRIDE:
+        return Ops(_lib.Binding(EMU_OVERRIDE), allow_cpu=True)
     srcs = [os.path.join(ROOT, "bcp_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "bcp_amd", "csrc")) if f.endswith((".hip", ".h"))]
     srcs += [os.path.join(ROOT, "tools", "emu", "emu_runtime.cpp"), os.path.join(ROOT, "tools", "emu", "hip", "hip_runtime.h")]
     if not os.path.exists(EMU) or any(os.path.getmtime(s) > os.path.getmtime(EMU) for s in srcs):
