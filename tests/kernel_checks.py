@@ -574,6 +574,18 @@ def check_conv3_b6(ops, dev):
                     ops.set_option("splitk")
         finally:
             ops.set_option("conv3_b6_flat")
+        # 16 -> 16 layers (3-D: 4x8x8 tiles, 2-D: 16x16 tiles) on the persistent direct-weight kernel: product default only from 256 K
+        # voxels, forced here (conv3_b6 = 3) on small ragged shapes; P = 2: two workgroups walk all tiles (cross-tile halo prefetch)
+        ops.set_option("conv3_b6", 3)
+        for P in (None, 2):
+            if P:
+                ops.set_option("conv3_p", P)
+            try:
+                check_conv3(ops, dev, cases=((2, 16, 16, (4, 8, 8), 3), (1, 16, 16, (5, 9, 11), 3), (2, 16, 16, (1, 16, 16), 1), (1, 16, 16, (1, 20, 27), 1),
+                                             (1, 12, 16, (1, 33, 18), 1)))
+            finally:
+                ops.set_option("conv3_p")
+        ops.set_option("conv3_b6", 2)
         for direct, P in ((2, None), (2, 2), (0, None)):      # k_c3d everywhere (persistent; P = 2: many tiles per workgroup) / k_c3b everywhere
             ops.set_option("conv3_b6_direct", direct)
             if P:
@@ -586,7 +598,8 @@ def check_conv3_b6(ops, dev):
         ops.set_option("conv3_b6")
         ops.set_option("wgrad_b6")
     rng = np.random.default_rng(41)
-    for (N, Cin, Cout, sp, KD, G) in ((4, 32, 32, (4, 8, 8), 3, 2), (2, 64, 64, (4, 8, 8), 3, 2), (2, 32, 64, (1, 16, 16), 1, 1)):
+    for (N, Cin, Cout, sp, KD, G) in ((4, 32, 32, (4, 8, 8), 3, 2), (2, 64, 64, (4, 8, 8), 3, 2), (2, 32, 64, (1, 16, 16), 1, 1),
+                                      (4, 16, 16, (4, 8, 16), 3, 2), (4, 16, 16, (1, 32, 32), 1, 2)):
         two_d = KD == 1
         x = R(rng, N, Cin, *(sp[1:] if two_d else sp))
         w = R(rng, Cout, Cin, *((3, 3) if two_d else (3, 3, 3))) * 0.1
@@ -597,7 +610,7 @@ def check_conv3_b6(ops, dev):
         for P in (None, 3, "flat"):  # 3: the persistent kernel walks several tiles per workgroup and crosses statistics groups; flat: k_c3f
           if P == "flat" and (KD != 3 or Cout % 64):
               continue
-          ops.set_option("conv3_b6", 2)
+          ops.set_option("conv3_b6", 3 if Cout == 16 else 2)      # (the 16 -> 16 layers need the explicit switch at these sizes)
           ops.set_option("splitk", 1)
           if P == "flat":
               ops.set_option("conv3_b6_flat", 1)
