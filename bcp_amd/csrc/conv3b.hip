@@ -807,8 +807,9 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
   } else {
     // 2-D (U-Net): ACDC step 5.18 -> 4.24 ms with the 32- to 256-channel levels (and their weight gradients) on the bf16 pipe
     const bool on = o.conv3_b6 >= 2 || ((o.conv3_b6_levels & 8) && vox >= o.conv3_b6_minvox);
-    if (cd.Cout16 == 16 && cd.Cin16 == 16) {
-      // the U-Net's 16 -> 16 layers at full resolution: 16x16 tiles on the persistent direct-weight kernel, as the 3-D 16-channel level
+    if (cd.Cout16 == 16 && cd.Cin16 <= o.conv3_b6_cin16max) {
+      // the U-Net's 16-channel layers at full resolution (16 -> 16 and, after the skip concatenation, 32 -> 16): 16x16 tiles on the
+      // persistent direct-weight kernel, as the 3-D 16-channel level (work items = (tile, cin chunk))
       if (o.conv3_b6 >= 3 || (o.conv3_b6 == 1 && (o.conv3_b6_levels & 8) && (o.conv3_b6_levels & 4) && vox >= 256LL * 1024)) {
         rows = b6_launch<1, 1, 16, 16, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
         *handled = true;

@@ -582,7 +582,7 @@ def check_conv3_b6(ops, dev):
                 ops.set_option("conv3_p", P)
             try:
                 check_conv3(ops, dev, cases=((2, 16, 16, (4, 8, 8), 3), (1, 16, 16, (5, 9, 11), 3), (2, 16, 16, (1, 16, 16), 1), (1, 16, 16, (1, 20, 27), 1),
-                                             (1, 12, 16, (1, 33, 18), 1)))
+                                             (1, 12, 16, (1, 33, 18), 1), (2, 32, 16, (1, 16, 32), 1), (1, 24, 16, (1, 21, 19), 1)))
             finally:
                 ops.set_option("conv3_p")
         ops.set_option("conv3_b6", 2)
