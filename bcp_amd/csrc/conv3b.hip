@@ -815,10 +815,15 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
         *handled = true;
       }
     } else if (cd.Cout16 % 64 == 0 && on) {
+      // (flat 64-pixel tiles, k_c3f<1,..>, lose here: ACDC step 4.28 / 4.44 vs 4.14 ms for the levels up to 16 K / 64 K pixels)
       rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
       *handled = true;
     } else if (cd.Cout16 % 32 == 0 && on) {
-      rows = b6_launch<1, 1, 8, 16, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      // 32-channel slabs: from 64 K pixels on 16x16 tiles with direct weight fragments (k_c3d, as the 3-D 32-channel level) -- the
+      // staged 8x16 kernel ran the 16 -> 32 dgrad at 256x256 at 54 TFLOP/s-eq; ACDC step 4.11 -> 4.05 ms (cfg2d: 0 staged, 2 always direct)
+      if (o.conv3_b6_cfg2d >= 2 || (o.conv3_b6_cfg2d == 1 && vox >= 64LL * 1024))
+        rows = b6_launch<1, 1, 16, 16, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      else rows = b6_launch<1, 1, 8, 16, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
       *handled = true;
     }
   }

@@ -586,6 +586,11 @@ def check_conv3_b6(ops, dev):
             finally:
                 ops.set_option("conv3_p")
         ops.set_option("conv3_b6", 2)
+        ops.set_option("conv3_b6_cfg2d", 2)         # 2-D 32-channel slabs on the direct-weight 16x16 tiles (product default from 64 K pixels)
+        try:
+            check_conv3(ops, dev, cases=((2, 64, 32, (1, 12, 20), 1), (1, 16, 32, (1, 33, 17), 1), (2, 32, 96, (1, 16, 16), 1)))
+        finally:
+            ops.set_option("conv3_b6_cfg2d")
         for direct, P in ((2, None), (2, 2), (0, None)):      # k_c3d everywhere (persistent; P = 2: many tiles per workgroup) / k_c3b everywhere
             ops.set_option("conv3_b6_direct", direct)
             if P:
