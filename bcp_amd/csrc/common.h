@@ -65,7 +65,7 @@ static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b)
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: a wave with global loads in
-// flight (the helper waves of k_conv3_ws prefetching the next halo) would park at the barrier for a full HBM round trip and
+// flight (a kernel prefetching its next halo or weight stage under the current one) would park at the barrier for a full HBM round trip and
 // hold every other wave of the workgroup with it.  Here the wave waits for its own LDS operations (lgkmcnt) and joins the
 // barrier; registers being filled by outstanding global loads are private and need no fence.
 #ifndef BCP_LDS_BARRIER

@@ -1,5 +1,5 @@
 // bcp_amd/csrc/conv3_defs.h -- tile geometry, halo fetch and fused-statistics helpers shared by the 3x3(x3) convolution
-// kernels (conv3.hip: streaming / resident / wgrad kernels; conv3p.hip: the persistent 8-wave pipeline kernels).
+// kernels (conv3.hip: fp32-MFMA streaming / resident / wgrad kernels; conv3b.hip / conv3bw.hip: the bf16-pipe kernels).
 #pragma once
 #include "common.h"
 #include <type_traits>

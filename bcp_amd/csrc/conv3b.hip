@@ -1,7 +1,7 @@
 // bcp_amd/csrc/conv3b.hip -- 3x3x3 / 3x3 convolution (forward and dgrad) with fp32 numerics on the BF16 matrix pipe.
 //
 // v_mfma_f32_16x16x4_f32 issues once per 32 cycles per SIMD and -- measured on gfx950 (tools/probe/overlap_probe.hip) -- shares
-// its issue time with every VALU / LDS / VMEM instruction of the SIMD, so the fp32 kernels of conv3.hip / conv3p.hip stop near
+// its issue time with every VALU / LDS / VMEM instruction of the SIMD, so the fp32 kernels of conv3.hip stop near
 // 100-110 TFLOP/s.  Here both operands are split into THREE bf16 pieces when they enter the LDS (8 + 8 + 8 mantissa bits:
 // x = p0 + p1 + p2 up to 2^-26 |x|) and the tap loop issues six v_mfma_f32_16x16x32_bf16 per K = 32 block
 //     a0 b0 + a0 b1 + a1 b0 + a0 b2 + a1 b1 + a2 b0        (dropped cross terms < 2^-24 of the product)

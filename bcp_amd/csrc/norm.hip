@@ -474,7 +474,7 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   float* c1 = reinterpret_cast<float*>(partial + (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2);
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
-  if (partial_in) {   // (sum dz, sum dz * xhat) partials came out of the dgrad conv's epilogue (bcp_conv3_dgrad_bwdstats)
+  if (partial_in) {   // (sum dz, sum dz * xhat) partials handed in by the caller (no kernel of the library produces them any more)
     BCP_REQUIRE(!chan_scale && !elem_mask && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
     hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw);

@@ -43,7 +43,7 @@ int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
  * (csrc/common.h: conv3_p, splitk, res_pcu, res_nt, res_tile2d_vox, conv3_cfg, wgrad_nt, wgrad_tile, tn_groups, cc_tile,
- * conv3_p8, wgrad_p8); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
+ * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
  * HOST strings.  Set options before work is enqueued, not concurrently with launches. */
 int bcp_set_option(const char* name, const char* value);
 /* writes the gcnArchName of the current device ("gfx950...") */
@@ -99,8 +99,9 @@ int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const f
 int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
                  const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
                  float* dbeta, int accumulate, void* workspace, const double* partial_in_or_null, int nb_in, float* dy, void* stream);
-/* partial_in: (sum dz, sum dz*xhat) partials [G][nb_in][C][2] produced by bcp_conv3_dgrad_bwdstats -- the statistics pass
- * over (y, da) is skipped (not available together with chan_scale / elem_mask). */
+/* partial_in: (sum dz, sum dz*xhat) partials [G][nb_in][C][2] computed by the caller -- the statistics pass over (y, da) is
+ * skipped (not available together with chan_scale / elem_mask).  No kernel of this library produces them any more: the dgrad
+ * epilogue that did was slower in the step and was removed in round 2; pass NULL. */
 
 /* ---- 3x3x3 / 3x3 convolution, pad 1 (nn.Conv3d networks/VNet.py:17, nn.Conv2d networks/unet.py:19-25) on fp32 MFMA.
  *      KD = 3 (3-D) or 1 (2-D, D = 1).  Weights are packed once per optimizer step from the torch layout
