@@ -22,7 +22,7 @@ import bcp_amd.hip_ops as H  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 rng = np.random.default_rng(seed)
-ops = Ops(_lib.Binding(os.path.join(ROOT, "tests", "_emu", "libbcp_emu.so")), allow_cpu=True)
+ops = Ops(_lib.Binding(os.environ.get("BCP_EMU_LIB") or os.path.join(ROOT, "tests", "_emu", "libbcp_emu.so")), allow_cpu=True)   # BCP_EMU_LIB: the ASan build
 BU.set_test_ops(ops)
 dev = torch.device("cpu")
 fails, runs = [], 0
@@ -52,7 +52,20 @@ while time.time() - t0 < budget:
         else:
             sp = (int(rng.integers(1, 9)), int(rng.integers(1, 12)), int(rng.integers(1, 21))) if KD == 3 else (1, int(rng.integers(1, 24)), int(rng.integers(1, 40)))
         case = (int(rng.integers(1, 4)), cin, cout, sp, KD)
-        attempt(f"conv3 {case}", lambda: K.check_conv3(ops, dev, cases=[case]))
+        # half of the cases with the bf16-pipe kernels forced onto every eligible shape (the product only takes them from size
+        # thresholds these extents never reach), in a random variant: persistent grid of 1-3 workgroups, direct / staged weights,
+        # 2-D 32-channel slabs on either tile
+        forced = {}
+        if rng.random() < 0.5 and cin % 4 == 0:
+            forced = {"conv3_b6": 3, "wgrad_b6": 2, "conv3_p": int(rng.integers(0, 4)), "conv3_b6_cfg2d": int(rng.choice([0, 2])),
+                      "conv3_b6_direct": int(rng.choice([0, 1, 2])), "conv3_b6_flat": int(rng.choice([0, 1]))}
+        for k_, v_ in forced.items():
+            ops.set_option(k_, v_)
+        try:
+            attempt(f"conv3 {case} {forced}", lambda: K.check_conv3(ops, dev, cases=[case]))
+        finally:
+            for k_ in forced:
+                ops.set_option(k_)
     elif kind == 1:   # largest connected component vs the oracle
         D, Hh, W = int(rng.integers(1, 12)), int(rng.integers(1, 40)), int(rng.integers(1, 40))
         p = float(rng.choice([0.1, 0.3, 0.5, 0.7]))
