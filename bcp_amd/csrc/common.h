@@ -39,6 +39,7 @@ struct Options {
   int conv3_p = 0;          // cap on persistent workgroups of the resident / pipeline convs (tests: force multi-tile loops)
   int splitk = 0;           // streaming conv: split-K factor 1..4
   int conv3_b6_cin16max = 32;   // 2-D layers with 16 output channels on the bf16 pipe: widest input (measurement switch)
+  int conv3_b6_w22 = 1;         // 64-voxel x 64-channel staged tiles: waves arranged 2 x 2 (k_c3h) instead of 1 x 4 (k_c3b)
   int conv3_b6_cfg2d = 1;       // 2-D 32-channel slabs: 1 = direct-weight 16x16 tiles from 64 K pixels, 2 = always, 0 = staged 8x16 tiles
   int conv3_b6_flat_sk = 0; // flat bf16-pipe tiles: split-K factor 1..8 (0: the launcher's rule)
   int res_pcu = 0;          // resident conv: persistent workgroups per CU 1..4

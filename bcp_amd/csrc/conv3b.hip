@@ -45,12 +45,13 @@ __device__ __forceinline__ constexpr int b6_row(int i) {
 
 // epilogue shared by the bf16-pipe forward kernels: lane (li, lg) holds voxel b6_row(li) of each m-tile, channels lg*4 .. lg*4+3 of
 // each 16-channel n-tile (D = W^T-tile x X-tile), so a lane stores 16 bytes per (m-tile, n-tile)
-template <class TL, int TD, int TH, int TW, int NT>
-__device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[TL::MT][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
+// (MTv / wv: m-tiles per wave and the wave's position along m when the waves of a workgroup also split the channels -- k_c3h)
+template <class TL, int TD, int TH, int TW, int NT, int MTv = TL::MT>
+__device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
                                               int n, int d0, int h0, int w0, int cout0, int accumulate, bool want_stats,
-                                              double (&s1)[NT][4], double (&s2)[NT][4]) {
-  constexpr int MT = TL::MT, CT = NT * 16;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+                                              double (&s1)[NT][4], double (&s2)[NT][4], int wv = -1) {
+  constexpr int MT = MTv, CT = NT * 16;
+  const int lane = threadIdx.x & 63, wave = wv >= 0 ? wv : (int)(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const bool full = cout0 + CT <= cd.Cout && (cd.Cout & 3) == 0 && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
   const long long tile_base = ((((long long)n * cd.D + d0) * cd.H + h0) * cd.W + w0) * cd.Cout;
@@ -279,6 +280,173 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   }
 
   b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_c3b for the 64-voxel x 64-channel workgroup tile with the four waves arranged 2 x 2: wave (wm, wn) owns m-tiles 2 wm, 2 wm + 1 and
+// n-tiles 2 wn, 2 wn + 1.  Same 24 MFMAs per wave and tap pair as k_c3b's 1 x 4 arrangement, but 6 + 6 instead of 3 + 12
+// ds_read_b128 of fragments: the LDS pipe of these kernels is throughput-bound at the mid / deep levels (15 reads per wave and stage
+// x 8 waves per CU = 960 LDS cycles against 768 cycles of MFMA), so reads per MFMA are what counts.
+// One tap pair per stage, two weight buffers, everything else as k_c3b.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void stats_flush_22(double (&s1)[2][4], double (&s2)[2][4], double* __restrict__ Ss /* [4 waves][32][2] */,
+                                               double* __restrict__ dst_row, int cout0, int Cout) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double a = s1[nt][r], b = s2[nt][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if (li == 0) { Ss[(wave * 32 + nt * 16 + lg * 4 + r) * 2] = a; Ss[(wave * 32 + nt * 16 + lg * 4 + r) * 2 + 1] = b; }
+    }
+  __syncthreads();
+  if ((int)threadIdx.x < 64 && cout0 + (int)threadIdx.x < Cout) {
+    const int c = threadIdx.x, wn = c >> 5, cl = c & 31;          // channel c belongs to waves (wm = 0, wn) and (wm = 1, wn): wave = wn * 2 + wm
+    const double a = Ss[((wn * 2) * 32 + cl) * 2] + Ss[((wn * 2 + 1) * 32 + cl) * 2];
+    const double b = Ss[((wn * 2) * 32 + cl) * 2 + 1] + Ss[((wn * 2 + 1) * 32 + cl) * 2 + 1];
+    dst_row[(cout0 + c) * 2] = a;
+    dst_row[(cout0 + c) * 2 + 1] = b;
+  }
+  __syncthreads();
+}
+
+template <int KD, int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
+                                             float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
+  using TL = Tile<KD, TD, TH, TW>;
+  static_assert(TL::M == 64, "k_c3h: 64-voxel tiles (four m-tiles: two per wave)");
+  constexpr int T = TL::T, TP = (T + 1) / 2, CT = 64;
+  constexpr int S = (TP + 1) & ~1;                             // weight stages per cin chunk, even (2-D: one all-zero pad stage)
+  static_assert(S >= 4, "the stage pipeline needs four weight stages per chunk");
+  constexpr int XPLANE = TL::HV * XSB;
+  constexpr int WPLANE = CT * 32;
+  constexpr int WSTAGE = 3 * WPLANE;
+  constexpr int NW4 = (12 * CT + 255) / 256;
+  using HF = HaloFetch<TL>;
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
+  unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][CT][32]
+  double* Ss = reinterpret_cast<double*>(Wb + 2 * WSTAGE);         // [4][32][2] statistics scratch
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;
+  int n, d0, h0, w0;
+  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
+  const int cout0 = blockIdx.y * CT;
+
+  int voff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) voff[mt] = TL::voff((wm * 2 + mt) * 16 + b6_row<TW>(li)) * XSB + (lg & 1) * 8;
+  const int woff = (wn * 32 + li) * 32 + ((lg ^ ((li & 8) ? 2 : 0)) * 8);      // this wave's two n-tiles start at channel wn * 32 of the slab
+  HF hf;
+  hf.init(cd, reinterpret_cast<float*>(smem4));
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = cd.Cin16 >> 4;
+  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
+  Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
+
+  const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+    if (sg >= S) { sg -= S; ++cc; }
+    if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
+    const int tp = sg < TP ? sg : TP - 1;
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) {
+      const int q = (threadIdx.x + u * 256) % (12 * CT);
+      const int kq = q & 3, co = (q >> 2) % CT, sp = q / (4 * CT);
+      wpre[u] = *reinterpret_cast<const float4*>(Wb16 + ((((long long)cc * TP + tp) * 3 + sp) * cd.Cout16 + cout0 + co) * 32 + kq * 8);
+    }
+  };
+  auto wstash = [&](unsigned short* Wbuf, int sg, const float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) {
+      const int q = threadIdx.x + u * 256;
+      const int kq = q & 3, co = (q >> 2) % CT, sp = q / (4 * CT);
+      const float4 v = (sg < TP) ? wpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);       // pad pair: zero weights
+      if (q < 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + co * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
+    }
+  };
+  unsigned hvm = 0;
+  auto hfetch = [&](int cc, float4 (&pre)[HF::NP]) __attribute__((always_inline)) { hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, cc, pre); };
+  auto hstash = [&](const float4 (&pre)[HF::NP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < HF::NP; ++u)
+      if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
+        const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_store4(v, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
+      }
+  };
+
+  constexpr int HPF = S - 4;
+  float4 hpre[HF::NP], W0[NW4], W1[NW4];
+  hfetch(c_begin, hpre);
+  wfetch_at(c_begin, 0, W0);
+  wfetch_at(c_begin, 1, W1);
+  hstash(hpre);
+  wstash(Wb, 0, W0);
+  wfetch_at(c_begin, 2, W0);
+  BCP_LDS_BARRIER();
+
+  auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
+    const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
+    if (sg < TP) {     // uniform
+      const int t0 = 2 * sg, t1 = 2 * sg + 1 < T ? 2 * sg + 1 : T - 1;
+      const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
+      const int toff = ((lg >> 1) ? tB : tA) * XSB;
+      bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + nt * 16 * 32 + woff);
+      }
+#define BCP_B6(I, J)                                                                                            \
+  _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)              \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][J], a[mt][I], acc[mt][nt], 0, 0, 0);
+      BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
+#undef BCP_B6
+    }
+    if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
+    wfetch_at(cc, sg + 3, Wn);
+    if (sg + 1 < S) BCP_LDS_BARRIER();
+  };
+#pragma unroll 1
+  for (int cc = c_begin; cc < c_end; ++cc) {
+    if (cc > c_begin) {
+      BCP_LDS_BARRIER();
+      hstash(hpre);
+      BCP_LDS_BARRIER();
+    }
+#pragma unroll 1
+    for (int sg = 0; sg < HPF; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+    hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);
+#pragma unroll 1
+    for (int sg = HPF; sg < S; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+  }
+
+  double s1[2][4], s2[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
+  b6_store_tile<TL, TD, TH, TW, 2, 2>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm);
+  if (st.partial) {
+    const int gg = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
+    BCP_LDS_BARRIER();
+    stats_flush_22(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -699,6 +867,9 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     return sd.partial ? sd.rows : 0;
   }
   if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
+  if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
+    if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;       // 2 x 2 wave arrangement of the 64 x 64 tile (same LDS layout and size)
+  }
   if (sk == 1) {
     hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);
   } else {

@@ -586,6 +586,36 @@ def check_conv3_b6(ops, dev):
             finally:
                 ops.set_option("conv3_p")
         ops.set_option("conv3_b6", 2)
+        # 64-voxel x 64-channel staged tiles: waves arranged 2 x 2 (k_c3h, the default) vs 1 x 4 (k_c3b) -- the same products in the same
+        # order per accumulator, so the two are BIT-identical; full / partial tiles, several cin chunks, two slabs, statistics, split-K, +=
+        ops.set_option("conv3_b6_flat", 0)
+        try:
+            w22_cases = ((2, 64, 64, (4, 8, 12), 3), (1, 32, 128, (6, 9, 5), 3), (1, 64, 64, (7, 7, 5), 3), (2, 48, 64, (3, 5, 9), 3))
+            check_conv3(ops, dev, cases=w22_cases)
+            rng2 = np.random.default_rng(77)
+            for (N, Cin, Cout, sp, KD) in w22_cases:
+                x = to_cl(R(rng2, N, Cin, *sp)).to(dev)
+                w = (R(rng2, Cout, Cin, 3, 3, 3) * 0.1).to(dev).contiguous()
+                b = (R(rng2, Cout) * 0.1).to(dev)
+                wf, _ = ops.conv3_pack(w, KD)
+                outs = []
+                for w22 in (1, 0):
+                    ops.set_option("conv3_b6_w22", w22)
+                    ops.set_option("splitk", 1)            # (fused statistics need the unsplit launch)
+                    try:
+                        y, part, rows = ops.conv3_fwd_stats(x, wf, b, Cout, KD, 1)
+                        y2 = y.clone()
+                        ops.conv3_fwd(x, wf, None, Cout, KD, out=y2, accumulate=True)
+                        outs.append((y.clone(), part.clone(), rows, y2))
+                    finally:
+                        ops.set_option("conv3_b6_w22"); ops.set_option("splitk")
+                assert outs[0][2] == outs[1][2] and outs[0][2] > 0
+                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][3], outs[1][3]), "k_c3h vs k_c3b: outputs differ"
+                nb = outs[0][2] * Cout * 16           # (the fp64 statistics are summed in a different order: equal to rounding, not bitwise)
+                pa, pb = (np.frombuffer(o[1].cpu().numpy().tobytes()[:nb], dtype=np.float64) for o in outs)
+                assert np.allclose(pa, pb, rtol=1e-12, atol=1e-12), "k_c3h vs k_c3b: statistics rows differ"
+        finally:
+            ops.set_option("conv3_b6_flat")
         ops.set_option("conv3_b6_cfg2d", 2)         # 2-D 32-channel slabs on the direct-weight 16x16 tiles (product default from 64 K pixels)
         try:
             check_conv3(ops, dev, cases=((2, 64, 32, (1, 12, 20), 1), (1, 16, 32, (1, 33, 17), 1), (2, 32, 96, (1, 16, 16), 1)))
