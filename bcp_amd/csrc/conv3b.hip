@@ -360,7 +360,8 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
     if (sg >= S) { sg -= S; ++cc; }
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
-    const int tp = sg < TP ? sg : TP - 1;
+    int tp = sg < TP ? sg : TP - 1;
+    if (B6_ABLATE & 64) { tp = 0; cc = c_begin; }        // (measurement: every stage re-reads the first stage's weights -- cache-resident fetches)
 #pragma unroll
     for (int u = 0; u < NW4; ++u) {
       const int q = (threadIdx.x + u * 256) % (12 * CT);
@@ -388,14 +389,21 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
       }
   };
 
+  // FOUR weight stages in flight in registers (k_c3b: two): a stage is ~0.9 us here and its 12 KB come from L2 under the traffic of
+  // ~500 workgroups -- with every stage re-reading stage 0's (cache-resident) weights the kernel ran 11 % faster, i.e. a two-stage
+  // window stalls.  Set (g + 1) & 3 holds stage g + 1's weights while stage g runs (g = stage counted over the workgroup's chunks); it
+  // goes to LDS buffer (g + 1) & 1 during stage g and is refilled with stage g + 5.  The chunk body is fully unrolled (static register
+  // sets, compile-time tap offsets); S = 14 is not a multiple of 4, so chunks alternate between the two phases of the rotation.
   constexpr int HPF = S - 4;
-  float4 hpre[HF::NP], W0[NW4], W1[NW4];
+  float4 hpre[HF::NP], W[4][NW4];
   hfetch(c_begin, hpre);
-  wfetch_at(c_begin, 0, W0);
-  wfetch_at(c_begin, 1, W1);
+  wfetch_at(c_begin, 0, W[0]);
+  wfetch_at(c_begin, 1, W[1]);
+  wfetch_at(c_begin, 2, W[2]);
+  wfetch_at(c_begin, 3, W[3]);
   hstash(hpre);
-  wstash(Wb, 0, W0);
-  wfetch_at(c_begin, 2, W0);
+  wstash(Wb, 0, W[0]);
+  wfetch_at(c_begin, 4, W[0]);
   BCP_LDS_BARRIER();
 
   auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
@@ -419,21 +427,26 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
 #undef BCP_B6
     }
     if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
-    wfetch_at(cc, sg + 3, Wn);
+    wfetch_at(cc, sg + 5, Wn);
     if (sg + 1 < S) BCP_LDS_BARRIER();
   };
-#pragma unroll 1
-  for (int cc = c_begin; cc < c_end; ++cc) {
+  auto chunk = [&](int cc, auto phase_tag) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phase_tag)::value;
     if (cc > c_begin) {
-      BCP_LDS_BARRIER();
+      BCP_LDS_BARRIER();                             // every wave is done with the previous chunk's halo planes
       hstash(hpre);
       BCP_LDS_BARRIER();
     }
+#pragma unroll
+    for (int sg = 0; sg < S; ++sg) {
+      if (sg == HPF) hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (compile-time position: not a conditional load)
+      stage(cc, sg, W[(PH + sg + 1) & 3]);
+    }
+  };
 #pragma unroll 1
-    for (int sg = 0; sg < HPF; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
-    hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);
-#pragma unroll 1
-    for (int sg = HPF; sg < S; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+  for (int cc = c_begin; cc < c_end; cc += 2) {
+    chunk(cc, std::integral_constant<int, 0>{});
+    if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
   double s1[2][4], s2[2][4];
