@@ -736,14 +736,18 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
     wfetch(cc, sg, wpre);
   };
+  // four weight stages in flight in registers, chunk body fully unrolled (static register sets): see k_c3h
   constexpr int HPF = S - 4;
-  float4 hpre[NP], W0[NW4], W1[NW4];
+  static_assert(SP == 1, "k_c3f: one tap pair per stage");
+  float4 hpre[NP], W[4][NW4];
   hfetch(c_begin, hpre);
-  wfetch_at(c_begin, 0, W0);
-  wfetch_at(c_begin, 1, W1);
+  wfetch_at(c_begin, 0, W[0]);
+  wfetch_at(c_begin, 1, W[1]);
+  wfetch_at(c_begin, 2, W[2]);
+  wfetch_at(c_begin, 3, W[3]);
   hstash(hpre);
-  wstash(Wb, 0, W0);
-  wfetch_at(c_begin, 2, W0);
+  wstash(Wb, 0, W[0]);
+  wfetch_at(c_begin, 4, W[0]);
   BCP_LDS_BARRIER();
 
   auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
@@ -774,21 +778,26 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
       }
     }
     if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
-    wfetch_at(cc, sg + 3, Wn);
+    wfetch_at(cc, sg + 5, Wn);
     if (sg + 1 < S) BCP_LDS_BARRIER();
   };
-#pragma unroll 1
-  for (int cc = c_begin; cc < c_end; ++cc) {
+  auto chunk = [&](int cc, auto phase_tag) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phase_tag)::value;
     if (cc > c_begin) {
       BCP_LDS_BARRIER();
       hstash(hpre);
       BCP_LDS_BARRIER();
     }
+#pragma unroll
+    for (int sg = 0; sg < S; ++sg) {
+      if (sg == HPF) hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (compile-time position: not a conditional load)
+      stage(cc, sg, W[(PH + sg + 1) & 3]);
+    }
+  };
 #pragma unroll 1
-    for (int sg = 0; sg < HPF; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
-    hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);
-#pragma unroll 1
-    for (int sg = HPF; sg < S; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+  for (int cc = c_begin; cc < c_end; cc += 2) {
+    chunk(cc, std::integral_constant<int, 0>{});
+    if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
   // epilogue: lane (li, lg) holds voxel m0 + wave*16 + li, channels lg*4 .. lg*4+3 of each n-tile: 16-byte stores into flat rows
