@@ -214,13 +214,16 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
     if (!(B6_ABLATE & 4)) wfetch(cc, sg, wpre);
   };
   constexpr int HPF = S - 4;                         // even stage of a chunk in front of which the next chunk's halo is fetched
-  float4 hpre[HF::NP], W0[NW4], W1[NW4];
+  // (since late round 2: FOUR stages in flight, chunk body fully unrolled with static register sets -- see k_c3h)
+  float4 hpre[HF::NP], W[4][NW4];
   hfetch(c_begin, hpre);
-  wfetch_at(c_begin, 0, W0);
-  wfetch_at(c_begin, 1, W1);
+  wfetch_at(c_begin, 0, W[0]);
+  wfetch_at(c_begin, 1, W[1]);
+  wfetch_at(c_begin, 2, W[2]);
+  wfetch_at(c_begin, 3, W[3]);
   hstash(hpre);
-  if (!(B6_ABLATE & 4)) wstash(Wb, 0, W0);
-  wfetch_at(c_begin, 2, W0);
+  if (!(B6_ABLATE & 4)) wstash(Wb, 0, W[0]);
+  wfetch_at(c_begin, 4, W[0]);
   BCP_LDS_BARRIER();
 
   bf16x8 abl_a[MT][3], abl_b[NT][3];                 // (measurement only, B6_ABLATE & 32)
@@ -262,21 +265,26 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
     }
     // the next stage's weights -> the other buffer (last read one stage ago: every wave has passed the barrier that ended that stage)
     if (!(B6_ABLATE & 4) && (sg + 1 < S || cc + 1 < c_end)) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
-    wfetch_at(cc, sg + 3, Wn);
+    wfetch_at(cc, sg + 5, Wn);
     if (sg + 1 < S && !(B6_ABLATE & 16)) BCP_LDS_BARRIER();               // (a chunk boundary brings its own)
   };
-#pragma unroll 1
-  for (int cc = c_begin; cc < c_end; ++cc) {
+  auto chunk = [&](int cc, auto phase_tag) __attribute__((always_inline)) {
+    constexpr int PH = decltype(phase_tag)::value;
     if (cc > c_begin) {
       BCP_LDS_BARRIER();                             // every wave is done with the previous chunk's halo planes
       hstash(hpre);
       BCP_LDS_BARRIER();
     }
+#pragma unroll
+    for (int sg = 0; sg < S; ++sg) {
+      if (sg == HPF) hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (compile-time position; the last chunk re-reads its own halo: no conditional load)
+      stage(cc, sg, W[(PH + sg + 1) & 3]);
+    }
+  };
 #pragma unroll 1
-    for (int sg = 0; sg < HPF; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
-    hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (the last chunk re-reads its own halo: no conditional load)
-#pragma unroll 1
-    for (int sg = HPF; sg < S; sg += 2) { stage(cc, sg, W1); stage(cc, sg + 1, W0); }
+  for (int cc = c_begin; cc < c_end; cc += 2) {
+    chunk(cc, std::integral_constant<int, 0>{});
+    if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
   b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss);
