@@ -1122,7 +1122,7 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16, bool for_w
 int b6_wgrad(const float* x, const float* dy, float* partial, const ConvDims& cd, int KD, hipStream_t s);
 size_t b6_wgrad_workspace_bytes(const ConvDims& cd, int KD);
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
-           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled);
+           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk = nullptr);
 
 }  // namespace bcp
 
@@ -1133,6 +1133,7 @@ static int fill_dims(ConvDims& cd, int N, int D, int H, int W, int Cin, int Cout
   cd.Cin16 = (Cin + 15) / 16 * 16;
   cd.Cout16 = (Cout + 15) / 16 * 16;
   cd.tiles_d = cd.tiles_h = cd.tiles_w = 0;
+  cd.xcd = options().conv3_xcd;
   return 0;
 }
 
@@ -1300,6 +1301,40 @@ extern "C" int bcp_conv3_fwd_stats(const float* x, const float* wp, const float*
   if (rc < 0) return rc;
   BCP_REQUIRE(rc > 0, "bcp_conv3_fwd_stats: fused statistics unavailable for this shape (check bcp_conv3_stat_rows first)");
   BCP_CHECK_LAUNCH("bcp_conv3_fwd_stats");
+  return BCP_OK;
+}
+
+// Raw variant for the deep levels: the kernel's split-K partial slabs are the RESULT -- float[nslabs][N*D*H*W*Cout], no bias, no
+// slab-sum launch; bcp_norm_fwd_small / bcp_norm_bwd_small sum them (and add the bias) on their way in.  bcp_conv3_fwd_nslabs tells
+// how many slabs the launch will write for this shape under the current options (1..8), or 0: shape not served in raw mode (use
+// bcp_conv3_fwd).  Forward and dgrad alike (dgrad = the flipped pack).
+extern "C" int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD) {
+  if (Cin % 4 || Cin < 4 || (KD != 1 && KD != 3) || N < 1 || D < 1 || H < 1 || W < 1) return 0;
+  if ((long long)N * D * H * W * Cout > (1LL << 20)) return 0;      // the slab buffer is sized like bcp_conv3_fwd_workspace_bytes: deep levels only
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  bool handled = false;
+  static float dummy;
+  int sk = 0;
+  b6_fwd(nullptr, nullptr, nullptr, &dummy, cd, KD, 0, &dummy, nullptr, 0, true, nullptr, &handled, &sk);
+  return handled ? sk : 0;
+}
+
+extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int N, int D, int H, int W, int Cin, int Cout, int KD,
+                                 void* stream) {
+  BCP_REQUIRE(x && wp && slabs, "bcp_conv3_fwd_raw: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd_raw: bad extents");
+  BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd_raw: KD=1 needs D=1");
+  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd_raw: Cin=%d must be a multiple of 4", Cin);
+  BCP_REQUIRE(aligned16(x) && aligned16(wp) && aligned16(slabs), "bcp_conv3_fwd_raw: x / wp / slabs must be 16-B aligned");
+  BCP_REQUIRE((long long)N * D * H * W * Cout <= (1LL << 20), "bcp_conv3_fwd_raw: output too large for raw slabs (check bcp_conv3_fwd_nslabs)");
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  bool handled = false;
+  int sk = 0;
+  b6_fwd(x, wp, nullptr, slabs, cd, KD, 0, slabs, nullptr, 0, false, (hipStream_t)stream, &handled, &sk);
+  BCP_REQUIRE(handled && sk > 0, "bcp_conv3_fwd_raw: shape not served in raw mode (check bcp_conv3_fwd_nslabs first)");
+  BCP_CHECK_LAUNCH("bcp_conv3_fwd_raw");
   return BCP_OK;
 }
 

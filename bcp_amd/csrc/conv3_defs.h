@@ -39,7 +39,24 @@ struct ConvDims {
   int Cin, Cout;        // real channel counts (row strides of X and Y)
   int Cin16, Cout16;    // padded to multiples of 16 (packed-weight extents)
   int tiles_d, tiles_h, tiles_w;
+  int xcd;              // != 0: XCD-aware workgroup -> tile order in the bf16-pipe kernels (option conv3_xcd)
 };
+
+// XCD-aware tile order for one-tile-per-workgroup grids.  Workgroups are dealt round-robin to the 8 XCDs in linear-id order, so
+// workgroup x of a grid row whose first workgroup has linear id `row_lin` runs on XCD (x + row_lin) % 8.  The workgroups of XCD c
+// get a CONTIGUOUS range of the row's tile list (x-th of its class -> start_c + x / 8): tiles in flight on an XCD are spatial
+// neighbours and their halo overlap (2.3x per brick tile, ~6x per flat deep-level tile) hits that XCD's own 4 MB L2 instead of
+// the fabric.  A bijection of [0, gx) for every gx (classes hold gx / 8 or gx / 8 + 1 tiles).  All SALU (block-uniform).
+__device__ __forceinline__ int xcd_tile(int x, int gx, int row_lin) {
+  const int o = row_lin & 7, c = (x + o) & 7;
+  int start = 0;
+#pragma unroll
+  for (int cc = 0; cc < 7; ++cc) {
+    const int x0 = (cc - o) & 7;
+    if (cc < c && x0 < gx) start += (gx - x0 + 7) >> 3;
+  }
+  return start + (x >> 3);
+}
 
 __device__ __forceinline__ void tile_origin(const ConvDims& cd, int bx, int TD, int TH, int TW, int& n, int& d0, int& h0,
                                             int& w0) {

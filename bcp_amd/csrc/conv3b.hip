@@ -106,7 +106,7 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
 // one tile per workgroup (k_c3b): store + one statistics row per tile
 template <class TL, int TD, int TH, int TW, int NT>
 __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
-                                            int n, int d0, int h0, int w0, int cout0, int accumulate, const StatsArg& st, double* Ss) {
+                                            int n, int d0, int h0, int w0, int cout0, int accumulate, const StatsArg& st, double* Ss, int bx) {
   double s1[NT][4], s2[NT][4];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -114,7 +114,7 @@ __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __r
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
   b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st.partial != nullptr, s1, s2);
   if (st.partial) {
-    const int gg = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
+    const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();                           // the scratch below aliases nothing, but waves may still be in the last stage
     stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
   }
@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
+  const int bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;   // tile of this workgroup
   int n, d0, h0, w0;
-  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
+  tile_origin(cd, bx, TD, TH, TW, n, d0, h0, w0);
   const int cout0 = blockIdx.y * CT;
   const int cin4 = cd.Cin16 >> 2;
 
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
     if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
-  b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss);
+  b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, bx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -343,8 +344,9 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
+  const int bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;   // tile of this workgroup
   int n, d0, h0, w0;
-  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
+  tile_origin(cd, bx, TD, TH, TW, n, d0, h0, w0);
   const int cout0 = blockIdx.y * CT;
 
   int voff[2];
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
   b6_store_tile<TL, TD, TH, TW, 2, 2>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm);
   if (st.partial) {
-    const int gg = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
+    const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();
     stats_flush_22(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
   }
@@ -516,9 +518,22 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   // level has ONE chunk per tile: without this a workgroup's life is prologue + epilogue).
   // (PER = false: one tile per workgroup -- the 32-channel-slab instances, whose persistent form needs 355 VGPRs and would drop to
   //  one workgroup per CU: 102-109 vs 78-84 us)
-  const int my_tiles = !PER ? 1 : ((int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0);
+  // XCD-aware (cd.xcd): one tile per workgroup -> xcd_tile(); persistent -> each XCD (= blockIdx.x % 8 when the grid row is a multiple
+  // of 8) walks ONE contiguous eighth of the tile list with its gridDim.x / 8 workgroups side by side, as k_conv3_res does
+  int t_first, t_step, my_tiles;
+  if (!PER) {
+    t_first = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;
+    t_step = 0; my_tiles = 1;
+  } else if (cd.xcd && (gridDim.x & 7) == 0) {
+    const int xc = blockIdx.x & 7, xs = (int)((long long)n_tiles * xc / 8), xe = (int)((long long)n_tiles * (xc + 1) / 8);
+    t_step = gridDim.x >> 3;
+    t_first = xs + (int)(blockIdx.x >> 3);
+    my_tiles = t_first < xe ? (xe - 1 - t_first) / t_step + 1 : 0;
+  } else {
+    t_first = blockIdx.x; t_step = gridDim.x;
+    my_tiles = (int)blockIdx.x < n_tiles ? (n_tiles - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  }
   const int n_items = my_tiles * nch;
-  if (n_items == 0) return;
 
   // statistics: one row per (group, workgroup); rows this workgroup never reaches must read as zero
   const bool want_stats = PER && st.partial != nullptr;
@@ -528,6 +543,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
       z[0] = 0.0; z[1] = 0.0;
     }
   }
+  if (n_items == 0) return;
   double s1[NT][4], s2[NT][4];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
@@ -550,7 +566,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   auto hfetch_item = [&](int it) __attribute__((always_inline)) {      // (past the end: re-read the last item, no conditional load)
     if (B6_ABLATE & 2) return;
     const int itc = it < n_items ? it : n_items - 1;
-    const int tl = blockIdx.x + (itc / nch) * gridDim.x;
+    const int tl = t_first + (itc / nch) * t_step;
     int n, d0, h0, w0;
     tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
     hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, c_begin + itc % nch, hpre);
@@ -577,7 +593,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   hstash();
   BCP_LDS_BARRIER();
   constexpr int HPF = TPE >= 6 ? TPE - 4 : 0;        // pair in front of which the next item's halo is fetched
-  int cur_g = want_stats ? (int)blockIdx.x / st.tiles_per_group : 0;
+  int cur_g = want_stats ? t_first / st.tiles_per_group : 0;
 #pragma unroll 1
   for (int it = 0; it < n_items; ++it) {
     if (it > 0) {
@@ -612,12 +628,12 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
       }
     }
     if (it % nch == nch - 1) {                       // the tile is complete: store it (uniform branch; stores only, no loads to wait for)
-      const int tl = blockIdx.x + (it / nch) * gridDim.x;
+      const int tl = t_first + (it / nch) * t_step;
       int n, d0, h0, w0;
       tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
       if (!PER) {
         BCP_LDS_BARRIER();
-        b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss);      // one statistics row per tile
+        b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, t_first);      // one statistics row per tile
         return;
       }
       if (want_stats && tl / st.tiles_per_group != cur_g) {
@@ -668,7 +684,8 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   const int li = lane & 15, lg = lane >> 4;
   const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
   const int R = PD * HW + cd.W + 1, AV = BM + 2 * R;               // AV <= AVMAX (checked by the launcher)
-  const int n = blockIdx.x / tiles_per_sample, m0 = (blockIdx.x % tiles_per_sample) * BM;
+  const int bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;   // tile of this workgroup
+  const int n = bx / tiles_per_sample, m0 = (bx % tiles_per_sample) * BM;
   const int cout0 = blockIdx.y * CT;
 
   // this lane's voxel (one m-tile per wave), its halo row and the validity bits of its 27 neighbours
@@ -837,7 +854,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
     }
   }
   if (want_stats) {
-    const int gg = blockIdx.x / st.tiles_per_group, row = blockIdx.x % st.tiles_per_group;
+    const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();
     stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
   }
@@ -854,7 +871,7 @@ __global__ __launch_bounds__(256) void k_b6_sum_slabs(const float* __restrict__ 
 
 template <int KD, int TD, int TH, int TW, int NT, int SP>
 static int b6_launch(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
-                     double* stat_partial, int G, bool dry, hipStream_t s) {
+                     double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int CT = NT * 16;
   // k_c3d only where a wave's weight traffic is small next to its MFMAs: 256-voxel tiles with a 32-channel slab (6 KB per 48 MFMAs;
@@ -870,6 +887,25 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   const bool ws_fits = ws && (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout <= (1LL << 20);     // bcp_conv3_fwd_workspace_bytes
   if (ws_fits && (long long)gx * gy <= 256 && nch >= 4) { sk = nch / 2; if (sk > 4) sk = 4; }
   { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
+  if (raw_sk) {
+    // raw mode (bcp_conv3_fwd_raw): the sk partial slabs go to Y = float[sk][N*D*H*W*Cout] and stay there -- no bias, no slab sum, no
+    // statistics; the consumer (bcp_norm_fwd_small / bcp_norm_bwd_small) sums them on its way in
+    *raw_sk = sk;
+    if (dry) return 0;
+    StatsArg none{nullptr, 0, 1, cd.Cout, 1};
+    if (direct && NT != 1) {                           // (16-channel slabs: the persistent form of k_c3d is not a slab writer; staged kernel)
+      auto kd = k_c3d<KD, TD, TH, TW, NT, false>;
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kd, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, gx, 0, none);
+    } else {
+      if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
+        if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;
+      }
+      if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, 0, none);
+    }
+    return 0;
+  }
   StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
   if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
   if (direct) {
@@ -879,6 +915,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     const int slots = 512 / (gy * sk) > 0 ? 512 / (gy * sk) : 1;
     const int per = PER ? cdiv(gx, slots) : 1;
     int P = cdiv(gx, per);
+    if (PER && cd.xcd && P >= 8) P = (P + 7) & ~7;                                           // the XCD-aware walk needs whole rounds of the 8 XCDs
     if (PER && options().conv3_p > 0 && options().conv3_p < P) P = options().conv3_p;      // tests: few workgroups, many tiles each
     StatsArg sd{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
     if (sk == 1 && G > 0 && gx % G == 0) { sd.rows = PER ? P : gx / G; sd.tiles_per_group = gx / G; sd.partial = stat_partial; }
@@ -898,7 +935,10 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   }
   if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
   if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
-    if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;       // 2 x 2 wave arrangement of the 64 x 64 tile (same LDS layout and size)
+    if (options().conv3_b6_w22 != 0) {
+      kfn = k_c3h<KD, TD, TH, TW>;       // 2 x 2 wave arrangement of the 64 x 64 tile (same LDS layout and size)
+      if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
   }
   if (sk == 1) {
     hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);
@@ -916,7 +956,7 @@ static constexpr int kB6FlatAvMax = 384;    // flat halo rows (BM + 2 R) the fla
 
 template <int KD, int NT, int SP>
 static int b6_launch_flat(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
-                          double* stat_partial, int G, bool dry, hipStream_t s) {
+                          double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk) {
   constexpr int CT = NT * 16, BM = 64;
   const int V = cd.D * cd.H * cd.W, tps = cdiv(V, BM);
   const size_t lds = (size_t)3 * kB6FlatAvMax * XSB * 2 + (size_t)2 * 3 * SP * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
@@ -936,6 +976,13 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
   }
   { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
   { const int f = options().conv3_b6_flat_sk; if (ws_fits && f >= 1 && f <= 8 && f <= nch) sk = f; }      // measurement override
+  if (raw_sk) {                                       // raw mode: see b6_launch
+    *raw_sk = sk;
+    if (dry) return 0;
+    StatsArg none{nullptr, 0, 1, cd.Cout, 1};
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, tps, 0, none);
+    return 0;
+  }
   StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
   const bool stats_ok = sk == 1 && G > 0 && cd.N % G == 0;        // tiles are sample-major and never straddle samples
   if (stats_ok) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
@@ -955,7 +1002,7 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
 // Forward / dgrad on the bf16 pipe where option conv3_b6 allows it.  Returns the statistics rows (as conv3_fwd_impl does);
 // *handled = false leaves the shape to the fp32 kernels.
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
-           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled) {
+           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk) {
   *handled = false;
   const Options& o = options();
   if (o.conv3_b6 == 0) return 0;
@@ -966,7 +1013,7 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
     const bool forced = o.conv3_b6 >= 2;
     if (cd.Cout16 == 16 && cd.Cin16 == 16) {
       if (o.conv3_b6 >= 3 || (o.conv3_b6 == 1 && (o.conv3_b6_levels & 4) && vox >= 256LL * 1024)) {
-        rows = b6_launch<3, 4, 8, 8, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        rows = b6_launch<3, 4, 8, 8, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
         *handled = true;
       }
     } else if (cd.Cout16 % 64 == 0) {
@@ -977,31 +1024,31 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
         // 7.90 against 7.97 ms.  The 7x7x5 level stays with the fp32 kernel (35 vs 32 us).
         const int v = o.conv3_b6_cfg64;             // measurement switch
         if (vox >= 16LL * 1024) {
-          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
         } else if (o.conv3_b6_flat && 64 + 2 * (cd.H * cd.W + cd.W + 1) <= kB6FlatAvMax) {
           // flat 64-voxel tiles; narrower slabs for the smallest volumes (7x7x5: 8 tiles) so that the grid still covers the CUs at the
           // split-K the launcher picks
           const long long gx8 = (long long)cd.N * cdiv(cd.D * cd.H * cd.W, 64) * (cd.Cout16 / 64) * 8;     // workgroups with 64-channel slabs at split 8
           const int nt = o.conv3_b6_flat >= 2 ? (o.conv3_b6_flat == 2 ? 2 : (o.conv3_b6_flat == 4 ? 4 : 1))
                                               : ((vox >= 2048 || (cd.Cin16 >= 256 && gx8 >= 512)) ? 4 : 2);
-          if (nt == 4) rows = b6_launch_flat<3, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else if (nt == 2) rows = b6_launch_flat<3, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else rows = b6_launch_flat<3, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          if (nt == 4) rows = b6_launch_flat<3, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else if (nt == 2) rows = b6_launch_flat<3, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else rows = b6_launch_flat<3, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
         } else {
-          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else if (v == 5) rows = b6_launch<3, 2, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-          else rows = b6_launch<3, 2, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else if (v == 5) rows = b6_launch<3, 2, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          else rows = b6_launch<3, 2, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
         }
         *handled = true;
       }
     } else if (cd.Cout16 % 32 == 0) {
       if (forced || ((o.conv3_b6_levels & 1) && vox >= o.conv3_b6_minvox)) {
-        if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-        else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+        else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
         *handled = true;
       }
     }
@@ -1012,19 +1059,19 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
       // the U-Net's 16-channel layers at full resolution (16 -> 16 and, after the skip concatenation, 32 -> 16): 16x16 tiles on the
       // persistent direct-weight kernel, as the 3-D 16-channel level (work items = (tile, cin chunk))
       if (o.conv3_b6 >= 3 || (o.conv3_b6 == 1 && (o.conv3_b6_levels & 8) && (o.conv3_b6_levels & 4) && vox >= 256LL * 1024)) {
-        rows = b6_launch<1, 1, 16, 16, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        rows = b6_launch<1, 1, 16, 16, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
         *handled = true;
       }
     } else if (cd.Cout16 % 64 == 0 && on) {
       // (flat 64-pixel tiles, k_c3f<1,..>, lose here: ACDC step 4.28 / 4.44 vs 4.14 ms for the levels up to 16 K / 64 K pixels)
-      rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+      rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
       *handled = true;
     } else if (cd.Cout16 % 32 == 0 && on) {
       // 32-channel slabs: from 64 K pixels on 16x16 tiles with direct weight fragments (k_c3d, as the 3-D 32-channel level) -- the
       // staged 8x16 kernel ran the 16 -> 32 dgrad at 256x256 at 54 TFLOP/s-eq; ACDC step 4.11 -> 4.05 ms (cfg2d: 0 staged, 2 always direct)
       if (o.conv3_b6_cfg2d >= 2 || (o.conv3_b6_cfg2d == 1 && vox >= 64LL * 1024))
-        rows = b6_launch<1, 1, 16, 16, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
-      else rows = b6_launch<1, 1, 8, 16, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s);
+        rows = b6_launch<1, 1, 16, 16, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+      else rows = b6_launch<1, 1, 8, 16, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
       *handled = true;
     }
   }

@@ -73,9 +73,19 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int cc = blockIdx.y;                 // cin chunk
-  const int cout0 = blockIdx.z * CT;
-  const int grp = blockIdx.x;
+  // work item (tile group, cin chunk, cout slab).  XCD-aware (cd.xcd): the workgroups an XCD receives (linear id % 8) take a
+  // CONTIGUOUS range of the item list ordered (group, cout slab, cin chunk) with the cin chunk fastest -- the items of one tile
+  // group read the same dY tile and the two 64-byte halves of the same X lines, and neighbouring groups share halo planes: on one
+  // XCD, at about the same time, they meet in its L2 (grid order put them 5 XCDs apart: X fetched ~2x, dY once per cin chunk)
+  int cc = blockIdx.y, cslab = blockIdx.z, grp = blockIdx.x;
+  if (cd.xcd) {
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int w = xcd_tile(lin, gridDim.x * gridDim.y * gridDim.z, 0);
+    cc = w % (int)gridDim.y;
+    cslab = (w / (int)gridDim.y) % (int)gridDim.z;
+    grp = w / (int)(gridDim.y * gridDim.z);
+  }
+  const int cout0 = cslab * CT;
 
   f32x4 acc[TPW][NT];
 #pragma unroll

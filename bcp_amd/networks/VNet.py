@@ -184,11 +184,22 @@ class VNet(HipNet):
             part, nb = None, 0
             if L.skip_push:
                 skips.append(h)
+            # deep levels (<= 4096 rows per normalisation group): the conv leaves its split-K slabs and ONE kernel sums them, adds the
+            # bias, takes the statistics, finalises and applies them (bcp_norm_fwd_small) -- 2 launches per layer instead of 5
+            sp = h.shape[1] * h.shape[2] * h.shape[3]
+            sp_out = sp // 8 if L.kind == "dw" else (sp * 8 if L.kind == "up" else sp)
+            small = self.training and not (li == last and fuse_head) and ops.norm_small_ok(G, N * sp_out // G, L.cout)
+            src, nsl, bsrc = None, 1, None
             if L.kind == "c1":
                 y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
             elif L.kind == "c3":
                 wf, _ = self.conv3_packed(("c3", li), save)
-                if self.training or L.bn is None:
+                sk = ops.conv3_nslabs(h.shape, L.cout, 3) if small else 0
+                if sk > 0:
+                    src, nsl, bsrc = ops.conv3_fwd_raw(h, wf, L.cout, 3, sk), sk, b.data
+                elif small:
+                    y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)
+                elif self.training or L.bn is None:
                     y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
                 else:
                     y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)          # eval-mode BatchNorm needs no batch statistics
@@ -200,7 +211,12 @@ class VNet(HipNet):
                 y = ops.up_fwd(h, bp, b.data, L.cout)
             res = skips.pop() if L.skip_pop else None
             cs = self._chan_scale(L, N, xcl.device)
-            if li == last and fuse_head:
+            if small:
+                bn = L.bn
+                a, stats, y = ops.norm_fwd_small(y if src is None else src, nsl, bsrc, G,
+                                                 *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var) if bn is not None else (None,) * 4),
+                                                 H.ACT_RELU, chan_scale=cs, residual=res)
+            elif li == last and fuse_head:
                 # the head normalises on its way in: block_nine's 16-channel activation is never written (statistics only here)
                 bn = L.bn
                 a, stats = ops.norm_fwd(y, G, *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var) if bn is not None else (None,) * 4),
@@ -250,17 +266,22 @@ class VNet(HipNet):
         else:
             dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
         skip_grads = []
+        nsl = 1                          # dh is a plain gradient tensor (1) or the raw split-K slabs of the dgrad that produced it (> 1)
         for li in range(len(self._layers) - 1, -1, -1):
             L = self._layers[li]
             x_in, y, stats, cs, _ = saved[li]
             w = L.conv.weight
             da = dh
+            dg, db = (L.bn.weight.grad, L.bn.bias.grad) if L.bn is not None else (None, None)
+            if ops.norm_small_ok(G, y.numel() // (y.shape[-1] * G), y.shape[-1]):
+                # deep levels: slab sum + statistics + apply in one launch (bcp_norm_bwd_small)
+                dy, da = ops.norm_bwd_small(y, da, nsl, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs, want_da=L.skip_pop)
+            else:
+                assert nsl == 1
+                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs)
+            nsl = 1
             if L.skip_pop:
                 skip_grads.append(da)       # d(out)/d(skip) = identity: the skip source gets `da` itself
-            if L.bn is not None:
-                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, L.bn.weight.grad, L.bn.bias.grad, True, chan_scale=cs)
-            else:
-                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, None, None, False, chan_scale=cs)
             gw, acc = w.grad, True
             # conv biases feed a norm: their gradient is identically zero (DESIGN.md "bias gradients"); the flat
             # gradient buffer was cleared by begin_backward(), nothing to add.
@@ -279,7 +300,13 @@ class VNet(HipNet):
                 dh = None
             elif L.kind == "c3":
                 _, wd = self.conv3_packed(("c3", li), True)
-                dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
+                # the consumer of this dgrad is the previous layer's norm backward: when that one runs as the one-launch kernel, it
+                # takes the raw split-K slabs (no slab-sum launch)
+                sk = ops.conv3_nslabs(dy.shape, L.cin, 3) if ops.norm_small_ok(G, x_in.numel() // (L.cin * G), L.cin) else 0
+                if sk > 0:
+                    dh, nsl = ops.conv3_fwd_raw(dy, wd, L.cin, 3, sk), sk
+                else:
+                    dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
             elif L.kind == "dw":
                 _, bp = self.k2_packed(("k2", li), True)
                 sg = skip_grads.pop()        # x_in is a skip source: join the decoder-side gradient in place

@@ -43,8 +43,10 @@ int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
  * (csrc/common.h: conv3_p, splitk, res_pcu, res_nt, res_tile2d_vox, conv3_cfg, wgrad_nt, wgrad_tile, tn_groups, cc_tile,
- * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
- * HOST strings.  Set options before work is enqueued, not concurrently with launches. */
+ * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles; norm_small, conv3_xcd); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
+ * HOST strings.  NOT thread-safe and not per-stream: ONE Options struct per process, read by every launch on every stream and
+ * device.  Set options before work is enqueued, never concurrently with launches from another thread (the launch entry points
+ * themselves are re-entrant across streams / devices as long as the options stay put). */
 int bcp_set_option(const char* name, const char* value);
 /* writes the gcnArchName of the current device ("gfx950...") */
 int bcp_device_arch(char* buf, int n);
@@ -103,6 +105,24 @@ int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_grou
  * skipped (not available together with chan_scale / elem_mask).  No kernel of this library produces them any more: the dgrad
  * epilogue that did was slower in the step and was removed in round 2; pass NULL. */
 
+/* One-launch variants for SMALL groups (rows_per_group <= 4096: the 128- / 256-channel levels of the V-Nets, the U-Net's
+ * deepest level -- networks/VNet.py:74-86,101-113 block_four .. block_six, networks/unet.py down4 / up1): a workgroup owns four
+ * channels of a group for all its rows and keeps them in registers, so statistics, their finalisation and the apply pass (and
+ * the sum of the producing conv's split-K slabs + its bias) are ONE kernel instead of three to five ~5 us launches on the
+ * step's critical path.  Same per-element arithmetic as bcp_norm_fwd / bcp_norm_bwd (fp64 statistics, summed in a different
+ * fixed order).  bcp_norm_small_ok: 1 when the shape is served (and option norm_small is on).
+ *   fwd: slabs = float[nslab][slab_stride] (nslab = 1: y itself); y = bias + slab 0 + slab 1 + ... is written to ysum_or_null
+ *        (required when nslab > 1 or a bias is given); out_or_null = NULL: statistics only.
+ *   bwd: da = sum of da_slabs (nslab = 1: da itself), written to da_sum_or_null when the caller needs it (skip connections). */
+int bcp_norm_small_ok(int G, long long rows_per_group, int C);
+int bcp_norm_fwd_small(const float* slabs, int nslab, long long slab_stride, const float* bias_or_null, float* ysum_or_null, int G,
+                       long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                       float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
+                       float elem_scale, const float* residual, float* stats, float* out_or_null, void* stream);
+int bcp_norm_bwd_small(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum_or_null, int G,
+                       long long rows_per_group, int C, const float* stats, int act, const float* chan_scale, long long rows_per_sample,
+                       const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta, int accumulate, float* dy, void* stream);
+
 /* ---- 3x3x3 / 3x3 convolution, pad 1 (nn.Conv3d networks/VNet.py:17, nn.Conv2d networks/unet.py:19-25) on fp32 MFMA.
  *      KD = 3 (3-D) or 1 (2-D, D = 1).  Weights are packed once per optimizer step from the torch layout
  *      [Cout][Cin][KD*9]: wp_fwd feeds bcp_conv3_fwd(x -> y); wp_dgrad feeds the SAME entry point as
@@ -122,6 +142,11 @@ int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, fl
 int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace);
 int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin,
                         int Cout, int KD, void* workspace_or_null, double* stat_partial, int groups, void* stream);
+/* raw variant for the deep levels: the kernel's split-K partial slabs are the result -- slabs = float[nslabs][N*D*H*W*Cout], no bias,
+ * no slab-sum launch; bcp_norm_fwd_small / bcp_norm_bwd_small sum them on their way in.  nslabs = bcp_conv3_fwd_nslabs(...) under the
+ * current options (1..8; 0: shape not served in raw mode -> bcp_conv3_fwd).  Forward and dgrad alike. */
+int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD);
+int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int N, int D, int H, int W, int Cin, int Cout, int KD, void* stream);
 /* which matrix pipe serves bcp_conv3_fwd / bcp_conv3_fwd_stats for this shape under the current options (no launch): 0 = fp32 MFMA
  * (v_mfma_f32_16x16x4_f32), 1 = bf16 MFMA with three-piece operands (fp32-equivalent results; csrc/conv3b.hip).  Measurement record only. */
 size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Cout, int KD);

@@ -711,6 +711,130 @@ def check_conv3_stats(ops, dev):
         close(a1, a2, rtol=1e-6, msg="norm from fused partials")
 
 
+def check_norm_small(ops, dev):
+    """one-launch norm for small groups (bcp_norm_fwd_small / _bwd_small) + raw split-K conv slabs (bcp_conv3_fwd_raw):
+    (a) against torch (BatchNorm / grouped BatchNorm / InstanceNorm, every epilogue), (b) against the streaming three-kernel chain
+    on the same inputs: y / da sums bit-identical to the slab-sum kernel, activations and gradients equal to fp64-statistics rounding,
+    (c) conv -> slabs -> fused norm == conv3_fwd_stats -> norm_fwd, forward and dgrad, split-K forced to 1 / 2 / 4"""
+    rng = np.random.default_rng(41)
+    cases = (  # N, C, spatial, act, use_cs, use_res, G, nslab, mode ('bn' | 'in')
+        (2, 128, (14, 14, 10), H.ACT_RELU, False, False, 2, 4, "bn"),     # LA level 4: 1960 rows per group, 8 rows per thread, two groups per trip
+        (2, 256, (7, 7, 5), H.ACT_RELU, True, False, 2, 8, "bn"),         # LA level 5 + Dropout3d (x5)
+        (2, 128, (14, 14, 10), H.ACT_RELU, False, True, 1, 1, "bn"),      # transposed-conv layer: residual, 3920 rows in ONE group (16 per thread)
+        (4, 128, (12, 12, 12), H.ACT_RELU, False, False, 4, 3, "in"),     # pancreas level 4 (InstanceNorm: groups split over grid.y)
+        (3, 32, (3, 5, 7), H.ACT_LRELU, False, False, 1, 2, "bn"),        # ragged: 315 rows, 2 per thread; elementwise dropout mask
+        (4, 16, (1, 6, 9), H.ACT_RELU, True, True, 2, 1, "bn"),           # 2-D, 108 rows per group (1 per thread), 2 samples per group + chan scale
+        (5, 64, (2, 3, 3), H.ACT_RELU, False, False, 5, 2, "in"),         # odd group count
+    )
+    for (N, Cc, sp, act, use_cs, use_res, G, nslab, mode) in cases:
+        assert ops.norm_small_ok(G, N * sp[0] * sp[1] * sp[2] // G, Cc)
+        parts = [R(rng, N, Cc, *sp) * (1.7 if k == 0 else 0.3) + (0.4 if k == 0 else 0.0) for k in range(nslab)]
+        bias = R(rng, Cc) * 0.2 if nslab > 1 else None
+        y_t = sum(parts[1:], parts[0]) + (bias.view(1, Cc, 1, 1, 1) if bias is not None else 0)
+        y = y_t.clone().requires_grad_(True)
+        bn = mode == "bn"
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cc).astype(np.float32)).requires_grad_(True)
+        beta = torch.from_numpy(rng.uniform(-0.3, 0.3, Cc).astype(np.float32)).requires_grad_(True)
+        cs = torch.from_numpy(((rng.random((N, Cc)) < 0.5) * 2.0).astype(np.float32)) if use_cs else None
+        res = R(rng, N, Cc, *sp) if use_res else None
+        em = torch.from_numpy((rng.random((N, Cc, *sp)) < 0.8).astype(np.uint8)) if act == H.ACT_LRELU else None
+        rm_ref, rv_ref = torch.zeros(Cc), torch.ones(Cc)
+        if bn:
+            per = N // G
+            z = torch.cat([F.batch_norm(y[g * per:(g + 1) * per], rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5) for g in range(G)])
+        else:
+            z = F.instance_norm(y, eps=1e-5)
+        a_ref = F.relu(z) if act == H.ACT_RELU else F.leaky_relu(z, 0.01)
+        if cs is not None:
+            a_ref = a_ref * cs.view(N, Cc, 1, 1, 1)
+        if em is not None:
+            a_ref = a_ref * em.float() / 0.8
+        if res is not None:
+            a_ref = a_ref + res
+        dparts = [R(rng, N, Cc, *sp) * (1.0 if k == 0 else 0.2) for k in range(nslab)]
+        da_t = sum(dparts[1:], dparts[0])
+        a_ref.backward(da_t)
+        # ---- HIP, one launch
+        slabs = torch.stack([to_cl(q) for q in parts]).to(dev) if nslab > 1 else to_cl(parts[0]).to(dev)
+        gd, bd = (gamma.detach().to(dev), beta.detach().to(dev)) if bn else (None, None)
+        rmd, rvd = (torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)) if bn else (None, None)
+        kw = dict(chan_scale=None if cs is None else cs.to(dev), elem_mask=None if em is None else to_cl(em).to(dev), elem_scale=1 / 0.8)
+        a, stats, ycl = ops.norm_fwd_small(slabs, nslab, None if bias is None else bias.to(dev), G, gd, bd, rmd, rvd, act,
+                                           residual=None if res is None else to_cl(res).to(dev), **kw)
+        tag = f"norm_small C={Cc} G={G} sp={sp} slabs={nslab}"
+        # the slab sum follows k_b6_sum_slabs' order (bias, then the slabs front to back): compare with the same order on the host
+        yh = (bias.view(1, 1, 1, 1, Cc) if bias is not None else 0) + to_cl(parts[0])
+        for q in parts[1:]:
+            yh = yh + to_cl(q)
+        assert torch.equal(ycl.cpu(), yh if torch.is_tensor(yh) else to_cl(parts[0])), tag + ": slab sum is not bit-identical to bias + slabs in order"
+        close(from_cl(a), a_ref, msg=tag + " fwd")
+        if bn:
+            close(rmd, rm_ref, rtol=1e-5, msg=tag + " running_mean")
+            close(rvd, rv_ref, rtol=1e-5, msg=tag + " running_var")
+        dslabs = torch.stack([to_cl(q) for q in dparts]).to(dev) if nslab > 1 else to_cl(dparts[0]).to(dev)
+        dg, db = (torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)) if bn else (None, None)
+        dy, da_out = ops.norm_bwd_small(ycl, dslabs, nslab, G, stats, act, dg, db, False, want_da=True, **kw)
+        close(from_cl(dy), y.grad, rtol=2e-4, msg=tag + " bwd dy")
+        dh = to_cl(dparts[0])
+        for q in dparts[1:]:
+            dh = dh + to_cl(q)
+        assert torch.equal(da_out.cpu(), dh), tag + ": da slab sum"
+        if bn:
+            close(dg, gamma.grad, rtol=2e-4, msg=tag + " dgamma")
+            close(db, beta.grad, rtol=2e-4, msg=tag + " dbeta")
+            ops.norm_bwd_small(ycl, dslabs, nslab, G, stats, act, dg, db, True, **kw)
+            close(dg, 2 * gamma.grad, rtol=2e-4, msg=tag + " dgamma accumulate")
+        # ---- against the streaming three-kernel chain on the same y / da
+        rm2, rv2 = (torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)) if bn else (None, None)
+        a2, stats2 = ops.norm_fwd(ycl, G, gd, bd, rm2, rv2, act, residual=None if res is None else to_cl(res).to(dev), **kw)
+        close(stats, stats2, rtol=2e-6, msg=tag + " stats vs streaming chain")
+        close(a, a2, rtol=2e-6, msg=tag + " fwd vs streaming chain")
+        if bn:
+            close(rmd, rm2, rtol=1e-6, msg=tag + " running_mean vs chain")
+        dg2, db2 = (torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)) if bn else (None, None)
+        dy2 = ops.norm_bwd(ycl, da_out, G, stats2, act, dg2, db2, False, **kw)
+        close(dy, dy2, rtol=2e-5, msg=tag + " bwd vs streaming chain")
+    # ---- (c) conv -> raw slabs -> fused norm == fused-statistics conv -> streaming norm (forward and dgrad packs)
+    for (N, Cin, Cout, sp, G) in ((2, 128, 128, (14, 14, 10), 2), (2, 256, 256, (7, 7, 5), 2), (2, 64, 128, (6, 5, 7), 1), (2, 32, 32, (4, 8, 8), 2)):
+        x = R(rng, N, Cin, *sp)
+        w = R(rng, Cout, Cin, 3, 3, 3) * 0.05
+        b = R(rng, Cout) * 0.1
+        wf, wd = ops.conv3_pack(w.to(dev).contiguous(), 3)
+        xcl = to_cl(x).to(dev)
+        g1, b1 = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)).to(dev), torch.from_numpy(rng.uniform(-0.3, 0.3, Cout).astype(np.float32)).to(dev)
+        y_ref = ops.conv3_fwd(xcl, wf, b.to(dev), Cout, 3)
+        a_ref, st_ref = ops.norm_fwd(y_ref, G, g1, b1, torch.zeros(Cout).to(dev), torch.ones(Cout).to(dev), H.ACT_RELU)
+        close(from_cl(y_ref), F.conv3d(x, w, b, padding=1), msg="conv3 reference for the raw check")
+        for force in (0, 1, 2, 4):
+            if force:
+                ops.set_option("conv3_b6_flat_sk", force)
+                ops.set_option("splitk", force)
+            try:
+                sk = ops.conv3_nslabs(xcl.shape, Cout, 3)
+                if sk == 0:
+                    continue
+                slabs = ops.conv3_fwd_raw(xcl, wf, Cout, 3, sk)
+                a, st, y = ops.norm_fwd_small(slabs, sk, b.to(dev), G, g1, b1, torch.zeros(Cout).to(dev), torch.ones(Cout).to(dev), H.ACT_RELU)
+                close(y, y_ref, rtol=2e-5, msg=f"raw conv slabs {Cin}->{Cout} {sp} sk={sk}")
+                close(a, a_ref, rtol=2e-5, msg=f"raw conv + fused norm {Cin}->{Cout} {sp} sk={sk}")
+                # dgrad through the flipped pack: da slabs straight into the backward kernel
+                dyt = R(rng, N, Cout, *sp)
+                dycl = to_cl(dyt).to(dev)
+                skd = ops.conv3_nslabs(dycl.shape, Cin, 3)
+                if skd:
+                    dsl = ops.conv3_fwd_raw(dycl, wd, Cin, 3, skd)
+                    da_ref = ops.conv3_fwd(dycl, wd, None, Cin, 3)
+                    assert ops.norm_small_ok(G, N * sp[0] * sp[1] * sp[2] // G, Cin)
+                    xs, xst = ops.norm_fwd(xcl, G, None, None, None, None, H.ACT_RELU)
+                    d1, dsum = ops.norm_bwd_small(xcl, dsl, skd, G, xst, H.ACT_RELU, want_da=True)
+                    d2 = ops.norm_bwd(xcl, da_ref, G, xst, H.ACT_RELU)
+                    close(dsum, da_ref, rtol=2e-5, msg=f"raw dgrad slabs sk={skd}")
+                    close(d1, d2, rtol=5e-5, msg=f"raw dgrad + fused norm backward sk={skd}")
+            finally:
+                ops.set_option("conv3_b6_flat_sk")
+                ops.set_option("splitk")
+
+
 def check_augment(ops, dev, golden_dir):
     """device-side RandomRotFlip + RandomCrop == the REFERENCE's transform classes on the same np.random state
     (tests/golden/aug_la.npz), bit for bit, and == the oracle restatement"""
@@ -797,4 +921,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+ALL_CHECKS = ("norm_small", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
