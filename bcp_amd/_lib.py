@@ -52,6 +52,8 @@ _SIGS = {
     "bcp_norm_fwd_small": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P]),
     "bcp_norm_bwd_small": (I, [P, P, I, L, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P]),
     "bcp_conv3_fwd_nslabs": (I, [I, I, I, I, I, I, I]),
+    "bcp_conv3_bwdstat_rows": (I, [I, I, I, I, I, I, I, I]),
+    "bcp_conv3_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, I, P]),
     "bcp_conv3_fwd_raw": (I, [P, P, P, I, I, I, I, I, I, I, P]),
     "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
     "bcp_conv3_fwd_path": (SZ, [I, I, I, I, I, I, I]),
@@ -82,6 +84,7 @@ _SIGS = {
     "bcp_pw16_bwd_norm": (I, [P, P, P, I, I, I, P, P, P, P, P, L, I, I, P, P]),
     "bcp_colsum": (I, [P, L, I, P, I, P, P]),
     "bcp_maxpool2d_fwd": (I, [P, P, I, I, I, I, P]),
+    "bcp_maxpool3d_k3s2_fwd": (I, [P, P, I, I, I, I, I, P]),
     "bcp_maxpool2d_bwd": (I, [P, P, P, I, I, I, I, I, P]),
     "bcp_bilinear2x_fwd": (I, [P, P, I, I, I, I, I, I, P]),
     "bcp_bilinear2x_bwd": (I, [P, P, I, I, I, I, I, I, P]),
@@ -176,7 +179,7 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_small_ok", "bcp_conv3_fwd_nslabs")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_small_ok", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
         self._rec = None          # a bcp_amd.plan.LaunchPlan while a network pass is being recorded
 

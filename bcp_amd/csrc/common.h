@@ -59,6 +59,7 @@ struct Options {
   int wgrad_b6 = 1;         // weight gradient on the bf16 matrix pipe (conv3bw.hip): 0 off, 1 where measured faster, 2 wherever valid.  LA step (interleaved A/B): off 7.82 ms, 32/64-channel levels 7.52, + 128-channel level 7.38
   int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)
   int norm_small = 1;       // groups of <= 4096 rows (deep levels): statistics + finalize + apply (+ the split-K slab sum) in ONE launch (k_norm_small_*) instead of 3-5
+  int fuse_bwd_stats = 1;   // dgrad epilogue of the bf16-pipe kernels accumulates the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): no k_col_partial<1> pass over (y, da) for conv -> conv edges
   int conv3_xcd = 1;        // bf16-pipe kernels: XCD-aware workgroup -> tile order (each XCD walks a contiguous eighth of the tile list: halo overlap hits its own L2)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };

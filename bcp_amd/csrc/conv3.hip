@@ -1122,7 +1122,7 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16, bool for_w
 int b6_wgrad(const float* x, const float* dy, float* partial, const ConvDims& cd, int KD, hipStream_t s);
 size_t b6_wgrad_workspace_bytes(const ConvDims& cd, int KD);
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
-           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk = nullptr);
+           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk = nullptr, const BwdStatsIn* bw = nullptr);
 
 }  // namespace bcp
 
@@ -1301,6 +1301,38 @@ extern "C" int bcp_conv3_fwd_stats(const float* x, const float* wp, const float*
   if (rc < 0) return rc;
   BCP_REQUIRE(rc > 0, "bcp_conv3_fwd_stats: fused statistics unavailable for this shape (check bcp_conv3_stat_rows first)");
   BCP_CHECK_LAUNCH("bcp_conv3_fwd_stats");
+  return BCP_OK;
+}
+
+// dgrad with the consumer's norm-backward statistics in its epilogue (bf16-pipe kernels only): the conv output is da of the norm
+// layer whose pre-norm tensor is y_prev / statistics stats_prev; stat_partial receives (sum dz, sum dz * xhat) partials
+// [groups][rows][Cout][2], rows = bcp_conv3_bwdstat_rows(...) (0: not available for this shape), to be handed to bcp_norm_bwd as
+// partial_in -- its statistics pass over (y, da) is then skipped.  No dropout epilogues (chan_scale / elem_mask) on that layer.
+extern "C" int bcp_conv3_bwdstat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups) {
+  if (Cin % 4 || Cin < 4 || groups < 1 || options().fuse_bwd_stats == 0) return 0;
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  bool handled = false;
+  static float dummy;
+  const BwdStatsIn bw{&dummy, &dummy, 0};
+  const int rows = b6_fwd(nullptr, nullptr, nullptr, nullptr, cd, KD, 0, &dummy, nullptr, groups, true, nullptr, &handled, nullptr, &bw);
+  return handled && rows > 0 ? rows : 0;
+}
+
+extern "C" int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout,
+                                        int KD, const float* y_prev, const float* stats_prev, int act, void* workspace,
+                                        double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(dy && wp_dgrad && da && y_prev && stats_prev && stat_partial, "bcp_conv3_dgrad_bwdstats: null pointer");
+  BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0 && groups >= 1, "bcp_conv3_dgrad_bwdstats: bad extents");
+  BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_dgrad_bwdstats: Cin=%d must be a multiple of 4", Cin);
+  BCP_REQUIRE(aligned16(dy) && aligned16(wp_dgrad) && aligned16(y_prev), "bcp_conv3_dgrad_bwdstats: dy / wp / y_prev must be 16-B aligned");
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  bool handled = false;
+  const BwdStatsIn bw{y_prev, stats_prev, act};
+  const int rows = b6_fwd(dy, wp_dgrad, nullptr, da, cd, KD, 0, workspace, stat_partial, groups, false, (hipStream_t)stream, &handled, nullptr, &bw);
+  BCP_REQUIRE(handled && rows > 0, "bcp_conv3_dgrad_bwdstats: fused statistics unavailable for this shape (check bcp_conv3_bwdstat_rows first)");
+  BCP_CHECK_LAUNCH("bcp_conv3_dgrad_bwdstats");
   return BCP_OK;
 }
 

@@ -190,7 +190,15 @@ struct StatsArg {
   int tiles_per_group;   // spatial tiles per normalisation group (tiles are sample-major)
   int C;                 // channel count of the partial rows (= Cout)
   int G;                 // normalisation groups
+  // BACKWARD statistics (bf16-pipe dgrad kernels, bcp_conv3_dgrad_bwdstats): the conv output IS da of the consumer's norm layer; with
+  // that layer's pre-norm tensor `by` (same [voxel][C] layout) and statistics table the epilogue accumulates (sum dz, sum dz * xhat),
+  // dz = da * act'(z) -- what k_col_partial<1> would re-read y and da for.  by == nullptr: forward statistics (sum y, sum y^2).
+  const float* by;
+  const float* bstats;   // float[5][G][C]: mean, rstd, scale, shift(, unbiased variance)
+  int bact;
 };
+struct BwdStatsIn { const float* y; const float* stats; int act; };     // host side of StatsArg's backward fields
+
 template <int MODE>
 __device__ __forceinline__ void stat_add(double& s1, double& s2, float v) {
   if (MODE == 1) {

@@ -49,7 +49,7 @@ __device__ __forceinline__ constexpr int b6_row(int i) {
 template <class TL, int TD, int TH, int TW, int NT, int MTv = TL::MT>
 __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
                                               int n, int d0, int h0, int w0, int cout0, int accumulate, bool want_stats,
-                                              double (&s1)[NT][4], double (&s2)[NT][4], int wv = -1) {
+                                              double (&s1)[NT][4], double (&s2)[NT][4], int wv = -1, const StatsArg* sb = nullptr, int gg = 0) {
   constexpr int MT = MTv, CT = NT * 16;
   const int lane = threadIdx.x & 63, wave = wv >= 0 ? wv : (int)(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
@@ -63,23 +63,55 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
       const int co = cout0 + nt * 16 + lg * 4 + r;
       bv[nt][r] = (bias && co < cd.Cout) ? bias[co] : 0.f;
     }
+  // MODE 2 (backward statistics, see StatsArg): this lane's channels of the consumer norm layer's statistics rows of group gg
+  const bool bwd = want_stats && sb && sb->by;
+  float pmu[NT][4], prs[NT][4], psc[NT][4], psh[NT][4];
+  if (bwd) {
+    const long long GC = (long long)sb->G * sb->C;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cout0 + nt * 16 + lg * 4 + r;
+        const long long i = (long long)gg * sb->C + (co < cd.Cout ? co : 0);
+        pmu[nt][r] = sb->bstats[i]; prs[nt][r] = sb->bstats[GC + i]; psc[nt][r] = sb->bstats[2 * GC + i]; psh[nt][r] = sb->bstats[3 * GC + i];
+      }
+  }
   auto rows = [&](auto mode_tag, auto acc_tag) __attribute__((always_inline)) {
     constexpr int MODE = decltype(mode_tag)::value;
     constexpr bool ACCUM = decltype(acc_tag)::value;
+    // dz = da * act'(z), xhat = (y - mean) * rstd -- k_col_partial<1>'s arithmetic on the value just stored
+    auto bstat = [&](int nt, int r, float v, float yv) __attribute__((always_inline)) {
+      const float z = (yv - pmu[nt][r]) * psc[nt][r] + psh[nt][r];
+      const float g1 = v * act_grad(z, sb->bact);
+      const float xh = (yv - pmu[nt][r]) * prs[nt][r];
+      s1[nt][r] += (double)g1;
+      s2[nt][r] += (double)g1 * (double)xh;
+    };
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const int m = (wave * MT + mt) * 16 + b6_row<TW>(li);
       const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
       const int d = d0 + td, h = h0 + th, w = w0 + tw;
-      float* yrow = Y + tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout) + cout0 + lg * 4;
+      const long long eoff = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout) + cout0 + lg * 4;
+      float* yrow = Y + eoff;
       if (full) {
+        float4 yb[NT];
+        if (MODE == 2) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) yb[nt] = ld4(sb->by + eoff + nt * 16);
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           float4 v = make_float4(acc[mt][nt][0] + bv[nt][0], acc[mt][nt][1] + bv[nt][1], acc[mt][nt][2] + bv[nt][2], acc[mt][nt][3] + bv[nt][3]);
           if (ACCUM) { const float4 o = ld4(yrow + nt * 16); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
           if (!(B6_ABLATE & 1) || v.x == 1.2345e-30f) st4(yrow + nt * 16, v);
-          stat_add<MODE>(s1[nt][0], s2[nt][0], v.x); stat_add<MODE>(s1[nt][1], s2[nt][1], v.y);
-          stat_add<MODE>(s1[nt][2], s2[nt][2], v.z); stat_add<MODE>(s1[nt][3], s2[nt][3], v.w);
+          if (MODE == 2) {
+            bstat(nt, 0, v.x, yb[nt].x); bstat(nt, 1, v.y, yb[nt].y); bstat(nt, 2, v.z, yb[nt].z); bstat(nt, 3, v.w, yb[nt].w);
+          } else {
+            stat_add<MODE>(s1[nt][0], s2[nt][0], v.x); stat_add<MODE>(s1[nt][1], s2[nt][1], v.y);
+            stat_add<MODE>(s1[nt][2], s2[nt][2], v.z); stat_add<MODE>(s1[nt][3], s2[nt][3], v.w);
+          }
         }
       } else if (d < cd.D && h < cd.H && w < cd.W) {
 #pragma unroll
@@ -91,7 +123,8 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
               float v = acc[mt][nt][r] + bv[nt][r];
               if (ACCUM) v += yrow[nt * 16 + r];
               if (!(B6_ABLATE & 1) || v == 1.2345e-30f) yrow[nt * 16 + r] = v;
-              stat_add<MODE>(s1[nt][r], s2[nt][r], v);
+              if (MODE == 2) bstat(nt, r, v, sb->by[eoff + nt * 16 + r]);
+              else stat_add<MODE>(s1[nt][r], s2[nt][r], v);
             }
           }
       }
@@ -100,7 +133,8 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
   if (!want_stats) {
     if (accumulate) rows(std::integral_constant<int, 0>{}, std::true_type{});
     else rows(std::integral_constant<int, 0>{}, std::false_type{});
-  } else rows(std::integral_constant<int, 1>{}, std::false_type{});       // the statistics variant never accumulates (bcp_conv3_fwd_stats)
+  } else if (bwd) rows(std::integral_constant<int, 2>{}, std::false_type{});
+  else rows(std::integral_constant<int, 1>{}, std::false_type{});       // the statistics variants never accumulate (bcp_conv3_fwd_stats)
 }
 
 // one tile per workgroup (k_c3b): store + one statistics row per tile
@@ -112,7 +146,8 @@ __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __r
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
-  b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st.partial != nullptr, s1, s2);
+  b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st.partial != nullptr, s1, s2, -1, &st,
+                                    st.partial ? bx / st.tiles_per_group : 0);
   if (st.partial) {
     const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();                           // the scratch below aliases nothing, but waves may still be in the last stage
@@ -464,7 +499,8 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
-  b6_store_tile<TL, TD, TH, TW, 2, 2>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm);
+  b6_store_tile<TL, TD, TH, TW, 2, 2>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm, &st,
+                                      st.partial ? bx / st.tiles_per_group : 0);
   if (st.partial) {
     const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();
@@ -641,7 +677,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
         stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
         cur_g = tl / st.tiles_per_group;
       }
-      b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, want_stats, s1, s2);
+      b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, want_stats, s1, s2, -1, &st, cur_g);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -871,7 +907,7 @@ __global__ __launch_bounds__(256) void k_b6_sum_slabs(const float* __restrict__ 
 
 template <int KD, int TD, int TH, int TW, int NT, int SP>
 static int b6_launch(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
-                     double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk) {
+                     double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk, const BwdStatsIn* bw) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int CT = NT * 16;
   // k_c3d only where a wave's weight traffic is small next to its MFMAs: 256-voxel tiles with a 32-channel slab (6 KB per 48 MFMAs;
@@ -908,6 +944,10 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   }
   StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
   if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
+  if (bw) {                                           // backward statistics in the epilogue (bcp_conv3_dgrad_bwdstats): one-pass launches only
+    if (sk != 1 || G <= 0 || gx % G) return 0;
+    st.by = bw->y; st.bstats = bw->stats; st.bact = bw->act;
+  }
   if (direct) {
     // persistent grid (16-channel slabs): tiles dealt round-robin to P workgroups (two per CU), balanced: every workgroup gets
     // cdiv(tiles, slots) tiles; 32-channel slabs: one tile per workgroup (register budget, see k_c3d)
@@ -919,6 +959,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     if (PER && options().conv3_p > 0 && options().conv3_p < P) P = options().conv3_p;      // tests: few workgroups, many tiles each
     StatsArg sd{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
     if (sk == 1 && G > 0 && gx % G == 0) { sd.rows = PER ? P : gx / G; sd.tiles_per_group = gx / G; sd.partial = stat_partial; }
+    if (bw) { sd.by = bw->y; sd.bstats = bw->stats; sd.bact = bw->act; }
     if (dry) return (sk == 1 && G > 0 && gx % G == 0) ? (PER ? P : gx / G) : 0;
     auto kd = k_c3d<KD, TD, TH, TW, NT, PER>;
     hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -956,7 +997,7 @@ static constexpr int kB6FlatAvMax = 384;    // flat halo rows (BM + 2 R) the fla
 
 template <int KD, int NT, int SP>
 static int b6_launch_flat(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
-                          double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk) {
+                          double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk, const BwdStatsIn* bw) {
   constexpr int CT = NT * 16, BM = 64;
   const int V = cd.D * cd.H * cd.W, tps = cdiv(V, BM);
   const size_t lds = (size_t)3 * kB6FlatAvMax * XSB * 2 + (size_t)2 * 3 * SP * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
@@ -983,6 +1024,7 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
     hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, tps, 0, none);
     return 0;
   }
+  if (bw) return 0;                                   // (deep levels: the one-launch norm backward takes the raw slabs instead)
   StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
   const bool stats_ok = sk == 1 && G > 0 && cd.N % G == 0;        // tiles are sample-major and never straddle samples
   if (stats_ok) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
@@ -1002,7 +1044,7 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
 // Forward / dgrad on the bf16 pipe where option conv3_b6 allows it.  Returns the statistics rows (as conv3_fwd_impl does);
 // *handled = false leaves the shape to the fp32 kernels.
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
-           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk) {
+           double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk, const BwdStatsIn* bw) {
   *handled = false;
   const Options& o = options();
   if (o.conv3_b6 == 0) return 0;
@@ -1013,7 +1055,7 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
     const bool forced = o.conv3_b6 >= 2;
     if (cd.Cout16 == 16 && cd.Cin16 == 16) {
       if (o.conv3_b6 >= 3 || (o.conv3_b6 == 1 && (o.conv3_b6_levels & 4) && vox >= 256LL * 1024)) {
-        rows = b6_launch<3, 4, 8, 8, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+        rows = b6_launch<3, 4, 8, 8, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         *handled = true;
       }
     } else if (cd.Cout16 % 64 == 0) {
@@ -1024,31 +1066,31 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
         // 7.90 against 7.97 ms.  The 7x7x5 level stays with the fp32 kernel (35 vs 32 us).
         const int v = o.conv3_b6_cfg64;             // measurement switch
         if (vox >= 16LL * 1024) {
-          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         } else if (o.conv3_b6_flat && 64 + 2 * (cd.H * cd.W + cd.W + 1) <= kB6FlatAvMax) {
           // flat 64-voxel tiles; narrower slabs for the smallest volumes (7x7x5: 8 tiles) so that the grid still covers the CUs at the
           // split-K the launcher picks
           const long long gx8 = (long long)cd.N * cdiv(cd.D * cd.H * cd.W, 64) * (cd.Cout16 / 64) * 8;     // workgroups with 64-channel slabs at split 8
           const int nt = o.conv3_b6_flat >= 2 ? (o.conv3_b6_flat == 2 ? 2 : (o.conv3_b6_flat == 4 ? 4 : 1))
                                               : ((vox >= 2048 || (cd.Cin16 >= 256 && gx8 >= 512)) ? 4 : 2);
-          if (nt == 4) rows = b6_launch_flat<3, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else if (nt == 2) rows = b6_launch_flat<3, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else rows = b6_launch_flat<3, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          if (nt == 4) rows = b6_launch_flat<3, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else if (nt == 2) rows = b6_launch_flat<3, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else rows = b6_launch_flat<3, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         } else {
-          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else if (v == 5) rows = b6_launch<3, 2, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-          else rows = b6_launch<3, 2, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else if (v == 5) rows = b6_launch<3, 2, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          else rows = b6_launch<3, 2, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         }
         *handled = true;
       }
     } else if (cd.Cout16 % 32 == 0) {
       if (forced || ((o.conv3_b6_levels & 1) && vox >= o.conv3_b6_minvox)) {
-        if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-        else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+        if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+        else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         *handled = true;
       }
     }
@@ -1059,19 +1101,19 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
       // the U-Net's 16-channel layers at full resolution (16 -> 16 and, after the skip concatenation, 32 -> 16): 16x16 tiles on the
       // persistent direct-weight kernel, as the 3-D 16-channel level (work items = (tile, cin chunk))
       if (o.conv3_b6 >= 3 || (o.conv3_b6 == 1 && (o.conv3_b6_levels & 8) && (o.conv3_b6_levels & 4) && vox >= 256LL * 1024)) {
-        rows = b6_launch<1, 1, 16, 16, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+        rows = b6_launch<1, 1, 16, 16, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         *handled = true;
       }
     } else if (cd.Cout16 % 64 == 0 && on) {
       // (flat 64-pixel tiles, k_c3f<1,..>, lose here: ACDC step 4.28 / 4.44 vs 4.14 ms for the levels up to 16 K / 64 K pixels)
-      rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+      rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
       *handled = true;
     } else if (cd.Cout16 % 32 == 0 && on) {
       // 32-channel slabs: from 64 K pixels on 16x16 tiles with direct weight fragments (k_c3d, as the 3-D 32-channel level) -- the
       // staged 8x16 kernel ran the 16 -> 32 dgrad at 256x256 at 54 TFLOP/s-eq; ACDC step 4.11 -> 4.05 ms (cfg2d: 0 staged, 2 always direct)
       if (o.conv3_b6_cfg2d >= 2 || (o.conv3_b6_cfg2d == 1 && vox >= 64LL * 1024))
-        rows = b6_launch<1, 1, 16, 16, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
-      else rows = b6_launch<1, 1, 8, 16, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk);
+        rows = b6_launch<1, 1, 16, 16, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+      else rows = b6_launch<1, 1, 8, 16, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
       *handled = true;
     }
   }

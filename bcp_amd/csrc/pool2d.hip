@@ -27,6 +27,28 @@ __global__ __launch_bounds__(256) void k_maxpool2d_fwd(const float* __restrict__
   }
 }
 
+// nn.MaxPool3d(3, stride=2), no padding (networks/VNet.py:246,288: the V-Net's second return value, pool(x5) -- forward only, the
+// reference never differentiates it in any train script).  One thread per (output voxel, float4 channel group).
+__global__ __launch_bounds__(256) void k_maxpool3d_k3s2_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int D, int H, int W, int C) {
+  const int Do = (D - 3) / 2 + 1, Ho = (H - 3) / 2 + 1, Wo = (W - 3) / 2 + 1, C4 = C >> 2;
+  const long long total = (long long)N * Do * Ho * Wo * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    long long r = i / C4;
+    const int wo = (int)(r % Wo); r /= Wo;
+    const int ho = (int)(r % Ho); r /= Ho;
+    const int d_o = (int)(r % Do), n = (int)(r / Do);
+    float4 o = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int kd = 0; kd < 3; ++kd)
+      for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) {
+          const float4 v = ld4(x + ((((long long)n * D + 2 * d_o + kd) * H + 2 * ho + kh) * W + 2 * wo + kw) * C + c4 * 4);
+          o.x = fmaxf(o.x, v.x); o.y = fmaxf(o.y, v.y); o.z = fmaxf(o.z, v.z); o.w = fmaxf(o.w, v.w);
+        }
+    st4(y + i * 4, o);
+  }
+}
+
 // gradient goes to the FIRST maximal element of each 2x2 window (row-major), as torch's max_pool2d does
 __global__ __launch_bounds__(256) void k_maxpool2d_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ dx, int N, int H, int W, int C, int accumulate) {
@@ -164,6 +186,15 @@ extern "C" int bcp_maxpool2d_fwd(const float* x, float* y, int N, int H, int W, 
   BCP_CHECK_LAUNCH("bcp_maxpool2d_fwd");
   return BCP_OK;
 }
+extern "C" int bcp_maxpool3d_k3s2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream) {
+  BCP_REQUIRE(x && y && N > 0 && D >= 3 && H >= 3 && W >= 3 && C >= 4 && (C & 3) == 0, "bcp_maxpool3d_k3s2_fwd: need D,H,W >= 3 and C %% 4 == 0");
+  const long long total = (long long)N * ((D - 3) / 2 + 1) * ((H - 3) / 2 + 1) * ((W - 3) / 2 + 1) * (C / 4);
+  hipLaunchKernelGGL(k_maxpool3d_k3s2_fwd, dim3((int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, y, N, D, H, W, C);
+  BCP_CHECK_LAUNCH("bcp_maxpool3d_k3s2_fwd");
+  return BCP_OK;
+}
+
 extern "C" int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate, void* stream) {
   BCP_REQUIRE(x && dy && dx && N > 0 && H % 2 == 0 && W % 2 == 0, "bcp_maxpool2d_bwd: bad argument");
   hipLaunchKernelGGL(k_maxpool2d_bwd, dim3(sgrid((long long)N * (H / 2) * (W / 2) * C)), dim3(256), 0, (hipStream_t)stream, x, dy, dx,

@@ -8,8 +8,8 @@ do.  N ranks == N sequential micro-batches with averaged gradients (tests/test_d
 
 Transports (BCP_DP_BACKEND, default "rccl" on a GPU):
   * "rccl": the library's own communicator -- bcp_comm_init_rank / bcp_allreduce_f32 (include/bcp_hip.h, csrc/comm.hip:
-    ncclAllReduce on a stream we own); the 128-byte unique id travels from rank 0 through a file under BCP_DP_ID_DIR
-    (default /tmp) named after the launch (MASTER_PORT + TORCHELASTIC_RUN_ID).  torch.distributed is not imported.
+    ncclAllReduce on a stream we own); the 128-byte unique id travels from rank 0 through the launch's c10d store at
+    MASTER_ADDR:MASTER_PORT (multi-node capable; _exchange_id), torch.distributed's process groups are not used.
   * "nccl" / "gloo": torch.distributed process groups ("nccl" IS RCCL on ROCm; "gloo" runs the CPU tests).
 """
 from __future__ import annotations
@@ -19,6 +19,60 @@ import os
 import time
 
 import torch
+
+
+_ID_SEQ = [0]      # communicators built by this process so far (the ranks of a launch build them in the same order)
+
+
+def _exchange_id(ident, world, rank):
+    """rank 0's 128-byte RCCL unique id -> every rank, over the launch's own rendezvous: the c10d store at MASTER_ADDR:MASTER_PORT
+    exactly as torch.distributed's env:// method finds it (the elastic agent's store under torchrun, else a TCPStore served by
+    rank 0) -- works across nodes, needs no shared filesystem, and a key is written once per (launch, communicator), so a crashed
+    earlier launch cannot leave a stale id behind (round-2 ADVICE: the id used to travel through a file under /tmp).
+    BCP_DP_ID_DIR=<dir> selects the file transport instead (single node, no TCP): rank 0 unlinks any old file first and the file
+    carries a per-launch nonce (BCP_DP_LAUNCH_ID or the launcher's pid) in its name."""
+    _ID_SEQ[0] += 1
+    if world == 1:
+        return ident                                 # a one-rank communicator (tests): nothing to exchange
+    d = os.environ.get("BCP_DP_ID_DIR")
+    if not d:
+        from datetime import timedelta
+        from torch.distributed import rendezvous
+        store, _, _ = next(iter(rendezvous("env://", rank=rank, world_size=world, timeout=timedelta(seconds=180))))
+        key = f"bcp_rccl_id/{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/{_ID_SEQ[0]}"
+        if rank == 0:
+            store.set(key, ident)
+        out = bytes(store.get(key))                  # blocks until rank 0 has set it (store timeout: 180 s)
+        assert len(out) == 128, "malformed RCCL unique id in the rendezvous store"
+        _STORES.append(store)                        # rank 0 may be serving it: keep it alive for the life of the process
+        return out
+    tag = (f"{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{world}_"
+           f"{os.environ.get('BCP_DP_LAUNCH_ID', os.getppid())}_{_ID_SEQ[0]}")
+    path = os.path.join(d, f"bcp_rccl_id_{tag}")
+    if rank == 0:
+        try:
+            os.remove(path)                          # nothing older may be mistaken for this launch's id
+        except OSError:
+            pass
+        tmp = path + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(ident)
+        os.replace(tmp, path)                        # atomic: readers never see a half-written id
+        return ident
+    t_launch = time.time() - float(os.environ.get("BCP_DP_ID_MAX_AGE", "120"))
+    t0 = time.time()
+    while True:
+        try:
+            if os.path.getmtime(path) >= t_launch and os.path.getsize(path) == 128:
+                return open(path, "rb").read()
+        except OSError:
+            pass
+        if time.time() - t0 > 120:
+            raise RuntimeError(f"rank {rank}: no RCCL unique id at {path} after 120 s")
+        time.sleep(0.01)
+
+
+_STORES = []
 
 
 class _RcclAbi:
@@ -32,39 +86,15 @@ class _RcclAbi:
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         ident = (C.c_char * 128)()
-        # one file per LAUNCH: port, elastic run id, world size and the launcher's pid (all ranks of a torchrun / spawn share their
-        # parent) -- a file left behind by a crashed earlier launch can never be mistaken for this one's
-        tag = f"{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{world}_{os.environ.get('BCP_DP_LAUNCH_ID', os.getppid())}"
-        path = os.path.join(os.environ.get("BCP_DP_ID_DIR", "/tmp"), f"bcp_rccl_id_{tag}")
         if rank == 0:
             self.b.call("bcp_comm_unique_id", C.cast(ident, C.c_void_p))
-            tmp = path + f".{os.getpid()}"
-            with open(tmp, "wb") as f:
-                f.write(bytes(ident))
-            os.replace(tmp, path)                    # atomic: readers never see a half-written id
-        else:
-            t0 = time.time()
-            while True:
-                try:
-                    if os.path.getmtime(path) >= t0 - 600 and os.path.getsize(path) == 128:
-                        break
-                except OSError:
-                    pass
-                if time.time() - t0 > 120:
-                    raise RuntimeError(f"rank {rank}: no RCCL unique id at {path} after 120 s")
-                time.sleep(0.01)
-            C.memmove(ident, open(path, "rb").read(), 128)
+        C.memmove(ident, _exchange_id(bytes(ident) if rank == 0 else None, world, rank), 128)
         comm = C.c_void_p()
         self.b.call("bcp_comm_init_rank", C.byref(comm), world, rank, C.cast(ident, C.c_void_p))
         self.comm = comm
         self.stream = torch.cuda.Stream(device=self.dev)
-        self.world, self.rank, self._path = world, rank, path
-        self.barrier()                               # every rank has read the id: rank 0 may remove the file
-        if rank == 0:
-            try:
-                os.remove(path)
-            except OSError:
-                pass
+        self.world, self.rank = world, rank
+        self.barrier()
 
     def count(self):
         n = C.c_int(0)
@@ -120,6 +150,7 @@ class DataParallel:
         self.bucket_bytes = int(float(os.environ.get("BCP_DP_BUCKET_MB", "8")) * (1 << 20))
         self.n_collectives = 0
         self._works, self._armed, self._hi = [], False, 0
+        self._exposed, self._buckets = [], []      # (event before, event after) of allreduce_grads' final wait; bucket sizes of the last step
         self.abi = None
         self.backend = None
         if not self.enabled:
@@ -207,6 +238,7 @@ class DataParallel:
 
     def _launch(self, model, lo, hi, like, overlapped):
         g = model.flat_grads()[lo:hi]
+        self._buckets.append(((hi - lo) * 4, bool(overlapped)))
         side = model._side_streams.get(like.device) if (overlapped and like.is_cuda and model.overlap_wgrad) else None
         if side is not None:
             # weight gradients of the layers in this bucket were enqueued on the side stream, norm / bias gradients on the main
@@ -230,9 +262,17 @@ class DataParallel:
             self._armed = False
             if self._hi > 0:
                 self._launch(model, 0, self._hi, g, overlapped=False)
+            ev0 = ev1 = None
+            if g.is_cuda and self._measure:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             for w in self._works:
                 w.wait()                 # rccl / nccl: the current stream waits for the collective; gloo: the host does
+            if ev0 is not None:
+                ev1.record()
+                self._exposed.append((ev0, ev1))
             self._works = []
+            self._last_buckets, self._buckets = self._buckets, []
         else:
             if self.abi is not None:
                 self.abi.all_reduce(g)
@@ -244,6 +284,28 @@ class DataParallel:
             optimizer.grad_scale = 1.0 / self.world
         else:
             g.mul_(1.0 / self.world)
+
+    # ---- measurement (bench.py --gpus N): how long the optimiser's stream really waited for the exchange
+    _measure = False
+    _last_buckets = ()
+
+    def reset_exposed(self):
+        self._exposed, self._measure = [], self.enabled
+
+    def exposed_ms_per_step(self, steps):
+        """stream time between `the backward pass is enqueued` and `every bucket has arrived`, averaged over the timed steps:
+        the part of the gradient exchange the backward pass did not hide (0 when not data-parallel)"""
+        self._measure = False
+        if not self._exposed:
+            return 0.0 if not self.enabled else None
+        torch.cuda.synchronize()
+        tot = sum(a.elapsed_time(b) for a, b in self._exposed)
+        self._exposed = []
+        return round(tot / max(steps, 1), 4)
+
+    def bucket_report(self):
+        return {"bucket_mb_min": self.bucket_bytes / (1 << 20), "transport": self.backend,
+                "buckets_bytes": [b for b, _ in self._last_buckets], "overlapped_with_backward": [o for _, o in self._last_buckets]}
 
     def barrier(self):
         if not self.enabled:

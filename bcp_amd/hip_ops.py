@@ -351,6 +351,22 @@ class Ops:
         self.b.call("bcp_conv3_fwd_stats", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, _p(ws), _p(part), groups, self.stream(x))
         return out, part, rows
 
+    def conv3_dgrad_bwdstats(self, dy, wd, Cin, KD, y_prev, stats_prev, act, groups):
+        """dgrad whose epilogue also accumulates the backward statistics of the norm layer that consumes it (pre-norm tensor y_prev,
+        statistics stats_prev): -> (da, partial, rows) for norm_bwd(partial=, nb=); rows == 0: not fused for this shape (plain dgrad)"""
+        self._chk(dy, wd, y_prev, stats_prev)
+        N, D, H, W, Cout = dy.shape
+        rows = self._ws_bytes("bcp_conv3_bwdstat_rows", N, D, H, W, Cout, Cin, KD, groups)
+        if rows == 0:
+            return self.conv3_fwd(dy, wd, None, Cin, KD), None, 0
+        nbytes = self._ws_bytes("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cout, Cin, KD)
+        ws = self.workspace("conv3", nbytes, dy) if nbytes else None
+        da = torch.empty((N, D, H, W, Cin), dtype=torch.float32, device=dy.device)
+        part = self.workspace(("bstatpart", rows), groups * rows * Cin * 16, dy)
+        self.b.call("bcp_conv3_dgrad_bwdstats", _p(dy), _p(wd), _p(da), N, D, H, W, Cout, Cin, KD, _p(y_prev), _p(stats_prev), act, _p(ws),
+                    _p(part), groups, self.stream(dy))
+        return da, part, rows
+
     def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):
         """dw: torch-layout gradient tensor [Cout,Cin,(3,)3,3], written (or += when accumulate)"""
         self._chk(x, dy, dw)
@@ -515,6 +531,14 @@ class Ops:
         self.b.call("bcp_maxpool2d_fwd", _p(x), _p(y), N, H, W, Cc, self.stream(x))
         return y
 
+    def maxpool3d_k3s2_fwd(self, x):
+        """nn.MaxPool3d(3, stride=2) of a channels-last volume (the V-Net's pooled x5 features; forward only)"""
+        self._chk(x)
+        N, D, H, W, Cc = x.shape
+        y = torch.empty((N, (D - 3) // 2 + 1, (H - 3) // 2 + 1, (W - 3) // 2 + 1, Cc), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_maxpool3d_k3s2_fwd", _p(x), _p(y), N, D, H, W, Cc, self.stream(x))
+        return y
+
     def maxpool2d_bwd(self, x, dy, dx, accumulate=False):
         self._chk(x, dy, dx)
         N, D, H, W, Cc = x.shape
@@ -625,7 +649,7 @@ class Ops:
 # ---------------------------------------------------------------------------------------------- measurement hooks
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
-_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_small", "norm_bwd_small", "conv3_fwd_raw", "conv3_pack_many",
+_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_small", "norm_bwd_small", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "conv3_pack_many",
              "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")

@@ -150,13 +150,17 @@ class VNet(HipNet):
         self._turnoff_drop = bool(turnoff_drop)
         assert N % groups == 0
         self._groups = int(groups)
+        self._feat_out = None
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in (self._layers[0].conv.weight,)):
             out = NetFn.apply(xcl, self._layers[0].conv.weight, self)   # eval() is forward-only (validation, test_3d_patch)
         else:
             out, _ = self._run_forward(xcl, False)
         logits = out.permute(0, 4, 1, 2, 3)  # logical [N,C,X,Y,Z], channels_last_3d strides
         if self.variant == "la":
-            return logits, None   # second value (pooled x5) is dead in every train script (LA_BCP_train.py:158,252)
+            # second value: pool(x5) [N,256,3,3,2] at the LA size (networks/VNet.py:286-290; dead in every train script, LA_BCP_train.py:158,252;
+            # forward only -- no gradient flows into it).  None when the deepest level is smaller than the 3x3x3 window (the reference raises there).
+            f = self._feat_out
+            return logits, (None if f is None else f.permute(0, 4, 1, 2, 3))
         return [logits]
 
     # ------------------------------------------------------------------ schedule
@@ -176,6 +180,7 @@ class VNet(HipNet):
         h = xcl
         skips = []
         saved = []
+        feat = None
         last = len(self._layers) - 1
         Ll = self._layers[last]
         fuse_head = (self.fuse_head and self.training and Ll.kind == "c3" and Ll.cout == 16 and not Ll.skip_pop and N <= 32)
@@ -232,6 +237,8 @@ class VNet(HipNet):
             if save:
                 saved.append((h, y, stats, cs, G))
             h = a
+            if L.drop == "x5" and min(a.shape[1:4]) >= 3:
+                feat = ops.maxpool3d_k3s2_fwd(a)      # pool(features[4]): the reference's second return value (networks/VNet.py:286-290)
         if self.norm == "batchnorm" and self.training:
             for _ in range(G):
                 self._nbt_tick()
@@ -241,6 +248,7 @@ class VNet(HipNet):
             logits = ops.pw16_fwd(h, self._out.weight.data, self._out.bias.data, self.n_classes)
         if save:
             saved.append((h,))          # None when the head is fused: the backward recomputes it from saved[last]
+        logits._bcp_feat = feat         # rides on the result object (launch plans keep it; _run_forward hands out a copy)
         return logits, saved
 
     def _grad_stages(self):
@@ -267,6 +275,7 @@ class VNet(HipNet):
             dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
         skip_grads = []
         nsl = 1                          # dh is a plain gradient tensor (1) or the raw split-K slabs of the dgrad that produced it (> 1)
+        bpart, bnb = None, 0             # backward-statistics partials of THIS layer's norm, left by the dgrad that produced dh
         for li in range(len(self._layers) - 1, -1, -1):
             L = self._layers[li]
             x_in, y, stats, cs, _ = saved[li]
@@ -278,8 +287,8 @@ class VNet(HipNet):
                 dy, da = ops.norm_bwd_small(y, da, nsl, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs, want_da=L.skip_pop)
             else:
                 assert nsl == 1
-                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs)
-            nsl = 1
+                dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs, partial=bpart, nb=bnb)
+            nsl, bpart, bnb = 1, None, 0
             if L.skip_pop:
                 skip_grads.append(da)       # d(out)/d(skip) = identity: the skip source gets `da` itself
             gw, acc = w.grad, True
@@ -305,6 +314,10 @@ class VNet(HipNet):
                 sk = ops.conv3_nslabs(dy.shape, L.cin, 3) if ops.norm_small_ok(G, x_in.numel() // (L.cin * G), L.cin) else 0
                 if sk > 0:
                     dh, nsl = ops.conv3_fwd_raw(dy, wd, L.cin, 3, sk), sk
+                elif li > 0 and saved[li - 1][3] is None:
+                    # conv -> conv edge without a dropout epilogue: the dgrad epilogue leaves the previous norm layer's backward statistics
+                    # (bcp_conv3_dgrad_bwdstats; a plain dgrad when the shape is not served)
+                    dh, bpart, bnb = ops.conv3_dgrad_bwdstats(dy, wd, L.cin, 3, saved[li - 1][1], saved[li - 1][2], H.ACT_RELU, G)
                 else:
                     dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
             elif L.kind == "dw":

@@ -478,7 +478,9 @@ class HipNet(nn.Module):
 
     def _run_forward(self, xcl, save):
         if not self._plan_ok(xcl):
-            return self._forward_impl(xcl, save)
+            r = self._forward_impl(xcl, save)
+            self._feat_out = getattr(r[0], "_bcp_feat", None)
+            return r
         from .. import plan
         self._ensure_flat()
         plans = self._plans_for()
@@ -487,7 +489,9 @@ class HipNet(nn.Module):
         if pl is not None and pl.busy:
             # the plan's static activations belong to a forward whose backward has not run yet (the unfused loop calls the student
             # twice per step): this call must not overwrite them
-            return self._forward_impl(xcl, save)
+            r = self._forward_impl(xcl, save)
+            self._feat_out = getattr(r[0], "_bcp_feat", None)
+            return r
         self._ensure_packed(save)
         if pl is None:
             pl = plan.LaunchPlan()
@@ -504,6 +508,8 @@ class HipNet(nn.Module):
             for _ in range(pl.ticks):
                 self._nbt_tick()
         out, saved = pl.result
+        f = getattr(out, "_bcp_feat", None)
+        self._feat_out = None if f is None else f.clone()
         # the logits leave the plan as a COPY (16 MB at the LA size): callers may hold them across the next replay (logging, the
         # reference's unfused loop), and a replay overwrites the plan's static tensors in place
         if save:

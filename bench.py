@@ -67,10 +67,11 @@ def _numel(s):
 def _work(name, shapes, ints):
     """algorithmic work of one call: (bound, flops, bytes).  SURVEY.md 8d / DESIGN.md section 3: every tensor read / written once"""
     s0 = shapes[0] if shapes else ()
-    if name in ("conv3_fwd", "conv3_fwd_stats"):          # (x [N,D,H,W,Cin], wp, [bias]); ints = (Cout, KD)
+    if name in CONV3_FWD_OPS:                              # (x [N,D,H,W,Cin], wp, [bias | y_prev]); ints = (Cout, KD, ...)
         cout, kd = ints[0], ints[1]
         vox = _numel(s0[:-1])
-        return "mfma", 2.0 * vox * kd * 9 * s0[-1] * cout, 4.0 * (_numel(s0) + vox * cout)
+        extra = vox * cout if name == "conv3_dgrad_bwdstats" else 0      # the epilogue also reads the consumer norm layer's y
+        return "mfma", 2.0 * vox * kd * 9 * s0[-1] * cout, 4.0 * (_numel(s0) + vox * cout + extra)
     if name == "conv3_wgrad":                              # (x, dy, dw); ints = (KD,)
         vox = _numel(s0[:-1])
         return "mfma", 2.0 * vox * ints[0] * 9 * s0[-1] * shapes[1][-1], 4.0 * (_numel(s0) + _numel(shapes[1]))
@@ -89,6 +90,13 @@ def _work(name, shapes, ints):
         fl = 2.0 * min(_numel(s0[:-1]), _numel(shapes[1][:-1])) * 8 * s0[-1] * shapes[1][-1]
         by = 4.0 * (_numel(s0) + _numel(shapes[1]))
         return ("hbm" if fl / by < 20 else "mfma"), fl, by
+    if name == "norm_fwd_small":                           # (slabs [nslab, ...] | y, ...); ints = (nslab, G, act): read the slabs, write y and a
+        nsl = ints[0] if ints else 1
+        n = _numel(s0) // (nsl if len(s0) == 6 else 1)
+        return "hbm", 0.0, 4.0 * n * ((nsl if len(s0) == 6 else 1) + 2)
+    if name == "norm_bwd_small":                           # (y, da slabs | da, ...): read y and the slabs, write dy
+        s1 = shapes[1] if len(shapes) > 1 else s0
+        return "hbm", 0.0, 4.0 * (2 * _numel(s0) + _numel(s1))
     if name == "norm_fwd":                                 # statistics (fused into the conv when possible) + apply: read y twice, write a
         return "hbm", 0.0, 12.0 * _numel(s0)
     if name == "norm_bwd":                                 # statistics pass over (y, da) + apply pass reading both, writing dy
@@ -116,6 +124,9 @@ def _work(name, shapes, ints):
     if name == "adam":
         return "hbm", 0.0, 28.0 * _numel(s0)
     return None, 0.0, 0.0
+
+
+CONV3_FWD_OPS = ("conv3_fwd", "conv3_fwd_stats", "conv3_fwd_raw", "conv3_dgrad_bwdstats")
 
 
 def _conv3_path(xshape, ints, wgrad_cout=None):
@@ -146,7 +157,7 @@ def op_table(records, steps, step_ms, top=14):
             tf = fl / (avg * 1e-3) / 1e12
             pipe, peak = "f32", PEAK_F32_MFMA_TFLOPS
             on_bf16 = False
-            if name in ("conv3_fwd", "conv3_fwd_stats") and shapes and len(shapes[0]) == 5:
+            if name in CONV3_FWD_OPS and shapes and len(shapes[0]) == 5:
                 on_bf16 = _conv3_path(shapes[0], ints)
             elif name == "conv3_wgrad" and len(shapes) > 1 and len(shapes[0]) == 5:
                 on_bf16 = _conv3_path(shapes[0], ints, wgrad_cout=shapes[1][-1])
@@ -345,6 +356,88 @@ def make_workload(args, dp, dev):
                           "(BASELINE.json configs[4])", "gflop_per_item": 70.72 * 2}
 
 
+def measure(args, dp, dev, cpu_budget_s=45.0, trim=False):
+    """one workload under the timing contract: W warm-ups, K timed steps between barrier + synchronize, max over ranks; then the
+    per-op table from profiled steps and (rank 0, N = 1) the CPU baseline.  -> the JSON object of the line (rank 0), None elsewhere"""
+    step, info = make_workload(args, dp, dev)
+    ranks_seen = dp.ranks_seen()
+
+    for _ in range(args.warmup):
+        step()
+    dp.barrier()
+    torch.cuda.synchronize()
+    dp.reset_exposed()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (host-bound if ~= the total)
+    torch.cuda.synchronize()
+    dp.barrier()
+    dt = time.perf_counter() - t0
+    dt = dp.max_over_ranks(dt)
+    loss = float(r["loss"])
+    assert np.isfinite(loss), "non-finite loss in the timed region"
+    exposed = dp.exposed_ms_per_step(args.steps)
+    # host cost of ONE step with an empty queue (t_enq above includes back-pressure: once the host runs ahead, hipLaunchKernel
+    # blocks on the full queue and "enqueue time" just tracks the GPU)
+    host_one = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        step()
+        host_one.append(time.perf_counter() - h0)
+    torch.cuda.synchronize()
+    host_ms = sorted(host_one)[len(host_one) // 2] * 1e3
+
+    rows_top, rows_all, prof_ms = [], [], None
+    if args.profile_steps > 0:
+        recs, prof_ms = profile_steps(step, args.profile_steps)
+        rows_top, rows_all = op_table(recs, args.profile_steps, dt / args.steps * 1e3, top=8 if trim else 14)
+    dp.barrier()
+    del step
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
+    if dp.rank != 0:
+        return None
+    ms = dt / args.steps * 1e3
+    global_batch = args.batch_size * dp.world
+    value = global_batch * args.steps / dt
+    step_tflops = value * info["gflop_per_item"] / 1e3 / dp.world
+    out = {
+        "metric": info["metric"], "value": round(value, 3), "unit": info["unit"], "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "host_ms_per_step_empty_queue": round(host_ms, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6),
+                   "arithmetic": "fp32 tensors, fp32 accumulation; the 16- to 256-channel 3x3x3 / 3x3 convolutions (forward, dgrad, weight gradient) take their fp32 "
+                                 "operands as three bf16 pieces each and run six bf16 MFMAs per product block (csrc/conv3b.hip, conv3bw.hip): fp32-equivalent "
+                                 "results -- same parity tolerances as the fp32-MFMA kernels (tests/kernel_checks.py check_conv3_b6, tests/test_gpu_vnet.py)"},
+        "ranks_seen": ranks_seen,
+        "step_flops": {"gflop_per_item": info["gflop_per_item"], "achieved_tflops_per_gpu": round(step_tflops, 2),
+                       "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                       "frac_of_bf16x3_peak": round(step_tflops / PEAK_BF16X3_F32EQ_TFLOPS, 4)},
+    }
+    if dp.world > 1:
+        # how much of the gradient exchange the backward pass did NOT hide: wall time the optimiser's stream waited for the last
+        # buckets (HIP events around allreduce_grads' final wait), and the bucket plan the run used
+        out["allreduce_exposed_ms"] = exposed
+        out["allreduce_buckets"] = dp.bucket_report()
+    if rows_all:
+        out["roofline"] = roofline_from(rows_all, "mfma")
+        out["roofline_hbm"] = roofline_from(rows_all, "hbm")
+        out["kernels"] = rows_top
+        out["kernels_note"] = (f"{args.profile_steps} profiled steps of {prof_ms:.2f} ms after the timed region; ms_per_step sums over streams "
+                               "(teacher / student / weight-gradient streams overlap), so shares add up to more than 1")
+    else:
+        out["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
+    r0 = out["roofline"] or {}
+    print(f"[bench] {args.workload} gpu: {value:.2f} {info['unit']}, {ms:.2f} ms/step (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step), "
+          f"dominant MFMA op {r0.get('kernel')} {r0.get('achieved')} TFLOP/s", file=sys.stderr, flush=True)
+    if dp.world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.workload, args.batch_size, args.labeled_bs, budget_s=cpu_budget_s)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -359,6 +452,7 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning switch (bcp_set_option) for A/B measurements; the product defaults need none")
     ap.add_argument("--no-roofline", action="store_true", help="same as --profile-steps 0 (A/B runs)")
+    ap.add_argument("--no-extra", action="store_true", help="la, 1 GPU: skip the secondary lines (extra_workloads: acdc, pancreas; cpu_only: configs[0])")
     args = ap.parse_args()
     if args.batch_size is None:
         args.batch_size = {"la": 4, "acdc": 24, "pancreas": 4}[args.workload]
@@ -388,70 +482,28 @@ def main():
             VNet.fuse_head = bool(int(v))
             continue
         ops.set_option(k, v)
-    step, info = make_workload(args, dp, dev)
-    ranks_seen = dp.ranks_seen()
-
-    for _ in range(args.warmup):
-        step()
-    dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step()
-    t_enq = time.perf_counter() - t0          # host time to enqueue the K steps (host-bound if ~= the total)
-    torch.cuda.synchronize()
-    dp.barrier()
-    dt = time.perf_counter() - t0
-    dt = dp.max_over_ranks(dt)
-    loss = float(r["loss"])
-    assert np.isfinite(loss), "non-finite loss in the timed region"
-    # host cost of ONE step with an empty queue (t_enq above includes back-pressure: once the host runs ahead, hipLaunchKernel
-    # blocks on the full queue and "enqueue time" just tracks the GPU)
-    host_one = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        h0 = time.perf_counter()
-        step()
-        host_one.append(time.perf_counter() - h0)
-    torch.cuda.synchronize()
-    host_ms = sorted(host_one)[len(host_one) // 2] * 1e3
-
-    rows_top, rows_all, prof_ms = [], [], None
-    if args.profile_steps > 0:
-        recs, prof_ms = profile_steps(step, args.profile_steps)
-        rows_top, rows_all = op_table(recs, args.profile_steps, dt / args.steps * 1e3)
-    dp.barrier()
-
+    out = measure(args, dp, dev)
     if dp.rank == 0:
-        ms = dt / args.steps * 1e3
-        global_batch = args.batch_size * dp.world
-        value = global_batch * args.steps / dt
-        step_tflops = value * info["gflop_per_item"] / 1e3 / dp.world
-        out = {
-            "metric": info["metric"], "value": round(value, 3), "unit": info["unit"], "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "host_ms_per_step_empty_queue": round(host_ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6),
-                       "arithmetic": "fp32 tensors, fp32 accumulation; the 32- to 128-channel 3x3x3 convolutions (forward / dgrad) take their fp32 operands as "
-                                     "three bf16 pieces each and run six bf16 MFMAs per product block (csrc/conv3b.hip): fp32-equivalent results -- same parity "
-                                     "tolerances as the fp32-MFMA kernels (tests/kernel_checks.py check_conv3_b6, tests/test_gpu_vnet.py)"},
-            "ranks_seen": ranks_seen,
-            "step_flops": {"gflop_per_item": info["gflop_per_item"], "achieved_tflops_per_gpu": round(step_tflops, 2),
-                           "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
-        }
-        if rows_all:
-            out["roofline"] = roofline_from(rows_all, "mfma")
-            out["roofline_hbm"] = roofline_from(rows_all, "hbm")
-            out["kernels"] = rows_top
-            out["kernels_note"] = (f"{args.profile_steps} profiled steps of {prof_ms:.2f} ms after the timed region; ms_per_step sums over streams "
-                                   "(teacher / student / weight-gradient streams overlap), so shares add up to more than 1")
-        else:
-            out["roofline"] = {"bound": "mfma", "achieved": None, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None, "traffic": None}
-        r0 = out["roofline"] or {}
-        print(f"[bench] gpu: {value:.2f} {info['unit']}, {ms:.2f} ms/step (host enqueue {t_enq / args.steps * 1e3:.2f} ms/step), "
-              f"dominant MFMA op {r0.get('kernel')} {r0.get('achieved')} TFLOP/s", file=sys.stderr, flush=True)
-        if dp.world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.workload, args.batch_size, args.labeled_bs)
+        if dp.world == 1 and args.workload == "la" and not args.no_extra:
+            # the north_star's other single-GPU lines in the same driver-run record (same timing contract, own roofline + cpu_baseline),
+            # bounded: fewer timed steps and a shorter CPU sample each
+            import copy
+            extra = {}
+            for wl in ("acdc", "pancreas"):
+                a2 = copy.copy(args)
+                a2.workload, a2.batch_size, a2.labeled_bs = wl, {"acdc": 24, "pancreas": 4}[wl], {"acdc": 12, "pancreas": 2}[wl]
+                a2.profile_steps = min(args.profile_steps, 2)
+                try:
+                    extra[wl] = measure(a2, dp, dev, cpu_budget_s=20.0, trim=True)
+                except Exception as e:      # the headline line must survive a failure of a secondary one
+                    extra[wl] = {"error": f"{type(e).__name__}: {e}"}
+            out["extra_workloads"] = extra
+            if not args.no_cpu_baseline:
+                try:
+                    # BASELINE.json configs[0]: ACDC batch 8 (4 labeled) -- the reference's CPU-runnable case: the oracle on the host cores
+                    out["cpu_only"] = {"configs[0] ACDC 2D U-Net batch 8 (4 labeled) 256x256, CPU": cpu_baseline("acdc", 8, 4, budget_s=15.0)}
+                except Exception as e:
+                    out["cpu_only"] = {"error": f"{type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     dp.shutdown()
 

@@ -102,8 +102,8 @@ int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_grou
                  const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
                  float* dbeta, int accumulate, void* workspace, const double* partial_in_or_null, int nb_in, float* dy, void* stream);
 /* partial_in: (sum dz, sum dz*xhat) partials [G][nb_in][C][2] computed by the caller -- the statistics pass over (y, da) is
- * skipped (not available together with chan_scale / elem_mask).  No kernel of this library produces them any more: the dgrad
- * epilogue that did was slower in the step and was removed in round 2; pass NULL. */
+ * skipped (not available together with chan_scale / elem_mask).  Producer: bcp_conv3_dgrad_bwdstats (round 3: the epilogue of the
+ * bf16-pipe dgrad kernels, where the extra vector work overlaps the matrix pipe). */
 
 /* One-launch variants for SMALL groups (rows_per_group <= 4096: the 128- / 256-channel levels of the V-Nets, the U-Net's
  * deepest level -- networks/VNet.py:74-86,101-113 block_four .. block_six, networks/unet.py down4 / up1): a workgroup owns four
@@ -142,6 +142,16 @@ int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, fl
 int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace);
 int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin,
                         int Cout, int KD, void* workspace_or_null, double* stat_partial, int groups, void* stream);
+/* dgrad with the CONSUMER's norm-backward statistics in its epilogue (bf16-pipe kernels; autograd of Conv3d/Conv2d followed by
+ * BatchNorm/InstanceNorm backward, networks/VNet.py:17-26): the output da feeds the norm layer whose pre-norm tensor is y_prev and
+ * whose statistics are stats_prev ([5][groups][Cout] as bcp_norm_fwd leaves them); stat_partial = double[groups][rows][Cout][2]
+ * receives (sum dz, sum dz * xhat), dz = da * act'(z), rows = bcp_conv3_bwdstat_rows(...) (0: unavailable -> bcp_conv3_fwd), and
+ * goes to bcp_norm_bwd as partial_in / nb_in.  Cin / Cout are those of THIS launch (Cin = channels of dy, Cout = channels of da).
+ * Only for norm layers without chan_scale / elem_mask. */
+int bcp_conv3_bwdstat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups);
+int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout, int KD,
+                             const float* y_prev, const float* stats_prev, int act, void* workspace_or_null, double* stat_partial,
+                             int groups, void* stream);
 /* raw variant for the deep levels: the kernel's split-K partial slabs are the result -- slabs = float[nslabs][N*D*H*W*Cout], no bias,
  * no slab-sum launch; bcp_norm_fwd_small / bcp_norm_bwd_small sum them on their way in.  nslabs = bcp_conv3_fwd_nslabs(...) under the
  * current options (1..8; 0: shape not served in raw mode -> bcp_conv3_fwd).  Forward and dgrad alike. */
@@ -193,6 +203,9 @@ int bcp_colsum(const float* x, long long rows, int C, float* out, int accumulate
 
 /* ---- 2-D U-Net plumbing (networks/unet.py:36-57): MaxPool2d(2), bilinear x2 align_corners=True, channel concat ---- */
 int bcp_maxpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* nn.MaxPool3d(3, stride=2), forward only: pool(x5), the V-Net's second return value (networks/VNet.py:246,286-290); x [N][D][H][W][C]
+ * -> y [N][(D-3)/2+1][(H-3)/2+1][(W-3)/2+1][C] */
+int bcp_maxpool3d_k3s2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
 int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate, void* stream);
 int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int y_off, void* stream);
 int bcp_bilinear2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, int lddy, int dy_off, void* stream);

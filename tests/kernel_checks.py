@@ -448,6 +448,10 @@ def check_pool2d(ops, dev):
     assert torch.equal(from_cl(y, True).cpu(), y_ref.detach())
     dx = ops.maxpool2d_bwd(xcl, to_cl(dy).to(dev), torch.empty_like(xcl))
     assert torch.equal(from_cl(dx, True).cpu(), x.grad)
+    # nn.MaxPool3d(3, stride=2): the V-Net's pooled x5 features (7x7x5 -> 3x3x2 at the LA size), odd and even extents
+    for sp in ((7, 7, 5), (6, 8, 3), (3, 3, 3)):
+        x3 = R(rng, 2, 32, *sp)
+        assert torch.equal(from_cl(ops.maxpool3d_k3s2_fwd(to_cl(x3).to(dev))).cpu(), F.max_pool3d(x3, 3, stride=2)), f"maxpool3d {sp}"
     # bilinear x2 align_corners=True into the second half of a concat buffer, and its backward
     x = R(rng, 2, 16, 5, 7).requires_grad_(True)
     skip = R(rng, 2, 16, 10, 14)
@@ -835,6 +839,67 @@ def check_norm_small(ops, dev):
                 ops.set_option("splitk")
 
 
+def check_dgrad_bwdstats(ops, dev):
+    """dgrad epilogue with the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): da bit-identical to the plain
+    dgrad, the partial rows sum to k_col_partial<1>'s (sum dz, sum dz * xhat), and norm_bwd fed with them equals the norm_bwd that
+    runs its own statistics pass; shapes of every bf16-pipe kernel family that carries the epilogue (k_c3d one-tile / persistent,
+    k_c3h, k_c3b, 2-D), ragged tiles and padded channels included"""
+    rng = np.random.default_rng(57)
+    cases = (  # N, C_dy (channels of dy), C_da (channels of da = the consumer norm's channels), spatial, KD, G, act
+        (2, 32, 32, (8, 16, 16), 3, 2, H.ACT_RELU),       # k_c3d 4x8x8 x 32
+        (2, 32, 32, (5, 9, 11), 3, 1, H.ACT_RELU),        # ragged tiles
+        (2, 64, 64, (16, 16, 40), 3, 2, H.ACT_RELU),      # k_c3h (> 16 K voxels and > 256 tiles, or the launch is split-K; below that the flat deep-level kernel, which hands raw slabs to the one-launch norm instead)
+        (2, 16, 16, (16, 16, 32), 3, 2, H.ACT_RELU),      # persistent k_c3d (forced below)
+        (2, 16, 32, (6, 10, 12), 3, 2, H.ACT_RELU),       # channel counts differ
+        (4, 32, 32, (1, 32, 48), 1, 2, H.ACT_LRELU),      # 2-D
+        (3, 64, 64, (1, 80, 96), 1, 1, H.ACT_LRELU),
+    )
+    ops.set_option("conv3_b6", 3)       # every eligible shape on the bf16 pipe (the 16-channel persistent kernel included)
+    try:
+        n_fused, fused_tags = 0, []
+        for (N, Cdy, Cda, sp, KD, G, act) in cases:
+            two_d = KD == 1
+            w = R(rng, Cdy, Cda, *((3, 3) if two_d else (3, 3, 3))) * 0.1      # forward weight [Cout = Cdy][Cin = Cda]
+            _, wd = ops.conv3_pack(w.to(dev).contiguous(), KD)
+            shape = (N, 1, sp[1], sp[2]) if two_d else (N,) + sp
+            dy = torch.from_numpy(rng.standard_normal(shape + (Cdy,), dtype=np.float32)).to(dev)
+            yprev = (torch.from_numpy(rng.standard_normal(shape + (Cda,), dtype=np.float32)) * 1.3 + 0.2).to(dev)
+            gam, bet = torch.from_numpy(rng.uniform(0.5, 1.5, Cda).astype(np.float32)).to(dev), torch.from_numpy(rng.uniform(-0.3, 0.3, Cda).astype(np.float32)).to(dev)
+            _, st = ops.norm_fwd(yprev, G, gam, bet, torch.zeros(Cda).to(dev), torch.ones(Cda).to(dev), act)
+            da_ref = ops.conv3_fwd(dy, wd, None, Cda, KD)
+            da, part, rows = ops.conv3_dgrad_bwdstats(dy, wd, Cda, KD, yprev, st, act, G)
+            tag = f"dgrad_bwdstats {Cdy}->{Cda} {sp} G={G}"
+            assert torch.equal(da.cpu(), da_ref.cpu()), tag + ": da differs from the plain dgrad"
+            if rows == 0:
+                continue
+            n_fused += 1
+            fused_tags.append(tag)
+            pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cda * 16]), dtype=torch.float64).view(G, rows, Cda, 2).sum(1)
+            # reference sums in fp64 from the same fp32 per-element arithmetic
+            mean, rstd, scale, shift = [st[k].cpu() for k in range(4)]
+            yv = yprev.cpu().view(G, -1, Cda)
+            dav = da_ref.cpu().view(G, -1, Cda)
+            z = (yv - mean[:, None]) * scale[:, None] + shift[:, None]
+            gr = torch.where(z > 0, torch.ones_like(z), torch.full_like(z, 0.01 if act == H.ACT_LRELU else 0.0))
+            g1 = (dav * gr).double()
+            xh = ((yv - mean[:, None]) * rstd[:, None]).double()
+            close(pt[..., 0], g1.sum(1), rtol=1e-5, msg=tag + " sum dz")
+            close(pt[..., 1], (g1 * xh).sum(1), rtol=1e-5, msg=tag + " sum dz*xhat")
+            dg1, db1 = torch.zeros(Cda).to(dev), torch.zeros(Cda).to(dev)
+            dg2, db2 = torch.zeros(Cda).to(dev), torch.zeros(Cda).to(dev)
+            d1 = ops.norm_bwd(yprev, da, G, st, act, dg1, db1, False, partial=part, nb=rows)
+            d2 = ops.norm_bwd(yprev, da_ref, G, st, act, dg2, db2, False)
+            close(d1, d2, rtol=2e-5, msg=tag + " norm_bwd from fused partials")
+            close(dg1, dg2, rtol=2e-5, msg=tag + " dgamma")
+            close(db1, db2, rtol=2e-5, msg=tag + " dbeta")
+        assert n_fused >= 7, f"only {n_fused} shapes took the fused path: {fused_tags}"
+        ops.set_option("fuse_bwd_stats", 0)
+        assert ops.conv3_dgrad_bwdstats(dy, wd, Cda, KD, yprev, st, act, G)[2] == 0
+    finally:
+        ops.set_option("fuse_bwd_stats")
+        ops.set_option("conv3_b6")
+
+
 def check_augment(ops, dev, golden_dir):
     """device-side RandomRotFlip + RandomCrop == the REFERENCE's transform classes on the same np.random state
     (tests/golden/aug_la.npz), bit for bit, and == the oracle restatement"""
@@ -921,4 +986,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("norm_small", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+ALL_CHECKS = ("norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")

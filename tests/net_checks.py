@@ -866,6 +866,34 @@ def check_vnet_pattern_grads(ops, dev, variant="la", shape=(32, 32, 16), seed=11
     return worst
 
 
+def check_vnet_features(ops, dev, shape=(48, 48, 48)):
+    """the LA V-Net's SECOND return value (networks/VNet.py:286-290): pool(features[4]) = MaxPool3d(3, stride=2) of the (dropped-out)
+    x5 -- eager path, recorded launch plan and its replay; x5 itself is pinned by the forward parity checks"""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(77)
+    P = O.init_params(O.vnet_param_shapes(), seed=78, random_affine=True)
+    x = torch.from_numpy(rng.standard_normal((2, 1) + shape, dtype=np.float32)).to(dev)
+    net = make_vnet(P, dev, ops)
+    net._keep_saved = True                     # (also keeps this call on the eager path)
+    out, feat = net(x)
+    idx5 = max(i for i, L in enumerate(net._layers) if L.name.startswith("block_five."))
+    x5 = net._last_saved[idx5 + 1][0]           # input of block_five_up = x5 after Dropout3d, channels-last
+    ref = F.max_pool3d(x5.permute(0, 4, 1, 2, 3), 3, stride=2)
+    assert tuple(feat.shape) == (2, 256) + tuple((s // 16 - 3) // 2 + 1 for s in shape), tuple(feat.shape)
+    assert torch.equal(feat.contiguous().cpu(), ref.contiguous().cpu())
+    net._keep_saved = False
+    net.drop_masks = None
+    for _ in range(3):                          # record, replay, replay: the pooled features come out of the plan as a copy
+        o2, f2 = net(x)
+        assert f2 is not None and tuple(f2.shape) == tuple(feat.shape) and bool(torch.isfinite(f2).all())
+    net.eval()
+    with torch.no_grad():
+        o3, f3 = net(x)
+    assert tuple(f3.shape) == tuple(feat.shape)
+    small = make_vnet(P, dev, ops)
+    assert small(x[:, :, :32, :32, :16])[1] is None      # deepest level 2x2x1: smaller than the window (the reference raises there)
+
+
 def check_unet_pattern_grads(ops, dev, hw=(64, 64), N=2, seed=12, bound=1e-4):
     """the 2-D U-Net (LeakyReLU, elementwise dropout) under the same construction as check_vnet_pattern_grads"""
     rng = np.random.default_rng(seed)

@@ -133,3 +133,113 @@ def test_dp2_unet_buckets_equal_single_allreduce(tmp_path):
     assert out["1"][0]["collectives"] >= 3 and out["0"][0]["collectives"] == 1
     assert torch.equal(out["1"][0]["flat"], out["0"][0]["flat"]), "bucketed and single all-reduce must give identical steps"
     assert out["1"][0]["loss"] == out["0"][0]["loss"]
+
+
+# ---------------------------------------------------------------------------------------------- C5: pancreas, 4 ranks, Adam
+PSHAPE = (16, 16, 16)
+
+
+def _pancreas_inputs(O, rank):
+    vol, lab = O.synth_la_batch(4, shape=PSHAPE, seed=500 + rank)
+    return vol, lab, (1 + rank % 2, 2, 1 + rank // 2, 10, 10, 10)
+
+
+def _worker_pancreas(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BCP_DP_BUCKET_MB="8")
+    os.environ["BCP_EMU_THREADS"] = "2"
+    torch.set_num_threads(1)
+    O, NC, train_step, ops = _setup()
+    from bcp_amd.dp import DataParallel
+    dp = DataParallel(backend="gloo")
+    P = O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=21 + rank, random_affine=True)     # different per rank: the broadcast fixes it
+    model = NC.make_vnet(P, torch.device("cpu"), ops, variant="pancreas", has_dropout=False)
+    ema = NC.make_vnet(P, torch.device("cpu"), ops, variant="pancreas", has_dropout=False)
+    for p in ema.parameters():
+        p.detach_()
+    dp.broadcast_params(model)
+    dp.broadcast_params(ema)
+    opt = train_step.FlatAdam(model, lr=1e-3)
+    vol, lab, box = _pancreas_inputs(O, rank)
+    r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=box, variant="pancreas", connect_mode=2, dp=dp)
+    torch.save({"flat": model.flat_params().clone(), "ema": ema.flat_params().clone(), "loss": float(r["loss"]),
+                "collectives": dp.n_collectives}, os.path.join(out_dir, f"panc_rank{rank}.pt"))
+    dp.shutdown()
+
+
+@pytest.mark.slow
+def test_dp4_pancreas_adam_equals_four_averaged_microbatches(tmp_path):
+    """BASELINE.json configs[4]'s partitioning: FOUR ranks, each with its own four pancreas streams and box, the
+    InstanceNorm V-Net and Adam -- after one step every rank holds the same student / teacher, equal to one Adam step on the average
+    of the four ranks' gradients (tiny 16^3 patches on the host simulator; the collective, buckets and 1/world scaling are the product's)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_pancreas, args=(4, port, str(tmp_path)), nprocs=4, join=True)
+    rs = [torch.load(tmp_path / f"panc_rank{r}.pt") for r in range(4)]
+    for r in rs[1:]:
+        assert torch.equal(rs[0]["flat"], r["flat"]) and torch.equal(rs[0]["ema"], r["ema"]), "ranks diverged"
+        assert r["collectives"] == rs[0]["collectives"] >= 1
+    O, NC, train_step, ops = _setup()
+    P = O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=21, random_affine=True)
+    dev = torch.device("cpu")
+    gsum = None
+    for rank in range(4):
+        m = NC.make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+        e = NC.make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+        vol, lab, box = _pancreas_inputs(O, rank)
+        r = train_step.la_self_train_step(m, e, None, vol, lab, 2, box=box, variant="pancreas", connect_mode=2)
+        assert abs(float(r["loss"]) - rs[rank]["loss"]) < 1e-6
+        g = m.flat_trainable()[1].clone()
+        gsum = g if gsum is None else gsum + g
+    m = NC.make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+    opt = train_step.FlatAdam(m, lr=1e-3)
+    m.begin_backward()
+    m.flat_trainable()[1].copy_(gsum)
+    opt.grad_scale = 0.25
+    opt.step()
+    # Adam's first update is lr * g / (|g| + eps): compare the UPDATES (summation order of the four ranks' gradients differs between a ring
+    # all-reduce and the sequential sum, and elements with |g| ~ eps amplify that)
+    P0 = NC.make_vnet(P, dev, ops, variant="pancreas", has_dropout=False).flat_params()
+    du, dr = m.flat_params() - P0, rs[0]["flat"] - P0
+    frac_close = float(((du - dr).abs() < 1e-5).float().mean())
+    assert frac_close > 0.999, f"only {frac_close:.5f} of the Adam updates agree with the averaged-micro-batch step"
+
+
+# ---------------------------------------------------------------------------------------------- RCCL unique-id exchange (no GPU needed)
+def _worker_id(rank, world, port, out_dir, id_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BCP_DP_LAUNCH_ID="t%d" % port)
+    if id_dir:
+        os.environ["BCP_DP_ID_DIR"] = id_dir
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from bcp_amd import dp
+    got = []
+    for k in range(2):            # two communicators in one launch: independent keys
+        ident = bytes([(17 * k + i) % 251 for i in range(128)]) if rank == 0 else None
+        got.append(dp._exchange_id(ident, world, rank))
+    torch.save(got, os.path.join(out_dir, f"id_{'file' if id_dir else 'store'}_{rank}.pt"))
+
+
+@pytest.mark.parametrize("transport", ["store", "file"])
+def test_rccl_unique_id_exchange(tmp_path, transport):
+    """bcp_amd/dp.py::_exchange_id: rank 0's 128-byte id reaches every rank over the c10d store at MASTER_ADDR:MASTER_PORT (default;
+    multi-node capable) or, with BCP_DP_ID_DIR, through a per-launch file -- where a stale file of an earlier launch is never accepted"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    id_dir = ""
+    if transport == "file":
+        id_dir = str(tmp_path / "ids")
+        os.makedirs(id_dir)
+        stale = os.path.join(id_dir, f"bcp_rccl_id_{port}_none_3_t{port}_1")      # same name as this launch's first id, left by a "crashed" run
+        open(stale, "wb").write(b"\xff" * 128)
+        os.utime(stale, (1, 1))
+    mp.spawn(_worker_id, args=(3, port, str(tmp_path), id_dir), nprocs=3, join=True)
+    res = [torch.load(tmp_path / f"id_{transport}_{r}.pt") for r in range(3)]
+    for k in range(2):
+        want = bytes([(17 * k + i) % 251 for i in range(128)])
+        assert all(r[k] == want for r in res), f"communicator {k}: ids differ"

@@ -92,3 +92,8 @@ def test_recorded_launch_plans_equal_eager_path(emu_ops):
 def test_head_fused_with_last_norm_equals_separate_apply(emu_ops):
     """VNet.fuse_head: block_nine's norm + ReLU + Dropout3d applied inside the 1x1x1 head (its activation never stored)"""
     NC.check_fused_head(emu_ops, CPU, steps=1)
+
+
+@pytest.mark.extended
+def test_vnet_second_output_is_pooled_x5(emu_ops):
+    NC.check_vnet_features(emu_ops, CPU)

@@ -45,7 +45,8 @@ def test_vnet_la_full_shape_vs_reference_golden(ops, golden_dir):
     x, lab = O.synth_la_batch(1, seed=m["data_seed"])
     net = NC.make_vnet(P, DEV, ops)
     net.drop_masks = {"x5": torch.from_numpy(g["drop_x5"]), "x9": torch.from_numpy(g["drop_x9"])}
-    out, _ = net(x.to(DEV))
+    out, feat = net(x.to(DEV))
+    assert tuple(feat.shape) == (1, 256, 3, 3, 2)          # pool(x5), the reference's second return value (networks/VNet.py:286-290)
     from bcp_amd.utils import BCP_utils as BU
     loss = BU.sup_loss(out, lab.to(DEV))
     assert abs(float(loss.detach()) - float(g["loss"])) < 1e-5, (float(loss.detach()), float(g["loss"]))
@@ -63,11 +64,18 @@ def test_vnet_la_full_shape_vs_reference_golden(ops, golden_dir):
     assert abs(d_ref - d_hip) < 1e-4, (d_ref, d_hip)
     loss.backward()
     params = dict(net.named_parameters())
+    # SANITY ONLY (not a parity gate): every gradient tensor's L2 norm lands within 3 % of the reference's recorded norm -- two fp32
+    # gradients of a half-ReLU network differ by 3e-3..7e-3 per tensor in the reference's own arithmetic.  The
+    # full-size backward is PINNED by test_la_full_size_gradients_on_hip_activation_pattern (rel-L2 of the difference <= 1e-4).
     for n_, stg in zip([str(n) for n in g["grad_names"]], g["grad_stats"]):
         if NC.is_prenorm_bias(n_, params):
             continue
         l2 = float(params[n_].grad.double().norm())
         assert abs(l2 - stg[2]) / max(stg[2], 1e-12) < 3e-2, (n_, l2, stg[2])
+
+
+def test_vnet_second_output_is_pooled_x5(ops):
+    NC.check_vnet_features(ops, DEV)
 
 
 def test_grouped_forward_equals_separate_calls(ops):
