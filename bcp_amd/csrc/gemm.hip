@@ -129,10 +129,13 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const float4 b = ld4(Bs + (((kq * 4 + lg) * CT) + nt * 16 + li) * 4);
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.y, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b.z, acc[nt], 0, 0, 0);
-        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b.w, acc[nt], 0, 0, 0);
+        // D^T = B^T x A^T: rows of the MFMA = output columns (channels), columns = GEMM rows (voxels), so that a lane ends with FOUR
+        // CONSECUTIVE channels of one voxel -- 16-byte stores / accumulate loads in the epilogue (the transposed-conv scatter wrote
+        // 64-byte runs with dword stores: 2.8 TB/s on a 160 MB stream)
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.x, a.x, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.y, a.y, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.z, a.z, acc[nt], 0, 0, 0);
+        acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(b.w, a.w, acc[nt], 0, 0, 0);
       }
     }
     if (!has_next) break;
@@ -140,22 +143,20 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
     stash();
     __syncthreads();
   }
-  // epilogue: lane (li, lg) holds rows m0 + wave*16 + lg*4 + r, column n0 + nt*16 + li
-  long long cb[4];
-  const int mr = m0 + wave * 16 + lg * 4;
-  C.base4(mr < M ? mr : 0, cb);
+  // epilogue: lane (li, lg) holds row m0 + wave*16 + li, columns n0 + nt*16 + lg*4 .. + 3
+  const int mr = m0 + wave * 16 + li;
+  if (mr < M) {
+    float* crow = C.p + C.base(mr) + lg * 4;                            // one row decomposition per lane
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const long long coff = C.off16(n0 + nt * 16) + li;                  // block-uniform + lane
-    const float bv = bias ? bias[(n0 + nt * 16) % bias_mod + li] : 0.f;  // bias_mod % 16 == 0
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      if (mr + r < M) {
-        float* o = C.p + cb[r] + coff;
-        float v = acc[nt][r] + bv;
-        if (accumulate) v += *o;
-        *o = v;
+    for (int nt = 0; nt < NT; ++nt) {
+      float* o = crow + C.off16(n0 + nt * 16);                          // block-uniform offset (Cs % 16 == 0)
+      float4 v = make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]);
+      if (bias) {
+        const float4 bv = ld4(bias + (n0 + nt * 16) % bias_mod + lg * 4);   // bias_mod % 16 == 0
+        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       }
+      if (accumulate) { const float4 p = ld4(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
+      st4(o, v);
     }
   }
 }

@@ -359,9 +359,10 @@ def update_model_ema(model, ema_model, alpha):
 
 
 def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
-                         u_weight=0.5, alpha=0.99, dp=None, grouped=True, overlap=True):
+                         u_weight=0.5, alpha=0.99, dp=None, grouped=True, overlap=True, plabs=None):
     """One ACDC self-training iteration, ACDC_BCP_train.py:355-390 (grouped: see la_self_train_step; needs
-    labeled_bs == batch - labeled_bs so that both halves have equal size)."""
+    labeled_bs == batch - labeled_bs so that both halves have equal size).  plabs / optimizer=None: the parity hooks of
+    la_self_train_step (forced pseudo-labels; gradient-only mode)."""
     bs = volume_batch.shape[0]
     lsub, usub = int(labeled_bs / 2), int((bs - labeled_bs) / 2)
     grouped = grouped and lsub == usub
@@ -403,6 +404,9 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
         else:
             sp = tuple(volume_batch.shape[2:])
             img_mask, loss_mask = BU.BoxMask(box, sp, None, False, volume_batch.device), BU.BoxMask(box, sp, lsub, False, volume_batch.device)
+    own_plabs = (plab_a, plab_b)
+    if plabs is not None:
+        plab_a, plab_b = plabs[0].to(volume_batch.device), plabs[1].to(volume_batch.device)
     if grouped:
         mixed = torch.empty((2 * lsub,) + tuple(volume_batch.shape[1:]), dtype=volume_batch.dtype, device=volume_batch.device)
         BU.mix(uimg_a, img_a, img_mask, out=mixed[:lsub])      # net_input_unl, ACDC_BCP_train.py:372
@@ -426,17 +430,20 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
     loss_ce = unl_ce + l_ce
     loss_dice = unl_dice + l_dice
     loss = (loss_dice + loss_ce) / 2
-    optimizer.zero_grad()
-    if dp is not None:
-        dp.arm(model)                  # one backward covers both student batches (grouped or not: `loss` sums their terms)
-    loss.backward()
-    if dp is not None:
-        dp.allreduce_grads(model, optimizer)
-    optimizer.step()
-    update_model_ema(model, ema_model, alpha)
+    if optimizer is None:              # gradient-only mode: the caller owns zero_grad / step / EMA
+        loss.backward()
+    else:
+        optimizer.zero_grad()
+        if dp is not None:
+            dp.arm(model)              # one backward covers both student batches (grouped or not: `loss` sums their terms)
+        loss.backward()
+        if dp is not None:
+            dp.allreduce_grads(model, optimizer)
+        optimizer.step()
+        update_model_ema(model, ema_model, alpha)
     model.drop_masks = None
     ema_model.drop_masks = None
-    return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach(), plab_a=plab_a, plab_b=plab_b,
+    return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach(), plab_a=own_plabs[0], plab_b=own_plabs[1],
                 out_unl=out_unl.detach(), out_l=out_l.detach())
 
 

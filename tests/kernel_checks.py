@@ -665,11 +665,6 @@ def check_conv3_b6(ops, dev):
           yg = y64.transpose(0, 1).reshape(Cout, G, -1)
           close(pt[..., 0], yg.sum(2).t(), rtol=1e-5, msg="b6 fused sum")
           close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-5, msg="b6 fused sum of squares")
-        assert rows > 0
-        pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * Cout * 16]), dtype=torch.float64).view(G, rows, Cout, 2).sum(1)
-        yg = y64.transpose(0, 1).reshape(Cout, G, -1)
-        close(pt[..., 0], yg.sum(2).t(), rtol=1e-5, msg="b6 fused sum")
-        close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-5, msg="b6 fused sum of squares")
         ops.set_option("conv3_b6", 0)          # the fp32-MFMA kernel on the same data
         try:
             y32 = ops.conv3_fwd(to_cl(x).to(dev), wf, b.to(dev), Cout, KD)

@@ -345,6 +345,107 @@ def check_pancreas_step(ops, dev, modes=(True, False)):
             assert K.rel_l2(params[k].grad, ro["grads"][k]) < 3e-2, (grouped, k)
 
 
+def _rand_unet_drops(rng, n, hw):
+    return {f"d{i}": torch.from_numpy((rng.random((n, c, hw[0] >> i, hw[1] >> i)) < 1.0 - O.UNET_DROP[i]).astype(np.float32)) for i, c in enumerate(O.UNET_CH)}
+
+
+def check_acdc_step_full(ops, dev, batch=24, labeled_bs=12, hw=(256, 256), report=None, seed=61):
+    """BASELINE.json configs[3] at FULL size -- batch 24 (labeled_bs 12), 256x256 -- one whole ACDC self-training step
+    (ACDC_BCP_train.py:353-390) vs the fp32 oracle run beside it; also configs[0]'s layout (batch 8 / labeled 4).
+    Free run: dice and ce to 1e-5 plus the pseudo-label budget; then with the oracle's pseudo-labels forced: dice / ce / loss 1e-5
+    and every gradient tensor by rel-L2 of the difference (two noisy fp32 gradients -- the pattern check pins the backward).
+    PSEUDO-LABEL BUDGET (stated, per config): argmax over 4 softmax channels flips where the two largest logits agree to fp32
+    rounding, and the per-class largest-CC filter can then move a whole small component: <= max(16, pixels / 20000) pixels."""
+    from bcp_amd import train_step
+    rng = np.random.default_rng(seed)
+    lsub, usub = labeled_bs // 2, (batch - labeled_bs) // 2
+    P = O.init_params(O.unet_param_shapes(), seed=seed + 1, random_affine=True)
+    vol, lab = O.synth_acdc_batch(batch, shape=hw, seed=seed + 2)
+    drops = {k: _rand_unet_drops(rng, lsub if k.startswith("s") else usub, hw) for k in ("t_a", "t_b", "s_unl", "s_l")}
+    box = (37, 61, int(hw[0] * 2 / 3), int(hw[1] * 2 / 3))            # a 2/3-size box as generate_mask draws it (ACDC_BCP_train.py:141-150)
+    ro = O.acdc_self_train_step({k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in P.items()}, vol, lab, box, drops, lsub, usub)
+    model, ema = make_unet(P, dev, ops), make_unet(P, dev, ops)
+    for p in ema.parameters():
+        p.detach_()
+    r = train_step.acdc_self_train_step(model, ema, None, vol.to(dev), lab.to(dev), labeled_bs, box=box, drops=drops)
+    npix = 2 * usub * hw[0] * hw[1]
+    flips = int((r["plab_a"].cpu().float() != ro["plab_a"].float()).sum() + (r["plab_b"].cpu().float() != ro["plab_b"].float()).sum())
+    dd, dc = abs(float(r["loss_dice"]) - float(ro["loss_dice"])), abs(float(r["loss_ce"]) - float(ro["loss_ce"]))
+    assert flips <= max(16, npix // 20000), (flips, npix)
+    assert dd < 1e-5 + 4.0 * flips / npix and dc < 1e-5 + 8.0 * flips / npix, (dd, dc, flips)
+    model = make_unet(P, dev, ops)
+    r2 = train_step.acdc_self_train_step(model, ema, None, vol.to(dev), lab.to(dev), labeled_bs, box=box, drops=drops,
+                                         plabs=(ro["plab_a"].to(torch.uint8).to(dev), ro["plab_b"].to(torch.uint8).to(dev)))
+    for k in ("loss", "loss_dice", "loss_ce"):
+        assert abs(float(r2[k]) - float(ro[k])) < 1e-5, (k, float(r2[k]), float(ro[k]))
+    params = dict(model.named_parameters())
+    errs = sorted(((K.rel_l2(params[k].grad, gref), k) for k, gref in ro["grads"].items() if not is_prenorm_bias(k, params) and float(gref.norm()) > 1e-9),
+                  reverse=True)
+    worst, med = (errs[0][1], errs[0][0]), errs[len(errs) // 2][0]
+    if report is not None:
+        report.update(flips=flips, npix=npix, ddice=dd, dce=dc, worst_grad=worst, median_grad=med, top5=errs[:5])
+    assert med < 1.5e-2 and worst[1] < 5e-2, (med, errs[:5])          # sanity bound on two noisy fp32 gradients (see check_la_step_full)
+    return flips, dd, dc, worst
+
+
+def check_pancreas_step_full(ops, dev, shape=(96, 96, 96), report=None, seed=71):
+    """BASELINE.json configs[4] per rank at FULL size -- four streams x 1, 96^3, InstanceNorm V-Net -- one whole self-training step
+    (pancreas/train_pancreas.py:144-171) vs the fp32 oracle beside it, then the FIRST Adam update (lr 1e-3) and the EMA.
+    Pseudo-label budget: <= max(8, voxels / 50000) (threshold at 0.5 + 18-connectivity largest component), as for LA."""
+    from bcp_amd import train_step
+    P = O.init_params(O.vnet_param_shapes(variant="pancreas"), seed=seed, random_affine=True)
+    vol, lab = O.synth_la_batch(4, shape=shape, seed=seed + 1)
+    box = (11, 17, 9, 64, 64, 64)                                     # generate_mask(img, 64): a 64^3 box inside the 96^3 patch
+    Ps, Pt = {k: v.clone() for k, v in P.items()}, {k: v.clone() for k, v in P.items()}
+    ro = O.la_self_train_step(Ps, Pt, vol, lab, box, {}, 1, variant="pancreas", connectivity=2)
+    model = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+    ema = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+    for p in ema.parameters():
+        p.detach_()
+    r = train_step.la_self_train_step(model, ema, None, vol.to(dev), lab.to(dev), 2, box=box, variant="pancreas", connect_mode=2)
+    nvox = 2 * shape[0] * shape[1] * shape[2]
+    flips = int((r["plab_a"].cpu().float() != ro["plab_a"]).sum() + (r["plab_b"].cpu().float() != ro["plab_b"]).sum())
+    dl = abs(float(r["loss"]) - float(ro["loss"]))
+    assert flips <= max(8, nvox // 50000), (flips, nvox)
+    assert dl < 1e-5 + 2.0 * flips / nvox, (dl, flips)
+    # forced pseudo-labels + the optimiser: loss terms 1e-5, then Adam's first update and the EMA against the oracle's
+    model = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+    ema = make_vnet(P, dev, ops, variant="pancreas", has_dropout=False)
+    for p in ema.parameters():
+        p.detach_()
+    opt = train_step.FlatAdam(model, lr=1e-3)
+    r2 = train_step.la_self_train_step(model, ema, opt, vol.to(dev), lab.to(dev), 2, box=box, variant="pancreas", connect_mode=2,
+                                       plabs=(ro["plab_a"].to(torch.uint8).to(dev), ro["plab_b"].to(torch.uint8).to(dev)))
+    for k in ("loss", "loss_l", "loss_u"):
+        assert abs(float(r2[k]) - float(ro[k])) < 1e-5, (k, float(r2[k]), float(ro[k]))
+    tkeys = O.trainable_keys(O.vnet_param_shapes(variant="pancreas"))
+    P0 = {k: v.clone() for k, v in Ps.items()}
+    O.adam_step(Ps, ro["grads"], {}, tkeys)
+    O.ema_params(Ps, Pt, tkeys, 0.99)
+    params, eparams = dict(model.named_parameters()), dict(ema.named_parameters())
+    # Adam's first update is lr * g / (|g| + eps) ~ lr * sign(g): elements with |g| ~ eps (1e-8) amplify fp32 gradient noise, so the
+    # update is compared where it is well-conditioned (|g| > 1e-6: > 99 % of the elements) and in the mean over everything
+    agree, total, mean_d = 0, 0, 0.0
+    for k in tkeys:
+        if is_prenorm_bias(k, params):
+            continue
+        du, dr = (params[k].detach().cpu() - P0[k]), (Ps[k] - P0[k])
+        g = ro["grads"][k].abs()
+        sel = g > 1e-6
+        agree += int(((du - dr).abs()[sel] < 2e-4).sum())
+        total += int(sel.sum())
+        mean_d += float((du - dr).abs().sum())
+        # EMA (update_ema_variables, alpha 0.99) of the teacher towards the UPDATED student: exact against the HIP student's own new weights
+        # (the EMA kernel is bit-exact, kernel_checks.check_optim), and against the oracle's wherever Adam's update agreed
+        K.close(eparams[k].detach().cpu(), 0.99 * P0[k] + 0.01 * params[k].detach().cpu(), rtol=1e-6, atol_scale=1e-7, msg="EMA " + k)
+        assert float((eparams[k].detach().cpu() - Pt[k]).abs().max()) <= 0.01 * float((du - dr).abs().max()) + 1e-7, "EMA vs oracle " + k
+    n_all = sum(Ps[k].numel() for k in tkeys)
+    if report is not None:
+        report.update(flips=flips, nvox=nvox, dloss=dl, adam_agree=agree / max(total, 1), adam_mean_abs_diff=mean_d / n_all)
+    assert agree / max(total, 1) > 0.98 and mean_d / n_all < 2e-5, (agree / max(total, 1), mean_d / n_all)
+    return flips, dl
+
+
 def check_pre_train_steps(ops, dev):
     """the pre-training step functions the train scripts call (LA_BCP_train.py:150-167, ACDC_BCP_train.py:236-256): loss and the
     updated weights after one SGD step vs the oracle (labeled halves copy-pasted into each other, supervised / mix loss)"""
@@ -787,10 +888,13 @@ def check_la_traj5(ops, dev, golden_dir, report=None, fixture="la_traj5.npz"):
         assert pl <= 3 * plr + max(8.0, 0.02 * float(g["traj"][it, 3:].sum())), f"step {it}: {pl} pseudo-label voxels differ from the reference's (its own fp32 vs fp64: {plr})"
 
 
-def check_acdc_traj5(ops, dev, golden_dir, report=None):
-    """K = 5 ACDC self-training steps vs tests/golden/acdc_traj5.npz (same construction as check_la_traj5)"""
+def check_acdc_traj5(ops, dev, golden_dir, report=None, fixture="acdc_traj5.npz"):
+    """K = 5 ACDC self-training steps vs tests/golden/acdc_traj5.npz (same construction as check_la_traj5); acdc_traj5f.npz = the
+    same at 256x256, whose dropout masks and boxes are re-drawn here from the fixture's generator seed in the generator's order
+    (oracle/make_golden_traj.py:acdc -- per step four unet_drop_masks draws, then the box) instead of being stored"""
     from bcp_amd import train_step
-    g = np.load(os.path.join(golden_dir, "acdc_traj5.npz"))
+    g = np.load(os.path.join(golden_dir, fixture))
+    rngd = np.random.default_rng(int(g["drop_seed"])) if "drop_seed" in g else None
     tol, drift = _traj_bounds(g)
     P = O.init_params(O.unet_param_shapes(), seed=int(g["param_seed"]), random_affine=True)
     model, ema = make_unet(P, dev, ops), make_unet(P, dev, ops)
@@ -802,7 +906,14 @@ def check_acdc_traj5(ops, dev, golden_dir, report=None):
     opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
     rows = []
     for it in range(g["traj"].shape[0]):
-        drops = {k: unet_drops(g["dropbits"][it, j], 2, shape) for j, k in enumerate(("t_a", "t_b", "s_unl", "s_l"))}
+        if rngd is None:
+            drops = {k: unet_drops(g["dropbits"][it, j], 2, shape) for j, k in enumerate(("t_a", "t_b", "s_unl", "s_l"))}
+        else:
+            drops = {k: {f"d{i}": torch.from_numpy((rngd.random((2, c, shape[0] >> i, shape[1] >> i)) >= p).astype(np.float32))
+                         for i, (c, p) in enumerate(zip(O.UNET_CH, O.UNET_DROP))} for k in ("t_a", "t_b", "s_unl", "s_l")}
+            bsz = (int(shape[0] * 2 / 3), int(shape[1] * 2 / 3))
+            box = (int(rngd.integers(0, shape[0] - bsz[0])), int(rngd.integers(0, shape[1] - bsz[1]))) + bsz
+            assert box == tuple(int(v) for v in g["boxes"][it]), "the re-drawn stream left the fixture's draw order"
         r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=tuple(int(v) for v in g["boxes"][it]), drops=drops)
         got = np.array([float(r["loss"]), float(r["loss_dice"]), float(r["loss_ce"]), float(r["plab_a"].float().sum()), float(r["plab_b"].float().sum())])
         rows.append((it, float(np.abs(got[:3] - g["traj"][it, :3]).max()), float(np.abs(got[:3] - g["traj64"][it, :3]).max()), float(drift[it]),

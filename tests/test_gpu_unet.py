@@ -94,3 +94,31 @@ def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
     finally:
         ops.set_option("conv3_b6")
         ops.set_option("wgrad_b6")
+
+
+def test_acdc_full_size_self_train_step_vs_oracle(ops):
+    """configs[3]: batch 24 (12 labeled), 256x256 -- one whole self-training step against the fp32 oracle beside it"""
+    rep = {}
+    NC.check_acdc_step_full(ops, DEV, report=rep)
+    print("ACDC full-size step:", rep)
+
+
+def test_acdc_c1_layout_step_vs_oracle(ops):
+    """configs[0]'s layout (batch 8, 4 labeled) at 256x256 through the HIP path -- the CPU-plumbing case of BASELINE.json"""
+    rep = {}
+    NC.check_acdc_step_full(ops, DEV, batch=8, labeled_bs=4, report=rep, seed=161)
+    print("ACDC batch-8 step:", rep)
+
+
+def test_acdc_five_step_trajectory_full_size(ops, golden_dir):
+    """K = 5 at 256x256 (batch 8: configs[0]'s layout; acdc_traj5f.npz, dropout masks re-drawn from the fixture's generator seed).
+    The reference's own fp32-vs-fp64 drift here is 5e-8 .. 4.5e-6, so SURVEY 8d's gate (|dloss| <= 1e-4 over the 5 steps) is
+    asserted as written, next to the fixture-derived bound (twice the reference's drift, floor 1e-5)."""
+    rep = []
+    try:
+        NC.check_acdc_traj5(ops, DEV, golden_dir, report=rep, fixture="acdc_traj5f.npz")
+    finally:
+        for r in rep:
+            print("acdc_traj5f step %d: |hip - ref32| %.2e  |hip - ref64| %.2e  (reference 32 vs 64: %.2e)  pseudo-label sum diff %.0f (reference: %.0f)" % r)
+    for it, d32, d64, dr, pl, plr in rep:
+        assert d32 <= 1e-4 and d64 <= 1e-4, (it, d32, d64)

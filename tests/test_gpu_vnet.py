@@ -120,6 +120,25 @@ def test_la_five_step_trajectory(ops, golden_dir):
                 print(fx, "step %d: |hip-ref32| %.2e  |hip-ref64| %.2e  ref drift %.2e  own plab xor %g (ref %g)" % r)
 
 
+def test_la_five_step_trajectory_full_size(ops, golden_dir):
+    """K = 5 at configs[1]'s size (4 x 112x112x80; la_traj5f.npz = the reference's own functions, fp32 / fp64 / fp64 forced + a 4-member
+    1-ulp ensemble).  SURVEY 8d asks |dloss| <= 1e-4 over 5 steps: the REFERENCE's own fp32 run misses that against its fp64 run from
+    step 2 on even at this size (forced pseudo-labels: 8.6e-8, 9.4e-6, 4.3e-4, 2.3e-4, 1.5e-3) -- the drift is the optimiser's (random
+    init, lr 0.01, momentum), not the small fixtures' 4-value BatchNorm groups.  So: the 1e-4 gate where the reference itself meets it
+    (steps 0-1), the ensemble bound of check_la_traj5 everywhere."""
+    rep = []
+    try:
+        NC.check_la_traj5(ops, DEV, golden_dir, report=rep, fixture="la_traj5f.npz")
+    finally:
+        for r in rep:
+            print("la_traj5f step %d: |hip - ref32| %.2e  |hip - ref64f| %.2e  (reference ensemble median %.2e)  own pseudo-label voxels differing %d (reference 32 vs 64: %d)" % r)
+    g = np.load(os.path.join(golden_dir, "la_traj5f.npz"))
+    ref_own = g["drift_ens"].max(axis=0)
+    for it, d32, d64, dr, pl, plr in rep:
+        if ref_own[it] <= 5e-5:
+            assert d64 <= 1e-4, (it, d64)
+
+
 def test_standard_regime_gradients_on_hip_activation_pattern(ops):
     """every gradient tensor of the LA and the InstanceNorm V-Net to 1e-4 rel-L2 of the difference vs the fp64 oracle linearised
     on the activation pattern the HIP forward took (no smooth-regime crutch): small and a mid-size volume"""
@@ -138,6 +157,13 @@ def test_la_full_size_self_train_step_vs_oracle(ops):
     rep = {}
     NC.check_la_step_full(ops, DEV, report=rep)
     print("full-size step:", rep)
+
+
+def test_pancreas_full_size_self_train_step_vs_oracle(ops):
+    """configs[4] per rank: 4 streams x 1, 96^3, IN-V-Net, one whole step + the first Adam update against the fp32 oracle beside it"""
+    rep = {}
+    NC.check_pancreas_step_full(ops, DEV, report=rep)
+    print("pancreas full-size step:", rep)
 
 
 def test_la_full_size_gradients_on_hip_activation_pattern(ops):

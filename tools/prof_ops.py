@@ -60,6 +60,22 @@ for C, sp in LEVELS:
     run(f"norm_fwd[{tag}]", nf, {"flop": 0, "bytes": 12.0 * vox * C})
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     run(f"norm_bwd[{tag}]", lambda: ops.norm_bwd(x, dy, N, st[0], H.ACT_RELU, dg, db, True, out=a), {"flop": 0, "bytes": 20.0 * vox * C})
+    # round 3: the layer as the networks launch it now
+    if ops.norm_small_ok(N, vox // N, C):
+        sk = ops.conv3_nslabs(x.shape, C, 3)
+        if sk:
+            # deep levels: conv leaves its split-K slabs, ONE norm kernel sums / finalises / applies
+            def chain_f():
+                st[0] = ops.norm_fwd_small(ops.conv3_fwd_raw(x, wf, C, 3, sk), sk, b, N, g, be, rm, rv, H.ACT_RELU)[1]
+            run(f"conv3_raw+norm_small_fwd[{tag}]", chain_f, {"flop": fl, "bytes": 16.0 * vox * C})
+            run(f"dgrad_raw+norm_small_bwd[{tag}]", lambda: ops.norm_bwd_small(x, ops.conv3_fwd_raw(dy, wd, C, 3, sk), sk, N, st[0], H.ACT_RELU, dg, db, True),
+                {"flop": fl, "bytes": 16.0 * vox * C})
+    else:
+        def chain_b():
+            da, part, rows = ops.conv3_dgrad_bwdstats(dy, wd, C, 3, x, st[0], H.ACT_RELU, N)
+            ops.norm_bwd(x, da, N, st[0], H.ACT_RELU, dg, db, True, out=a, partial=part, nb=rows)
+        run(f"dgrad_bwdstats+norm_bwd[{tag}]", chain_b, {"flop": fl, "bytes": 24.0 * vox * C})
+        run(f"conv3_dgrad_bwdstats[{tag}]", lambda: ops.conv3_dgrad_bwdstats(dy, wd, C, 3, x, st[0], H.ACT_RELU, N), {"flop": fl, "bytes": 12.0 * vox * C})
 
 sp = (112, 112, 80)
 vox = N * sp[0] * sp[1] * sp[2]
