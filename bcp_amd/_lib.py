@@ -67,6 +67,8 @@ _SIGS = {
     "bcp_conv3_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
     "bcp_conv3_c1_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
+    "bcp_conv3_c1_stat_rows": (I, [I, I, I, I, I, I]),
+    "bcp_conv3_c1_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, I, P]),
     "bcp_conv3_c1_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_k2_pack_weight": (I, [P, P, I, I, I, P]),
     "bcp_k2_pack_desc": (I, [P, P, I, I, I, P]),
@@ -179,7 +181,7 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_small_ok", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_small_ok", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
         self._rec = None          # a bcp_amd.plan.LaunchPlan while a network pass is being recorded
 

@@ -847,23 +847,17 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
 // ------------------------------------------------------------------------------------------------
 template <int KD, int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, const float* __restrict__ w /*[16][1][T]*/,
-                                                  const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd) {
+                                                  const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd, int n_tiles,
+                                                  int tiles_per_block, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int T = TL::T, MT = TL::MT, KS = (T + 3) / 4;
   __shared__ __attribute__((aligned(16))) float Xs[TL::HV];
+  __shared__ double Ss[4 * 16 * 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  int n, d0, h0, w0;
-  tile_origin(cd, blockIdx.x, TD, TH, TW, n, d0, h0, w0);
-  for (int q = threadIdx.x; q < TL::HV; q += 256) {
-    const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
-    const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
-    float v = 0.f;
-    if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
-      v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
-    Xs[q] = v;
-  }
-  // lane (li, lg): B[k = lg][co = li] of k-step ks is the weight of tap 4*ks + lg
+  // lane (li, lg): A[co = li][k = lg] of k-step ks is the weight of tap 4*ks + lg.  D = W x X^T (rows = channels, columns = voxels):
+  // a lane ends with FOUR CONSECUTIVE channels (lg*4 ..) of voxel li -- one 16-byte store per m-tile (round 3; the dword stores of
+  // the [vox][co] orientation ran this 128 MB stream at 3.2 TB/s) and the layout the fused norm statistics want.
   float wv[KS];
   int toff[KS];
 #pragma unroll
@@ -872,30 +866,63 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
     wv[ks] = tap < T ? w[li * T + tap] : 0.f;
     toff[ks] = tap < T ? TL::tapoff(tap) : 0;
   }
-  const float bv = bias ? bias[li] : 0.f;
-  __syncthreads();
-  const bool full = (TW % 4 == 0) && d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (bias) bv = ld4(bias + lg * 4);
+  double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};       // fused norm statistics of this lane's four channels (bcp_conv3_c1_fwd_stats)
+  const int t_begin = blockIdx.x * tiles_per_block;
+  int t_end = t_begin + tiles_per_block;
+  if (t_end > n_tiles) t_end = n_tiles;
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    int n, d0, h0, w0;
+    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+    if (tile > t_begin) __syncthreads();                  // every wave is done with the previous tile's halo
+    for (int q = threadIdx.x; q < TL::HV; q += 256) {
+      const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
+      const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
+      float v = 0.f;
+      if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
+        v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
+      Xs[q] = v;
+    }
+    __syncthreads();
+    const bool full = d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int vo = TL::voff((wave * MT + mt) * 16 + li);   // A[vox = li][k = lg]
-    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < MT; ++mt) {
+      const int m = (wave * MT + mt) * 16 + li;             // B[k = lg][vox = li]
+      const int vo = TL::voff(m);
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[vo + toff[ks]], wv[ks], acc, 0, 0, 0);
-    // D[vox = lg*4 + r][co = li]
-    const int m0 = (wave * MT + mt) * 16 + lg * 4;
-    if (full) {
-      const int tw = m0 % TW, th = (m0 / TW) % TH, td = m0 / (TW * TH);
-      float* p = Y + ((((long long)n * cd.D + d0 + td) * cd.H + h0 + th) * cd.W + w0 + tw) * 16 + li;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) p[r * 16] = acc[r] + bv;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + r;
-        const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-        const int d = d0 + td, h = h0 + th, wq = w0 + tw;
-        if (d < cd.D && h < cd.H && wq < cd.W) Y[((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16 + li] = acc[r] + bv;
+      for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], Xs[vo + toff[ks]], acc, 0, 0, 0);
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int d = d0 + td, h = h0 + th, wq = w0 + tw;
+      if (full || (d < cd.D && h < cd.H && wq < cd.W)) {
+        const float4 v = make_float4(acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w);
+        st4(Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16 + lg * 4, v);
+        if (st.partial) {
+          s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x; s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
+          s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z; s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+        }
       }
+    }
+  }
+  if (st.partial) {
+    // one row per workgroup (its tiles lie in ONE normalisation group: the launcher picks tiles_per_block | tiles_per_group)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double a = s1[r], b = s2[r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+      if (li == 0) { Ss[(wave * 16 + lg * 4 + r) * 2] = a; Ss[(wave * 16 + lg * 4 + r) * 2 + 1] = b; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+      const int c = threadIdx.x;
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int wv_ = 0; wv_ < 4; ++wv_) { a += Ss[(wv_ * 16 + c) * 2]; b += Ss[(wv_ * 16 + c) * 2 + 1]; }
+      const int gg = t_begin / st.tiles_per_group, row = (t_begin % st.tiles_per_group) / tiles_per_block;
+      double* dst = st.partial + (((long long)gg * st.rows + row) * 16 + c) * 2;
+      dst[0] = a; dst[1] = b;
     }
   }
 }
@@ -1461,22 +1488,62 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
 }
 
 // ---- Cin = 1 -> Cout = 16 first layer
+// tiles per workgroup of the first-layer kernel when it also takes the statistics: the largest of 8 / 4 / 2 / 1 that divides the tiles of
+// a normalisation group (a workgroup's statistics row belongs to ONE group) -- 980 rows per group at the LA size instead of 3920
+static int c1_tiles_per_block(int tiles_per_group) {
+  for (int t = 8; t > 1; t >>= 1)
+    if (tiles_per_group % t == 0 && tiles_per_group / t >= 256) return t;
+  return 1;
+}
+
+static int c1_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int KD, double* stat_partial,
+                       int groups, bool dry, hipStream_t s) {
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, 1, 16);
+  if (KD == 3) { cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 4); cd.tiles_w = cdiv(W, 16); }
+  else { cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16); }
+  const int tiles = N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+  StatsArg st{nullptr, 0, 1, 16, groups > 0 ? groups : 1};
+  int tpb = 1;
+  if (groups > 0) {
+    if (N % groups) return 0;                             // tiles are sample-major: a group = whole samples
+    const int tpg = tiles / groups;
+    tpb = c1_tiles_per_block(tpg);
+    st.tiles_per_group = tpg; st.rows = tpg / tpb; st.partial = stat_partial;
+    if (dry) return st.rows;
+  }
+  const dim3 grid(cdiv(tiles, tpb));
+  if (KD == 3) hipLaunchKernelGGL((k_conv3_c1<3, 4, 4, 16>), grid, dim3(256), 0, s, x, w, bias, y, cd, tiles, tpb, st);
+  else hipLaunchKernelGGL((k_conv3_c1<1, 1, 16, 16>), grid, dim3(256), 0, s, x, w, bias, y, cd, tiles, tpb, st);
+  return st.rows;
+}
+
 extern "C" int bcp_conv3_c1_fwd(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int KD,
                                 void* stream) {
   BCP_REQUIRE(x && w && y, "bcp_conv3_c1_fwd: null pointer");
   BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_fwd: bad KD/D");
-  ConvDims cd;
-  fill_dims(cd, N, D, H, W, 1, 16);
-  if (KD == 3) {
-    cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 4); cd.tiles_w = cdiv(W, 16);
-    hipLaunchKernelGGL((k_conv3_c1<3, 4, 4, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0,
-                       (hipStream_t)stream, x, w, bias, y, cd);
-  } else {
-    cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16);
-    hipLaunchKernelGGL((k_conv3_c1<1, 1, 16, 16>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, (hipStream_t)stream, x, w,
-                       bias, y, cd);
-  }
+  BCP_REQUIRE(aligned16(y) && (!bias || aligned16(bias)), "bcp_conv3_c1_fwd: y / bias must be 16-B aligned");
+  c1_fwd_impl(x, w, bias, y, N, D, H, W, KD, nullptr, 0, false, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_fwd");
+  return BCP_OK;
+}
+
+// fused variant (as bcp_conv3_fwd_stats): the epilogue also leaves the (sum, sum^2) partials of y for `groups` consecutive sample
+// ranges -- stat_partial = double[groups][rows][16][2], rows = bcp_conv3_c1_stat_rows(...) -- so the norm behind the first layer
+// needs no statistics pass over its 64-byte-per-voxel output
+extern "C" int bcp_conv3_c1_stat_rows(int N, int D, int H, int W, int KD, int groups) {
+  if (groups < 1 || N < 1 || D < 1 || H < 1 || W < 1 || !((KD == 1 && D == 1) || KD == 3)) return 0;
+  return c1_fwd_impl(nullptr, nullptr, nullptr, nullptr, N, D, H, W, KD, nullptr, groups, true, nullptr);
+}
+
+extern "C" int bcp_conv3_c1_fwd_stats(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int KD,
+                                      double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(x && w && y && stat_partial && groups >= 1, "bcp_conv3_c1_fwd_stats: null pointer / bad groups");
+  BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_fwd_stats: bad KD/D");
+  BCP_REQUIRE(aligned16(y) && (!bias || aligned16(bias)), "bcp_conv3_c1_fwd_stats: y / bias must be 16-B aligned");
+  const int rows = c1_fwd_impl(x, w, bias, y, N, D, H, W, KD, stat_partial, groups, false, (hipStream_t)stream);
+  BCP_REQUIRE(rows > 0, "bcp_conv3_c1_fwd_stats: fused statistics unavailable (N %% groups != 0): check bcp_conv3_c1_stat_rows first");
+  BCP_CHECK_LAUNCH("bcp_conv3_c1_fwd_stats");
   return BCP_OK;
 }
 

@@ -386,6 +386,19 @@ class Ops:
         self.b.call("bcp_conv3_c1_fwd", _p(x), _p(w), _p(bias), _p(out), N, D, H, W, KD, self.stream(x))
         return out
 
+    def conv3_c1_fwd_stats(self, x, w, bias, KD, groups):
+        """first layer + fused norm statistics -> (y, partial, rows), as conv3_fwd_stats"""
+        self._chk(x, w, bias)
+        N, D, H, W, Cin = x.shape
+        assert Cin == 1 and w.shape[0] == 16
+        rows = self._ws_bytes("bcp_conv3_c1_stat_rows", N, D, H, W, KD, groups)
+        if rows == 0:
+            return self.conv3_c1_fwd(x, w, bias, KD), None, 0
+        out = torch.empty((N, D, H, W, 16), dtype=torch.float32, device=x.device)
+        part = self.workspace(("statpart", rows), groups * rows * 16 * 16, x)
+        self.b.call("bcp_conv3_c1_fwd_stats", _p(x), _p(w), _p(bias), _p(out), N, D, H, W, KD, _p(part), groups, self.stream(x))
+        return out, part, rows
+
     def conv3_c1_wgrad(self, x, dy, dw, KD, accumulate=False):
         self._chk(x, dy, dw)
         N, D, H, W, _ = x.shape
@@ -650,7 +663,7 @@ class Ops:
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
 _PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_small", "norm_bwd_small", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "conv3_pack_many",
-             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
+             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")
 

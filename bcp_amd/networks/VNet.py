@@ -196,7 +196,10 @@ class VNet(HipNet):
             small = self.training and not (li == last and fuse_head) and ops.norm_small_ok(G, N * sp_out // G, L.cout)
             src, nsl, bsrc = None, 1, None
             if L.kind == "c1":
-                y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
+                if self.training and not small:
+                    y, part, nb = ops.conv3_c1_fwd_stats(h, w.data, b.data, 3, G)      # statistics in the epilogue: no pass over the 16-channel y
+                else:
+                    y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
             elif L.kind == "c3":
                 wf, _ = self.conv3_packed(("c3", li), save)
                 sk = ops.conv3_nslabs(h.shape, L.cout, 3) if small else 0

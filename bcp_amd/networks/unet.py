@@ -126,7 +126,10 @@ class UNet_2d(HipNet):
         part1, nb1 = None, 0
         src, nsl, bsrc = None, 1, None
         if cb.cin == 1:
-            y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
+            if small:
+                y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
+            else:
+                y1, part1, nb1 = ops.conv3_c1_fwd_stats(h, cb.c1.weight.data, cb.c1.bias.data, 1, G)
         else:
             wf, _ = self.conv3_packed((tag, 1), save)
             sk = ops.conv3_nslabs(h.shape, cb.cout, 1) if small else 0

@@ -75,7 +75,7 @@ def _work(name, shapes, ints):
     if name == "conv3_wgrad":                              # (x, dy, dw); ints = (KD,)
         vox = _numel(s0[:-1])
         return "mfma", 2.0 * vox * ints[0] * 9 * s0[-1] * shapes[1][-1], 4.0 * (_numel(s0) + _numel(shapes[1]))
-    if name in ("conv3_c1_fwd", "conv3_c1_wgrad"):         # Cin = 1 -> 16: HBM-bound (AI 12.7)
+    if name in ("conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_wgrad"):         # Cin = 1 -> 16: HBM-bound (AI 12.7)
         vox = _numel(s0[:-1])
         return "hbm", 2.0 * vox * ints[0] * 9 * 16, 4.0 * vox * 17
     if name in ("down_fwd", "up_fwd", "down_dgrad", "up_dgrad", "pw_fwd"):   # k2s2 / 1x1 GEMMs: (x, packed B, [bias]); ints = (Cout,)

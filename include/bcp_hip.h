@@ -166,6 +166,10 @@ int bcp_conv3_wgrad(const float* x, const float* dy, float* dw /*[Cout][Cin][KD*
                     int KD, int accumulate, void* workspace, void* stream);
 /* first layer, Cin = 1 -> Cout = 16 (torch weight layout used directly) */
 int bcp_conv3_c1_fwd(const float* x, const float* w, const float* bias_or_null, float* y, int N, int D, int H, int W, int KD, void* stream);
+/* fused variant, as bcp_conv3_fwd_stats: stat_partial = double[groups][rows][16][2], rows = bcp_conv3_c1_stat_rows(...) (0: unavailable) */
+int bcp_conv3_c1_stat_rows(int N, int D, int H, int W, int KD, int groups);
+int bcp_conv3_c1_fwd_stats(const float* x, const float* w, const float* bias_or_null, float* y, int N, int D, int H, int W, int KD,
+                           double* stat_partial, int groups, void* stream);
 int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int KD, int accumulate, void* workspace,
                        void* stream);
 

@@ -320,6 +320,25 @@ def check_conv3_c1(ops, dev):
         dw = torch.zeros(w.shape).to(dev)
         ops.conv3_c1_wgrad(xcl, to_cl(dy).to(dev), dw, KD)
         close(dw, w.grad, rtol=2e-4, msg=f"conv3_c1 wgrad {sp}")
+    # fused norm statistics (bcp_conv3_c1_fwd_stats): y bit-identical to the plain launch; the partial rows sum to the per-group column
+    # sums / sums of squares; several tiles per workgroup (32 / 16 tiles per group -> 8 / 4 per workgroup), ragged tiles, 2-D
+    for (N, sp, KD, G) in ((2, (16, 16, 64), 3, 2), (4, (8, 16, 32), 3, 2), (2, (6, 5, 21), 3, 2), (1, (6, 5, 21), 3, 1), (4, (1, 40, 48), 1, 2)):
+        two_d = KD == 1
+        x = R(rng, N, 1, *(sp[1:] if two_d else sp))
+        w = R(rng, 16, 1, *((3, 3) if two_d else (3, 3, 3))) * 0.2
+        b = R(rng, 16) * 0.1
+        xcl = to_cl(x).to(dev)
+        y0 = ops.conv3_c1_fwd(xcl, w.to(dev).contiguous(), b.to(dev), KD)
+        y, part, rows = ops.conv3_c1_fwd_stats(xcl, w.to(dev).contiguous(), b.to(dev), KD, G)
+        assert rows > 0 and torch.equal(y.cpu(), y0.cpu()), f"conv3_c1_fwd_stats y {sp}"
+        pt = torch.frombuffer(bytearray(part.cpu().numpy().tobytes()[:G * rows * 16 * 16]), dtype=torch.float64).view(G, rows, 16, 2).sum(1)
+        yg = from_cl(y0, two_d).cpu().double().transpose(0, 1).reshape(16, G, -1)
+        close(pt[..., 0], yg.sum(2).t(), rtol=1e-6, msg=f"c1 fused sum {sp}")
+        close(pt[..., 1], (yg * yg).sum(2).t(), rtol=1e-6, msg=f"c1 fused sum of squares {sp}")
+        g1, b1 = torch.ones(16).to(dev), torch.zeros(16).to(dev)
+        a1, _ = ops.norm_fwd(y, G, g1, b1, torch.zeros(16).to(dev), torch.ones(16).to(dev), H.ACT_RELU, partial=part, nb=rows)
+        a2, _ = ops.norm_fwd(y, G, g1, b1, torch.zeros(16).to(dev), torch.ones(16).to(dev), H.ACT_RELU)
+        close(a1, a2, rtol=1e-6, msg=f"norm from the first layer's fused partials {sp}")
 
 
 K2_CASES = ((1, 16, 32, (4, 6, 8)), (2, 32, 64, (2, 4, 6)), (1, 128, 256, (2, 2, 2)), (1, 16, 16, (10, 12, 14)), (2, 32, 16, (8, 6, 10)))
