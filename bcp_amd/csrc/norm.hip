@@ -410,7 +410,10 @@ __global__ __launch_bounds__(256) void k_norm_small_fwd(const float* __restrict_
                                                         float* __restrict__ stats, float* __restrict__ out) {
   __shared__ double red[4 * GU * 8];
   __shared__ double fin[GU * 8];
-  const int c0 = blockIdx.x * 4;
+  // channel quad of this workgroup: the gridDim.x / 8 workgroups an XCD receives (linear id % 8) take NEIGHBOURING quads, so the 128-byte
+  // lines of a row (8 quads) are fetched into one or two L2s instead of all eight (8 MB of slabs crossed the fabric as 44 MB)
+  const int nq = gridDim.x;
+  const int c0 = ((nq & 7) == 0 ? (int)(blockIdx.x & 7) * (nq >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 4;
   const int g_begin = blockIdx.y * groups_per_block, g_end = g_begin + groups_per_block < G ? g_begin + groups_per_block : G;
   float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) b4 = ld4(bias + c0);
@@ -420,22 +423,38 @@ __global__ __launch_bounds__(256) void k_norm_small_fwd(const float* __restrict_
   if (running_mean && threadIdx.x < 4) { rm = (double)running_mean[c0 + threadIdx.x]; rv = (double)running_var[c0 + threadIdx.x]; }
   for (int g0 = g_begin; g0 < g_end; g0 += GU) {
     float4 v[GU][RPT];
-    // ---- slab sum (the order of k_b6_sum_slabs: bias first, then the slabs front to back): all loads of a trip are independent
+    // ---- slab sum (the order of k_b6_sum_slabs: bias first, then the slabs front to back).  The SLAB loop is the outer one and all
+    // GU * RPT loads of a slab are issued before the first add: a runtime-count loop around each element's loads compiled to one
+    // dependent round trip per (element, slab) -- 64 in a row, 40 us for 8 MB (measured, round 3); now nslab round trips.
+    long long eoff[GU][RPT];
 #pragma unroll
     for (int u = 0; u < GU; ++u)
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int r = threadIdx.x + k * 256;
+        const bool ok = g0 + u < g_end && r < R;
+        eoff[u][k] = ok ? ((long long)(g0 + u) * R + r) * C + c0 : -1;
         v[u][k] = b4;
-        if (g0 + u < g_end && r < R) {
-          const long long e = ((long long)(g0 + u) * R + r) * C + c0;
-          for (int s = 0; s < nslab; ++s) {
-            const float4 p = ld4(slabs + (long long)s * slab_stride + e);
-            v[u][k].x += p.x; v[u][k].y += p.y; v[u][k].z += p.z; v[u][k].w += p.w;
-          }
-          if (ysum) st4(ysum + e, v[u][k]);
-        }
       }
+    for (int s = 0; s < nslab; ++s) {
+      const float* sl = slabs + (long long)s * slab_stride;
+      float4 p[GU][RPT];
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) p[u][k] = ld4(sl + (eoff[u][k] >= 0 ? eoff[u][k] : (long long)c0));      // (unconditional loads: row 0 stands in)
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) { v[u][k].x += p[u][k].x; v[u][k].y += p[u][k].y; v[u][k].z += p[u][k].z; v[u][k].w += p[u][k].w; }
+    }
+    if (ysum) {
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+          if (eoff[u][k] >= 0) st4(ysum + eoff[u][k], v[u][k]);
+    }
     double acc[GU * 8];
 #pragma unroll
     for (int u = 0; u < GU; ++u) {
@@ -511,33 +530,49 @@ __global__ __launch_bounds__(256) void k_norm_small_bwd(const float* __restrict_
                                                         float* __restrict__ dy) {
   __shared__ double red[4 * GU * 8];
   __shared__ double fin[GU * 8];
-  const int c0 = blockIdx.x * 4;
+  // channel quad of this workgroup: the gridDim.x / 8 workgroups an XCD receives (linear id % 8) take NEIGHBOURING quads, so the 128-byte
+  // lines of a row (8 quads) are fetched into one or two L2s instead of all eight (8 MB of slabs crossed the fabric as 44 MB)
+  const int nq = gridDim.x;
+  const int c0 = ((nq & 7) == 0 ? (int)(blockIdx.x & 7) * (nq >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x) * 4;
   const int g_begin = blockIdx.y * groups_per_block, g_end = g_begin + groups_per_block < G ? g_begin + groups_per_block : G;
   const float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float gb = 0.f, gg = 0.f;                               // parameter gradients of channel c0 + tid (threads 0..3), groups in order
   if (dgamma && threadIdx.x < 4 && accumulate) { gb = dbeta[c0 + threadIdx.x]; gg = dgamma[c0 + threadIdx.x]; }
   for (int g0 = g_begin; g0 < g_end; g0 += GU) {
     float4 v[GU][RPT], d[GU][RPT];
+    long long eoff[GU][RPT];
 #pragma unroll
     for (int u = 0; u < GU; ++u)
 #pragma unroll
       for (int k = 0; k < RPT; ++k) {
         const int r = threadIdx.x + k * 256;
-        v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool ok = g0 + u < g_end && r < R;
+        eoff[u][k] = ok ? ((long long)(g0 + u) * R + r) * C + c0 : -1;
+        v[u][k] = ld4(y + (ok ? eoff[u][k] : (long long)c0));
         d[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g0 + u < g_end && r < R) {
-          const long long e = ((long long)(g0 + u) * R + r) * C + c0;
-          v[u][k] = ld4(y + e);
-          if (nslab == 1) d[u][k] = ld4(da_slabs + e);
-          else {
-            for (int s = 0; s < nslab; ++s) {
-              const float4 p = ld4(da_slabs + (long long)s * slab_stride + e);
-              d[u][k].x += p.x; d[u][k].y += p.y; d[u][k].z += p.z; d[u][k].w += p.w;
-            }
-          }
-          if (da_sum) st4(da_sum + e, d[u][k]);
-        }
       }
+    for (int s = 0; s < nslab; ++s) {                     // slab loop outermost, loads of a slab issued together: see k_norm_small_fwd
+      const float* sl = da_slabs + (long long)s * slab_stride;
+      float4 p[GU][RPT];
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) p[u][k] = ld4(sl + (eoff[u][k] >= 0 ? eoff[u][k] : (long long)c0));
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k) {
+          if (nslab == 1) d[u][k] = p[u][k];            // (bit-identical to the plain tensor: no 0 + x)
+          else { d[u][k].x += p[u][k].x; d[u][k].y += p[u][k].y; d[u][k].z += p[u][k].z; d[u][k].w += p[u][k].w; }
+        }
+    }
+    if (da_sum) {
+#pragma unroll
+      for (int u = 0; u < GU; ++u)
+#pragma unroll
+        for (int k = 0; k < RPT; ++k)
+          if (eoff[u][k] >= 0) st4(da_sum + eoff[u][k], d[u][k]);
+    }
     // dz replaces da in the registers; xhat is recomputed in the apply loop
     float mu[GU][4], sc[GU][4], sh[GU][4], rs[GU][4];
     double acc[GU * 8];

@@ -68,6 +68,35 @@ def main():
             fns["dgrad"] = lambda: ops.conv3_fwd(dy, wd, None, C, 3, out=y)
         if "wgrad" in want:
             fns["wgrad"] = lambda: ops.conv3_wgrad(x, dy, dw, 3)
+        # round 3: the layer as the networks launch it (conv + norm forward; dgrad + norm backward) under the current options
+        from bcp_amd import hip_ops as H
+        g1, b1 = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        vox_g = sp[0] * sp[1] * sp[2]
+        st = [ops.norm_fwd(x, N, g1, b1, rm, rv, H.ACT_RELU)[1]]
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+
+        def fwd_chain():
+            if ops.norm_small_ok(N, vox_g, C):
+                sk = ops.conv3_nslabs(x.shape, C, 3)
+                if sk:
+                    return ops.norm_fwd_small(ops.conv3_fwd_raw(x, wf, C, 3, sk), sk, b, N, g1, b1, rm, rv, H.ACT_RELU)
+                return ops.norm_fwd_small(ops.conv3_fwd(x, wf, b, C, 3), 1, None, N, g1, b1, rm, rv, H.ACT_RELU)
+            yy, part, nb = ops.conv3_fwd_stats(x, wf, b, C, 3, N)
+            return ops.norm_fwd(yy, N, g1, b1, rm, rv, H.ACT_RELU, partial=part, nb=nb)
+
+        def bwd_chain():
+            if ops.norm_small_ok(N, vox_g, C):
+                sk = ops.conv3_nslabs(dy.shape, C, 3)
+                if sk:
+                    return ops.norm_bwd_small(x, ops.conv3_fwd_raw(dy, wd, C, 3, sk), sk, N, st[0], H.ACT_RELU, dg, db, True)
+                return ops.norm_bwd_small(x, ops.conv3_fwd(dy, wd, None, C, 3), 1, N, st[0], H.ACT_RELU, dg, db, True)
+            da, part, nb = ops.conv3_dgrad_bwdstats(dy, wd, C, 3, x, st[0], H.ACT_RELU, N)
+            return ops.norm_bwd(x, da, N, st[0], H.ACT_RELU, dg, db, True, partial=part, nb=nb)
+        if "fwd_chain" in want:
+            fns["fwd_chain"] = fwd_chain
+        if "bwd_chain" in want:
+            fns["bwd_chain"] = bwd_chain
         times = {(op, vn): [] for op in fns for vn, _ in variants}
         for r in range(a.rounds + 1):
             for vn, opts in variants:
