@@ -54,12 +54,12 @@ struct Options {
   int conv3_b6_levels = 15;  // automatic choice (conv3_b6 = 1): bit 0 = 32-channel slabs (256-voxel tiles), bit 1 = 64-channel slabs, bit 2 = the 16 -> 16 layers (persistent k_c3d with cross-tile halo prefetch: 176 vs 243-258 us alone, step 7.00 vs 7.18 ms; one tile per workgroup it was 209-228 us and no step gain), bit 3 = the 2-D instances (ACDC step 5.18 -> 4.24 ms together with the weight gradients).  LA step, interleaved A/B (ms per step): off 8.87, 32-channel level 8.32, + 64-channel level 8.05 -- the latter although ALONE that kernel is slower than the exclusive pipeline kernel it replaces (66-71 vs 61 us): two workgroups per CU leave room for the other stream
   int conv3_b6_minvox = 256;     // automatic choice: smallest launch (voxels, batch included) that goes to the bf16-pipe kernels
   int conv3_b6_flat = 1;    // deep levels (64-channel slabs, < 16 K voxels): flat 64-voxel tiles with per-lane validity masks (k_c3f) instead of bricks: 128 channels @14x14x10 35 vs 41 us (fp32 kernel 52), 256 @7x7x5 31 vs 33 (fp32); LA step 6.87 vs 6.96 ms.  2 / 3: force 32- / 16-channel slabs (measurements)
-  int conv3_b6_flatd = 1;   // deep levels: flat tiles with DIRECT weight fragments and MT m-tiles per wave (k_c3g) instead of k_c3f: 1 = automatic tile (256 / 128 voxels), 2 / 4 = force 128 / 256, 0 = off
+  int conv3_b6_flatd = 0;   // deep levels: flat tiles with DIRECT weight fragments and MT m-tiles per wave (k_c3g) instead of k_c3f: 1 = automatic tile (256 / 128 voxels), 2 / 4 = force 128 / 256, 0 = off (default: measured no faster -- 128 channels 36.6 vs 34.8 us, 256 channels 30.4 vs 24.7 us alone)
   int conv3_b6_direct = 1;  // bf16-pipe forward: weight fragments straight from global memory (k_c3d, no stage barriers) instead of an LDS stage (k_c3b): 1 = for the 256-voxel x 32-channel tiles (78-82 vs 84-89 us alone, 7.32 vs 7.34 ms per step), 2 = everywhere (measurements)
   int conv3_b6_cfg64 = 0;   // measurements: tile / slab variant of the 64-channel bf16-pipe instances
   int wgrad_b6 = 1;         // weight gradient on the bf16 matrix pipe (conv3bw.hip): 0 off, 1 where measured faster, 2 wherever valid.  LA step (interleaved A/B): off 7.82 ms, 32/64-channel levels 7.52, + 128-channel level 7.38
   int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)
-  int norm_small = 1;       // groups of <= 4096 rows (deep levels): statistics + finalize + apply (+ the split-K slab sum) in ONE launch (k_norm_small_*) instead of 3-5
+  int norm_small = 0;       // groups of <= 4096 rows (deep levels): statistics + finalize + apply (+ the split-K slab sum) in ONE launch (k_norm_small_*) instead of 3-5.  OFF by default -- measured slower (round 3): a workgroup that owns four channels of every row touches one cache line per lane (TA-bound: 31 us for 8 MB) while the back-to-back chain it replaces costs 12 us; LA step 6.67 vs 6.54 ms
   int fuse_bwd_stats = 1;   // dgrad epilogue of the bf16-pipe kernels accumulates the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): no k_col_partial<1> pass over (y, da) for conv -> conv edges
   int conv3_xcd = 1;        // bf16-pipe kernels: XCD-aware workgroup -> tile order (each XCD walks a contiguous eighth of the tile list: halo overlap hits its own L2)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step

@@ -46,7 +46,10 @@ __device__ __forceinline__ constexpr int b6_row(int i) {
 // epilogue shared by the bf16-pipe forward kernels: lane (li, lg) holds voxel b6_row(li) of each m-tile, channels lg*4 .. lg*4+3 of
 // each 16-channel n-tile (D = W^T-tile x X-tile), so a lane stores 16 bytes per (m-tile, n-tile)
 // (MTv / wv: m-tiles per wave and the wave's position along m when the waves of a workgroup also split the channels -- k_c3h)
-template <class TL, int TD, int TH, int TW, int NT, int MTv = TL::MT>
+// BW: the backward-statistics epilogue (MODE 2) exists only in the instances that carry it -- its parameter registers cost the persistent
+// 16-channel kernel and the 2-D 64-channel-slab kernel their second workgroup per CU when every instance compiled it in (round 3,
+// measured: 171 -> 310 us in the step)
+template <class TL, int TD, int TH, int TW, int NT, int MTv = TL::MT, bool BW = false>
 __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
                                               int n, int d0, int h0, int w0, int cout0, int accumulate, bool want_stats,
                                               double (&s1)[NT][4], double (&s2)[NT][4], int wv = -1, const StatsArg* sb = nullptr, int gg = 0) {
@@ -64,9 +67,9 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
       bv[nt][r] = (bias && co < cd.Cout) ? bias[co] : 0.f;
     }
   // MODE 2 (backward statistics, see StatsArg): this lane's channels of the consumer norm layer's statistics rows of group gg
-  const bool bwd = want_stats && sb && sb->by;
-  float pmu[NT][4], prs[NT][4], psc[NT][4], psh[NT][4];
-  if (bwd) {
+  const bool bwd = BW && want_stats && sb && sb->by;
+  float pmu[BW ? NT : 1][4], prs[BW ? NT : 1][4], psc[BW ? NT : 1][4], psh[BW ? NT : 1][4];
+  if (BW && bwd) {
     const long long GC = (long long)sb->G * sb->C;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -82,9 +85,11 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
     constexpr bool ACCUM = decltype(acc_tag)::value;
     // dz = da * act'(z), xhat = (y - mean) * rstd -- k_col_partial<1>'s arithmetic on the value just stored
     auto bstat = [&](int nt, int r, float v, float yv) __attribute__((always_inline)) {
-      const float z = (yv - pmu[nt][r]) * psc[nt][r] + psh[nt][r];
+      if (!BW) return;
+      const int pn = BW ? nt : 0;
+      const float z = (yv - pmu[pn][r]) * psc[pn][r] + psh[pn][r];
       const float g1 = v * act_grad(z, sb->bact);
-      const float xh = (yv - pmu[nt][r]) * prs[nt][r];
+      const float xh = (yv - pmu[pn][r]) * prs[pn][r];
       s1[nt][r] += (double)g1;
       s2[nt][r] += (double)g1 * (double)xh;
     };
@@ -142,12 +147,12 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
   if (!want_stats) {
     if (accumulate) rows(std::integral_constant<int, 0>{}, std::true_type{});
     else rows(std::integral_constant<int, 0>{}, std::false_type{});
-  } else if (bwd) rows(std::integral_constant<int, 2>{}, std::false_type{});
+  } else if (BW && bwd) rows(std::integral_constant<int, BW ? 2 : 1>{}, std::false_type{});
   else rows(std::integral_constant<int, 1>{}, std::false_type{});       // the statistics variants never accumulate (bcp_conv3_fwd_stats)
 }
 
 // one tile per workgroup (k_c3b): store + one statistics row per tile
-template <class TL, int TD, int TH, int TW, int NT>
+template <class TL, int TD, int TH, int TW, int NT, bool BW = false>
 __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
                                             int n, int d0, int h0, int w0, int cout0, int accumulate, const StatsArg& st, double* Ss, int bx) {
   double s1[NT][4], s2[NT][4];
@@ -155,8 +160,8 @@ __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __r
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
-  b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st.partial != nullptr, s1, s2, -1, &st,
-                                    st.partial ? bx / st.tiles_per_group : 0);
+  b6_store_tile<TL, TD, TH, TW, NT, TL::MT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st.partial != nullptr, s1, s2, -1, &st,
+                                                st.partial ? bx / st.tiles_per_group : 0);
   if (st.partial) {
     const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();                           // the scratch below aliases nothing, but waves may still be in the last stage
@@ -164,7 +169,7 @@ __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __r
   }
 }
 
-template <int KD, int TD, int TH, int TW, int NT, int SP>
+template <int KD, int TD, int TH, int TW, int NT, int SP, bool BW = false>
 __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   // block re-read its last stage (never stashed); the next chunk's halo is fetched between two copies of the stage loop.
   // Barriers inside the loop order LDS traffic only (BCP_LDS_BARRIER): the global loads stay in flight across them.
   auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {     // stage sg (may run past S) of chunk cc
-    if (sg >= S) { sg -= S; ++cc; }
+    while (sg >= S) { sg -= S; ++cc; }      // (S = 4 for the 2-D two-pair stages: a five-stage lookahead can cross TWO chunk ends)
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
     if (!(B6_ABLATE & 4)) wfetch(cc, sg, wpre);
   };
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
     if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
-  b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, bx);
+  b6_epilogue<TL, TD, TH, TW, NT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, bx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -366,7 +371,7 @@ __device__ __forceinline__ void stats_flush_22(double (&s1)[2][4], double (&s2)[
   __syncthreads();
 }
 
-template <int KD, int TD, int TH, int TW>
+template <int KD, int TD, int TH, int TW, bool BW = false>
 __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
@@ -412,7 +417,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
 
   const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
   auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
-    if (sg >= S) { sg -= S; ++cc; }
+    while (sg >= S) { sg -= S; ++cc; }      // (S = 4 for the 2-D two-pair stages: a five-stage lookahead can cross TWO chunk ends)
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
     int tp = sg < TP ? sg : TP - 1;
     if (B6_ABLATE & 64) { tp = 0; cc = c_begin; }        // (measurement: every stage re-reads the first stage's weights -- cache-resident fetches)
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
-  b6_store_tile<TL, TD, TH, TW, 2, 2>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm, &st,
+  b6_store_tile<TL, TD, TH, TW, 2, 2, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm, &st,
                                       st.partial ? bx / st.tiles_per_group : 0);
   if (st.partial) {
     const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
@@ -524,7 +529,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
 // waves run free and the matrix pipe always finds one with work; k_c3b synchronises its four waves after every tap pair (~0.35 us)
 // to hand the weight buffers over.  The pair loop is fully unrolled (compile-time tap offsets and register sets).
 // ------------------------------------------------------------------------------------------------
-template <int KD, int TD, int TH, int TW, int NT, bool PER>
+template <int KD, int TD, int TH, int TW, int NT, bool PER, bool BW = false>
 __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int n_tiles, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
@@ -681,7 +686,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
       tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
       if (!PER) {
         BCP_LDS_BARRIER();
-        b6_epilogue<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, t_first);      // one statistics row per tile
+        b6_epilogue<TL, TD, TH, TW, NT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, t_first);      // one statistics row per tile
         return;
       }
       if (want_stats && tl / st.tiles_per_group != cur_g) {
@@ -689,7 +694,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
         stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
         cur_g = tl / st.tiles_per_group;
       }
-      b6_store_tile<TL, TD, TH, TW, NT>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, want_stats, s1, s2, -1, &st, cur_g);
+      b6_store_tile<TL, TD, TH, TW, NT, TL::MT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, want_stats, s1, s2, -1, &st, cur_g);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -805,7 +810,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
     }
   };
   auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
-    if (sg >= S) { sg -= S; ++cc; }
+    while (sg >= S) { sg -= S; ++cc; }      // (S = 4 for the 2-D two-pair stages: a five-stage lookahead can cross TWO chunk ends)
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
     wfetch(cc, sg, wpre);
   };
@@ -1098,6 +1103,16 @@ __global__ __launch_bounds__(256) void k_b6_sum_slabs(const float* __restrict__ 
   }
 }
 
+// tile configurations whose dgrad launches carry the backward-statistics epilogue (bcp_conv3_dgrad_bwdstats): the conv -> conv edges of
+// the V-Nets' 32- / 64-channel levels and of the U-Net's decoder blocks; everything else answers "not available" and takes the plain dgrad
+template <int KD, int TD, int TH, int TW, int NT, int SP>
+constexpr bool b6_has_bw() {
+  return (KD == 3 && TD == 4 && TH == 8 && TW == 8 && NT == 2 && SP == 1) || (KD == 3 && TD == 4 && TH == 4 && TW == 8 && NT == 2 && SP == 1) ||
+         (KD == 3 && TD == 4 && TH == 4 && TW == 4 && NT == 4 && SP == 1) || (KD == 1 && TD == 1 && TH == 16 && TW == 16 && NT == 2 && SP == 1) ||
+         (KD == 1 && TD == 1 && TH == 8 && TW == 16 && NT == 2 && SP == 2);
+  // (not the 2-D 8x16 x 64-channel-slab instance: with the epilogue it needs 256 + 48 registers = one workgroup per CU)
+}
+
 template <int KD, int TD, int TH, int TW, int NT, int SP>
 static int b6_launch(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
                      double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk, const BwdStatsIn* bw) {
@@ -1138,7 +1153,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
   if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
   if (bw) {                                           // backward statistics in the epilogue (bcp_conv3_dgrad_bwdstats): one-pass launches only
-    if (sk != 1 || G <= 0 || gx % G) return 0;
+    if (!b6_has_bw<KD, TD, TH, TW, NT, SP>() || sk != 1 || G <= 0 || gx % G || (direct && NT == 1)) return 0;
     st.by = bw->y; st.bstats = bw->stats; st.bact = bw->act;
   }
   if (direct) {
@@ -1155,6 +1170,9 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     if (bw) { sd.by = bw->y; sd.bstats = bw->stats; sd.bact = bw->act; }
     if (dry) return (sk == 1 && G > 0 && gx % G == 0) ? (PER ? P : gx / G) : 0;
     auto kd = k_c3d<KD, TD, TH, TW, NT, PER>;
+    if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>() && !PER) {
+      if (bw) kd = k_c3d<KD, TD, TH, TW, NT, PER, true>;
+    }
     hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (sk == 1) {
       hipLaunchKernelGGL(kd, dim3(P, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, gx, accumulate, sd);
@@ -1168,9 +1186,18 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     return sd.partial ? sd.rows : 0;
   }
   if (dry) return sk == 1 && G > 0 && gx % G == 0 ? gx / G : 0;
+  if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
+    if (bw) {
+      kfn = k_c3b<KD, TD, TH, TW, NT, SP, true>;
+      if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+  }
   if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
     if (options().conv3_b6_w22 != 0) {
       kfn = k_c3h<KD, TD, TH, TW>;       // 2 x 2 wave arrangement of the 64 x 64 tile (same LDS layout and size)
+      if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
+        if (bw) kfn = k_c3h<KD, TD, TH, TW, true>;
+      }
       if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
   }

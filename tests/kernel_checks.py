@@ -579,6 +579,14 @@ def check_conv3_b6(ops, dev):
     ops.set_option("wgrad_b6", 2)           # csrc/conv3bw.hip: the weight gradient on the same pipe (transposed LDS reads)
     try:
         check_conv3(ops, dev, cases=CONV3_B6_CASES)
+        # regression (round 3, found by the full-size ACDC step check): the 2-D two-pairs-per-stage instance has FOUR weight stages per
+        # cin chunk while five are in flight -- the prefetch of stage s + 5 wraps over TWO chunk ends; with >= 3 chunks per workgroup
+        # (64 -> 32 channels and no split-K: the U-Net's level-2 dgrad at batch 12) stage 0 of every later chunk got the last stage's weights
+        ops.set_option("splitk", 1)
+        try:
+            check_conv3(ops, dev, cases=((2, 64, 32, (1, 12, 20), 1), (1, 128, 32, (1, 16, 16), 1), (1, 96, 32, (1, 9, 17), 1)))
+        finally:
+            ops.set_option("splitk")
         for sk in (2, 4):
             ops.set_option("splitk", sk)
             try:
@@ -597,6 +605,15 @@ def check_conv3_b6(ops, dev):
                     ops.set_option("splitk")
         finally:
             ops.set_option("conv3_b6_flat")
+        for mtsel in (4, 2):                           # k_c3g: flat tiles of 256 / 128 voxels, direct weight fragments (option; not the default)
+            ops.set_option("conv3_b6_flatd", mtsel)
+            try:
+                check_conv3(ops, dev, cases=((2, 64, 64, (4, 8, 12), 3), (1, 32, 128, (6, 9, 5), 3), (1, 64, 64, (7, 7, 5), 3), (3, 64, 64, (3, 3, 3), 3)))
+                ops.set_option("splitk", 2)
+                check_conv3(ops, dev, cases=((2, 64, 64, (7, 7, 5), 3),))
+            finally:
+                ops.set_option("splitk")
+                ops.set_option("conv3_b6_flatd")
         # 16 -> 16 layers (3-D: 4x8x8 tiles, 2-D: 16x16 tiles) on the persistent direct-weight kernel: product default only from 256 K
         # voxels, forced here (conv3_b6 = 3) on small ragged shapes; P = 2: two workgroups walk all tiles (cross-tile halo prefetch)
         ops.set_option("conv3_b6", 3)
@@ -734,8 +751,19 @@ def check_norm_small(ops, dev):
     (a) against torch (BatchNorm / grouped BatchNorm / InstanceNorm, every epilogue), (b) against the streaming three-kernel chain
     on the same inputs: y / da sums bit-identical to the slab-sum kernel, activations and gradients equal to fp64-statistics rounding,
     (c) conv -> slabs -> fused norm == conv3_fwd_stats -> norm_fwd, forward and dgrad, split-K forced to 1 / 2 / 4"""
+    ops.set_option("norm_small", 1)          # (off by default since round 3's measurements: DESIGN.md 8.6; the entry points stay and stay tested)
+    try:
+        _check_norm_small(ops, dev)
+        ops.set_option("conv3_b6_flatd", 1)  # the same conv -> slabs -> norm chains with the flat direct-weight deep-level kernel (k_c3g)
+        _check_norm_small(ops, dev, chains_only=True)
+    finally:
+        ops.set_option("norm_small")
+        ops.set_option("conv3_b6_flatd")
+
+
+def _check_norm_small(ops, dev, chains_only=False):
     rng = np.random.default_rng(41)
-    cases = (  # N, C, spatial, act, use_cs, use_res, G, nslab, mode ('bn' | 'in')
+    cases = () if chains_only else (  # N, C, spatial, act, use_cs, use_res, G, nslab, mode ('bn' | 'in')
         (2, 128, (14, 14, 10), H.ACT_RELU, False, False, 2, 4, "bn"),     # LA level 4: 1960 rows per group, 8 rows per thread, two groups per trip
         (2, 256, (7, 7, 5), H.ACT_RELU, True, False, 2, 8, "bn"),         # LA level 5 + Dropout3d (x5)
         (2, 128, (14, 14, 10), H.ACT_RELU, False, True, 1, 1, "bn"),      # transposed-conv layer: residual, 3920 rows in ONE group (16 per thread)
@@ -856,8 +884,9 @@ def check_norm_small(ops, dev):
 def check_dgrad_bwdstats(ops, dev):
     """dgrad epilogue with the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): da bit-identical to the plain
     dgrad, the partial rows sum to k_col_partial<1>'s (sum dz, sum dz * xhat), and norm_bwd fed with them equals the norm_bwd that
-    runs its own statistics pass; shapes of every bf16-pipe kernel family that carries the epilogue (k_c3d one-tile / persistent,
-    k_c3h, k_c3b, 2-D), ragged tiles and padded channels included"""
+    runs its own statistics pass; shapes of every bf16-pipe kernel family that carries the epilogue (k_c3d one-tile, k_c3h, k_c3b, 2-D),
+    ragged tiles and padded channels included.  The persistent 16-channel kernel and the 2-D 64-channel-slab kernel do NOT carry it (it
+    cost them their second workgroup per CU): those shapes answer rows = 0 and return the plain dgrad -- checked for equality only."""
     rng = np.random.default_rng(57)
     cases = (  # N, C_dy (channels of dy), C_da (channels of da = the consumer norm's channels), spatial, KD, G, act
         (2, 32, 32, (8, 16, 16), 3, 2, H.ACT_RELU),       # k_c3d 4x8x8 x 32
@@ -906,7 +935,7 @@ def check_dgrad_bwdstats(ops, dev):
             close(d1, d2, rtol=2e-5, msg=tag + " norm_bwd from fused partials")
             close(dg1, dg2, rtol=2e-5, msg=tag + " dgamma")
             close(db1, db2, rtol=2e-5, msg=tag + " dbeta")
-        assert n_fused >= 7, f"only {n_fused} shapes took the fused path: {fused_tags}"
+        assert n_fused >= 5, f"only {n_fused} shapes took the fused path: {fused_tags}"
         ops.set_option("fuse_bwd_stats", 0)
         assert ops.conv3_dgrad_bwdstats(dy, wd, Cda, KD, yprev, st, act, G)[2] == 0
     finally:
