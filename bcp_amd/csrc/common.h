@@ -61,6 +61,8 @@ struct Options {
   int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)
   int norm_small = 0;       // groups of <= 4096 rows (deep levels): statistics + finalize + apply (+ the split-K slab sum) in ONE launch (k_norm_small_*) instead of 3-5.  OFF by default -- measured slower (round 3): a workgroup that owns four channels of every row touches one cache line per lane (TA-bound: 31 us for 8 MB) while the back-to-back chain it replaces costs 12 us; LA step 6.67 vs 6.54 ms
   int fuse_bwd_stats = 1;   // dgrad epilogue of the bf16-pipe kernels accumulates the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): no k_col_partial<1> pass over (y, da) for conv -> conv edges
+  int conv3_stagger = 0;    // bf16-pipe kernels: workgroups whose linear id has bit conv3_stagger_bit set start ~0.9 us x this late (s_sleep): de-phases the two workgroups of a CU so that one's halo / weight / store phases fall into the other's MFMA phase (measured additive otherwise: 47.8 us MFMA + LDS loop + 20.8 us everything else = 71.9 us at the 32-channel level)
+  int conv3_stagger_bit = 8;
   int conv3_xcd = 1;        // bf16-pipe kernels: XCD-aware workgroup -> tile order (each XCD walks a contiguous eighth of the tile list: halo overlap hits its own L2)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };
@@ -75,6 +77,11 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // barrier; registers being filled by outstanding global loads are private and need no fence.
 #ifndef BCP_LDS_BARRIER
 #define BCP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+// ---- timing-only pause (s_sleep n = ~64 n clocks); the host simulator defines it away
+#ifndef BCP_S_SLEEP
+#define BCP_S_SLEEP(n) __builtin_amdgcn_s_sleep(n)
 #endif
 
 // ---- wavefront (64-lane) reductions; every lane of the wave must call.

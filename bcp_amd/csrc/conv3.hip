@@ -1161,6 +1161,7 @@ static int fill_dims(ConvDims& cd, int N, int D, int H, int W, int Cin, int Cout
   cd.Cout16 = (Cout + 15) / 16 * 16;
   cd.tiles_d = cd.tiles_h = cd.tiles_w = 0;
   cd.xcd = options().conv3_xcd;
+  cd.stagger = (options().conv3_stagger & 0xffff) | (options().conv3_stagger_bit << 16);
   return 0;
 }
 

@@ -40,7 +40,18 @@ struct ConvDims {
   int Cin16, Cout16;    // padded to multiples of 16 (packed-weight extents)
   int tiles_d, tiles_h, tiles_w;
   int xcd;              // != 0: XCD-aware workgroup -> tile order in the bf16-pipe kernels (option conv3_xcd)
+  int stagger;          // low 16 bits: late start of every second workgroup in ~0.9-us units (option conv3_stagger); bits 16..: which id bit selects them
 };
+
+// de-phase the co-resident workgroups of a CU (see Options::conv3_stagger): called once at kernel entry
+__device__ __forceinline__ void stagger_start(const ConvDims& cd) {
+  const int n = cd.stagger & 0xffff;
+  if (n) {
+    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if ((lin >> (cd.stagger >> 16)) & 1u)
+      for (int i = 0; i < n; ++i) BCP_S_SLEEP(32);
+  }
+}
 
 // XCD-aware tile order for one-tile-per-workgroup grids.  Workgroups are dealt round-robin to the 8 XCDs in linear-id order, so
 // workgroup x of a grid row whose first workgroup has linear id `row_lin` runs on XCD (x + row_lin) % 8.  The workgroups of XCD c

@@ -26,6 +26,16 @@
 #ifndef B6_ABLATE
 #define B6_ABLATE 0
 #endif
+// k_c3d: A fragments of a tap pair as a prefetched stream in a fixed order (1, the product) or all requested at the top of the pair (0: round 2)
+#ifndef BCP_C3D_STREAM
+#define BCP_C3D_STREAM 1
+#endif
+#ifndef BCP_C3D_FD
+#define BCP_C3D_FD 3        // prefetch distance of the stream in fragments (4 costs the 32-slab instance its second workgroup per CU)
+#endif
+#ifndef BCP_C3D_MP
+#define BCP_C3D_MP 2        // m-tiles per MFMA group: consecutive MFMAs into one accumulator are MP * NT apart
+#endif
 
 namespace bcp {
 
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   constexpr int NW4 = (SP * 12 * CT + 255) / 256;              // 16-byte pieces of a stage per thread
   using HF = HaloFetch<TL>;
 
+  stagger_start(cd);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
   unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][SP][CT][32]
@@ -385,6 +396,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   constexpr int NW4 = (12 * CT + 255) / 256;
   using HF = HaloFetch<TL>;
 
+  stagger_start(cd);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
   unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][CT][32]
@@ -537,6 +549,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
   constexpr int XPLANE = TL::HV * XSB;
   using HF = HaloFetch<TL>;
 
+  stagger_start(cd);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
   double* Ss = reinterpret_cast<double*>(Xb + 3 * XPLANE);         // [4][CT][2] statistics scratch
@@ -656,6 +669,9 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
     }
     const int cc = c_begin + it % nch;
     const int ccn = c_begin + (it + 1 < n_items ? (it + 1) % nch : it % nch);
+#if BCP_C3D_STREAM
+    bf16x8 nx[BCP_C3D_FD];                           // the next pair's first fragments (fragment stream, below)
+#endif
 #pragma unroll
     for (int tp = 0; tp < TPE; ++tp) {
       // the next pair's weight fragments (the next item's pair 0 after the last one) into the other register set
@@ -666,6 +682,60 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
         const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
         const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
         const int toff = ((lg >> 1) ? tB : tA) * XSB;
+#if BCP_C3D_STREAM
+        // FRAGMENT STREAM (round 3).  hipcc kept ONE register quad for the piece-2 fragments of a pair and re-loaded it four times --
+        // read, s_waitcnt, two MFMAs, read again (ISA of round 2's loop): the LDS round trip was exposed ~4x per pair, the "LDS
+        // fragment reads" share of the ablation (47.8 us for MFMAs + reads against a 36.4 us MFMA floor at the 32-channel level).
+        // Here the MT * 3 A fragments of a pair are consumed in a FIXED order -- m-tile pairs, pieces 2, 1, 0 -- and each is requested
+        // FD fragments ahead of its MFMAs; sched_barrier pins the read in front of the MFMA group it hides under, so the compiler's
+        // wait counts become lgkmcnt(FD - 1) instead of lgkmcnt(0).  Per accumulator the products arrive as (2,0) (1,1) (1,0) (0,2)
+        // (0,1) (0,0): the two ~2^-16 terms swap places against round 2's order, nothing else; consecutive MFMAs into one accumulator
+        // are four apart.
+        {
+          constexpr int MP = (NT > 1 && MT % BCP_C3D_MP == 0) ? BCP_C3D_MP : 1;      // m-tiles per MFMA group (one n-tile per wave: 1 -- measured 161 vs 168 us at the 16-channel level)
+          constexpr int NF = MT * 3, FD = BCP_C3D_FD < NF ? BCP_C3D_FD : NF;     // fragments per pair, prefetch distance
+          static_assert(FD <= NF && MT % MP == 0, "fragment stream geometry");
+          auto fidx = [&](int f, int& mt, int& I) __attribute__((always_inline)) { const int g = f / (3 * MP), r = f % (3 * MP); I = 2 - r / MP; mt = g * MP + r % MP; };
+          // the stream runs ACROSS the pairs of a chunk: the first FD fragments of pair tp + 1 are requested under the last MFMA groups
+          // of pair tp (nx), so only a chunk's first pair waits for an LDS round trip
+          const int t0n = 2 * (tp + 1), t1n = 2 * (tp + 1) + 1 < T ? 2 * (tp + 1) + 1 : T - 1;
+          const int tAn = ((t0n / 9) * TL::HH + (t0n / 3) % 3) * TL::HW + t0n % 3, tBn = ((t1n / 9) * TL::HH + (t1n / 3) % 3) * TL::HW + t1n % 3;
+          const int toffn = ((lg >> 1) ? tBn : tAn) * XSB;
+          const bool have_nx = tp > 0;                         // (compile-time after unrolling: pair 0 of a chunk follows a barrier)
+          const bool want_nx = tp + 1 < TP;
+          bf16x8 fr[NF];
+#pragma unroll
+          for (int f = 0; f < FD; ++f) {
+            int mt, I;
+            fidx(f, mt, I);
+            if (have_nx) fr[f] = nx[f];
+            else fr[f] = *reinterpret_cast<const bf16x8*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toff));
+          }
+#pragma unroll
+          for (int f0 = 0; f0 < NF; f0 += MP) {
+#pragma unroll
+            for (int q = 0; q < MP; ++q) {
+              const int g = f0 + q + FD;
+              int mt, I;
+              if (g < NF) { fidx(g, mt, I); fr[g] = *reinterpret_cast<const bf16x8*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toff)); }
+              else if (want_nx) { fidx(g - NF, mt, I); nx[g - NF] = *reinterpret_cast<const bf16x8*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toffn)); }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            int mt0, I;
+            fidx(f0, mt0, I);
+#pragma unroll
+            for (int J = 2 - I; J >= 0; --J)
+#pragma unroll
+              for (int q = 0; q < MP; ++q)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                  if (tp & 1) acc[mt0 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1[nt][J], fr[f0 + q], acc[mt0 + q][nt], 0, 0, 0);
+                  else acc[mt0 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0[nt][J], fr[f0 + q], acc[mt0 + q][nt], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+#else
         bf16x8 a[MT][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -678,6 +748,7 @@ __global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const 
         if (tp & 1) { BCP_B6(B1, 2, 0) BCP_B6(B1, 1, 1) BCP_B6(B1, 0, 2) BCP_B6(B1, 1, 0) BCP_B6(B1, 0, 1) BCP_B6(B1, 0, 0) }
         else { BCP_B6(B0, 2, 0) BCP_B6(B0, 1, 1) BCP_B6(B0, 0, 2) BCP_B6(B0, 1, 0) BCP_B6(B0, 0, 1) BCP_B6(B0, 0, 0) }
 #undef BCP_B6
+#endif
       }
     }
     if (it % nch == nch - 1) {                       // the tile is complete: store it (uniform branch; stores only, no loads to wait for)

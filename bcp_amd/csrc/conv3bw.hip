@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
   static_assert(TW % 4 == 0 && M % 32 == 0, "a transposed read covers 4 consecutive voxels of a W row");
   using HF = HaloFetch<TL>;
 
+  stagger_start(cd);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][16]
   unsigned short* Yb = Xb + 3 * XPLANE;                            // [3][M][YS]
@@ -167,6 +168,12 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
   for (;;) {
     const bool has_next = tile + 1 < t_end;
     fetch(has_next ? tile + 1 : tile);       // (the last tile re-reads itself: no conditional load in the loop)
+    // A fragments as a prefetched STREAM (round 3, as k_c3d): hipcc issued the six transposed reads of a tap right in front of its
+    // MFMAs (read, s_waitcnt, MFMA: one LDS round trip exposed per tap); here tap t + 1's fragments -- tap 0 of the next K block after
+    // the last tap -- are requested before tap t's MFMAs and sched_barrier keeps them there.
+    bf16x8 an[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) an[s] = cat8(ds_read_tr16(Xb + s * XPLANE + xo[0] + toff[0]), ds_read_tr16(Xb + s * XPLANE + xo[1] + toff[0]));
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const unsigned short* Yk = Yb + kb * YSTEP;
@@ -181,14 +188,22 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
       for (int t = 0; t < TPW; ++t) {
         bf16x8 a[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s)
-          a[s] = cat8(ds_read_tr16(Xk + s * XPLANE + xo[0] + toff[t]), ds_read_tr16(Xk + s * XPLANE + xo[1] + toff[t]));
+        for (int s = 0; s < 3; ++s) a[s] = an[s];
+        if (t + 1 < TPW) {
+#pragma unroll
+          for (int s = 0; s < 3; ++s) an[s] = cat8(ds_read_tr16(Xk + s * XPLANE + xo[0] + toff[t + 1]), ds_read_tr16(Xk + s * XPLANE + xo[1] + toff[t + 1]));
+        } else if (kb + 1 < KB) {
+#pragma unroll
+          for (int s = 0; s < 3; ++s) an[s] = cat8(ds_read_tr16(Xk + XSTEP + s * XPLANE + xo[0] + toff[0]), ds_read_tr16(Xk + XSTEP + s * XPLANE + xo[1] + toff[0]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // rows = input channels (A = X^T fragment), columns = output channels (B = dY fragment); smallest terms first
 #define BCP_W6(I, J)                                                                                                   \
   _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                      \
       acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[I], b[nt][J], acc[t][nt], 0, 0, 0);
         BCP_W6(2, 0) BCP_W6(1, 1) BCP_W6(0, 2) BCP_W6(1, 0) BCP_W6(0, 1) BCP_W6(0, 0)
 #undef BCP_W6
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (!has_next) break;

@@ -349,7 +349,7 @@ class HipNet(nn.Module):
             main = torch.cuda.current_stream(t.device)
             side = self.net._side_streams.get(t.device)
             if side is None:
-                side = self.net._side_streams[t.device] = torch.cuda.Stream(device=t.device)
+                side = self.net._side_streams[t.device] = torch.cuda.Stream(device=t.device, priority=HipNet.WGRAD_STREAM_PRIORITY)
             b = self.net.ops.b
             if b._rec is not None:                 # recorded pass: the fork is an entry of the launch list (bcp_stream_wait_stream)
                 b.call("bcp_stream_wait_stream", side.cuda_stream, main.cuda_stream)
@@ -367,6 +367,7 @@ class HipNet(nn.Module):
             return False
 
     overlap_wgrad = True
+    WGRAD_STREAM_PRIORITY = 0      # measurement switch (bench.py --opt wgrad_prio=..)
     _side_streams = {}
 
     def _wgrad_stream(self, *tensors):

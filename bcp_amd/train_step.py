@@ -20,10 +20,13 @@ def _ops_for(t):
 _SIDE = {}
 
 
+TEACHER_STREAM_PRIORITY = 0      # measurement switch (bench.py --opt teacher_prio=-1): HIP priority of the teacher's side stream
+
+
 def _side_stream(t):
     s = _SIDE.get(t.device)
     if s is None:
-        s = _SIDE[t.device] = torch.cuda.Stream(device=t.device)
+        s = _SIDE[t.device] = torch.cuda.Stream(device=t.device, priority=TEACHER_STREAM_PRIORITY)
     return s
 
 

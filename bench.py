@@ -477,6 +477,14 @@ def main():
         if k == "graphs":             # host-side switch (bcp_amd/plan.py)
             plan.GRAPHS = int(v)
             continue
+        if k == "teacher_prio":       # host-side switch (train_step.py): HIP priority of the teacher's side stream
+            from bcp_amd import train_step as _ts
+            _ts.TEACHER_STREAM_PRIORITY = int(v)
+            continue
+        if k == "wgrad_prio":         # host-side switch (networks/_hipnet.py): HIP priority of the weight-gradient side stream
+            from bcp_amd.networks._hipnet import HipNet as _hn
+            _hn.WGRAD_STREAM_PRIORITY = int(v)
+            continue
         if k == "fuse_head":          # host-side switch (networks/VNet.py), not a library option
             from bcp_amd.networks.VNet import VNet
             VNet.fuse_head = bool(int(v))
