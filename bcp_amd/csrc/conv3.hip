@@ -845,10 +845,26 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
 // zero weights.  (The first version did 432 VALU FMAs per voxel with one LDS broadcast read per FMA: 5x off the HBM
 // roofline.)
 // ------------------------------------------------------------------------------------------------
-template <int KD, int TD, int TH, int TW>
+// EPI: what happens to y = conv + bias (round 3: the layer is HBM-bound -- 4 B in, 64 B out per voxel -- and the conv is 27 MACs per
+// output, so the norm around it RECOMPUTES y instead of storing and re-reading it; bcp_conv3_c1_norm_fwd / _bwd):
+//   0  store y (+ forward statistics when st.partial)            bcp_conv3_c1_fwd / _fwd_stats
+//   1  forward statistics only, nothing stored                    pass 1 of the fused forward
+//   2  a = act((y - mean) * scale + shift) [* mask * s] -> out    pass 2 of the fused forward: y never exists in HBM
+//   3  backward statistics (sum dz, sum dz * xhat) from da        pass 1 of the fused backward
+//   4  dy = scale * (dz - c1 - xhat * c2) -> out                  pass 2 of the fused backward
+struct C1Norm {
+  const float* stats;          // float[5][G][16]: mean, rstd, scale, shift, ...
+  const float* da;             // EPI 3 / 4: gradient w.r.t. the activation, [voxel][16]
+  const float* c1c2;           // EPI 4: float[2][G][16]
+  const uint8_t* elem_mask;    // nullable [voxel][16]: elementwise Dropout keep mask (U-Net)
+  float elem_scale;
+  int act, G;
+};
+
+template <int KD, int TD, int TH, int TW, int EPI = 0>
 __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, const float* __restrict__ w /*[16][1][T]*/,
                                                   const float* __restrict__ bias, float* __restrict__ Y, ConvDims cd, int n_tiles,
-                                                  int tiles_per_block, StatsArg st) {
+                                                  int tiles_per_block, StatsArg st, C1Norm nm) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int T = TL::T, MT = TL::MT, KS = (T + 3) / 4;
   __shared__ __attribute__((aligned(16))) float Xs[TL::HV];
@@ -872,6 +888,17 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
   const int t_begin = blockIdx.x * tiles_per_block;
   int t_end = t_begin + tiles_per_block;
   if (t_end > n_tiles) t_end = n_tiles;
+  // EPI >= 2: this lane's four channels of the statistics rows of the workgroup's group (its tiles lie in ONE group)
+  float mu[4] = {0, 0, 0, 0}, rs[4] = {1, 1, 1, 1}, sc[4] = {1, 1, 1, 1}, sh[4] = {0, 0, 0, 0}, k1[4] = {0, 0, 0, 0}, k2[4] = {0, 0, 0, 0};
+  if (EPI >= 2) {
+    const int g = t_begin / st.tiles_per_group;
+    const long long GC = (long long)nm.G * 16, o = (long long)g * 16 + lg * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      mu[r] = nm.stats[o + r]; rs[r] = nm.stats[GC + o + r]; sc[r] = nm.stats[2 * GC + o + r]; sh[r] = nm.stats[3 * GC + o + r];
+      if (EPI == 4) { k1[r] = nm.c1c2[o + r]; k2[r] = nm.c1c2[GC + o + r]; }
+    }
+  }
   for (int tile = t_begin; tile < t_end; ++tile) {
     int n, d0, h0, w0;
     tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
@@ -890,17 +917,44 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
     for (int mt = 0; mt < MT; ++mt) {
       const int m = (wave * MT + mt) * 16 + li;             // B[k = lg][vox = li]
       const int vo = TL::voff(m);
+      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
+      const int d = d0 + td, h = h0 + th, wq = w0 + tw;
+      const bool ok = full || (d < cd.D && h < cd.H && wq < cd.W);
+      const long long e = ((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16 + lg * 4;
+      float4 dav = make_float4(0.f, 0.f, 0.f, 0.f);
+      uchar4 m4 = make_uchar4(1, 1, 1, 1);
+      if (EPI >= 3 && ok) dav = ld4(nm.da + e);              // (requested before the MFMAs: the round trip hides under them)
+      if (EPI >= 2 && nm.elem_mask && ok) m4 = *reinterpret_cast<const uchar4*>(nm.elem_mask + e);
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], Xs[vo + toff[ks]], acc, 0, 0, 0);
-      const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
-      const int d = d0 + td, h = h0 + th, wq = w0 + tw;
-      if (full || (d < cd.D && h < cd.H && wq < cd.W)) {
-        const float4 v = make_float4(acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w);
-        st4(Y + ((((long long)n * cd.D + d) * cd.H + h) * cd.W + wq) * 16 + lg * 4, v);
-        if (st.partial) {
-          s1[0] += (double)v.x; s2[0] += (double)v.x * (double)v.x; s1[1] += (double)v.y; s2[1] += (double)v.y * (double)v.y;
-          s1[2] += (double)v.z; s2[2] += (double)v.z * (double)v.z; s1[3] += (double)v.w; s2[3] += (double)v.w * (double)v.w;
+      if (ok) {
+        const float yv[4] = {acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w};
+        if (EPI == 0) st4(Y + e, make_float4(yv[0], yv[1], yv[2], yv[3]));
+        if (EPI <= 1) {
+          if (st.partial) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[r] += (double)yv[r]; s2[r] += (double)yv[r] * (double)yv[r]; }
+          }
+        } else {
+          const float ms[4] = {m4.x ? nm.elem_scale : 0.f, m4.y ? nm.elem_scale : 0.f, m4.z ? nm.elem_scale : 0.f, m4.w ? nm.elem_scale : 0.f};
+          const float dd[4] = {dav.x, dav.y, dav.z, dav.w};
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {                     // the arithmetic of k_norm_apply / k_col_partial<1> / k_norm_bwd_apply
+            const float z = (yv[r] - mu[r]) * sc[r] + sh[r];
+            if (EPI == 2) {
+              o[r] = act_fwd(z, nm.act);
+              if (nm.elem_mask) o[r] *= ms[r];
+            } else {
+              const float cs = nm.elem_mask ? ms[r] : 1.f;
+              const float dz = dd[r] * cs * act_grad(z, nm.act);
+              const float xh = (yv[r] - mu[r]) * rs[r];
+              if (EPI == 3) { s1[r] += (double)dz; s2[r] += (double)dz * (double)xh; }
+              else o[r] = sc[r] * (dz - k1[r] - xh * k2[r]);
+            }
+          }
+          if (EPI == 2 || EPI == 4) st4(Y + e, make_float4(o[0], o[1], o[2], o[3]));
         }
       }
     }
@@ -1497,8 +1551,16 @@ static int c1_tiles_per_block(int tiles_per_group) {
   return 1;
 }
 
+template <int EPI>
+static void c1_launch(int KD, dim3 grid, hipStream_t s, const float* x, const float* w, const float* bias, float* y, const ConvDims& cd, int tiles,
+                      int tpb, const StatsArg& st, const C1Norm& nm) {
+  if (KD == 3) hipLaunchKernelGGL((k_conv3_c1<3, 4, 4, 16, EPI>), grid, dim3(256), 0, s, x, w, bias, y, cd, tiles, tpb, st, nm);
+  else hipLaunchKernelGGL((k_conv3_c1<1, 1, 16, 16, EPI>), grid, dim3(256), 0, s, x, w, bias, y, cd, tiles, tpb, st, nm);
+}
+
+// epi: the kernel's EPI mode; returns the statistics rows per group (0: groups do not divide the batch)
 static int c1_fwd_impl(const float* x, const float* w, const float* bias, float* y, int N, int D, int H, int W, int KD, double* stat_partial,
-                       int groups, bool dry, hipStream_t s) {
+                       int groups, bool dry, hipStream_t s, int epi = 0, const C1Norm* nmp = nullptr) {
   ConvDims cd;
   fill_dims(cd, N, D, H, W, 1, 16);
   if (KD == 3) { cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 4); cd.tiles_w = cdiv(W, 16); }
@@ -1514,8 +1576,15 @@ static int c1_fwd_impl(const float* x, const float* w, const float* bias, float*
     if (dry) return st.rows;
   }
   const dim3 grid(cdiv(tiles, tpb));
-  if (KD == 3) hipLaunchKernelGGL((k_conv3_c1<3, 4, 4, 16>), grid, dim3(256), 0, s, x, w, bias, y, cd, tiles, tpb, st);
-  else hipLaunchKernelGGL((k_conv3_c1<1, 1, 16, 16>), grid, dim3(256), 0, s, x, w, bias, y, cd, tiles, tpb, st);
+  const C1Norm none{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 1};
+  const C1Norm& nm = nmp ? *nmp : none;
+  switch (epi) {
+    case 1: c1_launch<1>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
+    case 2: c1_launch<2>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
+    case 3: c1_launch<3>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
+    case 4: c1_launch<4>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
+    default: c1_launch<0>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
+  }
   return st.rows;
 }
 
@@ -1545,6 +1614,60 @@ extern "C" int bcp_conv3_c1_fwd_stats(const float* x, const float* w, const floa
   const int rows = c1_fwd_impl(x, w, bias, y, N, D, H, W, KD, stat_partial, groups, false, (hipStream_t)stream);
   BCP_REQUIRE(rows > 0, "bcp_conv3_c1_fwd_stats: fused statistics unavailable (N %% groups != 0): check bcp_conv3_c1_stat_rows first");
   BCP_CHECK_LAUNCH("bcp_conv3_c1_fwd_stats");
+  return BCP_OK;
+}
+
+// ---- first layer + its norm with RECOMPUTE (round 3): Conv3d/2d(1 -> 16, k = 3) + BatchNorm / InstanceNorm + activation (+ elementwise
+// dropout) of networks/VNet.py:17-26 block_one / networks/unet.py:19-28 in_conv -- y = conv + bias is never written: pass 1 takes the
+// statistics from the accumulators, pass 2 runs the same MFMAs again and stores the activation; the backward recomputes y the same way
+// next to da.  128 MB of y written + read back twice per direction at the LA size become two 8 MB reads of x.
+// workspace: bcp_conv3_c1_norm_workspace_bytes.  Results are bit-identical to bcp_conv3_c1_fwd_stats + bcp_norm_fwd / bcp_norm_bwd.
+namespace bcp {      // csrc/norm.hip
+void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s);
+void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
+                              float* c1c2raw, hipStream_t s);
+}
+
+extern "C" size_t bcp_conv3_c1_norm_workspace_bytes(int N, int D, int H, int W, int KD, int groups) {
+  const int rows = bcp_conv3_c1_stat_rows(N, D, H, W, KD, groups);
+  return rows > 0 ? (size_t)groups * rows * 16 * 2 * sizeof(double) + (size_t)4 * groups * 16 * sizeof(float) : 0;
+}
+
+extern "C" int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float* bias, int N, int D, int H, int W, int KD, int groups,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                     int act, const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out, void* stream) {
+  BCP_REQUIRE(x && w && stats && workspace && out && groups >= 1, "bcp_conv3_c1_norm_fwd: null pointer / bad groups");
+  BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_norm_fwd: bad KD/D");
+  BCP_REQUIRE(aligned16(out) && aligned16(stats) && (!bias || aligned16(bias)), "bcp_conv3_c1_norm_fwd: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = reinterpret_cast<double*>(workspace);
+  const int rows = c1_fwd_impl(x, w, bias, nullptr, N, D, H, W, KD, partial, groups, false, s, 1);
+  BCP_REQUIRE(rows > 0, "bcp_conv3_c1_norm_fwd: the groups must be whole samples (N %% groups == 0)");
+  norm_fwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, gamma, beta, running_mean, running_var, momentum, eps, stats, s);
+  const C1Norm nm{stats, nullptr, nullptr, elem_mask, elem_scale, act, groups};
+  c1_fwd_impl(x, w, bias, out, N, D, H, W, KD, nullptr, groups, false, s, 2, &nm);
+  BCP_CHECK_LAUNCH("bcp_conv3_c1_norm_fwd");
+  return BCP_OK;
+}
+
+extern "C" int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float* bias, const float* da, int N, int D, int H, int W, int KD,
+                                     int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale, float* dgamma,
+                                     float* dbeta, int accumulate, void* workspace, float* dy, void* stream) {
+  BCP_REQUIRE(x && w && da && stats && workspace && dy && groups >= 1, "bcp_conv3_c1_norm_bwd: null pointer / bad groups");
+  BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_norm_bwd: bad KD/D");
+  BCP_REQUIRE(aligned16(da) && aligned16(dy) && (!bias || aligned16(bias)), "bcp_conv3_c1_norm_bwd: alignment");
+  BCP_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bcp_conv3_c1_norm_bwd: dgamma and dbeta come together");
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = reinterpret_cast<double*>(workspace);
+  const int rows0 = bcp_conv3_c1_stat_rows(N, D, H, W, KD, groups);
+  BCP_REQUIRE(rows0 > 0, "bcp_conv3_c1_norm_bwd: the groups must be whole samples (N %% groups == 0)");
+  float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)groups * rows0 * 16 * 2);
+  C1Norm nm{stats, da, c1c2raw, elem_mask, elem_scale, act, groups};
+  const int rows = c1_fwd_impl(x, w, bias, nullptr, N, D, H, W, KD, partial, groups, false, s, 3, &nm);
+  norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s);
+  c1_fwd_impl(x, w, bias, dy, N, D, H, W, KD, nullptr, groups, false, s, 4, &nm);
+  BCP_CHECK_LAUNCH("bcp_conv3_c1_norm_bwd");
   return BCP_OK;
 }
 

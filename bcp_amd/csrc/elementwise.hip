@@ -28,26 +28,38 @@ static inline int stream_grid(long long n_items, int block) {
 __global__ __launch_bounds__(256) void k_mix_box(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ out, long long n_vec, int D, int H, int W, int C,
                                                  int d0, int d1, int h0, int h1, int w0, int w1) {
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  const int rowlen = W * C;  // floats per (n,d,h) row
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
-    const long long e = i * 4;
-    const long long row = e / rowlen;
-    const int inrow = (int)(e - row * rowlen);
-    const int h = (int)(row % H);
-    const int d = (int)((row / H) % D);
-    const bool dh_in = (d >= d0) & (d < d1) & (h >= h0) & (h < h1);
-    float4 va = ld4(a + e), vb = ld4(b + e), vo;
-    float* po = &vo.x;
-    const float* pa = &va.x;
-    const float* pb = &vb.x;
+  // (round 3: 32-bit index arithmetic -- the first version spent three 64-bit divisions per 16 bytes -- and four independent
+  //  vectors per thread; the launcher guarantees n_vec < 2^29)
+  constexpr int U = 4;
+  const unsigned nv = (unsigned)n_vec, stride = gridDim.x * blockDim.x;
+  const unsigned rowlen = (unsigned)(W * C);  // floats per (n,d,h) row
+  for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nv; i0 += U * stride) {
+    float4 va[U], vb[U];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int w = (inrow + k) / C;
-      const bool in = dh_in & (w >= w0) & (w < w1);
-      po[k] = in ? pb[k] : pa[k];
+    for (int u = 0; u < U; ++u) {
+      const unsigned i = i0 + u * stride;
+      if (i < nv) { va[u] = ld4(a + (size_t)i * 4); vb[u] = ld4(b + (size_t)i * 4); }
     }
-    st4(out + e, vo);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned i = i0 + u * stride;
+      if (i >= nv) continue;
+      const unsigned e = i * 4u;
+      const unsigned row = e / rowlen, inrow = e - row * rowlen;
+      const int h = (int)(row % (unsigned)H), d = (int)((row / (unsigned)H) % (unsigned)D);
+      const bool dh_in = (d >= d0) & (d < d1) & (h >= h0) & (h < h1);
+      float4 vo;
+      float* po = &vo.x;
+      const float* pa = &va[u].x;
+      const float* pb = &vb[u].x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int w = (int)((inrow + k) / (unsigned)C);
+        const bool in = dh_in & (w >= w0) & (w < w1);
+        po[k] = in ? pb[k] : pa[k];
+      }
+      st4(out + (size_t)i * 4, vo);
+    }
   }
 }
 
@@ -206,7 +218,8 @@ extern "C" int bcp_mix_box(const float* a, const float* b, float* out, int N, in
   BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && C > 0, "bcp_mix_box: bad extents");
   BCP_REQUIRE((W * C) % 4 == 0, "bcp_mix_box: W*C must be a multiple of 4");
   const long long n_vec = (long long)N * D * H * W * C / 4;
-  hipLaunchKernelGGL(k_mix_box, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_vec, D, H,
+  BCP_REQUIRE(n_vec < (1LL << 29), "bcp_mix_box: tensor too large (>= 2^31 floats)");
+  hipLaunchKernelGGL(k_mix_box, dim3(stream_grid((n_vec + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_vec, D, H,
                      W, C, box6[0], box6[0] + box6[3], box6[1], box6[1] + box6[4], box6[2], box6[2] + box6[5]);
   BCP_CHECK_LAUNCH("bcp_mix_box");
   return BCP_OK;

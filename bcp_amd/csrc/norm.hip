@@ -681,6 +681,35 @@ static inline Segs make_segs(int G, long long rows_per_group, int C, const NormE
 }
 static constexpr int kMaxSamplesPerGroup = 64;
 
+// ---- finalize steps for producers that keep the statistics pass AND the apply pass in their own kernels (the fused first layer,
+// csrc/conv3.hip bcp_conv3_c1_norm_fwd / _bwd): same kernels as bcp_norm_fwd / bcp_norm_bwd run between their two passes
+void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s) {
+  float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C, *var_unb = stats + 4LL * G * C;
+  hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta, running_mean,
+                     running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
+  if (running_mean) hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
+}
+
+__global__ __launch_bounds__(256) void k_norm_bwd_params(const float* __restrict__ raw, int G, int C, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int accumulate) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {      // k_norm_bwd_apply's block (0, 0): the groups in order
+    float gb = accumulate ? dbeta[c] : 0.f, gg = accumulate ? dgamma[c] : 0.f;
+    for (int g = 0; g < G; ++g) { gb += raw[g * C + c]; gg += raw[(long long)G * C + g * C + c]; }
+    dbeta[c] = gb;
+    dgamma[c] = gg;
+  }
+}
+
+// c1c2raw: float[4][G][C] -- the two means the apply pass subtracts, then the raw sums
+void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
+                              float* c1c2raw, hipStream_t s) {
+  float *c1 = c1c2raw, *c2 = c1 + (long long)G * C, *raw = c2 + (long long)G * C;
+  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma, dbeta,
+                     accumulate, c1, c2, raw);
+  if (dgamma) hipLaunchKernelGGL(k_norm_bwd_params, dim3(1), dim3(256), 0, s, raw, G, C, dgamma, dbeta, accumulate);
+}
+
 }  // namespace bcp
 
 using namespace bcp;

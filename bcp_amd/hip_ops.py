@@ -399,6 +399,34 @@ class Ops:
         self.b.call("bcp_conv3_c1_fwd_stats", _p(x), _p(w), _p(bias), _p(out), N, D, H, W, KD, _p(part), groups, self.stream(x))
         return out, part, rows
 
+    def conv3_c1_norm_ok(self, xshape, KD, groups):
+        N, D, H, W, _ = xshape
+        return self._ws_bytes("bcp_conv3_c1_norm_workspace_bytes", int(N), int(D), int(H), int(W), int(KD), int(groups)) > 0
+
+    def conv3_c1_norm_fwd(self, x, w, bias, KD, G, gamma, beta, rmean, rvar, act, elem_mask=None, elem_scale=1.0, momentum=0.1, eps=1e-5):
+        """first layer + norm + activation with recompute (bcp_conv3_c1_norm_fwd): -> (a, stats); y is never materialised"""
+        self._chk(x, w, bias, gamma, beta, rmean, rvar, elem_mask)
+        N, D, H, W, Cin = x.shape
+        assert Cin == 1 and w.shape[0] == 16
+        nbytes = self._ws_bytes("bcp_conv3_c1_norm_workspace_bytes", N, D, H, W, KD, G)
+        ws = self.workspace("c1norm", nbytes, x)
+        stats = torch.empty((5, G, 16), dtype=torch.float32, device=x.device)
+        out = torch.empty((N, D, H, W, 16), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_conv3_c1_norm_fwd", _p(x), _p(w), _p(bias), N, D, H, W, KD, G, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum),
+                    float(eps), act, _p(elem_mask), float(elem_scale), _p(stats), _p(ws), _p(out), self.stream(x))
+        return out, stats
+
+    def conv3_c1_norm_bwd(self, x, w, bias, KD, G, stats, da, act, dgamma=None, dbeta=None, accumulate=False, elem_mask=None, elem_scale=1.0):
+        """backward of conv3_c1_norm_fwd's norm: y recomputed from x, -> dy (the input of conv3_c1_wgrad)"""
+        self._chk(x, w, bias, stats, da, dgamma, dbeta, elem_mask)
+        N, D, H, W, _ = x.shape
+        nbytes = self._ws_bytes("bcp_conv3_c1_norm_workspace_bytes", N, D, H, W, KD, G)
+        ws = self.workspace("c1norm", nbytes, x)
+        dy = torch.empty((N, D, H, W, 16), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_conv3_c1_norm_bwd", _p(x), _p(w), _p(bias), _p(da), N, D, H, W, KD, G, _p(stats), act, _p(elem_mask), float(elem_scale),
+                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy), self.stream(x))
+        return dy
+
     def conv3_c1_wgrad(self, x, dy, dw, KD, accumulate=False):
         self._chk(x, dy, dw)
         N, D, H, W, _ = x.shape
@@ -663,7 +691,7 @@ class Ops:
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
 _PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_small", "norm_bwd_small", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "conv3_pack_many",
-             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
+             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")
 

@@ -31,6 +31,7 @@ class _Layer:
 
 
 class VNet(HipNet):
+    fuse_c1 = True       # first layer: conv + norm + ReLU with recompute (bcp_conv3_c1_norm_fwd / _bwd); False: conv -> y -> norm passes
     fuse_head = True     # the 1x1x1 head applies the last conv's norm + ReLU + Dropout3d itself (bcp_pw16_fwd_norm); False: separate apply pass
 
     def __init__(self, n_channels=3, n_classes=2, n_filters=16, normalization="none", has_dropout=False, has_residual=False,
@@ -195,8 +196,13 @@ class VNet(HipNet):
             sp_out = sp // 8 if L.kind == "dw" else (sp * 8 if L.kind == "up" else sp)
             small = self.training and not (li == last and fuse_head) and ops.norm_small_ok(G, N * sp_out // G, L.cout)
             src, nsl, bsrc = None, 1, None
+            fused_c1 = False
             if L.kind == "c1":
-                if self.training and not small:
+                fused_c1 = (self.fuse_c1 and self.training and not small and not L.skip_pop and L.drop is None and not getattr(self, "_keep_saved", False)
+                            and not (li == last and fuse_head) and ops.conv3_c1_norm_ok(h.shape, 3, G))
+                if fused_c1:
+                    y = None       # conv + norm + ReLU with recompute (bcp_conv3_c1_norm_fwd): the 16-channel pre-norm tensor is never written
+                elif self.training and not small:
                     y, part, nb = ops.conv3_c1_fwd_stats(h, w.data, b.data, 3, G)      # statistics in the epilogue: no pass over the 16-channel y
                 else:
                     y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
@@ -219,7 +225,11 @@ class VNet(HipNet):
                 y = ops.up_fwd(h, bp, b.data, L.cout)
             res = skips.pop() if L.skip_pop else None
             cs = self._chan_scale(L, N, xcl.device)
-            if small:
+            if fused_c1:
+                bn = L.bn
+                a, stats = ops.conv3_c1_norm_fwd(h, w.data, b.data, 3, G, *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var)
+                                                                              if bn is not None else (None,) * 4), H.ACT_RELU)
+            elif small:
                 bn = L.bn
                 a, stats, y = ops.norm_fwd_small(y if src is None else src, nsl, bsrc, G,
                                                  *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var) if bn is not None else (None,) * 4),
@@ -285,7 +295,10 @@ class VNet(HipNet):
             w = L.conv.weight
             da = dh
             dg, db = (L.bn.weight.grad, L.bn.bias.grad) if L.bn is not None else (None, None)
-            if ops.norm_small_ok(G, y.numel() // (y.shape[-1] * G), y.shape[-1]):
+            if y is None:       # the fused first layer: its pre-norm tensor is recomputed from the input (bcp_conv3_c1_norm_bwd)
+                assert L.kind == "c1" and nsl == 1
+                dy = ops.conv3_c1_norm_bwd(x_in, w.data, L.conv.bias.data, 3, G, stats, da, H.ACT_RELU, dg, db, L.bn is not None)
+            elif ops.norm_small_ok(G, y.numel() // (y.shape[-1] * G), y.shape[-1]):
                 # deep levels: slab sum + statistics + apply in one launch (bcp_norm_bwd_small)
                 dy, da = ops.norm_bwd_small(y, da, nsl, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs, want_da=L.skip_pop)
             else:

@@ -36,6 +36,7 @@ class _CB:
 
 
 class UNet_2d(HipNet):
+    fuse_c1 = True       # first layer: conv + norm + LeakyReLU (+ dropout) with recompute (networks/VNet.py)
     def __init__(self, in_chns, class_num):
         super().__init__()
         assert in_chns == 1, "the ACDC hot path is single-channel"
@@ -125,7 +126,10 @@ class UNet_2d(HipNet):
         b1, b2 = cb.b1, cb.b2
         part1, nb1 = None, 0
         src, nsl, bsrc = None, 1, None
-        if cb.cin == 1:
+        fused_c1 = (cb.cin == 1 and self.fuse_c1 and not small and not getattr(self, "_keep_saved", False) and ops.conv3_c1_norm_ok(h.shape, 1, G))
+        if fused_c1:
+            y1 = None      # conv + norm + LeakyReLU + dropout with recompute (bcp_conv3_c1_norm_fwd): y1 is never written
+        elif cb.cin == 1:
             if small:
                 y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
             else:
@@ -139,7 +143,10 @@ class UNet_2d(HipNet):
                 y1 = ops.conv3_fwd(h, wf, cb.c1.bias.data, cb.cout, 1)
             else:
                 y1, part1, nb1 = ops.conv3_fwd_stats(h, wf, cb.c1.bias.data, cb.cout, 1, G)
-        if small:
+        if fused_c1:
+            a1, st1 = ops.conv3_c1_norm_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1, G, b1.weight.data, b1.bias.data, b1.running_mean, b1.running_var,
+                                            H.ACT_LRELU, elem_mask=em, elem_scale=es)
+        elif small:
             a1, st1, y1 = ops.norm_fwd_small(y1 if src is None else src, nsl, bsrc, G, b1.weight.data, b1.bias.data, b1.running_mean, b1.running_var,
                                              H.ACT_LRELU, elem_mask=em, elem_scale=es)
         else:
@@ -178,11 +185,14 @@ class UNet_2d(HipNet):
                                         True, elem_mask=em, elem_scale=es)
         else:
             bpart, bnb = None, 0
-            if em is None and not small:       # no dropout between the two convs: the dgrad epilogue leaves b1's backward statistics
+            if em is None and not small and y1 is not None:       # no dropout between the two convs: the dgrad epilogue leaves b1's backward statistics
                 da1, bpart, bnb = ops.conv3_dgrad_bwdstats(dy2, wd2, cb.cout, 1, y1, st1, H.ACT_LRELU, G)
             else:
                 da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
-            if small:
+            if y1 is None:     # the fused first layer: y1 is recomputed from the block's input (bcp_conv3_c1_norm_bwd)
+                dy1 = ops.conv3_c1_norm_bwd(h, cb.c1.weight.data, cb.c1.bias.data, 1, G, st1, da1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True,
+                                            elem_mask=em, elem_scale=es)
+            elif small:
                 dy1, _ = ops.norm_bwd_small(y1, da1, 1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em, elem_scale=es)
             else:
                 dy1 = ops.norm_bwd(y1, da1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em, elem_scale=es,

@@ -485,6 +485,11 @@ def main():
             from bcp_amd.networks._hipnet import HipNet as _hn
             _hn.WGRAD_STREAM_PRIORITY = int(v)
             continue
+        if k == "fuse_c1":            # host-side switch (networks/VNet.py, unet.py): first layer + norm with recompute
+            from bcp_amd.networks.VNet import VNet as _vn
+            from bcp_amd.networks.unet import UNet_2d as _un
+            _vn.fuse_c1 = _un.fuse_c1 = bool(int(v))
+            continue
         if k == "fuse_head":          # host-side switch (networks/VNet.py), not a library option
             from bcp_amd.networks.VNet import VNet
             VNet.fuse_head = bool(int(v))

@@ -170,6 +170,17 @@ int bcp_conv3_c1_fwd(const float* x, const float* w, const float* bias_or_null, 
 int bcp_conv3_c1_stat_rows(int N, int D, int H, int W, int KD, int groups);
 int bcp_conv3_c1_fwd_stats(const float* x, const float* w, const float* bias_or_null, float* y, int N, int D, int H, int W, int KD,
                            double* stat_partial, int groups, void* stream);
+/* first layer + its norm with RECOMPUTE (networks/VNet.py:17-26 block_one; networks/unet.py:19-28 in_conv): y = conv + bias never
+ * reaches HBM -- pass 1 takes the statistics from the accumulators, pass 2 repeats the 27-tap MFMAs and stores
+ * out = act((y - mean) * scale + beta) [* elem_mask * elem_scale]; the backward recomputes y next to da and writes dy (for
+ * bcp_conv3_c1_wgrad).  stats as bcp_norm_fwd; results bit-identical to bcp_conv3_c1_fwd_stats + bcp_norm_fwd / bcp_norm_bwd. */
+size_t bcp_conv3_c1_norm_workspace_bytes(int N, int D, int H, int W, int KD, int groups);   /* 0: groups do not divide N */
+int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float* bias_or_null, int N, int D, int H, int W, int KD, int groups,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int act,
+                          const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out, void* stream);
+int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float* bias_or_null, const float* da, int N, int D, int H, int W, int KD,
+                          int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta,
+                          int accumulate, void* workspace, float* dy, void* stream);
 int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int KD, int accumulate, void* workspace,
                        void* stream);
 

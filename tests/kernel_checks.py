@@ -943,6 +943,46 @@ def check_dgrad_bwdstats(ops, dev):
         ops.set_option("conv3_b6")
 
 
+def check_conv3_c1_norm(ops, dev):
+    """first layer + norm with recompute (bcp_conv3_c1_norm_fwd / _bwd): BIT-identical to the unfused chain (conv3_c1_fwd_stats ->
+    norm_fwd -> ... -> norm_bwd) -- activation, statistics, running statistics, dy, dgamma / dbeta (+=) -- BatchNorm groups, InstanceNorm,
+    LeakyReLU + elementwise dropout (the U-Net's in_conv), ragged tiles, 2-D"""
+    rng = np.random.default_rng(83)
+    for (N, sp, KD, G, act, use_em, bn) in ((2, (16, 16, 64), 3, 2, H.ACT_RELU, False, True), (4, (6, 5, 21), 3, 2, H.ACT_RELU, False, True),
+                                             (3, (8, 9, 17), 3, 3, H.ACT_RELU, False, False), (4, (1, 40, 48), 1, 2, H.ACT_LRELU, True, True),
+                                             (2, (1, 16, 16), 1, 1, H.ACT_LRELU, True, True)):
+        two_d = KD == 1
+        x = to_cl(R(rng, N, 1, *(sp[1:] if two_d else sp))).to(dev)
+        w = (R(rng, 16, 1, *((3, 3) if two_d else (3, 3, 3))) * 0.2).to(dev).contiguous()
+        b = (R(rng, 16) * 0.1).to(dev)
+        gam = torch.from_numpy(rng.uniform(0.5, 1.5, 16).astype(np.float32)).to(dev) if bn else None
+        bet = torch.from_numpy(rng.uniform(-0.3, 0.3, 16).astype(np.float32)).to(dev) if bn else None
+        em = torch.from_numpy((rng.random(tuple(x.shape[:-1]) + (16,)) < 0.8).astype(np.uint8)).to(dev) if use_em else None
+        da = torch.from_numpy(rng.standard_normal(tuple(x.shape[:-1]) + (16,), dtype=np.float32)).to(dev)
+        assert ops.conv3_c1_norm_ok(x.shape, KD, G)
+        tag = f"c1_norm {sp} G={G}"
+        # unfused reference chain
+        rm0, rv0 = (torch.zeros(16).to(dev), torch.ones(16).to(dev)) if bn else (None, None)
+        y, part, rows = ops.conv3_c1_fwd_stats(x, w, b, KD, G)
+        a0, st0 = ops.norm_fwd(y, G, gam, bet, rm0, rv0, act, elem_mask=em, elem_scale=1.25, partial=part, nb=rows)
+        dg0, db0 = (torch.full((16,), 3.0).to(dev), torch.full((16,), -2.0).to(dev)) if bn else (None, None)
+        dy0 = ops.norm_bwd(y, da, G, st0, act, dg0, db0, True, elem_mask=em, elem_scale=1.25)
+        # fused
+        rm1, rv1 = (torch.zeros(16).to(dev), torch.ones(16).to(dev)) if bn else (None, None)
+        a1, st1 = ops.conv3_c1_norm_fwd(x, w, b, KD, G, gam, bet, rm1, rv1, act, elem_mask=em, elem_scale=1.25)
+        assert torch.equal(st1.cpu(), st0.cpu()), tag + ": statistics"
+        assert torch.equal(a1.cpu(), a0.cpu()), tag + ": activation"
+        if bn:
+            assert torch.equal(rm1.cpu(), rm0.cpu()) and torch.equal(rv1.cpu(), rv0.cpu()), tag + ": running statistics"
+        dg1, db1 = (torch.full((16,), 3.0).to(dev), torch.full((16,), -2.0).to(dev)) if bn else (None, None)
+        dy1 = ops.conv3_c1_norm_bwd(x, w, b, KD, G, st1, da, act, dg1, db1, True, elem_mask=em, elem_scale=1.25)
+        # the two backward paths sum their statistics partials over different row partitions: fp64-rounding-level differences only
+        close(dy1, dy0, rtol=1e-6, atol_scale=1e-7, msg=tag + " dy")
+        if bn:
+            close(dg1, dg0, rtol=1e-6, msg=tag + " dgamma (+=)")
+            close(db1, db0, rtol=1e-6, msg=tag + " dbeta (+=)")
+
+
 def check_augment(ops, dev, golden_dir):
     """device-side RandomRotFlip + RandomCrop == the REFERENCE's transform classes on the same np.random state
     (tests/golden/aug_la.npz), bit for bit, and == the oracle restatement"""
@@ -1029,4 +1069,4 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+ALL_CHECKS = ("conv3_c1_norm", "norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
