@@ -56,6 +56,7 @@ struct Options {
   int conv3_b6_flat = 1;    // deep levels (64-channel slabs, < 16 K voxels): flat 64-voxel tiles with per-lane validity masks (k_c3f) instead of bricks: 128 channels @14x14x10 35 vs 41 us (fp32 kernel 52), 256 @7x7x5 31 vs 33 (fp32); LA step 6.87 vs 6.96 ms.  2 / 3: force 32- / 16-channel slabs (measurements)
   int conv3_b6_flatd = 0;   // deep levels: flat tiles with DIRECT weight fragments and MT m-tiles per wave (k_c3g) instead of k_c3f: 1 = automatic tile (256 / 128 voxels), 2 / 4 = force 128 / 256, 0 = off (default: measured no faster -- 128 channels 36.6 vs 34.8 us, 256 channels 30.4 vs 24.7 us alone)
   int conv3_b6_direct = 1;  // bf16-pipe forward: weight fragments straight from global memory (k_c3d, no stage barriers) instead of an LDS stage (k_c3b): 1 = for the 256-voxel x 32-channel tiles (78-82 vs 84-89 us alone, 7.32 vs 7.34 ms per step), 2 = everywhere (measurements)
+  int conv3_b6_cfg32 = 0;   // measurements: 1 = 128-voxel (4x4x8) tiles for the 32-channel slabs at every size
   int conv3_b6_cfg64 = 0;   // measurements: tile / slab variant of the 64-channel bf16-pipe instances
   int wgrad_b6 = 1;         // weight gradient on the bf16 matrix pipe (conv3bw.hip): 0 off, 1 where measured faster, 2 wherever valid.  LA step (interleaved A/B): off 7.82 ms, 32/64-channel levels 7.52, + 128-channel level 7.38
   int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)

@@ -541,8 +541,11 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
 // waves run free and the matrix pipe always finds one with work; k_c3b synchronises its four waves after every tap pair (~0.35 us)
 // to hand the weight buffers over.  The pair loop is fully unrolled (compile-time tap offsets and register sets).
 // ------------------------------------------------------------------------------------------------
+#ifndef BCP_C3D_ATTR
+#define BCP_C3D_ATTR
+#endif
 template <int KD, int TD, int TH, int TW, int NT, bool PER, bool BW = false>
-__global__ __launch_bounds__(256) void k_c3d(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int n_tiles, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, TP = (T + 1) / 2, TPE = (TP + 1) & ~1, CT = NT * 16;
@@ -1433,7 +1436,7 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
       }
     } else if (cd.Cout16 % 32 == 0) {
       if (forced || ((o.conv3_b6_levels & 1) && vox >= o.conv3_b6_minvox)) {
-        if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+        if (o.conv3_b6_cfg32 != 1 && (vox >= 64LL * 1024 || cd.W % 8 == 0)) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         *handled = true;
       }
