@@ -1,0 +1,9 @@
+#!/bin/bash
+out=$PWD/gpurun_out/s11; mkdir -p $out
+( time python -m pytest tests -m gpu -q ) > $out/pytest_gpu.txt 2>&1; tail -4 $out/pytest_gpu.txt; grep -E "^FAILED|Error" $out/pytest_gpu.txt | head
+ab() { python bench.py --no-cpu-baseline --no-extra --no-roofline --steps 40 --warmup 5 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['host_ms_per_step_empty_queue'])"; }
+for rep in 1 2; do
+  echo "rep $rep la overlap=0 $(ab --opt overlap_step=0)"; echo "rep $rep la default   $(ab)"
+  echo "rep $rep acdc overlap=0 $(ab --workload acdc --opt overlap_step=0)"; echo "rep $rep acdc default   $(ab --workload acdc)"
+  echo "rep $rep panc overlap=0 $(ab --workload pancreas --opt overlap_step=0)"; echo "rep $rep panc default   $(ab --workload pancreas)"
+done > $out/ab.txt 2>&1; cat $out/ab.txt
