@@ -37,6 +37,19 @@
 #define BCP_C3D_MP 2        // m-tiles per MFMA group: consecutive MFMAs into one accumulator are MP * NT apart
 #endif
 
+// measurement only (-DBCP_TS_DEBUG=1, tools/ts_probe.py): wave 0 of the first 64 workgroups of k_c3f stamps s_memtime at its phase
+// boundaries into a device array read back with bcp_debug_ts -- where does a deep-level workgroup's life go?
+#ifndef BCP_TS_DEBUG
+#define BCP_TS_DEBUG 0
+#endif
+#if BCP_TS_DEBUG
+__device__ unsigned long long bcp_ts_buf[64 * 64];
+#define BCP_TS(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 64 && (i) < 64) bcp_ts_buf[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int bcp_debug_ts(unsigned long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bcp_ts_buf), sizeof(bcp_ts_buf)); }
+#else
+#define BCP_TS(i) ((void)0)
+#endif
+
 namespace bcp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -807,6 +820,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][SP][CT][32]
   double* Ss = reinterpret_cast<double*>(Wb + 2 * WSTAGE);         // [4][CT][2] statistics scratch
 
+  BCP_TS(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
@@ -886,11 +900,13 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
     while (sg >= S) { sg -= S; ++cc; }      // (S = 4 for the 2-D two-pair stages: a five-stage lookahead can cross TWO chunk ends)
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
+    if (B6_ABLATE & 64) { cc = c_begin; sg = 0; }       // (measurement: every stage re-reads the first stage's weights -- cache-resident fetches)
     wfetch(cc, sg, wpre);
   };
   // four weight stages in flight in registers, chunk body fully unrolled (static register sets): see k_c3h
   constexpr int HPF = S - 4;
   static_assert(SP == 1, "k_c3f: one tap pair per stage");
+  BCP_TS(1);
   float4 hpre[NP], W[4][NW4];
   hfetch(c_begin, hpre);
   wfetch_at(c_begin, 0, W[0]);
@@ -901,6 +917,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   wstash(Wb, 0, W[0]);
   wfetch_at(c_begin, 4, W[0]);
   BCP_LDS_BARRIER();
+  BCP_TS(2);
 
   auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
     const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
@@ -932,6 +949,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
     if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
     wfetch_at(cc, sg + 5, Wn);
     if (sg + 1 < S) BCP_LDS_BARRIER();
+    BCP_TS(3 + (cc - c_begin) * S + sg);
   };
   auto chunk = [&](int cc, auto phase_tag) __attribute__((always_inline)) {
     constexpr int PH = decltype(phase_tag)::value;
@@ -952,6 +970,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
     if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
+  BCP_TS(60);
   // epilogue: lane (li, lg) holds voxel m0 + wave*16 + li, channels lg*4 .. lg*4+3 of each n-tile: 16-byte stores into flat rows
   double s1[NT][4], s2[NT][4];
 #pragma unroll
@@ -985,6 +1004,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
     BCP_LDS_BARRIER();
     stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
   }
+  BCP_TS(61);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1048,6 +1068,7 @@ __global__ __launch_bounds__(256) void k_c3g(const float* __restrict__ X, const 
   const unsigned short* Wl = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16) + (long long)(cout0 + li) * 32 + lg * 8;
   const long long piece_stride = (long long)cd.Cout16 * 32;
   auto bload = [&](int cc, int tp, bf16x8 (&b)[NT][3]) __attribute__((always_inline)) {
+    if (B6_ABLATE & 64) { cc = c_begin; tp = 0; }       // (measurement: cache-resident weight fetches)
     const unsigned short* p = Wl + ((long long)cc * TP + (tp < TP ? tp : TP - 1)) * 3 * piece_stride;
 #pragma unroll
     for (int s = 0; s < 3; ++s)

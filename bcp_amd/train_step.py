@@ -233,14 +233,20 @@ class OverlapStep:
     the head of the next step, where nothing overlapped them) mostly disappear from the critical path.
     Only for ONE backward pass per step (grouped student batches) and without data parallelism (its buckets must be reduced first)."""
 
-    def __init__(self, optimizer, model, ema_model, alpha, ema_whole_state, bucket_mb=4.0):
+    def __init__(self, optimizer, model, ema_model, alpha, ema_whole_state, bucket_mb=None, first_frac=0.6):
+        """bucket_mb None (the product): ONE early range -- as soon as `first_frac` of the trainable buffer is final (the end of the deep
+        levels) -- then the remainder in finish(): every range costs a Python callback in the middle of the replayed backward pass, and
+        with 4 MB ranges (nine callbacks) the host fell behind the GPU at the deep levels (LA step 6.33 vs 6.11 ms).  A number: that many
+        MB per range (tests)."""
         self.opt, self.model, self.ema, self.alpha, self.whole = optimizer, model, ema_model, alpha, ema_whole_state
-        self.bucket = int(bucket_mb * (1 << 20)) // 4
         model._ensure_flat()
         ema_model._ensure_flat()
         self.hi = model._n_trainable_flat
+        self.bucket = int(bucket_mb * (1 << 20)) // 4 if bucket_mb is not None else int(first_frac * self.hi)
+        self.once = bucket_mb is None
         self.ok = (ema_model._n_trainable_flat == self.hi and ema_model.flat_state().numel() == model.flat_state().numel())
         self.first = None
+        self.stream = None
 
     def arm(self):
         if self.ok:
@@ -260,18 +266,31 @@ class OverlapStep:
     def _on_final(self, model, lo, like):
         if lo >= self.hi or self.hi - lo < self.bucket:
             return
-        side = model._side_streams.get(like.device) if (like.is_cuda and model.overlap_wgrad) else None
-        if side is not None:
-            side.wait_stream(torch.cuda.current_stream(like.device))      # norm / bias gradients of the range come from the main stream
-            with torch.cuda.stream(side):                                  # its weight gradients were enqueued on this stream
+        if like.is_cuda:
+            # a stream of its own: ordered after the main stream (norm / bias gradients) and the weight-gradient side stream, it runs
+            # next to both -- HBM-bound launches underneath MFMA-bound ones -- and delays neither
+            dev = like.device
+            st = _OPT_STREAMS.get(dev)
+            if st is None:
+                st = _OPT_STREAMS[dev] = torch.cuda.Stream(device=dev)
+            st.wait_stream(torch.cuda.current_stream(dev))
+            side = model._side_streams.get(dev) if model.overlap_wgrad else None
+            if side is not None:
+                st.wait_stream(side)
+            with torch.cuda.stream(st):
                 self._apply(lo, self.hi)
+            self.stream = st
         else:
             self._apply(lo, self.hi)
         self.hi = lo
+        if self.once:
+            self.bucket = 1 << 62                # one early range only
 
     def finish(self):
         """after loss.backward() (the side stream has been joined): the remainder, the EMA of the non-trainable tail, bookkeeping"""
         self.model._opt_bucket_hook = None
+        if self.stream is not None:
+            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
         if self.hi > 0:
             self._apply(0, self.hi)
         n_tr = self.model._n_trainable_flat
@@ -288,13 +307,17 @@ class OverlapStep:
             self.ema._nbt_dirty = True
 
 
-OVERLAP_STEP = True        # module switch (bench.py --opt overlap_step=0; parity tests compare both)
+_OPT_STREAMS = {}
+OVERLAP_STEP = False       # module switch (bench.py --opt overlap_step=1; parity tests compare both).  OFF: measured no faster (LA 6.26-6.30 vs
+                           # 6.16-6.22 ms, pancreas 5.66-5.71 vs 5.59-5.62): optimiser / EMA / pack launches at the step boundary are already
+                           # hidden -- the step is bound by its MFMA kernels and the deep levels' dependency chains
 
 
 def _overlap_for(optimizer, model, ema_model, alpha, whole, dp, grouped):
     from .networks._hipnet import HipNet
+    from . import plan
     if not (OVERLAP_STEP and grouped and dp is None and isinstance(optimizer, (FlatSGD, FlatAdam)) and isinstance(model, HipNet)
-            and isinstance(ema_model, HipNet) and optimizer.model is model):
+            and isinstance(ema_model, HipNet) and optimizer.model is model and plan.GRAPHS < 2):      # (a captured backward takes no callbacks)
         return None
     ov = OverlapStep(optimizer, model, ema_model, alpha, whole)
     return ov if ov.arm() else None

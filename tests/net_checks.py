@@ -1119,7 +1119,7 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
             assert torch.equal(a[2][k], b[2][k]), (what, "teacher", k)
 
 
-def check_overlap_step(ops, dev, steps=3, cases=("la", "pancreas", "acdc"), bucket_mb=(4.0, 0.25)):
+def check_overlap_step(ops, dev, steps=3, cases=("la", "pancreas", "acdc"), bucket_mb=(None, 0.25)):
     """train_step.OverlapStep -- optimiser, EMA and weight re-pack applied range by range underneath the backward pass -- against the
     plain step (one optimiser launch, one EMA launch after the backward pass; packs at the head of the next forward): BIT-identical
     students, teachers, running statistics, losses and optimiser state over three steps, with recorded launch plans (the bucket hook is
@@ -1170,11 +1170,11 @@ def check_overlap_step(ops, dev, steps=3, cases=("la", "pancreas", "acdc"), buck
                     {k: v.detach().clone().cpu() for k, v in ema.state_dict().items()}, ostate)
         finally:
             train_step.OverlapStep.__init__ = real_init
-            train_step.OVERLAP_STEP = True
+            train_step.OVERLAP_STEP = False
             plan.ENABLED = True
 
     for what in cases:
-        ref = run(False, what, True, 4.0)
+        ref = run(False, what, True, None)
         for plans_on, mb in ((True, bucket_mb[0]), (True, bucket_mb[1]), (False, bucket_mb[1])):
             got = run(True, what, plans_on, mb)
             assert ref[0] == got[0], (what, plans_on, mb, ref[0], got[0])

@@ -1,0 +1,54 @@
+"""Where does a deep-level conv workgroup's life go?  Needs a library built with -DBCP_TS_DEBUG=1 (tools/_abl/ts.so): wave 0 of the first
+64 workgroups of k_c3f stamps s_memtime at its phase boundaries.   python tools/ts_probe.py tools/_abl/ts.so [C] [sk]"""
+import ctypes as C
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bcp_amd import _lib  # noqa: E402
+from bcp_amd.hip_ops import Ops  # noqa: E402
+
+lib = sys.argv[1]
+Cc = int(sys.argv[2]) if len(sys.argv) > 2 else 128
+ops = Ops(_lib.Binding(lib))
+if len(sys.argv) > 3:
+    ops.set_option("conv3_b6_flat_sk", int(sys.argv[3]))
+dev = torch.device("cuda:0")
+sp = {128: (14, 14, 10), 256: (7, 7, 5), 64: (28, 28, 20)}[Cc]
+x = torch.randn(2, *sp, Cc, device=dev)
+w = torch.randn(Cc, Cc, 3, 3, 3, device=dev) * 0.05
+wf, wd = ops.conv3_pack(w, 3)
+for _ in range(3):
+    y = ops.conv3_fwd(x, wd, None, Cc, 3)
+torch.cuda.synchronize()
+y = ops.conv3_fwd(x, wd, None, Cc, 3)
+torch.cuda.synchronize()
+buf = (C.c_ulonglong * (64 * 64))()
+fn = ops.b.cdll.bcp_debug_ts
+fn.argtypes = [C.c_void_p]
+assert fn(buf) == 0
+import numpy as np
+a = np.frombuffer(buf, dtype=np.uint64).reshape(64, 64).astype(np.int64)
+print(f"C={Cc}: s_memtime ticks (~ shader clocks) since the workgroup's own start (the counters of different XCDs have different bases)")
+print("        setup  first-barrier | stage durations ... | epilogue | lifetime")
+life = []
+for wg in range(64):
+    r = a[wg]
+    if r[0] == 0 or r[61] == 0:
+        continue
+    stages = [i for i in range(3, 60) if r[i] > 0]
+    pts = [r[0], r[1], r[2]] + [r[i] for i in stages] + [r[60], r[61]]
+    d = np.diff(np.array(pts))
+    life.append((r[61] - r[0], d))
+    if wg in (0, 1, 7, 8, 31, 63):
+        print(f"wg {wg:2d}: {d[0]:6d} {d[1]:6d} | " + " ".join(f"{v:5d}" for v in d[2:-2]) + f" | {d[-2]:6d} {d[-1]:6d} | {r[61] - r[0]:7d}")
+if life:
+    L = np.array([l for l, _ in life])
+    print("workgroup lifetime (ticks): min %d median %d max %d over %d workgroups" % (L.min(), np.median(L), L.max(), len(L)))
+    D = np.array([d for _, d in life if len(d) == len(life[0][1])])
+    med = np.median(D, axis=0)
+    print("median per phase: setup %d, first fetch + stash + barrier %d, stages total %d (median stage %d, %d stages), last stage -> epilogue start %d, epilogue %d"
+          % (med[0], med[1], med[2:-2].sum(), np.median(med[2:-2]), len(med) - 4, med[-2], med[-1]))
