@@ -39,6 +39,7 @@ struct Options {
   int conv3_p = 0;          // cap on persistent workgroups of the resident / pipeline convs (tests: force multi-tile loops)
   int splitk = 0;           // streaming conv: split-K factor 1..4
   int conv3_b6_cin16max = 32;   // 2-D layers with 16 output channels on the bf16 pipe: widest input (measurement switch)
+  int conv3_b6_pipe = 1;        // ... and of those the 3-D ones as the LDS-DMA software pipeline k_c3p (0: k_c3h, register-staged weights)
   int conv3_b6_w22 = 1;         // 64-voxel x 64-channel staged tiles: waves arranged 2 x 2 (k_c3h) instead of 1 x 4 (k_c3b)
   int conv3_b6_cfg2d = 1;       // 2-D 32-channel slabs: 1 = direct-weight 16x16 tiles from 64 K pixels, 2 = always, 0 = staged 8x16 tiles
   int conv3_b6_flat_sk = 0; // flat bf16-pipe tiles: split-K factor 1..8 (0: the launcher's rule)
@@ -78,6 +79,16 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // barrier; registers being filled by outstanding global loads are private and need no fence.
 #ifndef BCP_LDS_BARRIER
 #define BCP_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
+// ---- LDS-DMA (gfx950 global_load_lds_dwordx4): 16 bytes per lane from a PER-LANE global address to LDS at a WAVE-UNIFORM base +
+// 16 * lane.  The data is ordered for a ds_read by the issuing wave's counted vmcnt followed by a barrier the reader has passed:
+// BCP_VM_LDS_BARRIER(N) = "at most N younger vector-memory operations may still be in flight" + the LDS barrier above.  N counts
+// LDS-DMAs ONLY: the counter retires LDS-DMAs in order among themselves, but an ordinary load issued later can retire earlier (k_c3p).
+#ifndef BCP_GLDS16
+typedef __attribute__((address_space(3))) void* bcp_lds_ptr_t;
+#define BCP_GLDS16(gsrc, lds_wave_base) __builtin_amdgcn_global_load_lds((gsrc), (bcp_lds_ptr_t)(lds_wave_base), 16, 0, 0)
+#define BCP_VM_LDS_BARRIER(N) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory")
 #endif
 
 // ---- timing-only pause (s_sleep n = ~64 n clocks); the host simulator defines it away

@@ -44,10 +44,13 @@
 #endif
 #if BCP_TS_DEBUG
 __device__ unsigned long long bcp_ts_buf[64 * 64];
-#define BCP_TS(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 64 && (i) < 64) bcp_ts_buf[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define BCP_TS(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && (i) < 64) bcp_ts_buf[(blockIdx.x >> 3) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+// (slots 59 / 62: the 100 MHz constant clock at the same two points as slots 0 / 61 -> the shader clock the kernel actually ran at)
+#define BCP_TSR(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && (i) < 64) bcp_ts_buf[(blockIdx.x >> 3) * 64 + (i)] = wall_clock64(); } while (0)
 extern "C" int bcp_debug_ts(unsigned long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bcp_ts_buf), sizeof(bcp_ts_buf)); }
 #else
 #define BCP_TS(i) ((void)0)
+#define BCP_TSR(i) ((void)0)
 #endif
 
 namespace bcp {
@@ -243,13 +246,27 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
   // (branch-free: every thread loads -- slots past the stage re-read its first pieces, pairs past TP re-read the last pair -- and
   //  wstash drops / zeroes what is not wanted; a predicated load would cost a vmcnt(0) per stage, see fetch_nb)
-  auto wfetch = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+  // (one tap pair per stage: ONE uniform base per stage + a per-thread 32-bit offset fixed for the whole kernel; see k_c3h)
+  unsigned wq[NW4];
 #pragma unroll
-    for (int u = 0; u < NW4; ++u) {
-      const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
-      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
-      const int tp = sg * SP + pr < TP ? sg * SP + pr : TP - 1;
-      wpre[u] = *reinterpret_cast<const float4*>(Wb16 + ((((long long)cc * TP + tp) * 3 + sp) * cd.Cout16 + cout0 + co) * 32 + kq * 8);
+  for (int u = 0; u < NW4; ++u) {
+    const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
+    const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3;
+    wq[u] = (unsigned)((sp * cd.Cout16 + cout0 + co) * 32 + kq * 8);
+  }
+  auto wfetch = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+    if constexpr (SP == 1) {
+      const unsigned short* wst = Wb16 + (long long)(cc * TP + (sg < TP ? sg : TP - 1)) * 3 * cd.Cout16 * 32;      // uniform
+#pragma unroll
+      for (int u = 0; u < NW4; ++u) wpre[u] = *reinterpret_cast<const float4*>(wst + wq[u]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < NW4; ++u) {
+        const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
+        const int pr = q / (12 * CT);
+        const int tp = sg * SP + pr < TP ? sg * SP + pr : TP - 1;
+        wpre[u] = *reinterpret_cast<const float4*>(Wb16 + (long long)(cc * TP + tp) * 3 * cd.Cout16 * 32 + wq[u]);
+      }
     }
   };
   auto wstash = [&](unsigned short* Wbuf, int sg, const float4 (&wpre)[NW4]) __attribute__((always_inline)) {
@@ -258,7 +275,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
       const int q = threadIdx.x + u * 256;
       const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
       const float4 v = (sg * SP + pr < TP) ? wpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);       // pad pairs: zero weights
-      if (q < SP * 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
+      if ((SP * 12 * CT) % 256 == 0 || q < SP * 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
     }
   };
   unsigned hvm = 0;                                  // validity bits of the halo rows in flight (fetch_nb)
@@ -310,8 +327,12 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
       for (int nt = 0; nt < NT; ++nt) abl_b[nt][s] = *reinterpret_cast<const bf16x8*>(Wb + s * WPLANE + nt * 16 * 32 + woff);
     }
   }
+  // (order within a stage: fragment reads, the NEXT stage's weights to the other buffer -- last read one stage ago, every wave has passed
+  //  the barrier that ended that stage -- and the refill of their registers, THEN the MFMAs: the wave reaches the barrier behind its
+  //  last MFMA; see k_c3h)
   auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
     const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
+    bf16x8 a[SP][MT][3], b[SP][NT][3];
 #pragma unroll
     for (int pr = 0; pr < SP; ++pr) {
       const int tp = sg * SP + pr;
@@ -320,26 +341,30 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
         const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
         const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
         const int toff = ((lg >> 1) ? tB : tA) * XSB;
-        bf16x8 a[MT][3], b[NT][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[mt][s] = (B6_ABLATE & 32) ? abl_a[mt][s] : *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
+          for (int mt = 0; mt < MT; ++mt) a[pr][mt][s] = (B6_ABLATE & 32) ? abl_a[mt][s] : *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) b[nt][s] = (B6_ABLATE & 32) ? abl_b[nt][s] : *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + (pr * CT + nt * 16) * 32 + woff);
+          for (int nt = 0; nt < NT; ++nt) b[pr][nt][s] = (B6_ABLATE & 32) ? abl_b[nt][s] : *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + (pr * CT + nt * 16) * 32 + woff);
         }
+      }
+    }
+    if (!(B6_ABLATE & 4) && (sg + 1 < S || cc + 1 < c_end)) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
+    wfetch_at(cc, sg + 5, Wn);
+#pragma unroll
+    for (int pr = 0; pr < SP; ++pr) {
+      const int tp = sg * SP + pr;
+      if (tp < TP && !(B6_ABLATE & 8)) {     // uniform
         // D = W^T-tile x X-tile: rows = output channels, columns = voxels, so that a lane ends up with FOUR CONSECUTIVE channels of
         // one voxel (one 16-byte store).  Smallest terms first; the six products of an accumulator are spread over the MT*NT accumulators.
 #define BCP_B6(I, J)                                                                                            \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)            \
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][J], a[mt][I], acc[mt][nt], 0, 0, 0);
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[pr][nt][J], a[pr][mt][I], acc[mt][nt], 0, 0, 0);
         BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
 #undef BCP_B6
       }
     }
-    // the next stage's weights -> the other buffer (last read one stage ago: every wave has passed the barrier that ended that stage)
-    if (!(B6_ABLATE & 4) && (sg + 1 < S || cc + 1 < c_end)) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
-    wfetch_at(cc, sg + 5, Wn);
     if (sg + 1 < S && !(B6_ABLATE & 16)) BCP_LDS_BARRIER();               // (a chunk boundary brings its own)
   };
   auto chunk = [&](int cc, auto phase_tag) __attribute__((always_inline)) {
@@ -410,6 +435,8 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   using HF = HaloFetch<TL>;
 
   stagger_start(cd);
+  BCP_TS(0);
+  BCP_TSR(59);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
   unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][CT][32]
@@ -441,17 +468,23 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
 
   const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  // weight fetch of stage (cc, sg): ONE uniform base per stage (scalar registers) + a per-thread 32-bit offset fixed for the whole
+  // kernel -- the per-load 64-bit index arithmetic this replaced was ~25 VALU instructions per stage on the critical path of the wave
+  unsigned wq[NW4];
+#pragma unroll
+  for (int u = 0; u < NW4; ++u) {
+    const int q = (threadIdx.x + u * 256) % (12 * CT);
+    const int kq = q & 3, co = (q >> 2) % CT, sp = q / (4 * CT);
+    wq[u] = (unsigned)((sp * cd.Cout16 + cout0 + co) * 32 + kq * 8);
+  }
   auto wfetch_at = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
     while (sg >= S) { sg -= S; ++cc; }      // (S = 4 for the 2-D two-pair stages: a five-stage lookahead can cross TWO chunk ends)
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }
     int tp = sg < TP ? sg : TP - 1;
     if (B6_ABLATE & 64) { tp = 0; cc = c_begin; }        // (measurement: every stage re-reads the first stage's weights -- cache-resident fetches)
+    const unsigned short* wst = Wb16 + (long long)(cc * TP + tp) * 3 * cd.Cout16 * 32;      // uniform
 #pragma unroll
-    for (int u = 0; u < NW4; ++u) {
-      const int q = (threadIdx.x + u * 256) % (12 * CT);
-      const int kq = q & 3, co = (q >> 2) % CT, sp = q / (4 * CT);
-      wpre[u] = *reinterpret_cast<const float4*>(Wb16 + ((((long long)cc * TP + tp) * 3 + sp) * cd.Cout16 + cout0 + co) * 32 + kq * 8);
-    }
+    for (int u = 0; u < NW4; ++u) wpre[u] = *reinterpret_cast<const float4*>(wst + wq[u]);
   };
   auto wstash = [&](unsigned short* Wbuf, int sg, const float4 (&wpre)[NW4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -459,7 +492,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
       const int q = threadIdx.x + u * 256;
       const int kq = q & 3, co = (q >> 2) % CT, sp = q / (4 * CT);
       const float4 v = (sg < TP) ? wpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);       // pad pair: zero weights
-      if (q < 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + co * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
+      if ((12 * CT) % 256 == 0 || q < 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + co * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
     }
   };
   unsigned hvm = 0;
@@ -479,6 +512,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   // goes to LDS buffer (g + 1) & 1 during stage g and is refilled with stage g + 5.  The chunk body is fully unrolled (static register
   // sets, compile-time tap offsets); S = 14 is not a multiple of 4, so chunks alternate between the two phases of the rotation.
   constexpr int HPF = S - 4;
+  BCP_TS(1);
   float4 hpre[HF::NP], W[4][NW4];
   hfetch(c_begin, hpre);
   wfetch_at(c_begin, 0, W[0]);
@@ -489,14 +523,20 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   wstash(Wb, 0, W[0]);
   wfetch_at(c_begin, 4, W[0]);
   BCP_LDS_BARRIER();
+  BCP_TS(2);
 
+  // One stage.  Order within it (round 3, from the s_memtime stamps of tools/ts_probe.py: fragments + MFMAs 664 ticks, weight stash +
+  // fetch issued AFTER them 436, barrier 128 -- a serial chain per wave of which only the MFMA part can hide behind the co-resident
+  // workgroup's wave): the next stage's weights go to the other LDS buffer and the refill of their registers is issued BEFORE the
+  // MFMAs (that buffer was last read in stage sg - 1, which every wave left through the barrier), so the wave reaches the next
+  // barrier straight behind its last MFMA.
   auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
     const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
+    bf16x8 a[2][3], b[2][3];
     if (sg < TP) {     // uniform
       const int t0 = 2 * sg, t1 = 2 * sg + 1 < T ? 2 * sg + 1 : T - 1;
       const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
       const int toff = ((lg >> 1) ? tB : tA) * XSB;
-      bf16x8 a[2][3], b[2][3];
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
 #pragma unroll
@@ -504,15 +544,18 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + nt * 16 * 32 + woff);
       }
+    }
+    if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
+    wfetch_at(cc, sg + 5, Wn);
+    if (sg < TP) {
 #define BCP_B6(I, J)                                                                                            \
   _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)              \
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][J], a[mt][I], acc[mt][nt], 0, 0, 0);
       BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
 #undef BCP_B6
     }
-    if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
-    wfetch_at(cc, sg + 5, Wn);
     if (sg + 1 < S) BCP_LDS_BARRIER();
+    BCP_TS(3 + (cc - c_begin) * S + sg);
   };
   auto chunk = [&](int cc, auto phase_tag) __attribute__((always_inline)) {
     constexpr int PH = decltype(phase_tag)::value;
@@ -533,6 +576,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
     if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
+  BCP_TS(60);
   double s1[2][4], s2[2][4];
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt)
@@ -545,6 +589,208 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
     BCP_LDS_BARRIER();
     stats_flush_22(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
   }
+  BCP_TS(61);
+  BCP_TSR(62);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_c3h as a SOFTWARE PIPELINE (round 3).  What the s_memtime stamps of k_c3h showed (tools/ts_probe.py, 64 -> 64 channels at 28 x 28 x
+// 20 x 2): a workgroup alone on its CU needs ~810 ticks per stage for 384 cycles of MFMA per wave, two co-resident ones ~1000 and ~1600
+// (the older one wins the arbitration), and the launch lasts as long as the slower of the pair -- each wave runs the chain
+// [fragment reads -> wait -> 24 MFMAs -> weight stash -> barrier] serially and two waves per SIMD cannot fill each other's gaps.  Here
+// the chain is cut:
+//   * the weight stages come by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write pass) into a ring of THREE 12 KB
+//     slots, three stages ahead: the DMA of stage g + 3 is issued at the top of stage g into the slot stage g's fragments were read
+//     from a stage earlier, and is waited for (counted vmcnt) in front of the barrier that ends stage g + 1;
+//   * the fragments of stage g + 1 (halo planes + slot (g + 1) % 3) are read into a second register set at the top of stage g, so the
+//     MFMAs of a stage start right behind the barrier with their operands in registers;
+//   * the halo has two buffers: the next chunk's planes are written during the chunk's second-last stage, so a chunk boundary is an
+//     ordinary stage (k_c3h: two extra barriers around the stash, ~1300 ticks).
+// The LDS image of a slot is lane-linear (piece q of the stage at byte 16 q); the XOR swizzle of the k quarters that makes the
+// fragment reads conflict-free is applied on the SOURCE address of the DMA (the read side keeps k_c3h's addresses).
+// LDS: 2 x 20.25 KB halo + 3 x 12 KB weights + 2 KB = 78.5 KB -> two workgroups per CU.  Same MFMA sequence per accumulator as
+// k_c3h: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <int KD, int TD, int TH, int TW, bool BW = false>
+__global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
+                                             float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
+  using TL = Tile<KD, TD, TH, TW>;
+  static_assert(TL::M == 64, "k_c3p: 64-voxel tiles (four m-tiles: two per wave)");
+  constexpr int T = TL::T, TP = (T + 1) / 2, CT = 64;
+  constexpr int S = (TP + 1) & ~1;                             // stages per cin chunk, even: the fragment register sets alternate statically
+  static_assert(S >= 8 && S == TP, "k_c3p: 3-D taps (no pad stage), halo prefetch six stages ahead");
+  constexpr int XPLANE = TL::HV * XSB, XBUF = 3 * XPLANE;      // bf16 elements per halo plane / buffer
+  constexpr int WPLANE = CT * 32, WSLOT = 3 * WPLANE;          // one ring slot: 3 planes x 64 rows x 64 B = 12 KB
+  constexpr int HFS = S - 6, HSS = S - 2;                      // stage of a chunk that fetches / stashes the next chunk's halo
+  using HF = HaloFetch<TL>;
+
+  stagger_start(cd);
+  BCP_TS(0);
+  BCP_TSR(59);
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [2][3][HV][XSB]
+  unsigned short* Wr = Xb + 2 * XBUF;                              // [3 slots][3][CT][32]
+  double* Ss = reinterpret_cast<double*>(Wr + 3 * WSLOT);          // [4][32][2] statistics scratch
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;   // tile of this workgroup
+  int n, d0, h0, w0;
+  tile_origin(cd, bx, TD, TH, TW, n, d0, h0, w0);
+  const int cout0 = blockIdx.y * CT;
+
+  int voff[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) voff[mt] = TL::voff((wm * 2 + mt) * 16 + b6_row<TW>(li)) * XSB + (lg & 1) * 8;
+  const int woff = (wn * 32 + li) * 32 + ((lg ^ ((li & 8) ? 2 : 0)) * 8);
+  HF hf;
+  hf.init(cd, reinterpret_cast<float*>(smem4));
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = cd.Cin16 >> 4;
+  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
+  Y += (long long)blockIdx.z * cd.N * cd.D * cd.H * cd.W * cd.Cout;
+
+  // DMA piece q = u * 256 + thread of a stage lands at byte 16 q of the slot = (plane u, row q >> 2 & 63, k quarter POSITION q & 3);
+  // that position holds k quarter (q & 3) ^ (row & 8 ? 2 : 0): per-thread source byte offsets, fixed for the whole kernel
+  const char* Wb16 = reinterpret_cast<const char*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  unsigned wq[3];
+  {
+    const int co = (threadIdx.x >> 2) & 63, kq = (threadIdx.x & 3) ^ ((co & 8) ? 2 : 0);
+#pragma unroll
+    for (int u = 0; u < 3; ++u) wq[u] = (unsigned)(((u * cd.Cout16 + cout0 + co) * 32 + kq * 8) * 2);
+  }
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  char* const Wr_wave = reinterpret_cast<char*>(Wr) + wave_u * 1024;        // this wave's 1 KB of every plane
+  auto wdma = [&](int cc, int sg, unsigned slot_bytes) __attribute__((always_inline)) {
+    while (sg >= S) { sg -= S; ++cc; }
+    if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }                        // (past the end: re-read the last stage; never used)
+    const char* wst = Wb16 + (long long)(cc * TP + sg) * 3 * cd.Cout16 * 64;      // uniform
+#pragma unroll
+    for (int u = 0; u < 3; ++u) BCP_GLDS16(wst + wq[u], Wr_wave + slot_bytes + u * 4096);
+  };
+  unsigned hvm = 0;
+  auto hfetch = [&](int cc, float4 (&pre)[HF::NP]) __attribute__((always_inline)) { hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, cc, pre); };
+  auto hstash = [&](int hb, const float4 (&pre)[HF::NP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < HF::NP; ++u)
+      if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
+        const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_store4(v, Xb + hb * XBUF + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
+      }
+  };
+  // fragments of stage sg (halo buffer hb, ring slot at element offset slot_el) -> one register set
+  auto frag_read = [&](int hb, int sg, unsigned slot_el, bf16x8 (&a)[2][3], bf16x8 (&b)[2][3]) __attribute__((always_inline)) {
+    const int t0 = 2 * sg, t1 = 2 * sg + 1 < T ? 2 * sg + 1 : T - 1;
+    const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
+    const int toff = ((lg >> 1) ? tB : tA) * XSB;
+    const unsigned short* Xc = Xb + hb * XBUF;
+    const unsigned short* Wc = Wr + slot_el;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xc + s * XPLANE + voff[mt] + toff);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + nt * 16 * 32 + woff);
+    }
+  };
+
+  BCP_TS(1);
+  // prologue: halo of the first chunk, weight stages 0 .. 2, fragments of stage 0
+  float4 hpre[HF::NP];
+  bf16x8 fa[2][2][3], fb[2][2][3];
+  unsigned sl0 = 0, sl1 = WSLOT * 2, sl2 = 2 * WSLOT * 2;      // ring slots (byte offsets) of stages g, g + 1, g + 2
+  hfetch(c_begin, hpre);
+  wdma(c_begin, 0, sl0);
+  wdma(c_begin, 1, sl1);
+  wdma(c_begin, 2, sl2);
+  hstash(0, hpre);
+  BCP_VM_LDS_BARRIER(0);
+  frag_read(0, 0, sl0 >> 1, fa[0], fb[0]);
+  BCP_LDS_BARRIER();                                           // every wave has its stage-0 fragments: slot 0 may be refilled
+  BCP_TS(2);
+
+  // One stage = 24 MFMAs on the current register set with the 15 memory instructions of the pipeline (3 DMAs of stage g + 3, 12
+  // fragment reads of stage g + 1) issued BETWEEN them, one behind each of the first 15 MFMAs: an MFMA keeps the matrix pipe busy for 16
+  // cycles while the wave issues the next instruction.  Issued in front of the MFMAs instead they cost the wave ~300 cycles per stage
+  // (684 ticks per stage for a workgroup alone on its CU against 384 cycles of MFMA); hipcc left alone sinks the reads next to THEIR
+  // MFMAs -- pulled up across the barrier -- and the pipeline is gone: the order is pinned with sched_barrier.
+  auto stage = [&](int cc, auto hb_tag, auto sg_tag) __attribute__((always_inline)) {
+    constexpr int HB = decltype(hb_tag)::value, sg = decltype(sg_tag)::value, PAR = sg & 1;
+    constexpr int NHB = sg + 1 < S ? HB : HB ^ 1, NSG = sg + 1 < S ? sg + 1 : 0;     // next stage (behind the last chunk: stale planes, never used)
+    if (sg == HFS) hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (compile-time position; the last chunk re-reads its own halo)
+    if (sg == HSS) hstash(HB ^ 1, hpre);
+    // uniform addresses of the stage's memory instructions
+    int dcc = cc, dsg = sg + 3;
+    while (dsg >= S) { dsg -= S; ++dcc; }
+    if (dcc >= c_end) { dcc = c_end - 1; dsg = S - 1; }                            // (past the end: re-read the last stage; never used)
+    const char* wst = Wb16 + (long long)(dcc * TP + dsg) * 3 * cd.Cout16 * 64;
+    char* const wdst = Wr_wave + sl0;
+    constexpr int t0 = 2 * NSG, t1 = 2 * NSG + 1 < T ? 2 * NSG + 1 : T - 1;
+    constexpr int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
+    const int toff = ((lg >> 1) ? tB : tA) * XSB;
+    const unsigned short* Xc = Xb + NHB * XBUF + toff;
+    const unsigned short* Wc = Wr + (sl1 >> 1) + woff;
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PI[6] = {2, 1, 0, 1, 0, 0}, PJ[6] = {0, 1, 2, 0, 1, 0};       // piece products, smallest terms first (as k_c3h)
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      const int pr = k >> 2, mt = (k >> 1) & 1, nt = k & 1;
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PAR][nt][PJ[pr]], fa[PAR][mt][PI[pr]], acc[mt][nt], 0, 0, 0);
+      if (k < 3) BCP_GLDS16(wst + wq[k], wdst + k * 4096);
+      else if (k < 15) {
+        const int r = k - 3, sp = r >> 2, w = r & 3;
+        if (w < 2) fa[PAR ^ 1][w][sp] = *reinterpret_cast<const bf16x8*>(Xc + sp * XPLANE + voff[w]);
+        else fb[PAR ^ 1][w - 2][sp] = *reinterpret_cast<const bf16x8*>(Wc + sp * WPLANE + (w - 2) * 16 * 32);
+      }
+      if (k < 15) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // The DMA issued a stage ago must have landed before anyone reads its slot at the top of the next stage: at most this stage's
+    // three DMAs may still be in flight.  The halo loads of the fetch stage are younger than that DMA too, but they must NOT be
+    // added to the count: vmcnt is in order among the LDS-DMAs, not between an LDS-DMA and an ordinary load -- halo loads that hit
+    // the L2 retire in front of an older DMA that went to HBM, the counter drops to 3 + NP with the old DMA still in flight, and the
+    // next stage reads a slot that has not landed (measured: wrong results exactly where the weight stream misses the caches -- first
+    // call on cold caches, the 256-channel level; tools/diag/pipe_diag.py).  Counting only DMAs, the wait also covers the halo
+    // loads of this stage (once per chunk; they have had the stage to arrive).
+    BCP_VM_LDS_BARRIER(3);
+    const unsigned t = sl0; sl0 = sl1; sl1 = sl2; sl2 = t;
+    BCP_TS(3 + (cc - c_begin) * S + sg);
+  };
+  auto chunk = [&](int cc, auto hb_tag) __attribute__((always_inline)) {
+    static_assert(S == 14, "k_c3p: the stage list below is written out for 14 stages");
+#define BCP_ST(I) stage(cc, hb_tag, std::integral_constant<int, I>{});
+    BCP_ST(0) BCP_ST(1) BCP_ST(2) BCP_ST(3) BCP_ST(4) BCP_ST(5) BCP_ST(6) BCP_ST(7) BCP_ST(8) BCP_ST(9) BCP_ST(10) BCP_ST(11) BCP_ST(12) BCP_ST(13)
+#undef BCP_ST
+  };
+#pragma unroll 1
+  for (int cc = c_begin; cc < c_end; cc += 2) {
+    chunk(cc, std::integral_constant<int, 0>{});
+    if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, 1>{});
+  }
+  BCP_TS(60);
+  BCP_VM_LDS_BARRIER(0);                                       // (the DMAs past the end have landed: nothing writes the LDS behind the epilogue)
+
+  double s1[2][4], s2[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
+  b6_store_tile<TL, TD, TH, TW, 2, 2, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm, &st,
+                                      st.partial ? bx / st.tiles_per_group : 0);
+  if (st.partial) {
+    const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
+    BCP_LDS_BARRIER();
+    stats_flush_22(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
+  }
+  BCP_TS(61);
+  BCP_TSR(62);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -821,6 +1067,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   double* Ss = reinterpret_cast<double*>(Wb + 2 * WSTAGE);         // [4][CT][2] statistics scratch
 
   BCP_TS(0);
+  BCP_TSR(59);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
@@ -854,14 +1101,19 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   Y += (long long)blockIdx.z * cd.N * V * cd.Cout;
 
   const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
-  auto wfetch = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+  // (ONE uniform base per stage + a per-thread 32-bit offset fixed for the whole kernel; see k_c3h)
+  static_assert(SP == 1, "k_c3f: one tap pair per stage");
+  unsigned wq[NW4];
 #pragma unroll
-    for (int u = 0; u < NW4; ++u) {
-      const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
-      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
-      const int tp = sg * SP + pr < TP ? sg * SP + pr : TP - 1;
-      wpre[u] = *reinterpret_cast<const float4*>(Wb16 + ((((long long)cc * TP + tp) * 3 + sp) * cd.Cout16 + cout0 + co) * 32 + kq * 8);
-    }
+  for (int u = 0; u < NW4; ++u) {
+    const int q = (threadIdx.x + u * 256) % (12 * CT);
+    const int kq = q & 3, co = (q >> 2) % CT, sp = q / (4 * CT);
+    wq[u] = (unsigned)((sp * cd.Cout16 + cout0 + co) * 32 + kq * 8);
+  }
+  auto wfetch = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
+    const unsigned short* wst = Wb16 + (long long)(cc * TP + (sg < TP ? sg : TP - 1)) * 3 * cd.Cout16 * 32;      // uniform
+#pragma unroll
+    for (int u = 0; u < NW4; ++u) wpre[u] = *reinterpret_cast<const float4*>(wst + wq[u]);
   };
   auto wstash = [&](unsigned short* Wbuf, int sg, const float4 (&wpre)[NW4]) __attribute__((always_inline)) {
 #pragma unroll
@@ -869,7 +1121,7 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
       const int q = threadIdx.x + u * 256;
       const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
       const float4 v = (sg * SP + pr < TP) ? wpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < SP * 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
+      if ((SP * 12 * CT) % 256 == 0 || q < SP * 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
     }
   };
   // halo: row r of the flat range = voxel m0 - R + r of sample n (zero outside [0, V) and beyond Cin); branch-free loads
@@ -905,7 +1157,6 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   };
   // four weight stages in flight in registers, chunk body fully unrolled (static register sets): see k_c3h
   constexpr int HPF = S - 4;
-  static_assert(SP == 1, "k_c3f: one tap pair per stage");
   BCP_TS(1);
   float4 hpre[NP], W[4][NW4];
   hfetch(c_begin, hpre);
@@ -919,35 +1170,36 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
   BCP_LDS_BARRIER();
   BCP_TS(2);
 
+  // (order within a stage: fragment reads, the next stage's weights to the other buffer + the refill of their registers, THEN the MFMAs;
+  //  see k_c3h)
   auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
     const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
+    const int tp = sg;
+    bf16x8 a[3], b[NT][3];
+    if (tp < TP) {     // uniform
+      const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
+      const int oA = ((t0 / 9) - PD) * HW + ((t0 / 3) % 3 - 1) * cd.W + (t0 % 3 - 1);      // wave-uniform row offsets of the two taps
+      const int oB = ((t1 / 9) - PD) * HW + ((t1 / 3) % 3 - 1) * cd.W + (t1 % 3 - 1);
+      const int toff = ((lg >> 1) ? oB : oA) * XSB;
+      const bool ok = (((lg >> 1) ? (vbits >> t1) : (vbits >> t0)) & 1u) != 0;
+      const bf16x8 zero = __builtin_bit_cast(bf16x8, make_float4(0.f, 0.f, 0.f, 0.f));
 #pragma unroll
-    for (int pr = 0; pr < SP; ++pr) {
-      const int tp = sg * SP + pr;
-      if (tp < TP) {     // uniform
-        const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
-        const int oA = ((t0 / 9) - PD) * HW + ((t0 / 3) % 3 - 1) * cd.W + (t0 % 3 - 1);      // wave-uniform row offsets of the two taps
-        const int oB = ((t1 / 9) - PD) * HW + ((t1 / 3) % 3 - 1) * cd.W + (t1 % 3 - 1);
-        const int toff = ((lg >> 1) ? oB : oA) * XSB;
-        const bool ok = (((lg >> 1) ? (vbits >> t1) : (vbits >> t0)) & 1u) != 0;
-        bf16x8 a[3], b[NT][3];
-        const bf16x8 zero = __builtin_bit_cast(bf16x8, make_float4(0.f, 0.f, 0.f, 0.f));
+      for (int s = 0; s < 3; ++s) {
+        const bf16x8 v = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + vrow + toff);
+        a[s] = ok ? v : zero;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-          const bf16x8 v = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + vrow + toff);
-          a[s] = ok ? v : zero;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + (pr * CT + nt * 16) * 32 + woff);
-        }
-#define BCP_B6(I, J)                                                                                            \
-  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                              \
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][J], a[I], acc[nt], 0, 0, 0);
-        BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
-#undef BCP_B6
+        for (int nt = 0; nt < NT; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + nt * 16 * 32 + woff);
       }
     }
     if (sg + 1 < S || cc + 1 < c_end) wstash(Wb + ((sg + 1) & 1) * WSTAGE, sg + 1 < S ? sg + 1 : 0, Wn);
     wfetch_at(cc, sg + 5, Wn);
+    if (tp < TP) {
+#define BCP_B6(I, J)                                                                                            \
+  _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                              \
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[nt][J], a[I], acc[nt], 0, 0, 0);
+      BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
+#undef BCP_B6
+    }
     if (sg + 1 < S) BCP_LDS_BARRIER();
     BCP_TS(3 + (cc - c_begin) * S + sg);
   };
@@ -1005,6 +1257,245 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
     stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
   }
   BCP_TS(61);
+  BCP_TSR(62);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_c3f as the software pipeline of k_c3p (round 3): weight stages by LDS-DMA into a ring of three slots, three stages ahead; the
+// fragments of stage g + 1 read into a second register set between the MFMAs of stage g; one memory instruction behind each MFMA.
+// What differs from k_c3p: one m-tile x NT n-tiles per wave (3 + 3 NT fragment reads per 6 NT MFMAs); ONE halo buffer (two of 36 KB
+// would cost the second workgroup per CU), so a chunk boundary keeps its two barriers around the stash and the first stage of a chunk
+// reads its voxel fragments late; a neighbour outside the volume is not masked after the read but reads the all-zero row AVMAX of the
+// planes (a select on the address, one per stage, instead of on twelve data registers behind the wait for the read).
+// LDS: 3 x 385 x 32 B halo + 3 slots x 3 x CT x 64 B + statistics scratch = 36 + 36 + 2 KB at 64-channel slabs.
+// Same MFMA sequence per accumulator as k_c3f: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int AVMAX>
+__global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
+                                             float* __restrict__ Y, ConvDims cd, int tiles_per_sample, int accumulate, StatsArg st) {
+  constexpr int BM = 64, T = 27, TP = 14, S = 14, CT = NT * 16;
+  constexpr int XPLANE = (AVMAX + 1) * XSB;                      // (row AVMAX: zeros)
+  constexpr int WPLANE = CT * 32, WSLOT = 3 * WPLANE;            // elements
+  constexpr int NPIECE = 12 * CT, NDMA = (NPIECE + 255) / 256;   // 16-byte pieces of a stage; DMA instructions per wave and stage
+  constexpr int NP = (AVMAX * 4 + 255) / 256;                    // halo float4 per thread (row, 4-channel part)
+  constexpr int HPF = S - 4;
+  constexpr int NMEM = NDMA + 3 + 3 * NT, NMMA = 6 * NT;
+
+  HIP_DYNAMIC_SHARED(float4, smem4)
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][AVMAX + 1][XSB]
+  unsigned short* Wr = Xb + 3 * XPLANE;                            // [3 slots][3][CT][32]
+  double* Ss = reinterpret_cast<double*>(Wr + 3 * WSLOT);          // [4][CT][2] statistics scratch
+
+  BCP_TS(0);
+  BCP_TSR(59);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
+  const int R = HW + cd.W + 1, AV = BM + 2 * R;                    // AV <= AVMAX (checked by the launcher)
+  const int bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;   // tile of this workgroup
+  const int n = bx / tiles_per_sample, m0 = (bx % tiles_per_sample) * BM;
+  const int cout0 = blockIdx.y * CT;
+
+  // this lane's voxel (one m-tile per wave), its halo row and the validity bits of its 27 neighbours
+  const int ml = wave * 16 + li, mv = m0 + ml;
+  const int vrow = (ml + R) * XSB + (lg & 1) * 8, zrow = AVMAX * XSB + (lg & 1) * 8;
+  unsigned vbits = 0;
+  if (mv < V) {
+    const int w = mv % cd.W, h = (mv / cd.W) % cd.H, d = mv / HW;
+    const unsigned mw = (w >= 1 ? 1u : 0u) | 2u | (w + 1 < cd.W ? 4u : 0u);
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+        if ((unsigned)(d + kd - 1) < (unsigned)cd.D && (unsigned)(h + kh - 1) < (unsigned)cd.H) vbits |= mw << (kd * 9 + kh * 3);
+  }
+  const int woff = li * 32 + ((lg ^ ((li & 8) ? 2 : 0)) * 8);
+
+  f32x4 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = cd.Cin16 >> 4;
+  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
+  Y += (long long)blockIdx.z * cd.N * V * cd.Cout;
+
+  // DMA instruction u of wave w carries pieces (u * 256 + w * 64) % NPIECE + lane (instructions past the stage repeat its first
+  // pieces: same bytes to the same place); piece q = (plane q / (4 CT), row (q >> 2) % CT, k quarter POSITION q & 3) at byte 16 q
+  const char* Wb16 = reinterpret_cast<const char*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  static_assert(NDMA <= 3, "k_c3q: at most 64-channel slabs");
+  unsigned wq[3];      // (literal bounds: with a bound that depends on the template parameter the DMA builtin's address argument is type-dependent and
+  int wdst[3];         //  hipcc's HOST pass silently drops the kernel's stub -- the library then fails to load with an undefined symbol)
+#pragma unroll
+  for (int u = 0; u < NDMA; ++u) {
+    const int qb = (u * 256 + wave_u * 64) % NPIECE, q = qb + lane;
+    const int co = (q >> 2) % CT, sp = q / (4 * CT), kq = (q & 3) ^ ((co & 8) ? 2 : 0);
+    wq[u] = (unsigned)(((sp * cd.Cout16 + cout0 + co) * 32 + kq * 8) * 2);
+    wdst[u] = qb * 16;
+  }
+  char* const Wr_b = reinterpret_cast<char*>(Wr);
+  // (results through reference parameters: a value-returning lambda in a kernel template makes hipcc's HOST pass drop the kernel's
+  //  stub without a diagnostic -- the library then fails to load with an undefined symbol)
+  auto wsrc = [&](int cc, int sg, const char*& src) __attribute__((always_inline)) {
+    while (sg >= S) { sg -= S; ++cc; }
+    if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }                        // (past the end: re-read the last stage; never used)
+    src = Wb16 + (long long)(cc * TP + sg) * 3 * cd.Cout16 * 64;            // uniform
+  };
+  // halo: row r of the flat range = voxel m0 - R + r of sample n (zero outside [0, V) and beyond Cin); branch-free loads
+  unsigned hvm = 0;
+  const long long xbase = (long long)n * V * cd.Cin;
+  auto hfetch = [&](int cc, float4 (&pre)[NP]) __attribute__((always_inline)) {
+    hvm = 0;
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int q = threadIdx.x + u * 256, r = q >> 2, part = q & 3;
+      const int gm = m0 - R + r;
+      const unsigned ok = (r < AV && (unsigned)gm < (unsigned)V && cc * 16 + part * 4 < cd.Cin) ? 1u : 0u;
+      const unsigned off = ok ? (unsigned)(xbase + (long long)gm * cd.Cin + cc * 16 + part * 4) : 0u;
+      pre[u] = ld4(X + off);
+      hvm |= ok << u;
+    }
+  };
+  auto hstash = [&](const float4 (&pre)[NP]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int q = threadIdx.x + u * 256, r = q >> 2, part = q & 3;
+      if (r < AV) {
+        const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+        split_store4(v, Xb + r * XSB + part * 4, XPLANE);
+      }
+    }
+  };
+  // address of this lane's voxel fragment of stage sg (the all-zero row where the neighbour lies outside the volume)
+  auto a_addr = [&](int sg, const unsigned short*& xa) __attribute__((always_inline)) {
+    const int t0 = 2 * sg, t1 = 2 * sg + 1 < T ? 2 * sg + 1 : T - 1;
+    const int oA = ((t0 / 9) - 1) * HW + ((t0 / 3) % 3 - 1) * cd.W + (t0 % 3 - 1);      // wave-uniform row offsets of the two taps
+    const int oB = ((t1 / 9) - 1) * HW + ((t1 / 3) % 3 - 1) * cd.W + (t1 % 3 - 1);
+    const bool ok = (((lg >> 1) ? (vbits >> t1) : (vbits >> t0)) & 1u) != 0;
+    xa = Xb + (ok ? vrow + ((lg >> 1) ? oB : oA) * XSB : zrow);
+  };
+
+  BCP_TS(1);
+  float4 hpre[NP];
+  bf16x8 fa[2][3], fb[2][NT][3];
+  unsigned sl0 = 0, sl1 = WSLOT * 2, sl2 = 2 * WSLOT * 2;      // ring slots (byte offsets) of stages g, g + 1, g + 2
+  hfetch(c_begin, hpre);
+  auto wdma = [&](int sg, unsigned slot) __attribute__((always_inline)) {
+    const char* w;
+    wsrc(c_begin, sg, w);
+#pragma unroll
+    for (int u = 0; u < NDMA; ++u) BCP_GLDS16(w + wq[u], Wr_b + slot + wdst[u]);
+  };
+  wdma(0, sl0);
+  wdma(1, sl1);
+  wdma(2, sl2);
+  if (threadIdx.x < 6) *reinterpret_cast<float4*>(Xb + (threadIdx.x >> 1) * XPLANE + AVMAX * XSB + (threadIdx.x & 1) * 8) = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero rows
+  hstash(hpre);
+  BCP_VM_LDS_BARRIER(0);
+  auto frag0 = [&]() __attribute__((always_inline)) {
+    const unsigned short* Xc;
+    a_addr(0, Xc);
+    const unsigned short* Wc = Wr + (sl0 >> 1) + woff;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      fa[0][s] = *reinterpret_cast<const bf16x8*>(Xc + s * XPLANE);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) fb[0][nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + nt * 16 * 32);
+    }
+  };
+  frag0();
+  BCP_LDS_BARRIER();                                           // every wave has its stage-0 fragments: slot 0 may be refilled
+  BCP_TS(2);
+
+  auto stage = [&](int cc, auto sg_tag) __attribute__((always_inline)) {
+    constexpr int sg = decltype(sg_tag)::value, PAR = sg & 1, NSG = sg + 1 < S ? sg + 1 : 0;
+    constexpr bool LAST = sg + 1 == S;                         // the next stage's voxel fragments wait for the next chunk's planes
+    if (sg == HPF) hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (compile-time position; the last chunk re-reads its own halo)
+    const char* wst;
+    wsrc(cc, sg + 3, wst);
+    const unsigned short* Xc;
+    a_addr(NSG, Xc);
+    const unsigned short* Wc = Wr + (sl1 >> 1) + woff;
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int PI[6] = {2, 1, 0, 1, 0, 0}, PJ[6] = {0, 1, 2, 0, 1, 0};       // piece products, smallest terms first (as k_c3f)
+    int m = 0;                                                 // memory instructions issued so far (compile-time after unrolling)
+#pragma unroll
+    for (int k = 0; k < NMMA; ++k) {
+      const int pr = k / NT, nt = k % NT;
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PAR][nt][PJ[pr]], fa[PAR][PI[pr]], acc[nt], 0, 0, 0);
+#pragma unroll
+      for (; m < ((k + 1) * NMEM + NMMA - 1) / NMMA; ++m) {
+        if (m < NDMA) BCP_GLDS16(wst + wq[m], Wr_b + sl0 + wdst[m]);
+        else if (m < NDMA + 3 * NT) {
+          const int r = m - NDMA, sp = r / NT, nt2 = r % NT;
+          fb[PAR ^ 1][nt2][sp] = *reinterpret_cast<const bf16x8*>(Wc + sp * WPLANE + nt2 * 16 * 32);
+        } else if (!LAST) {
+          const int sp = m - NDMA - 3 * NT;
+          fa[PAR ^ 1][sp] = *reinterpret_cast<const bf16x8*>(Xc + sp * XPLANE);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // the DMA issued a stage ago must have landed before anyone reads its slot at the top of the next stage: at most this stage's NDMA
+    // DMAs may still be in flight (see k_c3p: the halo loads of the fetch stage are NOT added to the count)
+    BCP_VM_LDS_BARRIER(NDMA);
+    const unsigned t = sl0; sl0 = sl1; sl1 = sl2; sl2 = t;
+    BCP_TS(3 + (cc - c_begin) * S + sg);
+  };
+#pragma unroll 1
+  for (int cc = c_begin; cc < c_end; ++cc) {
+#define BCP_ST(I) stage(cc, std::integral_constant<int, I>{});
+    BCP_ST(0) BCP_ST(1) BCP_ST(2) BCP_ST(3) BCP_ST(4) BCP_ST(5) BCP_ST(6) BCP_ST(7) BCP_ST(8) BCP_ST(9) BCP_ST(10) BCP_ST(11) BCP_ST(12) BCP_ST(13)
+#undef BCP_ST
+    // chunk boundary (every wave is done with the planes: the barrier that ended the last stage): the next chunk's planes, then the
+    // voxel fragments of its first stage
+    if (cc + 1 < c_end) {
+      hstash(hpre);
+      BCP_LDS_BARRIER();
+      const unsigned short* Xc;
+      a_addr(0, Xc);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) fa[0][s] = *reinterpret_cast<const bf16x8*>(Xc + s * XPLANE);
+    }
+  }
+  BCP_TS(60);
+  BCP_VM_LDS_BARRIER(0);                                       // (the DMAs past the end have landed: nothing writes the LDS behind the epilogue)
+
+  // epilogue: lane (li, lg) holds voxel m0 + wave*16 + li, channels lg*4 .. lg*4+3 of each n-tile: 16-byte stores into flat rows
+  double s1[NT][4], s2[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
+  const bool vec = cout0 + CT <= cd.Cout && (cd.Cout & 3) == 0;     // uniform
+  const bool want_stats = st.partial != nullptr;
+  if (mv < V) {
+    float* yrow = Y + ((long long)n * V + mv) * cd.Cout + cout0 + lg * 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = cout0 + nt * 16 + lg * 4 + r;
+        float v = acc[nt][r] + ((bias && co < cd.Cout) ? bias[co] : 0.f);
+        if (accumulate && co < cd.Cout) v += yrow[nt * 16 + r];
+        acc[nt][r] = v;
+        if (want_stats && co < cd.Cout) { s1[nt][r] += (double)v; s2[nt][r] += (double)v * (double)v; }
+      }
+      if (vec) st4(yrow + nt * 16, make_float4(acc[nt][0], acc[nt][1], acc[nt][2], acc[nt][3]));
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (cout0 + nt * 16 + lg * 4 + r < cd.Cout) yrow[nt * 16 + r] = acc[nt][r];
+      }
+    }
+  }
+  if (want_stats) {
+    const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
+    BCP_LDS_BARRIER();
+    stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
+  }
+  BCP_TS(61);
+  BCP_TSR(62);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1208,6 +1699,10 @@ constexpr bool b6_has_bw() {
   // (not the 2-D 8x16 x 64-channel-slab instance: with the epilogue it needs 256 + 48 registers = one workgroup per CU)
 }
 
+// dynamic LDS of k_c3p: two halo buffers, three weight slots, statistics scratch
+template <class TL>
+static constexpr size_t kC3pLds = (size_t)2 * 3 * TL::HV * XSB * 2 + (size_t)3 * 3 * 64 * 32 * 2 + (size_t)4 * 32 * 2 * sizeof(double);
+
 template <int KD, int TD, int TH, int TW, int NT, int SP>
 static int b6_launch(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
                      double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk, const BwdStatsIn* bw) {
@@ -1237,11 +1732,15 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
       hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kd, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, gx, 0, none);
     } else {
+      size_t lds_k = lds;
       if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
         if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;
+        if constexpr (KD == 3) {
+          if (options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0) { kfn = k_c3p<KD, TD, TH, TW>; lds_k = kC3pLds<TL>; }
+        }
       }
-      if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, 0, none);
+      if (lds_k > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
+      hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds_k, s, X, Wp, (const float*)nullptr, Y, cd, 0, none);
     }
     return 0;
   }
@@ -1287,21 +1786,31 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
       if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     }
   }
+  size_t lds_k = lds;
   if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
     if (options().conv3_b6_w22 != 0) {
       kfn = k_c3h<KD, TD, TH, TW>;       // 2 x 2 wave arrangement of the 64 x 64 tile (same LDS layout and size)
       if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
         if (bw) kfn = k_c3h<KD, TD, TH, TW, true>;
       }
-      if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if constexpr (KD == 3) {
+        if (options().conv3_b6_pipe != 0) {   // the same tile as an LDS-DMA software pipeline (its own LDS layout)
+          kfn = k_c3p<KD, TD, TH, TW>;
+          if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
+            if (bw) kfn = k_c3p<KD, TD, TH, TW, true>;
+          }
+          lds_k = kC3pLds<TL>;
+        }
+      }
+      if (lds_k > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
     }
   }
   if (sk == 1) {
-    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, accumulate, st);
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds_k, s, X, Wp, bias, Y, cd, accumulate, st);
   } else {
     const long long n = (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout;
     StatsArg none{nullptr, 0, 1, cd.Cout, 1};
-    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, 0, none);
+    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds_k, s, X, Wp, (const float*)nullptr, ws, cd, 0, none);
     hipLaunchKernelGGL(k_b6_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y,
                        accumulate);
   }
@@ -1315,8 +1824,15 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
                           double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk, const BwdStatsIn* bw) {
   constexpr int CT = NT * 16, BM = 64;
   const int V = cd.D * cd.H * cd.W, tps = cdiv(V, BM);
-  const size_t lds = (size_t)3 * kB6FlatAvMax * XSB * 2 + (size_t)2 * 3 * SP * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
+  size_t lds = (size_t)3 * kB6FlatAvMax * XSB * 2 + (size_t)2 * 3 * SP * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
   auto kfn = k_c3f<KD, NT, SP, kB6FlatAvMax>;
+  if constexpr (KD == 3 && SP == 1) {
+    if (options().conv3_b6_pipe != 0) {       // the LDS-DMA software pipeline (its own LDS layout: a zero row per plane, three weight slots)
+      auto kq = k_c3q<NT, kB6FlatAvMax>;
+      kfn = kq;
+      lds = (size_t)3 * (kB6FlatAvMax + 1) * XSB * 2 + (size_t)3 * 3 * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
+    }
+  }
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * tps, gy = cd.Cout16 / CT;
   const int nch = cd.Cin16 / 16;

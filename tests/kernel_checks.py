@@ -593,18 +593,46 @@ def check_conv3_b6(ops, dev):
                 check_conv3(ops, dev, cases=[CONV3_B6_CASES[2]])
             finally:
                 ops.set_option("splitk")
-        ops.set_option("conv3_b6_flat", 1)          # k_c3f: flat 64-voxel tiles + per-lane validity masks (deep levels, 64-channel slabs)
+        # flat 64-voxel tiles + per-lane validity (deep levels): k_c3q (LDS-DMA software pipeline, the default) and k_c3f (register-staged
+        # weights, conv3_b6_pipe = 0); slab widths: 1 = the launcher's choice (32 channels at these sizes), 4 = 64, 3 = 16 channels
+        flat_cases = ((2, 64, 64, (4, 8, 12), 3), (1, 32, 128, (6, 9, 5), 3), (1, 64, 64, (7, 7, 5), 3), (2, 32, 64, (5, 6, 7), 3), (3, 64, 64, (3, 3, 3), 3))
         try:
-            check_conv3(ops, dev, cases=((2, 64, 64, (4, 8, 12), 3), (1, 32, 128, (6, 9, 5), 3), (1, 64, 64, (7, 7, 5), 3), (2, 32, 64, (5, 6, 7), 3),
-                                         (3, 64, 64, (3, 3, 3), 3)))
-            for sk in (2, 4):
-                ops.set_option("splitk", sk)
-                try:
-                    check_conv3(ops, dev, cases=((2, 64, 64, (7, 7, 5), 3),))
-                finally:
-                    ops.set_option("splitk")
+            for flat in (1, 4, 3):
+                ops.set_option("conv3_b6_flat", flat)
+                for pipe in (1, 0):
+                    ops.set_option("conv3_b6_pipe", pipe)
+                    check_conv3(ops, dev, cases=flat_cases if flat == 1 else flat_cases[:3])
+                    for sk in (2, 4):
+                        ops.set_option("splitk", sk)
+                        try:
+                            check_conv3(ops, dev, cases=((2, 64, 64, (7, 7, 5), 3),))
+                        finally:
+                            ops.set_option("splitk")
+                # the two kernels issue the same MFMA sequence per accumulator: bit-identical outputs (one-pass + statistics, +=, split-K)
+                rng3 = np.random.default_rng(78 + flat)
+                for (N, Cin, Cout, sp, KD) in ((2, 64, 64, (4, 8, 12), 3), (1, 48, 128, (6, 9, 5), 3), (1, 112, 64, (7, 7, 5), 3)):
+                    x = to_cl(R(rng3, N, Cin, *sp)).to(dev)
+                    w = (R(rng3, Cout, Cin, 3, 3, 3) * 0.1).to(dev).contiguous()
+                    b = (R(rng3, Cout) * 0.1).to(dev)
+                    wf, _ = ops.conv3_pack(w, KD)
+                    outs = []
+                    for pipe in (1, 0):
+                        ops.set_option("conv3_b6_pipe", pipe)
+                        try:
+                            ops.set_option("splitk", 1)
+                            y, part, rows = ops.conv3_fwd_stats(x, wf, b, Cout, KD, 1)
+                            y2 = y.clone()
+                            ops.conv3_fwd(x, wf, None, Cout, KD, out=y2, accumulate=True)
+                            ops.set_option("splitk", 3)
+                            y3 = ops.conv3_fwd(x, wf, b, Cout, KD)
+                            outs.append((y.clone(), rows, y2, y3.clone()))
+                        finally:
+                            ops.set_option("splitk")
+                    assert outs[0][1] == outs[1][1]
+                    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2]) and torch.equal(outs[0][3], outs[1][3]), \
+                        f"k_c3q vs k_c3f (slab mode {flat}): outputs differ"
         finally:
-            ops.set_option("conv3_b6_flat")
+            ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe")
         for mtsel in (4, 2):                           # k_c3g: flat tiles of 256 / 128 voxels, direct weight fragments (option; not the default)
             ops.set_option("conv3_b6_flatd", mtsel)
             try:
@@ -630,7 +658,7 @@ def check_conv3_b6(ops, dev):
         # order per accumulator, so the two are BIT-identical; full / partial tiles, several cin chunks, two slabs, statistics, split-K, +=
         ops.set_option("conv3_b6_flat", 0)
         try:
-            w22_cases = ((2, 64, 64, (4, 8, 12), 3), (1, 32, 128, (6, 9, 5), 3), (1, 64, 64, (7, 7, 5), 3), (2, 48, 64, (3, 5, 9), 3))
+            w22_cases = ((2, 64, 64, (4, 8, 12), 3), (1, 32, 128, (6, 9, 5), 3), (1, 64, 64, (7, 7, 5), 3), (2, 48, 64, (3, 5, 9), 3), (1, 112, 64, (4, 4, 8), 3))
             check_conv3(ops, dev, cases=w22_cases)
             rng2 = np.random.default_rng(77)
             for (N, Cin, Cout, sp, KD) in w22_cases:
@@ -639,21 +667,27 @@ def check_conv3_b6(ops, dev):
                 b = (R(rng2, Cout) * 0.1).to(dev)
                 wf, _ = ops.conv3_pack(w, KD)
                 outs = []
-                for w22 in (1, 0):
+                # (w22, pipe): k_c3p (LDS-DMA software pipeline, the default), k_c3h (register-staged weights), k_c3b
+                for w22, pipe in ((1, 1), (1, 0), (0, 0)):
                     ops.set_option("conv3_b6_w22", w22)
+                    ops.set_option("conv3_b6_pipe", pipe)
                     ops.set_option("splitk", 1)            # (fused statistics need the unsplit launch)
                     try:
                         y, part, rows = ops.conv3_fwd_stats(x, wf, b, Cout, KD, 1)
                         y2 = y.clone()
                         ops.conv3_fwd(x, wf, None, Cout, KD, out=y2, accumulate=True)
-                        outs.append((y.clone(), part.clone(), rows, y2))
+                        ops.set_option("splitk", 2)
+                        y3 = ops.conv3_fwd(x, wf, b, Cout, KD)
+                        outs.append((y.clone(), part.clone(), rows, y2, y3.clone()))
                     finally:
-                        ops.set_option("conv3_b6_w22"); ops.set_option("splitk")
-                assert outs[0][2] == outs[1][2] and outs[0][2] > 0
-                assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][3], outs[1][3]), "k_c3h vs k_c3b: outputs differ"
-                nb = outs[0][2] * Cout * 16           # (the fp64 statistics are summed in a different order: equal to rounding, not bitwise)
-                pa, pb = (np.frombuffer(o[1].cpu().numpy().tobytes()[:nb], dtype=np.float64) for o in outs)
-                assert np.allclose(pa, pb, rtol=1e-12, atol=1e-12), "k_c3h vs k_c3b: statistics rows differ"
+                        ops.set_option("conv3_b6_w22"); ops.set_option("conv3_b6_pipe"); ops.set_option("splitk")
+                for o in outs[1:]:
+                    assert outs[0][2] == o[2] and outs[0][2] > 0
+                    assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][3], o[3]) and torch.equal(outs[0][4], o[4]), \
+                        "k_c3p vs k_c3h vs k_c3b: outputs differ"
+                    nb = outs[0][2] * Cout * 16           # (the fp64 statistics are summed in a different order: equal to rounding, not bitwise)
+                    pa, pb = (np.frombuffer(q[1].cpu().numpy().tobytes()[:nb], dtype=np.float64) for q in (outs[0], o))
+                    assert np.allclose(pa, pb, rtol=1e-12, atol=1e-12), "k_c3p vs k_c3h vs k_c3b: statistics rows differ"
         finally:
             ops.set_option("conv3_b6_flat")
         ops.set_option("conv3_b6_cfg2d", 2)         # 2-D 32-channel slabs on the direct-weight 16x16 tiles (product default from 64 K pixels)
@@ -1069,4 +1103,43 @@ def check_augment_acdc(ops, dev, golden_dir):
         assert np.array_equal(got, O._nearest_zoom(O._nearest_rotate(img, angle), (64, 64))), f"angle {angle}"
 
 
-ALL_CHECKS = ("conv3_c1_norm", "norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+def check_conv3_pipe_cold(ops, dev):
+    """The LDS-DMA pipelines (k_c3p / k_c3q) against their register-staged twins (conv3_b6_pipe = 0), BIT-identical, with the caches
+    flushed in front of every launch: the pipelines hand weight slots over with counted vmcnt waits, and a miscounted wait only shows
+    when the weight stream actually misses the caches (first call, the 256-channel level) -- this check found one (k_c3p's comment).
+    On the host simulator the DMA is synchronous: there it is an identity check of the two code paths only."""
+    rng = np.random.default_rng(91)
+    on_gpu = dev.type == "cuda"
+    flush = torch.empty(192 << 20, dtype=torch.float32, device=dev) if on_gpu else None      # 768 MB: past the L2s and the 256 MB MALL
+    shapes = ((2, 64, 64, (4, 8, 12)), (1, 32, 128, (6, 9, 5)), (1, 64, 64, (7, 7, 5)), (1, 16, 64, (5, 5, 5)))
+    if on_gpu:
+        shapes += ((2, 128, 128, (14, 14, 10)), (2, 256, 256, (7, 7, 5)), (2, 64, 64, (28, 28, 20)), (4, 256, 256, (6, 6, 6)))
+    try:
+        for flat in (1, 4, 3, 0):                       # slab widths of the flat kernel; 0: the tiled kernels (k_c3p where 64 x 64 tiles apply)
+            ops.set_option("conv3_b6_flat", flat)
+            for (N, Cin, Cout, sp) in shapes:
+                if not on_gpu and flat in (4, 3) and N * sp[0] * sp[1] * sp[2] > 400:
+                    continue
+                x = R(rng, N, *sp, Cin).to(dev)
+                w = (R(rng, Cout, Cin, 3, 3, 3) * 0.1).to(dev)
+                wf, wd = ops.conv3_pack(w, 3)
+                ops.set_option("conv3_b6_pipe", 0)
+                ref = ops.conv3_fwd(x, wf, None, Cout, 3).clone()
+                refd = ops.conv3_fwd(x, wd, None, Cin, 3).clone() if Cin == Cout else None
+                ops.set_option("conv3_b6_pipe", 1)
+                for rep in range(3 if on_gpu else 1):
+                    if on_gpu:
+                        flush.fill_(float(rep))
+                    y = ops.conv3_fwd(x, wf, None, Cout, 3)
+                    assert torch.equal(y, ref), f"pipeline vs register-staged kernel (slab mode {flat}) {N}x{sp} {Cin}->{Cout} rep {rep}: " \
+                                                f"{int((y != ref).sum())} of {y.numel()} outputs differ"
+                    if refd is not None:
+                        if on_gpu:
+                            flush.fill_(float(rep) + 0.5)
+                        yd = ops.conv3_fwd(x, wd, None, Cin, 3)
+                        assert torch.equal(yd, refd), f"pipeline vs register-staged kernel, dgrad pack (slab mode {flat}) {N}x{sp} rep {rep}"
+    finally:
+        ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe")
+
+
+ALL_CHECKS = ("conv3_pipe_cold", "conv3_c1_norm", "norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")

@@ -33,6 +33,10 @@
 // LDS-only workgroup barrier of the product code (common.h): a plain barrier on the host
 #define BCP_LDS_BARRIER() ::bcpemu::block_sync()
 #define BCP_S_SLEEP(n) ((void)0)      /* a timing-only instruction */
+// LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane to a wave-uniform LDS base + 16 * lane; synchronous on the host (a fiber runs
+// from barrier to barrier, so a slot refilled too early shows up as wrong data in the fibers scheduled later)
+#define BCP_GLDS16(gsrc, lds_wave_base) __builtin_memcpy(reinterpret_cast<char*>(lds_wave_base) + 16 * (threadIdx.x & 63), (gsrc), 16)
+#define BCP_VM_LDS_BARRIER(N) ::bcpemu::block_sync()
 // v_cvt_pk_bf16_f32 (round to nearest even, finite values): software on the host
 static inline unsigned bcpemu_rne_bf16(float x) { unsigned u; __builtin_memcpy(&u, &x, 4); u += 0x7FFFu + ((u >> 16) & 1u); return u >> 16; }
 // ds_read_b64_tr_b16: lane i of a 16-lane group gets element (i & 3) of the 8 bytes addressed by lane 4 j + (i >> 2) as its element j

@@ -35,17 +35,30 @@ a = np.frombuffer(buf, dtype=np.uint64).reshape(64, 64).astype(np.int64)
 print(f"C={Cc}: s_memtime ticks (~ shader clocks) since the workgroup's own start (the counters of different XCDs have different bases)")
 print("        setup  first-barrier | stage durations ... | epilogue | lifetime")
 life = []
+clk = []
 for wg in range(64):
     r = a[wg]
     if r[0] == 0 or r[61] == 0:
         continue
-    stages = [i for i in range(3, 60) if r[i] > 0]
+    stages = [i for i in range(3, 59) if r[i] > 0]
     pts = [r[0], r[1], r[2]] + [r[i] for i in stages] + [r[60], r[61]]
     d = np.diff(np.array(pts))
     life.append((r[61] - r[0], d))
+    if r[62] > r[59] > 0:
+        clk.append((r[61] - r[0]) / ((r[62] - r[59]) * 10.0))      # ticks per ns: s_memtime ticks against the 100 MHz constant clock
     if wg in (0, 1, 7, 8, 31, 63):
         print(f"wg {wg:2d}: {d[0]:6d} {d[1]:6d} | " + " ".join(f"{v:5d}" for v in d[2:-2]) + f" | {d[-2]:6d} {d[-1]:6d} | {r[61] - r[0]:7d}")
+rt = a[(a[:, 59] > 0) & (a[:, 62] > 0)]
+if len(rt):
+    print("constant-clock view of the recorded workgroups: starts spread over %.2f us, first start -> last end %.2f us" % ((rt[:, 59].max() - rt[:, 59].min()) / 100.0, (rt[:, 62].max() - rt[:, 59].min()) / 100.0))
+if clk:
+    print("s_memtime ticks per ns over the workgroup's life (= the clock it ran at, GHz): median %.3f  min %.3f  max %.3f" % (np.median(clk), min(clk), max(clk)))
 if life:
+    order = sorted(range(len(life)), key=lambda i: life[i][0])
+    print('lifetimes (ticks) by recorded workgroup:', ' '.join(str(int(life[i][0])) for i in range(len(life))))
+    for tag, i in (('fastest', order[0]), ('slowest', order[-1])):
+        d = life[i][1]
+        print(f'{tag} workgroup: setup {d[0]} first {d[1]} stages ' + ' '.join(str(int(v)) for v in d[2:-2]) + f' | {d[-2]} epilogue {d[-1]}')
     L = np.array([l for l, _ in life])
     print("workgroup lifetime (ticks): min %d median %d max %d over %d workgroups" % (L.min(), np.median(L), L.max(), len(L)))
     D = np.array([d for _, d in life if len(d) == len(life[0][1])])
