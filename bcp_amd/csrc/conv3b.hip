@@ -44,10 +44,14 @@
 #endif
 #if BCP_TS_DEBUG
 __device__ unsigned long long bcp_ts_buf[64 * 64];
-#define BCP_TS(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && (i) < 64) bcp_ts_buf[(blockIdx.x >> 3) * 64 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long bcp_ts_span[8192 * 2];     // every workgroup of the launch: constant-clock start / end (slots 0 / 61)
+#define BCP_TS(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && (i) < 64) bcp_ts_buf[(blockIdx.x >> 3) * 64 + (i)] = __builtin_amdgcn_s_memtime(); \
+    if (__builtin_constant_p(i) && threadIdx.x == 0 && ((i) == 0 || (i) == 61)) { const unsigned l_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); if (l_ < 8192) bcp_ts_span[l_ * 2 + ((i) == 61)] = wall_clock64(); } } while (0)
 // (slots 59 / 62: the 100 MHz constant clock at the same two points as slots 0 / 61 -> the shader clock the kernel actually ran at)
 #define BCP_TSR(i) do { if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x & 7) == 0 && (blockIdx.x >> 3) < 64 && (i) < 64) bcp_ts_buf[(blockIdx.x >> 3) * 64 + (i)] = wall_clock64(); } while (0)
 extern "C" int bcp_debug_ts(unsigned long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bcp_ts_buf), sizeof(bcp_ts_buf)); }
+extern "C" int bcp_debug_ts_span(unsigned long long* out_host) { return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(bcp_ts_span), sizeof(bcp_ts_span)); }
+extern "C" int bcp_debug_ts_clear() { static unsigned long long z[8192 * 2]; hipMemcpyToSymbol(HIP_SYMBOL(bcp_ts_buf), z, sizeof(bcp_ts_buf)); return (int)hipMemcpyToSymbol(HIP_SYMBOL(bcp_ts_span), z, sizeof(bcp_ts_span)); }
 #else
 #define BCP_TS(i) ((void)0)
 #define BCP_TSR(i) ((void)0)
@@ -621,7 +625,10 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
   static_assert(S >= 8 && S == TP, "k_c3p: 3-D taps (no pad stage), halo prefetch six stages ahead");
   constexpr int XPLANE = TL::HV * XSB, XBUF = 3 * XPLANE;      // bf16 elements per halo plane / buffer
   constexpr int WPLANE = CT * 32, WSLOT = 3 * WPLANE;          // one ring slot: 3 planes x 64 rows x 64 B = 12 KB
-  constexpr int HFS = S - 6, HSS = S - 2;                      // stage of a chunk that fetches / stashes the next chunk's halo
+#ifndef BCP_C3P_HFS
+#define BCP_C3P_HFS 1
+#endif
+  constexpr int HFS = BCP_C3P_HFS >= 0 ? BCP_C3P_HFS : S - 6, HSS = S - 2;     // stage of a chunk that fetches / stashes the next chunk's halo (fetch early: see k_c3d's HPF)
   using HF = HaloFetch<TL>;
 
   stagger_start(cd);
@@ -729,7 +736,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     // uniform addresses of the stage's memory instructions
     int dcc = cc, dsg = sg + 3;
     while (dsg >= S) { dsg -= S; ++dcc; }
-    if (dcc >= c_end) { dcc = c_end - 1; dsg = S - 1; }                            // (past the end: re-read the last stage; never used)
+    const bool dma_on = sg + 3 < S || cc + 1 < c_end;                              // uniform: nothing to fetch behind the workgroup's last stage
     const char* wst = Wb16 + (long long)(dcc * TP + dsg) * 3 * cd.Cout16 * 64;
     char* const wdst = Wr_wave + sl0;
     constexpr int t0 = 2 * NSG, t1 = 2 * NSG + 1 < T ? 2 * NSG + 1 : T - 1;
@@ -743,7 +750,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     for (int k = 0; k < 24; ++k) {
       const int pr = k >> 2, mt = (k >> 1) & 1, nt = k & 1;
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PAR][nt][PJ[pr]], fa[PAR][mt][PI[pr]], acc[mt][nt], 0, 0, 0);
-      if (k < 3) BCP_GLDS16(wst + wq[k], wdst + k * 4096);
+      if (k < 3) { if (dma_on) BCP_GLDS16(wst + wq[k], wdst + k * 4096); }
       else if (k < 15) {
         const int r = k - 3, sp = r >> 2, w = r & 3;
         if (w < 2) fa[PAR ^ 1][w][sp] = *reinterpret_cast<const bf16x8*>(Xc + sp * XPLANE + voff[w]);
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     // next stage reads a slot that has not landed (measured: wrong results exactly where the weight stream misses the caches -- first
     // call on cold caches, the 256-channel level; tools/diag/pipe_diag.py).  Counting only DMAs, the wait also covers the halo
     // loads of this stage (once per chunk; they have had the stage to arrive).
-    BCP_VM_LDS_BARRIER(3);
+    if (dma_on) BCP_VM_LDS_BARRIER(3); else BCP_VM_LDS_BARRIER(0);      // (no DMAs issued in this stage: the previous stage's are the youngest)
     const unsigned t = sl0; sl0 = sl1; sl1 = sl2; sl2 = t;
     BCP_TS(3 + (cc - c_begin) * S + sg);
   };
@@ -775,7 +782,6 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, 1>{});
   }
   BCP_TS(60);
-  BCP_VM_LDS_BARRIER(0);                                       // (the DMAs past the end have landed: nothing writes the LDS behind the epilogue)
 
   double s1[2][4], s2[2][4];
 #pragma unroll
@@ -812,6 +818,8 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
   using HF = HaloFetch<TL>;
 
   stagger_start(cd);
+  BCP_TS(0);
+  BCP_TSR(59);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
   double* Ss = reinterpret_cast<double*>(Xb + 3 * XPLANE);         // [4][CT][2] statistics scratch
@@ -916,11 +924,22 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) { B0[nt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * 64 + nt * 8 + lane); B1[nt][s] = B0[nt][s]; }
   }
+  BCP_TS(1);
   hfetch_item(0);
   bload(c_begin, 0, B0);
   hstash();
   BCP_LDS_BARRIER();
-  constexpr int HPF = TPE >= 6 ? TPE - 4 : 0;        // pair in front of which the next item's halo is fetched
+  BCP_TS(2);
+  // pair in front of which the next item's halo is fetched.  Round 3 (s_memtime stamps, tools/ts_probe.py, 32-channel level): with the
+  // fetch four pairs ahead (TPE - 4) a chunk boundary cost ~9000 ticks against ~1000 per pair -- every workgroup of the launch
+  // fetches at the same time and the loads take longer than four pairs; the registers are live across the peak of the register
+  // pressure either way, so the fetch moves to the front of the chunk
+  // (the instances with the backward-statistics epilogue sit at 248 registers: from pair 7 down the longer live range costs them the
+  //  second workgroup per CU -- they fetch six pairs ahead)
+#ifndef BCP_C3D_HPF
+#define BCP_C3D_HPF 3
+#endif
+  constexpr int HPF = TPE >= 10 ? (BCP_C3D_HPF >= 0 && !BW ? BCP_C3D_HPF : TPE - 6) : (TPE >= 6 ? TPE - 4 : 0);
   int cur_g = want_stats ? t_first / st.tiles_per_group : 0;
 #pragma unroll 1
   for (int it = 0; it < n_items; ++it) {
@@ -1012,14 +1031,18 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
 #undef BCP_B6
 #endif
       }
+      if (!PER) BCP_TS(3 + it * TPE + tp);
     }
     if (it % nch == nch - 1) {                       // the tile is complete: store it (uniform branch; stores only, no loads to wait for)
       const int tl = t_first + (it / nch) * t_step;
       int n, d0, h0, w0;
       tile_origin(cd, tl, TD, TH, TW, n, d0, h0, w0);
       if (!PER) {
+        BCP_TS(60);
         BCP_LDS_BARRIER();
         b6_epilogue<TL, TD, TH, TW, NT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, t_first);      // one statistics row per tile
+        BCP_TS(61);
+        BCP_TSR(62);
         return;
       }
       if (want_stats && tl / st.tiles_per_group != cur_g) {
@@ -1278,7 +1301,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   constexpr int WPLANE = CT * 32, WSLOT = 3 * WPLANE;            // elements
   constexpr int NPIECE = 12 * CT, NDMA = (NPIECE + 255) / 256;   // 16-byte pieces of a stage; DMA instructions per wave and stage
   constexpr int NP = (AVMAX * 4 + 255) / 256;                    // halo float4 per thread (row, 4-channel part)
-  constexpr int HPF = S - 4;
+  constexpr int HPF = BCP_C3P_HFS >= 0 ? BCP_C3P_HFS : S - 4;   // stage that fetches the next chunk's halo (early: see k_c3d's HPF)
   constexpr int NMEM = NDMA + 3 + 3 * NT, NMMA = 6 * NT;
 
   HIP_DYNAMIC_SHARED(float4, smem4)
@@ -1338,7 +1361,6 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   //  stub without a diagnostic -- the library then fails to load with an undefined symbol)
   auto wsrc = [&](int cc, int sg, const char*& src) __attribute__((always_inline)) {
     while (sg >= S) { sg -= S; ++cc; }
-    if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }                        // (past the end: re-read the last stage; never used)
     src = Wb16 + (long long)(cc * TP + sg) * 3 * cd.Cout16 * 64;            // uniform
   };
   // halo: row r of the flat range = voxel m0 - R + r of sample n (zero outside [0, V) and beyond Cin); branch-free loads
@@ -1413,6 +1435,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
     if (sg == HPF) hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (compile-time position; the last chunk re-reads its own halo)
     const char* wst;
     wsrc(cc, sg + 3, wst);
+    const bool dma_on = sg + 3 < S || cc + 1 < c_end;          // uniform: nothing to fetch behind the workgroup's last stage
     const unsigned short* Xc;
     a_addr(NSG, Xc);
     const unsigned short* Wc = Wr + (sl1 >> 1) + woff;
@@ -1425,7 +1448,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
       acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PAR][nt][PJ[pr]], fa[PAR][PI[pr]], acc[nt], 0, 0, 0);
 #pragma unroll
       for (; m < ((k + 1) * NMEM + NMMA - 1) / NMMA; ++m) {
-        if (m < NDMA) BCP_GLDS16(wst + wq[m], Wr_b + sl0 + wdst[m]);
+        if (m < NDMA) { if (dma_on) BCP_GLDS16(wst + wq[m], Wr_b + sl0 + wdst[m]); }
         else if (m < NDMA + 3 * NT) {
           const int r = m - NDMA, sp = r / NT, nt2 = r % NT;
           fb[PAR ^ 1][nt2][sp] = *reinterpret_cast<const bf16x8*>(Wc + sp * WPLANE + nt2 * 16 * 32);
@@ -1438,7 +1461,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
     }
     // the DMA issued a stage ago must have landed before anyone reads its slot at the top of the next stage: at most this stage's NDMA
     // DMAs may still be in flight (see k_c3p: the halo loads of the fetch stage are NOT added to the count)
-    BCP_VM_LDS_BARRIER(NDMA);
+    if (dma_on) BCP_VM_LDS_BARRIER(NDMA); else BCP_VM_LDS_BARRIER(0);      // (no DMAs issued in this stage: the previous stage's are the youngest)
     const unsigned t = sl0; sl0 = sl1; sl1 = sl2; sl2 = t;
     BCP_TS(3 + (cc - c_begin) * S + sg);
   };
@@ -1459,7 +1482,6 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
     }
   }
   BCP_TS(60);
-  BCP_VM_LDS_BARRIER(0);                                       // (the DMAs past the end have landed: nothing writes the LDS behind the epilogue)
 
   // epilogue: lane (li, lg) holds voxel m0 + wave*16 + li, channels lg*4 .. lg*4+3 of each n-tile: 16-byte stores into flat rows
   double s1[NT][4], s2[NT][4];

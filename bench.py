@@ -174,18 +174,26 @@ def op_table(records, steps, step_ms, top=14):
 
 
 def pmc_traffic(kernel_key):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (tools/collect_pmc.sh: FETCH_SIZE and WRITE_SIZE in separate
-    runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams).  bench.py cannot run the profiler itself;
-    null when profiles/ holds no entry for this op."""
-    for fn in ("r02_pmc_ops.json",):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (tools/collect_pmc_ops.sh: FETCH_SIZE and WRITE_SIZE in
+    separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams), next to the op's algorithmic
+    bytes.  bench.py cannot run the profiler itself: the numbers are those of the commit the file's `_meta` names (the newest
+    round's file first); null when profiles/ holds no entry for this op."""
+    for fn in ("r03_pmc_ops.json", "r02_pmc_ops.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:
             continue
         e = d.get(kernel_key)
         if e and "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-            return {"bytes_per_launch": int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024), "fetch_kb_raw": e["FETCH_SIZE"], "write_kb": e["WRITE_SIZE"],
-                    "source": "profiles/" + fn}
+            by = int((2 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024)
+            out = {"bytes_per_launch": by, "fetch_kb_raw": e["FETCH_SIZE"], "write_kb": e["WRITE_SIZE"], "source": "profiles/" + fn}
+            if e.get("algorithmic_mb"):
+                out["algorithmic_bytes_per_launch"] = int(e["algorithmic_mb"] * 1e6)
+                out["traffic_over_algorithmic"] = round(by / (e["algorithmic_mb"] * 1e6), 3)
+            meta = d.get("_meta") or {}
+            out["measured_at_commit"] = meta.get("commit")
+            out["evidence_set"] = meta.get("evidence_set")
+            return out
     return None
 
 

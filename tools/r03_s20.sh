@@ -2,8 +2,8 @@
 # round 3, GPU session 20: k_c3q (LDS-DMA software pipeline of the flat deep-level kernel): parity, probe, alone timings, step A/B
 out=$PWD/gpurun_out/s20; mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_kernels.py -q -x -k "conv3" 2>&1 | tail -5
-(python tools/ts_probe.py tools/_abl/ts.so 128; python tools/ts_probe.py tools/_abl/ts.so 256) 2>&1 | grep -v amdgpu | grep -v "^wg" > $out/ts.txt; cut -c1-600 $out/ts.txt
-python tools/bench_conv.py --levels 128,256 --ops fwd_stats,dgrad,fwd_chain,bwd_chain --json $out/c.json --variants "pipe:;nopipe:conv3_b6_pipe=0" > $out/c.txt 2>&1; cat $out/c.txt
+(python tools/ts_probe.py tools/_abl/ts.so 64; python tools/ts_probe.py tools/_abl/ts.so 128; python tools/ts_probe.py tools/_abl/ts.so 256) 2>&1 | grep -v amdgpu | grep -v "^wg" > $out/ts.txt; cut -c1-600 $out/ts.txt
+python tools/bench_conv.py --levels 64,128,256 --ops fwd_stats,dgrad,fwd_chain,bwd_chain --json $out/c.json --variants "pipe:;nopipe:conv3_b6_pipe=0" > $out/c.txt 2>&1; cat $out/c.txt
 ab() { python bench.py --no-cpu-baseline --no-extra --no-roofline --steps 40 --warmup 5 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['host_ms_per_step_empty_queue'])"; }
 for rep in 1 2; do
   echo "rep $rep la nopipe $(ab --opt conv3_b6_pipe=0)"; echo "rep $rep la pipe $(ab)"

@@ -17,15 +17,37 @@ ops = Ops(_lib.Binding(lib))
 if len(sys.argv) > 3:
     ops.set_option("conv3_b6_flat_sk", int(sys.argv[3]))
 dev = torch.device("cuda:0")
-sp = {128: (14, 14, 10), 256: (7, 7, 5), 64: (28, 28, 20)}[Cc]
+sp = {128: (14, 14, 10), 256: (7, 7, 5), 64: (28, 28, 20), 32: (56, 56, 40)}[Cc]
 x = torch.randn(2, *sp, Cc, device=dev)
 w = torch.randn(Cc, Cc, 3, 3, 3, device=dev) * 0.05
 wf, wd = ops.conv3_pack(w, 3)
 for _ in range(3):
     y = ops.conv3_fwd(x, wd, None, Cc, 3)
 torch.cuda.synchronize()
+ops.b.cdll.bcp_debug_ts_clear()
 y = ops.conv3_fwd(x, wd, None, Cc, 3)
 torch.cuda.synchronize()
+span = (C.c_ulonglong * (8192 * 2))()
+fs = ops.b.cdll.bcp_debug_ts_span
+fs.argtypes = [C.c_void_p]
+assert fs(span) == 0
+import numpy as np
+sp_ = np.frombuffer(span, dtype=np.uint64).reshape(8192, 2).astype(np.int64)
+sp_ = sp_[(sp_[:, 0] > 0) & (sp_[:, 1] > 0)]
+if len(sp_):
+    t0 = sp_[:, 0].min()
+    st, en = (sp_[:, 0] - t0) / 100.0, (sp_[:, 1] - t0) / 100.0      # us
+    print(f"C={Cc}: {len(sp_)} workgroups; launch span first start -> last end {en.max():.2f} us; lifetimes us: min {np.min(en - st):.2f} median {np.median(en - st):.2f} max {np.max(en - st):.2f}")
+    order = np.argsort(st)
+    hist, edges = np.histogram(st, bins=12)
+    print("  starts (us) histogram:", " ".join(f"{edges[i]:.1f}:{hist[i]}" for i in range(len(hist))))
+    hist, edges = np.histogram(en, bins=12)
+    print("  ends   (us) histogram:", " ".join(f"{edges[i]:.1f}:{hist[i]}" for i in range(len(hist))))
+    busy = float(np.sum(en - st))
+    print(f"  sum of lifetimes {busy:.0f} us = {busy / en.max():.0f} workgroups resident on average (512 slots at two per CU)")
+    late = st > 1.0
+    if late.any():
+        print(f"  second-wave workgroups (start > 1 us): {int(late.sum())}, lifetimes median {np.median((en - st)[late]):.2f} us; first-wave median {np.median((en - st)[~late]):.2f} us")
 buf = (C.c_ulonglong * (64 * 64))()
 fn = ops.b.cdll.bcp_debug_ts
 fn.argtypes = [C.c_void_p]
