@@ -1315,9 +1315,23 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   const int li = lane & 15, lg = lane >> 4;
   const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
   const int R = HW + cd.W + 1, AV = BM + 2 * R;                    // AV <= AVMAX (checked by the launcher)
-  const int bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;   // tile of this workgroup
+  // Workgroup -> (tile, channel slab, cin range).  The workgroups of one (slab, cin range) read the SAME weight stream (12 KB x 14 per
+  // chunk); dealt out in launch order they land on all eight XCDs and every L2 pulls every weight of the layer from the fabric --
+  // 94 MB fetched per launch at the 256-channel level for 10.6 MB of weights (rocprofv3 FETCH_SIZE), 34 MB at 128 channels.  With a
+  // multiple of eight weight streams, XCD k (= linear workgroup id % 8) takes streams k * Gw / 8 .. and all their tiles.
+  int bx, by = blockIdx.y, bz = blockIdx.z;
+  {
+    const int Gw = gridDim.y * gridDim.z;
+    if (cd.xcd && (Gw & 7) == 0) {
+      const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), j = L >> 3;
+      const int grp = (L & 7) * (Gw >> 3) + j / (int)gridDim.x;
+      bx = j % (int)gridDim.x; by = grp % (int)gridDim.y; bz = grp / (int)gridDim.y;
+    } else {
+      bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;
+    }
+  }
   const int n = bx / tiles_per_sample, m0 = (bx % tiles_per_sample) * BM;
-  const int cout0 = blockIdx.y * CT;
+  const int cout0 = by * CT;
 
   // this lane's voxel (one m-tile per wave), its halo row and the validity bits of its 27 neighbours
   const int ml = wave * 16 + li, mv = m0 + ml;
@@ -1339,8 +1353,8 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = cd.Cin16 >> 4;
-  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
-  Y += (long long)blockIdx.z * cd.N * V * cd.Cout;
+  const int c_begin = (int)((long long)nchunks * bz / gridDim.z), c_end = (int)((long long)nchunks * (bz + 1) / gridDim.z);
+  Y += (long long)bz * cd.N * V * cd.Cout;
 
   // DMA instruction u of wave w carries pieces (u * 256 + w * 64) % NPIECE + lane (instructions past the stage repeat its first
   // pieces: same bytes to the same place); piece q = (plane q / (4 CT), row (q >> 2) % CT, k quarter POSITION q & 3) at byte 16 q
