@@ -1317,17 +1317,19 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   const int R = HW + cd.W + 1, AV = BM + 2 * R;                    // AV <= AVMAX (checked by the launcher)
   // Workgroup -> (tile, channel slab, cin range).  The workgroups of one (slab, cin range) read the SAME weight stream (12 KB x 14 per
   // chunk); dealt out in launch order they land on all eight XCDs and every L2 pulls every weight of the layer from the fabric --
-  // 94 MB fetched per launch at the 256-channel level for 10.6 MB of weights (rocprofv3 FETCH_SIZE), 34 MB at 128 channels.  With a
-  // multiple of eight weight streams, XCD k (= linear workgroup id % 8) takes streams k * Gw / 8 .. and all their tiles.
+  // 94 MB fetched per launch at the 256-channel level for 10.6 MB of weights (rocprofv3 FETCH_SIZE).  With a multiple of eight weight
+  // streams (>= 16), XCD k (= linear workgroup id % 8) takes streams k * Gw / 8 .. and all their tiles: 21.8 -> 19.4 us alone.
   int bx, by = blockIdx.y, bz = blockIdx.z;
   {
     const int Gw = gridDim.y * gridDim.z;
-    if (cd.xcd && (Gw & 7) == 0) {
+    if (cd.xcd && (Gw & 7) == 0 && Gw >= 16) {
       const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), j = L >> 3;
       const int grp = (L & 7) * (Gw >> 3) + j / (int)gridDim.x;
       bx = j % (int)gridDim.x; by = grp % (int)gridDim.y; bz = grp / (int)gridDim.y;
     } else {
-      bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;
+      // (few weight streams, e.g. 8 at 128 channels: everything the launch reads fits the MALL and the plain launch order is the
+      //  fastest -- alone 27.6 us against 29.9 with the tile order of xcd_tile() and 30.4 with one stream per XCD)
+      bx = blockIdx.x;
     }
   }
   const int n = bx / tiles_per_sample, m0 = (bx % tiles_per_sample) * BM;
