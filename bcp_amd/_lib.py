@@ -196,6 +196,8 @@ class Binding:
         if isinstance(value, (tuple, list)):
             value = ",".join(str(int(v)) for v in value)
         self.call("bcp_set_option", name.encode(), str(value).encode())
+        from . import plan
+        plan.invalidate_all()      # recorded launch plans carry the kernel choices and workspace sizes of the old options
 
     def call(self, name: str, *args):
         fn, is_status = self._fns[name]

@@ -2,6 +2,7 @@
 // one call from the host language instead of one foreign-function call per launch.  Also the stream fork / join the backward pass
 // uses for its weight-gradient side stream, so that the whole pass -- ordering included -- lives in the list.
 // No reference counterpart: the reference's host path is PyTorch's eager dispatch.
+#include <mutex>
 #include <cstring>
 #include <vector>
 
@@ -44,10 +45,10 @@ struct Replay { std::vector<Entry> e; };
 
 // events for bcp_stream_wait_stream: a wait takes the state of the event's LAST record at the time of the call, so a small ring
 // can be re-recorded freely
-constexpr int kEvRing = 64;
-static hipEvent_t g_ev[kEvRing];
-static int g_ev_next = 0;
-static bool g_ev_ready = false;
+constexpr int kEvRing = 64, kMaxDev = 16;
+struct EvRing { hipEvent_t ev[kEvRing]; int next = 0; bool ready = false; };
+static EvRing g_ring[kMaxDev];       // one per device (bcp_stream_wait_stream)
+static std::mutex g_ev_mu;
 
 }  // namespace bcp
 
@@ -84,16 +85,27 @@ extern "C" int bcp_replay_destroy(void* h) {
   return BCP_OK;
 }
 
-// `waiter` does not run past this point before everything enqueued on `signaller` so far has finished
+// `waiter` does not run past this point before everything enqueued on `signaller` so far has finished.
+// One ring of events PER DEVICE (an event records only on streams of the device it was created on), created lazily for the device
+// that is current at the call; ring creation and the index are under a mutex -- the autograd thread replays recorded backward passes
+// while the main thread enqueues the next forward.  (An event may be re-recorded while an earlier wait on it is still pending: the
+// wait captured the earlier record.)
 extern "C" int bcp_stream_wait_stream(void* waiter, void* signaller) {
   if (waiter == signaller) return BCP_OK;
-  if (!bcp::g_ev_ready) {
-    for (int i = 0; i < bcp::kEvRing; ++i)
-      if (hipEventCreateWithFlags(&bcp::g_ev[i], hipEventDisableTiming) != hipSuccess) { bcp::set_error("hipEventCreateWithFlags failed"); return BCP_ELAUNCH; }
-    bcp::g_ev_ready = true;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= bcp::kMaxDev) { bcp::set_error("bcp_stream_wait_stream: no current device"); return BCP_ELAUNCH; }
+  hipEvent_t ev;
+  {
+    std::lock_guard<std::mutex> lock(bcp::g_ev_mu);
+    bcp::EvRing& r = bcp::g_ring[dev];
+    if (!r.ready) {
+      for (int i = 0; i < bcp::kEvRing; ++i)
+        if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) { bcp::set_error("hipEventCreateWithFlags failed"); return BCP_ELAUNCH; }
+      r.ready = true;
+    }
+    ev = r.ev[r.next];
+    r.next = (r.next + 1) % bcp::kEvRing;
   }
-  hipEvent_t ev = bcp::g_ev[bcp::g_ev_next];
-  bcp::g_ev_next = (bcp::g_ev_next + 1) % bcp::kEvRing;
   hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
   if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
   if (e != hipSuccess) { bcp::set_error("bcp_stream_wait_stream: %s", hipGetErrorString(e)); return BCP_ELAUNCH; }

@@ -534,7 +534,10 @@ class HipNet(nn.Module):
         from .. import plan
         self._ensure_flat()
         plans = self._plans_for()
-        key = ("f", tuple(xcl.shape), getattr(self, "_groups", 1), bool(save), bool(getattr(self, "_turnoff_drop", False)), self.ops.stream(xcl))
+        # (every switch that changes the launch list is part of the key: a toggled switch must never replay the other sequence)
+        key = ("f", tuple(xcl.shape), getattr(self, "_groups", 1), bool(save), bool(getattr(self, "_turnoff_drop", False)), self.ops.stream(xcl),
+               bool(getattr(self, "fuse_head", False)), bool(getattr(self, "fuse_c1", False)), bool(self.overlap_wgrad),
+               bool(getattr(self, "_keep_saved", False)))
         pl = plans.get(key)
         if pl is not None and pl.busy:
             # the plan's static activations belong to a forward whose backward has not run yet (the unfused loop calls the student
@@ -563,20 +566,22 @@ class HipNet(nn.Module):
         # the logits leave the plan as a COPY (16 MB at the LA size): callers may hold them across the next replay (logging, the
         # reference's unfused loop), and a replay overwrites the plan's static tensors in place
         if save:
-            pl.busy = True
-            return out.clone(), _PlanSaved(saved, pl)
+            ps = _PlanSaved(saved, pl)
+            pl.busy = ps.token          # cleared by the backward pass -- or when `ps` dies without one (a discarded loss, an exception)
+            return out.clone(), ps
         return out.clone(), None
 
     def _run_backward(self, saved, dout):
         if not isinstance(saved, _PlanSaved):
             return self._backward_impl(saved, dout)
         from .. import plan
-        fwd, saved = saved.plan, saved.saved
+        fwd, tok, saved = saved.plan, saved.token, saved.saved
         try:
             if not self._plan_ok(dout):
                 return self._backward_impl(saved, dout)
             plans = self._plans_for()
-            key = ("b", id(saved), tuple(dout.shape), self.ops.stream(dout), self._grad_bucket_hook is not None, self._opt_bucket_hook is not None)
+            key = ("b", id(saved), tuple(dout.shape), self.ops.stream(dout), self._grad_bucket_hook is not None, self._opt_bucket_hook is not None,
+                   bool(self.overlap_wgrad))
             pl = plans.get(key)
             self._ensure_packed(True)
             if pl is None:
@@ -592,16 +597,26 @@ class HipNet(nn.Module):
                 self.begin_backward()
                 pl.replay(self.ops, (), dout)
         finally:
-            fwd.busy = False
+            if fwd.busy is tok:
+                fwd.busy = False
         return None
 
 
 class _PlanSaved:
     """what NetFn keeps between forward and backward when the forward came from a launch plan"""
-    __slots__ = ("saved", "plan")
+    __slots__ = ("saved", "plan", "token")
 
     def __init__(self, saved, plan):
-        self.saved, self.plan = saved, plan
+        self.saved, self.plan, self.token = saved, plan, object()
+
+    def __del__(self):
+        # a training-mode forward that is never backpropagated (loss discarded, an exception, a logging forward with grad enabled)
+        # must not leave its plan busy for ever: every later pass of the net would silently take the eager path
+        try:
+            if self.plan.busy is self.token:
+                self.plan.busy = False
+        except Exception:
+            pass
 
 
 class NetFn(torch.autograd.Function):

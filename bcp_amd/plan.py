@@ -188,12 +188,54 @@ def recording(ops, plan):
     b._rec = plan
     ops._rec_plan = plan
     torch.empty, torch.empty_like = empty, empty_like
+    ok = False
     try:
         yield plan
+        ok = True
     finally:
         torch.empty, torch.empty_like = real_empty, real_empty_like
         ops._rec_plan = None
         b._rec = prev
+    if ok:
+        _assert_no_dangling_pointers(plan)
+
+
+def _assert_no_dangling_pointers(plan):
+    """Every device pointer a recorded launch carries must still be allocated when the recording ends.  The plan keeps what the pass
+    allocated through torch.empty / torch.empty_like alive; a tensor made any other way inside a recorded pass (torch.zeros, clone,
+    .contiguous(), .to()) would be freed after the pass and the replay -- or the HIP graph -- would silently read or write memory the
+    caching allocator has handed to someone else.  Checked against the allocator's own block table (CUDA tensors only)."""
+    import ctypes as C
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        return
+    ptrs = []
+    for fn, args, name in plan.entries:
+        at = getattr(fn, "argtypes", None)
+        if name is None or not at:
+            continue
+        for a, t in zip(args, at):
+            if t is C.c_void_p and isinstance(a, int) and a:
+                ptrs.append((a, name))
+    if not ptrs:
+        return
+    free = []                                   # [lo, hi) of every block the allocator holds but has not handed out
+    for seg in torch.cuda.memory_snapshot():
+        addr = seg["address"]
+        for blk in seg["blocks"]:
+            if blk["state"] != "active_allocated":
+                free.append((addr, addr + blk["size"]))
+            addr += blk["size"]
+    if not free:
+        return
+    free.sort()
+    import bisect
+    los = [f[0] for f in free]
+    for a, name in ptrs:
+        i = bisect.bisect_right(los, a) - 1
+        if i >= 0 and free[i][0] <= a < free[i][1]:
+            raise RuntimeError(f"launch plan: {name} was recorded with a device pointer ({a:#x}) into memory that was freed before the "
+                               "recording ended -- a tensor allocated inside the recorded pass by something other than torch.empty / "
+                               "torch.empty_like (the plan cannot keep it alive)")
 
 
 @contextlib.contextmanager

@@ -118,6 +118,7 @@ def _worker_acdc(rank, world, port, out_dir, bucket_mb):
     dp.shutdown()
 
 
+@pytest.mark.extended
 def test_dp2_unet_buckets_equal_single_allreduce(tmp_path):
     """2-D U-Net (7.26 MB of gradients): 1 MB buckets started inside the backward pass == one all-reduce after it, bit for bit,
     and both ranks end the step with the same student and teacher"""
@@ -168,6 +169,7 @@ def _worker_pancreas(rank, world, port, out_dir):
 
 
 @pytest.mark.slow
+@pytest.mark.extended
 def test_dp4_pancreas_adam_equals_four_averaged_microbatches(tmp_path):
     """BASELINE.json configs[4]'s partitioning: FOUR ranks, each with its own four pancreas streams and box, the
     InstanceNorm V-Net and Adam -- after one step every rank holds the same student / teacher, equal to one Adam step on the average

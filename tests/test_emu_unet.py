@@ -23,10 +23,12 @@ def test_unet_golden_tiny(emu_ops, golden_dir):
     NC.check_unet_golden_tiny(emu_ops, CPU, golden_dir)
 
 
+@pytest.mark.extended
 def test_unet_smooth_grads(emu_ops):
     NC.check_unet_smooth(emu_ops, CPU)
 
 
+@pytest.mark.extended
 def test_acdc_self_train_trajectory(emu_ops, golden_dir):
     NC.check_acdc_step(emu_ops, CPU, golden_dir)
 
@@ -35,6 +37,7 @@ def test_unet_eval_mode(emu_ops):
     NC.check_unet_eval(emu_ops, CPU)
 
 
+@pytest.mark.extended
 def test_val_2d_single_volume(emu_ops):
     NC.check_val_2d(emu_ops, CPU)
 
@@ -73,5 +76,6 @@ def test_acdc_five_step_trajectory(emu_ops, golden_dir):
     NC.check_acdc_traj5(emu_ops, CPU, golden_dir)
 
 
+@pytest.mark.extended
 def test_unet_standard_regime_gradients_on_hip_pattern(emu_ops):
     NC.check_unet_pattern_grads(emu_ops, CPU)

@@ -13,10 +13,12 @@ def test_vnet_la_golden_tiny(emu_ops, golden_dir):
     NC.check_vnet_golden_tiny(emu_ops, CPU, golden_dir)
 
 
+@pytest.mark.extended
 def test_vnet_la_smooth_grads(emu_ops):
     NC.check_vnet_smooth(emu_ops, CPU, shape=(32, 32, 16), N=2)
 
 
+@pytest.mark.extended
 def test_vnet_pancreas_smooth(emu_ops):
     NC.check_vnet_smooth(emu_ops, CPU, shape=(32, 32, 32), variant="pancreas")
 
@@ -31,6 +33,7 @@ def test_grouped_forward_equals_separate_calls(emu_ops):
     NC.check_grouped_equals_separate(emu_ops, CPU)
 
 
+@pytest.mark.extended
 def test_sliding_window_validation(emu_ops, golden_dir):
     NC.check_sliding_window(emu_ops, CPU, golden_dir)
 
@@ -40,6 +43,7 @@ def test_sliding_window_validation_pancreas(emu_ops, golden_dir):
     NC.check_sliding_window_pancreas(emu_ops, CPU, golden_dir)
 
 
+@pytest.mark.extended
 def test_pre_train_steps(emu_ops):
     NC.check_pre_train_steps(emu_ops, CPU)
 
@@ -49,6 +53,7 @@ def test_la_step_reference_default_batch(emu_ops):
     NC.check_la_step_batch8(emu_ops, CPU)
 
 
+@pytest.mark.extended
 def test_pancreas_self_train_step(emu_ops):
     NC.check_pancreas_step(emu_ops, CPU, modes=(True,))   # (grouped == four separate calls is a GPU test: tests/test_gpu_scripts.py)
 
@@ -71,24 +76,29 @@ def test_la_five_step_trajectory(emu_ops, golden_dir):
     NC.check_la_traj5(emu_ops, CPU, golden_dir)
 
 
+@pytest.mark.extended
 def test_vnet_la_standard_regime_gradients_on_hip_pattern(emu_ops):
     NC.check_vnet_pattern_grads(emu_ops, CPU, "la", (32, 32, 16))
 
 
+@pytest.mark.extended
 def test_vnet_pancreas_standard_regime_gradients_on_hip_pattern(emu_ops):
     NC.check_vnet_pattern_grads(emu_ops, CPU, "pancreas", (32, 32, 32))
 
 
+@pytest.mark.extended
 def test_la_loop_body_as_the_reference_writes_it(emu_ops, golden_dir):
     NC.check_la_unfused_loop(emu_ops, CPU, golden_dir, steps=2)
 
 
+@pytest.mark.extended
 def test_recorded_launch_plans_equal_eager_path(emu_ops):
     from bcp_amd.utils import BCP_utils as BU
     BU.set_test_ops(emu_ops)
     NC.check_launch_plans(emu_ops, CPU, steps=2, cases=(("la", False),))      # unfused: plan + busy-plan fallback (all four workloads: the GPU suite)
 
 
+@pytest.mark.extended
 def test_head_fused_with_last_norm_equals_separate_apply(emu_ops):
     """VNet.fuse_head: block_nine's norm + ReLU + Dropout3d applied inside the 1x1x1 head (its activation never stored)"""
     NC.check_fused_head(emu_ops, CPU, steps=1)
@@ -99,6 +109,7 @@ def test_vnet_second_output_is_pooled_x5(emu_ops):
     NC.check_vnet_features(emu_ops, CPU)
 
 
+@pytest.mark.extended
 def test_overlapped_optimiser_step_equals_plain_step(emu_ops):
     from bcp_amd.utils import BCP_utils as BU
     BU.set_test_ops(emu_ops)

@@ -93,6 +93,15 @@ def main():
                 return ops.norm_bwd_small(x, ops.conv3_fwd(dy, wd, None, C, 3), 1, N, st[0], H.ACT_RELU, dg, db, True)
             da, part, nb = ops.conv3_dgrad_bwdstats(dy, wd, C, 3, x, st[0], H.ACT_RELU, N)
             return ops.norm_bwd(x, da, N, st[0], H.ACT_RELU, dg, db, True, partial=part, nb=nb)
+        if C == 16 and ("c1_norm_fwd" in want or "c1_norm_bwd" in want):
+            # the first layer (Cin = 1 -> 16) fused with its norm, at the level's spatial size (round 3)
+            x1 = torch.randn(N, *sp, 1, device=dev)
+            w1 = torch.randn(16, 1, 3, 3, 3, device=dev) * 0.1
+            a1, st1 = ops.conv3_c1_norm_fwd(x1, w1, b, 3, N, g1, b1, rm, rv, H.ACT_RELU)
+            if "c1_norm_fwd" in want:
+                fns["c1_norm_fwd"] = lambda: ops.conv3_c1_norm_fwd(x1, w1, b, 3, N, g1, b1, rm, rv, H.ACT_RELU)
+            if "c1_norm_bwd" in want:
+                fns["c1_norm_bwd"] = lambda: ops.conv3_c1_norm_bwd(x1, w1, b, 3, N, st1, dy, H.ACT_RELU, dg, db, True)
         if "fwd_chain" in want:
             fns["fwd_chain"] = fwd_chain
         if "bwd_chain" in want:
