@@ -1048,6 +1048,47 @@ def check_unet_pattern_grads(ops, dev, hw=(64, 64), N=2, seed=12, bound=1e-4):
 
 
 # ------------------------------------------------------------------------------------------ launch plans
+def check_plan_hygiene(ops, dev):
+    """(1) a training-mode forward whose result is dropped WITHOUT a backward must release its launch plan (it used to stay
+    busy for ever and every later pass of the net silently took the eager path); (2) Binding.set_option -- not only Ops.set_option --
+    invalidates recorded plans; (3) the plan key carries the switches that change the launch list"""
+    from bcp_amd import plan
+    plan.ENABLED = True
+    try:
+        P = O.init_params(O.unet_param_shapes(), seed=51, random_affine=True)
+        model = make_unet(P, dev, ops)
+        model.train()
+        x = O.synth_acdc_batch(4, shape=(32, 32), seed=3)[0].to(dev)
+        out = model(x)                                # records the forward plan; saved activations belong to `out`'s graph
+        plans = model._plans_for()
+        fwd = [pl for k, pl in plans.items() if k[0] == "f"]
+        assert len(fwd) == 1 and fwd[0].busy, "a training-mode forward holds its plan until the backward pass"
+        del out
+        import gc
+        gc.collect()
+        assert not fwd[0].busy, "the plan must be released when the saved activations die without a backward"
+        n0 = fwd[0].n_calls
+        out = model(x)                                # replays (not the eager path): no new plan, same launch count
+        assert len([k for k in model._plans_for() if k[0] == "f"]) == 1 and fwd[0].n_calls == n0
+        out[0].sum().backward() if isinstance(out, (tuple, list)) else out.sum().backward()
+        assert not fwd[0].busy
+        e0 = plan.epoch()
+        ops.b.set_option("splitk", 1)                 # the Binding-level call (bypasses Ops.set_option)
+        ops.b.set_option("splitk")
+        assert plan.epoch() > e0, "Binding.set_option must invalidate recorded plans"
+        model(x)
+        keys = [k for k in model._plans_for() if k[0] == "f"]
+        model.fuse_c1 = not bool(getattr(model, "fuse_c1", False))
+        try:
+            model(x)
+            keys2 = [k for k in model._plans_for() if k[0] == "f"]
+            assert len(keys2) == len(keys) + 1, "a toggled launch-list switch must record its own plan, not replay the other sequence"
+        finally:
+            model.fuse_c1 = not model.fuse_c1
+    finally:
+        plan.ENABLED = True
+
+
 def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=False):
     """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net
     (grouped and as the reference's four separate calls -- the second student call must not reuse the busy plan), the pancreas

@@ -79,3 +79,7 @@ def test_acdc_five_step_trajectory(emu_ops, golden_dir):
 @pytest.mark.extended
 def test_unet_standard_regime_gradients_on_hip_pattern(emu_ops):
     NC.check_unet_pattern_grads(emu_ops, CPU)
+
+
+def test_launch_plan_hygiene(emu_ops):
+    NC.check_plan_hygiene(emu_ops, torch.device("cpu"))

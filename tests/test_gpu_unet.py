@@ -124,3 +124,9 @@ def test_acdc_five_step_trajectory_full_size(ops, golden_dir):
             print("acdc_traj5f step %d: |hip - ref32| %.2e  |hip - ref64| %.2e  (reference 32 vs 64: %.2e)  pseudo-label sum diff %.0f (reference: %.0f)" % r)
     for it, d32, d64, dr, pl, plr in rep:
         assert d32 <= 1e-4 and d64 <= 1e-4, (it, d32, d64)
+
+
+def test_launch_plan_hygiene(ops):
+    """a discarded training forward releases its plan, Binding.set_option invalidates plans, launch-list switches are plan keys --
+    with the dangling-pointer check of plan.recording() active on the device allocator"""
+    NC.check_plan_hygiene(ops, DEV)
