@@ -857,7 +857,7 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
   if (!PER) {
     t_first = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;
     t_step = 0; my_tiles = 1;
-  } else if (cd.xcd >= 2 && (gridDim.x & 7) == 0) {
+  } else if ((cd.xcd & 2) && (gridDim.x & 7) == 0) {
     // (measurement switch only: with every XCD walking its own eighth the eight tile streams start 16 MB apart and march in lockstep --
     //  fabric fetch halves (337 -> 176 MB at 2x112x112x80x16) but the kernel runs 242 instead of 186 us alone, 310 vs 171 in the step:
     //  the round-robin deal below keeps all workgroups inside one moving window of the volume)
@@ -1316,20 +1316,22 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
   const int R = HW + cd.W + 1, AV = BM + 2 * R;                    // AV <= AVMAX (checked by the launcher)
   // Workgroup -> (tile, channel slab, cin range).  The workgroups of one (slab, cin range) read the SAME weight stream (12 KB x 14 per
-  // chunk); dealt out in launch order they land on all eight XCDs and every L2 pulls every weight of the layer from the fabric --
-  // 94 MB fetched per launch at the 256-channel level for 10.6 MB of weights (rocprofv3 FETCH_SIZE).  With a multiple of eight weight
-  // streams (>= 16), XCD k (= linear workgroup id % 8) takes streams k * Gw / 8 .. and all their tiles: 21.8 -> 19.4 us alone.
+  // chunk); dealt out in launch order they land on all eight XCDs and every L2 pulls every weight of the layer from the fabric.  With
+  // a multiple of eight weight streams, XCD k (= linear workgroup id % 8) takes streams k * Gw / 8 .. and all their tiles.  Fabric
+  // fetch per launch (rocprofv3 FETCH_SIZE) and time alone:  256 channels 94 -> 15.8 MB, 21.8 -> 19.4 us;  128 channels (8 streams:
+  // one per XCD) 36.3 -> 6.8 MB -- the algorithmic 4 MB of activations + 2.65 MB of weights -- but 28.4 -> 30.3 us alone (all 248
+  // waves of an XCD ask its L2 for the same lines at the same time); in the step the smaller footprint wins it back (LA 6.05 -> 6.02
+  // ms, three interleaved pairs): the concurrent stream's kernels keep more of the L2s and the fabric.  (conv3_xcd bit 3: plain launch
+  // order, bit 4: the tile order of xcd_tile() -- 29.2 us, 24.3 MB -- for measurements.)
   int bx, by = blockIdx.y, bz = blockIdx.z;
   {
     const int Gw = gridDim.y * gridDim.z;
-    if (cd.xcd && (Gw & 7) == 0 && Gw >= 16) {
+    if (cd.xcd && (Gw & 7) == 0 && !(cd.xcd & (8 | 16))) {
       const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), j = L >> 3;
       const int grp = (L & 7) * (Gw >> 3) + j / (int)gridDim.x;
       bx = j % (int)gridDim.x; by = grp % (int)gridDim.y; bz = grp / (int)gridDim.y;
     } else {
-      // (few weight streams, e.g. 8 at 128 channels: everything the launch reads fits the MALL and the plain launch order is the
-      //  fastest -- alone 27.6 us against 29.9 with the tile order of xcd_tile() and 30.4 with one stream per XCD)
-      bx = blockIdx.x;
+      bx = (cd.xcd & 16) ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;
     }
   }
   const int n = bx / tiles_per_sample, m0 = (bx % tiles_per_sample) * BM;
@@ -1795,7 +1797,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     const int slots = 512 / (gy * sk) > 0 ? 512 / (gy * sk) : 1;
     const int per = PER ? cdiv(gx, slots) : 1;
     int P = cdiv(gx, per);
-    if (PER && cd.xcd >= 2 && P >= 8) P = (P + 7) & ~7;                                           // the XCD-aware walk needs whole rounds of the 8 XCDs
+    if (PER && (cd.xcd & 2) && P >= 8) P = (P + 7) & ~7;                                           // the XCD-aware walk needs whole rounds of the 8 XCDs
     if (PER && options().conv3_p > 0 && options().conv3_p < P) P = options().conv3_p;      // tests: few workgroups, many tiles each
     StatsArg sd{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
     if (sk == 1 && G > 0 && gx % G == 0) { sd.rows = PER ? P : gx / G; sd.tiles_per_group = gx / G; sd.partial = stat_partial; }

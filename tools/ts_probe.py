@@ -21,11 +21,20 @@ sp = {128: (14, 14, 10), 256: (7, 7, 5), 64: (28, 28, 20), 32: (56, 56, 40)}[Cc]
 x = torch.randn(2, *sp, Cc, device=dev)
 w = torch.randn(Cc, Cc, 3, 3, 3, device=dev) * 0.05
 wf, wd = ops.conv3_pack(w, 3)
+BW = os.environ.get("TS_BW") == "1"          # probe the dgrad + backward-statistics instance instead of the plain forward
+if BW:
+    from bcp_amd import hip_ops as H
+    g1, b1, rm, rv = torch.ones(Cc, device=dev), torch.zeros(Cc, device=dev), torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+    yprev = torch.randn(2, *sp, Cc, device=dev)
+    stp = ops.norm_fwd(yprev, 2, g1, b1, rm, rv, H.ACT_RELU)[1]
+    run = lambda: ops.conv3_dgrad_bwdstats(x, wd, Cc, 3, yprev, stp, H.ACT_RELU, 2)
+else:
+    run = lambda: ops.conv3_fwd(x, wd, None, Cc, 3)
 for _ in range(3):
-    y = ops.conv3_fwd(x, wd, None, Cc, 3)
+    y = run()
 torch.cuda.synchronize()
 ops.b.cdll.bcp_debug_ts_clear()
-y = ops.conv3_fwd(x, wd, None, Cc, 3)
+y = run()
 torch.cuda.synchronize()
 span = (C.c_ulonglong * (8192 * 2))()
 fs = ops.b.cdll.bcp_debug_ts_span
