@@ -65,7 +65,7 @@ struct Options {
   int fuse_bwd_stats = 1;   // dgrad epilogue of the bf16-pipe kernels accumulates the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): no k_col_partial<1> pass over (y, da) for conv -> conv edges
   int conv3_stagger = 0;    // bf16-pipe kernels: workgroups whose linear id has bit conv3_stagger_bit set start ~0.9 us x this late (s_sleep): de-phases the two workgroups of a CU so that one's halo / weight / store phases fall into the other's MFMA phase (measured additive otherwise: 47.8 us MFMA + LDS loop + 20.8 us everything else = 71.9 us at the 32-channel level)
   int conv3_stagger_bit = 8;
-  int conv3_xcd = 1;        // bf16-pipe kernels: XCD-aware workgroup -> tile order (each XCD walks a contiguous eighth of the tile list: halo overlap hits its own L2; the flat deep-level kernel deals WEIGHT STREAMS to XCDs).  Bits for measurements: 2 = also the persistent 16-channel kernel (slower), 8 / 16 = k_c3q in plain launch order / tile order
+  int conv3_xcd = 1;        // bf16-pipe kernels: XCD-aware workgroup -> tile order (each XCD walks a contiguous eighth of the tile list: halo overlap hits its own L2; the flat deep-level kernel deals WEIGHT STREAMS to XCDs).  Bits for measurements: 2 = also the persistent 16-channel kernel (slower), 8 = k_c3q deals weight streams to XCDs also when there are only 8 of them (128-channel level: minimal fabric traffic, slower alone, step unchanged), 16 = k_c3q in tile order
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };
 Options& options();

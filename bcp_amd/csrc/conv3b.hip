@@ -1317,16 +1317,18 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   const int R = HW + cd.W + 1, AV = BM + 2 * R;                    // AV <= AVMAX (checked by the launcher)
   // Workgroup -> (tile, channel slab, cin range).  The workgroups of one (slab, cin range) read the SAME weight stream (12 KB x 14 per
   // chunk); dealt out in launch order they land on all eight XCDs and every L2 pulls every weight of the layer from the fabric.  With
-  // a multiple of eight weight streams, XCD k (= linear workgroup id % 8) takes streams k * Gw / 8 .. and all their tiles.  Fabric
-  // fetch per launch (rocprofv3 FETCH_SIZE) and time alone:  256 channels 94 -> 15.8 MB, 21.8 -> 19.4 us;  128 channels (8 streams:
-  // one per XCD) 36.3 -> 6.8 MB -- the algorithmic 4 MB of activations + 2.65 MB of weights -- but 28.4 -> 30.3 us alone (all 248
-  // waves of an XCD ask its L2 for the same lines at the same time); in the step the smaller footprint wins it back (LA 6.05 -> 6.02
-  // ms, three interleaved pairs): the concurrent stream's kernels keep more of the L2s and the fabric.  (conv3_xcd bit 3: plain launch
-  // order, bit 4: the tile order of xcd_tile() -- 29.2 us, 24.3 MB -- for measurements.)
+  // a multiple of eight weight streams, XCD k (= linear workgroup id % 8) can take streams k * Gw / 8 .. and all their tiles.  Fabric
+  // fetch per launch (rocprofv3 FETCH_SIZE) and time alone:
+  //   256 channels (64 streams): 94 -> 15.8 MB, 21.8 -> 19.4 us                                          => on
+  //   128 channels (8 streams, one per XCD): 36.3 -> 6.8 MB (= 4 MB of activations + 2.65 MB of weights, the algorithmic minimum)
+  //     but 28.4 -> 30.3 us alone (all 248 waves of an XCD ask its L2 for the same lines at the same time), and the op's in-step
+  //     launch time 33 -> 37 us; the STEP does not move (LA 6.05 vs 6.02 ms over three interleaved pairs: what this kernel loses the
+  //     other stream's kernels gain from the emptier fabric)                                              => off (conv3_xcd bit 3 turns it on)
+  //   (bit 4: the tile order of xcd_tile() -- 29.2 us, 24.3 MB -- for measurements)
   int bx, by = blockIdx.y, bz = blockIdx.z;
   {
     const int Gw = gridDim.y * gridDim.z;
-    if (cd.xcd && (Gw & 7) == 0 && !(cd.xcd & (8 | 16))) {
+    if (cd.xcd && (Gw & 7) == 0 && (Gw >= 16 || (cd.xcd & 8))) {
       const int L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), j = L >> 3;
       const int grp = (L & 7) * (Gw >> 3) + j / (int)gridDim.x;
       bx = j % (int)gridDim.x; by = grp % (int)gridDim.y; bz = grp / (int)gridDim.y;
