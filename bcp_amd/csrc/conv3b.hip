@@ -17,6 +17,15 @@
 // [piece][pair][cout][32 k] copied from the pre-split bf16 pack the weight packer writes behind the fp32 pack.  Two workgroups per
 // CU: one computes while the other refills (the halo split is ~22 VALU per float4: v_cvt_pk_bf16_f32).
 //
+// Kernel families in this file (which one serves a shape: b6_fwd at the end; DESIGN.md sections 3a / 3b):
+//   k_c3d  weight fragments straight from global memory, no barrier in the tap loop, fragment stream; 32-channel slabs on 256-voxel
+//          tiles, and -- persistent, next tile's halo under the current tile's MFMAs -- the 16 -> 16 layers (3-D and 2-D)
+//   k_c3p  64-voxel x 64-channel tiles as an LDS-DMA software pipeline (round 3): weight ring of three slots filled by
+//          global_load_lds three stages ahead, next stage's fragments into a second register set between the MFMAs
+//   k_c3q  the same pipeline on FLAT 64-voxel tiles for the deep levels (14x14x10, 7x7x5, 12^3, 6^3 ...), split-K
+//   k_c3b / k_c3h / k_c3f  the register-staged predecessors (2-D instances of k_c3b are still the U-Net's 64-channel-slab kernel; the
+//          others are kept behind conv3_b6_pipe = 0 and as the bit-identity twins of the pipelines in the tests)
+//   k_c3g  flat tiles with direct weight fragments (measured, not a default)
 // Reference ops: nn.Conv3d(k=3,pad=1) networks/VNet.py:17, nn.Conv2d(k=3,pad=1) networks/unet.py:19-25 and their backward.
 #include "conv3_defs.h"
 #include "../../include/bcp_hip.h"
