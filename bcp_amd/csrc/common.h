@@ -41,6 +41,7 @@ struct Options {
   int conv3_b6_cin16max = 32;   // 2-D layers with 16 output channels on the bf16 pipe: widest input (measurement switch)
   int conv3_b6_pipe = 1;        // ... and of those the 3-D ones as the LDS-DMA software pipeline k_c3p (0: k_c3h, register-staged weights)
   int conv3_b6_w22 = 1;         // 64-voxel x 64-channel staged tiles: waves arranged 2 x 2 (k_c3h) instead of 1 x 4 (k_c3b)
+  int conv3_b6_cfg2d64 = 0;     // 2-D 64-channel slabs: 0 = 8x16 tiles on k_c3b (1 x 4 waves), 1 = 8x8 tiles on the 2 x 2 arrangement: k_c3p (five stages per chunk) or, with conv3_b6_pipe = 0, k_c3h -- ACDC step 4.17 / 4.02 ms against 4.04: off
   int conv3_b6_cfg2d = 1;       // 2-D 32-channel slabs: 1 = direct-weight 16x16 tiles from 64 K pixels, 2 = always, 0 = staged 8x16 tiles
   int conv3_b6_flat_sk = 0; // flat bf16-pipe tiles: split-K factor 1..8 (0: the launcher's rule)
   int res_pcu = 0;          // resident conv: persistent workgroups per CU 1..4

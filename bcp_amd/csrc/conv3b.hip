@@ -630,8 +630,10 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
   using TL = Tile<KD, TD, TH, TW>;
   static_assert(TL::M == 64, "k_c3p: 64-voxel tiles (four m-tiles: two per wave)");
   constexpr int T = TL::T, TP = (T + 1) / 2, CT = 64;
-  constexpr int S = (TP + 1) & ~1;                             // stages per cin chunk, even: the fragment register sets alternate statically
-  static_assert(S >= 8 && S == TP, "k_c3p: 3-D taps (no pad stage), halo prefetch six stages ahead");
+  constexpr int S = TP;                                        // stages per cin chunk: 14 (3-D) / 5 (2-D); no pad stage -- with an odd count the
+                                                               // fragment register sets swap roles from chunk to chunk (PAR below), which the
+                                                               // statically unrolled chunk PAIR absorbs
+  static_assert(S >= 5 && S <= 14, "k_c3p: 5 (3x3) or 14 (3x3x3) tap pairs per chunk");
   constexpr int XPLANE = TL::HV * XSB, XBUF = 3 * XPLANE;      // bf16 elements per halo plane / buffer
   constexpr int WPLANE = CT * 32, WSLOT = 3 * WPLANE;          // one ring slot: 3 planes x 64 rows x 64 B = 12 KB
 #ifndef BCP_C3P_HFS
@@ -738,7 +740,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
   // (684 ticks per stage for a workgroup alone on its CU against 384 cycles of MFMA); hipcc left alone sinks the reads next to THEIR
   // MFMAs -- pulled up across the barrier -- and the pipeline is gone: the order is pinned with sched_barrier.
   auto stage = [&](int cc, auto hb_tag, auto sg_tag) __attribute__((always_inline)) {
-    constexpr int HB = decltype(hb_tag)::value, sg = decltype(sg_tag)::value, PAR = sg & 1;
+    constexpr int HB = decltype(hb_tag)::value, sg = decltype(sg_tag)::value, PAR = (HB * S + sg) & 1;
     constexpr int NHB = sg + 1 < S ? HB : HB ^ 1, NSG = sg + 1 < S ? sg + 1 : 0;     // next stage (behind the last chunk: stale planes, never used)
     if (sg == HFS) hfetch(cc + 1 < c_end ? cc + 1 : cc, hpre);      // (compile-time position; the last chunk re-reads its own halo)
     if (sg == HSS) hstash(HB ^ 1, hpre);
@@ -780,8 +782,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     BCP_TS(3 + (cc - c_begin) * S + sg);
   };
   auto chunk = [&](int cc, auto hb_tag) __attribute__((always_inline)) {
-    static_assert(S == 14, "k_c3p: the stage list below is written out for 14 stages");
-#define BCP_ST(I) stage(cc, hb_tag, std::integral_constant<int, I>{});
+#define BCP_ST(I) if constexpr (I < S) stage(cc, hb_tag, std::integral_constant<int, I>{});
     BCP_ST(0) BCP_ST(1) BCP_ST(2) BCP_ST(3) BCP_ST(4) BCP_ST(5) BCP_ST(6) BCP_ST(7) BCP_ST(8) BCP_ST(9) BCP_ST(10) BCP_ST(11) BCP_ST(12) BCP_ST(13)
 #undef BCP_ST
   };
@@ -1786,9 +1787,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
       size_t lds_k = lds;
       if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
         if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;
-        if constexpr (KD == 3) {
-          if (options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0) { kfn = k_c3p<KD, TD, TH, TW>; lds_k = kC3pLds<TL>; }
-        }
+        if (options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0) { kfn = k_c3p<KD, TD, TH, TW>; lds_k = kC3pLds<TL>; }
       }
       if (lds_k > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
       hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds_k, s, X, Wp, (const float*)nullptr, Y, cd, 0, none);
@@ -1844,14 +1843,12 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
       if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
         if (bw) kfn = k_c3h<KD, TD, TH, TW, true>;
       }
-      if constexpr (KD == 3) {
-        if (options().conv3_b6_pipe != 0) {   // the same tile as an LDS-DMA software pipeline (its own LDS layout)
-          kfn = k_c3p<KD, TD, TH, TW>;
-          if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
-            if (bw) kfn = k_c3p<KD, TD, TH, TW, true>;
-          }
-          lds_k = kC3pLds<TL>;
+      if (options().conv3_b6_pipe != 0) {   // the same tile as an LDS-DMA software pipeline (its own LDS layout)
+        kfn = k_c3p<KD, TD, TH, TW>;
+        if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
+          if (bw) kfn = k_c3p<KD, TD, TH, TW, true>;
         }
+        lds_k = kC3pLds<TL>;
       }
       if (lds_k > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
     }
@@ -2041,7 +2038,8 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
       }
     } else if (cd.Cout16 % 64 == 0 && on) {
       // (flat 64-pixel tiles, k_c3f<1,..>, lose here: ACDC step 4.28 / 4.44 vs 4.14 ms for the levels up to 16 K / 64 K pixels)
-      rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+      if (o.conv3_b6_cfg2d64 == 1) rows = b6_launch<1, 1, 8, 8, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);   // 64-pixel tiles: the 2 x 2 wave arrangement (k_c3h / k_c3p)
+      else rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
       *handled = true;
     } else if (cd.Cout16 % 32 == 0 && on) {
       // 32-channel slabs: from 64 K pixels on 16x16 tiles with direct weight fragments (k_c3d, as the 3-D 32-channel level) -- the

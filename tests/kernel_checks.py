@@ -690,6 +690,38 @@ def check_conv3_b6(ops, dev):
                     assert np.allclose(pa, pb, rtol=1e-12, atol=1e-12), "k_c3p vs k_c3h vs k_c3b: statistics rows differ"
         finally:
             ops.set_option("conv3_b6_flat")
+        # the same three kernels on 2-D 8x8 tiles (conv3_b6_cfg2d64 = 1): k_c3p with FIVE stages per chunk -- the fragment register sets swap
+        # roles from chunk to chunk -- against k_c3h and k_c3b, bit-identical; one to five cin chunks, ragged images, statistics, +=, split-K
+        ops.set_option("conv3_b6_cfg2d64", 1)
+        try:
+            cases2d = ((2, 64, 64, (1, 32, 32), 1), (3, 32, 128, (1, 21, 19), 1), (2, 80, 64, (1, 16, 24), 1), (1, 16, 64, (1, 9, 40), 1))
+            check_conv3(ops, dev, cases=cases2d)
+            rng4 = np.random.default_rng(79)
+            for (N, Cin, Cout, sp, KD) in cases2d:
+                x = to_cl(R(rng4, N, Cin, *sp[1:])).to(dev)
+                w = (R(rng4, Cout, Cin, 3, 3) * 0.1).to(dev).contiguous()
+                b = (R(rng4, Cout) * 0.1).to(dev)
+                wf, _ = ops.conv3_pack(w, KD)
+                outs = []
+                for w22, pipe in ((1, 1), (1, 0), (0, 0)):
+                    ops.set_option("conv3_b6_w22", w22)
+                    ops.set_option("conv3_b6_pipe", pipe)
+                    ops.set_option("splitk", 1)
+                    try:
+                        y, part, rows = ops.conv3_fwd_stats(x, wf, b, Cout, KD, 1)
+                        y2 = y.clone()
+                        ops.conv3_fwd(x, wf, None, Cout, KD, out=y2, accumulate=True)
+                        ops.set_option("splitk", 2)
+                        y3 = ops.conv3_fwd(x, wf, b, Cout, KD)
+                        outs.append((y.clone(), rows, y2, y3.clone()))
+                    finally:
+                        ops.set_option("conv3_b6_w22"); ops.set_option("conv3_b6_pipe"); ops.set_option("splitk")
+                for o in outs[1:]:
+                    assert outs[0][1] == o[1] and outs[0][1] > 0
+                    assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][2], o[2]) and torch.equal(outs[0][3], o[3]), \
+                        "2-D k_c3p vs k_c3h vs k_c3b: outputs differ"
+        finally:
+            ops.set_option("conv3_b6_cfg2d64")
         ops.set_option("conv3_b6_cfg2d", 2)         # 2-D 32-channel slabs on the direct-weight 16x16 tiles (product default from 64 K pixels)
         try:
             check_conv3(ops, dev, cases=((2, 64, 32, (1, 12, 20), 1), (1, 16, 32, (1, 33, 17), 1), (2, 32, 96, (1, 16, 16), 1)))
@@ -1138,8 +1170,22 @@ def check_conv3_pipe_cold(ops, dev):
                             flush.fill_(float(rep) + 0.5)
                         yd = ops.conv3_fwd(x, wd, None, Cin, 3)
                         assert torch.equal(yd, refd), f"pipeline vs register-staged kernel, dgrad pack (slab mode {flat}) {N}x{sp} rep {rep}"
+        # 2-D 8x8 tiles (five stages per chunk)
+        ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6", 2); ops.set_option("conv3_b6_cfg2d64", 1)
+        for (N, Cin, Cout, hw) in ((2, 64, 64, (32, 32)), (3, 32, 128, (21, 19))) + (((12, 128, 128, (32, 32)), (12, 256, 256, (16, 16))) if on_gpu else ()):
+            x = R(rng, N, 1, *hw, Cin).to(dev)
+            w = (R(rng, Cout, Cin, 3, 3) * 0.1).to(dev)
+            wf, _ = ops.conv3_pack(w, 1)
+            ops.set_option("conv3_b6_pipe", 0)
+            ref = ops.conv3_fwd(x, wf, None, Cout, 1).clone()
+            ops.set_option("conv3_b6_pipe", 1)
+            for rep in range(3 if on_gpu else 1):
+                if on_gpu:
+                    flush.fill_(float(rep) + 0.25)
+                y = ops.conv3_fwd(x, wf, None, Cout, 1)
+                assert torch.equal(y, ref), f"2-D pipeline vs register-staged kernel {N}x{hw} {Cin}->{Cout} rep {rep}: {int((y != ref).sum())} outputs differ"
     finally:
-        ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe")
+        ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6"); ops.set_option("conv3_b6_cfg2d64")
 
 
 ALL_CHECKS = ("conv3_pipe_cold", "conv3_c1_norm", "norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
