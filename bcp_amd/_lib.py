@@ -45,6 +45,9 @@ _SIGS = {
     "bcp_mixloss_workspace_bytes": (SZ, [I, I]),
     "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P]),
     "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, P, P]),
+    "bcp_dice_prob_workspace_bytes": (SZ, [I]),
+    "bcp_dice_prob_fwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, P, P]),
+    "bcp_dice_prob_bwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, F, P, P]),
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
     "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, P]),
     "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, I, P, P]),

@@ -1784,7 +1784,9 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
       hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kd, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, gx, 0, none);
     } else {
-      size_t lds_k = lds;
+      // the STAGED kernel always needs its weight stage: `lds` left it out when `direct` chose k_c3d (16-channel slabs
+      // come here with direct && NT == 1 and overran their allocation by the 6 KB stage)
+      size_t lds_k = lds + (direct ? (size_t)2 * 3 * SP * CT * 32 * 2 : 0);
       if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
         if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;
         if (options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0) { kfn = k_c3p<KD, TD, TH, TW>; lds_k = kC3pLds<TL>; }

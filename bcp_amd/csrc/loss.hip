@@ -52,8 +52,10 @@ template <int C, bool ACDC>
 __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ logits, const uint8_t* __restrict__ img_l,
                                                      const uint8_t* __restrict__ patch_l,
                                                      const uint8_t* __restrict__ mask /* nullable: 1 = image term */,
-                                                     BoxArg box, int D, int H, int W, double* __restrict__ acc, int N) {
+                                                     BoxArg box, int D, int H, int W, double* __restrict__ acc, int N,
+                                                     unsigned* __restrict__ ticket) {
   const int n = blockIdx.y;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ticket = 0u;      // for k_mixloss_reduce's last-arriver hand-over
   const long long V = (long long)D * H * W;
   const float* lg = logits + (long long)n * V * C;
   const uint8_t* la = img_l + (long long)n * V;
@@ -66,25 +68,10 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
 #pragma unroll
     for (int c = 0; c < C; ++c) s[t][c][0] = s[t][c][1] = s[t][c][2] = 0.0;
 
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
-    float x[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) x[c] = lg[v * C + c];
-    int t;
-    if (mk) {
-      t = mk[v] ? 0 : 1;
-    } else {
-      const unsigned vu = (unsigned)v, q1 = vu / (unsigned)W;          // V < 2^31 (checked by the entry point): 32-bit divisions
-      const int w = (int)(vu - q1 * (unsigned)W);
-      const int d = (int)(q1 / (unsigned)H);
-      const int h = (int)(q1 - (unsigned)d * (unsigned)H);
-      t = in_box(d, h, w, box.v) ? 1 : 0;
-    }
-    const int y = t ? lb[v] : la[v];
+  // one voxel: softmax + branch-free accumulation into the term the voxel belongs to
+  auto voxel = [&](const float (&x)[C], int t, int y) __attribute__((always_inline)) {
     Softmax<C> sm;
     sm.compute(x);
-    // branch-free accumulation into the term the voxel belongs to
 #pragma unroll
     for (int tt = 0; tt < 2; ++tt) {
       const float m = (tt == t) ? 1.f : 0.f;
@@ -104,6 +91,42 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
       for (int c = 1; c < C; ++c) xy = (y == c) ? x[c] : xy;
       ce[tt] += (double)((sm.lse - xy) * m);
       cnt[tt] += (double)m;
+    }
+  };
+  auto term_of = [&](long long v) __attribute__((always_inline)) -> int {
+    if (mk) return mk[v] ? 0 : 1;
+    const unsigned vu = (unsigned)v, q1 = vu / (unsigned)W;          // V < 2^31 (checked by the entry point): 32-bit divisions
+    const int w = (int)(vu - q1 * (unsigned)W);
+    const int d = (int)(q1 / (unsigned)H);
+    const int h = (int)(q1 - (unsigned)d * (unsigned)H);
+    return in_box(d, h, w, box.v) ? 1 : 0;
+  };
+  // 16 bytes of logits per lane and iteration (VP voxels), two iterations in flight; V % VP == 0 is the launcher's condition for
+  // this path (sample bases stay 16-byte aligned), the scalar loop below serves the rest
+  constexpr int VP = 4 / C;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (VP >= 1 && C * VP == 4 && (V % VP) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15u) == 0) {
+    const long long VV = V / VP;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < VV; i += stride) {
+      const float4 q = ld4(lg + i * 4);
+      const float xv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int u = 0; u < VP; ++u) {
+        const long long v = i * VP + u;
+        float x[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = xv[u * C + c];
+        const int t = term_of(v);
+        voxel(x, t, t ? lb[v] : la[v]);
+      }
+    }
+  } else {
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+      float x[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) x[c] = lg[v * C + c];
+      const int t = term_of(v);
+      voxel(x, t, t ? lb[v] : la[v]);
     }
   }
   // block reduction: wave shuffles then LDS, then one fp64 atomic per quantity
@@ -130,34 +153,10 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-template <int C, bool ACDC>
-__global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict__ partial, int nb, double* __restrict__ acc, int N) {
-  // block n: the nb (<= 256) per-block rows of sample n -> acc[n][2*C*3] and tailp[n][4], in a fixed order (thread = row)
-  constexpr int nq = 2 * C * 3 + 4;
-  __shared__ double wred[4][nq];
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  const double* row = partial + ((long long)n * nb + threadIdx.x) * nq;
-  double v[nq];
-#pragma unroll
-  for (int q = 0; q < nq; ++q) v[q] = ((int)threadIdx.x < nb) ? row[q] : 0.0;
-#pragma unroll
-  for (int q = 0; q < nq; ++q) {
-    const double r = wave_sum(v[q]);
-    if (lane == 0) wred[wid][q] = r;
-  }
-  __syncthreads();
-  if ((int)threadIdx.x < nq) {
-    const double t = wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
-    if ((int)threadIdx.x < 2 * C * 3) acc[(long long)n * 2 * C * 3 + threadIdx.x] = t;
-    else acc[(long long)N * 2 * C * 3 + (long long)n * 4 + (threadIdx.x - 2 * C * 3)] = t;
-  }
-}
-
 // out[0] = LA: loss ; ACDC: dice.   out[1] = ACDC: ce (LA: ce part, informational). out[2] = LA dice part.
 template <int C, bool ACDC>
-__global__ void k_mixloss_finalize(const double* __restrict__ acc, float* __restrict__ coef, float* __restrict__ out, int N,
-                                   float w_img, float w_patch) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void mixloss_finalize(const double* __restrict__ acc, float* __restrict__ coef, float* __restrict__ out, int N,
+                                 float w_img, float w_patch) {
   double tail[4] = {0.0, 0.0, 0.0, 0.0};
   for (int n = 0; n < N; ++n)
     for (int q = 0; q < 4; ++q) tail[q] += acc[(long long)N * 2 * C * 3 + (long long)n * 4 + q];
@@ -218,6 +217,47 @@ __global__ void k_mixloss_finalize(const double* __restrict__ acc, float* __rest
 }
 
 template <int C, bool ACDC>
+__global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict__ partial, int nb, double* __restrict__ acc, int N,
+                                                        unsigned* __restrict__ ticket, float* __restrict__ coef, float* __restrict__ out,
+                                                        float w_img, float w_patch) {
+  // block n: the nb per-block rows of sample n -> acc[n][2*C*3] and tailp[n][4], in a fixed order (thread t sums rows t, t + 256, ...;
+  // then lanes, waves).  The LAST block to arrive (ticket zeroed by the forward kernel, a kernel boundary earlier) turns the N reduced
+  // rows into the loss scalar(s) and the coefficient table: no finalize launch.  The hand-over is a few hundred bytes per block:
+  // release fence -> ticket -> acquire fence in the last arriver only.
+  constexpr int nq = 2 * C * 3 + 4;
+  __shared__ double wred[4][nq];
+  __shared__ unsigned s_last;
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double v[nq];
+#pragma unroll
+  for (int q = 0; q < nq; ++q) v[q] = 0.0;
+  for (int r = threadIdx.x; r < nb; r += 256) {
+    const double* row = partial + ((long long)n * nb + r) * nq;
+#pragma unroll
+    for (int q = 0; q < nq; ++q) v[q] += row[q];
+  }
+#pragma unroll
+  for (int q = 0; q < nq; ++q) {
+    const double r = wave_sum(v[q]);
+    if (lane == 0) wred[wid][q] = r;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nq) {
+    const double t = wred[0][threadIdx.x] + wred[1][threadIdx.x] + wred[2][threadIdx.x] + wred[3][threadIdx.x];
+    if ((int)threadIdx.x < 2 * C * 3) acc[(long long)n * 2 * C * 3 + threadIdx.x] = t;
+    else acc[(long long)N * 2 * C * 3 + (long long)n * 4 + (threadIdx.x - 2 * C * 3)] = t;
+    __threadfence();
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == (unsigned)(N - 1)) ? 1u : 0u;
+  __syncthreads();
+  if (s_last && threadIdx.x == 0) {
+    __threadfence();
+    mixloss_finalize<C, ACDC>(acc, coef, out, N, w_img, w_patch);
+  }
+}
+
+template <int C, bool ACDC>
 __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ logits, const uint8_t* __restrict__ img_l,
                                                      const uint8_t* __restrict__ patch_l, const uint8_t* __restrict__ mask,
                                                      BoxArg box, int D, int H, int W, const float* __restrict__ coef,
@@ -236,22 +276,15 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
   if ((int)threadIdx.x < 2) cce[threadIdx.x] = coef[(long long)N * 2 * C * 2 + threadIdx.x];
   __syncthreads();
   if (g_dev) { g_dice *= g_dev[0]; g_ce *= g_dev[1]; }  // upstream gradients stay on the device (no host sync)
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
-    float x[C];
-#pragma unroll
-    for (int c = 0; c < C; ++c) x[c] = lg[v * C + c];
-    int t;
-    if (mk) {
-      t = mk[v] ? 0 : 1;
-    } else {
-      const unsigned vu = (unsigned)v, q1 = vu / (unsigned)W;          // V < 2^31 (checked by the entry point): 32-bit divisions
-      const int w = (int)(vu - q1 * (unsigned)W);
-      const int d = (int)(q1 / (unsigned)H);
-      const int h = (int)(q1 - (unsigned)d * (unsigned)H);
-      t = in_box(d, h, w, box.v) ? 1 : 0;
-    }
-    const int y = t ? lb[v] : la[v];
+  auto term_of = [&](long long v) __attribute__((always_inline)) -> int {
+    if (mk) return mk[v] ? 0 : 1;
+    const unsigned vu = (unsigned)v, q1 = vu / (unsigned)W;          // V < 2^31 (checked by the entry point): 32-bit divisions
+    const int w = (int)(vu - q1 * (unsigned)W);
+    const int d = (int)(q1 / (unsigned)H);
+    const int h = (int)(q1 - (unsigned)d * (unsigned)H);
+    return in_box(d, h, w, box.v) ? 1 : 0;
+  };
+  auto voxel = [&](const float (&x)[C], int t, int y, float (&o)[C]) __attribute__((always_inline)) {
     Softmax<C> sm;
     sm.compute(x);
     float gp[C];
@@ -266,18 +299,44 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       const float oh = (y == c) ? 1.f : 0.f;
-      dl[v * C + c] = g_dice * (sm.p[c] * (gp[c] - dot)) + kce * (sm.p[c] - oh);
+      o[c] = g_dice * (sm.p[c] * (gp[c] - dot)) + kce * (sm.p[c] - oh);
+    }
+  };
+  constexpr int VP = 4 / C;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  if (VP >= 1 && C * VP == 4 && (V % VP) == 0 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15u) == 0) {
+    const long long VV = V / VP;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < VV; i += stride) {
+      const float4 q = ld4(lg + i * 4);
+      const float xv[4] = {q.x, q.y, q.z, q.w};
+      float ov[4];
+#pragma unroll
+      for (int u = 0; u < VP; ++u) {
+        const long long v = i * VP + u;
+        float x[C], o[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) x[c] = xv[u * C + c];
+        const int t = term_of(v);
+        voxel(x, t, t ? lb[v] : la[v], o);
+#pragma unroll
+        for (int c = 0; c < C; ++c) ov[u * C + c] = o[c];
+      }
+      st4(dl + i * 4, make_float4(ov[0], ov[1], ov[2], ov[3]));
+    }
+  } else {
+    for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
+      float x[C], o[C];
+#pragma unroll
+      for (int c = 0; c < C; ++c) x[c] = lg[v * C + c];
+      const int t = term_of(v);
+      voxel(x, t, t ? lb[v] : la[v], o);
+#pragma unroll
+      for (int c = 0; c < C; ++c) dl[v * C + c] = o[c];
     }
   }
 }
 
-constexpr int kLossPartialRows = 256;   // forward blocks per sample = rows of per-block partials the finalize kernel sums
-
-static inline int loss_grid(long long V) {
-  long long g = (V + 255) / 256;
-  if (g > 1024) g = 1024;
-  return (int)(g < 1 ? 1 : g);
-}
+constexpr int kLossPartialRows = 1024;  // most forward blocks per sample = rows of per-block partials the reduce kernel sums
 
 template <int C, bool ACDC>
 static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
@@ -288,11 +347,14 @@ static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* 
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
   bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
   const long long V = (long long)D * H * W;
-  const int nb = loss_grid(V) < kLossPartialRows ? loss_grid(V) : kLossPartialRows;
-  hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(nb, N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H, W, acc, N);
+  // 16 bytes of logits per lane and iteration: ~2 iterations per thread at the LA size, >= 2048 workgroups per launch at most
+  long long nbl = (V * C / 4 + 511) / 512;
+  if (nbl * N > 2048) nbl = (2048 + N - 1) / N;
+  const int nb = (int)(nbl < 1 ? 1 : (nbl > kLossPartialRows ? kLossPartialRows : nbl));
   double* red = acc + (size_t)N * kLossPartialRows * (2 * C * 3 + 4);          // [N][2*C*3] | [N][4]
-  hipLaunchKernelGGL((k_mixloss_reduce<C, ACDC>), dim3(N), dim3(256), 0, s, acc, nb, red, N);
-  hipLaunchKernelGGL((k_mixloss_finalize<C, ACDC>), dim3(1), dim3(64), 0, s, red, coef, out, N, w_img, w_patch);
+  unsigned* ticket = reinterpret_cast<unsigned*>(red + (size_t)N * (2 * C * 3 + 4));
+  hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(nb, N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H, W, acc, N, ticket);
+  hipLaunchKernelGGL((k_mixloss_reduce<C, ACDC>), dim3(N), dim3(256), 0, s, acc, nb, red, N, ticket, coef, out, w_img, w_patch);
   return 0;
 }
 
@@ -304,24 +366,219 @@ static int launch_bwd(const float* logits, const uint8_t* img_l, const uint8_t* 
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
   bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
   const long long V = (long long)D * H * W;
-  hipLaunchKernelGGL((k_mixloss_bwd<C, ACDC>), dim3(loss_grid(V), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
+  long long gb = (V * C / 4 + 255) / 256;          // one 16-byte vector per thread, at most ~4096 workgroups per launch
+  if (gb * N > 4096) gb = (4096 + N - 1) / N;
+  hipLaunchKernelGGL((k_mixloss_bwd<C, ACDC>), dim3((int)(gb < 1 ? 1 : gb), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
                      W, coef, dlogits, N, g_dice, g_ce, g_dev);
   return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// utils/losses.py:79-134 `DiceLoss.forward(inputs, target, mask, weight, softmax)` AS A CLASS: `inputs` are PROBABILITIES (the
+// ACDC script hands it F.softmax(output), ACDC_BCP_train.py:170-176), any dense layout (channel / voxel / sample strides in
+// elements: torch's softmax returns NCHW-contiguous, the networks here produce NHWC), per-class sums over the whole batch,
+// squared denominators, smooth 1e-10 with a mask and 1e-5 without, per-class weights.  The fused step uses bcp_mixloss_* above;
+// this pair exists so the reference's own loss body runs unchanged on the seam.
+// mask_mode: 0 none, 1 dense uint8 (non-zero = counted), 2 box (1 OUTSIDE the box), 3 box complement (1 inside)
+constexpr int kDiceProbRows = 512;
+constexpr int kDiceProbMaxC = 8;
+struct DiceW { float w[kDiceProbMaxC]; };
+
+__device__ __forceinline__ float dice_prob_mask(const uint8_t* mk, long long nv, int mode, BoxArg box, unsigned v, int H, int W) {
+  if (mode == 0) return 1.f;
+  if (mode == 1) return mk[nv] ? 1.f : 0.f;
+  const unsigned q1 = v / (unsigned)W;
+  const int w = (int)(v - q1 * (unsigned)W);
+  const int d = (int)(q1 / (unsigned)H);
+  const int h = (int)(q1 - (unsigned)d * (unsigned)H);
+  const bool in = in_box(d, h, w, box.v);
+  return (mode == 2) ? (in ? 0.f : 1.f) : (in ? 1.f : 0.f);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_dice_prob_fwd(const float* __restrict__ p, long long cs, long long vs, long long ns,
+                                                       const uint8_t* __restrict__ target, const uint8_t* __restrict__ mask, int mode,
+                                                       BoxArg box, int N, int D, int H, int W, double* __restrict__ partial) {
+  const long long V = (long long)D * H * W, T = (long long)N * V;
+  double s[C * 3];
+#pragma unroll
+  for (int i = 0; i < C * 3; ++i) s[i] = 0.0;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += stride) {
+    const long long n = i / V, v = i - n * V;
+    const float m = dice_prob_mask(mask, i, mode, box, (unsigned)v, H, W);
+    const int y = target[i];
+    const float* q = p + n * ns + v * vs;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float pc = q[c * cs], oh = (y == c) ? 1.f : 0.f;
+      s[c * 3 + 0] += (double)(pc * oh * m);
+      s[c * 3 + 1] += (double)(pc * pc * m);
+      s[c * 3 + 2] += (double)(oh * m);
+    }
+  }
+  __shared__ double red[4 * C * 3];
+  block_sum_256<C * 3>(s, red);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int i = 0; i < C * 3; ++i) partial[(long long)blockIdx.x * (C * 3) + i] = s[i];
+  }
+}
+
+// one block: rows summed in a fixed order -> loss, per-class (1 - dice) and the coefficient table {A_c, B_c}:
+// dL/dp_c(v) = m(v) * (A_c * 1[y == c] + B_c * p_c(v))
+template <int C>
+__global__ __launch_bounds__(256) void k_dice_prob_finalize(const double* __restrict__ partial, int nb, DiceW wt, int masked,
+                                                            float* __restrict__ coef, float* __restrict__ out) {
+  double s[C * 3];
+#pragma unroll
+  for (int i = 0; i < C * 3; ++i) s[i] = 0.0;
+  for (int r = threadIdx.x; r < nb; r += 256) {
+#pragma unroll
+    for (int i = 0; i < C * 3; ++i) s[i] += partial[(long long)r * (C * 3) + i];
+  }
+  __shared__ double red[4 * C * 3];
+  block_sum_256<C * 3>(s, red);
+  if (threadIdx.x != 0) return;
+  const double smooth = masked ? 1e-10 : 1e-5;
+  double loss = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double I = s[c * 3], Z = s[c * 3 + 1], Y = s[c * 3 + 2];
+    const double den = Z + Y + smooth, num = 2.0 * I + smooth;
+    const double dice = 1.0 - num / den;
+    loss += dice * (double)wt.w[c];
+    const double k = (double)wt.w[c] / (double)C;
+    coef[c * 2 + 0] = (float)(-k * 2.0 / den);
+    coef[c * 2 + 1] = (float)(k * num * 2.0 / (den * den));
+    out[1 + c] = (float)(1.0 - dice);          // class_wise_dice of the reference (computed there, never returned)
+  }
+  out[0] = (float)(loss / (double)C);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void k_dice_prob_bwd(const float* __restrict__ p, long long cs, long long vs, long long ns,
+                                                       const uint8_t* __restrict__ target, const uint8_t* __restrict__ mask, int mode,
+                                                       BoxArg box, int N, int D, int H, int W, const float* __restrict__ coef,
+                                                       const float* __restrict__ g_dev, float g, float* __restrict__ dp) {
+  const long long V = (long long)D * H * W, T = (long long)N * V;
+  __shared__ float cf[C * 2];
+  if ((int)threadIdx.x < C * 2) cf[threadIdx.x] = coef[threadIdx.x];
+  __syncthreads();
+  if (g_dev) g *= g_dev[0];
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < T; i += stride) {
+    const long long n = i / V, v = i - n * V;
+    const float m = dice_prob_mask(mask, i, mode, box, (unsigned)v, H, W) * g;
+    const int y = target[i];
+    const long long o = n * ns + v * vs;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const float pc = p[o + c * cs], oh = (y == c) ? 1.f : 0.f;
+      dp[o + c * cs] = m * (cf[c * 2] * oh + cf[c * 2 + 1] * pc);
+    }
+  }
+}
+
+static inline int dice_prob_grid(long long T) {
+  long long gx = (T + 255) / 256;
+  if (gx > kDiceProbRows) gx = kDiceProbRows;
+  return (int)(gx < 1 ? 1 : gx);
+}
+
+static inline BoxArg box_arg(const int* box6) {
+  BoxArg bx;
+  bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
+  bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
+  bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
+  return bx;
 }
 
 }  // namespace bcp
 
 using namespace bcp;
 
+extern "C" size_t bcp_dice_prob_workspace_bytes(int C) {
+  // [per-block partial rows (doubles) | coef floats C*2]
+  return (size_t)kDiceProbRows * (size_t)C * 3 * sizeof(double) + (size_t)C * 2 * sizeof(float) + 16;
+}
+
+static inline float* dice_prob_coef(void* ws, int C) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + (size_t)kDiceProbRows * (size_t)C * 3 * sizeof(double));
+}
+
+template <int CC>
+static void dice_prob_launch_fwd(const float* probs, long long cs, long long vs, long long ns, const uint8_t* target, const uint8_t* mask,
+                                 int mode, BoxArg bx, int N, int D, int H, int W, DiceW wt, double* partial, float* coef, float* out,
+                                 int nb, hipStream_t s) {
+  hipLaunchKernelGGL((k_dice_prob_fwd<CC>), dim3(nb), dim3(256), 0, s, probs, cs, vs, ns, target, mask, mode, bx, N, D, H, W, partial);
+  hipLaunchKernelGGL((k_dice_prob_finalize<CC>), dim3(1), dim3(256), 0, s, partial, nb, wt, mode != 0 ? 1 : 0, coef, out);
+}
+
+template <int CC>
+static void dice_prob_launch_bwd(const float* probs, long long cs, long long vs, long long ns, const uint8_t* target, const uint8_t* mask,
+                                 int mode, BoxArg bx, int N, int D, int H, int W, const float* coef, const float* g_dev, float g,
+                                 float* dprobs, int gx, hipStream_t s) {
+  hipLaunchKernelGGL((k_dice_prob_bwd<CC>), dim3(gx), dim3(256), 0, s, probs, cs, vs, ns, target, mask, mode, bx, N, D, H, W, coef, g_dev,
+                     g, dprobs);
+}
+
+extern "C" int bcp_dice_prob_fwd(const float* probs, long long cstride, long long vstride, long long nstride, const uint8_t* target,
+                                 const uint8_t* mask_or_null, int mask_mode, const int* box6, int N, int D, int H, int W, int C,
+                                 const float* weight_host_or_null, void* workspace, float* out /* [1 + C] */, void* stream) {
+  BCP_REQUIRE(probs && target && workspace && out, "bcp_dice_prob_fwd: null pointer");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_dice_prob_fwd: bad extents");
+  BCP_REQUIRE(C >= 2 && C <= 4, "bcp_dice_prob_fwd: C = %d unsupported (2..4)", C);
+  BCP_REQUIRE(mask_mode >= 0 && mask_mode <= 3 && (mask_mode != 1 || mask_or_null) && (mask_mode < 2 || box6),
+              "bcp_dice_prob_fwd: mask_mode %d without its mask / box", mask_mode);
+  BCP_REQUIRE(cstride > 0 && vstride > 0 && nstride > 0, "bcp_dice_prob_fwd: strides must be positive");
+  DiceW wt;
+  for (int c = 0; c < kDiceProbMaxC; ++c) wt.w[c] = (weight_host_or_null && c < C) ? weight_host_or_null[c] : 1.f;
+  BoxArg bx = {};
+  if (mask_mode >= 2) bx = box_arg(box6);
+  const long long T = (long long)N * D * H * W;
+  const int nb = dice_prob_grid(T);
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* coef = dice_prob_coef(workspace, C);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 2) dice_prob_launch_fwd<2>(probs, cstride, vstride, nstride, target, mask_or_null, mask_mode, bx, N, D, H, W, wt, partial, coef, out, nb, s);
+  else if (C == 3) dice_prob_launch_fwd<3>(probs, cstride, vstride, nstride, target, mask_or_null, mask_mode, bx, N, D, H, W, wt, partial, coef, out, nb, s);
+  else dice_prob_launch_fwd<4>(probs, cstride, vstride, nstride, target, mask_or_null, mask_mode, bx, N, D, H, W, wt, partial, coef, out, nb, s);
+  BCP_CHECK_LAUNCH("bcp_dice_prob_fwd");
+  return BCP_OK;
+}
+
+extern "C" int bcp_dice_prob_bwd(const float* probs, long long cstride, long long vstride, long long nstride, const uint8_t* target,
+                                 const uint8_t* mask_or_null, int mask_mode, const int* box6, int N, int D, int H, int W, int C,
+                                 const void* workspace, const float* g_dev_or_null, float g, float* dprobs, void* stream) {
+  BCP_REQUIRE(probs && target && workspace && dprobs, "bcp_dice_prob_bwd: null pointer");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_dice_prob_bwd: bad extents");
+  BCP_REQUIRE(C >= 2 && C <= 4, "bcp_dice_prob_bwd: C = %d unsupported (2..4)", C);
+  BCP_REQUIRE(mask_mode >= 0 && mask_mode <= 3 && (mask_mode != 1 || mask_or_null) && (mask_mode < 2 || box6),
+              "bcp_dice_prob_bwd: mask_mode %d without its mask / box", mask_mode);
+  BoxArg bx = {};
+  if (mask_mode >= 2) bx = box_arg(box6);
+  const long long T = (long long)N * D * H * W;
+  long long gx = (T + 255) / 256;
+  if (gx > 2048) gx = 2048;
+  const float* coef = dice_prob_coef(const_cast<void*>(workspace), C);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 2) dice_prob_launch_bwd<2>(probs, cstride, vstride, nstride, target, mask_or_null, mask_mode, bx, N, D, H, W, coef, g_dev_or_null, g, dprobs, (int)gx, s);
+  else if (C == 3) dice_prob_launch_bwd<3>(probs, cstride, vstride, nstride, target, mask_or_null, mask_mode, bx, N, D, H, W, coef, g_dev_or_null, g, dprobs, (int)gx, s);
+  else dice_prob_launch_bwd<4>(probs, cstride, vstride, nstride, target, mask_or_null, mask_mode, bx, N, D, H, W, coef, g_dev_or_null, g, dprobs, (int)gx, s);
+  BCP_CHECK_LAUNCH("bcp_dice_prob_bwd");
+  return BCP_OK;
+}
+
 extern "C" size_t bcp_mixloss_workspace_bytes(int N, int C) {
   // [acc doubles | coef floats], both 16-B aligned
-  const size_t acc = (size_t)N * (kLossPartialRows + 1) * (2 * C * 3 + 4) * sizeof(double);   // per-block rows + the reduced row per sample
+  const size_t acc = (size_t)N * (kLossPartialRows + 1) * (2 * C * 3 + 4) * sizeof(double) + 16;   // per-block rows + the reduced row per sample + the ticket
   const size_t coef = ((size_t)N * 2 * C * 2 + 2) * sizeof(float);
   return ((acc + 15) / 16) * 16 + ((coef + 15) / 16) * 16;
 }
 
 static inline float* coef_ptr(void* ws, int N, int C) {
-  const size_t acc = (size_t)N * (kLossPartialRows + 1) * (2 * C * 3 + 4) * sizeof(double);   // per-block rows + the reduced row per sample
+  const size_t acc = (size_t)N * (kLossPartialRows + 1) * (2 * C * 3 + 4) * sizeof(double) + 16;   // per-block rows + the reduced row per sample + the ticket
   return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((acc + 15) / 16) * 16);
 }
 

@@ -43,7 +43,9 @@ __global__ __launch_bounds__(256) void k_maxpool3d_k3s2_fwd(const float* __restr
       for (int kh = 0; kh < 3; ++kh)
         for (int kw = 0; kw < 3; ++kw) {
           const float4 v = ld4(x + ((((long long)n * D + 2 * d_o + kd) * H + 2 * ho + kh) * W + 2 * wo + kw) * C + c4 * 4);
-          o.x = fmaxf(o.x, v.x); o.y = fmaxf(o.y, v.y); o.z = fmaxf(o.z, v.z); o.w = fmaxf(o.w, v.w);
+          // NaN-propagating like torch's MaxPool3d (fmaxf would drop a NaN)
+          o.x = (v.x > o.x || v.x != v.x) ? v.x : o.x; o.y = (v.y > o.y || v.y != v.y) ? v.y : o.y;
+          o.z = (v.z > o.z || v.z != v.z) ? v.z : o.z; o.w = (v.w > o.w || v.w != v.w) ? v.w : o.w;
         }
     st4(y + i * 4, o);
   }

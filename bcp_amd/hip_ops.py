@@ -156,6 +156,44 @@ class Ops:
                     _p(ws), float(g_dice), float(g_ce), _p(g_dev), _p(dlogits), self.stream(logits))
         return dlogits
 
+    # ------------------------------------------------------------------ DiceLoss class on probabilities (utils/losses.py:113-134)
+    def _dice_prob_args(self, probs, target, mask, mode, box6):
+        """probs: logical [N,C,*sp] float32, any DENSE layout whose spatial dims are jointly contiguous"""
+        N, Cc = probs.shape[0], probs.shape[1]
+        sp = tuple(probs.shape[2:])
+        V = 1
+        for e in sp:
+            V *= e
+        st = probs.stride()
+        vs = st[-1]
+        exp = vs
+        for e, s_ in zip(reversed(sp), reversed(st[2:])):      # spatial dims must collapse into one index with stride vs
+            if e != 1 and s_ != exp:
+                raise _lib.BcpError("DiceLoss: probabilities must be dense (NCHW- or NHWC-contiguous)")
+            exp *= e
+        D, H, W = (1,) * (3 - len(sp)) + sp
+        if not self.allow_cpu and not probs.is_cuda:
+            raise _lib.BcpError("HIP op called with a CPU tensor: the product path has no CPU fallback")
+        self._chk(target, mask)
+        return (_p(probs), int(st[1]), int(vs), int(st[0]), _p(target), _p(mask), int(mode),
+                self.box_arg(box6 if box6 is not None else (0,) * 6), N, D, H, W, Cc)
+
+    def dice_prob_fwd(self, probs, target, mask=None, mode=0, box6=None, weight=None):
+        """-> (out float32[1 + C] on device {loss, class-wise dice}, workspace for dice_prob_bwd)"""
+        args = self._dice_prob_args(probs, target, mask, mode, box6)
+        Cc = probs.shape[1]
+        ws = torch.empty(self._ws_bytes("bcp_dice_prob_workspace_bytes", Cc), dtype=torch.uint8, device=probs.device)
+        out = torch.empty(1 + Cc, dtype=torch.float32, device=probs.device)
+        w = None if weight is None else (C.c_float * Cc)(*[float(v) for v in weight])
+        self.b.call("bcp_dice_prob_fwd", *args, w, _p(ws), _p(out), self.stream(probs))
+        return out, ws
+
+    def dice_prob_bwd(self, probs, target, ws, mask=None, mode=0, box6=None, g_dev=None, g=1.0):
+        args = self._dice_prob_args(probs, target, mask, mode, box6)
+        d = torch.empty_strided(probs.shape, probs.stride(), dtype=torch.float32, device=probs.device)
+        self.b.call("bcp_dice_prob_bwd", *args, _p(ws), _p(g_dev), float(g), _p(d), self.stream(probs))
+        return d
+
     # ------------------------------------------------------------------ norm
     def norm_fwd(self, y, G, gamma, beta, rmean, rvar, act, out=None, chan_scale=None, elem_mask=None, elem_scale=1.0,
                  residual=None, momentum=0.1, eps=1e-5, partial=None, nb=0, stats_only=False):

@@ -138,7 +138,9 @@ class VNet(HipNet):
                 self.register_k2(("k2", li), L.conv.weight, L.cin, L.cout, H.PACK_UP_FWD, H.PACK_UP_DGRAD)
 
     # ------------------------------------------------------------------ public call
-    def forward(self, input, turnoff_drop=False, groups=1):
+    pool_features = True      # LA variant: also return pool(x5) as the reference does (networks/VNet.py:286-290)
+
+    def forward(self, input, turnoff_drop=False, groups=1, features=None):
         """groups > 1: `input` holds `groups` consecutive sub-batches that the reference would push through the net in
         separate calls (LA_BCP_train.py:241-242, 252-253); they are normalised separately (grouped BatchNorm) but every
         layer is ONE launch over all of them -- identical results, half the launches, twice the work per launch."""
@@ -152,6 +154,8 @@ class VNet(HipNet):
         assert N % groups == 0
         self._groups = int(groups)
         self._feat_out = None
+        # `features=False` (the fused step functions of train_step.py, which discard it): no max-pool launch, no copy out of the plan
+        self._want_feat = bool(self.pool_features if features is None else features) and self.variant == "la"
         if self.training and torch.is_grad_enabled() and any(p.requires_grad for p in (self._layers[0].conv.weight,)):
             out = NetFn.apply(xcl, self._layers[0].conv.weight, self)   # eval() is forward-only (validation, test_3d_patch)
         else:
@@ -250,7 +254,7 @@ class VNet(HipNet):
             if save:
                 saved.append((h, y, stats, cs, G))
             h = a
-            if L.drop == "x5" and min(a.shape[1:4]) >= 3:
+            if L.drop == "x5" and getattr(self, "_want_feat", False) and min(a.shape[1:4]) >= 3:
                 feat = ops.maxpool3d_k3s2_fwd(a)      # pool(features[4]): the reference's second return value (networks/VNet.py:286-290)
         if self.norm == "batchnorm" and self.training:
             for _ in range(G):

@@ -8,7 +8,10 @@ def _dev():
 
 
 def net_factory(net_type="unet", in_chns=1, class_num=2, mode="train", tsne=0):
-    if net_type == "VNet" and mode == "train" and tsne == 0:
+    if net_type == "unet" and mode == "train":
+        from .unet import UNet
+        net = UNet(in_chns=in_chns, class_num=class_num).to(_dev())
+    elif net_type == "VNet" and mode == "train" and tsne == 0:
         net = VNet(n_channels=in_chns, n_classes=class_num, normalization='batchnorm', has_dropout=True).to(_dev())
     elif net_type == "VNet" and mode == "test" and tsne == 0:
         net = VNet(n_channels=in_chns, n_classes=class_num, normalization='batchnorm', has_dropout=False).to(_dev())

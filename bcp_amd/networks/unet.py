@@ -229,6 +229,8 @@ class UNet_2d(HipNet):
             h = self._convblock_fwd(cb, f"u{i}", cat, save, saved)
         wf, _ = self.conv3_packed(("out", 0), save)
         logits = ops.conv3_fwd(h, wf, self._out.bias.data, self.n_classes, 1)
+        if getattr(self, "_want_features", False):
+            self._last_feature = h
         if self.training:
             for _ in range(getattr(self, "_groups", 1)):
                 self._nbt_tick()
@@ -284,3 +286,23 @@ class UNet_2d(HipNet):
         self._convblock_bwd(self._enc[0], "e0", dh, saved, False)
         self._join_wgrad_stream(dlogits)
         return None
+
+
+class UNet(UNet_2d):
+    """networks/unet.py:148-201 `UNet`: the SAME layers and state_dict keys as `UNet_2d`, but `forward` returns
+    `(output, features)` with `features` the decoder's last 16-channel activation (:104-116).  The reference only builds it through
+    `net_factory(net_type="unet")` in its offline test / demo scripts (test_ACDC.py:91, under `torch.no_grad()` after `.eval()`);
+    no training loop uses the second output, so it is served on the no-grad path only."""
+
+    def forward(self, x, groups=1):
+        if self.training and torch.is_grad_enabled() and self._enc[0].c1.weight.requires_grad:
+            raise NotImplementedError("UNet (net_factory('unet')): (output, features) is an inference-time interface in BCP; train with "
+                                      "BCP_net() / UNet_2d, or call under torch.no_grad()")
+        self._want_features, plans, self.use_plans = True, self.use_plans, False      # a replayed pass would not refresh _last_feature
+        try:
+            out = super().forward(x, groups)
+            feat = self._last_feature
+        finally:
+            self._want_features, self.use_plans = False, plans
+            self._last_feature = None
+        return out, feat.permute(0, 4, 1, 2, 3).squeeze(2)

@@ -362,18 +362,18 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
                 main = torch.cuda.current_stream(volume_batch.device)
                 side.wait_stream(main)               # last step's EMA (and this step's inputs) are ordered before the teacher
                 with torch.cuda.stream(side):
-                    unout = ema_model(volume_batch[labeled_bs:], groups=2)[0]
+                    unout = ema_model(volume_batch[labeled_bs:], groups=2, features=False)[0]
                     plab = get_cut_mask(unout, nms=1, connect_mode=connect_mode)
                 plab.record_stream(main)
             else:
-                unout = ema_model(volume_batch[labeled_bs:], groups=2)[0]
+                unout = ema_model(volume_batch[labeled_bs:], groups=2, features=False)[0]
                 plab = get_cut_mask(unout, nms=1, connect_mode=connect_mode)
             plab_a, plab_b = plab[:sub_bs], plab[sub_bs:]
         else:
             ema_model.drop_masks = drops.get("t_a")
-            unoutput_a = ema_model(unimg_a)[0]
+            unoutput_a = ema_model(unimg_a, features=False)[0]
             ema_model.drop_masks = drops.get("t_b")
-            unoutput_b = ema_model(unimg_b)[0]
+            unoutput_b = ema_model(unimg_b, features=False)[0]
             plab_a = get_cut_mask(unoutput_a, nms=1, connect_mode=connect_mode)
             plab_b = get_cut_mask(unoutput_b, nms=1, connect_mode=connect_mode)
         if box is None:
@@ -400,7 +400,7 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         BU.mix(pairs[0][0], pairs[0][1], img_mask, out=mixed[:sub_bs])
         BU.mix(pairs[1][0], pairs[1][1], img_mask, out=mixed[sub_bs:])
         model.drop_masks = cat_drops("s_l", "s_u")
-        outputs = model(mixed, groups=2)[0]
+        outputs = model(mixed, groups=2, features=False)[0]
         if side is not None:
             torch.cuda.current_stream(volume_batch.device).wait_stream(side)   # pseudo-labels are needed from here on
         loss_l, loss_u = BU.mix_loss_pair(outputs, terms[0], terms[1], loss_mask)
@@ -409,10 +409,10 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         mixl_img = pairs[0][0] * img_mask + pairs[0][1] * (1 - img_mask)
         mixu_img = pairs[1][0] * img_mask + pairs[1][1] * (1 - img_mask)
         model.drop_masks = drops.get("s_l")
-        outputs_l = model(mixl_img)[0]
+        outputs_l = model(mixl_img, features=False)[0]
         loss_l = BU.mix_loss(outputs_l, terms[0][0], terms[0][1], loss_mask, l_weight=terms[0][2], u_weight=terms[0][3])
         model.drop_masks = drops.get("s_u")
-        outputs_u = model(mixu_img)[0]
+        outputs_u = model(mixu_img, features=False)[0]
         loss_u = BU.mix_loss(outputs_u, terms[1][0], terms[1][1], loss_mask, l_weight=terms[1][2], u_weight=terms[1][3])
     loss = loss_l + loss_u
     if optimizer is None:      # gradient-only mode (DP equivalence tests): caller owns zero_grad / step / EMA
@@ -454,7 +454,7 @@ def la_pre_train_step(model, optimizer, volume_batch, label_batch, mask_ratio=2 
             img_mask = BU.BoxMask(box, tuple(volume_batch.shape[2:]), None, False, volume_batch.device)
     mixed_img = img_a * img_mask + img_b * (1 - img_mask)
     mixed_lab = lab_a * img_mask + lab_b * (1 - img_mask)
-    outputs = model(mixed_img)[0]
+    outputs = model(mixed_img, features=False)[0]
     loss_ce, loss_dice = sup_loss_parts(outputs, mixed_lab)
     loss = (loss_ce + loss_dice) / 2
     optimizer.zero_grad()

@@ -43,6 +43,10 @@ class BoxMask:
     def long(self):
         return self
 
+    def unsqueeze(self, _dim):
+        """`mask.unsqueeze(1)` of ACDC_BCP_train.py:175-176: the kernels see the box, not a channel axis"""
+        return self
+
     def type(self, *_a, **_k):
         return self
 
@@ -95,6 +99,11 @@ class _Masked:
 
     def dense(self):
         return self.t * self.mask.tensor(self.t.device, self.t.dtype)
+
+    def sum(self, *a, **k):
+        """`(CE(output, img_l) * mask).sum()` of ACDC_BCP_train.py:177-178 with a BoxMask: dense fallback (compatibility; the
+        fused step never comes through here)"""
+        return self.dense().sum(*a, **k)
 
 
 def mix(a, b, mask: BoxMask, out=None):

@@ -25,19 +25,40 @@ class mask_DiceLoss(nn.Module):
 
 
 class DiceLoss(nn.Module):
-    """ACDC flavour; `inputs` are LOGITS here (pass softmax=... is ignored: the kernel applies the softmax)."""
+    """The reference's class (utils/losses.py:79-134), same call contract:
+    `forward(inputs, target, mask=None, weight=None, softmax=False)` with `inputs` PROBABILITIES [N,C,H,W] (logits when
+    softmax=True), `target` / `mask` [N,1,H,W] (any of the reference's dtypes; a `BCP_utils.BoxMask` also works as the mask),
+    `weight` a per-class list.  Per-class Dice over the whole batch with squared denominators, smooth 1e-10 masked / 1e-5
+    unmasked, sum(weight_i * dice_i) / n_classes.  Gradients flow to `inputs` (csrc/loss.hip: bcp_dice_prob_fwd / _bwd);
+    the fused training step does not come through here (train_step.acdc_mix_loss: one pass over the logits for both terms)."""
 
     def __init__(self, n_classes):
         super().__init__()
-        assert n_classes == 4
+        if not 2 <= int(n_classes) <= 4:
+            raise ValueError("DiceLoss: n_classes in 2..4 (BCP uses 4)")
+        self.n_classes = int(n_classes)
 
-    def forward(self, logits, target, mask=None):
-        cl = BU._as_cl(logits)
-        ops = BU._ops_for(cl)
-        N, sp = cl.shape[0], tuple(logits.shape[2:])
-        lab = BU._labels_u8(ops, target.squeeze(1) if target.dim() == logits.dim() else target, N, sp)
-        box6, m8 = ((0, 0, 0, 0, 0, 0), None) if mask is None else BU._mask_args(mask.squeeze(1) if hasattr(mask, "dim") and mask.dim() == logits.dim() else mask, ops, N, sp)
-        return _DiceOnly.apply(cl, lab, box6, m8, H.LOSS_ACDC)
+    def forward(self, inputs, target, mask=None, weight=None, softmax=False):
+        if softmax:
+            inputs = torch.softmax(inputs, dim=1)
+        if target.dim() == inputs.dim():
+            assert target.shape[1] == 1, "predict & target shape do not match"
+            target = target[:, 0]
+        assert inputs.shape[1] == self.n_classes and tuple(target.shape) == (inputs.shape[0],) + tuple(inputs.shape[2:]), \
+            "predict & target shape do not match"
+        if weight is not None:
+            assert len(weight) == self.n_classes
+        inputs = inputs if inputs.dtype == torch.float32 else inputs.float()
+        ops = BU._ops_for(inputs)
+        lab = ops.to_u8(target)
+        mode, box6, m8 = 0, None, None
+        if isinstance(mask, BU.BoxMask):
+            mode, box6 = (3 if mask.complement else 2), mask.box6()
+        elif mask is not None:
+            m = mask[:, 0] if mask.dim() == inputs.dim() else mask
+            m8 = ops.to_u8(m if tuple(m.shape) == tuple(target.shape) else m.expand(target.shape))
+            mode = 1
+        return _DiceProb.apply(inputs, lab, m8, mode, box6, None if weight is None else tuple(float(w) for w in weight))
 
 
 import torch  # noqa: E402
@@ -61,6 +82,42 @@ class _DiceOnly(torch.autograd.Function):
         g_dev = torch.cat([gd, torch.zeros_like(gd)]).contiguous()
         d = ops.mixloss_bwd(logits_cl, lab, lab, box6, flavour, ws, 1.0, 1.0, mask=m8, g_dev=g_dev)
         return d, None, None, None, None
+
+
+def _dense(t):
+    """non-overlapping and dense (any dim order): what bcp_dice_prob_* address through three strides"""
+    return sum((e - 1) * st for e, st in zip(t.shape, t.stride())) + 1 == t.numel()
+
+
+def _spatial_collapses(t):
+    """the spatial dims of [N,C,*sp] form ONE index with stride t.stride(-1) (true for NCHW- and NHWC-contiguous)"""
+    exp = t.stride(-1)
+    for e, st in zip(reversed(t.shape[2:]), reversed(t.stride()[2:])):
+        if e != 1 and st != exp:
+            return False
+        exp *= e
+    return True
+
+
+class _DiceProb(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, probs, lab, m8, mode, box6, weight):
+        pd = probs.detach()
+        if not (_dense(pd) and _spatial_collapses(pd)):
+            pd = pd.contiguous()
+        ops = BU._ops_for(pd)
+        out, ws = ops.dice_prob_fwd(pd, lab, m8, mode, box6, weight)
+        ctx.save_for_backward(pd, lab, ws)
+        ctx.meta = (m8, mode, box6)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        pd, lab, ws = ctx.saved_tensors
+        m8, mode, box6 = ctx.meta
+        ops = BU._ops_for(pd)
+        d = ops.dice_prob_bwd(pd, lab, ws, m8, mode, box6, g_dev=g.reshape(1).to(torch.float32).contiguous())
+        return d, None, None, None, None, None
 
 
 def sup_loss_parts(outputs, label):

@@ -86,6 +86,21 @@ int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* pa
                     int N, int D, int H, int W, int C, int flavour, const void* workspace, float g_dice, float g_ce, const float* g_dev_or_null,
                     float* dlogits, void* stream);
 
+/* ---- utils/losses.py:79-134 `DiceLoss.forward(inputs, target, mask=None, weight=None, softmax=False)` as the CLASS the ACDC
+ *      script instantiates (ACDC_BCP_train.py:66) and calls on F.softmax(output) (:170-176): `probs` are PROBABILITIES in any
+ *      dense layout (strides in elements: channel, voxel, sample -- NCHW-contiguous: V, 1, C*V; NHWC: 1, C, V*C), per-class
+ *      sums over the WHOLE batch, squared denominators, smooth 1e-10 with a mask / 1e-5 without (:95-112), per-class weights
+ *      (HOST float[C] or NULL = ones), result / C.  mask_mode: 0 none, 1 dense uint8 [N][V] (non-zero = counted), 2 = ones
+ *      with a zero box (box6 as for bcp_mix_box), 3 = its complement.  out = float[1 + C] {loss, class_wise_dice...}.
+ *      bwd writes d(g * g_dev[0] * loss)/dprobs in the layout of `probs`.  C in 2..4. */
+size_t bcp_dice_prob_workspace_bytes(int C);
+int bcp_dice_prob_fwd(const float* probs, long long cstride, long long vstride, long long nstride, const uint8_t* target,
+                      const uint8_t* mask_or_null, int mask_mode, const int* box6 /* HOST, modes 2/3 */, int N, int D, int H, int W, int C,
+                      const float* weight_host_or_null, void* workspace, float* out, void* stream);
+int bcp_dice_prob_bwd(const float* probs, long long cstride, long long vstride, long long nstride, const uint8_t* target,
+                      const uint8_t* mask_or_null, int mask_mode, const int* box6 /* HOST */, int N, int D, int H, int W, int C,
+                      const void* workspace, const float* g_dev_or_null, float g, float* dprobs, void* stream);
+
 /* ---- norm + activation (+Dropout3d channel scale, +elementwise dropout mask, +residual)
  *      (nn.BatchNorm3d/2d train mode networks/VNet.py:18-26, networks/unet.py:21-28; nn.InstanceNorm3d pancreas/Vnet.py:93;
  *      ReLU / LeakyReLU(0.01); Dropout3d VNet.py:165,211; Dropout unet.py:23; skip add VNet.py:220-233).

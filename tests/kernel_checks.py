@@ -150,6 +150,101 @@ def check_mixloss(ops, dev, golden_dir):
         close(from_cl(dl, True), torch.from_numpy(g["g" + key]), rtol=1e-4, msg="mixloss_acdc grad " + key)
 
 
+def _acdc_mix_loss_body(dice_loss, output, img_l, patch_l, mask, l_weight=1.0, u_weight=0.5, unlab=False):
+    """the reference's ACDC mix_loss BODY as its script writes it (ACDC_BCP_train.py:167-179; `dice_loss` is the module-level
+    `losses.DiceLoss(n_classes=4)` of :66) -- only the class behind `dice_loss` is ours"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+    CE = nn.CrossEntropyLoss(reduction='none')
+    img_l, patch_l = img_l.type(torch.int64), patch_l.type(torch.int64)
+    output_soft = F.softmax(output, dim=1)
+    image_weight, patch_weight = l_weight, u_weight
+    if unlab:
+        image_weight, patch_weight = u_weight, l_weight
+    patch_mask = 1 - mask
+    loss_dice = dice_loss(output_soft, img_l.unsqueeze(1), mask.unsqueeze(1)) * image_weight
+    loss_dice += dice_loss(output_soft, patch_l.unsqueeze(1), patch_mask.unsqueeze(1)) * patch_weight
+    loss_ce = image_weight * (CE(output, img_l) * mask).sum() / (mask.sum() + 1e-16)
+    loss_ce += patch_weight * (CE(output, patch_l) * patch_mask).sum() / (patch_mask.sum() + 1e-16)
+    return loss_dice, loss_ce
+
+
+def check_diceloss_class(ops, dev, golden_dir):
+    """SURVEY 8b seam `utils.losses.DiceLoss(n)(inputs, target, mask=None, weight=None, softmax=False)`: (1) the reference's
+    ACDC mix_loss body run as written on top of it vs mixloss_acdc.npz (values 1e-5, gradient 1e-5 rel); (2) every keyword of
+    the class vs diceloss_class.npz (the reference's class, oracle/make_golden_dice.py); (3) layouts: NCHW-contiguous,
+    channels-last and BoxMask inputs give the same numbers."""
+    from bcp_amd.utils import BCP_utils as BU
+    from bcp_amd.utils import losses as L
+    if dev.type == "cpu":
+        BU.set_test_ops(ops)
+    dice_loss = L.DiceLoss(4)
+    g = np.load(f"{golden_dir}/mixloss_acdc.npz")
+    a, b, mask = (torch.from_numpy(g[k]).to(dev) for k in ("a", "b", "mask"))
+    for key, kw in (("1", dict(u_weight=0.5, unlab=True)), ("2", dict(u_weight=0.5))):
+        for cl in (False, True):
+            lo = torch.from_numpy(g["logits"]).to(dev)
+            if cl:
+                lo = lo.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)     # the networks' NHWC memory behind an NCHW shape
+            lo.requires_grad_(True)
+            d, c = _acdc_mix_loss_body(dice_loss, lo, a, b, mask, **kw)
+            ((d + c) / 2).backward()
+            d, c = float(d.detach()), float(c.detach())
+            assert abs(d - float(g["d" + key])) < 1e-5 and abs(c - float(g["c" + key])) < 1e-5, (d, c)
+            gr = torch.from_numpy(g["g" + key])
+            assert rel_l2(lo.grad, gr) < 1e-5, rel_l2(lo.grad, gr)
+            close(lo.grad, gr, rtol=1e-5, atol_scale=1e-6, msg="ACDC mix_loss body grad " + key)
+    # ... and with this build's generate_mask (six integers instead of the reference's dense int64 masks) in the same body
+    lo = torch.from_numpy(g["logits"]).to(dev).requires_grad_(True)
+    bm = BU.BoxMask((4, 6, 21, 21), (32, 32), 2, False, dev)
+    assert torch.equal(bm.tensor(dev), mask)
+    d, c = _acdc_mix_loss_body(dice_loss, lo, a, b, bm, u_weight=0.5)
+    ((d + c) / 2).backward()
+    assert abs(float(d.detach()) - float(g["d2"])) < 1e-5 and abs(float(c.detach()) - float(g["c2"])) < 1e-5
+    assert rel_l2(lo.grad, torch.from_numpy(g["g2"])) < 1e-5
+    # the class alone, every keyword
+    g = np.load(f"{golden_dir}/diceloss_class.npz")
+    logits = torch.from_numpy(g["logits"]).to(dev)
+    target, mask = torch.from_numpy(g["target"]).to(dev), torch.from_numpy(g["mask"]).to(dev)
+    weight = [float(v) for v in g["weight"]]
+    N, Cc, Hh, Ww = logits.shape
+    bm = BU.BoxMask((5, 7, 11, 18), (Hh, Ww), N, False, dev)
+    cases = (("masked", lambda p: dice_loss(p, target, mask), False),
+             ("masked", lambda p: dice_loss(p, target, mask.float()), False),                  # float masks (dataset.py hands floats around)
+             ("masked", lambda p: dice_loss(p, target, bm.unsqueeze(1)), False),               # six integers instead of a dense mask
+             ("masked_c", lambda p: dice_loss(p, target, 1 - mask), False),
+             ("masked_c", lambda p: dice_loss(p, target, (1 - bm).unsqueeze(1)), False),
+             ("nomask", lambda p: dice_loss(p, target), False),
+             ("nomask", lambda p: dice_loss(p, target[:, 0]), False),
+             ("weighted", lambda p: dice_loss(p, target, mask, weight=weight), False),
+             ("softmax", lambda x: dice_loss(x, target, mask, softmax=True), True))
+    for name, fn, on_logits in cases:
+        for cl in (False, True):
+            leaf = logits if on_logits else torch.softmax(logits, dim=1)
+            if cl:
+                leaf = leaf.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            leaf = leaf.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+            v = fn(leaf)
+            v.backward()
+            assert abs(float(v.detach()) - float(g[name])) < 1e-5, (name, float(v.detach()), float(g[name]))
+            gr = torch.from_numpy(g["g_" + name])
+            assert rel_l2(leaf.grad, gr) < 1e-5, (name, cl, rel_l2(leaf.grad, gr))
+    with pytest_raises(AssertionError):
+        dice_loss(torch.softmax(logits, 1)[:, :3], target)
+
+
+class pytest_raises:
+    def __init__(self, exc):
+        self.exc = exc
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, t, v, tb):
+        assert t is not None and issubclass(t, self.exc), f"expected {self.exc.__name__}"
+        return True
+
+
 def check_norm(ops, dev):
     rng = np.random.default_rng(4)
     for (N, Cc, sp, act, use_cs, use_res, G) in ((2, 16, (4, 6, 8), H.ACT_RELU, True, True, 1), (1, 64, (2, 4, 4), H.ACT_RELU, False, False, 1),
@@ -1188,4 +1283,4 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6"); ops.set_option("conv3_b6_cfg2d64")
 
 
-ALL_CHECKS = ("conv3_pipe_cold", "conv3_c1_norm", "norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+ALL_CHECKS = ("diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")

@@ -37,7 +37,7 @@ EXTENDED_EMU = {"norm_small", "conv3_b6", "conv3_res", "dgrad_bwdstats"}
 @pytest.mark.parametrize("name", [pytest.param(n, marks=pytest.mark.extended) if n in EXTENDED_EMU else n for n in K.ALL_CHECKS])
 def test_emu(emu_ops, golden_dir, name):
     fn = getattr(K, "check_" + name)
-    if name in ("plabel", "cc", "mixloss", "augment", "augment_acdc", "augment_pancreas"):
+    if name in ("diceloss_class", "plabel", "cc", "mixloss", "augment", "augment_acdc", "augment_pancreas"):
         fn(emu_ops, torch.device("cpu"), golden_dir)
     else:
         fn(emu_ops, torch.device("cpu"))

@@ -20,7 +20,7 @@ def gpu_ops():
 def test_kernel(gpu_ops, golden_dir, name):
     fn = getattr(K, "check_" + name)
     dev = torch.device("cuda:0")
-    if name in ("plabel", "cc", "mixloss", "augment", "augment_acdc", "augment_pancreas"):
+    if name in ("diceloss_class", "plabel", "cc", "mixloss", "augment", "augment_acdc", "augment_pancreas"):
         fn(gpu_ops, dev, golden_dir)
     else:
         fn(gpu_ops, dev)
