@@ -51,13 +51,13 @@ _SIGS = {
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
     "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, P]),
     "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, I, P, P]),
-    "bcp_norm_small_ok": (I, [I, L, I]),
-    "bcp_norm_fwd_small": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P]),
-    "bcp_norm_bwd_small": (I, [P, P, I, L, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P]),
+    "bcp_norm_slabs_ok": (I, [I, L, I]),
+    "bcp_norm_fwd_slabs": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P]),
+    "bcp_norm_bwd_slabs": (I, [P, P, I, L, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, P]),
     "bcp_conv3_fwd_nslabs": (I, [I, I, I, I, I, I, I]),
     "bcp_conv3_bwdstat_rows": (I, [I, I, I, I, I, I, I, I]),
     "bcp_conv3_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, I, P]),
-    "bcp_conv3_fwd_raw": (I, [P, P, P, I, I, I, I, I, I, I, P]),
+    "bcp_conv3_fwd_raw": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
     "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
     "bcp_conv3_fwd_path": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_wgrad_path": (SZ, [I, I, I, I, I, I, I]),
@@ -187,9 +187,10 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_small_ok", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
         self._rec = None          # a bcp_amd.plan.LaunchPlan while a network pass is being recorded
+        self.options_epoch = 0    # bumped by set_option: cached shape queries (hip_ops.Ops._ws_bytes) are keyed on it
 
     def last_error(self) -> str:
         return self.cdll.bcp_last_error().decode("utf-8", "replace")
@@ -199,6 +200,7 @@ class Binding:
         if isinstance(value, (tuple, list)):
             value = ",".join(str(int(v)) for v in value)
         self.call("bcp_set_option", name.encode(), str(value).encode())
+        self.options_epoch += 1
         from . import plan
         plan.invalidate_all()      # recorded launch plans carry the kernel choices and workspace sizes of the old options
 

@@ -62,7 +62,7 @@ struct Options {
   int conv3_b6_cfg64 = 0;   // measurements: tile / slab variant of the 64-channel bf16-pipe instances
   int wgrad_b6 = 1;         // weight gradient on the bf16 matrix pipe (conv3bw.hip): 0 off, 1 where measured faster, 2 wherever valid.  LA step (interleaved A/B): off 7.82 ms, 32/64-channel levels 7.52, + 128-channel level 7.38
   int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)
-  int norm_small = 0;       // groups of <= 4096 rows (deep levels): statistics + finalize + apply (+ the split-K slab sum) in ONE launch (k_norm_small_*) instead of 3-5.  OFF by default -- measured slower (round 3): a workgroup that owns four channels of every row touches one cache line per lane (TA-bound: 31 us for 8 MB) while the back-to-back chain it replaces costs 12 us; LA step 6.67 vs 6.54 ms
+  int norm_slabs = 1;       // deep levels (<= 4096 rows per group): the conv leaves its raw split-K slabs and the norm's row-major statistics pass sums them on its way in (bcp_norm_fwd_slabs / _bwd_slabs): no k_b6_sum_slabs launch (27 per LA step).  0: slab-sum launches (round 3)
   int fuse_bwd_stats = 1;   // dgrad epilogue of the bf16-pipe kernels accumulates the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): no k_col_partial<1> pass over (y, da) for conv -> conv edges
   int conv3_stagger = 0;    // bf16-pipe kernels: workgroups whose linear id has bit conv3_stagger_bit set start ~0.9 us x this late (s_sleep): de-phases the two workgroups of a CU so that one's halo / weight / store phases fall into the other's MFMA phase (measured additive otherwise: 47.8 us MFMA + LDS loop + 20.8 us everything else = 71.9 us at the 32-channel level)
   int conv3_stagger_bit = 8;

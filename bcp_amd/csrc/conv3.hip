@@ -1419,7 +1419,7 @@ extern "C" int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, 
 }
 
 // Raw variant for the deep levels: the kernel's split-K partial slabs are the RESULT -- float[nslabs][N*D*H*W*Cout], no bias, no
-// slab-sum launch; bcp_norm_fwd_small / bcp_norm_bwd_small sum them (and add the bias) on their way in.  bcp_conv3_fwd_nslabs tells
+// slab-sum launch; bcp_norm_fwd_slabs / bcp_norm_bwd_slabs sum them (and add the bias) on their way in.  bcp_conv3_fwd_nslabs tells
 // how many slabs the launch will write for this shape under the current options (1..8), or 0: shape not served in raw mode (use
 // bcp_conv3_fwd).  Forward and dgrad alike (dgrad = the flipped pack).
 extern "C" int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD) {
@@ -1434,8 +1434,8 @@ extern "C" int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cou
   return handled ? sk : 0;
 }
 
-extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int N, int D, int H, int W, int Cin, int Cout, int KD,
-                                 void* stream) {
+extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int nslab, int N, int D, int H, int W, int Cin, int Cout,
+                                 int KD, void* stream) {
   BCP_REQUIRE(x && wp && slabs, "bcp_conv3_fwd_raw: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd_raw: bad extents");
   BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd_raw: KD=1 needs D=1");
@@ -1446,8 +1446,14 @@ extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, 
   fill_dims(cd, N, D, H, W, Cin, Cout);
   bool handled = false;
   int sk = 0;
-  b6_fwd(x, wp, nullptr, slabs, cd, KD, 0, slabs, nullptr, 0, false, (hipStream_t)stream, &handled, &sk);
+  // the caller sized `slabs` for nslab slabs: the count the launch will write under the CURRENT options must be that one (a count
+  // cached under other options would be a device buffer overflow) -- dry run first, nothing is launched on a mismatch
+  b6_fwd(nullptr, nullptr, nullptr, slabs, cd, KD, 0, slabs, nullptr, 0, true, nullptr, &handled, &sk);
   BCP_REQUIRE(handled && sk > 0, "bcp_conv3_fwd_raw: shape not served in raw mode (check bcp_conv3_fwd_nslabs first)");
+  BCP_REQUIRE(sk == nslab, "bcp_conv3_fwd_raw: the launch writes %d slabs under the current options, the caller allocated %d (stale bcp_conv3_fwd_nslabs answer?)", sk, nslab);
+  handled = false;
+  b6_fwd(x, wp, nullptr, slabs, cd, KD, 0, slabs, nullptr, 0, false, (hipStream_t)stream, &handled, &sk);
+  BCP_REQUIRE(handled && sk == nslab, "bcp_conv3_fwd_raw: shape not served in raw mode (check bcp_conv3_fwd_nslabs first)");
   BCP_CHECK_LAUNCH("bcp_conv3_fwd_raw");
   return BCP_OK;
 }

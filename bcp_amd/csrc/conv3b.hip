@@ -1775,7 +1775,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
   if (raw_sk) {
     // raw mode (bcp_conv3_fwd_raw): the sk partial slabs go to Y = float[sk][N*D*H*W*Cout] and stay there -- no bias, no slab sum, no
-    // statistics; the consumer (bcp_norm_fwd_small / bcp_norm_bwd_small) sums them on its way in
+    // statistics; the consumer (bcp_norm_fwd_slabs / bcp_norm_bwd_slabs) sums them on its way in
     *raw_sk = sk;
     if (dry) return 0;
     StatsArg none{nullptr, 0, 1, cd.Cout, 1};

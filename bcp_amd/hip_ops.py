@@ -70,8 +70,10 @@ class Ops:
         return None
 
     def _ws_bytes(self, fn, *args):
-        """`*_workspace_bytes` answers depend on the shape only: one ctypes round trip per distinct shape"""
-        key = (fn,) + args
+        """size / shape queries: one ctypes round trip per distinct (options epoch, shape).  Several answers depend on the library's
+        options (split-K slab counts, fused-statistics rows): the binding counts its set_option calls, so a query cached under other
+        options -- also when someone went through Binding.set_option directly -- is never reused"""
+        key = (self.b.options_epoch, fn) + args
         v = self._wsz.get(key)
         if v is None:
             v = self._wsz[key] = int(self.b.call(fn, *args))
@@ -287,10 +289,10 @@ class Ops:
         return out
 
 
-    # ------------------------------------------------------------------ small groups (deep levels): the norm in ONE launch
-    def norm_small_ok(self, G, rows_per_group, Cc):
-        """True when bcp_norm_fwd_small / bcp_norm_bwd_small serve this shape (rows per group <= 4096, option norm_small)"""
-        return bool(self._ws_bytes("bcp_norm_small_ok", int(G), int(rows_per_group), int(Cc)))
+    # ------------------------------------------------------------------ deep levels: the norm takes the conv's raw split-K slabs
+    def norm_slabs_ok(self, G, rows_per_group, Cc):
+        """True when bcp_norm_fwd_slabs / bcp_norm_bwd_slabs serve this shape (rows per group <= 4096, option norm_slabs)"""
+        return bool(self._ws_bytes("bcp_norm_slabs_ok", int(G), int(rows_per_group), int(Cc)))
 
     def conv3_nslabs(self, xshape, Cout, KD):
         """split-K slabs bcp_conv3_fwd_raw writes for this shape; 0: not served in raw mode"""
@@ -299,17 +301,17 @@ class Ops:
 
     def conv3_fwd_raw(self, x, wp, Cout, KD, nslab):
         """conv (forward or dgrad) whose split-K partial slabs ARE the result: float32 [nslab, N, D, H, W, Cout], no bias; the
-        consumer (norm_fwd_small / norm_bwd_small) sums them on its way in"""
+        consumer (norm_fwd_slabs / norm_bwd_slabs) sums them on its way in"""
         self._chk(x, wp)
         N, D, H, W, Cin = x.shape
         slabs = torch.empty((nslab, N, D, H, W, Cout), dtype=torch.float32, device=x.device)
-        self.b.call("bcp_conv3_fwd_raw", _p(x), _p(wp), _p(slabs), N, D, H, W, Cin, Cout, KD, self.stream(x))
+        self.b.call("bcp_conv3_fwd_raw", _p(x), _p(wp), _p(slabs), int(nslab), N, D, H, W, Cin, Cout, KD, self.stream(x))
         return slabs
 
-    def norm_fwd_small(self, src, nslab, bias, G, gamma, beta, rmean, rvar, act, chan_scale=None, elem_mask=None, elem_scale=1.0,
+    def norm_fwd_slabs(self, src, nslab, bias, G, gamma, beta, rmean, rvar, act, chan_scale=None, elem_mask=None, elem_scale=1.0,
                        residual=None, momentum=0.1, eps=1e-5, stats_only=False):
-        """src: y [N,D,H,W,C] (nslab == 1, bias None) or raw conv slabs [nslab,N,D,H,W,C] (+ the conv bias) -> (a, stats, y):
-        slab sum + bias, statistics, finalize and apply in one launch (k_norm_small_fwd)"""
+        """src: raw conv slabs [nslab,N,D,H,W,C] (+ the conv bias) -> (a, stats, y): the statistics pass sums the slabs (+ bias) on its way
+        in and writes y once; finalize and apply as bcp_norm_fwd"""
         self._chk(src, bias, gamma, beta, rmean, rvar, chan_scale, elem_mask, residual)
         shape = tuple(src.shape[1:]) if src.dim() == 6 else tuple(src.shape)
         N, Cc = shape[0], shape[-1]
@@ -318,31 +320,28 @@ class Ops:
             n *= d
         rows = n // Cc
         rpg, rps = rows // G, rows // N
-        if src.dim() == 6 or bias is not None:
-            y = torch.empty(shape, dtype=torch.float32, device=src.device)
-            ysum = y
-        else:
-            y, ysum = src, None
+        y = torch.empty(shape, dtype=torch.float32, device=src.device)
         stats = torch.empty((5, G, Cc), dtype=torch.float32, device=src.device)
         out = None if stats_only else torch.empty(shape, dtype=torch.float32, device=src.device)
-        self.b.call("bcp_norm_fwd_small", _p(src), int(nslab), n, _p(bias), _p(ysum), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar),
-                    float(momentum), float(eps), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(out),
-                    self.stream(src))
+        ws = self.workspace("norm", self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc), src)
+        self.b.call("bcp_norm_fwd_slabs", _p(src), int(nslab), n, _p(bias), _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar),
+                    float(momentum), float(eps), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws),
+                    _p(out), self.stream(src))
         return out, stats, y
 
-    def norm_bwd_small(self, y, da_src, nslab, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
-                       elem_scale=1.0, want_da=False):
-        """da_src: da [N,D,H,W,C] or the dgrad's raw slabs [nslab,N,D,H,W,C] -> (dy, da or None): one launch (k_norm_small_bwd)"""
+    def norm_bwd_slabs(self, y, da_src, nslab, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
+                       elem_scale=1.0):
+        """da_src: the dgrad's raw slabs [nslab,N,D,H,W,C] -> (dy, da): the backward-statistics pass sums the slabs and writes da once"""
         self._chk(y, da_src, stats, dgamma, dbeta, chan_scale, elem_mask)
         N, Cc = y.shape[0], y.shape[-1]
         rows = y.numel() // Cc
         rpg, rps = rows // G, rows // N
         dy = torch.empty_like(y)
-        da = None
-        if want_da:
-            da = torch.empty_like(y) if da_src.dim() == 6 else da_src
-        self.b.call("bcp_norm_bwd_small", _p(y), _p(da_src), int(nslab), y.numel(), _p(da if da_src.dim() == 6 else None), G, rpg, Cc, _p(stats), act,
-                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(dy), self.stream(y))
+        da = torch.empty_like(y)
+        ws = self.workspace("norm", self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc), y)
+        self.b.call("bcp_norm_bwd_slabs", _p(y), _p(da_src), int(nslab), y.numel(), _p(da), G, rpg, Cc, _p(stats), act,
+                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy),
+                    self.stream(y))
         return dy, da
 
     # ------------------------------------------------------------------ 3x3(x3) conv
@@ -728,7 +727,7 @@ class Ops:
 # ---------------------------------------------------------------------------------------------- measurement hooks
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
-_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_small", "norm_bwd_small", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "conv3_pack_many",
+_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "conv3_pack_many",
              "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")

@@ -194,11 +194,11 @@ class VNet(HipNet):
             part, nb = None, 0
             if L.skip_push:
                 skips.append(h)
-            # deep levels (<= 4096 rows per normalisation group): the conv leaves its split-K slabs and ONE kernel sums them, adds the
-            # bias, takes the statistics, finalises and applies them (bcp_norm_fwd_small) -- 2 launches per layer instead of 5
+            # deep levels (<= 4096 rows per normalisation group) whose conv runs split-K: the conv leaves its raw slabs and the norm's
+            # statistics pass sums them (+ bias) on its way in (bcp_norm_fwd_slabs) -- no slab-sum launch; decided per layer below
             sp = h.shape[1] * h.shape[2] * h.shape[3]
-            sp_out = sp // 8 if L.kind == "dw" else (sp * 8 if L.kind == "up" else sp)
-            small = self.training and not (li == last and fuse_head) and ops.norm_small_ok(G, N * sp_out // G, L.cout)
+            slabs_ok = (self.training and L.kind == "c3" and not (li == last and fuse_head) and ops.norm_slabs_ok(G, N * sp // G, L.cout))
+            small = False
             src, nsl, bsrc = None, 1, None
             fused_c1 = False
             if L.kind == "c1":
@@ -212,11 +212,9 @@ class VNet(HipNet):
                     y = ops.conv3_c1_fwd(h, w.data, b.data, 3)
             elif L.kind == "c3":
                 wf, _ = self.conv3_packed(("c3", li), save)
-                sk = ops.conv3_nslabs(h.shape, L.cout, 3) if small else 0
-                if sk > 0:
-                    src, nsl, bsrc = ops.conv3_fwd_raw(h, wf, L.cout, 3, sk), sk, b.data
-                elif small:
-                    y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)
+                sk = ops.conv3_nslabs(h.shape, L.cout, 3) if slabs_ok else 0
+                if sk > 1:
+                    src, nsl, bsrc, small = ops.conv3_fwd_raw(h, wf, L.cout, 3, sk), sk, b.data, True
                 elif self.training or L.bn is None:
                     y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
                 else:
@@ -235,7 +233,7 @@ class VNet(HipNet):
                                                                               if bn is not None else (None,) * 4), H.ACT_RELU)
             elif small:
                 bn = L.bn
-                a, stats, y = ops.norm_fwd_small(y if src is None else src, nsl, bsrc, G,
+                a, stats, y = ops.norm_fwd_slabs(src, nsl, bsrc, G,
                                                  *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var) if bn is not None else (None,) * 4),
                                                  H.ACT_RELU, chan_scale=cs, residual=res)
             elif li == last and fuse_head:
@@ -302,11 +300,10 @@ class VNet(HipNet):
             if y is None:       # the fused first layer: its pre-norm tensor is recomputed from the input (bcp_conv3_c1_norm_bwd)
                 assert L.kind == "c1" and nsl == 1
                 dy = ops.conv3_c1_norm_bwd(x_in, w.data, L.conv.bias.data, 3, G, stats, da, H.ACT_RELU, dg, db, L.bn is not None)
-            elif ops.norm_small_ok(G, y.numel() // (y.shape[-1] * G), y.shape[-1]):
-                # deep levels: slab sum + statistics + apply in one launch (bcp_norm_bwd_small)
-                dy, da = ops.norm_bwd_small(y, da, nsl, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs, want_da=L.skip_pop)
+            elif nsl > 1:
+                # deep levels: dh is the raw split-K slabs of the dgrad that produced it; the backward-statistics pass sums them (bcp_norm_bwd_slabs)
+                dy, da = ops.norm_bwd_slabs(y, da, nsl, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs)
             else:
-                assert nsl == 1
                 dy = ops.norm_bwd(y, da, G, stats, H.ACT_RELU, dg, db, L.bn is not None, chan_scale=cs, partial=bpart, nb=bnb)
             nsl, bpart, bnb = 1, None, 0
             if L.skip_pop:
@@ -329,10 +326,11 @@ class VNet(HipNet):
                 dh = None
             elif L.kind == "c3":
                 _, wd = self.conv3_packed(("c3", li), True)
-                # the consumer of this dgrad is the previous layer's norm backward: when that one runs as the one-launch kernel, it
-                # takes the raw split-K slabs (no slab-sum launch)
-                sk = ops.conv3_nslabs(dy.shape, L.cin, 3) if ops.norm_small_ok(G, x_in.numel() // (L.cin * G), L.cin) else 0
-                if sk > 0:
+                # the consumer of this dgrad is the previous layer's norm backward: at the deep levels it takes the raw split-K slabs
+                # (no slab-sum launch); the previous layer must have a pre-norm tensor of its own (not the recomputing first layer)
+                sk = (ops.conv3_nslabs(dy.shape, L.cin, 3) if li > 0 and saved[li - 1][1] is not None
+                      and ops.norm_slabs_ok(G, x_in.numel() // (L.cin * G), L.cin) else 0)
+                if sk > 1:
                     dh, nsl = ops.conv3_fwd_raw(dy, wd, L.cin, 3, sk), sk
                 elif li > 0 and saved[li - 1][3] is None:
                     # conv -> conv edge without a dropout epilogue: the dgrad epilogue leaves the previous norm layer's backward statistics

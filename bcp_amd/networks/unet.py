@@ -119,47 +119,40 @@ class UNet_2d(HipNet):
             return ops.norm_eval(y2, cb.b2.weight.data, cb.b2.bias.data, cb.b2.running_mean, cb.b2.running_var, H.ACT_LRELU)
         N, _, Hh, Ww, _ = h.shape
         oshape = (N, 1, Hh, Ww, cb.cout)
-        # deepest level (<= 4096 rows per group): raw split-K slabs + ONE norm launch per layer (networks/VNet.py, bcp_norm_fwd_small)
-        small = ops.norm_small_ok(G, N * Hh * Ww // G, cb.cout)
+        # deepest level (<= 4096 rows per group) with split-K convs: the conv leaves its raw slabs and the norm's statistics pass sums them
+        # on its way in (networks/VNet.py, bcp_norm_fwd_slabs) -- no slab-sum launch
+        slabs_ok = ops.norm_slabs_ok(G, N * Hh * Ww // G, cb.cout)
         es = 1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0
         em = self._elem_mask(cb, oshape, h.device)
         b1, b2 = cb.b1, cb.b2
         part1, nb1 = None, 0
         src, nsl, bsrc = None, 1, None
-        fused_c1 = (cb.cin == 1 and self.fuse_c1 and not small and not getattr(self, "_keep_saved", False) and ops.conv3_c1_norm_ok(h.shape, 1, G))
+        fused_c1 = (cb.cin == 1 and self.fuse_c1 and not getattr(self, "_keep_saved", False) and ops.conv3_c1_norm_ok(h.shape, 1, G))
         if fused_c1:
             y1 = None      # conv + norm + LeakyReLU + dropout with recompute (bcp_conv3_c1_norm_fwd): y1 is never written
         elif cb.cin == 1:
-            if small:
-                y1 = ops.conv3_c1_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1)
-            else:
-                y1, part1, nb1 = ops.conv3_c1_fwd_stats(h, cb.c1.weight.data, cb.c1.bias.data, 1, G)
+            y1, part1, nb1 = ops.conv3_c1_fwd_stats(h, cb.c1.weight.data, cb.c1.bias.data, 1, G)
         else:
             wf, _ = self.conv3_packed((tag, 1), save)
-            sk = ops.conv3_nslabs(h.shape, cb.cout, 1) if small else 0
-            if sk > 0:
+            sk = ops.conv3_nslabs(h.shape, cb.cout, 1) if slabs_ok else 0
+            if sk > 1:
                 src, nsl, bsrc = ops.conv3_fwd_raw(h, wf, cb.cout, 1, sk), sk, cb.c1.bias.data
-            elif small:
-                y1 = ops.conv3_fwd(h, wf, cb.c1.bias.data, cb.cout, 1)
             else:
                 y1, part1, nb1 = ops.conv3_fwd_stats(h, wf, cb.c1.bias.data, cb.cout, 1, G)
         if fused_c1:
             a1, st1 = ops.conv3_c1_norm_fwd(h, cb.c1.weight.data, cb.c1.bias.data, 1, G, b1.weight.data, b1.bias.data, b1.running_mean, b1.running_var,
                                             H.ACT_LRELU, elem_mask=em, elem_scale=es)
-        elif small:
-            a1, st1, y1 = ops.norm_fwd_small(y1 if src is None else src, nsl, bsrc, G, b1.weight.data, b1.bias.data, b1.running_mean, b1.running_var,
+        elif src is not None:
+            a1, st1, y1 = ops.norm_fwd_slabs(src, nsl, bsrc, G, b1.weight.data, b1.bias.data, b1.running_mean, b1.running_var,
                                              H.ACT_LRELU, elem_mask=em, elem_scale=es)
         else:
             a1, st1 = ops.norm_fwd(y1, G, b1.weight.data, b1.bias.data, b1.running_mean, b1.running_var, H.ACT_LRELU,
                                    elem_mask=em, elem_scale=es, partial=part1, nb=nb1)
         wf2, _ = self.conv3_packed((tag, 2), save)
-        sk = ops.conv3_nslabs(a1.shape, cb.cout, 1) if small else 0
-        if sk > 0:
-            a2, st2, y2 = ops.norm_fwd_small(ops.conv3_fwd_raw(a1, wf2, cb.cout, 1, sk), sk, cb.c2.bias.data, G, b2.weight.data, b2.bias.data,
+        sk = ops.conv3_nslabs(a1.shape, cb.cout, 1) if slabs_ok else 0
+        if sk > 1:
+            a2, st2, y2 = ops.norm_fwd_slabs(ops.conv3_fwd_raw(a1, wf2, cb.cout, 1, sk), sk, cb.c2.bias.data, G, b2.weight.data, b2.bias.data,
                                              b2.running_mean, b2.running_var, H.ACT_LRELU)
-        elif small:
-            y2 = ops.conv3_fwd(a1, wf2, cb.c2.bias.data, cb.cout, 1)
-            a2, st2, y2 = ops.norm_fwd_small(y2, 1, None, G, b2.weight.data, b2.bias.data, b2.running_mean, b2.running_var, H.ACT_LRELU)
         else:
             y2, part2, nb2 = ops.conv3_fwd_stats(a1, wf2, cb.c2.bias.data, cb.cout, 1, G)
             a2, st2 = ops.norm_fwd(y2, G, b2.weight.data, b2.bias.data, b2.running_mean, b2.running_var, H.ACT_LRELU, partial=part2, nb=nb2)
@@ -170,30 +163,24 @@ class UNet_2d(HipNet):
     def _convblock_bwd(self, cb, tag, da2, saved, need_dx):
         ops = self.ops
         h, y1, st1, em, a1, y2, st2, G = saved[tag]
-        small = ops.norm_small_ok(G, y2.numel() // (cb.cout * G), cb.cout)
-        if small:
-            dy2, _ = ops.norm_bwd_small(y2, da2, 1, G, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
-        else:
-            dy2 = ops.norm_bwd(y2, da2, G, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
+        dy2 = ops.norm_bwd(y2, da2, G, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
         with self._wgrad_stream(dy2, a1):      # weight gradients run underneath the dgrad -> norm_bwd chain (VNet.py)
             ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
         _, wd2 = self.conv3_packed((tag, 2), True)
         es = 1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0
-        sk = ops.conv3_nslabs(dy2.shape, cb.cout, 1) if small else 0
-        if sk > 0:      # the dgrad's raw slabs go straight into the one-launch norm backward
-            dy1, _ = ops.norm_bwd_small(y1, ops.conv3_fwd_raw(dy2, wd2, cb.cout, 1, sk), sk, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad,
+        sk = (ops.conv3_nslabs(dy2.shape, cb.cout, 1) if y1 is not None and ops.norm_slabs_ok(G, y2.numel() // (cb.cout * G), cb.cout) else 0)
+        if sk > 1:      # deepest level: the dgrad's raw split-K slabs are summed by the norm backward's statistics pass (bcp_norm_bwd_slabs)
+            dy1, _ = ops.norm_bwd_slabs(y1, ops.conv3_fwd_raw(dy2, wd2, cb.cout, 1, sk), sk, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad,
                                         True, elem_mask=em, elem_scale=es)
         else:
             bpart, bnb = None, 0
-            if em is None and not small and y1 is not None:       # no dropout between the two convs: the dgrad epilogue leaves b1's backward statistics
+            if em is None and y1 is not None:       # no dropout between the two convs: the dgrad epilogue leaves b1's backward statistics
                 da1, bpart, bnb = ops.conv3_dgrad_bwdstats(dy2, wd2, cb.cout, 1, y1, st1, H.ACT_LRELU, G)
             else:
                 da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
             if y1 is None:     # the fused first layer: y1 is recomputed from the block's input (bcp_conv3_c1_norm_bwd)
                 dy1 = ops.conv3_c1_norm_bwd(h, cb.c1.weight.data, cb.c1.bias.data, 1, G, st1, da1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True,
                                             elem_mask=em, elem_scale=es)
-            elif small:
-                dy1, _ = ops.norm_bwd_small(y1, da1, 1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em, elem_scale=es)
             else:
                 dy1 = ops.norm_bwd(y1, da1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em, elem_scale=es,
                                    partial=bpart, nb=bnb)

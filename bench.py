@@ -90,11 +90,11 @@ def _work(name, shapes, ints):
         fl = 2.0 * min(_numel(s0[:-1]), _numel(shapes[1][:-1])) * 8 * s0[-1] * shapes[1][-1]
         by = 4.0 * (_numel(s0) + _numel(shapes[1]))
         return ("hbm" if fl / by < 20 else "mfma"), fl, by
-    if name == "norm_fwd_small":                           # (slabs [nslab, ...] | y, ...); ints = (nslab, G, act): read the slabs, write y and a
+    if name == "norm_fwd_slabs":                           # (slabs [nslab, ...] | y, ...); ints = (nslab, G, act): read the slabs, write y and a
         nsl = ints[0] if ints else 1
         n = _numel(s0) // (nsl if len(s0) == 6 else 1)
         return "hbm", 0.0, 4.0 * n * ((nsl if len(s0) == 6 else 1) + 2)
-    if name == "norm_bwd_small":                           # (y, da slabs | da, ...): read y and the slabs, write dy
+    if name == "norm_bwd_slabs":                           # (y, da slabs | da, ...): read y and the slabs, write dy
         s1 = shapes[1] if len(shapes) > 1 else s0
         return "hbm", 0.0, 4.0 * (2 * _numel(s0) + _numel(s1))
     if name == "norm_fwd":                                 # statistics (fused into the conv when possible) + apply: read y twice, write a

@@ -43,7 +43,7 @@ int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
  * (csrc/common.h: conv3_p, splitk, res_pcu, res_nt, res_tile2d_vox, conv3_cfg, wgrad_nt, wgrad_tile, tn_groups, cc_tile,
- * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles; norm_small, conv3_xcd); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
+ * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles; norm_slabs, conv3_xcd); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
  * HOST strings.  NOT thread-safe and not per-stream: ONE Options struct per process, read by every launch on every stream and
  * device.  Set options before work is enqueued, never concurrently with launches from another thread (the launch entry points
  * themselves are re-entrant across streams / devices as long as the options stay put). */
@@ -120,23 +120,25 @@ int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_grou
  * skipped (not available together with chan_scale / elem_mask).  Producer: bcp_conv3_dgrad_bwdstats (round 3: the epilogue of the
  * bf16-pipe dgrad kernels, where the extra vector work overlaps the matrix pipe). */
 
-/* One-launch variants for SMALL groups (rows_per_group <= 4096: the 128- / 256-channel levels of the V-Nets, the U-Net's
- * deepest level -- networks/VNet.py:74-86,101-113 block_four .. block_six, networks/unet.py down4 / up1): a workgroup owns four
- * channels of a group for all its rows and keeps them in registers, so statistics, their finalisation and the apply pass (and
- * the sum of the producing conv's split-K slabs + its bias) are ONE kernel instead of three to five ~5 us launches on the
- * step's critical path.  Same per-element arithmetic as bcp_norm_fwd / bcp_norm_bwd (fp64 statistics, summed in a different
- * fixed order).  bcp_norm_small_ok: 1 when the shape is served (and option norm_small is on).
- *   fwd: slabs = float[nslab][slab_stride] (nslab = 1: y itself); y = bias + slab 0 + slab 1 + ... is written to ysum_or_null
- *        (required when nslab > 1 or a bias is given); out_or_null = NULL: statistics only.
- *   bwd: da = sum of da_slabs (nslab = 1: da itself), written to da_sum_or_null when the caller needs it (skip connections). */
-int bcp_norm_small_ok(int G, long long rows_per_group, int C);
-int bcp_norm_fwd_small(const float* slabs, int nslab, long long slab_stride, const float* bias_or_null, float* ysum_or_null, int G,
+/* Deep levels (rows_per_group <= 4096: the 128- / 256-channel levels of the V-Nets, the U-Net's deepest level --
+ * networks/VNet.py:74-86,101-113 block_four .. block_six, networks/unet.py down4 / up1): the producing conv leaves its raw split-K
+ * slabs (bcp_conv3_fwd_raw) and the ROW-MAJOR statistics pass of the norm sums them on its way in (bias first, then the slabs front
+ * to back -- bit-identical to the slab-sum launch it replaces) and writes the sum once for the apply pass: one launch and one
+ * round trip of the tensor fewer per layer on the step's critical path.  Same kernels and arithmetic as bcp_norm_fwd / bcp_norm_bwd
+ * otherwise.  bcp_norm_slabs_ok: 1 when the shape is served (and option norm_slabs is on, the default).
+ *   fwd: slabs = float[nslab][slab_stride] (nslab = 1: y itself); ysum = bias + slab 0 + slab 1 + ... (always written);
+ *        out_or_null = NULL: statistics only.
+ *   bwd: da_sum = sum of da_slabs (always written; it is also the gradient a skip connection forwards).
+ * (Round 3's one-launch form of these -- a workgroup owning four channels of every row, TA-bound -- lives in tools/attic/norm_small.hip.) */
+int bcp_norm_slabs_ok(int G, long long rows_per_group, int C);
+int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_stride, const float* bias_or_null, float* ysum, int G,
                        long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
-                       float elem_scale, const float* residual, float* stats, float* out_or_null, void* stream);
-int bcp_norm_bwd_small(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum_or_null, int G,
+                       float elem_scale, const float* residual, float* stats, void* workspace, float* out_or_null, void* stream);
+int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum, int G,
                        long long rows_per_group, int C, const float* stats, int act, const float* chan_scale, long long rows_per_sample,
-                       const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta, int accumulate, float* dy, void* stream);
+                       const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy,
+                       void* stream);
 
 /* ---- 3x3x3 / 3x3 convolution, pad 1 (nn.Conv3d networks/VNet.py:17, nn.Conv2d networks/unet.py:19-25) on fp32 MFMA.
  *      KD = 3 (3-D) or 1 (2-D, D = 1).  Weights are packed once per optimizer step from the torch layout
@@ -168,10 +170,12 @@ int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, 
                              const float* y_prev, const float* stats_prev, int act, void* workspace_or_null, double* stat_partial,
                              int groups, void* stream);
 /* raw variant for the deep levels: the kernel's split-K partial slabs are the result -- slabs = float[nslabs][N*D*H*W*Cout], no bias,
- * no slab-sum launch; bcp_norm_fwd_small / bcp_norm_bwd_small sum them on their way in.  nslabs = bcp_conv3_fwd_nslabs(...) under the
- * current options (1..8; 0: shape not served in raw mode -> bcp_conv3_fwd).  Forward and dgrad alike. */
+ * no slab-sum launch; bcp_norm_fwd_slabs / bcp_norm_bwd_slabs sum them on their way in.  nslabs = bcp_conv3_fwd_nslabs(...) under the
+ * current options (1..8; 0: shape not served in raw mode -> bcp_conv3_fwd).  Forward and dgrad alike.  bcp_conv3_fwd_raw is told how
+ * many slabs the caller allocated and refuses (nothing launched) when the launch would write a different number. */
 int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD);
-int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int N, int D, int H, int W, int Cin, int Cout, int KD, void* stream);
+int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int nslab, int N, int D, int H, int W, int Cin, int Cout, int KD,
+                      void* stream);
 /* which matrix pipe serves bcp_conv3_fwd / bcp_conv3_fwd_stats for this shape under the current options (no launch): 0 = fp32 MFMA
  * (v_mfma_f32_16x16x4_f32), 1 = bf16 MFMA with three-piece operands (fp32-equivalent results; csrc/conv3b.hip).  Measurement record only. */
 size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Cout, int KD);

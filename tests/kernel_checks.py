@@ -907,22 +907,16 @@ def check_conv3_stats(ops, dev):
         close(a1, a2, rtol=1e-6, msg="norm from fused partials")
 
 
-def check_norm_small(ops, dev):
-    """one-launch norm for small groups (bcp_norm_fwd_small / _bwd_small) + raw split-K conv slabs (bcp_conv3_fwd_raw):
-    (a) against torch (BatchNorm / grouped BatchNorm / InstanceNorm, every epilogue), (b) against the streaming three-kernel chain
-    on the same inputs: y / da sums bit-identical to the slab-sum kernel, activations and gradients equal to fp64-statistics rounding,
-    (c) conv -> slabs -> fused norm == conv3_fwd_stats -> norm_fwd, forward and dgrad, split-K forced to 1 / 2 / 4"""
-    ops.set_option("norm_small", 1)          # (off by default since round 3's measurements: DESIGN.md 8.6; the entry points stay and stay tested)
-    try:
-        _check_norm_small(ops, dev)
-        ops.set_option("conv3_b6_flatd", 1)  # the same conv -> slabs -> norm chains with the flat direct-weight deep-level kernel (k_c3g)
-        _check_norm_small(ops, dev, chains_only=True)
-    finally:
-        ops.set_option("norm_small")
-        ops.set_option("conv3_b6_flatd")
+def check_norm_slabs(ops, dev):
+    """deep-level norm that takes the producing conv's raw split-K slabs (bcp_conv3_fwd_raw -> bcp_norm_fwd_slabs / _bwd_slabs: the slab
+    sum folded into the row-major statistics pass): (a) against torch (BatchNorm / grouped BatchNorm / InstanceNorm, every epilogue),
+    (b) against the plain chain on the same inputs: y / da sums bit-identical to the slab-sum kernel, statistics, activations and
+    gradients BIT-identical to bcp_norm_fwd / _bwd on the summed tensor, (c) conv -> slabs -> norm == conv3_fwd -> norm_fwd, forward and
+    dgrad, split-K forced to 1 / 2 / 4"""
+    _check_norm_slabs(ops, dev)
 
 
-def _check_norm_small(ops, dev, chains_only=False):
+def _check_norm_slabs(ops, dev, chains_only=False):
     rng = np.random.default_rng(41)
     cases = () if chains_only else (  # N, C, spatial, act, use_cs, use_res, G, nslab, mode ('bn' | 'in')
         (2, 128, (14, 14, 10), H.ACT_RELU, False, False, 2, 4, "bn"),     # LA level 4: 1960 rows per group, 8 rows per thread, two groups per trip
@@ -934,7 +928,7 @@ def _check_norm_small(ops, dev, chains_only=False):
         (5, 64, (2, 3, 3), H.ACT_RELU, False, False, 5, 2, "in"),         # odd group count
     )
     for (N, Cc, sp, act, use_cs, use_res, G, nslab, mode) in cases:
-        assert ops.norm_small_ok(G, N * sp[0] * sp[1] * sp[2] // G, Cc)
+        assert ops.norm_slabs_ok(G, N * sp[0] * sp[1] * sp[2] // G, Cc)
         parts = [R(rng, N, Cc, *sp) * (1.7 if k == 0 else 0.3) + (0.4 if k == 0 else 0.0) for k in range(nslab)]
         bias = R(rng, Cc) * 0.2 if nslab > 1 else None
         y_t = sum(parts[1:], parts[0]) + (bias.view(1, Cc, 1, 1, 1) if bias is not None else 0)
@@ -966,9 +960,9 @@ def _check_norm_small(ops, dev, chains_only=False):
         gd, bd = (gamma.detach().to(dev), beta.detach().to(dev)) if bn else (None, None)
         rmd, rvd = (torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)) if bn else (None, None)
         kw = dict(chan_scale=None if cs is None else cs.to(dev), elem_mask=None if em is None else to_cl(em).to(dev), elem_scale=1 / 0.8)
-        a, stats, ycl = ops.norm_fwd_small(slabs, nslab, None if bias is None else bias.to(dev), G, gd, bd, rmd, rvd, act,
+        a, stats, ycl = ops.norm_fwd_slabs(slabs, nslab, None if bias is None else bias.to(dev), G, gd, bd, rmd, rvd, act,
                                            residual=None if res is None else to_cl(res).to(dev), **kw)
-        tag = f"norm_small C={Cc} G={G} sp={sp} slabs={nslab}"
+        tag = f"norm_slabs C={Cc} G={G} sp={sp} slabs={nslab}"
         # the slab sum follows k_b6_sum_slabs' order (bias, then the slabs front to back): compare with the same order on the host
         yh = (bias.view(1, 1, 1, 1, Cc) if bias is not None else 0) + to_cl(parts[0])
         for q in parts[1:]:
@@ -980,7 +974,7 @@ def _check_norm_small(ops, dev, chains_only=False):
             close(rvd, rv_ref, rtol=1e-5, msg=tag + " running_var")
         dslabs = torch.stack([to_cl(q) for q in dparts]).to(dev) if nslab > 1 else to_cl(dparts[0]).to(dev)
         dg, db = (torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)) if bn else (None, None)
-        dy, da_out = ops.norm_bwd_small(ycl, dslabs, nslab, G, stats, act, dg, db, False, want_da=True, **kw)
+        dy, da_out = ops.norm_bwd_slabs(ycl, dslabs, nslab, G, stats, act, dg, db, False, **kw)
         close(from_cl(dy), y.grad, rtol=2e-4, msg=tag + " bwd dy")
         dh = to_cl(dparts[0])
         for q in dparts[1:]:
@@ -989,18 +983,23 @@ def _check_norm_small(ops, dev, chains_only=False):
         if bn:
             close(dg, gamma.grad, rtol=2e-4, msg=tag + " dgamma")
             close(db, beta.grad, rtol=2e-4, msg=tag + " dbeta")
-            ops.norm_bwd_small(ycl, dslabs, nslab, G, stats, act, dg, db, True, **kw)
+            ops.norm_bwd_slabs(ycl, dslabs, nslab, G, stats, act, dg, db, True, **kw)
             close(dg, 2 * gamma.grad, rtol=2e-4, msg=tag + " dgamma accumulate")
-        # ---- against the streaming three-kernel chain on the same y / da
+        # ---- against the plain chain on the same (summed) y / da: same kernels on the same bits -> bit-identical
         rm2, rv2 = (torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)) if bn else (None, None)
         a2, stats2 = ops.norm_fwd(ycl, G, gd, bd, rm2, rv2, act, residual=None if res is None else to_cl(res).to(dev), **kw)
-        close(stats, stats2, rtol=2e-6, msg=tag + " stats vs streaming chain")
-        close(a, a2, rtol=2e-6, msg=tag + " fwd vs streaming chain")
+        assert torch.equal(stats, stats2), tag + " stats vs the plain chain"
+        assert torch.equal(a, a2), tag + " fwd vs the plain chain"
         if bn:
-            close(rmd, rm2, rtol=1e-6, msg=tag + " running_mean vs chain")
+            assert torch.equal(rmd, rm2), tag + " running_mean vs the plain chain"
         dg2, db2 = (torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)) if bn else (None, None)
         dy2 = ops.norm_bwd(ycl, da_out, G, stats2, act, dg2, db2, False, **kw)
-        close(dy, dy2, rtol=2e-5, msg=tag + " bwd vs streaming chain")
+        assert torch.equal(dy, dy2), tag + " bwd vs the plain chain"
+        if bn:
+            ops.norm_bwd_slabs(ycl, dslabs, nslab, G, stats, act, dg2, db2, False, **kw)      # (dg / db of the first call were doubled above)
+            dg3, db3 = torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)
+            ops.norm_bwd(ycl, da_out, G, stats2, act, dg3, db3, False, **kw)
+            assert torch.equal(dg2, dg3) and torch.equal(db2, db3), tag + " dgamma / dbeta vs the plain chain"
     # ---- (c) conv -> raw slabs -> fused norm == fused-statistics conv -> streaming norm (forward and dgrad packs)
     for (N, Cin, Cout, sp, G) in ((2, 128, 128, (14, 14, 10), 2), (2, 256, 256, (7, 7, 5), 2), (2, 64, 128, (6, 5, 7), 1), (2, 32, 32, (4, 8, 8), 2)):
         x = R(rng, N, Cin, *sp)
@@ -1021,9 +1020,11 @@ def _check_norm_small(ops, dev, chains_only=False):
                 if sk == 0:
                     continue
                 slabs = ops.conv3_fwd_raw(xcl, wf, Cout, 3, sk)
-                a, st, y = ops.norm_fwd_small(slabs, sk, b.to(dev), G, g1, b1, torch.zeros(Cout).to(dev), torch.ones(Cout).to(dev), H.ACT_RELU)
+                a, st, y = ops.norm_fwd_slabs(slabs, sk, b.to(dev), G, g1, b1, torch.zeros(Cout).to(dev), torch.ones(Cout).to(dev), H.ACT_RELU)
                 close(y, y_ref, rtol=2e-5, msg=f"raw conv slabs {Cin}->{Cout} {sp} sk={sk}")
-                close(a, a_ref, rtol=2e-5, msg=f"raw conv + fused norm {Cin}->{Cout} {sp} sk={sk}")
+                close(a, a_ref, rtol=2e-5, msg=f"raw conv + norm from slabs {Cin}->{Cout} {sp} sk={sk}")
+                if not force:      # the default split: the slabs path IS the default path minus the slab-sum launch -> bit-identical
+                    assert torch.equal(y, y_ref) and torch.equal(a, a_ref), f"slabs path vs slab-sum launch {Cin}->{Cout} {sp} sk={sk}"
                 # dgrad through the flipped pack: da slabs straight into the backward kernel
                 dyt = R(rng, N, Cout, *sp)
                 dycl = to_cl(dyt).to(dev)
@@ -1031,12 +1032,12 @@ def _check_norm_small(ops, dev, chains_only=False):
                 if skd:
                     dsl = ops.conv3_fwd_raw(dycl, wd, Cin, 3, skd)
                     da_ref = ops.conv3_fwd(dycl, wd, None, Cin, 3)
-                    assert ops.norm_small_ok(G, N * sp[0] * sp[1] * sp[2] // G, Cin)
+                    assert ops.norm_slabs_ok(G, N * sp[0] * sp[1] * sp[2] // G, Cin)
                     xs, xst = ops.norm_fwd(xcl, G, None, None, None, None, H.ACT_RELU)
-                    d1, dsum = ops.norm_bwd_small(xcl, dsl, skd, G, xst, H.ACT_RELU, want_da=True)
+                    d1, dsum = ops.norm_bwd_slabs(xcl, dsl, skd, G, xst, H.ACT_RELU)
                     d2 = ops.norm_bwd(xcl, da_ref, G, xst, H.ACT_RELU)
                     close(dsum, da_ref, rtol=2e-5, msg=f"raw dgrad slabs sk={skd}")
-                    close(d1, d2, rtol=5e-5, msg=f"raw dgrad + fused norm backward sk={skd}")
+                    close(d1, d2, rtol=5e-5, msg=f"raw dgrad + norm backward from slabs sk={skd}")
             finally:
                 ops.set_option("conv3_b6_flat_sk")
                 ops.set_option("splitk")
@@ -1283,4 +1284,4 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6"); ops.set_option("conv3_b6_cfg2d64")
 
 
-ALL_CHECKS = ("diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_small", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+ALL_CHECKS = ("diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")

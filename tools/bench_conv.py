@@ -77,20 +77,18 @@ def main():
         dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
 
         def fwd_chain():
-            if ops.norm_small_ok(N, vox_g, C):
+            if ops.norm_slabs_ok(N, vox_g, C):
                 sk = ops.conv3_nslabs(x.shape, C, 3)
-                if sk:
-                    return ops.norm_fwd_small(ops.conv3_fwd_raw(x, wf, C, 3, sk), sk, b, N, g1, b1, rm, rv, H.ACT_RELU)
-                return ops.norm_fwd_small(ops.conv3_fwd(x, wf, b, C, 3), 1, None, N, g1, b1, rm, rv, H.ACT_RELU)
+                if sk > 1:
+                    return ops.norm_fwd_slabs(ops.conv3_fwd_raw(x, wf, C, 3, sk), sk, b, N, g1, b1, rm, rv, H.ACT_RELU)
             yy, part, nb = ops.conv3_fwd_stats(x, wf, b, C, 3, N)
             return ops.norm_fwd(yy, N, g1, b1, rm, rv, H.ACT_RELU, partial=part, nb=nb)
 
         def bwd_chain():
-            if ops.norm_small_ok(N, vox_g, C):
+            if ops.norm_slabs_ok(N, vox_g, C):
                 sk = ops.conv3_nslabs(dy.shape, C, 3)
-                if sk:
-                    return ops.norm_bwd_small(x, ops.conv3_fwd_raw(dy, wd, C, 3, sk), sk, N, st[0], H.ACT_RELU, dg, db, True)
-                return ops.norm_bwd_small(x, ops.conv3_fwd(dy, wd, None, C, 3), 1, N, st[0], H.ACT_RELU, dg, db, True)
+                if sk > 1:
+                    return ops.norm_bwd_slabs(x, ops.conv3_fwd_raw(dy, wd, C, 3, sk), sk, N, st[0], H.ACT_RELU, dg, db, True)
             da, part, nb = ops.conv3_dgrad_bwdstats(dy, wd, C, 3, x, st[0], H.ACT_RELU, N)
             return ops.norm_bwd(x, da, N, st[0], H.ACT_RELU, dg, db, True, partial=part, nb=nb)
         if C == 16 and ("c1_norm_fwd" in want or "c1_norm_bwd" in want):

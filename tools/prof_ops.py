@@ -61,14 +61,14 @@ for C, sp in LEVELS:
     dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
     run(f"norm_bwd[{tag}]", lambda: ops.norm_bwd(x, dy, N, st[0], H.ACT_RELU, dg, db, True, out=a), {"flop": 0, "bytes": 20.0 * vox * C})
     # round 3: the layer as the networks launch it now
-    if ops.norm_small_ok(N, vox // N, C):
+    if ops.norm_slabs_ok(N, vox // N, C):
         sk = ops.conv3_nslabs(x.shape, C, 3)
-        if sk:
+        if sk > 1:
             # deep levels: conv leaves its split-K slabs, ONE norm kernel sums / finalises / applies
             def chain_f():
-                st[0] = ops.norm_fwd_small(ops.conv3_fwd_raw(x, wf, C, 3, sk), sk, b, N, g, be, rm, rv, H.ACT_RELU)[1]
-            run(f"conv3_raw+norm_small_fwd[{tag}]", chain_f, {"flop": fl, "bytes": 16.0 * vox * C})
-            run(f"dgrad_raw+norm_small_bwd[{tag}]", lambda: ops.norm_bwd_small(x, ops.conv3_fwd_raw(dy, wd, C, 3, sk), sk, N, st[0], H.ACT_RELU, dg, db, True),
+                st[0] = ops.norm_fwd_slabs(ops.conv3_fwd_raw(x, wf, C, 3, sk), sk, b, N, g, be, rm, rv, H.ACT_RELU)[1]
+            run(f"conv3_raw+norm_slabs_fwd[{tag}]", chain_f, {"flop": fl, "bytes": 16.0 * vox * C})
+            run(f"dgrad_raw+norm_slabs_bwd[{tag}]", lambda: ops.norm_bwd_slabs(x, ops.conv3_fwd_raw(dy, wd, C, 3, sk), sk, N, st[0], H.ACT_RELU, dg, db, True),
                 {"flop": fl, "bytes": 16.0 * vox * C})
     else:
         def chain_b():
