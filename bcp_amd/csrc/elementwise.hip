@@ -25,12 +25,13 @@ static inline int stream_grid(long long n_items, int block) {
 // out = a outside the box, b inside (reference: a*mask + b*(1-mask), mask = 1 outside the box;
 // LA_BCP_train.py:248-251, ACDC_BCP_train.py:372-373, utils/BCP_utils.py:18-28).
 // Layout [N][D][H][W][C] with C*W % 4 == 0; the box is in (d,h,w) voxel coordinates.
+template <int U>
 __global__ __launch_bounds__(256) void k_mix_box(const float* __restrict__ a, const float* __restrict__ b,
                                                  float* __restrict__ out, long long n_vec, int D, int H, int W, int C,
                                                  int d0, int d1, int h0, int h1, int w0, int w1) {
-  // (round 3: 32-bit index arithmetic -- the first version spent three 64-bit divisions per 16 bytes -- and four independent
-  //  vectors per thread; the launcher guarantees n_vec < 2^29)
-  constexpr int U = 4;
+  // (round 3: 32-bit index arithmetic -- the first version spent three 64-bit divisions per 16 bytes -- and U independent
+  //  vectors per thread; the launcher guarantees n_vec < 2^29.  Round 4: U = 1 for launches under 4 M floats -- one LA volume with
+  //  U = 4 is 245 workgroups, less than one per CU, and the launch is latency: 31 us alone for 12 MB)
   const unsigned nv = (unsigned)n_vec, stride = gridDim.x * blockDim.x;
   const unsigned rowlen = (unsigned)(W * C);  // floats per (n,d,h) row
   for (unsigned i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < nv; i0 += U * stride) {
@@ -219,8 +220,12 @@ extern "C" int bcp_mix_box(const float* a, const float* b, float* out, int N, in
   BCP_REQUIRE((W * C) % 4 == 0, "bcp_mix_box: W*C must be a multiple of 4");
   const long long n_vec = (long long)N * D * H * W * C / 4;
   BCP_REQUIRE(n_vec < (1LL << 29), "bcp_mix_box: tensor too large (>= 2^31 floats)");
-  hipLaunchKernelGGL(k_mix_box, dim3(stream_grid((n_vec + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_vec, D, H,
-                     W, C, box6[0], box6[0] + box6[3], box6[1], box6[1] + box6[4], box6[2], box6[2] + box6[5]);
+  if (n_vec <= (1LL << 20))
+    hipLaunchKernelGGL(k_mix_box<1>, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_vec, D, H,
+                       W, C, box6[0], box6[0] + box6[3], box6[1], box6[1] + box6[4], box6[2], box6[2] + box6[5]);
+  else
+    hipLaunchKernelGGL(k_mix_box<4>, dim3(stream_grid((n_vec + 3) / 4, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_vec, D, H,
+                       W, C, box6[0], box6[0] + box6[3], box6[1], box6[1] + box6[4], box6[2], box6[2] + box6[5]);
   BCP_CHECK_LAUNCH("bcp_mix_box");
   return BCP_OK;
 }

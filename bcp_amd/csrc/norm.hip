@@ -429,6 +429,18 @@ static inline int norm_blocks(long long rows_per_group, int C) {
   return (int)nb;
 }
 
+// statistics pass that also sums split-K slabs (k_col_partial<MODE, true>): it moves nslab + 1 times the tensor and serves the deep levels
+// only (<= 4096 rows per group), where norm_blocks' ~64 rows per thread-slot would leave 3-15 workgroups to do it (round 4, measured:
+// LA step 6.10 vs 6.02 ms with the slab-sum launch) -- one row per thread-slot and pass, at most ~256 workgroups per launch
+static inline int norm_blocks_slabs(long long rows_per_group, int C, int G) {
+  const int slots = 256 / (C / 4);
+  long long nb = (rows_per_group + slots - 1) / slots;
+  const long long cap = G >= 256 ? 1 : 256 / G;
+  if (nb > cap) nb = cap;
+  const int plain = norm_blocks(rows_per_group, C);
+  return (int)(nb < plain ? plain : nb);
+}
+
 static inline int apply_grid(long long nvec, int nseg) {
   long long g = (nvec + 256 * 4 - 1) / (256 * 4);          // 4 float4 per thread per trip
   const long long cap = 2048 / nseg < 1 ? 1 : 2048 / nseg;
@@ -438,8 +450,8 @@ static inline int apply_grid(long long nvec, int nseg) {
 
 // segments (see k_col_partial): the finer of (group, sample) when a per-sample channel scale is present
 struct Segs { long long seg_rows; int spg; int nbps; };
-static inline Segs make_segs(int G, long long rows_per_group, int C, const NormEpilogue& ep) {
-  Segs sg{rows_per_group, 1, norm_blocks(rows_per_group, C)};
+static inline Segs make_segs(int G, long long rows_per_group, int C, const NormEpilogue& ep, int nblocks = 0) {
+  Segs sg{rows_per_group, 1, nblocks > 0 ? nblocks : norm_blocks(rows_per_group, C)};
   if (ep.chan_scale && ep.rows_per_sample < rows_per_group) {
     sg.seg_rows = ep.rows_per_sample;
     sg.spg = (int)(rows_per_group / ep.rows_per_sample);
@@ -485,7 +497,9 @@ using namespace bcp;
 extern "C" size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C) {
   if (G < 1 || C < 16 || rows_per_group < 1) return 0;
   // per-block fp64 partials, then the two per-(g,c) backward means (c1, c2)
-  return (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2 * sizeof(double) + (size_t)4 * G * C * sizeof(float);
+  // (the slab-summing statistics pass of the deep levels uses more, smaller blocks: size the partial rows for whichever is larger)
+  const int nbmax = rows_per_group <= 4096 ? norm_blocks_slabs(rows_per_group, C, G) : norm_blocks(rows_per_group, C);
+  return (size_t)G * (nbmax + kMaxSamplesPerGroup) * C * 2 * sizeof(double) + (size_t)4 * G * C * sizeof(float);
 }
 
 static int check_norm_args(const char* fn, int G, long long rows_per_group, int C) {
@@ -576,6 +590,7 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
                                   const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace, float* out,
                                   void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd_slabs", G, rows_per_group, C)) return rc;
+  BCP_REQUIRE(rows_per_group <= 4096, "bcp_norm_fwd_slabs: rows_per_group=%lld > 4096 (check bcp_norm_slabs_ok)", rows_per_group);
   BCP_REQUIRE(slabs && ysum && stats && workspace && nslab >= 1 && nslab <= 64, "bcp_norm_fwd_slabs: null pointer / bad slab count");
   BCP_REQUIRE(aligned16(slabs) && aligned16(ysum) && (!out || aligned16(out)) && aligned16(stats) && (slab_stride & 3) == 0 && (!bias || aligned16(bias)),
               "bcp_norm_fwd_slabs: alignment");
@@ -584,7 +599,7 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
   NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
   BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
               "bcp_norm_fwd_slabs: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
-  const Segs sg = make_segs(G, rows_per_group, C, ep);
+  const Segs sg = make_segs(G, rows_per_group, C, ep, norm_blocks_slabs(rows_per_group, C, G));
   const int nseg = G * sg.spg, nb = sg.nbps * sg.spg;
   double* partial = reinterpret_cast<double*>(workspace);
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
@@ -608,6 +623,7 @@ extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nsl
                                   long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta,
                                   int accumulate, void* workspace, float* dy, void* stream) {
   if (int rc = check_norm_args("bcp_norm_bwd_slabs", G, rows_per_group, C)) return rc;
+  BCP_REQUIRE(rows_per_group <= 4096, "bcp_norm_bwd_slabs: rows_per_group=%lld > 4096 (check bcp_norm_slabs_ok)", rows_per_group);
   BCP_REQUIRE(y && da_slabs && da_sum && stats && workspace && dy && nslab >= 1 && nslab <= 64, "bcp_norm_bwd_slabs: null pointer / bad slab count");
   BCP_REQUIRE(aligned16(y) && aligned16(da_slabs) && aligned16(dy) && aligned16(da_sum) && (slab_stride & 3) == 0, "bcp_norm_bwd_slabs: alignment");
   BCP_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bcp_norm_bwd_slabs: dgamma and dbeta come together");
@@ -615,11 +631,11 @@ extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nsl
   NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
   BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
               "bcp_norm_bwd_slabs: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
-  const Segs sg = make_segs(G, rows_per_group, C, ep);
+  const Segs sg = make_segs(G, rows_per_group, C, ep, norm_blocks_slabs(rows_per_group, C, G));
   const int nseg = G * sg.spg, nb = sg.nbps * sg.spg;
   double* partial = reinterpret_cast<double*>(workspace);
   const float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
-  float* c1 = reinterpret_cast<float*>(partial + (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2);
+  float* c1 = reinterpret_cast<float*>(partial + (size_t)G * (norm_blocks_slabs(rows_per_group, C, G) + kMaxSamplesPerGroup) * C * 2);
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
   const SlabSrc sl{da_slabs, nslab, slab_stride, nullptr, da_sum};

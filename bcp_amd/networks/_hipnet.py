@@ -226,7 +226,7 @@ class HipNet(nn.Module):
         total = sum(sizes)
         self._pack_buf = torch.empty(2 * total, dtype=torch.float32, device=dev)
         self._pack_views = {}
-        fwd_desc, all_desc = b"", b""
+        fwd_desc, all_desc, dg_desc = b"", b"", b""
         off = 0
         for (key, w, KD), n in zip(self._c3, sizes):
             Cout, Cin = w.shape[0], w.shape[1]
@@ -237,9 +237,11 @@ class HipNet(nn.Module):
             d_d = struct.pack("<QQiiiiii", w.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, N16, K16, 1)
             fwd_desc += d_f
             all_desc += d_f + d_d
+            dg_desc += d_d
             off += n
         self._desc_fwd = torch.frombuffer(bytearray(fwd_desc), dtype=torch.uint8).to(dev)
         self._desc_all = torch.frombuffer(bytearray(all_desc), dtype=torch.uint8).to(dev)
+        self._desc_dg = torch.frombuffer(bytearray(dg_desc), dtype=torch.uint8).to(dev)
         self._pack_state = None
         self._pack_ptr = self._flat.data_ptr()
 
@@ -269,12 +271,48 @@ class HipNet(nn.Module):
         st = self._pack_state
         if st is None or st[0] != ver or (need_dgrad and not st[1]):
             n = len(self._c3)
-            if need_dgrad:
-                self.ops.conv3_pack_many(self._desc_all, 2 * n)
-            else:
+            fresh = st is not None and st[0] == ver            # the forward packs of this weight version exist already
+            if not need_dgrad:
                 self.ops.conv3_pack_many(self._desc_fwd, n)
-            self._pack_state = (ver, need_dgrad or (st is not None and st[0] == ver and st[1]))
+            elif self._defer_dgrad_pack():
+                # the forward needs the forward packs NOW and the dgrad packs only in the backward pass: the latter go to the
+                # weight-gradient side stream (idle during the forward) and the backward waits for them (_wait_dgrad_packs)
+                if not fresh:
+                    self.ops.conv3_pack_many(self._desc_fwd, n)
+                with self._on_pack_stream():
+                    self.ops.conv3_pack_many(self._desc_dg, n)
+            elif fresh:
+                self.ops.conv3_pack_many(self._desc_dg, n)
+            else:
+                self.ops.conv3_pack_many(self._desc_all, 2 * n)
+            self._pack_state = (ver, need_dgrad or (fresh and st[1]))
         return self._pack_views[key]
+
+    # ---- dgrad packs off the forward's critical path (round 4): 37.8 MB of V-Net weights -> ~95 MB of packs per direction; the student's
+    # forward used to wait for both directions (k_pack_conv3_many 2 x n descriptors: 65-100 us at the head of its stream)
+    DEFER_DGRAD_PACK = True
+
+    def _defer_dgrad_pack(self):
+        return (self.DEFER_DGRAD_PACK and self.overlap_wgrad and self._flat.is_cuda and self.ops.b._rec is None and self.training
+                and torch.is_grad_enabled())
+
+    def _on_pack_stream(self):
+        dev = self._flat.device
+        main = torch.cuda.current_stream(dev)
+        side = self._side_streams.get(dev)
+        if side is None:
+            side = self._side_streams[dev] = torch.cuda.Stream(device=dev, priority=HipNet.WGRAD_STREAM_PRIORITY)
+        side.wait_stream(main)                 # the optimiser's update of the weights is ordered before the pack
+        self._dgrad_pack_pending = (dev, side)
+        return torch.cuda.stream(side)
+
+    def _wait_dgrad_packs(self):
+        """called at the head of the backward pass: the main stream joins the side stream's dgrad packs"""
+        pend = self.__dict__.get("_dgrad_pack_pending")
+        if pend is not None:
+            dev, side = pend
+            torch.cuda.current_stream(dev).wait_stream(side)
+            self._dgrad_pack_pending = None
 
     # ---- same for the k2s2 / 1x1 GEMM weights: (fwd kind, dgrad kind) per layer, one launch per weight version
     def register_k2(self, key, weight, Cin, Cout, kind_fwd, kind_dgrad):
@@ -287,7 +325,7 @@ class HipNet(nn.Module):
         total = sum(w.numel() for _, w, *_ in self._k2)
         self._k2_buf = torch.empty(2 * total, dtype=torch.float32, device=dev)
         self._k2_views = {}
-        fwd_desc, all_desc = b"", b""
+        fwd_desc, all_desc, dg_desc = b"", b"", b""
         off = 0
         for key, w, Cin, Cout, kf, kd in self._k2:
             n = w.numel()
@@ -297,9 +335,11 @@ class HipNet(nn.Module):
             d_d = self.ops.k2_pack_desc(w.data, bd, Cin, Cout, kd)
             fwd_desc += d_f
             all_desc += d_f + d_d
+            dg_desc += d_d
             off += n
         self._k2_desc_fwd = torch.frombuffer(bytearray(fwd_desc), dtype=torch.uint8).to(dev)
         self._k2_desc_all = torch.frombuffer(bytearray(all_desc), dtype=torch.uint8).to(dev)
+        self._k2_desc_dg = torch.frombuffer(bytearray(dg_desc), dtype=torch.uint8).to(dev)
         self._k2_state = None
         self._k2_ptr = self._flat.data_ptr()
 
@@ -311,11 +351,19 @@ class HipNet(nn.Module):
         st = self._k2_state
         if st is None or st[0] != ver or (need_dgrad and not st[1]):
             n = len(self._k2)
-            if need_dgrad:
-                self.ops.k2_pack_many(self._k2_desc_all, 2 * n)
-            else:
+            fresh = st is not None and st[0] == ver
+            if not need_dgrad:
                 self.ops.k2_pack_many(self._k2_desc_fwd, n)
-            self._k2_state = (ver, need_dgrad or (st is not None and st[0] == ver and st[1]))
+            elif self._defer_dgrad_pack():            # (see conv3_packed)
+                if not fresh:
+                    self.ops.k2_pack_many(self._k2_desc_fwd, n)
+                with self._on_pack_stream():
+                    self.ops.k2_pack_many(self._k2_desc_dg, n)
+            elif fresh:
+                self.ops.k2_pack_many(self._k2_desc_dg, n)
+            else:
+                self.ops.k2_pack_many(self._k2_desc_all, 2 * n)
+            self._k2_state = (ver, need_dgrad or (fresh and st[1]))
         return self._k2_views[key]
 
     def _packed(self, key, p, fn):
@@ -572,6 +620,7 @@ class HipNet(nn.Module):
         return out.clone(), None
 
     def _run_backward(self, saved, dout):
+        self._wait_dgrad_packs()
         if not isinstance(saved, _PlanSaved):
             return self._backward_impl(saved, dout)
         from .. import plan

@@ -502,6 +502,10 @@ def main():
             from bcp_amd.networks.unet import UNet_2d as _un
             _vn.fuse_c1 = _un.fuse_c1 = bool(int(v))
             continue
+        if k == "defer_dgrad_pack":   # host-side switch (networks/_hipnet.py): dgrad weight packs on the side stream, off the forward's critical path
+            from bcp_amd.networks._hipnet import HipNet as _hn2
+            _hn2.DEFER_DGRAD_PACK = bool(int(v))
+            continue
         if k == "fuse_head":          # host-side switch (networks/VNet.py), not a library option
             from bcp_amd.networks.VNet import VNet
             VNet.fuse_head = bool(int(v))

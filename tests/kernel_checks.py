@@ -911,7 +911,7 @@ def check_norm_slabs(ops, dev):
     """deep-level norm that takes the producing conv's raw split-K slabs (bcp_conv3_fwd_raw -> bcp_norm_fwd_slabs / _bwd_slabs: the slab
     sum folded into the row-major statistics pass): (a) against torch (BatchNorm / grouped BatchNorm / InstanceNorm, every epilogue),
     (b) against the plain chain on the same inputs: y / da sums bit-identical to the slab-sum kernel, statistics, activations and
-    gradients BIT-identical to bcp_norm_fwd / _bwd on the summed tensor, (c) conv -> slabs -> norm == conv3_fwd -> norm_fwd, forward and
+    gradients equal to bcp_norm_fwd / _bwd on the summed tensor up to the grouping of the fp64 partial sums, (c) conv -> slabs -> norm == conv3_fwd -> norm_fwd, forward and
     dgrad, split-K forced to 1 / 2 / 4"""
     _check_norm_slabs(ops, dev)
 
@@ -988,18 +988,20 @@ def _check_norm_slabs(ops, dev, chains_only=False):
         # ---- against the plain chain on the same (summed) y / da: same kernels on the same bits -> bit-identical
         rm2, rv2 = (torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)) if bn else (None, None)
         a2, stats2 = ops.norm_fwd(ycl, G, gd, bd, rm2, rv2, act, residual=None if res is None else to_cl(res).to(dev), **kw)
-        assert torch.equal(stats, stats2), tag + " stats vs the plain chain"
-        assert torch.equal(a, a2), tag + " fwd vs the plain chain"
+        # (the slab-summing pass cuts the rows into more blocks: fp64 partial sums in another grouping -> equal to fp64 rounding, not bitwise)
+        close(stats, stats2, rtol=2e-6, msg=tag + " stats vs the plain chain")
+        close(a, a2, rtol=2e-6, msg=tag + " fwd vs the plain chain")
         if bn:
-            assert torch.equal(rmd, rm2), tag + " running_mean vs the plain chain"
+            close(rmd, rm2, rtol=1e-6, msg=tag + " running_mean vs the plain chain")
         dg2, db2 = (torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)) if bn else (None, None)
         dy2 = ops.norm_bwd(ycl, da_out, G, stats2, act, dg2, db2, False, **kw)
-        assert torch.equal(dy, dy2), tag + " bwd vs the plain chain"
+        close(dy, dy2, rtol=2e-5, msg=tag + " bwd vs the plain chain")
         if bn:
             ops.norm_bwd_slabs(ycl, dslabs, nslab, G, stats, act, dg2, db2, False, **kw)      # (dg / db of the first call were doubled above)
             dg3, db3 = torch.full((Cc,), 7.0).to(dev), torch.full((Cc,), 7.0).to(dev)
             ops.norm_bwd(ycl, da_out, G, stats2, act, dg3, db3, False, **kw)
-            assert torch.equal(dg2, dg3) and torch.equal(db2, db3), tag + " dgamma / dbeta vs the plain chain"
+            close(dg2, dg3, rtol=2e-5, msg=tag + " dgamma vs the plain chain")
+            close(db2, db3, rtol=2e-5, msg=tag + " dbeta vs the plain chain")
     # ---- (c) conv -> raw slabs -> fused norm == fused-statistics conv -> streaming norm (forward and dgrad packs)
     for (N, Cin, Cout, sp, G) in ((2, 128, 128, (14, 14, 10), 2), (2, 256, 256, (7, 7, 5), 2), (2, 64, 128, (6, 5, 7), 1), (2, 32, 32, (4, 8, 8), 2)):
         x = R(rng, N, Cin, *sp)
@@ -1023,8 +1025,8 @@ def _check_norm_slabs(ops, dev, chains_only=False):
                 a, st, y = ops.norm_fwd_slabs(slabs, sk, b.to(dev), G, g1, b1, torch.zeros(Cout).to(dev), torch.ones(Cout).to(dev), H.ACT_RELU)
                 close(y, y_ref, rtol=2e-5, msg=f"raw conv slabs {Cin}->{Cout} {sp} sk={sk}")
                 close(a, a_ref, rtol=2e-5, msg=f"raw conv + norm from slabs {Cin}->{Cout} {sp} sk={sk}")
-                if not force:      # the default split: the slabs path IS the default path minus the slab-sum launch -> bit-identical
-                    assert torch.equal(y, y_ref) and torch.equal(a, a_ref), f"slabs path vs slab-sum launch {Cin}->{Cout} {sp} sk={sk}"
+                if not force:      # the default split: the slab sum IS k_b6_sum_slabs' arithmetic -> y bit-identical
+                    assert torch.equal(y, y_ref), f"slabs path vs slab-sum launch {Cin}->{Cout} {sp} sk={sk}"
                 # dgrad through the flipped pack: da slabs straight into the backward kernel
                 dyt = R(rng, N, Cout, *sp)
                 dycl = to_cl(dyt).to(dev)
