@@ -49,24 +49,24 @@ _SIGS = {
     "bcp_dice_prob_fwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, P, P]),
     "bcp_dice_prob_bwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, F, P, P]),
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
-    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, P]),
+    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, P, P]),
     "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, I, P, P]),
     "bcp_norm_slabs_ok": (I, [I, L, I]),
-    "bcp_norm_fwd_slabs": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P]),
+    "bcp_norm_fwd_slabs": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P, P]),
     "bcp_norm_bwd_slabs": (I, [P, P, I, L, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, P]),
     "bcp_conv3_fwd_nslabs": (I, [I, I, I, I, I, I, I]),
     "bcp_conv3_bwdstat_rows": (I, [I, I, I, I, I, I, I, I]),
-    "bcp_conv3_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, I, P]),
-    "bcp_conv3_fwd_raw": (I, [P, P, P, I, I, I, I, I, I, I, I, P]),
+    "bcp_conv3_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, I, P, P]),
+    "bcp_conv3_fwd_raw": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
     "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
     "bcp_conv3_fwd_path": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_wgrad_path": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_pack_weight": (I, [P, P, P, I, I, I, P]),
     "bcp_conv3_pack_many": (I, [P, I, P]),
     "bcp_conv3_fwd_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
-    "bcp_conv3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "bcp_conv3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P, P, P]),
     "bcp_conv3_stat_rows": (I, [I, I, I, I, I, I, I, I, I]),
-    "bcp_conv3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P]),
+    "bcp_conv3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P, P]),
     "bcp_conv3_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
     "bcp_conv3_c1_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),

@@ -41,7 +41,6 @@ struct Options {
   int conv3_b6_cin16max = 32;   // 2-D layers with 16 output channels on the bf16 pipe: widest input (measurement switch)
   int conv3_b6_pipe = 1;        // ... and of those the 3-D ones as the LDS-DMA software pipeline k_c3p (0: k_c3h, register-staged weights)
   int conv3_b6_w22 = 1;         // 64-voxel x 64-channel staged tiles: waves arranged 2 x 2 (k_c3h) instead of 1 x 4 (k_c3b)
-  int conv3_b6_cfg2d64 = 0;     // 2-D 64-channel slabs: 0 = 8x16 tiles on k_c3b (1 x 4 waves), 1 = 8x8 tiles on the 2 x 2 arrangement: k_c3p (five stages per chunk) or, with conv3_b6_pipe = 0, k_c3h -- ACDC step 4.17 / 4.02 ms against 4.04: off
   int conv3_b6_cfg2d = 1;       // 2-D 32-channel slabs: 1 = direct-weight 16x16 tiles from 64 K pixels, 2 = always, 0 = staged 8x16 tiles
   int conv3_b6_flat_sk = 0; // flat bf16-pipe tiles: split-K factor 1..8 (0: the launcher's rule)
   int res_pcu = 0;          // resident conv: persistent workgroups per CU 1..4
@@ -56,17 +55,13 @@ struct Options {
   int conv3_b6_levels = 15;  // automatic choice (conv3_b6 = 1): bit 0 = 32-channel slabs (256-voxel tiles), bit 1 = 64-channel slabs, bit 2 = the 16 -> 16 layers (persistent k_c3d with cross-tile halo prefetch: 176 vs 243-258 us alone, step 7.00 vs 7.18 ms; one tile per workgroup it was 209-228 us and no step gain), bit 3 = the 2-D instances (ACDC step 5.18 -> 4.24 ms together with the weight gradients).  LA step, interleaved A/B (ms per step): off 8.87, 32-channel level 8.32, + 64-channel level 8.05 -- the latter although ALONE that kernel is slower than the exclusive pipeline kernel it replaces (66-71 vs 61 us): two workgroups per CU leave room for the other stream
   int conv3_b6_minvox = 256;     // automatic choice: smallest launch (voxels, batch included) that goes to the bf16-pipe kernels
   int conv3_b6_flat = 1;    // deep levels (64-channel slabs, < 16 K voxels): flat 64-voxel tiles with per-lane validity masks (k_c3f) instead of bricks: 128 channels @14x14x10 35 vs 41 us (fp32 kernel 52), 256 @7x7x5 31 vs 33 (fp32); LA step 6.87 vs 6.96 ms.  2 / 3: force 32- / 16-channel slabs (measurements)
-  int conv3_b6_flatd = 0;   // deep levels: flat tiles with DIRECT weight fragments and MT m-tiles per wave (k_c3g) instead of k_c3f: 1 = automatic tile (256 / 128 voxels), 2 / 4 = force 128 / 256, 0 = off (default: measured no faster -- 128 channels 36.6 vs 34.8 us, 256 channels 30.4 vs 24.7 us alone)
   int conv3_b6_direct = 1;  // bf16-pipe forward: weight fragments straight from global memory (k_c3d, no stage barriers) instead of an LDS stage (k_c3b): 1 = for the 256-voxel x 32-channel tiles (78-82 vs 84-89 us alone, 7.32 vs 7.34 ms per step), 2 = everywhere (measurements)
-  int conv3_b6_cfg32 = 0;   // measurements: 1 = 128-voxel (4x4x8) tiles for the 32-channel slabs at every size
-  int conv3_b6_cfg64 = 0;   // measurements: tile / slab variant of the 64-channel bf16-pipe instances
   int wgrad_b6 = 1;         // weight gradient on the bf16 matrix pipe (conv3bw.hip): 0 off, 1 where measured faster, 2 wherever valid.  LA step (interleaved A/B): off 7.82 ms, 32/64-channel levels 7.52, + 128-channel level 7.38
   int wgrad_b6_minvox = 256;     // (7x7x5 level included: 39 vs 57 us alone, 7.30 vs 7.36 ms per step)
   int norm_slabs = 1;       // deep levels (<= 4096 rows per group): the conv leaves its raw split-K slabs and the norm's row-major statistics pass sums them on its way in (bcp_norm_fwd_slabs / _bwd_slabs): no k_b6_sum_slabs launch (27 per LA step).  0: slab-sum launches (round 3)
   int fuse_bwd_stats = 1;   // dgrad epilogue of the bf16-pipe kernels accumulates the consumer norm layer's backward statistics (bcp_conv3_dgrad_bwdstats): no k_col_partial<1> pass over (y, da) for conv -> conv edges
-  int conv3_stagger = 0;    // bf16-pipe kernels: workgroups whose linear id has bit conv3_stagger_bit set start ~0.9 us x this late (s_sleep): de-phases the two workgroups of a CU so that one's halo / weight / store phases fall into the other's MFMA phase (measured additive otherwise: 47.8 us MFMA + LDS loop + 20.8 us everything else = 71.9 us at the 32-channel level)
-  int conv3_stagger_bit = 8;
   int conv3_xcd = 1;        // bf16-pipe kernels: XCD-aware workgroup -> tile order (each XCD walks a contiguous eighth of the tile list: halo overlap hits its own L2; the flat deep-level kernel deals WEIGHT STREAMS to XCDs).  Bits for measurements: 2 = also the persistent 16-channel kernel (slower), 8 = k_c3q deals weight streams to XCDs also when there are only 8 of them (128-channel level: minimal fabric traffic, slower alone, step unchanged), 16 = k_c3q in tile order
+  int conv3_f16 = 1;        // round 4: bf16-pipe kernels that have a two-plane fp16 instance (k_c3d) use it when the launch carries the input tensor's |max| (per-tensor power-of-two pre-scales, conv3_defs.h): three MFMAs per K block instead of six.  0: three bf16 planes everywhere
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };
 Options& options();

@@ -732,6 +732,7 @@ static void launch_reduce_deep(const float* ws, float* dw, int G, int T, int Cin
 __global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
                                                     int T, int K16, int N16, int dgrad) {
   const long long total = (long long)T * K16 * N16;
+  float* hdr = wp + pack_off_hdr(T, K16, N16);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int k4 = (int)(i & 3);
     const int nn = (int)((i >> 2) % N16);
@@ -765,12 +766,55 @@ __global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w,
     split3_bf16(v, pc);
 #pragma unroll
     for (int q = 0; q < 3; ++q) wb[((((long long)ch * TP + tp) * 3 + q) * N16 + nn) * 32 + j] = pc[q];
+    // two-plane fp16 section (round 4, conv3b.hip PL = 2), pre-scaled by the layer's power-of-two scale (header: k_wamax)
+    {
+      float amax = 0.f;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) amax = fmaxf(amax, hdr[1 + b]);
+      const float sc = f16_scale(amax);
+      unsigned short* wh = reinterpret_cast<unsigned short*>(wp + pack_off_f16(T, K16, N16));
+      const float vs = v * sc;
+      const _Float16 h0 = (_Float16)vs;
+      const _Float16 h1 = (_Float16)(vs - (float)h0);
+      wh[((((long long)ch * TP + tp) * 2 + 0) * N16 + nn) * 32 + j] = __builtin_bit_cast(unsigned short, h0);
+      wh[((((long long)ch * TP + tp) * 2 + 1) * N16 + nn) * 32 + j] = __builtin_bit_cast(unsigned short, h1);
+      if (i == 0) hdr[0] = amax;
+    }
   }
+}
+
+// max |w| of a layer in 16 per-block partials -> header[1 .. 16] of its pack (no atomics, nothing to zero): the packers read them
+__global__ __launch_bounds__(256) void k_wamax(const float* __restrict__ w, long long count, float* __restrict__ hdr) {
+  __shared__ float red[4];
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += 16LL * 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) hdr[1 + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (blockIdx.x == 0 && threadIdx.x >= 17 && threadIdx.x < kPackHeaderFloats) hdr[threadIdx.x] = 0.f;      // reserved words: defined contents
 }
 
 // all conv layers of a network in ONE launch (blockIdx.y = descriptor): 80 five-microsecond pack launches per step otherwise
 struct PackDesc { const float* w; float* wp; int Cout, Cin, T, K16, N16, dgrad; };
 static constexpr int kMaxPackDescs = 512;
+
+// max |w| of every layer of the descriptor list: block (b, di) leaves the b-th of 16 partial maxima in header[1 + b] of desc di's pack
+__global__ __launch_bounds__(256) void k_wamax_many(const PackDesc* __restrict__ descs) {
+  __shared__ float red[4];
+  const PackDesc d = descs[blockIdx.y];
+  const long long count = (long long)d.Cout * d.Cin * d.T;
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += 16LL * 256) m = fmaxf(m, fabsf(d.w[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  float* hdr = d.wp + pack_off_hdr(d.T, d.K16, d.N16);
+  if (threadIdx.x == 0) hdr[1 + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (blockIdx.x == 0 && threadIdx.x >= 17 && threadIdx.x < kPackHeaderFloats) hdr[threadIdx.x] = 0.f;      // reserved words: defined contents
+}
 // Work unit = one 16 x 16 (k, n) block of one layer, all taps: the 16 source rows are runs of 16*T contiguous floats
 // (coalesced reads), transposed through LDS, written as 256-B runs.  Units are dealt round-robin to the blocks, so the
 // 256-channel layers (256 units each) no longer serialise on a fixed 64 blocks of scattered 4-byte gathers.
@@ -832,6 +876,29 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
         o[ps] = h;
         v0 -= __uint_as_float(h << 16); v1 -= __uint_as_float(h & 0xffff0000u);
         o[2 * ps] = cvt_pk_bf16(v0, v1);
+      }
+      // two-plane fp16 section (round 4): same (chunk, pair, n, k) order with two pieces, pre-scaled by the layer's power of two
+      float* hdr = d.wp + pack_off_hdr(T, d.K16, d.N16);
+      float amax = 0.f;
+#pragma unroll
+      for (int b = 0; b < 16; ++b) amax = fmaxf(amax, hdr[1 + b]);
+      const float sc = f16_scale(amax);
+      if (u == 0 && threadIdx.x == 0) hdr[0] = amax;
+      unsigned* wh = reinterpret_cast<unsigned*>(d.wp + pack_off_f16(T, d.K16, d.N16));
+      for (int q = threadIdx.x; q < TP * 16 * 16; q += 256) {
+        const int j2 = q & 15, nn = (q >> 4) & 15, tp = q >> 8;
+        const int t = 2 * tp + (j2 >> 3), kk = (j2 * 2) & 15;
+        float v0 = 0.f, v1 = 0.f;
+        if (t < T) {
+          v0 = d.dgrad ? tile[(kk * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk) * T + t];
+          v1 = d.dgrad ? tile[((kk + 1) * 16 + nn) * T + (T - 1 - t)] : tile[(nn * 16 + kk + 1) * T + t];
+        }
+        v0 *= sc; v1 *= sc;
+        unsigned* o = wh + ((((((long long)ch * TP + tp) * 2) * d.N16 + n0 + nn) * 32 + j2 * 2) >> 1);
+        const long long ps = ((long long)d.N16 * 32) >> 1;
+        const unsigned h = cvt_pk_f16(v0, v1);
+        o[0] = h;
+        o[ps] = cvt_pk_f16(v0 - f16lo_to_f32(h), v1 - f16hi_to_f32(h));
       }
     }
     __syncthreads();
@@ -1215,14 +1282,15 @@ static int fill_dims(ConvDims& cd, int N, int D, int H, int W, int Cin, int Cout
   cd.Cout16 = (Cout + 15) / 16 * 16;
   cd.tiles_d = cd.tiles_h = cd.tiles_w = 0;
   cd.xcd = options().conv3_xcd;
-  cd.stagger = (options().conv3_stagger & 0xffff) | (options().conv3_stagger_bit << 16);
+  cd.xamax = nullptr;
   return 0;
 }
 
 extern "C" size_t bcp_conv3_packed_weight_floats(int Cin, int Cout, int KD) {
-  // fp32 pack [T][K16 / 4][N16][4] followed by the three-piece bf16 pack [K16 / 16][TP][3][N16][32] (2 B elements) of conv3b.hip
-  const int K16 = (Cin + 15) / 16 * 16, N16 = (Cout + 15) / 16 * 16, T = KD * 9, TP = (T + 1) / 2;
-  return (size_t)(T + 3 * TP) * K16 * N16;
+  // fp32 pack [T][K16 / 4][N16][4], the three-piece bf16 pack [K16 / 16][TP][3][N16][32] (2 B elements) and the two-piece fp16 pack
+  // [K16 / 16][TP][2][N16][32] of conv3b.hip, and a 32-float header (max |w|: the fp16 planes' power-of-two scale)
+  const int K16 = (Cin + 15) / 16 * 16, N16 = (Cout + 15) / 16 * 16, T = KD * 9;
+  return (size_t)pack_off_hdr(T, K16, N16) + kPackHeaderFloats;
 }
 
 extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dgrad, int Cin, int Cout, int KD, void* stream) {
@@ -1231,8 +1299,15 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
   const int T = KD * 9, Ci16 = (Cin + 15) / 16 * 16, Co16 = (Cout + 15) / 16 * 16;
   const long long total = (long long)T * Ci16 * Co16;
   const int grid = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-  if (wp_fwd) hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_fwd, Cout, Cin, T, Ci16, Co16, 0);
-  if (wp_dgrad) hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_dgrad, Cout, Cin, T, Co16, Ci16, 1);
+  const long long count = (long long)Cout * Cin * T;
+  if (wp_fwd) {
+    hipLaunchKernelGGL(k_wamax, dim3(16), dim3(256), 0, (hipStream_t)stream, w, count, wp_fwd + pack_off_hdr(T, Ci16, Co16));
+    hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_fwd, Cout, Cin, T, Ci16, Co16, 0);
+  }
+  if (wp_dgrad) {
+    hipLaunchKernelGGL(k_wamax, dim3(16), dim3(256), 0, (hipStream_t)stream, w, count, wp_dgrad + pack_off_hdr(T, Co16, Ci16));
+    hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_dgrad, Cout, Cin, T, Co16, Ci16, 1);
+  }
   BCP_CHECK_LAUNCH("bcp_conv3_pack_weight");
   return BCP_OK;
 }
@@ -1241,6 +1316,7 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
 extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
   BCP_REQUIRE(descs_dev && n > 0 && n <= kMaxPackDescs, "bcp_conv3_pack_many: need 1..%d descriptors", kMaxPackDescs);
   static_assert(sizeof(PackDesc) == 40, "descriptor layout is part of the ABI");
+  hipLaunchKernelGGL(k_wamax_many, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
   hipLaunchKernelGGL(k_pack_conv3_many, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n);
   BCP_CHECK_LAUNCH("bcp_conv3_pack_many");
   return BCP_OK;
@@ -1299,9 +1375,11 @@ extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int 
 // shared by the launch and by the statistics-rows query: returns the number of partial rows per group the chosen kernel
 // writes (0: this shape does not support fused statistics, e.g. split-K), or a negative error
 static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout,
-                          int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream) {
+                          int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream,
+                          const float* x_amax = nullptr) {
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
+  cd.xamax = x_amax;
   bool done = false;
   int rows = 0;
   Cfg r;
@@ -1330,13 +1408,13 @@ static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, fl
 }
 
 extern "C" int bcp_conv3_fwd(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
-                             int Cout, int KD, int accumulate, void* workspace, void* stream) {
+                             int Cout, int KD, int accumulate, void* workspace, const float* x_amax_or_null, void* stream) {
   BCP_REQUIRE(x && wp && y, "bcp_conv3_fwd: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd: bad extents");
   BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd: KD=1 needs D=1");
   BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd: Cin=%d must be a multiple of 4 (Cin=1 has its own entry point)", Cin);
   BCP_REQUIRE(aligned16(x) && aligned16(wp), "bcp_conv3_fwd: x / wp must be 16-B aligned");
-  const int rc = conv3_fwd_impl(x, wp, bias, y, N, D, H, W, Cin, Cout, KD, accumulate, workspace, nullptr, 0, false, stream);
+  const int rc = conv3_fwd_impl(x, wp, bias, y, N, D, H, W, Cin, Cout, KD, accumulate, workspace, nullptr, 0, false, stream, x_amax_or_null);
   if (rc < 0) return rc;
   BCP_CHECK_LAUNCH("bcp_conv3_fwd");
   return BCP_OK;
@@ -1374,12 +1452,13 @@ extern "C" size_t bcp_conv3_wgrad_path(int N, int D, int H, int W, int Cin, int 
 }
 
 extern "C" int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
-                                   int Cout, int KD, void* workspace, double* stat_partial, int groups, void* stream) {
+                                   int Cout, int KD, void* workspace, double* stat_partial, int groups, const float* x_amax_or_null,
+                                   void* stream) {
   BCP_REQUIRE(x && wp && y && stat_partial, "bcp_conv3_fwd_stats: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0 && groups >= 1, "bcp_conv3_fwd_stats: bad extents");
   BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd_stats: Cin=%d must be a multiple of 4", Cin);
   BCP_REQUIRE(aligned16(x) && aligned16(wp), "bcp_conv3_fwd_stats: x / wp must be 16-B aligned");
-  const int rc = conv3_fwd_impl(x, wp, bias, y, N, D, H, W, Cin, Cout, KD, 0, workspace, stat_partial, groups, false, stream);
+  const int rc = conv3_fwd_impl(x, wp, bias, y, N, D, H, W, Cin, Cout, KD, 0, workspace, stat_partial, groups, false, stream, x_amax_or_null);
   if (rc < 0) return rc;
   BCP_REQUIRE(rc > 0, "bcp_conv3_fwd_stats: fused statistics unavailable for this shape (check bcp_conv3_stat_rows first)");
   BCP_CHECK_LAUNCH("bcp_conv3_fwd_stats");
@@ -1403,13 +1482,14 @@ extern "C" int bcp_conv3_bwdstat_rows(int N, int D, int H, int W, int Cin, int C
 
 extern "C" int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout,
                                         int KD, const float* y_prev, const float* stats_prev, int act, void* workspace,
-                                        double* stat_partial, int groups, void* stream) {
+                                        double* stat_partial, int groups, const float* dy_amax_or_null, void* stream) {
   BCP_REQUIRE(dy && wp_dgrad && da && y_prev && stats_prev && stat_partial, "bcp_conv3_dgrad_bwdstats: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0 && groups >= 1, "bcp_conv3_dgrad_bwdstats: bad extents");
   BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_dgrad_bwdstats: Cin=%d must be a multiple of 4", Cin);
   BCP_REQUIRE(aligned16(dy) && aligned16(wp_dgrad) && aligned16(y_prev), "bcp_conv3_dgrad_bwdstats: dy / wp / y_prev must be 16-B aligned");
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
+  cd.xamax = dy_amax_or_null;
   bool handled = false;
   const BwdStatsIn bw{y_prev, stats_prev, act};
   const int rows = b6_fwd(dy, wp_dgrad, nullptr, da, cd, KD, 0, workspace, stat_partial, groups, false, (hipStream_t)stream, &handled, nullptr, &bw);
@@ -1435,7 +1515,7 @@ extern "C" int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cou
 }
 
 extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int nslab, int N, int D, int H, int W, int Cin, int Cout,
-                                 int KD, void* stream) {
+                                 int KD, const float* x_amax_or_null, void* stream) {
   BCP_REQUIRE(x && wp && slabs, "bcp_conv3_fwd_raw: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_fwd_raw: bad extents");
   BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd_raw: KD=1 needs D=1");
@@ -1452,6 +1532,7 @@ extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, 
   BCP_REQUIRE(handled && sk > 0, "bcp_conv3_fwd_raw: shape not served in raw mode (check bcp_conv3_fwd_nslabs first)");
   BCP_REQUIRE(sk == nslab, "bcp_conv3_fwd_raw: the launch writes %d slabs under the current options, the caller allocated %d (stale bcp_conv3_fwd_nslabs answer?)", sk, nslab);
   handled = false;
+  cd.xamax = x_amax_or_null;
   b6_fwd(x, wp, nullptr, slabs, cd, KD, 0, slabs, nullptr, 0, false, (hipStream_t)stream, &handled, &sk);
   BCP_REQUIRE(handled && sk == nslab, "bcp_conv3_fwd_raw: shape not served in raw mode (check bcp_conv3_fwd_nslabs first)");
   BCP_CHECK_LAUNCH("bcp_conv3_fwd_raw");

@@ -40,18 +40,9 @@ struct ConvDims {
   int Cin16, Cout16;    // padded to multiples of 16 (packed-weight extents)
   int tiles_d, tiles_h, tiles_w;
   int xcd;              // != 0: XCD-aware workgroup -> tile order in the bf16-pipe kernels (option conv3_xcd)
-  int stagger;          // low 16 bits: late start of every second workgroup in ~0.9-us units (option conv3_stagger); bits 16..: which id bit selects them
+  const float* xamax;   // device float: max |x| of the input tensor (from the norm apply pass that wrote it), or NULL.  Non-NULL selects the
+                        // two-plane fp16 instances where they exist (option conv3_f16); the three-plane bf16 ones need no scale
 };
-
-// de-phase the co-resident workgroups of a CU (see Options::conv3_stagger): called once at kernel entry
-__device__ __forceinline__ void stagger_start(const ConvDims& cd) {
-  const int n = cd.stagger & 0xffff;
-  if (n) {
-    const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if ((lin >> (cd.stagger >> 16)) & 1u)
-      for (int i = 0; i < n; ++i) BCP_S_SLEEP(32);
-  }
-}
 
 // XCD-aware tile order for one-tile-per-workgroup grids.  Workgroups are dealt round-robin to the 8 XCDs in linear-id order, so
 // workgroup x of a grid row whose first workgroup has linear id `row_lin` runs on XCD (x + row_lin) % 8.  The workgroups of XCD c
@@ -315,6 +306,60 @@ __device__ __forceinline__ void split_store4(const float4& v, unsigned short* ba
   w.x = cvt_pk_bf16(r0, r1); w.y = cvt_pk_bf16(r2, r3);
   *reinterpret_cast<uint2*>(base + 2 * plane_stride) = w;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 4: TWO fp16 planes instead of three bf16 ones (conv3b.hip PL = 2).  x * s = h0 + h1 with h0 = fp16(x * s), h1 = fp16(x * s - h0)
+// (22 mantissa bits + the sign of the residual), a * b ~ a0 b0 + a0 b1 + a1 b0: THREE v_mfma_f32_16x16x32_f16 per K block instead of
+// six bf16 ones, two thirds of the LDS fragment reads.  fp16 has 5 exponent bits, so both operands are pre-scaled by POWERS OF TWO taken
+// from the tensor's own |max| (exact; undone on the accumulator in the epilogue): the activation's comes from the norm apply pass that
+// wrote it (bcp_norm_fwd ... amax_out), the weights' from the packer (pack header).  With max * s in [2^13, 2^14) nothing overflows
+// (fp16 max 65504) and every element keeps an ABSOLUTE error <= 2^-25 in scaled units = 2^-38 of the tensor's max; measured error of a
+// conv against fp64: 1.0-1.3x the fp32 kernel's (tools/probe/f16split_numeric.py, tests/kernel_checks.py check_conv3_f16).
+// Without the per-tensor scale the split is NOT fp32-equivalent (uniformly small tensors lose up to 3 decimal digits): no scale, no PL = 2.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bcp_f16x2 __attribute__((ext_vector_type(2)));
+#ifndef BCP_F32X2_DEFINED
+typedef float bcp_f32x2b __attribute__((ext_vector_type(2)));
+#endif
+
+// power of two s with amax * s in [2^13, 2^14); 1 for amax = 0 / NaN / Inf.  Exponent clamped to +-60 so that the product of an
+// activation scale and a weight scale (and its reciprocal) stays a normal fp32 number.
+__host__ __device__ __forceinline__ int f16_scale_exp(float amax) {
+  if (!(amax > 0.f) || !(amax < 3.0e38f)) return 0;
+  int e;
+  (void)frexpf(amax, &e);                  // amax = m * 2^e, m in [0.5, 1)
+  e = 14 - e;
+  return e > 60 ? 60 : (e < -60 ? -60 : e);
+}
+__host__ __device__ __forceinline__ float f16_scale(float amax) { return ldexpf(1.f, f16_scale_exp(amax)); }
+
+// two floats -> packed fp16 pair (low half = a), round to nearest even (v_cvt_pk_f16_f32 on gfx950)
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {
+  const bcp_f32x2b v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bcp_f16x2));
+}
+__device__ __forceinline__ float f16lo_to_f32(unsigned h) { return (float)__builtin_bit_cast(bcp_f16x2, h)[0]; }
+__device__ __forceinline__ float f16hi_to_f32(unsigned h) { return (float)__builtin_bit_cast(bcp_f16x2, h)[1]; }
+
+// four consecutive channels of one voxel row, pre-scaled by s -> the two fp16 planes (8-byte stores)
+__device__ __forceinline__ void split_store4_f16(const float4& v, float s, unsigned short* base, int plane_stride) {
+  const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
+  const unsigned h0 = cvt_pk_f16(x0, x1), h1 = cvt_pk_f16(x2, x3);
+  uint2 w;
+  w.x = h0; w.y = h1;
+  *reinterpret_cast<uint2*>(base) = w;
+  w.x = cvt_pk_f16(x0 - f16lo_to_f32(h0), x1 - f16hi_to_f32(h0));
+  w.y = cvt_pk_f16(x2 - f16lo_to_f32(h1), x3 - f16hi_to_f32(h1));
+  *reinterpret_cast<uint2*>(base + plane_stride) = w;
+}
+
+// pack header behind the fp32 / bf16 / fp16 sections of a packed conv weight (bcp_conv3_packed_weight_floats): 32 floats,
+// [0] = max |w| of the layer, [1 .. 16] = the per-block partial maxima k_wamax_many left, rest reserved
+static constexpr int kPackHeaderFloats = 32;
+// float offsets of the sections of one packed weight: fp32 [T][K16/4][N16][4] | bf16 [K16/16][TP][3][N16][32] | fp16 [K16/16][TP][2][N16][32] | header
+__host__ __device__ __forceinline__ long long pack_off_bf16(int T, int K16, int N16) { return (long long)T * K16 * N16; }
+__host__ __device__ __forceinline__ long long pack_off_f16(int T, int K16, int N16) { return (long long)(T + 3 * ((T + 1) / 2)) * K16 * N16; }
+__host__ __device__ __forceinline__ long long pack_off_hdr(int T, int K16, int N16) { return (long long)(T + 5 * ((T + 1) / 2)) * K16 * N16; }
 
 struct Cfg { int KD, TD, TH, TW, NT, WT; };
 

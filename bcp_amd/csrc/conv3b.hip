@@ -25,7 +25,6 @@
 //   k_c3q  the same pipeline on FLAT 64-voxel tiles for the deep levels (14x14x10, 7x7x5, 12^3, 6^3 ...), split-K
 //   k_c3b / k_c3h / k_c3f  the register-staged predecessors (2-D instances of k_c3b are still the U-Net's 64-channel-slab kernel; the
 //          others are kept behind conv3_b6_pipe = 0 and as the bit-identity twins of the pipelines in the tests)
-//   k_c3g  flat tiles with direct weight fragments (measured, not a default)
 // Reference ops: nn.Conv3d(k=3,pad=1) networks/VNet.py:17, nn.Conv2d(k=3,pad=1) networks/unet.py:19-25 and their backward.
 #include "conv3_defs.h"
 #include "../../include/bcp_hip.h"
@@ -69,6 +68,20 @@ extern "C" int bcp_debug_ts_clear() { static unsigned long long z[8192 * 2]; hip
 namespace bcp {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// operand planes: PL = 3 -> three bf16 pieces, six MFMAs per K block; PL = 2 -> two pre-scaled fp16 pieces, three MFMAs (conv3_defs.h)
+template <int PL> struct Pipe;
+template <> struct Pipe<3> {
+  using frag = bf16x8;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(const float4& v, float, unsigned short* base, int plane_stride) { split_store4(v, base, plane_stride); }
+  static __device__ __forceinline__ long long pack_off(int T, int K16, int N16) { return pack_off_bf16(T, K16, N16); }
+};
+template <> struct Pipe<2> {
+  using frag = f16x8;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(const float4& v, float s, unsigned short* base, int plane_stride) { split_store4_f16(v, s, base, plane_stride); }
+  static __device__ __forceinline__ long long pack_off(int T, int K16, int N16) { return pack_off_f16(T, K16, N16); }
+};
 static constexpr int XSB = 16;   // bf16 elements per halo voxel row: 32-byte rows, no padding (see b6_row)
 
 // ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32
@@ -91,7 +104,8 @@ __device__ __forceinline__ constexpr int b6_row(int i) {
 template <class TL, int TD, int TH, int TW, int NT, int MTv = TL::MT, bool BW = false>
 __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
                                               int n, int d0, int h0, int w0, int cout0, int accumulate, bool want_stats,
-                                              double (&s1)[NT][4], double (&s2)[NT][4], int wv = -1, const StatsArg* sb = nullptr, int gg = 0) {
+                                              double (&s1)[NT][4], double (&s2)[NT][4], int wv = -1, const StatsArg* sb = nullptr, int gg = 0,
+                                              float osc = 1.f /* power of two undoing the fp16 pre-scales (PL = 2); 1: exact no-op */) {
   constexpr int MT = MTv, CT = NT * 16;
   const int lane = threadIdx.x & 63, wave = wv >= 0 ? wv : (int)(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
@@ -156,7 +170,7 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
         float4 (&yb)[NT] = yball[MODE == 2 ? mt : 0];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          float4 v = make_float4(acc[mt][nt][0] + bv[nt][0], acc[mt][nt][1] + bv[nt][1], acc[mt][nt][2] + bv[nt][2], acc[mt][nt][3] + bv[nt][3]);
+          float4 v = make_float4(acc[mt][nt][0] * osc + bv[nt][0], acc[mt][nt][1] * osc + bv[nt][1], acc[mt][nt][2] * osc + bv[nt][2], acc[mt][nt][3] * osc + bv[nt][3]);
           if (ACCUM) { const float4 o = ld4(yrow + nt * 16); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
           if (!(B6_ABLATE & 1) || v.x == 1.2345e-30f) st4(yrow + nt * 16, v);
           if (MODE == 2) {
@@ -173,7 +187,7 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
           for (int r = 0; r < 4; ++r) {
             const int co = cout0 + nt * 16 + lg * 4 + r;
             if (co < cd.Cout) {
-              float v = acc[mt][nt][r] + bv[nt][r];
+              float v = acc[mt][nt][r] * osc + bv[nt][r];
               if (ACCUM) v += yrow[nt * 16 + r];
               if (!(B6_ABLATE & 1) || v == 1.2345e-30f) yrow[nt * 16 + r] = v;
               if (MODE == 2) bstat(nt, r, v, sb->by[eoff + nt * 16 + r]);
@@ -193,14 +207,15 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
 // one tile per workgroup (k_c3b): store + one statistics row per tile
 template <class TL, int TD, int TH, int TW, int NT, bool BW = false>
 __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __restrict__ Y, const float* __restrict__ bias, const ConvDims& cd,
-                                            int n, int d0, int h0, int w0, int cout0, int accumulate, const StatsArg& st, double* Ss, int bx) {
+                                            int n, int d0, int h0, int w0, int cout0, int accumulate, const StatsArg& st, double* Ss, int bx,
+                                            float osc = 1.f) {
   double s1[NT][4], s2[NT][4];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
   b6_store_tile<TL, TD, TH, TW, NT, TL::MT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st.partial != nullptr, s1, s2, -1, &st,
-                                                st.partial ? bx / st.tiles_per_group : 0);
+                                                st.partial ? bx / st.tiles_per_group : 0, osc);
   if (st.partial) {
     const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();                           // the scratch below aliases nothing, but waves may still be in the last stage
@@ -221,7 +236,6 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   constexpr int NW4 = (SP * 12 * CT + 255) / 256;              // 16-byte pieces of a stage per thread
   using HF = HaloFetch<TL>;
 
-  stagger_start(cd);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
   unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][SP][CT][32]
@@ -447,7 +461,6 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
   constexpr int NW4 = (12 * CT + 255) / 256;
   using HF = HaloFetch<TL>;
 
-  stagger_start(cd);
   BCP_TS(0);
   BCP_TSR(59);
   HIP_DYNAMIC_SHARED(float4, smem4)
@@ -642,7 +655,6 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
   constexpr int HFS = BCP_C3P_HFS >= 0 ? BCP_C3P_HFS : S - 6, HSS = S - 2;     // stage of a chunk that fetches / stashes the next chunk's halo (fetch early: see k_c3d's HPF)
   using HF = HaloFetch<TL>;
 
-  stagger_start(cd);
   BCP_TS(0);
   BCP_TSR(59);
   HIP_DYNAMIC_SHARED(float4, smem4)
@@ -819,20 +831,21 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
 #ifndef BCP_C3D_ATTR
 #define BCP_C3D_ATTR
 #endif
-template <int KD, int TD, int TH, int TW, int NT, bool PER, bool BW = false>
+template <int KD, int TD, int TH, int TW, int NT, bool PER, bool BW = false, int PL = 3>
 __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int n_tiles, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int MT = TL::MT, T = TL::T, TP = (T + 1) / 2, TPE = (TP + 1) & ~1, CT = NT * 16;
   constexpr int XPLANE = TL::HV * XSB;
   using HF = HaloFetch<TL>;
+  using PP = Pipe<PL>;
+  using frag_t = typename PP::frag;
 
-  stagger_start(cd);
   BCP_TS(0);
   BCP_TSR(59);
   HIP_DYNAMIC_SHARED(float4, smem4)
-  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
-  double* Ss = reinterpret_cast<double*>(Xb + 3 * XPLANE);         // [4][CT][2] statistics scratch
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [PL][HV][XSB]
+  double* Ss = reinterpret_cast<double*>(Xb + PL * XPLANE);        // [4][CT][2] statistics scratch
 
   const int lane = threadIdx.x & 63;
   const int li = lane & 15, lg = lane >> 4, wave = threadIdx.x >> 6;
@@ -896,16 +909,24 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
 
+  // PL = 2: power-of-two pre-scale of the activations (their |max| from the norm apply pass that wrote them) and of the weights
+  // (pack header); osc undoes both on the accumulators
+  float xsc = 1.f, osc = 1.f;
+  if (PL == 2) {
+    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    xsc = ldexpf(1.f, ex);
+    osc = ldexpf(1.f, -(ex + ew));
+  }
   // lane (li, lg): output channel li of n-tile nt, k quarter lg of pre-split pack row [chunk][pair][piece][cout][32 k]
-  const unsigned short* Wl = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16) + (long long)(cout0 + li) * 32 + lg * 8;
+  const unsigned short* Wl = reinterpret_cast<const unsigned short*>(Wp + PP::pack_off(T, cd.Cin16, cd.Cout16)) + (long long)(cout0 + li) * 32 + lg * 8;
   const long long piece_stride = (long long)cd.Cout16 * 32;
-  auto bload = [&](int cc, int tp, bf16x8 (&b)[NT][3]) __attribute__((always_inline)) {
+  auto bload = [&](int cc, int tp, frag_t (&b)[NT][PL]) __attribute__((always_inline)) {
     if (B6_ABLATE & 4) return;
-    const unsigned short* p = Wl + ((long long)cc * TP + (tp < TP ? tp : TP - 1)) * 3 * piece_stride;
+    const unsigned short* p = Wl + ((long long)cc * TP + (tp < TP ? tp : TP - 1)) * PL * piece_stride;
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < PL; ++s)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(p + s * piece_stride + nt * 16 * 32);
+      for (int nt = 0; nt < NT; ++nt) b[nt][s] = *reinterpret_cast<const frag_t*>(p + s * piece_stride + nt * 16 * 32);
   };
   unsigned hvm = 0;
   float4 hpre[HF::NP];
@@ -923,16 +944,16 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
     for (int u = 0; u < HF::NP; ++u)
       if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
         const float4 v = ((hvm >> u) & 1u) ? hpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
+        PP::split(v, xsc, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
       }
   };
 
-  bf16x8 B0[NT][3], B1[NT][3];
+  frag_t B0[NT][PL], B1[NT][PL];
   if (B6_ABLATE & 4) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s)
+    for (int s = 0; s < PL; ++s)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) { B0[nt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * 64 + nt * 8 + lane); B1[nt][s] = B0[nt][s]; }
+      for (int nt = 0; nt < NT; ++nt) { B0[nt][s] = *reinterpret_cast<const frag_t*>(Xb + s * 64 + nt * 8 + lane); B1[nt][s] = B0[nt][s]; }
   }
   BCP_TS(1);
   hfetch_item(0);
@@ -961,7 +982,7 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
     const int cc = c_begin + it % nch;
     const int ccn = c_begin + (it + 1 < n_items ? (it + 1) % nch : it % nch);
 #if BCP_C3D_STREAM
-    bf16x8 nx[BCP_C3D_FD];                           // the next pair's first fragments (fragment stream, below)
+    frag_t nx[BCP_C3D_FD];                           // the next pair's first fragments (fragment stream, below)
 #endif
 #pragma unroll
     for (int tp = 0; tp < TPE; ++tp) {
@@ -984,9 +1005,9 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
         // are four apart.
         {
           constexpr int MP = (NT > 1 && MT % BCP_C3D_MP == 0) ? BCP_C3D_MP : 1;      // m-tiles per MFMA group (one n-tile per wave: 1 -- measured 161 vs 168 us at the 16-channel level)
-          constexpr int NF = MT * 3, FD = BCP_C3D_FD < NF ? BCP_C3D_FD : NF;     // fragments per pair, prefetch distance
+          constexpr int NF = MT * PL, FD = BCP_C3D_FD < NF ? BCP_C3D_FD : NF;     // fragments per pair, prefetch distance
           static_assert(FD <= NF && MT % MP == 0, "fragment stream geometry");
-          auto fidx = [&](int f, int& mt, int& I) __attribute__((always_inline)) { const int g = f / (3 * MP), r = f % (3 * MP); I = 2 - r / MP; mt = g * MP + r % MP; };
+          auto fidx = [&](int f, int& mt, int& I) __attribute__((always_inline)) { const int g = f / (PL * MP), r = f % (PL * MP); I = PL - 1 - r / MP; mt = g * MP + r % MP; };
           // the stream runs ACROSS the pairs of a chunk: the first FD fragments of pair tp + 1 are requested under the last MFMA groups
           // of pair tp (nx), so only a chunk's first pair waits for an LDS round trip
           const int t0n = 2 * (tp + 1), t1n = 2 * (tp + 1) + 1 < T ? 2 * (tp + 1) + 1 : T - 1;
@@ -994,13 +1015,13 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
           const int toffn = ((lg >> 1) ? tBn : tAn) * XSB;
           const bool have_nx = tp > 0;                         // (compile-time after unrolling: pair 0 of a chunk follows a barrier)
           const bool want_nx = tp + 1 < TP;
-          bf16x8 fr[NF];
+          frag_t fr[NF];
 #pragma unroll
           for (int f = 0; f < FD; ++f) {
             int mt, I;
             fidx(f, mt, I);
             if (have_nx) fr[f] = nx[f];
-            else fr[f] = *reinterpret_cast<const bf16x8*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toff));
+            else fr[f] = *reinterpret_cast<const frag_t*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toff));
           }
 #pragma unroll
           for (int f0 = 0; f0 < NF; f0 += MP) {
@@ -1008,25 +1029,26 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
             for (int q = 0; q < MP; ++q) {
               const int g = f0 + q + FD;
               int mt, I;
-              if (g < NF) { fidx(g, mt, I); fr[g] = *reinterpret_cast<const bf16x8*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toff)); }
-              else if (want_nx) { fidx(g - NF, mt, I); nx[g - NF] = *reinterpret_cast<const bf16x8*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toffn)); }
+              if (g < NF) { fidx(g, mt, I); fr[g] = *reinterpret_cast<const frag_t*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toff)); }
+              else if (want_nx) { fidx(g - NF, mt, I); nx[g - NF] = *reinterpret_cast<const frag_t*>(Xb + I * XPLANE + voff[mt] + ((B6_ABLATE & 32) ? 0 : toffn)); }
             }
             __builtin_amdgcn_sched_barrier(0);
             int mt0, I;
             fidx(f0, mt0, I);
 #pragma unroll
-            for (int J = 2 - I; J >= 0; --J)
+            for (int J = PL - 1 - I; J >= 0; --J)
 #pragma unroll
               for (int q = 0; q < MP; ++q)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                  if (tp & 1) acc[mt0 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B1[nt][J], fr[f0 + q], acc[mt0 + q][nt], 0, 0, 0);
-                  else acc[mt0 + q][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(B0[nt][J], fr[f0 + q], acc[mt0 + q][nt], 0, 0, 0);
+                  if (tp & 1) acc[mt0 + q][nt] = PP::mfma(B1[nt][J], fr[f0 + q], acc[mt0 + q][nt]);
+                  else acc[mt0 + q][nt] = PP::mfma(B0[nt][J], fr[f0 + q], acc[mt0 + q][nt]);
                 }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
 #else
+        static_assert(PL == 3, "the unstreamed tap loop exists for the bf16 planes only");
         bf16x8 a[MT][3];
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -1050,7 +1072,7 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
       if (!PER) {
         BCP_TS(60);
         BCP_LDS_BARRIER();
-        b6_epilogue<TL, TD, TH, TW, NT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, t_first);      // one statistics row per tile
+        b6_epilogue<TL, TD, TH, TW, NT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, t_first, osc);      // one statistics row per tile
         BCP_TS(61);
         BCP_TSR(62);
         return;
@@ -1060,7 +1082,7 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
         stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)cur_g * st.rows + blockIdx.x) * st.C * 2, cout0, cd.Cout);
         cur_g = tl / st.tiles_per_group;
       }
-      b6_store_tile<TL, TD, TH, TW, NT, TL::MT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, want_stats, s1, s2, -1, &st, cur_g);
+      b6_store_tile<TL, TD, TH, TW, NT, TL::MT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, want_stats, s1, s2, -1, &st, cur_g, osc);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1550,188 +1572,6 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   BCP_TSR(62);
 }
 
-// ------------------------------------------------------------------------------------------------
-// FLAT tiles + DIRECT weight fragments (round 3): the deep-level kernel with the structure of the best mid-level one.  k_c3f gives
-// a wave ONE 16-voxel m-tile against a 64-channel slab (15 LDS fragment reads per 24 MFMAs: its tap loop is LDS-bound, and every
-// stage ends in a barrier that hands the weight buffers over); here a wave owns MT m-tiles (BM = 64 * MT consecutive voxels per
-// workgroup, waves along M) against a 32-channel slab, takes its weight fragments straight from the pre-split pack one tap pair
-// ahead (k_c3d: 6 KB per 48 MFMAs at MT = 4, no LDS stage, NO barrier in the tap loop) and reads 3 * (MT + 2) fragments per
-// 12 * MT MFMAs.  A 256-voxel tile also halves the flat halo over-read (BM + 2R rows staged per BM outputs: 2.2x instead of 5.8x
-// at 14x14x10) and the number of times the layer's weights cross the L2.  Split-K over the cin chunks fills the chip; the slabs go to
-// the one-launch norm kernels raw (bcp_conv3_fwd_raw) or are summed by k_b6_sum_slabs.
-// ------------------------------------------------------------------------------------------------
-template <int KD, int MT, int NT, int AVMAX>
-__global__ __launch_bounds__(256) void k_c3g(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
-                                             float* __restrict__ Y, ConvDims cd, int tiles_per_sample, int accumulate, StatsArg st) {
-  constexpr int BM = 64 * MT, T = KD * 9, TP = (T + 1) / 2, TPE = (TP + 1) & ~1, CT = NT * 16, PD = KD == 3 ? 1 : 0;
-  constexpr int XPLANE = AVMAX * XSB;
-  constexpr int NP = (AVMAX * 4 + 255) / 256;                  // halo float4 per thread (row, 4-channel part)
-
-  HIP_DYNAMIC_SHARED(float4, smem4)
-  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][AVMAX][XSB]
-  double* Ss = reinterpret_cast<double*>(Xb + 3 * XPLANE);         // [4][CT][2] statistics scratch
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int V = cd.D * cd.H * cd.W, HW = cd.H * cd.W;
-  const int R = PD * HW + cd.W + 1, AV = BM + 2 * R;               // AV <= AVMAX (checked by the launcher)
-  const int bx = cd.xcd ? xcd_tile(blockIdx.x, gridDim.x, gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) : (int)blockIdx.x;
-  const int n = bx / tiles_per_sample, m0 = (bx % tiles_per_sample) * BM;
-  const int cout0 = blockIdx.y * CT;
-
-  // this lane's MT voxels (one per m-tile), their halo rows and the validity bits of their 27 neighbours
-  int vrow[MT];
-  unsigned vbits[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int ml = (wave * MT + mt) * 16 + li, mv = m0 + ml;
-    vrow[mt] = (ml + R) * XSB + (lg & 1) * 8;
-    const int w = mv % cd.W, h = (mv / cd.W) % cd.H, d = mv / HW;
-    unsigned vb = 0;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-      const int kw = t % 3, kh = (t / 3) % 3, kd = t / 9;
-      const bool ok = (unsigned)(w + kw - 1) < (unsigned)cd.W && (unsigned)(h + kh - 1) < (unsigned)cd.H && (unsigned)(d + kd - PD) < (unsigned)cd.D;
-      vb |= (ok ? 1u : 0u) << t;
-    }
-    vbits[mt] = mv < V ? vb : 0u;
-  }
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int nchunks = cd.Cin16 >> 4;
-  const int c_begin = (int)((long long)nchunks * blockIdx.z / gridDim.z), c_end = (int)((long long)nchunks * (blockIdx.z + 1) / gridDim.z);
-  Y += (long long)blockIdx.z * cd.N * V * cd.Cout;
-
-  // lane (li, lg): output channel li of n-tile nt, k quarter lg of pre-split pack row [chunk][pair][piece][cout][32 k]  (k_c3d)
-  const unsigned short* Wl = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16) + (long long)(cout0 + li) * 32 + lg * 8;
-  const long long piece_stride = (long long)cd.Cout16 * 32;
-  auto bload = [&](int cc, int tp, bf16x8 (&b)[NT][3]) __attribute__((always_inline)) {
-    if (B6_ABLATE & 64) { cc = c_begin; tp = 0; }       // (measurement: cache-resident weight fetches)
-    const unsigned short* p = Wl + ((long long)cc * TP + (tp < TP ? tp : TP - 1)) * 3 * piece_stride;
-#pragma unroll
-    for (int s = 0; s < 3; ++s)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(p + s * piece_stride + nt * 16 * 32);
-  };
-  // halo: row r of the flat range = voxel m0 - R + r of sample n (zero outside [0, V) and beyond Cin); branch-free loads (k_c3f)
-  unsigned hvm = 0;
-  float4 hpre[NP];
-  const long long xbase = (long long)n * V * cd.Cin;
-  auto hfetch = [&](int cc) __attribute__((always_inline)) {
-    hvm = 0;
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      const int q = threadIdx.x + u * 256, r = q >> 2, part = q & 3;
-      const int gm = m0 - R + r;
-      const unsigned ok = (r < AV && (unsigned)gm < (unsigned)V && cc * 16 + part * 4 < cd.Cin) ? 1u : 0u;
-      const unsigned off = ok ? (unsigned)(xbase + (long long)gm * cd.Cin + cc * 16 + part * 4) : 0u;
-      hpre[u] = ld4(X + off);
-      hvm |= ok << u;
-    }
-  };
-  auto hstash = [&]() __attribute__((always_inline)) {
-#pragma unroll
-    for (int u = 0; u < NP; ++u) {
-      const int q = threadIdx.x + u * 256, r = q >> 2, part = q & 3;
-      if (r < AV) {
-        const float4 v = ((hvm >> u) & 1u) ? hpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Xb + r * XSB + part * 4, XPLANE);
-      }
-    }
-  };
-
-  bf16x8 B0[NT][3], B1[NT][3];
-  hfetch(c_begin);
-  bload(c_begin, 0, B0);
-  hstash();
-  BCP_LDS_BARRIER();
-  constexpr int HPF = TPE >= 6 ? TPE - 4 : 0;        // pair in front of which the next chunk's halo is fetched
-  const bf16x8 zero = __builtin_bit_cast(bf16x8, make_float4(0.f, 0.f, 0.f, 0.f));
-#pragma unroll 1
-  for (int cc = c_begin; cc < c_end; ++cc) {
-    if (cc > c_begin) {
-      BCP_LDS_BARRIER();                             // every wave is done with the previous chunk's halo planes
-      hstash();
-      BCP_LDS_BARRIER();
-    }
-    const int ccn = cc + 1 < c_end ? cc + 1 : cc;
-#pragma unroll
-    for (int tp = 0; tp < TPE; ++tp) {
-      // the next pair's weight fragments (the next chunk's pair 0 after the last one) into the other register set
-      if (tp & 1) { if (tp + 1 < TPE) bload(cc, tp + 1, B0); else bload(ccn, 0, B0); }
-      else bload(cc, tp + 1, B1);
-      if (tp == HPF) hfetch(ccn);                    // (the last chunk re-reads its own halo: no conditional load)
-      if (tp < TP) {
-        const int t0 = 2 * tp, t1 = 2 * tp + 1 < T ? 2 * tp + 1 : T - 1;
-        const int oA = ((t0 / 9) - PD) * HW + ((t0 / 3) % 3 - 1) * cd.W + (t0 % 3 - 1);      // wave-uniform row offsets of the two taps
-        const int oB = ((t1 / 9) - PD) * HW + ((t1 / 3) % 3 - 1) * cd.W + (t1 % 3 - 1);
-        const int toff = ((lg >> 1) ? oB : oA) * XSB;
-        const int tsel = (lg >> 1) ? t1 : t0;
-        bf16x8 a[MT][3];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const bool ok = ((vbits[mt] >> tsel) & 1u) != 0;
-#pragma unroll
-          for (int s = 0; s < 3; ++s) {
-            const bf16x8 v = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + vrow[mt] + toff);
-            a[mt][s] = ok ? v : zero;
-          }
-        }
-#define BCP_B6(BS, I, J)                                                                                        \
-  _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)            \
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BS[nt][J], a[mt][I], acc[mt][nt], 0, 0, 0);
-        if (tp & 1) { BCP_B6(B1, 2, 0) BCP_B6(B1, 1, 1) BCP_B6(B1, 0, 2) BCP_B6(B1, 1, 0) BCP_B6(B1, 0, 1) BCP_B6(B1, 0, 0) }
-        else { BCP_B6(B0, 2, 0) BCP_B6(B0, 1, 1) BCP_B6(B0, 0, 2) BCP_B6(B0, 1, 0) BCP_B6(B0, 0, 1) BCP_B6(B0, 0, 0) }
-#undef BCP_B6
-      }
-    }
-  }
-
-  // epilogue: lane (li, lg) holds voxel m0 + (wave*MT + mt)*16 + li, channels lg*4 .. lg*4+3 of each n-tile: 16-byte stores into flat rows
-  double s1[NT][4], s2[NT][4];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
-  const bool vec = cout0 + CT <= cd.Cout && (cd.Cout & 3) == 0;     // uniform
-  const bool want_stats = st.partial != nullptr;
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int mv = m0 + (wave * MT + mt) * 16 + li;
-    if (mv < V) {
-      float* yrow = Y + ((long long)n * V + mv) * cd.Cout + cout0 + lg * 4;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float o[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int co = cout0 + nt * 16 + lg * 4 + r;
-          float v = acc[mt][nt][r] + ((bias && co < cd.Cout) ? bias[co] : 0.f);
-          if (accumulate && co < cd.Cout) v += yrow[nt * 16 + r];
-          o[r] = v;
-          if (want_stats && co < cd.Cout) { s1[nt][r] += (double)v; s2[nt][r] += (double)v * (double)v; }
-        }
-        if (vec) st4(yrow + nt * 16, make_float4(o[0], o[1], o[2], o[3]));
-        else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (cout0 + nt * 16 + lg * 4 + r < cd.Cout) yrow[nt * 16 + r] = o[r];
-        }
-      }
-    }
-  }
-  if (want_stats) {
-    const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
-    BCP_LDS_BARRIER();
-    stats_flush_t<NT>(s1, s2, Ss, st.partial + ((long long)gg * st.rows + row) * st.C * 2, cout0, cd.Cout);
-  }
-}
-
 __global__ __launch_bounds__(256) void k_b6_sum_slabs(const float* __restrict__ part, int K, long long n, int Cout,
                                                       const float* __restrict__ bias, float* __restrict__ y, int accumulate) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
@@ -1751,6 +1591,14 @@ constexpr bool b6_has_bw() {
   // (not the 2-D 8x16 x 64-channel-slab instance: with the epilogue it needs 256 + 48 registers = one workgroup per CU)
 }
 
+// tile configurations that have a two-plane fp16 instance (PL = 2; selected when the launch carries the input's |max| and option conv3_f16
+// allows it): round 4 -- the direct-weight kernel k_c3d (16- / 32-channel slabs, 3-D and 2-D)
+template <int KD, int TD, int TH, int TW, int NT, int SP>
+constexpr bool b6_has_f16() {
+  return SP == 1 && ((KD == 3 && TD == 4 && TH == 8 && TW == 8 && (NT == 1 || NT == 2)) || (KD == 3 && TD == 4 && TH == 4 && TW == 8 && NT == 2) ||
+                     (KD == 1 && TD == 1 && TH == 16 && TW == 16 && (NT == 1 || NT == 2)));
+}
+
 // dynamic LDS of k_c3p: two halo buffers, three weight slots, statistics scratch
 template <class TL>
 static constexpr size_t kC3pLds = (size_t)2 * 3 * TL::HV * XSB * 2 + (size_t)3 * 3 * 64 * 32 * 2 + (size_t)4 * 32 * 2 * sizeof(double);
@@ -1763,7 +1611,10 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   // k_c3d only where a wave's weight traffic is small next to its MFMAs: 256-voxel tiles with a 32-channel slab (6 KB per 48 MFMAs;
   // the 64-voxel / 64-channel instances would pull 12 KB per 24 MFMAs through L1: 79-84 vs 47-51 us)
   const bool direct = options().conv3_b6_direct != 0 && (options().conv3_b6_direct >= 2 || (TL::MT == 4 && NT <= 2));
-  const size_t lds = (size_t)3 * TL::HV * XSB * 2 + (direct ? 0 : (size_t)2 * 3 * SP * CT * 32 * 2) + (size_t)4 * CT * 2 * sizeof(double);
+  // two fp16 planes instead of three bf16 ones: the launch must carry the input's |max| (cd.xamax) and the instance must exist
+  const bool use_f16 = b6_has_f16<KD, TD, TH, TW, NT, SP>() && direct && cd.xamax != nullptr && options().conv3_f16 != 0;
+  if (!use_f16) cd.xamax = nullptr;
+  const size_t lds = (size_t)(use_f16 ? 2 : 3) * TL::HV * XSB * 2 + (direct ? 0 : (size_t)2 * 3 * SP * CT * 32 * 2) + (size_t)4 * CT * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   auto kfn = k_c3b<KD, TD, TH, TW, NT, SP>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1781,6 +1632,9 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     StatsArg none{nullptr, 0, 1, cd.Cout, 1};
     if (direct && NT != 1) {                           // (16-channel slabs: the persistent form of k_c3d is not a slab writer; staged kernel)
       auto kd = k_c3d<KD, TD, TH, TW, NT, false>;
+      if constexpr (b6_has_f16<KD, TD, TH, TW, NT, SP>()) {
+        if (use_f16) kd = k_c3d<KD, TD, TH, TW, NT, false, false, 2>;
+      }
       hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kd, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, gx, 0, none);
     } else {
@@ -1818,6 +1672,14 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     auto kd = k_c3d<KD, TD, TH, TW, NT, PER>;
     if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>() && !PER) {
       if (bw) kd = k_c3d<KD, TD, TH, TW, NT, PER, true>;
+    }
+    if constexpr (b6_has_f16<KD, TD, TH, TW, NT, SP>()) {
+      if (use_f16) {
+        kd = k_c3d<KD, TD, TH, TW, NT, PER, false, 2>;
+        if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>() && !PER) {
+          if (bw) kd = k_c3d<KD, TD, TH, TW, NT, PER, true, 2>;
+        }
+      }
     }
     hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (sk == 1) {
@@ -1922,52 +1784,6 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
   return st.partial ? st.rows : 0;
 }
 
-static constexpr int kB6FlatDAvMax = 576;   // flat halo rows (BM + 2 R) of the direct-weight flat instances: 3 x 576 x 32 B = 54 KB (two workgroups per CU)
-
-template <int KD, int MT, int NT>
-static int b6_launch_flatd(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
-                           double* stat_partial, int G, bool dry, hipStream_t s, int* raw_sk, const BwdStatsIn* bw) {
-  constexpr int CT = NT * 16, BM = 64 * MT;
-  const int V = cd.D * cd.H * cd.W, tps = cdiv(V, BM);
-  const size_t lds = (size_t)3 * kB6FlatDAvMax * XSB * 2 + (size_t)4 * CT * 2 * sizeof(double);
-  auto kfn = k_c3g<KD, MT, NT, kB6FlatDAvMax>;
-  if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  const int gx = cd.N * tps, gy = cd.Cout16 / CT;
-  const int nch = cd.Cin16 / 16;
-  // split-K over the cin chunks: as many workgroups as the 512 co-resident slots take (a power of two <= 8, >= 1 chunk each): the chain
-  // of a workgroup is 14 barrier-free tap pairs per chunk
-  int sk = 1;
-  const bool ws_fits = ws && (long long)cd.N * V * cd.Cout <= (1LL << 20);
-  if (ws_fits) {
-    const int cap = nch < 8 ? nch : 8;
-    while (sk * 2 <= cap && (long long)gx * gy * sk * 2 <= 512) sk *= 2;
-  }
-  { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
-  { const int f = options().conv3_b6_flat_sk; if (ws_fits && f >= 1 && f <= 8 && f <= nch) sk = f; }      // measurement override
-  if (raw_sk) {                                       // raw mode: see b6_launch
-    *raw_sk = sk;
-    if (dry) return 0;
-    StatsArg none{nullptr, 0, 1, cd.Cout, 1};
-    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, Y, cd, tps, 0, none);
-    return 0;
-  }
-  if (bw) return 0;
-  StatsArg st{nullptr, 0, 1, cd.Cout, G > 0 ? G : 1};
-  const bool stats_ok = sk == 1 && G > 0 && cd.N % G == 0;        // tiles are sample-major and never straddle samples
-  if (stats_ok) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
-  if (dry) return stats_ok ? gx / G : 0;
-  if (sk == 1) {
-    hipLaunchKernelGGL(kfn, dim3(gx, gy, 1), dim3(256), lds, s, X, Wp, bias, Y, cd, tps, accumulate, st);
-  } else {
-    const long long n = (long long)cd.N * V * cd.Cout;
-    StatsArg none{nullptr, 0, 1, cd.Cout, 1};
-    hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds, s, X, Wp, (const float*)nullptr, ws, cd, tps, 0, none);
-    hipLaunchKernelGGL(k_b6_sum_slabs, dim3((int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, s, ws, sk, n, cd.Cout, bias, Y,
-                       accumulate);
-  }
-  return st.partial ? st.rows : 0;
-}
-
 // Forward / dgrad on the bf16 pipe where option conv3_b6 allows it.  Returns the statistics rows (as conv3_fwd_impl does);
 // *handled = false leaves the shape to the fp32 kernels.
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
@@ -1991,19 +1807,8 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
         // (128-voxel tiles: 280 workgroups, one per CU, nothing to overlap with: 66-71 us against 47-51 us).  Deep level
         // (14x14x10, from 2 K voxels): 2x8x4 tiles (37 % padding; 4x8x4 wastes 57 %): 40 us against 52 us for the fp32 kernel, LA step
         // 7.90 against 7.97 ms.  The 7x7x5 level stays with the fp32 kernel (35 vs 32 us).
-        const int v = o.conv3_b6_cfg64;             // measurement switch
         if (vox >= 16LL * 1024) {
-          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-          else if (v == 4) rows = b6_launch<3, 4, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-          else rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-        } else if (o.conv3_b6_flatd && 128 + 2 * (cd.H * cd.W + cd.W + 1) <= kB6FlatDAvMax) {
-          // flat tiles + direct weight fragments (k_c3g): 256-voxel tiles where the launch still fills the chip at split-K <= 8, else 128
-          const int nchs = cd.Cin16 / 16 < 8 ? cd.Cin16 / 16 : 8;
-          const long long wg4 = (long long)cd.N * cdiv(cd.D * cd.H * cd.W, 256) * (cd.Cout16 / 32) * nchs;
-          const bool mt4 = o.conv3_b6_flatd == 4 || (o.conv3_b6_flatd != 2 && wg4 >= 384 && 256 + 2 * (cd.H * cd.W + cd.W + 1) <= kB6FlatDAvMax);
-          if (mt4) rows = b6_launch_flatd<3, 4, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-          else rows = b6_launch_flatd<3, 2, 2>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          rows = b6_launch<3, 4, 4, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         } else if (o.conv3_b6_flat && 64 + 2 * (cd.H * cd.W + cd.W + 1) <= kB6FlatAvMax) {
           // flat 64-voxel tiles; narrower slabs for the smallest volumes (7x7x5: 8 tiles) so that the grid still covers the CUs at the
           // split-K the launcher picks
@@ -2014,16 +1819,13 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
           else if (nt == 2) rows = b6_launch_flat<3, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
           else rows = b6_launch_flat<3, 1, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         } else {
-          if (v == 1) rows = b6_launch<3, 4, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-          else if (v == 3) rows = b6_launch<3, 4, 4, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-          else if (v == 5) rows = b6_launch<3, 2, 8, 4, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
-          else rows = b6_launch<3, 2, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+          rows = b6_launch<3, 2, 8, 4, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         }
         *handled = true;
       }
     } else if (cd.Cout16 % 32 == 0) {
       if (forced || ((o.conv3_b6_levels & 1) && vox >= o.conv3_b6_minvox)) {
-        if (o.conv3_b6_cfg32 != 1 && (vox >= 64LL * 1024 || cd.W % 8 == 0)) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+        if (vox >= 64LL * 1024 || cd.W % 8 == 0) rows = b6_launch<3, 4, 8, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         else rows = b6_launch<3, 4, 4, 8, 2, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
         *handled = true;
       }
@@ -2040,8 +1842,7 @@ int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const C
       }
     } else if (cd.Cout16 % 64 == 0 && on) {
       // (flat 64-pixel tiles, k_c3f<1,..>, lose here: ACDC step 4.28 / 4.44 vs 4.14 ms for the levels up to 16 K / 64 K pixels)
-      if (o.conv3_b6_cfg2d64 == 1) rows = b6_launch<1, 1, 8, 8, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);   // 64-pixel tiles: the 2 x 2 wave arrangement (k_c3h / k_c3p)
-      else rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
+      rows = b6_launch<1, 1, 8, 16, 4, 1>(x, wp, bias, y, cd, accumulate, ws, stat_partial, G, dry, s, raw_sk, bw);
       *handled = true;
     } else if (cd.Cout16 % 32 == 0 && on) {
       // 32-channel slabs: from 64 K pixels on 16x16 tiles with direct weight fragments (k_c3d, as the 3-D 32-channel level) -- the

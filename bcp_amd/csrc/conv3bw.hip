@@ -67,7 +67,6 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
   static_assert(TW % 4 == 0 && M % 32 == 0, "a transposed read covers 4 consecutive voxels of a W row");
   using HF = HaloFetch<TL>;
 
-  stagger_start(cd);
   HIP_DYNAMIC_SHARED(float4, smem4)
   unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][16]
   unsigned short* Yb = Xb + 3 * XPLANE;                            // [3][M][YS]

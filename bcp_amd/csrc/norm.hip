@@ -234,7 +234,8 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_norm_finalize(const double
                                                        const float* __restrict__ beta, float* __restrict__ running_mean,
                                                        float* __restrict__ running_var, float momentum, float eps,
                                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
-                                                       float* __restrict__ shift, float* __restrict__ var_unb) {
+                                                       float* __restrict__ shift, float* __restrict__ var_unb, float* __restrict__ amax_out) {
+  if (amax_out && blockIdx.x == 0 && threadIdx.x == 0) *amax_out = 0.f;      // the apply pass that follows max-reduces |a| into it
   const int chunks = C >> 4;
   const int g = blockIdx.x / chunks, chunk = blockIdx.x % chunks, c = chunk * 16 + (threadIdx.x & 15);
   double s1, s2;
@@ -289,6 +290,21 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_norm_bwd_finalize(const do
 // ------------------------------------------------------------------ apply passes
 // row-reversed position of float4 index p inside a segment (same column): (rows-1-r)*C4 + col
 #define REV(p) (nv - C4 - (p) + 2 * col)
+// block maximum of a non-negative per-thread value -> ONE atomic per block, and only when it would raise the slot (a stale read of the
+// slot only costs a redundant atomic).  fmaxf drops NaNs, so a NaN in the tensor is forwarded explicitly: the consumer then sees NaN,
+// takes scale 1, and the NaN reaches its output as it would on the bf16 / fp32 paths.  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void block_amax_publish(float m, float* __restrict__ slot) {
+  __shared__ float amax_red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = (t > m || t != t) ? t : m; }
+  if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) { const float t = amax_red[k]; m = (t > m || t != t) ? t : m; }
+    if (m != m) m = __uint_as_float(0x7fc00000u);                              // canonical positive NaN: above every number as an unsigned
+    if (!(m <= *reinterpret_cast<volatile float*>(slot))) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+  }
+}
 // a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]      (segments: see k_col_partial)
 __global__ __launch_bounds__(256) void k_norm_running_only(const float* __restrict__ mean, const float* __restrict__ var_unb, int G, int C,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {
@@ -300,8 +316,9 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
                                                     const float* __restrict__ residual, NormEpilogue ep, long long seg_rows,
                                                     int spg, int G, int C, float* __restrict__ out,
                                                     const float* __restrict__ var_unb, float* __restrict__ running_mean,
-                                                    float* __restrict__ running_var, float momentum) {
+                                                    float* __restrict__ running_var, float momentum, float* __restrict__ amax_out) {
   constexpr int U = 4;
+  float amax = 0.f;            // max |a| of what this thread writes (round 4: the fp16 pre-scale of the conv that reads a, conv3_defs.h)
   if (blockIdx.x == 0 && blockIdx.y == 0 && running_mean) update_running(mean, var_unb, G, C, running_mean, running_var, momentum);
   const int C4 = C >> 2;
   const int col = threadIdx.x & (C4 - 1);          // C4 is a power of two dividing 256: fixed for the whole loop
@@ -322,6 +339,8 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
     }
     if (residual) { o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w; }
     st4(out + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float t = fabsf(o[k]); amax = (t > amax || t != t) ? t : amax; }
   };
   // Back to front: the statistics pass (or the conv epilogue) that ran just before this kernel swept the tensor front to
   // back, so its tail is what the 256 MB memory-side cache still holds.  (col stays fixed: nv and stride are multiples of C4.)
@@ -348,6 +367,7 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
     if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
     one(i, v, r4, m4);
   }
+  if (amax_out) block_amax_publish(amax, amax_out);
 }
 
 // dy = scale * (dz - c1 - xhat*c2),  dz = da * epilogue' * act'(z)
@@ -467,7 +487,7 @@ void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long 
                               float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s) {
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C, *var_unb = stats + 4LL * G * C;
   hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta, running_mean,
-                     running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
+                     running_var, momentum, eps, mean, rstd, scale, shift, var_unb, (float*)nullptr);
   if (running_mean) hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
 }
 
@@ -512,7 +532,8 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
                             float* running_mean, float* running_var, float momentum, float eps, int act,
                             const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale,
                             const float* residual, float* stats /* [5][G][C]: mean, rstd, scale, beta, unbiased var */, void* workspace,
-                            const double* partial_in, int nb_in, float* out, void* stream) {
+                            const double* partial_in, int nb_in, float* out, float* amax_out /* nullable: max |out| (fp16 pre-scale of the conv that reads it) */,
+                            void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(y && stats && workspace, "bcp_norm_fwd: null pointer");
   BCP_REQUIRE(aligned16(y) && (!out || aligned16(out)) && aligned16(stats), "bcp_norm_fwd: alignment");
@@ -528,16 +549,16 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   float* var_unb = stats + 4LL * G * C;
   if (partial_in) {   // statistics partials were produced by the conv epilogue (bcp_conv3_fwd_stats)
     hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
+                       running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb, out ? amax_out : (float*)nullptr);
   } else {
     hipLaunchKernelGGL((k_col_partial<0>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial, SlabSrc{});
     hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
-                       running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
+                       running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb, out ? amax_out : (float*)nullptr);
   }
   if (out)
     hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, scale, shift, mean, residual,
-                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum);
+                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out);
   else if (running_mean)   // statistics only: the consumer applies the normalisation itself (bcp_pw16_fwd_norm); the apply pass also carries the running-statistics update
     hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
   BCP_CHECK_LAUNCH("bcp_norm_fwd");
@@ -588,7 +609,7 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
                                   long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
                                   const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace, float* out,
-                                  void* stream) {
+                                  float* amax_out, void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd_slabs", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(rows_per_group <= 4096, "bcp_norm_fwd_slabs: rows_per_group=%lld > 4096 (check bcp_norm_slabs_ok)", rows_per_group);
   BCP_REQUIRE(slabs && ysum && stats && workspace && nslab >= 1 && nslab <= 64, "bcp_norm_fwd_slabs: null pointer / bad slab count");
@@ -608,10 +629,10 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
   hipLaunchKernelGGL((k_col_partial<0, true>), dim3(sg.nbps, nseg), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial, sl);
   hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
-                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb);
+                     running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb, out ? amax_out : (float*)nullptr);
   if (out)
     hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, ysum, scale, shift, mean, residual,
-                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum);
+                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out);
   else if (running_mean)
     hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
   BCP_CHECK_LAUNCH("bcp_norm_fwd_slabs");

@@ -35,7 +35,7 @@ static const ShapeRow kShapes[] = {
 #undef BCP_SHAPE
 };
 
-constexpr int kMaxArgs = 24;
+constexpr int kMaxArgs = 28;
 struct Entry {
   Caller call;
   void* fn;

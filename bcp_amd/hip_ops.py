@@ -92,6 +92,22 @@ class Ops:
             self._ws[k] = w
         return w
 
+    # ---- per-tensor |max| (round 4): the norm apply pass that writes an activation leaves max |a| in a device float riding on the tensor
+    # object (`_bcp_amax`); a conv that reads the tensor hands it to the library (x_amax: power-of-two pre-scale of the fp16 planes).
+    # Views / slices do not carry the attribute: those launches take the three-plane bf16 kernels, which need no scale.
+    AMAX = True
+
+    def _amax_slot(self, out):
+        if out is None or not self.AMAX:
+            return None
+        a = torch.empty(4, dtype=torch.float32, device=out.device)
+        out._bcp_amax = a
+        return a
+
+    @staticmethod
+    def _amax_of(x):
+        return getattr(x, "_bcp_amax", None)
+
     def box_arg(self, box6):
         key = tuple(int(v) for v in box6)
         a = self._box_cache.get(key)
@@ -215,9 +231,10 @@ class Ops:
             assert out is None and residual is None and elem_mask is None
         elif out is None:
             out = torch.empty_like(y)
+        amax = self._amax_slot(out)
         self.b.call("bcp_norm_fwd", _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps), act,
                     _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws), _p(partial), int(nb), _p(out),
-                    self.stream(y))
+                    _p(amax), self.stream(y))
         return out, stats
 
     def norm_eval(self, y, gamma, beta, rmean, rvar, act, residual=None, eps=1e-5, out=None):
@@ -305,7 +322,7 @@ class Ops:
         self._chk(x, wp)
         N, D, H, W, Cin = x.shape
         slabs = torch.empty((nslab, N, D, H, W, Cout), dtype=torch.float32, device=x.device)
-        self.b.call("bcp_conv3_fwd_raw", _p(x), _p(wp), _p(slabs), int(nslab), N, D, H, W, Cin, Cout, KD, self.stream(x))
+        self.b.call("bcp_conv3_fwd_raw", _p(x), _p(wp), _p(slabs), int(nslab), N, D, H, W, Cin, Cout, KD, _p(self._amax_of(x)), self.stream(x))
         return slabs
 
     def norm_fwd_slabs(self, src, nslab, bias, G, gamma, beta, rmean, rvar, act, chan_scale=None, elem_mask=None, elem_scale=1.0,
@@ -324,9 +341,10 @@ class Ops:
         stats = torch.empty((5, G, Cc), dtype=torch.float32, device=src.device)
         out = None if stats_only else torch.empty(shape, dtype=torch.float32, device=src.device)
         ws = self.workspace("norm", self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc), src)
+        amax = self._amax_slot(out)
         self.b.call("bcp_norm_fwd_slabs", _p(src), int(nslab), n, _p(bias), _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar),
                     float(momentum), float(eps), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws),
-                    _p(out), self.stream(src))
+                    _p(out), _p(amax), self.stream(src))
         return out, stats, y
 
     def norm_bwd_slabs(self, y, da_src, nslab, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
@@ -371,7 +389,8 @@ class Ops:
             out = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=x.device)
         nbytes = self._ws_bytes("bcp_conv3_fwd_workspace_bytes", N, D, H, W, Cin, Cout, KD)
         ws = self.workspace("conv3", nbytes, x) if nbytes else None
-        self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), self.stream(x))
+        self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), _p(self._amax_of(x)),
+                    self.stream(x))
         return out
 
     def conv3_fwd_stats(self, x, wp, bias, Cout, KD, groups):
@@ -385,7 +404,8 @@ class Ops:
         ws = self.workspace("conv3", nbytes, x) if nbytes else None
         out = torch.empty((N, D, H, W, Cout), dtype=torch.float32, device=x.device)
         part = self.workspace(("statpart", rows), groups * rows * Cout * 16, x)
-        self.b.call("bcp_conv3_fwd_stats", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, _p(ws), _p(part), groups, self.stream(x))
+        self.b.call("bcp_conv3_fwd_stats", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, _p(ws), _p(part), groups, _p(self._amax_of(x)),
+                    self.stream(x))
         return out, part, rows
 
     def conv3_dgrad_bwdstats(self, dy, wd, Cin, KD, y_prev, stats_prev, act, groups):
@@ -401,7 +421,7 @@ class Ops:
         da = torch.empty((N, D, H, W, Cin), dtype=torch.float32, device=dy.device)
         part = self.workspace(("bstatpart", rows), groups * rows * Cin * 16, dy)
         self.b.call("bcp_conv3_dgrad_bwdstats", _p(dy), _p(wd), _p(da), N, D, H, W, Cout, Cin, KD, _p(y_prev), _p(stats_prev), act, _p(ws),
-                    _p(part), groups, self.stream(dy))
+                    _p(part), groups, _p(self._amax_of(dy)), self.stream(dy))
         return da, part, rows
 
     def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):

@@ -460,69 +460,21 @@ class HipNet(nn.Module):
         object.__setattr__(self, "_bplan", (self._offs, plan))
         return plan
 
-    # a second consumer of the same signal: the optimiser (train_step.OverlapStep) applies SGD / Adam + EMA + the weight re-pack to a
-    # suffix of the flat buffer as soon as its gradients are final, underneath the rest of the backward pass
-    _opt_bucket_hook = None
-
     def _grads_final_from(self, p, like):
-        if self._grad_bucket_hook is None and self._opt_bucket_hook is None:
+        if self._grad_bucket_hook is None:
             return
         lo = self._bucket_plan().get(id(p))
         if lo is None:
             return
-        for hook in (self._grad_bucket_hook, self._opt_bucket_hook):
-            if hook is not None:
-                hook(self, lo, like)
+        self._grad_bucket_hook(self, lo, like)
         rec = self.ops.b._rec
         if rec is not None:
             rec.add_py(self._replay_bucket_hook, lo, like, capturable=False)
 
     def _replay_bucket_hook(self, lo, like):
-        for hook in (self._grad_bucket_hook, self._opt_bucket_hook):     # the hooks armed for THIS step, not the ones seen while recording
-            if hook is not None:
-                hook(self, lo, like)
-
-    # ---- packed-weight bookkeeping for the overlapped optimiser step: which conv / k2 layers have their weight inside a flat range,
-    # and "everything is packed for the current weights" without a launch
-    def _pack_index(self):
-        idx = self.__dict__.get("_pidx")
-        if idx is None or idx[0] is not self._offs:
-            c3 = [self._offs[id(w)] for _, w, _ in getattr(self, "_c3", ())]
-            k2 = [self._offs[id(w)] for _, w, *_ in getattr(self, "_k2", ())]
-            assert c3 == sorted(c3) and k2 == sorted(k2), "layers are registered in flat-buffer order"
-            idx = (self._offs, c3, k2)
-            object.__setattr__(self, "_pidx", idx)
-        return idx[1], idx[2]
-
-    def pack_range(self, lo, hi, need_dgrad):
-        """re-pack the conv / k2 weights living in flat elements [lo, hi) (their layers form a contiguous run of the descriptor tables)"""
-        import bisect
-        if getattr(self, "_pack_ptr", None) != self._flat.data_ptr():
-            self._build_pack_tables()
-        if getattr(self, "_k2", None) and getattr(self, "_k2_ptr", None) != self._flat.data_ptr():
-            self._build_k2_tables()
-        c3, k2 = self._pack_index()
-        i0, i1 = bisect.bisect_left(c3, lo), bisect.bisect_left(c3, hi)
-        if i1 > i0:
-            if need_dgrad:
-                self.ops.conv3_pack_many(self._desc_all[80 * i0:80 * i1], 2 * (i1 - i0))
-            else:
-                self.ops.conv3_pack_many(self._desc_fwd[40 * i0:40 * i1], i1 - i0)
-        j0, j1 = bisect.bisect_left(k2, lo), bisect.bisect_left(k2, hi)
-        if j1 > j0:
-            if need_dgrad:
-                self.ops.k2_pack_many(self._k2_desc_all[128 * j0:128 * j1], 2 * (j1 - j0))
-            else:
-                self.ops.k2_pack_many(self._k2_desc_fwd[64 * j0:64 * j1], j1 - j0)
-
-    def mark_packed(self, has_dgrad):
-        """the flat weights changed (bump) AND every pack was refreshed range by range: the next forward must not pack again"""
-        self.bump()
-        ver = self.refresh_weights_version()
-        if getattr(self, "_c3", None):
-            self._pack_state = (ver, bool(has_dgrad))
-        if getattr(self, "_k2", None):
-            self._k2_state = (ver, bool(has_dgrad))
+        hook = self._grad_bucket_hook          # the hook armed for THIS step, not the one seen while recording
+        if hook is not None:
+            hook(self, lo, like)
 
     _instances = 0   # per-process instance counter: every network gets its own dropout stream
 
@@ -629,7 +581,7 @@ class HipNet(nn.Module):
             if not self._plan_ok(dout):
                 return self._backward_impl(saved, dout)
             plans = self._plans_for()
-            key = ("b", id(saved), tuple(dout.shape), self.ops.stream(dout), self._grad_bucket_hook is not None, self._opt_bucket_hook is not None,
+            key = ("b", id(saved), tuple(dout.shape), self.ops.stream(dout), self._grad_bucket_hook is not None,
                    bool(self.overlap_wgrad))
             pl = plans.get(key)
             self._ensure_packed(True)

@@ -98,21 +98,6 @@ class FlatSGD:
         self.steps += 1
         self.model.bump()
 
-    # ---- the same update a range at a time (OverlapStep): elementwise, so bit-identical to step()
-    def begin_step(self):
-        p, _ = self.model.flat_trainable()
-        if self.buf is None:
-            self.buf = torch.zeros_like(p)
-        return self.steps == 0
-
-    def step_range(self, lo, hi, first):
-        g = self.param_groups[0]
-        p, gr = self.model.flat_trainable()
-        _ops_for(p).sgd(p[lo:hi], gr[lo:hi], self.buf[lo:hi], g["lr"], g["momentum"], g["weight_decay"], first_step=first, grad_scale=self.grad_scale)
-
-    def end_step(self):
-        self.steps += 1
-
     def state_dict(self):
         """torch.optim.SGD's layout: {'state': {i: {'momentum_buffer': tensor}}, 'param_groups': [{..., 'params': [0..n-1]}]}
         with per-parameter VIEWS of the flat momentum buffer (no state before the first step, as in torch)."""
@@ -169,22 +154,6 @@ class FlatAdam:
         _ops_for(p).adam(p, gr, self.m, self.v, g["lr"], self.steps, g["betas"][0], g["betas"][1], g["eps"], grad_scale=self.grad_scale)
         self.model.bump()
 
-    # ---- the same update a range at a time (OverlapStep)
-    def begin_step(self):
-        p, _ = self.model.flat_trainable()
-        if self.m is None:
-            self.m, self.v = torch.zeros_like(p), torch.zeros_like(p)
-        self.steps += 1
-        return self.steps
-
-    def step_range(self, lo, hi, step_no):
-        g = self.param_groups[0]
-        p, gr = self.model.flat_trainable()
-        _ops_for(p).adam(p[lo:hi], gr[lo:hi], self.m[lo:hi], self.v[lo:hi], g["lr"], step_no, g["betas"][0], g["betas"][1], g["eps"], grad_scale=self.grad_scale)
-
-    def end_step(self):
-        pass
-
     def state_dict(self):
         """torch.optim.Adam's layout: state[i] = {'step', 'exp_avg', 'exp_avg_sq'} (views of the flat moment buffers)"""
         g = self.param_groups[0]
@@ -218,109 +187,6 @@ class FlatAdam:
                 self.m[off:off + q.numel()].copy_(e["exp_avg"].reshape(-1).to(self.m.device, torch.float32))
                 self.v[off:off + q.numel()].copy_(e["exp_avg_sq"].reshape(-1).to(self.v.device, torch.float32))
                 self.steps = max(self.steps, int(float(e["step"])))
-
-
-class OverlapStep:
-    """The optimiser step, the EMA and the weight re-pack UNDERNEATH the backward pass (round 3).
-
-    The backward pass walks the layers in reverse registration order, so once layer L is done the flat gradient buffer is final from
-    L's first parameter to its end (the signal the data-parallel bucket exchange uses, bcp_amd/dp.py).  Every time >= `bucket_mb` of
-    new final gradients exist, this object applies -- on the weight-gradient side stream, ordered after the main stream -- the
-    optimiser update of that range (bcp_sgd / bcp_adam: elementwise, so a range at a time is bit-identical to one launch), the
-    teacher's EMA of the same range, and the re-pack of the conv / k2 weights living there (student: forward + dgrad packs, teacher:
-    forward).  What is left for `finish()` after the backward pass is the shallow remainder (a few hundred KB) plus the EMA of the
-    non-trainable tail.  The deep levels hold 80 % of the parameters and are differentiated first, so SGD + EMA + 2 x pack (0.2 ms at
-    the head of the next step, where nothing overlapped them) mostly disappear from the critical path.
-    Only for ONE backward pass per step (grouped student batches) and without data parallelism (its buckets must be reduced first)."""
-
-    def __init__(self, optimizer, model, ema_model, alpha, ema_whole_state, bucket_mb=None, first_frac=0.6):
-        """bucket_mb None (the product): ONE early range -- as soon as `first_frac` of the trainable buffer is final (the end of the deep
-        levels) -- then the remainder in finish(): every range costs a Python callback in the middle of the replayed backward pass, and
-        with 4 MB ranges (nine callbacks) the host fell behind the GPU at the deep levels (LA step 6.33 vs 6.11 ms).  A number: that many
-        MB per range (tests)."""
-        self.opt, self.model, self.ema, self.alpha, self.whole = optimizer, model, ema_model, alpha, ema_whole_state
-        model._ensure_flat()
-        ema_model._ensure_flat()
-        self.hi = model._n_trainable_flat
-        self.bucket = int(bucket_mb * (1 << 20)) // 4 if bucket_mb is not None else int(first_frac * self.hi)
-        self.once = bucket_mb is None
-        self.ok = (ema_model._n_trainable_flat == self.hi and ema_model.flat_state().numel() == model.flat_state().numel())
-        self.first = None
-        self.stream = None
-
-    def arm(self):
-        if self.ok:
-            self.first = self.opt.begin_step()
-            self.model._opt_bucket_hook = self._on_final
-        return self.ok
-
-    def _apply(self, lo, hi):
-        from . import plan
-        ops = self.model.ops
-        with plan.suspended(ops):               # never part of a recorded pass: lr / step count change from step to step
-            self.opt.step_range(lo, hi, self.first)
-            ops.ema(self.ema.flat_state()[lo:hi], self.model.flat_state()[lo:hi], self.alpha)
-            self.model.pack_range(lo, hi, True)
-            self.ema.pack_range(lo, hi, False)
-
-    def _on_final(self, model, lo, like):
-        if lo >= self.hi or self.hi - lo < self.bucket:
-            return
-        if like.is_cuda:
-            # a stream of its own: ordered after the main stream (norm / bias gradients) and the weight-gradient side stream, it runs
-            # next to both -- HBM-bound launches underneath MFMA-bound ones -- and delays neither
-            dev = like.device
-            st = _OPT_STREAMS.get(dev)
-            if st is None:
-                st = _OPT_STREAMS[dev] = torch.cuda.Stream(device=dev)
-            st.wait_stream(torch.cuda.current_stream(dev))
-            side = model._side_streams.get(dev) if model.overlap_wgrad else None
-            if side is not None:
-                st.wait_stream(side)
-            with torch.cuda.stream(st):
-                self._apply(lo, self.hi)
-            self.stream = st
-        else:
-            self._apply(lo, self.hi)
-        self.hi = lo
-        if self.once:
-            self.bucket = 1 << 62                # one early range only
-
-    def finish(self):
-        """after loss.backward() (the side stream has been joined): the remainder, the EMA of the non-trainable tail, bookkeeping"""
-        self.model._opt_bucket_hook = None
-        if self.stream is not None:
-            torch.cuda.current_stream(self.stream.device).wait_stream(self.stream)
-        if self.hi > 0:
-            self._apply(0, self.hi)
-        n_tr = self.model._n_trainable_flat
-        src = self.model.flat_state() if self.whole else self.model.flat_params()
-        dst = self.ema.flat_state() if self.whole else self.ema.flat_params()
-        if src.numel() > n_tr:
-            self.model.ops.ema(dst[n_tr:], src[n_tr:], self.alpha)        # unused heads (and, for the state-dict EMA, the BN buffers)
-        self.opt.end_step()
-        self.model.mark_packed(True)
-        self.ema.mark_packed(False)
-        if self.whole:
-            a, b = float(getattr(self.ema, "_nbt", 0)), float(getattr(self.model, "_nbt", 0))
-            self.ema._nbt = int(np.float32(np.float32(self.alpha) * np.float32(a)) + np.float32(np.float32(1 - self.alpha) * np.float32(b)))
-            self.ema._nbt_dirty = True
-
-
-_OPT_STREAMS = {}
-OVERLAP_STEP = False       # module switch (bench.py --opt overlap_step=1; parity tests compare both).  OFF: measured no faster (LA 6.26-6.30 vs
-                           # 6.16-6.22 ms, pancreas 5.66-5.71 vs 5.59-5.62): optimiser / EMA / pack launches at the step boundary are already
-                           # hidden -- the step is bound by its MFMA kernels and the deep levels' dependency chains (DESIGN.md 8.6)
-
-
-def _overlap_for(optimizer, model, ema_model, alpha, whole, dp, grouped):
-    from .networks._hipnet import HipNet
-    from . import plan
-    if not (OVERLAP_STEP and grouped and dp is None and isinstance(optimizer, (FlatSGD, FlatAdam)) and isinstance(model, HipNet)
-            and isinstance(ema_model, HipNet) and optimizer.model is model and plan.GRAPHS < 2):      # (a captured backward takes no callbacks)
-        return None
-    ov = OverlapStep(optimizer, model, ema_model, alpha, whole)
-    return ov if ov.arm() else None
 
 
 # ------------------------------------------------------------------------------------------ LA / pancreas step
@@ -421,15 +287,11 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         optimizer.zero_grad()
         if dp is not None and grouped:
             dp.arm(model)              # ONE backward in this step: gradient buckets go out underneath it
-        ov = _overlap_for(optimizer, model, ema_model, alpha, False, dp, grouped)
         loss.backward()
-        if ov is not None:
-            ov.finish()                # optimiser + EMA + re-pack ran range by range underneath the backward pass: only the remainder is left
-        else:
-            if dp is not None:
-                dp.allreduce_grads(model, optimizer)
-            optimizer.step()
-            BU.update_ema_variables(model, ema_model, alpha)
+        if dp is not None:
+            dp.allreduce_grads(model, optimizer)
+        optimizer.step()
+        BU.update_ema_variables(model, ema_model, alpha)
     model.drop_masks = None
     ema_model.drop_masks = None
     return dict(loss=loss.detach(), loss_l=loss_l.detach(), loss_u=loss_u.detach(), plab_a=own_plabs[0], plab_b=own_plabs[1],
@@ -577,15 +439,11 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
         optimizer.zero_grad()
         if dp is not None:
             dp.arm(model)              # one backward covers both student batches (grouped or not: `loss` sums their terms)
-        ov = _overlap_for(optimizer, model, ema_model, alpha, True, dp, grouped)
         loss.backward()
-        if ov is not None:
-            ov.finish()
-        else:
-            if dp is not None:
-                dp.allreduce_grads(model, optimizer)
-            optimizer.step()
-            update_model_ema(model, ema_model, alpha)
+        if dp is not None:
+            dp.allreduce_grads(model, optimizer)
+        optimizer.step()
+        update_model_ema(model, ema_model, alpha)
     model.drop_masks = None
     ema_model.drop_masks = None
     return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach(), plab_a=own_plabs[0], plab_b=own_plabs[1],

@@ -493,10 +493,6 @@ def main():
             from bcp_amd.networks._hipnet import HipNet as _hn
             _hn.WGRAD_STREAM_PRIORITY = int(v)
             continue
-        if k == "overlap_step":       # host-side switch (train_step.py): optimiser + EMA + re-pack underneath the backward pass
-            from bcp_amd import train_step as _ts2
-            _ts2.OVERLAP_STEP = bool(int(v))
-            continue
         if k == "fuse_c1":            # host-side switch (networks/VNet.py, unet.py): first layer + norm with recompute
             from bcp_amd.networks.VNet import VNet as _vn
             from bcp_amd.networks.unet import UNet_2d as _un

@@ -112,7 +112,9 @@ size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C);
 int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
                  const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace,
-                 const double* partial_in_or_null /* [G][nb_in][C][2] from bcp_conv3_fwd_stats */, int nb_in, float* out, void* stream);
+                 const double* partial_in_or_null /* [G][nb_in][C][2] from bcp_conv3_fwd_stats */, int nb_in, float* out,
+                 float* amax_out_or_null /* device float <- max |out| (round 4: the x_amax of the conv that reads out, see bcp_conv3_fwd) */,
+                 void* stream);
 int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
                  const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
                  float* dbeta, int accumulate, void* workspace, const double* partial_in_or_null, int nb_in, float* dy, void* stream);
@@ -134,7 +136,8 @@ int bcp_norm_slabs_ok(int G, long long rows_per_group, int C);
 int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_stride, const float* bias_or_null, float* ysum, int G,
                        long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
-                       float elem_scale, const float* residual, float* stats, void* workspace, float* out_or_null, void* stream);
+                       float elem_scale, const float* residual, float* stats, void* workspace, float* out_or_null, float* amax_out_or_null,
+                       void* stream);
 int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum, int G,
                        long long rows_per_group, int C, const float* stats, int act, const float* chan_scale, long long rows_per_sample,
                        const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy,
@@ -151,14 +154,19 @@ int bcp_conv3_pack_weight(const float* w, float* wp_fwd_or_null, float* wp_dgrad
  * (fwd: K16 = Cin16, N16 = Cout16; dgrad: K16 = Cout16, N16 = Cin16). */
 int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream);
 size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD); /* split-K slabs of the deep levels; may be 0 */
+/* x_amax_or_null (round 4, here and in _fwd_stats / _dgrad_bwdstats / _fwd_raw): device float holding max |x| over the WHOLE input
+ * tensor (an upper bound is enough), as the norm pass that wrote x leaves it (bcp_norm_fwd ... amax_out).  With it, shapes that have a
+ * two-plane fp16 instance take their operands as x * 2^ex = h0 + h1 (fp16) -- three v_mfma_f32_16x16x32_f16 per K block instead of six
+ * bf16 ones; power-of-two pre-scales from the tensor's and the layer's weights' own maxima, undone exactly on the accumulator; error
+ * against fp64 1.0-1.3x the fp32 kernel's.  NULL (or option conv3_f16 = 0): three bf16 planes, no scale needed. */
 int bcp_conv3_fwd(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin, int Cout,
-                  int KD, int accumulate, void* workspace_or_null, void* stream);
+                  int KD, int accumulate, void* workspace_or_null, const float* x_amax_or_null, void* stream);
 /* fused variant: the conv epilogue also emits the (sum, sum^2) partials of y that bcp_norm_fwd needs, for `groups`
  * consecutive sample ranges; rows = bcp_conv3_stat_rows(...) (0: unavailable for this shape -> use bcp_conv3_fwd);
  * stat_partial = double[groups][rows][Cout][2], handed to bcp_norm_fwd as partial_in with nb_in = rows. */
 int bcp_conv3_stat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups, int has_workspace);
 int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_null, float* y, int N, int D, int H, int W, int Cin,
-                        int Cout, int KD, void* workspace_or_null, double* stat_partial, int groups, void* stream);
+                        int Cout, int KD, void* workspace_or_null, double* stat_partial, int groups, const float* x_amax_or_null, void* stream);
 /* dgrad with the CONSUMER's norm-backward statistics in its epilogue (bf16-pipe kernels; autograd of Conv3d/Conv2d followed by
  * BatchNorm/InstanceNorm backward, networks/VNet.py:17-26): the output da feeds the norm layer whose pre-norm tensor is y_prev and
  * whose statistics are stats_prev ([5][groups][Cout] as bcp_norm_fwd leaves them); stat_partial = double[groups][rows][Cout][2]
@@ -168,14 +176,14 @@ int bcp_conv3_fwd_stats(const float* x, const float* wp, const float* bias_or_nu
 int bcp_conv3_bwdstat_rows(int N, int D, int H, int W, int Cin, int Cout, int KD, int groups);
 int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, int N, int D, int H, int W, int Cin, int Cout, int KD,
                              const float* y_prev, const float* stats_prev, int act, void* workspace_or_null, double* stat_partial,
-                             int groups, void* stream);
+                             int groups, const float* dy_amax_or_null, void* stream);
 /* raw variant for the deep levels: the kernel's split-K partial slabs are the result -- slabs = float[nslabs][N*D*H*W*Cout], no bias,
  * no slab-sum launch; bcp_norm_fwd_slabs / bcp_norm_bwd_slabs sum them on their way in.  nslabs = bcp_conv3_fwd_nslabs(...) under the
  * current options (1..8; 0: shape not served in raw mode -> bcp_conv3_fwd).  Forward and dgrad alike.  bcp_conv3_fwd_raw is told how
  * many slabs the caller allocated and refuses (nothing launched) when the launch would write a different number. */
 int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD);
 int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int nslab, int N, int D, int H, int W, int Cin, int Cout, int KD,
-                      void* stream);
+                      const float* x_amax_or_null, void* stream);
 /* which matrix pipe serves bcp_conv3_fwd / bcp_conv3_fwd_stats for this shape under the current options (no launch): 0 = fp32 MFMA
  * (v_mfma_f32_16x16x4_f32), 1 = bf16 MFMA with three-piece operands (fp32-equivalent results; csrc/conv3b.hip).  Measurement record only. */
 size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Cout, int KD);

@@ -1160,75 +1160,6 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
             assert torch.equal(a[2][k], b[2][k]), (what, "teacher", k)
 
 
-def check_overlap_step(ops, dev, steps=3, cases=("la", "pancreas", "acdc"), bucket_mb=(None, 0.25)):
-    """train_step.OverlapStep -- optimiser, EMA and weight re-pack applied range by range underneath the backward pass -- against the
-    plain step (one optimiser launch, one EMA launch after the backward pass; packs at the head of the next forward): BIT-identical
-    students, teachers, running statistics, losses and optimiser state over three steps, with recorded launch plans (the bucket hook is
-    a Python callable inside the backward plan) and without; SGD (LA, ACDC: state-dict EMA + num_batches_tracked) and Adam (pancreas);
-    two bucket sizes (0.25 MB: a dozen ranges per step)"""
-    from bcp_amd import plan, train_step
-
-    def run(overlap, what, plans_on, mb):
-        train_step.OVERLAP_STEP = overlap
-        plan.ENABLED = plans_on
-        real_init = train_step.OverlapStep.__init__
-
-        def init(self, *a, **k):
-            k["bucket_mb"] = mb
-            real_init(self, *a, **k)
-        train_step.OverlapStep.__init__ = init
-        try:
-            torch.manual_seed(5)
-            np.random.seed(5)
-            if what == "acdc":
-                P = O.init_params(O.unet_param_shapes(), seed=51, random_affine=True)
-                model, ema = make_unet(P, dev, ops), make_unet(P, dev, ops)
-                vol, lab = O.synth_acdc_batch(8, shape=(64, 64), seed=78)
-                opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
-            else:
-                shape = (32, 32, 16) if what == "la" else (32, 32, 32)
-                P = O.init_params(O.vnet_param_shapes(variant=what), seed=41, random_affine=True)
-                model, ema = make_vnet(P, dev, ops, what), make_vnet(P, dev, ops, what)
-                vol, lab = O.synth_la_batch(4, shape=shape, seed=77)
-                opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4) if what == "la" else train_step.FlatAdam(model, lr=1e-3)
-            model.seed_dropout(11)
-            ema.seed_dropout(12)
-            for p in ema.parameters():
-                p.detach_()
-            vol, lab = vol.to(dev), lab.to(dev)
-            losses = []
-            for it in range(steps):
-                opt.param_groups[0]["lr"] = (0.01 if what != "pancreas" else 1e-3) * (1.0 - 0.1 * it)      # a schedule: nothing may be baked into a plan
-                if what == "acdc":
-                    r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=(9, 13, 42, 42))
-                else:
-                    r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), variant=what,
-                                                      connect_mode=2 if what != "la" else None)
-                losses.append(float(r["loss"]))
-            st = opt.state_dict()["state"]
-            ostate = {(i, k): (v.detach().clone().cpu() if torch.is_tensor(v) else v) for i, e in st.items() for k, v in e.items()}
-            return (losses, {k: v.detach().clone().cpu() for k, v in model.state_dict().items()},
-                    {k: v.detach().clone().cpu() for k, v in ema.state_dict().items()}, ostate)
-        finally:
-            train_step.OverlapStep.__init__ = real_init
-            train_step.OVERLAP_STEP = False
-            plan.ENABLED = True
-
-    for what in cases:
-        ref = run(False, what, True, None)
-        for plans_on, mb in ((True, bucket_mb[0]), (True, bucket_mb[1]), (False, bucket_mb[1])):
-            got = run(True, what, plans_on, mb)
-            assert ref[0] == got[0], (what, plans_on, mb, ref[0], got[0])
-            for k in ref[1]:
-                assert torch.equal(ref[1][k], got[1][k]), (what, plans_on, mb, "student", k)
-            for k in ref[2]:
-                assert torch.equal(ref[2][k], got[2][k]), (what, plans_on, mb, "teacher", k)
-            assert ref[3].keys() == got[3].keys()
-            for k in ref[3]:
-                a, b = ref[3][k], got[3][k]
-                assert (torch.equal(a, b) if torch.is_tensor(a) else a == b), (what, "optimiser state", k)
-
-
 def check_fused_head(ops, dev, steps=2):
     """the head that normalises on its way in (VNet.fuse_head, bcp_pw16_fwd_norm / _bwd_norm) against the separate apply pass:
     self-training steps of the LA (BatchNorm, Dropout3d live, grouped) and pancreas (InstanceNorm) V-Nets from the same seeds;

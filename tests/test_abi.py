@@ -42,7 +42,7 @@ def test_version_and_argument_validation(lib):
     lib.bcp_norm_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_longlong, ctypes.c_int]
     assert lib.bcp_norm_workspace_bytes(1, 1003520, 16) > 0
     lib.bcp_conv3_packed_weight_floats.restype = ctypes.c_size_t
-    assert lib.bcp_conv3_packed_weight_floats(16, 16, 3) == (27 + 3 * 14) * 16 * 16    # fp32 pack + three bf16 planes of 14 tap pairs
+    assert lib.bcp_conv3_packed_weight_floats(16, 16, 3) == (27 + 3 * 14 + 2 * 14) * 16 * 16 + 32    # fp32 pack + three bf16 / two fp16 planes of 14 tap pairs + header
 
 
 def test_product_ops_refuse_cpu_tensors():

@@ -107,10 +107,3 @@ def test_head_fused_with_last_norm_equals_separate_apply(emu_ops):
 @pytest.mark.extended
 def test_vnet_second_output_is_pooled_x5(emu_ops):
     NC.check_vnet_features(emu_ops, CPU)
-
-
-@pytest.mark.extended
-def test_overlapped_optimiser_step_equals_plain_step(emu_ops):
-    from bcp_amd.utils import BCP_utils as BU
-    BU.set_test_ops(emu_ops)
-    NC.check_overlap_step(emu_ops, CPU, steps=2, cases=("la",), bucket_mb=(None, 0.25))      # (pancreas / ACDC: the GPU suite)

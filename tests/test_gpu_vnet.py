@@ -195,11 +195,6 @@ def test_recorded_launch_plans_equal_eager_path(ops):
     NC.check_launch_plans(ops, DEV)
 
 
-def test_overlapped_optimiser_step_equals_plain_step(ops):
-    """SGD / Adam + EMA + weight re-pack underneath the backward pass (train_step.OverlapStep) == the plain step, bit for bit"""
-    NC.check_overlap_step(ops, DEV)
-
-
 def test_graph_replays_equal_eager_path(ops):
     """on a real stream the recorded passes are captured: hipGraphLaunch per network pass == the eager path, bit for bit"""
     NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True), ("acdc", True)), graphs=1)

@@ -144,6 +144,27 @@ f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 cacc) {
   return cacc;
 }
 
+f32x4 mfma_16x16x32_f16(f16x8_emu a, f16x8_emu b, f32x4 cacc) {
+  // v_mfma_f32_16x16x32_f16: the bf16 instruction's lane layout with IEEE half operands (products exact in fp32; dot product + C in
+  // fp64, rounded once -- see mfma_16x16x32_bf16)
+  WaveScratch& w = my_wave();
+  unsigned p = next_phase();
+  int l = lane_id();
+  memcpy(w.a16[p][l], &a, 16);
+  memcpy(w.b16[p][l], &b, 16);
+  wave_sync();
+  auto hf = [](uint16_t h) { _Float16 f; memcpy(&f, &h, 2); return (double)(float)f; };
+  int col = l & 15, rg = l >> 4;
+  for (int r = 0; r < 4; ++r) {
+    int row = rg * 4 + r;
+    double acc = (double)cacc[r];
+    for (int kg = 0; kg < 4; ++kg)
+      for (int j = 0; j < 8; ++j) acc += hf(w.a16[p][kg * 16 + row][j]) * hf(w.b16[p][kg * 16 + col][j]);
+    cacc[r] = (float)acc;
+  }
+  return cacc;
+}
+
 uint64_t ds_read_tr16_b64(const void* ptr) {
   WaveScratch& w = my_wave();
   unsigned p = next_phase();

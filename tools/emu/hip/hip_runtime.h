@@ -167,6 +167,8 @@ f32x4 mfma_16x16x4(float a, float b, f32x4 c);
 f32x16 mfma_32x32x2(float a, float b, f32x16 c);
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 f32x4 mfma_16x16x32_bf16(bf16x8 a, bf16x8 b, f32x4 c);
+typedef _Float16 f16x8_emu __attribute__((ext_vector_type(8)));
+f32x4 mfma_16x16x32_f16(f16x8_emu a, f16x8_emu b, f32x4 c);
 uint64_t ds_read_tr16_b64(const void* p);   // ds_read_b64_tr_b16
 
 }  // namespace bcpemu
@@ -293,6 +295,7 @@ using std::min;
 #define __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, x, y, z) ::bcpemu::mfma_16x16x4((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) ::bcpemu::mfma_32x32x2((a), (b), (c))
 #define __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z) ::bcpemu::mfma_16x16x32_bf16((a), (b), (c))
+#define __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z) ::bcpemu::mfma_16x16x32_f16((a), (b), (c))
 #define __builtin_amdgcn_readfirstlane(v) (::bcpemu::shfl_generic((int)(v), 0))
 #define __builtin_amdgcn_s_barrier() ::bcpemu::block_sync()
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
