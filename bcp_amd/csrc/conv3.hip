@@ -783,16 +783,41 @@ __global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w,
   }
 }
 
-// max |w| of a layer in 16 per-block partials -> header[1 .. 16] of its pack (no atomics, nothing to zero): the packers read them
-__global__ __launch_bounds__(256) void k_wamax(const float* __restrict__ w, long long count, float* __restrict__ hdr) {
-  __shared__ float red[4];
-  float m = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += 16LL * 256) m = fmaxf(m, fabsf(w[i]));
+// max |w| over count floats, this block's share (blocks of a 16-wide grid row interleave 1024-float chunks): 16-byte loads, four
+// independent chains per thread (round 4, first version: one scalar load per iteration = a dependent-latency loop, 100 us for the V-Net)
+__device__ __forceinline__ float wamax_block(const float* __restrict__ w, long long count, float* red /* [4] shared */) {
+  float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  if ((reinterpret_cast<uintptr_t>(w) & 15u) == 0) {
+    const long long nv = count >> 2, stride = 16LL * 256;
+    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < nv; i += 4 * stride) {
+      const float4 a = ld4(w + i * 4), b = ld4(w + (i + stride) * 4), c = ld4(w + (i + 2 * stride) * 4), d = ld4(w + (i + 3 * stride) * 4);
+      m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+      m1 = fmaxf(m1, fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w))));
+      m2 = fmaxf(m2, fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w))));
+      m3 = fmaxf(m3, fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))));
+    }
+    for (; i < nv; i += stride) {
+      const float4 a = ld4(w + i * 4);
+      m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < (int)(count & 3)) m1 = fmaxf(m1, fabsf(w[(nv << 2) + threadIdx.x]));
+  } else {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += 16LL * 256) m0 = fmaxf(m0, fabsf(w[i]));
+  }
+  float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) hdr[1 + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+// max |w| of a layer in 16 per-block partials -> header[1 .. 16] of its pack (no atomics, nothing to zero): the packers read them
+__global__ __launch_bounds__(256) void k_wamax(const float* __restrict__ w, long long count, float* __restrict__ hdr) {
+  __shared__ float red[4];
+  const float m = wamax_block(w, count, red);
+  if (threadIdx.x == 0) hdr[1 + blockIdx.x] = m;
   if (blockIdx.x == 0 && threadIdx.x >= 17 && threadIdx.x < kPackHeaderFloats) hdr[threadIdx.x] = 0.f;      // reserved words: defined contents
 }
 
@@ -804,15 +829,9 @@ static constexpr int kMaxPackDescs = 512;
 __global__ __launch_bounds__(256) void k_wamax_many(const PackDesc* __restrict__ descs) {
   __shared__ float red[4];
   const PackDesc d = descs[blockIdx.y];
-  const long long count = (long long)d.Cout * d.Cin * d.T;
-  float m = 0.f;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += 16LL * 256) m = fmaxf(m, fabsf(d.w[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
-  __syncthreads();
+  const float m = wamax_block(d.w, (long long)d.Cout * d.Cin * d.T, red);
   float* hdr = d.wp + pack_off_hdr(d.T, d.K16, d.N16);
-  if (threadIdx.x == 0) hdr[1 + blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (threadIdx.x == 0) hdr[1 + blockIdx.x] = m;
   if (blockIdx.x == 0 && threadIdx.x >= 17 && threadIdx.x < kPackHeaderFloats) hdr[threadIdx.x] = 0.f;      // reserved words: defined contents
 }
 // Work unit = one 16 x 16 (k, n) block of one layer, all taps: the 16 source rows are runs of 16*T contiguous floats
