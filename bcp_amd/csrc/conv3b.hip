@@ -637,7 +637,7 @@ __global__ __launch_bounds__(256) void k_c3h(const float* __restrict__ X, const 
 // LDS: 2 x 20.25 KB halo + 3 x 12 KB weights + 2 KB = 78.5 KB -> two workgroups per CU.  Same MFMA sequence per accumulator as
 // k_c3h: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int KD, int TD, int TH, int TW, bool BW = false>
+template <int KD, int TD, int TH, int TW, bool BW = false, int PL = 3>
 __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
@@ -647,8 +647,10 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
                                                                // fragment register sets swap roles from chunk to chunk (PAR below), which the
                                                                // statically unrolled chunk PAIR absorbs
   static_assert(S >= 5 && S <= 14, "k_c3p: 5 (3x3) or 14 (3x3x3) tap pairs per chunk");
-  constexpr int XPLANE = TL::HV * XSB, XBUF = 3 * XPLANE;      // bf16 elements per halo plane / buffer
-  constexpr int WPLANE = CT * 32, WSLOT = 3 * WPLANE;          // one ring slot: 3 planes x 64 rows x 64 B = 12 KB
+  constexpr int XPLANE = TL::HV * XSB, XBUF = PL * XPLANE;     // 16-bit elements per halo plane / buffer
+  constexpr int WPLANE = CT * 32, WSLOT = PL * WPLANE;         // one ring slot: PL planes x 64 rows x 64 B = 12 KB (8 KB with two fp16 planes)
+  using PP = Pipe<PL>;
+  using frag_t = typename PP::frag;
 #ifndef BCP_C3P_HFS
 #define BCP_C3P_HFS 1
 #endif
@@ -658,8 +660,8 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
   BCP_TS(0);
   BCP_TSR(59);
   HIP_DYNAMIC_SHARED(float4, smem4)
-  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [2][3][HV][XSB]
-  unsigned short* Wr = Xb + 2 * XBUF;                              // [3 slots][3][CT][32]
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [2][PL][HV][XSB]
+  unsigned short* Wr = Xb + 2 * XBUF;                              // [3 slots][PL][CT][32]
   double* Ss = reinterpret_cast<double*>(Wr + 3 * WSLOT);          // [4][32][2] statistics scratch
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -689,21 +691,27 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
 
   // DMA piece q = u * 256 + thread of a stage lands at byte 16 q of the slot = (plane u, row q >> 2 & 63, k quarter POSITION q & 3);
   // that position holds k quarter (q & 3) ^ (row & 8 ? 2 : 0): per-thread source byte offsets, fixed for the whole kernel
-  const char* Wb16 = reinterpret_cast<const char*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  const char* Wb16 = reinterpret_cast<const char*>(Wp + PP::pack_off(T, cd.Cin16, cd.Cout16));
   unsigned wq[3];
   {
     const int co = (threadIdx.x >> 2) & 63, kq = (threadIdx.x & 3) ^ ((co & 8) ? 2 : 0);
 #pragma unroll
-    for (int u = 0; u < 3; ++u) wq[u] = (unsigned)(((u * cd.Cout16 + cout0 + co) * 32 + kq * 8) * 2);
+    for (int u = 0; u < 3; ++u) wq[u] = (unsigned)((((u < PL ? u : 0) * cd.Cout16 + cout0 + co) * 32 + kq * 8) * 2);
+  }
+  float xsc = 1.f, osc = 1.f;          // PL = 2: power-of-two pre-scales (k_c3d)
+  if (PL == 2) {
+    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    xsc = ldexpf(1.f, ex);
+    osc = ldexpf(1.f, -(ex + ew));
   }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   char* const Wr_wave = reinterpret_cast<char*>(Wr) + wave_u * 1024;        // this wave's 1 KB of every plane
   auto wdma = [&](int cc, int sg, unsigned slot_bytes) __attribute__((always_inline)) {
     while (sg >= S) { sg -= S; ++cc; }
     if (cc >= c_end) { cc = c_end - 1; sg = S - 1; }                        // (past the end: re-read the last stage; never used)
-    const char* wst = Wb16 + (long long)(cc * TP + sg) * 3 * cd.Cout16 * 64;      // uniform
+    const char* wst = Wb16 + (long long)(cc * TP + sg) * PL * cd.Cout16 * 64;      // uniform
 #pragma unroll
-    for (int u = 0; u < 3; ++u) BCP_GLDS16(wst + wq[u], Wr_wave + slot_bytes + u * 4096);
+    for (int u = 0; u < PL; ++u) BCP_GLDS16(wst + wq[u], Wr_wave + slot_bytes + u * 4096);
   };
   unsigned hvm = 0;
   auto hfetch = [&](int cc, float4 (&pre)[HF::NP]) __attribute__((always_inline)) { hvm = hf.fetch_nb(X, cd, n, d0, h0, w0, cc, pre); };
@@ -712,29 +720,29 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     for (int u = 0; u < HF::NP; ++u)
       if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
         const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Xb + hb * XBUF + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
+        PP::split(v, xsc, Xb + hb * XBUF + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
       }
   };
   // fragments of stage sg (halo buffer hb, ring slot at element offset slot_el) -> one register set
-  auto frag_read = [&](int hb, int sg, unsigned slot_el, bf16x8 (&a)[2][3], bf16x8 (&b)[2][3]) __attribute__((always_inline)) {
+  auto frag_read = [&](int hb, int sg, unsigned slot_el, frag_t (&a)[2][PL], frag_t (&b)[2][PL]) __attribute__((always_inline)) {
     const int t0 = 2 * sg, t1 = 2 * sg + 1 < T ? 2 * sg + 1 : T - 1;
     const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
     const int toff = ((lg >> 1) ? tB : tA) * XSB;
     const unsigned short* Xc = Xb + hb * XBUF;
     const unsigned short* Wc = Wr + slot_el;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < PL; ++s) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) a[mt][s] = *reinterpret_cast<const bf16x8*>(Xc + s * XPLANE + voff[mt] + toff);
+      for (int mt = 0; mt < 2; ++mt) a[mt][s] = *reinterpret_cast<const frag_t*>(Xc + s * XPLANE + voff[mt] + toff);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) b[nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + nt * 16 * 32 + woff);
+      for (int nt = 0; nt < 2; ++nt) b[nt][s] = *reinterpret_cast<const frag_t*>(Wc + s * WPLANE + nt * 16 * 32 + woff);
     }
   };
 
   BCP_TS(1);
   // prologue: halo of the first chunk, weight stages 0 .. 2, fragments of stage 0
   float4 hpre[HF::NP];
-  bf16x8 fa[2][2][3], fb[2][2][3];
+  frag_t fa[2][2][PL], fb[2][2][PL];
   unsigned sl0 = 0, sl1 = WSLOT * 2, sl2 = 2 * WSLOT * 2;      // ring slots (byte offsets) of stages g, g + 1, g + 2
   hfetch(c_begin, hpre);
   wdma(c_begin, 0, sl0);
@@ -746,8 +754,8 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
   BCP_LDS_BARRIER();                                           // every wave has its stage-0 fragments: slot 0 may be refilled
   BCP_TS(2);
 
-  // One stage = 24 MFMAs on the current register set with the 15 memory instructions of the pipeline (3 DMAs of stage g + 3, 12
-  // fragment reads of stage g + 1) issued BETWEEN them, one behind each of the first 15 MFMAs: an MFMA keeps the matrix pipe busy for 16
+  // One stage = 24 MFMAs (PL = 2: 12) on the current register set with the 15 (10) memory instructions of the pipeline (PL DMAs of stage
+  // g + 3, 4 PL fragment reads of stage g + 1) issued BETWEEN them, one behind each of the first 15 MFMAs: an MFMA keeps the matrix pipe busy for 16
   // cycles while the wave issues the next instruction.  Issued in front of the MFMAs instead they cost the wave ~300 cycles per stage
   // (684 ticks per stage for a workgroup alone on its CU against 384 cycles of MFMA); hipcc left alone sinks the reads next to THEIR
   // MFMAs -- pulled up across the barrier -- and the pipeline is gone: the order is pinned with sched_barrier.
@@ -760,7 +768,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     int dcc = cc, dsg = sg + 3;
     while (dsg >= S) { dsg -= S; ++dcc; }
     const bool dma_on = sg + 3 < S || cc + 1 < c_end;                              // uniform: nothing to fetch behind the workgroup's last stage
-    const char* wst = Wb16 + (long long)(dcc * TP + dsg) * 3 * cd.Cout16 * 64;
+    const char* wst = Wb16 + (long long)(dcc * TP + dsg) * PL * cd.Cout16 * 64;
     char* const wdst = Wr_wave + sl0;
     constexpr int t0 = 2 * NSG, t1 = 2 * NSG + 1 < T ? 2 * NSG + 1 : T - 1;
     constexpr int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
@@ -768,18 +776,20 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     const unsigned short* Xc = Xb + NHB * XBUF + toff;
     const unsigned short* Wc = Wr + (sl1 >> 1) + woff;
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int PI[6] = {2, 1, 0, 1, 0, 0}, PJ[6] = {0, 1, 2, 0, 1, 0};       // piece products, smallest terms first (as k_c3h)
+    // piece products, smallest terms first (as k_c3h); two planes: a1 b0, a0 b1, a0 b0
+    constexpr int NPR = PL * (PL + 1) / 2, NMEM = 5 * PL;
+    constexpr int PI[6] = {PL == 3 ? 2 : 1, PL == 3 ? 1 : 0, 0, 1, 0, 0}, PJ[6] = {0, 1, PL == 3 ? 2 : 0, 0, 1, 0};
 #pragma unroll
-    for (int k = 0; k < 24; ++k) {
+    for (int k = 0; k < 4 * NPR; ++k) {
       const int pr = k >> 2, mt = (k >> 1) & 1, nt = k & 1;
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PAR][nt][PJ[pr]], fa[PAR][mt][PI[pr]], acc[mt][nt], 0, 0, 0);
-      if (k < 3) { if (dma_on) BCP_GLDS16(wst + wq[k], wdst + k * 4096); }
-      else if (k < 15) {
-        const int r = k - 3, sp = r >> 2, w = r & 3;
-        if (w < 2) fa[PAR ^ 1][w][sp] = *reinterpret_cast<const bf16x8*>(Xc + sp * XPLANE + voff[w]);
-        else fb[PAR ^ 1][w - 2][sp] = *reinterpret_cast<const bf16x8*>(Wc + sp * WPLANE + (w - 2) * 16 * 32);
+      acc[mt][nt] = PP::mfma(fb[PAR][nt][PJ[pr]], fa[PAR][mt][PI[pr]], acc[mt][nt]);
+      if (k < PL) { if (dma_on) BCP_GLDS16(wst + wq[k < 3 ? k : 0], wdst + k * 4096); }
+      else if (k < NMEM) {
+        const int r = k - PL, sp = r >> 2, w = r & 3;
+        if (w < 2) fa[PAR ^ 1][w][sp] = *reinterpret_cast<const frag_t*>(Xc + sp * XPLANE + voff[w]);
+        else fb[PAR ^ 1][w - 2][sp] = *reinterpret_cast<const frag_t*>(Wc + sp * WPLANE + (w - 2) * 16 * 32);
       }
-      if (k < 15) __builtin_amdgcn_sched_barrier(0);
+      if (k < NMEM) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
     // The DMA issued a stage ago must have landed before anyone reads its slot at the top of the next stage: at most this stage's
@@ -789,7 +799,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
     // next stage reads a slot that has not landed (measured: wrong results exactly where the weight stream misses the caches -- first
     // call on cold caches, the 256-channel level; tools/diag/pipe_diag.py).  Counting only DMAs, the wait also covers the halo
     // loads of this stage (once per chunk; they have had the stage to arrive).
-    if (dma_on) BCP_VM_LDS_BARRIER(3); else BCP_VM_LDS_BARRIER(0);      // (no DMAs issued in this stage: the previous stage's are the youngest)
+    if (dma_on) BCP_VM_LDS_BARRIER(PL); else BCP_VM_LDS_BARRIER(0);      // (no DMAs issued in this stage: the previous stage's are the youngest)
     const unsigned t = sl0; sl0 = sl1; sl1 = sl2; sl2 = t;
     BCP_TS(3 + (cc - c_begin) * S + sg);
   };
@@ -811,7 +821,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
 #pragma unroll
     for (int r = 0; r < 4; ++r) { s1[nt][r] = 0.0; s2[nt][r] = 0.0; }
   b6_store_tile<TL, TD, TH, TW, 2, 2, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0 + wn * 32, accumulate, st.partial != nullptr, s1, s2, wm, &st,
-                                      st.partial ? bx / st.tiles_per_group : 0);
+                                      st.partial ? bx / st.tiles_per_group : 0, osc);
   if (st.partial) {
     const int gg = bx / st.tiles_per_group, row = bx % st.tiles_per_group;
     BCP_LDS_BARRIER();
@@ -1596,12 +1606,13 @@ constexpr bool b6_has_bw() {
 template <int KD, int TD, int TH, int TW, int NT, int SP>
 constexpr bool b6_has_f16() {
   return SP == 1 && ((KD == 3 && TD == 4 && TH == 8 && TW == 8 && (NT == 1 || NT == 2)) || (KD == 3 && TD == 4 && TH == 4 && TW == 8 && NT == 2) ||
-                     (KD == 1 && TD == 1 && TH == 16 && TW == 16 && (NT == 1 || NT == 2)));
+                     (KD == 1 && TD == 1 && TH == 16 && TW == 16 && (NT == 1 || NT == 2)) ||
+                     (KD == 3 && TD * TH * TW == 64 && NT == 4));        // k_c3p (64-voxel x 64-channel pipeline, 4x4x4 / 2x8x4 bricks; not its register-staged twins)
 }
 
 // dynamic LDS of k_c3p: two halo buffers, three weight slots, statistics scratch
-template <class TL>
-static constexpr size_t kC3pLds = (size_t)2 * 3 * TL::HV * XSB * 2 + (size_t)3 * 3 * 64 * 32 * 2 + (size_t)4 * 32 * 2 * sizeof(double);
+template <class TL, int PL = 3>
+static constexpr size_t kC3pLds = (size_t)2 * PL * TL::HV * XSB * 2 + (size_t)3 * PL * 64 * 32 * 2 + (size_t)4 * 32 * 2 * sizeof(double);
 
 template <int KD, int TD, int TH, int TW, int NT, int SP>
 static int b6_launch(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
@@ -1612,7 +1623,8 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   // the 64-voxel / 64-channel instances would pull 12 KB per 24 MFMAs through L1: 79-84 vs 47-51 us)
   const bool direct = options().conv3_b6_direct != 0 && (options().conv3_b6_direct >= 2 || (TL::MT == 4 && NT <= 2));
   // two fp16 planes instead of three bf16 ones: the launch must carry the input's |max| (cd.xamax) and the instance must exist
-  const bool use_f16 = b6_has_f16<KD, TD, TH, TW, NT, SP>() && direct && cd.xamax != nullptr && options().conv3_f16 != 0;
+  const bool pipe64 = TL::M == 64 && NT == 4 && SP == 1 && options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0;      // -> k_c3p
+  const bool use_f16 = b6_has_f16<KD, TD, TH, TW, NT, SP>() && (NT == 4 ? pipe64 : direct) && cd.xamax != nullptr && options().conv3_f16 != 0;
   if (!use_f16) cd.xamax = nullptr;
   const size_t lds = (size_t)(use_f16 ? 2 : 3) * TL::HV * XSB * 2 + (direct ? 0 : (size_t)2 * 3 * SP * CT * 32 * 2) + (size_t)4 * CT * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
@@ -1643,7 +1655,12 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
       size_t lds_k = lds + (direct ? (size_t)2 * 3 * SP * CT * 32 * 2 : 0);
       if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
         if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;
-        if (options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0) { kfn = k_c3p<KD, TD, TH, TW>; lds_k = kC3pLds<TL>; }
+        if (options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0) {
+          kfn = k_c3p<KD, TD, TH, TW>; lds_k = kC3pLds<TL>;
+          if constexpr (b6_has_f16<KD, TD, TH, TW, NT, SP>()) {
+            if (use_f16) { kfn = k_c3p<KD, TD, TH, TW, false, 2>; lds_k = kC3pLds<TL, 2>; }
+          }
+        }
       }
       if (lds_k > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
       hipLaunchKernelGGL(kfn, dim3(gx, gy, sk), dim3(256), lds_k, s, X, Wp, (const float*)nullptr, Y, cd, 0, none);
@@ -1713,6 +1730,15 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
           if (bw) kfn = k_c3p<KD, TD, TH, TW, true>;
         }
         lds_k = kC3pLds<TL>;
+        if constexpr (b6_has_f16<KD, TD, TH, TW, NT, SP>()) {
+          if (use_f16) {
+            kfn = k_c3p<KD, TD, TH, TW, false, 2>;
+            if constexpr (b6_has_bw<KD, TD, TH, TW, NT, SP>()) {
+              if (bw) kfn = k_c3p<KD, TD, TH, TW, true, 2>;
+            }
+            lds_k = kC3pLds<TL, 2>;
+          }
+        }
       }
       if (lds_k > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k);
     }

@@ -275,7 +275,9 @@ __device__ __forceinline__ void update_running(const float* __restrict__ mean, c
 __global__ __launch_bounds__(kFinalizeThreads) void k_norm_bwd_finalize(const double* __restrict__ partial, int nb, int G, int C,
                                                            long long rows_per_group, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ c1,
-                                                           float* __restrict__ c2, float* __restrict__ raw /* [2][G][C] */) {
+                                                           float* __restrict__ c2, float* __restrict__ raw /* [2][G][C] */,
+                                                           float* __restrict__ amax_out) {
+  if (amax_out && blockIdx.x == 0 && threadIdx.x == 0) *amax_out = 0.f;      // the apply pass that follows max-reduces |dy| into it
   const int chunks = C >> 4;
   const int g = blockIdx.x / chunks, chunk = blockIdx.x % chunks, c = chunk * 16 + (threadIdx.x & 15);
   double s1, s2;
@@ -377,8 +379,10 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
                                                         const float* __restrict__ c1, const float* __restrict__ c2,
                                                         NormEpilogue ep, long long seg_rows, int spg, int G, int C,
                                                         float* __restrict__ dy, const float* __restrict__ raw,
-                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate) {
+                                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+                                                        float* __restrict__ amax_out) {
   constexpr int U = 4;
+  float amax = 0.f;            // max |dy| of what this thread writes: the fp16 pre-scale of the dgrad / weight-gradient kernels that read dy
   if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {   // parameter gradients: sum the groups in order (deterministic)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       float gb = accumulate ? dbeta[c] : 0.f, gg = accumulate ? dgamma[c] : 0.f;
@@ -416,6 +420,8 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
       o[k] = scv[k] * (dz - k1v[k] - xh * k2v[k]);
     }
     st4(dy + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float t = fabsf(o[q]); amax = (t > amax || t != t) ? t : amax; }
   };
   long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   for (; j + (U - 1) * stride < nv; j += U * stride) {
@@ -438,6 +444,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
     if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
     one(i, v, d4, m4);
   }
+  if (amax_out) block_amax_publish(amax, amax_out);
 }
 
 static inline int norm_blocks(long long rows_per_group, int C) {
@@ -506,7 +513,7 @@ void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long 
                               float* c1c2raw, hipStream_t s) {
   float *c1 = c1c2raw, *c2 = c1 + (long long)G * C, *raw = c2 + (long long)G * C;
   hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma, dbeta,
-                     accumulate, c1, c2, raw);
+                     accumulate, c1, c2, raw, (float*)nullptr);
   if (dgamma) hipLaunchKernelGGL(k_norm_bwd_params, dim3(1), dim3(256), 0, s, raw, G, C, dgamma, dbeta, accumulate);
 }
 
@@ -568,7 +575,7 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
 extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats,
                             int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
                             float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace,
-                            const double* partial_in, int nb_in, float* dy, void* stream) {
+                            const double* partial_in, int nb_in, float* dy, float* amax_out /* nullable: max |dy| */, void* stream) {
   if (int rc = check_norm_args("bcp_norm_bwd", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(y && da && stats && workspace && dy, "bcp_norm_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -586,15 +593,15 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   if (partial_in) {   // (sum dz, sum dz * xhat) partials handed in by the caller (no kernel of the library produces them any more)
     BCP_REQUIRE(!chan_scale && !elem_mask && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
     hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
-                       dbeta, accumulate, c1, c2, raw);
+                       dbeta, accumulate, c1, c2, raw, amax_out);
   } else {
     hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
                        C, partial, SlabSrc{});
     hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
-                       dbeta, accumulate, c1, c2, raw);
+                       dbeta, accumulate, c1, c2, raw, amax_out);
   }
   hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da, scale, shift, mean,
-                     rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate);
+                     rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate, amax_out);
   BCP_CHECK_LAUNCH("bcp_norm_bwd");
   return BCP_OK;
 }
@@ -642,7 +649,7 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
 extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum, int G,
                                   long long rows_per_group, int C, const float* stats, int act, const float* chan_scale,
                                   long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta,
-                                  int accumulate, void* workspace, float* dy, void* stream) {
+                                  int accumulate, void* workspace, float* dy, float* amax_out, void* stream) {
   if (int rc = check_norm_args("bcp_norm_bwd_slabs", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(rows_per_group <= 4096, "bcp_norm_bwd_slabs: rows_per_group=%lld > 4096 (check bcp_norm_slabs_ok)", rows_per_group);
   BCP_REQUIRE(y && da_slabs && da_sum && stats && workspace && dy && nslab >= 1 && nslab <= 64, "bcp_norm_bwd_slabs: null pointer / bad slab count");
@@ -663,9 +670,9 @@ extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nsl
   hipLaunchKernelGGL((k_col_partial<1, true>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, (const float*)nullptr, scale, shift, mean, rstd, ep,
                      sg.seg_rows, sg.spg, C, partial, sl);
   hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
-                     dbeta, accumulate, c1, c2, raw);
+                     dbeta, accumulate, c1, c2, raw, amax_out);
   hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da_sum, scale, shift, mean,
-                     rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate);
+                     rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate, amax_out);
   BCP_CHECK_LAUNCH("bcp_norm_bwd_slabs");
   return BCP_OK;
 }

@@ -302,7 +302,7 @@ class Ops:
         if out is None:
             out = torch.empty_like(y)
         self.b.call("bcp_norm_bwd", _p(y), _p(da), G, rpg, Cc, _p(stats), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale),
-                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(partial), int(nb), _p(out), self.stream(y))
+                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(partial), int(nb), _p(out), _p(self._amax_slot(out)), self.stream(y))
         return out
 
 
@@ -359,7 +359,7 @@ class Ops:
         ws = self.workspace("norm", self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc), y)
         self.b.call("bcp_norm_bwd_slabs", _p(y), _p(da_src), int(nslab), y.numel(), _p(da), G, rpg, Cc, _p(stats), act,
                     _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy),
-                    self.stream(y))
+                    _p(self._amax_slot(dy)), self.stream(y))
         return dy, da
 
     # ------------------------------------------------------------------ 3x3(x3) conv

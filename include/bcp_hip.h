@@ -117,7 +117,9 @@ int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const f
                  void* stream);
 int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
                  const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
-                 float* dbeta, int accumulate, void* workspace, const double* partial_in_or_null, int nb_in, float* dy, void* stream);
+                 float* dbeta, int accumulate, void* workspace, const double* partial_in_or_null, int nb_in, float* dy,
+                 float* amax_out_or_null /* device float <- max |dy|: the x_amax of the dgrad conv and of the weight gradient that read dy */,
+                 void* stream);
 /* partial_in: (sum dz, sum dz*xhat) partials [G][nb_in][C][2] computed by the caller -- the statistics pass over (y, da) is
  * skipped (not available together with chan_scale / elem_mask).  Producer: bcp_conv3_dgrad_bwdstats (round 3: the epilogue of the
  * bf16-pipe dgrad kernels, where the extra vector work overlaps the matrix pipe). */
@@ -141,7 +143,7 @@ int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_stride, con
 int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum, int G,
                        long long rows_per_group, int C, const float* stats, int act, const float* chan_scale, long long rows_per_sample,
                        const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy,
-                       void* stream);
+                       float* amax_out_or_null, void* stream);
 
 /* ---- 3x3x3 / 3x3 convolution, pad 1 (nn.Conv3d networks/VNet.py:17, nn.Conv2d networks/unet.py:19-25) on fp32 MFMA.
  *      KD = 3 (3-D) or 1 (2-D, D = 1).  Weights are packed once per optimizer step from the torch layout

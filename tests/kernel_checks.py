@@ -846,13 +846,15 @@ def check_conv3_f16(ops, dev):
         (2, 64, 32, (5, 9, 16), 3, 2, None),         # ragged tiles (D, H), four cin chunks
         (2, 16, 16, (8, 8, 24), 3, 3, 3),            # persistent 16-channel kernel, several tiles per workgroup
         (1, 32, 96, (4, 8, 8), 3, 2, None),          # three 32-channel slabs (grid.y)
+        (1, 64, 64, (8, 8, 8), 3, 2, None),          # k_c3p (64-voxel x 64-channel LDS-DMA pipeline), four cin chunks
+        (2, 48, 128, (5, 7, 9), 3, 2, None),         # k_c3p ragged, three chunks, two slabs
         (2, 32, 32, (1, 32, 48), 1, 2, None),        # 2-D 16x16 tiles
         (3, 16, 16, (1, 21, 37), 1, 3, 2),           # 2-D persistent, ragged
     )
     kinds = (("unit", 1.0, 0.05), ("tiny x", 1e-4, 0.05), ("huge x", 1e3, 0.05), ("tiny w", 1.0, 1e-4), ("huge w", 1.0, 30.0), ("mixed", None, 0.05))
     for ci, (N, Cin, Cout, sp, KD, lvl, P) in enumerate(cases):
         two_d = KD == 1
-        for kind, xs, wsc in kinds if ci < 2 else kinds[:1] + kinds[5:]:
+        for kind, xs, wsc in kinds if ci < 2 or ci == 4 else kinds[:1] + kinds[5:]:
             x = R(rng, N, Cin, *(sp[1:] if two_d else sp)).clamp_(min=-0.5)                      # ReLU-like: mostly non-negative, some negatives
             if xs is None:
                 x = x * torch.from_numpy((10.0 ** rng.uniform(-4, 3, tuple(x.shape))).astype(np.float32))
@@ -867,6 +869,8 @@ def check_conv3_f16(ops, dev):
             ops.set_option("splitk", 1)           # (one-pass launches: the plain and the fused-statistics launch are then the same kernel call)
             if two_d:
                 ops.set_option("conv3_b6_cfg2d", 2)   # 2-D 32-channel slabs on the direct-weight 16x16 tiles at every size (product: from 64 K pixels)
+            if Cout % 64 == 0:
+                ops.set_option("conv3_b6_flat", 0)    # 64-channel slabs: brick tiles (k_c3p) also below 16 K voxels, where the product takes the flat kernel
             if P:
                 ops.set_option("conv3_p", P)
             try:
@@ -880,7 +884,7 @@ def check_conv3_f16(ops, dev):
                 y3b = ops.conv3_fwd(xcl, wf, b.to(dev), Cout, KD)                                    # the option switches the fp16 instances off
                 ops.set_option("conv3_f16")
             finally:
-                ops.set_option("conv3_b6"); ops.set_option("conv3_p"); ops.set_option("conv3_f16"); ops.set_option("splitk"); ops.set_option("conv3_b6_cfg2d")
+                ops.set_option("conv3_b6"); ops.set_option("conv3_p"); ops.set_option("conv3_f16"); ops.set_option("splitk"); ops.set_option("conv3_b6_cfg2d"); ops.set_option("conv3_b6_flat")
             ops.set_option("conv3_b6", 0)
             try:
                 y32 = ops.conv3_fwd(to_cl(x).to(dev), wf, b.to(dev), Cout, KD)                       # the fp32-MFMA kernel
@@ -1337,6 +1341,19 @@ def check_conv3_pipe_cold(ops, dev):
                             flush.fill_(float(rep) + 0.5)
                         yd = ops.conv3_fwd(x, wd, None, Cin, 3)
                         assert torch.equal(yd, refd), f"pipeline vs register-staged kernel, dgrad pack (slab mode {flat}) {N}x{sp} rep {rep}"
+                # round 4: the two-plane fp16 instances of the pipelines have no register-staged twin -- cold launches against the warm one
+                # (same kernel, same bits: a slot read before it landed shows as a difference), and the warm one against torch
+                x._bcp_amax = x.abs().max().reshape(1).repeat(4).contiguous()
+                warm = ops.conv3_fwd(x, wf, None, Cout, 3).clone()
+                warm = ops.conv3_fwd(x, wf, None, Cout, 3).clone()
+                if not torch.equal(warm, ref):           # (shapes without an fp16 instance give the three-plane result: nothing new to check)
+                    close(from_cl(warm), F.conv3d(from_cl(x).cpu(), w.cpu(), None, padding=1), msg=f"fp16 pipeline (slab mode {flat}) {N}x{sp} {Cin}->{Cout}")
+                    for rep in range(3 if on_gpu else 1):
+                        if on_gpu:
+                            flush.fill_(float(rep) + 0.125)
+                        y = ops.conv3_fwd(x, wf, None, Cout, 3)
+                        assert torch.equal(y, warm), f"fp16 pipeline, cold vs warm launch (slab mode {flat}) {N}x{sp} {Cin}->{Cout} rep {rep}: " \
+                                                     f"{int((y != warm).sum())} of {y.numel()} outputs differ"
     finally:
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
