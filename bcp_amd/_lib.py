@@ -68,7 +68,7 @@ _SIGS = {
     "bcp_conv3_stat_rows": (I, [I, I, I, I, I, I, I, I, I]),
     "bcp_conv3_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, I, I, P, P, I, P, P]),
     "bcp_conv3_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
-    "bcp_conv3_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
+    "bcp_conv3_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P, P, P]),
     "bcp_conv3_c1_fwd": (I, [P, P, P, P, I, I, I, I, I, P]),
     "bcp_conv3_c1_stat_rows": (I, [I, I, I, I, I, I]),
     "bcp_conv3_c1_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, I, P]),

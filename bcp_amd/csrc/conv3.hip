@@ -1302,6 +1302,7 @@ static int fill_dims(ConvDims& cd, int N, int D, int H, int W, int Cin, int Cout
   cd.tiles_d = cd.tiles_h = cd.tiles_w = 0;
   cd.xcd = options().conv3_xcd;
   cd.xamax = nullptr;
+  cd.yamax = nullptr;
   return 0;
 }
 
@@ -1616,7 +1617,7 @@ extern "C" size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, in
   }
 
 extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin, int Cout, int KD,
-                               int accumulate, void* workspace, void* stream) {
+                               int accumulate, void* workspace, const float* x_amax_or_null, const float* dy_amax_or_null, void* stream) {
   BCP_REQUIRE(x && dy && dw && workspace, "bcp_conv3_wgrad: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_wgrad: bad extents");
   BCP_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "bcp_conv3_wgrad: Cin/Cout must be multiples of 4");
@@ -1626,6 +1627,7 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   const Cfg c = choose_wgrad_cfg(KD, N, D, H, W, cd.Cout16);
   const int groups = wgrad_groups(c, N, D, H, W, cd.Cin16, cd.Cout16);
   float* ws = reinterpret_cast<float*>(workspace);
+  if (x_amax_or_null && dy_amax_or_null) { cd.xamax = x_amax_or_null; cd.yamax = dy_amax_or_null; }      // (conv3bw.hip: two fp16 planes per operand)
   int G = b6_wgrad(x, dy, ws, cd, KD, (hipStream_t)stream);      // partial slabs from the bf16-pipe kernel (conv3bw.hip), when it takes the shape
   if (G > 0) done = true;
   if (!done) {

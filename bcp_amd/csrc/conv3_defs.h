@@ -40,6 +40,7 @@ struct ConvDims {
   int Cin16, Cout16;    // padded to multiples of 16 (packed-weight extents)
   int tiles_d, tiles_h, tiles_w;
   int xcd;              // != 0: XCD-aware workgroup -> tile order in the bf16-pipe kernels (option conv3_xcd)
+  const float* yamax;   // weight gradient only: max |dy| of the second operand (bcp_conv3_wgrad ... dy_amax); see xamax
   const float* xamax;   // device float: max |x| of the input tensor (from the norm apply pass that wrote it), or NULL.  Non-NULL selects the
                         // two-plane fp16 instances where they exist (option conv3_f16); the three-plane bf16 ones need no scale
 };

@@ -1335,20 +1335,23 @@ __global__ __launch_bounds__(256) void k_c3f(const float* __restrict__ X, const 
 // LDS: 3 x 385 x 32 B halo + 3 slots x 3 x CT x 64 B + statistics scratch = 36 + 36 + 2 KB at 64-channel slabs.
 // Same MFMA sequence per accumulator as k_c3f: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int AVMAX>
+template <int NT, int AVMAX, int PL = 3>
 __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int tiles_per_sample, int accumulate, StatsArg st) {
   constexpr int BM = 64, T = 27, TP = 14, S = 14, CT = NT * 16;
   constexpr int XPLANE = (AVMAX + 1) * XSB;                      // (row AVMAX: zeros)
-  constexpr int WPLANE = CT * 32, WSLOT = 3 * WPLANE;            // elements
-  constexpr int NPIECE = 12 * CT, NDMA = (NPIECE + 255) / 256;   // 16-byte pieces of a stage; DMA instructions per wave and stage
+  constexpr int WPLANE = CT * 32, WSLOT = PL * WPLANE;           // elements
+  constexpr int NPIECE = 4 * PL * CT, NDMA = (NPIECE + 255) / 256;   // 16-byte pieces of a stage; DMA instructions per wave and stage
+  constexpr int NPR = PL * (PL + 1) / 2;                         // piece products per accumulator and stage
+  using PP = Pipe<PL>;
+  using frag_t = typename PP::frag;
   constexpr int NP = (AVMAX * 4 + 255) / 256;                    // halo float4 per thread (row, 4-channel part)
   constexpr int HPF = BCP_C3P_HFS >= 0 ? BCP_C3P_HFS : S - 4;   // stage that fetches the next chunk's halo (early: see k_c3d's HPF)
-  constexpr int NMEM = NDMA + 3 + 3 * NT, NMMA = 6 * NT;
+  constexpr int NMEM = NDMA + PL + PL * NT, NMMA = NPR * NT;
 
   HIP_DYNAMIC_SHARED(float4, smem4)
-  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][AVMAX + 1][XSB]
-  unsigned short* Wr = Xb + 3 * XPLANE;                            // [3 slots][3][CT][32]
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [PL][AVMAX + 1][XSB]
+  unsigned short* Wr = Xb + PL * XPLANE;                           // [3 slots][PL][CT][32]
   double* Ss = reinterpret_cast<double*>(Wr + 3 * WSLOT);          // [4][CT][2] statistics scratch
 
   BCP_TS(0);
@@ -1406,7 +1409,13 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
 
   // DMA instruction u of wave w carries pieces (u * 256 + w * 64) % NPIECE + lane (instructions past the stage repeat its first
   // pieces: same bytes to the same place); piece q = (plane q / (4 CT), row (q >> 2) % CT, k quarter POSITION q & 3) at byte 16 q
-  const char* Wb16 = reinterpret_cast<const char*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  const char* Wb16 = reinterpret_cast<const char*>(Wp + PP::pack_off(T, cd.Cin16, cd.Cout16));
+  float xsc = 1.f, osc = 1.f;          // PL = 2: power-of-two pre-scales (k_c3d)
+  if (PL == 2) {
+    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    xsc = ldexpf(1.f, ex);
+    osc = ldexpf(1.f, -(ex + ew));
+  }
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   static_assert(NDMA <= 3, "k_c3q: at most 64-channel slabs");
   unsigned wq[3];      // (literal bounds: with a bound that depends on the template parameter the DMA builtin's address argument is type-dependent and
@@ -1423,7 +1432,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   //  stub without a diagnostic -- the library then fails to load with an undefined symbol)
   auto wsrc = [&](int cc, int sg, const char*& src) __attribute__((always_inline)) {
     while (sg >= S) { sg -= S; ++cc; }
-    src = Wb16 + (long long)(cc * TP + sg) * 3 * cd.Cout16 * 64;            // uniform
+    src = Wb16 + (long long)(cc * TP + sg) * PL * cd.Cout16 * 64;            // uniform
   };
   // halo: row r of the flat range = voxel m0 - R + r of sample n (zero outside [0, V) and beyond Cin); branch-free loads
   unsigned hvm = 0;
@@ -1446,7 +1455,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
       const int q = threadIdx.x + u * 256, r = q >> 2, part = q & 3;
       if (r < AV) {
         const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Xb + r * XSB + part * 4, XPLANE);
+        PP::split(v, xsc, Xb + r * XSB + part * 4, XPLANE);
       }
     }
   };
@@ -1461,7 +1470,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
 
   BCP_TS(1);
   float4 hpre[NP];
-  bf16x8 fa[2][3], fb[2][NT][3];
+  frag_t fa[2][PL], fb[2][NT][PL];
   unsigned sl0 = 0, sl1 = WSLOT * 2, sl2 = 2 * WSLOT * 2;      // ring slots (byte offsets) of stages g, g + 1, g + 2
   hfetch(c_begin, hpre);
   auto wdma = [&](int sg, unsigned slot) __attribute__((always_inline)) {
@@ -1473,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   wdma(0, sl0);
   wdma(1, sl1);
   wdma(2, sl2);
-  if (threadIdx.x < 6) *reinterpret_cast<float4*>(Xb + (threadIdx.x >> 1) * XPLANE + AVMAX * XSB + (threadIdx.x & 1) * 8) = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero rows
+  if (threadIdx.x < 2 * PL) *reinterpret_cast<float4*>(Xb + (threadIdx.x >> 1) * XPLANE + AVMAX * XSB + (threadIdx.x & 1) * 8) = make_float4(0.f, 0.f, 0.f, 0.f);   // the zero rows
   hstash(hpre);
   BCP_VM_LDS_BARRIER(0);
   auto frag0 = [&]() __attribute__((always_inline)) {
@@ -1481,10 +1490,10 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
     a_addr(0, Xc);
     const unsigned short* Wc = Wr + (sl0 >> 1) + woff;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      fa[0][s] = *reinterpret_cast<const bf16x8*>(Xc + s * XPLANE);
+    for (int s = 0; s < PL; ++s) {
+      fa[0][s] = *reinterpret_cast<const frag_t*>(Xc + s * XPLANE);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) fb[0][nt][s] = *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + nt * 16 * 32);
+      for (int nt = 0; nt < NT; ++nt) fb[0][nt][s] = *reinterpret_cast<const frag_t*>(Wc + s * WPLANE + nt * 16 * 32);
     }
   };
   frag0();
@@ -1502,21 +1511,21 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
     a_addr(NSG, Xc);
     const unsigned short* Wc = Wr + (sl1 >> 1) + woff;
     __builtin_amdgcn_sched_barrier(0);
-    constexpr int PI[6] = {2, 1, 0, 1, 0, 0}, PJ[6] = {0, 1, 2, 0, 1, 0};       // piece products, smallest terms first (as k_c3f)
+    constexpr int PI[6] = {PL == 3 ? 2 : 1, PL == 3 ? 1 : 0, 0, 1, 0, 0}, PJ[6] = {0, 1, PL == 3 ? 2 : 0, 0, 1, 0};       // piece products, smallest terms first (as k_c3f); two planes: a1 b0, a0 b1, a0 b0
     int m = 0;                                                 // memory instructions issued so far (compile-time after unrolling)
 #pragma unroll
     for (int k = 0; k < NMMA; ++k) {
       const int pr = k / NT, nt = k % NT;
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[PAR][nt][PJ[pr]], fa[PAR][PI[pr]], acc[nt], 0, 0, 0);
+      acc[nt] = PP::mfma(fb[PAR][nt][PJ[pr]], fa[PAR][PI[pr]], acc[nt]);
 #pragma unroll
       for (; m < ((k + 1) * NMEM + NMMA - 1) / NMMA; ++m) {
-        if (m < NDMA) { if (dma_on) BCP_GLDS16(wst + wq[m], Wr_b + sl0 + wdst[m]); }
-        else if (m < NDMA + 3 * NT) {
+        if (m < NDMA) { if (dma_on) BCP_GLDS16(wst + wq[m < 3 ? m : 0], Wr_b + sl0 + wdst[m < 3 ? m : 0]); }
+        else if (m < NDMA + PL * NT) {
           const int r = m - NDMA, sp = r / NT, nt2 = r % NT;
-          fb[PAR ^ 1][nt2][sp] = *reinterpret_cast<const bf16x8*>(Wc + sp * WPLANE + nt2 * 16 * 32);
+          fb[PAR ^ 1][nt2][sp] = *reinterpret_cast<const frag_t*>(Wc + sp * WPLANE + nt2 * 16 * 32);
         } else if (!LAST) {
-          const int sp = m - NDMA - 3 * NT;
-          fa[PAR ^ 1][sp] = *reinterpret_cast<const bf16x8*>(Xc + sp * XPLANE);
+          const int sp = m - NDMA - PL * NT;
+          fa[PAR ^ 1][sp] = *reinterpret_cast<const frag_t*>(Xc + sp * XPLANE);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -1540,7 +1549,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
       const unsigned short* Xc;
       a_addr(0, Xc);
 #pragma unroll
-      for (int s = 0; s < 3; ++s) fa[0][s] = *reinterpret_cast<const bf16x8*>(Xc + s * XPLANE);
+      for (int s = 0; s < PL; ++s) fa[0][s] = *reinterpret_cast<const frag_t*>(Xc + s * XPLANE);
     }
   }
   BCP_TS(60);
@@ -1560,7 +1569,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = cout0 + nt * 16 + lg * 4 + r;
-        float v = acc[nt][r] + ((bias && co < cd.Cout) ? bias[co] : 0.f);
+        float v = acc[nt][r] * osc + ((bias && co < cd.Cout) ? bias[co] : 0.f);
         if (accumulate && co < cd.Cout) v += yrow[nt * 16 + r];
         acc[nt][r] = v;
         if (want_stats && co < cd.Cout) { s1[nt][r] += (double)v; s2[nt][r] += (double)v * (double)v; }
@@ -1764,13 +1773,21 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
   const int V = cd.D * cd.H * cd.W, tps = cdiv(V, BM);
   size_t lds = (size_t)3 * kB6FlatAvMax * XSB * 2 + (size_t)2 * 3 * SP * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
   auto kfn = k_c3f<KD, NT, SP, kB6FlatAvMax>;
+  bool use_f16 = false;
   if constexpr (KD == 3 && SP == 1) {
     if (options().conv3_b6_pipe != 0) {       // the LDS-DMA software pipeline (its own LDS layout: a zero row per plane, three weight slots)
       auto kq = k_c3q<NT, kB6FlatAvMax>;
       kfn = kq;
       lds = (size_t)3 * (kB6FlatAvMax + 1) * XSB * 2 + (size_t)3 * 3 * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
+      if (cd.xamax != nullptr && options().conv3_f16 != 0) {      // two fp16 planes (round 4): the launch carries the input's |max|
+        auto kq2 = k_c3q<NT, kB6FlatAvMax, 2>;
+        kfn = kq2;
+        lds = (size_t)2 * (kB6FlatAvMax + 1) * XSB * 2 + (size_t)3 * 2 * CT * 32 * 2 + (size_t)4 * CT * 2 * sizeof(double);
+        use_f16 = true;
+      }
     }
   }
+  if (!use_f16) cd.xamax = nullptr;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * tps, gy = cd.Cout16 / CT;
   const int nch = cd.Cin16 / 16;

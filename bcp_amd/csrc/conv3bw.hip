@@ -54,10 +54,31 @@ constexpr bool w6_voff_linear() {
   return true;
 }
 
-template <int KD, int TD, int TH, int TW, int NT>
+// PL (round 4): 3 = three bf16 planes per operand, six MFMAs per K block; 2 = two fp16 planes pre-scaled by powers of two from the
+// tensors' own maxima (cd.xamax for X, cd.yamax for dY -- left by the norm passes that wrote them), three MFMAs per K block; the
+// partial slabs are scaled back on the way out (conv3_defs.h).  ds_read_b64_tr_b16 transposes 16-bit elements of either type.
+template <int PL> struct W6Pipe;
+template <> struct W6Pipe<3> {
+  using frag = bf16x8; using half4 = bf16x4;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(const float4& v, float, unsigned short* base, int ps) { split_store4(v, base, ps); }
+};
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+template <> struct W6Pipe<2> {
+  using frag = f16x8; using half4 = f16x4;
+  static __device__ __forceinline__ f32x4 mfma(frag a, frag b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ void split(const float4& v, float s, unsigned short* base, int ps) { split_store4_f16(v, s, base, ps); }
+};
+
+template <int KD, int TD, int TH, int TW, int NT, int PL = 3>
 __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ partial,
                                             ConvDims cd, int tiles_total, int tiles_per_group) {
   using TL = Tile<KD, TD, TH, TW>;
+  using PP = W6Pipe<PL>;
+  using frag_t = typename PP::frag;
+  auto rd = [](const unsigned short* lo, const unsigned short* hi) __attribute__((always_inline)) -> frag_t {
+    return __builtin_bit_cast(frag_t, cat8(ds_read_tr16(lo), ds_read_tr16(hi)));
+  };
   constexpr int T = TL::T, CT = NT * 16, M = TL::M, KB = M / 32;
   constexpr int TPW = (T + 3) / 4;                      // taps per wave
   constexpr int XPLANE = TL::HV * 16;                   // bf16 elements per halo piece plane ([HV][16])
@@ -68,8 +89,13 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
   using HF = HaloFetch<TL>;
 
   HIP_DYNAMIC_SHARED(float4, smem4)
-  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][16]
-  unsigned short* Yb = Xb + 3 * XPLANE;                            // [3][M][YS]
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [PL][HV][16]
+  unsigned short* Yb = Xb + PL * XPLANE;                           // [PL][M][YS]
+  float xsc = 1.f, ysc = 1.f, osc = 1.f;
+  if (PL == 2) {
+    const int ex = f16_scale_exp(*cd.xamax), ey = f16_scale_exp(*cd.yamax);
+    xsc = ldexpf(1.f, ex); ysc = ldexpf(1.f, ey); osc = ldexpf(1.f, -(ex + ey));
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -149,14 +175,14 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
     for (int u = 0; u < HF::NP; ++u)
       if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
         const float4 v = ((xvm >> u) & 1u) ? px[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * 16 + hf.part * 4, XPLANE);
+        PP::split(v, xsc, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * 16 + hf.part * 4, XPLANE);
       }
 #pragma unroll
     for (int u = 0; u < NY4; ++u) {
       const int q = threadIdx.x + u * 256;
       if (q < M * (CT / 4)) {
         const float4 v = ((yvm >> u) & 1u) ? py[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Yb + (q / (CT / 4)) * YS + (q % (CT / 4)) * 4, YPLANE);
+        PP::split(v, ysc, Yb + (q / (CT / 4)) * YS + (q % (CT / 4)) * 4, YPLANE);
       }
     }
   };
@@ -170,37 +196,38 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
     // A fragments as a prefetched STREAM (round 3, as k_c3d): hipcc issued the six transposed reads of a tap right in front of its
     // MFMAs (read, s_waitcnt, MFMA: one LDS round trip exposed per tap); here tap t + 1's fragments -- tap 0 of the next K block after
     // the last tap -- are requested before tap t's MFMAs and sched_barrier keeps them there.
-    bf16x8 an[3];
+    frag_t an[PL];
 #pragma unroll
-    for (int s = 0; s < 3; ++s) an[s] = cat8(ds_read_tr16(Xb + s * XPLANE + xo[0] + toff[0]), ds_read_tr16(Xb + s * XPLANE + xo[1] + toff[0]));
+    for (int s = 0; s < PL; ++s) an[s] = rd(Xb + s * XPLANE + xo[0] + toff[0], Xb + s * XPLANE + xo[1] + toff[0]);
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       const unsigned short* Yk = Yb + kb * YSTEP;
       const unsigned short* Xk = Xb + kb * XSTEP;
-      bf16x8 b[NT][3];
+      frag_t b[NT][PL];
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < PL; ++s)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-          b[nt][s] = cat8(ds_read_tr16(Yk + s * YPLANE + yo[0] + nt * 16), ds_read_tr16(Yk + s * YPLANE + yo[1] + nt * 16));
+          b[nt][s] = rd(Yk + s * YPLANE + yo[0] + nt * 16, Yk + s * YPLANE + yo[1] + nt * 16);
 #pragma unroll
       for (int t = 0; t < TPW; ++t) {
-        bf16x8 a[3];
+        frag_t a[PL];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a[s] = an[s];
+        for (int s = 0; s < PL; ++s) a[s] = an[s];
         if (t + 1 < TPW) {
 #pragma unroll
-          for (int s = 0; s < 3; ++s) an[s] = cat8(ds_read_tr16(Xk + s * XPLANE + xo[0] + toff[t + 1]), ds_read_tr16(Xk + s * XPLANE + xo[1] + toff[t + 1]));
+          for (int s = 0; s < PL; ++s) an[s] = rd(Xk + s * XPLANE + xo[0] + toff[t + 1], Xk + s * XPLANE + xo[1] + toff[t + 1]);
         } else if (kb + 1 < KB) {
 #pragma unroll
-          for (int s = 0; s < 3; ++s) an[s] = cat8(ds_read_tr16(Xk + XSTEP + s * XPLANE + xo[0] + toff[0]), ds_read_tr16(Xk + XSTEP + s * XPLANE + xo[1] + toff[0]));
+          for (int s = 0; s < PL; ++s) an[s] = rd(Xk + XSTEP + s * XPLANE + xo[0] + toff[0], Xk + XSTEP + s * XPLANE + xo[1] + toff[0]);
         }
         __builtin_amdgcn_sched_barrier(0);
         // rows = input channels (A = X^T fragment), columns = output channels (B = dY fragment); smallest terms first
 #define BCP_W6(I, J)                                                                                                   \
   _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                                                                      \
-      acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[I], b[nt][J], acc[t][nt], 0, 0, 0);
-        BCP_W6(2, 0) BCP_W6(1, 1) BCP_W6(0, 2) BCP_W6(1, 0) BCP_W6(0, 1) BCP_W6(0, 0)
+      acc[t][nt] = PP::mfma(a[I], b[nt][J], acc[t][nt]);
+        if constexpr (PL == 3) { BCP_W6(2, 0) BCP_W6(1, 1) BCP_W6(0, 2) BCP_W6(1, 0) BCP_W6(0, 1) BCP_W6(0, 0) }
+        else { BCP_W6(1, 0) BCP_W6(0, 1) BCP_W6(0, 0) }
 #undef BCP_W6
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -221,7 +248,7 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          P[((long long)tap * cd.Cin16 + cc * 16 + lg * 4 + r) * cd.Cout16 + cout0 + nt * 16 + li] = acc[t][nt][r];
+          P[((long long)tap * cd.Cin16 + cc * 16 + lg * 4 + r) * cd.Cout16 + cout0 + nt * 16 + li] = acc[t][nt][r] * osc;
     }
   }
 }
@@ -264,11 +291,13 @@ template <int KD, int TD, int TH, int TW, int NT>
 static int w6_launch(const float* X, const float* dY, float* partial, ConvDims cd, int groups, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int CT = NT * 16;
-  const size_t lds = (size_t)3 * TL::HV * 16 * 2 + (size_t)3 * TL::M * (CT + 16) * 2;
+  const bool f16 = cd.xamax != nullptr && cd.yamax != nullptr && options().conv3_f16 != 0;      // both operands' |max| known: two fp16 planes
+  const size_t lds = (size_t)(f16 ? 2 : 3) * (TL::HV * 16 * 2 + (size_t)TL::M * (CT + 16) * 2);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
   const int tpg = cdiv(tiles, groups);
   auto kfn = k_w6<KD, TD, TH, TW, NT>;
+  if (f16) kfn = k_w6<KD, TD, TH, TW, NT, 2>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const dim3 grid(cdiv(tiles, tpg), cd.Cin16 / 16, cd.Cout16 / CT);
   hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, dY, partial, cd, tiles, tpg);

@@ -431,7 +431,8 @@ class Ops:
         Cout = dy.shape[-1]
         nbytes = self._ws_bytes("bcp_conv3_wgrad_workspace_bytes", N, D, H, W, Cin, Cout, KD)
         ws = self.workspace("wgrad", nbytes, x)
-        self.b.call("bcp_conv3_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), self.stream(x))
+        self.b.call("bcp_conv3_wgrad", _p(x), _p(dy), _p(dw), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), _p(self._amax_of(x)),
+                    _p(self._amax_of(dy)), self.stream(x))
         return dw
 
     def conv3_c1_fwd(self, x, w, bias, KD, out=None):

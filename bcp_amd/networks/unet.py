@@ -202,6 +202,9 @@ class UNet_2d(HipNet):
         xs = [self._convblock_fwd(self._enc[0], "e0", xcl, save, saved)]
         for i in range(1, 5):
             pooled = ops.maxpool2d_fwd(xs[-1])
+            am = getattr(xs[-1], "_bcp_amax", None)
+            if am is not None:
+                pooled._bcp_amax = am          # max |pool(x)| <= max |x|: an upper bound is all the fp16 pre-scale of the next conv needs
             xs.append(self._convblock_fwd(self._enc[i], f"e{i}", pooled, save, saved))
         h = xs[4]
         for i, (pw, cb, c1, c2) in enumerate(self._up, start=1):

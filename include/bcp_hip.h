@@ -192,7 +192,8 @@ size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Cout, int KD)
 size_t bcp_conv3_wgrad_path(int N, int D, int H, int W, int Cin, int Cout, int KD);   /* the same for bcp_conv3_wgrad (csrc/conv3bw.hip) */
 size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD);
 int bcp_conv3_wgrad(const float* x, const float* dy, float* dw /*[Cout][Cin][KD*9]*/, int N, int D, int H, int W, int Cin, int Cout,
-                    int KD, int accumulate, void* workspace, void* stream);
+                    int KD, int accumulate, void* workspace, const float* x_amax_or_null, const float* dy_amax_or_null /* both given: two
+                    fp16 planes per operand, see bcp_conv3_fwd */, void* stream);
 /* first layer, Cin = 1 -> Cout = 16 (torch weight layout used directly) */
 int bcp_conv3_c1_fwd(const float* x, const float* w, const float* bias_or_null, float* y, int N, int D, int H, int W, int KD, void* stream);
 /* fused variant, as bcp_conv3_fwd_stats: stat_partial = double[groups][rows][16][2], rows = bcp_conv3_c1_stat_rows(...) (0: unavailable) */

@@ -848,6 +848,8 @@ def check_conv3_f16(ops, dev):
         (1, 32, 96, (4, 8, 8), 3, 2, None),          # three 32-channel slabs (grid.y)
         (1, 64, 64, (8, 8, 8), 3, 2, None),          # k_c3p (64-voxel x 64-channel LDS-DMA pipeline), four cin chunks
         (2, 48, 128, (5, 7, 9), 3, 2, None),         # k_c3p ragged, three chunks, two slabs
+        (2, 128, 128, (6, 7, 5), 3, 2, None),        # k_c3q (flat deep-level pipeline), 64-channel slabs, split-K as the launcher picks
+        (1, 128, 64, (7, 7, 5), 3, 2, None),         # k_c3q with 32-channel slabs (245 voxels)
         (2, 32, 32, (1, 32, 48), 1, 2, None),        # 2-D 16x16 tiles
         (3, 16, 16, (1, 21, 37), 1, 3, 2),           # 2-D persistent, ragged
     )
@@ -869,7 +871,7 @@ def check_conv3_f16(ops, dev):
             ops.set_option("splitk", 1)           # (one-pass launches: the plain and the fused-statistics launch are then the same kernel call)
             if two_d:
                 ops.set_option("conv3_b6_cfg2d", 2)   # 2-D 32-channel slabs on the direct-weight 16x16 tiles at every size (product: from 64 K pixels)
-            if Cout % 64 == 0:
+            if Cout % 64 == 0 and Cin < 128:
                 ops.set_option("conv3_b6_flat", 0)    # 64-channel slabs: brick tiles (k_c3p) also below 16 K voxels, where the product takes the flat kernel
             if P:
                 ops.set_option("conv3_p", P)
@@ -934,6 +936,41 @@ def check_conv3_f16(ops, dev):
         assert bool(torch.isnan(yn[0, 1, 2, 3]).all()) and bool(torch.isfinite(yn[0, 3, 7, 7]).all()), "f16: a NaN input voxel reaches its 27 outputs, nothing else"
     finally:
         ops.set_option("conv3_b6")
+    # weight gradient (conv3bw.hip k_w6 PL = 2): both operands pre-scaled from their own |max|; backward-sized dy magnitudes
+    for (N, Cin, Cout, sp, KD) in ((1, 32, 32, (8, 8, 8), 3), (2, 16, 16, (4, 8, 16), 3), (1, 64, 48, (4, 8, 4), 3), (2, 32, 32, (1, 16, 32), 1), (1, 32, 32, (20, 36, 24), 3)):
+        two_d = KD == 1
+        for xs_, ys_ in ((1.0, 1e-6), (1e-3, 1e2), (None, None)):
+            x = R(rng, N, Cin, *(sp[1:] if two_d else sp)).clamp_(min=-0.5)
+            dy = R(rng, N, Cout, *(sp[1:] if two_d else sp))
+            if xs_ is None:
+                x = x * torch.from_numpy((10.0 ** rng.uniform(-4, 3, tuple(x.shape))).astype(np.float32))
+                dy = dy * torch.from_numpy((10.0 ** rng.uniform(-8, -2, tuple(dy.shape))).astype(np.float32))
+            else:
+                x, dy = x * xs_, dy * ys_
+            wshape = (Cout, Cin, 3, 3) if two_d else (Cout, Cin, 3, 3, 3)
+            g64 = (torch.nn.grad.conv2d_weight if two_d else torch.nn.grad.conv3d_weight)(x.double(), wshape, dy.double(), padding=1)
+            xcl, dycl = to_cl(x).to(dev), to_cl(dy).to(dev)
+            ops.set_option("wgrad_b6", 2)
+            try:
+                g3 = ops.conv3_wgrad(xcl, dycl, torch.empty(wshape, device=dev), KD).clone()
+                xcl._bcp_amax = x.abs().max().reshape(1).repeat(4).to(dev)
+                dycl._bcp_amax = dy.abs().max().reshape(1).repeat(4).to(dev)
+                g2 = ops.conv3_wgrad(xcl, dycl, torch.empty(wshape, device=dev), KD).clone()
+                acc = g2.clone()
+                ops.conv3_wgrad(xcl, dycl, acc, KD, accumulate=True)
+            finally:
+                ops.set_option("wgrad_b6")
+            ops.set_option("wgrad_b6", 0)
+            try:
+                g32 = ops.conv3_wgrad(to_cl(x).to(dev), to_cl(dy).to(dev), torch.empty(wshape, device=dev), KD).clone()      # the fp32-MFMA kernel
+            finally:
+                ops.set_option("wgrad_b6")
+            scale = float(g64.abs().max())
+            e2, e3, e32 = (float((t.double().cpu() - g64).abs().max()) for t in (g2, g3, g32))
+            tag = f"f16 wgrad {N}x{sp} {Cin}->{Cout} x~{xs_} dy~{ys_}"
+            assert e2 <= 3.0 * e32 + 1e-7 * scale, f"{tag}: error vs fp64 {e2:.3e} (fp32-MFMA kernel {e32:.3e}, three bf16 planes {e3:.3e}, scale {scale:.3e})"
+            assert not torch.equal(g2, g3), tag + ": the launch with both maxima must take the fp16 instance"
+            close(acc, 2 * g2, rtol=1e-6, msg=tag + " +=")
     # the producer side: bcp_norm_fwd leaves max |a| of what it wrote (every epilogue), bcp_norm_fwd_slabs alike
     for (N, Cc, sp, G, use_res) in ((2, 32, (4, 6, 8), 2, True), (1, 16, (1, 9, 13), 1, False), (2, 128, (3, 5, 5), 2, False)):
         y = to_cl(R(rng, N, Cc, *sp) * 3.0).to(dev)
@@ -943,8 +980,13 @@ def check_conv3_f16(ops, dev):
         a, _ = ops.norm_fwd(y, G, g1, b1, torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev), H.ACT_RELU, chan_scale=cs, residual=res)
         am = getattr(a, "_bcp_amax", None)
         assert am is not None and float(am[0]) == float(a.abs().max()), f"norm_fwd amax {float(am[0])} vs {float(a.abs().max())}"
-        a2, _, _ = ops.norm_fwd_slabs(torch.stack([y, y * 0.5]).contiguous(), 2, None, G, g1, b1, torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev), H.ACT_RELU)
+        a2, st2, y2 = ops.norm_fwd_slabs(torch.stack([y, y * 0.5]).contiguous(), 2, None, G, g1, b1, torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev), H.ACT_RELU)
         assert float(a2._bcp_amax[0]) == float(a2.abs().max()), "norm_fwd_slabs amax"
+        da = to_cl(R(rng, N, Cc, *sp) * 1e-5).to(dev)
+        dyn = ops.norm_bwd(y2, da, G, st2, H.ACT_RELU, torch.zeros(Cc).to(dev), torch.zeros(Cc).to(dev), False)
+        assert float(dyn._bcp_amax[0]) == float(dyn.abs().max()), "norm_bwd amax"
+        dyn2, _ = ops.norm_bwd_slabs(y2, torch.stack([da, da * 0.25]).contiguous(), 2, G, st2, H.ACT_RELU, torch.zeros(Cc).to(dev), torch.zeros(Cc).to(dev), False)
+        assert float(dyn2._bcp_amax[0]) == float(dyn2.abs().max()), "norm_bwd_slabs amax"
 
 
 def check_conv3_stats(ops, dev):
