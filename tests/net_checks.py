@@ -174,7 +174,8 @@ def check_la_step(ops, dev, golden_dir):
         # 17 of 3912 pseudo-label voxels at step 2 on this fixture (oracle run in both precisions; DESIGN.md "parity");
         # the HIP path measured 1e-7 / 2e-4 / 8e-4 (MI355X) -- same order, bounds set 5x above; step 2 at 1e-2 since round 4 (free-running
         # pseudo-labels on the 32x32x16 fixture: ~5e-3 measured with the two-plane fp16 conv instances, as in check_la_unfused_loop)
-        tol = (1e-5, 1e-3, 1e-2)[it]
+        tol = (1e-5, 2e-3, 1e-2)[it]            # (step 1: 1.25e-3 measured once the weight gradients run on two fp16 planes too; the full-size
+                                                #  trajectory -- la_traj5f, asserted against the reference's ensemble -- did not move: 7.5e-6 / 2.4e-4 / 3.0e-4 / 6.3e-4)
         for key, j in (("loss", 0), ("loss_l", 1), ("loss_u", 2)):
             assert abs(float(r[key]) - ref[j]) < tol, (it, key, float(r[key]), ref[j])
         for key, j in (("plab_a", 3), ("plab_b", 4)):
@@ -272,7 +273,7 @@ def check_la_unfused_loop(ops, dev, golden_dir, steps=2):
         optimizer.step()
         update_ema_variables(model, ema_model, 0.99)
         ref = g["traj"][it]
-        tol = (1e-5, 1e-3, 1e-2)[it]          # same chaos budget as check_la_step (the reference's own fp32/fp64 drift, x5; step 2: x10 since
+        tol = (1e-5, 2e-3, 1e-2)[it]          # same chaos budget as check_la_step (the reference's own fp32/fp64 drift, x5; step 2: x10 since
                                               # round 4 -- free-running pseudo-labels on the 32x32x16 fixture: 5.05e-3 measured with the two-plane fp16 conv instances)
         for val, j in ((loss, 0), (loss_l, 1), (loss_u, 2)):
             assert abs(float(val.detach()) - ref[j]) < tol, (it, j, float(val.detach()), ref[j])
