@@ -60,6 +60,7 @@ _SIGS = {
     "bcp_conv3_fwd_raw": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
     "bcp_conv3_packed_weight_floats": (SZ, [I, I, I]),
     "bcp_conv3_fwd_path": (SZ, [I, I, I, I, I, I, I]),
+    "bcp_conv3_planes": (I, [I, I, I, I, I, I, I, I]),
     "bcp_conv3_wgrad_path": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_pack_weight": (I, [P, P, P, I, I, I, P]),
     "bcp_conv3_pack_many": (I, [P, I, P]),
@@ -94,9 +95,9 @@ _SIGS = {
     "bcp_maxpool2d_fwd": (I, [P, P, I, I, I, I, P]),
     "bcp_maxpool3d_k3s2_fwd": (I, [P, P, I, I, I, I, I, P]),
     "bcp_maxpool2d_bwd": (I, [P, P, P, I, I, I, I, I, P]),
-    "bcp_bilinear2x_fwd": (I, [P, P, I, I, I, I, I, I, P]),
+    "bcp_bilinear2x_fwd": (I, [P, P, I, I, I, I, I, I, P, P]),
     "bcp_bilinear2x_bwd": (I, [P, P, I, I, I, I, I, I, P]),
-    "bcp_copy_channels": (I, [P, P, L, I, I, I, I, I, I, P]),
+    "bcp_copy_channels": (I, [P, P, L, I, I, I, I, I, I, P, P, P]),
     "bcp_ema": (I, [P, P, L, C.c_double, P]),
     "bcp_sgd": (I, [P, P, P, P, L, F, F, F, F, I, C.c_double, P]),
     "bcp_adam": (I, [P, P, P, P, L, F, F, F, F, I, F, P]),
@@ -187,7 +188,7 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_planes", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
         self._rec = None          # a bcp_amd.plan.LaunchPlan while a network pass is being recorded
         self.options_epoch = 0    # bumped by set_option: cached shape queries (hip_ops.Ops._ws_bytes) are keyed on it

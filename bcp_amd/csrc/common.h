@@ -128,6 +128,22 @@ __device__ __forceinline__ void block_sum_256(double (&v)[NV], double* lds /* [4
   }
 }
 
+// block maximum of a non-negative per-thread value -> ONE atomic per block, and only when it would raise the slot (a stale read of the
+// slot only costs a redundant atomic).  fmaxf drops NaNs, so a NaN in the tensor is forwarded explicitly: the consumer then sees NaN,
+// takes scale 1, and the NaN reaches its output as it would on the bf16 / fp32 paths.  Non-negative floats order like their bit patterns.
+__device__ __forceinline__ void block_amax_publish(float m, float* __restrict__ slot) {
+  __shared__ float amax_red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = (t > m || t != t) ? t : m; }
+  if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; ++k) { const float t = amax_red[k]; m = (t > m || t != t) ? t : m; }
+    if (m != m) m = __uint_as_float(0x7fc00000u);                              // canonical positive NaN: above every number as an unsigned
+    if (!(m <= *reinterpret_cast<volatile float*>(slot))) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+  }
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -1465,6 +1465,22 @@ extern "C" size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Co
   return handled ? 1 : 0;
 }
 
+namespace bcp { int b6_last_planes(); }
+// operand planes of the kernel that serves this shape when the launch carries the tensors' maxima (x_amax ...): 3 = three bf16 planes
+// (six MFMAs per K block), 2 = two fp16 planes (three), 0 = not on the 16-bit matrix pipe at all.  Measurement record (bench.py prices
+// the op against bf16 peak / 6 or / 3 accordingly); no launch.  wgrad != 0: the weight gradient of the same layer.
+extern "C" int bcp_conv3_planes(int N, int D, int H, int W, int Cin, int Cout, int KD, int wgrad) {
+  if (Cin % 4 || Cin < 4) return 0;
+  ConvDims cd;
+  fill_dims(cd, N, D, H, W, Cin, Cout);
+  static float dummy;
+  if (wgrad) return b6_wgrad_workspace_bytes(cd, KD) > 0 ? (options().conv3_f16 != 0 ? 2 : 3) : 0;
+  cd.xamax = &dummy;
+  bool handled = false;
+  b6_fwd(nullptr, nullptr, nullptr, nullptr, cd, KD, 0, &dummy, nullptr, 0, true, nullptr, &handled);
+  return handled ? bcp::b6_last_planes() : 0;
+}
+
 extern "C" size_t bcp_conv3_wgrad_path(int N, int D, int H, int W, int Cin, int Cout, int KD) {
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);

@@ -223,7 +223,7 @@ __device__ __forceinline__ void b6_epilogue(f32x4 (&acc)[TL::MT][NT], float* __r
   }
 }
 
-template <int KD, int TD, int TH, int TW, int NT, int SP, bool BW = false>
+template <int KD, int TD, int TH, int TW, int NT, int SP, bool BW = false, int PL = 3>
 __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const float* __restrict__ Wp, const float* __restrict__ bias,
                                              float* __restrict__ Y, ConvDims cd, int accumulate, StatsArg st) {
   using TL = Tile<KD, TD, TH, TW>;
@@ -232,13 +232,15 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   static_assert(S >= 4, "the stage pipeline needs four weight stages per chunk");
   constexpr int XPLANE = TL::HV * XSB;                         // bf16 elements per halo piece plane
   constexpr int WPLANE = SP * CT * 32;                         // bf16 elements per weight piece plane of one stage
-  constexpr int WSTAGE = 3 * WPLANE;                           // one stage buffer
-  constexpr int NW4 = (SP * 12 * CT + 255) / 256;              // 16-byte pieces of a stage per thread
+  constexpr int WSTAGE = PL * WPLANE;                          // one stage buffer
+  constexpr int NW4 = (SP * 4 * PL * CT + 255) / 256;          // 16-byte pieces of a stage per thread
   using HF = HaloFetch<TL>;
+  using PP = Pipe<PL>;
+  using frag_t = typename PP::frag;
 
   HIP_DYNAMIC_SHARED(float4, smem4)
-  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [3][HV][XSB]
-  unsigned short* Wb = Xb + 3 * XPLANE;                            // [2][3][SP][CT][32]
+  unsigned short* Xb = reinterpret_cast<unsigned short*>(smem4);   // [PL][HV][XSB]
+  unsigned short* Wb = Xb + PL * XPLANE;                           // [2][PL][SP][CT][32]
   double* Ss = reinterpret_cast<double*>(Wb + 2 * WSTAGE);         // [4][CT][2] statistics scratch
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -270,29 +272,35 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
 
   // stage `sg` of chunk `cc`: tap pairs sg*SP .. sg*SP+SP-1 of the pre-split pack Wb16[chunk][pair][piece][Cout16][32] (bf16, behind the
   // fp32 pack: bcp_conv3_packed_weight_floats); 16-byte piece q of the stage = (pair, piece, cout, k quarter)
-  const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + (long long)T * cd.Cin16 * cd.Cout16);
+  const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + PP::pack_off(T, cd.Cin16, cd.Cout16));
+  float xsc = 1.f, osc = 1.f;          // PL = 2: power-of-two pre-scales (k_c3d)
+  if (PL == 2) {
+    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    xsc = ldexpf(1.f, ex);
+    osc = ldexpf(1.f, -(ex + ew));
+  }
   // (branch-free: every thread loads -- slots past the stage re-read its first pieces, pairs past TP re-read the last pair -- and
   //  wstash drops / zeroes what is not wanted; a predicated load would cost a vmcnt(0) per stage, see fetch_nb)
   // (one tap pair per stage: ONE uniform base per stage + a per-thread 32-bit offset fixed for the whole kernel; see k_c3h)
   unsigned wq[NW4];
 #pragma unroll
   for (int u = 0; u < NW4; ++u) {
-    const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
-    const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3;
+    const int q = (threadIdx.x + u * 256) % (SP * 4 * PL * CT);
+    const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % PL;
     wq[u] = (unsigned)((sp * cd.Cout16 + cout0 + co) * 32 + kq * 8);
   }
   auto wfetch = [&](int cc, int sg, float4 (&wpre)[NW4]) __attribute__((always_inline)) {
     if constexpr (SP == 1) {
-      const unsigned short* wst = Wb16 + (long long)(cc * TP + (sg < TP ? sg : TP - 1)) * 3 * cd.Cout16 * 32;      // uniform
+      const unsigned short* wst = Wb16 + (long long)(cc * TP + (sg < TP ? sg : TP - 1)) * PL * cd.Cout16 * 32;      // uniform
 #pragma unroll
       for (int u = 0; u < NW4; ++u) wpre[u] = *reinterpret_cast<const float4*>(wst + wq[u]);
     } else {
 #pragma unroll
       for (int u = 0; u < NW4; ++u) {
-        const int q = (threadIdx.x + u * 256) % (SP * 12 * CT);
-        const int pr = q / (12 * CT);
+        const int q = (threadIdx.x + u * 256) % (SP * 4 * PL * CT);
+        const int pr = q / (4 * PL * CT);
         const int tp = sg * SP + pr < TP ? sg * SP + pr : TP - 1;
-        wpre[u] = *reinterpret_cast<const float4*>(Wb16 + (long long)(cc * TP + tp) * 3 * cd.Cout16 * 32 + wq[u]);
+        wpre[u] = *reinterpret_cast<const float4*>(Wb16 + (long long)(cc * TP + tp) * PL * cd.Cout16 * 32 + wq[u]);
       }
     }
   };
@@ -300,9 +308,9 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
 #pragma unroll
     for (int u = 0; u < NW4; ++u) {
       const int q = threadIdx.x + u * 256;
-      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % 3, pr = q / (12 * CT);
+      const int kq = q & 3, co = (q >> 2) % CT, sp = (q / (4 * CT)) % PL, pr = q / (4 * PL * CT);
       const float4 v = (sg * SP + pr < TP) ? wpre[u] : make_float4(0.f, 0.f, 0.f, 0.f);       // pad pairs: zero weights
-      if ((SP * 12 * CT) % 256 == 0 || q < SP * 12 * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
+      if ((SP * 4 * PL * CT) % 256 == 0 || q < SP * 4 * PL * CT) *reinterpret_cast<float4*>(Wbuf + sp * WPLANE + (pr * CT + co) * 32 + ((kq ^ ((co & 8) ? 2 : 0)) * 8)) = v;
     }
   };
   unsigned hvm = 0;                                  // validity bits of the halo rows in flight (fetch_nb)
@@ -315,7 +323,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
     for (int u = 0; u < HF::NP; ++u)
       if (hf.act && u * HF::RPP + hf.r0 < HF::HR) {
         const float4 v = ((hvm >> u) & 1u) ? pre[u] : make_float4(0.f, 0.f, 0.f, 0.f);
-        split_store4(v, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
+        PP::split(v, xsc, Xb + ((u * HF::RPP + hf.r0) * TL::HW + hf.hw) * XSB + hf.part * 4, XPLANE);
       }
   };
 
@@ -344,14 +352,14 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   wfetch_at(c_begin, 4, W[0]);
   BCP_LDS_BARRIER();
 
-  bf16x8 abl_a[MT][3], abl_b[NT][3];                 // (measurement only, B6_ABLATE & 32)
+  frag_t abl_a[MT][PL], abl_b[NT][PL];               // (measurement only, B6_ABLATE & 32)
   if (B6_ABLATE & 32) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) {
+    for (int s = 0; s < PL; ++s) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) abl_a[mt][s] = *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt]);
+      for (int mt = 0; mt < MT; ++mt) abl_a[mt][s] = *reinterpret_cast<const frag_t*>(Xb + s * XPLANE + voff[mt]);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) abl_b[nt][s] = *reinterpret_cast<const bf16x8*>(Wb + s * WPLANE + nt * 16 * 32 + woff);
+      for (int nt = 0; nt < NT; ++nt) abl_b[nt][s] = *reinterpret_cast<const frag_t*>(Wb + s * WPLANE + nt * 16 * 32 + woff);
     }
   }
   // (order within a stage: fragment reads, the NEXT stage's weights to the other buffer -- last read one stage ago, every wave has passed
@@ -359,7 +367,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   //  last MFMA; see k_c3h)
   auto stage = [&](int cc, int sg, float4 (&Wn)[NW4]) __attribute__((always_inline)) {
     const unsigned short* Wc = Wb + (sg & 1) * WSTAGE;
-    bf16x8 a[SP][MT][3], b[SP][NT][3];
+    frag_t a[SP][MT][PL], b[SP][NT][PL];
 #pragma unroll
     for (int pr = 0; pr < SP; ++pr) {
       const int tp = sg * SP + pr;
@@ -369,11 +377,11 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
         const int tA = ((t0 / 9) * TL::HH + (t0 / 3) % 3) * TL::HW + t0 % 3, tB = ((t1 / 9) * TL::HH + (t1 / 3) % 3) * TL::HW + t1 % 3;
         const int toff = ((lg >> 1) ? tB : tA) * XSB;
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
+        for (int s = 0; s < PL; ++s) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a[pr][mt][s] = (B6_ABLATE & 32) ? abl_a[mt][s] : *reinterpret_cast<const bf16x8*>(Xb + s * XPLANE + voff[mt] + toff);
+          for (int mt = 0; mt < MT; ++mt) a[pr][mt][s] = (B6_ABLATE & 32) ? abl_a[mt][s] : *reinterpret_cast<const frag_t*>(Xb + s * XPLANE + voff[mt] + toff);
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt) b[pr][nt][s] = (B6_ABLATE & 32) ? abl_b[nt][s] : *reinterpret_cast<const bf16x8*>(Wc + s * WPLANE + (pr * CT + nt * 16) * 32 + woff);
+          for (int nt = 0; nt < NT; ++nt) b[pr][nt][s] = (B6_ABLATE & 32) ? abl_b[nt][s] : *reinterpret_cast<const frag_t*>(Wc + s * WPLANE + (pr * CT + nt * 16) * 32 + woff);
         }
       }
     }
@@ -387,8 +395,9 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
         // one voxel (one 16-byte store).  Smallest terms first; the six products of an accumulator are spread over the MT*NT accumulators.
 #define BCP_B6(I, J)                                                                                            \
   _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)            \
-      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[pr][nt][J], a[pr][mt][I], acc[mt][nt], 0, 0, 0);
-        BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0)
+      acc[mt][nt] = PP::mfma(b[pr][nt][J], a[pr][mt][I], acc[mt][nt]);
+        if constexpr (PL == 3) { BCP_B6(2, 0) BCP_B6(1, 1) BCP_B6(0, 2) BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0) }
+        else { BCP_B6(1, 0) BCP_B6(0, 1) BCP_B6(0, 0) }
 #undef BCP_B6
       }
     }
@@ -413,7 +422,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
     if (cc + 1 < c_end) chunk(cc + 1, std::integral_constant<int, (S & 3)>{});
   }
 
-  b6_epilogue<TL, TD, TH, TW, NT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, bx);
+  b6_epilogue<TL, TD, TH, TW, NT, BW>(acc, Y, bias, cd, n, d0, h0, w0, cout0, accumulate, st, Ss, bx, osc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1616,12 +1625,16 @@ template <int KD, int TD, int TH, int TW, int NT, int SP>
 constexpr bool b6_has_f16() {
   return SP == 1 && ((KD == 3 && TD == 4 && TH == 8 && TW == 8 && (NT == 1 || NT == 2)) || (KD == 3 && TD == 4 && TH == 4 && TW == 8 && NT == 2) ||
                      (KD == 1 && TD == 1 && TH == 16 && TW == 16 && (NT == 1 || NT == 2)) ||
+                     (KD == 1 && TD == 1 && TH == 8 && TW == 16 && NT == 4) ||      // k_c3b, the U-Net's 64-channel-slab kernel
                      (KD == 3 && TD * TH * TW == 64 && NT == 4));        // k_c3p (64-voxel x 64-channel pipeline, 4x4x4 / 2x8x4 bricks; not its register-staged twins)
 }
 
 // dynamic LDS of k_c3p: two halo buffers, three weight slots, statistics scratch
 template <class TL, int PL = 3>
 static constexpr size_t kC3pLds = (size_t)2 * PL * TL::HV * XSB * 2 + (size_t)3 * PL * 64 * 32 * 2 + (size_t)4 * 32 * 2 * sizeof(double);
+
+// measurement record (bcp_conv3_fwd_planes): how many operand planes the last launcher call on this thread chose (dry runs included)
+thread_local int g_b6_last_planes = 3;
 
 template <int KD, int TD, int TH, int TW, int NT, int SP>
 static int b6_launch(const float* X, const float* Wp, const float* bias, float* Y, ConvDims cd, int accumulate, float* ws,
@@ -1633,11 +1646,17 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   const bool direct = options().conv3_b6_direct != 0 && (options().conv3_b6_direct >= 2 || (TL::MT == 4 && NT <= 2));
   // two fp16 planes instead of three bf16 ones: the launch must carry the input's |max| (cd.xamax) and the instance must exist
   const bool pipe64 = TL::M == 64 && NT == 4 && SP == 1 && options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0;      // -> k_c3p
-  const bool use_f16 = b6_has_f16<KD, TD, TH, TW, NT, SP>() && (NT == 4 ? pipe64 : direct) && cd.xamax != nullptr && options().conv3_f16 != 0;
+  const bool staged2d = KD == 1 && NT == 4;                                                       // -> k_c3b itself
+  const bool use_f16 = b6_has_f16<KD, TD, TH, TW, NT, SP>() && (staged2d || (NT == 4 ? pipe64 : direct)) && cd.xamax != nullptr && options().conv3_f16 != 0;
   if (!use_f16) cd.xamax = nullptr;
-  const size_t lds = (size_t)(use_f16 ? 2 : 3) * TL::HV * XSB * 2 + (direct ? 0 : (size_t)2 * 3 * SP * CT * 32 * 2) + (size_t)4 * CT * 2 * sizeof(double);
+  const int npl = use_f16 ? 2 : 3;
+  g_b6_last_planes = npl;
+  const size_t lds = (size_t)npl * TL::HV * XSB * 2 + (direct ? 0 : (size_t)2 * npl * SP * CT * 32 * 2) + (size_t)4 * CT * 2 * sizeof(double);
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   auto kfn = k_c3b<KD, TD, TH, TW, NT, SP>;
+  if constexpr (KD == 1 && NT == 4 && b6_has_f16<KD, TD, TH, TW, NT, SP>()) {
+    if (use_f16) kfn = k_c3b<KD, TD, TH, TW, NT, SP, false, 2>;       // the U-Net's 64-channel slabs on two fp16 planes
+  }
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / CT;
   const int nch = cd.Cin16 / 16;
@@ -1661,7 +1680,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
     } else {
       // the STAGED kernel always needs its weight stage: `lds` left it out when `direct` chose k_c3d (16-channel slabs
       // come here with direct && NT == 1 and overran their allocation by the 6 KB stage)
-      size_t lds_k = lds + (direct ? (size_t)2 * 3 * SP * CT * 32 * 2 : 0);
+      size_t lds_k = lds + (direct ? (size_t)2 * npl * SP * CT * 32 * 2 : 0);
       if constexpr (TL::M == 64 && NT == 4 && SP == 1) {
         if (options().conv3_b6_w22 != 0) kfn = k_c3h<KD, TD, TH, TW>;
         if (options().conv3_b6_w22 != 0 && options().conv3_b6_pipe != 0) {
@@ -1788,6 +1807,7 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
     }
   }
   if (!use_f16) cd.xamax = nullptr;
+  g_b6_last_planes = use_f16 ? 2 : 3;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int gx = cd.N * tps, gy = cd.Cout16 / CT;
   const int nch = cd.Cin16 / 16;
@@ -1829,9 +1849,12 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
 
 // Forward / dgrad on the bf16 pipe where option conv3_b6 allows it.  Returns the statistics rows (as conv3_fwd_impl does);
 // *handled = false leaves the shape to the fp32 kernels.
+int b6_last_planes() { return g_b6_last_planes; }
+
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
            double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk, const BwdStatsIn* bw) {
   *handled = false;
+  g_b6_last_planes = 3;
   const Options& o = options();
   if (o.conv3_b6 == 0) return 0;
   const long long vox = (long long)cd.N * cd.D * cd.H * cd.W;

@@ -292,21 +292,6 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_norm_bwd_finalize(const do
 // ------------------------------------------------------------------ apply passes
 // row-reversed position of float4 index p inside a segment (same column): (rows-1-r)*C4 + col
 #define REV(p) (nv - C4 - (p) + 2 * col)
-// block maximum of a non-negative per-thread value -> ONE atomic per block, and only when it would raise the slot (a stale read of the
-// slot only costs a redundant atomic).  fmaxf drops NaNs, so a NaN in the tensor is forwarded explicitly: the consumer then sees NaN,
-// takes scale 1, and the NaN reaches its output as it would on the bf16 / fp32 paths.  Non-negative floats order like their bit patterns.
-__device__ __forceinline__ void block_amax_publish(float m, float* __restrict__ slot) {
-  __shared__ float amax_red[4];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = (t > m || t != t) ? t : m; }
-  if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    for (int k = 1; k < 4; ++k) { const float t = amax_red[k]; m = (t > m || t != t) ? t : m; }
-    if (m != m) m = __uint_as_float(0x7fc00000u);                              // canonical positive NaN: above every number as an unsigned
-    if (!(m <= *reinterpret_cast<volatile float*>(slot))) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
-  }
-}
 // a = act(y*scale + shift) [* chan_scale] [* elem_mask*elem_scale] [+ residual]      (segments: see k_col_partial)
 __global__ __launch_bounds__(256) void k_norm_running_only(const float* __restrict__ mean, const float* __restrict__ var_unb, int G, int C,
                                                            float* __restrict__ running_mean, float* __restrict__ running_var, float momentum) {

@@ -90,7 +90,8 @@ __device__ __forceinline__ Lerp lerp_ac(int o, int in, int out) {  // align_corn
 }
 
 __global__ __launch_bounds__(256) void k_bilinear2x_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W,
-                                                        int C, int ldy, int y_off) {
+                                                        int C, int ldy, int y_off, float* __restrict__ amax_io) {
+  float amax = 0.f;            // max |o| of what this thread writes, max-reduced INTO amax_io (round 4: see bcp_copy_channels)
   const int Ho = 2 * H, Wo = 2 * W, C4 = C >> 2;
   const long long total = (long long)N * Ho * Wo * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -106,7 +107,10 @@ __global__ __launch_bounds__(256) void k_bilinear2x_fwd(const float* __restrict_
     o.z = lh.l0 * (lw.l0 * a.z + lw.l1 * b.z) + lh.l1 * (lw.l0 * c.z + lw.l1 * d.z);
     o.w = lh.l0 * (lw.l0 * a.w + lw.l1 * b.w) + lh.l1 * (lw.l0 * c.w + lw.l1 * d.w);
     st4(y + (((long long)n * Ho + ho) * Wo + wo) * ldy + y_off + c4 * 4, o);
+    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
+    if (o.x != o.x || o.y != o.y || o.z != o.z || o.w != o.w) amax = o.x + o.y + o.z + o.w;      // (a NaN is forwarded, see block_amax_publish)
   }
+  if (amax_io) block_amax_publish(amax, amax_io);
 }
 
 // dx[h][w] = sum over output pixels whose stencil touches (h, w) of weight * dy  (gather; deterministic)
@@ -155,7 +159,9 @@ __global__ __launch_bounds__(256) void k_bilinear2x_bwd(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_copy_channels(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C,
-                                                       int ld_src, int src_off, int ld_dst, int dst_off, int accumulate) {
+                                                       int ld_src, int src_off, int ld_dst, int dst_off, int accumulate,
+                                                       const float* __restrict__ amax_src, float* __restrict__ amax_dst) {
+  if (amax_dst && blockIdx.x == 0 && threadIdx.x == 0) *amax_dst = amax_src ? *amax_src : 0.f;
   const int C4 = C >> 2;
   const long long total = rows * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -204,10 +210,10 @@ extern "C" int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int
   BCP_CHECK_LAUNCH("bcp_maxpool2d_bwd");
   return BCP_OK;
 }
-extern "C" int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int y_off, void* stream) {
+extern "C" int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int y_off, float* amax_io_or_null, void* stream) {
   BCP_REQUIRE(x && y && N > 0 && C % 4 == 0 && ldy % 4 == 0 && y_off % 4 == 0, "bcp_bilinear2x_fwd: bad argument");
   hipLaunchKernelGGL(k_bilinear2x_fwd, dim3(sgrid((long long)N * 4 * H * W * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W,
-                     C, ldy, y_off);
+                     C, ldy, y_off, amax_io_or_null);
   BCP_CHECK_LAUNCH("bcp_bilinear2x_fwd");
   return BCP_OK;
 }
@@ -219,11 +225,11 @@ extern "C" int bcp_bilinear2x_bwd(const float* dy, float* dx, int N, int H, int 
   return BCP_OK;
 }
 extern "C" int bcp_copy_channels(const float* src, float* dst, long long rows, int C, int ld_src, int src_off, int ld_dst, int dst_off,
-                                 int accumulate, void* stream) {
+                                 int accumulate, const float* amax_src_or_null, float* amax_dst_or_null, void* stream) {
   BCP_REQUIRE(src && dst && rows > 0 && C % 4 == 0 && ld_src % 4 == 0 && ld_dst % 4 == 0 && src_off % 4 == 0 && dst_off % 4 == 0,
               "bcp_copy_channels: bad argument");
   hipLaunchKernelGGL(k_copy_channels, dim3(sgrid(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, dst, rows, C, ld_src, src_off,
-                     ld_dst, dst_off, accumulate);
+                     ld_dst, dst_off, accumulate, amax_src_or_null, amax_dst_or_null);
   BCP_CHECK_LAUNCH("bcp_copy_channels");
   return BCP_OK;
 }

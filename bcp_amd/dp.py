@@ -35,6 +35,12 @@ def _exchange_id(ident, world, rank):
     if world == 1:
         return ident                                 # a one-rank communicator (tests): nothing to exchange
     d = os.environ.get("BCP_DP_ID_DIR")
+    if not d and not (os.environ.get("MASTER_ADDR") and os.environ.get("MASTER_PORT")):
+        # launched without torchrun's rendezvous variables (only RANK / WORLD_SIZE set): the store transport cannot work -- say so
+        # instead of failing inside the TCP rendezvous
+        raise RuntimeError("bcp_amd.dp: the RCCL unique id travels through the torch.distributed rendezvous store and needs MASTER_ADDR / "
+                           "MASTER_PORT (python -m torch.distributed.run sets them); on a single node without them set BCP_DP_ID_DIR=<a "
+                           "directory all ranks see> to exchange the id through a file instead")
     if not d:
         from datetime import timedelta
         from torch.distributed import rendezvous
@@ -274,11 +280,20 @@ class DataParallel:
             self._works = []
             self._last_buckets, self._buckets = self._buckets, []
         else:
+            # not armed (ungrouped steps: several backward passes): ONE collective after the last of them, nothing hidden -- the whole
+            # exchange is exposed, and is measured as such (this branch used to leave exposed_ms_per_step at None)
+            ev0 = ev1 = None
+            if g.is_cuda and self._measure:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
             if self.abi is not None:
                 self.abi.all_reduce(g)
             else:
                 import torch.distributed as dist
                 dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            if ev0 is not None:
+                ev1.record()
+                self._exposed.append((ev0, ev1))
             self.n_collectives += 1
         if optimizer is not None and hasattr(optimizer, "grad_scale"):
             optimizer.grad_scale = 1.0 / self.world

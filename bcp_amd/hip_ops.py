@@ -648,7 +648,7 @@ class Ops:
         """writes the 2x upsample of x [N,1,H,W,C] into channels [y_off, y_off+C) of y [N,1,2H,2W,ld]"""
         self._chk(x, y)
         N, D, H, W, Cc = x.shape
-        self.b.call("bcp_bilinear2x_fwd", _p(x), _p(y), N, H, W, Cc, y.shape[-1], y_off, self.stream(x))
+        self.b.call("bcp_bilinear2x_fwd", _p(x), _p(y), N, H, W, Cc, y.shape[-1], y_off, _p(self._amax_of(y)), self.stream(x))
         return y
 
     def bilinear2x_bwd(self, dy, dy_off, Cc):
@@ -658,11 +658,15 @@ class Ops:
         self.b.call("bcp_bilinear2x_bwd", _p(dy), _p(dx), N, Ho // 2, Wo // 2, Cc, ld, dy_off, self.stream(dy))
         return dx
 
-    def copy_channels(self, src, dst, Cc, src_off=0, dst_off=0, accumulate=False):
+    def copy_channels(self, src, dst, Cc, src_off=0, dst_off=0, accumulate=False, carry_amax=False):
+        """carry_amax: dst gets an |max| slot initialised with src's (the skip half of a concat buffer; bilinear2x_fwd max-reduces the
+        other half into it) -- only when src carries one"""
         self._chk(src, dst)
         rows = src.numel() // src.shape[-1]
+        a_src = self._amax_of(src) if carry_amax else None
+        a_dst = self._amax_slot(dst) if a_src is not None else None
         self.b.call("bcp_copy_channels", _p(src), _p(dst), rows, Cc, src.shape[-1], src_off, dst.shape[-1], dst_off,
-                    int(bool(accumulate)), self.stream(src))
+                    int(bool(accumulate)), _p(a_src), _p(a_dst), self.stream(src))
         return dst
 
     # ------------------------------------------------------------------ optimiser / EMA / misc
@@ -766,7 +770,8 @@ def _profiled(name, fn):
         r = fn(self, *a, **k)
         self.event_record(e1, like)
         extra = tuple(x for x in a if isinstance(x, int))[:3]
-        prof.append((name, tuple(tuple(t.shape) for t in ts[:3]), extra, e0, e1))
+        namax = sum(1 for t in ts[:2] if getattr(t, "_bcp_amax", None) is not None)      # operands that carried their |max| (fp16 instances)
+        prof.append((name, tuple(tuple(t.shape) for t in ts[:3]), extra, e0, e1, namax))
         return r
     wrapper.__name__ = name
     wrapper.__doc__ = fn.__doc__
@@ -792,8 +797,8 @@ def _install_profile_hooks():
         """-> [(op, shapes, ints, milliseconds)] in call order; the caller must have synchronised the device"""
         rec, self._prof = self._prof, None
         out = []
-        for name, shapes, extra, e0, e1 in rec:
-            out.append((name, shapes, extra, self.event_elapsed_ms(e0, e1)))
+        for name, shapes, extra, e0, e1, namax in rec:
+            out.append((name, shapes, extra, self.event_elapsed_ms(e0, e1), namax))
             self._prof_pool.append(e0); self._prof_pool.append(e1)
         return out
 

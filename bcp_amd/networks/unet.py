@@ -212,7 +212,7 @@ class UNet_2d(HipNet):
             z = ops.pw_fwd(h, bp, pw.bias.data, c2)
             skip = xs[4 - i]
             cat = torch.empty((N, 1, skip.shape[2], skip.shape[3], 2 * c2), dtype=torch.float32, device=xcl.device)
-            ops.copy_channels(skip, cat, c2, 0, 0)
+            ops.copy_channels(skip, cat, c2, 0, 0, carry_amax=True)      # (+ the |max| of the concat buffer: skip's, then the upsampled half's)
             ops.bilinear2x_fwd(z, cat, c2)
             if save:
                 saved[f"pw{i}"] = (h,)

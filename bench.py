@@ -39,6 +39,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense BF16 MFMA peak
 # csrc/conv3b.hip computes the fp32 convolution with SIX bf16 MFMAs per K = 32 block (three-piece operands, fp32 accumulate):
 # its roofline in fp32-equivalent TFLOP/s is the bf16 peak / 6
 PEAK_BF16X3_F32EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+PEAK_F16X2_F32EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0      # round 4: two fp16 planes per operand, three MFMAs per product block (same MFMA rate as bf16)
 PEAK_HBM_GBS = 8000.0               # same guide: HBM3E spec (6290 GB/s measured with a float4 copy)
 STEP_GFLOP_PER_VOLUME = 160.0       # 1/2 teacher fwd + 1/2 student fwd+bwd per input volume
 
@@ -129,26 +130,37 @@ def _work(name, shapes, ints):
 CONV3_FWD_OPS = ("conv3_fwd", "conv3_fwd_stats", "conv3_fwd_raw", "conv3_dgrad_bwdstats")
 
 
-def _conv3_path(xshape, ints, wgrad_cout=None):
-    """1 when the library serves this conv shape on the bf16 pipe (bcp_conv3_fwd_path / bcp_conv3_wgrad_path, no launch)"""
+def _conv3_path(xshape, ints, wgrad_cout=None, namax=0):
+    """operand planes of the kernel the library serves this conv launch with: 0 = fp32 MFMA, 3 = three bf16 planes (six MFMAs per product
+    block), 2 = two fp16 planes (three MFMAs) -- the latter only when the launch carried its operands' maxima (namax: forward / dgrad
+    need 1, the weight gradient 2) and the shape has such an instance (bcp_conv3_planes; no launch)"""
     try:
         from bcp_amd.hip_ops import Ops
         N, D, H, W, Cin = xshape
+        b = Ops.product().b
         if wgrad_cout is not None:
-            return int(Ops.product().b.call("bcp_conv3_wgrad_path", int(N), int(D), int(H), int(W), int(Cin), int(wgrad_cout), int(ints[0]))) == 1
-        return int(Ops.product().b.call("bcp_conv3_fwd_path", int(N), int(D), int(H), int(W), int(Cin), int(ints[0]), int(ints[1]))) == 1
+            on16 = int(b.call("bcp_conv3_wgrad_path", int(N), int(D), int(H), int(W), int(Cin), int(wgrad_cout), int(ints[0]))) == 1
+            if not on16:
+                return 0
+            return 2 if (namax >= 2 and int(b.call("bcp_conv3_planes", int(N), int(D), int(H), int(W), int(Cin), int(wgrad_cout), int(ints[0]), 1)) == 2) else 3
+        on16 = int(b.call("bcp_conv3_fwd_path", int(N), int(D), int(H), int(W), int(Cin), int(ints[0]), int(ints[1]))) == 1
+        if not on16:
+            return 0
+        return 2 if (namax >= 1 and int(b.call("bcp_conv3_planes", int(N), int(D), int(H), int(W), int(Cin), int(ints[0]), int(ints[1]), 0)) == 2) else 3
     except Exception:
-        return False
+        return 0
 
 
 def op_table(records, steps, step_ms, top=14):
     agg = {}
-    for name, shapes, ints, ms in records:
-        a = agg.setdefault((name, shapes[:2], ints[:2]), [0, 0.0, shapes, ints])
+    for rec in records:
+        name, shapes, ints, ms = rec[:4]
+        namax = rec[4] if len(rec) > 4 else 0
+        a = agg.setdefault((name, shapes[:2], ints[:2], namax), [0, 0.0, shapes, ints])
         a[0] += 1
         a[1] += ms
     rows = []
-    for (name, _, _), (calls, tot, shapes, ints) in agg.items():
+    for (name, _, _, namax), (calls, tot, shapes, ints) in agg.items():
         bound, fl, by = _work(name, shapes, ints)
         avg = tot / calls
         row = {"op": name, "shape": "x".join(str(v) for v in shapes[0]) if shapes else "", "launches_per_step": round(calls / steps, 2),
@@ -156,13 +168,15 @@ def op_table(records, steps, step_ms, top=14):
         if bound == "mfma":
             tf = fl / (avg * 1e-3) / 1e12
             pipe, peak = "f32", PEAK_F32_MFMA_TFLOPS
-            on_bf16 = False
+            planes = 0
             if name in CONV3_FWD_OPS and shapes and len(shapes[0]) == 5:
-                on_bf16 = _conv3_path(shapes[0], ints)
+                planes = _conv3_path(shapes[0], ints, namax=namax)
             elif name == "conv3_wgrad" and len(shapes) > 1 and len(shapes[0]) == 5:
-                on_bf16 = _conv3_path(shapes[0], ints, wgrad_cout=shapes[1][-1])
-            if on_bf16:
+                planes = _conv3_path(shapes[0], ints, wgrad_cout=shapes[1][-1], namax=namax)
+            if planes == 3:
                 pipe, peak = "bf16x3 (fp32-equivalent, 6 bf16 MFMAs per product)", PEAK_BF16X3_F32EQ_TFLOPS
+            elif planes == 2:
+                pipe, peak = "f16x2 (fp32-equivalent, 3 fp16 MFMAs per product, per-tensor power-of-two pre-scales)", PEAK_F16X2_F32EQ_TFLOPS
             row.update({"flop_per_launch": fl, "achieved_tflops": round(tf, 2), "pipe": pipe, "peak_tflops": round(peak, 1), "frac": round(tf / peak, 4),
                         "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4)})
         elif bound == "hbm":
@@ -178,7 +192,7 @@ def pmc_traffic(kernel_key):
     separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams), next to the op's algorithmic
     bytes.  bench.py cannot run the profiler itself: the numbers are those of the commit the file's `_meta` names (the newest
     round's file first); null when profiles/ holds no entry for this op."""
-    for fn in ("r03_pmc_ops.json", "r02_pmc_ops.json"):
+    for fn in ("r04_pmc_ops.json", "r03_pmc_ops.json", "r02_pmc_ops.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:
@@ -418,12 +432,16 @@ def measure(args, dp, dev, cpu_budget_s=45.0, trim=False):
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6),
                    "arithmetic": "fp32 tensors, fp32 accumulation; the 16- to 256-channel 3x3x3 / 3x3 convolutions (forward, dgrad, weight gradient) take their fp32 "
-                                 "operands as three bf16 pieces each and run six bf16 MFMAs per product block (csrc/conv3b.hip, conv3bw.hip): fp32-equivalent "
-                                 "results -- same parity tolerances as the fp32-MFMA kernels (tests/kernel_checks.py check_conv3_b6, tests/test_gpu_vnet.py)"},
+                                 "operands as 16-bit pieces on the matrix cores (csrc/conv3b.hip, conv3bw.hip): two fp16 pieces pre-scaled by powers of two from "
+                                 "each tensor's own |max| (three MFMAs per product block; round 4) wherever the producing norm pass left that |max|, three bf16 "
+                                 "pieces (six MFMAs) elsewhere -- fp32-equivalent results: error vs fp64 within 3x of the fp32-MFMA kernels' "
+                                 "(tests/kernel_checks.py check_conv3_f16 / check_conv3_b6), same network parity tolerances (tests/test_gpu_vnet.py); the kernels "
+                                 "table names the pipe and the peak each op is priced against"},
         "ranks_seen": ranks_seen,
         "step_flops": {"gflop_per_item": info["gflop_per_item"], "achieved_tflops_per_gpu": round(step_tflops, 2),
                        "frac_of_f32_mfma_peak": round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
-                       "frac_of_bf16x3_peak": round(step_tflops / PEAK_BF16X3_F32EQ_TFLOPS, 4)},
+                       "frac_of_bf16x3_peak": round(step_tflops / PEAK_BF16X3_F32EQ_TFLOPS, 4),
+                       "frac_of_f16x2_peak": round(step_tflops / PEAK_F16X2_F32EQ_TFLOPS, 4)},
     }
     if dp.world > 1:
         # how much of the gradient exchange the backward pass did NOT hide: wall time the optimiser's stream waited for the last

@@ -189,6 +189,9 @@ int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int nslab, 
 /* which matrix pipe serves bcp_conv3_fwd / bcp_conv3_fwd_stats for this shape under the current options (no launch): 0 = fp32 MFMA
  * (v_mfma_f32_16x16x4_f32), 1 = bf16 MFMA with three-piece operands (fp32-equivalent results; csrc/conv3b.hip).  Measurement record only. */
 size_t bcp_conv3_fwd_path(int N, int D, int H, int W, int Cin, int Cout, int KD);
+/* operand planes of the kernel serving this shape when the launch carries the tensors' maxima: 3 = three bf16 planes (six MFMAs per K block),
+ * 2 = two fp16 planes (three MFMAs), 0 = not on the 16-bit matrix pipe.  wgrad != 0: the layer's weight gradient.  Measurement record only. */
+int bcp_conv3_planes(int N, int D, int H, int W, int Cin, int Cout, int KD, int wgrad);
 size_t bcp_conv3_wgrad_path(int N, int D, int H, int W, int Cin, int Cout, int KD);   /* the same for bcp_conv3_wgrad (csrc/conv3bw.hip) */
 size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD);
 int bcp_conv3_wgrad(const float* x, const float* dy, float* dw /*[Cout][Cin][KD*9]*/, int N, int D, int H, int W, int Cin, int Cout,
@@ -252,10 +255,13 @@ int bcp_maxpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, void
  * -> y [N][(D-3)/2+1][(H-3)/2+1][(W-3)/2+1][C] */
 int bcp_maxpool3d_k3s2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
 int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate, void* stream);
-int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int y_off, void* stream);
+/* amax (round 4, the |max| a conv needs for its fp16 planes, see bcp_conv3_fwd), through the U-Net's skip concatenation: bcp_copy_channels
+ * initialises the concat buffer's slot with the skip tensor's |max| (amax_src_or_null; NULL: 0), bcp_bilinear2x_fwd max-reduces what it
+ * writes INTO the slot (amax_io_or_null) -- in that order on one stream. */
+int bcp_bilinear2x_fwd(const float* x, float* y, int N, int H, int W, int C, int ldy, int y_off, float* amax_io_or_null, void* stream);
 int bcp_bilinear2x_bwd(const float* dy, float* dx, int N, int H, int W, int C, int lddy, int dy_off, void* stream);
 int bcp_copy_channels(const float* src, float* dst, long long rows, int C, int ld_src, int src_off, int ld_dst, int dst_off,
-                      int accumulate, void* stream);
+                      int accumulate, const float* amax_src_or_null, float* amax_dst_or_null, void* stream);
 
 /* ---- optimiser / mean teacher (utils/BCP_utils.py:78-81 update_ema_variables, ACDC_BCP_train.py:123-129 update_model_ema,
  *      torch.optim.SGD LA_BCP_train.py:218, torch.optim.Adam pancreas/dataloaders.py:182) over FLAT fp32 buffers ------- */

@@ -553,6 +553,16 @@ def check_pw16_norm(ops, dev):
 
 def check_pool2d(ops, dev):
     rng = np.random.default_rng(8)
+    # round 4: |max| of a concat buffer = max(skip's slot, what the upsample writes)
+    skip, z = to_cl(R(rng, 2, 16, 8, 12) * 0.5).to(dev), to_cl(R(rng, 2, 16, 4, 6) * 3.0).to(dev)
+    skip._bcp_amax = skip.abs().max().reshape(1).repeat(4).contiguous()
+    cat = torch.empty((2, 1, 8, 12, 32), dtype=torch.float32, device=dev)
+    ops.copy_channels(skip, cat, 16, 0, 0, carry_amax=True)
+    ops.bilinear2x_fwd(z, cat, 16)
+    assert float(cat._bcp_amax[0]) == float(cat.abs().max()), (float(cat._bcp_amax[0]), float(cat.abs().max()))
+    cat2 = torch.empty_like(cat)
+    ops.copy_channels(to_cl(R(rng, 2, 16, 8, 12)).to(dev), cat2, 16, 0, 0, carry_amax=True)      # a source without a slot: none on the buffer either
+    assert getattr(cat2, "_bcp_amax", None) is None
     x = R(rng, 2, 16, 8, 12).requires_grad_(True)
     y_ref = F.max_pool2d(x, 2)
     dy = R(rng, *y_ref.shape)
@@ -851,12 +861,13 @@ def check_conv3_f16(ops, dev):
         (2, 128, 128, (6, 7, 5), 3, 2, None),        # k_c3q (flat deep-level pipeline), 64-channel slabs, split-K as the launcher picks
         (1, 128, 64, (7, 7, 5), 3, 2, None),         # k_c3q with 32-channel slabs (245 voxels)
         (2, 32, 32, (1, 32, 48), 1, 2, None),        # 2-D 16x16 tiles
+        (2, 96, 64, (1, 20, 40), 1, 2, None),        # 2-D 8x16 tiles x 64-channel slab (k_c3b, the U-Net's mid levels), six cin chunks
         (3, 16, 16, (1, 21, 37), 1, 3, 2),           # 2-D persistent, ragged
     )
     kinds = (("unit", 1.0, 0.05), ("tiny x", 1e-4, 0.05), ("huge x", 1e3, 0.05), ("tiny w", 1.0, 1e-4), ("huge w", 1.0, 30.0), ("mixed", None, 0.05))
     for ci, (N, Cin, Cout, sp, KD, lvl, P) in enumerate(cases):
         two_d = KD == 1
-        for kind, xs, wsc in kinds if ci < 2 or ci == 4 else kinds[:1] + kinds[5:]:
+        for kind, xs, wsc in (kinds if ci < 2 or ci == 4 else kinds[:1] + kinds[5:]) if dev.type == "cuda" else (kinds[:2] + kinds[5:] if ci == 0 else kinds[5:]):
             x = R(rng, N, Cin, *(sp[1:] if two_d else sp)).clamp_(min=-0.5)                      # ReLU-like: mostly non-negative, some negatives
             if xs is None:
                 x = x * torch.from_numpy((10.0 ** rng.uniform(-4, 3, tuple(x.shape))).astype(np.float32))
@@ -940,9 +951,10 @@ def check_conv3_f16(ops, dev):
     finally:
         ops.set_option("conv3_b6")
     # weight gradient (conv3bw.hip k_w6 PL = 2): both operands pre-scaled from their own |max|; backward-sized dy magnitudes
-    for (N, Cin, Cout, sp, KD) in ((1, 32, 32, (8, 8, 8), 3), (2, 16, 16, (4, 8, 16), 3), (1, 64, 48, (4, 8, 4), 3), (2, 32, 32, (1, 16, 32), 1), (1, 32, 32, (20, 36, 24), 3)):
+    on_gpu = dev.type == "cuda"         # (the host simulator runs the small shapes and two of the three magnitude sets: the CPU suite's time budget)
+    for (N, Cin, Cout, sp, KD) in ((1, 32, 32, (8, 8, 8), 3), (2, 16, 16, (4, 8, 16), 3), (1, 64, 48, (4, 8, 4), 3), (2, 32, 32, (1, 16, 32), 1)) + (((1, 32, 32, (20, 36, 24), 3),) if on_gpu else ()):
         two_d = KD == 1
-        for xs_, ys_ in ((1.0, 1e-6), (1e-3, 1e2), (None, None)):
+        for xs_, ys_ in ((1.0, 1e-6), (1e-3, 1e2), (None, None)) if on_gpu else ((1.0, 1e-6), (None, None)):
             x = R(rng, N, Cin, *(sp[1:] if two_d else sp)).clamp_(min=-0.5)
             dy = R(rng, N, Cout, *(sp[1:] if two_d else sp))
             if xs_ is None:

@@ -39,6 +39,9 @@ def run(key, fn, work):
 for C, sp in LEVELS:
     x = torch.randn(N, *sp, C, device=dev)
     dy = torch.randn(N, *sp, C, device=dev)
+    if os.environ.get("BCP_PROF_NO_AMAX") != "1":      # as in the step: the tensors carry their |max| (two-plane fp16 conv instances, round 4)
+        x._bcp_amax = x.abs().max().reshape(1).repeat(4).contiguous()
+        dy._bcp_amax = dy.abs().max().reshape(1).repeat(4).contiguous()
     w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
     b = torch.zeros(C, device=dev)
     wf, wd = ops.conv3_pack(w, 3)
