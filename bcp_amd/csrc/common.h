@@ -128,10 +128,20 @@ __device__ __forceinline__ void block_sum_256(double (&v)[NV], double* lds /* [4
   }
 }
 
-// block maximum of a non-negative per-thread value -> ONE atomic per block, and only when it would raise the slot (a stale read of the
-// slot only costs a redundant atomic).  fmaxf drops NaNs, so a NaN in the tensor is forwarded explicitly: the consumer then sees NaN,
-// takes scale 1, and the NaN reaches its output as it would on the bf16 / fp32 paths.  Non-negative floats order like their bit patterns.
-__device__ __forceinline__ void block_amax_publish(float m, float* __restrict__ slot) {
+// ---- per-tensor |max| slots (round 4: the power-of-two pre-scale of the two-plane fp16 conv instances, conv3_defs.h).  A tensor's |max| lives
+// in kAmaxSlots floats, one per 128-byte line (kAmaxStride apart): the pass that writes the tensor max-reduces every workgroup's maximum
+// into slot (workgroup id % kAmaxSlots), the kernel that reads the tensor takes the maximum over the slots.  ONE slot serialised ~2000
+// atomics per launch on one L2 address (k_norm_apply 12.9 -> 24.3 us at the 32-channel level); spread over 32 lines they are noise.
+constexpr int kAmaxSlots = 32, kAmaxStride = 32, kAmaxFloats = kAmaxSlots * kAmaxStride;
+// the kernel in front of the producing pass clears the slots (threads 0 .. 31 of ONE workgroup)
+__device__ __forceinline__ void amax_clear(float* __restrict__ slots) {
+  if (threadIdx.x < kAmaxSlots) slots[threadIdx.x * kAmaxStride] = 0.f;
+}
+// block maximum of a non-negative per-thread value -> at most ONE atomic per block, and only when it would raise the block's slot (read
+// past the L1: a stale read only costs a redundant atomic).  fmaxf drops NaNs, so a NaN in the tensor is forwarded explicitly: the
+// consumer then sees NaN, takes scale 1, and the NaN reaches its output as it would on the bf16 / fp32 paths.  Non-negative floats
+// order like their bit patterns.
+__device__ __forceinline__ void block_amax_publish(float m, float* __restrict__ slots) {
   __shared__ float amax_red[4];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = (t > m || t != t) ? t : m; }
@@ -140,8 +150,17 @@ __device__ __forceinline__ void block_amax_publish(float m, float* __restrict__ 
   if (threadIdx.x == 0) {
     for (int k = 1; k < 4; ++k) { const float t = amax_red[k]; m = (t > m || t != t) ? t : m; }
     if (m != m) m = __uint_as_float(0x7fc00000u);                              // canonical positive NaN: above every number as an unsigned
-    if (!(m <= *reinterpret_cast<volatile float*>(slot))) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
+    float* slot = slots + ((blockIdx.x + blockIdx.y * gridDim.x) % kAmaxSlots) * kAmaxStride;
+    const float cur = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!(m <= cur)) atomicMax(reinterpret_cast<unsigned*>(slot), __float_as_uint(m));
   }
+}
+// the tensor's |max| as its consumer sees it: maximum over the slots (every wave reads them itself: one load per lane, five shuffles)
+__device__ __forceinline__ float amax_read(const float* __restrict__ slots) {
+  float m = slots[(threadIdx.x & (kAmaxSlots - 1)) * kAmaxStride];
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) { const float t = __shfl_xor(m, o); m = (t > m || t != t) ? t : m; }
+  return m;
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

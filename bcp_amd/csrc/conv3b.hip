@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_c3b(const float* __restrict__ X, const 
   const unsigned short* Wb16 = reinterpret_cast<const unsigned short*>(Wp + PP::pack_off(T, cd.Cin16, cd.Cout16));
   float xsc = 1.f, osc = 1.f;          // PL = 2: power-of-two pre-scales (k_c3d)
   if (PL == 2) {
-    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    const int ex = f16_scale_exp(amax_read(cd.xamax)), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
     xsc = ldexpf(1.f, ex);
     osc = ldexpf(1.f, -(ex + ew));
   }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void k_c3p(const float* __restrict__ X, const 
   }
   float xsc = 1.f, osc = 1.f;          // PL = 2: power-of-two pre-scales (k_c3d)
   if (PL == 2) {
-    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    const int ex = f16_scale_exp(amax_read(cd.xamax)), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
     xsc = ldexpf(1.f, ex);
     osc = ldexpf(1.f, -(ex + ew));
   }
@@ -932,7 +932,7 @@ __global__ __launch_bounds__(256) BCP_C3D_ATTR void k_c3d(const float* __restric
   // (pack header); osc undoes both on the accumulators
   float xsc = 1.f, osc = 1.f;
   if (PL == 2) {
-    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    const int ex = f16_scale_exp(amax_read(cd.xamax)), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
     xsc = ldexpf(1.f, ex);
     osc = ldexpf(1.f, -(ex + ew));
   }
@@ -1421,7 +1421,7 @@ __global__ __launch_bounds__(256) void k_c3q(const float* __restrict__ X, const 
   const char* Wb16 = reinterpret_cast<const char*>(Wp + PP::pack_off(T, cd.Cin16, cd.Cout16));
   float xsc = 1.f, osc = 1.f;          // PL = 2: power-of-two pre-scales (k_c3d)
   if (PL == 2) {
-    const int ex = f16_scale_exp(*cd.xamax), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
+    const int ex = f16_scale_exp(amax_read(cd.xamax)), ew = f16_scale_exp(Wp[pack_off_hdr(T, cd.Cin16, cd.Cout16)]);
     xsc = ldexpf(1.f, ex);
     osc = ldexpf(1.f, -(ex + ew));
   }

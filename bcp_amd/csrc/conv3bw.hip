@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
   unsigned short* Yb = Xb + PL * XPLANE;                           // [PL][M][YS]
   float xsc = 1.f, ysc = 1.f, osc = 1.f;
   if (PL == 2) {
-    const int ex = f16_scale_exp(*cd.xamax), ey = f16_scale_exp(*cd.yamax);
+    const int ex = f16_scale_exp(amax_read(cd.xamax)), ey = f16_scale_exp(amax_read(cd.yamax));
     xsc = ldexpf(1.f, ex); ysc = ldexpf(1.f, ey); osc = ldexpf(1.f, -(ex + ey));
   }
 

@@ -248,9 +248,19 @@ __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict
   __syncthreads();
   if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == (unsigned)(N - 1)) ? 1u : 0u;
   __syncthreads();
-  if (s_last && threadIdx.x == 0) {
-    __threadfence();
-    mixloss_finalize<C, ACDC>(acc, coef, out, N, w_img, w_patch);
+  if (s_last) {
+    // the N reduced rows come into the LDS with ALL threads loading (one dependent global round trip instead of ~N * nq of them in the
+    // single finalising thread: that serial walk was 19 us of the launch), then thread 0 does the scalar arithmetic out of the LDS
+    constexpr int kStageRows = 32;
+    __shared__ double stage[kStageRows * nq];
+    if (threadIdx.x == 0) __threadfence();
+    __syncthreads();
+    const int tot = N * nq;
+    const bool staged = N <= kStageRows;
+    if (staged)
+      for (int i = threadIdx.x; i < tot; i += 256) stage[i] = acc[i];          // acc = [N][2*C*3] | [N][4]: the layout mixloss_finalize reads
+    __syncthreads();
+    if (threadIdx.x == 0) mixloss_finalize<C, ACDC>(staged ? stage : acc, coef, out, N, w_img, w_patch);
   }
 }
 

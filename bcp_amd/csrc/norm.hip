@@ -235,7 +235,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_norm_finalize(const double
                                                        float* __restrict__ running_var, float momentum, float eps,
                                                        float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                                        float* __restrict__ shift, float* __restrict__ var_unb, float* __restrict__ amax_out) {
-  if (amax_out && blockIdx.x == 0 && threadIdx.x == 0) *amax_out = 0.f;      // the apply pass that follows max-reduces |a| into it
+  if (amax_out && blockIdx.x == 0) amax_clear(amax_out);      // the apply pass that follows max-reduces |a| into the slots
   const int chunks = C >> 4;
   const int g = blockIdx.x / chunks, chunk = blockIdx.x % chunks, c = chunk * 16 + (threadIdx.x & 15);
   double s1, s2;
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void k_norm_bwd_finalize(const do
                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ c1,
                                                            float* __restrict__ c2, float* __restrict__ raw /* [2][G][C] */,
                                                            float* __restrict__ amax_out) {
-  if (amax_out && blockIdx.x == 0 && threadIdx.x == 0) *amax_out = 0.f;      // the apply pass that follows max-reduces |dy| into it
+  if (amax_out && blockIdx.x == 0) amax_clear(amax_out);      // the apply pass that follows max-reduces |dy| into the slots
   const int chunks = C >> 4;
   const int g = blockIdx.x / chunks, chunk = blockIdx.x % chunks, c = chunk * 16 + (threadIdx.x & 15);
   double s1, s2;

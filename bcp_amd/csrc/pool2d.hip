@@ -161,7 +161,8 @@ __global__ __launch_bounds__(256) void k_bilinear2x_bwd(const float* __restrict_
 __global__ __launch_bounds__(256) void k_copy_channels(const float* __restrict__ src, float* __restrict__ dst, long long rows, int C,
                                                        int ld_src, int src_off, int ld_dst, int dst_off, int accumulate,
                                                        const float* __restrict__ amax_src, float* __restrict__ amax_dst) {
-  if (amax_dst && blockIdx.x == 0 && threadIdx.x == 0) *amax_dst = amax_src ? *amax_src : 0.f;
+  if (amax_dst && blockIdx.x == 0 && threadIdx.x < kAmaxSlots)      // the concat buffer's slots start as the skip tensor's
+    amax_dst[threadIdx.x * kAmaxStride] = amax_src ? amax_src[threadIdx.x * kAmaxStride] : 0.f;
   const int C4 = C >> 2;
   const long long total = rows * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {

@@ -20,6 +20,22 @@ WG_DOWN, WG_UP, WG_PW = range(3)
 CAST_I64_U8, CAST_F32_U8, CAST_U8_F32, CAST_U8_I64 = range(4)
 
 
+AMAX_FLOATS, AMAX_STRIDE = 1024, 32      # csrc/common.h kAmaxFloats / kAmaxStride
+
+
+def amax_slots(value, device):
+    """a |max| slot buffer holding `value` (tests, tools: tensors that did not come out of a norm pass)"""
+    a = torch.zeros(AMAX_FLOATS, dtype=torch.float32, device=device)
+    a[0] = value
+    return a
+
+
+def amax_value(a):
+    """the |max| a slot buffer stands for"""
+    v = a[::AMAX_STRIDE]
+    return float("nan") if bool(torch.isnan(v).any()) else float(v.max())
+
+
 def _p(t):
     # plain int: the bound functions declare c_void_p argtypes, ctypes converts (an explicit c_void_p object per pointer
     # was 10 % of the host time of a step)
@@ -100,7 +116,7 @@ class Ops:
     def _amax_slot(self, out):
         if out is None or not self.AMAX:
             return None
-        a = torch.empty(4, dtype=torch.float32, device=out.device)
+        a = torch.empty(AMAX_FLOATS, dtype=torch.float32, device=out.device)      # 32 slots, one per 128-byte line (csrc/common.h)
         out._bcp_amax = a
         return a
 

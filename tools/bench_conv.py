@@ -56,8 +56,9 @@ def main():
         x = torch.randn(N, *sp, C, device=dev)
         dy = torch.randn(N, *sp, C, device=dev)
         # as in the step: the tensors carry their |max| -> the two-plane fp16 instances (option conv3_f16 = 0 in a variant switches them off)
-        x._bcp_amax = x.abs().max().reshape(1).repeat(4).contiguous()
-        dy._bcp_amax = dy.abs().max().reshape(1).repeat(4).contiguous()
+        from bcp_amd import hip_ops as H
+        x._bcp_amax = H.amax_slots(float(x.abs().max()), dev)
+        dy._bcp_amax = H.amax_slots(float(dy.abs().max()), dev)
         w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
         b = torch.zeros(C, device=dev)
         wf, wd = ops.conv3_pack(w, 3)

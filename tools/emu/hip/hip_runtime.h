@@ -310,6 +310,11 @@ inline void bcpemu_launch(K kernel, dim3 grid, dim3 block, size_t shmem, hipStre
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
   bcpemu_launch(kernel, dim3(grid), dim3(block), (size_t)(shmem), (hipStream_t)(stream), ##__VA_ARGS__)
 
+// ---- relaxed agent-scope loads (L1-bypassing on the device): plain loads here
+// (clang's __hip_atomic_load builtin exists on the host too; only the scope constant may be missing)
+#ifndef __HIP_MEMORY_SCOPE_AGENT
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#endif
 // ---- added: rounding-mode intrinsics and 64-bit atomicMax used by the kernels
 inline float __fmul_rn(float a, float b) { volatile float r = a * b; return r; }
 inline float __fadd_rn(float a, float b) { volatile float r = a + b; return r; }

@@ -40,8 +40,8 @@ for C, sp in LEVELS:
     x = torch.randn(N, *sp, C, device=dev)
     dy = torch.randn(N, *sp, C, device=dev)
     if os.environ.get("BCP_PROF_NO_AMAX") != "1":      # as in the step: the tensors carry their |max| (two-plane fp16 conv instances, round 4)
-        x._bcp_amax = x.abs().max().reshape(1).repeat(4).contiguous()
-        dy._bcp_amax = dy.abs().max().reshape(1).repeat(4).contiguous()
+        x._bcp_amax = H.amax_slots(float(x.abs().max()), dev)
+        dy._bcp_amax = H.amax_slots(float(dy.abs().max()), dev)
     w = torch.randn(C, C, 3, 3, 3, device=dev) * 0.05
     b = torch.zeros(C, device=dev)
     wf, wd = ops.conv3_pack(w, 3)
