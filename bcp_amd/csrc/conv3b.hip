@@ -1699,6 +1699,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   if (sk == 1 && G > 0 && gx % G == 0) { st.rows = gx / G; st.tiles_per_group = gx / G; st.partial = stat_partial; }
   if (bw) {                                           // backward statistics in the epilogue (bcp_conv3_dgrad_bwdstats): one-pass launches only
     if (!b6_has_bw<KD, TD, TH, TW, NT, SP>() || sk != 1 || G <= 0 || gx % G || (direct && NT == 1)) return 0;
+    if (options().fuse_bwd_stats == 2 && KD == 3 && NT == 2) return 0;      // measurement: not at the 3-D 32-channel slabs (k_c3d's epilogue: +39 us per launch)
     st.by = bw->y; st.bstats = bw->stats; st.bact = bw->act;
   }
   if (direct) {
