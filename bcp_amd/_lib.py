@@ -74,7 +74,7 @@ _SIGS = {
     "bcp_conv3_c1_stat_rows": (I, [I, I, I, I, I, I]),
     "bcp_conv3_c1_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, I, P]),
     "bcp_conv3_c1_norm_workspace_bytes": (SZ, [I, I, I, I, I, I]),
-    "bcp_conv3_c1_norm_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P, P, F, F, I, P, F, P, P, P, P]),
+    "bcp_conv3_c1_norm_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P, P, F, F, I, P, F, P, P, P, P, P]),
     "bcp_conv3_c1_norm_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P, F, P, P, I, P, P, P]),
     "bcp_conv3_c1_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_k2_pack_weight": (I, [P, P, I, I, I, P]),

@@ -945,6 +945,7 @@ struct C1Norm {
   const uint8_t* elem_mask;    // nullable [voxel][16]: elementwise Dropout keep mask (U-Net)
   float elem_scale;
   int act, G;
+  float* amax;                 // EPI 2, nullable: |max| slots of the activation written (round 4: the fp16 pre-scale of the conv that reads it)
 };
 
 template <int KD, int TD, int TH, int TW, int EPI = 0>
@@ -971,6 +972,7 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (bias) bv = ld4(bias + lg * 4);
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};       // fused norm statistics of this lane's four channels (bcp_conv3_c1_fwd_stats)
+  float amax_o = 0.f;                                      // EPI 2: max |a| of what this thread writes
   const int t_begin = blockIdx.x * tiles_per_block;
   int t_end = t_begin + tiles_per_block;
   if (t_end > n_tiles) t_end = n_tiles;
@@ -1032,6 +1034,8 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
             if (EPI == 2) {
               o[r] = act_fwd(z, nm.act);
               if (nm.elem_mask) o[r] *= ms[r];
+              const float t = fabsf(o[r]);
+              amax_o = (t > amax_o || t != t) ? t : amax_o;
             } else {
               const float cs = nm.elem_mask ? ms[r] : 1.f;
               const float dz = dd[r] * cs * act_grad(z, nm.act);
@@ -1065,6 +1069,7 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
       dst[0] = a; dst[1] = b;
     }
   }
+  if (EPI == 2 && nm.amax) { __syncthreads(); block_amax_publish(amax_o, nm.amax); }
 }
 
 // wgrad of the Cin = 1 layer: dW[co][0][tap] = sum_v x[v + off(tap)] * dY[v][co] -- a (taps x voxels) x (voxels x 16)
@@ -1700,7 +1705,7 @@ static int c1_fwd_impl(const float* x, const float* w, const float* bias, float*
     if (dry) return st.rows;
   }
   const dim3 grid(cdiv(tiles, tpb));
-  const C1Norm none{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 1};
+  const C1Norm none{nullptr, nullptr, nullptr, nullptr, 1.f, 0, 1, nullptr};
   const C1Norm& nm = nmp ? *nmp : none;
   switch (epi) {
     case 1: c1_launch<1>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
@@ -1748,7 +1753,7 @@ extern "C" int bcp_conv3_c1_fwd_stats(const float* x, const float* w, const floa
 // workspace: bcp_conv3_c1_norm_workspace_bytes.  Results are bit-identical to bcp_conv3_c1_fwd_stats + bcp_norm_fwd / bcp_norm_bwd.
 namespace bcp {      // csrc/norm.hip
 void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s);
+                              float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s, float* amax_clear_or_null);
 void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
                               float* c1c2raw, hipStream_t s);
 }
@@ -1760,7 +1765,8 @@ extern "C" size_t bcp_conv3_c1_norm_workspace_bytes(int N, int D, int H, int W, 
 
 extern "C" int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float* bias, int N, int D, int H, int W, int KD, int groups,
                                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                     int act, const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out, void* stream) {
+                                     int act, const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out,
+                                     float* amax_out_or_null, void* stream) {
   BCP_REQUIRE(x && w && stats && workspace && out && groups >= 1, "bcp_conv3_c1_norm_fwd: null pointer / bad groups");
   BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_norm_fwd: bad KD/D");
   BCP_REQUIRE(aligned16(out) && aligned16(stats) && (!bias || aligned16(bias)), "bcp_conv3_c1_norm_fwd: alignment");
@@ -1768,8 +1774,9 @@ extern "C" int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float
   double* partial = reinterpret_cast<double*>(workspace);
   const int rows = c1_fwd_impl(x, w, bias, nullptr, N, D, H, W, KD, partial, groups, false, s, 1);
   BCP_REQUIRE(rows > 0, "bcp_conv3_c1_norm_fwd: the groups must be whole samples (N %% groups == 0)");
-  norm_fwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, gamma, beta, running_mean, running_var, momentum, eps, stats, s);
-  const C1Norm nm{stats, nullptr, nullptr, elem_mask, elem_scale, act, groups};
+  norm_fwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, gamma, beta, running_mean, running_var, momentum, eps, stats, s,
+                           amax_out_or_null);
+  const C1Norm nm{stats, nullptr, nullptr, elem_mask, elem_scale, act, groups, amax_out_or_null};
   c1_fwd_impl(x, w, bias, out, N, D, H, W, KD, nullptr, groups, false, s, 2, &nm);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_norm_fwd");
   return BCP_OK;
@@ -1787,7 +1794,7 @@ extern "C" int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float
   const int rows0 = bcp_conv3_c1_stat_rows(N, D, H, W, KD, groups);
   BCP_REQUIRE(rows0 > 0, "bcp_conv3_c1_norm_bwd: the groups must be whole samples (N %% groups == 0)");
   float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)groups * rows0 * 16 * 2);
-  C1Norm nm{stats, da, c1c2raw, elem_mask, elem_scale, act, groups};
+  C1Norm nm{stats, da, c1c2raw, elem_mask, elem_scale, act, groups, nullptr};
   const int rows = c1_fwd_impl(x, w, bias, nullptr, N, D, H, W, KD, partial, groups, false, s, 3, &nm);
   norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s);
   c1_fwd_impl(x, w, bias, dy, N, D, H, W, KD, nullptr, groups, false, s, 4, &nm);

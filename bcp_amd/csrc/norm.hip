@@ -476,10 +476,10 @@ static constexpr int kMaxSamplesPerGroup = 64;
 // ---- finalize steps for producers that keep the statistics pass AND the apply pass in their own kernels (the fused first layer,
 // csrc/conv3.hip bcp_conv3_c1_norm_fwd / _bwd): same kernels as bcp_norm_fwd / bcp_norm_bwd run between their two passes
 void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, const float* gamma, const float* beta,
-                              float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s) {
+                              float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s, float* amax_clear_or_null) {
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C, *var_unb = stats + 4LL * G * C;
   hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta, running_mean,
-                     running_var, momentum, eps, mean, rstd, scale, shift, var_unb, (float*)nullptr);
+                     running_var, momentum, eps, mean, rstd, scale, shift, var_unb, amax_clear_or_null);
   if (running_mean) hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
 }
 

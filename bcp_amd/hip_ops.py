@@ -487,7 +487,7 @@ class Ops:
         stats = torch.empty((5, G, 16), dtype=torch.float32, device=x.device)
         out = torch.empty((N, D, H, W, 16), dtype=torch.float32, device=x.device)
         self.b.call("bcp_conv3_c1_norm_fwd", _p(x), _p(w), _p(bias), N, D, H, W, KD, G, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum),
-                    float(eps), act, _p(elem_mask), float(elem_scale), _p(stats), _p(ws), _p(out), self.stream(x))
+                    float(eps), act, _p(elem_mask), float(elem_scale), _p(stats), _p(ws), _p(out), _p(self._amax_slot(out)), self.stream(x))
         return out, stats
 
     def conv3_c1_norm_bwd(self, x, w, bias, KD, G, stats, da, act, dgamma=None, dbeta=None, accumulate=False, elem_mask=None, elem_scale=1.0):

@@ -210,7 +210,7 @@ int bcp_conv3_c1_fwd_stats(const float* x, const float* w, const float* bias_or_
 size_t bcp_conv3_c1_norm_workspace_bytes(int N, int D, int H, int W, int KD, int groups);   /* 0: groups do not divide N */
 int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float* bias_or_null, int N, int D, int H, int W, int KD, int groups,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int act,
-                          const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out, void* stream);
+                          const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out, float* amax_out_or_null /* |max| slots of out, see bcp_norm_fwd */, void* stream);
 int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float* bias_or_null, const float* da, int N, int D, int H, int W, int KD,
                           int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta,
                           int accumulate, void* workspace, float* dy, void* stream);

@@ -1264,6 +1264,7 @@ def check_conv3_c1_norm(ops, dev):
         # fused
         rm1, rv1 = (torch.zeros(16).to(dev), torch.ones(16).to(dev)) if bn else (None, None)
         a1, st1 = ops.conv3_c1_norm_fwd(x, w, b, KD, G, gam, bet, rm1, rv1, act, elem_mask=em, elem_scale=1.25)
+        assert H.amax_value(a1._bcp_amax) == float(a1.abs().max()), "fused first layer: |max| slots"      # (round 4: feeds the next conv's fp16 pre-scale)
         assert torch.equal(st1.cpu(), st0.cpu()), tag + ": statistics"
         assert torch.equal(a1.cpu(), a0.cpu()), tag + ": activation"
         if bn:
