@@ -405,6 +405,10 @@ class HipNet(nn.Module):
                 side.wait_stream(main)             # dy (and the zeroed gradient buffer) are ready
             for x in self.tensors:
                 x.record_stream(side)              # keep the allocator from recycling them under the side stream
+                am = getattr(x, "_bcp_amax", None)
+                if am is not None:
+                    am.record_stream(side)         # ... and the |max| slots the side stream's kernels read next to them (round 4: an eager
+                                                   # step's slot buffer was recycled under the weight-gradient kernel -- plans keep theirs)
             self.ctx = torch.cuda.stream(side)
             self.ctx.__enter__()
             return self

