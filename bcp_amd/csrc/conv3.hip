@@ -1342,7 +1342,9 @@ extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
   BCP_REQUIRE(descs_dev && n > 0 && n <= kMaxPackDescs, "bcp_conv3_pack_many: need 1..%d descriptors", kMaxPackDescs);
   static_assert(sizeof(PackDesc) == 40, "descriptor layout is part of the ABI");
   hipLaunchKernelGGL(k_wamax_many, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
-  hipLaunchKernelGGL(k_pack_conv3_many, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n);
+  // (2048 workgroups: the V-Net's 84 layers are 1368 work units of one 16 x 16 x taps block each -- with 1024 workgroups a third of them
+  //  did two units and the launch lasted as long as those)
+  hipLaunchKernelGGL(k_pack_conv3_many, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n);
   BCP_CHECK_LAUNCH("bcp_conv3_pack_many");
   return BCP_OK;
 }

@@ -34,6 +34,11 @@
 #ifndef B6_ABLATE
 #define B6_ABLATE 0
 #endif
+// measurement only (tools/sessions/r04_s14.sh): parts of the backward-statistics epilogue (MODE 2) off -- 1 no re-read of y (the value just
+// computed stands in), 2 no statistics arithmetic, 4 fp32 instead of fp64 accumulation.  The product is built with 0.
+#ifndef BCP_BW_ABLATE
+#define BCP_BW_ABLATE 0
+#endif
 // k_c3d: A fragments of a tap pair as a prefetched stream in a fixed order (1, the product) or all requested at the top of the pair (0: round 2)
 #ifndef BCP_C3D_STREAM
 #define BCP_C3D_STREAM 1
@@ -140,9 +145,11 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
     auto bstat = [&](int nt, int r, float v, float yv) __attribute__((always_inline)) {
       if (!BW) return;
       const int pn = BW ? nt : 0;
+      if (BCP_BW_ABLATE & 2) return;
       const float z = (yv - pmu[pn][r]) * psc[pn][r] + psh[pn][r];
       const float g1 = v * act_grad(z, sb->bact);
       const float xh = (yv - pmu[pn][r]) * prs[pn][r];
+      if (BCP_BW_ABLATE & 4) { s1[nt][r] = (double)((float)s1[nt][r] + g1); s2[nt][r] = (double)((float)s2[nt][r] + g1 * xh); return; }
       s1[nt][r] += (double)g1;
       s2[nt][r] += (double)g1 * (double)xh;
     };
@@ -156,7 +163,7 @@ __device__ __forceinline__ void b6_store_tile(f32x4 (&acc)[MTv][NT], float* __re
         const int tw = m % TW, th = (m / TW) % TH, td = m / (TW * TH);
         const long long eoff = tile_base + (unsigned)(((td * cd.H + th) * cd.W + tw) * cd.Cout) + cout0 + lg * 4;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) yball[MODE == 2 ? mt : 0][nt] = ld4(sb->by + eoff + nt * 16);
+        for (int nt = 0; nt < NT; ++nt) yball[MODE == 2 ? mt : 0][nt] = (BCP_BW_ABLATE & 1) ? make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]) : ld4(sb->by + eoff + nt * 16);
       }
     }
 #pragma unroll

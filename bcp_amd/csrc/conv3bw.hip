@@ -273,7 +273,7 @@ static bool w6_plan(W6Plan& p, const ConvDims& cd, int KD) {
   p.NT = cd.Cout16 % 32 ? 1 : 2;
   const int tiles = cd.N * cdiv(cd.D, p.TD) * cdiv(cd.H, p.TH) * cdiv(cd.W, p.TW);
   const int chan_blocks = (cd.Cin16 / 16) * (cd.Cout16 / (p.NT * 16));
-  int g = cdiv(512, chan_blocks);
+  int g = cdiv(options().wgrad_b6_slots > 0 ? options().wgrad_b6_slots : 512, chan_blocks);
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
   const int tpg = cdiv(tiles, g);

@@ -293,8 +293,9 @@ class HipNet(nn.Module):
     DEFER_DGRAD_PACK = True
 
     def _defer_dgrad_pack(self):
-        return (self.DEFER_DGRAD_PACK and self.overlap_wgrad and self._flat.is_cuda and self.ops.b._rec is None and self.training
-                and torch.is_grad_enabled())
+        # (asked for only with need_dgrad, i.e. from a forward that saves for backward; NOT torch.is_grad_enabled(): that is False inside
+        #  autograd.Function.forward, where the network passes run -- the first version of this switch never fired)
+        return self.DEFER_DGRAD_PACK and self.overlap_wgrad and self._flat.is_cuda and self.ops.b._rec is None and self.training
 
     def _on_pack_stream(self):
         dev = self._flat.device
