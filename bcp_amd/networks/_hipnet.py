@@ -290,7 +290,8 @@ class HipNet(nn.Module):
 
     # ---- dgrad packs off the forward's critical path (round 4): 37.8 MB of V-Net weights -> ~95 MB of packs per direction; the student's
     # forward used to wait for both directions (k_pack_conv3_many 2 x n descriptors: 65-100 us at the head of its stream)
-    DEFER_DGRAD_PACK = True
+    DEFER_DGRAD_PACK = False      # measured, not adopted (round 4, tools/sessions/r04_s18.sh): LA 5.29 vs 5.33 ms, ACDC / pancreas inside the noise, and the
+                                  # captured-backward mode (plan.GRAPHS = 2) lost its bit-identity with the eager path in test_graph_replays_equal_eager_path
 
     def _defer_dgrad_pack(self):
         # (asked for only with need_dgrad, i.e. from a forward that saves for backward; NOT torch.is_grad_enabled(): that is False inside
