@@ -32,6 +32,7 @@
 #define __shared__ static thread_local
 // LDS-only workgroup barrier of the product code (common.h): a plain barrier on the host
 #define BCP_LDS_BARRIER() ::bcpemu::block_sync()
+#define BCP_DRAIN_VMEM() ((void)0)
 #define BCP_S_SLEEP(n) ((void)0)      /* a timing-only instruction */
 // LDS-DMA (global_load_lds_dwordx4): 16 bytes per lane to a wave-uniform LDS base + 16 * lane; synchronous on the host (a fiber runs
 // from barrier to barrier, so a slot refilled too early shows up as wrong data in the fibers scheduled later)
@@ -89,6 +90,7 @@ struct dim3 {
 struct uint3_ { unsigned x, y, z; };
 
 struct float2 { float x, y; };
+struct double2 { double x, y; };
 struct float4 { float x, y, z, w; };
 struct int2 { int x, y; };
 struct int4 { int x, y, z, w; };
@@ -96,6 +98,7 @@ struct uint2 { unsigned x, y; };
 struct uint4 { unsigned x, y, z, w; };
 struct uchar4 { unsigned char x, y, z, w; };
 inline float2 make_float2(float x, float y) { return {x, y}; }
+inline double2 make_double2(double x, double y) { return {x, y}; }
 inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
 inline int2 make_int2(int x, int y) { return {x, y}; }
 inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }

@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--json", default=None)
     ap.add_argument("--top", type=int, default=40)
+    ap.add_argument("--gaps", type=int, default=0, help="also list the N largest (previous kernel -> next kernel) idle-gap families")
+    ap.add_argument("--dump", default=None, help="write the LAST step's launches (offset us, duration us, stream, workgroups, kernel) to this file")
     args = ap.parse_args()
     rows = []
     for r in csv.DictReader(open(args.trace)):
@@ -52,6 +54,8 @@ def main():
     idle = 0.0
     conc = collections.defaultdict(float)
     last = t0
+    gaps = collections.defaultdict(lambda: [0.0, 0])       # (kernel that ended last, kernel that starts next) -> [ns, count]
+    last_ended = None
     for t, kind, i in ev:
         dt = t - last
         if dt > 0:
@@ -60,12 +64,17 @@ def main():
                     share[(win[j][2], win[j][3])] += dt / len(running)
             else:
                 idle += dt
+                if kind == 1 and last_ended is not None:
+                    g = gaps[(win[last_ended][2], win[i][2])]
+                    g[0] += dt
+                    g[1] += 1
             conc[len(running)] += dt
         last = t
         if kind == 1:
             running.add(i)
         else:
             running.discard(i)
+            last_ended = i
     for (s, e, n, g, st) in win:
         busy[(n, g)] += e - s
         count[(n, g)] += 1
@@ -79,6 +88,16 @@ def main():
     print("concurrency (ms per step with n kernels running):", {k: round(v / K / 1e6, 3) for k, v in sorted(conc.items())})
     for o in out[:args.top]:
         print(f"{o['wall_share_ms_per_step']:7.3f} ms {o['wall_frac'] * 100:5.1f}%  busy {o['busy_ms_per_step']:6.3f}  x{o['launches_per_step']:5.1f}  avg {o['avg_us']:7.1f} us  wgs {o['workgroups']:6d}  {o['kernel']}")
+    if args.gaps:
+        print(f"idle gaps by (kernel that ended -> kernel that started), per step:")
+        for (a, b), (ns, c) in sorted(gaps.items(), key=lambda kv: -kv[1][0])[:args.gaps]:
+            print(f"  {ns / K / 1e3:8.1f} us  x{c / K:5.1f}  avg {ns / c / 1e3:6.1f} us   {a[:44]} -> {b[:44]}")
+    if args.dump:
+        s0 = marks[-2]
+        with open(args.dump, "w") as f:
+            for (s, e, n, g, st) in rows:
+                if e > s0 and s < t1:
+                    f.write(f"{(s - s0) / 1e3:9.1f} {(e - s) / 1e3:8.1f} s{st} {g:6d} {n}\n")
     if args.json:
         json.dump({"ms_per_step": total / K / 1e6, "idle_ms_per_step": idle / K / 1e6,
                    "concurrency_ms": {str(k): v / K / 1e6 for k, v in sorted(conc.items())}, "kernels": out}, open(args.json, "w"), indent=1)
