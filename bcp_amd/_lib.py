@@ -43,13 +43,13 @@ _SIGS = {
     "bcp_cc_workspace_bytes": (SZ, [I, I, I, I, I]),
     "bcp_cc_largest": (I, [P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_mixloss_workspace_bytes": (SZ, [I, I]),
-    "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P]),
-    "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, P, P]),
+    "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P, P, P]),
+    "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, I, P, P]),
     "bcp_dice_prob_workspace_bytes": (SZ, [I]),
     "bcp_dice_prob_fwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, P, P]),
     "bcp_dice_prob_bwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, F, P, P]),
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
-    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, P, P]),
+    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, L, P, P]),
     "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, I, P, P, P]),
     "bcp_norm_slabs_ok": (I, [I, L, I]),
     "bcp_norm_fwd_slabs": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P, P]),
@@ -92,9 +92,9 @@ _SIGS = {
     "bcp_pw16_fwd_norm": (I, [P, P, P, I, I, I, P, P, P, L, I, P]),
     "bcp_pw16_bwd_norm": (I, [P, P, P, I, I, I, P, P, P, P, P, L, I, I, P, P]),
     "bcp_colsum": (I, [P, L, I, P, I, P, P]),
-    "bcp_maxpool2d_fwd": (I, [P, P, I, I, I, I, P]),
+    "bcp_maxpool2d_fwd": (I, [P, I, P, I, I, I, I, P]),
     "bcp_maxpool3d_k3s2_fwd": (I, [P, P, I, I, I, I, I, P]),
-    "bcp_maxpool2d_bwd": (I, [P, P, P, I, I, I, I, I, P]),
+    "bcp_maxpool2d_bwd": (I, [P, I, P, P, I, I, I, I, I, P, I, P]),
     "bcp_bilinear2x_fwd": (I, [P, P, I, I, I, I, I, I, P, P]),
     "bcp_bilinear2x_bwd": (I, [P, P, I, I, I, I, I, I, P]),
     "bcp_copy_channels": (I, [P, P, L, I, I, I, I, I, I, P, P, P]),

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
 // out[0] = LA: loss ; ACDC: dice.   out[1] = ACDC: ce (LA: ce part, informational). out[2] = LA dice part.
 template <int C, bool ACDC>
 __device__ void mixloss_finalize(const double* __restrict__ acc, float* __restrict__ coef, float* __restrict__ out, int N,
-                                 float w_img, float w_patch) {
+                                 float w_img, float w_patch, const float* __restrict__ prev, float* __restrict__ total) {
   double tail[4] = {0.0, 0.0, 0.0, 0.0};
   for (int n = 0; n < N; ++n)
     for (int q = 0; q < 4; ++q) tail[q] += acc[(long long)N * 2 * C * 3 + (long long)n * 4 + q];
@@ -214,12 +214,19 @@ __device__ void mixloss_finalize(const double* __restrict__ acc, float* __restri
     out[1] = (float)ce_total;
     out[2] = (float)((dice_total + ce_total) / 2.0);
   }
+  // the step's total over both mix_loss calls, in the reference's fp32 order (round 4: the torch adds / division that followed are gone):
+  //   LA / pancreas  loss = loss_l + loss_u                                        LA_BCP_train.py:255, train_pancreas.py:166
+  //   ACDC           loss = ((unl_dice + l_dice) + (unl_ce + l_ce)) / 2            ACDC_BCP_train.py:381-384
+  if (total) {
+    if (!ACDC) total[0] = prev[0] + out[0];
+    else total[0] = ((prev[0] + out[0]) + (prev[1] + out[1])) / 2.f;
+  }
 }
 
 template <int C, bool ACDC>
 __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict__ partial, int nb, double* __restrict__ acc, int N,
                                                         unsigned* __restrict__ ticket, float* __restrict__ coef, float* __restrict__ out,
-                                                        float w_img, float w_patch) {
+                                                        float w_img, float w_patch, const float* __restrict__ prev, float* __restrict__ total) {
   // block n: the nb per-block rows of sample n -> acc[n][2*C*3] and tailp[n][4], in a fixed order (thread t sums rows t, t + 256, ...;
   // then lanes, waves).  The LAST block to arrive (ticket zeroed by the forward kernel, a kernel boundary earlier) turns the N reduced
   // rows into the loss scalar(s) and the coefficient table: no finalize launch.  The hand-over is a few hundred bytes per block:
@@ -272,7 +279,7 @@ __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict
     if (staged)
       for (int i = threadIdx.x; i < tot; i += 256) stage[i] = acc[i];          // acc = [N][2*C*3] | [N][4]: the layout mixloss_finalize reads
     __syncthreads();
-    if (threadIdx.x == 0) mixloss_finalize<C, ACDC>(staged ? stage : acc, coef, out, N, w_img, w_patch);
+    if (threadIdx.x == 0) mixloss_finalize<C, ACDC>(staged ? stage : acc, coef, out, N, w_img, w_patch, prev, total);
   }
 }
 
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
                                                      const uint8_t* __restrict__ patch_l, const uint8_t* __restrict__ mask,
                                                      BoxArg box, int D, int H, int W, const float* __restrict__ coef,
                                                      float* __restrict__ dlogits, int N, float g_dice, float g_ce,
-                                                     const float* __restrict__ g_dev /* nullable [2] */) {
+                                                     const float* __restrict__ g_dev /* nullable [g_dev_n] */, int g_dev_n) {
   const int n = blockIdx.y;
   const long long V = (long long)D * H * W;
   const float* lg = logits + (long long)n * V * C;
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
   if ((int)threadIdx.x < 2 * C * 2) (&cf[0][0][0])[threadIdx.x] = coef[(long long)n * 2 * C * 2 + threadIdx.x];
   if ((int)threadIdx.x < 2) cce[threadIdx.x] = coef[(long long)N * 2 * C * 2 + threadIdx.x];
   __syncthreads();
-  if (g_dev) { g_dice *= g_dev[0]; g_ce *= g_dev[1]; }  // upstream gradients stay on the device (no host sync)
+  if (g_dev) { g_dice *= g_dev[0]; g_ce *= g_dev[g_dev_n > 1 ? 1 : 0]; }  // upstream gradients stay on the device (no host sync)
   auto term_of = [&](long long v) __attribute__((always_inline)) -> int {
     if (mk) return mk[v] ? 0 : 1;
     const unsigned vu = (unsigned)v, q1 = vu / (unsigned)W;          // V < 2^31 (checked by the entry point): 32-bit divisions
@@ -360,7 +367,7 @@ constexpr int kLossPartialRows = 512;  // most forward blocks per sample = rows 
 template <int C, bool ACDC>
 static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
                       int N, int D, int H, int W, float w_img, float w_patch, double* acc,
-                      float* coef, float* out, hipStream_t s) {
+                      float* coef, float* out, const float* prev, float* total, hipStream_t s) {
   BoxArg bx;
   bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
@@ -373,13 +380,13 @@ static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* 
   double* red = acc + (size_t)N * kLossPartialRows * (2 * C * 3 + 4);          // [N][2*C*3] | [N][4]
   unsigned* ticket = reinterpret_cast<unsigned*>(red + (size_t)N * (2 * C * 3 + 4));
   hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(nb, N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H, W, acc, N, ticket);
-  hipLaunchKernelGGL((k_mixloss_reduce<C, ACDC>), dim3(N), dim3(256), 0, s, acc, nb, red, N, ticket, coef, out, w_img, w_patch);
+  hipLaunchKernelGGL((k_mixloss_reduce<C, ACDC>), dim3(N), dim3(256), 0, s, acc, nb, red, N, ticket, coef, out, w_img, w_patch, prev, total);
   return 0;
 }
 
 template <int C, bool ACDC>
 static int launch_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
-                      int N, int D, int H, int W, const float* coef, float* dlogits, float g_dice, float g_ce, const float* g_dev, hipStream_t s) {
+                      int N, int D, int H, int W, const float* coef, float* dlogits, float g_dice, float g_ce, const float* g_dev, int g_dev_n, hipStream_t s) {
   BoxArg bx;
   bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
@@ -388,7 +395,7 @@ static int launch_bwd(const float* logits, const uint8_t* img_l, const uint8_t* 
   long long gb = (V * C / 4 + 255) / 256;          // one 16-byte vector per thread, at most ~4096 workgroups per launch
   if (gb * N > 4096) gb = (4096 + N - 1) / N;
   hipLaunchKernelGGL((k_mixloss_bwd<C, ACDC>), dim3((int)(gb < 1 ? 1 : gb), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
-                     W, coef, dlogits, N, g_dice, g_ce, g_dev);
+                     W, coef, dlogits, N, g_dice, g_ce, g_dev, g_dev_n);
   return 0;
 }
 
@@ -603,34 +610,36 @@ static inline float* coef_ptr(void* ws, int N, int C) {
 
 extern "C" int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null,
                                const int* box6, int N, int D, int H, int W, int C, int flavour, float w_img, float w_patch,
-                               void* workspace, float* out3, void* stream) {
+                               void* workspace, float* out3, const float* prev_out3_or_null, float* total_or_null, void* stream) {
   BCP_REQUIRE(logits && img_l && patch_l && box6 && workspace && out3, "bcp_mixloss_fwd: null pointer");
+  BCP_REQUIRE((prev_out3_or_null == nullptr) == (total_or_null == nullptr), "bcp_mixloss_fwd: prev_out3 and total come together");
   BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_mixloss_fwd: bad extents");
   BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4),
               "bcp_mixloss_fwd: flavour/C combination unsupported (LA: C=2, ACDC: C=4), got flavour=%d C=%d", flavour, C);
   double* acc = reinterpret_cast<double*>(workspace);
   float* coef = coef_ptr(workspace, N, C);
   if (flavour == BCP_LOSS_LA)
-    launch_fwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out3,
-                         (hipStream_t)stream);
+    launch_fwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out3, prev_out3_or_null,
+                         total_or_null, (hipStream_t)stream);
   else
-    launch_fwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out3,
-                        (hipStream_t)stream);
+    launch_fwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out3, prev_out3_or_null,
+                        total_or_null, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_mixloss_fwd");
   return BCP_OK;
 }
 
 extern "C" int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null,
                                const int* box6, int N, int D, int H, int W, int C, int flavour, const void* workspace,
-                               float g_dice, float g_ce, const float* g_dev_or_null, float* dlogits, void* stream) {
+                               float g_dice, float g_ce, const float* g_dev_or_null, int g_dev_n, float* dlogits, void* stream) {
   BCP_REQUIRE(logits && img_l && patch_l && box6 && workspace && dlogits, "bcp_mixloss_bwd: null pointer");
+  BCP_REQUIRE(!g_dev_or_null || g_dev_n == 1 || g_dev_n == 2, "bcp_mixloss_bwd: g_dev_n=%d (1: one upstream gradient for both terms, 2: {dice, ce})", g_dev_n);
   BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_mixloss_bwd: bad extents");
   BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4), "bcp_mixloss_bwd: flavour/C");
   const float* coef = coef_ptr(const_cast<void*>(workspace), N, C);
   if (flavour == BCP_LOSS_LA)
-    launch_bwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, (hipStream_t)stream);
+    launch_bwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, g_dev_n, (hipStream_t)stream);
   else
-    launch_bwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, (hipStream_t)stream);
+    launch_bwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, g_dev_n, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_mixloss_bwd");
   return BCP_OK;
 }

@@ -303,11 +303,14 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
                                                     const float* __restrict__ residual, NormEpilogue ep, long long seg_rows,
                                                     int spg, int G, int C, float* __restrict__ out,
                                                     const float* __restrict__ var_unb, float* __restrict__ running_mean,
-                                                    float* __restrict__ running_var, float momentum, float* __restrict__ amax_out) {
+                                                    float* __restrict__ running_var, float momentum, float* __restrict__ amax_out,
+                                                    long long ldo4 /* row stride of out in float4: C / 4, or wider when out is the first C
+                                                                      channels of a concat buffer (bcp_norm_fwd out_ld) */) {
   constexpr int U = 4;
   float amax = 0.f;            // max |a| of what this thread writes (round 4: the fp16 pre-scale of the conv that reads a, conv3_defs.h)
   if (blockIdx.x == 0 && blockIdx.y == 0 && running_mean) update_running(mean, var_unb, G, C, running_mean, running_var, momentum);
   const int C4 = C >> 2;
+  const int c4sh = 31 - __clz(C4);
   const int col = threadIdx.x & (C4 - 1);          // C4 is a power of two dividing 256: fixed for the whole loop
   const int seg = blockIdx.y, g = seg / spg;
   const long long nv = seg_rows * C4, base = (long long)seg * nv;
@@ -325,7 +328,8 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
       o[2] *= m4.z ? ep.elem_scale : 0.f; o[3] *= m4.w ? ep.elem_scale : 0.f;
     }
     if (residual) { o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w; }
-    st4(out + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+    const long long io = ldo4 == C4 ? i : ((i - col) >> c4sh) * ldo4 + col;      // (i - col) / C4 = row: C4 is a power of two
+    st4(out + io * 4, make_float4(o[0], o[1], o[2], o[3]));
 #pragma unroll
     for (int k = 0; k < 4; ++k) { const float t = fabsf(o[k]); amax = (t > amax || t != t) ? t : amax; }
   };
@@ -524,9 +528,11 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
                             float* running_mean, float* running_var, float momentum, float eps, int act,
                             const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale,
                             const float* residual, float* stats /* [5][G][C]: mean, rstd, scale, beta, unbiased var */, void* workspace,
-                            const double* partial_in, int nb_in, float* out, float* amax_out /* nullable: max |out| (fp16 pre-scale of the conv that reads it) */,
-                            void* stream) {
+                            const double* partial_in, int nb_in, float* out, long long out_ld /* row stride of out in floats; 0: C */,
+                            float* amax_out /* nullable: max |out| (fp16 pre-scale of the conv that reads it) */, void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd", G, rows_per_group, C)) return rc;
+  if (out_ld == 0) out_ld = C;
+  BCP_REQUIRE(out_ld >= C && (out_ld & 3) == 0, "bcp_norm_fwd: out_ld=%lld (need a multiple of 4 >= C)", out_ld);
   BCP_REQUIRE(y && stats && workspace, "bcp_norm_fwd: null pointer");
   BCP_REQUIRE(aligned16(y) && (!out || aligned16(out)) && aligned16(stats), "bcp_norm_fwd: alignment");
   BCP_REQUIRE(out || !residual, "bcp_norm_fwd: statistics-only mode (out = NULL) takes no residual");
@@ -550,7 +556,7 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   }
   if (out)
     hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, scale, shift, mean, residual,
-                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out);
+                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out, (long long)(out_ld / 4));
   else if (running_mean)   // statistics only: the consumer applies the normalisation itself (bcp_pw16_fwd_norm); the apply pass also carries the running-statistics update
     hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
   BCP_CHECK_LAUNCH("bcp_norm_fwd");
@@ -624,7 +630,7 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
                      running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb, out ? amax_out : (float*)nullptr);
   if (out)
     hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, ysum, scale, shift, mean, residual,
-                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out);
+                       ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out, (long long)(C / 4));
   else if (running_mean)
     hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
   BCP_CHECK_LAUNCH("bcp_norm_fwd_slabs");

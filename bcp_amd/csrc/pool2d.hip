@@ -9,15 +9,17 @@
 
 namespace bcp {
 
+// ldx: row stride of x in floats -- C, or the width of the concat buffer whose first C channels x is (round 4: an encoder block's
+// output lives only there; no copy into the concat buffer)
 __global__ __launch_bounds__(256) void k_maxpool2d_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W,
-                                                       int C) {
+                                                       int C, int ldx) {
   const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
   const long long total = (long long)N * Ho * Wo * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c4 = (int)(i % C4);
     const int wo = (int)((i / C4) % Wo), ho = (int)((i / ((long long)C4 * Wo)) % Ho), n = (int)(i / ((long long)C4 * Wo * Ho));
-    const float* p = x + ((((long long)n * H + 2 * ho) * W + 2 * wo) * C) + c4 * 4;
-    const float4 a = ld4(p), b = ld4(p + C), c = ld4(p + (long long)W * C), d = ld4(p + (long long)W * C + C);
+    const float* p = x + ((((long long)n * H + 2 * ho) * W + 2 * wo) * ldx) + c4 * 4;
+    const float4 a = ld4(p), b = ld4(p + ldx), c = ld4(p + (long long)W * ldx), d = ld4(p + (long long)W * ldx + ldx);
     float4 o;
     o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(c.x, d.x));
     o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(c.y, d.y));
@@ -51,28 +53,46 @@ __global__ __launch_bounds__(256) void k_maxpool3d_k3s2_fwd(const float* __restr
   }
 }
 
-// gradient goes to the FIRST maximal element of each 2x2 window (row-major), as torch's max_pool2d does
-__global__ __launch_bounds__(256) void k_maxpool2d_bwd(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* __restrict__ dx, int N, int H, int W, int C, int accumulate) {
-  const int Ho = H >> 1, Wo = W >> 1;
-  const long long total = (long long)N * Ho * Wo * C;
+// gradient goes to the FIRST maximal element of each 2x2 window (row-major), as torch's max_pool2d does.  One thread per (window, float4
+// channel group).  add (nullable, row stride ld_add): a second gradient of x joined on the way out -- the decoder-side skip gradient,
+// the first C channels of the concat buffer's gradient (dx = scatter + add: the += launch that followed is gone)
+__global__ __launch_bounds__(256) void k_maxpool2d_bwd(const float* __restrict__ x, int ldx, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, int N, int H, int W, int C, int accumulate,
+                                                       const float* __restrict__ add, int ld_add) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+  const long long total = (long long)N * Ho * Wo * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int c = (int)(i % C);
-    const int wo = (int)((i / C) % Wo), ho = (int)((i / ((long long)C * Wo)) % Ho), n = (int)(i / ((long long)C * Wo * Ho));
-    const long long base = (((long long)n * H + 2 * ho) * W + 2 * wo) * C + c;
-    const long long off[4] = {0, C, (long long)W * C, (long long)W * C + C};
-    int best = 0;
-    float bv = x[base];
-#pragma unroll
-    for (int k = 1; k < 4; ++k) {
-      const float v = x[base + off[k]];
-      if (v > bv) { bv = v; best = k; }
-    }
-    const float g = dy[i];
+    const int c4 = (int)(i % C4);
+    const int wo = (int)((i / C4) % Wo), ho = (int)((i / ((long long)C4 * Wo)) % Ho), n = (int)(i / ((long long)C4 * Wo * Ho));
+    const long long row = ((long long)n * H + 2 * ho) * W + 2 * wo;
+    const long long roff[4] = {0, 1, W, (long long)W + 1};
+    float xv[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float v = (k == best) ? g : 0.f;
-      dx[base + off[k]] = accumulate ? dx[base + off[k]] + v : v;
+      const float4 v = ld4(x + (row + roff[k]) * ldx + c4 * 4);
+      xv[k][0] = v.x; xv[k][1] = v.y; xv[k][2] = v.z; xv[k][3] = v.w;
+    }
+    const float4 g4 = ld4(dy + i * 4);
+    const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+    int best[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      int b = 0;
+      float bv = xv[0][q];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (xv[k][q] > bv) { bv = xv[k][q]; b = k; }
+      best[q] = b;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = (best[q] == k) ? g[q] : 0.f;
+      float* dp = dx + (row + roff[k]) * C + c4 * 4;
+      if (accumulate) { const float4 t = ld4(dp); o[0] = t.x + o[0]; o[1] = t.y + o[1]; o[2] = t.z + o[2]; o[3] = t.w + o[3]; }
+      if (add) { const float4 t = ld4(add + (row + roff[k]) * ld_add + c4 * 4); o[0] += t.x; o[1] += t.y; o[2] += t.z; o[3] += t.w; }
+      st4(dp, make_float4(o[0], o[1], o[2], o[3]));
     }
   }
 }
@@ -188,10 +208,11 @@ static inline int sgrid(long long n) {
 
 using namespace bcp;
 
-extern "C" int bcp_maxpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream) {
-  BCP_REQUIRE(x && y && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, "bcp_maxpool2d_fwd: bad argument");
+extern "C" int bcp_maxpool2d_fwd(const float* x, int ldx, float* y, int N, int H, int W, int C, void* stream) {
+  if (ldx == 0) ldx = C;
+  BCP_REQUIRE(x && y && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0 && aligned16(x), "bcp_maxpool2d_fwd: bad argument");
   hipLaunchKernelGGL(k_maxpool2d_fwd, dim3(sgrid((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
-                     N, H, W, C);
+                     N, H, W, C, ldx);
   BCP_CHECK_LAUNCH("bcp_maxpool2d_fwd");
   return BCP_OK;
 }
@@ -204,10 +225,15 @@ extern "C" int bcp_maxpool3d_k3s2_fwd(const float* x, float* y, int N, int D, in
   return BCP_OK;
 }
 
-extern "C" int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate, void* stream) {
-  BCP_REQUIRE(x && dy && dx && N > 0 && H % 2 == 0 && W % 2 == 0, "bcp_maxpool2d_bwd: bad argument");
-  hipLaunchKernelGGL(k_maxpool2d_bwd, dim3(sgrid((long long)N * (H / 2) * (W / 2) * C)), dim3(256), 0, (hipStream_t)stream, x, dy, dx,
-                     N, H, W, C, accumulate);
+extern "C" int bcp_maxpool2d_bwd(const float* x, int ldx, const float* dy, float* dx, int N, int H, int W, int C, int accumulate,
+                                 const float* add_or_null, int ld_add, void* stream) {
+  if (ldx == 0) ldx = C;
+  if (add_or_null && ld_add == 0) ld_add = C;
+  BCP_REQUIRE(x && dy && dx && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0, "bcp_maxpool2d_bwd: bad argument");
+  BCP_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && (!add_or_null || (aligned16(add_or_null) && ld_add >= C && ld_add % 4 == 0)),
+              "bcp_maxpool2d_bwd: alignment / add stride");
+  hipLaunchKernelGGL(k_maxpool2d_bwd, dim3(sgrid((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, ldx, dy, dx,
+                     N, H, W, C, accumulate, add_or_null, ld_add);
   BCP_CHECK_LAUNCH("bcp_maxpool2d_bwd");
   return BCP_OK;
 }

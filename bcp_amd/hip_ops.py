@@ -71,6 +71,31 @@ class Ops:
         from . import plan
         plan.invalidate_all()      # recorded launch plans carry kernel choices and workspace sizes of the old options
 
+    @staticmethod
+    def channel_slab(buf, Cc):
+        """the first Cc channels of a channels-last buffer [..., ld] as a tensor view (row stride ld): what an encoder block of the U-Net
+        writes its output into when the buffer is the decoder's concat buffer"""
+        return buf[..., :Cc]
+
+    @staticmethod
+    def row_stride(t):
+        """row stride (floats) of a channels-last tensor that is either contiguous or the leading channels of a contiguous buffer"""
+        ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+        exp = ld
+        for d in range(t.dim() - 2, -1, -1):
+            if t.shape[d] != 1 and t.stride(d) != exp:
+                raise _lib.BcpError("HIP op needs a channels-last tensor or the leading channels of one")
+            exp *= t.shape[d]
+        if t.stride(-1) != 1 or ld < t.shape[-1]:
+            raise _lib.BcpError("HIP op needs unit channel stride")
+        return int(ld)
+
+    def _chk_rows(self, t):
+        """like _chk, for the arguments that may be channel slabs (row_stride)"""
+        if not self.allow_cpu and not t.is_cuda:
+            raise _lib.BcpError("HIP op called with a CPU tensor: the product path has no CPU fallback")
+        return self.row_stride(t)
+
     def _chk(self, *ts):
         for t in ts:
             if t is None:
@@ -171,23 +196,25 @@ class Ops:
         self.b.call("bcp_cc_largest", _p(seg), _p(out), _p(outf), N, D, H, W, nclass, connectivity, _p(ws), self.stream(seg))
         return (out, outf) if want_f32 else out
 
-    def mixloss_fwd(self, logits, img_l, patch_l, box6, flavour, w_img, w_patch, mask=None):
-        """-> (out3 float32[3] on device, workspace tensor to hand to mixloss_bwd)"""
-        self._chk(logits, img_l, patch_l, mask)
+    def mixloss_fwd(self, logits, img_l, patch_l, box6, flavour, w_img, w_patch, mask=None, prev=None, total=None):
+        """-> (out3 float32[3] on device, workspace tensor to hand to mixloss_bwd).  prev + total: the step's second call hands in the
+        first call's out3 and a float32[1] that receives the step's total loss (the reference's sum order, bcp_hip.h)"""
+        self._chk(logits, img_l, patch_l, mask, prev, total)
         N, D, H, W, Cc = logits.shape
         nbytes = self._ws_bytes("bcp_mixloss_workspace_bytes", N, Cc)
         ws = torch.empty(int(nbytes), dtype=torch.uint8, device=logits.device)  # kept alive for backward
         out3 = torch.empty(3, dtype=torch.float32, device=logits.device)
         self.b.call("bcp_mixloss_fwd", _p(logits), _p(img_l), _p(patch_l), _p(mask), self.box_arg(box6), N, D, H, W, Cc, flavour,
-                    float(w_img), float(w_patch), _p(ws), _p(out3), self.stream(logits))
+                    float(w_img), float(w_patch), _p(ws), _p(out3), _p(prev), _p(total), self.stream(logits))
         return out3, ws
 
     def mixloss_bwd(self, logits, img_l, patch_l, box6, flavour, ws, g_dice, g_ce, mask=None, g_dev=None, out=None):
-        self._chk(logits, img_l, patch_l, mask, out)
+        """g_dev: device float32 of upstream gradients -- two elements {dice, ce} or ONE for both terms"""
+        self._chk(logits, img_l, patch_l, mask, out, g_dev)
         N, D, H, W, Cc = logits.shape
         dlogits = torch.empty_like(logits) if out is None else out
         self.b.call("bcp_mixloss_bwd", _p(logits), _p(img_l), _p(patch_l), _p(mask), self.box_arg(box6), N, D, H, W, Cc, flavour,
-                    _p(ws), float(g_dice), float(g_ce), _p(g_dev), _p(dlogits), self.stream(logits))
+                    _p(ws), float(g_dice), float(g_ce), _p(g_dev), 0 if g_dev is None else int(g_dev.numel()), _p(dlogits), self.stream(logits))
         return dlogits
 
     # ------------------------------------------------------------------ DiceLoss class on probabilities (utils/losses.py:113-134)
@@ -243,14 +270,17 @@ class Ops:
         nbytes = self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc)
         ws = self.workspace("norm", nbytes, y)
         stats = torch.empty((5, G, Cc), dtype=torch.float32, device=y.device)
+        out_ld = 0
         if stats_only:
             assert out is None and residual is None and elem_mask is None
         elif out is None:
             out = torch.empty_like(y)
+        else:
+            out_ld = self._chk_rows(out)        # out may be the leading channels of a wider buffer (channel_slab: the U-Net's concat)
         amax = self._amax_slot(out)
         self.b.call("bcp_norm_fwd", _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps), act,
                     _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws), _p(partial), int(nb), _p(out),
-                    _p(amax), self.stream(y))
+                    out_ld, _p(amax), self.stream(y))
         return out, stats
 
     def norm_eval(self, y, gamma, beta, rmean, rvar, act, residual=None, eps=1e-5, out=None):
@@ -639,11 +669,12 @@ class Ops:
 
     # ------------------------------------------------------------------ 2-D U-Net plumbing
     def maxpool2d_fwd(self, x):
-        self._chk(x)
+        """x: contiguous or a channel slab (channel_slab)"""
+        ldx = self._chk_rows(x)
         N, D, H, W, Cc = x.shape
         assert D == 1
         y = torch.empty((N, 1, H // 2, W // 2, Cc), dtype=torch.float32, device=x.device)
-        self.b.call("bcp_maxpool2d_fwd", _p(x), _p(y), N, H, W, Cc, self.stream(x))
+        self.b.call("bcp_maxpool2d_fwd", _p(x), ldx, _p(y), N, H, W, Cc, self.stream(x))
         return y
 
     def maxpool3d_k3s2_fwd(self, x):
@@ -654,10 +685,14 @@ class Ops:
         self.b.call("bcp_maxpool3d_k3s2_fwd", _p(x), _p(y), N, D, H, W, Cc, self.stream(x))
         return y
 
-    def maxpool2d_bwd(self, x, dy, dx, accumulate=False):
-        self._chk(x, dy, dx)
+    def maxpool2d_bwd(self, x, dy, dx, accumulate=False, add=None):
+        """add: a second gradient of x joined on the way out (contiguous or a channel slab, e.g. the skip half of the concat buffer's
+        gradient): dx = scatter(dy) + add"""
+        self._chk(dy, dx)
+        ldx = self._chk_rows(x)
+        ld_add = self._chk_rows(add) if add is not None else 0
         N, D, H, W, Cc = x.shape
-        self.b.call("bcp_maxpool2d_bwd", _p(x), _p(dy), _p(dx), N, H, W, Cc, int(bool(accumulate)), self.stream(x))
+        self.b.call("bcp_maxpool2d_bwd", _p(x), ldx, _p(dy), _p(dx), N, H, W, Cc, int(bool(accumulate)), _p(add), ld_add, self.stream(x))
         return dx
 
     def bilinear2x_fwd(self, x, y, y_off):

@@ -37,6 +37,7 @@ class _CB:
 
 class UNet_2d(HipNet):
     fuse_c1 = True       # first layer: conv + norm + LeakyReLU (+ dropout) with recompute (networks/VNet.py)
+    skip_in_concat = True   # encoder outputs are written into the decoder's concat buffers (no torch.cat copy; pool backward joins the skip gradient)
     def __init__(self, in_chns, class_num):
         super().__init__()
         assert in_chns == 1, "the ACDC hot path is single-channel"
@@ -106,7 +107,10 @@ class UNet_2d(HipNet):
         m = torch.empty(shape, dtype=torch.uint8, device=dev)
         return self.ops.bernoulli(m, 1.0 - cb.p, 1.0, self.next_seed())
 
-    def _convblock_fwd(self, cb, tag, h, save, saved):
+    def _convblock_fwd(self, cb, tag, h, save, saved, out=None):
+        """out: where the block's output goes when the caller has a place for it -- the leading channels of the decoder's concat buffer
+        (Ops.channel_slab).  Returned as is when it was used; otherwise the block returns a tensor of its own (eval mode, the raw-slab
+        norm of the deepest level) and the caller copies."""
         ops = self.ops
         G = getattr(self, "_groups", 1)
         if not self.training:      # model.eval(): running statistics, no dropout (val_2d / test scripts, SURVEY 8f-1)
@@ -155,7 +159,8 @@ class UNet_2d(HipNet):
                                              b2.running_mean, b2.running_var, H.ACT_LRELU)
         else:
             y2, part2, nb2 = ops.conv3_fwd_stats(a1, wf2, cb.c2.bias.data, cb.cout, 1, G)
-            a2, st2 = ops.norm_fwd(y2, G, b2.weight.data, b2.bias.data, b2.running_mean, b2.running_var, H.ACT_LRELU, partial=part2, nb=nb2)
+            a2, st2 = ops.norm_fwd(y2, G, b2.weight.data, b2.bias.data, b2.running_mean, b2.running_var, H.ACT_LRELU, partial=part2, nb=nb2,
+                                   out=out)
         if save:
             saved[tag] = (h, y1, st1, em, a1, y2, st2, G)
         return a2
@@ -199,20 +204,35 @@ class UNet_2d(HipNet):
         ops = self.ops
         saved = {} if save else None
         N = xcl.shape[0]
-        xs = [self._convblock_fwd(self._enc[0], "e0", xcl, save, saved)]
+        # torch.cat([skip, up]) without the copy (round 4): encoder block j writes its output straight into the leading channels of the
+        # concat buffer its decoder block reads (bcp_norm_fwd out_ld), the pool reads it from there (bcp_maxpool2d_fwd ldx) -- the skip
+        # tensor exists once.  Hh, Ww of level j = input >> j; channels FT[j].
+        cats = [None] * 4
+        Hh, Ww = xcl.shape[2], xcl.shape[3]
+        if self.training and self.skip_in_concat:
+            cats = [torch.empty((N, 1, Hh >> j, Ww >> j, 2 * FT[j]), dtype=torch.float32, device=xcl.device) for j in range(4)]
+        slab = [None if c is None else ops.channel_slab(c, FT[j]) for j, c in enumerate(cats)]
+        xs = [self._convblock_fwd(self._enc[0], "e0", xcl, save, saved, out=slab[0])]
         for i in range(1, 5):
             pooled = ops.maxpool2d_fwd(xs[-1])
             am = getattr(xs[-1], "_bcp_amax", None)
             if am is not None:
                 pooled._bcp_amax = am          # max |pool(x)| <= max |x|: an upper bound is all the fp16 pre-scale of the next conv needs
-            xs.append(self._convblock_fwd(self._enc[i], f"e{i}", pooled, save, saved))
+            xs.append(self._convblock_fwd(self._enc[i], f"e{i}", pooled, save, saved, out=slab[i] if i < 4 else None))
         h = xs[4]
         for i, (pw, cb, c1, c2) in enumerate(self._up, start=1):
             bp, _ = self.k2_packed(("pw", i), save)
             z = ops.pw_fwd(h, bp, pw.bias.data, c2)
             skip = xs[4 - i]
-            cat = torch.empty((N, 1, skip.shape[2], skip.shape[3], 2 * c2), dtype=torch.float32, device=xcl.device)
-            ops.copy_channels(skip, cat, c2, 0, 0, carry_amax=True)      # (+ the |max| of the concat buffer: skip's, then the upsampled half's)
+            if slab[4 - i] is not None and skip is slab[4 - i]:
+                cat = cats[4 - i]
+                am = getattr(skip, "_bcp_amax", None)
+                if am is not None:
+                    cat._bcp_amax = am         # the concat buffer's |max| slots ARE the skip's; the upsample max-reduces its half into them
+                                               # (the skip's own readers then see an upper bound, which is all they need)
+            else:
+                cat = torch.empty((N, 1, skip.shape[2], skip.shape[3], 2 * c2), dtype=torch.float32, device=xcl.device)
+                ops.copy_channels(skip, cat, c2, 0, 0, carry_amax=True)      # (+ the |max| of the concat buffer: skip's, then the upsampled half's)
             ops.bilinear2x_fwd(z, cat, c2)
             if save:
                 saved[f"pw{i}"] = (h,)
@@ -267,10 +287,10 @@ class UNet_2d(HipNet):
         # dh = gradient w.r.t. x4; walk the encoder upwards
         for i in range(4, 0, -1):
             dpool = self._convblock_bwd(self._enc[i], f"e{i}", dh, saved, True)
-            dx = torch.empty_like(xs[i - 1])
-            ops.maxpool2d_bwd(xs[i - 1], dpool, dx)
+            dx = torch.empty(tuple(xs[i - 1].shape), dtype=torch.float32, device=dpool.device)
             dcat, c2 = skip_grads[i - 1]
-            ops.copy_channels(dcat, dx, c2, 0, 0, accumulate=True)               # join the decoder-side skip gradient
+            # pool backward + the decoder-side skip gradient (the leading c2 channels of dcat) in one pass
+            ops.maxpool2d_bwd(xs[i - 1], dpool, dx, add=ops.channel_slab(dcat, c2))
             dh = dx
             self._grads_final_from(self._enc[i].c1.weight, dx)
         self._convblock_bwd(self._enc[0], "e0", dh, saved, False)

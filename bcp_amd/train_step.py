@@ -13,6 +13,12 @@ from .hip_ops import Ops
 from .utils import BCP_utils as BU
 
 
+# grouped steps: the second mix_loss launch leaves the step's total loss on the device (BU.mix_loss_pair(total=True)) and the backward pass
+# starts from a cached unit gradient -- no torch elementwise launches between forward and backward.  False: the reference's adds / division
+# as torch ops (measurement switch, bench.py --opt step_total=0)
+STEP_TOTAL = True
+
+
 def _ops_for(t):
     return BU._ops_for(t)
 
@@ -269,7 +275,11 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         outputs = model(mixed, groups=2, features=False)[0]
         if side is not None:
             torch.cuda.current_stream(volume_batch.device).wait_stream(side)   # pseudo-labels are needed from here on
-        loss_l, loss_u = BU.mix_loss_pair(outputs, terms[0], terms[1], loss_mask)
+        if STEP_TOTAL:
+            loss, loss_l, loss_u = BU.mix_loss_pair(outputs, terms[0], terms[1], loss_mask, total=True)      # loss = loss_l + loss_u, summed on the device
+        else:
+            loss_l, loss_u = BU.mix_loss_pair(outputs, terms[0], terms[1], loss_mask)
+            loss = loss_l + loss_u
         outputs_l, outputs_u = outputs[:sub_bs], outputs[sub_bs:]
     else:
         mixl_img = pairs[0][0] * img_mask + pairs[0][1] * (1 - img_mask)
@@ -280,14 +290,14 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         model.drop_masks = drops.get("s_u")
         outputs_u = model(mixu_img, features=False)[0]
         loss_u = BU.mix_loss(outputs_u, terms[1][0], terms[1][1], loss_mask, l_weight=terms[1][2], u_weight=terms[1][3])
-    loss = loss_l + loss_u
+        loss = loss_l + loss_u
     if optimizer is None:      # gradient-only mode (DP equivalence tests): caller owns zero_grad / step / EMA
-        loss.backward()
+        loss.backward(gradient=BU.unit_gradient(loss))
     else:
         optimizer.zero_grad()
         if dp is not None and grouped:
             dp.arm(model)              # ONE backward in this step: gradient buckets go out underneath it
-        loss.backward()
+        loss.backward(gradient=BU.unit_gradient(loss))
         if dp is not None:
             dp.allreduce_grads(model, optimizer)
         optimizer.step()
@@ -418,8 +428,16 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
         out = model(mixed, groups=2)
         if side is not None:
             torch.cuda.current_stream(volume_batch.device).wait_stream(side)   # pseudo-labels are needed from here on
-        unl_dice, unl_ce, l_dice, l_ce = BU.mix_loss_pair(out, (plab_a, lab_a, u_weight, 1.0), (lab_b, plab_b, 1.0, u_weight), loss_mask,
-                                                          flavour=H.LOSS_ACDC)
+        if STEP_TOTAL:
+            loss, unl_dice, unl_ce, l_dice, l_ce = BU.mix_loss_pair(out, (plab_a, lab_a, u_weight, 1.0), (lab_b, plab_b, 1.0, u_weight), loss_mask,
+                                                                    flavour=H.LOSS_ACDC, total=True)     # loss: summed on the device, :381-384's order
+            loss_ce, loss_dice = None, None      # (reported below from the detached terms)
+        else:
+            unl_dice, unl_ce, l_dice, l_ce = BU.mix_loss_pair(out, (plab_a, lab_a, u_weight, 1.0), (lab_b, plab_b, 1.0, u_weight), loss_mask,
+                                                              flavour=H.LOSS_ACDC)
+            loss_ce = unl_ce + l_ce
+            loss_dice = unl_dice + l_dice
+            loss = (loss_dice + loss_ce) / 2
         out_unl, out_l = out[:lsub], out[lsub:]
     else:
         net_input_unl = uimg_a * img_mask + img_a * (1 - img_mask)
@@ -430,22 +448,24 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
         model.drop_masks = drops.get("s_l")
         out_l = model(net_input_l)
         l_dice, l_ce = acdc_mix_loss(out_l, lab_b, plab_b, loss_mask, u_weight=u_weight)
-    loss_ce = unl_ce + l_ce
-    loss_dice = unl_dice + l_dice
-    loss = (loss_dice + loss_ce) / 2
+        loss_ce = unl_ce + l_ce
+        loss_dice = unl_dice + l_dice
+        loss = (loss_dice + loss_ce) / 2
     if optimizer is None:              # gradient-only mode: the caller owns zero_grad / step / EMA
-        loss.backward()
+        loss.backward(gradient=BU.unit_gradient(loss))
     else:
         optimizer.zero_grad()
         if dp is not None:
             dp.arm(model)              # one backward covers both student batches (grouped or not: `loss` sums their terms)
-        loss.backward()
+        loss.backward(gradient=BU.unit_gradient(loss))
         if dp is not None:
             dp.allreduce_grads(model, optimizer)
         optimizer.step()
         update_model_ema(model, ema_model, alpha)
     model.drop_masks = None
     ema_model.drop_masks = None
+    if loss_ce is None:                # grouped: the two reported sums are side results, computed after the backward pass was enqueued
+        loss_ce, loss_dice = unl_ce + l_ce, unl_dice + l_dice
     return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach(), plab_a=own_plabs[0], plab_b=own_plabs[1],
                 out_unl=out_unl.detach(), out_l=out_l.detach())
 

@@ -233,17 +233,69 @@ class _MixLossPairFn(torch.autograd.Function):
         return (d,) + (None,) * 9
 
 
-def mix_loss_pair(out, first, second, mask, flavour=H.LOSS_LA):
+class _MixLossPairTotalFn(torch.autograd.Function):
+    """_MixLossPairFn whose differentiable output is the step's TOTAL loss -- LA / pancreas loss_l + loss_u, ACDC ((unl_dice + l_dice) +
+    (unl_ce + l_ce)) / 2, summed by the second call's finalize in the reference's fp32 order (bcp_mixloss_fwd prev / total) -- so that no
+    torch elementwise launch sits between the forward and the backward pass (round 4: the step functions' three adds, the division, their
+    autograd twins and two torch.cat calls were ~10 dependent 5 us launches per step).  The individual terms come back detached, for
+    logging, exactly as _MixLossPairFn computes them.  d total / d term is 1/2 for every (dice, ce) pair of both flavours."""
+
+    @staticmethod
+    def forward(ctx, logits_cl, lab1, plab1, lab2, plab2, box6, mask_u8, flavour, w1, w2):
+        ops = _ops_for(logits_cl)
+        n = logits_cl.shape[0] // 2
+        a, b = logits_cl[:n], logits_cl[n:]
+        total = torch.empty(1, dtype=torch.float32, device=logits_cl.device)
+        o1, ws1 = ops.mixloss_fwd(a, lab1, plab1, box6, flavour, w1[0], w1[1], mask=mask_u8)
+        o2, ws2 = ops.mixloss_fwd(b, lab2, plab2, box6, flavour, w2[0], w2[1], mask=mask_u8, prev=o1, total=total)
+        ctx.save_for_backward(logits_cl, lab1, plab1, lab2, plab2, ws1, ws2)
+        ctx.meta = (box6, mask_u8, flavour)
+        terms = (o1[0], o2[0]) if flavour == H.LOSS_LA else (o1[0], o1[1], o2[0], o2[1])
+        ctx.mark_non_differentiable(*terms)
+        return (total.reshape(()),) + terms
+
+    @staticmethod
+    def backward(ctx, g, *unused):
+        logits_cl, lab1, plab1, lab2, plab2, ws1, ws2 = ctx.saved_tensors
+        box6, mask_u8, flavour = ctx.meta
+        ops = _ops_for(logits_cl)
+        n = logits_cl.shape[0] // 2
+        d = torch.empty_like(logits_cl)
+        g1 = g.reshape(1)
+        if g1.dtype != torch.float32 or not g1.is_contiguous():
+            g1 = g1.to(torch.float32).contiguous()
+        for half, (lab, plab, ws) in enumerate(((lab1, plab1, ws1), (lab2, plab2, ws2))):
+            sl = slice(0, n) if half == 0 else slice(n, 2 * n)
+            ops.mixloss_bwd(logits_cl[sl], lab, plab, box6, flavour, ws, 0.5, 0.5, mask=mask_u8, g_dev=g1, out=d[sl])
+        return (d,) + (None,) * 9
+
+
+def mix_loss_pair(out, first, second, mask, flavour=H.LOSS_LA, total=False):
     """`out` = logits of a grouped forward over [batch1; batch2]; `first` / `second` = (img_l, patch_l, w_img, w_patch)
-    for each half.  LA: returns (loss_1, loss_2); ACDC: (dice_1, ce_1, dice_2, ce_2)."""
+    for each half.  LA: returns (loss_1, loss_2); ACDC: (dice_1, ce_1, dice_2, ce_2).  total=True: (total, *terms) with `total` the
+    step's loss as the reference sums it and the only differentiable output (_MixLossPairTotalFn)."""
     cl = _as_cl(out)
     ops = _ops_for(cl)
     N, sp = cl.shape[0] // 2, tuple(out.shape[2:])
     box6, m8 = _mask_args(mask, ops, N, sp)
     l1, p1, w1a, w1b = first
     l2, p2, w2a, w2b = second
-    return _MixLossPairFn.apply(cl, _labels_u8(ops, l1, N, sp), _labels_u8(ops, p1, N, sp), _labels_u8(ops, l2, N, sp),
-                                _labels_u8(ops, p2, N, sp), box6, m8, flavour, (float(w1a), float(w1b)), (float(w2a), float(w2b)))
+    fn = _MixLossPairTotalFn if total else _MixLossPairFn
+    return fn.apply(cl, _labels_u8(ops, l1, N, sp), _labels_u8(ops, p1, N, sp), _labels_u8(ops, l2, N, sp),
+                    _labels_u8(ops, p2, N, sp), box6, m8, flavour, (float(w1a), float(w1b)), (float(w2a), float(w2b)))
+
+
+_ONES = {}
+
+
+def unit_gradient(like):
+    """a cached 0-dim float32 one on `like`'s device: `loss.backward(gradient=unit_gradient(loss))` spares the fill launch autograd would
+    make for the implicit gradient of a scalar loss"""
+    k = (like.device.type, like.device.index)
+    o = _ONES.get(k)
+    if o is None:
+        o = _ONES[k] = torch.ones((), dtype=torch.float32, device=like.device)
+    return o
 
 
 def _mask_args(mask, ops, N, sp):

@@ -520,6 +520,14 @@ def main():
             from bcp_amd.networks._hipnet import HipNet as _hn2
             _hn2.DEFER_DGRAD_PACK = bool(int(v))
             continue
+        if k == "step_total":         # host-side switch (train_step.py): total loss summed by the second mix_loss launch, cached unit gradient
+            from bcp_amd import train_step as _ts2
+            _ts2.STEP_TOTAL = bool(int(v))
+            continue
+        if k == "skip_in_concat":     # host-side switch (networks/unet.py): encoder outputs written into the decoder's concat buffers
+            from bcp_amd.networks.unet import UNet_2d as _un2
+            _un2.skip_in_concat = bool(int(v))
+            continue
         if k == "fuse_head":          # host-side switch (networks/VNet.py), not a library option
             from bcp_amd.networks.VNet import VNet
             VNet.fuse_head = bool(int(v))

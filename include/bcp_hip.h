@@ -76,15 +76,20 @@ int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8_or_null, float* out_f32_o
 /* ---- masked Dice + CE "mix_loss" (utils/BCP_utils.py:58-69 + utils/losses.py:47-77 [flavour LA, C=2];
  *      ACDC_BCP_train.py:167-179 + utils/losses.py:102-134 [flavour ACDC, C=4]).  mask_or_null: explicit uint8 mask
  *      (1 = image term) or NULL to use the box.  out3: LA {loss, ce, dice}; ACDC {dice, ce, (dice+ce)/2}.
- *      bwd writes d(g_dice*dice + g_ce*ce)/dlogits (LA: g_dice = g_ce = 0.5); g_dev_or_null = device float[2] of upstream
- *      gradients multiplied in on the device, so autograd never has to read a scalar back. */
+ *      bwd writes d(g_dice*dice + g_ce*ce)/dlogits (LA: g_dice = g_ce = 0.5); g_dev_or_null = device float[g_dev_n] of upstream
+ *      gradients multiplied in on the device, so autograd never has to read a scalar back (g_dev_n = 2: {dice, ce}; 1: one gradient
+ *      for both terms).
+ *      prev_out3_or_null + total_or_null (round 4, together or not at all): the SECOND mix_loss call of a training step passes the
+ *      first call's out3 and receives the step's total loss, summed in the reference's fp32 order -- LA / pancreas loss_l + loss_u
+ *      (LA_BCP_train.py:255, train_pancreas.py:166), ACDC ((unl_dice + l_dice) + (unl_ce + l_ce)) / 2 (ACDC_BCP_train.py:381-384) --
+ *      so no elementwise launches sit between the forward and the backward pass. */
 size_t bcp_mixloss_workspace_bytes(int N, int C);
 int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6 /* HOST */,
                     int N, int D, int H, int W, int C, int flavour, float w_img, float w_patch, void* workspace, float* out3,
-                    void* stream);
+                    const float* prev_out3_or_null, float* total_or_null, void* stream);
 int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6 /* HOST */,
                     int N, int D, int H, int W, int C, int flavour, const void* workspace, float g_dice, float g_ce, const float* g_dev_or_null,
-                    float* dlogits, void* stream);
+                    int g_dev_n, float* dlogits, void* stream);
 
 /* ---- utils/losses.py:79-134 `DiceLoss.forward(inputs, target, mask=None, weight=None, softmax=False)` as the CLASS the ACDC
  *      script instantiates (ACDC_BCP_train.py:66) and calls on F.softmax(output) (:170-176): `probs` are PROBABILITIES in any
@@ -113,6 +118,8 @@ int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const f
                  float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
                  const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace,
                  const double* partial_in_or_null /* [G][nb_in][C][2] from bcp_conv3_fwd_stats */, int nb_in, float* out,
+                 long long out_ld /* row stride of out in floats, 0 = C.  Wider: out is the first C channels of a concat buffer
+                                     (networks/unet.py:56 torch.cat([skip, up]): the skip is WRITTEN there, never copied) */,
                  float* amax_out_or_null /* device float <- max |out| (round 4: the x_amax of the conv that reads out, see bcp_conv3_fwd) */,
                  void* stream);
 int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
@@ -250,11 +257,15 @@ int bcp_pw16_bwd_norm(const float* x_raw, const float* stats, const float* chan_
 int bcp_colsum(const float* x, long long rows, int C, float* out, int accumulate, void* workspace, void* stream);
 
 /* ---- 2-D U-Net plumbing (networks/unet.py:36-57): MaxPool2d(2), bilinear x2 align_corners=True, channel concat ---- */
-int bcp_maxpool2d_fwd(const float* x, float* y, int N, int H, int W, int C, void* stream);
+/* ldx: row stride of x in floats (0 = C): x may be the first C channels of a concat buffer (bcp_norm_fwd out_ld) */
+int bcp_maxpool2d_fwd(const float* x, int ldx, float* y, int N, int H, int W, int C, void* stream);
 /* nn.MaxPool3d(3, stride=2), forward only: pool(x5), the V-Net's second return value (networks/VNet.py:246,286-290); x [N][D][H][W][C]
  * -> y [N][(D-3)/2+1][(H-3)/2+1][(W-3)/2+1][C] */
 int bcp_maxpool3d_k3s2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);
-int bcp_maxpool2d_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, int accumulate, void* stream);
+/* dx = scatter(dy) [+ dx when accumulate] [+ add: a second gradient of x with row stride ld_add, e.g. the skip half of the concat
+ * buffer's gradient -- the join that used to be a bcp_copy_channels(accumulate) launch] */
+int bcp_maxpool2d_bwd(const float* x, int ldx, const float* dy, float* dx, int N, int H, int W, int C, int accumulate,
+                      const float* add_or_null, int ld_add, void* stream);
 /* amax (round 4, the |max| a conv needs for its fp16 planes, see bcp_conv3_fwd), through the U-Net's skip concatenation: bcp_copy_channels
  * initialises the concat buffer's slot with the skip tensor's |max| (amax_src_or_null; NULL: 0), bcp_bilinear2x_fwd max-reduces what it
  * writes INTO the slot (amax_io_or_null) -- in that order on one stream. */

@@ -137,6 +137,15 @@ def check_mixloss(ops, dev, golden_dir):
     assert abs(float(out3[0]) - float(g["l3"])) < 1e-5
     dl = ops.mixloss_bwd(lcl, a8, a8, (0, 0, 0, 0, 0, 0), H.LOSS_LA, ws, 0.5, 0.5)
     close(from_cl(dl), torch.from_numpy(g["g3"]), rtol=1e-4, msg="sup loss grad")
+    # round 4: the second call of a step sums the total on the device, in the reference's fp32 order (loss_l + loss_u); one upstream
+    # gradient for both terms == the same value twice
+    o1, _ = ops.mixloss_fwd(lcl, a8, b8, box, H.LOSS_LA, 1.0, 0.5)
+    tot = torch.empty(1, dtype=torch.float32, device=dev)
+    o2, ws2 = ops.mixloss_fwd(lcl, b8, a8, box, H.LOSS_LA, 0.5, 1.0, prev=o1, total=tot)
+    assert float(tot[0]) == float((o1[0] + o2[0]).cpu()), "step total (LA)"
+    gd = torch.tensor([0.37], dtype=torch.float32).to(dev)
+    assert torch.equal(ops.mixloss_bwd(lcl, b8, a8, box, H.LOSS_LA, ws2, 0.5, 0.5, g_dev=gd),
+                       ops.mixloss_bwd(lcl, b8, a8, box, H.LOSS_LA, ws2, 0.5, 0.5, g_dev=torch.cat([gd, gd])))
 
     g = np.load(f"{golden_dir}/mixloss_acdc.npz")
     lo = torch.from_numpy(g["logits"])
@@ -148,6 +157,11 @@ def check_mixloss(ops, dev, golden_dir):
         assert abs(float(out3[0]) - float(g["d" + key])) < 1e-5 and abs(float(out3[1]) - float(g["c" + key])) < 1e-5
         dl = ops.mixloss_bwd(lcl, a8, b8, box, H.LOSS_ACDC, ws, 0.5, 0.5)
         close(from_cl(dl, True), torch.from_numpy(g["g" + key]), rtol=1e-4, msg="mixloss_acdc grad " + key)
+    o1, _ = ops.mixloss_fwd(lcl, a8, b8, box, H.LOSS_ACDC, 0.5, 1.0)
+    tot = torch.empty(1, dtype=torch.float32, device=dev)
+    o2, _ = ops.mixloss_fwd(lcl, b8, a8, box, H.LOSS_ACDC, 1.0, 0.5, prev=o1, total=tot)
+    o1c, o2c = o1.cpu(), o2.cpu()
+    assert float(tot[0]) == float(((o1c[0] + o2c[0]) + (o1c[1] + o2c[1])) / 2), "step total (ACDC): ((unl_dice + l_dice) + (unl_ce + l_ce)) / 2"
 
 
 def _acdc_mix_loss_body(dice_loss, output, img_l, patch_l, mask, l_weight=1.0, u_weight=0.5, unlab=False):
@@ -572,6 +586,24 @@ def check_pool2d(ops, dev):
     assert torch.equal(from_cl(y, True).cpu(), y_ref.detach())
     dx = ops.maxpool2d_bwd(xcl, to_cl(dy).to(dev), torch.empty_like(xcl))
     assert torch.equal(from_cl(dx, True).cpu(), x.grad)
+    # round 4: the skip lives in the leading channels of the concat buffer -- the norm writes it there (out_ld), the pool reads it from
+    # there (ldx), the pool's backward joins the decoder-side skip gradient (add); all bit-identical to the contiguous / copied forms
+    wide = torch.full((2, 1, 8, 12, 32), 7.0, dtype=torch.float32, device=dev)
+    slab = ops.channel_slab(wide, 16)
+    slab.copy_(xcl)
+    assert torch.equal(ops.maxpool2d_fwd(slab), y)
+    dcat = to_cl(R(rng, 2, 32, 8, 12)).to(dev)
+    dx2 = ops.maxpool2d_bwd(slab, to_cl(dy).to(dev), torch.empty_like(xcl), add=ops.channel_slab(dcat, 16))
+    ref2 = ops.copy_channels(dcat, dx.clone(), 16, 0, 0, accumulate=True)
+    assert torch.equal(dx2, ref2), "maxpool2d_bwd + skip-gradient join"
+    ynorm = to_cl(R(rng, 2, 16, 8, 12) * 1.5 + 0.3).to(dev)
+    gam, bet = torch.from_numpy(rng.uniform(0.5, 1.5, 16).astype(np.float32)).to(dev), torch.from_numpy(rng.uniform(-0.3, 0.3, 16).astype(np.float32)).to(dev)
+    a_c, st_c = ops.norm_fwd(ynorm, 2, gam, bet, torch.zeros(16).to(dev), torch.ones(16).to(dev), H.ACT_LRELU)
+    wide.fill_(7.0)
+    a_s, st_s = ops.norm_fwd(ynorm, 2, gam, bet, torch.zeros(16).to(dev), torch.ones(16).to(dev), H.ACT_LRELU, out=ops.channel_slab(wide, 16))
+    assert a_s.data_ptr() == wide.data_ptr() and torch.equal(a_s, a_c) and torch.equal(st_s, st_c), "norm_fwd into a channel slab"
+    assert bool((wide[..., 16:] == 7.0).all()), "norm_fwd out_ld: wrote outside its channels"
+    assert H.amax_value(a_s._bcp_amax) == float(a_c.abs().max())
     # nn.MaxPool3d(3, stride=2): the V-Net's pooled x5 features (7x7x5 -> 3x3x2 at the LA size), odd and even extents
     for sp in ((7, 7, 5), (6, 8, 3), (3, 3, 3)):
         x3 = R(rng, 2, 32, *sp)

@@ -680,6 +680,44 @@ def check_sliding_window_pancreas(ops, dev, golden_dir):
     assert avg[0] > 0.99 and len(lst) == 1 and net.training      # the prediction against the reference's own label map
 
 
+def check_unet_skip_in_concat(ops, dev, hw=(64, 64), N=4, seed=23, min_direct=3):
+    """encoder outputs written straight into the decoder's concat buffers + pool backward joining the skip gradient (UNet_2d.skip_in_concat,
+    round 4) against the torch.cat-style copies they replace: same network, same input, live dropout off.  Not bit for bit -- the concat
+    buffer shares the skip's |max| slots, so the skip's own readers scale their fp16 planes by an upper bound instead of the exact maximum --
+    but far inside the parity tolerance"""
+    rng = np.random.default_rng(seed)
+    P = O.init_params(O.unet_param_shapes(), seed=seed + 100, random_affine=True)
+    x = torch.from_numpy(rng.random((N, 1) + hw, dtype=np.float32)).to(dev)
+    dm = {f"d{i}": torch.from_numpy((rng.random((N, c, hw[0] >> i, hw[1] >> i)) >= p).astype(np.float32)) for i, (c, p) in enumerate(zip(O.UNET_CH, O.UNET_DROP))}
+    w = torch.from_numpy(rng.standard_normal((N, 4) + hw).astype(np.float32)).to(dev)
+    res, copies = {}, {}
+    real_copy = ops.copy_channels
+    for flag in (True, False):
+        n = [0]
+
+        def counting(*a, **k):
+            n[0] += 1
+            return real_copy(*a, **k)
+        ops.copy_channels = counting
+        try:
+            net = make_unet(P, dev, ops)
+            net.skip_in_concat = flag
+            net.drop_masks = dm
+            out = net(x, groups=2)
+            (out * w).sum().backward()
+        finally:
+            del ops.copy_channels
+        copies[flag] = n[0]
+        res[flag] = (out.detach().cpu(), {k: p.grad.detach().cpu().clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert copies[False] == 4 and copies[True] <= min_direct, copies      # the four concat copies; a level served by the raw-slab norm still copies (tiny extents only)
+    assert K.rel_l2(res[True][0], res[False][0]) < 1e-5, K.rel_l2(res[True][0], res[False][0])
+    for k, g in res[False][1].items():
+        if float(g.norm()) < 1e-7:
+            continue
+        r = K.rel_l2(res[True][1][k], g)
+        assert r < 1e-4, (k, r)
+
+
 def check_unet_eval(ops, dev, seed=5):
     """model.eval() U-Net forward (running statistics, no dropout) vs the oracle; the running statistics stay untouched"""
     rng = np.random.default_rng(seed)

@@ -28,6 +28,11 @@ def test_unet_smooth_grads(ops):
     NC.check_unet_smooth(ops, DEV, hw=(64, 64), N=2)
 
 
+def test_skip_written_into_the_concat_buffer_equals_the_copy(ops):
+    NC.check_unet_skip_in_concat(ops, DEV, hw=(64, 64), N=4)
+    NC.check_unet_skip_in_concat(ops, DEV, hw=(256, 256), N=12, seed=29, min_direct=0)     # the student batch of the ACDC step: no level takes the raw-slab norm, no copy left
+
+
 def test_acdc_self_train_trajectory(ops, golden_dir):
     NC.check_acdc_step(ops, DEV, golden_dir)
 
