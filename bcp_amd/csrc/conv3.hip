@@ -987,19 +987,38 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
       if (EPI == 4) { k1[r] = nm.c1c2[o + r]; k2[r] = nm.c1c2[GC + o + r]; }
     }
   }
+  // 3-D: the halo of the NEXT tile travels in registers under the current tile's MFMAs (round 4, same box, three interleaved pairs: LA
+  // step 5.29-5.32 vs 5.30-5.36 ms; the kernel ALONE stays at 34 us for 11 us of matrix work -- its fp64 statistics and one dependent
+  // 7-MFMA chain per m-tile bound it, not the round trip).  2-D (PRE = false: fetched at the top of its own tile): the U-Net launches
+  // one or two 16x16 tiles per workgroup and the ACDC step was 3.43-3.44 vs 3.41-3.43 ms with the prefetch (tools/sessions/r04_s23.sh)
+  constexpr bool PRE = KD == 3;
+  constexpr int NPRE = (TL::HV + 255) / 256;
+  float pre[NPRE];
+  auto fetch = [&](int tile) __attribute__((always_inline)) {
+    int n, d0, h0, w0;
+    tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i) {
+      const int q = threadIdx.x + i * 256;
+      const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
+      const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
+      float v = 0.f;
+      if (q < TL::HV && (unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
+        v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
+      pre[i] = v;
+    }
+  };
+  if (PRE && t_begin < t_end) fetch(t_begin);
   for (int tile = t_begin; tile < t_end; ++tile) {
     int n, d0, h0, w0;
     tile_origin(cd, tile, TD, TH, TW, n, d0, h0, w0);
     if (tile > t_begin) __syncthreads();                  // every wave is done with the previous tile's halo
-    for (int q = threadIdx.x; q < TL::HV; q += 256) {
-      const int hw = q % TL::HW, hh = (q / TL::HW) % TL::HH, hd = q / (TL::HW * TL::HH);
-      const int d = d0 - TL::PD + hd, h = h0 - 1 + hh, wq = w0 - 1 + hw;
-      float v = 0.f;
-      if ((unsigned)d < (unsigned)cd.D && (unsigned)h < (unsigned)cd.H && (unsigned)wq < (unsigned)cd.W)
-        v = X[(((long long)n * cd.D + d) * cd.H + h) * cd.W + wq];
-      Xs[q] = v;
-    }
+    if (!PRE) fetch(tile);
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+      if (threadIdx.x + i * 256 < TL::HV) Xs[threadIdx.x + i * 256] = pre[i];
     __syncthreads();
+    if (PRE && tile + 1 < t_end) fetch(tile + 1);
     const bool full = d0 + TD <= cd.D && h0 + TH <= cd.H && w0 + TW <= cd.W;   // uniform
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
