@@ -4,7 +4,7 @@
 #   tools/collect_evidence.sh r03_t1
 tag=${1:-evidence}; out=$PWD/gpurun_out; mkdir -p $out
 ( time python -m pytest tests -m gpu -q -rP ) > $out/${tag}_pytest_gpu_full.txt 2>&1
-{ tail -3 $out/${tag}_pytest_gpu_full.txt | head -1; grep -E "full-size step|batch-8 step|traj5f step|la_traj5f|pancreas full|acdc full|flips|worst grad" $out/${tag}_pytest_gpu_full.txt | cut -c1-300; } > $out/${tag}_pytest_gpu.txt
+{ grep -E "^[0-9]+ (passed|failed)|^FAILED|^ERROR" $out/${tag}_pytest_gpu_full.txt | tail -5; grep -E "full-size step|batch-8 step|traj5f step|la_traj5f|pancreas full|acdc full|flips|worst grad" $out/${tag}_pytest_gpu_full.txt | cut -c1-300; } > $out/${tag}_pytest_gpu.txt
 python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
 python bench.py --workload acdc > $out/${tag}_bench_acdc.json 2>> $out/${tag}_bench.err
 python bench.py --workload pancreas > $out/${tag}_bench_pancreas.json 2>> $out/${tag}_bench.err
