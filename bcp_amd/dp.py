@@ -168,12 +168,20 @@ class DataParallel:
         self.backend = backend
         if backend == "rccl":
             from . import _lib
-            if _lib.product().call("bcp_comm_available"):
-                self.abi = _RcclAbi(self.world, self.rank, self.local_rank)
-                return
-            # librccl.so cannot be dlopen()ed on this box (the same on every rank): torch.distributed's bundled RCCL instead
             import sys
-            print("[bcp_amd.dp] librccl.so not loadable through the C ABI -- falling back to torch.distributed 'nccl'", file=sys.stderr)
+            if _lib.product().call("bcp_comm_available"):
+                try:
+                    self.abi = _RcclAbi(self.world, self.rank, self.local_rank)
+                    return
+                except Exception as e:      # communicator construction is collective: what fails here (id exchange, ncclCommInitRank) fails
+                    # on every rank alike, and every rank takes the same way out.  Loud, not silent: the transport is named in bench.py's line
+                    if os.environ.get("BCP_DP_BACKEND") == "rccl":
+                        raise               # asked for by name: no substitute
+                    print(f"[bcp_amd.dp] rank {self.rank}: RCCL communicator through the C ABI failed ({type(e).__name__}: {e}) -- "
+                          "falling back to torch.distributed 'nccl' (the same RCCL, torch's process group)", file=sys.stderr, flush=True)
+            else:
+                # librccl.so cannot be dlopen()ed on this box (the same on every rank): torch.distributed's bundled RCCL instead
+                print("[bcp_amd.dp] librccl.so not loadable through the C ABI -- falling back to torch.distributed 'nccl'", file=sys.stderr)
             backend = self.backend = "nccl"
         import torch.distributed as dist
         if not dist.is_initialized():

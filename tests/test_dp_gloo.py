@@ -245,3 +245,28 @@ def test_rccl_unique_id_exchange(tmp_path, transport):
     for k in range(2):
         want = bytes([(17 * k + i) % 251 for i in range(128)])
         assert all(r[k] == want for r in res), f"communicator {k}: ids differ"
+
+
+def test_rccl_unique_id_exchange_under_torchrun(tmp_path):
+    """the same exchange inside a REAL `python -m torch.distributed.run` launch (the driver's command line for bench.py --gpus N): there
+    the env:// rendezvous is the elastic agent's store (TORCHELASTIC_USE_AGENT_STORE), not a TCPStore served by rank 0"""
+    import subprocess
+    script = tmp_path / "idx.py"
+    script.write_text(
+        "import os, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "from bcp_amd import dp\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "for k in range(2):\n"
+        "    want = bytes([(13 * k + i) % 251 for i in range(128)])\n"
+        "    assert dp._exchange_id(want if rank == 0 else None, world, rank) == want\n"
+        "print('ID_OK', rank, flush=True)\n")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.pop("BCP_DP_ID_DIR", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0 and r.stdout.count("ID_OK") == 2, (r.stdout[-2000:], r.stderr[-2000:])
