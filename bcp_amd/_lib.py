@@ -49,11 +49,11 @@ _SIGS = {
     "bcp_dice_prob_fwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, P, P]),
     "bcp_dice_prob_bwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, F, P, P]),
     "bcp_norm_workspace_bytes": (SZ, [I, L, I]),
-    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, I, P, L, P, P]),
-    "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, I, P, P, P]),
+    "bcp_norm_fwd": (I, [P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, F, P, P, P, P, I, P, L, P, P]),
+    "bcp_norm_bwd": (I, [P, P, I, L, I, P, I, P, L, P, F, P, F, P, P, I, P, P, I, P, P, P]),
     "bcp_norm_slabs_ok": (I, [I, L, I]),
-    "bcp_norm_fwd_slabs": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, P, P, P, P, P]),
-    "bcp_norm_bwd_slabs": (I, [P, P, I, L, P, I, L, I, P, I, P, L, P, F, P, P, I, P, P, P, P]),
+    "bcp_norm_fwd_slabs": (I, [P, I, L, P, P, I, L, I, P, P, P, P, F, F, I, P, L, P, F, P, F, P, P, P, P, P, P]),
+    "bcp_norm_bwd_slabs": (I, [P, P, I, L, P, I, L, I, P, I, P, L, P, F, P, F, P, P, I, P, P, P, P]),
     "bcp_conv3_fwd_nslabs": (I, [I, I, I, I, I, I, I]),
     "bcp_conv3_bwdstat_rows": (I, [I, I, I, I, I, I, I, I]),
     "bcp_conv3_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P, P, I, P, P]),
@@ -74,8 +74,8 @@ _SIGS = {
     "bcp_conv3_c1_stat_rows": (I, [I, I, I, I, I, I]),
     "bcp_conv3_c1_fwd_stats": (I, [P, P, P, P, I, I, I, I, I, P, I, P]),
     "bcp_conv3_c1_norm_workspace_bytes": (SZ, [I, I, I, I, I, I]),
-    "bcp_conv3_c1_norm_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P, P, F, F, I, P, F, P, P, P, P, P]),
-    "bcp_conv3_c1_norm_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P, F, P, P, I, P, P, P]),
+    "bcp_conv3_c1_norm_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P, P, F, F, I, P, F, P, F, P, P, P, P, P]),
+    "bcp_conv3_c1_norm_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P, F, P, F, P, P, I, P, P, P]),
     "bcp_conv3_c1_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_k2_pack_weight": (I, [P, P, I, I, I, P]),
     "bcp_k2_pack_desc": (I, [P, P, I, I, I, P]),

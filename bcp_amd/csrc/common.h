@@ -164,6 +164,23 @@ __device__ __forceinline__ float amax_read(const float* __restrict__ slots) {
   return m;
 }
 
+// ---- counter-hash Bernoulli keep bit of element i under a 64-bit seed (bcp_bernoulli / bcp_bernoulli_dev write exactly these bits as a
+// mask; round 4: the norm kernels can also evaluate them in place -- NormEpilogue::mask_seed -- so that an elementwise Dropout needs no
+// mask tensor and no launch of its own)
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ bool bern_keep(long long i, unsigned seed_lo, unsigned seed_hi, float p_keep) {
+  const unsigned h = mix32((unsigned)i ^ mix32(seed_lo + 0x9e3779b9u * (unsigned)(i >> 32)) ^ seed_hi);
+  return (float)(h >> 8) * (1.0f / 16777216.0f) < p_keep;
+}
+// keep bits of elements e .. e+3 as the four bytes a mask load would return
+__device__ __forceinline__ uchar4 bern_keep4(long long e, unsigned seed_lo, unsigned seed_hi, float p_keep) {
+  return make_uchar4(bern_keep(e, seed_lo, seed_hi, p_keep) ? 1 : 0, bern_keep(e + 1, seed_lo, seed_hi, p_keep) ? 1 : 0,
+                     bern_keep(e + 2, seed_lo, seed_hi, p_keep) ? 1 : 0, bern_keep(e + 3, seed_lo, seed_hi, p_keep) ? 1 : 0);
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -946,6 +946,8 @@ struct C1Norm {
   float elem_scale;
   int act, G;
   float* amax;                 // EPI 2, nullable: |max| slots of the activation written (round 4: the fp16 pre-scale of the conv that reads it)
+  const unsigned long long* mask_seed;   // nullable: evaluate the Dropout keep bits from this device seed instead of reading elem_mask
+  float p_keep;                          //   (bern_keep, common.h; see norm.hip NormEpilogue)
 };
 
 template <int KD, int TD, int TH, int TW, int EPI = 0>
@@ -973,6 +975,9 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
   if (bias) bv = ld4(bias + lg * 4);
   double s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};       // fused norm statistics of this lane's four channels (bcp_conv3_c1_fwd_stats)
   float amax_o = 0.f;                                      // EPI 2: max |a| of what this thread writes
+  unsigned mseed_lo = 0, mseed_hi = 0;
+  if (EPI >= 2 && nm.mask_seed) { const unsigned long long s_ = *nm.mask_seed; mseed_lo = (unsigned)s_; mseed_hi = (unsigned)(s_ >> 32); }
+  const bool has_mask = EPI >= 2 && (nm.elem_mask != nullptr || nm.mask_seed != nullptr);
   const int t_begin = blockIdx.x * tiles_per_block;
   int t_end = t_begin + tiles_per_block;
   if (t_end > n_tiles) t_end = n_tiles;
@@ -1031,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
       float4 dav = make_float4(0.f, 0.f, 0.f, 0.f);
       uchar4 m4 = make_uchar4(1, 1, 1, 1);
       if (EPI >= 3 && ok) dav = ld4(nm.da + e);              // (requested before the MFMAs: the round trip hides under them)
-      if (EPI >= 2 && nm.elem_mask && ok) m4 = *reinterpret_cast<const uchar4*>(nm.elem_mask + e);
+      if (has_mask && ok) m4 = nm.mask_seed ? bern_keep4(e, mseed_lo, mseed_hi, nm.p_keep) : *reinterpret_cast<const uchar4*>(nm.elem_mask + e);
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], Xs[vo + toff[ks]], acc, 0, 0, 0);
@@ -1052,11 +1057,11 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
             const float z = (yv[r] - mu[r]) * sc[r] + sh[r];
             if (EPI == 2) {
               o[r] = act_fwd(z, nm.act);
-              if (nm.elem_mask) o[r] *= ms[r];
+              if (has_mask) o[r] *= ms[r];
               const float t = fabsf(o[r]);
               amax_o = (t > amax_o || t != t) ? t : amax_o;
             } else {
-              const float cs = nm.elem_mask ? ms[r] : 1.f;
+              const float cs = has_mask ? ms[r] : 1.f;
               const float dz = dd[r] * cs * act_grad(z, nm.act);
               const float xh = (yv[r] - mu[r]) * rs[r];
               if (EPI == 3) { s1[r] += (double)dz; s2[r] += (double)dz * (double)xh; }
@@ -1786,8 +1791,8 @@ extern "C" size_t bcp_conv3_c1_norm_workspace_bytes(int N, int D, int H, int W, 
 
 extern "C" int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float* bias, int N, int D, int H, int W, int KD, int groups,
                                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                     int act, const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out,
-                                     float* amax_out_or_null, void* stream) {
+                                     int act, const uint8_t* elem_mask, float elem_scale, const unsigned long long* mask_seed, float mask_p_keep,
+                                     float* stats, void* workspace, float* out, float* amax_out_or_null, void* stream) {
   BCP_REQUIRE(x && w && stats && workspace && out && groups >= 1, "bcp_conv3_c1_norm_fwd: null pointer / bad groups");
   BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_norm_fwd: bad KD/D");
   BCP_REQUIRE(aligned16(out) && aligned16(stats) && (!bias || aligned16(bias)), "bcp_conv3_c1_norm_fwd: alignment");
@@ -1797,14 +1802,15 @@ extern "C" int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float
   BCP_REQUIRE(rows > 0, "bcp_conv3_c1_norm_fwd: the groups must be whole samples (N %% groups == 0)");
   norm_fwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, gamma, beta, running_mean, running_var, momentum, eps, stats, s,
                            amax_out_or_null);
-  const C1Norm nm{stats, nullptr, nullptr, elem_mask, elem_scale, act, groups, amax_out_or_null};
+  const C1Norm nm{stats, nullptr, nullptr, elem_mask, elem_scale, act, groups, amax_out_or_null, mask_seed, mask_p_keep};
   c1_fwd_impl(x, w, bias, out, N, D, H, W, KD, nullptr, groups, false, s, 2, &nm);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_norm_fwd");
   return BCP_OK;
 }
 
 extern "C" int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float* bias, const float* da, int N, int D, int H, int W, int KD,
-                                     int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale, float* dgamma,
+                                     int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale,
+                                     const unsigned long long* mask_seed, float mask_p_keep, float* dgamma,
                                      float* dbeta, int accumulate, void* workspace, float* dy, void* stream) {
   BCP_REQUIRE(x && w && da && stats && workspace && dy && groups >= 1, "bcp_conv3_c1_norm_bwd: null pointer / bad groups");
   BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_norm_bwd: bad KD/D");
@@ -1815,7 +1821,7 @@ extern "C" int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float
   const int rows0 = bcp_conv3_c1_stat_rows(N, D, H, W, KD, groups);
   BCP_REQUIRE(rows0 > 0, "bcp_conv3_c1_norm_bwd: the groups must be whole samples (N %% groups == 0)");
   float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)groups * rows0 * 16 * 2);
-  C1Norm nm{stats, da, c1c2raw, elem_mask, elem_scale, act, groups, nullptr};
+  C1Norm nm{stats, da, c1c2raw, elem_mask, elem_scale, act, groups, nullptr, mask_seed, mask_p_keep};
   const int rows = c1_fwd_impl(x, w, bias, nullptr, N, D, H, W, KD, partial, groups, false, s, 3, &nm);
   norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s);
   c1_fwd_impl(x, w, bias, dy, N, D, H, W, KD, nullptr, groups, false, s, 4, &nm);

@@ -181,10 +181,6 @@ __global__ __launch_bounds__(256) void k_axpy(float* __restrict__ y, const float
 }
 
 // Counter-hash Bernoulli keep-masks for throughput runs (parity runs inject masks instead).
-__device__ __forceinline__ unsigned mix32(unsigned x) {
-  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
-  return x;
-}
 // seed_dev != nullptr: the seed lives in device memory (a launch captured in a HIP graph keeps its arguments; the seed still changes
 // every pass -- bcp_store_u64 writes it ahead of the graph launch)
 __global__ __launch_bounds__(256) void k_bernoulli_f32(float* __restrict__ out, long long n, float p_keep, float keep_value,
@@ -192,9 +188,7 @@ __global__ __launch_bounds__(256) void k_bernoulli_f32(float* __restrict__ out, 
   if (seed_dev) { const unsigned long long s = *seed_dev; seed_lo = (unsigned)s; seed_hi = (unsigned)(s >> 32); }
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const unsigned h = mix32((unsigned)i ^ mix32(seed_lo + 0x9e3779b9u * (unsigned)(i >> 32)) ^ seed_hi);
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    out[i] = (u < p_keep) ? keep_value : 0.f;
+    out[i] = bern_keep(i, seed_lo, seed_hi, p_keep) ? keep_value : 0.f;
   }
 }
 __global__ __launch_bounds__(256) void k_bernoulli_u8(uint8_t* __restrict__ out, long long n, float p_keep,
@@ -202,9 +196,7 @@ __global__ __launch_bounds__(256) void k_bernoulli_u8(uint8_t* __restrict__ out,
   if (seed_dev) { const unsigned long long s = *seed_dev; seed_lo = (unsigned)s; seed_hi = (unsigned)(s >> 32); }
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const unsigned h = mix32((unsigned)i ^ mix32(seed_lo + 0x9e3779b9u * (unsigned)(i >> 32)) ^ seed_hi);
-    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
-    out[i] = (u < p_keep) ? 1 : 0;
+    out[i] = bern_keep(i, seed_lo, seed_hi, p_keep) ? 1 : 0;
   }
 }
 

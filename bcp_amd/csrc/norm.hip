@@ -23,7 +23,15 @@ struct NormEpilogue {
   float elem_scale;            // 1/(1-p) for elem_mask
   long long rows_per_sample;   // spatial size (rows per n) for chan_scale indexing
   int act;
+  const unsigned long long* mask_seed;   // nullable (round 4): device seed of an elementwise Dropout whose keep bits are EVALUATED here
+  float p_keep;                          //   (bern_keep, common.h: the bits bcp_bernoulli_dev would write) instead of read from elem_mask
 };
+// the four mask bytes of elements e .. e+3: loaded, or evaluated from the seed
+#define BCP_NORM_MASK_PROLOGUE(ep)                                                                                  \
+  unsigned mseed_lo = 0, mseed_hi = 0;                                                                              \
+  if ((ep).mask_seed) { const unsigned long long s_ = *(ep).mask_seed; mseed_lo = (unsigned)s_; mseed_hi = (unsigned)(s_ >> 32); } \
+  const bool has_mask = (ep).elem_mask != nullptr || (ep).mask_seed != nullptr;
+#define BCP_NORM_MASK4(ep, e) ((ep).mask_seed ? bern_keep4((e), mseed_lo, mseed_hi, (ep).p_keep) : *reinterpret_cast<const uchar4*>((ep).elem_mask + (e)))
 
 // ------------------------------------------------------------------ column reductions
 // MODE 0: (sum x, sum x^2) of y.   MODE 1: (sum dz, sum dz*xhat) for the backward pass.
@@ -46,6 +54,7 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
                                                      NormEpilogue ep, long long seg_rows, int spg /* segments per group */, int C,
                                                      double* __restrict__ partial /* [G][spg * gridDim.x][C][2] */, SlabSrc sl) {
   constexpr int U = 4;
+  BCP_NORM_MASK_PROLOGUE(ep)
   const int C4 = C >> 2;
   const int col = threadIdx.x % C4;        // float4 column
   const int slot = threadIdx.x / C4;       // row slot within a pass
@@ -79,7 +88,7 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
     } else {
       const float dz[4] = {d4.x, d4.y, d4.z, d4.w};
       float cs[4] = {csv[0], csv[1], csv[2], csv[3]};
-      if (ep.elem_mask) {
+      if (has_mask) {
         cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
         cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
       }
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
           else {
             d4[u] = a[u];
             v[u] = ld4(y + e);
-            if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + e);
+            if (has_mask) m4[u] = BCP_NORM_MASK4(ep, e);
           }
         }
       } else {
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
           v[u] = ld4(y + e);
           if (MODE == 1) {
             d4[u] = ld4(da + e);
-            if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + e);
+            if (has_mask) m4[u] = BCP_NORM_MASK4(ep, e);
           }
         }
       }
@@ -156,7 +165,7 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
       else v = ld4(y + e);
       if (MODE == 1) {
         d4 = SL ? slab_sum(e) : ld4(da + e);
-        if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + e);
+        if (has_mask) m4 = BCP_NORM_MASK4(ep, e);
       }
       accum(v, d4, m4);
     }
@@ -307,6 +316,7 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
                                                     long long ldo4 /* row stride of out in float4: C / 4, or wider when out is the first C
                                                                       channels of a concat buffer (bcp_norm_fwd out_ld) */) {
   constexpr int U = 4;
+  BCP_NORM_MASK_PROLOGUE(ep)
   float amax = 0.f;            // max |a| of what this thread writes (round 4: the fp16 pre-scale of the conv that reads a, conv3_defs.h)
   if (blockIdx.x == 0 && blockIdx.y == 0 && running_mean) update_running(mean, var_unb, G, C, running_mean, running_var, momentum);
   const int C4 = C >> 2;
@@ -323,7 +333,7 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
     float o[4] = {act_fwd((v.x - mu.x) * sc.x + sh.x, ep.act), act_fwd((v.y - mu.y) * sc.y + sh.y, ep.act),
                   act_fwd((v.z - mu.z) * sc.z + sh.z, ep.act), act_fwd((v.w - mu.w) * sc.w + sh.w, ep.act)};
     if (ep.chan_scale) { o[0] *= cs.x; o[1] *= cs.y; o[2] *= cs.z; o[3] *= cs.w; }
-    if (ep.elem_mask) {
+    if (has_mask) {
       o[0] *= m4.x ? ep.elem_scale : 0.f; o[1] *= m4.y ? ep.elem_scale : 0.f;
       o[2] *= m4.z ? ep.elem_scale : 0.f; o[3] *= m4.w ? ep.elem_scale : 0.f;
     }
@@ -344,7 +354,7 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
       const long long i = base + REV(j + u * stride);
       v[u] = ld4(y + i * 4);
       if (residual) r4[u] = ld4(residual + i * 4);
-      if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+      if (has_mask) m4[u] = BCP_NORM_MASK4(ep, i * 4);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) one(base + REV(j + u * stride), v[u], r4[u], m4[u]);
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(256) void k_norm_apply(const float* __restrict__ y,
     uchar4 m4 = make_uchar4(0, 0, 0, 0);
     const float4 v = ld4(y + i * 4);
     if (residual) r4 = ld4(residual + i * 4);
-    if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+    if (has_mask) m4 = BCP_NORM_MASK4(ep, i * 4);
     one(i, v, r4, m4);
   }
   if (amax_out) block_amax_publish(amax, amax_out);
@@ -371,6 +381,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
                                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
                                                         float* __restrict__ amax_out) {
   constexpr int U = 4;
+  BCP_NORM_MASK_PROLOGUE(ep)
   float amax = 0.f;            // max |dy| of what this thread writes: the fp16 pre-scale of the dgrad / weight-gradient kernels that read dy
   if (blockIdx.x == 0 && blockIdx.y == 0 && dgamma) {   // parameter gradients: sum the groups in order (deterministic)
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
   const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
   auto one = [&](long long i, const float4& v, const float4& d4, const uchar4& m4) {
     float cs[4] = {csl.x, csl.y, csl.z, csl.w};
-    if (ep.elem_mask) {
+    if (has_mask) {
       cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
       cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
     }
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
       const long long i = base + REV(j + u * stride);
       v[u] = ld4(y + i * 4);
       d4[u] = ld4(da + i * 4);
-      if (ep.elem_mask) m4[u] = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+      if (has_mask) m4[u] = BCP_NORM_MASK4(ep, i * 4);
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) one(base + REV(j + u * stride), v[u], d4[u], m4[u]);
@@ -430,7 +441,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
     const long long i = base + REV(j);
     uchar4 m4 = make_uchar4(0, 0, 0, 0);
     const float4 v = ld4(y + i * 4), d4 = ld4(da + i * 4);
-    if (ep.elem_mask) m4 = *reinterpret_cast<const uchar4*>(ep.elem_mask + i * 4);
+    if (has_mask) m4 = BCP_NORM_MASK4(ep, i * 4);
     one(i, v, d4, m4);
   }
   if (amax_out) block_amax_publish(amax, amax_out);
@@ -527,6 +538,7 @@ static int check_norm_args(const char* fn, int G, long long rows_per_group, int 
 extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, int act,
                             const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale,
+                            const unsigned long long* mask_seed /* nullable: evaluate the Dropout keep bits from this device seed */, float mask_p_keep,
                             const float* residual, float* stats /* [5][G][C]: mean, rstd, scale, beta, unbiased var */, void* workspace,
                             const double* partial_in, int nb_in, float* out, long long out_ld /* row stride of out in floats; 0: C */,
                             float* amax_out /* nullable: max |out| (fp16 pre-scale of the conv that reads it) */, void* stream) {
@@ -537,7 +549,7 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   BCP_REQUIRE(aligned16(y) && (!out || aligned16(out)) && aligned16(stats), "bcp_norm_fwd: alignment");
   BCP_REQUIRE(out || !residual, "bcp_norm_fwd: statistics-only mode (out = NULL) takes no residual");
   hipStream_t s = (hipStream_t)stream;
-  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act, mask_seed, mask_p_keep};
   BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
               "bcp_norm_fwd: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
   const Segs sg = make_segs(G, rows_per_group, C, ep);
@@ -565,12 +577,12 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
 
 extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats,
                             int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
-                            float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace,
+                            float elem_scale, const unsigned long long* mask_seed, float mask_p_keep, float* dgamma, float* dbeta, int accumulate, void* workspace,
                             const double* partial_in, int nb_in, float* dy, float* amax_out /* nullable: max |dy| */, void* stream) {
   if (int rc = check_norm_args("bcp_norm_bwd", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(y && da && stats && workspace && dy, "bcp_norm_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act, mask_seed, mask_p_keep};
   BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
               "bcp_norm_bwd: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
   const Segs sg = make_segs(G, rows_per_group, C, ep);
@@ -582,7 +594,7 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
   if (partial_in) {   // (sum dz, sum dz * xhat) partials handed in by the caller (no kernel of the library produces them any more)
-    BCP_REQUIRE(!chan_scale && !elem_mask && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
+    BCP_REQUIRE(!chan_scale && !elem_mask && !mask_seed && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
     hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw, amax_out);
   } else {
@@ -606,7 +618,8 @@ extern "C" int bcp_norm_slabs_ok(int G, long long rows_per_group, int C) {
 extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_stride, const float* bias, float* ysum, int G,
                                   long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
-                                  const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace, float* out,
+                                  const uint8_t* elem_mask, float elem_scale, const unsigned long long* mask_seed, float mask_p_keep,
+                                  const float* residual, float* stats, void* workspace, float* out,
                                   float* amax_out, void* stream) {
   if (int rc = check_norm_args("bcp_norm_fwd_slabs", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(rows_per_group <= 4096, "bcp_norm_fwd_slabs: rows_per_group=%lld > 4096 (check bcp_norm_slabs_ok)", rows_per_group);
@@ -615,7 +628,7 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
               "bcp_norm_fwd_slabs: alignment");
   BCP_REQUIRE(out || !residual, "bcp_norm_fwd_slabs: statistics-only mode (out = NULL) takes no residual");
   hipStream_t s = (hipStream_t)stream;
-  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act, mask_seed, mask_p_keep};
   BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
               "bcp_norm_fwd_slabs: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
   const Segs sg = make_segs(G, rows_per_group, C, ep, norm_blocks_slabs(rows_per_group, C, G));
@@ -639,7 +652,8 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
 
 extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum, int G,
                                   long long rows_per_group, int C, const float* stats, int act, const float* chan_scale,
-                                  long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta,
+                                  long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, const unsigned long long* mask_seed,
+                                  float mask_p_keep, float* dgamma, float* dbeta,
                                   int accumulate, void* workspace, float* dy, float* amax_out, void* stream) {
   if (int rc = check_norm_args("bcp_norm_bwd_slabs", G, rows_per_group, C)) return rc;
   BCP_REQUIRE(rows_per_group <= 4096, "bcp_norm_bwd_slabs: rows_per_group=%lld > 4096 (check bcp_norm_slabs_ok)", rows_per_group);
@@ -647,7 +661,7 @@ extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nsl
   BCP_REQUIRE(aligned16(y) && aligned16(da_slabs) && aligned16(dy) && aligned16(da_sum) && (slab_stride & 3) == 0, "bcp_norm_bwd_slabs: alignment");
   BCP_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bcp_norm_bwd_slabs: dgamma and dbeta come together");
   hipStream_t s = (hipStream_t)stream;
-  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act};
+  NormEpilogue ep{chan_scale, elem_mask, elem_scale, rows_per_sample > 0 ? rows_per_sample : rows_per_group, act, mask_seed, mask_p_keep};
   BCP_REQUIRE(!chan_scale || (rows_per_group % ep.rows_per_sample == 0 && rows_per_group / ep.rows_per_sample <= kMaxSamplesPerGroup),
               "bcp_norm_bwd_slabs: a group must hold 1..%d whole samples", kMaxSamplesPerGroup);
   const Segs sg = make_segs(G, rows_per_group, C, ep, norm_blocks_slabs(rows_per_group, C, G));

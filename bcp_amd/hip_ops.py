@@ -42,6 +42,17 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class SeedMask:
+    """An elementwise-Dropout keep mask that exists only as its 64-bit seed in device memory (round 4): the norm kernels evaluate the keep
+    bit of element i from the seed -- the bit `Ops.bernoulli` would have written at mask[i] -- in the forward AND the backward pass of the
+    layer, so there is no mask tensor and no launch for it.  Pass it wherever a wrapper takes `elem_mask=`.  `ptr`: device address of the
+    seed (a launch plan's seed slot, refilled before every replay, or a one-element tensor held here)."""
+    __slots__ = ("ptr", "p_keep", "shape", "_hold")
+
+    def __init__(self, ptr, p_keep, shape, hold=None):
+        self.ptr, self.p_keep, self.shape, self._hold = int(ptr), float(p_keep), tuple(shape), hold
+
+
 class Ops:
     """All kernels, bound to one library handle.  `Ops.product()` is the only constructor product
     code uses; tests build `Ops(Binding(emu_path), allow_cpu=True)` to run the same wrappers on the
@@ -109,6 +120,29 @@ class Ops:
         if t.is_cuda:
             return torch._C._cuda_getCurrentRawStream(t.device.index)
         return None
+
+    @staticmethod
+    def _mask_split(elem_mask):
+        """elem_mask= of the norm wrappers: a uint8 tensor, a SeedMask or None -> (tensor | None, seed address | None, p_keep)"""
+        if isinstance(elem_mask, SeedMask):
+            return None, elem_mask.ptr, elem_mask.p_keep
+        return elem_mask, None, 0.0
+
+    def seed_mask(self, shape, p_keep, seed, like):
+        """the Dropout keep mask of a tensor of `shape` under `seed`, as a SeedMask (see there).  Inside a recorded pass the seed lives in
+        the plan's device table (one more slot; refilled before every replay like the bernoulli launches' seeds)"""
+        pl = self._rec_plan
+        if pl is not None:
+            slot = pl.seed_slot(like.device)
+            fn, _ = self.b._fns["bcp_store_u64"]
+            arr = (C.c_ulonglong * 1)(int(seed) & 0xFFFFFFFFFFFFFFFF)
+            rc = fn(slot, 1, arr, self.stream(like))
+            if rc:
+                raise _lib.BcpError(f"bcp_store_u64 failed ({rc}): {self.b.last_error()}")
+            return SeedMask(slot, p_keep, shape)
+        t = torch.empty(1, dtype=torch.int64, device=like.device)
+        self.store_u64(t, [seed], like)
+        return SeedMask(t.data_ptr(), p_keep, shape, hold=t)
 
     def _ws_bytes(self, fn, *args):
         """size / shape queries: one ctypes round trip per distinct (options epoch, shape).  Several answers depend on the library's
@@ -261,6 +295,7 @@ class Ops:
         """y [N,D,H,W,C] -> (a, stats[5,G,C]).  G = 1: BatchNorm; G = N (no affine): InstanceNorm; G > 1 with affine:
         G consecutive BatchNorm calls in one launch.  stats_only: statistics (and the running-statistics update) without the
         apply pass -- the consumer normalises on its way in (pw16_fwd_norm); returns (None, stats)."""
+        elem_mask, em_seed, em_keep = self._mask_split(elem_mask)
         self._chk(y, gamma, beta, rmean, rvar, chan_scale, elem_mask, residual)
         N = y.shape[0]
         Cc = y.shape[-1]
@@ -272,15 +307,15 @@ class Ops:
         stats = torch.empty((5, G, Cc), dtype=torch.float32, device=y.device)
         out_ld = 0
         if stats_only:
-            assert out is None and residual is None and elem_mask is None
+            assert out is None and residual is None and elem_mask is None and em_seed is None
         elif out is None:
             out = torch.empty_like(y)
         else:
             out_ld = self._chk_rows(out)        # out may be the leading channels of a wider buffer (channel_slab: the U-Net's concat)
         amax = self._amax_slot(out)
         self.b.call("bcp_norm_fwd", _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum), float(eps), act,
-                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws), _p(partial), int(nb), _p(out),
-                    out_ld, _p(amax), self.stream(y))
+                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), em_seed, em_keep, _p(residual), _p(stats), _p(ws), _p(partial), int(nb),
+                    _p(out), out_ld, _p(amax), self.stream(y))
         return out, stats
 
     def norm_eval(self, y, gamma, beta, rmean, rvar, act, residual=None, eps=1e-5, out=None):
@@ -337,6 +372,7 @@ class Ops:
 
     def norm_bwd(self, y, da, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
                  elem_scale=1.0, out=None, partial=None, nb=0):
+        elem_mask, em_seed, em_keep = self._mask_split(elem_mask)
         self._chk(y, da, stats, dgamma, dbeta, chan_scale, elem_mask)
         N = y.shape[0]
         Cc = y.shape[-1]
@@ -348,7 +384,7 @@ class Ops:
         if out is None:
             out = torch.empty_like(y)
         self.b.call("bcp_norm_bwd", _p(y), _p(da), G, rpg, Cc, _p(stats), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale),
-                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(partial), int(nb), _p(out), _p(self._amax_slot(out)), self.stream(y))
+                    em_seed, em_keep, _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(partial), int(nb), _p(out), _p(self._amax_slot(out)), self.stream(y))
         return out
 
 
@@ -375,6 +411,7 @@ class Ops:
                        residual=None, momentum=0.1, eps=1e-5, stats_only=False):
         """src: raw conv slabs [nslab,N,D,H,W,C] (+ the conv bias) -> (a, stats, y): the statistics pass sums the slabs (+ bias) on its way
         in and writes y once; finalize and apply as bcp_norm_fwd"""
+        elem_mask, em_seed, em_keep = self._mask_split(elem_mask)
         self._chk(src, bias, gamma, beta, rmean, rvar, chan_scale, elem_mask, residual)
         shape = tuple(src.shape[1:]) if src.dim() == 6 else tuple(src.shape)
         N, Cc = shape[0], shape[-1]
@@ -389,13 +426,14 @@ class Ops:
         ws = self.workspace("norm", self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc), src)
         amax = self._amax_slot(out)
         self.b.call("bcp_norm_fwd_slabs", _p(src), int(nslab), n, _p(bias), _p(y), G, rpg, Cc, _p(gamma), _p(beta), _p(rmean), _p(rvar),
-                    float(momentum), float(eps), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(residual), _p(stats), _p(ws),
-                    _p(out), _p(amax), self.stream(src))
+                    float(momentum), float(eps), act, _p(chan_scale), rps, _p(elem_mask), float(elem_scale), em_seed, em_keep, _p(residual),
+                    _p(stats), _p(ws), _p(out), _p(amax), self.stream(src))
         return out, stats, y
 
     def norm_bwd_slabs(self, y, da_src, nslab, G, stats, act, dgamma=None, dbeta=None, accumulate=False, chan_scale=None, elem_mask=None,
                        elem_scale=1.0):
         """da_src: the dgrad's raw slabs [nslab,N,D,H,W,C] -> (dy, da): the backward-statistics pass sums the slabs and writes da once"""
+        elem_mask, em_seed, em_keep = self._mask_split(elem_mask)
         self._chk(y, da_src, stats, dgamma, dbeta, chan_scale, elem_mask)
         N, Cc = y.shape[0], y.shape[-1]
         rows = y.numel() // Cc
@@ -404,8 +442,8 @@ class Ops:
         da = torch.empty_like(y)
         ws = self.workspace("norm", self._ws_bytes("bcp_norm_workspace_bytes", G, rpg, Cc), y)
         self.b.call("bcp_norm_bwd_slabs", _p(y), _p(da_src), int(nslab), y.numel(), _p(da), G, rpg, Cc, _p(stats), act,
-                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy),
-                    _p(self._amax_slot(dy)), self.stream(y))
+                    _p(chan_scale), rps, _p(elem_mask), float(elem_scale), em_seed, em_keep, _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws),
+                    _p(dy), _p(self._amax_slot(dy)), self.stream(y))
         return dy, da
 
     # ------------------------------------------------------------------ 3x3(x3) conv
@@ -509,6 +547,7 @@ class Ops:
 
     def conv3_c1_norm_fwd(self, x, w, bias, KD, G, gamma, beta, rmean, rvar, act, elem_mask=None, elem_scale=1.0, momentum=0.1, eps=1e-5):
         """first layer + norm + activation with recompute (bcp_conv3_c1_norm_fwd): -> (a, stats); y is never materialised"""
+        elem_mask, em_seed, em_keep = self._mask_split(elem_mask)
         self._chk(x, w, bias, gamma, beta, rmean, rvar, elem_mask)
         N, D, H, W, Cin = x.shape
         assert Cin == 1 and w.shape[0] == 16
@@ -517,18 +556,20 @@ class Ops:
         stats = torch.empty((5, G, 16), dtype=torch.float32, device=x.device)
         out = torch.empty((N, D, H, W, 16), dtype=torch.float32, device=x.device)
         self.b.call("bcp_conv3_c1_norm_fwd", _p(x), _p(w), _p(bias), N, D, H, W, KD, G, _p(gamma), _p(beta), _p(rmean), _p(rvar), float(momentum),
-                    float(eps), act, _p(elem_mask), float(elem_scale), _p(stats), _p(ws), _p(out), _p(self._amax_slot(out)), self.stream(x))
+                    float(eps), act, _p(elem_mask), float(elem_scale), em_seed, em_keep, _p(stats), _p(ws), _p(out), _p(self._amax_slot(out)),
+                    self.stream(x))
         return out, stats
 
     def conv3_c1_norm_bwd(self, x, w, bias, KD, G, stats, da, act, dgamma=None, dbeta=None, accumulate=False, elem_mask=None, elem_scale=1.0):
         """backward of conv3_c1_norm_fwd's norm: y recomputed from x, -> dy (the input of conv3_c1_wgrad)"""
+        elem_mask, em_seed, em_keep = self._mask_split(elem_mask)
         self._chk(x, w, bias, stats, da, dgamma, dbeta, elem_mask)
         N, D, H, W, _ = x.shape
         nbytes = self._ws_bytes("bcp_conv3_c1_norm_workspace_bytes", N, D, H, W, KD, G)
         ws = self.workspace("c1norm", nbytes, x)
         dy = torch.empty((N, D, H, W, 16), dtype=torch.float32, device=x.device)
         self.b.call("bcp_conv3_c1_norm_bwd", _p(x), _p(w), _p(bias), _p(da), N, D, H, W, KD, G, _p(stats), act, _p(elem_mask), float(elem_scale),
-                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy), self.stream(x))
+                    em_seed, em_keep, _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy), self.stream(x))
         return dy
 
     def conv3_c1_wgrad(self, x, dy, dw, KD, accumulate=False):

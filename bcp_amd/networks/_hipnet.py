@@ -543,7 +543,7 @@ class HipNet(nn.Module):
         # (every switch that changes the launch list is part of the key: a toggled switch must never replay the other sequence)
         key = ("f", tuple(xcl.shape), getattr(self, "_groups", 1), bool(save), bool(getattr(self, "_turnoff_drop", False)), self.ops.stream(xcl),
                bool(getattr(self, "fuse_head", False)), bool(getattr(self, "fuse_c1", False)), bool(self.overlap_wgrad),
-               bool(getattr(self, "_keep_saved", False)), bool(getattr(self, "_want_feat", False)), bool(getattr(self, "skip_in_concat", False)))
+               bool(getattr(self, "_keep_saved", False)), bool(getattr(self, "_want_feat", False)), bool(getattr(self, "skip_in_concat", False)), bool(getattr(self, "inline_dropout", False)))
         pl = plans.get(key)
         if pl is not None and pl.busy:
             # the plan's static activations belong to a forward whose backward has not run yet (the unfused loop calls the student

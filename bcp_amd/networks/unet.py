@@ -38,6 +38,7 @@ class _CB:
 class UNet_2d(HipNet):
     fuse_c1 = True       # first layer: conv + norm + LeakyReLU (+ dropout) with recompute (networks/VNet.py)
     skip_in_concat = True   # encoder outputs are written into the decoder's concat buffers (no torch.cat copy; pool backward joins the skip gradient)
+    inline_dropout = True   # nn.Dropout keep bits evaluated inside the norm kernels from a device seed (hip_ops.SeedMask): no mask tensors
     def __init__(self, in_chns, class_num):
         super().__init__()
         assert in_chns == 1, "the ACDC hot path is single-channel"
@@ -98,12 +99,17 @@ class UNet_2d(HipNet):
         return out.permute(0, 4, 1, 2, 3).squeeze(2)   # logical [N,4,H,W]
 
     # ------------------------------------------------------------------ pieces
-    def _elem_mask(self, cb, shape, dev):
+    def _elem_mask(self, cb, shape, like):
+        """the block's nn.Dropout keep mask: injected (parity runs: a uint8 tensor), or drawn -- as a SeedMask the norm kernels evaluate in
+        place (inline_dropout, round 4: no mask tensor, no launch), else as a uint8 tensor from bcp_bernoulli with the SAME bits"""
+        dev = like.device
         if cb.p <= 0.0 or not self.training:
             return None
         if self.drop_masks is not None:
             m = self.drop_masks[cb.dkey]                       # logical [N,C,H,W] keep mask
             return m.to(dev).permute(0, 2, 3, 1).unsqueeze(1).contiguous().to(torch.uint8)
+        if self.inline_dropout:
+            return self.ops.seed_mask(shape, 1.0 - cb.p, self.next_seed(), like)
         m = torch.empty(shape, dtype=torch.uint8, device=dev)
         return self.ops.bernoulli(m, 1.0 - cb.p, 1.0, self.next_seed())
 
@@ -127,7 +133,7 @@ class UNet_2d(HipNet):
         # on its way in (networks/VNet.py, bcp_norm_fwd_slabs) -- no slab-sum launch
         slabs_ok = ops.norm_slabs_ok(G, N * Hh * Ww // G, cb.cout)
         es = 1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0
-        em = self._elem_mask(cb, oshape, h.device)
+        em = self._elem_mask(cb, oshape, h)
         b1, b2 = cb.b1, cb.b2
         part1, nb1 = None, 0
         src, nsl, bsrc = None, 1, None

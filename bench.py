@@ -524,6 +524,10 @@ def main():
             from bcp_amd import train_step as _ts2
             _ts2.STEP_TOTAL = bool(int(v))
             continue
+        if k == "inline_dropout":     # host-side switch (networks/unet.py): Dropout keep bits evaluated in the norm kernels (no mask tensors)
+            from bcp_amd.networks.unet import UNet_2d as _un3
+            _un3.inline_dropout = bool(int(v))
+            continue
         if k == "skip_in_concat":     # host-side switch (networks/unet.py): encoder outputs written into the decoder's concat buffers
             from bcp_amd.networks.unet import UNet_2d as _un2
             _un2.skip_in_concat = bool(int(v))

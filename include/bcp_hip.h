@@ -112,18 +112,24 @@ int bcp_dice_prob_bwd(const float* probs, long long cstride, long long vstride, 
  *      G = 1: BatchNorm over all rows; G = N without gamma/beta: InstanceNorm; G > 1 WITH gamma/beta/running stats: "grouped
  *      BatchNorm" = G consecutive BatchNorm calls in one launch (statistics per group, running stats updated group after
  *      group in order) -- how the two student / teacher batches of a BCP step are normalised separately yet launched together.
- *      stats = float[5][G][C] {mean, rstd, scale = gamma*rstd, beta, unbiased var}; z = (y - mean)*scale + beta. */
+ *      stats = float[5][G][C] {mean, rstd, scale = gamma*rstd, beta, unbiased var}; z = (y - mean)*scale + beta.
+ *      Elementwise Dropout (nn.Dropout, unet.py:23): either elem_mask (uint8 keep bits, [rows][C]) or -- round 4 -- mask_seed_or_null +
+ *      mask_p_keep: the keep bit of element i is EVALUATED in the kernels from the 64-bit seed in device memory, exactly the bit
+ *      bcp_bernoulli_dev(out, n, p_keep, ., as_u8 = 1, seed_dev) would write at out[i]; forward and backward of a layer get the same seed
+ *      and no mask tensor exists.  Both NULL: no elementwise dropout.  elem_scale = 1 / (1 - p) either way. */
 size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C);
 int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
-                 const uint8_t* elem_mask, float elem_scale, const float* residual, float* stats, void* workspace,
-                 const double* partial_in_or_null /* [G][nb_in][C][2] from bcp_conv3_fwd_stats */, int nb_in, float* out,
+                 const uint8_t* elem_mask, float elem_scale,
+                 const unsigned long long* mask_seed_or_null /* DEVICE u64 */, float mask_p_keep, const float* residual, float* stats,
+                 void* workspace, const double* partial_in_or_null /* [G][nb_in][C][2] from bcp_conv3_fwd_stats */, int nb_in, float* out,
                  long long out_ld /* row stride of out in floats, 0 = C.  Wider: out is the first C channels of a concat buffer
                                      (networks/unet.py:56 torch.cat([skip, up]): the skip is WRITTEN there, never copied) */,
                  float* amax_out_or_null /* device float <- max |out| (round 4: the x_amax of the conv that reads out, see bcp_conv3_fwd) */,
                  void* stream);
 int bcp_norm_bwd(const float* y, const float* da, int G, long long rows_per_group, int C, const float* stats, int act,
-                 const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale, float* dgamma,
+                 const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask, float elem_scale,
+                 const unsigned long long* mask_seed_or_null, float mask_p_keep, float* dgamma,
                  float* dbeta, int accumulate, void* workspace, const double* partial_in_or_null, int nb_in, float* dy,
                  float* amax_out_or_null /* device float <- max |dy|: the x_amax of the dgrad conv and of the weight gradient that read dy */,
                  void* stream);
@@ -145,12 +151,12 @@ int bcp_norm_slabs_ok(int G, long long rows_per_group, int C);
 int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_stride, const float* bias_or_null, float* ysum, int G,
                        long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean, float* running_var,
                        float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample, const uint8_t* elem_mask,
-                       float elem_scale, const float* residual, float* stats, void* workspace, float* out_or_null, float* amax_out_or_null,
-                       void* stream);
+                       float elem_scale, const unsigned long long* mask_seed_or_null, float mask_p_keep, const float* residual, float* stats,
+                       void* workspace, float* out_or_null, float* amax_out_or_null, void* stream);
 int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nslab, long long slab_stride, float* da_sum, int G,
                        long long rows_per_group, int C, const float* stats, int act, const float* chan_scale, long long rows_per_sample,
-                       const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy,
-                       float* amax_out_or_null, void* stream);
+                       const uint8_t* elem_mask, float elem_scale, const unsigned long long* mask_seed_or_null, float mask_p_keep,
+                       float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy, float* amax_out_or_null, void* stream);
 
 /* ---- 3x3x3 / 3x3 convolution, pad 1 (nn.Conv3d networks/VNet.py:17, nn.Conv2d networks/unet.py:19-25) on fp32 MFMA.
  *      KD = 3 (3-D) or 1 (2-D, D = 1).  Weights are packed once per optimizer step from the torch layout
@@ -217,9 +223,11 @@ int bcp_conv3_c1_fwd_stats(const float* x, const float* w, const float* bias_or_
 size_t bcp_conv3_c1_norm_workspace_bytes(int N, int D, int H, int W, int KD, int groups);   /* 0: groups do not divide N */
 int bcp_conv3_c1_norm_fwd(const float* x, const float* w, const float* bias_or_null, int N, int D, int H, int W, int KD, int groups,
                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int act,
-                          const uint8_t* elem_mask, float elem_scale, float* stats, void* workspace, float* out, float* amax_out_or_null /* |max| slots of out, see bcp_norm_fwd */, void* stream);
+                          const uint8_t* elem_mask, float elem_scale, const unsigned long long* mask_seed_or_null, float mask_p_keep,
+                          float* stats, void* workspace, float* out, float* amax_out_or_null /* |max| slots of out, see bcp_norm_fwd */, void* stream);
 int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float* bias_or_null, const float* da, int N, int D, int H, int W, int KD,
-                          int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale, float* dgamma, float* dbeta,
+                          int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale,
+                          const unsigned long long* mask_seed_or_null, float mask_p_keep, float* dgamma, float* dbeta,
                           int accumulate, void* workspace, float* dy, void* stream);
 int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int KD, int accumulate, void* workspace,
                        void* stream);

@@ -1069,6 +1069,70 @@ def check_conv3_stats(ops, dev):
         close(a1, a2, rtol=1e-6, msg="norm from fused partials")
 
 
+def check_inline_dropout(ops, dev):
+    """round 4: an elementwise Dropout whose keep bits the norm kernels EVALUATE from a device seed (hip_ops.SeedMask; bcp_norm_fwd / _bwd,
+    the raw-slab pair, the fused first layer) == the same layer fed the uint8 mask bcp_bernoulli writes under that seed, bit for bit"""
+    rng = np.random.default_rng(91)
+    p = 0.3
+    es = 1.0 / (1.0 - p)
+    for k, (N, Cc, sp, G) in enumerate(((2, 32, (1, 12, 20), 2), (3, 16, (1, 9, 11), 1), (2, 64, (2, 6, 6), 1), (1, 16, (3, 40, 44), 1))):
+        seed = (0x9E3779B97F4A7C15 * (k + 3)) & 0xFFFFFFFFFFFFFFFF
+        y = to_cl(R(rng, N, Cc, *sp) * 1.4 + 0.2).to(dev)
+        da = to_cl(R(rng, N, Cc, *sp)).to(dev)
+        gam = torch.from_numpy(rng.uniform(0.5, 1.5, Cc).astype(np.float32)).to(dev)
+        bet = torch.from_numpy(rng.uniform(-0.3, 0.3, Cc).astype(np.float32)).to(dev)
+        m = ops.bernoulli(torch.empty(tuple(y.shape), dtype=torch.uint8, device=dev), 1.0 - p, 1.0, seed)
+        frac = float(m.float().mean())
+        assert abs(frac - (1.0 - p)) < 0.05, frac
+        sm = ops.seed_mask(tuple(y.shape), 1.0 - p, seed, y)
+        outs = []
+        for em in (m, sm):
+            rm, rv = torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)
+            a, st = ops.norm_fwd(y, G, gam, bet, rm, rv, H.ACT_LRELU, elem_mask=em, elem_scale=es)
+            dg, db = torch.zeros(Cc).to(dev), torch.zeros(Cc).to(dev)
+            dy = ops.norm_bwd(y, da, G, st, H.ACT_LRELU, dg, db, False, elem_mask=em, elem_scale=es)
+            outs.append((a, st, dy, dg, db))
+        for u, v, name in zip(outs[0], outs[1], ("a", "stats", "dy", "dgamma", "dbeta")):
+            assert torch.equal(u, v), f"inline dropout, norm pair C={Cc}: {name}"
+        assert float((outs[1][0] == 0).float().mean()) > 0.5 * p, "the seeded mask did not drop anything"
+        rows_pg = y.numel() // Cc // G
+        if ops.norm_slabs_ok(G, rows_pg, Cc):
+            slabs = torch.stack([y * 0.25, y * 0.75]).contiguous()
+            dslabs = torch.stack([da * 0.5, da * 0.5]).contiguous()
+            outs = []
+            for em in (m, sm):
+                rm, rv = torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)
+                a, st, ysum = ops.norm_fwd_slabs(slabs, 2, None, G, gam, bet, rm, rv, H.ACT_LRELU, elem_mask=em, elem_scale=es)
+                dg, db = torch.zeros(Cc).to(dev), torch.zeros(Cc).to(dev)
+                dy, dsum = ops.norm_bwd_slabs(ysum, dslabs, 2, G, st, H.ACT_LRELU, dg, db, False, elem_mask=em, elem_scale=es)
+                outs.append((a, st, dy, dg, db))
+            for u, v, name in zip(outs[0], outs[1], ("a", "stats", "dy", "dgamma", "dbeta")):
+                assert torch.equal(u, v), f"inline dropout, raw-slab pair C={Cc}: {name}"
+    # the fused first layer (2-D as the U-Net launches it, 3-D for the record)
+    for (N, sp, KD, G) in ((4, (1, 32, 32), 1, 2), (2, (4, 8, 16), 3, 1)):
+        x = to_cl(R(rng, N, 1, *sp)).to(dev)
+        w = (R(rng, 16, 1, *((3, 3, 3) if KD == 3 else (3, 3))) * 0.3).to(dev)
+        b = (R(rng, 16) * 0.1).to(dev)
+        if not ops.conv3_c1_norm_ok(tuple(x.shape), KD, G):
+            continue
+        shape = (N,) + sp + (16,)
+        da = to_cl(R(rng, N, 16, *sp)).to(dev)
+        gam = torch.from_numpy(rng.uniform(0.5, 1.5, 16).astype(np.float32)).to(dev)
+        bet = torch.from_numpy(rng.uniform(-0.3, 0.3, 16).astype(np.float32)).to(dev)
+        seed = 0xC0FFEE123456789 + KD
+        m = ops.bernoulli(torch.empty(shape, dtype=torch.uint8, device=dev), 1.0 - p, 1.0, seed)
+        sm = ops.seed_mask(shape, 1.0 - p, seed, x)
+        outs = []
+        for em in (m, sm):
+            rm, rv = torch.zeros(16).to(dev), torch.ones(16).to(dev)
+            a, st = ops.conv3_c1_norm_fwd(x, w, b, KD, G, gam, bet, rm, rv, H.ACT_LRELU, elem_mask=em, elem_scale=es)
+            dg, db = torch.zeros(16).to(dev), torch.zeros(16).to(dev)
+            dy = ops.conv3_c1_norm_bwd(x, w, b, KD, G, st, da, H.ACT_LRELU, dg, db, False, elem_mask=em, elem_scale=es)
+            outs.append((a, st, dy, dg, db))
+        for u, v, name in zip(outs[0], outs[1], ("a", "stats", "dy", "dgamma", "dbeta")):
+            assert torch.equal(u, v), f"inline dropout, fused first layer KD={KD}: {name}"
+
+
 def check_norm_slabs(ops, dev):
     """deep-level norm that takes the producing conv's raw split-K slabs (bcp_conv3_fwd_raw -> bcp_norm_fwd_slabs / _bwd_slabs: the slab
     sum folded into the row-major statistics pass): (a) against torch (BatchNorm / grouped BatchNorm / InstanceNorm, every epilogue),
@@ -1448,4 +1512,4 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")

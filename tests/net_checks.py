@@ -718,6 +718,34 @@ def check_unet_skip_in_concat(ops, dev, hw=(64, 64), N=4, seed=23, min_direct=3)
         assert r < 1e-4, (k, r)
 
 
+def check_unet_inline_dropout(ops, dev, hw=(64, 64), N=4, seed=31):
+    """live nn.Dropout with the keep bits evaluated inside the norm kernels (UNet_2d.inline_dropout, hip_ops.SeedMask) == the same network
+    drawing uint8 masks with bcp_bernoulli from the same dropout stream: logits and every gradient bit for bit, two passes in a row (the
+    second one is a plan replay with refreshed seeds when plans are on)"""
+    rng = np.random.default_rng(seed)
+    P = O.init_params(O.unet_param_shapes(), seed=seed + 100, random_affine=True)
+    x = torch.from_numpy(rng.random((N, 1) + hw, dtype=np.float32)).to(dev)
+    w = torch.from_numpy(rng.standard_normal((N, 4) + hw).astype(np.float32)).to(dev)
+    res = {}
+    for flag in (True, False):
+        net = make_unet(P, dev, ops)
+        net.inline_dropout = flag
+        net.seed_dropout(777)
+        got = []
+        for _ in range(2):
+            for p_ in net.parameters():
+                p_.grad = None
+            out = net(x, groups=2)
+            (out * w).sum().backward()
+            got.append((out.detach().cpu(), {k: p_.grad.detach().cpu().clone() for k, p_ in net.named_parameters() if p_.grad is not None}))
+        res[flag] = got
+    assert not torch.equal(res[True][0][0], res[True][1][0]), "two passes drew the same dropout masks"
+    for it in range(2):
+        assert torch.equal(res[True][it][0], res[False][it][0]), f"inline dropout: logits differ (pass {it})"
+        for k, g in res[False][it][1].items():
+            assert torch.equal(res[True][it][1][k], g), (f"inline dropout: gradient differs (pass {it})", k)
+
+
 def check_unet_eval(ops, dev, seed=5):
     """model.eval() U-Net forward (running statistics, no dropout) vs the oracle; the running statistics stay untouched"""
     rng = np.random.default_rng(seed)

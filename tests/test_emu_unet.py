@@ -23,6 +23,10 @@ def test_unet_golden_tiny(emu_ops, golden_dir):
     NC.check_unet_golden_tiny(emu_ops, CPU, golden_dir)
 
 
+def test_dropout_bits_evaluated_in_the_norm_kernels_equal_the_mask_tensors(emu_ops):
+    NC.check_unet_inline_dropout(emu_ops, CPU, hw=(32, 32), N=4)
+
+
 def test_skip_written_into_the_concat_buffer_equals_the_copy(emu_ops):
     NC.check_unet_skip_in_concat(emu_ops, CPU, hw=(32, 32), N=4)
 

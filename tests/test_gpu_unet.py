@@ -33,6 +33,11 @@ def test_skip_written_into_the_concat_buffer_equals_the_copy(ops):
     NC.check_unet_skip_in_concat(ops, DEV, hw=(256, 256), N=12, seed=29, min_direct=0)     # the student batch of the ACDC step: no level takes the raw-slab norm, no copy left
 
 
+def test_dropout_bits_evaluated_in_the_norm_kernels_equal_the_mask_tensors(ops):
+    NC.check_unet_inline_dropout(ops, DEV, hw=(64, 64), N=4)
+    NC.check_unet_inline_dropout(ops, DEV, hw=(256, 256), N=12, seed=37)
+
+
 def test_acdc_self_train_trajectory(ops, golden_dir):
     NC.check_acdc_step(ops, DEV, golden_dir)
 
