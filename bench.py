@@ -496,7 +496,7 @@ def main():
     dev = torch.device("cuda", dp.local_rank)
     torch.cuda.set_device(dev)
     from bcp_amd import plan
-    plan.use_real_stream(dev)       # as the training scripts do: network passes replay as HIP graphs (the null stream cannot be captured)
+    plan.use_real_stream(dev)       # as the training scripts do (a real stream is also what --opt graphs=1 needs: the null stream cannot be captured)
     ops = Ops.product()
     for kv in args.opt:
         k, _, v = kv.partition("=")

@@ -1162,16 +1162,19 @@ def check_plan_hygiene(ops, dev):
         plan.ENABLED = True
 
 
-def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=False):
+def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=False, overlap=True, real_stream=False):
     """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net
     (grouped and as the reference's four separate calls -- the second student call must not reuse the busy plan), the pancreas
     V-Net and the ACDC U-Net, live Dropout / Dropout3d (the seeds are patched into the recorded launches), weights, teacher
-    weights and running statistics compared after the last step"""
+    weights and running statistics compared after the last step.
+    graphs (GPU, plan.GRAPHS for the replayed run; not the default since round 4): pass overlap=False with it -- a captured pass reproduces
+    the eager bits when it runs ALONE; beside another stream's work (the teacher under the student) it did not (bcp_amd/plan.py)"""
     from bcp_amd import plan, train_step
 
     def run(enabled, what, grouped):
-        if enabled and graphs:
-            # graphs=True (GPU only): the replayed run lives on a real stream, so the first replay of every pass is captured and
+        if enabled and (graphs or real_stream):
+            # graphs / real_stream (GPU only): the replayed run lives on a real stream as in the training scripts and bench.py; with graphs
+            # the first replay of every pass is captured and
             # the later ones are single hipGraphLaunch calls (side-stream weight gradients inside the graph)
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -1207,10 +1210,10 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
             losses = []
             for _ in range(steps):
                 if what == "acdc":
-                    r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=(9, 13, 42, 42))
+                    r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=(9, 13, 42, 42), overlap=overlap)
                 else:
                     r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), variant=what,
-                                                      connect_mode=2 if what != "la" else None, grouped=grouped)
+                                                      connect_mode=2 if what != "la" else None, grouped=grouped, overlap=overlap)
                 losses.append(float(r["loss"]))
             plans = list(model.__dict__.get("_plan_state", (None, {}))[1].values()) + list(ema.__dict__.get("_plan_state", (None, {}))[1].values())
             n_plans = len(model.__dict__.get("_plan_state", (None, {}))[1])

@@ -196,9 +196,19 @@ def test_recorded_launch_plans_equal_eager_path(ops):
 
 
 def test_graph_replays_equal_eager_path(ops):
-    """on a real stream the recorded passes are captured: hipGraphLaunch per network pass == the eager path, bit for bit"""
-    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True), ("acdc", True)), graphs=1)
-    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("acdc", True)), graphs=2)      # + the backward pass (not the default: plan.py)
+    """opt-in capture (plan.GRAPHS >= 1; the default is the per-launch replay): hipGraphLaunch per network pass == the eager path, bit for
+    bit -- with the teacher on the student's stream (overlap=False).  A graph that runs BESIDE another stream's work did not reproduce the
+    eager bits on ROCm 7.2 (24 of 150 small ACDC runs: tools/probe/graph_concurrency_probe.py), which is why capture is off by default."""
+    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True), ("acdc", True)), graphs=1, overlap=False)
+    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("acdc", True)), graphs=2, overlap=False)      # + the backward pass
+
+
+@pytest.mark.gpu
+def test_replayed_passes_beside_the_teacher_stream_equal_eager_path(ops):
+    """the product configuration: recorded passes replayed launch by launch, teacher forward on its side stream under the student's --
+    bit for bit the eager path, several times over (this is the check that caught the graphs: 0 deviations in 150 runs)"""
+    for _ in range(3):
+        NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True), ("la", True)), graphs=False, real_stream=True)
 
 
 @pytest.mark.gpu

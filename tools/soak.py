@@ -6,7 +6,7 @@ import bench
 from bcp_amd import synth, train_step
 from bcp_amd.hip_ops import Ops
 from bcp_amd import plan
-dev = torch.device("cuda:0"); torch.cuda.set_device(dev); plan.use_real_stream(dev); Ops.product(); np.random.seed(1)   # real stream: forward passes replay as HIP graphs
+dev = torch.device("cuda:0"); torch.cuda.set_device(dev); plan.use_real_stream(dev); Ops.product(); np.random.seed(1)   # real stream, as the training scripts
 model, ema = bench.build_models(dev, 1337)
 opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
 vol, lab = synth.la_batch(4, seed=1337); vol, lab = vol.to(dev), lab.to(dev)
