@@ -14,6 +14,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
+ABI_VERSION = 501      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+
 P = C.c_void_p
 I = C.c_int
 L = C.c_longlong
@@ -92,7 +94,7 @@ _SIGS = {
     "bcp_pw16_fwd_norm": (I, [P, P, P, I, I, I, P, P, P, L, I, P]),
     "bcp_pw16_bwd_norm": (I, [P, P, P, I, I, I, P, P, P, P, P, L, I, I, P, P]),
     "bcp_colsum": (I, [P, L, I, P, I, P, P]),
-    "bcp_maxpool2d_fwd": (I, [P, I, P, I, I, I, I, P]),
+    "bcp_maxpool2d_fwd": (I, [P, I, P, I, I, I, I, P, P, P]),
     "bcp_maxpool3d_k3s2_fwd": (I, [P, P, I, I, I, I, I, P]),
     "bcp_maxpool2d_bwd": (I, [P, I, P, P, I, I, I, I, I, P, I, P]),
     "bcp_bilinear2x_fwd": (I, [P, P, I, I, I, I, I, I, P, P]),
@@ -190,6 +192,10 @@ class Binding:
             fn.argtypes = args
         self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_planes", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
+        got = int(self.cdll.bcp_version())
+        if got != ABI_VERSION:
+            raise BcpError(f"{path}: ABI revision {got}, this binding was written against {ABI_VERSION} (include/bcp_hip.h) -- rebuild: "
+                           "python -c 'import __graft_entry__ as g; g.build()'")
         self._rec = None          # a bcp_amd.plan.LaunchPlan while a network pass is being recorded
         self.options_epoch = 0    # bumped by set_option: cached shape queries (hip_ops.Ops._ws_bytes) are keyed on it
 

@@ -17,7 +17,7 @@ Options& options() {
 }
 }  // namespace bcp
 
-extern "C" int bcp_version(void) { return 200; }
+extern "C" int bcp_version(void) { return BCP_ABI_VERSION; }
 
 // name = one of the Options fields (common.h); value = decimal integer(s), comma separated for the array-valued options;
 // an empty value restores the default.  Not thread-safe against concurrent launches: set options before the work starts.

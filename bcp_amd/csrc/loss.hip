@@ -404,7 +404,7 @@ static int launch_bwd(const float* logits, const uint8_t* img_l, const uint8_t* 
 // utils/losses.py:79-134 `DiceLoss.forward(inputs, target, mask, weight, softmax)` AS A CLASS: `inputs` are PROBABILITIES (the
 // ACDC script hands it F.softmax(output), ACDC_BCP_train.py:170-176), any dense layout (channel / voxel / sample strides in
 // elements: torch's softmax returns NCHW-contiguous, the networks here produce NHWC), per-class sums over the whole batch,
-// squared denominators, smooth 1e-10 with a mask and 1e-5 without, per-class weights.  The fused step uses bcp_mixloss_* above;
+// squared denominators, smooth 1e-10 (utils/losses.py:94 and :105: masked and unmasked alike), per-class weights.  The fused step uses bcp_mixloss_* above;
 // this pair exists so the reference's own loss body runs unchanged on the seam.
 // mask_mode: 0 none, 1 dense uint8 (non-zero = counted), 2 box (1 OUTSIDE the box), 3 box complement (1 inside)
 constexpr int kDiceProbRows = 512;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(256) void k_dice_prob_finalize(const double* __rest
   __shared__ double red[4 * C * 3];
   block_sum_256<C * 3>(s, red);
   if (threadIdx.x != 0) return;
-  const double smooth = masked ? 1e-10 : 1e-5;
+  const double smooth = 1e-10;      // _dice_loss AND _dice_mask_loss (utils/losses.py:94, :105); (void)masked
   double loss = 0.0;
   for (int c = 0; c < C; ++c) {
     const double I = s[c * 3], Z = s[c * 3 + 1], Y = s[c * 3 + 2];

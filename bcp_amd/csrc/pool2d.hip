@@ -11,8 +11,13 @@ namespace bcp {
 
 // ldx: row stride of x in floats -- C, or the width of the concat buffer whose first C channels x is (round 4: an encoder block's
 // output lives only there; no copy into the concat buffer)
+// amax_src / amax_dst (round 5): x is a skip tensor living in the leading channels of a concat buffer; the buffer gets |max| slots OF ITS
+// OWN, started here as a copy of x's (final since x's producing pass; this launch sits between that pass and the upsample that
+// max-reduces its half into them).  x's slots stay what its producer left: every reader of x -- the next encoder conv through the pooled
+// tensor, its weight-gradient kernel a backward pass later -- sees ONE scale (they used to be the concat buffer's slots as well).
 __global__ __launch_bounds__(256) void k_maxpool2d_fwd(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W,
-                                                       int C, int ldx) {
+                                                       int C, int ldx, const float* __restrict__ amax_src, float* __restrict__ amax_dst) {
+  if (amax_dst && blockIdx.x == 0 && threadIdx.x < kAmaxSlots) amax_dst[threadIdx.x * kAmaxStride] = amax_src[threadIdx.x * kAmaxStride];
   const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
   const long long total = (long long)N * Ho * Wo * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -127,8 +132,11 @@ __global__ __launch_bounds__(256) void k_bilinear2x_fwd(const float* __restrict_
     o.z = lh.l0 * (lw.l0 * a.z + lw.l1 * b.z) + lh.l1 * (lw.l0 * c.z + lw.l1 * d.z);
     o.w = lh.l0 * (lw.l0 * a.w + lw.l1 * b.w) + lh.l1 * (lw.l0 * c.w + lw.l1 * d.w);
     st4(y + (((long long)n * Ho + ho) * Wo + wo) * ldy + y_off + c4 * 4, o);
-    amax = fmaxf(amax, fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w))));
-    if (o.x != o.x || o.y != o.y || o.z != o.z || o.w != o.w) amax = o.x + o.y + o.z + o.w;      // (a NaN is forwarded, see block_amax_publish)
+    // NaN-propagating maximum (fmaxf drops NaNs -- also the one a previous iteration stored): once NaN, `t > amax` is false for every
+    // later t and the NaN stays; block_amax_publish forwards it to the slot
+    const float ov[4] = {o.x, o.y, o.z, o.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float t = fabsf(ov[k]); amax = (t > amax || t != t) ? t : amax; }
   }
   if (amax_io) block_amax_publish(amax, amax_io);
 }
@@ -208,11 +216,13 @@ static inline int sgrid(long long n) {
 
 using namespace bcp;
 
-extern "C" int bcp_maxpool2d_fwd(const float* x, int ldx, float* y, int N, int H, int W, int C, void* stream) {
+extern "C" int bcp_maxpool2d_fwd(const float* x, int ldx, float* y, int N, int H, int W, int C, const float* amax_src_or_null,
+                                 float* amax_dst_or_null, void* stream) {
   if (ldx == 0) ldx = C;
   BCP_REQUIRE(x && y && N > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && ldx >= C && ldx % 4 == 0 && aligned16(x), "bcp_maxpool2d_fwd: bad argument");
+  BCP_REQUIRE((amax_src_or_null == nullptr) == (amax_dst_or_null == nullptr), "bcp_maxpool2d_fwd: the |max| slot copy needs source and destination");
   hipLaunchKernelGGL(k_maxpool2d_fwd, dim3(sgrid((long long)N * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, y,
-                     N, H, W, C, ldx);
+                     N, H, W, C, ldx, amax_src_or_null, amax_dst_or_null);
   BCP_CHECK_LAUNCH("bcp_maxpool2d_fwd");
   return BCP_OK;
 }

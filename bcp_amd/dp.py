@@ -81,26 +81,89 @@ def _exchange_id(ident, world, rank):
 _STORES = []
 
 
+_AGREE_SEQ = [0]   # agreements held by this process so far (one per communicator attempt, the same count on every rank)
+
+
+def _agree(ok, world, rank, timeout_s=None):
+    """True iff EVERY rank reports ok.  Runs between the rank-local half of building a communicator (dlopen, id exchange) and the
+    collective half (ncclCommInitRank): a failure that hits one rank only -- an id file that never appeared, a rendezvous time-out --
+    used to send that rank into the torch.distributed fall-back while the others sat in ncclCommInitRank for ever.
+    Flags travel the way the id did: keys in the launch's c10d store, or files next to the id file (BCP_DP_ID_DIR).  A flag that
+    does not arrive within the time-out counts as a failure, so every rank takes the same way out."""
+    _AGREE_SEQ[0] += 1
+    if world == 1:
+        return bool(ok)
+    seq = _AGREE_SEQ[0]      # (not _ID_SEQ: a rank that failed before its id exchange has not counted that one)
+    timeout_s = float(os.environ.get("BCP_DP_AGREE_TIMEOUT", "180")) if timeout_s is None else timeout_s
+    d = os.environ.get("BCP_DP_ID_DIR")
+    if d:
+        tag = (f"{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{world}_"
+               f"{os.environ.get('BCP_DP_LAUNCH_ID', os.getppid())}_{seq}")
+        mine = os.path.join(d, f"bcp_rccl_ok_{tag}.{rank}")
+        tmp = mine + f".{os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(b"1" if ok else b"0")
+        os.replace(tmp, mine)
+        t0, all_ok = time.time(), bool(ok)
+        for r in range(world):
+            path = os.path.join(d, f"bcp_rccl_ok_{tag}.{r}")
+            while True:
+                try:
+                    v = open(path, "rb").read()
+                    if v in (b"0", b"1"):
+                        all_ok = all_ok and v == b"1"
+                        break
+                except OSError:
+                    pass
+                if time.time() - t0 > timeout_s:
+                    return False
+                time.sleep(0.01)
+        return all_ok
+    try:
+        store = _STORES[-1] if _STORES else None
+        if store is None:
+            from datetime import timedelta
+            from torch.distributed import rendezvous
+            store, _, _ = next(iter(rendezvous("env://", rank=rank, world_size=world, timeout=timedelta(seconds=timeout_s))))
+            _STORES.append(store)
+        base = f"bcp_rccl_ok/{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}/{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}/{seq}"
+        store.set(f"{base}/{rank}", b"1" if ok else b"0")
+        all_ok = bool(ok)
+        for r in range(world):
+            all_ok = all_ok and bytes(store.get(f"{base}/{r}")) == b"1"      # blocks until rank r has reported (store time-out: a failure)
+        return all_ok
+    except Exception:
+        return False
+
+
 class _RcclAbi:
     """RCCL through the C ABI: communicator + one stream for the collectives"""
 
     def __init__(self, world, rank, local_rank):
+        """the RANK-LOCAL half: library, device, the unique id (rank 0 makes it, everyone fetches it).  init() is the collective half;
+        DataParallel calls _agree() between the two"""
         from . import _lib
         self.b = _lib.product()
         if not self.b.call("bcp_comm_available"):
             raise RuntimeError("librccl.so could not be loaded")
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
-        ident = (C.c_char * 128)()
+        self._ident = (C.c_char * 128)()
         if rank == 0:
-            self.b.call("bcp_comm_unique_id", C.cast(ident, C.c_void_p))
-        C.memmove(ident, _exchange_id(bytes(ident) if rank == 0 else None, world, rank), 128)
+            self.b.call("bcp_comm_unique_id", C.cast(self._ident, C.c_void_p))
+        C.memmove(self._ident, _exchange_id(bytes(self._ident) if rank == 0 else None, world, rank), 128)
+        self.world, self.rank = world, rank
+        self.comm = None
+
+    def init(self):
+        """ncclCommInitRank: COLLECTIVE -- call only when every rank got through __init__ (_agree); a failure in here is raised, there
+        is no common way out of a half-built communicator"""
         comm = C.c_void_p()
-        self.b.call("bcp_comm_init_rank", C.byref(comm), world, rank, C.cast(ident, C.c_void_p))
+        self.b.call("bcp_comm_init_rank", C.byref(comm), self.world, self.rank, C.cast(self._ident, C.c_void_p))
         self.comm = comm
         self.stream = torch.cuda.Stream(device=self.dev)
-        self.world, self.rank = world, rank
         self.barrier()
+        return self
 
     def count(self):
         n = C.c_int(0)
@@ -169,19 +232,24 @@ class DataParallel:
         if backend == "rccl":
             from . import _lib
             import sys
-            if _lib.product().call("bcp_comm_available"):
-                try:
-                    self.abi = _RcclAbi(self.world, self.rank, self.local_rank)
-                    return
-                except Exception as e:      # communicator construction is collective: what fails here (id exchange, ncclCommInitRank) fails
-                    # on every rank alike, and every rank takes the same way out.  Loud, not silent: the transport is named in bench.py's line
-                    if os.environ.get("BCP_DP_BACKEND") == "rccl":
-                        raise               # asked for by name: no substitute
-                    print(f"[bcp_amd.dp] rank {self.rank}: RCCL communicator through the C ABI failed ({type(e).__name__}: {e}) -- "
-                          "falling back to torch.distributed 'nccl' (the same RCCL, torch's process group)", file=sys.stderr, flush=True)
-            else:
-                # librccl.so cannot be dlopen()ed on this box (the same on every rank): torch.distributed's bundled RCCL instead
-                print("[bcp_amd.dp] librccl.so not loadable through the C ABI -- falling back to torch.distributed 'nccl'", file=sys.stderr)
+            # Two halves with an agreement in between: the rank-local half (dlopen of librccl, the id exchange) may fail on ONE rank only;
+            # every rank then learns it (_agree) and all of them take the same way out.  The collective half (ncclCommInitRank) runs only
+            # when every rank got that far, and a failure inside it is raised.
+            abi, err = None, None
+            try:
+                if not _lib.product().call("bcp_comm_available"):
+                    raise RuntimeError("librccl.so not loadable through the C ABI")
+                abi = _RcclAbi(self.world, self.rank, self.local_rank)
+            except Exception as e:
+                err = e
+            if _agree(err is None, self.world, self.rank):
+                self.abi = abi.init()
+                return
+            if os.environ.get("BCP_DP_BACKEND") == "rccl":      # asked for by name: no substitute
+                raise err if err is not None else RuntimeError("bcp_amd.dp: another rank could not prepare its RCCL communicator")
+            why = f"{type(err).__name__}: {err}" if err is not None else "another rank failed before ncclCommInitRank"
+            print(f"[bcp_amd.dp] rank {self.rank}: RCCL communicator through the C ABI not built ({why}) -- every rank falls back to "
+                  "torch.distributed 'nccl' (the same RCCL, torch's process group)", file=sys.stderr, flush=True)
             backend = self.backend = "nccl"
         import torch.distributed as dist
         if not dist.is_initialized():

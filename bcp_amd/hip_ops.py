@@ -8,6 +8,7 @@ labels / masks contiguous uint8 [N, D, H, W].  The logical NCDHW view the refere
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -179,9 +180,20 @@ class Ops:
         out._bcp_amax = a
         return a
 
-    @staticmethod
-    def _amax_of(x):
-        return getattr(x, "_bcp_amax", None)
+    # debug mode (BCP_AMAX_CHECK=1, or Ops.AMAX_CHECK = True): every launch that is handed a tensor's |max| slots first recomputes
+    # max |x| (a host synchronisation per launch: tests and triage only) and fails when the slots promise LESS than the tensor holds --
+    # a stale attribute (an in-place write after the producing pass, an attribute copied onto another tensor) would overflow the fp16
+    # planes silently.  A NaN on either side passes: the kernels then take scale 1 and forward the NaN.
+    AMAX_CHECK = os.environ.get("BCP_AMAX_CHECK", "0") == "1"
+
+    def _amax_of(self, x):
+        a = getattr(x, "_bcp_amax", None)
+        if a is not None and self.AMAX_CHECK:
+            have, want = amax_value(a), float(x.detach().abs().max())
+            if have == have and want == want and want > have:
+                raise _lib.BcpError(f"|max| slots of a {tuple(x.shape)} tensor promise {have:.9g} but the tensor holds {want:.9g}: the "
+                                    "attribute is stale (in-place write after the producing pass?)")
+        return a
 
     def box_arg(self, box6):
         key = tuple(int(v) for v in box6)
@@ -709,13 +721,19 @@ class Ops:
         return out
 
     # ------------------------------------------------------------------ 2-D U-Net plumbing
-    def maxpool2d_fwd(self, x):
-        """x: contiguous or a channel slab (channel_slab)"""
+    def maxpool2d_fwd(self, x, concat=None):
+        """x: contiguous or a channel slab (channel_slab).  The pooled tensor carries x's |max| slots (max |pool(x)| <= max |x|: an upper
+        bound is all the fp16 pre-scale of the next conv needs).  concat: the concat buffer whose leading channels x is -- it gets |max|
+        slots of its own, started as a copy of x's by this launch (bilinear2x_fwd max-reduces the upsampled half into them)"""
         ldx = self._chk_rows(x)
         N, D, H, W, Cc = x.shape
         assert D == 1
         y = torch.empty((N, 1, H // 2, W // 2, Cc), dtype=torch.float32, device=x.device)
-        self.b.call("bcp_maxpool2d_fwd", _p(x), ldx, _p(y), N, H, W, Cc, self.stream(x))
+        a_src = self._amax_of(x)
+        a_dst = self._amax_slot(concat) if (concat is not None and a_src is not None) else None
+        self.b.call("bcp_maxpool2d_fwd", _p(x), ldx, _p(y), N, H, W, Cc, _p(a_src if a_dst is not None else None), _p(a_dst), self.stream(x))
+        if a_src is not None:
+            y._bcp_amax = a_src
         return y
 
     def maxpool3d_k3s2_fwd(self, x):

@@ -220,10 +220,8 @@ class UNet_2d(HipNet):
         slab = [None if c is None else ops.channel_slab(c, FT[j]) for j, c in enumerate(cats)]
         xs = [self._convblock_fwd(self._enc[0], "e0", xcl, save, saved, out=slab[0])]
         for i in range(1, 5):
-            pooled = ops.maxpool2d_fwd(xs[-1])
-            am = getattr(xs[-1], "_bcp_amax", None)
-            if am is not None:
-                pooled._bcp_amax = am          # max |pool(x)| <= max |x|: an upper bound is all the fp16 pre-scale of the next conv needs
+            # (the pooled tensor carries xs[-1]'s |max| slots; the concat buffer xs[-1] lives in gets slots of its own, started as a copy)
+            pooled = ops.maxpool2d_fwd(xs[-1], concat=cats[i - 1] if (slab[i - 1] is not None and xs[-1] is slab[i - 1]) else None)
             xs.append(self._convblock_fwd(self._enc[i], f"e{i}", pooled, save, saved, out=slab[i] if i < 4 else None))
         h = xs[4]
         for i, (pw, cb, c1, c2) in enumerate(self._up, start=1):
@@ -231,11 +229,7 @@ class UNet_2d(HipNet):
             z = ops.pw_fwd(h, bp, pw.bias.data, c2)
             skip = xs[4 - i]
             if slab[4 - i] is not None and skip is slab[4 - i]:
-                cat = cats[4 - i]
-                am = getattr(skip, "_bcp_amax", None)
-                if am is not None:
-                    cat._bcp_amax = am         # the concat buffer's |max| slots ARE the skip's; the upsample max-reduces its half into them
-                                               # (the skip's own readers then see an upper bound, which is all they need)
+                cat = cats[4 - i]              # (its |max| slots: a copy of the skip's, made by the pool launch; the upsample max-reduces its half into them)
             else:
                 cat = torch.empty((N, 1, skip.shape[2], skip.shape[3], 2 * c2), dtype=torch.float32, device=xcl.device)
                 ops.copy_channels(skip, cat, c2, 0, 0, carry_amax=True)      # (+ the |max| of the concat buffer: skip's, then the upsampled half's)

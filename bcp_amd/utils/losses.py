@@ -28,8 +28,8 @@ class DiceLoss(nn.Module):
     """The reference's class (utils/losses.py:79-134), same call contract:
     `forward(inputs, target, mask=None, weight=None, softmax=False)` with `inputs` PROBABILITIES [N,C,H,W] (logits when
     softmax=True), `target` / `mask` [N,1,H,W] (any of the reference's dtypes; a `BCP_utils.BoxMask` also works as the mask),
-    `weight` a per-class list.  Per-class Dice over the whole batch with squared denominators, smooth 1e-10 masked / 1e-5
-    unmasked, sum(weight_i * dice_i) / n_classes.  Gradients flow to `inputs` (csrc/loss.hip: bcp_dice_prob_fwd / _bwd);
+    `weight` a per-class list.  Per-class Dice over the whole batch with squared denominators, smooth 1e-10 (masked and
+    unmasked alike, utils/losses.py:94 / :105), sum(weight_i * dice_i) / n_classes.  Gradients flow to `inputs` (csrc/loss.hip: bcp_dice_prob_fwd / _bwd);
     the fused training step does not come through here (train_step.acdc_mix_loss: one pass over the logits for both terms)."""
 
     def __init__(self, n_classes):

@@ -39,6 +39,10 @@ enum { BCP_PACK_DOWN_FWD = 0, BCP_PACK_DOWN_DGRAD = 1, BCP_PACK_UP_FWD = 2, BCP_
 enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 
 /* ---- library ------------------------------------------------------------------------------- */
+/* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
+ * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
+ * with shifted arguments inside a launch). */
+#define BCP_ABI_VERSION 501
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -266,7 +270,10 @@ int bcp_colsum(const float* x, long long rows, int C, float* out, int accumulate
 
 /* ---- 2-D U-Net plumbing (networks/unet.py:36-57): MaxPool2d(2), bilinear x2 align_corners=True, channel concat ---- */
 /* ldx: row stride of x in floats (0 = C): x may be the first C channels of a concat buffer (bcp_norm_fwd out_ld) */
-int bcp_maxpool2d_fwd(const float* x, int ldx, float* y, int N, int H, int W, int C, void* stream);
+/* amax_src / amax_dst (both or neither): also copies x's |max| slots (see "per-tensor |max|" below) into the slots of the concat buffer
+ * x lives in, which the upsample (bcp_bilinear2x_fwd amax_io) then max-reduces its half into */
+int bcp_maxpool2d_fwd(const float* x, int ldx, float* y, int N, int H, int W, int C, const float* amax_src_or_null, float* amax_dst_or_null,
+                      void* stream);
 /* nn.MaxPool3d(3, stride=2), forward only: pool(x5), the V-Net's second return value (networks/VNet.py:246,286-290); x [N][D][H][W][C]
  * -> y [N][(D-3)/2+1][(H-3)/2+1][(W-3)/2+1][C] */
 int bcp_maxpool3d_k3s2_fwd(const float* x, float* y, int N, int D, int H, int W, int C, void* stream);

@@ -4,7 +4,7 @@ utils/losses.py (build container only; reads /root/reference/code, writes tests/
 Run:  PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_dice.py
 
 Cases (utils/losses.py:113-134): probabilities in + dense [N,1,H,W] mask (how ACDC_BCP_train.py:175-176 calls it), the
-complementary mask, no mask (smooth 1e-5 branch), per-class `weight`, `softmax=True` on logits; each with the gradient w.r.t.
+complementary mask, no mask (`_dice_loss`, the same smooth 1e-10, utils/losses.py:94), per-class `weight`, `softmax=True` on logits, a class absent from target and prediction (the smooth term decides); each with the gradient w.r.t.
 the tensor that was passed in."""
 import os
 import sys
@@ -51,6 +51,15 @@ def main():
     run("nomask", lambda p: dl(p, target), probs)
     run("weighted", lambda p: dl(p, target, mask, weight=weight), probs)
     run("softmax", lambda x: dl(x, target, mask, softmax=True), logits)
+    # a class that is ABSENT from the target and all but absent from the prediction (sum p^2 ~ 1e-8): the only regime in which the smooth
+    # term decides the value -- 1e-10 gives that class a Dice near 0.01, a 1e-5 would give 0.999 (the unmasked branch)
+    target_abs = torch.where(target == 3, torch.zeros_like(target), target)
+    logits_abs = logits.clone()
+    logits_abs[:, 3] -= 13.0
+    probs_abs = F.softmax(logits_abs, dim=1)
+    out["target_abs"], out["logits_abs"] = target_abs.numpy(), logits_abs.numpy()
+    run("absent", lambda p: dl(p, target_abs), probs_abs)
+    run("absent_masked", lambda p: dl(p, target_abs, mask), probs_abs)
     np.savez_compressed(os.path.join(OUT, "diceloss_class.npz"), **out)
     print({k: float(v) for k, v in out.items() if np.ndim(v) == 0})
 

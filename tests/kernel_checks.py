@@ -243,6 +243,20 @@ def check_diceloss_class(ops, dev, golden_dir):
             assert abs(float(v.detach()) - float(g[name])) < 1e-5, (name, float(v.detach()), float(g[name]))
             gr = torch.from_numpy(g["g_" + name])
             assert rel_l2(leaf.grad, gr) < 1e-5, (name, cl, rel_l2(leaf.grad, gr))
+    # a class absent from the target and (all but) from the prediction: the regime in which the smooth term decides -- 1e-10 in BOTH
+    # branches of the reference (utils/losses.py:94, :105); with 1e-5 in the unmasked branch the value would be off by 0.25
+    la, ta = torch.from_numpy(g["logits_abs"]).to(dev), torch.from_numpy(g["target_abs"]).to(dev)
+    for name, fn in (("absent", lambda p: dice_loss(p, ta)), ("absent_masked", lambda p: dice_loss(p, ta, mask))):
+        for cl in (False, True):
+            leaf = torch.softmax(la, dim=1)
+            if cl:
+                leaf = leaf.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+            leaf = leaf.detach().clone(memory_format=torch.preserve_format).requires_grad_(True)
+            v = fn(leaf)
+            v.backward()
+            assert abs(float(v.detach()) - float(g[name])) < 1e-5, (name, float(v.detach()), float(g[name]))
+            gr = torch.from_numpy(g["g_" + name])
+            assert rel_l2(leaf.grad, gr) < 1e-5, (name, cl, rel_l2(leaf.grad, gr))
     with pytest_raises(AssertionError):
         dice_loss(torch.softmax(logits, 1)[:, :3], target)
 

@@ -33,7 +33,9 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_version_and_argument_validation(lib):
-    assert lib.bcp_version() >= 100
+    from bcp_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "bcp_hip.h")).read()
+    assert lib.bcp_version() == int(re.search(r"#define BCP_ABI_VERSION (\d+)", hdr).group(1)) == _lib.ABI_VERSION
     lib.bcp_last_error.restype = ctypes.c_char_p
     # null pointers / bad shapes are rejected before any launch (no GPU needed)
     rc = lib.bcp_mix_box(None, None, None, 1, 1, 1, 1, 1, None, None)

@@ -270,3 +270,39 @@ def test_rccl_unique_id_exchange_under_torchrun(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(script)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=240)
     assert r.returncode == 0 and r.stdout.count("ID_OK") == 2, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def _worker_agree(rank, world, port, out_dir, id_dir, bad_rank):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BCP_DP_LAUNCH_ID=f"t{port}")
+    if id_dir:
+        os.environ["BCP_DP_ID_DIR"] = id_dir
+    else:
+        os.environ.pop("BCP_DP_ID_DIR", None)
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from bcp_amd import dp
+    got = []
+    # communicator 1: every rank got its id; communicator 2: ONE rank failed in its rank-local half (it never ran the id exchange)
+    ident = bytes(range(128))
+    assert dp._exchange_id(ident if rank == 0 else None, world, rank) == ident
+    got.append(dp._agree(True, world, rank))
+    got.append(dp._agree(rank != bad_rank, world, rank))
+    torch.save(got, os.path.join(out_dir, f"agree_{rank}.pt"))
+
+
+@pytest.mark.parametrize("transport", ["store", "file"])
+def test_rank_local_failure_is_agreed_on_before_the_collective_init(tmp_path, transport):
+    """bcp_amd/dp.py::_agree (ADVICE r04): between the rank-local half of building the RCCL communicator and ncclCommInitRank every rank
+    learns whether EVERY rank got through -- one failing rank sends all of them the same way, nobody is left inside the collective"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    id_dir = ""
+    if transport == "file":
+        id_dir = str(tmp_path / "ids")
+        os.makedirs(id_dir)
+    mp.spawn(_worker_agree, args=(3, port, str(tmp_path), id_dir, 1), nprocs=3, join=True)
+    res = [torch.load(tmp_path / f"agree_{r}.pt") for r in range(3)]
+    assert res == [[True, False]] * 3, res
