@@ -104,7 +104,13 @@ __global__ __launch_bounds__(256) void k_maxpool2d_bwd(const float* __restrict__
 
 struct Lerp { int i0, i1; float l0, l1; };
 __device__ __forceinline__ Lerp lerp_ac(int o, int in, int out) {  // align_corners=True source coordinate (torch upsample math, fp32)
+#pragma clang fp contract(off)
   const float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  // the source coordinate is ROUNDED to fp32 before the integer part is taken off (torch: area_pixel_compute_source_index, then
+  // `lambda = src - floor`): no contraction of the product into the subtraction in here (the pragma; the _rn intrinsics alone do not stop
+  // -ffp-contract=fast, see elementwise.hip) -- with the fused form the weights of
+  // a 128 -> 256 upsample moved by up to an ulp of `src` (2.7e-5 in the output against torch; round 5, when the kernel lost its
+  // SLP-packed arithmetic and the contraction became possible)
   const float src = scale * (float)o;
   Lerp r;
   r.i0 = (int)src;

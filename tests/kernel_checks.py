@@ -1527,3 +1527,53 @@ def check_conv3_pipe_cold(ops, dev):
 
 
 ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+
+
+def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):
+    """Round 5 regression: bcp_pw_fwd + bcp_bilinear2x_fwd launched back to back on one stream BESIDE the bf16-pipe 2-D
+    convs on another stream and a copy / GEMM load on a third; every upsample output must carry the bits of the same launch on an idle
+    GPU.  The round-4 build of k_bilinear2x_fwd (packed-fp32 instructions with operand swizzles) failed this in 4-7 % of the launches --
+    which is what turned the replayed-vs-eager test red; tools/probe/bilinear_race_probe.py is the stand-alone version."""
+    import bcp_amd.hip_ops as Hh
+    assert dev.type == "cuda"
+    amax0 = type(ops).AMAX
+    type(ops).AMAX = False
+    try:
+        g = torch.Generator(device="cpu"); g.manual_seed(3)
+        C_, H_ = 32, 16
+        h = torch.randn(4, 1, H_, H_, 2 * C_, generator=g).to(dev)
+        wt = (torch.randn(C_, 2 * C_, generator=g) * 0.1).to(dev).contiguous()
+        bp, bias = ops.k2_pack(wt, 2 * C_, C_, Hh.PACK_PW_FWD), torch.zeros(C_, device=dev)
+        z = ops.pw_fwd(h, bp, bias, C_)
+        gold = torch.zeros(4, 1, 2 * H_, 2 * H_, 2 * C_, device=dev)
+        ops.bilinear2x_fwd(z, gold, C_)
+        torch.cuda.synchronize()
+        items = []
+        for (cc, hh) in ((16, 64), (32, 32), (64, 16), (128, 8)):
+            xi = torch.randn(4, 1, hh, hh, cc, device=dev)
+            w = (torch.randn(cc, cc, 3, 3, device=dev) * 0.1).contiguous()
+            wf, _ = ops.conv3_pack(w, 1)
+            items.append((xi, wf, torch.zeros(cc, device=dev), cc))
+        import net_checks as NC
+        load = NC.LoadGenerator(dev)
+        su, sc = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+        outs = [torch.zeros_like(gold) for _ in range(ring)]
+        torch.cuda.synchronize()
+        bad = 0
+        for r in range(rounds):
+            for y in outs:
+                y.zero_()
+            torch.cuda.synchronize()
+            load.burst()
+            for i in range(ring):
+                with torch.cuda.stream(sc):
+                    xi, wf, b_, cc = items[i % len(items)]
+                    ops.conv3_fwd(xi, wf, b_, cc, 1)
+                with torch.cuda.stream(su):
+                    ops.pw_fwd(h, bp, bias, C_, out=z)
+                    ops.bilinear2x_fwd(z, outs[i], C_)
+            torch.cuda.synchronize()
+            bad += sum(1 for y in outs if not torch.equal(y, gold))
+        assert bad == 0, f"{bad} of {rounds * ring} upsample launches beside the convs gave other bits than the idle-GPU launch"
+    finally:
+        type(ops).AMAX = amax0

@@ -1162,11 +1162,35 @@ def check_plan_hygiene(ops, dev):
         plan.ENABLED = True
 
 
-def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=False, overlap=True, real_stream=False):
+class LoadGenerator:
+    """a third stream kept busy beside the step under test: 128 MB copies (HBM / L2), 2048^3 GEMMs (CUs, matrix pipe) and a read-modify-write
+    -- the mix under which the round-4 build deviated in 21-35 % of small ACDC runs (tools/probe/replay_stress.py)"""
+
+    def __init__(self, dev):
+        self.s = torch.cuda.Stream(device=dev)
+        self.a = torch.randn(32 << 20, device=dev)
+        self.b = torch.empty_like(self.a)
+        self.m = torch.randn(2048, 2048, device=dev)
+        self.o = torch.empty_like(self.m)
+
+    def burst(self, n=8):
+        with torch.cuda.stream(self.s):
+            for _ in range(n):
+                self.b.copy_(self.a)
+                torch.mm(self.m, self.m, out=self.o)
+                self.a[: 1 << 20].add_(1.0)
+
+    def finish(self):
+        self.s.synchronize()
+
+
+def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=False, overlap=True, real_stream=False,
+                       load=None):
     """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net
     (grouped and as the reference's four separate calls -- the second student call must not reuse the busy plan), the pancreas
     V-Net and the ACDC U-Net, live Dropout / Dropout3d (the seeds are patched into the recorded launches), weights, teacher
     weights and running statistics compared after the last step.
+    load: a LoadGenerator -- every step of the REPLAYED run starts behind a burst of copies / GEMMs on a third stream (round 5)
     graphs (GPU, plan.GRAPHS for the replayed run; not the default since round 4): pass overlap=False with it -- a captured pass reproduces
     the eager bits when it runs ALONE; beside another stream's work (the teacher under the student) it did not (bcp_amd/plan.py)"""
     from bcp_amd import plan, train_step
@@ -1209,6 +1233,8 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
             opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
             losses = []
             for _ in range(steps):
+                if load is not None and enabled:
+                    load.burst()           # (the eager run is the reference: it runs on an otherwise idle GPU)
                 if what == "acdc":
                     r = train_step.acdc_self_train_step(model, ema, opt, vol, lab, 4, box=(9, 13, 42, 42), overlap=overlap)
                 else:

@@ -11,6 +11,12 @@ import kernel_checks as K
 import net_checks as NC
 
 pytestmark = pytest.mark.gpu
+
+
+def test_upsample_beside_convs_under_load(ops):
+    """round 5: the kernel behind round 4's red test, alone in its failing context (768 launches beside the convs and a load generator)"""
+    K.check_upsample_beside_convs(ops, DEV)
+
 DEV = torch.device("cuda:0")
 
 

@@ -1,0 +1,31 @@
+"""CPU-only (hipcc cross-compiles): the instruction-level gate of DESIGN.md section 4 -- the memory-bound plumbing kernels that run beside the
+bf16-pipe convs contain no swizzled packed-fp32 instruction (v_pk_mov_b32, v_pk_*_f32 with op_sel:[..]): the round-4 build of
+k_bilinear2x_fwd had them and returned wrong values under load (tools/probe/bilinear_race_probe.py)."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.mark.skipif(not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")), reason="needs hipcc")
+def test_plumbing_kernels_have_no_swizzled_packed_fp32(tmp_path):
+    import isa_scan
+    os.environ["BCP_ISA_DIR"] = str(tmp_path)
+    try:
+        bad = isa_scan.gate()
+    finally:
+        os.environ.pop("BCP_ISA_DIR", None)
+    assert not bad, bad[:5]
+
+
+def test_scanner_recognises_the_round4_forms(tmp_path):
+    import isa_scan
+    p = tmp_path / "k.s"
+    p.write_text("_Zk:\n\tv_pk_mov_b32 v[16:17], v[24:25], v[16:17] op_sel:[1,0]\n\tv_pk_mul_f32 v[18:19], v[18:19], v[14:15] op_sel:[0,1] op_sel_hi:[1,0]\n"
+                 "\tv_pk_fma_f32 v[16:17], v[16:17], v[32:33], v[24:25] op_sel_hi:[1,1,0]\n\tv_pk_add_f32 v[0:1], v[0:1], v[2:3]\n\ts_endpgm\n")
+    got = [ins.split()[0] for _, _, ins in isa_scan.swizzled_sites(str(p))]
+    assert got == ["v_pk_mov_b32", "v_pk_mul_f32"]

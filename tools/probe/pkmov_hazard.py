@@ -1,0 +1,71 @@
+"""Driver of tools/probe/pkmov_hazard.hip (GPU): every variant of "first consumer behind a partial s_waitcnt vmcnt" is launched RING times
+per round on its own stream BESIDE the library's bf16-pipe 2-D convs (LDS-DMA weight stages) on other streams and a copy / GEMM load;
+counts the lanes whose consumer saw something else than the loaded value.
+
+  hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o tools/probe/libpkmov.so tools/probe/pkmov_hazard.hip
+  python tools/probe/pkmov_hazard.py [rounds=20] [conv=2] [load=1]
+"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+import torch
+from bcp_amd.hip_ops import Ops
+
+kv = dict(a.split("=") for a in sys.argv[1:])
+ROUNDS, CONV, LOAD, RING = int(kv.get("rounds", 20)), int(kv.get("conv", 2)), int(kv.get("load", 1)), int(kv.get("ring", 64))
+lib = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpkmov.so"))
+lib.pk_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+ops = Ops.product(); dev = torch.device("cuda:0")
+Ops.AMAX = False
+ROWS, C4 = 4096 + 9, 8
+x = torch.randn(ROWS * C4 * 4, device=dev)
+n = (ROWS - 9) * C4
+st = torch.cuda.Stream(device=dev)
+ls = torch.cuda.Stream(device=dev)
+la = torch.randn(32 << 20, device=dev); lb = torch.empty_like(la); lm = torch.randn(2048, 2048, device=dev); lo = torch.empty_like(lm)
+convs = []
+for k in range(CONV):
+    items = []
+    for (cc, hh) in ((16, 64), (32, 32), (64, 16), (128, 8)):
+        xi = torch.randn(4, 1, hh, hh, cc, device=dev)
+        w = (torch.randn(cc, cc, 3, 3, device=dev) * 0.1).contiguous()
+        wf, _ = ops.conv3_pack(w, 1)
+        items.append((xi, wf, torch.zeros(cc, device=dev), cc))
+    convs.append((torch.cuda.Stream(device=dev), items))
+ring = [torch.zeros(n * 3, device=dev) for _ in range(RING)]
+torch.cuda.synchronize()
+NAMES = {0: "v_pk_mov_b32 op_sel:[1,0] behind vmcnt(1)", 1: "v_mov_b32 behind vmcnt(1)", 2: "v_pk_mov_b32 op_sel:[1,0] behind vmcnt(0)",
+         3: "v_pk_mov_b32 op_sel:[0,0] behind vmcnt(1), then v_mov_b32 of the dword", 4: "v_pk_mov_b32 behind vmcnt(1) + s_nop 7", 5: "v_pk_add_f32 op_sel:[1,0] behind vmcnt(1)",
+         6: "two v_pk_mov_b32 op_sel:[1,0] with destination == second source, behind vmcnt(0)", 7: "the same behind vmcnt(1)"}
+for variant in [int(v) for v in kv.get('variants', '0,1,2,3,4,5,6,7').split(',')]:
+    bad_seen = bad_later = launches_bad = 0
+    lanes = {}
+    sentinel = 0
+    for r in range(ROUNDS):
+        if LOAD:
+            with torch.cuda.stream(ls):
+                for _ in range(8):
+                    lb.copy_(la); torch.mm(lm, lm, out=lo); la[: 1 << 20].add_(1.0)
+        for i in range(RING):
+            for cs, items in convs:
+                with torch.cuda.stream(cs):
+                    xi, wf, bias, cc = items[i % len(items)]
+                    ops.conv3_fwd(xi, wf, bias, cc, 1)
+            rc = lib.pk_run(variant, x.data_ptr(), ring[i].data_ptr(), ROWS, C4, st.cuda_stream)
+            assert rc == 0
+        torch.cuda.synchronize()
+        for o in ring:
+            v = o.view(n, 3)
+            b0 = (v[:, 0] != v[:, 2]).nonzero().reshape(-1)
+            if b0.numel():
+                launches_bad += 1
+                bad_seen += b0.numel()
+                sentinel += int((v[b0, 0].view(torch.int32) == -1056969216).sum())          # 0xc0ffee00
+                for t in b0.tolist():
+                    q = (t % 64) // 16
+                    lanes[q] = lanes.get(q, 0) + 1
+            bad_later += int((v[:, 1] != v[:, 2]).sum())
+    print(f"variant {variant} [{NAMES[variant]}]: {launches_bad} of {ROUNDS * RING} launches, {bad_seen} lanes saw a wrong value ({sentinel} of them the "
+          f"register's OLD contents), quarter-wave histogram {dict(sorted(lanes.items()))}; the plain read 8 wait states later was wrong {bad_later} times", flush=True)

@@ -45,6 +45,7 @@ ap.add_argument("--pregraph", type=int, default=0)
 ap.add_argument("--opt", default="")
 ap.add_argument("--zero", type=int, default=1, help="deep mode: zero the plan tensors after the recording step")
 ap.add_argument("--tag", default="")
+ap.add_argument("--dump", default="", help="deep mode: file that receives the GEMM / upsample / concat tensors (bad and clean run) of the first deviating step")
 ap.add_argument("--attr", default="", help="network switches set on student and teacher, e.g. fuse_c1=0,skip_in_concat=0,inline_dropout=0")
 ap.add_argument("--selftest", type=int, default=0)
 ap.add_argument("--show", type=int, default=6, help="deviating runs to print in detail")
@@ -293,6 +294,14 @@ for k in range(A.runs):
                       f"equal to the SAME run's previous-step value: {stale}, to the clean run's previous-step value: {stale_c}; zeros: {int((xs == 0).sum())}", flush=True)
                 if idx.numel() <= 16:
                     print(f"         idx {idx.tolist()} got {xs.tolist()} clean {ys.tolist()}", flush=True)
+            if A.dump and not os.path.exists(A.dump):
+                which = sa[nd[0]][0]
+                keep = {}
+                for j, (ea, eb) in enumerate(zip(sa, sb)):
+                    if ea[0] == which and ea[2] in ("bcp_pw_fwd", "bcp_norm_fwd", "bcp_copy_channels", "bcp_bilinear2x_fwd") and ea[4] == "torch.float32" and ea[5].numel() <= 600000:
+                        keep[f"{j}|{ea[1]}|{ea[2]}|{ea[3]}"] = (ea[5].clone(), eb[5].clone())
+                torch.save({"step": si, "plan": which, "tensors": keep}, A.dump)
+                print(f"     deep: dumped {len(keep)} tensor pairs of plan {which} to {A.dump}", flush=True)
             done = True
             break
         if not done:
