@@ -63,6 +63,7 @@ struct Options {
   int conv3_xcd = 11;       // (round 4: 1 -> 11.  With two fp16 planes the kernels issue half the MFMAs and the fabric matters more: the persistent 16-channel kernel walking contiguous eighths (bit 2) is now FASTER alone (110 vs 117 us, fetch halved), one weight stream per XCD at the 128-channel level (bit 8) still slower alone (23.6 vs 22.0 us) but the LA step is 5.31 vs 5.34 ms with both, three interleaved pairs, pancreas 4.89 vs 4.92: tools/sessions/r04_s15.sh) // bf16-pipe kernels: XCD-aware workgroup -> tile order (each XCD walks a contiguous eighth of the tile list: halo overlap hits its own L2; the flat deep-level kernel deals WEIGHT STREAMS to XCDs).  Bits for measurements: 2 = also the persistent 16-channel kernel (slower), 8 = k_c3q deals weight streams to XCDs also when there are only 8 of them (128-channel level: minimal fabric traffic, slower alone, step unchanged), 16 = k_c3q in tile order
   int conv3_f16 = 1;        // round 4: bf16-pipe kernels that have a two-plane fp16 instance (k_c3d) use it when the launch carries the input tensor's |max| (per-tensor power-of-two pre-scales, conv3_defs.h): three MFMAs per K block instead of six.  0: three bf16 planes everywhere
   int wgrad_b6_slots = 0;   // weight gradient on the matrix pipe: workgroups per launch the tile groups are cut for (0 = 512: two per CU); measurement switch
+  int mix_c1 = 1;           // round 5: single-channel copy-paste mix as k_mix_box_c1 (one multiply-high per float4 instead of six divisions; b read inside the box only).  0: the general kernel (measurement switch)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };
 Options& options();

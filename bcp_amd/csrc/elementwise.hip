@@ -64,6 +64,35 @@ __global__ __launch_bounds__(256) void k_mix_box(const float* __restrict__ a, co
   }
 }
 
+// Single-channel images (C == 1, W % 4 == 0: every input of the three training loops).  Round 5: the general kernel above spends six
+// 32-bit divisions per 16 bytes on its (d, h, w) coordinates -- 30 us for one 8 MB LA batch at the head of the student's stream, 0.8 TB/s
+// (profiles/r04_t5_pmc_ops.txt).  Here a workgroup row (blockIdx.y) is one (n, d) slice, the row index inside it is one multiply-high by a
+// host-computed reciprocal, and `b` is read only where the box is: algorithmic bytes 8 (a) + 8 (out) + 8 x box fraction per voxel.
+__global__ __launch_bounds__(256) void k_mix_box_c1(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                                    int HW4 /* float4 per slice */, int W4 /* float4 per image row */,
+                                                    unsigned magic /* ceil(2^32 / W4) */, int D, int d0, int d1, int h0, int h1, int w0,
+                                                    int w1) {
+  const int slice = blockIdx.y;                     // n * D + d
+  const int d = slice % D;
+  const bool d_in = (d >= d0) & (d < d1);           // workgroup-uniform
+  const long long base = (long long)slice * HW4;
+  for (int s = blockIdx.x * 256 + threadIdx.x; s < HW4; s += gridDim.x * 256) {
+    float4 v = ld4(a + (base + s) * 4);
+    if (d_in) {
+      const int h = (int)__umulhi((unsigned)s, magic);          // s / W4 (exact: the launcher checks HW4 * W4 < 2^32)
+      const int w = (s - h * W4) * 4;
+      if ((h >= h0) & (h < h1) & (w + 3 >= w0) & (w < w1)) {
+        const float4 vb = ld4(b + (base + s) * 4);
+        if ((w >= w0) & (w < w1)) v.x = vb.x;
+        if ((w + 1 >= w0) & (w + 1 < w1)) v.y = vb.y;
+        if ((w + 2 >= w0) & (w + 2 < w1)) v.z = vb.z;
+        if ((w + 3 >= w0) & (w + 3 < w1)) v.w = vb.w;
+      }
+    }
+    st4(out + (base + s) * 4, v);
+  }
+}
+
 // ---------------------------------------------------------------- pseudo-label (A5)
 // LA / pancreas: softmax over 2 channels, (p1 >= thres) -> uint8 (LA_BCP_train.py:57-60).
 __global__ __launch_bounds__(256) void k_plabel_bin(const float* __restrict__ logits, uint8_t* __restrict__ out,
@@ -212,6 +241,18 @@ extern "C" int bcp_mix_box(const float* a, const float* b, float* out, int N, in
   BCP_REQUIRE((W * C) % 4 == 0, "bcp_mix_box: W*C must be a multiple of 4");
   const long long n_vec = (long long)N * D * H * W * C / 4;
   BCP_REQUIRE(n_vec < (1LL << 29), "bcp_mix_box: tensor too large (>= 2^31 floats)");
+  const long long HW4 = (long long)H * (W / 4);
+  if (options().mix_c1 && C == 1 && W % 4 == 0 && HW4 * (W / 4) < (1LL << 32) && (long long)N * D <= 65535) {
+    const int W4 = W / 4;
+    const unsigned magic = (unsigned)(((1ULL << 32) + W4 - 1) / W4);      // W4 >= 1; W4 == 1: 2^32 does not fit -> h = s below
+    const int gx = (int)((HW4 + 255) / 256 > 64 ? 64 : (HW4 + 255) / 256);
+    if (W4 > 1) {
+      hipLaunchKernelGGL(k_mix_box_c1, dim3(gx, N * D), dim3(256), 0, (hipStream_t)stream, a, b, out, (int)HW4, W4, magic, D, box6[0],
+                         box6[0] + box6[3], box6[1], box6[1] + box6[4], box6[2], box6[2] + box6[5]);
+      BCP_CHECK_LAUNCH("bcp_mix_box");
+      return BCP_OK;
+    }
+  }
   if (n_vec <= (1LL << 20))
     hipLaunchKernelGGL(k_mix_box<1>, dim3(stream_grid(n_vec, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n_vec, D, H,
                        W, C, box6[0], box6[0] + box6[3], box6[1], box6[1] + box6[4], box6[2], box6[2] + box6[5]);

@@ -9,10 +9,9 @@ no shape arithmetic, no `torch.empty`, no wrapper layers (bench: host enqueue of
 What varies between passes lives in device memory: the Dropout3d / Dropout seeds (the recorded draws are `bcp_bernoulli_dev`
 launches reading the plan's seed table, which one `bcp_store_u64` launch refills from the network's seed stream before a replay)
 and the input, which is copied into the plan's static input buffer (one device copy).  So a recorded pass is a constant launch
-sequence -- and CAN be captured: with GRAPHS >= 1 and the caller on a real (non-null) stream, the first replay of a FORWARD pass runs under HIP
-stream capture and every later one is ONE `hipGraphLaunch` (`bcp_graph_launch`); the backward pass captures too (event fork / join onto
-the weight-gradient side stream included; GRAPHS = 2).  Off by default since round 4 -- see GRAPHS below: a graph running beside another
-stream's work did not reproduce the eager results bit for bit.  Stream-ordering calls (`wait_stream`) and data-parallel bucket hooks are recorded as Python callables in
+sequence -- and IS captured: with GRAPHS >= 1 (the default) and the caller on a real (non-null) stream, the first replay of a FORWARD pass runs
+under HIP stream capture and every later one is ONE `hipGraphLaunch` (`bcp_graph_launch`); the backward pass can be captured too (event fork /
+join onto the weight-gradient side stream included; GRAPHS = 2, not the default: see GRAPHS below).  Stream-ordering calls (`wait_stream`) and data-parallel bucket hooks are recorded as Python callables in
 place.  Weight packing is NOT recorded: it depends on the weights' version and runs eagerly before a replay.
 
 The reference has no counterpart (its host path is PyTorch's eager dispatch); this is the "launch plan" of VERDICT r01 item 4.
@@ -22,19 +21,20 @@ import contextlib
 import torch
 
 ENABLED = True          # module switch (tests compare a replayed step with an eager one)
-# Capture a plan's second pass in a HIP graph when the caller runs on a real (non-null) stream.  0: never (the default since round 4);
-# 1: forward passes; 2: also the backward pass.
-# Why 0.  Round 4, ROCm 7.2 / MI355X (tools/probe/graph_concurrency_probe.py, tools/sessions/r04_s32.sh): with the teacher's forward
-# graph running on its side stream BESIDE the student's work on the main stream, the teacher's logits deviated from the eager path's in
-# 24 of 150 runs of a small ACDC step (checksum off by 1e-5, 3-6 pseudo-label pixels; the eager path and the graph-less replay: 0 of
-# 150 each; a host synchronisation behind every hipGraphLaunch: 0 of 150 -- a graph is right when it runs alone; an empty kernel behind
-# the launch, agent-scope loads of the |max| slots and a synchronisation IN FRONT of the launch changed nothing).  Parity first: the
-# passes stay per-launch replays from C (bcp_replay_run), which cost the GPU nothing -- LA 5.33-5.36 ms either way, ACDC 3.38 / 3.38,
-# pancreas 4.94 / 4.95 -- and the host 0.4-0.8 ms more per step (LA 3.6 -> 4.4 ms of enqueue against 5.3 ms of GPU time).
-# Earlier measurements, kept for the record: (round 2, LA step, same box, interleaved) per-launch replay 6.89 ms / host 2.6-3.0 ms;
-# forward graphs 6.90 ms / host 1.8-2.2 ms; forward + backward graphs 7.66-7.71 ms / host 1.5-1.8 ms -- inside a graph the weight-gradient
-# branch no longer overlaps the dgrad -> norm chain the way the side stream does (round 4: LA 5.81-5.92 vs 5.34-5.38, ACDC 3.83-3.93 vs 3.54).
-GRAPHS = 0
+# Capture a plan's second pass in a HIP graph when the caller runs on a real (non-null) stream.  0: never; 1: forward passes (the default
+# again since round 5); 2: also the backward pass.
+# History.  Round 4 switched capture off: with the teacher's forward graph on its side stream BESIDE the student's work, the teacher's logits
+# deviated from the eager path's in 24 of 150 runs of a small ACDC step -- and the driver's box then showed the same signature WITHOUT graphs
+# (per-launch replays, GPUTEST_r04).  Round 5 found the cause outside this module: the round-4 build of k_bilinear2x_fwd returned wrong values
+# for a quarter wave in 4-7 % of its launches whenever the bf16-pipe convs shared its CUs under load (DESIGN.md section 4,
+# tools/probe/bilinear_race_probe.py) -- a graph merely packed the two streams' kernels more tightly.  With the rebuilt kernel: graphs = 1 and
+# graphs = 2 beside the teacher stream under the load generator 0 of 150 runs each, LA 0 of 80 (tools/probe/replay_stress.py,
+# gpurun_out/r05_s11), per-launch replays 0 of 450.
+# What capture buys (round 5, gpurun_out/r05_s13/graphs_ab.txt, two interleaved pairs): nothing on the GPU -- LA 5.47 / 5.47 ms, ACDC 3.45 /
+# 3.44, pancreas 5.01 / 5.01 -- and 0.6-1.1 ms of host time per step (LA 2.7 -> 1.6 ms of enqueue, ACDC 1.9 -> 1.4, pancreas 2.5 -> 1.8): room
+# for the input pipeline and the Python around the step.  The backward pass stays a per-launch replay: inside a graph the weight-gradient
+# branch no longer overlaps the dgrad -> norm chain the way the side stream does (round 4: LA 5.81-5.92 vs 5.34-5.38 ms).
+GRAPHS = 1
 C_REPLAY = True         # replay runs of recorded launches from C (bcp_replay_run: one foreign call per run); False: one ctypes call per launch
 _EPOCH = [0]            # bumped when library options change: every plan recorded before is dropped
 

@@ -47,7 +47,12 @@ def R(rng, *shape):
 # ----------------------------------------------------------------------------------------------
 def check_mix_box(ops, dev):
     rng = np.random.default_rng(0)
-    for shape, box in (((2, 6, 8, 12, 1), (1, 2, 3, 4, 5, 6)), ((1, 1, 16, 16, 1), (0, 3, 4, 1, 10, 9)), ((2, 4, 4, 8, 16), (0, 0, 0, 2, 2, 4))):
+    # (single-channel shapes take k_mix_box_c1 when W % 4 == 0: box edges off the float4 grid, boxes touching every border, an empty box,
+    #  the whole volume, a row length that is not a power of two; W = 6 and C = 16 take the general kernel)
+    for shape, box in (((2, 6, 8, 12, 1), (1, 2, 3, 4, 5, 6)), ((1, 1, 16, 16, 1), (0, 3, 4, 1, 10, 9)), ((2, 4, 4, 8, 16), (0, 0, 0, 2, 2, 4)),
+                       ((2, 5, 7, 20, 1), (0, 0, 0, 5, 7, 20)), ((2, 5, 7, 20, 1), (4, 6, 17, 1, 1, 3)), ((1, 3, 9, 80, 1), (1, 2, 5, 2, 6, 70)),
+                       ((3, 1, 32, 32, 1), (0, 9, 13, 1, 21, 18)), ((1, 2, 4, 8, 1), (0, 0, 0, 0, 0, 0)), ((1, 2, 3, 6, 2), (1, 1, 1, 1, 2, 3)),
+                       ((2, 3, 5, 4, 1), (1, 1, 1, 2, 3, 2))):
         a, b = R(rng, *shape).to(dev), R(rng, *shape).to(dev)
         out = ops.mix_box(a, b, box)
         m = torch.ones(shape[1:4])

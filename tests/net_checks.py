@@ -1184,19 +1184,19 @@ class LoadGenerator:
         self.s.synchronize()
 
 
-def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=False, overlap=True, real_stream=False,
+def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=None, overlap=True, real_stream=False,
                        load=None):
     """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net
     (grouped and as the reference's four separate calls -- the second student call must not reuse the busy plan), the pancreas
     V-Net and the ACDC U-Net, live Dropout / Dropout3d (the seeds are patched into the recorded launches), weights, teacher
     weights and running statistics compared after the last step.
     load: a LoadGenerator -- every step of the REPLAYED run starts behind a burst of copies / GEMMs on a third stream (round 5)
-    graphs (GPU, plan.GRAPHS for the replayed run; not the default since round 4): pass overlap=False with it -- a captured pass reproduces
-    the eager bits when it runs ALONE; beside another stream's work (the teacher under the student) it did not (bcp_amd/plan.py)"""
+    graphs (GPU): plan.GRAPHS for the replayed run -- None: the module's default (1 since round 5: forward passes captured when the run
+    lives on a real stream), 0 / False: per-launch replays only, 2: the backward pass captured too"""
     from bcp_amd import plan, train_step
 
     def run(enabled, what, grouped):
-        if enabled and (graphs or real_stream):
+        if enabled and (graphs or real_stream):      # (graphs=None with the default >= 1 also captures -- when real_stream puts the run on one)
             # graphs / real_stream (GPU only): the replayed run lives on a real stream as in the training scripts and bench.py; with graphs
             # the first replay of every pass is captured and
             # the later ones are single hipGraphLaunch calls (side-stream weight gradients inside the graph)
@@ -1211,8 +1211,8 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
     def run_(enabled, what, grouped):
         plan.ENABLED = enabled
         level0 = plan.GRAPHS
-        if graphs:
-            plan.GRAPHS = int(graphs)      # 1: forward passes (the default), 2: the backward pass with its side-stream fork / join too
+        if graphs is not None:
+            plan.GRAPHS = int(graphs)      # 0: per-launch replays, 1: forward passes (the default), 2: the backward pass with its side-stream fork / join too
         try:
             torch.manual_seed(5)
             np.random.seed(5)
@@ -1297,3 +1297,57 @@ def check_fused_head(ops, dev, steps=2):
             if a[1][k].dtype.is_floating_point:
                 d = float((a[1][k] - b[1][k]).abs().max())
                 assert d <= 2e-5 * max(float(a[1][k].abs().max()), 1e-3), (what, k, d)
+
+
+def check_fp16_backward_long_run(ops, dev, steps=1000, probes=(0, 10, 100, 300, 600, 999), bound=2e-5, report=None):
+    """do the two-plane fp16 instances hold for dgrad / weight-gradient operands (dy is heavy-tailed, the planes' error is
+    absolute: 2^-22 of the tensor's |max|) as training moves the gradient distributions?  A small LA V-Net is trained for `steps`
+    self-training steps in the product configuration; at every probe the CURRENT state's gradients are computed twice from identical forward
+    bits (same kernels, same dropout seeds, forced pseudo-labels: same activation patterns) -- once with fp16 planes for dy (AMAX_BWD, the
+    default) and once with three bf16 planes for every launch that reads dy -- and compared per parameter tensor (rel-L2 of the difference).
+    Also: the |max| slots never promise less than their tensors hold (Ops.AMAX_CHECK) during the probes."""
+    from bcp_amd import plan, train_step
+    Opsc = type(ops)
+    torch.manual_seed(7); np.random.seed(7)
+    P = O.init_params(O.vnet_param_shapes(), seed=91, random_affine=True)
+    model, ema = make_vnet(P, dev, ops), make_vnet(P, dev, ops)
+    for p in ema.parameters():
+        p.detach_()
+    model.seed_dropout(21); ema.seed_dropout(22)
+    vol, lab = O.synth_la_batch(4, shape=(32, 32, 16), seed=92)
+    vol, lab = vol.to(dev), lab.to(dev)
+    opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    box = (3, 5, 2, 21, 21, 10)
+
+    def grads(bwd16):
+        b0, e0, c0 = Opsc.AMAX_BWD, plan.ENABLED, Opsc.AMAX_CHECK
+        Opsc.AMAX_BWD, plan.ENABLED, Opsc.AMAX_CHECK = bwd16, False, True
+        s0, s1 = model._drop_seed, ema._drop_seed
+        try:
+            model.mark_grads_stale()
+            r = train_step.la_self_train_step(model, ema, None, vol, lab, 2, box=box, plabs=(lab[2:3].to(torch.uint8), lab[3:4].to(torch.uint8)))
+            g = model.flat_grads().clone()
+            return g, float(r["loss"])
+        finally:
+            Opsc.AMAX_BWD, plan.ENABLED, Opsc.AMAX_CHECK = b0, e0, c0
+            model._drop_seed, ema._drop_seed = s0, s1
+
+    worst = 0.0
+    for it in range(steps):
+        if it in probes:
+            g16, l16 = grads(True)
+            gb, lb = grads(False)
+            assert l16 == lb, (it, l16, lb)                       # same forward bits
+            per = []
+            for i, off, q in train_step._opt_param_slices(model):
+                a, b = g16[off:off + q.numel()].double(), gb[off:off + q.numel()].double()
+                nb = float(b.norm())
+                if nb > 0:
+                    per.append(float((a - b).norm()) / nb)
+            w = max(per)
+            worst = max(worst, w)
+            if report is not None:
+                report.append((it, l16, w, float(np.median(per))))
+            assert w <= bound, (it, w)
+        train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=box)
+    return worst

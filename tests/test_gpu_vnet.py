@@ -190,30 +190,60 @@ def test_network_parity_with_bf16_pipe_conv_forced_everywhere(ops, golden_dir):
         ops.set_option("wgrad_b6")
 
 
+def test_fp16_backward_planes_hold_over_a_long_run(ops):
+    """fp16 planes for dgrad / weight-gradient operands vs three bf16 planes, on identical forward bits, probed along 1000
+    training steps (rel-L2 of the difference per parameter tensor)"""
+    rep = []
+    try:
+        NC.check_fp16_backward_long_run(ops, DEV, report=rep)
+    finally:
+        for it, loss, w, med in rep:
+            print("fp16-bwd long run step %4d: loss %.5f  worst tensor %.2e  median %.2e" % (it, loss, w, med))
+
+
 def test_recorded_launch_plans_equal_eager_path(ops):
     """bcp_amd/plan.py: replayed passes == the eager Python path, bit for bit (LA grouped / unfused, pancreas, ACDC; live dropout)"""
     NC.check_launch_plans(ops, DEV)
 
 
 def test_graph_replays_equal_eager_path(ops):
-    """opt-in capture (plan.GRAPHS >= 1; the default is the per-launch replay): hipGraphLaunch per network pass == the eager path, bit for
-    bit -- with the teacher on the student's stream (overlap=False).  A graph that runs BESIDE another stream's work did not reproduce the
-    eager bits on ROCm 7.2 (24 of 150 small ACDC runs: tools/probe/graph_concurrency_probe.py), which is why capture is off by default."""
+    """plan.GRAPHS: hipGraphLaunch per network pass == the eager path, bit for bit -- forward passes (1, the default) and forward + backward
+    (2), with the teacher on the student's stream and on its own side stream"""
     NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True), ("acdc", True)), graphs=1, overlap=False)
     NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("acdc", True)), graphs=2, overlap=False)      # + the backward pass
+    NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("acdc", True)), graphs=1, overlap=True)
+    NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True),), graphs=2, overlap=True)
 
 
 @pytest.mark.gpu
 def test_replayed_passes_beside_the_teacher_stream_equal_eager_path(ops):
-    """the product configuration: recorded passes replayed launch by launch, teacher forward on its side stream under the student's --
-    bit for bit the eager path (serial reference), 20 times over with a LOAD GENERATOR on a third stream.  Round 4's build failed this on
-    the driver's box; under the load generator it failed in 21-35 % of the runs on every box (k_bilinear2x_fwd)."""
+    """per-launch replays from C (plan.GRAPHS = 0), teacher forward on its side stream under the student's -- bit for bit the eager path
+    (serial reference), 20 times over with a LOAD GENERATOR on a third stream.  Round 4's build failed this on the driver's box; under the
+    load generator it failed in 21-35 % of the runs on every box (k_bilinear2x_fwd)."""
     load = NC.LoadGenerator(DEV)
     try:
         for _ in range(20):
-            NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True),), graphs=False, real_stream=True, load=load)
+            NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True),), graphs=0, real_stream=True, load=load)
         for _ in range(4):
-            NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True)), graphs=False, real_stream=True, load=load)
+            NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True)), graphs=0, real_stream=True, load=load)
+    finally:
+        load.finish()
+
+
+@pytest.mark.gpu
+def test_product_configuration_under_load_equals_eager_path(ops):
+    """what bench.py times and the scripts run: the module defaults (forward passes as HIP graphs, backward as per-launch replays, teacher on
+    its side stream, weight gradients on theirs) on a real stream, 20 times over beside the load generator; then forward + backward graphs"""
+    from bcp_amd import plan
+    assert plan.GRAPHS == 1 and plan.ENABLED and plan.C_REPLAY
+    load = NC.LoadGenerator(DEV)
+    try:
+        for _ in range(20):
+            NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True),), graphs=None, real_stream=True, load=load)
+        for _ in range(4):
+            NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True)), graphs=None, real_stream=True, load=load)
+        for _ in range(6):
+            NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True),), graphs=2, real_stream=True, load=load)
     finally:
         load.finish()
 
