@@ -19,5 +19,18 @@ cd /tmp
 rocprofv3 --kernel-trace -d /tmp/ev2 -o run --output-format csv -- python $R/bench.py --no-cpu-baseline --no-extra --no-roofline --steps 8 --warmup 4 > /tmp/ev2.log 2>&1
 cd $R
 python tools/timeline_attrib.py $(find /tmp/ev2 -name "*kernel_trace.csv" | head -1) --steps 4 --json $out/${tag}_timeline.json > $out/${tag}_timeline.txt
+# round 5: the determinism evidence next to the numbers -- the stress harness (product configuration and per-launch replays, load generator)
+# and the upsample reproducer on this build
+{ timeout 600 python tools/probe/replay_stress.py --what acdc --mode replay --load 1 --runs 150 --graphs 1 --tag product_graphs1 2>&1 | grep RESULT
+  timeout 600 python tools/probe/replay_stress.py --what acdc --mode replay --load 1 --runs 150 --graphs 0 --tag per_launch_replays 2>&1 | grep RESULT
+  timeout 600 python tools/probe/replay_stress.py --what la --mode replay --load 1 --runs 80 --tag la_default 2>&1 | grep RESULT
+  timeout 600 python tools/probe/replay_stress.py --what pancreas --mode replay --load 1 --runs 60 --tag pancreas_default 2>&1 | grep RESULT
+  timeout 300 python tools/probe/bilinear_race_probe.py rounds=60 workers=1 conv=1 load=1 gemm=1 2>&1 | grep RESULT
+  timeout 300 python tools/probe/bilinear_race_probe.py rounds=30 workers=2 conv=3 load=1 gemm=1 C=64 H=8 2>&1 | grep RESULT; } > $out/${tag}_determinism.txt 2>&1
+cat $out/${tag}_determinism.txt | cut -c1-260
+bash tools/probe/boxinfo.sh > $out/${tag}_box.txt 2>&1
+# ACDC kernel statistics (the LA ones are above)
+cd /tmp; rocprofv3 --kernel-trace --stats -d /tmp/ev3 -o ev --output-format csv -- python $R/bench.py --workload acdc --no-cpu-baseline --no-extra --steps 10 --warmup 2 > /tmp/ev3.log 2>&1
+f=$(find /tmp/ev3 -name "*kernel_stats.csv" | head -1); cp $f $out/${tag}_kernel_stats_acdc.csv; cd $R
 rm -f $out/${tag}_pytest_gpu_full.txt.gz; gzip -9 $out/${tag}_pytest_gpu_full.txt
 tail -40 $out/${tag}_pmc_ops.txt; head -20 $out/${tag}_timeline.txt
