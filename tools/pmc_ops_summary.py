@@ -1,5 +1,6 @@
 """Per-op counter summary of the passes written by tools/collect_pmc_ops.sh: the dispatch list of every pass is cut at the
-marker launches (k_ema on 64 elements), segment i belongs to op i of <dir>/ops.json, counters are summed over all kernels of
+marker launches (k_ema on 64 elements: before the warm-up call, before the measured calls, behind them), the middle segment of triple i
+belongs to op i of <dir>/ops.json, counters are summed over all kernels of
 the segment and divided by the repetitions.  FETCH_SIZE / WRITE_SIZE are in KB; FETCH_SIZE is doubled for the HBM estimate
 (MI355X_MICROARCH.md: gfx950 tallies 128-B read requests at 64 B for 16-B/lane streams).
    python tools/pmc_ops_summary.py <dir>  -> JSON {op: {counter: per-launch value, ...}}"""
@@ -31,7 +32,7 @@ for f in sorted(glob.glob(os.path.join(d, "pass*", "**", "*counter_collection.cs
             cur, started = [], True
         elif started:
             cur.append(i)
-    segs = segs[1::2]          # [warm-up, measured] pairs: keep the measured ones
+    segs = segs[1::3]          # [warm-up, measured, set-up of the next op] triples: keep the measured ones (round 5: third marker)
     if len(segs) != len(plan):
         print(f"warning: {f}: {len(segs)} segments for {len(plan)} ops", file=sys.stderr)
     for p, seg in zip(plan, segs):
@@ -53,7 +54,7 @@ for f in sorted(glob.glob(os.path.join(d, "pass1", "**", "*kernel_trace.csv"), r
             cur, started = [], True
         elif started:
             cur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    for p, seg in zip(plan, segs[1::2]):
+    for p, seg in zip(plan, segs[1::3]):
         out[p["op"]]["avg_us"] = sum(seg) / p["reps"] / 1e3
 for p in plan:
     o = out[p["op"]]
