@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 501      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 502      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int
@@ -121,6 +121,7 @@ _SIGS = {
     "bcp_replay_create": (I, [C.POINTER(P)]),
     "bcp_replay_add": (I, [P, P, C.c_char_p, P, I]),
     "bcp_replay_run": (I, [P]),
+    "bcp_replay_run_timed": (I, [P, P, P, P]),
     "bcp_replay_count": (I, [P]),
     "bcp_replay_destroy": (I, [P]),
     "bcp_stream_wait_stream": (I, [P, P]),

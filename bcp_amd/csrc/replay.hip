@@ -80,6 +80,22 @@ extern "C" int bcp_replay_run(void* h) {
   return BCP_OK;
 }
 
+// Measurement twin of bcp_replay_run (round 5, bench.py's per-op table): the same walk with HIP events recorded around chosen entries ON THE
+// ENTRY'S OWN STREAM -- ev_before[i] in front of entry i, ev_after[i] behind it (NULL: none; streams[i] = the stream that entry launches on).
+// The host stays as far ahead of the GPU as in the timed region, so an (event before op, event behind op) pair brackets the op's kernels as
+// they run INSIDE the step -- beside the other streams' work -- which the eager profile steps of rounds 1-4 could not (their host was the
+// bottleneck: every bracket held the Python between the record and the launch, 8 % on a 55 us kernel, 3 ms where the allocator stalled).
+extern "C" int bcp_replay_run_timed(void* h, void* const* ev_before, void* const* ev_after, void* const* streams) {
+  BCP_REQUIRE(h && ev_before && ev_after && streams, "bcp_replay_run_timed: null");
+  const std::vector<bcp::Entry>& e = static_cast<bcp::Replay*>(h)->e;
+  for (size_t i = 0; i < e.size(); ++i) {
+    if (ev_before[i] && hipEventRecord((hipEvent_t)ev_before[i], (hipStream_t)streams[i]) != hipSuccess) { bcp::set_error("bcp_replay_run_timed: hipEventRecord failed"); return BCP_ELAUNCH; }
+    if (const int rc = e[i].call(e[i].fn, e[i].a)) return rc;
+    if (ev_after[i] && hipEventRecord((hipEvent_t)ev_after[i], (hipStream_t)streams[i]) != hipSuccess) { bcp::set_error("bcp_replay_run_timed: hipEventRecord failed"); return BCP_ELAUNCH; }
+  }
+  return BCP_OK;
+}
+
 extern "C" int bcp_replay_destroy(void* h) {
   delete static_cast<bcp::Replay*>(h);
   return BCP_OK;

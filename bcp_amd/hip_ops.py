@@ -879,10 +879,24 @@ _PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_f
 def _profiled(name, fn):
     def wrapper(self, *a, **k):
         prof = self._prof
+        rec = self.b._rec
+        if rec is not None and not k.get("stats_only"):
+            # a pass is being recorded (bcp_amd/plan.py): note which of its launches belong to this op, so that a profiled REPLAY can put
+            # its events around the same launches (LaunchPlan.run_entries_timed) -- the op's shape key is taken here, once
+            ts = [t for t in a if isinstance(t, torch.Tensor)]
+            n0 = len(rec.entries)
+            r = fn(self, *a, **k)
+            if ts:
+                rec.spans.append((name, tuple(tuple(t.shape) for t in ts[:3]), tuple(x for x in a if isinstance(x, int))[:3],
+                                  sum(1 for t in ts[:2] if getattr(t, "_bcp_amax", None) is not None), n0, len(rec.entries)))
+            return r
         if prof is None or k.get("stats_only"):      # (statistics-only norm_fwd behind a fused conv epilogue = one finalize launch: not an op row)
             return fn(self, *a, **k)
         ts = [t for t in a if isinstance(t, torch.Tensor)]
         like = ts[0]
+        from . import plan as _plan
+        if _plan.PROFILE_ONLY is not None and (name, tuple(like.shape)) not in _plan.PROFILE_ONLY:
+            return fn(self, *a, **k)
         e0, e1 = self._prof_event(), self._prof_event()
         self.event_record(e0, like)
         r = fn(self, *a, **k)

@@ -35,6 +35,13 @@ ENABLED = True          # module switch (tests compare a replayed step with an e
 # for the input pipeline and the Python around the step.  The backward pass stays a per-launch replay: inside a graph the weight-gradient
 # branch no longer overlaps the dgrad -> norm chain the way the side stream does (round 4: LA 5.81-5.92 vs 5.34-5.38 ms).
 GRAPHS = 1
+PROFILE = None          # bench.py's per-op table: an Ops whose profile_begin() is live -- replays then go launch by launch through
+                        # bcp_replay_run_timed with HIP events around every recorded op (LaunchPlan.spans), graphs bypassed; the host still
+                        # runs ahead of the GPU, so the brackets hold the ops as they run inside the step
+PROFILE_ONLY = None      # None: every recorded op gets its pair of events; a set of (op name, first tensor's shape): only those -- every event is a
+                        # marker packet between two kernels (the fully bracketed LA step runs 6.7 instead of 5.4 ms and a 55 us conv reads
+                        # 72 us), so bench.py ranks the ops with everything bracketed and then times the dominant ones ALONE in an otherwise
+                        # undisturbed step
 C_REPLAY = True         # replay runs of recorded launches from C (bcp_replay_run: one foreign call per run); False: one ctypes call per launch
 _EPOCH = [0]            # bumped when library options change: every plan recorded before is dropped
 
@@ -49,7 +56,7 @@ def epoch():
 
 class LaunchPlan:
     __slots__ = ("entries", "keep", "n_seeds", "seed_dev", "static_in", "result", "ticks", "n_calls", "busy", "graph", "graph_state",
-                 "capturable", "forks", "_owner", "segs", "_handles")
+                 "capturable", "forks", "_owner", "segs", "_handles", "spans", "_seg_of", "_timed")
 
     MAX_SEEDS = 16
 
@@ -70,6 +77,10 @@ class LaunchPlan:
         self._owner = None
         self.segs = None         # compiled form of `entries` (compile)
         self._handles = []
+        self.spans = []          # (op name, shapes, ints, operands carrying |max|, first entry, one past the last entry) of every profiled op of
+                                 # the pass, noted while recording (hip_ops._profiled): what bench.py's per-op events bracket in a replay
+        self._seg_of = None      # entry index -> (segment index, index inside the segment's C handle) (compile)
+        self._timed = None
 
     # called by Binding.call while recording
     def add_call(self, name, fn, args):
@@ -98,8 +109,9 @@ class LaunchPlan:
         import ctypes as C
         from . import _lib
         segs, cur = [], None
+        seg_of, n_in = {}, 0
         run = b._fns["bcp_replay_run"][0]
-        for fn, args, name in self.entries:
+        for ei, (fn, args, name) in enumerate(self.entries):
             if name is None or not C_REPLAY:
                 cur = None
                 segs.append((fn, args))
@@ -111,14 +123,56 @@ class LaunchPlan:
                 self._handles.append(cur)
                 self._owner = b
                 segs.append((run, [cur]))
+                n_in = 0
             shape = _lib.shape_of(name)
             if b.cdll.bcp_replay_add(cur, C.cast(fn, C.c_void_p), shape.encode(), _lib.pack_slots(shape, args), len(args)):
                 raise _lib.BcpError(f"{name}: {b.last_error()}")
+            seg_of[ei] = (len(segs) - 1, n_in)
+            n_in += 1
         self.segs = segs
+        self._seg_of = seg_of
 
     def run_entries(self, check):
         for fn, args in self.segs:
             rc = fn(*args)
+            if rc:
+                check(rc)
+
+    def run_entries_timed(self, ops, check):
+        """one pass, launch by launch from C, with a HIP event in front of and behind every recorded op (self.spans) on the stream the op's
+        first / last launch uses; the (op, shapes, ints, events) records go to ops._prof like the eager wrappers' (hip_ops._profiled)"""
+        import ctypes as C
+        b = ops.b
+        if self._timed is None:
+            # per C segment: entry count and the stream of every entry (the last argument of every launch entry point is its stream;
+            # bcp_stream_wait_stream has none and is never the first / last launch of an op)
+            per = {}
+            for ei, (si, li) in self._seg_of.items():
+                per.setdefault(si, []).append((li, self.entries[ei][1][-1] if self.entries[ei][2] != "bcp_stream_wait_stream" else None))
+            self._timed = {si: [st for _, st in sorted(v)] for si, v in per.items()}
+        arrays = {}
+        for si, streams in self._timed.items():
+            n = len(streams)
+            arrays[si] = ((C.c_void_p * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(*[C.c_void_p(s or 0) for s in streams]))
+        for name, shapes, ints, namax, n0, n1 in self.spans:
+            first, last = self._seg_of.get(n0), self._seg_of.get(n1 - 1)
+            if first is None or last is None or n1 <= n0:
+                continue                     # (an op that starts or ends with a Python callable: not bracketed)
+            if PROFILE_ONLY is not None and (name, shapes[0] if shapes else ()) not in PROFILE_ONLY:
+                continue
+            if arrays[first[0]][0][first[1]] or arrays[last[0]][1][last[1]]:
+                continue                     # (a wrapper that only forwards to another profiled op, e.g. a dgrad served by conv3_fwd: the inner
+                                             #  op has the slot -- one event per launch boundary, and no launch is counted twice)
+            e0, e1 = ops._prof_event(), ops._prof_event()
+            arrays[first[0]][0][first[1]] = e0
+            arrays[last[0]][1][last[1]] = e1
+            ops._prof.append((name, shapes, ints, e0, e1, namax))
+        timed = b._fns["bcp_replay_run_timed"][0]
+        for si, (fn, args) in enumerate(self.segs):
+            if si in arrays:
+                rc = timed(args[0], arrays[si][0], arrays[si][1], arrays[si][2])
+            else:
+                rc = fn(*args)
             if rc:
                 check(rc)
 
@@ -129,6 +183,9 @@ class LaunchPlan:
             self.compile(b)
         if self.n_seeds:
             ops.store_u64(self.seed_dev, seeds, like)
+        if PROFILE is not None and PROFILE._prof is not None and C_REPLAY:
+            self.run_entries_timed(PROFILE, b.check_replayed)
+            return
         if self.graph is not None:
             b.call("bcp_graph_launch", self.graph, ops.stream(like))
             return

@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 501
+#define BCP_ABI_VERSION 502
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -357,6 +357,10 @@ int bcp_replay_create(void** handle);
 int bcp_replay_add(void* handle, void* fn, const char* shape, const void* slots, int nargs);
 int bcp_replay_count(void* handle);
 int bcp_replay_run(void* handle);
+/* measurement twin (bench.py's per-op table): the same walk with HIP events recorded around chosen entries on the entry's own stream --
+ * ev_before[i] in front of entry i, ev_after[i] behind it (hipEvent_t as void*, NULL: none), streams[i] = the stream entry i launches on;
+ * three HOST arrays of bcp_replay_count(handle) elements */
+int bcp_replay_run_timed(void* handle, void* const* ev_before, void* const* ev_after, void* const* streams);
 int bcp_replay_destroy(void* handle);
 /* stream ordering inside such a list: `waiter` waits for everything enqueued on `signaller` so far (event record + wait; capturable) */
 int bcp_stream_wait_stream(void* waiter, void* signaller);

@@ -183,7 +183,7 @@ def run_(mode, overlap, wgrad, deep, graphs=0):
 
         def fwd(*a, **k):
             r = orig(*a, **k)
-            tl.append((r[0] if isinstance(r, tuple) else r).double().sum())      # teacher logits checksum, on the teacher's stream
+            tl.append((r[0] if isinstance(r, (tuple, list)) else r).double().sum())      # teacher logits checksum, on the teacher's stream
             return r
         ema.forward = fwd
         out, deepout = [], []
