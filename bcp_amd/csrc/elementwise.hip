@@ -64,10 +64,12 @@ __global__ __launch_bounds__(256) void k_mix_box(const float* __restrict__ a, co
   }
 }
 
-// Single-channel images (C == 1, W % 4 == 0: every input of the three training loops).  Round 5: the general kernel above spends six
-// 32-bit divisions per 16 bytes on its (d, h, w) coordinates -- 30 us for one 8 MB LA batch at the head of the student's stream, 0.8 TB/s
-// (profiles/r04_t5_pmc_ops.txt).  Here a workgroup row (blockIdx.y) is one (n, d) slice, the row index inside it is one multiply-high by a
-// host-computed reciprocal, and `b` is read only where the box is: algorithmic bytes 8 (a) + 8 (out) + 8 x box fraction per voxel.
+// Single-channel images (C == 1, W % 4 == 0: every input of the three training loops), round 5.  The general kernel above spends six
+// 32-bit divisions per 16 bytes on its (d, h, w) coordinates and reads both inputs everywhere; here a workgroup row (blockIdx.y) is one
+// (n, d) slice, the row index inside it is one multiply-high by a host-computed reciprocal, and `b` is read only where the box is:
+// algorithmic bytes 8 (a) + 8 (out) + 8 x box fraction per voxel -- 5.0 us for one 8 MB LA batch, 3.6 TB/s (profiles/r05_t2_pmc_ops.txt).
+// (The "30 us, 58.5 MB written" rounds 2-4 reported for the mix were the profiling script's own torch.randn launches, DESIGN.md section 5;
+// inside the step the two kernels are indistinguishable: 5.541 vs 5.524 ms.)
 __global__ __launch_bounds__(256) void k_mix_box_c1(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
                                                     int HW4 /* float4 per slice */, int W4 /* float4 per image row */,
                                                     unsigned magic /* ceil(2^32 / W4) */, int D, int d0, int d1, int h0, int h1, int w0,
