@@ -182,7 +182,7 @@ def main(argv=None):
         for seed_fn in (torch.manual_seed, random.seed, np.random.seed):
             seed_fn(args.seed)
     device = torch.device("cuda", torch.cuda.current_device())
-    plan.use_real_stream(device)      # a real stream: what plan.GRAPHS >= 1 (opt-in capture of the recorded passes) needs; harmless otherwise (bcp_amd/plan.py)
+    plan.use_real_stream(device)      # a real stream: what the capture of the recorded forward passes into HIP graphs needs (plan.GRAPHS = 1, the default; bcp_amd/plan.py)
     phase_dirs = ["./model/BCP/ACDC_{}_{}_labeled/{}".format(args.exp, args.labelnum, phase) for phase in ("pre_train", "self_train")]
     for d in phase_dirs:
         os.makedirs(d, exist_ok=True)

@@ -120,7 +120,7 @@ def main(argv=None):
     np.random.seed(seed_test)
     torch.manual_seed(seed_test)
     device = torch.device("cuda", torch.cuda.current_device())
-    plan.use_real_stream(device)      # a real stream: what plan.GRAPHS >= 1 (opt-in capture of the recorded passes) needs; harmless otherwise
+    plan.use_real_stream(device)      # a real stream: what the capture of the recorded forward passes into HIP graphs needs (plan.GRAPHS = 1, the default)
     net, ema_net = create_Vnet(), create_Vnet(ema=True)
     ema_net.load_state_dict(net.state_dict())
     optimizer = train_step.FlatAdam(net, lr=lr)
