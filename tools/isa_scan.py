@@ -6,7 +6,8 @@ values for 8-16 consecutive lanes (one input corner's dwords 1 and 3 counted as 
 packed-fp32 instruction in the kernel) or with this round's |max| expression (packed fma / mul in their plain forms only): 0 of 7680.  A full
 s_waitcnt vmcnt(0) in front of the consumers did not help; what the failing build had and no passing build has are the SWIZZLED packed forms --
 v_pk_mov_b32 ... op_sel:[1,0] and v_pk_mul_f32 / v_pk_fma_f32 with op_sel:[..] -- so those are what this gate keeps out of the kernels that
-run beside the convs and do not need them (pool2d.hip, elementwise.hip, eval.hip: HBM-bound, compiled with -fno-slp-vectorize).
+run beside the convs and do not need them (pool2d.hip, elementwise.hip, eval.hip, gemm.hip: HBM-bound streams and latency-bound small GEMMs,
+compiled with -fno-slp-vectorize).
 
   python tools/isa_scan.py            # gate: exit 1 if a plumbing kernel contains a swizzled packed-fp32 instruction
   python tools/isa_scan.py --report   # + per-kernel census of those forms over the whole library (information: conv / GEMM epilogues have some)
@@ -19,7 +20,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "bcp_amd", "csrc")
 SWIZZLED = re.compile(r"^\s*(v_pk_mov_b32\b.*|v_pk_\w+_f32\b.*\bop_sel:\[)")
-PLUMBING = ("pool2d", "elementwise", "eval")
+LABEL = re.compile(r"^([A-Za-z_][\w$]*):")            # a function label (not a .L local label, not a "; %bb.N:" comment)
+PLUMBING = ("pool2d", "elementwise", "eval", "gemm")
 
 
 def _flags(name):
@@ -50,8 +52,9 @@ def swizzled_sites(path):
     """[(kernel symbol, line number, instruction)] of the swizzled packed-fp32 instructions in one assembly file"""
     out, kernel = [], "?"
     for i, ln in enumerate(open(path).read().splitlines()):
-        if ln and not ln[0].isspace() and ln.rstrip().endswith(":") and not ln.startswith("."):
-            kernel = ln.split(":")[0]
+        m = LABEL.match(ln)
+        if m:
+            kernel = m.group(1)
         s = ln.split(";")[0]
         if SWIZZLED.match(s):
             out.append((kernel, i + 1, s.strip()))
