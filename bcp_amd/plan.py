@@ -25,9 +25,10 @@ ENABLED = True          # module switch (tests compare a replayed step with an e
 # again since round 5); 2: also the backward pass.
 # History.  Round 4 switched capture off: with the teacher's forward graph on its side stream BESIDE the student's work, the teacher's logits
 # deviated from the eager path's in 24 of 150 runs of a small ACDC step -- and the driver's box then showed the same signature WITHOUT graphs
-# (per-launch replays, GPUTEST_r04).  Round 5 found the cause outside this module: the round-4 build of k_bilinear2x_fwd returned wrong values
-# for a quarter wave in 4-7 % of its launches whenever the bf16-pipe convs shared its CUs under load (DESIGN.md section 4,
-# tools/probe/bilinear_race_probe.py) -- a graph merely packed the two streams' kernels more tightly.  With the rebuilt kernel: graphs = 1 and
+# (per-launch replays, GPUTEST_r04).  Round 5 found the cause outside this module: ONE instruction of the round-4 build of k_bilinear2x_fwd --
+# v_pk_mul_f32 with the halves of its second source crossed -- returns +-0 in lanes 48..63 whenever another kernel's wave on the same CU issues
+# 16-bit MFMAs, i.e. whenever the other network's bf16-pipe convs ran beside the upsample (DESIGN.md section 4.0,
+# tools/probe/pkmul_mfma_repro.hip) -- a graph merely packed the two streams' kernels more tightly.  With the rebuilt kernel: graphs = 1 and
 # graphs = 2 beside the teacher stream under the load generator 0 of 150 runs each, LA 0 of 80 (tools/probe/replay_stress.py,
 # gpurun_out/r05_s11), per-launch replays 0 of 450.
 # What capture buys (round 5, gpurun_out/r05_s13/graphs_ab.txt, two interleaved pairs): nothing on the GPU -- LA 5.47 / 5.47 ms, ACDC 3.45 /

@@ -22,6 +22,16 @@ def test_plumbing_kernels_have_no_swizzled_packed_fp32(tmp_path):
     assert not bad, bad[:5]
 
 
+def test_built_library_has_no_packed_multiply_with_a_crossed_multiplier_input():
+    """gate 1: the instruction tools/probe/pkmul_mfma_repro.hip shows returning +-0 beside 16-bit MFMAs is nowhere in libbcp_hip.so"""
+    import isa_scan
+    if not os.path.exists(isa_scan.LIB):
+        pytest.skip("libbcp_hip.so not built")
+    assert isa_scan.lib_gate() == []
+    assert isa_scan.CROSSED.match("\tv_pk_mul_f32 v[24:25], v[20:21], v[22:23] op_sel:[0,1] op_sel_hi:[1,0]").group(3) == "1"
+    assert isa_scan.CROSSED.match("\tv_pk_fma_f32 v[24:25], v[10:11], v[34:35], v[24:25] op_sel:[0,0,1] op_sel_hi:[1,1,0]").groups()[1:] == ("0", "0")
+
+
 def test_scanner_recognises_the_round4_forms(tmp_path):
     import isa_scan
     p = tmp_path / "k.s"

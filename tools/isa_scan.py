@@ -1,16 +1,22 @@
-"""tools/isa_scan.py -- instruction-level gate behind round 4's red test.
+"""tools/isa_scan.py -- instruction-level gates behind round 4's red test.
 
-What was measured (round 5, tools/probe/bilinear_race_probe.py, MI355X / ROCm 7.2): the round-4 build of k_bilinear2x_fwd returned wrong
-values for 8-16 consecutive lanes (one input corner's dwords 1 and 3 counted as zero) in 4-7 % of its launches whenever the bf16-pipe convs
-(MFMA + LDS-DMA) shared its CUs under a copy / GEMM load, and in none otherwise.  The same source compiled without the SLP vectoriser (no
-packed-fp32 instruction in the kernel) or with this round's |max| expression (packed fma / mul in their plain forms only): 0 of 7680.  A full
-s_waitcnt vmcnt(0) in front of the consumers did not help; what the failing build had and no passing build has are the SWIZZLED packed forms --
-v_pk_mov_b32 ... op_sel:[1,0] and v_pk_mul_f32 / v_pk_fma_f32 with op_sel:[..] -- so those are what this gate keeps out of the kernels that
-run beside the convs and do not need them (pool2d.hip, elementwise.hip, eval.hip, gemm.hip: HBM-bound streams and latency-bound small GEMMs,
-compiled with -fno-slp-vectorize).
+The cause, down to one instruction (round 5; tools/probe/pkmul_mfma_repro.hip is the stand-alone reproducer, tools/probe/isa_bisect.py the
+bisection that found it inside the round-4 build of k_bilinear2x_fwd; MI355X gfx950 / ROCm 7.2):
 
-  python tools/isa_scan.py            # gate: exit 1 if a plumbing kernel contains a swizzled packed-fp32 instruction
-  python tools/isa_scan.py --report   # + per-kernel census of those forms over the whole library (information: conv / GEMM epilogues have some)
+    v_pk_mul_f32 D, S0, S1 op_sel:[0,1] op_sel_hi:[1,0]        (packed fp32 multiply, the halves of the SECOND source crossed)
+
+returns D.lo = +-0 in lanes 48..63 whenever a wave of ANOTHER kernel on the same CU is issuing dense 16-bit MFMAs
+(v_mfma_f32_16x16x32_bf16 / _f16): 1908 of 1920 launches beside a pure MFMA loop, 0 of 1920 with the operands in plain order, 0 beside fp32
+MFMAs / LDS-DMA / LDS / VALU neighbours.  hipcc's SLP vectoriser emits the crossed form for float2 shuffles.  Two gates:
+
+  1. THE BUILT LIBRARY (what ships): no v_pk_mul_f32 / v_pk_fma_f32 anywhere whose LOW result takes the HIGH half of a multiplier input
+     (op_sel bit of source 0 or 1 set) -- disassembly of bcp_amd/csrc/libbcp_hip.so, two seconds; __graft_entry__.build() runs it.
+  2. the plumbing kernels (pool2d.hip, elementwise.hip, eval.hip, gemm.hip: HBM-bound streams and latency-bound small GEMMs that run beside the
+     convs and gain nothing from packed arithmetic) are compiled with -fno-slp-vectorize and must contain NO swizzled packed-fp32 instruction
+     at all (v_pk_mov_b32, v_pk_*_f32 with op_sel:[..]) -- checked on their assembly.
+
+  python tools/isa_scan.py            # both gates: exit 1 on a violation
+  python tools/isa_scan.py --report   # + per-kernel census of every swizzled packed form over the whole library (assembly of every source)
 """
 import os
 import re
@@ -68,11 +74,50 @@ def gate():
     return bad
 
 
+CROSSED = re.compile(r"^\s*(v_pk_(?:mul|fma)_f32)\b.*\bop_sel:\[([01]),([01])")       # op_sel bits of source 0 and source 1
+LIB = os.path.join(CSRC, "libbcp_hip.so")
+
+
+def lib_gate(lib=LIB):
+    """[(kernel, instruction)] of the packed multiplies / fmas of the BUILT library whose low result takes the high half of a multiplier
+    input (the form that fails beside 16-bit MFMAs); the library's code objects are extracted and disassembled in a scratch directory"""
+    import shutil
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        objdump = shutil.which("llvm-objdump") or objdump
+    out = []
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(lib, os.path.join(d, "lib.so"))
+        subprocess.run([objdump, "--offloading", "lib.so"], cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+        cos = [f for f in os.listdir(d) if "amdgcn" in f]
+        if not cos:
+            raise RuntimeError("no gfx950 code object found inside " + lib)
+        for f in sorted(cos):
+            kernel = "?"
+            dis = subprocess.run([objdump, "-d", f], cwd=d, capture_output=True, text=True, check=True).stdout
+            for ln in dis.splitlines():
+                m = re.match(r"^[0-9a-f]+ <([^>]+)>:", ln)
+                if m:
+                    kernel = m.group(1)
+                    continue
+                s = ln.split("//")[0]
+                c = CROSSED.match(s)
+                if c and (c.group(2) == "1" or c.group(3) == "1"):
+                    out.append((kernel, s.strip()))
+    return out
+
+
 def main(argv):
+    crossed = lib_gate() if os.path.exists(LIB) else []
+    for kernel, ins in crossed:
+        print(f"libbcp_hip.so: {kernel[:90]}: {ins}")
+    print(f"gate 1: {len(crossed)} packed fp32 multiply / fma with a crossed multiplier input in the built library" +
+          ("" if os.path.exists(LIB) else " (library not built: skipped)"))
     bad = gate()
     for n, kernel, line, ins in bad:
         print(f"{n}.hip: {kernel[:80]} line {line}: {ins}")
-    print(f"gate: {len(bad)} swizzled packed-fp32 instruction(s) in the plumbing kernels ({', '.join(p + '.hip' for p in PLUMBING)})")
+    print(f"gate 2: {len(bad)} swizzled packed-fp32 instruction(s) in the plumbing kernels ({', '.join(p + '.hip' for p in PLUMBING)})")
     if "--report" in argv:
         names = sorted(f[:-4] for f in os.listdir(CSRC) if f.endswith(".hip"))
         for n, path in assembly(names).items():
@@ -81,7 +126,7 @@ def main(argv):
                 per.setdefault(kernel, []).append(ins.split()[0])
             for kernel, ops in sorted(per.items(), key=lambda e: -len(e[1])):
                 print(f"  {n}.hip {kernel[:90]}: {len(ops)} ({', '.join(sorted(set(ops)))})")
-    return 1 if bad else 0
+    return 1 if (bad or crossed) else 0
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@
 #include <hip/hip_runtime.h>
 
 
-#define PK_CLOBBERS "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "memory"
+#define PK_CLOBBERS "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "memory"
 // WAIT: the s_waitcnt in front of the consumer; USE: the consumer (must leave the value in v56)
 #define PK_BODY(WAIT, USE)                                                                                                  \
   asm volatile("v_mov_b32 v49, 0xc0ffee00\n\t" /* sentinel: what a too-early read of the third load's second dword sees */  \
@@ -51,9 +51,68 @@ __global__ __launch_bounds__(256) void k_pk(const float* __restrict__ x, float* 
   // the partial one (7)
   if (V == 6) PK_BODY("s_waitcnt vmcnt(0)", "v_pk_mov_b32 v[40:41], v[48:49], v[40:41] op_sel:[1,0]\n\tv_pk_mov_b32 v[42:43], v[50:51], v[42:43] op_sel:[1,0]\n\tv_mov_b32 v56, v40");
   if (V == 7) PK_BODY("s_waitcnt vmcnt(1)", "v_pk_mov_b32 v[40:41], v[48:49], v[40:41] op_sel:[1,0]\n\tv_pk_mov_b32 v[42:43], v[50:51], v[42:43] op_sel:[1,0]\n\tv_mov_b32 v56, v40");
+  // 8 / 9 / 10: the instruction tools/probe/isa_bisect.py found guilty in the round-4 upsample kernel -- v_pk_mul_f32 with the halves of its
+  // SECOND source crossed (low result = S0.lo * S1.HI, high = S0.hi * S1.LO).  S1 = (2.0, 1.0) written by two v_mov_b32, so the low result
+  // must be the loaded dword v48 itself; 9: S0 written by the VALU too (v48 copied to v60 first); 10: the plain form on pre-swapped constants
+  if (V == 8) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 1.0\n\ts_waitcnt vmcnt(0)", "v_pk_mul_f32 v[56:57], v[48:49], v[58:59] op_sel:[0,1] op_sel_hi:[1,0]\n\tv_mov_b32 v49, v48");
+  if (V == 9) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 1.0\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32 v52, v48\n\tv_mov_b32 v53, v49", "v_pk_mul_f32 v[56:57], v[52:53], v[58:59] op_sel:[0,1] op_sel_hi:[1,0]\n\tv_mov_b32 v49, v48");
+  if (V == 10) PK_BODY("v_mov_b32 v58, 1.0\n\tv_mov_b32 v59, 2.0\n\ts_waitcnt vmcnt(0)", "v_pk_mul_f32 v[56:57], v[48:49], v[58:59]\n\tv_mov_b32 v49, v48");
+  // 11: the same crossing on a packed ADD (S1 = (2.0, 0.0): low = v48 + 0.0);  12: on the FIRST source instead (low = S0.HI * S1.lo, the form the
+  // bisection found innocent): S0 = (1.0, loaded) -> low = v48 * 1.0 with S0 = v[58:59] = (2.0, v48)
+  if (V == 11) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 0\n\ts_waitcnt vmcnt(0)", "v_pk_add_f32 v[56:57], v[48:49], v[58:59] op_sel:[0,1] op_sel_hi:[1,0]\n\tv_mov_b32 v49, v48");
+  if (V == 12) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v60, 1.0\n\tv_mov_b32 v61, 3.0\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32 v59, v48", "v_pk_mul_f32 v[56:57], v[58:59], v[60:61] op_sel:[1,0] op_sel_hi:[0,1]\n\tv_mov_b32 v49, v48");
   out[(long long)i * 3 + 0] = seen;
   out[(long long)i * 3 + 1] = later;
-  out[(long long)i * 3 + 2] = pc[1];
+  out[(long long)i * 3 + 2] = (V >= 8) ? pc[0] : pc[1];
+}
+
+// ---- stand-alone NEIGHBOURS (no library): which instruction class on the other stream makes the guilty multiply fail?
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float nb_f32x4;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 nb_bf16x8;
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 nb_f16x8;
+template <int KIND>
+__global__ __launch_bounds__(256) void k_nb(float* __restrict__ sink, const float* __restrict__ src, int iters) {
+  __shared__ __attribute__((aligned(16))) float lds[4096];
+  const int t = threadIdx.x;
+  nb_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  float v = (float)t * 1e-3f, w = 1.0001f;
+  if (KIND == 0) {                                   // dense bf16 MFMA, as the bf16-pipe convs issue
+    nb_bf16x8 a, b;
+    for (int k = 0; k < 8; ++k) { a[k] = (__bf16)(v + k); b[k] = (__bf16)(w + k); }
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+  } else if (KIND == 1) {                            // fp16 MFMA (the two-plane instances)
+    nb_f16x8 a, b;
+    for (int k = 0; k < 8; ++k) { a[k] = (_Float16)(v + k); b[k] = (_Float16)(w + k); }
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);
+  } else if (KIND == 2) {                            // fp32 MFMA
+    for (int i = 0; i < iters; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v, w, acc, 0, 0, 0);
+  } else if (KIND == 3) {                            // LDS-DMA: global -> LDS, 16 bytes per lane
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    for (int i = 0; i < iters; ++i) {
+      __builtin_amdgcn_global_load_lds(src + ((size_t)(blockIdx.x * 256 + t) * 4 + (size_t)(i & 63) * 262144) % (1 << 22), (lds_ptr_t)(lds + (t >> 6) * 256), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    acc[0] = lds[t];
+  } else if (KIND == 4) {                            // plain VALU fma chain
+    for (int i = 0; i < iters * 8; ++i) v = __builtin_fmaf(v, w, 0.5f);
+    acc[0] = v;
+  } else {                                           // LDS traffic (ds_write / ds_read)
+    for (int i = 0; i < iters; ++i) { lds[(t * 4 + i) & 4095] = v; __syncthreads(); v += lds[(t * 7 + i) & 4095]; }
+    acc[0] = v;
+  }
+  if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[t] = acc[0];
+}
+extern "C" int nb_run(int kind, float* sink, const float* src, int iters, int blocks, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  switch (kind) {
+    case 0: hipLaunchKernelGGL(k_nb<0>, dim3(blocks), dim3(256), 0, s, sink, src, iters); break;
+    case 1: hipLaunchKernelGGL(k_nb<1>, dim3(blocks), dim3(256), 0, s, sink, src, iters); break;
+    case 2: hipLaunchKernelGGL(k_nb<2>, dim3(blocks), dim3(256), 0, s, sink, src, iters); break;
+    case 3: hipLaunchKernelGGL(k_nb<3>, dim3(blocks), dim3(256), 0, s, sink, src, iters); break;
+    case 4: hipLaunchKernelGGL(k_nb<4>, dim3(blocks), dim3(256), 0, s, sink, src, iters); break;
+    default: hipLaunchKernelGGL(k_nb<5>, dim3(blocks), dim3(256), 0, s, sink, src, iters); break;
+  }
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 extern "C" int pk_run(int variant, const float* x, float* out, int rows, int C4, void* stream) {
@@ -69,6 +128,11 @@ extern "C" int pk_run(int variant, const float* x, float* out, int rows, int C4,
     case 5: hipLaunchKernelGGL(k_pk<5>, grid, block, 0, s, x, out, rows, C4); break;
     case 6: hipLaunchKernelGGL(k_pk<6>, grid, block, 0, s, x, out, rows, C4); break;
     case 7: hipLaunchKernelGGL(k_pk<7>, grid, block, 0, s, x, out, rows, C4); break;
+    case 8: hipLaunchKernelGGL(k_pk<8>, grid, block, 0, s, x, out, rows, C4); break;
+    case 9: hipLaunchKernelGGL(k_pk<9>, grid, block, 0, s, x, out, rows, C4); break;
+    case 10: hipLaunchKernelGGL(k_pk<10>, grid, block, 0, s, x, out, rows, C4); break;
+    case 11: hipLaunchKernelGGL(k_pk<11>, grid, block, 0, s, x, out, rows, C4); break;
+    case 12: hipLaunchKernelGGL(k_pk<12>, grid, block, 0, s, x, out, rows, C4); break;
     default: return -1;
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;
