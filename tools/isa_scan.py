@@ -7,7 +7,10 @@ bisection that found it inside the round-4 build of k_bilinear2x_fwd; MI355X gfx
 
 returns D.lo = +-0 in lanes 48..63 whenever a wave of ANOTHER kernel on the same CU is issuing dense 16-bit MFMAs
 (v_mfma_f32_16x16x32_bf16 / _f16): 1908 of 1920 launches beside a pure MFMA loop, 0 of 1920 with the operands in plain order, 0 beside fp32
-MFMAs / LDS-DMA / LDS / VALU neighbours.  hipcc's SLP vectoriser emits the crossed form for float2 shuffles.  Two gates:
+MFMAs / LDS-DMA / LDS / VALU neighbours.  The condition (tools/probe/pkmov_hazard.py variants 8-17): a packed fp32 multiply or fma whose LOW
+result takes its first multiplier input from a low half and its second from a HIGH half (op_sel:[0,1,..]); S1.lo broadcast (op_sel_hi only),
+the first source crossed, both crossed, packed adds: unaffected.  hipcc's SLP vectoriser emits the crossed form for float2 shuffles.  Two gates
+(the first forbids every op_sel bit on a multiplier input, a superset of the measured condition):
 
   1. THE BUILT LIBRARY (what ships): no v_pk_mul_f32 / v_pk_fma_f32 anywhere whose LOW result takes the HIGH half of a multiplier input
      (op_sel bit of source 0 or 1 set) -- disassembly of bcp_amd/csrc/libbcp_hip.so, two seconds; __graft_entry__.build() runs it.

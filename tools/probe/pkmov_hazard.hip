@@ -61,6 +61,12 @@ __global__ __launch_bounds__(256) void k_pk(const float* __restrict__ x, float* 
   // bisection found innocent): S0 = (1.0, loaded) -> low = v48 * 1.0 with S0 = v[58:59] = (2.0, v48)
   if (V == 11) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 0\n\ts_waitcnt vmcnt(0)", "v_pk_add_f32 v[56:57], v[48:49], v[58:59] op_sel:[0,1] op_sel_hi:[1,0]\n\tv_mov_b32 v49, v48");
   if (V == 12) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v60, 1.0\n\tv_mov_b32 v61, 3.0\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32 v59, v48", "v_pk_mul_f32 v[56:57], v[58:59], v[60:61] op_sel:[1,0] op_sel_hi:[0,1]\n\tv_mov_b32 v49, v48");
+  // 13 .. 17: which operand selections of a packed multiply / fma are affected (S0 = (x, x), constants chosen so that the low result must be x)
+  if (V == 13) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 1.0\n\tv_mov_b32 v60, 0\n\tv_mov_b32 v61, 0\n\ts_waitcnt vmcnt(0)", "v_pk_fma_f32 v[56:57], v[48:49], v[58:59], v[60:61] op_sel:[0,1,0] op_sel_hi:[1,0,1]\n\tv_mov_b32 v49, v48");   // fma, second source crossed
+  if (V == 14) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 1.0\n\ts_waitcnt vmcnt(0)", "v_pk_mul_f32 v[56:57], v[48:49], v[58:59] op_sel:[0,1]\n\tv_mov_b32 v49, v48");                  // S1.hi broadcast (both halves take S1.hi)
+  if (V == 15) PK_BODY("v_mov_b32 v58, 1.0\n\tv_mov_b32 v59, 2.0\n\ts_waitcnt vmcnt(0)", "v_pk_mul_f32 v[56:57], v[48:49], v[58:59] op_sel_hi:[1,0]\n\tv_mov_b32 v49, v48");               // S1.lo broadcast
+  if (V == 16) PK_BODY("v_mov_b32 v58, 2.0\n\tv_mov_b32 v59, 1.0\n\ts_waitcnt vmcnt(0)\n\tv_mov_b32 v52, 3.0\n\tv_mov_b32 v53, v48", "v_pk_mul_f32 v[56:57], v[52:53], v[58:59] op_sel:[1,1] op_sel_hi:[0,0]\n\tv_mov_b32 v49, v48");   // both sources crossed
+  if (V == 17) PK_BODY("v_mov_b32 v58, 1.0\n\tv_mov_b32 v59, 1.0\n\ts_waitcnt vmcnt(0)", "v_pk_mul_f32 v[56:57], v[48:49], v[58:59] op_sel:[0,1] op_sel_hi:[1,0]\n\tv_mov_b32 v49, v48");  // the guilty form with S1 = (1.0, 1.0): is it S1.hi read as 0, or the product?
   out[(long long)i * 3 + 0] = seen;
   out[(long long)i * 3 + 1] = later;
   out[(long long)i * 3 + 2] = (V >= 8) ? pc[0] : pc[1];
@@ -133,6 +139,11 @@ extern "C" int pk_run(int variant, const float* x, float* out, int rows, int C4,
     case 10: hipLaunchKernelGGL(k_pk<10>, grid, block, 0, s, x, out, rows, C4); break;
     case 11: hipLaunchKernelGGL(k_pk<11>, grid, block, 0, s, x, out, rows, C4); break;
     case 12: hipLaunchKernelGGL(k_pk<12>, grid, block, 0, s, x, out, rows, C4); break;
+    case 13: hipLaunchKernelGGL(k_pk<13>, grid, block, 0, s, x, out, rows, C4); break;
+    case 14: hipLaunchKernelGGL(k_pk<14>, grid, block, 0, s, x, out, rows, C4); break;
+    case 15: hipLaunchKernelGGL(k_pk<15>, grid, block, 0, s, x, out, rows, C4); break;
+    case 16: hipLaunchKernelGGL(k_pk<16>, grid, block, 0, s, x, out, rows, C4); break;
+    case 17: hipLaunchKernelGGL(k_pk<17>, grid, block, 0, s, x, out, rows, C4); break;
     default: return -1;
   }
   return hipGetLastError() == hipSuccess ? 0 : -2;

@@ -46,8 +46,10 @@ NAMES = {0: "v_pk_mov_b32 op_sel:[1,0] behind vmcnt(1)", 1: "v_mov_b32 behind vm
          3: "v_pk_mov_b32 op_sel:[0,0] behind vmcnt(1), then v_mov_b32 of the dword", 4: "v_pk_mov_b32 behind vmcnt(1) + s_nop 7", 5: "v_pk_add_f32 op_sel:[1,0] behind vmcnt(1)",
          6: "two v_pk_mov_b32 op_sel:[1,0] with destination == second source, behind vmcnt(0)", 7: "the same behind vmcnt(1)",
          8: "v_pk_mul_f32 S0=loaded pair, S1=(2.0,1.0) op_sel:[0,1] op_sel_hi:[1,0] (second source's halves crossed)", 9: "the same, S0 VALU-written",
-         10: "plain v_pk_mul_f32 on pre-swapped constants", 11: "v_pk_add_f32 with the second source's halves crossed", 12: "v_pk_mul_f32 with the FIRST source's halves crossed"}
-for variant in [int(v) for v in kv.get('variants', '0,1,2,3,4,5,6,7,8,9,10,11,12').split(',')]:
+         10: "plain v_pk_mul_f32 on pre-swapped constants", 11: "v_pk_add_f32 with the second source's halves crossed", 12: "v_pk_mul_f32 with the FIRST source's halves crossed",
+         13: "v_pk_fma_f32 with the second source's halves crossed", 14: "v_pk_mul_f32 op_sel:[0,1] (S1.hi to both halves)", 15: "v_pk_mul_f32 op_sel_hi:[1,0] (S1.lo to both halves)",
+         16: "v_pk_mul_f32 with BOTH sources' halves crossed", 17: "the guilty form with S1 = (1.0, 1.0)"}
+for variant in [int(v) for v in kv.get('variants', '0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17').split(',')]:
     bad_seen = bad_later = launches_bad = 0
     lanes = {}
     sentinel = 0
