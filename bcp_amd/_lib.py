@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 502      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 503      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int
@@ -93,6 +93,8 @@ _SIGS = {
     "bcp_pw16_bwd": (I, [P, P, P, P, P, P, L, I, I, P, P]),
     "bcp_pw16_fwd_norm": (I, [P, P, P, I, I, I, P, P, P, L, I, P]),
     "bcp_pw16_bwd_norm": (I, [P, P, P, I, I, I, P, P, P, P, P, L, I, I, P, P]),
+    "bcp_pw16_bwd_norm_bwd_workspace_bytes": (SZ, [I, I, L]),
+    "bcp_pw16_bwd_norm_bwd": (I, [P, P, P, I, I, I, P, P, P, P, P, P, P, I, L, I, I, P, P, P]),
     "bcp_colsum": (I, [P, L, I, P, I, P, P]),
     "bcp_maxpool2d_fwd": (I, [P, I, P, I, I, I, I, P, P, P]),
     "bcp_maxpool3d_k3s2_fwd": (I, [P, P, I, I, I, I, I, P]),

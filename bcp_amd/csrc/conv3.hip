@@ -1781,7 +1781,7 @@ namespace bcp {      // csrc/norm.hip
 void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s, float* amax_clear_or_null);
 void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
-                              float* c1c2raw, hipStream_t s);
+                              float* c1c2raw, hipStream_t s, float* amax_clear_or_null);
 }
 
 extern "C" size_t bcp_conv3_c1_norm_workspace_bytes(int N, int D, int H, int W, int KD, int groups) {
@@ -1823,7 +1823,7 @@ extern "C" int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float
   float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)groups * rows0 * 16 * 2);
   C1Norm nm{stats, da, c1c2raw, elem_mask, elem_scale, act, groups, nullptr, mask_seed, mask_p_keep};
   const int rows = c1_fwd_impl(x, w, bias, nullptr, N, D, H, W, KD, partial, groups, false, s, 3, &nm);
-  norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s);
+  norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s, nullptr);
   c1_fwd_impl(x, w, bias, dy, N, D, H, W, KD, nullptr, groups, false, s, 4, &nm);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_norm_bwd");
   return BCP_OK;

@@ -451,6 +451,177 @@ __global__ void k_pw16_finalize(const double* __restrict__ accum, float* __restr
   else if (i < CO * 16 + CO) db[i - CO * 16] = (accumulate ? db[i - CO * 16] : 0.f) + (float)accum[i];
 }
 
+// ---- round 5: the head's backward THROUGH the norm it applied on its way in (bcp_pw16_bwd_norm_bwd).  The gradient of the 16-channel
+// activation, da[v][c] = sum_co dy[v][co] w[co][c], is two fmas per element from an 8-byte read: cheaper to recompute than to write and
+// read back twice (128 MB each way at the LA size).  Pass 1 (k_pw16_bwd_stats) = k_pw16_bwd<CO, true> without the da store, plus the norm
+// layer's backward statistics (sum dz, sum dz * xhat; dz = da * chan_scale * act'(z)) in k_col_partial<1>'s arithmetic and partial-row
+// layout; the finalize kernels of norm.hip run in between; pass 2 (k_pw16_bwd_apply) recomputes da with the same fma chain and writes
+// dy = scale * (dz - c1 - xhat * c2), k_norm_bwd_apply's arithmetic.  Blocks are sample-uniform (blockIdx.y = sample), so any G | N works.
+// Thread = (voxel, four-channel group): da[c] and the head's dw[co][c] need nothing from the other channels of the voxel, so a thread keeps
+// one float4 column for the whole loop (per-channel parameters in registers, a wave reads 1 KiB contiguous per instruction, ~60 VGPRs);
+// the first version -- one thread per voxel, all 16 channels, k_pw16_bwd's shape -- needed 287.
+struct PwCol { float mu[4], sc[4], sh[4], cs[4], rs[4]; };
+__device__ __forceinline__ PwCol pw_col_load(const PwNorm& pn, int n, int col) {
+  PwCol q;
+  const int g = n / pn.spg;
+  const float4 mu = ld4(pn.stats + ((long long)0 * pn.G + g) * 16 + col * 4), rs = ld4(pn.stats + ((long long)1 * pn.G + g) * 16 + col * 4);
+  const float4 sc = ld4(pn.stats + ((long long)2 * pn.G + g) * 16 + col * 4), sh = ld4(pn.stats + ((long long)3 * pn.G + g) * 16 + col * 4);
+  float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (pn.chan_scale) cs = ld4(pn.chan_scale + n * 16 + col * 4);
+  q.mu[0] = mu.x; q.mu[1] = mu.y; q.mu[2] = mu.z; q.mu[3] = mu.w;
+  q.rs[0] = rs.x; q.rs[1] = rs.y; q.rs[2] = rs.z; q.rs[3] = rs.w;
+  q.sc[0] = sc.x; q.sc[1] = sc.y; q.sc[2] = sc.z; q.sc[3] = sc.w;
+  q.sh[0] = sh.x; q.sh[1] = sh.y; q.sh[2] = sh.z; q.sh[3] = sh.w;
+  q.cs[0] = cs.x; q.cs[1] = cs.y; q.cs[2] = cs.z; q.cs[3] = cs.w;
+  return q;
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void k_pw16_bwd_stats(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                        double* __restrict__ accum /* [CO*16 + CO] */,
+                                                        double* __restrict__ partial /* [G][spg * gridDim.x][16][2] */, PwNorm pn) {
+  constexpr int U = 4, NV = CO * 5 + 8;            // per thread: dw[co][4], db[co], (sum dz)[4], (sum dz * xhat)[4]
+  __shared__ double red[4][4][NV];
+  const int n = blockIdx.y, g = n / pn.spg, col = threadIdx.x & 3;
+  const PwCol q = pw_col_load(pn, n, col);
+  float wv[CO][4];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[co][k] = w[co * 16 + col * 4 + k];      // (a parameter view: no alignment promise)
+  }
+  double acc[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] = 0.0;
+  const float* xs = x + (long long)n * pn.vps * 16;
+  const float* ds = dy + (long long)n * pn.vps * CO;
+  auto one = [&](const float4& xv4, const float (&dv)[CO]) {
+    const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z = (xv[k] - q.mu[k]) * q.sc[k] + q.sh[k];
+      const float a = act_fwd(z, pn.act) * q.cs[k];                        // the head's input activation (never stored)
+      float s = 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) {
+        s = fmaf(dv[co], wv[co][k], s);
+        acc[co * 4 + k] += (double)dv[co] * (double)a;
+      }
+      const float g1 = s * q.cs[k] * act_grad(z, pn.act);
+      const float xh = (xv[k] - q.mu[k]) * q.rs[k];
+      acc[CO * 5 + k] += (double)g1;
+      acc[CO * 5 + 4 + k] += (double)g1 * (double)xh;
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) acc[CO * 4 + co] += (double)dv[co];
+  };
+  const long long nv = pn.vps * 4, stride = (long long)gridDim.x * 256;
+  long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; p + (U - 1) * stride < nv; p += U * stride) {
+    float4 xv[U];
+    float dv[U][CO];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long pp = p + u * stride;
+      xv[u] = ld4(xs + pp * 4);
+#pragma unroll
+      for (int co = 0; co < CO; ++co) dv[u][co] = ds[(pp >> 2) * CO + co];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(xv[u], dv[u]);
+  }
+  for (; p < nv; p += stride) {
+    const float4 xv = ld4(xs + p * 4);
+    float dv[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) dv[co] = ds[(p >> 2) * CO + co];
+    one(xv, dv);
+  }
+  // lanes with equal column are 4 apart: xor-shuffles over 4, 8, 16, 32, then one LDS hop over the four waves
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) acc[i] += __shfl_xor(acc[i], o);
+  }
+  if (lane < 4) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) red[wid][lane][i] = acc[i];
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < CO * 17) {
+    const int co = t < CO * 16 ? t >> 4 : t - CO * 16, c = t & 15;
+    const int cl = t < CO * 16 ? c >> 2 : 0, i = t < CO * 16 ? co * 4 + (c & 3) : CO * 4 + co;     // db: every column summed all voxels, take column 0's
+    atomicAdd(&accum[t], red[0][cl][i] + red[1][cl][i] + red[2][cl][i] + red[3][cl][i]);
+  } else if (t >= 128 && t < 160) {
+    const int e = t - 128, ch = e >> 1, i = CO * 5 + (e & 1) * 4 + (ch & 3), cl = ch >> 2;       // e = channel * 2 + {sum dz, sum dz * xhat}
+    const long long prow = (long long)g * pn.spg * gridDim.x + (long long)(n - g * pn.spg) * gridDim.x + blockIdx.x;
+    partial[prow * 32 + e] = red[0][cl][i] + red[1][cl][i] + red[2][cl][i] + red[3][cl][i];
+  }
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void k_pw16_bwd_apply(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
+                                                        const float* __restrict__ c1c2 /* [2][G][16] */, float* __restrict__ dxraw, PwNorm pn,
+                                                        float* __restrict__ amax_out) {
+  constexpr int U = 4;
+  const int n = blockIdx.y, g = n / pn.spg, col = threadIdx.x & 3;
+  const PwCol q = pw_col_load(pn, n, col);
+  const float4 k1 = ld4(c1c2 + (long long)g * 16 + col * 4), k2 = ld4(c1c2 + ((long long)pn.G + g) * 16 + col * 4);
+  const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
+  float wv[CO][4];
+#pragma unroll
+  for (int co = 0; co < CO; ++co) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) wv[co][k] = w[co * 16 + col * 4 + k];      // (a parameter view: no alignment promise)
+  }
+  float amax = 0.f;
+  const float* xs = x + (long long)n * pn.vps * 16;
+  const float* ds = dy + (long long)n * pn.vps * CO;
+  float* os = dxraw + (long long)n * pn.vps * 16;
+  auto one = [&](long long p, const float4& xv4, const float (&dv)[CO]) {
+    const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int co = 0; co < CO; ++co) s = fmaf(dv[co], wv[co][k], s);
+      const float z = (xv[k] - q.mu[k]) * q.sc[k] + q.sh[k];
+      const float dz = s * q.cs[k] * act_grad(z, pn.act);
+      const float xh = (xv[k] - q.mu[k]) * q.rs[k];
+      o[k] = q.sc[k] * (dz - k1v[k] - xh * k2v[k]);
+      const float t = fabsf(o[k]);
+      amax = (t > amax || t != t) ? t : amax;
+    }
+    st4(os + p * 4, make_float4(o[0], o[1], o[2], o[3]));
+  };
+  const long long nv = pn.vps * 4, stride = (long long)gridDim.x * 256;
+  long long p = (long long)blockIdx.x * 256 + threadIdx.x;
+  for (; p + (U - 1) * stride < nv; p += U * stride) {
+    float4 xv[U];
+    float dv[U][CO];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long pp = p + u * stride;
+      xv[u] = ld4(xs + pp * 4);
+#pragma unroll
+      for (int co = 0; co < CO; ++co) dv[u][co] = ds[(pp >> 2) * CO + co];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(p + u * stride, xv[u], dv[u]);
+  }
+  for (; p < nv; p += stride) {
+    const float4 xv = ld4(xs + p * 4);
+    float dv[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) dv[co] = ds[(p >> 2) * CO + co];
+    one(p, xv, dv);
+  }
+  if (amax_out) block_amax_publish(amax, amax_out);
+}
+
 // column sums of a [rows][C] matrix (bias gradients of convs that are NOT followed by a norm)
 __global__ __launch_bounds__(256) void k_colsum(const float* __restrict__ x, long long rows, int C, double* __restrict__ accum) {
   // thread t owns column t % C (C <= 256, 256 % C == 0); block-level sum first, then ONE atomic per column per block
@@ -758,6 +929,52 @@ extern "C" int bcp_pw16_bwd_norm(const float* x_raw, const float* stats, const f
   BCP_REQUIRE(pw_norm_args(pn, stats, chan_scale, N, G, nvox, act), "bcp_pw16_bwd_norm: needs stats, 1 <= N <= %d samples in G | N groups", kPwMaxN);
   if (int rc = pw16_bwd_impl("bcp_pw16_bwd_norm", x_raw, dy, w, dx, dw, db, nvox, Cout, accumulate, workspace, pn, (hipStream_t)stream)) return rc;
   BCP_CHECK_LAUNCH("bcp_pw16_bwd_norm");
+  return BCP_OK;
+}
+
+// ---- the head's backward through the norm (kernels above).  workspace: bcp_pw16_bwd_norm_bwd_workspace_bytes
+namespace bcp {      // csrc/norm.hip
+void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
+                              float* c1c2raw, hipStream_t s, float* amax_clear_or_null);
+}
+static int pw16_nbps(long long vps, int N) {
+  long long nb = vps / 1024;                       // >= 16 float4 per thread: the block reduction (18-28 fp64 values) is the kernel's tail
+  const long long cap = 768 / N < 1 ? 1 : 768 / N;  // k_pw16_bwd_stats holds 146 VGPRs: three workgroups per CU are resident, one round of them
+  if (nb > cap) nb = cap;
+  return (int)(nb < 1 ? 1 : nb);
+}
+extern "C" size_t bcp_pw16_bwd_norm_bwd_workspace_bytes(int N, int G, long long nvox) {
+  if (N < 1 || G < 1 || N % G || nvox < N || nvox % N) return 0;
+  return (size_t)128 * sizeof(double) + (size_t)N * pw16_nbps(nvox / N, N) * 32 * sizeof(double) + (size_t)4 * G * 16 * sizeof(float);
+}
+
+// dy_raw = gradient w.r.t. the RAW conv output x_raw (what bcp_pw16_bwd_norm + bcp_norm_bwd leave), dw / db of the head, dgamma / dbeta of the
+// norm (nullable pair); amax_out_or_null: |max| slots of dy_raw (cleared and max-reduced here, as bcp_norm_bwd does)
+extern "C" int bcp_pw16_bwd_norm_bwd(const float* x_raw, const float* stats, const float* chan_scale, int N, int G, int act, const float* dy,
+                                     const float* w, float* dy_raw, float* dw, float* db, float* dgamma, float* dbeta, int norm_accumulate,
+                                     long long nvox, int Cout, int accumulate, void* workspace, float* amax_out_or_null, void* stream) {
+  BCP_REQUIRE(x_raw && dy && w && dy_raw && dw && db && workspace && nvox > 0, "bcp_pw16_bwd_norm_bwd: bad argument");
+  BCP_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bcp_pw16_bwd_norm_bwd: dgamma and dbeta come together");
+  BCP_REQUIRE(Cout == 2 || Cout == 4, "bcp_pw16_bwd_norm_bwd: Cout=%d unsupported (2 or 4)", Cout);
+  BCP_REQUIRE(aligned16(x_raw) && aligned16(dy_raw) && aligned16(stats) && (!chan_scale || aligned16(chan_scale)), "bcp_pw16_bwd_norm_bwd: alignment");
+  PwNorm pn;
+  BCP_REQUIRE(pw_norm_args(pn, stats, chan_scale, N, G, nvox, act), "bcp_pw16_bwd_norm_bwd: needs stats, 1 <= N <= %d samples in G | N groups", kPwMaxN);
+  hipStream_t s = (hipStream_t)stream;
+  const int nbps = pw16_nbps(pn.vps, N);
+  double* acc = reinterpret_cast<double*>(workspace);
+  double* partial = acc + 128;
+  float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)N * nbps * 32);
+  hipMemsetAsync(acc, 0, (size_t)(Cout * 17) * sizeof(double), s);
+  if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd_stats<2>), dim3(nbps, N), dim3(256), 0, s, x_raw, dy, w, acc, partial, pn);
+  else hipLaunchKernelGGL((k_pw16_bwd_stats<4>), dim3(nbps, N), dim3(256), 0, s, x_raw, dy, w, acc, partial, pn);
+  hipLaunchKernelGGL(k_pw16_finalize, dim3(1), dim3(128), 0, s, acc, dw, db, Cout, accumulate);
+  norm_bwd_finalize_launch(partial, pn.spg * nbps, G, 16, pn.vps * pn.spg, dgamma, dbeta, norm_accumulate, c1c2raw, s, amax_out_or_null);
+  long long gx = (pn.vps * 4 + 1023) / 1024;       // 4 float4 per thread and trip
+  const long long cap = 2048 / N < 1 ? 1 : 2048 / N;
+  if (gx > cap) gx = cap;
+  if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd_apply<2>), dim3((int)gx, N), dim3(256), 0, s, x_raw, dy, w, c1c2raw, dy_raw, pn, amax_out_or_null);
+  else hipLaunchKernelGGL((k_pw16_bwd_apply<4>), dim3((int)gx, N), dim3(256), 0, s, x_raw, dy, w, c1c2raw, dy_raw, pn, amax_out_or_null);
+  BCP_CHECK_LAUNCH("bcp_pw16_bwd_norm_bwd");
   return BCP_OK;
 }
 

@@ -510,10 +510,10 @@ __global__ __launch_bounds__(256) void k_norm_bwd_params(const float* __restrict
 
 // c1c2raw: float[4][G][C] -- the two means the apply pass subtracts, then the raw sums
 void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
-                              float* c1c2raw, hipStream_t s) {
+                              float* c1c2raw, hipStream_t s, float* amax_clear_or_null) {
   float *c1 = c1c2raw, *c2 = c1 + (long long)G * C, *raw = c2 + (long long)G * C;
   hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma, dbeta,
-                     accumulate, c1, c2, raw, (float*)nullptr);
+                     accumulate, c1, c2, raw, amax_clear_or_null);
   if (dgamma) hipLaunchKernelGGL(k_norm_bwd_params, dim3(1), dim3(256), 0, s, raw, G, C, dgamma, dbeta, accumulate);
 }
 

@@ -721,6 +721,24 @@ class Ops:
                     int(bool(accumulate)), _p(ws), self.stream(y_raw))
         return dx
 
+    # networks/VNet.py: the fused head's backward runs THROUGH the last conv's norm (bcp_pw16_bwd_norm_bwd); False (BCP_HEAD_BWD_FUSED=0, a
+    # measurement switch): pw16_bwd_norm + norm_bwd, the round-4 chain
+    HEAD_BWD_FUSED = os.environ.get("BCP_HEAD_BWD_FUSED", "1") != "0"
+
+    def pw16_bwd_norm_bwd(self, y_raw, stats, chan_scale, G, act, dy, w, dw, db, dgamma=None, dbeta=None, norm_accumulate=False, accumulate=False):
+        """pw16_bwd_norm followed by norm_bwd of the same layer in one call: dw / db of the head (+= when accumulate), dgamma / dbeta of the
+        norm (+= when norm_accumulate), returns the gradient w.r.t. y_raw; the activation gradient in between is never written"""
+        self._chk(y_raw, stats, chan_scale, dy, w, dw, db, dgamma, dbeta)
+        Cout = dy.shape[-1]
+        N = y_raw.shape[0]
+        nvox = y_raw.numel() // 16
+        out = torch.empty_like(y_raw)
+        ws = self.workspace("pw16nb", self._ws_bytes("bcp_pw16_bwd_norm_bwd_workspace_bytes", N, int(G), nvox), y_raw)
+        self.b.call("bcp_pw16_bwd_norm_bwd", _p(y_raw), _p(stats), _p(chan_scale), N, int(G), act, _p(dy), _p(w), _p(out), _p(dw), _p(db),
+                    _p(dgamma), _p(dbeta), int(bool(norm_accumulate)), nvox, Cout, int(bool(accumulate)), _p(ws),
+                    _p(self._amax_slot(out, backward=True)), self.stream(y_raw))
+        return out
+
     def colsum(self, x, out, accumulate=False):
         self._chk(x, out)
         Cc = x.shape[-1]
@@ -870,7 +888,7 @@ class Ops:
 # ---------------------------------------------------------------------------------------------- measurement hooks
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
-_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "conv3_pack_many",
+_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_pack_many",
              "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")

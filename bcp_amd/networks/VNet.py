@@ -282,10 +282,18 @@ class VNet(HipNet):
         dlogits = dout if dout.is_contiguous() else dout.contiguous()
         self.begin_backward()
         (h_last,) = saved[-1]
+        dy_head = None                   # the fused head went THROUGH the last layer's norm: that layer's dy, no norm_bwd of its own
         if h_last is None:
+            Ll = self._layers[-1]
             _, y9, st9, cs9, _ = saved[len(self._layers) - 1]
-            dh = ops.pw16_bwd_norm(y9, st9, cs9, G, H.ACT_RELU, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad,
-                                   accumulate=True)
+            if ops.HEAD_BWD_FUSED and not Ll.skip_pop:
+                dg9, db9 = (Ll.bn.weight.grad, Ll.bn.bias.grad) if Ll.bn is not None else (None, None)
+                dy_head = ops.pw16_bwd_norm_bwd(y9, st9, cs9, G, H.ACT_RELU, dlogits, self._out.weight.data, self._out.weight.grad,
+                                                self._out.bias.grad, dg9, db9, norm_accumulate=Ll.bn is not None, accumulate=True)
+                dh = None
+            else:
+                dh = ops.pw16_bwd_norm(y9, st9, cs9, G, H.ACT_RELU, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad,
+                                       accumulate=True)
         else:
             dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
         skip_grads = []
@@ -297,7 +305,9 @@ class VNet(HipNet):
             w = L.conv.weight
             da = dh
             dg, db = (L.bn.weight.grad, L.bn.bias.grad) if L.bn is not None else (None, None)
-            if y is None:       # the fused first layer: its pre-norm tensor is recomputed from the input (bcp_conv3_c1_norm_bwd)
+            if dy_head is not None:
+                dy, dy_head = dy_head, None
+            elif y is None:     # the fused first layer: its pre-norm tensor is recomputed from the input (bcp_conv3_c1_norm_bwd)
                 assert L.kind == "c1" and nsl == 1
                 dy = ops.conv3_c1_norm_bwd(x_in, w.data, L.conv.bias.data, 3, G, stats, da, H.ACT_RELU, dg, db, L.bn is not None)
             elif nsl > 1:

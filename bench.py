@@ -116,6 +116,8 @@ def _work(name, shapes, ints):
         return "hbm", 0.0, 4.0 * (_numel(s0) + _numel(s0[:-1]) * (ints[2] if len(ints) > 2 else 2))
     if name == "pw16_bwd_norm":                            # read y and dlogits, write d(activation)
         return "hbm", 0.0, 4.0 * (2 * _numel(s0) + _numel(s0[:-1]) * 2)
+    if name == "pw16_bwd_norm_bwd":                        # two passes reading y and dlogits, one write of dy (the activation gradient is recomputed)
+        return "hbm", 0.0, 4.0 * (3 * _numel(s0) + _numel(s0[:-1]) * 4)
     if name == "mixloss_fwd":
         return "hbm", 0.0, _numel(s0) * 4.0 + 2.0 * _numel(s0[:-1])
     if name == "mixloss_bwd":

@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 502
+#define BCP_ABI_VERSION 503
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -265,6 +265,14 @@ int bcp_pw16_fwd_norm(const float* x_raw, const float* stats, const float* chan_
                       float* y, long long nvox, int Cout, void* stream);
 int bcp_pw16_bwd_norm(const float* x_raw, const float* stats, const float* chan_scale, int N, int G, int act, const float* dy, const float* w,
                       float* dx, float* dw, float* db, long long nvox, int Cout, int accumulate, void* workspace, void* stream);
+/* Round 5: the head's backward THROUGH that norm layer in one call -- bcp_pw16_bwd_norm + bcp_norm_bwd (networks/VNet.py:213-216 backward of
+ * out_conv(dropout(block_nine(...)))) without the 16-channel activation gradient ever written: pass 1 takes dw / db and the norm's backward
+ * statistics from (x_raw, dy), pass 2 recomputes da = dy * w per voxel and writes dy_raw = the gradient w.r.t. x_raw.  dgamma / dbeta: the
+ * norm's affine gradients (nullable pair; norm_accumulate: +=), accumulate: dw / db +=.  amax_out_or_null: |max| slots of dy_raw. */
+size_t bcp_pw16_bwd_norm_bwd_workspace_bytes(int N, int G, long long nvox);
+int bcp_pw16_bwd_norm_bwd(const float* x_raw, const float* stats, const float* chan_scale, int N, int G, int act, const float* dy, const float* w,
+                          float* dy_raw, float* dw, float* db, float* dgamma_or_null, float* dbeta_or_null, int norm_accumulate, long long nvox,
+                          int Cout, int accumulate, void* workspace, float* amax_out_or_null, void* stream);
 /* column sums of [rows][C] (bias gradients of convs not followed by a norm); workspace = C doubles */
 int bcp_colsum(const float* x, long long rows, int C, float* out, int accumulate, void* workspace, void* stream);
 

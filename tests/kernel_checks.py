@@ -584,6 +584,43 @@ def check_pw16_norm(ops, dev):
         close(dw1, 2 * dw0, rtol=1e-5, msg="pw16_bwd_norm accumulate")
 
 
+def check_pw16_bwd_norm_bwd(ops, dev):
+    """the head's backward through the norm in one call (bcp_pw16_bwd_norm_bwd) against the chain it replaces, pw16_bwd_norm -> norm_bwd:
+    dw / db of the head, dgamma / dbeta of the norm (accumulated on top of what is there) and the gradient w.r.t. the raw conv output;
+    BatchNorm groups and InstanceNorm, with and without the Dropout3d channel scale, sample counts that leave ragged blocks; the |max|
+    slots of the result equal the chain's."""
+    rng = np.random.default_rng(131)
+    for (N, G, Cout, affine, drop, sp) in ((4, 2, 2, True, True, (5, 6, 8)), (2, 2, 2, False, False, (5, 6, 8)), (4, 1, 4, True, False, (3, 7, 5)),
+                                           (3, 3, 2, False, True, (9, 11, 13)), (2, 1, 2, True, True, (16, 24, 40))):
+        y = (R(rng, N, *sp, 16) * 1.7 + 0.3).to(dev)
+        gamma = (R(rng, 16) * 0.3 + 1).to(dev) if affine else None
+        beta = (R(rng, 16) * 0.2).to(dev) if affine else None
+        rm, rv = (torch.zeros(16).to(dev), torch.ones(16).to(dev)) if affine else (None, None)
+        cs = ((torch.from_numpy(rng.integers(0, 2, (N, 16))).float() * 2).to(dev)) if drop else None
+        w = (R(rng, Cout, 16, 1, 1, 1) * 0.3).to(dev).contiguous()
+        dlog = R(rng, N, *sp, Cout).to(dev)
+        _, st = ops.norm_fwd(y, G, gamma, beta, rm, rv, H.ACT_RELU, chan_scale=cs, stats_only=True)
+        tag = f"pw16_bwd_norm_bwd N={N} G={G} Cout={Cout} affine={affine} drop={drop} {sp}"
+        dw0, db0 = (R(rng, Cout, 16, 1, 1, 1) * 0.1).to(dev).contiguous(), (R(rng, Cout) * 0.1).to(dev)
+        dw1, db1 = dw0.clone(), db0.clone()
+        dg0, dbe0 = ((R(rng, 16) * 0.1).to(dev), (R(rng, 16) * 0.1).to(dev)) if affine else (None, None)
+        dg1, dbe1 = (dg0.clone(), dbe0.clone()) if affine else (None, None)
+        da = ops.pw16_bwd_norm(y, st, cs, G, H.ACT_RELU, dlog, w, dw0, db0, accumulate=True)
+        ref = ops.norm_bwd(y, da, G, st, H.ACT_RELU, dg0, dbe0, affine, chan_scale=cs)
+        got = ops.pw16_bwd_norm_bwd(y, st, cs, G, H.ACT_RELU, dlog, w, dw1, db1, dg1, dbe1, norm_accumulate=affine, accumulate=True)
+        close(got, ref, rtol=2e-5, msg=tag + " dy")
+        close(dw1, dw0, rtol=1e-5, msg=tag + " dw")
+        close(db1, db0, rtol=1e-6, msg=tag + " db")
+        if affine:
+            close(dg1, dg0, rtol=2e-5, msg=tag + " dgamma")
+            close(dbe1, dbe0, rtol=2e-5, msg=tag + " dbeta")
+        if ops.AMAX:
+            a0, a1 = ops._amax_of(ref), ops._amax_of(got)
+            assert a0 is not None and a1 is not None, tag + ": |max| slots missing"
+            m0, m1 = H.amax_value(a0), H.amax_value(a1)
+            assert abs(m0 - m1) <= 2e-5 * max(m0, 1e-30) and m1 > 0, f"{tag}: |max| {m1} vs {m0}"
+
+
 def check_pool2d(ops, dev):
     rng = np.random.default_rng(8)
     # round 4: |max| of a concat buffer = max(skip's slot, what the upsample writes)
@@ -1531,7 +1568,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pool2d", "optim")
+ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):
