@@ -478,7 +478,7 @@ __device__ __forceinline__ PwCol pw_col_load(const PwNorm& pn, int n, int col) {
 
 template <int CO>
 __global__ __launch_bounds__(256) void k_pw16_bwd_stats(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ w,
-                                                        double* __restrict__ accum /* [CO*16 + CO] */,
+                                                        double* __restrict__ hpart /* [N * gridDim.x][CO*16 + CO]: dw, db of the head per block */,
                                                         double* __restrict__ partial /* [G][spg * gridDim.x][16][2] */, PwNorm pn) {
   constexpr int U = 4, NV = CO * 5 + 8;            // per thread: dw[co][4], db[co], (sum dz)[4], (sum dz * xhat)[4]
   __shared__ double red[4][4][NV];
@@ -495,6 +495,10 @@ __global__ __launch_bounds__(256) void k_pw16_bwd_stats(const float* __restrict_
   for (int i = 0; i < NV; ++i) acc[i] = 0.0;
   const float* xs = x + (long long)n * pn.vps * 16;
   const float* ds = dy + (long long)n * pn.vps * CO;
+  // the U elements of a trip are summed in fp32 (three additions per value), the trip's sums go into the fp64 accumulators: a quarter of
+  // the conversions and fp64 operations of an element-wise fp64 sum (no time gained by it -- 43.4 us either way at the LA size, the
+  // kernel's tail was the limit, see below -- but 16 VGPRs)
+  float tr[NV];
   auto one = [&](const float4& xv4, const float (&dv)[CO]) {
     const float xv[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
 #pragma unroll
@@ -505,15 +509,15 @@ __global__ __launch_bounds__(256) void k_pw16_bwd_stats(const float* __restrict_
 #pragma unroll
       for (int co = 0; co < CO; ++co) {
         s = fmaf(dv[co], wv[co][k], s);
-        acc[co * 4 + k] += (double)dv[co] * (double)a;
+        tr[co * 4 + k] = fmaf(dv[co], a, tr[co * 4 + k]);
       }
       const float g1 = s * q.cs[k] * act_grad(z, pn.act);
       const float xh = (xv[k] - q.mu[k]) * q.rs[k];
-      acc[CO * 5 + k] += (double)g1;
-      acc[CO * 5 + 4 + k] += (double)g1 * (double)xh;
+      tr[CO * 5 + k] += g1;
+      tr[CO * 5 + 4 + k] = fmaf(g1, xh, tr[CO * 5 + 4 + k]);
     }
 #pragma unroll
-    for (int co = 0; co < CO; ++co) acc[CO * 4 + co] += (double)dv[co];
+    for (int co = 0; co < CO; ++co) tr[CO * 4 + co] += dv[co];
   };
   const long long nv = pn.vps * 4, stride = (long long)gridDim.x * 256;
   long long p = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -528,15 +532,23 @@ __global__ __launch_bounds__(256) void k_pw16_bwd_stats(const float* __restrict_
       for (int co = 0; co < CO; ++co) dv[u][co] = ds[(pp >> 2) * CO + co];
     }
 #pragma unroll
+    for (int i = 0; i < NV; ++i) tr[i] = 0.f;
+#pragma unroll
     for (int u = 0; u < U; ++u) one(xv[u], dv[u]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] += (double)tr[i];
   }
-  for (; p < nv; p += stride) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) tr[i] = 0.f;
+  for (; p < nv; p += stride) {           // at most U - 1 elements
     const float4 xv = ld4(xs + p * 4);
     float dv[CO];
 #pragma unroll
     for (int co = 0; co < CO; ++co) dv[co] = ds[(p >> 2) * CO + co];
     one(xv, dv);
   }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc[i] += (double)tr[i];
   // lanes with equal column are 4 apart: xor-shuffles over 4, 8, 16, 32, then one LDS hop over the four waves
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -553,11 +565,30 @@ __global__ __launch_bounds__(256) void k_pw16_bwd_stats(const float* __restrict_
   if (t < CO * 17) {
     const int co = t < CO * 16 ? t >> 4 : t - CO * 16, c = t & 15;
     const int cl = t < CO * 16 ? c >> 2 : 0, i = t < CO * 16 ? co * 4 + (c & 3) : CO * 4 + co;     // db: every column summed all voxels, take column 0's
-    atomicAdd(&accum[t], red[0][cl][i] + red[1][cl][i] + red[2][cl][i] + red[3][cl][i]);
+    // per-block rows, summed by k_pw16_head_finalize in a fixed order: bitwise reproducible, and 32.4 us instead of 43.4 for 144 MB at the
+    // LA size (gpurun_out/r05_s24) -- the first version added them with fp64 atomics, 768 workgroups finishing together onto 34 addresses
+    hpart[((long long)n * gridDim.x + blockIdx.x) * (CO * 17) + t] = red[0][cl][i] + red[1][cl][i] + red[2][cl][i] + red[3][cl][i];
   } else if (t >= 128 && t < 160) {
     const int e = t - 128, ch = e >> 1, i = CO * 5 + (e & 1) * 4 + (ch & 3), cl = ch >> 2;       // e = channel * 2 + {sum dz, sum dz * xhat}
     const long long prow = (long long)g * pn.spg * gridDim.x + (long long)(n - g * pn.spg) * gridDim.x + blockIdx.x;
     partial[prow * 32 + e] = red[0][cl][i] + red[1][cl][i] + red[2][cl][i] + red[3][cl][i];
+  }
+}
+
+// dw / db of the head from the per-block rows: block = one value, 256 threads walk the rows, fixed summation order
+__global__ __launch_bounds__(256) void k_pw16_head_finalize(const double* __restrict__ hpart, int nrows, int CO, float* __restrict__ dw,
+                                                            float* __restrict__ db, int accumulate) {
+  __shared__ double red[4];
+  const int e = blockIdx.x, HP = CO * 17;
+  double a = 0.0;
+  for (int r = threadIdx.x; r < nrows; r += 256) a += hpart[(long long)r * HP + e];
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = (red[0] + red[1]) + (red[2] + red[3]);
+    float* o = e < CO * 16 ? dw + e : db + (e - CO * 16);
+    *o = (accumulate ? *o : 0.f) + (float)t;
   }
 }
 
@@ -939,13 +970,13 @@ void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long 
 }
 static int pw16_nbps(long long vps, int N) {
   long long nb = vps / 1024;                       // >= 16 float4 per thread: the block reduction (18-28 fp64 values) is the kernel's tail
-  const long long cap = 768 / N < 1 ? 1 : 768 / N;  // k_pw16_bwd_stats holds 146 VGPRs: three workgroups per CU are resident, one round of them
+  const long long cap = 768 / N < 1 ? 1 : 768 / N;  // k_pw16_bwd_stats holds 130 VGPRs (128 by force spills): three workgroups per CU are resident, one round of them
   if (nb > cap) nb = cap;
   return (int)(nb < 1 ? 1 : nb);
 }
 extern "C" size_t bcp_pw16_bwd_norm_bwd_workspace_bytes(int N, int G, long long nvox) {
   if (N < 1 || G < 1 || N % G || nvox < N || nvox % N) return 0;
-  return (size_t)128 * sizeof(double) + (size_t)N * pw16_nbps(nvox / N, N) * 32 * sizeof(double) + (size_t)4 * G * 16 * sizeof(float);
+  return (size_t)N * pw16_nbps(nvox / N, N) * (32 + 68) * sizeof(double) + (size_t)4 * G * 16 * sizeof(float);
 }
 
 // dy_raw = gradient w.r.t. the RAW conv output x_raw (what bcp_pw16_bwd_norm + bcp_norm_bwd leave), dw / db of the head, dgamma / dbeta of the
@@ -961,13 +992,12 @@ extern "C" int bcp_pw16_bwd_norm_bwd(const float* x_raw, const float* stats, con
   BCP_REQUIRE(pw_norm_args(pn, stats, chan_scale, N, G, nvox, act), "bcp_pw16_bwd_norm_bwd: needs stats, 1 <= N <= %d samples in G | N groups", kPwMaxN);
   hipStream_t s = (hipStream_t)stream;
   const int nbps = pw16_nbps(pn.vps, N);
-  double* acc = reinterpret_cast<double*>(workspace);
-  double* partial = acc + 128;
-  float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)N * nbps * 32);
-  hipMemsetAsync(acc, 0, (size_t)(Cout * 17) * sizeof(double), s);
-  if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd_stats<2>), dim3(nbps, N), dim3(256), 0, s, x_raw, dy, w, acc, partial, pn);
-  else hipLaunchKernelGGL((k_pw16_bwd_stats<4>), dim3(nbps, N), dim3(256), 0, s, x_raw, dy, w, acc, partial, pn);
-  hipLaunchKernelGGL(k_pw16_finalize, dim3(1), dim3(128), 0, s, acc, dw, db, Cout, accumulate);
+  double* partial = reinterpret_cast<double*>(workspace);
+  double* hpart = partial + (size_t)N * nbps * 32;
+  float* c1c2raw = reinterpret_cast<float*>(hpart + (size_t)N * nbps * 68);
+  if (Cout == 2) hipLaunchKernelGGL((k_pw16_bwd_stats<2>), dim3(nbps, N), dim3(256), 0, s, x_raw, dy, w, hpart, partial, pn);
+  else hipLaunchKernelGGL((k_pw16_bwd_stats<4>), dim3(nbps, N), dim3(256), 0, s, x_raw, dy, w, hpart, partial, pn);
+  hipLaunchKernelGGL(k_pw16_head_finalize, dim3(Cout * 17), dim3(256), 0, s, hpart, N * nbps, Cout, dw, db, accumulate);
   norm_bwd_finalize_launch(partial, pn.spg * nbps, G, 16, pn.vps * pn.spg, dgamma, dbeta, norm_accumulate, c1c2raw, s, amax_out_or_null);
   long long gx = (pn.vps * 4 + 1023) / 1024;       // 4 float4 per thread and trip
   const long long cap = 2048 / N < 1 ? 1 : 2048 / N;

@@ -1263,12 +1263,20 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
 
 
 def check_fused_head(ops, dev, steps=2):
-    """the head that normalises on its way in (VNet.fuse_head, bcp_pw16_fwd_norm / _bwd_norm) against the separate apply pass:
-    self-training steps of the LA (BatchNorm, Dropout3d live, grouped) and pancreas (InstanceNorm) V-Nets from the same seeds;
-    the two differ only in instruction contraction inside one kernel, so losses and weights agree to rounding."""
+    """the head that normalises on its way in (VNet.fuse_head, bcp_pw16_fwd_norm / _bwd_norm) against the separate apply pass, and its
+    backward THROUGH that norm (Ops.HEAD_BWD_FUSED, bcp_pw16_bwd_norm_bwd, round 5) against the chain pw16_bwd_norm -> norm_bwd:
+    self-training steps of the LA (BatchNorm, Dropout3d live, grouped) and pancreas (InstanceNorm) V-Nets from the same seeds.  The three
+    variants differ in instruction contraction and summation order only: after the FIRST step the loss is equal, every gradient tensor
+    agrees to 2e-5 of its largest entry and the weights to rounding.  Later steps are compared on the loss only: this 32 x 32 x 16 problem
+    normalises 8 values per channel at its deepest level, and one last-bit difference in dy after step 1 (the fused backward's apply pass
+    contracts differently from k_norm_bwd_apply: 4.5 % of the elements differ in the last bit at the LA size, tools/probe/head_fusion_diff.py)
+    is a 3e-3 relative weight difference after step 2 on the device -- the round-4 path passed two steps at 2e-5 only because its dy was
+    BIT-identical to the unfused one."""
     from bcp_amd import train_step
+    Opsc = type(ops)
 
-    def run(fuse, what):
+    def run(fuse, head_bwd, what):
+        Opsc.HEAD_BWD_FUSED = head_bwd
         torch.manual_seed(5)
         np.random.seed(5)
         shape = (32, 32, 16) if what == "la" else (32, 32, 32)
@@ -1282,21 +1290,36 @@ def check_fused_head(ops, dev, steps=2):
             p.detach_()
         vol, lab = vol.to(dev), lab.to(dev)
         opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
-        losses = []
-        for _ in range(steps):
+        losses, grads, weights = [], None, None
+        for s in range(steps):
             r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), variant=what,
                                               connect_mode=2 if what != "la" else None, grouped=True)
             losses.append(float(r["loss"]))
-        return losses, {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+            if s == 0:
+                grads = {k: p.grad.detach().clone().cpu() for k, p in model.named_parameters() if p.grad is not None}
+                weights = {k: v.detach().clone().cpu() for k, v in model.state_dict().items()}
+        return losses, grads, weights
 
-    for what in ("la", "pancreas"):
-        a, b = run(False, what), run(True, what)
-        for la_, lb_ in zip(a[0], b[0]):
-            assert abs(la_ - lb_) <= 2e-5 * abs(la_), (what, a[0], b[0])
-        for k in a[1]:
-            if a[1][k].dtype.is_floating_point:
-                d = float((a[1][k] - b[1][k]).abs().max())
-                assert d <= 2e-5 * max(float(a[1][k].abs().max()), 1e-3), (what, k, d)
+    head0 = Opsc.HEAD_BWD_FUSED
+    try:
+        for what in ("la", "pancreas"):
+            a = run(False, False, what)
+            assert len(a[1]) > 20 and all(float(g.abs().max()) > 0 for k, g in a[1].items() if k.endswith("conv.0.weight")), "no gradients captured"
+            for head_bwd in (False, True):
+                b = run(True, head_bwd, what)
+                tag = f"{what} fuse_head, head backward through the norm: {head_bwd}"
+                assert abs(a[0][0] - b[0][0]) <= 2e-6 * abs(a[0][0]), (tag, a[0], b[0])
+                for la_, lb_ in zip(a[0][1:], b[0][1:]):
+                    assert abs(la_ - lb_) <= 2e-3 * abs(la_), (tag, a[0], b[0])
+                for k in a[1]:
+                    d = float((a[1][k] - b[1][k]).abs().max())
+                    assert d <= 2e-5 * max(float(a[1][k].abs().max()), 1e-6), (tag, "gradient", k, d, float(a[1][k].abs().max()))
+                for k in a[2]:
+                    if a[2][k].dtype.is_floating_point:
+                        d = float((a[2][k] - b[2][k]).abs().max())
+                        assert d <= 1e-6 * max(float(a[2][k].abs().max()), 1e-3), (tag, "weight after one step", k, d)
+    finally:
+        Opsc.HEAD_BWD_FUSED = head0
 
 
 def check_fp16_backward_long_run(ops, dev, steps=1000, probes=(0, 10, 100, 300, 600, 999), bound=2e-5, report=None):
