@@ -103,6 +103,12 @@ lo = torch.empty(N, *sp, 2, device=dev)
 run("pw16_fwd[2x112x112x80x16]", lambda: ops.pw16_fwd(y16, wo, None, 2, out=lo), {"flop": 0, "bytes": 4.0 * (y16.numel() + lo.numel())})
 st16 = ops.norm_fwd(y16, N, None, None, None, None, H.ACT_RELU, stats_only=True)[1]
 run("pw16_fwd_norm[2x112x112x80x16]", lambda: ops.pw16_fwd_norm(y16, st16, None, N, H.ACT_RELU, wo, None, 2, out=lo), {"flop": 0, "bytes": 4.0 * (y16.numel() + lo.numel())})
+dwo, dbo, dlo = torch.zeros_like(wo), torch.zeros(2, device=dev), torch.randn(N, *sp, 2, device=dev) * 1e-3
+# round 5: the head's backward through the norm (stats pass + finalize kernels + apply pass; the activation gradient is recomputed) and the
+# round-4 chain it replaces
+run("pw16_bwd_norm_bwd[2x112x112x80x16]", lambda: ops.pw16_bwd_norm_bwd(y16, st16, None, N, H.ACT_RELU, dlo, wo, dwo, dbo), {"flop": 0, "bytes": 4.0 * (3 * y16.numel() + 2 * dlo.numel())})
+run("pw16_bwd_norm+norm_bwd[2x112x112x80x16]", lambda: ops.norm_bwd(y16, ops.pw16_bwd_norm(y16, st16, None, N, H.ACT_RELU, dlo, wo, dwo, dbo), N, st16, H.ACT_RELU),
+    {"flop": 0, "bytes": 4.0 * (3 * y16.numel() + 2 * dlo.numel())})
 la = (torch.rand(N, *sp, device=dev) > 0.9).to(torch.uint8)
 box = (10, 20, 5, 74, 74, 53)
 ws3 = [None]
