@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 503      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 504      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int
@@ -78,6 +78,8 @@ _SIGS = {
     "bcp_conv3_c1_norm_workspace_bytes": (SZ, [I, I, I, I, I, I]),
     "bcp_conv3_c1_norm_fwd": (I, [P, P, P, I, I, I, I, I, I, P, P, P, P, F, F, I, P, F, P, F, P, P, P, P, P]),
     "bcp_conv3_c1_norm_bwd": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P, F, P, F, P, P, I, P, P, P]),
+    "bcp_conv3_c1_norm_bwd_wgrad_workspace_bytes": (SZ, [I, I, I, I, I, I]),
+    "bcp_conv3_c1_norm_bwd_wgrad": (I, [P, P, P, P, I, I, I, I, I, I, P, I, P, F, P, F, P, P, I, P, P, I, P]),
     "bcp_conv3_c1_wgrad": (I, [P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_k2_pack_weight": (I, [P, P, I, I, I, P]),
     "bcp_k2_pack_desc": (I, [P, P, I, I, I, P]),

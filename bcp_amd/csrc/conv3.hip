@@ -938,6 +938,11 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
 //   2  a = act((y - mean) * scale + shift) [* mask * s] -> out    pass 2 of the fused forward: y never exists in HBM
 //   3  backward statistics (sum dz, sum dz * xhat) from da        pass 1 of the fused backward
 //   4  dy = scale * (dz - c1 - xhat * c2) -> out                  pass 2 of the fused backward
+//   5  (round 5) dy as in 4, but into LDS, and THIS layer's weight gradient from it: dW[tap][co] += sum_v x[v + off(tap)] * dy[v][co] on
+//      the matrix cores (k_conv3_c1_wgrad's product; the x halo is in LDS already, a wave multiplies the 64 voxels it just differentiated)
+//      -> one partial [T][16] slab per workgroup at Y.  The first layer has no dgrad, so dy had no other reader: 128 MB written and read
+//      back at the LA size, and the last launch of the backward pass (k_conv3_c1_wgrad, alone on the step's tail), are gone
+//      (bcp_conv3_c1_norm_bwd_wgrad)
 struct C1Norm {
   const float* stats;          // float[5][G][16]: mean, rstd, scale, shift, ...
   const float* da;             // EPI 3 / 4: gradient w.r.t. the activation, [voxel][16]
@@ -958,8 +963,16 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
   constexpr int T = TL::T, MT = TL::MT, KS = (T + 3) / 4;
   __shared__ __attribute__((aligned(16))) float Xs[TL::HV];
   __shared__ double Ss[4 * 16 * 2];
+  __shared__ __attribute__((aligned(16))) float Ys[EPI == 5 ? TL::M * 16 : 4];      // EPI 5: dy of the current tile, [voxel][16]
+  static_assert(EPI != 5 || (TL::M == 256 && T <= 32 && MT == 4), "EPI 5: four waves x 64 voxels, two 16-tap MFMA row tiles");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
+  int aoff[2] = {0, 0};                                    // EPI 5: lane's tap offset for the two row tiles of the weight-gradient product (tap = tt*16 + li)
+  f32x4 wacc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+  if (EPI == 5) {
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) aoff[tt] = (tt * 16 + li < T) ? TL::tapoff(tt * 16 + li) : 0;
+  }
   // lane (li, lg): A[co = li][k = lg] of k-step ks is the weight of tap 4*ks + lg.  D = W x X^T (rows = channels, columns = voxels):
   // a lane ends with FOUR CONSECUTIVE channels (lg*4 ..) of voxel li -- one 16-byte store per m-tile (round 3; the dword stores of
   // the [vox][co] orientation ran this 128 MB stream at 3.2 TB/s) and the layout the fused norm statistics want.
@@ -989,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       mu[r] = nm.stats[o + r]; rs[r] = nm.stats[GC + o + r]; sc[r] = nm.stats[2 * GC + o + r]; sh[r] = nm.stats[3 * GC + o + r];
-      if (EPI == 4) { k1[r] = nm.c1c2[o + r]; k2[r] = nm.c1c2[GC + o + r]; }
+      if (EPI >= 4) { k1[r] = nm.c1c2[o + r]; k2[r] = nm.c1c2[GC + o + r]; }
     }
   }
   // 3-D: the halo of the NEXT tile travels in registers under the current tile's MFMAs (round 4, same box, three interleaved pairs: LA
@@ -1040,6 +1053,7 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[ks], Xs[vo + toff[ks]], acc, 0, 0, 0);
+      float4 dyl = make_float4(0.f, 0.f, 0.f, 0.f);          // EPI 5: this lane's four dy values (zero outside the volume)
       if (ok) {
         const float yv[4] = {acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w};
         if (EPI == 0) st4(Y + e, make_float4(yv[0], yv[1], yv[2], yv[3]));
@@ -1069,9 +1083,34 @@ __global__ __launch_bounds__(256) void k_conv3_c1(const float* __restrict__ X, c
             }
           }
           if (EPI == 2 || EPI == 4) st4(Y + e, make_float4(o[0], o[1], o[2], o[3]));
+          if (EPI == 5) dyl = make_float4(o[0], o[1], o[2], o[3]);
         }
       }
+      if (EPI == 5) st4(Ys + m * 16 + lg * 4, dyl);
     }
+    if (EPI == 5) {
+      // D[tap = tt*16 + lg*4 + r][co = li] += sum over this wave's 64 voxels (the ones it just wrote: rows wave*64 .. +63 of Ys)
+      __syncthreads();
+#pragma unroll 4
+      for (int ks = 0; ks < 16; ++ks) {
+        const int v = wave * 64 + ks * 4 + lg;               // A[tap = li][k = lg], B[k = lg][co = li]
+        const int vo = TL::voff(v);
+        const float b = Ys[v * 16 + li];
+        wacc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[vo + aoff[0]], b, wacc[0], 0, 0, 0);
+        wacc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xs[vo + aoff[1]], b, wacc[1], 0, 0, 0);
+      }
+    }
+  }
+  if (EPI == 5) {      // sum the four waves, write this workgroup's partial [tap][co] slab (k_conv3_c1_wgrad's ending)
+    __syncthreads();
+    float* red = Ys;                                         // [4 waves][32 taps][16]
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[(wave * 32 + tt * 16 + lg * 4 + r) * 16 + li] = wacc[tt][r];
+    __syncthreads();
+    for (int o = threadIdx.x; o < T * 16; o += 256)
+      Y[(long long)blockIdx.x * T * 16 + o] = (red[o] + red[512 + o]) + (red[1024 + o] + red[1536 + o]);
   }
   if (st.partial) {
     // one row per workgroup (its tiles lie in ONE normalisation group: the launcher picks tiles_per_block | tiles_per_group)
@@ -1738,6 +1777,7 @@ static int c1_fwd_impl(const float* x, const float* w, const float* bias, float*
     case 2: c1_launch<2>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
     case 3: c1_launch<3>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
     case 4: c1_launch<4>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
+    case 5: c1_launch<5>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
     default: c1_launch<0>(KD, grid, s, x, w, bias, y, cd, tiles, tpb, st, nm); break;
   }
   return st.rows;
@@ -1826,6 +1866,43 @@ extern "C" int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float
   norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s, nullptr);
   c1_fwd_impl(x, w, bias, dy, N, D, H, W, KD, nullptr, groups, false, s, 4, &nm);
   BCP_CHECK_LAUNCH("bcp_conv3_c1_norm_bwd");
+  return BCP_OK;
+}
+
+// Round 5: the same backward with the layer's own weight gradient folded into pass 2 (kernel EPI 5): dy is never written -- the first
+// layer has no dgrad, its weight gradient was dy's only reader -- and bcp_conv3_c1_wgrad, the last launch of the backward pass, is not
+// needed.  dw[16][1][T] (+= when dw_accumulate) is what bcp_conv3_c1_norm_bwd + bcp_conv3_c1_wgrad leave, up to fp32 summation order
+// (one partial slab per workgroup of pass 2 instead of per tile group).  workspace: bcp_conv3_c1_norm_bwd_wgrad_workspace_bytes.
+extern "C" size_t bcp_conv3_c1_norm_bwd_wgrad_workspace_bytes(int N, int D, int H, int W, int KD, int groups) {
+  const int rows = bcp_conv3_c1_stat_rows(N, D, H, W, KD, groups);
+  if (rows <= 0) return 0;
+  return bcp_conv3_c1_norm_workspace_bytes(N, D, H, W, KD, groups) + (size_t)groups * rows * (KD * 9) * 16 * sizeof(float);
+}
+
+extern "C" int bcp_conv3_c1_norm_bwd_wgrad(const float* x, const float* w, const float* bias, const float* da, int N, int D, int H, int W, int KD,
+                                           int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale,
+                                           const unsigned long long* mask_seed, float mask_p_keep, float* dgamma, float* dbeta,
+                                           int accumulate, void* workspace, float* dw, int dw_accumulate, void* stream) {
+  BCP_REQUIRE(x && w && da && stats && workspace && dw && groups >= 1, "bcp_conv3_c1_norm_bwd_wgrad: null pointer / bad groups");
+  BCP_REQUIRE((KD == 1 && D == 1) || KD == 3, "bcp_conv3_c1_norm_bwd_wgrad: bad KD/D");
+  BCP_REQUIRE(aligned16(da) && (!bias || aligned16(bias)), "bcp_conv3_c1_norm_bwd_wgrad: alignment");
+  BCP_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bcp_conv3_c1_norm_bwd_wgrad: dgamma and dbeta come together");
+  hipStream_t s = (hipStream_t)stream;
+  double* partial = reinterpret_cast<double*>(workspace);
+  const int rows0 = bcp_conv3_c1_stat_rows(N, D, H, W, KD, groups);
+  BCP_REQUIRE(rows0 > 0, "bcp_conv3_c1_norm_bwd_wgrad: the groups must be whole samples (N %% groups == 0)");
+  float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)groups * rows0 * 16 * 2);
+  float* wpart = c1c2raw + (size_t)4 * groups * 16;            // [groups * rows0 workgroups][T][16]
+  C1Norm nm{stats, da, c1c2raw, elem_mask, elem_scale, act, groups, nullptr, mask_seed, mask_p_keep};
+  const int rows = c1_fwd_impl(x, w, bias, nullptr, N, D, H, W, KD, partial, groups, false, s, 3, &nm);
+  norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s, nullptr);
+  c1_fwd_impl(x, w, bias, wpart, N, D, H, W, KD, nullptr, groups, false, s, 5, &nm);
+  const int G = groups * rows, T = KD * 9;                     // workgroups of pass 2 = statistics rows of pass 1 (same tiling)
+  if (G >= 32)
+    launch_reduce_deep(wpart, dw, G, T, 1, 16, 1, 16, dw_accumulate, s);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(1, 1), dim3(256), 0, s, wpart, dw, G, T, 1, 16, 1, 16, dw_accumulate);
+  BCP_CHECK_LAUNCH("bcp_conv3_c1_norm_bwd_wgrad");
   return BCP_OK;
 }
 

@@ -592,6 +592,23 @@ class Ops:
                     em_seed, em_keep, _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy), self.stream(x))
         return dy
 
+    # networks: the first layer's backward leaves its weight gradient itself (bcp_conv3_c1_norm_bwd_wgrad: dy is never written); False
+    # (BCP_C1_BWD_FUSED=0, a measurement switch): conv3_c1_norm_bwd + conv3_c1_wgrad on the weight-gradient stream, the round-3 pair
+    C1_BWD_FUSED = os.environ.get("BCP_C1_BWD_FUSED", "1") != "0"
+
+    def conv3_c1_norm_bwd_wgrad(self, x, w, bias, KD, G, stats, da, act, dw, dgamma=None, dbeta=None, accumulate=False, dw_accumulate=False,
+                                elem_mask=None, elem_scale=1.0):
+        """conv3_c1_norm_bwd + conv3_c1_wgrad in one call: dgamma / dbeta of the norm and dw of the conv; the gradient w.r.t. the conv
+        output in between exists tile by tile in LDS only"""
+        elem_mask, em_seed, em_keep = self._mask_split(elem_mask)
+        self._chk(x, w, bias, stats, da, dgamma, dbeta, elem_mask, dw)
+        N, D, H, W, _ = x.shape
+        nbytes = self._ws_bytes("bcp_conv3_c1_norm_bwd_wgrad_workspace_bytes", N, D, H, W, KD, G)
+        ws = self.workspace("c1normw", nbytes, x)
+        self.b.call("bcp_conv3_c1_norm_bwd_wgrad", _p(x), _p(w), _p(bias), _p(da), N, D, H, W, KD, G, _p(stats), act, _p(elem_mask), float(elem_scale),
+                    em_seed, em_keep, _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dw), int(bool(dw_accumulate)), self.stream(x))
+        return dw
+
     def conv3_c1_wgrad(self, x, dy, dw, KD, accumulate=False):
         self._chk(x, dy, dw)
         N, D, H, W, _ = x.shape
@@ -888,7 +905,7 @@ class Ops:
 # ---------------------------------------------------------------------------------------------- measurement hooks
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
-_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_pack_many",
+_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
              "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")

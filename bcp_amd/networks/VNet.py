@@ -309,6 +309,11 @@ class VNet(HipNet):
                 dy, dy_head = dy_head, None
             elif y is None:     # the fused first layer: its pre-norm tensor is recomputed from the input (bcp_conv3_c1_norm_bwd)
                 assert L.kind == "c1" and nsl == 1
+                if ops.C1_BWD_FUSED:      # ... and the layer's weight gradient in the same pass: no dy, no launch left behind the main stream's last one
+                    ops.conv3_c1_norm_bwd_wgrad(x_in, w.data, L.conv.bias.data, 3, G, stats, da, H.ACT_RELU, w.grad, dg, db, L.bn is not None,
+                                                dw_accumulate=True)
+                    self._grads_final_from(w, da)
+                    break
                 dy = ops.conv3_c1_norm_bwd(x_in, w.data, L.conv.bias.data, 3, G, stats, da, H.ACT_RELU, dg, db, L.bn is not None)
             elif nsl > 1:
                 # deep levels: dh is the raw split-K slabs of the dgrad that produced it; the backward-statistics pass sums them (bcp_norm_bwd_slabs)

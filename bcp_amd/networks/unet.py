@@ -189,6 +189,10 @@ class UNet_2d(HipNet):
                 da1, bpart, bnb = ops.conv3_dgrad_bwdstats(dy2, wd2, cb.cout, 1, y1, st1, H.ACT_LRELU, G)
             else:
                 da1 = ops.conv3_fwd(dy2, wd2, None, cb.cout, 1)
+            if y1 is None and ops.C1_BWD_FUSED:      # the fused first layer, its weight gradient in the same pass (bcp_conv3_c1_norm_bwd_wgrad): no dy1
+                ops.conv3_c1_norm_bwd_wgrad(h, cb.c1.weight.data, cb.c1.bias.data, 1, G, st1, da1, H.ACT_LRELU, cb.c1.weight.grad, cb.b1.weight.grad,
+                                            cb.b1.bias.grad, True, dw_accumulate=True, elem_mask=em, elem_scale=es)
+                return None
             if y1 is None:     # the fused first layer: y1 is recomputed from the block's input (bcp_conv3_c1_norm_bwd)
                 dy1 = ops.conv3_c1_norm_bwd(h, cb.c1.weight.data, cb.c1.bias.data, 1, G, st1, da1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True,
                                             elem_mask=em, elem_scale=es)

@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 503
+#define BCP_ABI_VERSION 504
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -235,6 +235,15 @@ int bcp_conv3_c1_norm_bwd(const float* x, const float* w, const float* bias_or_n
                           int accumulate, void* workspace, float* dy, void* stream);
 int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int KD, int accumulate, void* workspace,
                        void* stream);
+/* Round 5: bcp_conv3_c1_norm_bwd with THIS layer's weight gradient (networks/VNet.py:17-26 block_one / networks/unet.py:19-28 in_conv,
+ * backward) folded into its second pass: dy is never written (the first layer has no dgrad -- its weight gradient was dy's only reader) and
+ * bcp_conv3_c1_wgrad is not needed.  dw = float[16][1][T], += when dw_accumulate; equal to the two calls it replaces up to fp32 summation
+ * order.  dgamma / dbeta / accumulate as in bcp_conv3_c1_norm_bwd. */
+size_t bcp_conv3_c1_norm_bwd_wgrad_workspace_bytes(int N, int D, int H, int W, int KD, int groups);
+int bcp_conv3_c1_norm_bwd_wgrad(const float* x, const float* w, const float* bias_or_null, const float* da, int N, int D, int H, int W, int KD,
+                                int groups, const float* stats, int act, const uint8_t* elem_mask, float elem_scale,
+                                const unsigned long long* mask_seed_or_null, float mask_p_keep, float* dgamma, float* dbeta,
+                                int accumulate, void* workspace, float* dw, int dw_accumulate, void* stream);
 
 /* ---- k=2,s=2 conv (networks/VNet.py:74), k=2,s=2 transposed conv (networks/VNet.py:101), 1x1 conv (networks/unet.py:48).
  *      (D,H,W) are always the FINE grid dims.  Packed B matrices via bcp_k2_pack_weight(kind). */

@@ -1428,6 +1428,21 @@ def check_conv3_c1_norm(ops, dev):
         if bn:
             close(dg1, dg0, rtol=1e-6, msg=tag + " dgamma (+=)")
             close(db1, db0, rtol=1e-6, msg=tag + " dbeta (+=)")
+        # round 5: the same backward with the layer's weight gradient folded into its second pass (bcp_conv3_c1_norm_bwd_wgrad): dgamma /
+        # dbeta from the same first pass (bit-identical), dw (+=) equal to conv3_c1_wgrad of dy1 up to fp32 summation order
+        dw0 = (R(rng, *w.shape) * 0.05).to(dev).contiguous()
+        dw2 = dw0.clone()
+        ops.conv3_c1_wgrad(x, dy1, dw0, KD, accumulate=True)
+        dg2, db2 = (torch.full((16,), 3.0).to(dev), torch.full((16,), -2.0).to(dev)) if bn else (None, None)
+        ops.conv3_c1_norm_bwd_wgrad(x, w, b, KD, G, st1, da, act, dw2, dg2, db2, True, dw_accumulate=True, elem_mask=em, elem_scale=1.25)
+        close(dw2, dw0, rtol=2e-5, msg=tag + " dw of the fused backward (+=)")
+        if bn:
+            assert torch.equal(dg2.cpu(), dg1.cpu()) and torch.equal(db2.cpu(), db1.cpu()), tag + ": dgamma / dbeta of the fused backward"
+        dw3 = torch.empty_like(dw2)
+        ops.conv3_c1_norm_bwd_wgrad(x, w, b, KD, G, st1, da, act, dw3, None, None, False, dw_accumulate=False, elem_mask=em, elem_scale=1.25)
+        dw4 = torch.zeros_like(dw2)
+        ops.conv3_c1_wgrad(x, dy1, dw4, KD, accumulate=False)
+        close(dw3, dw4, rtol=2e-5, msg=tag + " dw of the fused backward (=)")
 
 
 def check_augment(ops, dev, golden_dir):
