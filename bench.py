@@ -85,6 +85,9 @@ def _work(name, shapes, ints):
     if name == "conv3_c1_norm_bwd":                        # (x, ..., da [.,16]): statistics pass + apply pass both read x and da, dy [.,16] written once
         vox = _numel(s0[:-1])
         return "hbm", 2.0 * 2.0 * vox * ints[0] * 9 * 16, 4.0 * vox * (2 + 2 * 16 + 16)
+    if name == "conv3_c1_norm_bwd_wgrad":                  # the same two passes, dy stays in LDS and feeds the layer's weight gradient (a third product)
+        vox = _numel(s0[:-1])
+        return "hbm", 3.0 * 2.0 * vox * ints[0] * 9 * 16, 4.0 * vox * (2 + 2 * 16)
     if name in ("down_fwd", "up_fwd", "down_dgrad", "up_dgrad", "pw_fwd"):   # k2s2 / 1x1 GEMMs: (x, packed B, [bias]); ints = (Cout,)
         cout = ints[0]
         vin = _numel(s0[:-1])
