@@ -19,6 +19,7 @@ cd /tmp
 rocprofv3 --kernel-trace -d /tmp/ev2 -o run --output-format csv -- python $R/bench.py --no-cpu-baseline --no-extra --no-roofline --steps 8 --warmup 4 > /tmp/ev2.log 2>&1
 cd $R
 python tools/timeline_attrib.py $(find /tmp/ev2 -name "*kernel_trace.csv" | head -1) --steps 4 --json $out/${tag}_timeline.json > $out/${tag}_timeline.txt
+python tools/step_sequence.py $(find /tmp/ev2 -name "*kernel_trace.csv" | head -1) > $out/${tag}_step_sequence.txt 2>&1      # one step as an ordered list with queues and gaps
 # round 5: the determinism evidence next to the numbers -- the stress harness (product configuration and per-launch replays, load generator)
 # and the upsample reproducer on this build
 { timeout 600 python tools/probe/replay_stress.py --what acdc --mode replay --load 1 --runs 150 --graphs 1 --tag product_graphs1 2>&1 | grep RESULT
