@@ -203,6 +203,15 @@ class Ops:
                                     "attribute is stale (in-place write after the producing pass?)")
         return a
 
+    @staticmethod
+    def _no_amax(out):
+        """an op WITHOUT |max| slots of its own has written into `out`: whatever slots the tensor carried describe its old contents (ADVICE
+        r04: an attribute that outlives an in-place write would overflow the fp16 planes of the next reader silently) -- drop them; the
+        next conv that reads `out` then takes the three-plane bf16 instance, which needs no |max|"""
+        if out is not None and getattr(out, "_bcp_amax", None) is not None:
+            out._bcp_amax = None
+        return out
+
     def box_arg(self, box6):
         key = tuple(int(v) for v in box6)
         a = self._box_cache.get(key)
@@ -495,7 +504,7 @@ class Ops:
         ws = self.workspace("conv3", nbytes, x) if nbytes else None
         self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), _p(self._amax_of(x)),
                     self.stream(x))
-        return out
+        return self._no_amax(out)
 
     def conv3_fwd_stats(self, x, wp, bias, Cout, KD, groups):
         """conv + fused norm statistics -> (y, partial, rows); rows == 0: statistics not fused for this shape (partial None)"""
@@ -641,7 +650,7 @@ class Ops:
         if out is None:
             out = torch.empty((N, D // 2, H // 2, W // 2, Cout), dtype=torch.float32, device=x.device)
         self.b.call("bcp_down_fwd", _p(x), _p(bp), _p(bias), _p(out), N, D, H, W, Cin, Cout, self.stream(x))
-        return out
+        return self._no_amax(out)
 
     def down_dgrad(self, dy, bp, Cin, out=None, accumulate=False):
         self._chk(dy, bp, out)
@@ -650,7 +659,7 @@ class Ops:
             assert not accumulate
             out = torch.empty((N, 2 * Dc, 2 * Hc, 2 * Wc, Cin), dtype=torch.float32, device=dy.device)
         self.b.call("bcp_down_dgrad", _p(dy), _p(bp), _p(out), N, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, int(bool(accumulate)), self.stream(dy))
-        return out
+        return self._no_amax(out)
 
     def up_fwd(self, x, bp, bias, Cout, out=None):
         self._chk(x, bp, bias)
@@ -658,7 +667,7 @@ class Ops:
         if out is None:
             out = torch.empty((N, 2 * Dc, 2 * Hc, 2 * Wc, Cout), dtype=torch.float32, device=x.device)
         self.b.call("bcp_up_fwd", _p(x), _p(bp), _p(bias), _p(out), N, 2 * Dc, 2 * Hc, 2 * Wc, Cin, Cout, self.stream(x))
-        return out
+        return self._no_amax(out)
 
     def up_dgrad(self, dy, bp, Cin, out=None, accumulate=False):
         self._chk(dy, bp, out)
@@ -666,7 +675,7 @@ class Ops:
         if out is None:
             out = torch.empty((N, D // 2, H // 2, W // 2, Cin), dtype=torch.float32, device=dy.device)
         self.b.call("bcp_up_dgrad", _p(dy), _p(bp), _p(out), N, D, H, W, Cin, Cout, int(bool(accumulate)), self.stream(dy))
-        return out
+        return self._no_amax(out)
 
     def pw_fwd(self, x, bp, bias, Cout, out=None):
         self._chk(x, bp, bias)
@@ -675,7 +684,7 @@ class Ops:
         if out is None:
             out = torch.empty(tuple(x.shape[:-1]) + (Cout,), dtype=torch.float32, device=x.device)
         self.b.call("bcp_pw_fwd", _p(x), _p(bp), _p(bias), _p(out), rows, Cin, Cout, self.stream(x))
-        return out
+        return self._no_amax(out)
 
     def k2_wgrad(self, x, dy, dw, kind, accumulate=False):
         """kind WG_DOWN: x fine, dy coarse; WG_UP: x coarse, dy fine; WG_PW: same grid."""
