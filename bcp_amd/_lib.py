@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 504      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 505      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int
@@ -47,6 +47,9 @@ _SIGS = {
     "bcp_mixloss_workspace_bytes": (SZ, [I, I]),
     "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P, P, P]),
     "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, I, P, P]),
+    "bcp_mixloss_pair_workspace_bytes": (SZ, [I, I]),
+    "bcp_mixloss_pair_fwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, F, F, F, F, P, P, P, P]),
+    "bcp_mixloss_pair_bwd": (I, [P, P, P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, I, P, P]),
     "bcp_dice_prob_workspace_bytes": (SZ, [I]),
     "bcp_dice_prob_fwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, P, P]),
     "bcp_dice_prob_bwd": (I, [P, L, L, L, P, P, I, P, I, I, I, I, I, P, P, F, P, P]),

@@ -53,13 +53,16 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
                                                      const uint8_t* __restrict__ patch_l,
                                                      const uint8_t* __restrict__ mask /* nullable: 1 = image term */,
                                                      BoxArg box, int D, int H, int W, double* __restrict__ acc, int N,
-                                                     unsigned* __restrict__ ticket) {
-  const int n = blockIdx.y;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *ticket = 0u;      // for k_mixloss_reduce's last-arriver hand-over
+                                                     unsigned* __restrict__ ticket,
+                                                     const uint8_t* __restrict__ img_l2, const uint8_t* __restrict__ patch_l2) {
+  // PAIR mode (round 5, img_l2 != NULL): both mix_loss calls of a step in one launch -- logits = [2N] samples, the second N with label maps
+  // of their own (img_l2 / patch_l2), the mask shared; blockIdx.y = sample of the pair, rows of partials per sample as before
+  const int ny = blockIdx.y, half = (img_l2 && ny >= N) ? 1 : 0, n = ny - half * N;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) ticket[threadIdx.x] = 0u;      // for k_mixloss_reduce's last-arriver hand-overs
   const long long V = (long long)D * H * W;
-  const float* lg = logits + (long long)n * V * C;
-  const uint8_t* la = img_l + (long long)n * V;
-  const uint8_t* lb = patch_l + (long long)n * V;
+  const float* lg = logits + (long long)ny * V * C;
+  const uint8_t* la = (half ? img_l2 : img_l) + (long long)n * V;
+  const uint8_t* lb = (half ? patch_l2 : patch_l) + (long long)n * V;
   const uint8_t* mk = mask ? mask + (long long)n * V : nullptr;
   double s[2][C][3];
   double ce[2] = {0.0, 0.0}, cnt[2] = {0.0, 0.0};
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
   // adding into the same 28 fp64 addresses serialised in L2 for ~40 us at the LA size -- and a fixed summation order
   const int nq = 2 * C * 3 + 4;
   if ((int)threadIdx.x < nq)
-    acc[((long long)n * gridDim.x + blockIdx.x) * nq + threadIdx.x] =
+    acc[((long long)ny * gridDim.x + blockIdx.x) * nq + threadIdx.x] =
         red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
@@ -226,7 +229,11 @@ __device__ void mixloss_finalize(const double* __restrict__ acc, float* __restri
 template <int C, bool ACDC>
 __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict__ partial, int nb, double* __restrict__ acc, int N,
                                                         unsigned* __restrict__ ticket, float* __restrict__ coef, float* __restrict__ out,
-                                                        float w_img, float w_patch, const float* __restrict__ prev, float* __restrict__ total) {
+                                                        float w_img, float w_patch, const float* __restrict__ prev, float* __restrict__ total,
+                                                        int pair, float w_img2, float w_patch2) {
+  // PAIR mode (pair != 0; grid = 2N blocks): blocks 0 .. N-1 are the first call, N .. 2N-1 the second, each half with reduced rows, ticket,
+  // coefficient table and out3 of its own (the second half's right behind the first's); the last arriver of a half finalises that half as
+  // the single call would, then the LATER of the two finalisers adds the step's total from both out3 in the first-call-then-second order
   // block n: the nb per-block rows of sample n -> acc[n][2*C*3] and tailp[n][4], in a fixed order (thread t sums rows t, t + 256, ...;
   // then lanes, waves).  The LAST block to arrive (ticket zeroed by the forward kernel, a kernel boundary earlier) turns the N reduced
   // rows into the loss scalar(s) and the coefficient table: no finalize launch.  The hand-over is a few hundred bytes per block:
@@ -235,7 +242,10 @@ __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict
   static_assert(nq <= 32, "one 32-lane slot per row");
   __shared__ double wred[8][32];
   __shared__ unsigned s_last;
-  const int n = blockIdx.x;
+  const int ny = blockIdx.x, half = (pair && ny >= N) ? 1 : 0, n = ny - half * N;
+  acc += (size_t)half * N * nq;                    // this half's reduced rows [N][2*C*3] | [N][4]
+  coef += (size_t)half * (N * 2 * C * 2 + 2);
+  out += half * 3;
   // eight row slots of 32 lanes: a row's nq doubles are read by consecutive lanes (coalesced; round 4 -- with thread = row the 224-byte
   // rows were read at a 224-byte stride: 19 us for the ACDC launch); slot s sums rows s, s + 8, ... in order, then the slots in order
   const int q = threadIdx.x & 31, rs = threadIdx.x >> 5;
@@ -243,7 +253,7 @@ __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict
   if (q < nq) {
     // eight loads in flight per thread (the plain loop issued them one by one: 64 dependent L2 round trips = 19 us for the LA launch);
     // rows are added in ascending order either way
-    const double* base = partial + (long long)n * nb * nq + q;
+    const double* base = partial + (long long)ny * nb * nq + q;
     int r = rs;
     for (; r + 56 < nb; r += 64) {
       double t[8];
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict
     __threadfence();
   }
   __syncthreads();
-  if (threadIdx.x == 0) s_last = (atomicAdd(ticket, 1u) == (unsigned)(N - 1)) ? 1u : 0u;
+  if (threadIdx.x == 0) s_last = (atomicAdd(ticket + half, 1u) == (unsigned)(N - 1)) ? 1u : 0u;
   __syncthreads();
   if (s_last) {
     // the N reduced rows come into the LDS with ALL threads loading (one dependent global round trip instead of ~N * nq of them in the
@@ -279,7 +289,21 @@ __global__ __launch_bounds__(256) void k_mixloss_reduce(const double* __restrict
     if (staged)
       for (int i = threadIdx.x; i < tot; i += 256) stage[i] = acc[i];          // acc = [N][2*C*3] | [N][4]: the layout mixloss_finalize reads
     __syncthreads();
-    if (threadIdx.x == 0) mixloss_finalize<C, ACDC>(staged ? stage : acc, coef, out, N, w_img, w_patch, prev, total);
+    if (threadIdx.x == 0) {
+      if (!pair) mixloss_finalize<C, ACDC>(staged ? stage : acc, coef, out, N, w_img, w_patch, prev, total);
+      else {
+        mixloss_finalize<C, ACDC>(staged ? stage : acc, coef, out, N, half ? w_img2 : w_img, half ? w_patch2 : w_patch, nullptr, nullptr);
+        __threadfence();
+        if (atomicAdd(ticket + 2, 1u) == 1u) {       // the other half's out3 is final and visible: the step's total, as the second call's finalize forms it
+          __threadfence();
+          const float* o1 = out - half * 3;          // first call's out3
+          const float a0 = __hip_atomic_load(o1 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1 = __hip_atomic_load(o1 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const float b0 = __hip_atomic_load(o1 + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), b1 = __hip_atomic_load(o1 + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (!ACDC) total[0] = a0 + b0;
+          else total[0] = ((a0 + b0) + (a1 + b1)) / 2.f;
+        }
+      }
+    }
   }
 }
 
@@ -288,13 +312,15 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
                                                      const uint8_t* __restrict__ patch_l, const uint8_t* __restrict__ mask,
                                                      BoxArg box, int D, int H, int W, const float* __restrict__ coef,
                                                      float* __restrict__ dlogits, int N, float g_dice, float g_ce,
-                                                     const float* __restrict__ g_dev /* nullable [g_dev_n] */, int g_dev_n) {
-  const int n = blockIdx.y;
+                                                     const float* __restrict__ g_dev /* nullable [g_dev_n] */, int g_dev_n,
+                                                     const uint8_t* __restrict__ img_l2, const uint8_t* __restrict__ patch_l2) {
+  const int ny = blockIdx.y, half = (img_l2 && ny >= N) ? 1 : 0, n = ny - half * N;      // PAIR mode: see k_mixloss_fwd
+  coef += (size_t)half * (N * 2 * C * 2 + 2);
   const long long V = (long long)D * H * W;
-  const float* lg = logits + (long long)n * V * C;
-  float* dl = dlogits + (long long)n * V * C;
-  const uint8_t* la = img_l + (long long)n * V;
-  const uint8_t* lb = patch_l + (long long)n * V;
+  const float* lg = logits + (long long)ny * V * C;
+  float* dl = dlogits + (long long)ny * V * C;
+  const uint8_t* la = (half ? img_l2 : img_l) + (long long)n * V;
+  const uint8_t* lb = (half ? patch_l2 : patch_l) + (long long)n * V;
   const uint8_t* mk = mask ? mask + (long long)n * V : nullptr;
   __shared__ float cf[2][C][2];
   __shared__ float cce[2];
@@ -364,10 +390,13 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
 
 constexpr int kLossPartialRows = 512;  // most forward blocks per sample = rows of per-block partials the reduce kernel sums
 
+// pair: the second call's label maps and weights (img_l2 == NULL: one call); N = samples PER CALL
+struct PairArg { const uint8_t* img_l2; const uint8_t* patch_l2; float w_img2, w_patch2; };
 template <int C, bool ACDC>
 static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
                       int N, int D, int H, int W, float w_img, float w_patch, double* acc,
-                      float* coef, float* out, const float* prev, float* total, hipStream_t s) {
+                      float* coef, float* out, const float* prev, float* total, hipStream_t s, const PairArg pa = PairArg{nullptr, nullptr, 0.f, 0.f}) {
+  const int NT = pa.img_l2 ? 2 * N : N;            // samples of the launch
   BoxArg bx;
   bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
@@ -375,27 +404,31 @@ static int launch_fwd(const float* logits, const uint8_t* img_l, const uint8_t* 
   const long long V = (long long)D * H * W;
   // 16 bytes of logits per lane and iteration: ~2 iterations per thread at the LA size, >= 2048 workgroups per launch at most
   long long nbl = (V * C / 4 + 511) / 512;
-  if (nbl * N > 1024) nbl = (1024 + N - 1) / N;
+  if (nbl * NT > 1024) nbl = (1024 + NT - 1) / NT;
   const int nb = (int)(nbl < 1 ? 1 : (nbl > kLossPartialRows ? kLossPartialRows : nbl));
-  double* red = acc + (size_t)N * kLossPartialRows * (2 * C * 3 + 4);          // [N][2*C*3] | [N][4]
-  unsigned* ticket = reinterpret_cast<unsigned*>(red + (size_t)N * (2 * C * 3 + 4));
-  hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(nb, N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H, W, acc, N, ticket);
-  hipLaunchKernelGGL((k_mixloss_reduce<C, ACDC>), dim3(N), dim3(256), 0, s, acc, nb, red, N, ticket, coef, out, w_img, w_patch, prev, total);
+  double* red = acc + (size_t)NT * kLossPartialRows * (2 * C * 3 + 4);          // per call: [N][2*C*3] | [N][4]
+  unsigned* ticket = reinterpret_cast<unsigned*>(red + (size_t)NT * (2 * C * 3 + 4));      // three words (one per call, one for the pair)
+  hipLaunchKernelGGL((k_mixloss_fwd<C, ACDC>), dim3(nb, NT), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H, W, acc, N, ticket,
+                     pa.img_l2, pa.patch_l2);
+  hipLaunchKernelGGL((k_mixloss_reduce<C, ACDC>), dim3(NT), dim3(256), 0, s, acc, nb, red, N, ticket, coef, out, w_img, w_patch, prev, total,
+                     pa.img_l2 ? 1 : 0, pa.w_img2, pa.w_patch2);
   return 0;
 }
 
 template <int C, bool ACDC>
 static int launch_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask, const int* box6,
-                      int N, int D, int H, int W, const float* coef, float* dlogits, float g_dice, float g_ce, const float* g_dev, int g_dev_n, hipStream_t s) {
+                      int N, int D, int H, int W, const float* coef, float* dlogits, float g_dice, float g_ce, const float* g_dev, int g_dev_n, hipStream_t s,
+                      const PairArg pa = PairArg{nullptr, nullptr, 0.f, 0.f}) {
+  const int NT = pa.img_l2 ? 2 * N : N;
   BoxArg bx;
   bx.v[0] = box6[0]; bx.v[1] = box6[0] + box6[3];
   bx.v[2] = box6[1]; bx.v[3] = box6[1] + box6[4];
   bx.v[4] = box6[2]; bx.v[5] = box6[2] + box6[5];
   const long long V = (long long)D * H * W;
   long long gb = (V * C / 4 + 255) / 256;          // one 16-byte vector per thread, at most ~4096 workgroups per launch
-  if (gb * N > 4096) gb = (4096 + N - 1) / N;
-  hipLaunchKernelGGL((k_mixloss_bwd<C, ACDC>), dim3((int)(gb < 1 ? 1 : gb), N), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
-                     W, coef, dlogits, N, g_dice, g_ce, g_dev, g_dev_n);
+  if (gb * NT > 4096) gb = (4096 + NT - 1) / NT;
+  hipLaunchKernelGGL((k_mixloss_bwd<C, ACDC>), dim3((int)(gb < 1 ? 1 : gb), NT), dim3(256), 0, s, logits, img_l, patch_l, mask, bx, D, H,
+                     W, coef, dlogits, N, g_dice, g_ce, g_dev, g_dev_n, pa.img_l2, pa.patch_l2);
   return 0;
 }
 
@@ -625,6 +658,56 @@ extern "C" int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const 
     launch_fwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out3, prev_out3_or_null,
                         total_or_null, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_mixloss_fwd");
+  return BCP_OK;
+}
+
+// ---- round 5: both mix_loss calls of a self-training step (LA_BCP_train.py:252-254, ACDC_BCP_train.py:370-377, train_pancreas.py:160-165) in ONE
+// launch pair: logits = [2N] samples (the grouped student forward's output), call 1 = samples 0 .. N-1 with (img_l, patch_l, w_img, w_patch),
+// call 2 = samples N .. 2N-1 with (img_l2, patch_l2, w_img2, w_patch2), the mask / box shared.  out6 = the two calls' out3 back to back,
+// total = the step's loss (what bcp_mixloss_fwd's prev / total form).  Bit-identical to the two calls.  workspace: bcp_mixloss_pair_workspace_bytes.
+static inline size_t pair_acc_bytes(int N, int C) { return (size_t)2 * N * (kLossPartialRows + 1) * (2 * C * 3 + 4) * sizeof(double) + 16; }
+extern "C" size_t bcp_mixloss_pair_workspace_bytes(int N, int C) {
+  const size_t coef = (size_t)2 * ((size_t)N * 2 * C * 2 + 2) * sizeof(float);
+  return ((pair_acc_bytes(N, C) + 15) / 16) * 16 + ((coef + 15) / 16) * 16;
+}
+static inline float* pair_coef_ptr(void* ws, int N, int C) {
+  return reinterpret_cast<float*>(reinterpret_cast<char*>(ws) + ((pair_acc_bytes(N, C) + 15) / 16) * 16);
+}
+
+extern "C" int bcp_mixloss_pair_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* img_l2, const uint8_t* patch_l2,
+                                    const uint8_t* mask_or_null, const int* box6, int N, int D, int H, int W, int C, int flavour,
+                                    float w_img, float w_patch, float w_img2, float w_patch2, void* workspace, float* out6, float* total,
+                                    void* stream) {
+  BCP_REQUIRE(logits && img_l && patch_l && img_l2 && patch_l2 && box6 && workspace && out6 && total, "bcp_mixloss_pair_fwd: null pointer");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_mixloss_pair_fwd: bad extents");
+  BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4),
+              "bcp_mixloss_pair_fwd: flavour/C combination unsupported (LA: C=2, ACDC: C=4), got flavour=%d C=%d", flavour, C);
+  double* acc = reinterpret_cast<double*>(workspace);
+  float* coef = pair_coef_ptr(workspace, N, C);
+  const PairArg pa{img_l2, patch_l2, w_img2, w_patch2};
+  if (flavour == BCP_LOSS_LA)
+    launch_fwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out6, nullptr, total, (hipStream_t)stream, pa);
+  else
+    launch_fwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, w_img, w_patch, acc, coef, out6, nullptr, total, (hipStream_t)stream, pa);
+  BCP_CHECK_LAUNCH("bcp_mixloss_pair_fwd");
+  return BCP_OK;
+}
+
+extern "C" int bcp_mixloss_pair_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* img_l2, const uint8_t* patch_l2,
+                                    const uint8_t* mask_or_null, const int* box6, int N, int D, int H, int W, int C, int flavour,
+                                    const void* workspace, float g_dice, float g_ce, const float* g_dev_or_null, int g_dev_n, float* dlogits,
+                                    void* stream) {
+  BCP_REQUIRE(logits && img_l && patch_l && img_l2 && patch_l2 && box6 && workspace && dlogits, "bcp_mixloss_pair_bwd: null pointer");
+  BCP_REQUIRE(!g_dev_or_null || g_dev_n == 1 || g_dev_n == 2, "bcp_mixloss_pair_bwd: g_dev_n=%d (1: one upstream gradient for both terms, 2: {dice, ce})", g_dev_n);
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && (long long)D * H * W < (1LL << 31), "bcp_mixloss_pair_bwd: bad extents");
+  BCP_REQUIRE((flavour == BCP_LOSS_LA && C == 2) || (flavour == BCP_LOSS_ACDC && C == 4), "bcp_mixloss_pair_bwd: flavour/C");
+  const float* coef = pair_coef_ptr(const_cast<void*>(workspace), N, C);
+  const PairArg pa{img_l2, patch_l2, 0.f, 0.f};
+  if (flavour == BCP_LOSS_LA)
+    launch_bwd<2, false>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, g_dev_n, (hipStream_t)stream, pa);
+  else
+    launch_bwd<4, true>(logits, img_l, patch_l, mask_or_null, box6, N, D, H, W, coef, dlogits, g_dice, g_ce, g_dev_or_null, g_dev_n, (hipStream_t)stream, pa);
+  BCP_CHECK_LAUNCH("bcp_mixloss_pair_bwd");
   return BCP_OK;
 }
 

@@ -271,6 +271,31 @@ class Ops:
                     float(w_img), float(w_patch), _p(ws), _p(out3), _p(prev), _p(total), self.stream(logits))
         return out3, ws
 
+    # utils/BCP_utils.mix_loss_pair: both mix_loss calls of a step as ONE launch pair (bcp_mixloss_pair_fwd / _bwd); False
+    # (BCP_MIXLOSS_PAIR=0, a measurement switch): two calls each way, the second one forming the step's total
+    MIXLOSS_PAIR = os.environ.get("BCP_MIXLOSS_PAIR", "1") != "0"
+
+    def mixloss_pair_fwd(self, logits, img_l, patch_l, img_l2, patch_l2, box6, flavour, w1, w2, mask=None):
+        """logits [2N, ...]: call 1 on the first N samples, call 2 on the rest -> (out6 float32[2, 3], total float32[1], workspace)"""
+        self._chk(logits, img_l, patch_l, img_l2, patch_l2, mask)
+        N2, D, H, W, Cc = logits.shape
+        N = N2 // 2
+        ws = torch.empty(int(self._ws_bytes("bcp_mixloss_pair_workspace_bytes", N, Cc)), dtype=torch.uint8, device=logits.device)  # kept alive for backward
+        out6 = torch.empty((2, 3), dtype=torch.float32, device=logits.device)
+        total = torch.empty(1, dtype=torch.float32, device=logits.device)
+        self.b.call("bcp_mixloss_pair_fwd", _p(logits), _p(img_l), _p(patch_l), _p(img_l2), _p(patch_l2), _p(mask), self.box_arg(box6), N, D, H, W, Cc,
+                    flavour, float(w1[0]), float(w1[1]), float(w2[0]), float(w2[1]), _p(ws), _p(out6), _p(total), self.stream(logits))
+        return out6, total, ws
+
+    def mixloss_pair_bwd(self, logits, img_l, patch_l, img_l2, patch_l2, box6, flavour, ws, g_dice, g_ce, mask=None, g_dev=None, out=None):
+        self._chk(logits, img_l, patch_l, img_l2, patch_l2, mask, out, g_dev)
+        N2, D, H, W, Cc = logits.shape
+        dlogits = torch.empty_like(logits) if out is None else out
+        self.b.call("bcp_mixloss_pair_bwd", _p(logits), _p(img_l), _p(patch_l), _p(img_l2), _p(patch_l2), _p(mask), self.box_arg(box6), N2 // 2, D, H, W,
+                    Cc, flavour, _p(ws), float(g_dice), float(g_ce), _p(g_dev), 0 if g_dev is None else int(g_dev.numel()), _p(dlogits),
+                    self.stream(logits))
+        return dlogits
+
     def mixloss_bwd(self, logits, img_l, patch_l, box6, flavour, ws, g_dice, g_ce, mask=None, g_dev=None, out=None):
         """g_dev: device float32 of upstream gradients -- two elements {dice, ce} or ONE for both terms"""
         self._chk(logits, img_l, patch_l, mask, out, g_dev)
@@ -914,7 +939,7 @@ class Ops:
 # ---------------------------------------------------------------------------------------------- measurement hooks
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
-_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
+_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "mixloss_pair_fwd", "mixloss_pair_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
              "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")

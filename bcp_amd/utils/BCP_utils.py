@@ -245,9 +245,14 @@ class _MixLossPairTotalFn(torch.autograd.Function):
         ops = _ops_for(logits_cl)
         n = logits_cl.shape[0] // 2
         a, b = logits_cl[:n], logits_cl[n:]
-        total = torch.empty(1, dtype=torch.float32, device=logits_cl.device)
-        o1, ws1 = ops.mixloss_fwd(a, lab1, plab1, box6, flavour, w1[0], w1[1], mask=mask_u8)
-        o2, ws2 = ops.mixloss_fwd(b, lab2, plab2, box6, flavour, w2[0], w2[1], mask=mask_u8, prev=o1, total=total)
+        ctx.pair = bool(ops.MIXLOSS_PAIR and logits_cl.shape[0] == 2 * n and logits_cl.is_contiguous())
+        if ctx.pair:        # both calls in one launch pair (bcp_mixloss_pair_fwd): bit-identical results, three launches fewer per step
+            o6, total, ws1 = ops.mixloss_pair_fwd(logits_cl, lab1, plab1, lab2, plab2, box6, flavour, w1, w2, mask=mask_u8)
+            o1, o2, ws2 = o6[0], o6[1], ws1
+        else:
+            total = torch.empty(1, dtype=torch.float32, device=logits_cl.device)
+            o1, ws1 = ops.mixloss_fwd(a, lab1, plab1, box6, flavour, w1[0], w1[1], mask=mask_u8)
+            o2, ws2 = ops.mixloss_fwd(b, lab2, plab2, box6, flavour, w2[0], w2[1], mask=mask_u8, prev=o1, total=total)
         ctx.save_for_backward(logits_cl, lab1, plab1, lab2, plab2, ws1, ws2)
         ctx.meta = (box6, mask_u8, flavour)
         terms = (o1[0], o2[0]) if flavour == H.LOSS_LA else (o1[0], o1[1], o2[0], o2[1])
@@ -264,6 +269,9 @@ class _MixLossPairTotalFn(torch.autograd.Function):
         g1 = g.reshape(1)
         if g1.dtype != torch.float32 or not g1.is_contiguous():
             g1 = g1.to(torch.float32).contiguous()
+        if ctx.pair:
+            ops.mixloss_pair_bwd(logits_cl, lab1, plab1, lab2, plab2, box6, flavour, ws1, 0.5, 0.5, mask=mask_u8, g_dev=g1, out=d)
+            return (d,) + (None,) * 9
         for half, (lab, plab, ws) in enumerate(((lab1, plab1, ws1), (lab2, plab2, ws2))):
             sl = slice(0, n) if half == 0 else slice(n, 2 * n)
             ops.mixloss_bwd(logits_cl[sl], lab, plab, box6, flavour, ws, 0.5, 0.5, mask=mask_u8, g_dev=g1, out=d[sl])

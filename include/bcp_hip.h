@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 504
+#define BCP_ABI_VERSION 505
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -94,6 +94,17 @@ int bcp_mixloss_fwd(const float* logits, const uint8_t* img_l, const uint8_t* pa
 int bcp_mixloss_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* mask_or_null, const int* box6 /* HOST */,
                     int N, int D, int H, int W, int C, int flavour, const void* workspace, float g_dice, float g_ce, const float* g_dev_or_null,
                     int g_dev_n, float* dlogits, void* stream);
+/* Round 5: BOTH mix_loss calls of a self-training step (LA_BCP_train.py:252-254, ACDC_BCP_train.py:370-377, train_pancreas.py:160-165) in one
+ * launch pair.  logits = [2N] samples, the grouped student forward's output: call 1 = samples 0 .. N-1 with (img_l, patch_l, w_img, w_patch),
+ * call 2 = samples N .. 2N-1 with (img_l2, patch_l2, w_img2, w_patch2); mask / box shared ([N] samples).  out6 = the two calls' out3 back to
+ * back, total = the step's loss as prev_out3 / total of bcp_mixloss_fwd form it.  Results are bit-identical to the two calls. */
+size_t bcp_mixloss_pair_workspace_bytes(int N, int C);
+int bcp_mixloss_pair_fwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* img_l2, const uint8_t* patch_l2,
+                         const uint8_t* mask_or_null, const int* box6 /* HOST */, int N, int D, int H, int W, int C, int flavour,
+                         float w_img, float w_patch, float w_img2, float w_patch2, void* workspace, float* out6, float* total, void* stream);
+int bcp_mixloss_pair_bwd(const float* logits, const uint8_t* img_l, const uint8_t* patch_l, const uint8_t* img_l2, const uint8_t* patch_l2,
+                         const uint8_t* mask_or_null, const int* box6 /* HOST */, int N, int D, int H, int W, int C, int flavour,
+                         const void* workspace, float g_dice, float g_ce, const float* g_dev_or_null, int g_dev_n, float* dlogits, void* stream);
 
 /* ---- utils/losses.py:79-134 `DiceLoss.forward(inputs, target, mask=None, weight=None, softmax=False)` as the CLASS the ACDC
  *      script instantiates (ACDC_BCP_train.py:66) and calls on F.softmax(output) (:170-176): `probs` are PROBABILITIES in any

@@ -167,6 +167,31 @@ def check_mixloss(ops, dev, golden_dir):
     o2, _ = ops.mixloss_fwd(lcl, b8, a8, box, H.LOSS_ACDC, 1.0, 0.5, prev=o1, total=tot)
     o1c, o2c = o1.cpu(), o2.cpu()
     assert float(tot[0]) == float(((o1c[0] + o2c[0]) + (o1c[1] + o2c[1])) / 2), "step total (ACDC): ((unl_dice + l_dice) + (unl_ce + l_ce)) / 2"
+    # round 5: both calls of a step as ONE launch pair (bcp_mixloss_pair_fwd / _bwd) -- out3 of either call, the step's total and the
+    # gradient BIT-identical to the two calls; both flavours, box and dense mask, several samples per call, a sample count whose
+    # per-call blocks do not divide evenly
+    rng = np.random.default_rng(47)
+    for flavour, Cc, sp, N in ((H.LOSS_LA, 2, (12, 14, 10), 1), (H.LOSS_LA, 2, (9, 11, 7), 3), (H.LOSS_ACDC, 4, (1, 24, 28), 2), (H.LOSS_ACDC, 4, (1, 17, 19), 5)):
+        lg = torch.from_numpy(rng.standard_normal((2 * N,) + sp + (Cc,), dtype=np.float32) * 2).to(dev)
+        lab = [torch.from_numpy(rng.integers(0, Cc, (N,) + sp).astype(np.uint8)).to(dev) for _ in range(4)]
+        bx = (0, 3, 2, 1, sp[1] // 2, sp[2] // 2) if sp[0] == 1 else (2, 3, 1, sp[0] // 2, sp[1] // 2, sp[2] // 2)
+        for mask in (None, torch.from_numpy((rng.random((N,) + sp) < 0.6).astype(np.uint8)).to(dev)):
+            box = bx if mask is None else (0, 0, 0, 0, 0, 0)
+            w1, w2 = (1.0, 0.5), (0.5, 1.0)
+            o1, ws1 = ops.mixloss_fwd(lg[:N], lab[0], lab[1], box, flavour, w1[0], w1[1], mask=mask)
+            tot = torch.empty(1, dtype=torch.float32, device=dev)
+            o2, ws2 = ops.mixloss_fwd(lg[N:], lab[2], lab[3], box, flavour, w2[0], w2[1], mask=mask, prev=o1, total=tot)
+            gd = torch.tensor([0.83], dtype=torch.float32).to(dev)
+            d_ref = torch.empty_like(lg)
+            ops.mixloss_bwd(lg[:N], lab[0], lab[1], box, flavour, ws1, 0.5, 0.5, mask=mask, g_dev=gd, out=d_ref[:N])
+            ops.mixloss_bwd(lg[N:], lab[2], lab[3], box, flavour, ws2, 0.5, 0.5, mask=mask, g_dev=gd, out=d_ref[N:])
+            o6, tot2, wsp = ops.mixloss_pair_fwd(lg, lab[0], lab[1], lab[2], lab[3], box, flavour, w1, w2, mask=mask)
+            d_pair = ops.mixloss_pair_bwd(lg, lab[0], lab[1], lab[2], lab[3], box, flavour, wsp, 0.5, 0.5, mask=mask, g_dev=gd)
+            tag = f"mixloss pair flavour={flavour} {sp} N={N} mask={'dense' if mask is not None else 'box'}"
+            assert torch.equal(o6[0].cpu(), o1.cpu()) and torch.equal(o6[1].cpu(), o2.cpu()), (tag, o6.cpu(), o1.cpu(), o2.cpu())
+            assert torch.equal(tot2.cpu(), tot.cpu()), (tag, "total", float(tot2[0]), float(tot[0]))
+            assert torch.equal(d_pair.cpu(), d_ref.cpu()), tag + ": gradient"
+            assert float(d_pair.abs().max()) > 0 and float(tot2[0]) == float(tot2[0])
 
 
 def _acdc_mix_loss_body(dice_loss, output, img_l, patch_l, mask, l_weight=1.0, u_weight=0.5, unlab=False):
