@@ -155,6 +155,7 @@ def pre_train(args, snapshot_path, device):
 def self_train(args, pre_snapshot_path, snapshot_path, device):
     model = BCP_net(in_chns=1, class_num=args.num_classes)
     ema_model = BCP_net(in_chns=1, class_num=args.num_classes, ema=True)
+    model.volatile_io = ema_model.volatile_io = True      # this loop consumes a pass's outputs before the network's next pass (networks/_hipnet.py)
     db_train, sampler = _loader(args, device)
     optimizer = train_step.FlatSGD(model, lr=args.base_lr, momentum=0.9, weight_decay=0.0001)
     start = os.path.join(pre_snapshot_path, "{}_best_model.pth".format(args.model))

@@ -160,6 +160,7 @@ def self_train(args, pre_snapshot_path, self_snapshot_path, device):
     ema_model = net_factory(net_type=args.model, in_chns=1, class_num=num_classes, mode="train")
     for p in ema_model.parameters():
         p.detach_()                     # the teacher never sees a gradient
+    model.volatile_io = ema_model.volatile_io = True      # this loop consumes a pass's outputs before the network's next pass (networks/_hipnet.py)
     db_train, sampler = _data(args, device)
     optimizer = _optimizer(args, model)
     start = os.path.join(pre_snapshot_path, f"{args.model}_best_model.pth")

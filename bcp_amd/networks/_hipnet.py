@@ -532,6 +532,35 @@ class HipNet(nn.Module):
             object.__setattr__(self, "_plan_state", st)
         return st[1]
 
+    # volatile_io (the training scripts and bench.py set it; off by default): the caller consumes a replayed pass's results before the
+    # NEXT pass of this network and fills its inputs in place -- the logits are handed out as an alias of the plan's static tensor instead
+    # of a copy, input_buffer() / dout_buffer() hand the plan's static input tensors to the producers (the copy-paste mix, the loss
+    # backward), and a pass whose input already IS that tensor skips its copy: three device copies per student pass (8 + 16 + 16 MB at the
+    # LA size, ~30 us with their launch gaps) and one per teacher pass.  Everything else -- launch lists, arithmetic, results -- is the same.
+    volatile_io = False
+
+    def _io_plan(self, kind, shape):
+        if not self.volatile_io or self.__dict__.get("_plan_state") is None:
+            return None
+        self._ensure_flat()
+        pl = self._plans_for().get((kind, tuple(shape)))
+        return None if (pl is None or pl.busy) else pl
+
+    def input_buffer(self, xshape):
+        """a logical view [N, 1, ...] of the static input of the training-forward plan for inputs of this shape (None: no such plan yet, or
+        busy, or volatile_io off): what is written there needs no copy into the plan"""
+        xshape = tuple(xshape)
+        if len(xshape) not in (4, 5) or xshape[1] != 1:
+            return None
+        cl = (xshape[0],) + ((1,) if len(xshape) == 4 else ()) + xshape[2:] + (1,)
+        pl = self._io_plan("in", cl)
+        return None if pl is None else pl.static_in.view(xshape)
+
+    def dout_buffer(self, clshape):
+        """the static input of the backward plan for logits gradients of this (channels-last) shape, or None"""
+        pl = self._io_plan("bin", clshape)
+        return None if pl is None else pl.static_in
+
     def _run_forward(self, xcl, save):
         if not self._plan_ok(xcl):
             r = self._forward_impl(xcl, save)
@@ -562,20 +591,24 @@ class HipNet(nn.Module):
             pl.ticks = getattr(self, "_nbt", 0) - t0
             plans[key] = pl
         else:
-            pl.static_in.copy_(xcl)
+            if xcl.data_ptr() != pl.static_in.data_ptr():       # (volatile_io: the producer wrote into input_buffer())
+                pl.static_in.copy_(xcl)
             pl.replay(self.ops, [self.next_seed() for _ in range(pl.n_seeds)], xcl)
             for _ in range(pl.ticks):
                 self._nbt_tick()
+        if save:
+            plans[("in", tuple(xcl.shape))] = pl
         out, saved = pl.result
         f = getattr(out, "_bcp_feat", None)
         self._feat_out = None if f is None else f.clone()
         # the logits leave the plan as a COPY (16 MB at the LA size): callers may hold them across the next replay (logging, the
         # reference's unfused loop), and a replay overwrites the plan's static tensors in place
+        res = out.detach() if (self.volatile_io and self.training) else out.clone()      # volatile_io (training passes only): an alias, valid until the next pass of this network
         if save:
             ps = _PlanSaved(saved, pl)
             pl.busy = ps.token          # cleared by the backward pass -- or when `ps` dies without one (a discarded loss, an exception)
-            return out.clone(), ps
-        return out.clone(), None
+            return res, ps
+        return res, None
 
     def _run_backward(self, saved, dout):
         self._wait_dgrad_packs()
@@ -600,9 +633,11 @@ class HipNet(nn.Module):
                     self._backward_impl(saved, pl.static_in)
                 plans[key] = pl
             else:
-                pl.static_in.copy_(dout)
+                if dout.data_ptr() != pl.static_in.data_ptr():      # (volatile_io: the loss backward wrote into dout_buffer())
+                    pl.static_in.copy_(dout)
                 self.begin_backward()
                 pl.replay(self.ops, (), dout)
+            plans[("bin", tuple(dout.shape))] = pl
         finally:
             if fwd.busy is tok:
                 fwd.busy = False

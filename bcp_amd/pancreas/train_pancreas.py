@@ -122,6 +122,7 @@ def main(argv=None):
     device = torch.device("cuda", torch.cuda.current_device())
     plan.use_real_stream(device)      # a real stream: what the capture of the recorded forward passes into HIP graphs needs (plan.GRAPHS = 1, the default)
     net, ema_net = create_Vnet(), create_Vnet(ema=True)
+    net.volatile_io = ema_net.volatile_io = True      # the loops below consume a pass's outputs before the network's next pass (networks/_hipnet.py)
     ema_net.load_state_dict(net.state_dict())
     optimizer = train_step.FlatAdam(net, lr=lr)
     if args.data_root and args.list_dir:

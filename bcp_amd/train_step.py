@@ -29,6 +29,18 @@ _SIDE = {}
 TEACHER_STREAM_PRIORITY = 0      # measurement switch (bench.py --opt teacher_prio=-1): HIP priority of the teacher's side stream
 
 
+def _backward(model, loss):
+    """loss.backward() with the student's backward-plan input tensor offered to the loss backward (volatile_io, networks/_hipnet.py)"""
+    vol = getattr(model, "volatile_io", False)
+    if vol:
+        BU.set_grad_buffer_provider(model.dout_buffer)
+    try:
+        loss.backward(gradient=BU.unit_gradient(loss))
+    finally:
+        if vol:
+            BU.set_grad_buffer_provider(None)
+
+
 def _side_stream(t):
     s = _SIDE.get(t.device)
     if s is None:
@@ -268,7 +280,10 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
     else:
         terms = ((plab_a, lab_b, u_weight, 1.0), (lab_a, plab_b, 1.0, u_weight))       # train_pancreas.py:160,164 (the reference passes no u_weight: mix_loss's default 0.5 = ours)
     if grouped:
-        mixed = torch.empty((2 * sub_bs,) + tuple(volume_batch.shape[1:]), dtype=volume_batch.dtype, device=volume_batch.device)
+        mshape = (2 * sub_bs,) + tuple(volume_batch.shape[1:])
+        mixed = model.input_buffer(mshape) if getattr(model, "volatile_io", False) else None      # the forward plan's own input tensor: no copy
+        if mixed is None or mixed.dtype != volume_batch.dtype:
+            mixed = torch.empty(mshape, dtype=volume_batch.dtype, device=volume_batch.device)
         BU.mix(pairs[0][0], pairs[0][1], img_mask, out=mixed[:sub_bs])
         BU.mix(pairs[1][0], pairs[1][1], img_mask, out=mixed[sub_bs:])
         model.drop_masks = cat_drops("s_l", "s_u")
@@ -292,12 +307,12 @@ def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, l
         loss_u = BU.mix_loss(outputs_u, terms[1][0], terms[1][1], loss_mask, l_weight=terms[1][2], u_weight=terms[1][3])
         loss = loss_l + loss_u
     if optimizer is None:      # gradient-only mode (DP equivalence tests): caller owns zero_grad / step / EMA
-        loss.backward(gradient=BU.unit_gradient(loss))
+        _backward(model, loss)
     else:
         optimizer.zero_grad()
         if dp is not None and grouped:
             dp.arm(model)              # ONE backward in this step: gradient buckets go out underneath it
-        loss.backward(gradient=BU.unit_gradient(loss))
+        _backward(model, loss)
         if dp is not None:
             dp.allreduce_grads(model, optimizer)
         optimizer.step()
@@ -421,7 +436,10 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
     if plabs is not None:
         plab_a, plab_b = plabs[0].to(volume_batch.device), plabs[1].to(volume_batch.device)
     if grouped:
-        mixed = torch.empty((2 * lsub,) + tuple(volume_batch.shape[1:]), dtype=volume_batch.dtype, device=volume_batch.device)
+        mshape = (2 * lsub,) + tuple(volume_batch.shape[1:])
+        mixed = model.input_buffer(mshape) if getattr(model, "volatile_io", False) else None      # the forward plan's own input tensor: no copy
+        if mixed is None or mixed.dtype != volume_batch.dtype:
+            mixed = torch.empty(mshape, dtype=volume_batch.dtype, device=volume_batch.device)
         BU.mix(uimg_a, img_a, img_mask, out=mixed[:lsub])      # net_input_unl, ACDC_BCP_train.py:372
         BU.mix(img_b, uimg_b, img_mask, out=mixed[lsub:])      # net_input_l,   :373
         model.drop_masks = cat_drops("s_unl", "s_l")
@@ -452,12 +470,12 @@ def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch,
         loss_dice = unl_dice + l_dice
         loss = (loss_dice + loss_ce) / 2
     if optimizer is None:              # gradient-only mode: the caller owns zero_grad / step / EMA
-        loss.backward(gradient=BU.unit_gradient(loss))
+        _backward(model, loss)
     else:
         optimizer.zero_grad()
         if dp is not None:
             dp.arm(model)              # one backward covers both student batches (grouped or not: `loss` sums their terms)
-        loss.backward(gradient=BU.unit_gradient(loss))
+        _backward(model, loss)
         if dp is not None:
             dp.allreduce_grads(model, optimizer)
         optimizer.step()

@@ -233,6 +233,23 @@ class _MixLossPairFn(torch.autograd.Function):
         return (d,) + (None,) * 9
 
 
+_GRAD_BUFFER = None      # (volatile_io) callable: channels-last logits shape -> the tensor the network's backward plan reads its input from, or None
+
+
+def set_grad_buffer_provider(fn):
+    """the step functions hand the loss backward the student's dout_buffer (networks/_hipnet.py volatile_io): the logits gradient is then
+    written where the backward plan reads it, no copy in between; None switches it off"""
+    global _GRAD_BUFFER
+    _GRAD_BUFFER = fn
+
+
+def _grad_buffer(like):
+    d = _GRAD_BUFFER(tuple(like.shape)) if _GRAD_BUFFER is not None else None
+    if d is None or d.shape != like.shape or d.dtype != like.dtype or d.device != like.device:
+        d = torch.empty_like(like)
+    return d
+
+
 class _MixLossPairTotalFn(torch.autograd.Function):
     """_MixLossPairFn whose differentiable output is the step's TOTAL loss -- LA / pancreas loss_l + loss_u, ACDC ((unl_dice + l_dice) +
     (unl_ce + l_ce)) / 2, summed by the second call's finalize in the reference's fp32 order (bcp_mixloss_fwd prev / total) -- so that no
@@ -265,7 +282,7 @@ class _MixLossPairTotalFn(torch.autograd.Function):
         box6, mask_u8, flavour = ctx.meta
         ops = _ops_for(logits_cl)
         n = logits_cl.shape[0] // 2
-        d = torch.empty_like(logits_cl)
+        d = _grad_buffer(logits_cl)
         g1 = g.reshape(1)
         if g1.dtype != torch.float32 or not g1.is_contiguous():
             g1 = g1.to(torch.float32).contiguous()

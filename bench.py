@@ -44,6 +44,12 @@ PEAK_HBM_GBS = 8000.0               # same guide: HBM3E spec (6290 GB/s measured
 STEP_GFLOP_PER_VOLUME = 160.0       # 1/2 teacher fwd + 1/2 student fwd+bwd per input volume
 
 
+# as the training scripts run the networks (bcp_amd/LA_BCP_train.py, ACDC_BCP_train.py, pancreas/train_pancreas.py): results of a replayed pass
+# are consumed before the network's next pass, so they are handed out as aliases and the producers write into the plans' own input tensors
+# (networks/_hipnet.py volatile_io).  BCP_VOLATILE_IO=0: defensive copies in and out of every pass (measurement switch)
+_VOLATILE_IO = os.environ.get("BCP_VOLATILE_IO", "1") != "0"
+
+
 def build_models(dev, seed):
     from bcp_amd.networks.net_factory import net_factory
     torch.manual_seed(seed)
@@ -395,6 +401,7 @@ def make_workload(args, dp, dev):
         def step():
             return train_step.la_self_train_step(model, ema_model, opt, vol, lab, args.labeled_bs, dp=dp if dp.enabled else None)
         step.models = (model, ema_model)
+        model.volatile_io = ema_model.volatile_io = _VOLATILE_IO
         return step, {"metric": "training volumes/sec (LA 112x112x80 V-Net, BCP self-training step)", "unit": "volumes/s",
                       "what": f"LA 3D V-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), 112x112x80 patches, "
                               "SGD m0.9 wd1e-4, EMA 0.99 (BASELINE.json configs[1])", "gflop_per_item": STEP_GFLOP_PER_VOLUME}
@@ -412,6 +419,7 @@ def make_workload(args, dp, dev):
         def step():
             return train_step.acdc_self_train_step(model, ema_model, opt, vol, lab, args.labeled_bs, dp=dp if dp.enabled else None)
         step.models = (model, ema_model)
+        model.volatile_io = ema_model.volatile_io = _VOLATILE_IO
         return step, {"metric": "training slices/sec (ACDC 256x256 U-Net, BCP self-training step)", "unit": "slices/s",
                       "what": f"ACDC 2D U-Net BCP self-train step, per-GPU batch {args.batch_size} ({args.labeled_bs} labeled), 256x256 slices, SGD, "
                               "state-dict EMA (BASELINE.json configs[3])",
@@ -428,6 +436,7 @@ def make_workload(args, dp, dev):
     def step():
         return {"loss": TP.ema_cutmix(model, ema_model, opt, streams, 1, dp=dp if dp.enabled else None)}
     step.models = (model, ema_model)
+    model.volatile_io = ema_model.volatile_io = _VOLATILE_IO
     return step, {"metric": "training volumes/sec (Pancreas 96^3 IN-V-Net, BCP self-training step)", "unit": "volumes/s",
                   "what": f"Pancreas IN-V-Net BCP self-train step, per-GPU 4 streams x {args.batch_size // 4}, 96^3 patches, Adam 1e-3 "
                           "(BASELINE.json configs[4])", "gflop_per_item": 70.72 * 2}

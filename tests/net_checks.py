@@ -1185,12 +1185,15 @@ class LoadGenerator:
 
 
 def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=None, overlap=True, real_stream=False,
-                       load=None):
+                       load=None, volatile=False):
     """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net
     (grouped and as the reference's four separate calls -- the second student call must not reuse the busy plan), the pancreas
     V-Net and the ACDC U-Net, live Dropout / Dropout3d (the seeds are patched into the recorded launches), weights, teacher
     weights and running statistics compared after the last step.
     load: a LoadGenerator -- every step of the REPLAYED run starts behind a burst of copies / GEMMs on a third stream (round 5)
+    volatile: the replayed run's networks run with volatile_io (round 5, networks/_hipnet.py: logits handed out as aliases of the plans'
+    tensors, the copy-paste mix and the loss backward writing straight into the plans' input tensors) as the training scripts and bench.py
+    set it -- same bits, and the plans' input tensors must really have been handed out
     graphs (GPU): plan.GRAPHS for the replayed run -- None: the module's default (1 since round 5: forward passes captured when the run
     lives on a real stream), 0 / False: per-launch replays only, 2: the backward pass captured too"""
     from bcp_amd import plan, train_step
@@ -1229,6 +1232,8 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
             ema.seed_dropout(12)
             for p in ema.parameters():
                 p.detach_()
+            if enabled and volatile:
+                model.volatile_io = ema.volatile_io = True
             vol, lab = vol.to(dev), lab.to(dev)
             opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
             losses = []
@@ -1241,8 +1246,15 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
                     r = train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), variant=what,
                                                       connect_mode=2 if what != "la" else None, grouped=grouped, overlap=overlap)
                 losses.append(float(r["loss"]))
-            plans = list(model.__dict__.get("_plan_state", (None, {}))[1].values()) + list(ema.__dict__.get("_plan_state", (None, {}))[1].values())
-            n_plans = len(model.__dict__.get("_plan_state", (None, {}))[1])
+            if enabled and volatile and grouped:
+                half = vol.shape[0] // 2
+                buf = model.input_buffer((half,) + tuple(vol.shape[1:]))
+                assert buf is not None and r["outputs_l" if what != "acdc" else "out_unl"].data_ptr() != 0, (what, "volatile_io: no input buffer handed out")
+                cl_logits = tuple(BU._as_cl(torch.cat([r["outputs_l"], r["outputs_u"]]) if what != "acdc" else torch.cat([r["out_unl"], r["out_l"]])).shape)
+                assert model.dout_buffer(cl_logits) is not None, (what, "volatile_io: no backward input buffer")
+            plans = [p for k, p in model.__dict__.get("_plan_state", (None, {}))[1].items() if k[0] not in ("in", "bin")] + \
+                    [p for k, p in ema.__dict__.get("_plan_state", (None, {}))[1].items() if k[0] not in ("in", "bin")]
+            n_plans = len([k for k in model.__dict__.get("_plan_state", (None, {}))[1] if k[0] not in ("in", "bin")])
             if enabled and graphs:
                 assert steps >= 3
                 n_graph = sum(1 for p in plans if p.graph is not None)

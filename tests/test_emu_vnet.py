@@ -98,6 +98,13 @@ def test_recorded_launch_plans_equal_eager_path(emu_ops):
     NC.check_launch_plans(emu_ops, CPU, steps=2, cases=(("la", False),))      # unfused: plan + busy-plan fallback (all four workloads: the GPU suite)
 
 
+def test_volatile_io_replays_equal_eager_path(emu_ops):
+    """round 5: the networks as the training scripts run them (volatile_io: no copies in and out of the recorded passes) == the eager path"""
+    from bcp_amd.utils import BCP_utils as BU
+    BU.set_test_ops(emu_ops)
+    NC.check_launch_plans(emu_ops, CPU, steps=3, cases=(("la", True),), volatile=True)
+
+
 @pytest.mark.extended
 def test_head_fused_with_last_norm_equals_separate_apply(emu_ops):
     """VNet.fuse_head: block_nine's norm + ReLU + Dropout3d applied inside the 1x1x1 head (its activation never stored)"""

@@ -244,6 +244,11 @@ def test_product_configuration_under_load_equals_eager_path(ops):
             NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", True), ("pancreas", True)), graphs=None, real_stream=True, load=load)
         for _ in range(6):
             NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True),), graphs=2, real_stream=True, load=load)
+        # ... and exactly as bench.py and the training scripts set the networks up (round 5, volatile_io: no copies in and out of the passes)
+        for _ in range(6):
+            NC.check_launch_plans(ops, DEV, steps=4, cases=(("acdc", True), ("la", True), ("pancreas", True)), graphs=None, real_stream=True, load=load,
+                                  volatile=True)
+        NC.check_launch_plans(ops, DEV, steps=4, cases=(("la", False),), graphs=None, real_stream=True, load=load, volatile=True)      # (the unfused loop: busy plans)
     finally:
         load.finish()
 
