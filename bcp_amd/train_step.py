@@ -208,9 +208,36 @@ class FlatAdam:
 
 
 # ------------------------------------------------------------------------------------------ LA / pancreas step
+class _NoVolatileIO:
+    """the unfused loops (grouped=False: the reference's four separate network calls) hold the first call's outputs across the second call
+    of the same network, which volatile_io (networks/_hipnet.py) does not allow: those steps run with defensive copies"""
+
+    def __init__(self, *nets):
+        self.nets = [n for n in nets if getattr(n, "volatile_io", False)]
+
+    def __enter__(self):
+        for n in self.nets:
+            n.volatile_io = False
+
+    def __exit__(self, *a):
+        for n in self.nets:
+            n.volatile_io = True
+
+
 def la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
                        u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None, grouped=True,
                        overlap=True, plabs=None):
+    if not grouped and (getattr(model, "volatile_io", False) or getattr(ema_model, "volatile_io", False)):
+        with _NoVolatileIO(model, ema_model):
+            return la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box, drops, u_weight, mask_ratio, alpha,
+                                      variant, connect_mode, dp, grouped, overlap, plabs)
+    return _la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box, drops, u_weight, mask_ratio, alpha, variant,
+                               connect_mode, dp, grouped, overlap, plabs)
+
+
+def _la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
+                        u_weight=0.5, mask_ratio=2 / 3, alpha=0.99, variant="la", connect_mode=None, dp=None, grouped=True,
+                        overlap=True, plabs=None):
     """One self-training iteration, LA_BCP_train.py:235-270 (variant 'pancreas': train_pancreas.py:145-171).
 
     volume_batch [B,1,X,Y,Z] float32 laid out lab_a|lab_b|unlab_a|unlab_b, label_batch [B,X,Y,Z].
@@ -388,6 +415,16 @@ def update_model_ema(model, ema_model, alpha):
 
 def acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
                          u_weight=0.5, alpha=0.99, dp=None, grouped=True, overlap=True, plabs=None):
+    if not grouped and (getattr(model, "volatile_io", False) or getattr(ema_model, "volatile_io", False)):
+        with _NoVolatileIO(model, ema_model):
+            return acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box, drops, u_weight, alpha, dp, grouped,
+                                        overlap, plabs)
+    return _acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box, drops, u_weight, alpha, dp, grouped, overlap,
+                                 plabs)
+
+
+def _acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, labeled_bs, box=None, drops=None,
+                          u_weight=0.5, alpha=0.99, dp=None, grouped=True, overlap=True, plabs=None):
     """One ACDC self-training iteration, ACDC_BCP_train.py:355-390 (grouped: see la_self_train_step; needs
     labeled_bs == batch - labeled_bs so that both halves have equal size).  plabs / optimizer=None: the parity hooks of
     la_self_train_step (forced pseudo-labels; gradient-only mode)."""
