@@ -98,6 +98,7 @@ def test_recorded_launch_plans_equal_eager_path(emu_ops):
     NC.check_launch_plans(emu_ops, CPU, steps=2, cases=(("la", False),))      # unfused: plan + busy-plan fallback (all four workloads: the GPU suite)
 
 
+@pytest.mark.extended
 def test_volatile_io_replays_equal_eager_path(emu_ops):
     """round 5: the networks as the training scripts run them (volatile_io: no copies in and out of the recorded passes) == the eager path"""
     from bcp_amd.utils import BCP_utils as BU
