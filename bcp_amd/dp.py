@@ -15,6 +15,7 @@ Transports (BCP_DP_BACKEND, default "rccl" on a GPU):
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
 import time
 
@@ -64,13 +65,16 @@ def _exchange_id(ident, world, rank):
         with open(tmp, "wb") as f:
             f.write(ident)
         os.replace(tmp, path)                        # atomic: readers never see a half-written id
+        _NONCE[0] = hashlib.sha1(ident).hexdigest()[:12]
         return ident
     t_launch = time.time() - float(os.environ.get("BCP_DP_ID_MAX_AGE", "120"))
     t0 = time.time()
     while True:
         try:
             if os.path.getmtime(path) >= t_launch and os.path.getsize(path) == 128:
-                return open(path, "rb").read()
+                out = open(path, "rb").read()
+                _NONCE[0] = hashlib.sha1(out).hexdigest()[:12]
+                return out
         except OSError:
             pass
         if time.time() - t0 > 120:
@@ -79,6 +83,10 @@ def _exchange_id(ident, world, rank):
 
 
 _STORES = []
+
+
+_NONCE = [None]   # file transport: a per-launch nonce = digest of the exchanged unique id (rank 0 makes a new id per launch): flag files named by it
+                  # can never be mistaken for an earlier launch's; a rank that never got the id writes a ".noid" flag instead
 
 
 _AGREE_SEQ = [0]   # agreements held by this process so far (one per communicator attempt, the same count on every rank)
@@ -99,22 +107,41 @@ def _agree(ok, world, rank, timeout_s=None):
     if d:
         tag = (f"{os.environ.get('MASTER_PORT', '29500')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{world}_"
                f"{os.environ.get('BCP_DP_LAUNCH_ID', os.getppid())}_{seq}")
-        mine = os.path.join(d, f"bcp_rccl_ok_{tag}.{rank}")
+        nonce = _NONCE[0]
+        flag = lambda n, r: os.path.join(d, f"bcp_rccl_ok_{tag}.{n}.{r}")
+        mine = flag(nonce or "noid", rank)
+        if nonce:
+            try:
+                os.remove(flag("noid", rank))        # an earlier launch of this tag that failed here: its flag must not speak for this one
+            except OSError:
+                pass
         tmp = mine + f".{os.getpid()}"
         with open(tmp, "wb") as f:
             f.write(b"1" if ok else b"0")
-        os.replace(tmp, mine)
+        os.replace(tmp, mine)                        # atomic
+        # a peer's flag counts when it carries THIS launch's nonce; a ".noid" flag (the peer failed before it had the id) only when it is
+        # younger than the launch can be, as _exchange_id treats the id file.  Flags are left behind (a slower peer may still have to read
+        # them when this rank is done): nonce'd ones never match again, ".noid" ones age out / are unlinked by their owner's next launch
         t0, all_ok = time.time(), bool(ok)
+        t_launch = t0 - float(os.environ.get("BCP_DP_ID_MAX_AGE", "120"))
         for r in range(world):
-            path = os.path.join(d, f"bcp_rccl_ok_{tag}.{r}")
+            cands = ([flag(nonce, r)] if nonce else []) + [flag("noid", r)]
+            if not nonce:                            # this rank failed early and reports False whatever it reads; it only waits for its peers
+                import glob
             while True:
-                try:
-                    v = open(path, "rb").read()
+                v = b""
+                for path in (cands if nonce else glob.glob(flag("*", r))):
+                    try:
+                        if path.endswith(f".noid.{r}") and os.path.getmtime(path) < t_launch:
+                            continue
+                        v = open(path, "rb").read()
+                    except OSError:
+                        continue
                     if v in (b"0", b"1"):
-                        all_ok = all_ok and v == b"1"
                         break
-                except OSError:
-                    pass
+                if v in (b"0", b"1"):
+                    all_ok = all_ok and v == b"1"
+                    break
                 if time.time() - t0 > timeout_s:
                     return False
                 time.sleep(0.01)
@@ -143,6 +170,7 @@ class _RcclAbi:
         """the RANK-LOCAL half: library, device, the unique id (rank 0 makes it, everyone fetches it).  init() is the collective half;
         DataParallel calls _agree() between the two"""
         from . import _lib
+        _NONCE[0] = None                             # set again by this communicator's id exchange
         self.b = _lib.product()
         if not self.b.call("bcp_comm_available"):
             raise RuntimeError("librccl.so could not be loaded")

@@ -346,6 +346,9 @@ def _la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, 
         BU.update_ema_variables(model, ema_model, alpha)
     model.drop_masks = None
     ema_model.drop_masks = None
+    # ALIASING CONTRACT (volatile_io, networks/_hipnet.py): with model.volatile_io set, outputs_l / outputs_u are views of the forward plan's
+    # own logits tensor -- valid until this network's NEXT pass, which overwrites them in place; a caller that keeps them across steps clones
+    # them.  With volatile_io off (the default) they are private copies.
     return dict(loss=loss.detach(), loss_l=loss_l.detach(), loss_u=loss_u.detach(), plab_a=own_plabs[0], plab_b=own_plabs[1],
                 outputs_l=outputs_l.detach(), outputs_u=outputs_u.detach())
 
@@ -521,6 +524,7 @@ def _acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch
     ema_model.drop_masks = None
     if loss_ce is None:                # grouped: the two reported sums are side results, computed after the backward pass was enqueued
         loss_ce, loss_dice = unl_ce + l_ce, unl_dice + l_dice
+    # (out_unl / out_l: the aliasing contract of la_self_train_step's outputs_l / outputs_u under volatile_io)
     return dict(loss=loss.detach(), loss_dice=loss_dice.detach(), loss_ce=loss_ce.detach(), plab_a=own_plabs[0], plab_b=own_plabs[1],
                 out_unl=out_unl.detach(), out_l=out_l.detach())
 

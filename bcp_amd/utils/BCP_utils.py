@@ -233,18 +233,23 @@ class _MixLossPairFn(torch.autograd.Function):
         return (d,) + (None,) * 9
 
 
-_GRAD_BUFFER = None      # (volatile_io) callable: channels-last logits shape -> the tensor the network's backward plan reads its input from, or None
+import threading as _threading
+
+_GRAD_BUFFER = _threading.local()      # .fn (volatile_io): callable, channels-last logits shape -> the tensor the network's backward plan reads its
+                                       # input from, or None.  Per THREAD and set only for the duration of one backward call (train_step._backward
+                                       # installs the differentiated model's own dout_buffer and removes it in a finally): two models stepped
+                                       # from two threads never see each other's buffers
 
 
 def set_grad_buffer_provider(fn):
     """the step functions hand the loss backward the student's dout_buffer (networks/_hipnet.py volatile_io): the logits gradient is then
     written where the backward plan reads it, no copy in between; None switches it off"""
-    global _GRAD_BUFFER
-    _GRAD_BUFFER = fn
+    _GRAD_BUFFER.fn = fn
 
 
 def _grad_buffer(like):
-    d = _GRAD_BUFFER(tuple(like.shape)) if _GRAD_BUFFER is not None else None
+    fn = getattr(_GRAD_BUFFER, "fn", None)
+    d = fn(tuple(like.shape)) if fn is not None else None
     if d is None or d.shape != like.shape or d.dtype != like.dtype or d.device != like.device:
         d = torch.empty_like(like)
     return d

@@ -8,19 +8,18 @@ student forward x2, masked Dice+CE x2, backward, [gradient all-reduce when N>1],
   python bench.py [--gpus N --steps K --warmup W] [--workload la|acdc|pancreas]
   N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Prints ONE JSON line (rank 0):
-  value         whole-job items/s over the K timed steps (inputs resident in HBM; barrier + synchronize on both sides, max over ranks)
-  kernels       per-op table of the step (top entries by time per step): HIP events on the launch stream around every op of
-                `--profile-steps` additional steps run right after the timed region (the timed region itself carries no events:
-                ~600 event records per step would cost the GPU queue ~5 % of a step); algorithmic FLOP or bytes per launch,
-                average microseconds, achieved TFLOP/s or GB/s, fraction of the fp32-MFMA / HBM peak
-  roofline      the MFMA-bound entry of that table with the LARGEST share of the step (not a hand-picked layer), plus the HBM-side
-                bytes of the same kernel from the committed rocprofv3 --pmc passes when profiles/ holds them
-  cpu_baseline  the oracle (CPU restatement of the reference, oracle/bcp_oracle.py) on this box's host cores: median of >= 5 timed
-                steps after 2 warm-ups (rank 0, N = 1 only)
-  ranks_seen    N > 1: all-reduce of ones over the communicator (= the ranks RCCL really spans)
-  host_ms_per_step_empty_queue   host cost of one step (median of 5, queue drained before each); host_enqueue_ms_per_step is the
-                timed loop's enqueue time and includes launch-queue back-pressure
+stdout's LAST line (rank 0) is ONE compact JSON record (< 4 KB, asserted): the contract keys only --
+  metric value unit n_gpus steps warmup ms_per_step higher_is_better scaling vs_baseline dtype data config{workload, global_batch, parallelism}
+  roofline{bound, kernel, achieved, peak, unit, frac, traffic, ...}   the MFMA-bound op with the LARGEST share of the step (not a hand-picked
+                layer): `frac` from the mean duration of its recorded launches between two HIP events on its stream (agrees with the
+                rocprofv3 kernel trace of the same command, profiles/); `frac_in_step_bracket` = the same from an event pair around the op
+                inside the busy step (includes 10-20 us of marker latency); `traffic` = HBM bytes per launch from the committed --pmc passes
+  cpu_baseline{value, unit, cores, kind, sample}   the oracle (CPU restatement of the reference, oracle/bcp_oracle.py) on this box's host
+                cores: median of >= 5 timed steps after 2 warm-ups (rank 0, N = 1 only)
+  extra_workloads{acdc, pancreas, la_b8}{value, unit, ms_per_step, roofline_frac, cpu_baseline_value}   the north_star's other single-GPU lines
+  ranks_seen / exposed_allreduce_ms_per_step   N > 1 only
+Everything else -- the per-op table (`kernels`), `roofline_hbm`, host enqueue times, provenance prose -- is written to bench_detail.json
+(repo root, and gpurun_out/ when that directory exists) and summarised on stderr.
 """
 import argparse
 import json
@@ -41,6 +40,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # same guide: dense BF16 MFMA peak
 PEAK_BF16X3_F32EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 PEAK_F16X2_F32EQ_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0      # round 4: two fp16 planes per operand, three MFMAs per product block (same MFMA rate as bf16)
 PEAK_HBM_GBS = 8000.0               # same guide: HBM3E spec (6290 GB/s measured with a float4 copy)
+# the arithmetic type of the path: fp32 tensors and fp32 accumulation; the 3x3(x3) convolutions take each fp32 operand as two fp16 planes
+# (~22 mantissa bits, per-tensor power-of-two pre-scales) on the matrix cores -- said here, not only in the detail file
+DTYPE = "f32 (fp16x2 split operands)"
 STEP_GFLOP_PER_VOLUME = 160.0       # 1/2 teacher fwd + 1/2 student fwd+bwd per input volume
 
 
@@ -536,7 +538,7 @@ def measure(args, dp, dev, cpu_budget_s=45.0, trim=False):
     out = {
         "metric": info["metric"], "value": round(value, 3), "unit": info["unit"], "n_gpus": dp.world, "steps": args.steps, "warmup": args.warmup, "setup_steps": SETUP_STEPS,
         "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3), "host_ms_per_step_empty_queue": round(host_ms, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
         "config": {"workload": info["what"], "global_batch": global_batch, "parallelism": f"dp{dp.world}", "last_loss": round(loss, 6),
                    "host_path": (f"recorded network passes (bcp_amd/plan.py): forward = {'one HIP graph launch' if plan.GRAPHS >= 1 else 'per-launch replay from C'}, "
                                  f"backward = {'HIP graph' if plan.GRAPHS >= 2 else 'per-launch replay from C (bcp_replay_run)'}; teacher forward on its own stream "
@@ -575,6 +577,74 @@ def measure(args, dp, dev, cpu_budget_s=45.0, trim=False):
     if dp.world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.workload, args.batch_size, args.labeled_bs, budget_s=cpu_budget_s)
     return out
+
+
+# ------------------------------------------------------------------------------------------------ the record
+MAX_LINE_BYTES = 4096               # the LAST stdout line: a record, not a report
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def compact_roofline(r):
+    """contract keys of a `roofline` object: bound, kernel, achieved, peak, unit, frac, traffic (HBM bytes per launch from the committed --pmc
+    passes, or null) + the duration the fraction is taken from and the same op's in-step event bracket as a second figure"""
+    if not r:
+        return None
+    t = r.get("traffic")
+    o = _pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac"))
+    o["traffic"] = t.get("bytes_per_launch") if isinstance(t, dict) else t
+    if isinstance(t, dict) and t.get("algorithmic_bytes_per_launch"):
+        o["algorithmic_bytes"] = t["algorithmic_bytes_per_launch"]
+    if r.get("avg_launch_ms") is not None:
+        o["avg_launch_us"] = round(r["avg_launch_ms"] * 1e3, 1)
+    b = r.get("avg_launch_ms_in_step_event_bracket")
+    if b and r.get("avg_launch_ms") and o.get("frac") is not None:
+        o["avg_launch_us_in_step_bracket"] = round(b * 1e3, 1)
+        o["frac_in_step_bracket"] = round(o["frac"] * r["avg_launch_ms"] / b, 4)
+    return o
+
+
+def compact_record(out, detail=None):
+    """the one stdout line: the contract keys and nothing else (everything `measure()` collects beyond them lives in bench_detail.json)"""
+    rec = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    rec["config"] = _pick(out.get("config") or {}, ("workload", "global_batch", "parallelism"))
+    rec["roofline"] = compact_roofline(out.get("roofline"))
+    if out.get("cpu_baseline"):
+        rec["cpu_baseline"] = _pick(out["cpu_baseline"], ("value", "unit", "cores", "kind", "sample"))
+    for k in ("ranks_seen", "exposed_allreduce_ms_per_step"):
+        if out.get(k) is not None:
+            rec[k] = out[k]
+    ex = {}
+    for wl, e in (out.get("extra_workloads") or {}).items():
+        if "error" in e:
+            ex[wl] = {"error": str(e["error"])[:120]}
+            continue
+        ex[wl] = {"value": e.get("value"), "unit": e.get("unit"), "ms_per_step": e.get("ms_per_step"),
+                  "roofline_frac": (e.get("roofline") or {}).get("frac"), "cpu_baseline_value": (e.get("cpu_baseline") or {}).get("value")}
+    if ex:
+        rec["extra_workloads"] = ex
+    if detail:
+        rec["detail"] = detail
+    return rec
+
+
+def write_detail(out):
+    """the full report: ROOT/bench_detail.json (git-ignored) and, when the directory exists, gpurun_out/ (travels back from the GPU box)"""
+    paths = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if not os.path.isdir(d):
+            continue
+        try:
+            fn = os.path.join(d, "bench_detail.json")
+            with open(fn, "w") as f:
+                json.dump(out, f, indent=1)
+            paths.append(fn)
+        except OSError:
+            pass
+    print("[bench] detail: " + (", ".join(paths) if paths else "not written (read-only tree)"), file=sys.stderr, flush=True)
+    return paths
 
 
 def main():
@@ -663,9 +733,14 @@ def main():
             # bounded: fewer timed steps and a shorter CPU sample each
             import copy
             extra = {}
-            for wl in ("acdc", "pancreas"):
+            for wl in ("acdc", "pancreas", "la_b8"):
                 a2 = copy.copy(args)
-                a2.workload, a2.batch_size, a2.labeled_bs = wl, {"acdc": 24, "pancreas": 4}[wl], {"acdc": 12, "pancreas": 2}[wl]
+                if wl == "la_b8":
+                    # the reference's DEFAULT LA batch (LA_BCP_train.py:39-40: batch_size 8, labeled_bs 4; SURVEY 8d "also report"): GPU line only
+                    a2.workload, a2.batch_size, a2.labeled_bs, a2.no_cpu_baseline = "la", 8, 4, True
+                    a2.steps, a2.warmup = min(args.steps, 10), min(args.warmup, 3)
+                else:
+                    a2.workload, a2.batch_size, a2.labeled_bs = wl, {"acdc": 24, "pancreas": 4}[wl], {"acdc": 12, "pancreas": 2}[wl]
                 a2.profile_steps = min(args.profile_steps, 2)
                 try:
                     extra[wl] = measure(a2, dp, dev, cpu_budget_s=20.0, trim=True)
@@ -678,7 +753,13 @@ def main():
                     out["cpu_only"] = {"configs[0] ACDC 2D U-Net batch 8 (4 labeled) 256x256, CPU": cpu_baseline("acdc", 8, 4, budget_s=15.0)}
                 except Exception as e:
                     out["cpu_only"] = {"error": f"{type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        # the full report (per-op tables, both rooflines with their provenance, prose) goes to a FILE and to stderr; stdout's last line is
+        # the compact record of the contract keys (round 5's 24.6 KB line did not survive the driver's stdout tail: BENCH_r05.json parsed = null)
+        detail_paths = write_detail(out)
+        line = json.dumps(compact_record(out, detail=os.path.relpath(detail_paths[0], ROOT) if detail_paths else None), separators=(",", ":"))
+        assert len(line) < MAX_LINE_BYTES, f"bench record is {len(line)} bytes (limit {MAX_LINE_BYTES})"
+        sys.stderr.flush()
+        print(line, flush=True)
     dp.shutdown()
 
 

@@ -303,6 +303,9 @@ def test_rank_local_failure_is_agreed_on_before_the_collective_init(tmp_path, tr
     if transport == "file":
         id_dir = str(tmp_path / "ids")
         os.makedirs(id_dir)
+        # a FRESH flag of an earlier launch with the same tag saying "rank 1 was fine" for the second agreement: it carries
+        # that launch's nonce, not this one's, and must not be read
+        open(os.path.join(id_dir, f"bcp_rccl_ok_{port}_none_3_t{port}_2.0123456789ab.1"), "wb").write(b"1")
     mp.spawn(_worker_agree, args=(3, port, str(tmp_path), id_dir, 1), nprocs=3, join=True)
     res = [torch.load(tmp_path / f"agree_{r}.pt") for r in range(3)]
     assert res == [[True, False]] * 3, res
