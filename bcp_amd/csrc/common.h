@@ -64,6 +64,10 @@ struct Options {
   int conv3_f16 = 1;        // round 4: bf16-pipe kernels that have a two-plane fp16 instance (k_c3d) use it when the launch carries the input tensor's |max| (per-tensor power-of-two pre-scales, conv3_defs.h): three MFMAs per K block instead of six.  0: three bf16 planes everywhere
   int wgrad_b6_slots = 0;   // weight gradient on the matrix pipe: workgroups per launch the tile groups are cut for (0 = 512: two per CU); measurement switch
   int mix_c1 = 1;           // round 5: single-channel copy-paste mix as k_mix_box_c1 (one multiply-high per float4 instead of six divisions; b read inside the box only).  0: the general kernel (measurement switch)
+  int wgrad_b6_deep = 1;    // round 6: deep-level weight gradients (< 16 K voxels) with few tile groups; ONE group -> the kernel writes dW itself (k_w6 DIR), no partial slabs, no reduce launch.  0: rounds 2-5 (512 slots of [T][16][32] slabs)
+  int wgrad_b6_deep_nt = 0; // ... n-tiles per workgroup there: 0 = 1 (16-channel slabs: twice the channel blocks), 1, 2 (measurement switch)
+  int wgrad_b6_deep_slots = 0;  // ... workgroups the tile groups are cut for (0 = 256)
+  int wgrad_b6_deep_tile = 1;   // ... 1 = 128-voxel tiles (4x8x4: half the tiles to walk; 7x7x5 x 256 direct 23.7 vs 32.0 us), 0 = 64-voxel tiles (2x8x4, rounds 2-5)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };
 Options& options();

@@ -1354,7 +1354,7 @@ static Cfg choose_cfg(int KD, int N, int D, int H, int W, int Cout16, bool for_w
 }
 
 // conv3b.hip / conv3bw.hip: fp32 numerics on the bf16 matrix pipe (three-piece operands)
-int b6_wgrad(const float* x, const float* dy, float* partial, const ConvDims& cd, int KD, hipStream_t s);
+int b6_wgrad(const float* x, const float* dy, float* partial, float* dw, int accumulate, const ConvDims& cd, int KD, hipStream_t s);
 size_t b6_wgrad_workspace_bytes(const ConvDims& cd, int KD);
 int b6_fwd(const float* x, const float* wp, const float* bias, float* y, const ConvDims& cd, int KD, int accumulate, void* workspace,
            double* stat_partial, int G, bool dry, hipStream_t s, bool* handled, int* raw_sk = nullptr, const BwdStatsIn* bw = nullptr);
@@ -1714,7 +1714,11 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   const int groups = wgrad_groups(c, N, D, H, W, cd.Cin16, cd.Cout16);
   float* ws = reinterpret_cast<float*>(workspace);
   if (x_amax_or_null && dy_amax_or_null) { cd.xamax = x_amax_or_null; cd.yamax = dy_amax_or_null; }      // (conv3bw.hip: two fp16 planes per operand)
-  int G = b6_wgrad(x, dy, ws, cd, KD, (hipStream_t)stream);      // partial slabs from the bf16-pipe kernel (conv3bw.hip), when it takes the shape
+  int G = b6_wgrad(x, dy, ws, dw, accumulate, cd, KD, (hipStream_t)stream);      // partial slabs from the bf16-pipe kernel (conv3bw.hip), when it takes the shape
+  if (G < 0) {                                   // deep levels (round 6): the kernel wrote the gradient itself, no slabs, no reduce
+    BCP_CHECK_LAUNCH("bcp_conv3_wgrad");
+    return BCP_OK;
+  }
   if (G > 0) done = true;
   if (!done) {
   BCP_WG_CASE(3, 4, 4, 16, 1) BCP_WG_CASE(3, 4, 4, 16, 2) BCP_WG_CASE(3, 4, 4, 16, 4)

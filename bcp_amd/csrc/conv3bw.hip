@@ -70,9 +70,15 @@ template <> struct W6Pipe<2> {
   static __device__ __forceinline__ void split(const float4& v, float s, unsigned short* base, int ps) { split_store4_f16(v, s, base, ps); }
 };
 
-template <int KD, int TD, int TH, int TW, int NT, int PL = 3>
+// DIR (round 6, the deep levels): ONE tile group per (cin chunk, cout slab) -- the workgroup walks every tile of the launch and writes its
+// finished [CT][16][T] block STRAIGHT into the torch gradient dW[co][ci][tap] (transposed through the LDS the planes no longer need: rows of
+// 16 * T contiguous floats per output channel), `partial` unused: no slab is written, re-read or reduced and no reduce kernel follows.
+// Rounds 2-5 cut the 7x7x5 x 256 / 14x14x10 x 128 launches into 4 / 16 tile groups to fill 512 workgroup slots: 28 MB of partial slabs
+// written and read back for a 7 MB / 1.8 MB gradient (67.6 / 57.8 MB per launch in profiles/r05_pmc_ops.json against 8.1 / 5.8 MB of
+// operands + result).
+template <int KD, int TD, int TH, int TW, int NT, int PL = 3, bool DIR = false>
 __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const float* __restrict__ dY, float* __restrict__ partial,
-                                            ConvDims cd, int tiles_total, int tiles_per_group) {
+                                            ConvDims cd, int tiles_total, int tiles_per_group, int accumulate) {
   using TL = Tile<KD, TD, TH, TW>;
   using PP = W6Pipe<PL>;
   using frag_t = typename PP::frag;
@@ -186,7 +192,6 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
       }
     }
   };
-
   fetch(tile);
   stash();
   BCP_LDS_BARRIER();
@@ -238,6 +243,36 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
     BCP_LDS_BARRIER();
     ++tile;
   }
+  if constexpr (DIR) {
+    // dW[co][ci][tap] (+)= acc: lane (li, lg) holds ci = lg*4 + r, co = nt*16 + li of its wave's taps.  LDS image [CT][16 * T (+1: the 16
+    // output channels of a store instruction land in 16 different banks)], then 256 threads sweep each output channel's 16 * T contiguous
+    // floats (a 1728-byte run of dW at T = 27)
+    constexpr int RS = 16 * T + 1;
+    float* Ts = reinterpret_cast<float*>(smem4);
+    BCP_LDS_BARRIER();                          // every wave is done reading the planes
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const int tap = wave + 4 * t;
+      if (tap < T) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Ts[(nt * 16 + li) * RS + (lg * 4 + r) * T + tap] = acc[t][nt][r] * osc;
+      }
+    }
+    BCP_LDS_BARRIER();
+    float* dW = partial;                        // (DIR: the argument IS the gradient tensor)
+    const int ci_n = cd.Cin - cc * 16 < 16 ? cd.Cin - cc * 16 : 16;
+    for (int q = threadIdx.x; q < CT * 16 * T; q += 256) {
+      const int col = q / (16 * T), e = q - col * (16 * T);
+      if (cout0 + col < cd.Cout && e < ci_n * T) {
+        float* o = dW + ((long long)(cout0 + col) * cd.Cin + cc * 16) * T + e;
+        const float v = Ts[col * RS + e];
+        *o = accumulate ? (*o + v) : v;
+      }
+    }
+    return;
+  }
   // partial[grp][tap][ci][co]: lane (li, lg) holds ci = lg*4 + r (rows), co = li (columns)
   float* P = partial + (long long)grp * T * cd.Cin16 * cd.Cout16;
 #pragma unroll
@@ -253,7 +288,7 @@ __global__ __launch_bounds__(256) void k_w6(const float* __restrict__ X, const f
   }
 }
 
-struct W6Plan { int cfg, TD, TH, TW, NT, groups; };
+struct W6Plan { int cfg, TD, TH, TW, NT, groups; bool direct, deep; };
 
 static bool w6_plan(W6Plan& p, const ConvDims& cd, int KD) {
   const Options& o = options();
@@ -271,13 +306,31 @@ static bool w6_plan(W6Plan& p, const ConvDims& cd, int KD) {
     p.cfg = 3; p.TD = 1; p.TH = 8; p.TW = 16;
   }
   p.NT = cd.Cout16 % 32 ? 1 : 2;
+  p.direct = false;
+  p.deep = false;
+  int slots = o.wgrad_b6_slots > 0 ? o.wgrad_b6_slots : 512;
+  if (p.cfg == 2 && o.wgrad_b6_deep) {
+    // round 6, deep levels (< 16 K voxels: a few dozen tiles): the matrix work is microseconds, what the launch costs is the partial
+    // slabs.  Few tile groups -- ONE where the channel blocks alone fill the slots (256 -> 256: 16 x 16 blocks of 16 x 16 channels),
+    // then the kernel writes the gradient itself (k_w6<..., DIR>); narrow slabs (NT = 1) double the blocks.  Measured alone
+    // (tools/probe/wgrad_deep_probe.py, gpurun_out/r06_s2): 2x7x7x5 x 256 35.5 -> 23.7 us (67.6 -> 8.1 MB), 2x14x14x10 x 128 42.6 -> 38.2
+    // (four groups: 57.8 -> ~20 MB), pancreas 2x6^3 x 256 32.1 -> 23.9, 2x12^3 x 128 41.6 -> 32.2.  What did NOT help, each measured on
+    // the way: two / three register sets of tiles in flight (hipcc drains vmcnt at the loop head), the operands by LDS-DMA two to four
+    // tiles ahead (5-8 us SLOWER: the read-back is more LDS traffic), LDS fragment reads two / three tap steps ahead -- the tile walk is
+    // bound by its LDS reads (four transposed reads per three MFMAs at NT = 1) and ~1 us of stash / barriers per tile, not by a latency
+    p.deep = true;
+    p.NT = (o.wgrad_b6_deep_nt == 2 && cd.Cout16 % 32 == 0) ? 2 : 1;
+    slots = o.wgrad_b6_deep_slots > 0 ? o.wgrad_b6_deep_slots : 256;
+    if (o.wgrad_b6_deep_tile == 1) { p.cfg = 1; p.TD = 4; p.TH = 8; p.TW = 4; }      // 128-voxel tiles: half the tiles to walk
+  }
   const int tiles = cd.N * cdiv(cd.D, p.TD) * cdiv(cd.H, p.TH) * cdiv(cd.W, p.TW);
   const int chan_blocks = (cd.Cin16 / 16) * (cd.Cout16 / (p.NT * 16));
-  int g = cdiv(options().wgrad_b6_slots > 0 ? options().wgrad_b6_slots : 512, chan_blocks);
+  int g = cdiv(slots, chan_blocks);
   if (g > tiles) g = tiles;
   if (g < 1) g = 1;
   const int tpg = cdiv(tiles, g);
   p.groups = cdiv(tiles, tpg);
+  p.direct = p.deep && p.groups == 1;
   return true;
 }
 
@@ -287,41 +340,58 @@ size_t b6_wgrad_workspace_bytes(const ConvDims& cd, int KD) {
   return (size_t)p.groups * KD * 9 * cd.Cin16 * cd.Cout16 * sizeof(float);
 }
 
-template <int KD, int TD, int TH, int TW, int NT>
-static int w6_launch(const float* X, const float* dY, float* partial, ConvDims cd, int groups, hipStream_t s) {
+template <int KD, int TD, int TH, int TW, int NT, bool DIR = false>
+static int w6_launch(const float* X, const float* dY, float* partial, ConvDims cd, int groups, int accumulate, hipStream_t s) {
   using TL = Tile<KD, TD, TH, TW>;
   constexpr int CT = NT * 16;
   const bool f16 = cd.xamax != nullptr && cd.yamax != nullptr && options().conv3_f16 != 0;      // both operands' |max| known: two fp16 planes
-  const size_t lds = (size_t)(f16 ? 2 : 3) * (TL::HV * 16 * 2 + (size_t)TL::M * (CT + 16) * 2);
+  size_t lds = (size_t)(f16 ? 2 : 3) * (TL::HV * 16 * 2 + (size_t)TL::M * (CT + 16) * 2);
+  if (DIR && lds < (size_t)CT * (16 * TL::T + 1) * sizeof(float)) lds = (size_t)CT * (16 * TL::T + 1) * sizeof(float);      // the epilogue's transposed image
   cd.tiles_d = cdiv(cd.D, TD); cd.tiles_h = cdiv(cd.H, TH); cd.tiles_w = cdiv(cd.W, TW);
   const int tiles = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
   const int tpg = cdiv(tiles, groups);
-  auto kfn = k_w6<KD, TD, TH, TW, NT>;
-  if (f16) kfn = k_w6<KD, TD, TH, TW, NT, 2>;
+  auto kfn = k_w6<KD, TD, TH, TW, NT, 3, DIR>;
+  if (f16) kfn = k_w6<KD, TD, TH, TW, NT, 2, DIR>;
   if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const dim3 grid(cdiv(tiles, tpg), cd.Cin16 / 16, cd.Cout16 / CT);
-  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, dY, partial, cd, tiles, tpg);
+  hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, X, dY, partial, cd, tiles, tpg, accumulate);
   return cdiv(tiles, tpg);
 }
 
 // Partial weight-gradient slabs on the bf16 pipe where option wgrad_b6 allows it: returns the number of slabs written to
-// `partial` ([G][T][Cin16][Cout16], for k_wgrad_reduce(_deep)), 0 when the shape is left to the fp32 kernels.
-int b6_wgrad(const float* x, const float* dy, float* partial, const ConvDims& cd, int KD, hipStream_t s) {
+// `partial` ([G][T][Cin16][Cout16], for k_wgrad_reduce(_deep)), 0 when the shape is left to the fp32 kernels, -1 when the kernel wrote
+// (accumulate: added to) the gradient `dw` itself (deep levels, one tile group: nothing left to reduce).
+int b6_wgrad(const float* x, const float* dy, float* partial, float* dw, int accumulate, const ConvDims& cd, int KD, hipStream_t s) {
   W6Plan p;
   if (!w6_plan(p, cd, KD)) return 0;
+  if (p.deep) {
+    // deep level (round 6): ONE tile group -> the kernel writes (accumulate: adds to) dW itself; more -> slabs + reduce as before
+    float* out = p.direct ? dw : partial;
+    const int g = p.direct ? 1 : p.groups, acc = p.direct ? accumulate : 0;
+    int G = 0;
+#define BCP_W6_D1(TD_, TH_, TW_, NT_)                                                                     \
+  do {                                                                                                    \
+    if (p.direct) G = w6_launch<3, TD_, TH_, TW_, NT_, true>(x, dy, out, cd, g, acc, s);                  \
+    else G = w6_launch<3, TD_, TH_, TW_, NT_, false>(x, dy, out, cd, g, acc, s);                          \
+  } while (0)
+    if (p.cfg == 2) { if (p.NT == 1) BCP_W6_D1(2, 8, 4, 1); else BCP_W6_D1(2, 8, 4, 2); }
+    else { if (p.NT == 1) BCP_W6_D1(4, 8, 4, 1); else BCP_W6_D1(4, 8, 4, 2); }
+#undef BCP_W6_D1
+    return p.direct ? -1 : G;
+  }
   if (p.NT == 1) {
     switch (p.cfg) {
-      case 0: return w6_launch<3, 4, 4, 8, 1>(x, dy, partial, cd, p.groups, s);
-      case 1: return w6_launch<3, 4, 8, 4, 1>(x, dy, partial, cd, p.groups, s);
-      case 2: return w6_launch<3, 2, 8, 4, 1>(x, dy, partial, cd, p.groups, s);
-      default: return w6_launch<1, 1, 8, 16, 1>(x, dy, partial, cd, p.groups, s);
+      case 0: return w6_launch<3, 4, 4, 8, 1>(x, dy, partial, cd, p.groups, 0, s);
+      case 1: return w6_launch<3, 4, 8, 4, 1>(x, dy, partial, cd, p.groups, 0, s);
+      case 2: return w6_launch<3, 2, 8, 4, 1>(x, dy, partial, cd, p.groups, 0, s);
+      default: return w6_launch<1, 1, 8, 16, 1>(x, dy, partial, cd, p.groups, 0, s);
     }
   }
   switch (p.cfg) {
-    case 0: return w6_launch<3, 4, 4, 8, 2>(x, dy, partial, cd, p.groups, s);
-    case 1: return w6_launch<3, 4, 8, 4, 2>(x, dy, partial, cd, p.groups, s);
-    case 2: return w6_launch<3, 2, 8, 4, 2>(x, dy, partial, cd, p.groups, s);
-    default: return w6_launch<1, 1, 8, 16, 2>(x, dy, partial, cd, p.groups, s);
+    case 0: return w6_launch<3, 4, 4, 8, 2>(x, dy, partial, cd, p.groups, 0, s);
+    case 1: return w6_launch<3, 4, 8, 4, 2>(x, dy, partial, cd, p.groups, 0, s);
+    case 2: return w6_launch<3, 2, 8, 4, 2>(x, dy, partial, cd, p.groups, 0, s);
+    default: return w6_launch<1, 1, 8, 16, 2>(x, dy, partial, cd, p.groups, 0, s);
   }
 }
 
