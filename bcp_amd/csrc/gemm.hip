@@ -70,17 +70,43 @@ static constexpr int AS = KC + 4;   // LDS row stride of the A chunk (+4 pad kee
 // NN: block = 64 rows x (16*NT) cols, waves split the rows (one 16-row m-tile each); K walks in stages of 32 with the
 // next stage's A rows and B slab fetched into registers underneath the MFMAs of the current one.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+// STATS (round 6): the launch also leaves the per-channel (sum y, sum y^2) partial rows the norm layer behind a k2s2 / transposed conv needs
+// (csrc/norm.hip bcp_norm_fwd partial_in) -- its statistics pass over y (k_col_partial<0>: 23 us / 128 MB at the top V-Net level, eight
+// passes per forward) is skipped.  A workgroup then walks R consecutive 64-row blocks (one partial row per workgroup: the finalize kernel
+// reads <= ~1000 rows per group) and sums in fp64 per lane, as the 3x3x3 kernels' epilogues do (conv3_defs.h stats_flush_t: the same lane ->
+// (row, four channels) layout).  Columns fold onto channels: column n is channel n % Cout (the transposed conv's eight sub-positions).
+struct GemmStats {
+  double* partial;     // [G][nb][C][2]
+  int nb;              // partial rows per normalisation group
+  int C;               // channels (= Cout of the layer)
+  int wpg;             // workgroup x-indices per group
+  int R;               // 64-row blocks per workgroup
+  int ysets;           // column slabs per channel set: gridDim.y / max(1, C / CT)
+};
+
+template <int NT, bool STATS = false>
 __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restrict__ Bp, const float* __restrict__ bias,
-                                                 RowMap C, int M, int K, int N, int bias_mod, int accumulate) {
+                                                 RowMap C, int M, int K, int N, int bias_mod, int accumulate, GemmStats st) {
   constexpr int CT = NT * 16;
   constexpr int NB4 = (8 * CT + 255) / 256;          // B float4s per thread per stage
   __shared__ __attribute__((aligned(16))) float As[64 * AS];
   __shared__ __attribute__((aligned(16))) float Bs[8 * CT * 4];
+  __shared__ double Ss[STATS ? 4 * CT * 2 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * 64, n0 = blockIdx.y * CT;
+  const int n0 = blockIdx.y * CT;
+  // per-lane sums over the workgroup's R <= 16 row blocks in fp32 (one value per block and accumulator: the error of such a partial sum,
+  // <= 16 fp32 roundings, averages out over the ~10^5 partials of a tensor), everything behind it in fp64 -- 32 double accumulators cost the
+  // kernel three of its five waves per SIMD (151 VGPRs: 79.9 us against 51.9 for the plain launch at the top level, gpurun_out/r06_s10)
+  float p1[STATS ? NT : 1][4], p2[STATS ? NT : 1][4];
+  if constexpr (STATS) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p1[nt][r] = 0.f; p2[nt][r] = 0.f; }
+  }
 
+  auto tile = [&](const int m0) __attribute__((always_inline)) {
   // staging role: thread -> (row, 16-B part of a 16-k half stage)
   const int srow = threadIdx.x >> 2, spart = threadIdx.x & 3;
   const bool srow_ok = (m0 + srow) < M;
@@ -157,6 +183,62 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
       }
       if (accumulate) { const float4 p = ld4(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
       st4(o, v);
+      if constexpr (STATS) {
+        p1[nt][0] += v.x; p2[nt][0] = fmaf(v.x, v.x, p2[nt][0]);
+        p1[nt][1] += v.y; p2[nt][1] = fmaf(v.y, v.y, p2[nt][1]);
+        p1[nt][2] += v.z; p2[nt][2] = fmaf(v.z, v.z, p2[nt][2]);
+        p1[nt][3] += v.w; p2[nt][3] = fmaf(v.w, v.w, p2[nt][3]);
+      }
+    }
+  }
+  };
+
+  if constexpr (!STATS) {
+    tile(blockIdx.x * 64);
+  } else {
+    const int rb0 = blockIdx.x * st.R, nblk = (M + 63) >> 6;
+    for (int rb = rb0; rb < rb0 + st.R && rb < nblk; ++rb) {
+      if (rb > rb0) __syncthreads();               // every wave is done with the previous block's LDS stages
+      tile(rb * 64);
+    }
+    // columns -> channels: n-tile nt holds channels (n0 + nt*16) % C ..; with C < CT the n-tiles of a workgroup repeat the channel set
+    const int ntc = st.C < CT ? st.C >> 4 : NT;      // distinct 16-channel tiles of this workgroup (uniform)
+    // (static indices only: ntc is 1, 2 or NT)
+    if (NT > 1 && ntc == 1) {
+#pragma unroll
+      for (int nt = 1; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { p1[0][r] += p1[nt][r]; p2[0][r] += p2[nt][r]; }
+    } else if (NT == 4 && ntc == 2) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        p1[0][r] += p1[NT > 2 ? 2 : 0][r]; p2[0][r] += p2[NT > 2 ? 2 : 0][r];
+        p1[NT > 1 ? 1 : 0][r] += p1[NT > 3 ? 3 : 0][r]; p2[NT > 1 ? 1 : 0][r] += p2[NT > 3 ? 3 : 0][r];
+      }
+    }
+    // the 16 row lanes of a wave as an fp32 tree (with the R blocks and the folded sub-positions <= 256 values per partial: <= 8 roundings
+    // deep), the four waves and everything downstream in fp64
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float a = p1[nt][r], b = p2[nt][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+        if (li == 0 && nt < ntc) { Ss[(wave * CT + nt * 16 + lg * 4 + r) * 2] = (double)a; Ss[(wave * CT + nt * 16 + lg * 4 + r) * 2 + 1] = (double)b; }
+      }
+    __syncthreads();
+    const int ychan = st.C > CT ? st.C / CT : 1;                      // column slabs per channel set
+    const int g = blockIdx.x / st.wpg, row = (blockIdx.x % st.wpg) * st.ysets + blockIdx.y / ychan;
+    const int c0 = (blockIdx.y % ychan) * CT;
+    if ((int)threadIdx.x < ntc * 16) {
+      const int c = threadIdx.x;
+      double a = 0.0, b = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) { a += Ss[(w * CT + c) * 2]; b += Ss[(w * CT + c) * 2 + 1]; }
+      double* dst = st.partial + (((long long)g * st.nb + row) * st.C + c0 + c) * 2;
+      dst[0] = a;
+      dst[1] = b;
     }
   }
 }
@@ -693,10 +775,44 @@ static int launch_nn(RowMap A, const float* Bp, const float* bias, RowMap C, int
   const int rb = cdiv(M, 64);
   const int nt = pick_nt(N, rb);
   const dim3 grid(rb, N / (nt * 16));
-  if (nt == 4) hipLaunchKernelGGL((k_gemm_nn<4>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate);
-  else if (nt == 2) hipLaunchKernelGGL((k_gemm_nn<2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate);
-  else hipLaunchKernelGGL((k_gemm_nn<1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate);
+  const GemmStats none{nullptr, 0, 0, 0, 0, 0};
+  if (nt == 4) hipLaunchKernelGGL((k_gemm_nn<4>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
+  else if (nt == 2) hipLaunchKernelGGL((k_gemm_nn<2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
+  else hipLaunchKernelGGL((k_gemm_nn<1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
   return 0;
+}
+
+// the statistics variant's geometry: 64-row blocks per workgroup R, partial rows per group; false: not served (the norm's own pass runs)
+struct StatPlan { int nt, R, wpg, ysets, nb; };
+static bool stat_plan(StatPlan& p, int M, int N, int Cout, int groups) {
+  if (groups < 1 || M % groups) return false;
+  const int mpg = M / groups;
+  if (mpg % 64) return false;                       // a 64-row block must not straddle two normalisation groups
+  const int bpg = mpg / 64;
+  p.nt = pick_nt(N, (long long)bpg * groups);
+  const int CT = p.nt * 16;
+  if (Cout % 16 || (Cout < CT && CT % Cout) || (Cout > CT && Cout % CT) || N % Cout) return false;
+  const int gy = N / CT, ychan = Cout > CT ? Cout / CT : 1;
+  p.ysets = gy / ychan;
+  // as many row blocks per workgroup as keep <= ~1024 partial rows per group and >= 512 workgroups in the launch
+  int R = 1;
+  while (R < 16 && bpg % (R * 2) == 0 && ((long long)(bpg / R) * p.ysets > 1024) && (long long)(bpg / (R * 2)) * groups * gy >= 512) R *= 2;
+  p.R = R;
+  p.wpg = bpg / R;
+  p.nb = p.wpg * p.ysets;
+  return true;
+}
+
+static int launch_nn_stats(RowMap A, const float* Bp, const float* bias, RowMap C, int M, int K, int N, int Cout, double* partial, int groups,
+                           hipStream_t s) {
+  StatPlan p;
+  if (!stat_plan(p, M, N, Cout, groups)) return 0;
+  const dim3 grid(p.wpg * groups, N / (p.nt * 16));
+  const GemmStats st{partial, p.nb, Cout, p.wpg, p.R, p.ysets};
+  if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, true>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, Cout, 0, st);
+  else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, true>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, Cout, 0, st);
+  else hipLaunchKernelGGL((k_gemm_nn<1, true>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, Cout, 0, st);
+  return p.nb;
 }
 
 static int tn_groups(int M, int K, int N, int nt) {
@@ -796,6 +912,43 @@ extern "C" int bcp_down_fwd(const float* x, const float* bp, const float* bias, 
   launch_nn(make_map(x, MAP_PATCH, 8 * Cin, Cin, D, H, W), bp, bias, make_map(y, MAP_PLAIN, Cout, 0, 0, 0, 0), M, 8 * Cin, Cout,
             Cout, 0, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_down_fwd");
+  return BCP_OK;
+}
+
+// The k2s2 / transposed conv forward that also leaves the norm statistics of its output (round 6): stat_partial[groups][rows][Cout][2]
+// doubles, rows = bcp_k2_stat_rows(kind, ...) (kind 0 = down conv, 1 = transposed conv; (D, H, W) the FINE dims as in bcp_down_fwd /
+// bcp_up_fwd); rows == 0: not available for this shape (run the plain entry point and let bcp_norm_fwd make its own pass).
+extern "C" int bcp_k2_stat_rows(int kind, int N, int D, int H, int W, int Cin, int Cout, int groups) {
+  if (N < 1 || D < 2 || H < 2 || W < 2 || (D | H | W) & 1 || Cin % 16 || Cout % 16 || Cin < 16 || Cout < 16 || groups < 1) return 0;
+  if (options().k2_stats == 0) return 0;
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  // (k2_stats = 2: only where the output is >= 2^24 elements -- the statistics pass saved there is 19-23 us, the epilogue costs ~11 at every level)
+  if (options().k2_stats == 2 && (long long)(kind == 0 ? M : 8LL * M) * Cout < (1LL << 24)) return 0;
+  StatPlan p;
+  return stat_plan(p, M, kind == 0 ? Cout : 8 * Cout, Cout, groups) ? p.nb : 0;
+}
+
+extern "C" int bcp_down_fwd_stats(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                                  int Cout, double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(x && bp && y && stat_partial, "bcp_down_fwd_stats: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_down_fwd_stats: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  const int nb = launch_nn_stats(make_map(x, MAP_PATCH, 8 * Cin, Cin, D, H, W), bp, bias, make_map(y, MAP_PLAIN, Cout, 0, 0, 0, 0), M, 8 * Cin,
+                                 Cout, Cout, stat_partial, groups, (hipStream_t)stream);
+  BCP_REQUIRE(nb > 0, "bcp_down_fwd_stats: fused statistics unavailable for this shape (check bcp_k2_stat_rows first)");
+  BCP_CHECK_LAUNCH("bcp_down_fwd_stats");
+  return BCP_OK;
+}
+
+extern "C" int bcp_up_fwd_stats(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin,
+                                int Cout, double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(x && bp && y && stat_partial, "bcp_up_fwd_stats: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_up_fwd_stats: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  const int nb = launch_nn_stats(make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), bp, bias, make_map(y, MAP_PATCH, 8 * Cout, Cout, D, H, W), M, Cin,
+                                 8 * Cout, Cout, stat_partial, groups, (hipStream_t)stream);
+  BCP_REQUIRE(nb > 0, "bcp_up_fwd_stats: fused statistics unavailable for this shape (check bcp_k2_stat_rows first)");
+  BCP_CHECK_LAUNCH("bcp_up_fwd_stats");
   return BCP_OK;
 }
 

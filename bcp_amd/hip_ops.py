@@ -680,6 +680,27 @@ class Ops:
         self.b.call("bcp_down_fwd", _p(x), _p(bp), _p(bias), _p(out), N, D, H, W, Cin, Cout, self.stream(x))
         return self._no_amax(out)
 
+    def k2_stat_rows(self, kind, xshape, Cout, groups):
+        """partial rows per normalisation group k2_fwd_stats leaves for this shape (kind 0: down conv, 1: transposed conv); 0: not fused"""
+        N, D, H, W, Cin = xshape
+        fine = (D, H, W) if kind == 0 else (2 * D, 2 * H, 2 * W)
+        return self._ws_bytes("bcp_k2_stat_rows", int(kind), N, fine[0], fine[1], fine[2], Cin, Cout, int(groups))
+
+    def k2_fwd_stats(self, kind, x, bp, bias, Cout, groups):
+        """down (kind 0) / transposed (kind 1) conv forward + the norm statistics of its output in the GEMM's epilogue (round 6) ->
+        (y, partial, rows) for norm_fwd(partial=, nb=); only where k2_stat_rows(...) > 0"""
+        self._chk(x, bp, bias)
+        N, D, H, W, Cin = x.shape
+        fine = (D, H, W) if kind == 0 else (2 * D, 2 * H, 2 * W)
+        rows = self.k2_stat_rows(kind, x.shape, Cout, groups)
+        assert rows > 0, "k2_fwd_stats: statistics not fused for this shape (check k2_stat_rows)"
+        osp = (D // 2, H // 2, W // 2) if kind == 0 else fine
+        out = torch.empty((N,) + osp + (Cout,), dtype=torch.float32, device=x.device)
+        part = self.workspace(("statpart", rows), groups * rows * Cout * 16, x)
+        self.b.call("bcp_down_fwd_stats" if kind == 0 else "bcp_up_fwd_stats", _p(x), _p(bp), _p(bias), _p(out), N, fine[0], fine[1], fine[2], Cin, Cout,
+                    _p(part), int(groups), self.stream(x))
+        return self._no_amax(out), part, rows
+
     def down_dgrad(self, dy, bp, Cin, out=None, accumulate=False):
         self._chk(dy, bp, out)
         N, Dc, Hc, Wc, Cout = dy.shape
@@ -943,7 +964,7 @@ class Ops:
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
 _PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "mixloss_pair_fwd", "mixloss_pair_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
-             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd",
+             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd", "k2_fwd_stats",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")
 

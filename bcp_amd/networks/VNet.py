@@ -219,12 +219,16 @@ class VNet(HipNet):
                     y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
                 else:
                     y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)          # eval-mode BatchNorm needs no batch statistics
-            elif L.kind == "dw":
-                bp, _ = self.k2_packed(("k2", li), save)
-                y = ops.down_fwd(h, bp, b.data, L.cout)
             else:
+                kind = 0 if L.kind == "dw" else 1
                 bp, _ = self.k2_packed(("k2", li), save)
-                y = ops.up_fwd(h, bp, b.data, L.cout)
+                # (round 6) the norm's statistics from the GEMM's epilogue where the shape has them: no statistics pass over y
+                if self.training and ops.k2_stat_rows(kind, h.shape, L.cout, G) > 0:       # (library option k2_stats = 0: never)
+                    y, part, nb = ops.k2_fwd_stats(kind, h, bp, b.data, L.cout, G)
+                elif kind == 0:
+                    y = ops.down_fwd(h, bp, b.data, L.cout)
+                else:
+                    y = ops.up_fwd(h, bp, b.data, L.cout)
             res = skips.pop() if L.skip_pop else None
             cs = self._chan_scale(L, N, xcl.device)
             if fused_c1:

@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 505
+#define BCP_ABI_VERSION 506
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -267,6 +267,13 @@ int bcp_k2_pack_many(const void* descs_dev, int n, void* stream);
 int bcp_down_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, void* stream);
 int bcp_down_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 int bcp_up_fwd(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, void* stream);
+/* round 6: the same two forwards leaving the norm statistics of their output -- stat_partial[groups][rows][Cout][2] doubles (sum y, sum y^2)
+   for bcp_norm_fwd(partial_in, nb = rows): the norm layer behind every Conv3d(k=2,s=2) / ConvTranspose3d(k=2,s=2) of the reference
+   (networks/VNet.py:74-86, 101-113) then skips its statistics pass over y.  rows = bcp_k2_stat_rows(kind: 0 down / 1 transposed, ...);
+   0: not available for this shape (use the plain entry points).  (D, H, W): the FINE extents, as above. */
+int bcp_k2_stat_rows(int kind, int N, int D, int H, int W, int Cin, int Cout, int groups);
+int bcp_down_fwd_stats(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, double* stat_partial, int groups, void* stream);
+int bcp_up_fwd_stats(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, double* stat_partial, int groups, void* stream);
 int bcp_up_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 int bcp_pw_fwd(const float* x, const float* bp, const float* bias_or_null, float* y, long long rows, int Cin, int Cout, void* stream);
 size_t bcp_tn_workspace_bytes(long long M, int K, int N);

@@ -750,6 +750,69 @@ CONV3_RES_CASES = (
 )
 
 
+def check_k2_stats(ops, dev):
+    """round 6: the k2s2 / transposed conv forward whose epilogue leaves the norm statistics of its output (bcp_down_fwd_stats /
+    bcp_up_fwd_stats, reference: the norm behind networks/VNet.py:74-86, 101-113): y bit-identical to the plain launch, the partial rows sum
+    to the per-group (sum y, sum y^2) of that y, and bcp_norm_fwd fed with them equals bcp_norm_fwd making its own pass.  Cases: channels
+    folding four / two sub-positions onto one set (Cout < slab), Cout == slab, Cout > slab (two column slabs per channel set), G = 1 / 2 / 4,
+    one and several 64-row blocks per workgroup (R > 1: the big case, GPU only)"""
+    rng = np.random.default_rng(11)
+    ops.set_option("k2_stats", 1)       # every shape the variant serves (the product default, 2, keeps it to outputs of >= 2^24 elements)
+    try:
+        _check_k2_stats(ops, dev, rng)
+    finally:
+        ops.set_option("k2_stats")
+    assert ops.k2_stat_rows(1, (2, 4, 8, 8, 32), 16, 2) == 0 and (dev.type != "cuda" or ops.k2_stat_rows(1, (2, 56, 56, 40, 32), 16, 2) > 0)
+
+
+def _check_k2_stats(ops, dev, rng):
+    cases = [(0, 2, 16, 32, (8, 16, 16), 2), (0, 2, 32, 64, (8, 8, 16), 1), (0, 4, 64, 128, (8, 8, 8), 4), (0, 1, 16, 16, (16, 16, 16), 1),
+             (1, 2, 32, 16, (4, 8, 8), 2), (1, 2, 64, 32, (4, 4, 8), 1), (1, 2, 128, 64, (2, 4, 8), 2), (1, 1, 256, 128, (4, 4, 4), 1)]
+    if dev.type == "cuda":
+        cases += [(1, 2, 32, 16, (16, 32, 32), 2), (0, 2, 16, 32, (32, 64, 64), 2)]      # thousands of row blocks: R > 1
+    seen_fused = 0
+    for kind, N, Cin, Cout, sp, G in cases:
+        x = to_cl(R(rng, N, Cin, *sp)).to(dev)          # kind 0: sp = the FINE extents of x; kind 1: the COARSE extents of x
+        if kind == 0:
+            w = (R(rng, Cout, Cin, 2, 2, 2) * 0.1).to(dev)
+            bp = ops.k2_pack(w, Cin, Cout, H.PACK_DOWN_FWD)
+        else:
+            w = (R(rng, Cin, Cout, 2, 2, 2) * 0.1).to(dev)
+            bp = ops.k2_pack(w, Cin, Cout, H.PACK_UP_FWD)
+        b = (R(rng, Cout) * 0.1).to(dev)
+        rows = ops.k2_stat_rows(kind, x.shape, Cout, G)
+        tag = f"k2 stats kind {kind} {N}x{sp} {Cin}->{Cout} G={G}"
+        assert rows > 0, tag + ": expected the fused statistics for this shape"
+        y0 = (ops.down_fwd if kind == 0 else ops.up_fwd)(x, bp, b, Cout).clone()
+        y, part, nb = ops.k2_fwd_stats(kind, x, bp, b, Cout, G)
+        assert nb == rows and torch.equal(y, y0), tag + ": y differs from the plain launch"
+        P = part.view(torch.float64)[: G * nb * Cout * 2].view(G, nb, Cout, 2).sum(1).cpu()
+        yd = y.double().cpu().reshape(G, -1, Cout)
+        ref = torch.stack([yd.sum(1), (yd * yd).sum(1)], dim=-1)
+        # (sums of <= 256 values per lane group in fp32, everything behind them in fp64: the totals agree with the fp64 sums to ~1e-8 of their
+        #  natural scale -- sum |y| for the first moment)
+        nrm = torch.stack([yd.abs().sum(1), ref[..., 1]], dim=-1)
+        err = float(((P - ref).abs() / (nrm + 1e-30)).max())
+        assert err < 1e-6, (tag, err)
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)).to(dev)
+        beta = torch.from_numpy(rng.uniform(-0.3, 0.3, Cout).astype(np.float32)).to(dev)
+        a0, st0 = ops.norm_fwd(y0, G, gamma, beta, torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), H.ACT_RELU)
+        a0, st0 = a0.clone(), st0.clone()
+        y, part, nb = ops.k2_fwd_stats(kind, x, bp, b, Cout, G)
+        a1, st1 = ops.norm_fwd(y, G, gamma, beta, torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev), H.ACT_RELU, partial=part, nb=nb)
+        close(st1.cpu(), st0.cpu(), rtol=1e-6, atol_scale=1e-7, msg=tag + " statistics")
+        close(a1.cpu(), a0.cpu(), rtol=1e-5, atol_scale=1e-6, msg=tag + " activations")
+        seen_fused += 1
+    # shapes the variant does not serve answer 0 rows (a 64-row block would straddle two groups) and the option switches it off
+    assert ops.k2_stat_rows(0, (2, 6, 10, 10, 16), 32, 2) == 0
+    ops.set_option("k2_stats", 0)
+    try:
+        assert ops.k2_stat_rows(0, (2, 8, 16, 16, 16), 32, 2) == 0
+    finally:
+        ops.set_option("k2_stats", 1)
+    assert seen_fused == len(cases)
+
+
 def check_k2_chunks(ops, dev):
     """weight-gradient GEMMs with ONE row group, so every block walks several 64-row chunks (prefetch / row-table pipeline)"""
     ops.set_option("tn_groups", 1)
@@ -1608,7 +1671,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
+ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):
