@@ -561,6 +561,13 @@ class HipNet(nn.Module):
         pl = self._io_plan("bin", clshape)
         return None if pl is None else pl.static_in
 
+    def dout_buffer_for(self, logits):
+        """dout_buffer for the gradient of `logits` -- only when `logits` IS the alias this network's last training pass handed out (same
+        storage): a loss on some other tensor of the same shape (another network's output, a clone) gets None and allocates its own"""
+        if logits is None or logits.data_ptr() != self.__dict__.get("_volatile_logits_ptr"):
+            return None
+        return self.dout_buffer(tuple(logits.shape))
+
     def _run_forward(self, xcl, save):
         if not self._plan_ok(xcl):
             r = self._forward_impl(xcl, save)
@@ -604,6 +611,7 @@ class HipNet(nn.Module):
         # the logits leave the plan as a COPY (16 MB at the LA size): callers may hold them across the next replay (logging, the
         # reference's unfused loop), and a replay overwrites the plan's static tensors in place
         res = out.detach() if (self.volatile_io and self.training) else out.clone()      # volatile_io (training passes only): an alias, valid until the next pass of this network
+        object.__setattr__(self, "_volatile_logits_ptr", res.data_ptr() if (self.volatile_io and self.training and save) else None)
         if save:
             ps = _PlanSaved(saved, pl)
             pl.busy = ps.token          # cleared by the backward pass -- or when `ps` dies without one (a discarded loss, an exception)
@@ -635,6 +643,8 @@ class HipNet(nn.Module):
             else:
                 if dout.data_ptr() != pl.static_in.data_ptr():      # (volatile_io: the loss backward wrote into dout_buffer())
                     pl.static_in.copy_(dout)
+                else:
+                    object.__setattr__(self, "_dout_in_place", self.__dict__.get("_dout_in_place", 0) + 1)      # (tests: the copy really is gone)
                 self.begin_backward()
                 pl.replay(self.ops, (), dout)
             plans[("bin", tuple(dout.shape))] = pl

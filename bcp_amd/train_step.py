@@ -33,7 +33,7 @@ def _backward(model, loss):
     """loss.backward() with the student's backward-plan input tensor offered to the loss backward (volatile_io, networks/_hipnet.py)"""
     vol = getattr(model, "volatile_io", False)
     if vol:
-        BU.set_grad_buffer_provider(model.dout_buffer)
+        BU.set_grad_buffer_provider(model.dout_buffer_for)
     try:
         loss.backward(gradient=BU.unit_gradient(loss))
     finally:
@@ -300,6 +300,11 @@ def _la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, 
     own_plabs = (plab_a, plab_b)
     if plabs is not None:
         plab_a, plab_b = plabs[0].to(volume_batch.device), plabs[1].to(volume_batch.device)
+    if grouped and label_batch.is_cuda and label_batch.dtype != torch.uint8:
+        # the loss reads uint8 label maps; the labeled half is converted HERE, in front of the student's forward (one launch under the
+        # teacher's pass), not by the loss between the forward and the backward pass (two launches on the step's critical path)
+        lab8 = _ops_for(volume_batch).to_u8(label_batch[:labeled_bs])
+        lab_a, lab_b = lab8[:sub_bs], lab8[sub_bs:labeled_bs]
     # direction tables: LA_BCP_train.py:248-251 / train_pancreas.py:155-156
     pairs = ((img_a, unimg_a), (unimg_b, img_b)) if variant == "la" else ((unimg_a, img_b), (img_a, unimg_b))
     if variant == "la":
@@ -475,6 +480,9 @@ def _acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch
     own_plabs = (plab_a, plab_b)
     if plabs is not None:
         plab_a, plab_b = plabs[0].to(volume_batch.device), plabs[1].to(volume_batch.device)
+    if grouped and label_batch.is_cuda and label_batch.dtype != torch.uint8:
+        lab8 = _ops_for(volume_batch).to_u8(label_batch[:labeled_bs])      # in front of the student's forward, not between forward and backward (see la_self_train_step)
+        lab_a, lab_b = lab8[:lsub], lab8[lsub:labeled_bs]
     if grouped:
         mshape = (2 * lsub,) + tuple(volume_batch.shape[1:])
         mixed = model.input_buffer(mshape) if getattr(model, "volatile_io", False) else None      # the forward plan's own input tensor: no copy

@@ -233,23 +233,24 @@ class _MixLossPairFn(torch.autograd.Function):
         return (d,) + (None,) * 9
 
 
-import threading as _threading
-
-_GRAD_BUFFER = _threading.local()      # .fn (volatile_io): callable, channels-last logits shape -> the tensor the network's backward plan reads its
-                                       # input from, or None.  Per THREAD and set only for the duration of one backward call (train_step._backward
-                                       # installs the differentiated model's own dout_buffer and removes it in a finally): two models stepped
-                                       # from two threads never see each other's buffers
+_GRAD_BUFFER = None      # (volatile_io) callable: the LOGITS tensor a loss is differentiating -> the tensor that network's backward plan reads its input
+                         # from, or None.  Installed by train_step._backward for the duration of one backward call (removed in a finally).  It is
+                         # a plain module global on purpose: autograd runs the backward nodes on ITS OWN thread, a thread-local installed by the
+                         # caller is invisible there (the first fix of ADVICE r05 made it one and silently brought the 16 MB copy back).  What
+                         # keeps two models apart is the KEY: the provider only answers for the logits tensor its own network handed out
+                         # (HipNet.dout_buffer_for compares the storage pointer), not for "any tensor of that shape".
 
 
 def set_grad_buffer_provider(fn):
-    """the step functions hand the loss backward the student's dout_buffer (networks/_hipnet.py volatile_io): the logits gradient is then
+    """the step functions hand the loss backward the student's dout_buffer_for (networks/_hipnet.py volatile_io): the logits gradient is then
     written where the backward plan reads it, no copy in between; None switches it off"""
-    _GRAD_BUFFER.fn = fn
+    global _GRAD_BUFFER
+    _GRAD_BUFFER = fn
 
 
 def _grad_buffer(like):
-    fn = getattr(_GRAD_BUFFER, "fn", None)
-    d = fn(tuple(like.shape)) if fn is not None else None
+    fn = _GRAD_BUFFER
+    d = fn(like) if fn is not None else None
     if d is None or d.shape != like.shape or d.dtype != like.dtype or d.device != like.device:
         d = torch.empty_like(like)
     return d
@@ -279,6 +280,8 @@ class _MixLossPairTotalFn(torch.autograd.Function):
         ctx.meta = (box6, mask_u8, flavour)
         terms = (o1[0], o2[0]) if flavour == H.LOSS_LA else (o1[0], o1[1], o2[0], o2[1])
         ctx.mark_non_differentiable(*terms)
+        ctx.set_materialize_grads(False)       # (the terms' gradients are never used: materialised as zeros they were one 1-workgroup fill launch
+                                               #  each between the forward and the backward pass -- 13 us of the step's critical path at the LA size)
         return (total.reshape(()),) + terms
 
     @staticmethod
@@ -287,6 +290,8 @@ class _MixLossPairTotalFn(torch.autograd.Function):
         box6, mask_u8, flavour = ctx.meta
         ops = _ops_for(logits_cl)
         n = logits_cl.shape[0] // 2
+        if g is None:                          # (set_materialize_grads(False): the total was not part of what is being differentiated)
+            return (None,) * 10
         d = _grad_buffer(logits_cl)
         g1 = g.reshape(1)
         if g1.dtype != torch.float32 or not g1.is_contiguous():

@@ -1252,6 +1252,9 @@ def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("
                 assert buf is not None and r["outputs_l" if what != "acdc" else "out_unl"].data_ptr() != 0, (what, "volatile_io: no input buffer handed out")
                 cl_logits = tuple(BU._as_cl(torch.cat([r["outputs_l"], r["outputs_u"]]) if what != "acdc" else torch.cat([r["out_unl"], r["out_l"]])).shape)
                 assert model.dout_buffer(cl_logits) is not None, (what, "volatile_io: no backward input buffer")
+                # ... and the loss backward really wrote there: autograd runs the backward nodes on its own thread, a provider the step
+                # function installs thread-locally never reaches them (round 6: that brought the 16 MB copy back unnoticed)
+                assert steps < 3 or model.__dict__.get("_dout_in_place", 0) >= steps - 2, (what, "volatile_io: the logits gradient was copied into the backward plan")
             plans = [p for k, p in model.__dict__.get("_plan_state", (None, {}))[1].items() if k[0] not in ("in", "bin")] + \
                     [p for k, p in ema.__dict__.get("_plan_state", (None, {}))[1].items() if k[0] not in ("in", "bin")]
             n_plans = len([k for k in model.__dict__.get("_plan_state", (None, {}))[1] if k[0] not in ("in", "bin")])
