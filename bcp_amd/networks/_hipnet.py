@@ -187,6 +187,16 @@ class HipNet(nn.Module):
             self._flat_grad.zero_()        # FlatSGD / FlatAdam.zero_grad(): the views stay attached, one memset clears them
         self._grads_stale = False
 
+    def clear_grads_now(self):
+        """the memset a zero_grad() owes, issued NOW on the current stream instead of at the head of the next backward pass (the fused step
+        functions call it in front of the student's forward, where it runs under the teacher's pass: 7 us + a launch gap off the step's
+        critical path).  Only when the flat views are attached (otherwise begin_backward does everything, as before)"""
+        self._ensure_flat()
+        ps = self._opt_plist
+        if self._grads_stale and ps[0].grad is not None and ps[0].grad.data_ptr() == self.grad_view(ps[0]).data_ptr():
+            self._flat_grad.zero_()
+            self._grads_stale = False
+
     def mark_grads_stale(self):
         """zero_grad() of the flat optimisers: O(1) on the host -- the next backward clears the flat buffer with one memset"""
         self._grads_stale = True

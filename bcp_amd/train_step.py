@@ -311,6 +311,12 @@ def _la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, 
         terms = ((lab_a, plab_a, 1.0, u_weight), (plab_b, lab_b, u_weight, 1.0))       # mix_loss(.., u_weight) / (.., unlab=True)
     else:
         terms = ((plab_a, lab_b, u_weight, 1.0), (lab_a, plab_b, 1.0, u_weight))       # train_pancreas.py:160,164 (the reference passes no u_weight: mix_loss's default 0.5 = ours)
+    early_zero = optimizer is not None and grouped and isinstance(optimizer, (FlatSGD, FlatAdam)) and optimizer.model is model
+    if early_zero:
+        # optimizer.zero_grad() of the reference's loop body, moved in front of the forward pass (nothing reads a gradient in between): its
+        # one memset then runs under the teacher's pass instead of between the loss and the backward pass
+        optimizer.zero_grad()
+        model.clear_grads_now()
     if grouped:
         mshape = (2 * sub_bs,) + tuple(volume_batch.shape[1:])
         mixed = model.input_buffer(mshape) if getattr(model, "volatile_io", False) else None      # the forward plan's own input tensor: no copy
@@ -341,7 +347,8 @@ def _la_self_train_step(model, ema_model, optimizer, volume_batch, label_batch, 
     if optimizer is None:      # gradient-only mode (DP equivalence tests): caller owns zero_grad / step / EMA
         _backward(model, loss)
     else:
-        optimizer.zero_grad()
+        if not early_zero:
+            optimizer.zero_grad()
         if dp is not None and grouped:
             dp.arm(model)              # ONE backward in this step: gradient buckets go out underneath it
         _backward(model, loss)
@@ -483,6 +490,10 @@ def _acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch
     if grouped and label_batch.is_cuda and label_batch.dtype != torch.uint8:
         lab8 = _ops_for(volume_batch).to_u8(label_batch[:labeled_bs])      # in front of the student's forward, not between forward and backward (see la_self_train_step)
         lab_a, lab_b = lab8[:lsub], lab8[lsub:labeled_bs]
+    early_zero = optimizer is not None and grouped and isinstance(optimizer, (FlatSGD, FlatAdam)) and optimizer.model is model
+    if early_zero:
+        optimizer.zero_grad()          # (as la_self_train_step: the memset in front of the forward pass)
+        model.clear_grads_now()
     if grouped:
         mshape = (2 * lsub,) + tuple(volume_batch.shape[1:])
         mixed = model.input_buffer(mshape) if getattr(model, "volatile_io", False) else None      # the forward plan's own input tensor: no copy
@@ -520,7 +531,8 @@ def _acdc_self_train_step(model, ema_model, optimizer, volume_batch, label_batch
     if optimizer is None:              # gradient-only mode: the caller owns zero_grad / step / EMA
         _backward(model, loss)
     else:
-        optimizer.zero_grad()
+        if not early_zero:
+            optimizer.zero_grad()
         if dp is not None:
             dp.arm(model)              # one backward covers both student batches (grouped or not: `loss` sums their terms)
         _backward(model, loss)
