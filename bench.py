@@ -83,7 +83,7 @@ def _work(name, shapes, ints):
         return "mfma", 2.0 * vox * kd * 9 * s0[-1] * cout, 4.0 * (_numel(s0) + vox * cout + extra)
     if name == "conv3_wgrad":                              # (x, dy, dw); ints = (KD,)
         vox = _numel(s0[:-1])
-        return "mfma", 2.0 * vox * ints[0] * 9 * s0[-1] * shapes[1][-1], 4.0 * (_numel(s0) + _numel(shapes[1]))
+        return "mfma", 2.0 * vox * ints[0] * 9 * s0[-1] * shapes[1][-1], 4.0 * (_numel(s0) + _numel(shapes[1]) + ints[0] * 9 * s0[-1] * shapes[1][-1])      # x, dy and dW
     if name in ("conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_wgrad"):         # Cin = 1 -> 16: HBM-bound (AI 12.7)
         vox = _numel(s0[:-1])
         return "hbm", 2.0 * vox * ints[0] * 9 * 16, 4.0 * vox * 17
@@ -217,7 +217,7 @@ def pmc_traffic(kernel_key):
     separate runs; FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note on 16-B/lane streams), next to the op's algorithmic
     bytes.  bench.py cannot run the profiler itself: the numbers are those of the commit the file's `_meta` names (the newest
     round's file first); null when profiles/ holds no entry for this op."""
-    for fn in ("r05_pmc_ops.json", "r04_pmc_ops.json", "r03_pmc_ops.json", "r02_pmc_ops.json"):
+    for fn in ("r06_pmc_ops.json", "r05_pmc_ops.json", "r04_pmc_ops.json", "r03_pmc_ops.json", "r02_pmc_ops.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", fn)))
         except Exception:

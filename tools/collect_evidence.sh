@@ -5,9 +5,11 @@
 tag=${1:-evidence}; out=$PWD/gpurun_out; mkdir -p $out
 ( time python -m pytest tests -m gpu -q -rP ) > $out/${tag}_pytest_gpu_full.txt 2>&1
 { grep -E "^[0-9]+ (passed|failed)|^FAILED|^ERROR" $out/${tag}_pytest_gpu_full.txt | tail -5; grep -E "full-size step|batch-8 step|traj5f step|la_traj5f|pancreas full|acdc full|flips|worst grad" $out/${tag}_pytest_gpu_full.txt | cut -c1-300; } > $out/${tag}_pytest_gpu.txt
-python bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err
-python bench.py --workload acdc > $out/${tag}_bench_acdc.json 2>> $out/${tag}_bench.err
-python bench.py --workload pancreas > $out/${tag}_bench_pancreas.json 2>> $out/${tag}_bench.err
+# (round 6: the last stdout line is the compact record, the full report is bench_detail.json)
+python bench.py --gpus 1 --steps 20 --warmup 5 > $out/${tag}_bench.out 2> $out/${tag}_bench.err; tail -1 $out/${tag}_bench.out > $out/${tag}_bench.json; cp $out/bench_detail.json $out/${tag}_bench_detail.json
+python bench.py --workload acdc --no-extra > $out/${tag}_bench_acdc.out 2>> $out/${tag}_bench.err; tail -1 $out/${tag}_bench_acdc.out > $out/${tag}_bench_acdc.json
+python bench.py --workload pancreas --no-extra > $out/${tag}_bench_pancreas.out 2>> $out/${tag}_bench.err; tail -1 $out/${tag}_bench_pancreas.out > $out/${tag}_bench_pancreas.json
+rm -f $out/${tag}_bench.out $out/${tag}_bench_acdc.out $out/${tag}_bench_pancreas.out
 R=$PWD; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d /tmp/ev -o ev --output-format csv -- python $R/bench.py --no-cpu-baseline --no-extra --steps 10 --warmup 2 > /tmp/ev.log 2>&1
 f=$(find /tmp/ev -name "*kernel_stats.csv" | head -1); cp $f $out/${tag}_kernel_stats.csv

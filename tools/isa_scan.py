@@ -85,9 +85,14 @@ class ToolUnavailable(RuntimeError):
     """llvm-objdump is missing or cannot unpack offload bundles: the gate could not RUN (callers decide; build() wants BCP_SKIP_ISA_GATE=1)"""
 
 
-def lib_gate(lib=LIB):
+ANY_SEL = re.compile(r"^\s*v_pk_(?:mul|fma)_f32\b.*\bop_sel")       # a packed fp32 multiply / fma with ANY operand selection (op_sel / op_sel_hi)
+
+
+def lib_gate(lib=LIB, report=None):
     """[(kernel, instruction)] of the packed multiplies / fmas of the BUILT library whose low result takes the high half of a multiplier
-    input (the form that fails beside 16-bit MFMAs); the library's code objects are extracted and disassembled in a scratch directory"""
+    input (the form that fails beside 16-bit MFMAs); the library's code objects are extracted and disassembled in a scratch directory.
+    report: a list that receives (kernel, instruction) of EVERY packed fp32 multiply / fma carrying an operand selection of any kind --
+    not failures (the forms found wrong are the gate's), the watch list VERDICT r05 item 9 asked for: what a stack update could turn"""
     import shutil
     import tempfile
     objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
@@ -115,15 +120,31 @@ def lib_gate(lib=LIB):
                 c = CROSSED.match(s)
                 if c and (c.group(2) == "1" or c.group(3) == "1"):
                     out.append((kernel, s.strip()))
+                if report is not None and ANY_SEL.match(s):
+                    report.append((kernel, s.strip()))
     return out
 
 
 def main(argv):
-    crossed = lib_gate() if os.path.exists(LIB) else []
+    watch = []
+    crossed = lib_gate(report=watch) if os.path.exists(LIB) else []
     for kernel, ins in crossed:
         print(f"libbcp_hip.so: {kernel[:90]}: {ins}")
     print(f"gate 1: {len(crossed)} packed fp32 multiply / fma with a crossed multiplier input in the built library" +
           ("" if os.path.exists(LIB) else " (library not built: skipped)"))
+    by_kernel = {}
+    for kernel, ins in watch:
+        by_kernel[kernel] = by_kernel.get(kernel, 0) + 1
+    print(f"watch list (reported, not failed): {len(watch)} packed fp32 multiplies / fmas with an operand selection of any kind in {len(by_kernel)} kernels")
+    forms = {}
+    for _, ins in watch:
+        key = ins.split()[0] + " " + " ".join(t for t in ins.split() if t.startswith("op_sel"))
+        forms[key] = forms.get(key, 0) + 1
+    for k, n in sorted(forms.items(), key=lambda kv: -kv[1]):
+        print(f"    {n:5d}  {k}      (low result from low halves: the form measured 0-wrong beside 16-bit MFMAs, DESIGN.md section 4.0)")
+    if "--report" in argv:
+        for k, n in sorted(by_kernel.items(), key=lambda kv: -kv[1])[:40]:
+            print(f"    {n:5d}  {k[:120]}")
     bad = gate()
     for n, kernel, line, ins in bad:
         print(f"{n}.hip: {kernel[:80]} line {line}: {ins}")

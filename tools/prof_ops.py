@@ -55,7 +55,9 @@ for C, sp in LEVELS:
     tag = "x".join(str(v) for v in (N, *sp, C))
     run(f"conv3_fwd_stats[{tag}]", lambda: ops.conv3_fwd_stats(x, wf, b, C, 3, N), {"flop": fl, "bytes": 8.0 * vox * C})
     run(f"conv3_fwd[{tag}]", lambda: ops.conv3_fwd(dy, wd, None, C, 3, out=y), {"flop": fl, "bytes": 8.0 * vox * C})
-    run(f"conv3_wgrad[{tag}]", lambda: ops.conv3_wgrad(x, dy, dw, 3), {"flop": fl, "bytes": 8.0 * vox * C})
+    # (round 6: the gradient tensor itself counts -- 4 * 27 * C * C bytes, 7.1 MB at 256 channels against 1.0 MB of operands: rounds 2-5 priced the
+    #  deep weight gradients against their operands only)
+    run(f"conv3_wgrad[{tag}]", lambda: ops.conv3_wgrad(x, dy, dw, 3), {"flop": fl, "bytes": 8.0 * vox * C + 4.0 * 27 * C * C})
     g, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     a = torch.empty_like(y)
@@ -96,6 +98,17 @@ run("down_fwd[2x112x112x80x16]", lambda: ops.down_fwd(y16, bp, None, 32, out=yd)
 wup = torch.randn(32, 16, 2, 2, 2, device=dev)
 bpu = ops.k2_pack(wup, 32, 16, H.PACK_UP_FWD)
 run("up_fwd[2x56x56x40x32]", lambda: ops.up_fwd(yd, bpu, None, 16, out=y16), {"flop": 2.0 * yd.numel() * 128, "bytes": 4.0 * (y16.numel() + yd.numel())})
+# round 6: the transposed conv leaving its output's norm statistics (the statistics pass of the norm behind it is skipped) + that norm, and the
+# plain chain it replaces
+gu, beu, rmu, rvu = torch.ones(16, device=dev), torch.zeros(16, device=dev), torch.zeros(16, device=dev), torch.ones(16, device=dev)
+au = torch.empty_like(y16)
+if ops.k2_stat_rows(1, yd.shape, 16, N) > 0:
+    def up_chain():
+        yy, part, nb = ops.k2_fwd_stats(1, yd, bpu, None, 16, N)
+        ops.norm_fwd(yy, N, gu, beu, rmu, rvu, H.ACT_RELU, out=au, partial=part, nb=nb)
+    run("up_fwd_stats+norm_fwd[2x56x56x40x32]", up_chain, {"flop": 2.0 * yd.numel() * 128, "bytes": 4.0 * (yd.numel() + 3 * y16.numel())})
+run("up_fwd+norm_fwd[2x56x56x40x32]", lambda: ops.norm_fwd(ops.up_fwd(yd, bpu, None, 16, out=y16), N, gu, beu, rmu, rvu, H.ACT_RELU, out=au),
+    {"flop": 2.0 * yd.numel() * 128, "bytes": 4.0 * (yd.numel() + 4 * y16.numel())})
 dwd = torch.empty_like(wdn)
 run("k2_wgrad[2x112x112x80x16]", lambda: ops.k2_wgrad(y16, yd, dwd, H.WG_DOWN), {"flop": 2.0 * yd.numel() * 128, "bytes": 4.0 * (y16.numel() + yd.numel())})
 wo = torch.randn(2, 16, 1, 1, 1, device=dev)
