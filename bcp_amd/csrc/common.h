@@ -38,6 +38,7 @@ void set_error(const char* fmt, ...);
 struct Options {
   int conv3_p = 0;          // cap on persistent workgroups of the resident / pipeline convs (tests: force multi-tile loops)
   int splitk = 0;           // streaming conv: split-K factor 1..4
+  long long conv3_sk_elems = 1LL << 20;   // largest conv output (elements) that may run split-K over its cin chunks: the slab workspace is 8 x that (bcp_conv3_fwd_workspace_bytes)
   int conv3_b6_cin16max = 32;   // 2-D layers with 16 output channels on the bf16 pipe: widest input (measurement switch)
   int conv3_b6_pipe = 1;        // ... and of those the 3-D ones as the LDS-DMA software pipeline k_c3p (0: k_c3h, register-staged weights)
   int conv3_b6_w22 = 1;         // 64-voxel x 64-channel staged tiles: waves arranged 2 x 2 (k_c3h) instead of 1 x 4 (k_c3b)

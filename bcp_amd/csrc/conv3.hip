@@ -1459,7 +1459,7 @@ static bool choose_res(Cfg& r, int KD, int N, int D, int H, int W, int Cin16, in
 extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int KD) {
   // split-K partial slabs (deep levels only): at most 8 copies of the output
   const long long n = (long long)N * D * H * W * Cout;
-  return n <= (1LL << 20) ? (size_t)(8 * n * sizeof(float)) : 0;
+  return n <= options().conv3_sk_elems ? (size_t)(8 * n * sizeof(float)) : 0;
 }
 
 // shared by the launch and by the statistics-rows query: returns the number of partial rows per group the chosen kernel
@@ -1610,7 +1610,7 @@ extern "C" int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, 
 // bcp_conv3_fwd).  Forward and dgrad alike (dgrad = the flipped pack).
 extern "C" int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD) {
   if (Cin % 4 || Cin < 4 || (KD != 1 && KD != 3) || N < 1 || D < 1 || H < 1 || W < 1) return 0;
-  if ((long long)N * D * H * W * Cout > (1LL << 20)) return 0;      // the slab buffer is sized like bcp_conv3_fwd_workspace_bytes: deep levels only
+  if ((long long)N * D * H * W * Cout > options().conv3_sk_elems) return 0;      // the slab buffer is sized like bcp_conv3_fwd_workspace_bytes: deep levels only
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
   bool handled = false;
@@ -1627,7 +1627,7 @@ extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, 
   BCP_REQUIRE(KD == 3 || D == 1, "bcp_conv3_fwd_raw: KD=1 needs D=1");
   BCP_REQUIRE(Cin % 4 == 0 && Cin >= 4, "bcp_conv3_fwd_raw: Cin=%d must be a multiple of 4", Cin);
   BCP_REQUIRE(aligned16(x) && aligned16(wp) && aligned16(slabs), "bcp_conv3_fwd_raw: x / wp / slabs must be 16-B aligned");
-  BCP_REQUIRE((long long)N * D * H * W * Cout <= (1LL << 20), "bcp_conv3_fwd_raw: output too large for raw slabs (check bcp_conv3_fwd_nslabs)");
+  BCP_REQUIRE((long long)N * D * H * W * Cout <= options().conv3_sk_elems, "bcp_conv3_fwd_raw: output too large for raw slabs (check bcp_conv3_fwd_nslabs)");
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
   bool handled = false;

@@ -1668,7 +1668,7 @@ static int b6_launch(const float* X, const float* Wp, const float* bias, float* 
   const int gx = cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w, gy = cd.Cout16 / CT;
   const int nch = cd.Cin16 / 16;
   int sk = 1;
-  const bool ws_fits = ws && (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout <= (1LL << 20);     // bcp_conv3_fwd_workspace_bytes
+  const bool ws_fits = ws && (long long)cd.N * cd.D * cd.H * cd.W * cd.Cout <= options().conv3_sk_elems;     // bcp_conv3_fwd_workspace_bytes
   if (ws_fits && (long long)gx * gy <= 256 && nch >= 4) { sk = nch / 2; if (sk > 4) sk = 4; }
   { const int f = options().splitk; if (ws_fits && f >= 1 && f <= 4 && f <= nch) sk = f; }
   if (raw_sk) {
@@ -1824,7 +1824,7 @@ static int b6_launch_flat(const float* X, const float* Wp, const float* bias, fl
   // within the 512 co-resident workgroup slots; measured alone (fwd + statistics, us): 256 channels batch 2 / 4: 31.3 -> 25.8 /
   // 40.7 -> 34.3 (with 64-channel slabs at batch 4); 128 channels batch 4: 67.2 -> 59.4 (split 2: 496 workgroups instead of 992)
   int sk = 1;
-  const bool ws_fits = ws && (long long)cd.N * V * cd.Cout <= (1LL << 20);
+  const bool ws_fits = ws && (long long)cd.N * V * cd.Cout <= options().conv3_sk_elems;
   if (ws_fits && nch >= 4) {
     const int cap = nch / 2 < 8 ? nch / 2 : 8;
     while (sk * 2 <= cap && (long long)gx * gy * sk * 2 <= 512) sk *= 2;
