@@ -82,9 +82,15 @@ struct GemmStats {
   int wpg;             // workgroup x-indices per group
   int R;               // 64-row blocks per workgroup
   int ysets;           // column slabs per channel set: gridDim.y / max(1, C / CT)
+  // STATS == 2 (backward statistics, as bcp_conv3_dgrad_bwdstats): the GEMM output IS da of the consumer's norm layer; with that layer's
+  // pre-norm tensor `by` (laid out like the output) and statistics table float[5][G][C] (mean, rstd, scale, shift, ..) the epilogue
+  // accumulates (sum dz, sum dz * xhat), dz = da * act'(z) -- what k_col_partial<1> would re-read y and da for
+  const float* by;
+  const float* bstats;
+  int G, act;
 };
 
-template <int NT, bool STATS = false>
+template <int NT, int STATS = 0>
 __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restrict__ Bp, const float* __restrict__ bias,
                                                  RowMap C, int M, int K, int N, int bias_mod, int accumulate, GemmStats st) {
   constexpr int CT = NT * 16;
@@ -183,17 +189,34 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
       }
       if (accumulate) { const float4 p = ld4(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
       st4(o, v);
-      if constexpr (STATS) {
+      if constexpr (STATS == 1) {
         p1[nt][0] += v.x; p2[nt][0] = fmaf(v.x, v.x, p2[nt][0]);
         p1[nt][1] += v.y; p2[nt][1] = fmaf(v.y, v.y, p2[nt][1]);
         p1[nt][2] += v.z; p2[nt][2] = fmaf(v.z, v.z, p2[nt][2]);
         p1[nt][3] += v.w; p2[nt][3] = fmaf(v.w, v.w, p2[nt][3]);
       }
+      if constexpr (STATS == 2) {
+        // this lane's four channels of the consumer's statistics rows (group of the workgroup), its y at the element just written
+        const int cb = (n0 + nt * 16) % st.C + lg * 4;
+        const long long pi = (long long)(blockIdx.x / st.wpg) * st.C + cb, GC = (long long)st.G * st.C;
+        const float4 mu = ld4(st.bstats + pi), rs = ld4(st.bstats + GC + pi), sc = ld4(st.bstats + 2 * GC + pi), sh = ld4(st.bstats + 3 * GC + pi);
+        const float4 yv = ld4(st.by + (o - C.p));
+        const float vv[4] = {v.x, v.y, v.z, v.w}, yy[4] = {yv.x, yv.y, yv.z, yv.w};
+        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w}, s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float z = (yy[r] - m4[r]) * s4[r] + h4[r];
+          const float g1 = vv[r] * act_grad(z, st.act);
+          const float xh = (yy[r] - m4[r]) * r4[r];
+          p1[nt][r] += g1;
+          p2[nt][r] = fmaf(g1, xh, p2[nt][r]);
+        }
+      }
     }
   }
   };
 
-  if constexpr (!STATS) {
+  if constexpr (STATS == 0) {
     tile(blockIdx.x * 64);
   } else {
     const int rb0 = blockIdx.x * st.R, nblk = (M + 63) >> 6;
@@ -775,7 +798,7 @@ static int launch_nn(RowMap A, const float* Bp, const float* bias, RowMap C, int
   const int rb = cdiv(M, 64);
   const int nt = pick_nt(N, rb);
   const dim3 grid(rb, N / (nt * 16));
-  const GemmStats none{nullptr, 0, 0, 0, 0, 0};
+  const GemmStats none{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, 0, 0};
   if (nt == 4) hipLaunchKernelGGL((k_gemm_nn<4>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
   else if (nt == 2) hipLaunchKernelGGL((k_gemm_nn<2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
   else hipLaunchKernelGGL((k_gemm_nn<1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
@@ -803,15 +826,21 @@ static bool stat_plan(StatPlan& p, int M, int N, int Cout, int groups) {
   return true;
 }
 
-static int launch_nn_stats(RowMap A, const float* Bp, const float* bias, RowMap C, int M, int K, int N, int Cout, double* partial, int groups,
-                           hipStream_t s) {
+static int launch_nn_stats(RowMap A, const float* Bp, const float* bias, RowMap C, int M, int K, int N, int Cch, int bias_mod, int accumulate,
+                           double* partial, int groups, const float* by, const float* bstats, int act, hipStream_t s) {
   StatPlan p;
-  if (!stat_plan(p, M, N, Cout, groups)) return 0;
+  if (!stat_plan(p, M, N, Cch, groups)) return 0;
   const dim3 grid(p.wpg * groups, N / (p.nt * 16));
-  const GemmStats st{partial, p.nb, Cout, p.wpg, p.R, p.ysets};
-  if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, true>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, Cout, 0, st);
-  else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, true>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, Cout, 0, st);
-  else hipLaunchKernelGGL((k_gemm_nn<1, true>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, Cout, 0, st);
+  const GemmStats st{partial, p.nb, Cch, p.wpg, p.R, p.ysets, by, bstats, groups, act};
+  if (by) {
+    if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, 2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+    else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, 2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+    else hipLaunchKernelGGL((k_gemm_nn<1, 2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+  } else {
+    if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, 1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+    else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, 1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+    else hipLaunchKernelGGL((k_gemm_nn<1, 1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+  }
   return p.nb;
 }
 
@@ -934,7 +963,7 @@ extern "C" int bcp_down_fwd_stats(const float* x, const float* bp, const float* 
   BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_down_fwd_stats: bad shape");
   const int M = N * (D / 2) * (H / 2) * (W / 2);
   const int nb = launch_nn_stats(make_map(x, MAP_PATCH, 8 * Cin, Cin, D, H, W), bp, bias, make_map(y, MAP_PLAIN, Cout, 0, 0, 0, 0), M, 8 * Cin,
-                                 Cout, Cout, stat_partial, groups, (hipStream_t)stream);
+                                 Cout, Cout, Cout, 0, stat_partial, groups, nullptr, nullptr, 0, (hipStream_t)stream);
   BCP_REQUIRE(nb > 0, "bcp_down_fwd_stats: fused statistics unavailable for this shape (check bcp_k2_stat_rows first)");
   BCP_CHECK_LAUNCH("bcp_down_fwd_stats");
   return BCP_OK;
@@ -946,7 +975,7 @@ extern "C" int bcp_up_fwd_stats(const float* x, const float* bp, const float* bi
   BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_up_fwd_stats: bad shape");
   const int M = N * (D / 2) * (H / 2) * (W / 2);
   const int nb = launch_nn_stats(make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), bp, bias, make_map(y, MAP_PATCH, 8 * Cout, Cout, D, H, W), M, Cin,
-                                 8 * Cout, Cout, stat_partial, groups, (hipStream_t)stream);
+                                 8 * Cout, Cout, Cout, 0, stat_partial, groups, nullptr, nullptr, 0, (hipStream_t)stream);
   BCP_REQUIRE(nb > 0, "bcp_up_fwd_stats: fused statistics unavailable for this shape (check bcp_k2_stat_rows first)");
   BCP_CHECK_LAUNCH("bcp_up_fwd_stats");
   return BCP_OK;
@@ -973,6 +1002,45 @@ extern "C" int bcp_up_fwd(const float* x, const float* bp, const float* bias, fl
   launch_nn(make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), bp, bias, make_map(y, MAP_PATCH, 8 * Cout, Cout, D, H, W), M, Cin, 8 * Cout,
             Cout, 0, (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_up_fwd");
+  return BCP_OK;
+}
+
+// The two dgrads whose epilogue leaves the backward statistics of the norm layer that CONSUMES their output (round 6; as
+// bcp_conv3_dgrad_bwdstats for the 3x3x3 dgrads): the output (after the optional += of a skip gradient) is da of the layer in front of the
+// k2s2 / transposed conv, y_prev / stats_prev that layer's pre-norm tensor and statistics table; stat_partial[groups][rows][Cin][2]
+// receives (sum dz, sum dz * xhat) for bcp_norm_bwd(partial_in, nb_in = rows), whose statistics pass over (y, da) is then skipped.
+// rows = bcp_k2_bwdstat_rows(kind: 0 down-conv dgrad / 1 transposed-conv dgrad, ...); 0: not available (plain entry points).
+extern "C" int bcp_k2_bwdstat_rows(int kind, int N, int D, int H, int W, int Cin, int Cout, int groups) {
+  if (N < 1 || D < 2 || H < 2 || W < 2 || (D | H | W) & 1 || Cin % 16 || Cout % 16 || Cin < 16 || Cout < 16 || groups < 1) return 0;
+  if (options().k2_bwd_stats == 0 || options().fuse_bwd_stats == 0) return 0;
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  // (k2_bwd_stats = 2: only where the output is >= 2^22 elements -- the pass saved there is 23-33 us in the step, the epilogue costs ~11 at every level)
+  if (options().k2_bwd_stats == 2 && (long long)(kind == 0 ? 8LL * M : M) * Cin < (1LL << 22)) return 0;
+  StatPlan p;
+  return stat_plan(p, M, kind == 0 ? 8 * Cin : Cin, Cin, groups) ? p.nb : 0;
+}
+
+extern "C" int bcp_down_dgrad_bwdstats(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate,
+                                       const float* y_prev, const float* stats_prev, int act, double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(dy && bp && dx && y_prev && stats_prev && stat_partial, "bcp_down_dgrad_bwdstats: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_down_dgrad_bwdstats: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  const int nb = launch_nn_stats(make_map(dy, MAP_PLAIN, Cout, 0, 0, 0, 0), bp, nullptr, make_map(dx, MAP_PATCH, 8 * Cin, Cin, D, H, W), M, Cout,
+                                 8 * Cin, Cin, 1, accumulate, stat_partial, groups, y_prev, stats_prev, act, (hipStream_t)stream);
+  BCP_REQUIRE(nb > 0, "bcp_down_dgrad_bwdstats: fused statistics unavailable for this shape (check bcp_k2_bwdstat_rows first)");
+  BCP_CHECK_LAUNCH("bcp_down_dgrad_bwdstats");
+  return BCP_OK;
+}
+
+extern "C" int bcp_up_dgrad_bwdstats(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate,
+                                     const float* y_prev, const float* stats_prev, int act, double* stat_partial, int groups, void* stream) {
+  BCP_REQUIRE(dy && bp && dx && y_prev && stats_prev && stat_partial, "bcp_up_dgrad_bwdstats: null pointer");
+  BCP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0 && Cin % 16 == 0 && Cout % 16 == 0, "bcp_up_dgrad_bwdstats: bad shape");
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  const int nb = launch_nn_stats(make_map(dy, MAP_PATCH, 8 * Cout, Cout, D, H, W), bp, nullptr, make_map(dx, MAP_PLAIN, Cin, 0, 0, 0, 0), M, 8 * Cout,
+                                 Cin, Cin, 1, accumulate, stat_partial, groups, y_prev, stats_prev, act, (hipStream_t)stream);
+  BCP_REQUIRE(nb > 0, "bcp_up_dgrad_bwdstats: fused statistics unavailable for this shape (check bcp_k2_bwdstat_rows first)");
+  BCP_CHECK_LAUNCH("bcp_up_dgrad_bwdstats");
   return BCP_OK;
 }
 

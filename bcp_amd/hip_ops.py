@@ -701,6 +701,31 @@ class Ops:
                     _p(part), int(groups), self.stream(x))
         return self._no_amax(out), part, rows
 
+    def k2_bwdstat_rows(self, kind, dyshape, Cin, groups):
+        """partial rows per group k2_dgrad_bwdstats leaves (kind 0: dgrad of the down conv, dy coarse; 1: of the transposed conv, dy fine); 0: not fused"""
+        N, D, H, W, Cout = dyshape
+        fine = (2 * D, 2 * H, 2 * W) if kind == 0 else (D, H, W)
+        return self._ws_bytes("bcp_k2_bwdstat_rows", int(kind), N, fine[0], fine[1], fine[2], int(Cin), Cout, int(groups))
+
+    def k2_dgrad_bwdstats(self, kind, dy, bp, Cin, y_prev, stats_prev, act, groups, out=None, accumulate=False):
+        """dgrad of the down (kind 0) / transposed (kind 1) conv whose epilogue also accumulates the backward statistics of the norm layer in
+        front of it (pre-norm tensor y_prev -- laid out like the result -- and statistics stats_prev) -> (dx, partial, rows) for
+        norm_bwd(partial=, nb=); only where k2_bwdstat_rows(...) > 0.  out + accumulate: dx = out + dgrad (the skip gradient joined in place)"""
+        self._chk(dy, bp, out, y_prev, stats_prev)
+        N, D, H, W, Cout = dy.shape
+        fine = (2 * D, 2 * H, 2 * W) if kind == 0 else (D, H, W)
+        rows = self.k2_bwdstat_rows(kind, dy.shape, Cin, groups)
+        assert rows > 0, "k2_dgrad_bwdstats: statistics not fused for this shape (check k2_bwdstat_rows)"
+        osp = fine if kind == 0 else (D // 2, H // 2, W // 2)
+        if out is None:
+            assert not accumulate
+            out = torch.empty((N,) + osp + (Cin,), dtype=torch.float32, device=dy.device)
+        assert tuple(y_prev.shape) == tuple(out.shape), "k2_dgrad_bwdstats: y_prev must be laid out like the result"
+        part = self.workspace(("bstatpart", rows), groups * rows * Cin * 16, dy)
+        self.b.call("bcp_down_dgrad_bwdstats" if kind == 0 else "bcp_up_dgrad_bwdstats", _p(dy), _p(bp), _p(out), N, fine[0], fine[1], fine[2], int(Cin), Cout,
+                    int(bool(accumulate)), _p(y_prev), _p(stats_prev), int(act), _p(part), int(groups), self.stream(dy))
+        return self._no_amax(out), part, rows
+
     def down_dgrad(self, dy, bp, Cin, out=None, accumulate=False):
         self._chk(dy, bp, out)
         N, Dc, Hc, Wc, Cout = dy.shape
@@ -964,7 +989,7 @@ class Ops:
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
 _PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "mixloss_pair_fwd", "mixloss_pair_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
-             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd", "k2_fwd_stats",
+             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd", "k2_fwd_stats", "k2_dgrad_bwdstats",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")
 

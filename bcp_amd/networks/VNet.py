@@ -357,13 +357,19 @@ class VNet(HipNet):
                     dh, bpart, bnb = ops.conv3_dgrad_bwdstats(dy, wd, L.cin, 3, saved[li - 1][1], saved[li - 1][2], H.ACT_RELU, G)
                 else:
                     dh = ops.conv3_fwd(dy, wd, None, L.cin, 3)
-            elif L.kind == "dw":
-                _, bp = self.k2_packed(("k2", li), True)
-                sg = skip_grads.pop()        # x_in is a skip source: join the decoder-side gradient in place
-                dh = ops.down_dgrad(dy, bp, L.cin, out=sg, accumulate=True)
             else:
+                kind = 0 if L.kind == "dw" else 1
                 _, bp = self.k2_packed(("k2", li), True)
-                dh = ops.up_dgrad(dy, bp, L.cin)
+                sg = skip_grads.pop() if kind == 0 else None      # down conv: x_in is a skip source, the decoder-side gradient is joined in place
+                # (round 6) the layer in front has a pre-norm tensor of its own and no dropout epilogue: this dgrad's epilogue leaves its norm's
+                # backward statistics (bcp_down_dgrad_bwdstats / bcp_up_dgrad_bwdstats) where the shape is served -- no k_col_partial<1> pass over (y, da)
+                prev = saved[li - 1] if li > 0 else None
+                if prev is not None and prev[1] is not None and prev[3] is None and ops.k2_bwdstat_rows(kind, dy.shape, L.cin, G) > 0:
+                    dh, bpart, bnb = ops.k2_dgrad_bwdstats(kind, dy, bp, L.cin, prev[1], prev[2], H.ACT_RELU, G, out=sg, accumulate=sg is not None)
+                elif kind == 0:
+                    dh = ops.down_dgrad(dy, bp, L.cin, out=sg, accumulate=True)
+                else:
+                    dh = ops.up_dgrad(dy, bp, L.cin)
             self._grads_final_from(w, dy)
         self._join_wgrad_stream(dlogits)
         return None

@@ -111,6 +111,13 @@ def _work(name, shapes, ints):
         fl = 2.0 * min(vin, vout) * 8 * s0[-1] * cout
         by = 4.0 * (_numel(s0) + vout * cout)
         return ("hbm" if fl / by < 20 else "mfma"), fl, by
+    if name == "k2_dgrad_bwdstats":                        # (kind, dy, packed B, Cin, y_prev, ...): the k2s2 / transposed conv dgrad + the previous norm's backward statistics
+        kind, cin = ints[0], ints[1]
+        vin = _numel(s0[:-1])
+        vout = vin * 8 if kind == 0 else vin // 8
+        fl = 2.0 * min(vin, vout) * 8 * s0[-1] * cin
+        by = 4.0 * (_numel(s0) + 2 * vout * cin)
+        return ("hbm" if fl / by < 20 else "mfma"), fl, by
     if name == "k2_wgrad":
         fl = 2.0 * min(_numel(s0[:-1]), _numel(shapes[1][:-1])) * 8 * s0[-1] * shapes[1][-1]
         by = 4.0 * (_numel(s0) + _numel(shapes[1]))

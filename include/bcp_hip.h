@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 506
+#define BCP_ABI_VERSION 507
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -274,6 +274,15 @@ int bcp_up_fwd(const float* x, const float* bp, const float* bias, float* y, int
 int bcp_k2_stat_rows(int kind, int N, int D, int H, int W, int Cin, int Cout, int groups);
 int bcp_down_fwd_stats(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, double* stat_partial, int groups, void* stream);
 int bcp_up_fwd_stats(const float* x, const float* bp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout, double* stat_partial, int groups, void* stream);
+/* ... and the two dgrads leaving the BACKWARD statistics of the norm layer in front of the k2s2 / transposed conv (the autograd of
+   networks/VNet.py:74-86, 101-113 followed by that of the BatchNorm / InstanceNorm + ReLU before it): the output -- after the optional += of
+   a skip gradient -- is da of that layer; y_prev / stats_prev: its pre-norm tensor (laid out like dx) and statistics table (bcp_norm_fwd);
+   stat_partial[groups][rows][Cin][2] doubles = (sum dz, sum dz * xhat) partial rows for bcp_norm_bwd(partial_in, nb_in = rows).  Same
+   contract as bcp_conv3_dgrad_bwdstats (no chan_scale / elem_mask on that layer).  rows = bcp_k2_bwdstat_rows(kind: 0 = down-conv dgrad,
+   1 = transposed-conv dgrad; (D, H, W) the FINE extents); 0: not available for this shape. */
+int bcp_k2_bwdstat_rows(int kind, int N, int D, int H, int W, int Cin, int Cout, int groups);
+int bcp_down_dgrad_bwdstats(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, const float* y_prev, const float* stats_prev, int act, double* stat_partial, int groups, void* stream);
+int bcp_up_dgrad_bwdstats(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, const float* y_prev, const float* stats_prev, int act, double* stat_partial, int groups, void* stream);
 int bcp_up_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 int bcp_pw_fwd(const float* x, const float* bp, const float* bias_or_null, float* y, long long rows, int Cin, int Cout, void* stream);
 size_t bcp_tn_workspace_bytes(long long M, int K, int N);

@@ -813,6 +813,55 @@ def _check_k2_stats(ops, dev, rng):
     assert seen_fused == len(cases)
 
 
+def check_k2_bwdstats(ops, dev):
+    """round 6: the k2s2 / transposed conv DGRAD whose epilogue leaves the backward statistics of the norm layer in front of it
+    (bcp_down_dgrad_bwdstats / bcp_up_dgrad_bwdstats): dx bit-identical to the plain dgrad (+= a skip gradient included), and bcp_norm_bwd fed
+    with the partial rows equal to bcp_norm_bwd making its own pass over (y, da): dy, dgamma, dbeta.  Cases: channel folds as in
+    check_k2_stats, G = 1 / 2, with and without the accumulated skip gradient; one big case (GPU only) for R > 1"""
+    rng = np.random.default_rng(12)
+    ops.set_option("k2_bwd_stats", 1)
+    try:
+        # (kind, N, Cin, Cout, dy spatial, G): kind 0 = dgrad of the down conv Cin -> Cout (dy coarse [.., Cout], dx fine [.., Cin]);
+        #                                     kind 1 = dgrad of the transposed conv Cin -> Cout (dy fine [.., Cout], dx coarse [.., Cin])
+        cases = [(0, 2, 16, 32, (4, 8, 8), 2), (0, 2, 32, 64, (4, 4, 8), 1), (0, 1, 64, 128, (4, 4, 4), 1),
+                 (1, 2, 32, 16, (8, 16, 16), 2), (1, 2, 64, 32, (8, 8, 16), 1), (1, 1, 128, 64, (8, 8, 8), 1)]
+        if dev.type == "cuda":
+            cases += [(1, 2, 32, 16, (32, 64, 64), 2), (0, 2, 32, 64, (16, 32, 32), 2)]
+        for kind, N, Cin, Cout, sp, G in cases:
+            dy = to_cl(R(rng, N, Cout, *sp) * 1e-2).to(dev)
+            if kind == 0:
+                w = (R(rng, Cout, Cin, 2, 2, 2) * 0.1).to(dev)
+                bp = ops.k2_pack(w, Cin, Cout, H.PACK_DOWN_DGRAD)
+                osp = tuple(2 * e for e in sp)
+            else:
+                w = (R(rng, Cin, Cout, 2, 2, 2) * 0.1).to(dev)
+                bp = ops.k2_pack(w, Cin, Cout, H.PACK_UP_DGRAD)
+                osp = tuple(e // 2 for e in sp)
+            tag = f"k2 bwdstats kind {kind} {N}x{sp} {Cin}<-{Cout} G={G}"
+            rows = ops.k2_bwdstat_rows(kind, dy.shape, Cin, G)
+            assert rows > 0, tag + ": expected the fused statistics for this shape"
+            # the norm layer in front: pre-norm tensor y, its statistics from a real forward
+            y = to_cl(R(rng, N, Cin, *osp) * 1.3 + 0.2).to(dev)
+            gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cin).astype(np.float32)).to(dev)
+            beta = torch.from_numpy(rng.uniform(-0.3, 0.3, Cin).astype(np.float32)).to(dev)
+            _, st = ops.norm_fwd(y, G, gamma, beta, torch.zeros(Cin, device=dev), torch.ones(Cin, device=dev), H.ACT_RELU)
+            for acc in (False, True):
+                sg = (to_cl(R(rng, N, Cin, *osp) * 1e-2).to(dev)) if acc else None
+                plain = ops.down_dgrad if kind == 0 else ops.up_dgrad
+                d0 = plain(dy, bp, Cin, out=sg.clone() if acc else None, accumulate=acc).clone()
+                d1, part, nb = ops.k2_dgrad_bwdstats(kind, dy, bp, Cin, y, st, H.ACT_RELU, G, out=sg.clone() if acc else None, accumulate=acc)
+                assert nb == rows and torch.equal(d1, d0), tag + f" acc={acc}: dx differs from the plain dgrad"
+                dg0, db0 = torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
+                dg1, db1 = torch.zeros(Cin, device=dev), torch.zeros(Cin, device=dev)
+                dy0 = ops.norm_bwd(y, d0, G, st, H.ACT_RELU, dg0, db0, True).clone()
+                dy1 = ops.norm_bwd(y, d1, G, st, H.ACT_RELU, dg1, db1, True, partial=part, nb=nb)
+                close(dy1.cpu(), dy0.cpu(), rtol=1e-5, atol_scale=1e-6, msg=tag + f" acc={acc} dy")
+                close(dg1.cpu(), dg0.cpu(), rtol=1e-5, atol_scale=1e-6, msg=tag + f" acc={acc} dgamma")
+                close(db1.cpu(), db0.cpu(), rtol=1e-5, atol_scale=1e-6, msg=tag + f" acc={acc} dbeta")
+    finally:
+        ops.set_option("k2_bwd_stats")
+
+
 def check_k2_chunks(ops, dev):
     """weight-gradient GEMMs with ONE row group, so every block walks several 64-row chunks (prefetch / row-table pipeline)"""
     ops.set_option("tn_groups", 1)
@@ -1671,7 +1720,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
+ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):
