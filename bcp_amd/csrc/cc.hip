@@ -315,7 +315,8 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
   hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, L, lsize, size, n);
   {
     int gx = (int)((V + 255) / 256 / 4);      // ~4 voxels per thread
-    gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+    const int cap = options().cc_select_blocks > 0 ? options().cc_select_blocks : 256;
+    gx = gx < 1 ? 1 : (gx > cap ? cap : gx);  // (round 6, measured: 1024 blocks per sample make the chain 162 -> 155 us alone and move nothing in the step: gpurun_out/r06_s17)
     hipLaunchKernelGGL(k_cc_select, dim3(gx, N), dim3(256), 0, s, seg, L, size, best, V, n, nclass);
   }
   hipLaunchKernelGGL(k_cc_write, dim3(grid), dim3(256), 0, s, seg, L, best, out_u8, out_f32, V, n, nclass);

@@ -52,6 +52,7 @@ struct Options {
   long long wgrad_tile[5] = {0, 0, 0, 0, 1LL << 60};   // TD, TH, TW, min voxels, max voxels
   int tn_groups = 0;        // k2s2 / 1x1 weight-gradient GEMM: cap on voxel groups (tests: force multi-chunk groups)
   int cc_tile = 0;          // largest-CC tile flavour
+  int cc_select_blocks = 0; // largest-CC: workgroups per sample of the root-selection pass (0 = 256; measurement switch)
   int conv3_b6 = 1;         // fp32 conv on the bf16 matrix pipe (three-piece operands, conv3b.hip): 0 off, 1 where measured faster, 2 wherever valid
   int conv3_b6_levels = 15;  // automatic choice (conv3_b6 = 1): bit 0 = 32-channel slabs (256-voxel tiles), bit 1 = 64-channel slabs, bit 2 = the 16 -> 16 layers (persistent k_c3d with cross-tile halo prefetch: 176 vs 243-258 us alone, step 7.00 vs 7.18 ms; one tile per workgroup it was 209-228 us and no step gain), bit 3 = the 2-D instances (ACDC step 5.18 -> 4.24 ms together with the weight gradients).  LA step, interleaved A/B (ms per step): off 8.87, 32-channel level 8.32, + 64-channel level 8.05 -- the latter although ALONE that kernel is slower than the exclusive pipeline kernel it replaces (66-71 vs 61 us): two workgroups per CU leave room for the other stream
   int conv3_b6_minvox = 256;     // automatic choice: smallest launch (voxels, batch included) that goes to the bf16-pipe kernels

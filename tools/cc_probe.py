@@ -3,6 +3,9 @@ import sys, torch
 sys.path.insert(0, "/root/repo")
 from bcp_amd.hip_ops import Ops
 ops = Ops.product(); dev = torch.device("cuda:0")
+for kv in sys.argv[1:]:
+    k, _, v = kv.partition("=")
+    ops.set_option(k, v)
 g = torch.Generator(device="cpu").manual_seed(0)
 for p in (0.5, 0.1):
     seg = (torch.rand(2, 112, 112, 80, generator=g) < p).to(torch.uint8).to(dev)
