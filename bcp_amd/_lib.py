@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 507      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 508      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int
@@ -69,6 +69,7 @@ _SIGS = {
     "bcp_conv3_wgrad_path": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_pack_weight": (I, [P, P, P, I, I, I, P]),
     "bcp_conv3_pack_many": (I, [P, I, P]),
+    "bcp_conv3_last_section": (I, []),
     "bcp_conv3_fwd_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
     "bcp_conv3_fwd": (I, [P, P, P, P, I, I, I, I, I, I, I, I, P, P, P]),
     "bcp_conv3_stat_rows": (I, [I, I, I, I, I, I, I, I, I]),
@@ -204,7 +205,7 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_planes", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows", "bcp_k2_stat_rows", "bcp_k2_bwdstat_rows")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_planes", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows", "bcp_k2_stat_rows", "bcp_k2_bwdstat_rows", "bcp_conv3_last_section")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
         got = int(self.cdll.bcp_version())
         if got != ABI_VERSION:

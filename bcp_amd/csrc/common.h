@@ -51,6 +51,7 @@ struct Options {
   int wgrad_nt = 0;
   long long wgrad_tile[5] = {0, 0, 0, 0, 1LL << 60};   // TD, TH, TW, min voxels, max voxels
   int tn_groups = 0;        // k2s2 / 1x1 weight-gradient GEMM: cap on voxel groups (tests: force multi-chunk groups)
+  int pack_sections = 7;    // MEASUREMENT ONLY (bcp_conv3_pack_many): which sections of the weight packs are written -- 1 fp32, 2 three bf16 planes, 4 two fp16 planes; anything but 7 is only valid when no launch reads the others
   int cc_tile = 0;          // largest-CC tile flavour
   int cc_select_blocks = 0; // largest-CC: workgroups per sample of the root-selection pass (0 = 256; measurement switch)
   int conv3_b6 = 1;         // fp32 conv on the bf16 matrix pipe (three-piece operands, conv3b.hip): 0 off, 1 where measured faster, 2 wherever valid

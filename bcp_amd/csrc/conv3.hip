@@ -837,7 +837,8 @@ __global__ __launch_bounds__(256) void k_wamax_many(const PackDesc* __restrict__
 // Work unit = one 16 x 16 (k, n) block of one layer, all taps: the 16 source rows are runs of 16*T contiguous floats
 // (coalesced reads), transposed through LDS, written as 256-B runs.  Units are dealt round-robin to the blocks, so the
 // 256-channel layers (256 units each) no longer serialise on a fixed 64 blocks of scattered 4-byte gathers.
-__global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restrict__ descs, int n) {
+__global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restrict__ descs, int n, int sections) {
+  // sections (measurement switch, option pack_sections; 7 = everything): bit 0 the fp32 pack, bit 1 the three bf16 planes, bit 2 the two fp16 planes
   __shared__ float tile[16 * 16 * 27];
   __shared__ int ubeg[kMaxPackDescs + 1];           // exclusive prefix sums of the per-layer unit counts
   // (scanning the descriptor array in global memory per unit cost ~80 dependent scalar loads = 15+ us per unit)
@@ -856,7 +857,12 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
     int lo = 0, hi = n;                             // largest di with ubeg[di] <= unit
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ubeg[mid] <= unit) lo = mid; else hi = mid; }
     const int di = lo, u = unit - ubeg[lo];
-    const PackDesc d = descs[di];
+    PackDesc d = descs[di];
+    // the descriptor's last word: bit 0 = dgrad flavour, bits 8-10 = the sections this layer's launches read (0: all) -- round 6: a network
+    // repacks every weight every step, and most layers only ever read ONE of the three sections (the two fp16 planes)
+    int sec = (d.dgrad >> 8) & 7;
+    sec = (sec ? sec : 7) & sections;
+    d.dgrad &= 1;
     const int nb = d.N16 >> 4, k0 = (u / nb) * 16, n0 = (u % nb) * 16, T = d.T;
     // source rows: fwd w[nn][kk..][t] (row = nn, inner = kk = cin); dgrad w[kk][nn..][t] (row = kk = cout, inner = nn = cin)
     const int row0 = d.dgrad ? k0 : n0, in0 = d.dgrad ? n0 : k0;
@@ -868,6 +874,7 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
       tile[q] = v;                                   // tile[row][inner][t]
     }
     __syncthreads();
+    if (sec & 1)
     for (int q = threadIdx.x; q < 256 * T; q += 256) {
       const int k4 = q & 3, nn = (q >> 2) & 15, kq = (q >> 6) & 3, t = q >> 8;
       const int kk = kq * 4 + k4;
@@ -878,6 +885,7 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
        // exactly one packed pair per piece (v_cvt_pk_bf16_f32; the integer split of the first version cost 80 of the launch's 150 us)
       const int TP = (T + 1) / 2, ch = k0 >> 4;
       unsigned* wb = reinterpret_cast<unsigned*>(d.wp + (long long)T * d.K16 * d.N16);
+      if (sec & 2)
       for (int q = threadIdx.x; q < TP * 16 * 16; q += 256) {
         const int j2 = q & 15, nn = (q >> 4) & 15, tp = q >> 8;
         const int t = 2 * tp + (j2 >> 3), kk = (j2 * 2) & 15;
@@ -904,6 +912,7 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
       const float sc = f16_scale(amax);
       if (u == 0 && threadIdx.x == 0) hdr[0] = amax;
       unsigned* wh = reinterpret_cast<unsigned*>(d.wp + pack_off_f16(T, d.K16, d.N16));
+      if (sec & 4)
       for (int q = threadIdx.x; q < TP * 16 * 16; q += 256) {
         const int j2 = q & 15, nn = (q >> 4) & 15, tp = q >> 8;
         const int t = 2 * tp + (j2 >> 3), kk = (j2 * 2) & 15;
@@ -1407,7 +1416,7 @@ extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
   hipLaunchKernelGGL(k_wamax_many, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
   // (2048 workgroups: the V-Net's 84 layers are 1368 work units of one 16 x 16 x taps block each -- with 1024 workgroups a third of them
   //  did two units and the launch lasted as long as those)
-  hipLaunchKernelGGL(k_pack_conv3_many, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n);
+  hipLaunchKernelGGL(k_pack_conv3_many, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n, options().pack_sections);
   BCP_CHECK_LAUNCH("bcp_conv3_pack_many");
   return BCP_OK;
 }
@@ -1464,6 +1473,12 @@ extern "C" size_t bcp_conv3_fwd_workspace_bytes(int N, int D, int H, int W, int 
 
 // shared by the launch and by the statistics-rows query: returns the number of partial rows per group the chosen kernel
 // writes (0: this shape does not support fused statistics, e.g. split-K), or a negative error
+namespace bcp { int b6_last_planes(); }
+// which SECTION of the packed weight the last real (non-dry) forward / dgrad launch of this thread read: 1 = the fp32 pack (conv3.hip kernels),
+// 2 = the three bf16 planes, 4 = the two fp16 planes (conv3b.hip).  The host learns from it which sections a layer's packs must hold
+// (bcp_conv3_last_section; networks/_hipnet.py)
+static thread_local int g_last_section = 0;
+
 static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, float* y, int N, int D, int H, int W, int Cin, int Cout,
                           int KD, int accumulate, void* workspace, double* stat_partial, int G, bool dry, void* stream,
                           const float* x_amax = nullptr) {
@@ -1474,6 +1489,7 @@ static int conv3_fwd_impl(const float* x, const float* wp, const float* bias, fl
   int rows = 0;
   Cfg r;
   rows = b6_fwd(x, wp, bias, y, cd, KD, accumulate, workspace, stat_partial, G, dry, (hipStream_t)stream, &done);
+  if (!dry) g_last_section = done ? (bcp::b6_last_planes() == 2 ? 4 : 2) : 1;
   if (done) return rows;
   if (choose_res(r, KD, N, D, H, W, cd.Cin16, cd.Cout16)) {
     BCP_RES_CASE(3, 4, 4, 16, 1) BCP_RES_CASE(3, 4, 4, 16, 2)
@@ -1551,6 +1567,8 @@ extern "C" int bcp_conv3_planes(int N, int D, int H, int W, int Cin, int Cout, i
   return handled ? bcp::b6_last_planes() : 0;
 }
 
+extern "C" int bcp_conv3_last_section(void) { return g_last_section; }
+
 extern "C" size_t bcp_conv3_wgrad_path(int N, int D, int H, int W, int Cin, int Cout, int KD) {
   ConvDims cd;
   fill_dims(cd, N, D, H, W, Cin, Cout);
@@ -1600,6 +1618,7 @@ extern "C" int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, 
   const BwdStatsIn bw{y_prev, stats_prev, act};
   const int rows = b6_fwd(dy, wp_dgrad, nullptr, da, cd, KD, 0, workspace, stat_partial, groups, false, (hipStream_t)stream, &handled, nullptr, &bw);
   BCP_REQUIRE(handled && rows > 0, "bcp_conv3_dgrad_bwdstats: fused statistics unavailable for this shape (check bcp_conv3_bwdstat_rows first)");
+  g_last_section = bcp::b6_last_planes() == 2 ? 4 : 2;
   BCP_CHECK_LAUNCH("bcp_conv3_dgrad_bwdstats");
   return BCP_OK;
 }
@@ -1641,6 +1660,7 @@ extern "C" int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, 
   cd.xamax = x_amax_or_null;
   b6_fwd(x, wp, nullptr, slabs, cd, KD, 0, slabs, nullptr, 0, false, (hipStream_t)stream, &handled, &sk);
   BCP_REQUIRE(handled && sk == nslab, "bcp_conv3_fwd_raw: shape not served in raw mode (check bcp_conv3_fwd_nslabs first)");
+  g_last_section = bcp::b6_last_planes() == 2 ? 4 : 2;
   BCP_CHECK_LAUNCH("bcp_conv3_fwd_raw");
   return BCP_OK;
 }

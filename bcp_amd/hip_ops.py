@@ -455,6 +455,15 @@ class Ops:
         N, D, H, W, Cin = xshape
         return self._ws_bytes("bcp_conv3_fwd_nslabs", int(N), int(D), int(H), int(W), int(Cin), int(Cout), int(KD))
 
+    def _note_pack_section(self, wp):
+        """after an eager / recorded forward or dgrad launch: tell the network that owns the packed weight `wp` which of its sections the
+        launch read (bcp_conv3_last_section) -- what lets it pack partially in front of replays (networks/_hipnet.py PACK_PARTIAL)"""
+        info = getattr(wp, "_bcp_pack", None)
+        if info is not None:
+            net = info[0]()
+            if net is not None:
+                net.pack_section_used(info[1], info[2], int(self.b.call("bcp_conv3_last_section")))
+
     def conv3_fwd_raw(self, x, wp, Cout, KD, nslab):
         """conv (forward or dgrad) whose split-K partial slabs ARE the result: float32 [nslab, N, D, H, W, Cout], no bias; the
         consumer (norm_fwd_slabs / norm_bwd_slabs) sums them on its way in"""
@@ -462,6 +471,7 @@ class Ops:
         N, D, H, W, Cin = x.shape
         slabs = torch.empty((nslab, N, D, H, W, Cout), dtype=torch.float32, device=x.device)
         self.b.call("bcp_conv3_fwd_raw", _p(x), _p(wp), _p(slabs), int(nslab), N, D, H, W, Cin, Cout, KD, _p(self._amax_of(x)), self.stream(x))
+        self._note_pack_section(wp)
         return slabs
 
     def norm_fwd_slabs(self, src, nslab, bias, G, gamma, beta, rmean, rvar, act, chan_scale=None, elem_mask=None, elem_scale=1.0,
@@ -532,6 +542,7 @@ class Ops:
         ws = self.workspace("conv3", nbytes, x) if nbytes else None
         self.b.call("bcp_conv3_fwd", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, int(bool(accumulate)), _p(ws), _p(self._amax_of(x)),
                     self.stream(x))
+        self._note_pack_section(wp)
         return self._no_amax(out)
 
     def conv3_fwd_stats(self, x, wp, bias, Cout, KD, groups):
@@ -547,6 +558,7 @@ class Ops:
         part = self.workspace(("statpart", rows), groups * rows * Cout * 16, x)
         self.b.call("bcp_conv3_fwd_stats", _p(x), _p(wp), _p(bias), _p(out), N, D, H, W, Cin, Cout, KD, _p(ws), _p(part), groups, _p(self._amax_of(x)),
                     self.stream(x))
+        self._note_pack_section(wp)
         return out, part, rows
 
     def conv3_dgrad_bwdstats(self, dy, wd, Cin, KD, y_prev, stats_prev, act, groups):
@@ -563,6 +575,7 @@ class Ops:
         part = self.workspace(("bstatpart", rows), groups * rows * Cin * 16, dy)
         self.b.call("bcp_conv3_dgrad_bwdstats", _p(dy), _p(wd), _p(da), N, D, H, W, Cout, Cin, KD, _p(y_prev), _p(stats_prev), act, _p(ws),
                     _p(part), groups, _p(self._amax_of(dy)), self.stream(dy))
+        self._note_pack_section(wd)
         return da, part, rows
 
     def conv3_wgrad(self, x, dy, dw, KD, accumulate=False):

@@ -5,6 +5,7 @@ autograd bridge (one Function node per network call; the whole backward is sched
 from __future__ import annotations
 
 import os
+import weakref
 
 import torch
 import torch.nn as nn
@@ -236,6 +237,11 @@ class HipNet(nn.Module):
         total = sum(sizes)
         self._pack_buf = torch.empty(2 * total, dtype=torch.float32, device=dev)
         self._pack_views = {}
+        self._pack_items = []
+        self._pack_need = {}          # (key, direction) -> sections the launches observed so far read (1 fp32 pack, 2 bf16 planes, 4 fp16 planes)
+        self._pack_need_ver = 0
+        self._pack_partial = None     # (need version, fwd descriptors, fwd + dgrad descriptors) with per-layer section masks
+        self._pack_full = True        # the packs of _pack_state hold every section
         fwd_desc, all_desc, dg_desc = b"", b"", b""
         off = 0
         for (key, w, KD), n in zip(self._c3, sizes):
@@ -243,6 +249,8 @@ class HipNet(nn.Module):
             K16, N16 = (Cin + 15) // 16 * 16, (Cout + 15) // 16 * 16
             wf, wd = self._pack_buf[off:off + n], self._pack_buf[total + off:total + off + n]
             self._pack_views[key] = (wf, wd)
+            wf._bcp_pack, wd._bcp_pack = (weakref.ref(self), key, 0), (weakref.ref(self), key, 1)      # (Ops notes which section a launch read)
+            self._pack_items.append((key, w.data_ptr(), wf.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, K16, N16))
             d_f = struct.pack("<QQiiiiii", w.data_ptr(), wf.data_ptr(), Cout, Cin, KD * 9, K16, N16, 0)
             d_d = struct.pack("<QQiiiiii", w.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, N16, K16, 1)
             fwd_desc += d_f
@@ -279,9 +287,12 @@ class HipNet(nn.Module):
             self._build_pack_tables()
         ver = self._weights_version()
         st = self._pack_state
+        if st is not None and not self._pack_full:
+            st = None                 # this version was packed PARTIALLY (in front of a replay): anything else gets every section
         if st is None or st[0] != ver or (need_dgrad and not st[1]):
             n = len(self._c3)
             fresh = st is not None and st[0] == ver            # the forward packs of this weight version exist already
+            self._pack_full = True
             if not need_dgrad:
                 self.ops.conv3_pack_many(self._desc_fwd, n)
             elif self._defer_dgrad_pack():
@@ -524,6 +535,59 @@ class HipNet(nn.Module):
         return (plan.ENABLED and self.use_plans and self.training and self.drop_masks is None and not getattr(self, "_keep_saved", False)
                 and (x.is_cuda or self.ops.allow_cpu) and self.ops.b._rec is None)
 
+    # ---- round 6: partial packs in front of REPLAYS.  A pack holds three sections -- the fp32 pack (conv3.hip's kernels), three bf16 planes and
+    # two fp16 planes (conv3b.hip) -- and a launch reads exactly one; every network repacks every weight every step (500 MB per LA step, of which
+    # the step's launches read 130).  Ops notes after every eager / recorded forward or dgrad launch which section it read
+    # (bcp_conv3_last_section) for the (layer, direction) its packed weight belongs to; a REPLAY of a recorded pass issues exactly the launches
+    # that were observed when it was recorded, so in front of a replay only the observed sections are written (per-descriptor masks,
+    # bcp_conv3_pack_many).  Everything else -- eager passes, the recording of a new plan, a validation forward -- asks conv3_packed(), which
+    # repacks every section when the current version was packed partially.  LA 757.1 -> 764.3 volumes/s as an upper bound (gpurun_out/r06_s18).
+    PACK_PARTIAL = os.environ.get("BCP_PACK_PARTIAL", "1") != "0"
+
+    def pack_section_used(self, key, direction, sec):
+        k = (key, direction)
+        m = self._pack_need.get(k, 0)
+        if sec & ~m:
+            self._pack_need[k] = m | sec
+            self._pack_need_ver += 1
+
+    def _partial_descs(self):
+        import struct
+        hit = self._pack_partial
+        if hit is None or hit[0] != self._pack_need_ver:
+            fwd, both = b"", b""
+            for key, wptr, wfp, wdp, Cout, Cin, T, K16, N16 in self._pack_items:
+                sf, sd = self._pack_need.get((key, 0), 0), self._pack_need.get((key, 1), 0)      # 0: never observed -> every section
+                d_f = struct.pack("<QQiiiiii", wptr, wfp, Cout, Cin, T, K16, N16, 0 | (sf << 8))
+                d_d = struct.pack("<QQiiiiii", wptr, wdp, Cout, Cin, T, N16, K16, 1 | (sd << 8))
+                fwd += d_f
+                both += d_f + d_d
+            dev = self._flat.device
+            hit = (self._pack_need_ver, torch.frombuffer(bytearray(fwd), dtype=torch.uint8).to(dev), torch.frombuffer(bytearray(both), dtype=torch.uint8).to(dev))
+            self._pack_partial = hit
+        return hit[1], hit[2]
+
+    def _ensure_packed_replay(self, need_dgrad):
+        """_ensure_packed in front of the REPLAY of a recorded pass: only the sections its launches were seen reading"""
+        c3 = getattr(self, "_c3", None)
+        if c3 and self.PACK_PARTIAL and getattr(self, "_pack_ptr", None) == self._flat.data_ptr() and self._pack_need:
+            ver = self._weights_version()
+            st = self._pack_state
+            if st is None or st[0] != ver or (need_dgrad and not st[1]):
+                fwd, both = self._partial_descs()
+                n = len(self._c3)
+                if need_dgrad:
+                    self.ops.conv3_pack_many(both, 2 * n)
+                else:
+                    self.ops.conv3_pack_many(fwd, n)
+                self._pack_state = (ver, bool(need_dgrad))
+                self._pack_full = False
+        elif c3:
+            self.conv3_packed(c3[0][0], need_dgrad)
+        k2 = getattr(self, "_k2", None)
+        if k2:
+            self.k2_packed(k2[0][0], need_dgrad)
+
     def _ensure_packed(self, need_dgrad):
         """weight packs depend on the weights' version, not on the pass: (re)pack eagerly, outside any plan"""
         c3 = getattr(self, "_c3", None)
@@ -597,7 +661,10 @@ class HipNet(nn.Module):
             r = self._forward_impl(xcl, save)
             self._feat_out = getattr(r[0], "_bcp_feat", None)
             return r
-        self._ensure_packed(save)
+        if pl is None:
+            self._ensure_packed(save)              # a pass about to be RECORDED runs eagerly: every section
+        else:
+            self._ensure_packed_replay(save)
         if pl is None:
             pl = plan.LaunchPlan()
             pl.static_in = torch.empty_like(xcl)
@@ -641,7 +708,10 @@ class HipNet(nn.Module):
             key = ("b", id(saved), tuple(dout.shape), self.ops.stream(dout), self._grad_bucket_hook is not None,
                    bool(self.overlap_wgrad))
             pl = plans.get(key)
-            self._ensure_packed(True)
+            if pl is None:
+                self._ensure_packed(True)
+            else:
+                self._ensure_packed_replay(True)
             if pl is None:
                 pl = plan.LaunchPlan()
                 pl.static_in = torch.empty(tuple(dout.shape), dtype=dout.dtype, device=dout.device)

@@ -710,6 +710,10 @@ def main():
             from bcp_amd import train_step as _ts
             _ts.TEACHER_STREAM_PRIORITY = int(v)
             continue
+        if k == "pack_partial":       # host-side switch (networks/_hipnet.py): only the observed sections of the weight packs in front of replays
+            from bcp_amd.networks._hipnet import HipNet as _hn5
+            _hn5.PACK_PARTIAL = bool(int(v))
+            continue
         if k == "wgrad_prio":         # host-side switch (networks/_hipnet.py): HIP priority of the weight-gradient side stream
             from bcp_amd.networks._hipnet import HipNet as _hn
             _hn.WGRAD_STREAM_PRIORITY = int(v)

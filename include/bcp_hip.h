@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 507
+#define BCP_ABI_VERSION 508
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -212,6 +212,13 @@ int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, 
  * current options (1..8; 0: shape not served in raw mode -> bcp_conv3_fwd).  Forward and dgrad alike.  bcp_conv3_fwd_raw is told how
  * many slabs the caller allocated and refuses (nothing launched) when the launch would write a different number. */
 int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD);
+/* round 6: which section of the packed weight the LAST forward / dgrad launch issued by this thread read -- 1 = the fp32 pack, 2 = the three
+   bf16 planes, 4 = the two fp16 planes (0: none yet).  bcp_conv3_pack_many writes, per descriptor, only the sections named in bits 8-10 of the
+   descriptor's last word (0 = all three; bit 0 stays the dgrad flag): a host that repacks every weight every step (the BCP loop: the
+   optimiser and the EMA change all of them) learns from this query which sections each layer's launches read and stops writing the others --
+   300 of the 500 MB per LA step.  The host must hold every section a launch reads: bcp_amd/networks/_hipnet.py packs partially only in front
+   of REPLAYS of recorded passes whose launches it has observed, and fully before anything else. */
+int bcp_conv3_last_section(void);
 int bcp_conv3_fwd_raw(const float* x, const float* wp, float* slabs, int nslab, int N, int D, int H, int W, int Cin, int Cout, int KD,
                       const float* x_amax_or_null, void* stream);
 /* which matrix pipe serves bcp_conv3_fwd / bcp_conv3_fwd_stats for this shape under the current options (no launch): 0 = fp32 MFMA

@@ -1184,6 +1184,55 @@ class LoadGenerator:
         self.s.synchronize()
 
 
+def check_partial_packs(ops, dev):
+    """round 6 (networks/_hipnet.py PACK_PARTIAL): in front of REPLAYS a network writes only the sections of its weight packs the recorded
+    launches were seen reading; everything else must find every section.  (1) after a few LA steps on recorded plans the student's and the
+    teacher's packs ARE partial and most layers need exactly one section; (2) a pass that reads OTHER sections right behind a replay -- the
+    same weights, |max| slots switched off, so every conv takes the three bf16 planes instead of the two fp16 ones -- gets a full repack and
+    computes the same logits to conv-arithmetic tolerance (with stale planes it would be garbage); (3) the replayed steps themselves equal
+    the eager path bit for bit (check_launch_plans, which runs with partial packs since this round)."""
+    from bcp_amd import plan, train_step
+    plan.ENABLED = True
+    torch.manual_seed(5)
+    np.random.seed(5)
+    P = O.init_params(O.vnet_param_shapes(), seed=41, random_affine=True)
+    model, ema = make_vnet(P, dev, ops, "la"), make_vnet(P, dev, ops, "la")
+    model.seed_dropout(11)
+    ema.seed_dropout(12)
+    for p in ema.parameters():
+        p.detach_()
+    vol, lab = O.synth_la_batch(4, shape=(32, 32, 16), seed=77)
+    vol, lab = vol.to(dev), lab.to(dev)
+    opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    for _ in range(3):
+        train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), overlap=False)      # (teacher on the caller's stream: the pass below finds its plan)
+    for net, name in ((model, "student"), (ema, "teacher")):
+        assert type(net).PACK_PARTIAL and net._pack_need, (name, "no section was ever noted")
+        assert not net._pack_full, (name, "the last replay did not pack partially")
+        single = [m for m in net._pack_need.values() if m in (1, 2, 4)]
+        assert len(single) >= len(net._pack_need) // 2, (name, net._pack_need)
+    # (2) the teacher's weights as the last replay left them (partial packs of the CURRENT version): an eager forward of the same input
+    x = vol[2:].contiguous()
+    ema.train()
+    with torch.no_grad():
+        ema.seed_dropout(99)                                         # (the same Dropout3d draws in both passes)
+        ref = ema(x, groups=2, features=False)[0].clone()          # a replay: partial packs, fp16 / observed sections
+        assert not ema._pack_full
+        amax0 = type(ops).AMAX
+        plan.ENABLED = False
+        type(ops).AMAX = False                                       # no |max| slots: the convs take three bf16 planes (and the fp32 kernels where they did before)
+        try:
+            ema.seed_dropout(99)
+            out = ema(x, groups=2, features=False)[0].clone()
+        finally:
+            type(ops).AMAX = amax0
+            plan.ENABLED = True
+        assert ema._pack_full, "an eager pass behind a partial pack must repack every section"
+    d = float((out - ref).abs().max() / (ref.abs().max() + 1e-12))
+    print(f"partial packs: eager bf16-plane pass vs replayed fp16-plane pass, max |d| / max |ref| = {d:.2e}; student needs {sorted(set(model._pack_need.values()))}")
+    assert d < 2e-3, d        # (same dropout draws; bf16-plane vs fp16-plane arithmetic and the BatchNorm over 4 values at the deepest level: ~1e-4; stale planes: O(1))
+
+
 def check_launch_plans(ops, dev, steps=3, cases=(("la", True), ("la", False), ("pancreas", True), ("acdc", True)), graphs=None, overlap=True, real_stream=False,
                        load=None, volatile=False):
     """recorded launch plans (bcp_amd/plan.py) == the eager Python path, bit for bit: three self-training steps of the LA V-Net

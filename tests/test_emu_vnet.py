@@ -106,6 +106,13 @@ def test_volatile_io_replays_equal_eager_path(emu_ops):
     NC.check_launch_plans(emu_ops, CPU, steps=3, cases=(("la", True),), volatile=True)
 
 
+def test_partial_weight_packs(emu_ops):
+    """round 6: only the observed sections of the weight packs are written in front of replays; an eager pass behind one repacks everything"""
+    from bcp_amd.utils import BCP_utils as BU
+    BU.set_test_ops(emu_ops)
+    NC.check_partial_packs(emu_ops, CPU)
+
+
 @pytest.mark.extended
 def test_head_fused_with_last_norm_equals_separate_apply(emu_ops):
     """VNet.fuse_head: block_nine's norm + ReLU + Dropout3d applied inside the 1x1x1 head (its activation never stored)"""

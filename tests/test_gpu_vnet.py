@@ -201,6 +201,11 @@ def test_fp16_backward_planes_hold_over_a_long_run(ops):
             print("fp16-bwd long run step %4d: loss %.5f  worst tensor %.2e  median %.2e" % (it, loss, w, med))
 
 
+def test_partial_weight_packs(ops):
+    """round 6: only the observed sections of the weight packs are written in front of replays; an eager pass behind one repacks everything"""
+    NC.check_partial_packs(ops, DEV)
+
+
 def test_recorded_launch_plans_equal_eager_path(ops):
     """bcp_amd/plan.py: replayed passes == the eager Python path, bit for bit (LA grouped / unfused, pancreas, ACDC; live dropout)"""
     NC.check_launch_plans(ops, DEV)
