@@ -1186,7 +1186,7 @@ class LoadGenerator:
 
 def check_partial_packs(ops, dev):
     """round 6 (networks/_hipnet.py PACK_PARTIAL): in front of REPLAYS a network writes only the sections of its weight packs the recorded
-    launches were seen reading; everything else must find every section.  (1) after a few LA steps on recorded plans the student's and the
+    launches were seen reading; everything else must find every section.  (1) after two LA steps on recorded plans the student's and the
     teacher's packs ARE partial and most layers need exactly one section; (2) a pass that reads OTHER sections right behind a replay -- the
     same weights, |max| slots switched off, so every conv takes the three bf16 planes instead of the two fp16 ones -- gets a full repack and
     computes the same logits to conv-arithmetic tolerance (with stale planes it would be garbage); (3) the replayed steps themselves equal
@@ -1204,7 +1204,7 @@ def check_partial_packs(ops, dev):
     vol, lab = O.synth_la_batch(4, shape=(32, 32, 16), seed=77)
     vol, lab = vol.to(dev), lab.to(dev)
     opt = train_step.FlatSGD(model, lr=0.01, momentum=0.9, weight_decay=1e-4)
-    for _ in range(3):
+    for _ in range(2):        # step 1 records the passes (eager, full packs, sections noted), step 2 replays them (partial packs)
         train_step.la_self_train_step(model, ema, opt, vol, lab, 2, box=(3, 5, 2, 21, 21, 10), overlap=False)      # (teacher on the caller's stream: the pass below finds its plan)
     for net, name in ((model, "student"), (ema, "teacher")):
         assert type(net).PACK_PARTIAL and net._pack_need, (name, "no section was ever noted")
