@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 508      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 509      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int
@@ -98,6 +98,10 @@ _SIGS = {
     "bcp_k2_bwdstat_rows": (I, [I, I, I, I, I, I, I, I]),
     "bcp_down_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P, I, P]),
     "bcp_up_dgrad_bwdstats": (I, [P, P, P, I, I, I, I, I, I, I, P, P, I, P, I, P]),
+    "bcp_up_norm_rows": (I, [I, I, I, I, I, I, I]),
+    "bcp_up_norm_workspace_bytes": (SZ, [I, I, I, I, I, I, I]),
+    "bcp_up_fwd_norm": (I, [P, P, P, I, I, I, I, I, I, I, P, P, P, P, F, F, I, P, P, P, P, P, P]),
+    "bcp_up_norm_bwd": (I, [P, P, P, P, I, I, I, I, I, I, I, P, I, P, P, I, P, P, P]),
     "bcp_pw_fwd": (I, [P, P, P, P, L, I, I, P]),
     "bcp_tn_workspace_bytes": (SZ, [L, I, I]),
     "bcp_k2_wgrad": (I, [P, P, P, I, I, I, I, I, I, I, I, P, P]),
@@ -205,7 +209,7 @@ class Binding:
             fn = getattr(self.cdll, name)  # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args
-        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_planes", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows", "bcp_k2_stat_rows", "bcp_k2_bwdstat_rows", "bcp_conv3_last_section")}
+        self._status_fns = {n for n, (r, _) in _SIGS.items() if r is I and n not in ("bcp_version", "bcp_conv3_stat_rows", "bcp_comm_available", "bcp_replay_count", "bcp_norm_slabs_ok", "bcp_conv3_planes", "bcp_conv3_fwd_nslabs", "bcp_conv3_bwdstat_rows", "bcp_conv3_c1_stat_rows", "bcp_k2_stat_rows", "bcp_k2_bwdstat_rows", "bcp_conv3_last_section", "bcp_up_norm_rows")}
         self._fns = {n: (getattr(self.cdll, n), n in self._status_fns) for n in _SIGS}
         got = int(self.cdll.bcp_version())
         if got != ABI_VERSION:

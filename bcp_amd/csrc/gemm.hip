@@ -88,6 +88,13 @@ struct GemmStats {
   const float* by;
   const float* bstats;
   int G, act;
+  // STATS 3 .. 6 (round 6, the transposed conv whose output is RECOMPUTED instead of stored: bcp_up_fwd_norm / bcp_up_norm_bwd; the
+  // epilogues of k_conv3_c1's EPI 1 .. 4): 3 = forward statistics only, nothing stored; 4 = a = act((y - mean) * scale + shift)
+  // (+ residual) -> C, |max| published; 5 = backward statistics (sum dz, sum dz * xhat) from aux = da, nothing stored; 6 = dy = scale *
+  // (dz - c1 - xhat * c2) -> C.  bstats = the layer's own statistics table in all four.
+  const float* aux;      // 4: residual (nullable), 5 / 6: da -- laid out like the output
+  const float* c1c2;     // 6: float[2][G][C]
+  float* amax;           // 4: nullable |max| slots of the activation written
 };
 
 template <int NT, int STATS = 0>
@@ -97,15 +104,17 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
   constexpr int NB4 = (8 * CT + 255) / 256;          // B float4s per thread per stage
   __shared__ __attribute__((aligned(16))) float As[64 * AS];
   __shared__ __attribute__((aligned(16))) float Bs[8 * CT * 4];
-  __shared__ double Ss[STATS ? 4 * CT * 2 : 1];
+  constexpr bool ACCUM = STATS == 1 || STATS == 2 || STATS == 3 || STATS == 5;      // the modes that leave partial statistics rows
+  __shared__ double Ss[ACCUM ? 4 * CT * 2 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int n0 = blockIdx.y * CT;
   // per-lane sums over the workgroup's R <= 16 row blocks in fp32 (one value per block and accumulator: the error of such a partial sum,
   // <= 16 fp32 roundings, averages out over the ~10^5 partials of a tensor), everything behind it in fp64 -- 32 double accumulators cost the
   // kernel three of its five waves per SIMD (151 VGPRs: 79.9 us against 51.9 for the plain launch at the top level, gpurun_out/r06_s10)
-  float p1[STATS ? NT : 1][4], p2[STATS ? NT : 1][4];
-  if constexpr (STATS) {
+  float p1[ACCUM ? NT : 1][4], p2[ACCUM ? NT : 1][4];
+  float amax_o = 0.f;
+  if constexpr (ACCUM) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -188,7 +197,51 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       }
       if (accumulate) { const float4 p = ld4(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-      st4(o, v);
+      if constexpr (STATS <= 2) st4(o, v);
+      if constexpr (STATS == 3) {
+        p1[nt][0] += v.x; p2[nt][0] = fmaf(v.x, v.x, p2[nt][0]);
+        p1[nt][1] += v.y; p2[nt][1] = fmaf(v.y, v.y, p2[nt][1]);
+        p1[nt][2] += v.z; p2[nt][2] = fmaf(v.z, v.z, p2[nt][2]);
+        p1[nt][3] += v.w; p2[nt][3] = fmaf(v.w, v.w, p2[nt][3]);
+      }
+      if constexpr (STATS >= 4) {
+        // the arithmetic of k_norm_apply / k_col_partial<1> / k_norm_bwd_apply on the value just recomputed (k_conv3_c1 EPI 2 .. 4)
+        const int cb = (n0 + nt * 16) % st.C + lg * 4;
+        const long long pi = (long long)(blockIdx.x / st.wpg) * st.C + cb, GC = (long long)st.G * st.C;
+        const float4 mu = ld4(st.bstats + pi), rs = ld4(st.bstats + GC + pi), sc = ld4(st.bstats + 2 * GC + pi), sh = ld4(st.bstats + 3 * GC + pi);
+        const float yy[4] = {v.x, v.y, v.z, v.w};
+        const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, r4[4] = {rs.x, rs.y, rs.z, rs.w}, s4[4] = {sc.x, sc.y, sc.z, sc.w}, h4[4] = {sh.x, sh.y, sh.z, sh.w};
+        float ov[4];
+        if constexpr (STATS == 4) {
+          float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (st.aux) rv = ld4(st.aux + (o - C.p));
+          const float rr[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = (yy[r] - m4[r]) * s4[r] + h4[r];
+            ov[r] = act_fwd(z, st.act);
+            if (st.aux) ov[r] += rr[r];
+            const float t = fabsf(ov[r]);
+            amax_o = (t > amax_o || t != t) ? t : amax_o;
+          }
+          st4(o, make_float4(ov[0], ov[1], ov[2], ov[3]));
+        } else {
+          const float4 dv = ld4(st.aux + (o - C.p));
+          const float dd[4] = {dv.x, dv.y, dv.z, dv.w};
+          float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f), k2 = k1;
+          if constexpr (STATS == 6) { k1 = ld4(st.c1c2 + pi); k2 = ld4(st.c1c2 + GC + pi); }
+          const float a1[4] = {k1.x, k1.y, k1.z, k1.w}, a2[4] = {k2.x, k2.y, k2.z, k2.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float z = (yy[r] - m4[r]) * s4[r] + h4[r];
+            const float dz = dd[r] * act_grad(z, st.act);
+            const float xh = (yy[r] - m4[r]) * r4[r];
+            if constexpr (STATS == 5) { p1[nt][r] += dz; p2[nt][r] = fmaf(dz, xh, p2[nt][r]); }
+            else ov[r] = s4[r] * (dz - a1[r] - xh * a2[r]);
+          }
+          if constexpr (STATS == 6) st4(o, make_float4(ov[0], ov[1], ov[2], ov[3]));
+        }
+      }
       if constexpr (STATS == 1) {
         p1[nt][0] += v.x; p2[nt][0] = fmaf(v.x, v.x, p2[nt][0]);
         p1[nt][1] += v.y; p2[nt][1] = fmaf(v.y, v.y, p2[nt][1]);
@@ -224,6 +277,10 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
       if (rb > rb0) __syncthreads();               // every wave is done with the previous block's LDS stages
       tile(rb * 64);
     }
+    if constexpr (STATS == 4) {
+      if (st.amax) { __syncthreads(); block_amax_publish(amax_o, st.amax); }
+    }
+    if constexpr (ACCUM) {
     // columns -> channels: n-tile nt holds channels (n0 + nt*16) % C ..; with C < CT the n-tiles of a workgroup repeat the channel set
     const int ntc = st.C < CT ? st.C >> 4 : NT;      // distinct 16-channel tiles of this workgroup (uniform)
     // (static indices only: ntc is 1, 2 or NT)
@@ -262,6 +319,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
       double* dst = st.partial + (((long long)g * st.nb + row) * st.C + c0 + c) * 2;
       dst[0] = a;
       dst[1] = b;
+    }
     }
   }
 }
@@ -798,7 +856,7 @@ static int launch_nn(RowMap A, const float* Bp, const float* bias, RowMap C, int
   const int rb = cdiv(M, 64);
   const int nt = pick_nt(N, rb);
   const dim3 grid(rb, N / (nt * 16));
-  const GemmStats none{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, 0, 0};
+  const GemmStats none{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
   if (nt == 4) hipLaunchKernelGGL((k_gemm_nn<4>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
   else if (nt == 2) hipLaunchKernelGGL((k_gemm_nn<2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
   else hipLaunchKernelGGL((k_gemm_nn<1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
@@ -826,22 +884,24 @@ static bool stat_plan(StatPlan& p, int M, int N, int Cout, int groups) {
   return true;
 }
 
-static int launch_nn_stats(RowMap A, const float* Bp, const float* bias, RowMap C, int M, int K, int N, int Cch, int bias_mod, int accumulate,
-                           double* partial, int groups, const float* by, const float* bstats, int act, hipStream_t s) {
+template <int MODE>
+static int launch_nn_mode(RowMap A, const float* Bp, const float* bias, RowMap C, int M, int K, int N, int Cch, int bias_mod, int accumulate,
+                          double* partial, int groups, const float* by, const float* bstats, int act, const float* aux, const float* c1c2, float* amax,
+                          hipStream_t s) {
   StatPlan p;
   if (!stat_plan(p, M, N, Cch, groups)) return 0;
   const dim3 grid(p.wpg * groups, N / (p.nt * 16));
-  const GemmStats st{partial, p.nb, Cch, p.wpg, p.R, p.ysets, by, bstats, groups, act};
-  if (by) {
-    if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, 2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
-    else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, 2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
-    else hipLaunchKernelGGL((k_gemm_nn<1, 2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
-  } else {
-    if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, 1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
-    else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, 1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
-    else hipLaunchKernelGGL((k_gemm_nn<1, 1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
-  }
+  const GemmStats st{partial, p.nb, Cch, p.wpg, p.R, p.ysets, by, bstats, groups, act, aux, c1c2, amax};
+  if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, MODE>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+  else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, MODE>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+  else hipLaunchKernelGGL((k_gemm_nn<1, MODE>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
   return p.nb;
+}
+
+static int launch_nn_stats(RowMap A, const float* Bp, const float* bias, RowMap C, int M, int K, int N, int Cch, int bias_mod, int accumulate,
+                           double* partial, int groups, const float* by, const float* bstats, int act, hipStream_t s) {
+  if (by) return launch_nn_mode<2>(A, Bp, bias, C, M, K, N, Cch, bias_mod, accumulate, partial, groups, by, bstats, act, nullptr, nullptr, nullptr, s);
+  return launch_nn_mode<1>(A, Bp, bias, C, M, K, N, Cch, bias_mod, accumulate, partial, groups, nullptr, nullptr, 0, nullptr, nullptr, nullptr, s);
 }
 
 static int tn_groups(int M, int K, int N, int nt) {
@@ -1041,6 +1101,75 @@ extern "C" int bcp_up_dgrad_bwdstats(const float* dy, const float* bp, float* dx
                                  Cin, Cin, 1, accumulate, stat_partial, groups, y_prev, stats_prev, act, (hipStream_t)stream);
   BCP_REQUIRE(nb > 0, "bcp_up_dgrad_bwdstats: fused statistics unavailable for this shape (check bcp_k2_bwdstat_rows first)");
   BCP_CHECK_LAUNCH("bcp_up_dgrad_bwdstats");
+  return BCP_OK;
+}
+
+// Round 6: the transposed conv + its norm layer with the conv output RECOMPUTED instead of stored (networks/VNet.py:101-113 UpsamplingDeconvBlock:
+// ConvTranspose3d -> BatchNorm3d / InstanceNorm3d -> ReLU, then the decoder's skip add :268-283).  The layer is HBM-bound (32 MACs per output
+// from a tensor an eighth its size), so y = up(x) never exists in HBM: forward = statistics pass (GEMM, nothing stored) -> finalize -> apply pass
+// (GEMM again: a = act(norm(y)) + residual); backward = statistics pass (GEMM + da) -> finalize -> apply pass (dy).  At the top V-Net level
+// that is 224 MB less per forward and 192 MB less per backward pass (y written once and read two / two times before).  Same arithmetic per
+// element as bcp_up_fwd + bcp_norm_fwd / bcp_norm_bwd (k_norm_apply / k_col_partial<1> / k_norm_bwd_apply); the statistics are summed as in
+// bcp_up_fwd_stats (fp32 lane partials, fp64 behind them).  rows = bcp_up_norm_rows(...): 0 = shape not served (or option up_recompute off).
+namespace bcp {      // csrc/norm.hip
+void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s, float* amax_clear_or_null);
+void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
+                              float* c1c2raw, hipStream_t s, float* amax_clear_or_null);
+}
+
+extern "C" int bcp_up_norm_rows(int N, int D, int H, int W, int Cin, int Cout, int groups) {
+  if (N < 1 || D < 2 || H < 2 || W < 2 || (D | H | W) & 1 || Cin % 16 || Cout % 16 || Cin < 16 || Cout < 16 || groups < 1 || N % groups) return 0;
+  if (options().up_recompute == 0) return 0;
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  if (options().up_recompute == 2 && 8LL * M * Cout < (1LL << 24)) return 0;      // (2: the top level only)
+  StatPlan p;
+  return stat_plan(p, M, 8 * Cout, Cout, groups) ? p.nb : 0;
+}
+
+extern "C" size_t bcp_up_norm_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int groups) {
+  const int rows = bcp_up_norm_rows(N, D, H, W, Cin, Cout, groups);
+  return rows > 0 ? (size_t)groups * rows * Cout * 2 * sizeof(double) + (size_t)4 * groups * Cout * sizeof(float) : 0;
+}
+
+extern "C" int bcp_up_fwd_norm(const float* x, const float* bp, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int groups,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int act,
+                               const float* residual, float* stats, void* workspace, float* out, float* amax_out_or_null, void* stream) {
+  BCP_REQUIRE(x && bp && stats && workspace && out && groups >= 1, "bcp_up_fwd_norm: null pointer / bad groups");
+  BCP_REQUIRE(aligned16(out) && aligned16(stats) && (!residual || aligned16(residual)), "bcp_up_fwd_norm: alignment");
+  const int rows0 = bcp_up_norm_rows(N, D, H, W, Cin, Cout, groups);
+  BCP_REQUIRE(rows0 > 0, "bcp_up_fwd_norm: shape not served (check bcp_up_norm_rows first)");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  double* partial = reinterpret_cast<double*>(workspace);
+  const RowMap A = make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), Cm = make_map(out, MAP_PATCH, 8 * Cout, Cout, D, H, W);
+  const int rows = launch_nn_mode<3>(A, bp, bias, Cm, M, Cin, 8 * Cout, Cout, Cout, 0, partial, groups, nullptr, nullptr, 0, nullptr, nullptr, nullptr, s);
+  BCP_REQUIRE(rows == rows0, "bcp_up_fwd_norm: internal row count mismatch");
+  norm_fwd_finalize_launch(partial, rows, groups, Cout, (long long)N / groups * D * H * W, gamma, beta, running_mean, running_var, momentum, eps, stats, s,
+                           amax_out_or_null);
+  launch_nn_mode<4>(A, bp, bias, Cm, M, Cin, 8 * Cout, Cout, Cout, 0, nullptr, groups, nullptr, stats, act, residual, nullptr, amax_out_or_null, s);
+  BCP_CHECK_LAUNCH("bcp_up_fwd_norm");
+  return BCP_OK;
+}
+
+extern "C" int bcp_up_norm_bwd(const float* x, const float* bp, const float* bias, const float* da, int N, int D, int H, int W, int Cin, int Cout,
+                               int groups, const float* stats, int act, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy,
+                               void* stream) {
+  BCP_REQUIRE(x && bp && da && stats && workspace && dy && groups >= 1, "bcp_up_norm_bwd: null pointer / bad groups");
+  BCP_REQUIRE(aligned16(da) && aligned16(dy), "bcp_up_norm_bwd: alignment");
+  BCP_REQUIRE((dgamma == nullptr) == (dbeta == nullptr), "bcp_up_norm_bwd: dgamma and dbeta come together");
+  const int rows0 = bcp_up_norm_rows(N, D, H, W, Cin, Cout, groups);
+  BCP_REQUIRE(rows0 > 0, "bcp_up_norm_bwd: shape not served (check bcp_up_norm_rows first)");
+  hipStream_t s = (hipStream_t)stream;
+  const int M = N * (D / 2) * (H / 2) * (W / 2);
+  double* partial = reinterpret_cast<double*>(workspace);
+  float* c1c2raw = reinterpret_cast<float*>(partial + (size_t)groups * rows0 * Cout * 2);
+  const RowMap A = make_map(x, MAP_PLAIN, Cin, 0, 0, 0, 0), Cm = make_map(dy, MAP_PATCH, 8 * Cout, Cout, D, H, W);
+  const int rows = launch_nn_mode<5>(A, bp, bias, Cm, M, Cin, 8 * Cout, Cout, Cout, 0, partial, groups, nullptr, stats, act, da, nullptr, nullptr, s);
+  BCP_REQUIRE(rows == rows0, "bcp_up_norm_bwd: internal row count mismatch");
+  norm_bwd_finalize_launch(partial, rows, groups, Cout, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s, nullptr);
+  launch_nn_mode<6>(A, bp, bias, Cm, M, Cin, 8 * Cout, Cout, Cout, 0, nullptr, groups, nullptr, stats, act, da, c1c2raw, nullptr, s);
+  BCP_CHECK_LAUNCH("bcp_up_norm_bwd");
   return BCP_OK;
 }
 

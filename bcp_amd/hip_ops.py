@@ -739,6 +739,35 @@ class Ops:
                     int(bool(accumulate)), _p(y_prev), _p(stats_prev), int(act), _p(part), int(groups), self.stream(dy))
         return self._no_amax(out), part, rows
 
+    # ---- round 6: transposed conv + norm + activation (+ skip add) with the conv output recomputed instead of stored
+    def up_norm_rows(self, xshape, Cout, groups):
+        """> 0: bcp_up_fwd_norm / bcp_up_norm_bwd serve a transposed conv of this (coarse) input shape (option up_recompute)"""
+        N, D, H, W, Cin = xshape
+        return self._ws_bytes("bcp_up_norm_rows", N, 2 * D, 2 * H, 2 * W, Cin, int(Cout), int(groups))
+
+    def up_fwd_norm(self, x, bp, bias, Cout, G, gamma, beta, rmean, rvar, act, residual=None, momentum=0.1, eps=1e-5):
+        """-> (a, stats): a = act(norm(up(x))) + residual; y = up(x) is never materialised (both passes of the norm recompute it)"""
+        self._chk(x, bp, bias, gamma, beta, rmean, rvar, residual)
+        N, D, H, W, Cin = x.shape
+        fine = (2 * D, 2 * H, 2 * W)
+        ws = self.workspace("upnorm", self._ws_bytes("bcp_up_norm_workspace_bytes", N, fine[0], fine[1], fine[2], Cin, int(Cout), int(G)), x)
+        stats = torch.empty((5, G, Cout), dtype=torch.float32, device=x.device)
+        out = torch.empty((N,) + fine + (Cout,), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_up_fwd_norm", _p(x), _p(bp), _p(bias), N, fine[0], fine[1], fine[2], Cin, int(Cout), int(G), _p(gamma), _p(beta), _p(rmean),
+                    _p(rvar), float(momentum), float(eps), int(act), _p(residual), _p(stats), _p(ws), _p(out), _p(self._amax_slot(out)), self.stream(x))
+        return out, stats
+
+    def up_norm_bwd(self, x, bp, bias, Cout, G, stats, da, act, dgamma=None, dbeta=None, accumulate=False):
+        """backward of up_fwd_norm's norm: y recomputed from x -> dy (the input of the transposed conv's dgrad and weight gradient)"""
+        self._chk(x, bp, bias, stats, da, dgamma, dbeta)
+        N, D, H, W, Cin = x.shape
+        fine = (2 * D, 2 * H, 2 * W)
+        ws = self.workspace("upnorm", self._ws_bytes("bcp_up_norm_workspace_bytes", N, fine[0], fine[1], fine[2], Cin, int(Cout), int(G)), x)
+        dy = torch.empty((N,) + fine + (Cout,), dtype=torch.float32, device=x.device)
+        self.b.call("bcp_up_norm_bwd", _p(x), _p(bp), _p(bias), _p(da), N, fine[0], fine[1], fine[2], Cin, int(Cout), int(G), _p(stats), int(act),
+                    _p(dgamma), _p(dbeta), int(bool(accumulate)), _p(ws), _p(dy), self.stream(x))
+        return self._no_amax(dy)
+
     def down_dgrad(self, dy, bp, Cin, out=None, accumulate=False):
         self._chk(dy, bp, out)
         N, Dc, Hc, Wc, Cout = dy.shape
@@ -1002,7 +1031,7 @@ class Ops:
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
 _PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "mixloss_pair_fwd", "mixloss_pair_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
-             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd", "k2_fwd_stats", "k2_dgrad_bwdstats",
+             "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd", "k2_fwd_stats", "k2_dgrad_bwdstats", "up_fwd_norm", "up_norm_bwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")
 

@@ -201,6 +201,7 @@ class VNet(HipNet):
             small = False
             src, nsl, bsrc = None, 1, None
             fused_c1 = False
+            fused_up = False
             if L.kind == "c1":
                 fused_c1 = (self.fuse_c1 and self.training and not small and not L.skip_pop and L.drop is None and not getattr(self, "_keep_saved", False)
                             and not (li == last and fuse_head) and ops.conv3_c1_norm_ok(h.shape, 3, G))
@@ -219,6 +220,11 @@ class VNet(HipNet):
                     y, part, nb = ops.conv3_fwd_stats(h, wf, b.data, L.cout, 3, G)
                 else:
                     y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)          # eval-mode BatchNorm needs no batch statistics
+            elif (L.kind == "up" and self.training and L.drop is None and not (li == last and fuse_head) and not getattr(self, "_keep_saved", False)
+                  and ops.up_norm_rows(h.shape, L.cout, G) > 0):
+                # (round 6) transposed conv + norm + ReLU + skip add with recompute (bcp_up_fwd_norm): the pre-norm tensor is never written
+                bp, _ = self.k2_packed(("k2", li), save)
+                fused_up, y = True, None
             else:
                 kind = 0 if L.kind == "dw" else 1
                 bp, _ = self.k2_packed(("k2", li), save)
@@ -231,7 +237,11 @@ class VNet(HipNet):
                     y = ops.up_fwd(h, bp, b.data, L.cout)
             res = skips.pop() if L.skip_pop else None
             cs = self._chan_scale(L, N, xcl.device)
-            if fused_c1:
+            if fused_up:
+                bn = L.bn
+                a, stats = ops.up_fwd_norm(h, bp, b.data, L.cout, G, *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var)
+                                                                      if bn is not None else (None,) * 4), H.ACT_RELU, residual=res)
+            elif fused_c1:
                 bn = L.bn
                 a, stats = ops.conv3_c1_norm_fwd(h, w.data, b.data, 3, G, *((bn.weight.data, bn.bias.data, bn.running_mean, bn.running_var)
                                                                               if bn is not None else (None,) * 4), H.ACT_RELU)
@@ -311,6 +321,10 @@ class VNet(HipNet):
             dg, db = (L.bn.weight.grad, L.bn.bias.grad) if L.bn is not None else (None, None)
             if dy_head is not None:
                 dy, dy_head = dy_head, None
+            elif y is None and L.kind == "up":     # (round 6) the recomputing transposed conv: y = up(x_in) again, inside both passes of the norm's backward
+                assert nsl == 1 and cs is None
+                bpf, _ = self.k2_packed(("k2", li), True)      # (the FORWARD pack: y is recomputed)
+                dy = ops.up_norm_bwd(x_in, bpf, L.conv.bias.data, L.cout, G, stats, da, H.ACT_RELU, dg, db, L.bn is not None)
             elif y is None:     # the fused first layer: its pre-norm tensor is recomputed from the input (bcp_conv3_c1_norm_bwd)
                 assert L.kind == "c1" and nsl == 1
                 if ops.C1_BWD_FUSED:      # ... and the layer's weight gradient in the same pass: no dy, no launch left behind the main stream's last one
@@ -351,7 +365,7 @@ class VNet(HipNet):
                       and ops.norm_slabs_ok(G, x_in.numel() // (L.cin * G), L.cin) else 0)
                 if sk > 1:
                     dh, nsl = ops.conv3_fwd_raw(dy, wd, L.cin, 3, sk), sk
-                elif li > 0 and saved[li - 1][3] is None:
+                elif li > 0 and saved[li - 1][3] is None and saved[li - 1][1] is not None:      # (a recomputing layer in front keeps no pre-norm tensor)
                     # conv -> conv edge without a dropout epilogue: the dgrad epilogue leaves the previous norm layer's backward statistics
                     # (bcp_conv3_dgrad_bwdstats; a plain dgrad when the shape is not served)
                     dh, bpart, bnb = ops.conv3_dgrad_bwdstats(dy, wd, L.cin, 3, saved[li - 1][1], saved[li - 1][2], H.ACT_RELU, G)

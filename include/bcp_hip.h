@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 508
+#define BCP_ABI_VERSION 509
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -290,6 +290,17 @@ int bcp_up_fwd_stats(const float* x, const float* bp, const float* bias, float* 
 int bcp_k2_bwdstat_rows(int kind, int N, int D, int H, int W, int Cin, int Cout, int groups);
 int bcp_down_dgrad_bwdstats(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, const float* y_prev, const float* stats_prev, int act, double* stat_partial, int groups, void* stream);
 int bcp_up_dgrad_bwdstats(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, const float* y_prev, const float* stats_prev, int act, double* stat_partial, int groups, void* stream);
+/* Round 6: ConvTranspose3d(k=2,s=2) -> BatchNorm3d / InstanceNorm3d -> ReLU (+ the decoder's skip add) with the conv output RECOMPUTED instead
+   of stored (networks/VNet.py:101-113 UpsamplingDeconvBlock and :268-283): the layer is HBM-bound, y = up(x) is an eighth-size tensor times a
+   32 x 128 matrix, so both passes of the norm recompute it -- forward: statistics pass (nothing stored) -> finalize -> apply pass writing
+   out = act((y - mean) * scale + shift) + residual; backward: statistics pass over (recomputed y, da) -> finalize -> apply pass writing dy.
+   Per element the arithmetic of bcp_up_fwd + bcp_norm_fwd / bcp_norm_bwd; statistics summed as bcp_up_fwd_stats does.  stats: float[5][G][C]
+   as bcp_norm_fwd leaves it (mean, rstd, scale, shift, unbiased variance); running statistics updated group after group as there.
+   rows = bcp_up_norm_rows(...) > 0: shape served; workspace = bcp_up_norm_workspace_bytes(...).  (D, H, W): the FINE extents. */
+int bcp_up_norm_rows(int N, int D, int H, int W, int Cin, int Cout, int groups);
+size_t bcp_up_norm_workspace_bytes(int N, int D, int H, int W, int Cin, int Cout, int groups);
+int bcp_up_fwd_norm(const float* x, const float* bp, const float* bias, int N, int D, int H, int W, int Cin, int Cout, int groups, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, int act, const float* residual_or_null, float* stats, void* workspace, float* out, float* amax_out_or_null, void* stream);
+int bcp_up_norm_bwd(const float* x, const float* bp, const float* bias, const float* da, int N, int D, int H, int W, int Cin, int Cout, int groups, const float* stats, int act, float* dgamma, float* dbeta, int accumulate, void* workspace, float* dy, void* stream);
 int bcp_up_dgrad(const float* dy, const float* bp, float* dx, int N, int D, int H, int W, int Cin, int Cout, int accumulate, void* stream);
 int bcp_pw_fwd(const float* x, const float* bp, const float* bias_or_null, float* y, long long rows, int Cin, int Cout, void* stream);
 size_t bcp_tn_workspace_bytes(long long M, int K, int N);

@@ -862,6 +862,78 @@ def check_k2_bwdstats(ops, dev):
         ops.set_option("k2_bwd_stats")
 
 
+def check_up_norm(ops, dev):
+    """round 6: ConvTranspose3d(k=2,s=2) -> norm -> ReLU (+ skip add) with the conv output recomputed instead of stored (bcp_up_fwd_norm /
+    bcp_up_norm_bwd; reference networks/VNet.py:101-113 + the decoder's skip add) against the chain it replaces -- bcp_up_fwd_stats +
+    bcp_norm_fwd (statistics from the same GEMM epilogue: the activations must agree to the last bits of the apply arithmetic) and
+    bcp_norm_bwd (its own fp64 statistics pass: dy / dgamma / dbeta to 1e-5) -- and against torch on the CPU.  BatchNorm (G = 1, 2, affine,
+    running statistics) and InstanceNorm (G = N, no affine); with and without the residual; channel folds 16 / 32 / 64 / 128"""
+    rng = np.random.default_rng(13)
+    ops.set_option("up_recompute", 1)
+    ops.set_option("k2_stats", 1)
+    try:
+        cases = [(2, 32, 16, (4, 8, 8), 2, True, True), (2, 64, 32, (4, 4, 8), 1, True, False), (2, 128, 64, (2, 4, 8), 2, False, True),
+                 (1, 256, 128, (4, 4, 4), 1, True, True), (2, 32, 16, (8, 8, 8), 2, False, False)]
+        if dev.type == "cuda":
+            cases += [(2, 32, 16, (16, 32, 32), 2, True, True)]
+        for N, Cin, Cout, sp, G, affine, use_res in cases:
+            tag = f"up_norm {N}x{sp} {Cin}->{Cout} G={G} affine={affine} res={use_res}"
+            xt = R(rng, N, Cin, *sp)
+            wt = R(rng, Cin, Cout, 2, 2, 2) * 0.1
+            bt = R(rng, Cout) * 0.1
+            fine = tuple(2 * e for e in sp)
+            rest = R(rng, N, Cout, *fine) if use_res else None
+            dat = R(rng, N, Cout, *fine)
+            gam = torch.from_numpy(rng.uniform(0.5, 1.5, Cout).astype(np.float32)) if affine else None
+            bet = torch.from_numpy(rng.uniform(-0.3, 0.3, Cout).astype(np.float32)) if affine else None
+            x, res, da = to_cl(xt).to(dev), (to_cl(rest).to(dev) if use_res else None), to_cl(dat).to(dev)
+            w, b = wt.to(dev), bt.to(dev)
+            bp = ops.k2_pack(w, Cin, Cout, H.PACK_UP_FWD)
+            g_, b_ = (gam.to(dev), bet.to(dev)) if affine else (None, None)
+            assert ops.up_norm_rows(x.shape, Cout, G) > 0, tag
+            # the chain it replaces
+            rm0, rv0 = (torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)) if affine else (None, None)
+            y, part, nb = ops.k2_fwd_stats(1, x, bp, b, Cout, G)
+            a0, st0 = ops.norm_fwd(y, G, g_, b_, rm0, rv0, H.ACT_RELU, residual=res, partial=part, nb=nb)
+            a0, st0, y = a0.clone(), st0.clone(), y.clone()
+            dg0 = torch.zeros(Cout, device=dev) if affine else None
+            db0 = torch.zeros(Cout, device=dev) if affine else None
+            dy0 = ops.norm_bwd(y, da, G, st0, H.ACT_RELU, dg0, db0, affine).clone()
+            # the recomputing pair
+            rm1, rv1 = (torch.zeros(Cout, device=dev), torch.ones(Cout, device=dev)) if affine else (None, None)
+            a1, st1 = ops.up_fwd_norm(x, bp, b, Cout, G, g_, b_, rm1, rv1, H.ACT_RELU, residual=res)
+            assert torch.equal(st1, st0), tag + ": statistics differ from bcp_up_fwd_stats + finalize"
+            close(a1.cpu(), a0.cpu(), rtol=1e-6, atol_scale=1e-7, msg=tag + " activations")
+            if affine:
+                assert torch.equal(rm1, rm0) and torch.equal(rv1, rv0), tag + ": running statistics"
+            assert getattr(a1, "_bcp_amax", None) is not None or not type(ops).AMAX, tag + ": no |max| slots on the activation"
+            if type(ops).AMAX:
+                want = float(a1.abs().max())
+                have = float(H.amax_value(a1._bcp_amax))
+                assert abs(have - want) <= 1e-6 * max(want, 1e-30), (tag, have, want)
+            dg1 = torch.zeros(Cout, device=dev) if affine else None
+            db1 = torch.zeros(Cout, device=dev) if affine else None
+            dy1 = ops.up_norm_bwd(x, bp, b, Cout, G, st1, da, H.ACT_RELU, dg1, db1, affine)
+            close(dy1.cpu(), dy0.cpu(), rtol=1e-5, atol_scale=1e-6, msg=tag + " dy")
+            if affine:
+                close(dg1.cpu(), dg0.cpu(), rtol=1e-5, atol_scale=1e-6, msg=tag + " dgamma")
+                close(db1.cpu(), db0.cpu(), rtol=1e-5, atol_scale=1e-6, msg=tag + " dbeta")
+            # torch on the CPU: forward values
+            yt = F.conv_transpose3d(xt, wt, bt, stride=2)
+            if G == 1:
+                zt = F.batch_norm(yt, None, None, gam, bet, True, 0.1, 1e-5)
+            elif not affine:
+                zt = F.instance_norm(yt.reshape(G, (N // G) * Cout, *fine) if N != G else yt, eps=1e-5).reshape(yt.shape) if N == G else None
+            else:
+                zt = torch.cat([F.batch_norm(yt[g * (N // G):(g + 1) * (N // G)], None, None, gam, bet, True, 0.1, 1e-5) for g in range(G)])
+            if zt is not None:
+                at = F.relu(zt) + (rest if use_res else 0.0)
+                close(from_cl(a1), at, rtol=2e-4, msg=tag + " vs torch")
+    finally:
+        ops.set_option("up_recompute")
+        ops.set_option("k2_stats")
+
+
 def check_k2_chunks(ops, dev):
     """weight-gradient GEMMs with ONE row group, so every block walks several 64-row chunks (prefetch / row-table pipeline)"""
     ops.set_option("tn_groups", 1)
@@ -1720,7 +1792,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
+ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):

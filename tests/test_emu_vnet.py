@@ -106,6 +106,19 @@ def test_volatile_io_replays_equal_eager_path(emu_ops):
     NC.check_launch_plans(emu_ops, CPU, steps=3, cases=(("la", True),), volatile=True)
 
 
+@pytest.mark.extended
+def test_up_recompute_forced_everywhere(emu_ops):
+    """round 6 (built, measured, off by default): every transposed conv + norm the shape allows on the recomputing pair bcp_up_fwd_norm /
+    bcp_up_norm_bwd -- every gradient tensor within 1e-4 of the fp64 oracle linearised on the HIP activation pattern"""
+    from bcp_amd.utils import BCP_utils as BU
+    BU.set_test_ops(emu_ops)
+    emu_ops.set_option("up_recompute", 1)
+    try:
+        NC.check_vnet_pattern_grads(emu_ops, CPU, "la", (32, 32, 16))
+    finally:
+        emu_ops.set_option("up_recompute")
+
+
 def test_partial_weight_packs(emu_ops):
     """round 6: only the observed sections of the weight packs are written in front of replays; an eager pass behind one repacks everything"""
     from bcp_amd.utils import BCP_utils as BU

@@ -201,6 +201,19 @@ def test_fp16_backward_planes_hold_over_a_long_run(ops):
             print("fp16-bwd long run step %4d: loss %.5f  worst tensor %.2e  median %.2e" % (it, loss, w, med))
 
 
+def test_up_recompute_forced_everywhere(ops):
+    """round 6 (built, measured, off by default: DESIGN.md section 5): every transposed conv + norm the shape allows on the recomputing pair
+    bcp_up_fwd_norm / bcp_up_norm_bwd -- gradients within 1e-4 of the fp64 oracle on the HIP activation pattern (BatchNorm and InstanceNorm
+    V-Nets), and replays == the eager path with it on"""
+    ops.set_option("up_recompute", 1)
+    try:
+        NC.check_vnet_pattern_grads(ops, DEV, "la", (32, 32, 16))
+        NC.check_vnet_pattern_grads(ops, DEV, "pancreas", (32, 32, 32))
+        NC.check_launch_plans(ops, DEV, steps=3, cases=(("la", True), ("pancreas", True)))
+    finally:
+        ops.set_option("up_recompute")
+
+
 def test_partial_weight_packs(ops):
     """round 6: only the observed sections of the weight packs are written in front of replays; an eager pass behind one repacks everything"""
     NC.check_partial_packs(ops, DEV)
