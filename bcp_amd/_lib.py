@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 509      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 510      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int

@@ -829,8 +829,14 @@ static constexpr int kMaxPackDescs = 512;
 __global__ __launch_bounds__(256) void k_wamax_many(const PackDesc* __restrict__ descs) {
   __shared__ float red[4];
   const PackDesc d = descs[blockIdx.y];
-  const float m = wamax_block(d.w, (long long)d.Cout * d.Cin * d.T, red);
   float* hdr = d.wp + pack_off_hdr(d.T, d.K16, d.N16);
+  // bit 11 of the descriptor's last word (round 6): "the previous descriptor packs the SAME weight tensor" (the dgrad twin behind its forward
+  // descriptor): its partial maxima are the twin's -- k_pack_conv3_many reads them there -- and the weights are not read a second time
+  if (d.dgrad & 0x800) {
+    if (blockIdx.x == 0 && threadIdx.x >= 17 && threadIdx.x < kPackHeaderFloats) hdr[threadIdx.x] = 0.f;
+    return;
+  }
+  const float m = wamax_block(d.w, (long long)d.Cout * d.Cin * d.T, red);
   if (threadIdx.x == 0) hdr[1 + blockIdx.x] = m;
   if (blockIdx.x == 0 && threadIdx.x >= 17 && threadIdx.x < kPackHeaderFloats) hdr[threadIdx.x] = 0.f;      // reserved words: defined contents
 }
@@ -862,6 +868,7 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
     // repacks every weight every step, and most layers only ever read ONE of the three sections (the two fp16 planes)
     int sec = (d.dgrad >> 8) & 7;
     sec = (sec ? sec : 7) & sections;
+    const bool twin = (d.dgrad & 0x800) != 0 && di > 0;      // (k_wamax_many: the weight's partial maxima sit in the previous descriptor's header)
     d.dgrad &= 1;
     const int nb = d.N16 >> 4, k0 = (u / nb) * 16, n0 = (u % nb) * 16, T = d.T;
     // source rows: fwd w[nn][kk..][t] (row = nn, inner = kk = cin); dgrad w[kk][nn..][t] (row = kk = cout, inner = nn = cin)
@@ -906,9 +913,11 @@ __global__ __launch_bounds__(256) void k_pack_conv3_many(const PackDesc* __restr
       }
       // two-plane fp16 section (round 4): same (chunk, pair, n, k) order with two pieces, pre-scaled by the layer's power of two
       float* hdr = d.wp + pack_off_hdr(T, d.K16, d.N16);
+      const float* hsrc = hdr;
+      if (twin) { const PackDesc t = descs[di - 1]; hsrc = t.wp + pack_off_hdr(t.T, t.K16, t.N16); }
       float amax = 0.f;
 #pragma unroll
-      for (int b = 0; b < 16; ++b) amax = fmaxf(amax, hdr[1 + b]);
+      for (int b = 0; b < 16; ++b) amax = fmaxf(amax, hsrc[1 + b]);
       const float sc = f16_scale(amax);
       if (u == 0 && threadIdx.x == 0) hdr[0] = amax;
       unsigned* wh = reinterpret_cast<unsigned*>(d.wp + pack_off_f16(T, d.K16, d.N16));

@@ -253,8 +253,9 @@ class HipNet(nn.Module):
             self._pack_items.append((key, w.data_ptr(), wf.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, K16, N16))
             d_f = struct.pack("<QQiiiiii", w.data_ptr(), wf.data_ptr(), Cout, Cin, KD * 9, K16, N16, 0)
             d_d = struct.pack("<QQiiiiii", w.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, N16, K16, 1)
+            d_t = struct.pack("<QQiiiiii", w.data_ptr(), wd.data_ptr(), Cout, Cin, KD * 9, N16, K16, 1 | 0x800)      # ... right behind its forward twin: |max| from there
             fwd_desc += d_f
-            all_desc += d_f + d_d
+            all_desc += d_f + d_t
             dg_desc += d_d
             off += n
         self._desc_fwd = torch.frombuffer(bytearray(fwd_desc), dtype=torch.uint8).to(dev)
@@ -559,7 +560,7 @@ class HipNet(nn.Module):
             for key, wptr, wfp, wdp, Cout, Cin, T, K16, N16 in self._pack_items:
                 sf, sd = self._pack_need.get((key, 0), 0), self._pack_need.get((key, 1), 0)      # 0: never observed -> every section
                 d_f = struct.pack("<QQiiiiii", wptr, wfp, Cout, Cin, T, K16, N16, 0 | (sf << 8))
-                d_d = struct.pack("<QQiiiiii", wptr, wdp, Cout, Cin, T, N16, K16, 1 | (sd << 8))
+                d_d = struct.pack("<QQiiiiii", wptr, wdp, Cout, Cin, T, N16, K16, 1 | (sd << 8) | 0x800)      # (0x800: |max| from the forward twin in front)
                 fwd += d_f
                 both += d_f + d_d
             dev = self._flat.device

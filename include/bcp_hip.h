@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 509
+#define BCP_ABI_VERSION 510
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -214,7 +214,8 @@ int bcp_conv3_dgrad_bwdstats(const float* dy, const float* wp_dgrad, float* da, 
 int bcp_conv3_fwd_nslabs(int N, int D, int H, int W, int Cin, int Cout, int KD);
 /* round 6: which section of the packed weight the LAST forward / dgrad launch issued by this thread read -- 1 = the fp32 pack, 2 = the three
    bf16 planes, 4 = the two fp16 planes (0: none yet).  bcp_conv3_pack_many writes, per descriptor, only the sections named in bits 8-10 of the
-   descriptor's last word (0 = all three; bit 0 stays the dgrad flag): a host that repacks every weight every step (the BCP loop: the
+   descriptor's last word (0 = all three; bit 0 stays the dgrad flag; bit 11: "the previous descriptor packs the same weight tensor" -- its
+   |max| partials are taken from there instead of reading the weights again): a host that repacks every weight every step (the BCP loop: the
    optimiser and the EMA change all of them) learns from this query which sections each layer's launches read and stops writing the others --
    300 of the 500 MB per LA step.  The host must hold every section a launch reads: bcp_amd/networks/_hipnet.py packs partially only in front
    of REPLAYS of recorded passes whose launches it has observed, and fully before anything else. */
