@@ -52,9 +52,12 @@ __global__ __launch_bounds__(256) void k_col_partial(const float* __restrict__ y
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      NormEpilogue ep, long long seg_rows, int spg /* segments per group */, int C,
-                                                     double* __restrict__ partial /* [G][spg * gridDim.x][C][2] */, SlabSrc sl) {
+                                                     double* __restrict__ partial /* [G][spg * gridDim.x][C][2] */, SlabSrc sl,
+                                                     float* __restrict__ amax_clear_out /* nullable: the |max| slots of the tensor the fused apply pass
+                                                                                           behind this launch writes (k_norm_apply_fin: no finalize launch clears them) */) {
   constexpr int U = 4;
   BCP_NORM_MASK_PROLOGUE(ep)
+  if (amax_clear_out && blockIdx.x == 0 && blockIdx.y == 0) amax_clear(amax_clear_out);
   const int C4 = C >> 2;
   const int col = threadIdx.x % C4;        // float4 column
   const int slot = threadIdx.x / C4;       // row slot within a pass
@@ -447,6 +450,307 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply(const float* __restrict_
   if (amax_out) block_amax_publish(amax, amax_out);
 }
 
+
+// ------------------------------------------------------------------ apply passes that finalise the statistics themselves (round 6)
+// A dependent launch costs ~4 us on the step's critical path whatever it does (measured: the LA step with every finalize launch left out is
+// 7.7 % faster), and the finalize kernel does ~nothing.  Where the statistics pass left FEW partial rows (nb <= kFinMaxRows: the deep
+// levels, tensors of a few MB) the apply pass reduces them itself: a workgroup owns a 32-channel chunk (blockIdx.z) of a row block of one
+// segment, sums the nb x 32 x 2 doubles of its chunk (<= 64 KB, L2-resident) in a fixed order -- every workgroup gets the same bits -- and
+// forms mean / rstd / scale / shift (forward) or c1 / c2 (backward) in the LDS.  The first workgroup of a group writes the statistics table
+// (the backward pass reads it), workgroup (0, 0, chunk) the running statistics / parameter gradients of its chunk, group after group in
+// order.  Same arithmetic per element as k_norm_finalize + k_norm_apply / k_norm_bwd_finalize + k_norm_bwd_apply; the partial rows are
+// summed in ascending order per slot (the finalize kernels sum them in 32 slots and a tree), so the statistics can differ in the last
+// bit of their fp64 sums.
+constexpr int kFinMaxRows = 128;       // partial rows per group the fused apply passes accept
+constexpr int kFinChunk = 32;          // channels per workgroup
+
+// sums over the nb partial rows of group g for the cw channels of chunk c0 (both statistics: one double2 per row and channel): -> fin[2 * cw]
+// (LDS), all threads return after the barrier behind it.  red: 512 doubles of LDS.  Thread = (channel j, row slot sl); its <= kFinMaxRows / S
+// rows are ALL requested before the first add (one round trip: with four loads per loop trip the prologue was eight dependent round
+// trips and cost what the launch it replaces had), and added in ascending order; the S slots are added in order by thread j.
+__device__ __forceinline__ void fin_reduce_chunk(const double* __restrict__ partial, int nb, int C, int g, int c0, int cw, double* red,
+                                                 double* fin) {
+  const int S = 256 / cw;                                     // 8 (cw = 32) or 16 row slots
+  const int j = threadIdx.x % cw, sl = threadIdx.x / cw;
+  const long long rs = (long long)C * 2;
+  const double* p = partial + ((long long)g * nb * C + c0 + j) * 2;
+  constexpr int R = kFinMaxRows / 8;                          // rows per thread at most
+  double2 v[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int b = sl + k * S;
+    v[k] = b < nb ? *reinterpret_cast<const double2*>(p + b * rs) : make_double2(0.0, 0.0);
+  }
+  double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < R; ++k) { a0 += v[k].x; a1 += v[k].y; }
+  __syncthreads();                                            // (a previous call's readers of red / fin are done)
+  red[threadIdx.x * 2] = a0;
+  red[threadIdx.x * 2 + 1] = a1;
+  __syncthreads();
+  if ((int)threadIdx.x < 2 * cw) {
+    const int c = threadIdx.x >> 1, st = threadIdx.x & 1;
+    double t = 0.0;
+    for (int k = 0; k < S; ++k) t += red[(k * cw + c) * 2 + st];
+    fin[threadIdx.x] = t;
+  }
+  __syncthreads();
+}
+
+struct FinFwd {
+  const double* partial; int nb;
+  const float *gamma, *beta; float *running_mean, *running_var; float momentum, eps;
+  float* stats;                // [5][G][C]
+};
+
+__global__ __launch_bounds__(256) void k_norm_apply_fin(const float* __restrict__ y, const float* __restrict__ residual, NormEpilogue ep,
+                                                        long long seg_rows, int spg, int G, int C, long long rows_per_group, FinFwd f,
+                                                        float* __restrict__ out, float* __restrict__ amax_out, long long ldo) {
+  constexpr int U = 4;
+  __shared__ double red[512];
+  __shared__ double fin[2 * kFinChunk];
+  __shared__ float pmu[kFinChunk], psc[kFinChunk], psh[kFinChunk];
+  BCP_NORM_MASK_PROLOGUE(ep)
+  const int cw = C < kFinChunk ? C : kFinChunk, c0 = blockIdx.z * cw;
+  const int seg = blockIdx.y, g = seg / spg;
+  float *mean = f.stats, *rstd = f.stats + (long long)G * C, *scale = f.stats + 2LL * G * C, *shift = f.stats + 3LL * G * C;
+  float* var_unb = f.stats + 4LL * G * C;
+  const double n = (double)rows_per_group;
+  // one group's statistics of this chunk: thread c < cw holds channel c0 + c
+  auto group_stats = [&](int gg, float& m_f, float& r_f, float& sc_f, float& sh_f, float& vu_f) {
+    fin_reduce_chunk(f.partial, f.nb, C, gg, c0, cw, red, fin);
+    if ((int)threadIdx.x < cw) {
+      const int c = c0 + threadIdx.x;
+      const double s1 = fin[threadIdx.x * 2], s2 = fin[threadIdx.x * 2 + 1];
+      const double m = s1 / n;
+      double var = s2 / n - m * m;
+      if (var < 0.0) var = 0.0;
+      const double r = 1.0 / sqrt(var + (double)f.eps);
+      const double ga = f.gamma ? (double)f.gamma[c] : 1.0, be = f.beta ? (double)f.beta[c] : 0.0;
+      m_f = (float)m; r_f = (float)r; sc_f = (float)(ga * r); sh_f = (float)be;
+      vu_f = (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+    }
+  };
+  // running statistics of this chunk, the groups in order: an EXTRA workgroup per chunk (blockIdx.x == gridDim.x - 1, launched only when there
+  // are running statistics) that does nothing else -- inside a working block the G - 1 extra reductions were the launch's tail
+  if (f.running_mean && blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.y != 0) return;
+    double rm = 0.0, rv = 0.0;
+    if ((int)threadIdx.x < cw) { rm = (double)f.running_mean[c0 + threadIdx.x]; rv = (double)f.running_var[c0 + threadIdx.x]; }
+    for (int gg = 0; gg < G; ++gg) {
+      float m_f = 0.f, r_f = 0.f, sc_f = 0.f, sh_f = 0.f, vu_f = 0.f;
+      group_stats(gg, m_f, r_f, sc_f, sh_f, vu_f);
+      if ((int)threadIdx.x < cw) {      // update_running's arithmetic: fp32 rounding after every group
+        rm = (double)(float)((1.0 - (double)f.momentum) * rm + (double)f.momentum * (double)m_f);
+        rv = (double)(float)((1.0 - (double)f.momentum) * rv + (double)f.momentum * (double)vu_f);
+      }
+    }
+    if ((int)threadIdx.x < cw) { f.running_mean[c0 + threadIdx.x] = (float)rm; f.running_var[c0 + threadIdx.x] = (float)rv; }
+    return;
+  }
+  const int nbx = f.running_mean ? (int)gridDim.x - 1 : (int)gridDim.x;      // working blocks along x
+  const int cw4 = cw >> 2, col = threadIdx.x % cw4, slot = threadIdx.x / cw4, slots = 256 / cw4;
+  const long long sbase = (long long)seg * seg_rows;
+  const long long stride = (long long)nbx * slots;
+  long long r = (long long)blockIdx.x * slots + slot;
+  // the first trip's loads go out BEFORE the statistics are reduced: their latency runs under the prologue (at the deep levels a thread has one trip)
+  float4 v0[U], q0[U];
+  uchar4 k0[U];
+  if (out) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long rr = r + u * stride;
+      v0[u] = q0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      k0[u] = make_uchar4(0, 0, 0, 0);
+      if (rr < seg_rows) {
+        const long long e = (sbase + rr) * C + c0 + col * 4;
+        v0[u] = ld4(y + e);
+        if (residual) q0[u] = ld4(residual + e);
+        if (has_mask) k0[u] = BCP_NORM_MASK4(ep, e);
+      }
+    }
+  }
+  {
+    float m_f = 0.f, r_f = 0.f, sc_f = 0.f, sh_f = 0.f, vu_f = 0.f;
+    group_stats(g, m_f, r_f, sc_f, sh_f, vu_f);
+    if ((int)threadIdx.x < cw) {
+      pmu[threadIdx.x] = m_f; psc[threadIdx.x] = sc_f; psh[threadIdx.x] = sh_f;
+      if (blockIdx.x == 0 && seg == g * spg) {      // the group's first workgroup leaves the table the backward pass reads
+        const int idx = g * C + c0 + threadIdx.x;
+        mean[idx] = m_f; rstd[idx] = r_f; scale[idx] = sc_f; shift[idx] = sh_f; var_unb[idx] = vu_f;
+      }
+    }
+    __syncthreads();
+  }
+  if (!out) return;                                            // statistics only
+  const float4 mu = *reinterpret_cast<const float4*>(pmu + col * 4), sc = *reinterpret_cast<const float4*>(psc + col * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(psh + col * 4);
+  float4 cs = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (ep.chan_scale) cs = ld4(ep.chan_scale + (sbase / ep.rows_per_sample) * C + c0 + col * 4);
+  float amax = 0.f;
+  auto one = [&](long long row, const float4& v, const float4& r4, const uchar4& m4) {
+    float o[4] = {act_fwd((v.x - mu.x) * sc.x + sh.x, ep.act), act_fwd((v.y - mu.y) * sc.y + sh.y, ep.act),
+                  act_fwd((v.z - mu.z) * sc.z + sh.z, ep.act), act_fwd((v.w - mu.w) * sc.w + sh.w, ep.act)};
+    if (ep.chan_scale) { o[0] *= cs.x; o[1] *= cs.y; o[2] *= cs.z; o[3] *= cs.w; }
+    if (has_mask) {
+      o[0] *= m4.x ? ep.elem_scale : 0.f; o[1] *= m4.y ? ep.elem_scale : 0.f;
+      o[2] *= m4.z ? ep.elem_scale : 0.f; o[3] *= m4.w ? ep.elem_scale : 0.f;
+    }
+    if (residual) { o[0] += r4.x; o[1] += r4.y; o[2] += r4.z; o[3] += r4.w; }
+    st4(out + row * ldo + c0 + col * 4, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float t = fabsf(o[k]); amax = (t > amax || t != t) ? t : amax; }
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (r + u * stride < seg_rows) one(sbase + r + u * stride, v0[u], q0[u], k0[u]);
+  r += U * stride;
+  for (; r + (U - 1) * stride < seg_rows; r += U * stride) {
+    float4 v[U], r4[U];
+    uchar4 m4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long e = (sbase + r + u * stride) * C + c0 + col * 4;
+      v[u] = ld4(y + e);
+      if (residual) r4[u] = ld4(residual + e);
+      if (has_mask) m4[u] = BCP_NORM_MASK4(ep, e);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one(sbase + r + u * stride, v[u], r4[u], m4[u]);
+  }
+  for (; r < seg_rows; r += stride) {
+    const long long e = (sbase + r) * C + c0 + col * 4;
+    float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uchar4 m4 = make_uchar4(0, 0, 0, 0);
+    const float4 v = ld4(y + e);
+    if (residual) r4 = ld4(residual + e);
+    if (has_mask) m4 = BCP_NORM_MASK4(ep, e);
+    one(sbase + r, v, r4, m4);
+  }
+  if (amax_out) block_amax_publish(amax, amax_out);
+}
+
+struct FinBwd {
+  const double* partial; int nb;
+  float *dgamma, *dbeta; int accumulate;
+};
+
+__global__ __launch_bounds__(256) void k_norm_bwd_apply_fin(const float* __restrict__ y, const float* __restrict__ da,
+                                                            const float* __restrict__ stats, NormEpilogue ep, long long seg_rows, int spg,
+                                                            int G, int C, long long rows_per_group, FinBwd f, float* __restrict__ dy,
+                                                            float* __restrict__ amax_out) {
+  constexpr int U = 4;
+  __shared__ double red[512];
+  __shared__ double fin[2 * kFinChunk];
+  __shared__ float pc1[kFinChunk], pc2[kFinChunk];
+  BCP_NORM_MASK_PROLOGUE(ep)
+  const int cw = C < kFinChunk ? C : kFinChunk, c0 = blockIdx.z * cw;
+  const int seg = blockIdx.y, g = seg / spg;
+  const float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
+  // parameter gradients of this chunk, the groups in order (k_norm_bwd_apply's block (0, 0)): an EXTRA workgroup per chunk, as in the forward kernel
+  if (f.dgamma && blockIdx.x == gridDim.x - 1) {
+    if (blockIdx.y != 0) return;
+    float gb = 0.f, gg = 0.f;
+    if ((int)threadIdx.x < cw && f.accumulate) { gb = f.dbeta[c0 + threadIdx.x]; gg = f.dgamma[c0 + threadIdx.x]; }
+    for (int q = 0; q < G; ++q) {
+      fin_reduce_chunk(f.partial, f.nb, C, q, c0, cw, red, fin);
+      if ((int)threadIdx.x < cw) { gb += (float)fin[threadIdx.x * 2]; gg += (float)fin[threadIdx.x * 2 + 1]; }
+    }
+    if ((int)threadIdx.x < cw) { f.dbeta[c0 + threadIdx.x] = gb; f.dgamma[c0 + threadIdx.x] = gg; }
+    return;
+  }
+  const int nbx = f.dgamma ? (int)gridDim.x - 1 : (int)gridDim.x;
+  const int cw4 = cw >> 2, col = threadIdx.x % cw4, slot = threadIdx.x / cw4, slots = 256 / cw4;
+  const long long sbase = (long long)seg * seg_rows;
+  const long long stride = (long long)nbx * slots;
+  long long r = (long long)blockIdx.x * slots + slot;
+  float4 v0[U], d0[U];
+  uchar4 k0[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {      // the first trip's loads in front of the prologue
+    const long long rr = r + u * stride;
+    v0[u] = d0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    k0[u] = make_uchar4(0, 0, 0, 0);
+    if (rr < seg_rows) {
+      const long long e = (sbase + rr) * C + c0 + col * 4;
+      v0[u] = ld4(y + e);
+      d0[u] = ld4(da + e);
+      if (has_mask) k0[u] = BCP_NORM_MASK4(ep, e);
+    }
+  }
+  const long long gc = (long long)g * C + c0 + col * 4;
+  const float4 sc = ld4(scale + gc), sh = ld4(shift + gc), mu = ld4(mean + gc), rs = ld4(rstd + gc);
+  float4 csl = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (ep.chan_scale) csl = ld4(ep.chan_scale + (sbase / ep.rows_per_sample) * C + c0 + col * 4);
+  fin_reduce_chunk(f.partial, f.nb, C, g, c0, cw, red, fin);
+  if ((int)threadIdx.x < cw) {
+    pc1[threadIdx.x] = (float)(fin[threadIdx.x * 2] / (double)rows_per_group);
+    pc2[threadIdx.x] = (float)(fin[threadIdx.x * 2 + 1] / (double)rows_per_group);
+  }
+  __syncthreads();
+  const float4 k1 = *reinterpret_cast<const float4*>(pc1 + col * 4), k2 = *reinterpret_cast<const float4*>(pc2 + col * 4);
+  const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+  const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rs.x, rs.y, rs.z, rs.w};
+  const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
+  float amax = 0.f;
+  auto one = [&](long long e, const float4& v, const float4& d4, const uchar4& m4) {
+    float cs[4] = {csl.x, csl.y, csl.z, csl.w};
+    if (has_mask) {
+      cs[0] *= m4.x ? ep.elem_scale : 0.f; cs[1] *= m4.y ? ep.elem_scale : 0.f;
+      cs[2] *= m4.z ? ep.elem_scale : 0.f; cs[3] *= m4.w ? ep.elem_scale : 0.f;
+    }
+    const float vv[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d4.x, d4.y, d4.z, d4.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z = (vv[k] - muv[k]) * scv[k] + shv[k];
+      const float dz = dd[k] * cs[k] * act_grad(z, ep.act);
+      const float xh = (vv[k] - muv[k]) * rsv[k];
+      o[k] = scv[k] * (dz - k1v[k] - xh * k2v[k]);
+    }
+    st4(dy + e, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const float t = fabsf(o[q]); amax = (t > amax || t != t) ? t : amax; }
+  };
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (r + u * stride < seg_rows) one((sbase + r + u * stride) * C + c0 + col * 4, v0[u], d0[u], k0[u]);
+  r += U * stride;
+  for (; r + (U - 1) * stride < seg_rows; r += U * stride) {
+    float4 v[U], d4[U];
+    uchar4 m4[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long e = (sbase + r + u * stride) * C + c0 + col * 4;
+      v[u] = ld4(y + e);
+      d4[u] = ld4(da + e);
+      if (has_mask) m4[u] = BCP_NORM_MASK4(ep, e);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) one((sbase + r + u * stride) * C + c0 + col * 4, v[u], d4[u], m4[u]);
+  }
+  for (; r < seg_rows; r += stride) {
+    const long long e = (sbase + r) * C + c0 + col * 4;
+    uchar4 m4 = make_uchar4(0, 0, 0, 0);
+    const float4 v = ld4(y + e), d4 = ld4(da + e);
+    if (has_mask) m4 = BCP_NORM_MASK4(ep, e);
+    one(e, v, d4, m4);
+  }
+  if (amax_out) block_amax_publish(amax, amax_out);
+}
+
+// the fused apply passes serve: option norm_fuse_fin on, few partial rows, 16 <= C <= 256 (C a power of two: whole chunks)
+static inline bool fin_fused_ok(int nb, int C) { return options().norm_fuse_fin != 0 && nb >= 1 && nb <= kFinMaxRows && C >= 16 && C <= 256; }
+static inline dim3 fin_grid(long long seg_rows, int nseg, int C, bool runner) {
+  const int cw = C < kFinChunk ? C : kFinChunk, slots = 256 / (cw / 4);
+  long long gx = (seg_rows + (long long)slots * 4 - 1) / ((long long)slots * 4);      // four rows per thread and trip
+  const long long cap = 1024 / ((long long)nseg * (C / cw)) < 1 ? 1 : 1024 / ((long long)nseg * (C / cw));
+  if (gx > cap) gx = cap;
+  return dim3((unsigned)(gx < 1 ? 1 : gx) + (runner ? 1u : 0u), (unsigned)nseg, (unsigned)(C / cw));
+}
+
+static inline bool skip_fin(long long rpg) { const int w = options().whatif; return (w & 1) || ((w & 2) && rpg <= 4096); }
+static inline bool skip_app(long long rpg) { return (options().whatif & 2) && rpg <= 4096; }
 static inline int norm_blocks(long long rows_per_group, int C) {
   // enough blocks to fill the chip, but at least ~64 rows per thread-slot to amortise the LDS reduce
   const int slots = 256 / (C / 4);
@@ -459,10 +763,12 @@ static inline int norm_blocks(long long rows_per_group, int C) {
 // statistics pass that also sums split-K slabs (k_col_partial<MODE, true>): it moves nslab + 1 times the tensor and serves the deep levels
 // only (<= 4096 rows per group), where norm_blocks' ~64 rows per thread-slot would leave 3-15 workgroups to do it (round 4, measured:
 // LA step 6.10 vs 6.02 ms with the slab-sum launch) -- one row per thread-slot and pass, at most ~256 workgroups per launch
-static inline int norm_blocks_slabs(long long rows_per_group, int C, int G) {
+static inline int norm_blocks_slabs(long long rows_per_group, int C, int G, bool sizing = false /* workspace size: whatever the options say later */) {
   const int slots = 256 / (C / 4);
   long long nb = (rows_per_group + slots - 1) / slots;
-  const long long cap = G >= 256 ? 1 : 256 / G;
+  long long cap = G >= 256 ? 1 : 256 / G;
+  // (round 6) the fused apply pass behind this launch re-reads the partial rows in EVERY workgroup (k_norm_apply_fin): fewer, longer blocks
+  if (!sizing && options().norm_fuse_fin != 0 && C <= 256 && cap > options().norm_fin_rows && options().norm_fin_rows > 0) cap = options().norm_fin_rows;
   if (nb > cap) nb = cap;
   const int plain = norm_blocks(rows_per_group, C);
   return (int)(nb < plain ? plain : nb);
@@ -493,7 +799,7 @@ static constexpr int kMaxSamplesPerGroup = 64;
 void norm_fwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, const float* gamma, const float* beta,
                               float* running_mean, float* running_var, float momentum, float eps, float* stats, hipStream_t s, float* amax_clear_or_null) {
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C, *var_unb = stats + 4LL * G * C;
-  hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta, running_mean,
+  if (!skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, rstd, scale, shift, var_unb, amax_clear_or_null);
   if (running_mean) hipLaunchKernelGGL(k_norm_running_only, dim3(1), dim3(256), 0, s, mean, var_unb, G, C, running_mean, running_var, momentum);
 }
@@ -512,7 +818,7 @@ __global__ __launch_bounds__(256) void k_norm_bwd_params(const float* __restrict
 void norm_bwd_finalize_launch(const double* partial, int nb, int G, int C, long long rows_per_group, float* dgamma, float* dbeta, int accumulate,
                               float* c1c2raw, hipStream_t s, float* amax_clear_or_null) {
   float *c1 = c1c2raw, *c2 = c1 + (long long)G * C, *raw = c2 + (long long)G * C;
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma, dbeta,
+  if (!skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma, dbeta,
                      accumulate, c1, c2, raw, amax_clear_or_null);
   if (dgamma) hipLaunchKernelGGL(k_norm_bwd_params, dim3(1), dim3(256), 0, s, raw, G, C, dgamma, dbeta, accumulate);
 }
@@ -525,7 +831,7 @@ extern "C" size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int 
   if (G < 1 || C < 16 || rows_per_group < 1) return 0;
   // per-block fp64 partials, then the two per-(g,c) backward means (c1, c2)
   // (the slab-summing statistics pass of the deep levels uses more, smaller blocks: size the partial rows for whichever is larger)
-  const int nbmax = rows_per_group <= 4096 ? norm_blocks_slabs(rows_per_group, C, G) : norm_blocks(rows_per_group, C);
+  const int nbmax = rows_per_group <= 4096 ? norm_blocks_slabs(rows_per_group, C, G, true) : norm_blocks(rows_per_group, C);
   return (size_t)G * (nbmax + kMaxSamplesPerGroup) * C * 2 * sizeof(double) + (size_t)4 * G * C * sizeof(float);
 }
 
@@ -557,16 +863,22 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   double* partial = reinterpret_cast<double*>(workspace);
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float* var_unb = stats + 4LL * G * C;
+  const bool fused = out && !partial_in && fin_fused_ok(nb, C);      // (round 6) the apply pass finalises the statistics itself: no finalize launch
   if (partial_in) {   // statistics partials were produced by the conv epilogue (bcp_conv3_fwd_stats)
-    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
+    if (!skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb, out ? amax_out : (float*)nullptr);
   } else {
     hipLaunchKernelGGL((k_col_partial<0>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial, SlabSrc{});
-    hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
+                       (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial, SlabSrc{},
+                       fused ? amax_out : (float*)nullptr);
+    if (!fused && !skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
                        running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb, out ? amax_out : (float*)nullptr);
   }
-  if (out)
+  if (fused)
+    hipLaunchKernelGGL(k_norm_apply_fin, fin_grid(sg.seg_rows, nseg, C, running_mean != nullptr), dim3(256), 0, s, y, residual, ep, sg.seg_rows, sg.spg, G, C, rows_per_group,
+                       FinFwd{partial, nb, gamma, beta, running_mean, running_var, momentum, eps, stats}, out, amax_out, out_ld);
+  else if (out && skip_app(rows_per_group)) {}
+  else if (out)
     hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, scale, shift, mean, residual,
                        ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out, (long long)(out_ld / 4));
   else if (running_mean)   // statistics only: the consumer applies the normalisation itself (bcp_pw16_fwd_norm); the apply pass also carries the running-statistics update
@@ -593,17 +905,21 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   float* c1 = reinterpret_cast<float*>(partial + (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2);
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
+  const bool fused = !partial_in && fin_fused_ok(nb, C);
   if (partial_in) {   // (sum dz, sum dz * xhat) partials handed in by the caller (no kernel of the library produces them any more)
     BCP_REQUIRE(!chan_scale && !elem_mask && !mask_seed && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
-    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
+    if (!skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw, amax_out);
   } else {
     hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
-                       C, partial, SlabSrc{});
-    hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
+                       C, partial, SlabSrc{}, fused ? amax_out : (float*)nullptr);
+    if (!fused && !skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw, amax_out);
   }
-  hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da, scale, shift, mean,
+  if (fused)
+    hipLaunchKernelGGL(k_norm_bwd_apply_fin, fin_grid(sg.seg_rows, nseg, C, dgamma != nullptr), dim3(256), 0, s, y, da, stats, ep, sg.seg_rows, sg.spg, G, C, rows_per_group,
+                       FinBwd{partial, nb, dgamma, dbeta, accumulate}, dy, amax_out);
+  else if (!skip_app(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da, scale, shift, mean,
                      rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate, amax_out);
   BCP_CHECK_LAUNCH("bcp_norm_bwd");
   return BCP_OK;
@@ -637,11 +953,17 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float* var_unb = stats + 4LL * G * C;
   const SlabSrc sl{slabs, nslab, slab_stride, bias, ysum};
+  const bool fused = out && fin_fused_ok(nb, C);
   hipLaunchKernelGGL((k_col_partial<0, true>), dim3(sg.nbps, nseg), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr,
-                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial, sl);
-  hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
+                     (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial, sl,
+                     fused ? amax_out : (float*)nullptr);
+  if (!fused && !skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, rstd, scale, shift, var_unb, out ? amax_out : (float*)nullptr);
-  if (out)
+  if (fused)
+    hipLaunchKernelGGL(k_norm_apply_fin, fin_grid(sg.seg_rows, nseg, C, running_mean != nullptr), dim3(256), 0, s, ysum, residual, ep, sg.seg_rows, sg.spg, G, C, rows_per_group,
+                       FinFwd{partial, nb, gamma, beta, running_mean, running_var, momentum, eps, stats}, out, amax_out, (long long)C);
+  else if (out && skip_app(rows_per_group)) {}
+  else if (out)
     hipLaunchKernelGGL(k_norm_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, ysum, scale, shift, mean, residual,
                        ep, sg.seg_rows, sg.spg, G, C, out, var_unb, running_mean, running_var, momentum, amax_out, (long long)(C / 4));
   else if (running_mean)
@@ -672,11 +994,15 @@ extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nsl
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
   const SlabSrc sl{da_slabs, nslab, slab_stride, nullptr, da_sum};
+  const bool fused = fin_fused_ok(nb, C);
   hipLaunchKernelGGL((k_col_partial<1, true>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, (const float*)nullptr, scale, shift, mean, rstd, ep,
-                     sg.seg_rows, sg.spg, C, partial, sl);
-  hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
+                     sg.seg_rows, sg.spg, C, partial, sl, fused ? amax_out : (float*)nullptr);
+  if (!fused && !skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
                      dbeta, accumulate, c1, c2, raw, amax_out);
-  hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da_sum, scale, shift, mean,
+  if (fused)
+    hipLaunchKernelGGL(k_norm_bwd_apply_fin, fin_grid(sg.seg_rows, nseg, C, dgamma != nullptr), dim3(256), 0, s, y, da_sum, stats, ep, sg.seg_rows, sg.spg, G, C, rows_per_group,
+                       FinBwd{partial, nb, dgamma, dbeta, accumulate}, dy, amax_out);
+  else if (!skip_app(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_apply, dim3(apply_grid(sg.seg_rows * (C / 4), nseg), nseg), dim3(256), 0, s, y, da_sum, scale, shift, mean,
                      rstd, c1, c2, ep, sg.seg_rows, sg.spg, G, C, dy, raw, dgamma, dbeta, accumulate, amax_out);
   BCP_CHECK_LAUNCH("bcp_norm_bwd_slabs");
   return BCP_OK;

@@ -468,8 +468,13 @@ def measure(args, dp, dev, cpu_budget_s=45.0, trim=False):
     # one-time host-side setup, whatever W is: the first pass of a network records its launch plan, the second is captured into a HIP graph
     # (bcp_amd/plan.py) -- the equivalent of a compile step, never part of the W warm-ups or the K timed steps
     SETUP_STEPS = 2
-    for _ in range(SETUP_STEPS):
+    for i in range(SETUP_STEPS):
         step()
+        if i == 0:      # (measurement only: what-if switches that leave buffers unwritten go on AFTER one real pass has filled them)
+            for kv in getattr(args, "opt_late", None) or []:
+                k, _, v = kv.partition("=")
+                from bcp_amd.hip_ops import Ops as _Ops
+                _Ops.product().set_option(k, v)
     for _ in range(args.warmup):
         step()
     dp.barrier()
@@ -674,6 +679,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=3, help="steps run with per-op HIP events after the timed region (0: no kernels table)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="library tuning switch (bcp_set_option) for A/B measurements; the product defaults need none")
+    ap.add_argument("--opt-late", action="append", default=[], metavar="NAME=VALUE",
+                    help="MEASUREMENT ONLY: a library switch set after the first set-up step (the `whatif` bits: launches left out, results wrong)")
     ap.add_argument("--no-roofline", action="store_true", help="same as --profile-steps 0 (A/B runs)")
     ap.add_argument("--share-gpu", action="store_true",
                     help="N > 1 ranks on ONE GPU (every rank uses cuda:0, gradient exchange over gloo: RCCL refuses two ranks per device): times "
