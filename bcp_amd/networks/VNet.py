@@ -31,6 +31,7 @@ class _Layer:
 
 
 class VNet(HipNet):
+    WGRAD_DEFER = 2      # (round 6) small layers' weight gradients cross to the side stream in batches of this many layers (1: every layer forks, rounds 2-5)
     fuse_c1 = True       # first layer: conv + norm + ReLU with recompute (bcp_conv3_c1_norm_fwd / _bwd); False: conv -> y -> norm passes
     fuse_head = True     # the 1x1x1 head applies the last conv's norm + ReLU + Dropout3d itself (bcp_pw16_fwd_norm); False: separate apply pass
 
@@ -311,6 +312,24 @@ class VNet(HipNet):
         else:
             dh = ops.pw16_bwd(h_last, dlogits, self._out.weight.data, self._out.weight.grad, self._out.bias.grad, accumulate=True)
         skip_grads = []
+        pend = []
+
+        def flush_wgrads():
+            if not pend:
+                return
+            with self._wgrad_stream(*[t for j in pend for t in (j[2], j[1])]):
+                for kind, x_in_, dy_, gw_, acc_, _ in pend:
+                    if kind == "c1":
+                        ops.conv3_c1_wgrad(x_in_, dy_, gw_, 3, accumulate=acc_)
+                    elif kind == "c3":
+                        ops.conv3_wgrad(x_in_, dy_, gw_, 3, accumulate=acc_)
+                    elif kind == "dw":
+                        ops.k2_wgrad(x_in_, dy_, gw_, H.WG_DOWN, accumulate=acc_)
+                    else:
+                        ops.k2_wgrad(x_in_, dy_, gw_, H.WG_UP, accumulate=acc_)
+            for j in pend:       # (data parallelism: the flat gradient buffer is final from this layer's first parameter on -- bucket hook)
+                self._grads_final_from(j[5], j[2])
+            pend.clear()
         nsl = 1                          # dh is a plain gradient tensor (1) or the raw split-K slabs of the dgrad that produced it (> 1)
         bpart, bnb = None, 0             # backward-statistics partials of THIS layer's norm, left by the dgrad that produced dh
         for li in range(len(self._layers) - 1, -1, -1):
@@ -330,6 +349,7 @@ class VNet(HipNet):
                 if ops.C1_BWD_FUSED:      # ... and the layer's weight gradient in the same pass: no dy, no launch left behind the main stream's last one
                     ops.conv3_c1_norm_bwd_wgrad(x_in, w.data, L.conv.bias.data, 3, G, stats, da, H.ACT_RELU, w.grad, dg, db, L.bn is not None,
                                                 dw_accumulate=True)
+                    flush_wgrads()
                     self._grads_final_from(w, da)
                     break
                 dy = ops.conv3_c1_norm_bwd(x_in, w.data, L.conv.bias.data, 3, G, stats, da, H.ACT_RELU, dg, db, L.bn is not None)
@@ -346,15 +366,12 @@ class VNet(HipNet):
             # gradient buffer was cleared by begin_backward(), nothing to add.
             # The weight gradient of a layer has no consumer inside the backward pass: it runs on a side stream underneath
             # the dgrad -> norm_bwd critical path (the deep levels' kernels are too small to fill 256 CUs on their own).
-            with self._wgrad_stream(dy, x_in):
-                if L.kind == "c1":
-                    ops.conv3_c1_wgrad(x_in, dy, gw, 3, accumulate=acc)
-                elif L.kind == "c3":
-                    ops.conv3_wgrad(x_in, dy, gw, 3, accumulate=acc)
-                elif L.kind == "dw":
-                    ops.k2_wgrad(x_in, dy, gw, H.WG_DOWN, accumulate=acc)
-                else:
-                    ops.k2_wgrad(x_in, dy, gw, H.WG_UP, accumulate=acc)
+            # (round 6) every fork onto the side stream is an event record between two kernels of the MAIN stream -- a 5-7 us gap in front of
+            # the dgrad that follows (kernel trace, gpurun_out/r06_s31) -- so the small layers' weight gradients go over in batches of
+            # WGRAD_DEFER layers behind ONE fork; the large layers (>= 2^22 elements of dy) fork at once, as before
+            pend.append((L.kind, x_in, dy, gw, acc, w))
+            if dy.numel() >= (1 << 22) or len(pend) >= self.WGRAD_DEFER:
+                flush_wgrads()
             if L.kind == "c1":
                 dh = None
             elif L.kind == "c3":
@@ -384,6 +401,6 @@ class VNet(HipNet):
                     dh = ops.down_dgrad(dy, bp, L.cin, out=sg, accumulate=True)
                 else:
                     dh = ops.up_dgrad(dy, bp, L.cin)
-            self._grads_final_from(w, dy)
+        flush_wgrads()
         self._join_wgrad_stream(dlogits)
         return None

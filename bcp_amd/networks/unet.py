@@ -171,12 +171,39 @@ class UNet_2d(HipNet):
             saved[tag] = (h, y1, st1, em, a1, y2, st2, G)
         return a2
 
+    # (round 6) weight gradients cross to the side stream in batches: every fork is an event record between two kernels of the main stream
+    # (networks/VNet.py WGRAD_DEFER); launches on >= 2^22 elements of dy fork at once
+    WGRAD_DEFER = 2
+
+    _wg_pend = None
+
+    def _wgrad_later(self, launch, dy, x_in):
+        if self._wg_pend is None:
+            self._wg_pend = []
+        self._wg_pend.append((launch, dy, x_in))
+        if dy.numel() >= (1 << 22) or len(self._wg_pend) >= self.WGRAD_DEFER:
+            self._wgrad_flush()
+
+    def _wgrad_flush(self):
+        pend = self._wg_pend
+        if not pend:
+            return
+        with self._wgrad_stream(*[t for j in pend for t in (j[1], j[2])]):
+            for j in pend:
+                j[0]()
+        pend.clear()
+
+    def _final_from(self, p, like):
+        if self._grad_bucket_hook is not None:      # (data parallelism: the bucket's weight gradients must be on the side stream before the hook orders behind it)
+            self._wgrad_flush()
+        self._grads_final_from(p, like)
+
     def _convblock_bwd(self, cb, tag, da2, saved, need_dx):
         ops = self.ops
         h, y1, st1, em, a1, y2, st2, G = saved[tag]
         dy2 = ops.norm_bwd(y2, da2, G, st2, H.ACT_LRELU, cb.b2.weight.grad, cb.b2.bias.grad, True)
-        with self._wgrad_stream(dy2, a1):      # weight gradients run underneath the dgrad -> norm_bwd chain (VNet.py)
-            ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True)
+        # weight gradients run underneath the dgrad -> norm_bwd chain (VNet.py)
+        self._wgrad_later(lambda: ops.conv3_wgrad(a1, dy2, cb.c2.weight.grad, 1, accumulate=True), dy2, a1)
         _, wd2 = self.conv3_packed((tag, 2), True)
         es = 1.0 / (1.0 - cb.p) if cb.p > 0 else 1.0
         sk = (ops.conv3_nslabs(dy2.shape, cb.cout, 1) if y1 is not None and ops.norm_slabs_ok(G, y2.numel() // (cb.cout * G), cb.cout) else 0)
@@ -199,11 +226,10 @@ class UNet_2d(HipNet):
             else:
                 dy1 = ops.norm_bwd(y1, da1, G, st1, H.ACT_LRELU, cb.b1.weight.grad, cb.b1.bias.grad, True, elem_mask=em, elem_scale=es,
                                    partial=bpart, nb=bnb)
-        with self._wgrad_stream(dy1, h):
-            if cb.cin == 1:
-                ops.conv3_c1_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
-            else:
-                ops.conv3_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True)
+        if cb.cin == 1:
+            self._wgrad_later(lambda: ops.conv3_c1_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True), dy1, h)
+        else:
+            self._wgrad_later(lambda: ops.conv3_wgrad(h, dy1, cb.c1.weight.grad, 1, accumulate=True), dy1, h)
         if cb.cin == 1 or not need_dx:
             return None
         _, wd1 = self.conv3_packed((tag, 1), True)
@@ -270,9 +296,12 @@ class UNet_2d(HipNet):
         self.begin_backward()
         (h_last,) = saved["out"]
         xs = saved["xs"]
-        with self._wgrad_stream(dlogits, h_last):
+        self._wg_pend = []
+
+        def out_wgrad():
             ops.conv3_wgrad(h_last, dlogits, self._out.weight.grad, 1, accumulate=True)
             ops.colsum(dlogits, self._out.bias.grad, accumulate=True)
+        self._wgrad_later(out_wgrad, dlogits, h_last)
         _, wd = self.conv3_packed(("out", 0), True)
         dh = ops.conv3_fwd(dlogits, wd, None, FT[0], 1)
         skip_grads = {}
@@ -282,12 +311,13 @@ class UNet_2d(HipNet):
             skip_grads[4 - i] = (dcat, c2)                                       # first c2 channels belong to xs[4-i]
             dz = ops.bilinear2x_bwd(dcat, c2, c2)
             (h_in,) = saved[f"pw{i}"]
-            with self._wgrad_stream(dz, h_in):
+            def pw_wgrad(h_in=h_in, dz=dz, pw=pw):
                 ops.k2_wgrad(h_in, dz, pw.weight.grad, H.WG_PW, accumulate=True)
                 ops.colsum(dz, pw.bias.grad, accumulate=True)
+            self._wgrad_later(pw_wgrad, dz, h_in)
             _, bpd = self.k2_packed(("pw", i), True)
             dh = ops.pw_fwd(dz, bpd, None, c1)
-            self._grads_final_from(pw.weight, dz)
+            self._final_from(pw.weight, dz)
         # dh = gradient w.r.t. x4; walk the encoder upwards
         for i in range(4, 0, -1):
             dpool = self._convblock_bwd(self._enc[i], f"e{i}", dh, saved, True)
@@ -296,8 +326,9 @@ class UNet_2d(HipNet):
             # pool backward + the decoder-side skip gradient (the leading c2 channels of dcat) in one pass
             ops.maxpool2d_bwd(xs[i - 1], dpool, dx, add=ops.channel_slab(dcat, c2))
             dh = dx
-            self._grads_final_from(self._enc[i].c1.weight, dx)
+            self._final_from(self._enc[i].c1.weight, dx)
         self._convblock_bwd(self._enc[0], "e0", dh, saved, False)
+        self._wgrad_flush()
         self._join_wgrad_stream(dlogits)
         return None
 

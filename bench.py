@@ -746,6 +746,11 @@ def main():
             from bcp_amd.networks.unet import UNet_2d as _un2
             _un2.skip_in_concat = bool(int(v))
             continue
+        if k == "wgrad_defer":        # host-side switch (networks/VNet.py, unet.py): small layers' weight gradients fork in batches of this many
+            from bcp_amd.networks.VNet import VNet as _vn6
+            from bcp_amd.networks.unet import UNet_2d as _un6
+            _vn6.WGRAD_DEFER = _un6.WGRAD_DEFER = int(v)
+            continue
         if k == "fuse_head":          # host-side switch (networks/VNet.py), not a library option
             from bcp_amd.networks.VNet import VNet
             VNet.fuse_head = bool(int(v))
