@@ -276,6 +276,8 @@ extern "C" size_t bcp_cc_workspace_bytes(int N, int D, int H, int W, int nclass)
 
 extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f32, int N, int D, int H, int W, int nclass,
                               int connectivity, void* workspace, void* stream) {
+  if (bcp::options().whatif & 4) return BCP_OK;      // MEASUREMENT ONLY (common.h Options::whatif)
+
   BCP_REQUIRE(seg && (out_u8 || out_f32) && workspace, "bcp_cc_largest: null pointer");
   BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && nclass >= 1 && nclass <= 8, "bcp_cc_largest: bad extents");
   BCP_REQUIRE(connectivity >= 1 && connectivity <= 3, "bcp_cc_largest: connectivity must be 1..3 (number of axes that may differ)");

@@ -76,7 +76,8 @@ struct Options {
   int k2_bwd_stats = 0;     // round 6, measured and NOT adopted (kept for the record and its kernel check): the k2s2 / transposed-conv DGRADS leave the backward statistics of the norm layer in front of them (k_gemm_nn<.., 2>, bcp_down_dgrad_bwdstats / bcp_up_dgrad_bwdstats).  2 = where the output is >= 2^22 elements, 1 = wherever the shape allows, 0 = the norm's own pass (k_col_partial<1>).  LA 788.2 (off) / 786.9 (1) / 784.2 (2), pancreas 853.0 / 852.3 / 849.4 volumes/s (gpurun_out/r06_s16): the epilogue re-reads y, so all it saves is the da read, and it costs the GEMM its occupancy
   int norm_fuse_fin = 1;    // round 6: norm layers whose statistics pass leaves <= 128 partial rows per group (the deep levels): the apply pass finalises the statistics itself (k_norm_apply_fin / k_norm_bwd_apply_fin), no finalize launch.  0: finalize launches everywhere
   int norm_fin_rows = 128;   // ... partial rows per group the slab-summing statistics pass leaves in front of a fused apply pass (128: as without it)
-  int whatif = 0;           // MEASUREMENT ONLY (wrong results): bit 0 = no finalize launches of the norm layers, bit 1 = no finalize and no apply launches where rows per group <= 4096 (prices launch fusion before building it)
+  int wgrad_reduce_flat = 1;   // round 6: many-group weight-gradient slab sums read slab-contiguous float4 (k_wgrad_reduce_flat).  0: k_wgrad_reduce_deep
+  int whatif = 0;           // MEASUREMENT ONLY (wrong results): bit 0 = no finalize launches of the norm layers, bit 1 = no finalize and no apply launches where rows per group <= 4096, bit 2 = no largest-CC launches, bit 3 = no conv / k2 weight-gradient launches, bit 4 = no forward / backward apply pass at >= 100000 rows per group, bit 5 = no backward statistics pass there (prices a change before it is built)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };
 Options& options();

@@ -714,8 +714,55 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce_deep(const float* __restri
   }
 }
 
+// Round 6: the same sum with the SLAB as the fastest dimension of the read: a workgroup owns 64 float4 columns of the [T][Cin16][Cout16] slab
+// (1 KB contiguous per wave and slab) and 16 group slots, 4 independent float4 loads in flight per thread; the 16 slots are added in order
+// through the LDS (deterministic), the finished float4 (four consecutive co of one (tap, ci)) is scattered into dW[co][ci][tap].  The kernel
+// above reads 4 bytes per lane at a slab stride: 53 us for the 506 slabs (14 MB) of the 16 -> 16 layer, on the weight-gradient stream.
+__global__ __launch_bounds__(1024) void k_wgrad_reduce_flat(const float* __restrict__ partial, float* __restrict__ dW, int G, int T, int Cin,
+                                                            int Cout, int Cin16, int Cout16, int accumulate) {
+  __shared__ float4 red[16][64];
+  const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
+  const long long sq = (long long)T * Cin16 * Cout16 / 4;      // float4 per slab
+  const long long q = (long long)blockIdx.x * 64 + lane;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (q < sq) {
+    const float4* p = reinterpret_cast<const float4*>(partial) + q;
+    int g = slot;
+    for (; g + 48 < G; g += 64) {
+      const float4 a = p[(long long)g * sq], b = p[(long long)(g + 16) * sq], c = p[(long long)(g + 32) * sq], d = p[(long long)(g + 48) * sq];
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += c.x; s2.y += c.y; s2.z += c.z; s2.w += c.w;
+      s3.x += d.x; s3.y += d.y; s3.z += d.z; s3.w += d.w;
+    }
+    for (; g < G; g += 16) { const float4 a = p[(long long)g * sq]; s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w; }
+  }
+  red[slot][lane] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  if (slot == 0 && q < sq) {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const float4 t = red[k][lane]; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+    const long long e = q * 4;
+    const int co = (int)(e % Cout16), ci = (int)((e / Cout16) % Cin16), tap = (int)(e / ((long long)Cout16 * Cin16));
+    if (ci < Cin) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (co + k < Cout) {
+          float* o = dW + ((long long)(co + k) * Cin + ci) * T + tap;
+          *o = accumulate ? (*o + v[k]) : v[k];
+        }
+    }
+  }
+}
+
 static void launch_reduce_deep(const float* ws, float* dw, int G, int T, int Cin, int Cout, int Cin16, int Cout16, int accumulate,
                                hipStream_t s) {
+  if (options().wgrad_reduce_flat != 0 && (Cout16 & 3) == 0 && aligned16(ws)) {
+    const long long sq = (long long)T * Cin16 * Cout16 / 4;
+    hipLaunchKernelGGL(k_wgrad_reduce_flat, dim3((unsigned)((sq + 63) / 64)), dim3(1024), 0, s, ws, dw, G, T, Cin, Cout, Cin16, Cout16, accumulate);
+    return;
+  }
   if (Cout <= 16)
     hipLaunchKernelGGL((k_wgrad_reduce_deep<16>), dim3(Cin, cdiv(Cout, 16), T), dim3(256), 0, s, ws, dw, G, T, Cin, Cout, Cin16, Cout16, accumulate);
   else if (Cout <= 32)
@@ -1733,6 +1780,8 @@ extern "C" size_t bcp_conv3_wgrad_workspace_bytes(int N, int D, int H, int W, in
 
 extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin, int Cout, int KD,
                                int accumulate, void* workspace, const float* x_amax_or_null, const float* dy_amax_or_null, void* stream) {
+  if (bcp::options().whatif & 8) return BCP_OK;      // MEASUREMENT ONLY (common.h Options::whatif)
+
   BCP_REQUIRE(x && dy && dw && workspace, "bcp_conv3_wgrad: null pointer");
   BCP_REQUIRE((KD == 1 || KD == 3) && N > 0 && D > 0 && H > 0 && W > 0, "bcp_conv3_wgrad: bad extents");
   BCP_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "bcp_conv3_wgrad: Cin/Cout must be multiples of 4");
@@ -1760,7 +1809,7 @@ extern "C" int bcp_conv3_wgrad(const float* x, const float* dy, float* dw, int N
   }
   BCP_REQUIRE(done, "bcp_conv3_wgrad: no kernel instance for KD=%d tile=%dx%dx%d NT=%d", c.KD, c.TD, c.TH, c.TW, c.NT);
   const int T = KD * 9;
-  if (G >= 32)
+  if (G >= 32 || options().wgrad_reduce_flat == 2)      // (2: tests force the flat sum for every group count)
     launch_reduce_deep(ws, dw, G, T, Cin, Cout, cd.Cin16, cd.Cout16, accumulate, (hipStream_t)stream);
   else
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(Cin, cdiv(Cout, 64)), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, Cin, Cout, cd.Cin16,
@@ -1931,7 +1980,7 @@ extern "C" int bcp_conv3_c1_norm_bwd_wgrad(const float* x, const float* w, const
   norm_bwd_finalize_launch(partial, rows, groups, 16, (long long)N / groups * D * H * W, dgamma, dbeta, accumulate, c1c2raw, s, nullptr);
   c1_fwd_impl(x, w, bias, wpart, N, D, H, W, KD, nullptr, groups, false, s, 5, &nm);
   const int G = groups * rows, T = KD * 9;                     // workgroups of pass 2 = statistics rows of pass 1 (same tiling)
-  if (G >= 32)
+  if (G >= 32 || options().wgrad_reduce_flat == 2)      // (2: tests force the flat sum for every group count)
     launch_reduce_deep(wpart, dw, G, T, 1, 16, 1, 16, dw_accumulate, s);
   else
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(1, 1), dim3(256), 0, s, wpart, dw, G, T, 1, 16, 1, 16, dw_accumulate);
@@ -1961,7 +2010,7 @@ extern "C" int bcp_conv3_c1_wgrad(const float* x, const float* dy, float* dw, in
     hipLaunchKernelGGL((k_conv3_c1_wgrad<1, 1, 16, 16>), dim3(G), dim3(256), 0, (hipStream_t)stream, x, dy, ws, cd, tiles, tpg);
   }
   const int T = KD * 9;
-  if (G >= 32)
+  if (G >= 32 || options().wgrad_reduce_flat == 2)      // (2: tests force the flat sum for every group count)
     launch_reduce_deep(ws, dw, G, T, 1, 16, 1, 16, accumulate, (hipStream_t)stream);
   else
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(1, 1), dim3(256), 0, (hipStream_t)stream, ws, dw, G, T, 1, 16, 1, 16, accumulate);

@@ -1208,6 +1208,8 @@ extern "C" size_t bcp_tn_workspace_bytes(long long M, int K, int N) {
 //   BCP_WG_PW:   x [rows][Cin], dy [rows][Cout]      -> dw[Cout][Cin]      (rows = N*D*H*W)
 extern "C" int bcp_k2_wgrad(const float* x, const float* dy, float* dw, int N, int D, int H, int W, int Cin, int Cout, int kind,
                             int accumulate, void* workspace, void* stream) {
+  if (bcp::options().whatif & 8) return BCP_OK;      // MEASUREMENT ONLY (common.h Options::whatif)
+
   BCP_REQUIRE(x && dy && dw && workspace, "bcp_k2_wgrad: null pointer");
   BCP_REQUIRE(Cin % 16 == 0 && Cout % 16 == 0, "bcp_k2_wgrad: channels must be multiples of 16");
   float* ws = reinterpret_cast<float*>(workspace);

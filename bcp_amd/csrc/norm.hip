@@ -750,7 +750,8 @@ static inline dim3 fin_grid(long long seg_rows, int nseg, int C, bool runner) {
 }
 
 static inline bool skip_fin(long long rpg) { const int w = options().whatif; return (w & 1) || ((w & 2) && rpg <= 4096); }
-static inline bool skip_app(long long rpg) { return (options().whatif & 2) && rpg <= 4096; }
+static inline bool skip_app(long long rpg) { return ((options().whatif & 2) && rpg <= 4096) || ((options().whatif & 16) && rpg >= 100000); }
+static inline bool skip_bstat(long long rpg) { return (options().whatif & 32) && rpg >= 100000; }
 static inline int norm_blocks(long long rows_per_group, int C) {
   // enough blocks to fill the chip, but at least ~64 rows per thread-slot to amortise the LDS reduce
   const int slots = 256 / (C / 4);
@@ -911,7 +912,7 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
     if (!skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw, amax_out);
   } else {
-    hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
+    if (!skip_bstat(rows_per_group)) hipLaunchKernelGGL((k_col_partial<1>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, da, scale, shift, mean, rstd, ep, sg.seg_rows, sg.spg,
                        C, partial, SlabSrc{}, fused ? amax_out : (float*)nullptr);
     if (!fused && !skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_bwd_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial, nb, G, C, rows_per_group, dgamma,
                        dbeta, accumulate, c1, c2, raw, amax_out);

@@ -943,6 +943,22 @@ def check_k2_chunks(ops, dev):
         ops.set_option("tn_groups")
 
 
+def check_wgrad_reduce_flat(ops, dev):
+    """weight-gradient slab sums as k_wgrad_reduce_flat (round 6: slab-contiguous float4 reads, 16 group slots) for EVERY group count --
+    the product takes it from 32 groups on -- on the fp32-MFMA and the bf16-pipe weight gradients and the first layer's"""
+    ops.set_option("wgrad_reduce_flat", 2)
+    try:
+        check_conv3(ops, dev)
+        check_conv3_c1(ops, dev)
+        ops.set_option("wgrad_b6", 0)
+        try:
+            check_conv3(ops, dev, cases=CONV3_CASES[:6])
+        finally:
+            ops.set_option("wgrad_b6")
+    finally:
+        ops.set_option("wgrad_reduce_flat")
+
+
 def check_conv3_res(ops, dev):
     """resident-weight kernel, with the persistent grid forced small so every block walks several tiles"""
     ops.set_option("conv3_b6", 0)      # the fp32-MFMA kernels of conv3.hip (the bf16-pipe kernels have their own checks)
@@ -1792,7 +1808,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
+ALL_CHECKS = ("wgrad_reduce_flat", "inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):
