@@ -77,6 +77,7 @@ struct Options {
   int norm_fuse_fin = 1;    // round 6: norm layers whose statistics pass leaves <= 128 partial rows per group (the deep levels): the apply pass finalises the statistics itself (k_norm_apply_fin / k_norm_bwd_apply_fin), no finalize launch.  0: finalize launches everywhere
   int norm_fin_rows = 128;   // ... partial rows per group the slab-summing statistics pass leaves in front of a fused apply pass (128: as without it)
   int wgrad_reduce_flat = 1;   // round 6: many-group weight-gradient slab sums read slab-contiguous float4 (k_wgrad_reduce_flat).  0: k_wgrad_reduce_deep
+  int norm_own = 0;         // round 6, measured and NOT adopted (kept with its kernel checks): norm layers with a few hundred rows per group (LA 7x7x5, pancreas 6^3) in ONE launch (k_norm_own_fwd / _bwd: a 1024-thread workgroup owns an 8..32-channel chunk of all rows).  LA 800.2 (on) vs 800.7 (off), 32-channel chunks 804.4 vs 810.4 volumes/s (gpurun_out/r06_s35, s36): the statistics pass + fused apply pass it replaces spread over 4x the workgroups, and 1024-thread workgroups wait for a whole CU beside the other stream's convs
   int whatif = 0;           // MEASUREMENT ONLY (wrong results): bit 0 = no finalize launches of the norm layers, bit 1 = no finalize and no apply launches where rows per group <= 4096, bit 2 = no largest-CC launches, bit 3 = no conv / k2 weight-gradient launches, bit 4 = no forward / backward apply pass at >= 100000 rows per group, bit 5 = no backward statistics pass there (prices a change before it is built)
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };

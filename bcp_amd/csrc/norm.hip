@@ -739,6 +739,340 @@ __global__ __launch_bounds__(256) void k_norm_bwd_apply_fin(const float* __restr
   if (amax_out) block_amax_publish(amax, amax_out);
 }
 
+// ------------------------------------------------------------------ the smallest levels: the whole norm in ONE launch (round 6)
+// Where a group has a few hundred rows (LA 7x7x5, pancreas 6^3: <= 512 / GS rows) a 1024-thread workgroup OWNS a 32-channel chunk of GS
+// groups for all their rows: 128-byte row segments (whole cache lines -- round 3's one-launch form owned FOUR channels and was bound by one
+// line per lane, tools/attic/norm_small.hip), at most four rows per thread held in registers, the slab sum, the statistics, their
+// finalisation and the apply pass without a second read or a launch boundary in between.  GS = G when the groups are order-dependent
+// (running statistics / parameter gradients: G <= 2, both groups in one workgroup, finished in order), else 1 (grid.y = G).  At most 32
+// workgroups per launch: each writes its |max| into a slot of its own (no atomics, nobody has to clear them).  Same arithmetic per element
+// as the streaming kernels; the fp64 statistics are summed in a different fixed order (rows of a thread, lanes, waves).
+constexpr int kOwnThreads = 1024, kOwnMaxP = 4;
+
+struct OwnCommon {
+  const float* y;              // fwd: pre-norm input when nslab == 0; bwd: the saved pre-norm tensor
+  const float* slabs; int nslab; long long slab_stride; const float* bias;   // fwd: conv slabs (+ bias); bwd: da slabs
+  float* sum_out;              // fwd: y written here when nslab > 0; bwd: da sum (nullable)
+  int G, C, R, GS, cw;         // groups, channels, rows per group, groups per workgroup, channels per workgroup (8 / 16 / 32)
+  NormEpilogue ep;
+  float* amax_out;
+};
+
+// block reduction of 8 doubles per thread over the row slots of every group slot: -> fin[gs][32 channels][2] in LDS
+__device__ __forceinline__ void own_reduce(double (&acc8)[8], int GS, int cw, double* red /* [16][8][8] */, double* fin /* [GS][64] */) {
+  const int cw4 = cw >> 2;
+  // lanes with equal column are cw4 apart
+  for (int off = cw4; off < 64; off <<= 1) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc8[k] += __shfl_xor(acc8[k], off);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane < cw4) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) red[(wave * 8 + lane) * 8 + k] = acc8[k];
+  }
+  __syncthreads();
+  const int wpg = 16 / GS;                                     // waves per group slot
+  if ((int)threadIdx.x < GS * 2 * cw) {
+    const int gs = threadIdx.x / (2 * cw), j = threadIdx.x % (2 * cw), c = j >> 1, st = j & 1;      // channel c of the chunk, statistic st
+    const int col = c >> 2, k = (c & 3) + st * 4;
+    double t = 0.0;
+    for (int w = 0; w < wpg; ++w) t += red[((gs * wpg + w) * 8 + col) * 8 + k];
+    fin[gs * 64 + j] = t;
+  }
+  __syncthreads();
+}
+
+struct OwnFwd {
+  const float *gamma, *beta; float *running_mean, *running_var; float momentum, eps;
+  const float* residual; float* stats; float* out; long long ldo;
+};
+
+template <int P>
+__global__ __launch_bounds__(kOwnThreads) void k_norm_own_fwd(OwnCommon a, OwnFwd f) {
+  __shared__ double red[16 * 8 * 8];
+  __shared__ double fin[2 * 64];
+  __shared__ float pmu[2 * 32], psc[2 * 32], psh[2 * 32];
+  __shared__ float amax_red[16];
+  const NormEpilogue& ep = a.ep;
+  BCP_NORM_MASK_PROLOGUE(ep)
+  const int C = a.C, R = a.R, GS = a.GS, cw = a.cw, cw4 = cw >> 2, c0 = blockIdx.x * cw;
+  const int col = threadIdx.x & (cw4 - 1), slot = threadIdx.x / cw4;     // 1024 / cw4 row slots
+  const int spg = (kOwnThreads / cw4) / GS;                      // row slots per group slot
+  const int gs = slot / spg, rs = slot % spg;
+  const int g = blockIdx.y * GS + gs;
+  float4 v[P], q[P];
+  uchar4 m4[P];
+  bool ok[P];
+  long long eo[P];
+  const bool SL = a.nslab > 0;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (SL && a.bias) bias4 = ld4(a.bias + c0 + col * 4);
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int r = rs + p * spg;
+    ok[p] = r < R;
+    eo[p] = ((long long)g * R + r) * C + c0 + col * 4;
+    v[p] = SL ? bias4 : make_float4(0.f, 0.f, 0.f, 0.f);
+    q[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    m4[p] = make_uchar4(0, 0, 0, 0);
+    if (ok[p]) {
+      if (!SL) v[p] = ld4(a.y + eo[p]);
+      if (f.residual) q[p] = ld4(f.residual + eo[p]);
+      if (has_mask) m4[p] = BCP_NORM_MASK4(ep, eo[p]);
+    }
+  }
+  if (SL) {      // bias first, then the slabs front to back (k_b6_sum_slabs' order); up to four slabs' loads go out before the first add
+    constexpr int KU = P >= 4 ? 2 : 4;      // slabs requested together (P = 4: two, or the loads spill)
+    for (int k0 = 0; k0 < a.nslab; k0 += KU) {
+      float4 t[KU][P];
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          t[kk][p] = (k0 + kk < a.nslab && ok[p]) ? ld4(a.slabs + (long long)(k0 + kk) * a.slab_stride + eo[p]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk)
+        if (k0 + kk < a.nslab) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) { v[p].x += t[kk][p].x; v[p].y += t[kk][p].y; v[p].z += t[kk][p].z; v[p].w += t[kk][p].w; }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+      if (ok[p]) st4(a.sum_out + eo[p], v[p]);
+  }
+  double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int p = 0; p < P; ++p)
+    if (ok[p]) {
+      const float vv[4] = {v[p].x, v[p].y, v[p].z, v[p].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { acc8[k] += (double)vv[k]; acc8[4 + k] += (double)vv[k] * (double)vv[k]; }
+    }
+  own_reduce(acc8, GS, cw, red, fin);
+  float *mean = f.stats, *rstd = f.stats + (long long)a.G * C, *scale = f.stats + 2LL * a.G * C, *shift = f.stats + 3LL * a.G * C;
+  float* var_unb = f.stats + 4LL * a.G * C;
+  float vu_mine = 0.f, m_mine = 0.f;
+  if ((int)threadIdx.x < GS * cw) {      // thread = (group slot, channel): k_norm_finalize's arithmetic
+    const int gq = threadIdx.x / cw, c = threadIdx.x % cw, gg = blockIdx.y * GS + gq;
+    const double n = (double)R;
+    const double s1 = fin[gq * 64 + c * 2], s2 = fin[gq * 64 + c * 2 + 1];
+    const double m = s1 / n;
+    double var = s2 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const double r = 1.0 / sqrt(var + (double)f.eps);
+    const double ga = f.gamma ? (double)f.gamma[c0 + c] : 1.0, be = f.beta ? (double)f.beta[c0 + c] : 0.0;
+    const int idx = gg * C + c0 + c;
+    m_mine = (float)m;
+    vu_mine = (float)(n > 1.0 ? var * n / (n - 1.0) : var);
+    mean[idx] = m_mine; rstd[idx] = (float)r; scale[idx] = (float)(ga * r); shift[idx] = (float)be; var_unb[idx] = vu_mine;
+    pmu[gq * 32 + c] = m_mine; psc[gq * 32 + c] = (float)(ga * r); psh[gq * 32 + c] = (float)be;
+  }
+  __syncthreads();
+  if (f.running_mean) {      // (GS = G here) the groups in order, fp32 rounding after each: update_running's arithmetic
+    __shared__ float gm[2 * 32], gv[2 * 32];
+    if ((int)threadIdx.x < GS * cw) { gm[(threadIdx.x / cw) * 32 + threadIdx.x % cw] = m_mine; gv[(threadIdx.x / cw) * 32 + threadIdx.x % cw] = vu_mine; }
+    __syncthreads();
+    if ((int)threadIdx.x < cw) {
+      double rm = (double)f.running_mean[c0 + threadIdx.x], rv = (double)f.running_var[c0 + threadIdx.x];
+      for (int gq = 0; gq < GS; ++gq) {
+        rm = (double)(float)((1.0 - (double)f.momentum) * rm + (double)f.momentum * (double)gm[gq * 32 + threadIdx.x]);
+        rv = (double)(float)((1.0 - (double)f.momentum) * rv + (double)f.momentum * (double)gv[gq * 32 + threadIdx.x]);
+      }
+      f.running_mean[c0 + threadIdx.x] = (float)rm;
+      f.running_var[c0 + threadIdx.x] = (float)rv;
+    }
+  }
+  const float4 mu = *reinterpret_cast<const float4*>(pmu + gs * 32 + col * 4), sc = *reinterpret_cast<const float4*>(psc + gs * 32 + col * 4);
+  const float4 sh = *reinterpret_cast<const float4*>(psh + gs * 32 + col * 4);
+  float amax = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (!ok[p]) continue;
+    const long long row = (long long)g * R + rs + p * spg;
+    float o[4] = {act_fwd((v[p].x - mu.x) * sc.x + sh.x, ep.act), act_fwd((v[p].y - mu.y) * sc.y + sh.y, ep.act),
+                  act_fwd((v[p].z - mu.z) * sc.z + sh.z, ep.act), act_fwd((v[p].w - mu.w) * sc.w + sh.w, ep.act)};
+    if (ep.chan_scale) {
+      const float4 cs = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + c0 + col * 4);
+      o[0] *= cs.x; o[1] *= cs.y; o[2] *= cs.z; o[3] *= cs.w;
+    }
+    if (has_mask) {
+      o[0] *= m4[p].x ? ep.elem_scale : 0.f; o[1] *= m4[p].y ? ep.elem_scale : 0.f;
+      o[2] *= m4[p].z ? ep.elem_scale : 0.f; o[3] *= m4[p].w ? ep.elem_scale : 0.f;
+    }
+    if (f.residual) { o[0] += q[p].x; o[1] += q[p].y; o[2] += q[p].z; o[3] += q[p].w; }
+    st4(f.out + row * f.ldo + c0 + col * 4, make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float t = fabsf(o[k]); amax = (t > amax || t != t) ? t : amax; }
+  }
+  if (a.amax_out) {      // this workgroup's slot is its own; workgroup 0 also defines the slots nobody owns
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(amax, o); amax = (t > amax || t != t) ? t : amax; }
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    const int nwg = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+      float m = amax_red[0];
+      for (int k = 1; k < 16; ++k) { const float t = amax_red[k]; m = (t > m || t != t) ? t : m; }
+      if (m != m) m = __uint_as_float(0x7fc00000u);
+      a.amax_out[me * kAmaxStride] = m;
+    }
+    if (me == 0 && (int)threadIdx.x >= nwg && (int)threadIdx.x < kAmaxSlots) a.amax_out[threadIdx.x * kAmaxStride] = 0.f;
+  }
+}
+
+struct OwnBwd {
+  const float* stats; const float* da; float *dgamma, *dbeta; int accumulate; float* dy;
+};
+
+template <int P>
+__global__ __launch_bounds__(kOwnThreads) void k_norm_own_bwd(OwnCommon a, OwnBwd f) {
+  __shared__ double red[16 * 8 * 8];
+  __shared__ double fin[2 * 64];
+  __shared__ float pc1[2 * 32], pc2[2 * 32];
+  __shared__ float amax_red[16];
+  const NormEpilogue& ep = a.ep;
+  BCP_NORM_MASK_PROLOGUE(ep)
+  const int C = a.C, R = a.R, GS = a.GS, cw = a.cw, cw4 = cw >> 2, c0 = blockIdx.x * cw;
+  const int col = threadIdx.x & (cw4 - 1), slot = threadIdx.x / cw4;
+  const int spg = (kOwnThreads / cw4) / GS;
+  const int gs = slot / spg, rs = slot % spg;
+  const int g = blockIdx.y * GS + gs;
+  const float *mean = f.stats, *rstd = f.stats + (long long)a.G * C, *scale = f.stats + 2LL * a.G * C, *shift = f.stats + 3LL * a.G * C;
+  const long long gc = (long long)g * C + c0 + col * 4;
+  const float4 sc = ld4(scale + gc), sh = ld4(shift + gc), mu = ld4(mean + gc), rsd = ld4(rstd + gc);
+  const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+  const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, rsv[4] = {rsd.x, rsd.y, rsd.z, rsd.w};
+  float4 v[P], d[P];
+  uchar4 m4[P];
+  bool ok[P];
+  long long eo[P];
+  const bool SL = a.nslab > 0;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    const int r = rs + p * spg;
+    ok[p] = r < R;
+    eo[p] = ((long long)g * R + r) * C + c0 + col * 4;
+    v[p] = d[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+    m4[p] = make_uchar4(0, 0, 0, 0);
+    if (ok[p]) {
+      v[p] = ld4(a.y + eo[p]);
+      if (!SL) d[p] = ld4(f.da + eo[p]);
+      if (has_mask) m4[p] = BCP_NORM_MASK4(ep, eo[p]);
+    }
+  }
+  if (SL) {
+    constexpr int KU = P >= 4 ? 2 : 4;      // slabs requested together (P = 4: two, or the loads spill)
+    for (int k0 = 0; k0 < a.nslab; k0 += KU) {
+      float4 t[KU][P];
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk)
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+          t[kk][p] = (k0 + kk < a.nslab && ok[p]) ? ld4(a.slabs + (long long)(k0 + kk) * a.slab_stride + eo[p]) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int kk = 0; kk < KU; ++kk)
+        if (k0 + kk < a.nslab) {
+#pragma unroll
+          for (int p = 0; p < P; ++p) { d[p].x += t[kk][p].x; d[p].y += t[kk][p].y; d[p].z += t[kk][p].z; d[p].w += t[kk][p].w; }
+        }
+    }
+    if (a.sum_out) {
+#pragma unroll
+      for (int p = 0; p < P; ++p)
+        if (ok[p]) st4(a.sum_out + eo[p], d[p]);
+    }
+  }
+  // dz and xhat of every element stay in registers (k_col_partial<1>'s arithmetic)
+  float dzv[P][4], xhv[P][4];
+  double acc8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    float cs[4] = {1.f, 1.f, 1.f, 1.f};
+    if (ok[p] && ep.chan_scale) {
+      const long long row = (long long)g * R + rs + p * spg;
+      const float4 c4 = ld4(ep.chan_scale + (row / ep.rows_per_sample) * C + c0 + col * 4);
+      cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+    }
+    if (has_mask) {
+      cs[0] *= m4[p].x ? ep.elem_scale : 0.f; cs[1] *= m4[p].y ? ep.elem_scale : 0.f;
+      cs[2] *= m4[p].z ? ep.elem_scale : 0.f; cs[3] *= m4[p].w ? ep.elem_scale : 0.f;
+    }
+    const float vv[4] = {v[p].x, v[p].y, v[p].z, v[p].w}, dd[4] = {d[p].x, d[p].y, d[p].z, d[p].w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float z = (vv[k] - muv[k]) * scv[k] + shv[k];
+      dzv[p][k] = dd[k] * cs[k] * act_grad(z, ep.act);
+      xhv[p][k] = (vv[k] - muv[k]) * rsv[k];
+      if (ok[p]) { acc8[k] += (double)dzv[p][k]; acc8[4 + k] += (double)dzv[p][k] * (double)xhv[p][k]; }
+    }
+  }
+  own_reduce(acc8, GS, cw, red, fin);
+  if ((int)threadIdx.x < GS * cw) {
+    const int gq = threadIdx.x / cw, c = threadIdx.x % cw;
+    pc1[gq * 32 + c] = (float)(fin[gq * 64 + c * 2] / (double)R);
+    pc2[gq * 32 + c] = (float)(fin[gq * 64 + c * 2 + 1] / (double)R);
+  }
+  if (f.dgamma && (int)threadIdx.x < cw) {      // (GS = G) the groups in order: k_norm_bwd_apply's block (0, 0)
+    float gb = f.accumulate ? f.dbeta[c0 + threadIdx.x] : 0.f, gg = f.accumulate ? f.dgamma[c0 + threadIdx.x] : 0.f;
+    for (int gq = 0; gq < GS; ++gq) { gb += (float)fin[gq * 64 + threadIdx.x * 2]; gg += (float)fin[gq * 64 + threadIdx.x * 2 + 1]; }
+    f.dbeta[c0 + threadIdx.x] = gb;
+    f.dgamma[c0 + threadIdx.x] = gg;
+  }
+  __syncthreads();
+  const float4 k1 = *reinterpret_cast<const float4*>(pc1 + gs * 32 + col * 4), k2 = *reinterpret_cast<const float4*>(pc2 + gs * 32 + col * 4);
+  const float k1v[4] = {k1.x, k1.y, k1.z, k1.w}, k2v[4] = {k2.x, k2.y, k2.z, k2.w};
+  float amax = 0.f;
+#pragma unroll
+  for (int p = 0; p < P; ++p) {
+    if (!ok[p]) continue;
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = scv[k] * (dzv[p][k] - k1v[k] - xhv[p][k] * k2v[k]);
+    st4(f.dy + eo[p], make_float4(o[0], o[1], o[2], o[3]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float t = fabsf(o[k]); amax = (t > amax || t != t) ? t : amax; }
+  }
+  if (a.amax_out) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const float t = __shfl_xor(amax, o); amax = (t > amax || t != t) ? t : amax; }
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    const int nwg = gridDim.x * gridDim.y, me = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0) {
+      float m = amax_red[0];
+      for (int k = 1; k < 16; ++k) { const float t = amax_red[k]; m = (t > m || t != t) ? t : m; }
+      if (m != m) m = __uint_as_float(0x7fc00000u);
+      a.amax_out[me * kAmaxStride] = m;
+    }
+    if (me == 0 && (int)threadIdx.x >= nwg && (int)threadIdx.x < kAmaxSlots) a.amax_out[threadIdx.x * kAmaxStride] = 0.f;
+  }
+}
+
+// -> GS (groups per workgroup) when the one-launch form serves the shape, else 0; cw = channels per workgroup: the narrowest of 8 / 16 / 32 that
+// keeps the launch at <= 32 workgroups (a workgroup moves its bytes at one CU's rate: eight 32-channel workgroups were slower than the
+// two-launch chain at LA's 7x7x5 x 256 level).  ordered: running statistics / parameter gradients tie the groups together
+static inline int own_gs(int G, long long R, int C, bool ordered, int& cw) {
+  if (options().norm_own == 0 || (C & 31) != 0 || C > 1024) return 0;
+  const int GS = ordered ? G : 1;
+  if (GS > 2 || (GS == 2 && (G & 1))) return 0;
+  cw = 8;
+  while (cw < 32 && (long long)(C / cw) * (G / GS) > kAmaxSlots) cw <<= 1;
+  if ((long long)(C / cw) * (G / GS) > kAmaxSlots) return 0;
+  if (R > 512 || R > (long long)kOwnMaxP * ((kOwnThreads / (cw / 4)) / GS)) return 0;      // (a few hundred rows: beyond that the narrow chunks are bound by one cache line per lane -- pancreas 12^3 x 128 through here: -2.3 % on the step)
+  return GS;
+}
+#define BCP_OWN_LAUNCH(KERN, R_, GS_, G_, C_, s_, a_, b_)                                                              \
+  do {                                                                                                                \
+    const int rpp_ = (kOwnThreads / ((a_).cw / 4)) / (GS_);                                                             \
+    const int P_ = (int)(((R_) + rpp_ - 1) / rpp_);                                                                   \
+    const dim3 grid_((C_) / (a_).cw, (G_) / (GS_));                                                                        \
+    if (P_ <= 1) hipLaunchKernelGGL((KERN<1>), grid_, dim3(kOwnThreads), 0, s_, a_, b_);                              \
+    else if (P_ == 2) hipLaunchKernelGGL((KERN<2>), grid_, dim3(kOwnThreads), 0, s_, a_, b_);                         \
+    else hipLaunchKernelGGL((KERN<4>), grid_, dim3(kOwnThreads), 0, s_, a_, b_);                                      \
+  } while (0)
+
 // the fused apply passes serve: option norm_fuse_fin on, few partial rows, 16 <= C <= 256 (C a power of two: whole chunks)
 static inline bool fin_fused_ok(int nb, int C) { return options().norm_fuse_fin != 0 && nb >= 1 && nb <= kFinMaxRows && C >= 16 && C <= 256; }
 static inline dim3 fin_grid(long long seg_rows, int nseg, int C, bool runner) {
@@ -864,6 +1198,14 @@ extern "C" int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int
   double* partial = reinterpret_cast<double*>(workspace);
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float* var_unb = stats + 4LL * G * C;
+  int own_cw = 0;
+  if (const int GS = (out && !partial_in) ? own_gs(G, rows_per_group, C, running_mean != nullptr, own_cw) : 0) {      // (round 6) the smallest levels: ONE launch
+    const OwnCommon oc{y, nullptr, 0, 0, nullptr, nullptr, G, C, (int)rows_per_group, GS, own_cw, ep, amax_out};
+    const OwnFwd of{gamma, beta, running_mean, running_var, momentum, eps, residual, stats, out, out_ld};
+    BCP_OWN_LAUNCH(k_norm_own_fwd, rows_per_group, GS, G, C, s, oc, of);
+    BCP_CHECK_LAUNCH("bcp_norm_fwd");
+    return BCP_OK;
+  }
   const bool fused = out && !partial_in && fin_fused_ok(nb, C);      // (round 6) the apply pass finalises the statistics itself: no finalize launch
   if (partial_in) {   // statistics partials were produced by the conv epilogue (bcp_conv3_fwd_stats)
     if (!skip_fin(rows_per_group)) hipLaunchKernelGGL(k_norm_finalize, dim3(G * (C / 16)), dim3(kFinalizeThreads), 0, s, partial_in, nb_in, G, C, rows_per_group, gamma, beta,
@@ -906,6 +1248,14 @@ extern "C" int bcp_norm_bwd(const float* y, const float* da, int G, long long ro
   float* c1 = reinterpret_cast<float*>(partial + (size_t)G * (norm_blocks(rows_per_group, C) + kMaxSamplesPerGroup) * C * 2);
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
+  int own_cw = 0;
+  if (const int GS = !partial_in ? own_gs(G, rows_per_group, C, dgamma != nullptr, own_cw) : 0) {
+    const OwnCommon oc{y, nullptr, 0, 0, nullptr, nullptr, G, C, (int)rows_per_group, GS, own_cw, ep, amax_out};
+    const OwnBwd ob{stats, da, dgamma, dbeta, accumulate, dy};
+    BCP_OWN_LAUNCH(k_norm_own_bwd, rows_per_group, GS, G, C, s, oc, ob);
+    BCP_CHECK_LAUNCH("bcp_norm_bwd");
+    return BCP_OK;
+  }
   const bool fused = !partial_in && fin_fused_ok(nb, C);
   if (partial_in) {   // (sum dz, sum dz * xhat) partials handed in by the caller (no kernel of the library produces them any more)
     BCP_REQUIRE(!chan_scale && !elem_mask && !mask_seed && nb_in > 0, "bcp_norm_bwd: fused statistics do not cover dropout epilogues");
@@ -954,6 +1304,14 @@ extern "C" int bcp_norm_fwd_slabs(const float* slabs, int nslab, long long slab_
   float *mean = stats, *rstd = stats + (long long)G * C, *scale = stats + 2LL * G * C, *shift = stats + 3LL * G * C;
   float* var_unb = stats + 4LL * G * C;
   const SlabSrc sl{slabs, nslab, slab_stride, bias, ysum};
+  int own_cw = 0;
+  if (const int GS = out ? own_gs(G, rows_per_group, C, running_mean != nullptr, own_cw) : 0) {
+    const OwnCommon oc{nullptr, slabs, nslab, slab_stride, bias, ysum, G, C, (int)rows_per_group, GS, own_cw, ep, amax_out};
+    const OwnFwd of{gamma, beta, running_mean, running_var, momentum, eps, residual, stats, out, (long long)C};
+    BCP_OWN_LAUNCH(k_norm_own_fwd, rows_per_group, GS, G, C, s, oc, of);
+    BCP_CHECK_LAUNCH("bcp_norm_fwd_slabs");
+    return BCP_OK;
+  }
   const bool fused = out && fin_fused_ok(nb, C);
   hipLaunchKernelGGL((k_col_partial<0, true>), dim3(sg.nbps, nseg), dim3(256), 0, s, (const float*)nullptr, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, ep, sg.seg_rows, sg.spg, C, partial, sl,
@@ -995,6 +1353,14 @@ extern "C" int bcp_norm_bwd_slabs(const float* y, const float* da_slabs, int nsl
   float* c2 = c1 + (long long)G * C;
   float* raw = c2 + (long long)G * C;
   const SlabSrc sl{da_slabs, nslab, slab_stride, nullptr, da_sum};
+  int own_cw = 0;
+  if (const int GS = own_gs(G, rows_per_group, C, dgamma != nullptr, own_cw)) {
+    const OwnCommon oc{y, da_slabs, nslab, slab_stride, nullptr, da_sum, G, C, (int)rows_per_group, GS, own_cw, ep, amax_out};
+    const OwnBwd ob{stats, nullptr, dgamma, dbeta, accumulate, dy};
+    BCP_OWN_LAUNCH(k_norm_own_bwd, rows_per_group, GS, G, C, s, oc, ob);
+    BCP_CHECK_LAUNCH("bcp_norm_bwd_slabs");
+    return BCP_OK;
+  }
   const bool fused = fin_fused_ok(nb, C);
   hipLaunchKernelGGL((k_col_partial<1, true>), dim3(sg.nbps, nseg), dim3(256), 0, s, y, (const float*)nullptr, scale, shift, mean, rstd, ep,
                      sg.seg_rows, sg.spg, C, partial, sl, fused ? amax_out : (float*)nullptr);

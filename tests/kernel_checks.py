@@ -959,6 +959,19 @@ def check_wgrad_reduce_flat(ops, dev):
         ops.set_option("wgrad_reduce_flat")
 
 
+def check_norm_own(ops, dev):
+    """the one-launch norm of the smallest levels (k_norm_own_fwd / _bwd; library option norm_own, off in the product: measured, not adopted):
+    every norm check with it forced on -- BatchNorm / grouped BatchNorm (both groups in one workgroup, running statistics and parameter
+    gradients in order) / InstanceNorm, every epilogue, slabs, chunk widths 8 / 16 / 32"""
+    ops.set_option("norm_own", 1)
+    try:
+        check_norm(ops, dev)
+        check_norm_grouped(ops, dev)
+        _check_norm_slabs(ops, dev)
+    finally:
+        ops.set_option("norm_own")
+
+
 def check_conv3_res(ops, dev):
     """resident-weight kernel, with the persistent grid forced small so every block walks several tiles"""
     ops.set_option("conv3_b6", 0)      # the fp32-MFMA kernels of conv3.hip (the bf16-pipe kernels have their own checks)
@@ -1808,7 +1821,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("wgrad_reduce_flat", "inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
+ALL_CHECKS = ("wgrad_reduce_flat", "norm_own", "inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):

@@ -31,7 +31,7 @@ def emu_ops():
 
 # The heaviest simulator runs are twins of checks `pytest -m gpu` executes on the device every round: skipped in the default CPU run
 # (which must stay at a few minutes), BCP_EXTENDED=1 runs them.
-EXTENDED_EMU = {"norm_slabs", "conv3_b6", "conv3_res", "dgrad_bwdstats"}
+EXTENDED_EMU = {"norm_slabs", "norm_own", "conv3_b6", "conv3_res", "dgrad_bwdstats"}
 
 
 @pytest.mark.parametrize("name", [pytest.param(n, marks=pytest.mark.extended) if n in EXTENDED_EMU else n for n in K.ALL_CHECKS])
