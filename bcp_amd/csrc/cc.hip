@@ -76,7 +76,11 @@ __device__ __forceinline__ void for_fwd_neighbours(int conn, F&& body) {
 
 template <int TD, int TH, int TW>
 __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ seg, int* __restrict__ L, int* __restrict__ lsize,
-                                                  int* __restrict__ size, CcDims cd) {
+                                                  int* __restrict__ size, CcDims cd, unsigned long long* __restrict__ best, int nbest) {
+  // (round 6) the selection table k_cc_select max-reduces into, three launches later: cleared here instead of by a memset launch of its own
+  // on the teacher stream's tail (the step's critical path)
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < nbest; i += 256) best[i] = 0ull;
   constexpr int TV = TD * TH * TW, VPT = TV / 256;
   static_assert(TV % 256 == 0, "a whole number of voxels per thread");
   __shared__ int Ls[TV];
@@ -290,7 +294,6 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
   unsigned long long* best =
       reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(size + n) + 15) & ~(uintptr_t)15);
   const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  hipMemsetAsync(best, 0, (size_t)N * nclass * sizeof(unsigned long long), s);
   CcDims cd;
   cd.N = N; cd.D = D; cd.H = H; cd.W = W; cd.conn = connectivity;
   // local tiles: 8x16x16 / 32x64 voxels (8 per thread) when the volume has at least ~2 such tiles per CU, else 4x8x16 / 16x32;
@@ -299,19 +302,19 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
   const bool big = tile_opt ? tile_opt == 2 : (n >= 512LL * 2048);
   if (D > 1 && big) {
     cd.tiles_d = cdiv(D, 8); cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16);
-    hipLaunchKernelGGL((k_cc_local<8, 16, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_local<8, 16, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
     hipLaunchKernelGGL((k_cc_border<8, 16, 16>), dim3(border_grid(cd, CcFace<8, 16, 16>::NB)), dim3(256), 0, s, seg, L, cd);
   } else if (D > 1) {
     cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 8); cd.tiles_w = cdiv(W, 16);
-    hipLaunchKernelGGL((k_cc_local<4, 8, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_local<4, 8, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
     hipLaunchKernelGGL((k_cc_border<4, 8, 16>), dim3(border_grid(cd, CcFace<4, 8, 16>::NB)), dim3(256), 0, s, seg, L, cd);
   } else if (big) {
     cd.tiles_d = 1; cd.tiles_h = cdiv(H, 32); cd.tiles_w = cdiv(W, 64);
-    hipLaunchKernelGGL((k_cc_local<1, 32, 64>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_local<1, 32, 64>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
     hipLaunchKernelGGL((k_cc_border<1, 32, 64>), dim3(border_grid(cd, CcFace<1, 32, 64>::NB)), dim3(256), 0, s, seg, L, cd);
   } else {
     cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 32);
-    hipLaunchKernelGGL((k_cc_local<1, 16, 32>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd);
+    hipLaunchKernelGGL((k_cc_local<1, 16, 32>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
     hipLaunchKernelGGL((k_cc_border<1, 16, 32>), dim3(border_grid(cd, CcFace<1, 16, 32>::NB)), dim3(256), 0, s, seg, L, cd);
   }
   hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, L, lsize, size, n);

@@ -758,7 +758,9 @@ __global__ __launch_bounds__(1024) void k_wgrad_reduce_flat(const float* __restr
 
 static void launch_reduce_deep(const float* ws, float* dw, int G, int T, int Cin, int Cout, int Cin16, int Cout16, int accumulate,
                                hipStream_t s) {
-  if (options().wgrad_reduce_flat != 0 && (Cout16 & 3) == 0 && aligned16(ws)) {
+  // (slabs of at least 24 x 64 float4: the 2-D 16 -> 16 layers' 576-float4 slabs are 9 workgroups of this kernel, 17 us where the one below takes 9)
+  if (options().wgrad_reduce_flat != 0 && (Cout16 & 3) == 0 && aligned16(ws) &&
+      (options().wgrad_reduce_flat == 2 || (long long)T * Cin16 * Cout16 / 4 >= 24 * 64)) {
     const long long sq = (long long)T * Cin16 * Cout16 / 4;
     hipLaunchKernelGGL(k_wgrad_reduce_flat, dim3((unsigned)((sq + 63) / 64)), dim3(1024), 0, s, ws, dw, G, T, Cin, Cout, Cin16, Cout16, accumulate);
     return;
@@ -832,11 +834,14 @@ __global__ __launch_bounds__(256) void k_pack_conv3(const float* __restrict__ w,
 
 // max |w| over count floats, this block's share (blocks of a 16-wide grid row interleave 1024-float chunks): 16-byte loads, four
 // independent chains per thread (round 4, first version: one scalar load per iteration = a dependent-latency loop, 100 us for the V-Net)
-__device__ __forceinline__ float wamax_block(const float* __restrict__ w, long long count, float* red /* [4] shared */) {
+// (round 6: any block size up to 1024 -- the many-layer launch runs 1024 threads per block: with 256 the 256 x 256 x 27 layers were 27 dependent
+// trips per thread, 14.8 us at the head of both networks' forward passes)
+__device__ __forceinline__ float wamax_block(const float* __restrict__ w, long long count, float* red /* [16] shared */) {
   float m0 = 0.f, m1 = 0.f, m2 = 0.f, m3 = 0.f;
+  const int nt = blockDim.x;
   if ((reinterpret_cast<uintptr_t>(w) & 15u) == 0) {
-    const long long nv = count >> 2, stride = 16LL * 256;
-    long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nv = count >> 2, stride = 16LL * nt;
+    long long i = (long long)blockIdx.x * nt + threadIdx.x;
     for (; i + 3 * stride < nv; i += 4 * stride) {
       const float4 a = ld4(w + i * 4), b = ld4(w + (i + stride) * 4), c = ld4(w + (i + 2 * stride) * 4), d = ld4(w + (i + 3 * stride) * 4);
       m0 = fmaxf(m0, fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w))));
@@ -850,19 +855,21 @@ __device__ __forceinline__ float wamax_block(const float* __restrict__ w, long l
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < (int)(count & 3)) m1 = fmaxf(m1, fabsf(w[(nv << 2) + threadIdx.x]));
   } else {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < count; i += 16LL * 256) m0 = fmaxf(m0, fabsf(w[i]));
+    for (long long i = (long long)blockIdx.x * nt + threadIdx.x; i < count; i += 16LL * nt) m0 = fmaxf(m0, fabsf(w[i]));
   }
   float m = fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
   __syncthreads();
-  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float r = red[0];
+  for (int k = 1; k < (nt >> 6); ++k) r = fmaxf(r, red[k]);
+  return r;
 }
 
 // max |w| of a layer in 16 per-block partials -> header[1 .. 16] of its pack (no atomics, nothing to zero): the packers read them
-__global__ __launch_bounds__(256) void k_wamax(const float* __restrict__ w, long long count, float* __restrict__ hdr) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void k_wamax(const float* __restrict__ w, long long count, float* __restrict__ hdr) {
+  __shared__ float red[16];
   const float m = wamax_block(w, count, red);
   if (threadIdx.x == 0) hdr[1 + blockIdx.x] = m;
   if (blockIdx.x == 0 && threadIdx.x >= 17 && threadIdx.x < kPackHeaderFloats) hdr[threadIdx.x] = 0.f;      // reserved words: defined contents
@@ -873,8 +880,8 @@ struct PackDesc { const float* w; float* wp; int Cout, Cin, T, K16, N16, dgrad; 
 static constexpr int kMaxPackDescs = 512;
 
 // max |w| of every layer of the descriptor list: block (b, di) leaves the b-th of 16 partial maxima in header[1 + b] of desc di's pack
-__global__ __launch_bounds__(256) void k_wamax_many(const PackDesc* __restrict__ descs) {
-  __shared__ float red[4];
+__global__ __launch_bounds__(1024) void k_wamax_many(const PackDesc* __restrict__ descs) {
+  __shared__ float red[16];
   const PackDesc d = descs[blockIdx.y];
   float* hdr = d.wp + pack_off_hdr(d.T, d.K16, d.N16);
   // bit 11 of the descriptor's last word (round 6): "the previous descriptor packs the SAME weight tensor" (the dgrad twin behind its forward
@@ -1454,11 +1461,11 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
   const int grid = (int)((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
   const long long count = (long long)Cout * Cin * T;
   if (wp_fwd) {
-    hipLaunchKernelGGL(k_wamax, dim3(16), dim3(256), 0, (hipStream_t)stream, w, count, wp_fwd + pack_off_hdr(T, Ci16, Co16));
+    hipLaunchKernelGGL(k_wamax, dim3(16), dim3(1024), 0, (hipStream_t)stream, w, count, wp_fwd + pack_off_hdr(T, Ci16, Co16));
     hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_fwd, Cout, Cin, T, Ci16, Co16, 0);
   }
   if (wp_dgrad) {
-    hipLaunchKernelGGL(k_wamax, dim3(16), dim3(256), 0, (hipStream_t)stream, w, count, wp_dgrad + pack_off_hdr(T, Co16, Ci16));
+    hipLaunchKernelGGL(k_wamax, dim3(16), dim3(1024), 0, (hipStream_t)stream, w, count, wp_dgrad + pack_off_hdr(T, Co16, Ci16));
     hipLaunchKernelGGL(k_pack_conv3, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wp_dgrad, Cout, Cin, T, Co16, Ci16, 1);
   }
   BCP_CHECK_LAUNCH("bcp_conv3_pack_weight");
@@ -1469,7 +1476,7 @@ extern "C" int bcp_conv3_pack_weight(const float* w, float* wp_fwd, float* wp_dg
 extern "C" int bcp_conv3_pack_many(const void* descs_dev, int n, void* stream) {
   BCP_REQUIRE(descs_dev && n > 0 && n <= kMaxPackDescs, "bcp_conv3_pack_many: need 1..%d descriptors", kMaxPackDescs);
   static_assert(sizeof(PackDesc) == 40, "descriptor layout is part of the ABI");
-  hipLaunchKernelGGL(k_wamax_many, dim3(16, n), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
+  hipLaunchKernelGGL(k_wamax_many, dim3(16, n), dim3(1024), 0, (hipStream_t)stream, (const PackDesc*)descs_dev);
   // (2048 workgroups: the V-Net's 84 layers are 1368 work units of one 16 x 16 x taps block each -- with 1024 workgroups a third of them
   //  did two units and the launch lasted as long as those)
   hipLaunchKernelGGL(k_pack_conv3_many, dim3(2048), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)descs_dev, n, options().pack_sections);

@@ -746,6 +746,23 @@ def main():
             from bcp_amd.networks.unet import UNet_2d as _un2
             _un2.skip_in_concat = bool(int(v))
             continue
+        if k in ("wgrad_cumask", "teacher_cumask"):      # MEASUREMENT ONLY: the side stream as a CU-masked stream (hipExtStreamCreateWithCUMask); v = 8 hex words "w0:w1:..:w7", bit = CU
+            import ctypes as _C
+            _hip = _C.CDLL("libamdhip64.so")
+            words = [int(w, 16) for w in v.split(":")]
+            arr = (_C.c_uint32 * len(words))(*words)
+            st = _C.c_void_p()
+            rc = _hip.hipExtStreamCreateWithCUMask(_C.byref(st), len(words), arr)
+            assert rc == 0, f"hipExtStreamCreateWithCUMask failed: {rc}"
+            ext = torch.cuda.ExternalStream(st.value, device=dev)
+            if k == "wgrad_cumask":
+                from bcp_amd.networks._hipnet import HipNet as _hn7
+                _hn7._side_streams[dev] = ext
+            else:
+                from bcp_amd import train_step as _ts7
+                _ts7._SIDE[dev] = ext
+            print(f"[bench] {k}: {sum(bin(w).count('1') for w in words)} CUs", file=sys.stderr)
+            continue
         if k == "wgrad_defer":        # host-side switch (networks/VNet.py, unet.py): small layers' weight gradients fork in batches of this many
             from bcp_amd.networks.VNet import VNet as _vn6
             from bcp_amd.networks.unet import UNet_2d as _un6
