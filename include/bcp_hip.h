@@ -47,7 +47,8 @@ int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
  * (csrc/common.h: conv3_p, splitk, res_pcu, res_nt, res_tile2d_vox, conv3_cfg, wgrad_nt, wgrad_tile, tn_groups, cc_tile,
- * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles; norm_slabs, conv3_xcd); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
+ * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles; norm_slabs, conv3_xcd; round 6: norm_fuse_fin, norm_own,
+ * wgrad_reduce_flat, and the MEASUREMENT-ONLY whatif bits that leave launches out -- wrong results, for pricing a change); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
  * HOST strings.  NOT thread-safe and not per-stream: ONE Options struct per process, read by every launch on every stream and
  * device.  Set options before work is enqueued, never concurrently with launches from another thread (the launch entry points
  * themselves are re-entrant across streams / devices as long as the options stay put). */
@@ -131,7 +132,10 @@ int bcp_dice_prob_bwd(const float* probs, long long cstride, long long vstride, 
  *      Elementwise Dropout (nn.Dropout, unet.py:23): either elem_mask (uint8 keep bits, [rows][C]) or -- round 4 -- mask_seed_or_null +
  *      mask_p_keep: the keep bit of element i is EVALUATED in the kernels from the 64-bit seed in device memory, exactly the bit
  *      bcp_bernoulli_dev(out, n, p_keep, ., as_u8 = 1, seed_dev) would write at out[i]; forward and backward of a layer get the same seed
- *      and no mask tensor exists.  Both NULL: no elementwise dropout.  elem_scale = 1 / (1 - p) either way. */
+ *      and no mask tensor exists.  Both NULL: no elementwise dropout.  elem_scale = 1 / (1 - p) either way.
+ *      Launches (round 6): statistics pass -> finalize -> apply pass; where the statistics pass leaves <= 128 partial rows per group and
+ *      C <= 256 (tensors of a few MB) the apply pass reduces them itself and there is no finalize launch (option norm_fuse_fin; the
+ *      fp64 sums are then added in a different fixed order: the statistics can differ in the last bit, deterministically). */
 size_t bcp_norm_workspace_bytes(int G, long long rows_per_group, int C);
 int bcp_norm_fwd(const float* y, int G, long long rows_per_group, int C, const float* gamma, const float* beta, float* running_mean,
                  float* running_var, float momentum, float eps, int act, const float* chan_scale, long long rows_per_sample,
