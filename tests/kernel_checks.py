@@ -959,6 +959,50 @@ def check_wgrad_reduce_flat(ops, dev):
         ops.set_option("wgrad_reduce_flat")
 
 
+def check_norm_fuse_fin(ops, dev):
+    """the apply passes that finalise the statistics themselves (k_norm_apply_fin / k_norm_bwd_apply_fin, option norm_fuse_fin, the product
+    default) against the finalize-launch chain on the same inputs at the V-Net's deep shapes: grouped BatchNorm with running statistics,
+    Dropout3d channel scale and a skip add, plain tensors and split-K slabs -- activations / gradients to 1e-6 of the tensor's |max|, statistics
+    and running statistics to 1e-6 relative (the fp64 partial rows are added in another fixed order), and twice the same bits"""
+    rng = np.random.default_rng(77)
+    for (N, Cc, sp, G, nslab) in ((2, 128, (14, 14, 10), 2, 4), (2, 256, (7, 7, 5), 2, 2), (2, 64, (28, 28, 20), 2, 0), (2, 32, (1, 24, 40), 1, 0)):
+        parts = [R(rng, N, *sp, Cc) * (1.5 if k == 0 else 0.3) + (0.3 if k == 0 else 0.0) for k in range(max(nslab, 1))]
+        bias = R(rng, Cc) * 0.1 if nslab else None
+        gamma = torch.from_numpy(rng.uniform(0.5, 1.5, Cc).astype(np.float32)).to(dev)
+        beta = torch.from_numpy(rng.uniform(-0.3, 0.3, Cc).astype(np.float32)).to(dev)
+        cs = torch.from_numpy(((rng.random((N, Cc)) < 0.5) * 2.0).astype(np.float32)).to(dev)
+        res = R(rng, N, *sp, Cc).to(dev)
+        dparts = [R(rng, N, *sp, Cc) * (1.0 if k == 0 else 0.2) for k in range(max(nslab, 1))]
+        src = torch.stack(parts).to(dev) if nslab else parts[0].to(dev)
+        dsrc = torch.stack(dparts).to(dev) if nslab else dparts[0].to(dev)
+
+        def run():
+            rm, rv = torch.zeros(Cc).to(dev), torch.ones(Cc).to(dev)
+            if nslab:
+                a, st, ycl = ops.norm_fwd_slabs(src, nslab, bias.to(dev), G, gamma, beta, rm, rv, H.ACT_RELU, chan_scale=cs, residual=res)
+            else:
+                ycl = src
+                a, st = ops.norm_fwd(ycl, G, gamma, beta, rm, rv, H.ACT_RELU, chan_scale=cs, residual=res)
+            dg, db = torch.full((Cc,), 3.0).to(dev), torch.full((Cc,), -2.0).to(dev)
+            if nslab:
+                dy, _ = ops.norm_bwd_slabs(ycl, dsrc, nslab, G, st, H.ACT_RELU, dg, db, True, chan_scale=cs)
+            else:
+                dy = ops.norm_bwd(ycl, dsrc, G, st, H.ACT_RELU, dg, db, True, chan_scale=cs)
+            return [t.detach().cpu().clone() for t in (a, st, rm, rv, dy, dg, db)]
+
+        fused = run()
+        again = run()
+        ops.set_option("norm_fuse_fin", 0)
+        try:
+            chain = run()
+        finally:
+            ops.set_option("norm_fuse_fin")
+        tag = f"norm_fuse_fin C={Cc} sp={sp} G={G} slabs={nslab}"
+        for name, f, f2, c in zip(("a", "stats", "running_mean", "running_var", "dy", "dgamma", "dbeta"), fused, again, chain):
+            assert torch.equal(f, f2), f"{tag}: {name} differs between two launches"
+            close(f, c, rtol=1e-6, atol_scale=1e-6, msg=f"{tag} {name}")
+
+
 def check_norm_own(ops, dev):
     """the one-launch norm of the smallest levels (k_norm_own_fwd / _bwd; library option norm_own, off in the product: measured, not adopted):
     every norm check with it forced on -- BatchNorm / grouped BatchNorm (both groups in one workgroup, running statistics and parameter
@@ -1821,7 +1865,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("wgrad_reduce_flat", "norm_own", "inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
+ALL_CHECKS = ("wgrad_reduce_flat", "norm_own", "norm_fuse_fin", "inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):
