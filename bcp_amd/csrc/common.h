@@ -72,10 +72,12 @@ struct Options {
   int wgrad_b6_deep_slots = 0;  // ... workgroups the tile groups are cut for (0 = 256)
   int wgrad_b6_deep_tile = 1;   // ... 1 = 128-voxel tiles (4x8x4: half the tiles to walk; 7x7x5 x 256 direct 23.7 vs 32.0 us), 0 = 64-voxel tiles (2x8x4, rounds 2-5)
   int k2_stats = 2;         // round 6: k2s2 / transposed conv forwards leave the norm statistics of their output (k_gemm_nn<.., STATS>): 2 = where the output is >= 2^24 elements (the top level: the pass saved is 19-23 us, the epilogue costs ~11 us at every level; LA 786.9 -> 789.6, pancreas 850.0 -> 853.8 volumes/s, interleaved A/B), 1 = wherever the shape allows (788.2 / 848.2), 0 = the norm's own statistics pass
-  int up_recompute = 0;     // round 6, measured and NOT adopted (kept with its kernel / network checks): the transposed conv + its norm with the conv output recomputed instead of stored (bcp_up_fwd_norm / bcp_up_norm_bwd): 2 = where that output is >= 2^24 elements (the top V-Net level), 1 = wherever the shape allows, 0 = off.  640 MB less per LA step and SLOWER: 788.6 (off) -> 768.1 volumes/s (2), pancreas 849.5 -> 837.1 (gpurun_out/r06_s21) -- the GEMM passes move their bytes at ~3.3 TB/s where the streaming norm passes they replace run at 5+
+  int up_recompute = 0;     // (the host takes it only in forwards without a backward pass unless VNet.UP_RECOMPUTE_GRAD: teacher-only also measured no faster, gpurun_out/r06_s50) round 6, measured and NOT adopted (kept with its kernel / network checks): the transposed conv + its norm with the conv output recomputed instead of stored (bcp_up_fwd_norm / bcp_up_norm_bwd): 2 = where that output is >= 2^24 elements (the top V-Net level), 1 = wherever the shape allows, 0 = off.  640 MB less per LA step and SLOWER: 788.6 (off) -> 768.1 volumes/s (2), pancreas 849.5 -> 837.1 (gpurun_out/r06_s21) -- the GEMM passes move their bytes at ~3.3 TB/s where the streaming norm passes they replace run at 5+
   int k2_bwd_stats = 0;     // round 6, measured and NOT adopted (kept for the record and its kernel check): the k2s2 / transposed-conv DGRADS leave the backward statistics of the norm layer in front of them (k_gemm_nn<.., 2>, bcp_down_dgrad_bwdstats / bcp_up_dgrad_bwdstats).  2 = where the output is >= 2^22 elements, 1 = wherever the shape allows, 0 = the norm's own pass (k_col_partial<1>).  LA 788.2 (off) / 786.9 (1) / 784.2 (2), pancreas 853.0 / 852.3 / 849.4 volumes/s (gpurun_out/r06_s16): the epilogue re-reads y, so all it saves is the da read, and it costs the GEMM its occupancy
   int norm_fuse_fin = 1;    // round 6: norm layers whose statistics pass leaves <= 128 partial rows per group (the deep levels): the apply pass finalises the statistics itself (k_norm_apply_fin / k_norm_bwd_apply_fin), no finalize launch.  0: finalize launches everywhere
   int norm_fin_rows = 128;   // ... partial rows per group the slab-summing statistics pass leaves in front of a fused apply pass (128: as without it)
+  int norm_apply_cap = 2048;   // round 6 (measurement switches): workgroups per apply-pass launch at most ...
+  int norm_apply_vec = 4;      // ... and float4 per thread the grid is sized for (4 = one unrolled trip; 1 = every thread one float4, no loop)
   int wgrad_reduce_flat = 1;   // round 6: many-group weight-gradient slab sums read slab-contiguous float4 (k_wgrad_reduce_flat).  0: k_wgrad_reduce_deep
   int norm_own = 0;         // round 6, measured and NOT adopted (kept with its kernel checks): norm layers with a few hundred rows per group (LA 7x7x5, pancreas 6^3) in ONE launch (k_norm_own_fwd / _bwd: a 1024-thread workgroup owns an 8..32-channel chunk of all rows).  LA 800.2 (on) vs 800.7 (off), 32-channel chunks 804.4 vs 810.4 volumes/s (gpurun_out/r06_s35, s36): the statistics pass + fused apply pass it replaces spread over 4x the workgroups, and 1024-thread workgroups wait for a whole CU beside the other stream's convs
   int whatif = 0;           // MEASUREMENT ONLY (wrong results): bit 0 = no finalize launches of the norm layers, bit 1 = no finalize and no apply launches where rows per group <= 4096, bit 2 = no largest-CC launches, bit 3 = no conv / k2 weight-gradient launches, bit 4 = no forward / backward apply pass at >= 100000 rows per group, bit 5 = no backward statistics pass there (prices a change before it is built)

@@ -1110,8 +1110,9 @@ static inline int norm_blocks_slabs(long long rows_per_group, int C, int G, bool
 }
 
 static inline int apply_grid(long long nvec, int nseg) {
-  long long g = (nvec + 256 * 4 - 1) / (256 * 4);          // 4 float4 per thread per trip
-  const long long cap = 2048 / nseg < 1 ? 1 : 2048 / nseg;
+  const int vec = options().norm_apply_vec > 0 ? options().norm_apply_vec : 4, capw = options().norm_apply_cap > 0 ? options().norm_apply_cap : 2048;
+  long long g = (nvec + 256 * vec - 1) / (256 * vec);      // 4 float4 per thread per trip
+  const long long cap = capw / nseg < 1 ? 1 : capw / nseg;
   if (g > cap) g = cap;
   return (int)(g < 1 ? 1 : g);
 }

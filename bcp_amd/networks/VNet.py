@@ -31,6 +31,7 @@ class _Layer:
 
 
 class VNet(HipNet):
+    UP_RECOMPUTE_GRAD = False   # (round 6) the recomputing transposed conv + norm (library option up_recompute) also in forwards that save for a backward pass: measured slower there (both passes of the norm's backward recompute the conv); forwards WITHOUT a backward pass -- the teacher's -- take it wherever the library serves the shape
     WGRAD_DEFER = 2      # (round 6) small layers' weight gradients cross to the side stream in batches of this many layers (1: every layer forks, rounds 2-5)
     fuse_c1 = True       # first layer: conv + norm + ReLU with recompute (bcp_conv3_c1_norm_fwd / _bwd); False: conv -> y -> norm passes
     fuse_head = True     # the 1x1x1 head applies the last conv's norm + ReLU + Dropout3d itself (bcp_pw16_fwd_norm); False: separate apply pass
@@ -222,7 +223,7 @@ class VNet(HipNet):
                 else:
                     y = ops.conv3_fwd(h, wf, b.data, L.cout, 3)          # eval-mode BatchNorm needs no batch statistics
             elif (L.kind == "up" and self.training and L.drop is None and not (li == last and fuse_head) and not getattr(self, "_keep_saved", False)
-                  and ops.up_norm_rows(h.shape, L.cout, G) > 0):
+                  and (not save or self.UP_RECOMPUTE_GRAD) and ops.up_norm_rows(h.shape, L.cout, G) > 0):
                 # (round 6) transposed conv + norm + ReLU + skip add with recompute (bcp_up_fwd_norm): the pre-norm tensor is never written
                 bp, _ = self.k2_packed(("k2", li), save)
                 fused_up, y = True, None

@@ -763,6 +763,10 @@ def main():
                 _ts7._SIDE[dev] = ext
             print(f"[bench] {k}: {sum(bin(w).count('1') for w in words)} CUs", file=sys.stderr)
             continue
+        if k == "up_recompute_grad":  # host-side switch (networks/VNet.py): the recomputing transposed conv + norm also in forwards that save for a backward pass
+            from bcp_amd.networks.VNet import VNet as _vn9
+            _vn9.UP_RECOMPUTE_GRAD = bool(int(v))
+            continue
         if k == "wgrad_defer":        # host-side switch (networks/VNet.py, unet.py): small layers' weight gradients fork in batches of this many
             from bcp_amd.networks.VNet import VNet as _vn6
             from bcp_amd.networks.unet import UNet_2d as _un6

@@ -112,11 +112,14 @@ def test_up_recompute_forced_everywhere(emu_ops):
     bcp_up_norm_bwd -- every gradient tensor within 1e-4 of the fp64 oracle linearised on the HIP activation pattern"""
     from bcp_amd.utils import BCP_utils as BU
     BU.set_test_ops(emu_ops)
+    from bcp_amd.networks.VNet import VNet as _VN
     emu_ops.set_option("up_recompute", 1)
+    _VN.UP_RECOMPUTE_GRAD = True      # (the product takes the recomputing pair only in forwards without a backward pass: the teacher's)
     try:
         NC.check_vnet_pattern_grads(emu_ops, CPU, "la", (32, 32, 16))
     finally:
         emu_ops.set_option("up_recompute")
+        _VN.UP_RECOMPUTE_GRAD = False
 
 
 def test_partial_weight_packs(emu_ops):

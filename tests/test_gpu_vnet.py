@@ -205,13 +205,16 @@ def test_up_recompute_forced_everywhere(ops):
     """round 6 (built, measured, off by default: DESIGN.md section 5): every transposed conv + norm the shape allows on the recomputing pair
     bcp_up_fwd_norm / bcp_up_norm_bwd -- gradients within 1e-4 of the fp64 oracle on the HIP activation pattern (BatchNorm and InstanceNorm
     V-Nets), and replays == the eager path with it on"""
+    from bcp_amd.networks.VNet import VNet as _VN
     ops.set_option("up_recompute", 1)
+    _VN.UP_RECOMPUTE_GRAD = True      # (the product takes the recomputing pair only in forwards without a backward pass: the teacher's)
     try:
         NC.check_vnet_pattern_grads(ops, DEV, "la", (32, 32, 16))
         NC.check_vnet_pattern_grads(ops, DEV, "pancreas", (32, 32, 32))
         NC.check_launch_plans(ops, DEV, steps=3, cases=(("la", True), ("pancreas", True)))
     finally:
         ops.set_option("up_recompute")
+        _VN.UP_RECOMPUTE_GRAD = False
 
 
 def test_partial_weight_packs(ops):
