@@ -76,6 +76,9 @@ struct Options {
   int k2_bwd_stats = 0;     // round 6, measured and NOT adopted (kept for the record and its kernel check): the k2s2 / transposed-conv DGRADS leave the backward statistics of the norm layer in front of them (k_gemm_nn<.., 2>, bcp_down_dgrad_bwdstats / bcp_up_dgrad_bwdstats).  2 = where the output is >= 2^22 elements, 1 = wherever the shape allows, 0 = the norm's own pass (k_col_partial<1>).  LA 788.2 (off) / 786.9 (1) / 784.2 (2), pancreas 853.0 / 852.3 / 849.4 volumes/s (gpurun_out/r06_s16): the epilogue re-reads y, so all it saves is the da read, and it costs the GEMM its occupancy
   int norm_fuse_fin = 1;    // round 6: norm layers whose statistics pass leaves <= 128 partial rows per group (the deep levels): the apply pass finalises the statistics itself (k_norm_apply_fin / k_norm_bwd_apply_fin), no finalize launch.  0: finalize launches everywhere
   int norm_fin_rows = 128;   // ... partial rows per group the slab-summing statistics pass leaves in front of a fused apply pass (128: as without it)
+  int gemm_pipe = 1;        // round 6: k_gemm_nn instances that walk several row blocks per workgroup (the statistics / recompute epilogues) request the next block's operands under the current block's MFMAs and epilogue.  0: block after block
+  int gemm_stat_r = 0;      // ... measurement switch: row blocks per workgroup of those instances (0 = stat_plan's choice: <= ~1024 partial rows per group, >= 512 workgroups)
+  int gemm_walk = 0;        // ... measurement switch: plain k_gemm_nn launches of >= 2 W workgroups as ~W walking workgroups (k_gemm_nn<.., 7>); 0 = one row block per workgroup
   int norm_apply_cap = 2048;   // round 6 (measurement switches): workgroups per apply-pass launch at most ...
   int norm_apply_vec = 4;      // ... and float4 per thread the grid is sized for (4 = one unrolled trip; 1 = every thread one float4, no loop)
   int wgrad_reduce_flat = 1;   // round 6: many-group weight-gradient slab sums read slab-contiguous float4 (k_wgrad_reduce_flat).  0: k_wgrad_reduce_deep

@@ -95,6 +95,9 @@ struct GemmStats {
   const float* aux;      // 4: residual (nullable), 5 / 6: da -- laid out like the output
   const float* c1c2;     // 6: float[2][G][C]
   float* amax;           // 4: nullable |max| slots of the activation written
+  int pipe;              // (round 6) a workgroup that walks R > 1 row blocks requests the NEXT block's first A / B stage under the MFMAs and the
+                         // epilogue of the current one (the walk was a serial chain per block: load -> LDS -> MFMA -> store, nothing in flight
+                         // during two of its four phases); same arithmetic, same bits
 };
 
 template <int NT, int STATS = 0>
@@ -121,9 +124,12 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
       for (int r = 0; r < 4; ++r) { p1[nt][r] = 0.f; p2[nt][r] = 0.f; }
   }
 
-  auto tile = [&](const int m0) __attribute__((always_inline)) {
   // staging role: thread -> (row, 16-B part of a 16-k half stage)
   const int srow = threadIdx.x >> 2, spart = threadIdx.x & 3;
+  float4 pa[2], pb[NB4];
+  const bool b_static = K <= KC;                     // one K stage: the B slab in the LDS serves every row block of the walk
+  // pre: this tile's first stage is already in (pa, pb) -- requested under the previous tile (pipe); m_next >= 0: request the next tile's
+  auto tile = [&](const int m0, const bool pre, const int m_next) __attribute__((always_inline)) {
   const bool srow_ok = (m0 + srow) < M;
   const float* arow = A.p + (srow_ok ? A.base(m0 + srow) : 0) + spart * 4;
 
@@ -131,39 +137,46 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  float4 pa[2], pb[NB4];
-  auto fetch = [&](int kc) {
+  auto fetch = [&](const float* ar, const bool ok, const int kc, const bool with_b) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       pa[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (srow_ok && kc + 16 * h < K) pa[h] = ld4(arow + A.off16(kc + 16 * h));   // off16 argument is block-uniform
+      if (ok && kc + 16 * h < K) pa[h] = ld4(ar + A.off16(kc + 16 * h));   // off16 argument is block-uniform
     }
+    if (with_b) {
 #pragma unroll
-    for (int u = 0; u < NB4; ++u) {
-      const int q = threadIdx.x + u * 256;
-      pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (q < 8 * CT) {
-        const int co = q % CT, kq = q / CT;
-        if (kc + kq * 4 < K) pb[u] = ld4(Bp + (((long long)(kc >> 2) + kq) * N + n0 + co) * 4);
+      for (int u = 0; u < NB4; ++u) {
+        const int q = threadIdx.x + u * 256;
+        pb[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < 8 * CT) {
+          const int co = q % CT, kq = q / CT;
+          if (kc + kq * 4 < K) pb[u] = ld4(Bp + (((long long)(kc >> 2) + kq) * N + n0 + co) * 4);
+        }
       }
     }
   };
-  auto stash = [&]() {
+  auto stash = [&](const bool with_b) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) st4(As + srow * AS + h * 16 + spart * 4, pa[h]);
+    if (with_b) {
 #pragma unroll
-    for (int u = 0; u < NB4; ++u) {
-      const int q = threadIdx.x + u * 256;
-      if (q < 8 * CT) st4(Bs + q * 4, pb[u]);
+      for (int u = 0; u < NB4; ++u) {
+        const int q = threadIdx.x + u * 256;
+        if (q < 8 * CT) st4(Bs + q * 4, pb[u]);
+      }
     }
   };
 
-  fetch(0);
-  stash();
+  if (!pre) fetch(arow, srow_ok, 0, true);
+  stash(!(pre && b_static));
   __syncthreads();
   for (int kc = 0; kc < K; kc += KC) {
     const bool has_next = kc + KC < K;
-    if (has_next) fetch(kc + KC);
+    if (has_next) fetch(arow, srow_ok, kc + KC, true);
+    else if (m_next >= 0) {                          // the next row block's first stage, in flight under these MFMAs and the epilogue below
+      const bool ok_n = (m_next + srow) < M;
+      fetch(A.p + (ok_n ? A.base(m_next + srow) : 0) + spart * 4, ok_n, 0, !b_static);
+    }
 #pragma unroll
     for (int kq = 0; kq < KC / 16; ++kq) {           // 16 k per (a, b) fragment pair
       const float4 a = ld4(As + (wave * 16 + li) * AS + kq * 16 + lg * 4);
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
     }
     if (!has_next) break;
     __syncthreads();
-    stash();
+    stash(true);
     __syncthreads();
   }
   // epilogue: lane (li, lg) holds row m0 + wave*16 + li, columns n0 + nt*16 + lg*4 .. + 3
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
         v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
       }
       if (accumulate) { const float4 p = ld4(o); v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w; }
-      if constexpr (STATS <= 2) st4(o, v);
+      if constexpr (STATS <= 2 || STATS == 7) st4(o, v);      // (7: the plain launch as a row-block walk, nothing else in the epilogue)
       if constexpr (STATS == 3) {
         p1[nt][0] += v.x; p2[nt][0] = fmaf(v.x, v.x, p2[nt][0]);
         p1[nt][1] += v.y; p2[nt][1] = fmaf(v.y, v.y, p2[nt][1]);
@@ -270,12 +283,16 @@ __global__ __launch_bounds__(256) void k_gemm_nn(RowMap A, const float* __restri
   };
 
   if constexpr (STATS == 0) {
-    tile(blockIdx.x * 64);
+    tile(blockIdx.x * 64, false, -1);
   } else {
     const int rb0 = blockIdx.x * st.R, nblk = (M + 63) >> 6;
-    for (int rb = rb0; rb < rb0 + st.R && rb < nblk; ++rb) {
-      if (rb > rb0) __syncthreads();               // every wave is done with the previous block's LDS stages
-      tile(rb * 64);
+    const int rb1 = rb0 + st.R < nblk ? rb0 + st.R : nblk;
+    const bool pipe = st.pipe != 0;
+    for (int rb = rb0; rb < rb1; ++rb) {
+      // every wave is done with the previous block's LDS stages.  LDS-only barrier: __syncthreads() would also drain this wave's epilogue
+      // stores and the next block's operands already in flight
+      if (rb > rb0) BCP_LDS_BARRIER();
+      tile(rb * 64, pipe && rb > rb0, (pipe && rb + 1 < rb1) ? (rb + 1) * 64 : -1);
     }
     if constexpr (STATS == 4) {
       if (st.amax) { __syncthreads(); block_amax_publish(amax_o, st.amax); }
@@ -856,7 +873,22 @@ static int launch_nn(RowMap A, const float* Bp, const float* bias, RowMap C, int
   const int rb = cdiv(M, 64);
   const int nt = pick_nt(N, rb);
   const dim3 grid(rb, N / (nt * 16));
-  const GemmStats none{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr};
+  const GemmStats none{nullptr, 0, 0, 0, 0, 0, nullptr, nullptr, 0, 0, nullptr, nullptr, nullptr, 0};
+  // (round 6, option gemm_walk = W > 0) launches of >= 2 W workgroups as ~W workgroups that walk R <= 16 row blocks each with the next block's
+  // operands in flight (k_gemm_nn<.., 7>: the statistics instances' walk without their epilogue)
+  const int walk = options().gemm_walk;
+  if (walk > 0 && (long long)rb * grid.y >= 2LL * walk) {
+    int R = cdiv((long long)rb * grid.y, walk);
+    if (R > 16) R = 16;
+    GemmStats st = none;
+    st.R = R;
+    st.pipe = options().gemm_pipe;
+    const dim3 g2(cdiv(rb, R), grid.y);
+    if (nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, 7>), g2, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+    else if (nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, 7>), g2, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+    else hipLaunchKernelGGL((k_gemm_nn<1, 7>), g2, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
+    return 0;
+  }
   if (nt == 4) hipLaunchKernelGGL((k_gemm_nn<4>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
   else if (nt == 2) hipLaunchKernelGGL((k_gemm_nn<2>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
   else hipLaunchKernelGGL((k_gemm_nn<1>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, none);
@@ -878,6 +910,7 @@ static bool stat_plan(StatPlan& p, int M, int N, int Cout, int groups) {
   // as many row blocks per workgroup as keep <= ~1024 partial rows per group and >= 512 workgroups in the launch
   int R = 1;
   while (R < 16 && bpg % (R * 2) == 0 && ((long long)(bpg / R) * p.ysets > 1024) && (long long)(bpg / (R * 2)) * groups * gy >= 512) R *= 2;
+  { const int v = options().gemm_stat_r; if (v > 0 && v <= 16 && bpg % v == 0) R = v; }      // measurement switch
   p.R = R;
   p.wpg = bpg / R;
   p.nb = p.wpg * p.ysets;
@@ -891,7 +924,7 @@ static int launch_nn_mode(RowMap A, const float* Bp, const float* bias, RowMap C
   StatPlan p;
   if (!stat_plan(p, M, N, Cch, groups)) return 0;
   const dim3 grid(p.wpg * groups, N / (p.nt * 16));
-  const GemmStats st{partial, p.nb, Cch, p.wpg, p.R, p.ysets, by, bstats, groups, act, aux, c1c2, amax};
+  const GemmStats st{partial, p.nb, Cch, p.wpg, p.R, p.ysets, by, bstats, groups, act, aux, c1c2, amax, options().gemm_pipe};
   if (p.nt == 4) hipLaunchKernelGGL((k_gemm_nn<4, MODE>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
   else if (p.nt == 2) hipLaunchKernelGGL((k_gemm_nn<2, MODE>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);
   else hipLaunchKernelGGL((k_gemm_nn<1, MODE>), grid, dim3(256), 0, s, A, Bp, bias, C, M, K, N, bias_mod, accumulate, st);

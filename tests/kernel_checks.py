@@ -759,10 +759,51 @@ def check_k2_stats(ops, dev):
     rng = np.random.default_rng(11)
     ops.set_option("k2_stats", 1)       # every shape the variant serves (the product default, 2, keeps it to outputs of >= 2^24 elements)
     try:
-        _check_k2_stats(ops, dev, rng)
+        # (round 6) row blocks per workgroup forced (gemm_stat_r: the small cases walk several blocks too), with and without the next block's
+        # operands requested under the current one (gemm_pipe) -- one K stage (B stays in the LDS) and several
+        for r, pipe in ((0, 1), (2, 1), (4, 1), (2, 0)):
+            ops.set_option("gemm_stat_r", r)
+            ops.set_option("gemm_pipe", pipe)
+            _check_k2_stats(ops, dev, np.random.default_rng(11))
     finally:
         ops.set_option("k2_stats")
+        ops.set_option("gemm_stat_r")
+        ops.set_option("gemm_pipe")
     assert ops.k2_stat_rows(1, (2, 4, 8, 8, 32), 16, 2) == 0 and (dev.type != "cuda" or ops.k2_stat_rows(1, (2, 56, 56, 40, 32), 16, 2) > 0)
+
+
+def check_gemm_walk(ops, dev):
+    """round 6 (measurement switch gemm_walk): the plain k2s2 / transposed conv launches as workgroups that walk several row blocks with the
+    next block's operands in flight (k_gemm_nn<.., 7>) -- forward, dgrad and dgrad accumulating into a skip gradient bit-identical to the
+    one-block-per-workgroup launch, one K stage and several, ragged last walk"""
+    rng = np.random.default_rng(12)
+    cases = [(0, 2, 16, 32, (8, 16, 16)), (0, 1, 32, 64, (4, 12, 20)), (1, 2, 32, 16, (4, 8, 8)), (1, 1, 64, 32, (6, 10, 6)), (1, 2, 128, 64, (2, 4, 8))]
+    if dev.type == "cuda":
+        cases += [(1, 2, 32, 16, (16, 32, 32)), (0, 2, 16, 32, (32, 64, 64))]
+    for kind, N, Cin, Cout, sp in cases:
+        x = to_cl(R(rng, N, Cin, *sp)).to(dev)
+        w = ((R(rng, Cout, Cin, 2, 2, 2) if kind == 0 else R(rng, Cin, Cout, 2, 2, 2)) * 0.1).to(dev)
+        b = (R(rng, Cout) * 0.1).to(dev)
+        bp = ops.k2_pack(w, Cin, Cout, H.PACK_DOWN_FWD if kind == 0 else H.PACK_UP_FWD)
+        bd = ops.k2_pack(w, Cin, Cout, H.PACK_DOWN_DGRAD if kind == 0 else H.PACK_UP_DGRAD)
+        fwd, dgrad = (ops.down_fwd, ops.down_dgrad) if kind == 0 else (ops.up_fwd, ops.up_dgrad)
+        res = {}
+        for walk, pipe in ((0, 1), (3, 1), (3, 0), (1, 1)):
+            ops.set_option("gemm_walk", walk)
+            ops.set_option("gemm_pipe", pipe)
+            try:
+                y = fwd(x, bp, b, Cout).clone()
+                dy = torch.sin(y * 3.0)
+                dx = dgrad(dy, bd, Cin).clone()
+                acc = torch.cos(dx * 2.0)
+                dxa = dgrad(dy, bd, Cin, out=acc, accumulate=True).clone()
+            finally:
+                ops.set_option("gemm_walk")
+                ops.set_option("gemm_pipe")
+            res[(walk, pipe)] = (y, dx, dxa)
+        for k, v in res.items():
+            for a, b0, name in zip(v, res[(0, 1)], ("fwd", "dgrad", "dgrad accumulate")):
+                assert torch.equal(a, b0), f"gemm walk kind {kind} {N}x{sp} {Cin}->{Cout} {name}: walk, pipe = {k} differs from the plain launch"
 
 
 def _check_k2_stats(ops, dev, rng):
@@ -1865,7 +1906,7 @@ def check_conv3_pipe_cold(ops, dev):
         ops.set_option("conv3_b6_flat"); ops.set_option("conv3_b6_pipe"); ops.set_option("conv3_b6")
 
 
-ALL_CHECKS = ("wgrad_reduce_flat", "norm_own", "norm_fuse_fin", "inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
+ALL_CHECKS = ("wgrad_reduce_flat", "norm_own", "norm_fuse_fin", "inline_dropout", "diceloss_class", "conv3_pipe_cold", "conv3_c1_norm", "norm_slabs", "dgrad_bwdstats", "augment_acdc", "augment", "augment_pancreas", "pack_many", "conv3_f16", "conv3_b6", "conv3_stats", "conv3_res", "norm_grouped", "mix_box", "plabel", "cc", "mixloss", "norm", "conv3", "conv3_c1", "k2", "k2_stats", "gemm_walk", "k2_bwdstats", "up_norm", "k2_chunks", "pw16_norm", "pw16_bwd_norm_bwd", "pool2d", "optim")
 
 
 def check_upsample_beside_convs(ops, dev, rounds=12, ring=64):

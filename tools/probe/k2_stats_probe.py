@@ -12,6 +12,10 @@ from bcp_amd.hip_ops import Ops  # noqa: E402
 
 ops = Ops.product()
 dev = torch.device("cuda:0")
+for a in sys.argv[1:]:                 # library options: name=value  (e.g. gemm_pipe=0 gemm_stat_r=4)
+    k, _, v = a.partition("=")
+    ops.set_option(k, int(v))
+print("OPTIONS", sys.argv[1:], flush=True)
 
 
 def timeit(fn, like, iters=20, warm=3):
