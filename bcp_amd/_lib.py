@@ -14,7 +14,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libbcp_hip.so")
 
-ABI_VERSION = 510      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
+ABI_VERSION = 511      # include/bcp_hip.h BCP_ABI_VERSION: the revision these signatures were written against
 
 P = C.c_void_p
 I = C.c_int
@@ -44,6 +44,7 @@ _SIGS = {
     "bcp_plabel_argmax4": (I, [P, P, L, P]),
     "bcp_cc_workspace_bytes": (SZ, [I, I, I, I, I]),
     "bcp_cc_largest": (I, [P, P, P, I, I, I, I, I, I, P, P]),
+    "bcp_plabel_cc_largest": (I, [P, I, F, P, P, P, I, I, I, I, I, I, P, P]),
     "bcp_mixloss_workspace_bytes": (SZ, [I, I]),
     "bcp_mixloss_fwd": (I, [P, P, P, P, P, I, I, I, I, I, I, F, F, P, P, P, P, P]),
     "bcp_mixloss_bwd": (I, [P, P, P, P, P, I, I, I, I, I, I, P, F, F, P, I, P, P]),

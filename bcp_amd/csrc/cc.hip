@@ -74,8 +74,13 @@ __device__ __forceinline__ void for_fwd_neighbours(int conn, F&& body) {
       }
 }
 
-template <int TD, int TH, int TW>
-__global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ seg, int* __restrict__ L, int* __restrict__ lsize,
+// (round 6) SRC: where a voxel's class comes from -- 0: the uint8 map `seg`; 1 / 2: straight from the network's logits (two channels +
+// threshold as k_plabel_bin, four channels as k_plabel_argmax4: common.h plabel_*_of, the same bits), the map written to `seg` on the way
+// for the launches behind this one.  The pseudo-label launch in front of the chain (21 us + a boundary on the teacher's tail, the step's
+// critical path between the forward passes and the loss) is gone.
+struct CcSrc { const float* logits; float thres; };
+template <int TD, int TH, int TW, int SRC>
+__global__ __launch_bounds__(256) void k_cc_local(uint8_t* __restrict__ seg, CcSrc src, int* __restrict__ L, int* __restrict__ lsize,
                                                   int* __restrict__ size, CcDims cd, unsigned long long* __restrict__ best, int nbest) {
   // (round 6) the selection table k_cc_select max-reduces into, three launches later: cleared here instead of by a memset launch of its own
   // on the teacher stream's tail (the step's critical path)
@@ -98,7 +103,19 @@ __global__ __launch_bounds__(256) void k_cc_local(const uint8_t* __restrict__ se
     const int d = d0 + ld, h = h0 + lh, w = w0 + lw;
     const bool in = d < cd.D && h < cd.H && w < cd.W;
     gidx[u] = in ? (int)(nbase + ((long long)d * cd.H + h) * cd.W + w) : -1;
-    const uint8_t s = in ? seg[gidx[u]] : 0;
+    uint8_t s = 0;
+    if (in) {
+      if constexpr (SRC == 0) s = seg[gidx[u]];
+      else if constexpr (SRC == 1) {
+        const float2 x = *reinterpret_cast<const float2*>(src.logits + (long long)gidx[u] * 2);
+        s = plabel_bin_of(x.x, x.y, src.thres);
+        seg[gidx[u]] = s;
+      } else {
+        const float4 x = ld4(src.logits + (long long)gidx[u] * 4);
+        s = plabel_argmax4_of(x.x, x.y, x.z, x.w);
+        seg[gidx[u]] = s;
+      }
+    }
     Ss[i] = s;
     Ls[i] = s ? i : -1;
     Cnt[i] = 0;
@@ -159,13 +176,15 @@ struct CcFace {
 };
 
 template <int TD, int TH, int TW>
-__global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ seg, int* __restrict__ L, CcDims cd) {
+__global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ seg, int* __restrict__ L, CcDims cd, int dedupe) {
   using F = CcFace<TD, TH, TW>;
   const long long V = (long long)cd.D * cd.H * cd.W;
   const long long ntiles = (long long)cd.N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
   const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= ntiles * F::NB) return;
-  const int tile = (int)(id / F::NB), bi = (int)(id % F::NB);
+  // (round 6: no early return -- every lane of a wave walks the 13 neighbour offsets in lockstep for the pair exchange below; an idle lane
+  // carries cls = 0)
+  bool live = id < ntiles * F::NB;
+  const int tile = live ? (int)(id / F::NB) : 0, bi = live ? (int)(id % F::NB) : 0;
   int ld, lh, lw;
   if (bi < F::FACE) { ld = TD - 1; lh = bi / TW; lw = bi % TW; }
   else {
@@ -178,30 +197,40 @@ __global__ __launch_bounds__(256) void k_cc_border(const uint8_t* __restrict__ s
   const int tw = tile % cd.tiles_w, th = (tile / cd.tiles_w) % cd.tiles_h;
   const int td = (tile / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d, n = tile / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
   const int d = td * TD + ld, h = th * TH + lh, w = tw * TW + lw;
-  if (d >= cd.D || h >= cd.H || w >= cd.W) return;
+  live = live && d < cd.D && h < cd.H && w < cd.W;
   const long long v = (long long)n * V + ((long long)d * cd.H + h) * cd.W + w;
-  const uint8_t cls = seg[v];
-  if (!cls) return;
+  const uint8_t cls = live ? seg[v] : 0;
   // unions go between TILE-LOCAL ROOTS (L[x] after k_cc_local, or a nearer-to-root ancestor later on): the up to 13
   // out-of-tile neighbours of one voxel mostly belong to one or two components of the neighbouring tiles, and joining the
   // same pair again costs two more pointer chases through global memory -- skip the pairs this thread has just done.
-  const int rv = L[v];
+  const int rv = cls ? L[v] : -1;
   int seen0 = -1, seen1 = -1;
+  const int lane = threadIdx.x & 63;
   for_fwd_neighbours(cd.conn, [&](int dd, int dh, int dw) {
-    const int d2 = d + dd, h2 = h + dh, w2 = w + dw;
-    if (d2 < cd.D && h2 >= 0 && h2 < cd.H && w2 >= 0 && w2 < cd.W) {
-      const bool same_tile = (ld + dd < TD) && (lh + dh >= 0) && (lh + dh < TH) && (lw + dw >= 0) && (lw + dw < TW);
-      if (!same_tile) {
-        const long long u = v + ((long long)dd * cd.H + dh) * cd.W + dw;
-        if (seg[u] == cls) {
-          const int ru = L[u];
-          if (ru != seen0 && ru != seen1) {
-            uf_union(L, rv, ru);
-            seen1 = seen0;
-            seen0 = ru;
-          }
+    int ru = -1;
+    if (cls) {
+      const int d2 = d + dd, h2 = h + dh, w2 = w + dw;
+      if (d2 < cd.D && h2 >= 0 && h2 < cd.H && w2 >= 0 && w2 < cd.W) {
+        const bool same_tile = (ld + dd < TD) && (lh + dh >= 0) && (lh + dh < TH) && (lw + dw >= 0) && (lw + dw < TW);
+        if (!same_tile) {
+          const long long u = v + ((long long)dd * cd.H + dh) * cd.W + dw;
+          if (seg[u] == cls) ru = L[u];
         }
       }
+    }
+    // (round 6) neighbouring lanes are neighbouring face voxels and mostly join the SAME pair of tile-local roots at the same offset
+    // (a noise-like map: one percolating component through every tile): a lane whose pair is the previous lane's leaves it to that lane --
+    // which joins it now, has joined it before (its own `seen`), or leaves it to ITS predecessor; the first lane of a run always acts.
+    // Hundreds of redundant find chains per tile pair were what the kernel's 70-90 us were made of.
+    bool mine = ru >= 0 && ru != seen0 && ru != seen1;
+    if (dedupe) {
+      const int pru = __shfl_up(ru, 1), prv = __shfl_up(rv, 1);
+      if (lane > 0 && ru >= 0 && pru == ru && prv == rv) mine = false;
+    }
+    if (mine) {
+      uf_union(L, rv, ru);
+      seen1 = seen0;
+      seen0 = ru;
     }
   });
 }
@@ -211,6 +240,45 @@ __global__ __launch_bounds__(256) void k_cc_count(int* __restrict__ L, const int
   for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < n; v += (long long)gridDim.x * blockDim.x) {
     const int ls = lsize[v];
     if (ls > 0) atomicAdd(&size[uf_find_c(L, (int)v)], ls);   // (leaves every tile-local root one hop from its global root)
+  }
+}
+
+// (round 6) count AND select: the atomicAdd that adds a tile-local root's size to its global root returns the root's running total; the
+// maximum over ALL running totals' keys (size << 32 | ~root) is the maximum over the FINAL ones -- every running total of a root is
+// dominated by that root's final total, which the last adder sees -- so the selection needs no pass of its own over the finished sizes
+// (k_cc_select: 17.6 us + a boundary on the critical path).  Per-thread running maxima per class, one atomicMax per class and block, as
+// k_cc_select; blockIdx.y = sample.  Order-independent: same `best` bits whatever order the atomics land in.
+__global__ __launch_bounds__(256) void k_cc_count_select(const uint8_t* __restrict__ seg, int* __restrict__ L, const int* __restrict__ lsize,
+                                                         int* __restrict__ size, unsigned long long* __restrict__ best, long long V,
+                                                         int nclass) {
+  __shared__ unsigned long long red[4][8];
+  const int sample = blockIdx.y;
+  unsigned long long loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const long long base = (long long)sample * V;
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < V; r += (long long)gridDim.x * blockDim.x) {
+    const long long v = base + r;
+    const int ls = lsize[v];
+    if (ls <= 0) continue;
+    const int root = uf_find_c(L, (int)v);                       // (leaves every tile-local root one hop from its global root)
+    const int tot = atomicAdd(&size[root], ls) + ls;
+    const unsigned long long key = ((unsigned long long)(unsigned)tot << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)root);
+    const int c = seg[v] - 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k == c && key > loc[k]) loc[k] = key;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < nclass; ++k) {
+    unsigned long long m = loc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if (lane == 0) red[wave][k] = m;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nclass) {
+    unsigned long long m = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) m = red[w][threadIdx.x] > m ? red[w][threadIdx.x] : m;
+    if (m) atomicMax(&best[(long long)sample * nclass + threadIdx.x], m);
   }
 }
 
@@ -278,16 +346,10 @@ extern "C" size_t bcp_cc_workspace_bytes(int N, int D, int H, int W, int nclass)
   return n * 3 * sizeof(int) + (size_t)N * nclass * sizeof(unsigned long long) + 64;
 }
 
-extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f32, int N, int D, int H, int W, int nclass,
-                              int connectivity, void* workspace, void* stream) {
-  if (bcp::options().whatif & 4) return BCP_OK;      // MEASUREMENT ONLY (common.h Options::whatif)
-
-  BCP_REQUIRE(seg && (out_u8 || out_f32) && workspace, "bcp_cc_largest: null pointer");
-  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && nclass >= 1 && nclass <= 8, "bcp_cc_largest: bad extents");
-  BCP_REQUIRE(connectivity >= 1 && connectivity <= 3, "bcp_cc_largest: connectivity must be 1..3 (number of axes that may differ)");
+template <int SRC>
+static int cc_run(uint8_t* seg, CcSrc src, uint8_t* out_u8, float* out_f32, int N, int D, int H, int W, int nclass, int connectivity,
+                  void* workspace, hipStream_t s) {
   const long long V = (long long)D * H * W, n = V * N;
-  BCP_REQUIRE(n < (1LL << 31), "bcp_cc_largest: volume too large for 32-bit labels");
-  hipStream_t s = (hipStream_t)stream;
   int* L = reinterpret_cast<int*>(workspace);
   int* lsize = L + n;
   int* size = lsize + n;
@@ -302,29 +364,66 @@ extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f3
   const bool big = tile_opt ? tile_opt == 2 : (n >= 512LL * 2048);
   if (D > 1 && big) {
     cd.tiles_d = cdiv(D, 8); cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 16);
-    hipLaunchKernelGGL((k_cc_local<8, 16, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
-    hipLaunchKernelGGL((k_cc_border<8, 16, 16>), dim3(border_grid(cd, CcFace<8, 16, 16>::NB)), dim3(256), 0, s, seg, L, cd);
+    hipLaunchKernelGGL((k_cc_local<8, 16, 16, SRC>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, src, L, lsize, size, cd, best, N * nclass);
+    hipLaunchKernelGGL((k_cc_border<8, 16, 16>), dim3(border_grid(cd, CcFace<8, 16, 16>::NB)), dim3(256), 0, s, seg, L, cd, options().cc_border_dedupe);
   } else if (D > 1) {
     cd.tiles_d = cdiv(D, 4); cd.tiles_h = cdiv(H, 8); cd.tiles_w = cdiv(W, 16);
-    hipLaunchKernelGGL((k_cc_local<4, 8, 16>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
-    hipLaunchKernelGGL((k_cc_border<4, 8, 16>), dim3(border_grid(cd, CcFace<4, 8, 16>::NB)), dim3(256), 0, s, seg, L, cd);
+    hipLaunchKernelGGL((k_cc_local<4, 8, 16, SRC>), dim3(N * cd.tiles_d * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, src, L, lsize, size, cd, best, N * nclass);
+    hipLaunchKernelGGL((k_cc_border<4, 8, 16>), dim3(border_grid(cd, CcFace<4, 8, 16>::NB)), dim3(256), 0, s, seg, L, cd, options().cc_border_dedupe);
   } else if (big) {
     cd.tiles_d = 1; cd.tiles_h = cdiv(H, 32); cd.tiles_w = cdiv(W, 64);
-    hipLaunchKernelGGL((k_cc_local<1, 32, 64>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
-    hipLaunchKernelGGL((k_cc_border<1, 32, 64>), dim3(border_grid(cd, CcFace<1, 32, 64>::NB)), dim3(256), 0, s, seg, L, cd);
+    hipLaunchKernelGGL((k_cc_local<1, 32, 64, SRC>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, src, L, lsize, size, cd, best, N * nclass);
+    hipLaunchKernelGGL((k_cc_border<1, 32, 64>), dim3(border_grid(cd, CcFace<1, 32, 64>::NB)), dim3(256), 0, s, seg, L, cd, options().cc_border_dedupe);
   } else {
     cd.tiles_d = 1; cd.tiles_h = cdiv(H, 16); cd.tiles_w = cdiv(W, 32);
-    hipLaunchKernelGGL((k_cc_local<1, 16, 32>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, L, lsize, size, cd, best, N * nclass);
-    hipLaunchKernelGGL((k_cc_border<1, 16, 32>), dim3(border_grid(cd, CcFace<1, 16, 32>::NB)), dim3(256), 0, s, seg, L, cd);
+    hipLaunchKernelGGL((k_cc_local<1, 16, 32, SRC>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, src, L, lsize, size, cd, best, N * nclass);
+    hipLaunchKernelGGL((k_cc_border<1, 16, 32>), dim3(border_grid(cd, CcFace<1, 16, 32>::NB)), dim3(256), 0, s, seg, L, cd, options().cc_border_dedupe);
   }
-  hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, L, lsize, size, n);
-  {
+  if (options().cc_fuse_select != 0) {
+    int gx = (int)((V + 255) / 256);          // one voxel per thread up to 2048 workgroups per launch (k_cc_count's geometry)
+    const int cap = 2048 / N < 1 ? 1 : 2048 / N;
+    gx = gx < 1 ? 1 : (gx > cap ? cap : gx);
+    hipLaunchKernelGGL(k_cc_count_select, dim3(gx, N), dim3(256), 0, s, seg, L, lsize, size, best, V, nclass);
+  } else {
+    hipLaunchKernelGGL(k_cc_count, dim3(grid), dim3(256), 0, s, L, lsize, size, n);
     int gx = (int)((V + 255) / 256 / 4);      // ~4 voxels per thread
     const int cap = options().cc_select_blocks > 0 ? options().cc_select_blocks : 256;
     gx = gx < 1 ? 1 : (gx > cap ? cap : gx);  // (round 6, measured: 1024 blocks per sample make the chain 162 -> 155 us alone and move nothing in the step: gpurun_out/r06_s17)
     hipLaunchKernelGGL(k_cc_select, dim3(gx, N), dim3(256), 0, s, seg, L, size, best, V, n, nclass);
   }
   hipLaunchKernelGGL(k_cc_write, dim3(grid), dim3(256), 0, s, seg, L, best, out_u8, out_f32, V, n, nclass);
+  return 0;
+}
+
+extern "C" int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8, float* out_f32, int N, int D, int H, int W, int nclass,
+                              int connectivity, void* workspace, void* stream) {
+  if (bcp::options().whatif & 4) return BCP_OK;      // MEASUREMENT ONLY (common.h Options::whatif)
+
+  BCP_REQUIRE(seg && (out_u8 || out_f32) && workspace, "bcp_cc_largest: null pointer");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0 && nclass >= 1 && nclass <= 8, "bcp_cc_largest: bad extents");
+  BCP_REQUIRE(connectivity >= 1 && connectivity <= 3, "bcp_cc_largest: connectivity must be 1..3 (number of axes that may differ)");
+  BCP_REQUIRE((long long)D * H * W * N < (1LL << 31), "bcp_cc_largest: volume too large for 32-bit labels");
+  cc_run<0>(const_cast<uint8_t*>(seg) /* SRC 0 only reads it */, CcSrc{nullptr, 0.f}, out_u8, out_f32, N, D, H, W, nclass, connectivity, workspace,
+            (hipStream_t)stream);
   BCP_CHECK_LAUNCH("bcp_cc_largest");
+  return BCP_OK;
+}
+
+// (round 6) pseudo-label + largest-CC in one chain: get_cut_mask(out, nms=1) (LA_BCP_train.py:57-63, pancreas_utils.py:275-281; C = 2,
+// nclass = 1, thres) and get_ACDC_masks(output, nms=1) (ACDC_BCP_train.py:112-117; C = 4, nclass = 3, thres ignored) straight from the
+// channel-last logits.  seg_out receives what bcp_plabel_bin / bcp_plabel_argmax4 would have written (the unfiltered map; the chain's
+// later launches read it), out_* what bcp_cc_largest(seg_out, ..) would: the same bits as the two calls.
+extern "C" int bcp_plabel_cc_largest(const float* logits, int C, float thres, uint8_t* seg_out, uint8_t* out_u8, float* out_f32, int N, int D,
+                                     int H, int W, int nclass, int connectivity, void* workspace, void* stream) {
+  BCP_REQUIRE(logits && seg_out && (out_u8 || out_f32) && workspace, "bcp_plabel_cc_largest: null pointer");
+  BCP_REQUIRE((C == 2 && nclass == 1) || (C == 4 && nclass == 3), "bcp_plabel_cc_largest: C = 2 / nclass = 1 (threshold) or C = 4 / nclass = 3 (argmax)");
+  BCP_REQUIRE(N > 0 && D > 0 && H > 0 && W > 0, "bcp_plabel_cc_largest: bad extents");
+  BCP_REQUIRE(connectivity >= 1 && connectivity <= 3, "bcp_plabel_cc_largest: connectivity must be 1..3 (number of axes that may differ)");
+  BCP_REQUIRE((long long)D * H * W * N < (1LL << 31), "bcp_plabel_cc_largest: volume too large for 32-bit labels");
+  BCP_REQUIRE(aligned16(logits), "bcp_plabel_cc_largest: alignment");
+  if (bcp::options().whatif & 4) return BCP_OK;      // MEASUREMENT ONLY (common.h Options::whatif)
+  if (C == 2) cc_run<1>(seg_out, CcSrc{logits, thres}, out_u8, out_f32, N, D, H, W, nclass, connectivity, workspace, (hipStream_t)stream);
+  else cc_run<2>(seg_out, CcSrc{logits, 0.f}, out_u8, out_f32, N, D, H, W, nclass, connectivity, workspace, (hipStream_t)stream);
+  BCP_CHECK_LAUNCH("bcp_plabel_cc_largest");
   return BCP_OK;
 }

@@ -79,6 +79,8 @@ struct Options {
   int gemm_pipe = 1;        // round 6: k_gemm_nn instances that walk several row blocks per workgroup (the statistics / recompute epilogues) request the next block's operands under the current block's MFMAs and epilogue.  0: block after block
   int gemm_stat_r = 0;      // ... measurement switch: row blocks per workgroup of those instances (0 = stat_plan's choice: <= ~1024 partial rows per group, >= 512 workgroups)
   int gemm_walk = 0;        // ... measurement switch: plain k_gemm_nn launches of >= 2 W workgroups as ~W walking workgroups (k_gemm_nn<.., 7>); 0 = one row block per workgroup
+  int cc_border_dedupe = 1; // round 6: k_cc_border lanes leave a (root, root) pair that the previous lane also holds at the same neighbour offset to that lane.  0: every lane joins every pair it sees
+  int cc_fuse_select = 1;   // round 6: the largest-CC chain's size count also max-reduces the (size, root) keys (k_cc_count_select): no k_cc_select launch on the teacher's tail.  0: two launches
   int norm_apply_cap = 2048;   // round 6 (measurement switches): workgroups per apply-pass launch at most ...
   int norm_apply_vec = 4;      // ... and float4 per thread the grid is sized for (4 = one unrolled trip; 1 = every thread one float4, no loop)
   int wgrad_reduce_flat = 1;   // round 6: many-group weight-gradient slab sums read slab-contiguous float4 (k_wgrad_reduce_flat).  0: k_wgrad_reduce_deep
@@ -87,6 +89,30 @@ struct Options {
   int wgrad_b6_levels = 15; // bit 3: 2-D; bit 2: also the 16-channel slabs (one n-tile per wave): 187 vs 270 us alone, 7.28 vs 7.36 ms per step
 };
 Options& options();
+
+// ---- pseudo-label arithmetic shared by k_plabel_bin / k_plabel_argmax4 (elementwise.hip) and the largest-CC kernels that label straight
+// from the logits (cc.hip, bcp_plabel_cc_largest): ONE definition so both paths produce the same bits
+// LA / pancreas: softmax over 2 channels, (p1 >= thres)            (LA_BCP_train.py:57-60)
+__device__ __forceinline__ unsigned char plabel_bin_of(float x0, float x1, float thres) {
+  const float m = fmaxf(x0, x1);
+  const float e0 = expf(x0 - m), e1 = expf(x1 - m);
+  const float p1 = e1 / (e0 + e1);
+  return (p1 >= thres) ? 1 : 0;
+}
+// ACDC: softmax over 4 channels then argmax, first maximum wins       (ACDC_BCP_train.py:112-114)
+__device__ __forceinline__ unsigned char plabel_argmax4_of(float x0, float x1, float x2, float x3) {
+  const float m = fmaxf(fmaxf(x0, x1), fmaxf(x2, x3));
+  const float e0 = expf(x0 - m), e1 = expf(x1 - m), e2 = expf(x2 - m), e3 = expf(x3 - m);
+  const float s = e0 + e1 + e2 + e3;
+  const float p0 = e0 / s, p1 = e1 / s, p2 = e2 / s, p3 = e3 / s;
+  int best = 0;
+  float pb = p0;
+  if (p1 > pb) { pb = p1; best = 1; }
+  if (p2 > pb) { pb = p2; best = 2; }
+  if (p3 > pb) { pb = p3; best = 3; }
+  return (unsigned char)best;
+}
+
 
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

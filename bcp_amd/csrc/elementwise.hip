@@ -106,12 +106,7 @@ __global__ __launch_bounds__(256) void k_plabel_bin(const float* __restrict__ lo
     uchar4 r;
     unsigned char* pr = &r.x;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float m = fmaxf(x[2 * k], x[2 * k + 1]);
-      const float e0 = expf(x[2 * k] - m), e1 = expf(x[2 * k + 1] - m);
-      const float p1 = e1 / (e0 + e1);
-      pr[k] = (p1 >= thres) ? 1 : 0;
-    }
+    for (int k = 0; k < 4; ++k) pr[k] = plabel_bin_of(x[2 * k], x[2 * k + 1], thres);
     *reinterpret_cast<uchar4*>(out + i * 4) = r;
   }
 }
@@ -122,16 +117,7 @@ __global__ __launch_bounds__(256) void k_plabel_argmax4(const float* __restrict_
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_pix; i += stride) {
     const float4 l = ld4(logits + i * 4);
-    const float m = fmaxf(fmaxf(l.x, l.y), fmaxf(l.z, l.w));
-    const float e0 = expf(l.x - m), e1 = expf(l.y - m), e2 = expf(l.z - m), e3 = expf(l.w - m);
-    const float s = e0 + e1 + e2 + e3;
-    const float p0 = e0 / s, p1 = e1 / s, p2 = e2 / s, p3 = e3 / s;
-    int best = 0;
-    float pb = p0;
-    if (p1 > pb) { pb = p1; best = 1; }
-    if (p2 > pb) { pb = p2; best = 2; }
-    if (p3 > pb) { pb = p3; best = 3; }
-    out[i] = (uint8_t)best;
+    out[i] = plabel_argmax4_of(l.x, l.y, l.z, l.w);
   }
 }
 

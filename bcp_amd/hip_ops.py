@@ -262,6 +262,23 @@ class Ops:
         self.b.call("bcp_cc_largest", _p(seg), _p(out), _p(outf), N, D, H, W, nclass, connectivity, _p(ws), self.stream(seg))
         return (out, outf) if want_f32 else out
 
+    def plabel_cc_largest(self, logits, thres=0.5, connectivity=3, want_f32=False, want_seg=False):
+        """(round 6) channel-last logits [N,D,H,W,C] -> largest-CC-filtered pseudo-label uint8 [N,D,H,W]: plabel_bin (C = 2, one class) or
+        plabel_argmax4 (C = 4, three classes) + cc_largest as one chain (bcp_plabel_cc_largest: the first CC kernel labels from the
+        logits itself) -- the same bits as the two calls"""
+        self._chk(logits)
+        N, D, H, W, Cc = logits.shape
+        assert Cc in (2, 4)
+        nclass = 1 if Cc == 2 else 3
+        ws = self.workspace("cc", self._ws_bytes("bcp_cc_workspace_bytes", N, D, H, W, nclass), logits)
+        seg = torch.empty((N, D, H, W), dtype=torch.uint8, device=logits.device)
+        out = torch.empty_like(seg)
+        outf = torch.empty(seg.shape, dtype=torch.float32, device=seg.device) if want_f32 else None
+        self.b.call("bcp_plabel_cc_largest", _p(logits), Cc, float(thres), _p(seg), _p(out), _p(outf), N, D, H, W, nclass, connectivity, _p(ws),
+                    self.stream(logits))
+        res = (out, outf) if want_f32 else out
+        return (res, seg) if want_seg else res
+
     def mixloss_fwd(self, logits, img_l, patch_l, box6, flavour, w_img, w_patch, mask=None, prev=None, total=None):
         """-> (out3 float32[3] on device, workspace tensor to hand to mixloss_bwd).  prev + total: the step's second call hands in the
         first call's out3 and a float32[1] that receives the step's total loss (the reference's sum order, bcp_hip.h)"""
@@ -1030,7 +1047,7 @@ class Ops:
 # ---------------------------------------------------------------------------------------------- measurement hooks
 # bench.py's per-op table: HIP events on the launch stream around every call of the ops below while a profile is open
 # (Ops.profile_begin / profile_end).  Closed (the default) the wrappers cost one attribute test.
-_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "mixloss_fwd", "mixloss_bwd", "mixloss_pair_fwd", "mixloss_pair_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
+_PROFILED = ("mix_box", "plabel_bin", "plabel_argmax4", "cc_largest", "plabel_cc_largest", "mixloss_fwd", "mixloss_bwd", "mixloss_pair_fwd", "mixloss_pair_bwd", "norm_fwd", "norm_bwd", "norm_fwd_slabs", "norm_bwd_slabs", "conv3_fwd_raw", "conv3_dgrad_bwdstats", "pw16_bwd_norm_bwd", "conv3_c1_norm_bwd_wgrad", "conv3_pack_many",
              "conv3_fwd", "conv3_fwd_stats", "conv3_wgrad", "conv3_c1_fwd", "conv3_c1_fwd_stats", "conv3_c1_norm_fwd", "conv3_c1_norm_bwd", "conv3_c1_wgrad", "k2_pack_many", "down_fwd", "down_dgrad", "up_fwd", "k2_fwd_stats", "k2_dgrad_bwdstats", "up_fwd_norm", "up_norm_bwd",
              "up_dgrad", "pw_fwd", "k2_wgrad", "pw16_fwd", "pw16_bwd", "pw16_fwd_norm", "pw16_bwd_norm", "maxpool2d_fwd", "maxpool2d_bwd", "bilinear2x_fwd", "bilinear2x_bwd",
              "copy_channels", "ema", "sgd", "adam")

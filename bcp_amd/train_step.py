@@ -49,26 +49,30 @@ def _side_stream(t):
 
 
 # ------------------------------------------------------------------------------------------ pseudo labels
+PLABEL_CC_FUSED = True    # (round 6) pseudo-label + largest-CC as one chain (bcp_plabel_cc_largest); False: bcp_plabel_* then bcp_cc_largest (rounds 1-5; bench.py --opt plabel_cc_fused=0)
 def get_cut_mask(out, thres=0.5, nms=0, connect_mode=None):
     """LA_BCP_train.py:57-63 / pancreas_utils.py:275-281: softmax -> (p>=thres) -> channel 1 [-> largest CC].
     Returns uint8 [N,X,Y,Z] on the device (the reference returns int64 / float32 of the same values);
     connect_mode None = full connectivity (skimage default, 26), 2 = 18, 1 = 6."""
     cl = BU._as_cl(out)
     ops = _ops_for(cl)
+    conn = {None: 3, 3: 3, 2: 2, 1: 1}[connect_mode]
+    if nms and PLABEL_CC_FUSED:      # (round 6) one chain: the first largest-CC kernel labels from the logits itself (bcp_plabel_cc_largest)
+        return ops.plabel_cc_largest(cl, thres, conn)
     seg = ops.plabel_bin(cl, thres)
-    if nms:
-        conn = {None: 3, 3: 3, 2: 2, 1: 1}[connect_mode]
-        seg = ops.cc_largest(seg, 1, conn)
-    return seg
+    return ops.cc_largest(seg, 1, conn) if nms else seg
 
 
 def get_ACDC_masks(output, nms=0):
     """ACDC_BCP_train.py:112-117: softmax -> argmax [-> per-class largest 8-connected component] -> uint8 [N,H,W]"""
     cl = BU._as_cl(output)
     ops = _ops_for(cl)
-    seg = ops.plabel_argmax4(cl)            # [N,1,H,W]
-    if nms:
-        seg = ops.cc_largest(seg, 3, 2)
+    if nms and PLABEL_CC_FUSED:
+        seg = ops.plabel_cc_largest(cl, 0.5, 2)          # [N,1,H,W]
+    else:
+        seg = ops.plabel_argmax4(cl)
+        if nms:
+            seg = ops.cc_largest(seg, 3, 2)
     return seg.view(seg.shape[0], seg.shape[2], seg.shape[3])
 
 

@@ -763,6 +763,10 @@ def main():
                 _ts7._SIDE[dev] = ext
             print(f"[bench] {k}: {sum(bin(w).count('1') for w in words)} CUs", file=sys.stderr)
             continue
+        if k == "plabel_cc_fused":    # host-side switch (train_step.py): pseudo-label + largest-CC as one chain
+            import bcp_amd.train_step as _ts10
+            _ts10.PLABEL_CC_FUSED = bool(int(v))
+            continue
         if k == "up_recompute_grad":  # host-side switch (networks/VNet.py): the recomputing transposed conv + norm also in forwards that save for a backward pass
             from bcp_amd.networks.VNet import VNet as _vn9
             _vn9.UP_RECOMPUTE_GRAD = bool(int(v))

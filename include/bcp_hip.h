@@ -42,7 +42,7 @@ enum { BCP_WG_DOWN = 0, BCP_WG_UP = 1, BCP_WG_PW = 2 };
 /* ABI revision = 100 * round + change counter.  Bumped whenever an exported signature changes; a binding must refuse a library whose
  * bcp_version() differs from the header it was written against (bcp_amd/_lib.py does: a stale in-tree .so then fails at load, not
  * with shifted arguments inside a launch). */
-#define BCP_ABI_VERSION 510
+#define BCP_ABI_VERSION 511
 int bcp_version(void);
 const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
@@ -77,6 +77,12 @@ int bcp_plabel_argmax4(const float* logits /*[n_pix][4]*/, uint8_t* out, long lo
 size_t bcp_cc_workspace_bytes(int N, int D, int H, int W, int nclass);
 int bcp_cc_largest(const uint8_t* seg, uint8_t* out_u8_or_null, float* out_f32_or_null, int N, int D, int H, int W, int nclass,
                    int connectivity, void* workspace, void* stream);
+/*      (ABI 511) pseudo-label + largest-CC as ONE chain, straight from the channel-last logits: get_cut_mask(out, nms=1)
+ *      (LA_BCP_train.py:57-63, pancreas_utils.py:275-281; C = 2, nclass = 1) and get_ACDC_masks(output, nms=1) (ACDC_BCP_train.py:112-117;
+ *      C = 4, nclass = 3, thres ignored).  seg_out receives what bcp_plabel_bin / bcp_plabel_argmax4 would write, out_* what
+ *      bcp_cc_largest(seg_out, ..) would -- the same bits as the two calls, one launch fewer in front of the chain; workspace as above. */
+int bcp_plabel_cc_largest(const float* logits /*[N][D][H][W][C]*/, int C, float thres, uint8_t* seg_out, uint8_t* out_u8_or_null,
+                          float* out_f32_or_null, int N, int D, int H, int W, int nclass, int connectivity, void* workspace, void* stream);
 
 /* ---- masked Dice + CE "mix_loss" (utils/BCP_utils.py:58-69 + utils/losses.py:47-77 [flavour LA, C=2];
  *      ACDC_BCP_train.py:167-179 + utils/losses.py:102-134 [flavour ACDC, C=4]).  mask_or_null: explicit uint8 mask

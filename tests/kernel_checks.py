@@ -119,6 +119,37 @@ def check_cc(ops, dev, golden_dir):
         assert np.array_equal(ops.cc_largest(am.to(dev), 3, 2).cpu().numpy()[:, 0], g["argmax_cc"])
     finally:
         ops.set_option("cc_tile")
+    # (round 6) the two-launch count + select (cc_fuse_select = 0) against the fused kernel that everything above ran through
+    ops.set_option("cc_fuse_select", 0)
+    try:
+        for conn, key in ((3, "cc26"), (2, "cc18"), (1, "cc6")):
+            assert np.array_equal(ops.cc_largest(cut.to(dev).contiguous(), 1, conn).cpu().numpy(), g[key]), f"two-launch select cc {key}"
+        assert np.array_equal(ops.cc_largest(am.to(dev), 3, 2).cpu().numpy()[:, 0], g["argmax_cc"])
+        for conn, oc in ((3, None), (1, 1)):
+            assert torch.equal(ops.cc_largest(noise.to(dev), 1, conn).cpu().float(), O.largest_cc(noise.long(), oc))
+    finally:
+        ops.set_option("cc_fuse_select")
+    # (round 6) pseudo-label + largest-CC as one chain from the logits (bcp_plabel_cc_largest) == the two calls, bit for bit: the golden
+    # logits (values at the threshold's expf ties included), noise logits (a random-init teacher), both tile sizes, 3-D two-channel and 2-D
+    # four-channel
+    rl = np.random.default_rng(5)
+    cases2 = [to_cl(torch.from_numpy(g["logits3d"])).to(dev), to_cl(R(rl, 2, 2, 20, 40, 36)).to(dev), to_cl(R(rl, 1, 2, 9, 17, 20)).to(dev)]
+    cases4 = [to_cl(torch.from_numpy(g["logits2d"]).unsqueeze(2)).to(dev), to_cl(R(rl, 3, 4, 1, 48, 80)).to(dev), to_cl(R(rl, 2, 4, 1, 33, 47)).to(dev)]
+    for tile in (0, 2):
+        ops.set_option("cc_tile", tile)
+        try:
+            for lg in cases2:
+                for conn in (3, 2, 1):
+                    seg = ops.plabel_bin(lg, 0.5)
+                    (o2, f2), s2 = ops.plabel_cc_largest(lg, 0.5, conn, want_f32=True, want_seg=True)
+                    o1, f1 = ops.cc_largest(seg, 1, conn, want_f32=True)
+                    assert torch.equal(s2, seg) and torch.equal(o2, o1) and torch.equal(f2, f1), f"plabel + cc chain (2 channels, conn {conn}, tile {tile})"
+            for lg in cases4:
+                seg = ops.plabel_argmax4(lg)
+                o2, s2 = ops.plabel_cc_largest(lg, 0.5, 2, want_seg=True)
+                assert torch.equal(s2, seg) and torch.equal(o2, ops.cc_largest(seg, 3, 2)), f"plabel + cc chain (4 channels, tile {tile})"
+        finally:
+            ops.set_option("cc_tile")
 
 
 def check_mixloss(ops, dev, golden_dir):
