@@ -31,8 +31,18 @@ struct Softmax {
 #pragma unroll
     for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
     float s = 0.f;
+    if constexpr (C == 2) {
+      // (round 6) the larger logit's term is expf(0) = 1 exactly: one expf per voxel instead of two, the same bits (the forward kernel is
+      // VALU-bound: ~250 instructions per voxel, 4 cycles each per wave)
+      const bool hi1 = x[1] > x[0];                    // m == x[1] (ties: m == x[0] == x[1], both terms expf(0))
+      const float e = expf((x[0] - m) + (x[1] - m));   // one difference is +0 exactly, so the sum IS the other one; a NaN / inf - inf in either still reaches s
+      p[0] = hi1 ? e : 1.f;
+      p[1] = hi1 ? 1.f : e;
+      s = p[0] + p[1];
+    } else {
 #pragma unroll
-    for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - m); s += p[c]; }
+      for (int c = 0; c < C; ++c) { p[c] = expf(x[c] - m); s += p[c]; }
+    }
     const float inv = 1.0f / s;
 #pragma unroll
     for (int c = 0; c < C; ++c) p[c] *= inv;
@@ -71,7 +81,34 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
 #pragma unroll
     for (int c = 0; c < C; ++c) s[t][c][0] = s[t][c][1] = s[t][c][2] = 0.0;
 
-  // one voxel: softmax + branch-free accumulation into the term the voxel belongs to
+  // one voxel: softmax + branch-free accumulation into the term the voxel belongs to.  (round 6) Into fp32 partials of ONE trip -- an
+  // aligned group of <= 4 consecutive voxels (flush): <= 3 fp32 roundings per partial, and the grouping is a property of the voxel index,
+  // not of the launch geometry (the pair launch and the single launches cut the volume differently and still add the same numbers) -- and
+  // from there into the fp64 accumulators: a quarter of the fp64 adds and conversions (14 per voxel before: the kernel ran at 0.9 TB/s)
+  float fs[2][C][3], fce[2], fcnt[2];
+  auto trip_clear = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) fs[t][c][0] = fs[t][c][1] = fs[t][c][2] = 0.f;
+      fce[t] = 0.f; fcnt[t] = 0.f;
+    }
+  };
+  auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        s[t][c][0] += (double)fs[t][c][0];
+        s[t][c][1] += (double)fs[t][c][1];
+        if (ACDC) s[t][c][2] += (double)fs[t][c][2];
+      }
+      ce[t] += (double)fce[t];
+      cnt[t] += (double)fcnt[t];
+    }
+    trip_clear();
+  };
+  trip_clear();
   auto voxel = [&](const float (&x)[C], int t, int y) __attribute__((always_inline)) {
     Softmax<C> sm;
     sm.compute(x);
@@ -81,19 +118,19 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
 #pragma unroll
       for (int c = 0; c < C; ++c) {
         const float oh = (y == c) ? 1.f : 0.f;
-        s[tt][c][0] += (double)(sm.p[c] * oh * m);
+        fs[tt][c][0] += sm.p[c] * oh * m;
         if (ACDC) {
-          s[tt][c][1] += (double)(sm.p[c] * sm.p[c] * m);
-          s[tt][c][2] += (double)(oh * m);
+          fs[tt][c][1] += sm.p[c] * sm.p[c] * m;
+          fs[tt][c][2] += oh * m;
         } else {
-          s[tt][c][1] += (double)((sm.p[c] + oh) * m);
+          fs[tt][c][1] += (sm.p[c] + oh) * m;
         }
       }
       float xy = x[0];
 #pragma unroll
       for (int c = 1; c < C; ++c) xy = (y == c) ? x[c] : xy;
-      ce[tt] += (double)((sm.lse - xy) * m);
-      cnt[tt] += (double)m;
+      fce[tt] += (sm.lse - xy) * m;
+      fcnt[tt] += m;
     }
   };
   auto term_of = [&](long long v) __attribute__((always_inline)) -> int {
@@ -109,19 +146,55 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
   constexpr int VP = 4 / C;
   const long long stride = (long long)gridDim.x * blockDim.x;
   if (VP >= 1 && C * VP == 4 && (V % VP) == 0 && (reinterpret_cast<uintptr_t>(logits) & 15u) == 0) {
-    const long long VV = V / VP;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < VV; i += stride) {
-      const float4 q = ld4(lg + i * 4);
-      const float xv[4] = {q.x, q.y, q.z, q.w};
+    // a trip = G = 2 consecutive float4 of one lane (32 bytes: four voxels at C = 2, two at C = 4), both requested before the first is used
+    constexpr int G = 2;
+    const long long VV = V / VP, VG = VV / G;
+    const bool row_trip = !mk && (W % (G * VP)) == 0;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < VG; i += stride) {
+      float4 q[G];
 #pragma unroll
-      for (int u = 0; u < VP; ++u) {
-        const long long v = i * VP + u;
-        float x[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) x[c] = xv[u * C + c];
-        const int t = term_of(v);
-        voxel(x, t, t ? lb[v] : la[v]);
+      for (int g = 0; g < G; ++g) q[g] = ld4(lg + (i * G + g) * 4);
+      // the trip's G * VP consecutive voxels lie in one row when W is a multiple of that (80, 96, 256 in the reference's configurations):
+      // one (d, h, w) decomposition -- two 32-bit divisions -- per trip instead of per voxel
+      const long long v0 = i * G * VP;
+      int td = 0, th = 0, tw0 = 0;
+      if (row_trip) {
+        const unsigned vu = (unsigned)v0, q1 = vu / (unsigned)W;
+        tw0 = (int)(vu - q1 * (unsigned)W);
+        td = (int)(q1 / (unsigned)H);
+        th = (int)(q1 - (unsigned)td * (unsigned)H);
       }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float xv[4] = {q[g].x, q[g].y, q[g].z, q[g].w};
+#pragma unroll
+        for (int u = 0; u < VP; ++u) {
+          const long long v = v0 + g * VP + u;
+          float x[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) x[c] = xv[u * C + c];
+          const int t = row_trip ? (in_box(td, th, tw0 + g * VP + u, box.v) ? 1 : 0) : term_of(v);
+          voxel(x, t, t ? lb[v] : la[v]);
+        }
+      }
+      flush();
+    }
+    // the float4 behind the last whole trip (VV % G of them), one trip of their own -- by the block and lane that would own the next trip
+    if ((long long)blockIdx.x * blockDim.x + threadIdx.x == VG % stride && VG * G < VV) {
+      for (long long j = VG * G; j < VV; ++j) {
+        const float4 q = ld4(lg + j * 4);
+        const float xv[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int u = 0; u < VP; ++u) {
+          const long long v = j * VP + u;
+          float x[C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) x[c] = xv[u * C + c];
+          const int t = term_of(v);
+          voxel(x, t, t ? lb[v] : la[v]);
+        }
+      }
+      flush();
     }
   } else {
     for (long long v = (long long)blockIdx.x * blockDim.x + threadIdx.x; v < V; v += stride) {
@@ -130,6 +203,7 @@ __global__ __launch_bounds__(256) void k_mixloss_fwd(const float* __restrict__ l
       for (int c = 0; c < C; ++c) x[c] = lg[v * C + c];
       const int t = term_of(v);
       voxel(x, t, t ? lb[v] : la[v]);
+      flush();
     }
   }
   // block reduction: wave shuffles then LDS, then one fp64 atomic per quantity
@@ -358,17 +432,26 @@ __global__ __launch_bounds__(256) void k_mixloss_bwd(const float* __restrict__ l
   const long long stride = (long long)gridDim.x * blockDim.x;
   if (VP >= 1 && C * VP == 4 && (V % VP) == 0 && ((reinterpret_cast<uintptr_t>(logits) | reinterpret_cast<uintptr_t>(dlogits)) & 15u) == 0) {
     const long long VV = V / VP;
+    const bool row_vec = !mk && VP > 1 && (W % VP) == 0;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < VV; i += stride) {
       const float4 q = ld4(lg + i * 4);
       const float xv[4] = {q.x, q.y, q.z, q.w};
       float ov[4];
+      // (round 6) the float4's VP voxels lie in one row when W % VP == 0: one (d, h, w) decomposition for them (see k_mixloss_fwd)
+      int td = 0, th = 0, tw0 = 0;
+      if (row_vec) {
+        const unsigned vu = (unsigned)(i * VP), q1 = vu / (unsigned)W;
+        tw0 = (int)(vu - q1 * (unsigned)W);
+        td = (int)(q1 / (unsigned)H);
+        th = (int)(q1 - (unsigned)td * (unsigned)H);
+      }
 #pragma unroll
       for (int u = 0; u < VP; ++u) {
         const long long v = i * VP + u;
         float x[C], o[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) x[c] = xv[u * C + c];
-        const int t = term_of(v);
+        const int t = row_vec ? (in_box(td, th, tw0 + u, box.v) ? 1 : 0) : term_of(v);
         voxel(x, t, t ? lb[v] : la[v], o);
 #pragma unroll
         for (int c = 0; c < C; ++c) ov[u * C + c] = o[c];

@@ -223,6 +223,30 @@ def check_mixloss(ops, dev, golden_dir):
             assert torch.equal(tot2.cpu(), tot.cpu()), (tag, "total", float(tot2[0]), float(tot[0]))
             assert torch.equal(d_pair.cpu(), d_ref.cpu()), tag + ": gradient"
             assert float(d_pair.abs().max()) > 0 and float(tot2[0]) == float(tot2[0])
+    # round 6: the box path takes a trip's voxels' term from ONE (d, h, w) decomposition when W is a multiple of the trip (forward: 4 voxels
+    # at C = 2, 2 at C = 4; backward: one float4) -- against the dense mask of the same box (a byte per voxel, no arithmetic on indices):
+    # the same bits, forward and backward; W = 6 / 9 take the per-voxel decomposition
+    for flavour, Cc, sp in ((H.LOSS_LA, 2, (6, 10, 16)), (H.LOSS_LA, 2, (5, 7, 12)), (H.LOSS_LA, 2, (4, 6, 6)), (H.LOSS_ACDC, 4, (1, 20, 24)), (H.LOSS_ACDC, 4, (1, 11, 9))):
+        N = 2
+        lg = torch.from_numpy(rng.standard_normal((N,) + sp + (Cc,), dtype=np.float32) * 2).to(dev)
+        la_, lb_ = [torch.from_numpy(rng.integers(0, Cc, (N,) + sp).astype(np.uint8)).to(dev) for _ in range(2)]
+        bx = (0, 3, 2, 1, sp[1] // 2, sp[2] - 3) if sp[0] == 1 else (1, 2, 1, sp[0] // 2, sp[1] // 2, sp[2] - 2)
+        m = torch.ones((N,) + sp, dtype=torch.uint8)
+        m[:, bx[0]:bx[0] + bx[3], bx[1]:bx[1] + bx[4], bx[2]:bx[2] + bx[5]] = 0        # 1 = image term = OUTSIDE the box
+        ob, wsb = ops.mixloss_fwd(lg, la_, lb_, bx, flavour, 1.0, 0.5)
+        om, wsm = ops.mixloss_fwd(lg, la_, lb_, (0, 0, 0, 0, 0, 0), flavour, 1.0, 0.5, mask=m.to(dev))
+        assert torch.equal(ob.cpu(), om.cpu()), f"mixloss box vs dense mask of the box, flavour {flavour} {sp}: {ob.cpu()} {om.cpu()}"
+        db = ops.mixloss_bwd(lg, la_, lb_, bx, flavour, wsb, 0.5, 0.5)
+        dm = ops.mixloss_bwd(lg, la_, lb_, (0, 0, 0, 0, 0, 0), flavour, wsm, 0.5, 0.5, mask=m.to(dev))
+        assert torch.equal(db.cpu(), dm.cpu()), f"mixloss gradient box vs dense mask, flavour {flavour} {sp}"
+    # a NaN logit must reach the loss (the two-channel softmax computes ONE exponential: of the sum of both differences to the maximum)
+    lgn = torch.from_numpy(rng.standard_normal((2, 4, 6, 8, 2), dtype=np.float32)).to(dev)
+    l8 = torch.zeros((2, 4, 6, 8), dtype=torch.uint8, device=dev)
+    for ch in (0, 1):
+        bad = lgn.clone()
+        bad[1, 2, 3, 4, ch] = float("nan")
+        o, _ = ops.mixloss_fwd(bad, l8, l8, (1, 1, 1, 2, 2, 2), H.LOSS_LA, 1.0, 0.5)
+        assert float(o[0]) != float(o[0]), f"a NaN logit (channel {ch}) did not reach the loss"
 
 
 def _acdc_mix_loss_body(dice_loss, output, img_l, patch_l, mask, l_weight=1.0, u_weight=0.5, unlab=False):
