@@ -30,7 +30,7 @@ extern "C" int bcp_set_option(const char* name, const char* value) {
   const bool reset = n <= 0;
 #define BCP_OPT_INT(field) if (!strcmp(name, #field)) { o.field = reset ? def.field : (int)v[0]; return BCP_OK; }
   BCP_OPT_INT(conv3_p) BCP_OPT_INT(splitk) BCP_OPT_INT(conv3_b6_flat_sk) BCP_OPT_INT(conv3_b6_cfg2d) BCP_OPT_INT(conv3_b6_w22) BCP_OPT_INT(conv3_b6_pipe) BCP_OPT_INT(conv3_b6_cin16max) BCP_OPT_INT(res_pcu) BCP_OPT_INT(res_nt) BCP_OPT_INT(wgrad_nt)
-  BCP_OPT_INT(tn_groups) BCP_OPT_INT(cc_tile) BCP_OPT_INT(pack_sections) BCP_OPT_INT(cc_select_blocks) BCP_OPT_INT(conv3_b6) BCP_OPT_INT(conv3_b6_levels) BCP_OPT_INT(conv3_b6_direct) BCP_OPT_INT(conv3_b6_flat) BCP_OPT_INT(conv3_b6_minvox) BCP_OPT_INT(wgrad_b6) BCP_OPT_INT(wgrad_b6_minvox) BCP_OPT_INT(wgrad_b6_levels) BCP_OPT_INT(wgrad_b6_slots) BCP_OPT_INT(cc_border_dedupe) BCP_OPT_INT(cc_fuse_select) BCP_OPT_INT(gemm_walk) BCP_OPT_INT(gemm_pipe) BCP_OPT_INT(gemm_stat_r) BCP_OPT_INT(norm_apply_cap) BCP_OPT_INT(norm_apply_vec) BCP_OPT_INT(k2_stats) BCP_OPT_INT(k2_bwd_stats) BCP_OPT_INT(up_recompute) BCP_OPT_INT(wgrad_b6_deep) BCP_OPT_INT(wgrad_b6_deep_nt) BCP_OPT_INT(wgrad_b6_deep_slots) BCP_OPT_INT(wgrad_b6_deep_tile) BCP_OPT_INT(norm_slabs) BCP_OPT_INT(conv3_f16) BCP_OPT_INT(fuse_bwd_stats) BCP_OPT_INT(conv3_xcd) BCP_OPT_INT(mix_c1) BCP_OPT_INT(whatif) BCP_OPT_INT(norm_own) BCP_OPT_INT(wgrad_reduce_flat) BCP_OPT_INT(norm_fin_rows) BCP_OPT_INT(norm_fuse_fin)
+  BCP_OPT_INT(tn_groups) BCP_OPT_INT(cc_tile) BCP_OPT_INT(pack_sections) BCP_OPT_INT(cc_select_blocks) BCP_OPT_INT(conv3_b6) BCP_OPT_INT(conv3_b6_levels) BCP_OPT_INT(conv3_b6_direct) BCP_OPT_INT(conv3_b6_flat) BCP_OPT_INT(conv3_b6_minvox) BCP_OPT_INT(wgrad_b6) BCP_OPT_INT(wgrad_b6_minvox) BCP_OPT_INT(wgrad_b6_levels) BCP_OPT_INT(wgrad_b6_slots) BCP_OPT_INT(cc_border_dedupe) BCP_OPT_INT(cc_count_tile) BCP_OPT_INT(cc_fuse_select) BCP_OPT_INT(gemm_walk) BCP_OPT_INT(gemm_pipe) BCP_OPT_INT(gemm_stat_r) BCP_OPT_INT(norm_apply_cap) BCP_OPT_INT(norm_apply_vec) BCP_OPT_INT(k2_stats) BCP_OPT_INT(k2_bwd_stats) BCP_OPT_INT(up_recompute) BCP_OPT_INT(wgrad_b6_deep) BCP_OPT_INT(wgrad_b6_deep_nt) BCP_OPT_INT(wgrad_b6_deep_slots) BCP_OPT_INT(wgrad_b6_deep_tile) BCP_OPT_INT(norm_slabs) BCP_OPT_INT(conv3_f16) BCP_OPT_INT(fuse_bwd_stats) BCP_OPT_INT(conv3_xcd) BCP_OPT_INT(mix_c1) BCP_OPT_INT(whatif) BCP_OPT_INT(norm_own) BCP_OPT_INT(wgrad_reduce_flat) BCP_OPT_INT(norm_fin_rows) BCP_OPT_INT(norm_fuse_fin)
 #undef BCP_OPT_INT
   if (!strcmp(name, "conv3_sk_elems")) { o.conv3_sk_elems = reset ? def.conv3_sk_elems : v[0]; return BCP_OK; }
   if (!strcmp(name, "res_tile2d_vox")) { o.res_tile2d_vox = reset ? def.res_tile2d_vox : v[0]; return BCP_OK; }

@@ -90,12 +90,41 @@ __global__ __launch_bounds__(256) void k_cc_local(uint8_t* __restrict__ seg, CcS
   static_assert(TV % 256 == 0, "a whole number of voxels per thread");
   __shared__ int Ls[TV];
   __shared__ int Cnt[TV];
-  __shared__ uint8_t Ss[TV];
+  __shared__ __attribute__((aligned(16))) uint8_t Ss[TV];
   const int tw = blockIdx.x % cd.tiles_w, th = (blockIdx.x / cd.tiles_w) % cd.tiles_h;
   const int td = (blockIdx.x / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d, n = blockIdx.x / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
   const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
   const long long nbase = (long long)n * cd.D * cd.H * cd.W;
   int gidx[VPT];
+  // (round 6) from the logits with W % 4 == 0: a thread labels QUADS of four consecutive voxels of a row -- 16-byte loads of the logits
+  // and ONE 4-byte store of the map per quad (the voxel-per-lane form below read 8 bytes per lane and wrote the map byte by byte:
+  // k_cc_local 54.8 -> 76.3 us in the step, more than the pseudo-label launch it replaced) -- a quad is wholly inside or outside the volume
+  const bool quads = SRC != 0 && (cd.W & 3) == 0 && (reinterpret_cast<uintptr_t>(seg) & 3u) == 0;
+  if constexpr (SRC != 0) {
+    if (quads) {
+      for (int q = threadIdx.x; q < TV / 4; q += 256) {
+        const int i0 = q * 4;
+        const int lw = i0 % TW, lh = (i0 / TW) % TH, ld = i0 / (TW * TH);
+        const int d = d0 + ld, h = h0 + lh, w = w0 + lw;
+        uchar4 s4 = make_uchar4(0, 0, 0, 0);
+        if (d < cd.D && h < cd.H && w < cd.W) {
+          const long long gv = nbase + ((long long)d * cd.H + h) * cd.W + w;      // a multiple of 4
+          if constexpr (SRC == 1) {
+            const float4 a = ld4(src.logits + gv * 2), b = ld4(src.logits + gv * 2 + 4);
+            s4 = make_uchar4(plabel_bin_of(a.x, a.y, src.thres), plabel_bin_of(a.z, a.w, src.thres), plabel_bin_of(b.x, b.y, src.thres),
+                             plabel_bin_of(b.z, b.w, src.thres));
+          } else {
+            const float4 a = ld4(src.logits + gv * 4), b = ld4(src.logits + gv * 4 + 4), c = ld4(src.logits + gv * 4 + 8), e = ld4(src.logits + gv * 4 + 12);
+            s4 = make_uchar4(plabel_argmax4_of(a.x, a.y, a.z, a.w), plabel_argmax4_of(b.x, b.y, b.z, b.w), plabel_argmax4_of(c.x, c.y, c.z, c.w),
+                             plabel_argmax4_of(e.x, e.y, e.z, e.w));
+          }
+          *reinterpret_cast<uchar4*>(seg + gv) = s4;
+        }
+        *reinterpret_cast<uchar4*>(&Ss[i0]) = s4;
+      }
+      __syncthreads();
+    }
+  }
 #pragma unroll
   for (int u = 0; u < VPT; ++u) {
     const int i = threadIdx.x + u * 256;
@@ -104,7 +133,8 @@ __global__ __launch_bounds__(256) void k_cc_local(uint8_t* __restrict__ seg, CcS
     const bool in = d < cd.D && h < cd.H && w < cd.W;
     gidx[u] = in ? (int)(nbase + ((long long)d * cd.H + h) * cd.W + w) : -1;
     uint8_t s = 0;
-    if (in) {
+    if (quads) s = Ss[i];
+    else if (in) {
       if constexpr (SRC == 0) s = seg[gidx[u]];
       else if constexpr (SRC == 1) {
         const float2 x = *reinterpret_cast<const float2*>(src.logits + (long long)gidx[u] * 2);
@@ -116,7 +146,7 @@ __global__ __launch_bounds__(256) void k_cc_local(uint8_t* __restrict__ seg, CcS
         seg[gidx[u]] = s;
       }
     }
-    Ss[i] = s;
+    if (!quads) Ss[i] = s;
     Ls[i] = s ? i : -1;
     Cnt[i] = 0;
   }
@@ -282,6 +312,73 @@ __global__ __launch_bounds__(256) void k_cc_count_select(const uint8_t* __restri
   }
 }
 
+// (round 6) the same per TILE: one workgroup takes the tile-local roots of one k_cc_local tile, finds their global roots and adds up the sizes
+// of the ones that share a global root in an LDS table first (open addressing keyed on the root; a tile holds at most TV / 2 local roots, the
+// table has TV slots) -- ONE global atomicAdd per (tile, global root).  On a noise-like map every tile holds 5-20 tile-local pieces of the
+// one percolating component: ~10^4 atomics on that root's size word, serialised in one L2 channel, were what k_cc_count_select's 50-58 us in
+// the step were made of.
+template <int TD, int TH, int TW>
+__global__ __launch_bounds__(256) void k_cc_count_select_tile(const uint8_t* __restrict__ seg, int* __restrict__ L, const int* __restrict__ lsize,
+                                                              int* __restrict__ size, unsigned long long* __restrict__ best, CcDims cd, int nclass) {
+  constexpr int TV = TD * TH * TW, VPT = TV / 256;
+  __shared__ int hkey[TV];
+  __shared__ int hval[TV];
+  __shared__ unsigned long long red[4][8];
+  const int tw = blockIdx.x % cd.tiles_w, th = (blockIdx.x / cd.tiles_w) % cd.tiles_h;
+  const int td = (blockIdx.x / (cd.tiles_w * cd.tiles_h)) % cd.tiles_d, n = blockIdx.x / (cd.tiles_w * cd.tiles_h * cd.tiles_d);
+  const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+  const long long nbase = (long long)n * cd.D * cd.H * cd.W;
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) { hkey[threadIdx.x + u * 256] = -1; hval[threadIdx.x + u * 256] = 0; }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) {
+    const int i = threadIdx.x + u * 256;
+    const int lw = i % TW, lh = (i / TW) % TH, ld = i / (TW * TH);
+    const int d = d0 + ld, h = h0 + lh, w = w0 + lw;
+    if (d >= cd.D || h >= cd.H || w >= cd.W) continue;
+    const int v = (int)(nbase + ((long long)d * cd.H + h) * cd.W + w);
+    const int ls = lsize[v];
+    if (ls <= 0) continue;
+    const int root = uf_find_c(L, v);                            // (leaves every tile-local root one hop from its global root)
+    unsigned hs = ((unsigned)root * 2654435761u) >> 7;
+    for (;;) {
+      hs &= (unsigned)(TV - 1);
+      const int old = atomicCAS(&hkey[hs], -1, root);
+      if (old == -1 || old == root) { atomicAdd(&hval[hs], ls); break; }
+      ++hs;
+    }
+  }
+  __syncthreads();
+  unsigned long long loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int u = 0; u < VPT; ++u) {
+    const int sidx = threadIdx.x + u * 256;
+    const int root = hkey[sidx];
+    if (root < 0) continue;
+    const int add = hval[sidx];
+    const int tot = atomicAdd(&size[root], add) + add;
+    const unsigned long long key = ((unsigned long long)(unsigned)tot << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)root);
+    const int c = seg[root] - 1;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (k == c && key > loc[k]) loc[k] = key;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 0; k < nclass; ++k) {
+    unsigned long long m = loc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long t = __shfl_xor(m, o); m = t > m ? t : m; }
+    if (lane == 0) red[wave][k] = m;
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nclass) {
+    unsigned long long m = red[0][threadIdx.x];
+    for (int w = 1; w < 4; ++w) m = red[w][threadIdx.x] > m ? red[w][threadIdx.x] : m;
+    if (m) atomicMax(&best[(long long)n * nclass + threadIdx.x], m);
+  }
+}
+
 // blockIdx.y = sample: every thread keeps a running maximum per class, the block reduces them (64-bit max over shuffles +
 // one LDS hop) and issues ONE atomicMax per class.  (Noise maps have ~10^5 roots; one atomic -- or even one racy read -- per
 // root on N * nclass hot words cost 0.43 ms per ACDC step.)
@@ -379,7 +476,13 @@ static int cc_run(uint8_t* seg, CcSrc src, uint8_t* out_u8, float* out_f32, int 
     hipLaunchKernelGGL((k_cc_local<1, 16, 32, SRC>), dim3(N * cd.tiles_h * cd.tiles_w), dim3(256), 0, s, seg, src, L, lsize, size, cd, best, N * nclass);
     hipLaunchKernelGGL((k_cc_border<1, 16, 32>), dim3(border_grid(cd, CcFace<1, 16, 32>::NB)), dim3(256), 0, s, seg, L, cd, options().cc_border_dedupe);
   }
-  if (options().cc_fuse_select != 0) {
+  const int ntile = N * cd.tiles_d * cd.tiles_h * cd.tiles_w;
+  if (options().cc_fuse_select != 0 && options().cc_count_tile != 0) {
+    if (D > 1 && big) hipLaunchKernelGGL((k_cc_count_select_tile<8, 16, 16>), dim3(ntile), dim3(256), 0, s, seg, L, lsize, size, best, cd, nclass);
+    else if (D > 1) hipLaunchKernelGGL((k_cc_count_select_tile<4, 8, 16>), dim3(ntile), dim3(256), 0, s, seg, L, lsize, size, best, cd, nclass);
+    else if (big) hipLaunchKernelGGL((k_cc_count_select_tile<1, 32, 64>), dim3(ntile), dim3(256), 0, s, seg, L, lsize, size, best, cd, nclass);
+    else hipLaunchKernelGGL((k_cc_count_select_tile<1, 16, 32>), dim3(ntile), dim3(256), 0, s, seg, L, lsize, size, best, cd, nclass);
+  } else if (options().cc_fuse_select != 0) {
     int gx = (int)((V + 255) / 256);          // one voxel per thread up to 2048 workgroups per launch (k_cc_count's geometry)
     const int cap = 2048 / N < 1 ? 1 : 2048 / N;
     gx = gx < 1 ? 1 : (gx > cap ? cap : gx);

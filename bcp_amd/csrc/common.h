@@ -80,6 +80,7 @@ struct Options {
   int gemm_stat_r = 0;      // ... measurement switch: row blocks per workgroup of those instances (0 = stat_plan's choice: <= ~1024 partial rows per group, >= 512 workgroups)
   int gemm_walk = 0;        // ... measurement switch: plain k_gemm_nn launches of >= 2 W workgroups as ~W walking workgroups (k_gemm_nn<.., 7>); 0 = one row block per workgroup
   int cc_border_dedupe = 1; // round 6: k_cc_border lanes leave a (root, root) pair that the previous lane also holds at the same neighbour offset to that lane.  0: every lane joins every pair it sees
+  int cc_count_tile = 0;    // round 6, measured and NOT adopted as the default (p = 0.5 noise: chain 166.8 -> 172.1 us alone, p = 0.1: 137.6 -> 112.1; the step inside the noise, gpurun_out/r06_s59 -- the chain is bound by the find walks, not by the atomics): ... one workgroup per tile, sizes of tile-local roots that share a global root added up in an LDS table first (k_cc_count_select_tile): one global atomic per (tile, global root).  0: one per tile-local root
   int cc_fuse_select = 1;   // round 6: the largest-CC chain's size count also max-reduces the (size, root) keys (k_cc_count_select): no k_cc_select launch on the teacher's tail.  0: two launches
   int norm_apply_cap = 2048;   // round 6 (measurement switches): workgroups per apply-pass launch at most ...
   int norm_apply_vec = 4;      // ... and float4 per thread the grid is sized for (4 = one unrolled trip; 1 = every thread one float4, no loop)

@@ -120,20 +120,36 @@ def check_cc(ops, dev, golden_dir):
     finally:
         ops.set_option("cc_tile")
     # (round 6) the two-launch count + select (cc_fuse_select = 0) against the fused kernel that everything above ran through
-    ops.set_option("cc_fuse_select", 0)
-    try:
-        for conn, key in ((3, "cc26"), (2, "cc18"), (1, "cc6")):
-            assert np.array_equal(ops.cc_largest(cut.to(dev).contiguous(), 1, conn).cpu().numpy(), g[key]), f"two-launch select cc {key}"
-        assert np.array_equal(ops.cc_largest(am.to(dev), 3, 2).cpu().numpy()[:, 0], g["argmax_cc"])
-        for conn, oc in ((3, None), (1, 1)):
-            assert torch.equal(ops.cc_largest(noise.to(dev), 1, conn).cpu().float(), O.largest_cc(noise.long(), oc))
-    finally:
-        ops.set_option("cc_fuse_select")
+    # ... and the fused kernel with one atomic per tile-local root (cc_count_tile = 0) against the per-tile LDS table of the default
+    for fuse, tile_tab in ((0, 0), (1, 0)):
+        ops.set_option("cc_fuse_select", fuse)
+        ops.set_option("cc_count_tile", tile_tab)
+        try:
+            for conn, key in ((3, "cc26"), (2, "cc18"), (1, "cc6")):
+                assert np.array_equal(ops.cc_largest(cut.to(dev).contiguous(), 1, conn).cpu().numpy(), g[key]), f"select {fuse} / {tile_tab} cc {key}"
+            assert np.array_equal(ops.cc_largest(am.to(dev), 3, 2).cpu().numpy()[:, 0], g["argmax_cc"])
+            for conn, oc in ((3, None), (1, 1)):
+                assert torch.equal(ops.cc_largest(noise.to(dev), 1, conn).cpu().float(), O.largest_cc(noise.long(), oc))
+        finally:
+            ops.set_option("cc_fuse_select")
+            ops.set_option("cc_count_tile")
+    # a checkerboard under 6-connectivity: every foreground voxel its own component (the most tile-local roots a tile can hold: half its
+    # voxels -- the LDS table's worst case); the first voxel in raster order wins the tie
+    cb = torch.zeros(1, 16, 32, 32, dtype=torch.uint8)
+    idx = torch.arange(16).view(16, 1, 1) + torch.arange(32).view(1, 32, 1) + torch.arange(32).view(1, 1, 32)
+    cb[0][(idx % 2) == 1] = 1
+    for tile in (1, 2):
+        ops.set_option("cc_tile", tile)
+        try:
+            o = ops.cc_largest(cb.to(dev), 1, 1).cpu()
+        finally:
+            ops.set_option("cc_tile")
+        assert int(o.sum()) == 1 and int(o[0, 0, 0, 1]) == 1, f"checkerboard (tile option {tile}): {int(o.sum())} voxels kept"
     # (round 6) pseudo-label + largest-CC as one chain from the logits (bcp_plabel_cc_largest) == the two calls, bit for bit: the golden
     # logits (values at the threshold's expf ties included), noise logits (a random-init teacher), both tile sizes, 3-D two-channel and 2-D
     # four-channel
     rl = np.random.default_rng(5)
-    cases2 = [to_cl(torch.from_numpy(g["logits3d"])).to(dev), to_cl(R(rl, 2, 2, 20, 40, 36)).to(dev), to_cl(R(rl, 1, 2, 9, 17, 20)).to(dev)]
+    cases2 = [to_cl(torch.from_numpy(g["logits3d"])).to(dev), to_cl(R(rl, 2, 2, 20, 40, 36)).to(dev), to_cl(R(rl, 1, 2, 9, 17, 20)).to(dev), to_cl(R(rl, 2, 2, 8, 10, 6)).to(dev)]      # (W = 6: the voxel-per-lane labelling; the others label quads)
     cases4 = [to_cl(torch.from_numpy(g["logits2d"]).unsqueeze(2)).to(dev), to_cl(R(rl, 3, 4, 1, 48, 80)).to(dev), to_cl(R(rl, 2, 4, 1, 33, 47)).to(dev)]
     for tile in (0, 2):
         ops.set_option("cc_tile", tile)
