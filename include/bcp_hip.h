@@ -48,7 +48,8 @@ const char* bcp_last_error(void);
 /* process-wide tuning / test switches (the library never reads the environment): name = a field of bcp::Options
  * (csrc/common.h: conv3_p, splitk, res_pcu, res_nt, res_tile2d_vox, conv3_cfg, wgrad_nt, wgrad_tile, tn_groups, cc_tile,
  * conv3_b6*, wgrad_b6*: which shapes run on the bf16 matrix pipe and with which tiles; norm_slabs, conv3_xcd; round 6: norm_fuse_fin, norm_own,
- * wgrad_reduce_flat, and the MEASUREMENT-ONLY whatif bits that leave launches out -- wrong results, for pricing a change); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
+ * wgrad_reduce_flat, gemm_pipe (the statistics GEMMs' row-block walk prefetches the next block), cc_fuse_select / cc_border_dedupe (the largest-CC chain's
+ * fused selection and wave-level pair exchange), the measurement switches gemm_walk, gemm_stat_r, norm_apply_cap, norm_apply_vec, cc_count_tile, and the MEASUREMENT-ONLY whatif bits that leave launches out -- wrong results, for pricing a change); value = decimal integer(s), comma separated for the array-valued ones; "" restores the default.
  * HOST strings.  NOT thread-safe and not per-stream: ONE Options struct per process, read by every launch on every stream and
  * device.  Set options before work is enqueued, never concurrently with launches from another thread (the launch entry points
  * themselves are re-entrant across streams / devices as long as the options stay put). */
