@@ -344,6 +344,13 @@ __device__ __forceinline__ float f16hi_to_f32(unsigned h) { return (float)__buil
 
 // four consecutive channels of one voxel row, pre-scaled by s -> the two fp16 planes (8-byte stores)
 __device__ __forceinline__ void split_store4_f16(const float4& v, float s, unsigned short* base, int plane_stride) {
+#if defined(B6_ABLATE) && (B6_ABLATE & 128)
+  // MEASUREMENT ONLY (wrong results; tools/ablate_b6.sh 128): the operand's bits go to the two planes as they are -- the fetch and both LDS
+  // stores stay, the 16 VALU operations of the split go: what planes written by the PRODUCER would save this kernel
+  *reinterpret_cast<uint2*>(base) = make_uint2(__float_as_uint(v.x), __float_as_uint(v.y));
+  *reinterpret_cast<uint2*>(base + plane_stride) = make_uint2(__float_as_uint(v.z), __float_as_uint(v.w));
+  return;
+#endif
   const float x0 = v.x * s, x1 = v.y * s, x2 = v.z * s, x3 = v.w * s;
   const unsigned h0 = cvt_pk_f16(x0, x1), h1 = cvt_pk_f16(x2, x3);
   uint2 w;
