@@ -86,6 +86,22 @@ def test_full_size_properties(gpu_ops):
     cc1 = ops.cc_largest(seg, 1, 3)
     cc2 = ops.cc_largest(cc1, 1, 3)
     assert torch.equal(cc1, cc2) and bool((cc1 <= seg).all()) and 0 < int(cc1.sum()) <= int(seg.sum())
+    # (5b, round 6) the teacher's tail as ONE chain from the logits (bcp_plabel_cc_largest: quads of voxels labelled from 16-byte loads,
+    # the selection inside the size count, the wave-level pair exchange in the border pass) == pseudo-label launch + chain, bit for bit,
+    # at the full size, for every connectivity; the optional per-tile size table gives the same map; same properties as (5)
+    lg = torch.randn(2, *sp, 2, generator=g).to(dev)
+    pl = ops.plabel_bin(lg, 0.5)
+    for conn in (3, 2, 1):
+        two = ops.cc_largest(pl, 1, conn)
+        (one, onef), seg1 = ops.plabel_cc_largest(lg, 0.5, conn, want_f32=True, want_seg=True)
+        assert torch.equal(seg1, pl) and torch.equal(one, two) and torch.equal(onef, two.float()), f"one chain vs two calls, connectivity {conn}"
+        assert torch.equal(ops.cc_largest(one, 1, conn), one) and bool((one <= pl).all()) and 0 < int(one.sum()) <= int(pl.sum())
+        for opt in ("cc_count_tile", "cc_border_dedupe", "cc_fuse_select"):
+            ops.set_option(opt, 1 if opt == "cc_count_tile" else 0)
+            try:
+                assert torch.equal(ops.plabel_cc_largest(lg, 0.5, conn), one), f"{opt} flipped, connectivity {conn}"
+            finally:
+                ops.set_option(opt)
     # (6) EMA with alpha = 1 is the identity, with alpha = 0 a copy
     p, q = torch.randn(1 << 20, generator=g).to(dev), torch.randn(1 << 20, generator=g).to(dev)
     p0 = p.clone()
@@ -148,6 +164,9 @@ def test_full_size_properties_acdc(gpu_ops):
     for c in (1, 2, 3):
         per_slice = (cc1 == c).flatten(1).sum(1)
         assert bool((per_slice > 0).all()) and bool((per_slice <= (pl == c).flatten(1).sum(1)).all())
+    # (5b, round 6) the same as ONE chain from the logits (bcp_plabel_cc_largest, four channels / three classes) == the two calls, bit for bit
+    one, seg1 = ops.plabel_cc_largest(lo, 0.5, 2, want_seg=True)
+    assert torch.equal(seg1, pl) and torch.equal(one, cc1)
     # (6) the two complementary copy-paste mixes partition their inputs
     a, b = torch.randn(N, 1, H, W, 1, generator=g).to(dev), torch.randn(N, 1, H, W, 1, generator=g).to(dev)
     box = (0, 40, 31, 1, 170, 170)
